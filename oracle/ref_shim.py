@@ -1,0 +1,122 @@
+"""TEST INFRASTRUCTURE ONLY -- import shim for the read-only Python reference.
+
+Makes the *unmodified* reference modules under ``/root/reference`` importable in
+the build container (no isaacgym / rl_games / smpl_sim / hydra ... installed) so
+that ``oracle/gen_golden.py`` can run the reference's own functions and dump
+golden vectors into ``tests/golden``.  Nothing in the product (``phc_amd``),
+``bench.py`` or the ``-m gpu`` tests may import this file: ``/root/reference``
+does not exist on the GPU box.
+
+What is stubbed:
+  * ``isaacgym``           -> MagicMock, except ``isaacgym.torch_utils`` which is
+                              the reference's own ``phc/utils/isaacgym_torch_utils.py``
+  * ``easydict.EasyDict``  -> 15-line attribute dict
+  * ``smpl_sim.utils.torch_ext.to_torch`` -> tensor passthrough / from_numpy
+  * every other missing third-party package -> auto-mocked on import
+"""
+import importlib
+import importlib.abc
+import importlib.machinery
+import os
+import sys
+import types
+from unittest.mock import MagicMock
+
+REFERENCE_ROOT = os.environ.get("PHC_REFERENCE_ROOT", "/root/reference")
+
+_MOCK_TOPLEVEL = (
+    "isaacgym", "smpl_sim", "smplx", "open3d", "imageio", "aiohttp", "cv2", "gym",
+    "skimage", "lxml", "stl", "hydra", "omegaconf", "termcolor", "mujoco", "wandb",
+    "tensorboardX", "pyvirtualdisplay", "rl_games", "vtk", "chumpy", "mujoco_py",
+    "autograd", "pytorch3d", "ipdb", "gdown",
+)
+
+
+class _EasyDict(dict):
+    def __init__(self, d=None, **kw):
+        super().__init__()
+        for k, v in dict(d or {}, **kw).items():
+            self[k] = v
+
+    def __setitem__(self, k, v):
+        if isinstance(v, dict) and not isinstance(v, _EasyDict):
+            v = _EasyDict(v)
+        super().__setitem__(k, v)
+
+    __setattr__ = __setitem__
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k)
+
+
+class _MockModule(MagicMock):
+    """A MagicMock that import machinery accepts as a package."""
+    __path__ = []
+    __all__ = []
+
+
+class _MockFinder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
+    def find_spec(self, fullname, path, target=None):
+        if fullname.split(".")[0] in _MOCK_TOPLEVEL:
+            return importlib.machinery.ModuleSpec(fullname, self, is_package=True)
+        return None
+
+    def create_module(self, spec):
+        m = _MockModule(name=spec.name)
+        m.__name__ = spec.name
+        m.__spec__ = spec
+        m.__loader__ = self
+        return m
+
+    def exec_module(self, module):
+        pass
+
+
+_installed = False
+
+
+def install():
+    """Idempotently put the reference on sys.path and register all stubs."""
+    global _installed
+    if _installed:
+        return
+    if not os.path.isdir(REFERENCE_ROOT):
+        raise RuntimeError(f"reference not found at {REFERENCE_ROOT}; the shim only works in the build container")
+    import numpy as np
+    import torch
+
+    for p in (os.path.join(REFERENCE_ROOT, "phc"), REFERENCE_ROOT):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+
+    ed = types.ModuleType("easydict")
+    ed.EasyDict = _EasyDict
+    sys.modules.setdefault("easydict", ed)
+
+    sys.meta_path.append(_MockFinder())
+
+    # isaacgym.torch_utils must be the real (reference) quaternion library
+    itu = importlib.import_module("phc.utils.isaacgym_torch_utils")
+    importlib.import_module("isaacgym")
+    sys.modules["isaacgym.torch_utils"] = itu
+    sys.modules["isaacgym"].torch_utils = itu
+
+    def to_torch(x, *a, **k):
+        return x if isinstance(x, torch.Tensor) else torch.from_numpy(np.asarray(x))
+
+    te = importlib.import_module("smpl_sim.utils.torch_ext")
+    te.to_torch = to_torch
+
+    # numpy-2 removed aliases that the reference still uses at import/run time
+    for name, val in (("Inf", np.inf), ("int", int), ("float", float), ("bool", bool)):
+        if not hasattr(np, name):
+            setattr(np, name, val)
+    _installed = True
+
+
+def ref_module(name):
+    install()
+    return importlib.import_module(name)

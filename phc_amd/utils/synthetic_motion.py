@@ -1,0 +1,93 @@
+"""Synthetic AMASS-shaped reference motions (SURVEY.md section 8d "Synthetic inputs").
+
+There is no AMASS data in the build container or on the GPU box, so the bench
+and the tests drive the path with smooth random joint trajectories that have the
+*schema* of the reference's motion pkl (written by the reference's
+``scripts/data_process/convert_amass_isaac.py:129-138`` and read by
+``phc/utils/motion_lib_smpl.py:123-135``):
+
+    key -> {pose_quat_global [T,J,4] xyzw f64, pose_quat [T,J,4], root_trans_offset [T,3] f64,
+            pose_aa [T,J*3], trans_orig [T,3], beta [10], gender "neutral", fps 30}
+
+Pure numpy; the generator is deterministic in ``seed``.
+"""
+import numpy as np
+from scipy.ndimage import gaussian_filter1d
+
+
+def _exp_map_to_quat(e):
+    ang = np.linalg.norm(e, axis=-1, keepdims=True)
+    small = ang < 1e-8
+    axis = np.where(small, np.array([0.0, 0.0, 1.0]), e / np.maximum(ang, 1e-12))
+    half = 0.5 * ang
+    return np.concatenate([axis * np.sin(half), np.cos(half)], axis=-1)
+
+
+def _quat_mul(a, b):
+    x1, y1, z1, w1 = a[..., 0], a[..., 1], a[..., 2], a[..., 3]
+    x2, y2, z2, w2 = b[..., 0], b[..., 1], b[..., 2], b[..., 3]
+    return np.stack([w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2,
+                     w1 * y2 + y1 * w2 + z1 * x2 - x1 * z2,
+                     w1 * z2 + z1 * w2 + x1 * y2 - y1 * x2,
+                     w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2], axis=-1)
+
+
+def make_clip(rng, parents, num_frames, body_names=None, fps=30):
+    """One smooth random clip.  Per-joint exp-map = low-pass filtered random walk
+    (step N(0,0.05^2), sigma=3 frames), clipped to +-1 rad (knee y/z +-0.1);
+    root height 0.9+-0.05 m; root xy random walk ~1 m/s; random initial yaw."""
+    J = len(parents)
+    T = int(num_frames)
+    steps = rng.normal(0.0, 0.05, size=(T, J, 3))
+    e = gaussian_filter1d(np.cumsum(steps, axis=0), 3, axis=0, mode="nearest")
+    e = np.clip(e, -1.0, 1.0)
+    if body_names is not None:
+        for j, n in enumerate(body_names):
+            if n.endswith("Knee"):
+                e[:, j, 1:] = np.clip(e[:, j, 1:], -0.1, 0.1)
+    # root: mostly upright with a yaw walk
+    yaw = rng.uniform(-np.pi, np.pi) + gaussian_filter1d(np.cumsum(rng.normal(0, 0.03, size=T)), 3, mode="nearest")
+    e[:, 0, :2] *= 0.15
+    e[:, 0, 2] = 0.0
+    q_local = _exp_map_to_quat(e)
+    yaw_q = np.stack([np.zeros(T), np.zeros(T), np.sin(0.5 * yaw), np.cos(0.5 * yaw)], axis=-1)
+    q_local[:, 0] = _quat_mul(yaw_q, q_local[:, 0])
+    q_global = np.zeros_like(q_local)
+    for j in range(J):
+        p = parents[j]
+        q_global[:, j] = q_local[:, j] if p < 0 else _quat_mul(q_global[:, p], q_local[:, j])
+    q_global /= np.linalg.norm(q_global, axis=-1, keepdims=True)
+    vel_xy = gaussian_filter1d(rng.normal(0, 1.0, size=(T, 2)), 5, axis=0, mode="nearest") * 2.0
+    trans = np.zeros((T, 3))
+    trans[:, :2] = np.cumsum(vel_xy, axis=0) / fps
+    trans[:, 2] = 0.9 + np.clip(gaussian_filter1d(rng.normal(0, 0.05, size=T), 5, mode="nearest") * 3, -0.05, 0.05)
+    # axis-angle of local rotations (mujoco joint order) -- only carried through as "motion_aa"
+    w = np.clip(q_local[..., 3], -1, 1)
+    ang = 2 * np.arccos(np.abs(w))
+    s = np.sqrt(np.maximum(1 - w * w, 1e-16))
+    aa = q_local[..., :3] / s[..., None] * (ang * np.sign(w + 1e-30))[..., None]
+    return {
+        "pose_quat_global": q_global.astype(np.float64),
+        "pose_quat": q_local.astype(np.float64),
+        "root_trans_offset": trans.astype(np.float64),
+        "trans_orig": trans.astype(np.float64),
+        "pose_aa": aa.reshape(T, J * 3).astype(np.float64),
+        "beta": np.zeros(10),
+        "gender": "neutral",
+        "fps": fps,
+    }
+
+
+def make_motion_dict(parents, num_clips, seed=0, min_frames=30, max_frames=1800, mean_seconds=8.0,
+                     body_names=None, fps=30, lengths=None):
+    """AMASS-shaped dict of ``num_clips`` clips.  Lengths are log-normal around
+    ``mean_seconds`` clipped to [min_frames, max_frames] unless given."""
+    rng = np.random.default_rng(seed)
+    out = {}
+    for i in range(num_clips):
+        if lengths is not None:
+            T = int(lengths[i])
+        else:
+            T = int(np.clip(rng.lognormal(np.log(mean_seconds), 0.5) * fps, min_frames, max_frames))
+        out[f"synthetic_{i:05d}"] = make_clip(rng, parents, T, body_names=body_names, fps=fps)
+    return out

@@ -1,0 +1,100 @@
+"""Pin the numpy oracle (oracle/phc_oracle.py) against golden vectors produced by the
+reference's own code (oracle/gen_golden.py).  CPU only."""
+import numpy as np
+import pytest
+
+import phc_oracle as po
+
+TOL = dict(rtol=0, atol=1e-4)  # north_star: <=1e-4 on FK / quaternion floats
+
+
+def test_quat_kat(golden):
+    g = golden("quat_kat")
+    qa, qb, v, t, em = g["qa"], g["qb"], g["v"], g["t"], g["em"]
+    np.testing.assert_allclose(po.quat_mul(qa, qb), g["quat_mul"], atol=1e-6)
+    np.testing.assert_array_equal(po.quat_conjugate(qa), g["quat_conjugate"])
+    np.testing.assert_allclose(po.my_quat_rotate(qa, v), g["my_quat_rotate"], atol=2e-6)
+    ang, ax = po.quat_to_angle_axis(qa)
+    np.testing.assert_allclose(ang, g["angle"], atol=1e-5)
+    np.testing.assert_allclose(ax, g["axis"], atol=1e-4)
+    np.testing.assert_allclose(po.quat_to_exp_map(qa), g["quat_to_exp_map"], atol=1e-4)
+    np.testing.assert_allclose(po.quat_to_tan_norm(qa), g["quat_to_tan_norm"], atol=2e-6)
+    np.testing.assert_allclose(po.exp_map_to_quat(em), g["exp_map_to_quat"], atol=2e-6)
+    np.testing.assert_allclose(po.slerp(qa, qb, t), g["slerp"], atol=1e-5)
+    np.testing.assert_allclose(po.calc_heading(qa), g["calc_heading"], atol=1e-5)
+    np.testing.assert_allclose(po.calc_heading_quat(qa), g["calc_heading_quat"], atol=1e-6)
+    np.testing.assert_allclose(po.calc_heading_quat_inv(qa), g["calc_heading_quat_inv"], atol=1e-6)
+
+
+def _clips(golden):
+    c = golden("motion_clips")
+    return [{"pose_quat_global": c[f"{k}/pose_quat_global"], "root_trans_offset": c[f"{k}/root_trans_offset"], "fps": 30}
+            for k in c["keys"]]
+
+
+def test_motion_load_fk_and_velocities(golden):
+    """M3-M6: FK + finite-difference velocities == reference MotionLibSMPL.load_motions."""
+    sk = golden("skeleton_smpl")
+    lib_g = golden("motion_lib_eval")
+    clips = _clips(golden)
+    lib = po.build_motion_lib(sk["parent_indices"], sk["local_translation"], [clips[i] for i in lib_g["curr_motion_ids"]])
+    for k in ("gts", "grs", "lrs", "gvs", "gavs", "dvs"):
+        np.testing.assert_allclose(lib[k], lib_g[k], err_msg=k, **TOL)
+    for k in ("motion_lengths", "motion_dt"):
+        np.testing.assert_array_equal(lib[k], lib_g[k], err_msg=k)
+    for k in ("motion_num_frames", "length_starts"):
+        np.testing.assert_array_equal(lib[k], lib_g[k], err_msg=k)
+
+
+def test_frame_blend_indices_bit_exact(golden):
+    """M8: frame indices are the bit-exact part of the contract."""
+    g = golden("motion_lib_eval")
+    ids = g["ms_ids"]
+    i0, i1, bl = po.calc_frame_blend(g["ms_times"], g["motion_lengths"][ids], g["motion_num_frames"][ids], g["motion_dt"][ids])
+    np.testing.assert_array_equal(i0, g["ms_idx0"])
+    np.testing.assert_array_equal(i1, g["ms_idx1"])
+    np.testing.assert_array_equal(bl, g["ms_blend"])
+
+
+def test_sample_time_interval_bit_exact(golden):
+    g = golden("motion_lib_eval")
+    t = po.sample_time_interval(g["sti_phase"], g["motion_lengths"][g["ms_ids"]])
+    np.testing.assert_array_equal(t, g["sti_time"])
+
+
+def test_get_motion_state(golden):
+    """M9 on the reference's own frame tensors."""
+    g = golden("motion_lib_eval")
+    res = po.get_motion_state(g, g["ms_ids"], g["ms_times"], g["ms_offset"])
+    for k in ("root_pos", "root_rot", "dof_pos", "root_vel", "root_ang_vel", "dof_vel", "rg_pos", "rb_rot", "body_vel", "body_ang_vel"):
+        np.testing.assert_allclose(res[k], g["ms_" + k], err_msg=k, atol=2e-5, rtol=0)
+
+
+def test_reward_reset_obs(golden):
+    g = golden("task_fns")
+    rew, raw = po.compute_imitation_reward(g["body_pos"], g["body_rot"], g["body_vel"], g["body_ang_vel"],
+                                           g["ref_pos"], g["ref_rot"], g["ref_vel"], g["ref_ang_vel"])
+    np.testing.assert_allclose(rew, g["reward"], atol=1e-5)
+    np.testing.assert_allclose(raw, g["reward_raw"], atol=1e-5)
+    np.testing.assert_allclose(po.power_reward(g["dof_force"], g["dof_vel"], g["progress"]), g["power_reward"], atol=1e-5, rtol=1e-5)
+    rid = g["reset_body_ids"]
+    td = np.full((g["body_pos"].shape[0], len(rid)), 0.25, dtype=np.float32)
+    reset, term = po.compute_humanoid_im_reset(g["progress"], g["body_pos"][:, rid], g["ref_pos"][:, rid], g["pass_time"], td)
+    np.testing.assert_array_equal(reset, g["reset"])
+    np.testing.assert_array_equal(term, g["terminate"])
+    assert term.sum() > 0 and (1 - term).sum() > 0  # both branches exercised
+    reset, term = po.compute_humanoid_im_reset(g["progress"], g["body_pos"][:, rid], g["ref_pos"][:, rid], g["pass_time"], td, use_mean=True)
+    np.testing.assert_array_equal(reset, g["reset_mean"])
+    np.testing.assert_array_equal(term, g["terminate_mean"])
+    so = po.compute_humanoid_observations_smpl_max(g["body_pos"], g["body_rot"], g["body_vel"], g["body_ang_vel"])
+    assert so.shape[1] == 358
+    np.testing.assert_allclose(so, g["self_obs"], atol=1e-5)
+    to = po.compute_imitation_observations_v6(g["body_pos"][:, 0], g["body_rot"][:, 0], g["body_pos"], g["body_rot"], g["body_vel"],
+                                              g["body_ang_vel"], g["ref1_pos"], g["ref1_rot"], g["ref1_vel"], g["ref1_ang_vel"])
+    assert to.shape[1] == 576
+    np.testing.assert_allclose(to, g["task_obs"], atol=1e-5)
+    kid = g["key_body_ids"]
+    amp = po.build_amp_observations_smpl(g["body_pos"][:, 0], g["body_rot"][:, 0], g["body_vel"][:, 0], g["body_ang_vel"][:, 0],
+                                         g["dof_pos"], g["dof_vel"], g["body_pos"][:, kid], g["dof_subset"])
+    assert amp.shape[1] == 196
+    np.testing.assert_allclose(amp, g["amp_obs"], atol=1e-5)
