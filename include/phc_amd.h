@@ -1,0 +1,194 @@
+/* phc_amd.h -- C ABI of libphc_amd.so: the MI355X-native humanoid env-step hot path.
+ *
+ * The reference (ZhengyiLuo/PHC) is pure Python; its boundary for this path is the
+ * Isaac Gym tensor API seen by the task plus the task's own
+ * @torch.jit.script functions.  Each entry point below names the reference interface it
+ * replaces (paths relative to the reference root).  All pointers are DEVICE pointers
+ * (HBM) unless a field says "host"; `stream` is a hipStream_t passed as void*.  No torch
+ * types cross this boundary: the host side (phc_amd/*.py, ctypes) hands over
+ * tensor.data_ptr() values and the current stream.
+ *
+ * Return value: 0 on success, a negative PHC_E* code on argument errors, or the positive
+ * hipError_t of a failed launch.
+ *
+ * Layouts are the reference's (Isaac Gym) layouts so that torch views with the same
+ * shapes as `humanoid.py:201-235` alias these buffers:
+ *   root_states      f32 [N,13]      pos3 quat4(xyzw) linvel3 angvel3        (S1)
+ *   dof_state        f32 [N,D,2]     (pos, vel) pairs; spherical joints = exp-map (S2)
+ *   rigid_body_state f32 [N,NB,13]   pos3 quat4 linvel3 angvel3 per body      (S3)
+ *   contact_force    f32 [N,NB,3]                                             (S4)
+ *   dof_force        f32 [N,D]                                                (S5)
+ */
+#ifndef PHC_AMD_H
+#define PHC_AMD_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PHC_ABI_VERSION 1
+#define PHC_MAX_BODIES 32
+#define PHC_EINVAL (-1)
+#define PHC_EUNSUPPORTED (-2)
+
+/* Compiled articulation (phc_amd/model.py: ArticulationModel.pack()).  Replaces
+ * gym.load_asset / get_actor_dof_properties / get_actor_rigid_body_properties
+ * (phc/env/tasks/humanoid.py:768-990,1093-1106). */
+typedef struct {
+    int32_t num_bodies;       /* NB <= 32 */
+    int32_t num_dof;          /* D */
+    int32_t max_level;        /* tree depth */
+    int32_t num_contact_pts;
+    const int32_t* ints;      /* packed tables, see model.py pack() */
+    const float* floats;
+} phc_model_t;
+
+/* Flat reference-motion buffer.  Replaces MotionLibBase's gts/grs/lrs/gvs/gavs/dvs tensors
+ * (phc/utils/motion_lib_base.py:300-318).  One record per frame, fields contiguous:
+ *   [pos NB*3 | rot NB*4 | vel NB*3 | angvel NB*3 | local_rot NB*4 | dof_vel (NB-1)*3 | pad]
+ * so that one lookup touches one contiguous run instead of six separate tensors. */
+typedef struct {
+    const float* frames;              /* [F, frame_stride] */
+    int64_t num_frames_total;         /* F */
+    int32_t frame_stride;             /* floats per frame record */
+    int32_t num_bodies;
+    int32_t num_motions;              /* one clip per env (motion_lib_base.py:205-216) */
+    const float* motion_lengths;      /* [M] seconds */
+    const float* motion_dt;           /* [M] */
+    const int64_t* motion_num_frames; /* [M] */
+    const int64_t* length_starts;     /* [M] first frame of each clip */
+} phc_motion_lib_t;
+
+/* Simulator-owned state tensors (S1-S5, S8). */
+typedef struct {
+    int32_t num_envs;
+    float* root_states;
+    float* dof_state;
+    float* rigid_body_state;
+    float* contact_force;
+    float* dof_force;
+    float* pd_target;                 /* [N,D] set_dof_position_target_tensor (humanoid.py:1559-1560) */
+} phc_sim_state_t;
+
+/* Solver parameters.  Replaces gymapi.SimParams as filled by parse_sim_params
+ * (phc/run_hydra.py:76-111, phc/data/cfg/sim/default_sim.yaml). */
+typedef struct {
+    float sim_dt;                     /* physx.step_dt, 1/60 */
+    int32_t substeps;                 /* 2 */
+    int32_t control_freq_inv;         /* simulate() calls per env step, 2 */
+    float gravity_z;                  /* -9.81 */
+    float contact_stiffness;          /* penalty ground contact, N/m */
+    float contact_damping;            /* N s/m */
+    float friction;                   /* mu (plane static=dynamic=1, env_im.yaml) */
+    float friction_viscous;           /* regularised Coulomb: tangential damping N s/m before the cone clamp */
+    float angular_damping;            /* asset_options.angular_damping 0.01 (humanoid.py:819-822) */
+    float max_angular_velocity;       /* 100 */
+    float contact_offset;             /* 0.02: contact activates this far above the plane with zero force */
+} phc_sim_params_t;
+
+/* Imitation-task parameters (phc/env/tasks/humanoid_im.py:37-123, env_im.yaml). */
+typedef struct {
+    float dt;                         /* control dt = control_freq_inv * sim_dt, as fp32 */
+    int32_t max_episode_length;       /* episode_length 300 */
+    float k_pos, k_rot, k_vel, k_ang_vel, w_pos, w_rot, w_vel, w_ang_vel; /* reward_specs :57 */
+    int32_t power_reward;             /* env.power_reward */
+    float power_coefficient;          /* :107 */
+    int32_t enable_early_termination;
+    int32_t use_mean_termination;     /* flags.im_eval and not strict_eval (:1174) */
+    int32_t disable_collision_check;  /* flags.no_collision_check */
+    int32_t local_root_obs, root_height_obs;
+    int32_t num_track_bodies;         /* len(trackBodies) */
+    const int32_t* track_slot;        /* [NB] slot of body in trackBodies or -1 */
+    const int32_t* reset_mask;        /* [NB] 1 if body in reset_bodies */
+    int32_t num_reset_bodies;         /* len(reset_bodies) */
+    const float* termination_distances; /* [N,NB] (humanoid_im.py:1183-1185) */
+    int32_t num_key_bodies;
+    const int32_t* key_body_ids;      /* [K] */
+    int32_t num_amp_joints;           /* joints in dof_subset (19 for SMPL) */
+    const int32_t* amp_joint_slot;    /* [NB] slot of joint (body j) in dof_subset order or -1 */
+    int32_t num_amp_obs_steps;        /* numAMPObsSteps 10 */
+    int32_t num_amp_obs_per_step;     /* 196 */
+    int32_t num_self_obs, num_task_obs; /* 358, 576 */
+} phc_im_params_t;
+
+/* Task-owned per-env buffers (phc/env/tasks/base_task.py:99-105, humanoid_amp.py:109-116,
+ * humanoid_im.py:71-121).  int64 where the reference uses torch.long. */
+typedef struct {
+    int64_t* progress_buf;            /* [N] */
+    int64_t* reset_buf;               /* [N] */
+    int64_t* terminate_buf;           /* [N] */
+    float* rew_buf;                   /* [N] */
+    float* reward_raw;                /* [N,4 or 5] */
+    float* obs_buf;                   /* [N, num_self_obs+num_task_obs] */
+    float* amp_obs_in;                /* [N,S,A] history before this step */
+    float* amp_obs_out;               /* [N,S,A] history after this step (ping-pong; may equal amp_obs_in only for reset) */
+    const int64_t* sampled_motion_ids;/* [N] */
+    float* motion_start_times;        /* [N] */
+    float* motion_start_times_offset; /* [N] */
+    float* global_offset;             /* [N,3] */
+    float* ref_body_pos;              /* [N,NB,3] side-effect buffers of _compute_task_obs (:855-868), nullable */
+    float* ref_body_rot;              /* [N,NB,4] nullable */
+    float* ref_body_vel;              /* [N,NB,3] nullable */
+    float* ref_dof_pos;               /* [N,D] nullable */
+} phc_im_buffers_t;
+
+int32_t phc_abi_version(void);
+
+/* M9: MotionLibBase.get_motion_state (phc/utils/motion_lib_base.py:437-520) incl. M8
+ * _calc_frame_blend (:549-559).  Outputs nullable.  n lookups; offset nullable [n,3]. */
+int32_t phc_motion_state(const phc_motion_lib_t* lib, int32_t n, const int64_t* motion_ids, const float* motion_times,
+                         const float* offset, float* rg_pos /*[n,NB,3]*/, float* rb_rot /*[n,NB,4]*/,
+                         float* body_vel /*[n,NB,3]*/, float* body_ang_vel /*[n,NB,3]*/, float* dof_pos /*[n,(NB-1)*3]*/,
+                         float* dof_vel /*[n,(NB-1)*3]*/, int64_t* frame_idx0 /*[n]*/, int64_t* frame_idx1 /*[n]*/,
+                         float* blend /*[n]*/, void* stream);
+
+/* M7: MotionLibBase.sample_time_interval (motion_lib_base.py:414-423); `phase` is the
+ * caller's torch.rand draw so the reference RNG stream is preserved. */
+int32_t phc_sample_time_interval(const phc_motion_lib_t* lib, int32_t n, const int64_t* motion_ids, const float* phase,
+                                 float* motion_times, void* stream);
+
+/* A2 + S8 + S10 + S7: pre_physics_step's action->PD target (humanoid.py:1522-1572,1711-1713),
+ * then control_freq_inv x gym.simulate (humanoid.py:1602-1619) with `substeps` sub-steps each,
+ * then publication of body state / dof force / contact force (humanoid_amp.py:639-660).
+ * actions nullable (then pd_target is used as is).  freeze_mask [D] nullable: 1 -> target forced to 0
+ * (humanoid.py:1549-1554). */
+int32_t phc_sim_step(const phc_model_t* model, const phc_sim_params_t* params, const phc_sim_state_t* sim,
+                     const float* actions /*[N,D]*/, const float* pd_action_offset /*[D]*/, const float* pd_action_scale /*[D]*/,
+                     const int32_t* freeze_mask /*[D]*/, int32_t num_sim_calls, void* stream);
+
+/* S7 alone: forward kinematics from (root_states, dof_state) to rigid_body_state. */
+int32_t phc_refresh_body_state(const phc_model_t* model, const phc_sim_state_t* sim, void* stream);
+
+/* post_physics_step of HumanoidIm in one launch (humanoid.py:1634-1650, humanoid_amp.py:194-210,
+ * humanoid_im.py:694-948,1117-1190): progress_buf += 1, reference lookup at t and t+dt,
+ * imitation + power reward, reset / terminate, self obs, task obs v6, AMP obs + history shift. */
+int32_t phc_im_post_physics(const phc_model_t* model, const phc_motion_lib_t* lib, const phc_im_params_t* prm,
+                            const phc_sim_state_t* sim, const phc_im_buffers_t* buf, void* stream);
+
+/* Humanoid.reset(env_ids) -> _reset_envs (humanoid.py:585-621, humanoid_amp.py:378-398,508-528,559-637,
+ * humanoid_im.py:955-1023): per listed env sample a start time from `phase`, impose the reference
+ * state on root/dof/body tensors and PD targets, zero progress/reset/terminate/contact, recompute
+ * obs for those envs, and rebuild their AMP history from the reference motion. */
+int32_t phc_im_reset(const phc_model_t* model, const phc_motion_lib_t* lib, const phc_im_params_t* prm,
+                     const phc_sim_state_t* sim, const phc_im_buffers_t* buf, int32_t num_reset,
+                     const int64_t* env_ids, const float* phase /*[num_reset]*/, int32_t start_at_zero, void* stream);
+
+/* HumanoidAMP.build_amp_obs_demo (humanoid_amp.py:253-284): n samples x S steps back in time. */
+int32_t phc_amp_obs_demo(const phc_model_t* model, const phc_motion_lib_t* lib, const phc_im_params_t* prm, int32_t n,
+                         const int64_t* motion_ids, const float* motion_times0, float* amp_obs_demo /*[n,S,A]*/, void* stream);
+
+/* P5: CommonAgent.discount_values (phc/learning/common_agent.py:493-505), tensors [T,N]. */
+int32_t phc_gae(int32_t horizon, int32_t n, const float* fdones, const float* values, const float* rewards,
+                const float* next_values, float gamma, float tau, float* advs, void* stream);
+
+/* poselib FK for motion loading (M5): SkeletonState.global_transformation
+ * (poselib/poselib/skeleton/skeleton3d.py:390-426) in fp32 on device.  local_rot [T,NB,4],
+ * root_trans [T,3] -> global_rot [T,NB,4], global_pos [T,NB,3]. */
+int32_t phc_fk(const phc_model_t* model, int64_t num_frames, const float* local_rot, const float* root_trans,
+               float* global_rot, float* global_pos, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PHC_AMD_H */

@@ -1,0 +1,106 @@
+"""ctypes binding of libphc_amd.so (the C ABI in include/phc_amd.h).
+
+This is the only way the Python host side reaches the device code.  There is NO CPU
+fallback: if the shared library is missing or a symbol is absent the import fails loudly.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libphc_amd.so")
+
+c_f = C.c_float
+c_i32 = C.c_int32
+c_i64 = C.c_int64
+c_p = C.c_void_p
+
+
+class Model(C.Structure):
+    _fields_ = [("num_bodies", c_i32), ("num_dof", c_i32), ("max_level", c_i32), ("num_contact_pts", c_i32),
+                ("ints", c_p), ("floats", c_p)]
+
+
+class MotionLib(C.Structure):
+    _fields_ = [("frames", c_p), ("num_frames_total", c_i64), ("frame_stride", c_i32), ("num_bodies", c_i32),
+                ("num_motions", c_i32), ("motion_lengths", c_p), ("motion_dt", c_p), ("motion_num_frames", c_p),
+                ("length_starts", c_p)]
+
+
+class SimState(C.Structure):
+    _fields_ = [("num_envs", c_i32), ("root_states", c_p), ("dof_state", c_p), ("rigid_body_state", c_p),
+                ("contact_force", c_p), ("dof_force", c_p), ("pd_target", c_p)]
+
+
+class SimParams(C.Structure):
+    _fields_ = [("sim_dt", c_f), ("substeps", c_i32), ("control_freq_inv", c_i32), ("gravity_z", c_f),
+                ("contact_stiffness", c_f), ("contact_damping", c_f), ("friction", c_f), ("friction_viscous", c_f),
+                ("angular_damping", c_f), ("max_angular_velocity", c_f), ("contact_offset", c_f)]
+
+
+class ImParams(C.Structure):
+    _fields_ = [("dt", c_f), ("max_episode_length", c_i32),
+                ("k_pos", c_f), ("k_rot", c_f), ("k_vel", c_f), ("k_ang_vel", c_f),
+                ("w_pos", c_f), ("w_rot", c_f), ("w_vel", c_f), ("w_ang_vel", c_f),
+                ("power_reward", c_i32), ("power_coefficient", c_f),
+                ("enable_early_termination", c_i32), ("use_mean_termination", c_i32), ("disable_collision_check", c_i32),
+                ("local_root_obs", c_i32), ("root_height_obs", c_i32),
+                ("num_track_bodies", c_i32), ("track_slot", c_p), ("reset_mask", c_p), ("num_reset_bodies", c_i32),
+                ("termination_distances", c_p),
+                ("num_key_bodies", c_i32), ("key_body_ids", c_p),
+                ("num_amp_joints", c_i32), ("amp_joint_slot", c_p),
+                ("num_amp_obs_steps", c_i32), ("num_amp_obs_per_step", c_i32),
+                ("num_self_obs", c_i32), ("num_task_obs", c_i32)]
+
+
+class ImBuffers(C.Structure):
+    _fields_ = [("progress_buf", c_p), ("reset_buf", c_p), ("terminate_buf", c_p), ("rew_buf", c_p), ("reward_raw", c_p),
+                ("obs_buf", c_p), ("amp_obs_in", c_p), ("amp_obs_out", c_p), ("sampled_motion_ids", c_p),
+                ("motion_start_times", c_p), ("motion_start_times_offset", c_p), ("global_offset", c_p),
+                ("ref_body_pos", c_p), ("ref_body_rot", c_p), ("ref_body_vel", c_p), ("ref_dof_pos", c_p)]
+
+
+P = C.POINTER
+_SIGNATURES = {
+    "phc_abi_version": ([], c_i32),
+    "phc_motion_state": ([P(MotionLib), c_i32, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p], c_i32),
+    "phc_sample_time_interval": ([P(MotionLib), c_i32, c_p, c_p, c_p, c_p], c_i32),
+    "phc_sim_step": ([P(Model), P(SimParams), P(SimState), c_p, c_p, c_p, c_p, c_i32, c_p], c_i32),
+    "phc_refresh_body_state": ([P(Model), P(SimState), c_p], c_i32),
+    "phc_im_post_physics": ([P(Model), P(MotionLib), P(ImParams), P(SimState), P(ImBuffers), c_p], c_i32),
+    "phc_im_reset": ([P(Model), P(MotionLib), P(ImParams), P(SimState), P(ImBuffers), c_i32, c_p, c_p, c_i32, c_p], c_i32),
+    "phc_amp_obs_demo": ([P(Model), P(MotionLib), P(ImParams), c_i32, c_p, c_p, c_p, c_p], c_i32),
+    "phc_gae": ([c_i32, c_i32, c_p, c_p, c_p, c_p, c_f, c_f, c_p, c_p], c_i32),
+    "phc_fk": ([P(Model), c_i64, c_p, c_p, c_p, c_p, c_p], c_i32),
+}
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+def load():
+    """dlopen libphc_amd.so and type every entry point.  Raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} not found: build the HIP extension first "
+                          "(python -m phc_amd.build or __graft_entry__.build()); there is no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    for name, (argtypes, restype) in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export the symbol
+        fn.argtypes = argtypes
+        fn.restype = restype
+    if lib.phc_abi_version() != 1:
+        raise ImportError("libphc_amd.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+class PhcError(RuntimeError):
+    pass
+
+
+def check(rc, what):
+    if rc != 0:
+        kind = {-1: "invalid argument", -2: "unsupported configuration"}.get(rc, f"hipError {rc}")
+        raise PhcError(f"{what} failed: {kind}")

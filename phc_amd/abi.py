@@ -1,0 +1,143 @@
+"""Helpers that fill the C-ABI structs of include/phc_amd.h from array objects.
+
+Works for torch tensors (product: device pointers) and for numpy arrays (tests/hostemu: host
+pointers) -- the structs only carry raw addresses and sizes.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+def ptr(x):
+    """Raw address of a torch tensor / numpy array (must be contiguous), or None."""
+    if x is None:
+        return None
+    if isinstance(x, np.ndarray):
+        assert x.flags["C_CONTIGUOUS"], "numpy array must be C-contiguous"
+        return x.ctypes.data
+    assert x.is_contiguous(), "tensor must be contiguous"
+    return x.data_ptr()
+
+
+def model_struct(ints, floats, num_bodies, num_dof, max_level, num_contact_pts):
+    m = L.Model()
+    m.num_bodies, m.num_dof, m.max_level, m.num_contact_pts = num_bodies, num_dof, max_level, num_contact_pts
+    m.ints, m.floats = ptr(ints), ptr(floats)
+    return m
+
+
+def motion_lib_struct(frames, frame_stride, num_bodies, motion_lengths, motion_dt, motion_num_frames, length_starts):
+    s = L.MotionLib()
+    s.frames = ptr(frames)
+    s.num_frames_total = int(frames.shape[0])
+    s.frame_stride = int(frame_stride)
+    s.num_bodies = int(num_bodies)
+    s.num_motions = int(motion_lengths.shape[0])
+    s.motion_lengths, s.motion_dt = ptr(motion_lengths), ptr(motion_dt)
+    s.motion_num_frames, s.length_starts = ptr(motion_num_frames), ptr(length_starts)
+    return s
+
+
+def sim_state_struct(num_envs, root_states, dof_state, rigid_body_state, contact_force, dof_force, pd_target):
+    s = L.SimState()
+    s.num_envs = int(num_envs)
+    s.root_states, s.dof_state, s.rigid_body_state = ptr(root_states), ptr(dof_state), ptr(rigid_body_state)
+    s.contact_force, s.dof_force, s.pd_target = ptr(contact_force), ptr(dof_force), ptr(pd_target)
+    return s
+
+
+def sim_params_struct(sim_dt=1 / 60, substeps=2, control_freq_inv=2, gravity_z=-9.81, contact_stiffness=1.0e5,
+                      contact_damping=1.0e3, friction=1.0, friction_viscous=2.0e3, angular_damping=0.01,
+                      max_angular_velocity=100.0, contact_offset=0.02):
+    p = L.SimParams()
+    p.sim_dt, p.substeps, p.control_freq_inv, p.gravity_z = sim_dt, substeps, control_freq_inv, gravity_z
+    p.contact_stiffness, p.contact_damping, p.friction, p.friction_viscous = contact_stiffness, contact_damping, friction, friction_viscous
+    p.angular_damping, p.max_angular_velocity, p.contact_offset = angular_damping, max_angular_velocity, contact_offset
+    return p
+
+
+def frame_stride_for(num_bodies):
+    """Floats per frame record: pos 3 | rot 4 | vel 3 | angvel 3 | local_rot 4 per body + dof_vel 3 per joint,
+    padded to a multiple of 4 floats (16 B) so every record starts float4-aligned."""
+    n = num_bodies * 17 + (num_bodies - 1) * 3
+    return (n + 3) // 4 * 4
+
+
+def pack_frames(gts, grs, gvs, gavs, lrs, dvs, xp=np):
+    """[F,NB,3/4] field tensors -> [F, stride] records (layout of phc_motion_lib_t)."""
+    F_, nb = gts.shape[0], gts.shape[1]
+    stride = frame_stride_for(nb)
+    if xp is np:
+        out = np.zeros((F_, stride), dtype=np.float32)
+    else:
+        out = xp.zeros((F_, stride), dtype=xp.float32, device=gts.device)
+    o = 0
+    for arr, w in ((gts, 3), (grs, 4), (gvs, 3), (gavs, 3), (lrs, 4)):
+        out[:, o:o + nb * w] = arr.reshape(F_, nb * w)
+        o += nb * w
+    out[:, o:o + (nb - 1) * 3] = dvs.reshape(F_, (nb - 1) * 3)
+    return out
+
+
+def im_params_struct(dt, max_episode_length, reward_specs, power_reward, power_coefficient, enable_early_termination,
+                     use_mean_termination, disable_collision_check, local_root_obs, root_height_obs, num_track_bodies,
+                     track_slot, reset_mask, num_reset_bodies, termination_distances, num_key_bodies, key_body_ids,
+                     num_amp_joints, amp_joint_slot, num_amp_obs_steps, num_amp_obs_per_step, num_self_obs, num_task_obs):
+    p = L.ImParams()
+    p.dt = float(np.float32(dt))
+    p.max_episode_length = int(max_episode_length)
+    for k in ("k_pos", "k_rot", "k_vel", "k_ang_vel", "w_pos", "w_rot", "w_vel", "w_ang_vel"):
+        setattr(p, k, float(reward_specs[k]))
+    p.power_reward, p.power_coefficient = int(bool(power_reward)), float(power_coefficient)
+    p.enable_early_termination = int(bool(enable_early_termination))
+    p.use_mean_termination = int(bool(use_mean_termination))
+    p.disable_collision_check = int(bool(disable_collision_check))
+    p.local_root_obs, p.root_height_obs = int(bool(local_root_obs)), int(bool(root_height_obs))
+    p.num_track_bodies, p.track_slot = int(num_track_bodies), ptr(track_slot)
+    p.reset_mask, p.num_reset_bodies = ptr(reset_mask), int(num_reset_bodies)
+    p.termination_distances = ptr(termination_distances)
+    p.num_key_bodies, p.key_body_ids = int(num_key_bodies), ptr(key_body_ids)
+    p.num_amp_joints, p.amp_joint_slot = int(num_amp_joints), ptr(amp_joint_slot)
+    p.num_amp_obs_steps, p.num_amp_obs_per_step = int(num_amp_obs_steps), int(num_amp_obs_per_step)
+    p.num_self_obs, p.num_task_obs = int(num_self_obs), int(num_task_obs)
+    return p
+
+
+def im_buffers_struct(progress_buf, reset_buf, terminate_buf, rew_buf, reward_raw, obs_buf, amp_obs_in, amp_obs_out,
+                      sampled_motion_ids, motion_start_times, motion_start_times_offset, global_offset,
+                      ref_body_pos=None, ref_body_rot=None, ref_body_vel=None, ref_dof_pos=None):
+    b = L.ImBuffers()
+    b.progress_buf, b.reset_buf, b.terminate_buf = ptr(progress_buf), ptr(reset_buf), ptr(terminate_buf)
+    b.rew_buf, b.reward_raw, b.obs_buf = ptr(rew_buf), ptr(reward_raw), ptr(obs_buf)
+    b.amp_obs_in, b.amp_obs_out = ptr(amp_obs_in), ptr(amp_obs_out)
+    b.sampled_motion_ids = ptr(sampled_motion_ids)
+    b.motion_start_times, b.motion_start_times_offset = ptr(motion_start_times), ptr(motion_start_times_offset)
+    b.global_offset = ptr(global_offset)
+    b.ref_body_pos, b.ref_body_rot, b.ref_body_vel, b.ref_dof_pos = ptr(ref_body_pos), ptr(ref_body_rot), ptr(ref_body_vel), ptr(ref_dof_pos)
+    return b
+
+
+def task_index_tables(model, track_bodies, reset_bodies, key_bodies, amp_remove_names=("L_Hand", "R_Hand", "L_Toe", "R_Toe"),
+                      has_dof_subset=True):
+    """Per-body index tables the task kernels use (all int32 numpy, length 32).
+
+    track_slot / reset_mask follow `_build_key_body_ids_tensor` (humanoid.py:1674-1691) on cfg.env.trackBodies /
+    reset_bodies; amp_joint_slot follows the dof_subset construction (humanoid.py:388-413)."""
+    MB = 32
+    names = model.body_names
+    track_slot = np.full(MB, -1, dtype=np.int32)
+    for s, n in enumerate(track_bodies):
+        track_slot[names.index(n)] = s
+    reset_mask = np.zeros(MB, dtype=np.int32)
+    for n in reset_bodies:
+        reset_mask[names.index(n)] = 1
+    key_ids = np.array([names.index(n) for n in key_bodies], dtype=np.int32)
+    amp_slot = np.full(MB, -1, dtype=np.int32)
+    s = 0
+    for j in range(1, len(names)):
+        if (not has_dof_subset) or names[j] not in amp_remove_names:
+            amp_slot[j] = s
+            s += 1
+    return track_slot, reset_mask, key_ids, amp_slot, s

@@ -1,0 +1,43 @@
+"""Build libphc_amd.so (HIP, gfx950) in-tree with hipcc.  `python -m phc_amd.build`."""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libphc_amd.so")
+SOURCES = ["phc_kernels.hip"]
+HEADERS = ["phc_math.h", "phc_task.h", "phc_im.h", "phc_aba.h", os.path.join("..", "..", "include", "phc_amd.h")]
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found: the HIP extension cannot be built")
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+
+
+def build(force=False, verbose=False):
+    """Compile every HIP source for gfx950 into phc_amd/libphc_amd.so."""
+    if not force and not needs_build():
+        return LIB
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-comment",
+           *[os.path.join(CSRC, s) for s in SOURCES], "-o", LIB]
+    if verbose:
+        print(" ".join(cmd))
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

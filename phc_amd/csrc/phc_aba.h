@@ -1,0 +1,398 @@
+// phc_aba.h -- articulated-rigid-body stepper (S10 in SURVEY.md section 8a): the replacement for
+// the closed `gym.simulate` call (reference phc/env/tasks/humanoid.py:1613,1618).
+//
+// Algorithm: Featherstone's articulated-body algorithm (Rigid Body Dynamics Algorithms, ch. 7)
+// restated for one *lane per body*:
+//   * spatial quantities are expressed in WORLD-ALIGNED axes, each body's about its OWN origin
+//     (= joint anchor), with classical (not spatial) accelerations.  Parent<->child transforms are
+//     then pure translations by r = p_child - p_parent, moment arms stay below one link length
+//     (fp32-friendly), and the spherical-joint motion subspace is simply S = [1_3; 0].
+//   * the three sweeps (kinematics root->leaves, articulated inertia leaves->root, accelerations
+//     root->leaves) run level-synchronously: at tree level l only the lanes whose body sits at
+//     level l work; parent/child hand-off goes through a 28-float LDS slot per body.
+//   * everything stiff is integrated LINEARLY IMPLICITLY by augmenting the articulated inertia:
+//       - PD drive (kp,kd) + armature:  D += R diag(armature + dt*kd + dt^2*kp) R^T,
+//         tau_explicit = kp*err - (kd + dt*kp)*w_joint              (Isaac Gym "isaac_pd" drive, S8)
+//       - penalty ground contact with regularised Coulomb friction at sphere / capsule-end / box-corner
+//         points: I^A += dt * J^T C J,  p^A -= J^T F0               (C = diag(ct,ct,kn*dt+dn))
+//     so kp=800 / kd=80 at dt=1/120 s on light distal links stays stable (explicit PD would not).
+// There is no reference implementation of this arithmetic (PhysX is closed): the oracle is
+// oracle/aba_ref.c (fp64, body-sequential) + physical invariants -- "parity unpinned" at the PhysX level.
+#pragma once
+#include "phc_math.h"
+#include "../../include/phc_amd.h"
+
+namespace phc {
+
+#define PHC_XCH_STRIDE 28      // floats per exchange slot
+#define PHC_BODY_FLOATS 28     // floats per body in phc_model_t.floats (model.py pack())
+#define PHC_NTAB 10            // int tables per model
+
+struct Sym3 { float xx, xy, xz, yy, yz, zz; };
+
+PHC_HD V3 sym_mul(const Sym3& s, V3 v) {
+    return v3(s.xx * v.x + s.xy * v.y + s.xz * v.z, s.xy * v.x + s.yy * v.y + s.yz * v.z, s.xz * v.x + s.yz * v.y + s.zz * v.z);
+}
+PHC_HD Sym3 sym_inv(const Sym3& s) {
+    float c00 = s.yy * s.zz - s.yz * s.yz;
+    float c01 = s.xz * s.yz - s.xy * s.zz;
+    float c02 = s.xy * s.yz - s.xz * s.yy;
+    float det = s.xx * c00 + s.xy * c01 + s.xz * c02;
+    float id = 1.0f / det;
+    Sym3 r;
+    r.xx = c00 * id; r.xy = c01 * id; r.xz = c02 * id;
+    r.yy = (s.xx * s.zz - s.xz * s.xz) * id;
+    r.yz = (s.xy * s.xz - s.xx * s.yz) * id;
+    r.zz = (s.xx * s.yy - s.xy * s.xy) * id;
+    return r;
+}
+// R diag(d) R^T
+PHC_HD Sym3 rot_diag(const M3& R, V3 d) {
+    Sym3 s;
+    const float* m = R.m;
+    s.xx = m[0] * m[0] * d.x + m[1] * m[1] * d.y + m[2] * m[2] * d.z;
+    s.xy = m[0] * m[3] * d.x + m[1] * m[4] * d.y + m[2] * m[5] * d.z;
+    s.xz = m[0] * m[6] * d.x + m[1] * m[7] * d.y + m[2] * m[8] * d.z;
+    s.yy = m[3] * m[3] * d.x + m[4] * m[4] * d.y + m[5] * m[5] * d.z;
+    s.yz = m[3] * m[6] * d.x + m[4] * m[7] * d.y + m[5] * m[8] * d.z;
+    s.zz = m[6] * m[6] * d.x + m[7] * m[7] * d.y + m[8] * m[8] * d.z;
+    return s;
+}
+// R S R^T for symmetric S
+PHC_HD Sym3 rot_sym(const M3& R, const Sym3& S) {
+    // T = R S  (rows of R times S)
+    float t[9];
+    for (int i = 0; i < 3; ++i) {
+        float a = R.m[3 * i], b = R.m[3 * i + 1], c = R.m[3 * i + 2];
+        t[3 * i + 0] = a * S.xx + b * S.xy + c * S.xz;
+        t[3 * i + 1] = a * S.xy + b * S.yy + c * S.yz;
+        t[3 * i + 2] = a * S.xz + b * S.yz + c * S.zz;
+    }
+    Sym3 r;
+    r.xx = t[0] * R.m[0] + t[1] * R.m[1] + t[2] * R.m[2];
+    r.xy = t[0] * R.m[3] + t[1] * R.m[4] + t[2] * R.m[5];
+    r.xz = t[0] * R.m[6] + t[1] * R.m[7] + t[2] * R.m[8];
+    r.yy = t[3] * R.m[3] + t[4] * R.m[4] + t[5] * R.m[5];
+    r.yz = t[3] * R.m[6] + t[4] * R.m[7] + t[5] * R.m[8];
+    r.zz = t[6] * R.m[6] + t[7] * R.m[7] + t[8] * R.m[8];
+    return r;
+}
+
+// 6x6 symmetric articulated inertia in blocks: n = A alpha + B a ; f = B^T alpha + C a
+struct Inertia6 { Sym3 A; float B[9]; Sym3 C; };
+struct Force6 { V3 n, f; };
+
+PHC_HD V3 B_mul(const float* B, V3 v) {
+    return v3(B[0] * v.x + B[1] * v.y + B[2] * v.z, B[3] * v.x + B[4] * v.y + B[5] * v.z, B[6] * v.x + B[7] * v.y + B[8] * v.z);
+}
+PHC_HD V3 Bt_mul(const float* B, V3 v) {
+    return v3(B[0] * v.x + B[3] * v.y + B[6] * v.z, B[1] * v.x + B[4] * v.y + B[7] * v.z, B[2] * v.x + B[5] * v.y + B[8] * v.z);
+}
+
+// Per-lane registers of the stepper.
+struct AbaLane {
+    // --- constants (model) ---
+    int parent, level, jtype, dof_start, nchild, child[3], cp_start, cp_count;
+    V3 r_local;       // offset from parent origin, parent frame
+    float mass;
+    V3 mc_b;          // mass * com, body frame
+    Sym3 Io_b;        // inertia about body origin, body frame
+    V3 kp, kd, arm, effort;
+    // --- state ---
+    Q4 q;             // joint rotation child-in-parent (root: world rotation)
+    V3 wj;            // joint velocity, child frame (root: unused)
+    V3 p0, v0, w0;    // root only: position, linear velocity of the origin, angular velocity (world)
+    V3 target;        // PD target, exp-map
+    // --- kinematics (world) ---
+    Q4 Q; V3 p, w, v, rw, cw, ca;
+    // --- articulated quantities kept between the sweeps ---
+    Inertia6 IA; Force6 pA;
+    Sym3 Di; V3 u;    // D^-1 and tau_w - p_omega
+    V3 alpha, a;      // accelerations
+    V3 tau_local;     // explicit joint torque (child frame), for dof_force publication
+    V3 dimp;          // implicit diagonal (armature + dt kd + dt^2 kp), child frame
+    V3 fcontact;      // net explicit contact force on the body (S4)
+};
+
+PHC_HD const float* model_body(const phc_model_t& m, int j) { return m.floats + j * PHC_BODY_FLOATS; }
+PHC_HD int model_tab(const phc_model_t& m, int table, int j) { return m.ints[4 + table * PHC_MAX_BODIES + j]; }
+
+PHC_HD void aba_load_model(AbaLane& L, const phc_model_t& m, int j) {
+    L.parent = model_tab(m, 0, j); L.level = model_tab(m, 1, j); L.jtype = model_tab(m, 2, j);
+    L.dof_start = model_tab(m, 3, j);
+    L.child[0] = model_tab(m, 4, j); L.child[1] = model_tab(m, 5, j); L.child[2] = model_tab(m, 6, j);
+    L.nchild = model_tab(m, 7, j); L.cp_start = model_tab(m, 8, j); L.cp_count = model_tab(m, 9, j);
+    const float* f = model_body(m, j);
+    L.r_local = v3(f[0], f[1], f[2]); L.mass = f[3]; L.mc_b = v3(f[4], f[5], f[6]);
+    L.Io_b.xx = f[7]; L.Io_b.xy = f[8]; L.Io_b.xz = f[9]; L.Io_b.yy = f[10]; L.Io_b.yz = f[11]; L.Io_b.zz = f[12];
+    L.kp = v3(f[13], f[14], f[15]); L.kd = v3(f[16], f[17], f[18]);
+    L.arm = v3(f[19], f[20], f[21]); L.effort = v3(f[22], f[23], f[24]);
+}
+
+// State load: S1 root_states [N,13], S2 dof_state [N,D,2] (exp-map, joint velocity), S8 pd_target [N,D]
+PHC_HD void aba_load_state(AbaLane& L, const phc_sim_state_t& s, int nd, int64_t env, int j) {
+    if (j == 0) {
+        const float* r = s.root_states + env * 13;
+        L.p0 = v3(r[0], r[1], r[2]); L.q = quat_normalize(q4(r[3], r[4], r[5], r[6]));
+        L.v0 = v3(r[7], r[8], r[9]); L.w0 = v3(r[10], r[11], r[12]);
+        L.wj = v3(0.f, 0.f, 0.f); L.target = v3(0.f, 0.f, 0.f);
+    } else {
+        const float* d = s.dof_state + (env * nd + L.dof_start) * 2;
+        L.q = quat_from_rotvec(v3(d[0], d[2], d[4]));
+        L.wj = v3(d[1], d[3], d[5]);
+        const float* t = s.pd_target + env * nd + L.dof_start;
+        L.target = v3(t[0], t[1], t[2]);
+        L.p0 = L.v0 = L.w0 = v3(0.f, 0.f, 0.f);
+    }
+}
+
+// ---- sweep 1: kinematics, one tree level.  Slot layout: Q(4) p(3) w(3) v(3). ----
+PHC_HD void aba_fk_level(AbaLane& L, int level, int j, float* xch) {
+    if (L.level != level) return;
+    if (level == 0) {
+        L.Q = L.q; L.p = L.p0; L.w = L.w0; L.v = L.v0;
+        L.rw = L.cw = L.ca = v3(0.f, 0.f, 0.f);
+    } else {
+        const float* ps = xch + L.parent * PHC_XCH_STRIDE;
+        Q4 Qp = q4(ps[0], ps[1], ps[2], ps[3]);
+        V3 pp = v3(ps[4], ps[5], ps[6]), wp = v3(ps[7], ps[8], ps[9]), vp = v3(ps[10], ps[11], ps[12]);
+        L.rw = quat_rotate(Qp, L.r_local);
+        L.p = pp + L.rw;
+        L.Q = quat_normalize(quat_mul16(Qp, L.q));
+        V3 wJw = quat_rotate(L.Q, L.wj);
+        L.w = wp + wJw;
+        L.v = vp + cross(wp, L.rw);
+        L.cw = cross(wp, wJw);
+        L.ca = cross(wp, cross(wp, L.rw));
+    }
+    float* s = xch + j * PHC_XCH_STRIDE;
+    s[0] = L.Q.x; s[1] = L.Q.y; s[2] = L.Q.z; s[3] = L.Q.w;
+    s[4] = L.p.x; s[5] = L.p.y; s[6] = L.p.z; s[7] = L.w.x; s[8] = L.w.y; s[9] = L.w.z;
+    s[10] = L.v.x; s[11] = L.v.y; s[12] = L.v.z;
+}
+
+// ---- per-body initialisation of I^A, p^A and of the joint drive (no communication) ----
+PHC_HD void aba_body_init(AbaLane& L, const phc_model_t& m, const phc_sim_params_t& prm, float dt) {
+    M3 R = quat_to_mat(L.Q);
+    Sym3 Io = rot_sym(R, L.Io_b);
+    V3 mc = mat_mul(R, L.mc_b);
+    // rigid-body inertia about the origin: [[Io, [mc]x], [[mc]x^T, m 1]]
+    L.IA.A = Io;
+    L.IA.B[0] = 0.f;   L.IA.B[1] = -mc.z; L.IA.B[2] = mc.y;
+    L.IA.B[3] = mc.z;  L.IA.B[4] = 0.f;   L.IA.B[5] = -mc.x;
+    L.IA.B[6] = -mc.y; L.IA.B[7] = mc.x;  L.IA.B[8] = 0.f;
+    L.IA.C.xx = L.IA.C.yy = L.IA.C.zz = L.mass; L.IA.C.xy = L.IA.C.xz = L.IA.C.yz = 0.f;
+    // bias force + gravity (external forces enter p^A with a minus sign)
+    V3 g = v3(0.f, 0.f, prm.gravity_z);
+    L.pA.n = cross(L.w, sym_mul(Io, L.w)) - cross(mc, g);
+    L.pA.f = cross(L.w, cross(L.w, mc)) - g * L.mass;
+    // ground contact: plane z = 0, normal +z
+    L.fcontact = v3(0.f, 0.f, 0.f);
+    const float cn = prm.contact_stiffness * dt + prm.contact_damping;
+    const float* cp = m.floats + PHC_MAX_BODIES * PHC_BODY_FLOATS + L.cp_start * 4;
+    for (int k = 0; k < L.cp_count; ++k) {
+        V3 arm = mat_mul(R, v3(cp[4 * k], cp[4 * k + 1], cp[4 * k + 2]));
+        float rad = cp[4 * k + 3];
+        float depth = rad - (L.p.z + arm.z);
+        if (depth <= 0.f) continue;
+        arm.z -= rad;  // actual contact location relative to the body origin
+        V3 uc = L.v + cross(L.w, arm);
+        float fn0 = prm.contact_stiffness * depth - cn * uc.z;
+        if (fn0 <= 0.f) continue;  // separating: non-adhesive
+        float ut = sqrtf(uc.x * uc.x + uc.y * uc.y);
+        float ct = fminf(prm.friction_viscous, prm.friction * fn0 / (ut + 1e-6f));
+        V3 cc = cross(L.w, cross(L.w, arm));
+        V3 F0 = v3(-ct * uc.x - dt * ct * cc.x, -ct * uc.y - dt * ct * cc.y, fn0 - dt * cn * cc.z);
+        L.fcontact += F0;
+        L.pA.n -= cross(arm, F0);
+        L.pA.f -= F0;
+        float c1 = dt * ct, c3 = dt * cn;
+        float ax = arm.x, ay = arm.y, az = arm.z;
+        // A += [a]x C [a]x^T
+        L.IA.A.xx += az * az * c1 + ay * ay * c3;
+        L.IA.A.yy += az * az * c1 + ax * ax * c3;
+        L.IA.A.zz += (ax * ax + ay * ay) * c1;
+        L.IA.A.xy -= ax * ay * c3;
+        L.IA.A.xz -= ax * az * c1;
+        L.IA.A.yz -= ay * az * c1;
+        // B += [a]x C   ([a]x = [[0,-az,ay],[az,0,-ax],[-ay,ax,0]], columns scaled by (c1,c1,c3))
+        L.IA.B[1] += -az * c1; L.IA.B[2] += ay * c3;
+        L.IA.B[3] += az * c1;  L.IA.B[5] += -ax * c3;
+        L.IA.B[6] += -ay * c1; L.IA.B[7] += ax * c1;
+        // C += C
+        L.IA.C.xx += c1; L.IA.C.yy += c1; L.IA.C.zz += c3;
+    }
+    // joint drive (spherical): geodesic error in the child frame
+    if (L.level > 0) {
+        Q4 qt = quat_from_rotvec(L.target);
+        V3 err = quat_to_rotvec(quat_mul16(quat_conjugate(L.q), qt));
+        V3 tau = v3(L.kp.x * err.x - (L.kd.x + dt * L.kp.x) * L.wj.x,
+                    L.kp.y * err.y - (L.kd.y + dt * L.kp.y) * L.wj.y,
+                    L.kp.z * err.z - (L.kd.z + dt * L.kp.z) * L.wj.z);
+        V3 d = v3(L.arm.x + dt * L.kd.x + dt * dt * L.kp.x, L.arm.y + dt * L.kd.y + dt * dt * L.kp.y,
+                  L.arm.z + dt * L.kd.z + dt * dt * L.kp.z);
+        // effort saturation: a saturated axis is a constant torque, no implicit stiffness
+        if (fabsf(tau.x) > L.effort.x) { tau.x = copysignf(L.effort.x, tau.x); d.x = L.arm.x; }
+        if (fabsf(tau.y) > L.effort.y) { tau.y = copysignf(L.effort.y, tau.y); d.y = L.arm.y; }
+        if (fabsf(tau.z) > L.effort.z) { tau.z = copysignf(L.effort.z, tau.z); d.z = L.arm.z; }
+        L.tau_local = tau;
+        L.dimp = d;
+    }
+}
+
+// 6x6 congruence T^T I T and T^T p for a pure translation r (child origin - parent origin)
+PHC_HD void shift_to_parent(const Inertia6& I, const Force6& p, V3 r, float* out /*27*/) {
+    // Y = [r]x C ; B' = B + Y
+    V3 c0 = v3(I.C.xx, I.C.xy, I.C.xz), c1 = v3(I.C.xy, I.C.yy, I.C.yz), c2 = v3(I.C.xz, I.C.yz, I.C.zz);
+    V3 y0 = cross(r, c0), y1 = cross(r, c1), y2 = cross(r, c2);  // columns of Y
+    float Bp[9];
+    Bp[0] = I.B[0] + y0.x; Bp[1] = I.B[1] + y1.x; Bp[2] = I.B[2] + y2.x;
+    Bp[3] = I.B[3] + y0.y; Bp[4] = I.B[4] + y1.y; Bp[5] = I.B[5] + y2.y;
+    Bp[6] = I.B[6] + y0.z; Bp[7] = I.B[7] + y1.z; Bp[8] = I.B[8] + y2.z;
+    // A' = A + X^T + [r]x B'^T  with X = [r]x B^T ;  columns of B^T are rows of B
+    V3 b0 = v3(I.B[0], I.B[1], I.B[2]), b1 = v3(I.B[3], I.B[4], I.B[5]), b2 = v3(I.B[6], I.B[7], I.B[8]);
+    V3 x0 = cross(r, b0), x1 = cross(r, b1), x2 = cross(r, b2);  // columns of X
+    V3 bp0 = v3(Bp[0], Bp[1], Bp[2]), bp1 = v3(Bp[3], Bp[4], Bp[5]), bp2 = v3(Bp[6], Bp[7], Bp[8]);
+    V3 z0 = cross(r, bp0), z1 = cross(r, bp1), z2 = cross(r, bp2);  // columns of Z = [r]x B'^T
+    // (X^T)_{ij} = X_{ji} = (x_i)_j ; Z_{ij} = (z_j)_i
+    out[0] = I.A.xx + x0.x + z0.x;
+    out[1] = I.A.xy + x0.y + z1.x;
+    out[2] = I.A.xz + x0.z + z2.x;
+    out[3] = I.A.yy + x1.y + z1.y;
+    out[4] = I.A.yz + x1.z + z2.y;
+    out[5] = I.A.zz + x2.z + z2.z;
+    for (int k = 0; k < 9; ++k) out[6 + k] = Bp[k];
+    out[15] = I.C.xx; out[16] = I.C.xy; out[17] = I.C.xz; out[18] = I.C.yy; out[19] = I.C.yz; out[20] = I.C.zz;
+    V3 n = p.n + cross(r, p.f);
+    out[21] = n.x; out[22] = n.y; out[23] = n.z; out[24] = p.f.x; out[25] = p.f.y; out[26] = p.f.z;
+}
+
+PHC_HD void accumulate_child(Inertia6& I, Force6& p, const float* s) {
+    I.A.xx += s[0]; I.A.xy += s[1]; I.A.xz += s[2]; I.A.yy += s[3]; I.A.yz += s[4]; I.A.zz += s[5];
+    for (int k = 0; k < 9; ++k) I.B[k] += s[6 + k];
+    I.C.xx += s[15]; I.C.xy += s[16]; I.C.xz += s[17]; I.C.yy += s[18]; I.C.yz += s[19]; I.C.zz += s[20];
+    p.n.x += s[21]; p.n.y += s[22]; p.n.z += s[23]; p.f.x += s[24]; p.f.y += s[25]; p.f.z += s[26];
+}
+
+// ---- sweep 2: articulated inertia, one tree level (leaves -> root) ----
+// Lanes at `level` first absorb their children's contributions (written at level+1), then, unless
+// they are the root, reduce over their own joint and publish T^T I^a T, T^T p^a for their parent.
+PHC_HD void aba_backward_level(AbaLane& L, int level, int j, float* xch) {
+    if (L.level != level) return;
+    for (int k = 0; k < 3; ++k)
+        if (k < L.nchild) accumulate_child(L.IA, L.pA, xch + L.child[k] * PHC_XCH_STRIDE);
+    if (level == 0) return;
+    M3 R = quat_to_mat(L.Q);
+    Sym3 D = rot_diag(R, L.dimp);
+    D.xx += L.IA.A.xx; D.xy += L.IA.A.xy; D.xz += L.IA.A.xz; D.yy += L.IA.A.yy; D.yz += L.IA.A.yz; D.zz += L.IA.A.zz;
+    L.Di = sym_inv(D);
+    L.u = mat_mul(R, L.tau_local) - L.pA.n;
+    // G = Di A (3x3), H = Di B (3x3)
+    const Sym3& A = L.IA.A;
+    const float* B = L.IA.B;
+    V3 a0 = v3(A.xx, A.xy, A.xz), a1 = v3(A.xy, A.yy, A.yz), a2 = v3(A.xz, A.yz, A.zz);  // columns (=rows) of A
+    V3 g0 = sym_mul(L.Di, a0), g1 = sym_mul(L.Di, a1), g2 = sym_mul(L.Di, a2);         // columns of G
+    V3 bc0 = v3(B[0], B[3], B[6]), bc1 = v3(B[1], B[4], B[7]), bc2 = v3(B[2], B[5], B[8]);  // columns of B
+    V3 h0 = sym_mul(L.Di, bc0), h1 = sym_mul(L.Di, bc1), h2 = sym_mul(L.Di, bc2);      // columns of H
+    Inertia6 Ia;
+    // A_a = A - A G  (symmetric)
+    Ia.A.xx = A.xx - dot(a0, g0); Ia.A.xy = A.xy - dot(a0, g1); Ia.A.xz = A.xz - dot(a0, g2);
+    Ia.A.yy = A.yy - dot(a1, g1); Ia.A.yz = A.yz - dot(a1, g2); Ia.A.zz = A.zz - dot(a2, g2);
+    // B_a = B - A H : (A H)_{ij} = row_i(A) . h_j
+    Ia.B[0] = B[0] - dot(a0, h0); Ia.B[1] = B[1] - dot(a0, h1); Ia.B[2] = B[2] - dot(a0, h2);
+    Ia.B[3] = B[3] - dot(a1, h0); Ia.B[4] = B[4] - dot(a1, h1); Ia.B[5] = B[5] - dot(a1, h2);
+    Ia.B[6] = B[6] - dot(a2, h0); Ia.B[7] = B[7] - dot(a2, h1); Ia.B[8] = B[8] - dot(a2, h2);
+    // C_a = C - B^T H : (B^T H)_{ij} = col_i(B) . h_j
+    Ia.C.xx = L.IA.C.xx - dot(bc0, h0); Ia.C.xy = L.IA.C.xy - dot(bc0, h1); Ia.C.xz = L.IA.C.xz - dot(bc0, h2);
+    Ia.C.yy = L.IA.C.yy - dot(bc1, h1); Ia.C.yz = L.IA.C.yz - dot(bc1, h2); Ia.C.zz = L.IA.C.zz - dot(bc2, h2);
+    // p_a = p^A + I^a c + U Di u,  U = [A; B^T]
+    V3 du = sym_mul(L.Di, L.u);
+    Force6 pa;
+    pa.n = L.pA.n + sym_mul(Ia.A, L.cw) + B_mul(Ia.B, L.ca) + sym_mul(A, du);
+    pa.f = L.pA.f + Bt_mul(Ia.B, L.cw) + sym_mul(Ia.C, L.ca) + Bt_mul(B, du);
+    shift_to_parent(Ia, pa, L.rw, xch + j * PHC_XCH_STRIDE);
+}
+
+// ---- sweep 3: accelerations, one tree level (root -> leaves).  Slot layout: alpha(3) a(3). ----
+PHC_HD void aba_forward_level(AbaLane& L, int level, int j, float* xch) {
+    if (L.level != level) return;
+    if (level == 0) {
+        // free root: [A B; B^T C] [alpha; a] = -[n; f]  by block elimination on C
+        Sym3 Ci = sym_inv(L.IA.C);
+        const float* B = L.IA.B;
+        // W = B Ci (3x3), S = A - W B^T
+        V3 ci0 = v3(Ci.xx, Ci.xy, Ci.xz), ci1 = v3(Ci.xy, Ci.yy, Ci.yz), ci2 = v3(Ci.xz, Ci.yz, Ci.zz);
+        V3 br0 = v3(B[0], B[1], B[2]), br1 = v3(B[3], B[4], B[5]), br2 = v3(B[6], B[7], B[8]);
+        V3 w0 = v3(dot(br0, ci0), dot(br0, ci1), dot(br0, ci2));  // rows of W
+        V3 w1 = v3(dot(br1, ci0), dot(br1, ci1), dot(br1, ci2));
+        V3 w2 = v3(dot(br2, ci0), dot(br2, ci1), dot(br2, ci2));
+        Sym3 S;
+        S.xx = L.IA.A.xx - dot(w0, br0); S.xy = L.IA.A.xy - dot(w0, br1); S.xz = L.IA.A.xz - dot(w0, br2);
+        S.yy = L.IA.A.yy - dot(w1, br1); S.yz = L.IA.A.yz - dot(w1, br2); S.zz = L.IA.A.zz - dot(w2, br2);
+        V3 rhs = v3(-L.pA.n.x + dot(w0, L.pA.f), -L.pA.n.y + dot(w1, L.pA.f), -L.pA.n.z + dot(w2, L.pA.f));
+        L.alpha = sym_mul(sym_inv(S), rhs);
+        L.a = -sym_mul(Ci, L.pA.f + Bt_mul(B, L.alpha));
+    } else {
+        const float* ps = xch + L.parent * PHC_XCH_STRIDE;
+        V3 alp = v3(ps[0], ps[1], ps[2]), ap = v3(ps[3], ps[4], ps[5]);
+        V3 al1 = alp + L.cw;
+        V3 a1 = ap + cross(alp, L.rw) + L.ca;
+        V3 beta = sym_mul(L.Di, L.u - sym_mul(L.IA.A, al1) - B_mul(L.IA.B, a1));
+        L.alpha = al1 + beta;
+        L.a = a1;
+        // joint acceleration in the child frame; semi-implicit Euler on the joint
+        // (done here so that `beta` need not be kept)
+        L.u = beta;  // reuse: world-frame joint angular acceleration
+    }
+    float* s = xch + j * PHC_XCH_STRIDE;
+    s[0] = L.alpha.x; s[1] = L.alpha.y; s[2] = L.alpha.z; s[3] = L.a.x; s[4] = L.a.y; s[5] = L.a.z;
+}
+
+// ---- integration (semi-implicit Euler), no communication ----
+PHC_HD void aba_integrate(AbaLane& L, const phc_sim_params_t& prm, float dt) {
+    const float damp = 1.0f / (1.0f + dt * prm.angular_damping);
+    if (L.level == 0) {
+        L.v0 = L.v0 + L.a * dt;
+        L.w0 = (L.w0 + L.alpha * dt) * damp;
+        L.p0 = L.p0 + L.v0 * dt;
+        L.q = quat_normalize(quat_mul16(quat_from_rotvec(L.w0 * dt), L.q));
+    } else {
+        M3 R = quat_to_mat(L.Q);
+        V3 qdd = mat_tmul(R, L.u);  // child-frame joint acceleration
+        // torque actually applied over the step (explicit part minus the implicit augmentation), S5
+        L.tau_local = v3(L.tau_local.x - (L.dimp.x - L.arm.x) * qdd.x, L.tau_local.y - (L.dimp.y - L.arm.y) * qdd.y,
+                         L.tau_local.z - (L.dimp.z - L.arm.z) * qdd.z);
+        L.wj = (L.wj + qdd * dt) * damp;
+        float wn = norm(L.wj);
+        if (wn > prm.max_angular_velocity) L.wj = L.wj * (prm.max_angular_velocity / wn);
+        L.q = quat_normalize(quat_mul16(L.q, quat_from_rotvec(L.wj * dt)));
+    }
+}
+
+// ---- state store: S1/S2 (+S5 dof force), and S3/S4 publication from the last kinematics sweep ----
+PHC_HD void aba_store_state(const AbaLane& L, const phc_sim_state_t& s, int nd, int64_t env, int j) {
+    if (j == 0) {
+        float* r = s.root_states + env * 13;
+        r[0] = L.p0.x; r[1] = L.p0.y; r[2] = L.p0.z; r[3] = L.q.x; r[4] = L.q.y; r[5] = L.q.z; r[6] = L.q.w;
+        r[7] = L.v0.x; r[8] = L.v0.y; r[9] = L.v0.z; r[10] = L.w0.x; r[11] = L.w0.y; r[12] = L.w0.z;
+    } else {
+        float* d = s.dof_state + (env * nd + L.dof_start) * 2;
+        V3 e = quat_to_rotvec(L.q);
+        d[0] = e.x; d[1] = L.wj.x; d[2] = e.y; d[3] = L.wj.y; d[4] = e.z; d[5] = L.wj.z;
+        if (s.dof_force) {
+            float* f = s.dof_force + env * nd + L.dof_start;
+            f[0] = L.tau_local.x; f[1] = L.tau_local.y; f[2] = L.tau_local.z;
+        }
+    }
+}
+PHC_HD void aba_publish_body(const AbaLane& L, const phc_sim_state_t& s, int nb, int64_t env, int j, bool with_contact) {
+    float* b = s.rigid_body_state + (env * nb + j) * 13;
+    b[0] = L.p.x; b[1] = L.p.y; b[2] = L.p.z; b[3] = L.Q.x; b[4] = L.Q.y; b[5] = L.Q.z; b[6] = L.Q.w;
+    b[7] = L.v.x; b[8] = L.v.y; b[9] = L.v.z; b[10] = L.w.x; b[11] = L.w.y; b[12] = L.w.z;
+    if (with_contact && s.contact_force) {
+        float* c = s.contact_force + (env * nb + j) * 3;
+        c[0] = L.fcontact.x; c[1] = L.fcontact.y; c[2] = L.fcontact.z;
+    }
+}
+
+}  // namespace phc

@@ -1,0 +1,215 @@
+// phc_im.h -- per-lane bodies of the imitation-task kernels (post-physics step, reset, AMP demo).
+// One lane per rigid body, 32 lanes per environment.  PHC_HD so tests/hostemu can drive the same
+// code lane-by-lane on the CPU.  Reference call sites are cited at each step.
+#pragma once
+#include "phc_task.h"
+
+namespace phc {
+
+// AMP observation of one time step computed from the *reference motion* (no offset):
+// HumanoidAMP._init_amp_obs_ref / build_amp_obs_demo (humanoid_amp.py:575-603,253-284).
+// Lane j writes its slices of a[0..A).
+PHC_HD void amp_obs_from_ref_lane(const phc_motion_lib_t& lib, const phc_im_params_t& prm, int nb, int j,
+                                  int64_t mid, float t, float* a) {
+    FrameRef fr = frame_ref(lib, mid, t);
+    BodyState root = ref_body(lib, fr, 0);
+    Q4 hinv = calc_heading_quat_inv(root.rot);
+    if (j == 0) amp_obs_root(prm, root.pos, root.rot, root.vel, root.angvel, hinv, a);
+    if (j >= 1 && j < nb) {
+        int slot = prm.amp_joint_slot[j];
+        if (slot >= 0) {
+            V3 dp, dv;
+            ref_joint(lib, fr, j, &dp, &dv);
+            amp_obs_joint(prm, slot, dp, dv, a);
+        }
+    }
+    if (j < prm.num_key_bodies) {
+        BodyState kb = ref_body(lib, fr, prm.key_body_ids[j]);
+        amp_obs_key(prm, j, kb.pos, root.pos, hinv, a);
+    }
+}
+
+// AMP observation of the current step from simulator state:
+// HumanoidAMP._compute_amp_observations (humanoid_amp.py:672-707)
+PHC_HD void amp_obs_from_sim_lane(const phc_im_params_t& prm, const phc_sim_state_t& sim, int nb, int nd, int64_t env, int j,
+                                  const BodyState& root, Q4 hinv, const int* dof_start_tab, float* a) {
+    if (j == 0) amp_obs_root(prm, root.pos, root.rot, root.vel, root.angvel, hinv, a);
+    if (j >= 1 && j < nb) {
+        int slot = prm.amp_joint_slot[j];
+        if (slot >= 0) {
+            const float* d = sim.dof_state + (env * nd + dof_start_tab[j]) * 2;
+            amp_obs_joint(prm, slot, v3(d[0], d[2], d[4]), v3(d[1], d[3], d[5]), a);
+        }
+    }
+    if (j < prm.num_key_bodies) {
+        BodyState kb = load_body(sim.rigid_body_state, env, nb, prm.key_body_ids[j]);
+        amp_obs_key(prm, j, kb.pos, root.pos, hinv, a);
+    }
+}
+
+// History shift of HumanoidAMP._update_hist_amp_obs (humanoid_amp.py:662-670), ping-pong:
+// out[env][1..S) = in[env][0..S-1).  Cooperative over the 32 lanes of the env, float4 wide.
+PHC_HD void amp_shift_lane(const phc_im_params_t& prm, const phc_im_buffers_t& buf, int64_t env, int lane) {
+    const int A = prm.num_amp_obs_per_step, S = prm.num_amp_obs_steps;
+    const float* src = buf.amp_obs_in + env * (int64_t)(S * A);
+    float* dst = buf.amp_obs_out + env * (int64_t)(S * A) + A;
+    const int n = (S - 1) * A;
+    if ((A & 3) == 0) {
+        const float4* s4 = reinterpret_cast<const float4*>(src);
+        float4* d4 = reinterpret_cast<float4*>(dst);
+        for (int i = lane; i < n / 4; i += 32) d4[i] = s4[i];
+    } else {
+        for (int i = lane; i < n; i += 32) dst[i] = src[i];
+    }
+}
+
+// post_physics_step for lane (env, j); `progress` is the already incremented progress_buf value
+// (humanoid.py:1637).  Writes obs / AMP slices, returns the partials the caller reduces over the env.
+PHC_HD RewardPartial im_post_lane(const phc_model_t& model, const phc_motion_lib_t& lib, const phc_im_params_t& prm,
+                                  const phc_sim_state_t& sim, const phc_im_buffers_t& buf, int64_t env, int j, int64_t progress) {
+    const int nb = model.num_bodies, nd = model.num_dof;
+    RewardPartial rp;
+    rp.pos = rp.rot = rp.vel = rp.angvel = rp.power = rp.dist = 0.f; rp.fallen = 0;
+    if (j >= nb) return rp;
+    const int64_t mid = buf.sampled_motion_ids[env];
+    const float st = buf.motion_start_times[env], so = buf.motion_start_times_offset[env];
+    const V3 goff = ld3(buf.global_offset + env * 3);
+    // humanoid_im.py:879 (reward / reset time) and :752 (observation time, "next frame so +1")
+    const float t0 = motion_time(progress, prm.dt, st, so);
+    const float t1 = motion_time(progress + 1, prm.dt, st, so);
+    const FrameRef fr0 = frame_ref(lib, mid, t0), fr1 = frame_ref(lib, mid, t1);
+    BodyState body = load_body(sim.rigid_body_state, env, nb, j);
+    BodyState root = load_body(sim.rigid_body_state, env, nb, 0);
+    BodyState r0 = ref_body(lib, fr0, j), r1 = ref_body(lib, fr1, j);
+    r0.pos += goff; r1.pos += goff;  // motion_lib_base.py:476
+    // R1 / R5 partials
+    rp = reward_partial(prm, env, nb, j, body, r0);
+    // R2 power partial: sum |tau * qdot| over this body's joint (humanoid_im.py:939-946)
+    if (prm.power_reward && j >= 1) {
+        int ds = model.ints[4 + 3 * PHC_MAX_BODIES + j];
+        const float* d = sim.dof_state + (env * nd + ds) * 2;
+        const float* f = sim.dof_force + env * nd + ds;
+        rp.power = fabsf(f[0] * d[1]) + fabsf(f[1] * d[3]) + fabsf(f[2] * d[5]);
+    }
+    // observations for the next policy step (humanoid_im.py:694-726)
+    Q4 hinv = calc_heading_quat_inv(root.rot), h = calc_heading_quat(root.rot);
+    float* obs = buf.obs_buf + env * (int64_t)(prm.num_self_obs + prm.num_task_obs);
+    self_obs_lane(prm, nb, j, body, root, hinv, obs);
+    int slot = prm.track_slot[j];
+    if (slot >= 0) task_obs_lane(prm, slot, body, root, r1, hinv, h, obs + prm.num_self_obs);
+    // side-effect buffers of _compute_task_obs (humanoid_im.py:855-868)
+    if (buf.ref_body_pos) st3(buf.ref_body_pos + (env * nb + j) * 3, r1.pos);
+    if (buf.ref_body_rot) st4(buf.ref_body_rot + (env * nb + j) * 4, r1.rot);
+    if (buf.ref_body_vel) st3(buf.ref_body_vel + (env * nb + j) * 3, r1.vel);
+    if (buf.ref_dof_pos && j >= 1) {
+        V3 dp, dv;
+        ref_joint(lib, fr1, j, &dp, &dv);
+        st3(buf.ref_dof_pos + env * nd + model.ints[4 + 3 * PHC_MAX_BODIES + j], dp);
+    }
+    // AMP observation of this step -> slot 0 of the new history (humanoid_amp.py:204-209)
+    float* amp = buf.amp_obs_out + env * (int64_t)(prm.num_amp_obs_steps * prm.num_amp_obs_per_step);
+    amp_obs_from_sim_lane(prm, sim, nb, nd, env, j, root, hinv, model.ints + 4 + 3 * PHC_MAX_BODIES, amp);
+    return rp;
+}
+
+// Per-env epilogue (lane 0) once the partials are reduced: reward (humanoid_im.py:1524-1554, 939-946),
+// reset / terminate (:1117-1190, 1581-1608), progress write-back.
+PHC_HD void im_post_finalize(const phc_motion_lib_t& lib, const phc_im_params_t& prm, const phc_im_buffers_t& buf, int nb,
+                             int64_t env, int64_t progress, float s_pos, float s_rot, float s_vel, float s_angvel,
+                             float s_power, float s_dist, int any_fallen, int n_reset_bodies) {
+    const float J = (float)nb;
+    float r_pos = expf(-prm.k_pos * (s_pos / J));
+    float r_rot = expf(-prm.k_rot * (s_rot / J));
+    float r_vel = expf(-prm.k_vel * (s_vel / J));
+    float r_ang = expf(-prm.k_ang_vel * (s_angvel / J));
+    float rew = prm.w_pos * r_pos + prm.w_rot * r_rot + prm.w_vel * r_vel + prm.w_ang_vel * r_ang;
+    const int nraw = prm.power_reward ? 5 : 4;
+    float* raw = buf.reward_raw + env * nraw;
+    raw[0] = r_pos; raw[1] = r_rot; raw[2] = r_vel; raw[3] = r_ang;
+    if (prm.power_reward) {
+        float pr = -prm.power_coefficient * s_power;
+        if (progress <= 3) pr = 0.f;
+        rew += pr;
+        raw[4] = pr;
+    }
+    buf.rew_buf[env] = rew;
+    // _compute_reset
+    const int64_t mid = buf.sampled_motion_ids[env];
+    const float t0 = motion_time(progress, prm.dt, buf.motion_start_times[env], buf.motion_start_times_offset[env]);
+    const bool pass_time = t0 >= lib.motion_lengths[mid];
+    int fallen = any_fallen;
+    if (prm.use_mean_termination) {
+        // torch.norm(...).mean(-1, keepdim) > termination_distance[0]  (row of env 0, any over reset bodies)
+        float mean = s_dist / (float)n_reset_bodies;
+        fallen = 0;
+        for (int j = 0; j < nb; ++j)
+            if (prm.reset_mask[j] && mean > prm.termination_distances[j]) fallen = 1;
+    }
+    int64_t terminated = 0;
+    if (prm.enable_early_termination) {
+        if (!(progress > 1)) fallen = 0;
+        if (prm.disable_collision_check) fallen = 0;
+        terminated = fallen ? 1 : 0;
+    }
+    buf.terminate_buf[env] = terminated;
+    buf.reset_buf[env] = pass_time ? 1 : terminated;
+    buf.progress_buf[env] = progress;
+}
+
+// Reset of one env, lane j: HumanoidIm._reset_envs (humanoid.py:585-621; humanoid_amp.py:378-398,508-528,
+// 559-637; humanoid_im.py:955-1023).  `t` = sampled start time.
+PHC_HD void im_reset_lane(const phc_model_t& model, const phc_motion_lib_t& lib, const phc_im_params_t& prm,
+                          const phc_sim_state_t& sim, const phc_im_buffers_t& buf, int64_t env, int j, float t) {
+    const int nb = model.num_bodies, nd = model.num_dof;
+    const int64_t mid = buf.sampled_motion_ids[env];
+    if (j < nb) {
+        const FrameRef fr = frame_ref(lib, mid, t);
+        BodyState rs = ref_body(lib, fr, j);     // global offset was just zeroed (humanoid_im.py:956-957)
+        BodyState root = (j == 0) ? rs : ref_body(lib, fr, 0);
+        // _set_env_state (humanoid_amp.py:605-637)
+        store_body(sim.rigid_body_state, env, nb, j, rs);
+        if (sim.contact_force) st3(sim.contact_force + (env * nb + j) * 3, v3(0.f, 0.f, 0.f));  // humanoid.py:619
+        if (j == 0) {
+            float* r = sim.root_states + env * 13;
+            st3(r, rs.pos); st4(r + 3, rs.rot); st3(r + 7, rs.vel); st3(r + 10, rs.angvel);
+        } else {
+            V3 dp, dv;
+            ref_joint(lib, fr, j, &dp, &dv);
+            const int ds = model.ints[4 + 3 * PHC_MAX_BODIES + j];
+            float* d = sim.dof_state + (env * nd + ds) * 2;
+            d[0] = dp.x; d[1] = dv.x; d[2] = dp.y; d[3] = dv.y; d[4] = dp.z; d[5] = dv.z;
+            st3(sim.pd_target + env * nd + ds, dp);  // set_dof_position_target_tensor_indexed(dof_pos) humanoid.py:605
+            if (sim.dof_force) st3(sim.dof_force + env * nd + ds, v3(0.f, 0.f, 0.f));
+        }
+        // observations of the reset envs (humanoid.py:595 -> humanoid_im.py:694-726), progress_buf == 0
+        const float t1 = motion_time(1, prm.dt, t, 0.f);
+        const FrameRef fr1 = frame_ref(lib, mid, t1);
+        BodyState r1 = ref_body(lib, fr1, j);
+        Q4 hinv = calc_heading_quat_inv(root.rot), h = calc_heading_quat(root.rot);
+        float* obs = buf.obs_buf + env * (int64_t)(prm.num_self_obs + prm.num_task_obs);
+        self_obs_lane(prm, nb, j, rs, root, hinv, obs);
+        int slot = prm.track_slot[j];
+        if (slot >= 0) task_obs_lane(prm, slot, rs, root, r1, hinv, h, obs + prm.num_self_obs);
+        if (buf.ref_body_pos) st3(buf.ref_body_pos + (env * nb + j) * 3, r1.pos);
+        if (buf.ref_body_rot) st4(buf.ref_body_rot + (env * nb + j) * 4, r1.rot);
+        if (buf.ref_body_vel) st3(buf.ref_body_vel + (env * nb + j) * 3, r1.vel);
+        if (buf.ref_dof_pos && j >= 1) {
+            V3 dp, dv;
+            ref_joint(lib, fr1, j, &dp, &dv);
+            st3(buf.ref_dof_pos + env * nd + model.ints[4 + 3 * PHC_MAX_BODIES + j], dp);
+        }
+    }
+    // AMP history: slot 0 from the (just imposed) state == reference at t; slots 1..S-1 from the
+    // reference motion at t - k dt (humanoid_amp.py:559-603)
+    const int A = prm.num_amp_obs_per_step, S = prm.num_amp_obs_steps;
+    float* amp = buf.amp_obs_out + env * (int64_t)(S * A);
+    for (int k = 0; k < S; ++k) amp_obs_from_ref_lane(lib, prm, nb, j, mid, history_time(t, prm.dt, k), amp + k * A);
+    if (j == 0) {
+        buf.motion_start_times[env] = t;           // humanoid_amp.py:524
+        buf.motion_start_times_offset[env] = 0.f;  // humanoid_im.py:956
+        st3(buf.global_offset + env * 3, v3(0.f, 0.f, 0.f));
+        buf.progress_buf[env] = 0; buf.reset_buf[env] = 0; buf.terminate_buf[env] = 0;  // humanoid.py:616-618
+    }
+}
+
+}  // namespace phc

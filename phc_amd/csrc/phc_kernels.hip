@@ -1,0 +1,330 @@
+// phc_kernels.hip -- gfx950 kernels + the extern "C" entry points declared in include/phc_amd.h.
+//
+// Thread mapping used by every env kernel: ONE LANE PER RIGID BODY, 32 lanes per environment,
+// two environments per 64-wide wavefront.  The stepper runs one wavefront per workgroup so that
+// its level-synchronous tree sweeps synchronise with a (free) single-wave barrier; the task
+// kernels use 256-thread workgroups (8 envs).  Per-env sums use 32-lane butterfly shuffles.
+#include <hip/hip_runtime.h>
+#include "phc_aba.h"
+#include "phc_im.h"
+
+using namespace phc;
+
+#define GRP 32  // lanes per environment
+
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m, GRP);
+    return v;
+}
+__device__ __forceinline__ int group_or(int v) {
+#pragma unroll
+    for (int m = 16; m >= 1; m >>= 1) v |= __shfl_xor(v, m, GRP);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------
+// S10: the stepper.  blockDim = 64 (one wavefront, two envs).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void wave_sync() { __syncthreads(); }  // single-wave workgroup: no cross-wave wait
+
+template <bool STEP>
+__global__ __launch_bounds__(64) void k_sim_step(phc_model_t model, phc_sim_params_t prm, phc_sim_state_t sim,
+                                                const float* __restrict__ actions, const float* __restrict__ pd_off,
+                                                const float* __restrict__ pd_scale, const int32_t* __restrict__ freeze,
+                                                int num_sim_calls) {
+    __shared__ float xch_all[2 * PHC_MAX_BODIES * PHC_XCH_STRIDE];
+    const int lane = threadIdx.x & (GRP - 1);
+    const int grp = threadIdx.x >> 5;
+    const int64_t env = (int64_t)blockIdx.x * 2 + grp;
+    float* xch = xch_all + grp * PHC_MAX_BODIES * PHC_XCH_STRIDE;
+    const int nb = model.num_bodies, nd = model.num_dof;
+    const bool active = env < sim.num_envs && lane < nb;
+
+    AbaLane L;
+    L.level = -1;
+    if (active) {
+        aba_load_model(L, model, lane);
+        if (STEP && actions != nullptr && lane >= 1) {
+            // A2: pd_tar = offset + scale * action, frozen DoFs -> 0 (humanoid.py:1711-1713,1549-1554)
+            for (int k = 0; k < 3; ++k) {
+                const int d = L.dof_start + k;
+                float t = __fadd_rn(pd_off[d], __fmul_rn(pd_scale[d], actions[env * nd + d]));
+                if (freeze != nullptr && freeze[d]) t = 0.f;
+                sim.pd_target[env * nd + d] = t;
+            }
+        }
+        aba_load_state(L, sim, nd, env, lane);
+    }
+    const int max_level = model.max_level;
+    if (STEP) {
+        const float dt = prm.sim_dt / (float)prm.substeps;
+        const int nsub = num_sim_calls * prm.substeps;
+        for (int s = 0; s < nsub; ++s) {
+            for (int l = 0; l <= max_level; ++l) { aba_fk_level(L, l, lane, xch); wave_sync(); }
+            if (active) aba_body_init(L, model, prm, dt);
+            for (int l = max_level; l >= 0; --l) { aba_backward_level(L, l, lane, xch); wave_sync(); }
+            for (int l = 0; l <= max_level; ++l) { aba_forward_level(L, l, lane, xch); wave_sync(); }
+            if (active) aba_integrate(L, prm, dt);
+        }
+    }
+    // S7: publish the end-of-step state (one more kinematics sweep on the integrated state)
+    for (int l = 0; l <= max_level; ++l) { aba_fk_level(L, l, lane, xch); wave_sync(); }
+    if (active) {
+        if (STEP) aba_store_state(L, sim, nd, env, lane);
+        aba_publish_body(L, sim, nb, env, lane, STEP);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// post_physics_step of the imitation task.  blockDim = 256 (8 envs).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_im_post_physics(phc_model_t model, phc_motion_lib_t lib, phc_im_params_t prm,
+                                                        phc_sim_state_t sim, phc_im_buffers_t buf, int n_reset_bodies) {
+    const int lane = threadIdx.x & (GRP - 1);
+    const int64_t env = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+    if (env >= sim.num_envs) return;  // whole 32-lane group exits together
+    const int64_t progress = buf.progress_buf[env] + 1;  // humanoid.py:1637
+    amp_shift_lane(prm, buf, env, lane);
+    RewardPartial rp = im_post_lane(model, lib, prm, sim, buf, env, lane, progress);
+    float s_pos = group_sum(rp.pos), s_rot = group_sum(rp.rot), s_vel = group_sum(rp.vel), s_ang = group_sum(rp.angvel);
+    float s_pow = group_sum(rp.power), s_dist = group_sum(rp.dist);
+    int fallen = group_or(rp.fallen);
+    if (lane == 0)
+        im_post_finalize(lib, prm, buf, model.num_bodies, env, progress, s_pos, s_rot, s_vel, s_ang, s_pow, s_dist, fallen, n_reset_bodies);
+}
+
+// Reset of a list of envs.  blockDim = 256 (8 envs).
+__global__ __launch_bounds__(256) void k_im_reset(phc_model_t model, phc_motion_lib_t lib, phc_im_params_t prm, phc_sim_state_t sim,
+                                                 phc_im_buffers_t buf, int num_reset, const int64_t* __restrict__ env_ids,
+                                                 const float* __restrict__ phase, int start_at_zero) {
+    const int lane = threadIdx.x & (GRP - 1);
+    const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+    if (r >= num_reset) return;
+    const int64_t env = env_ids[r];
+    const int64_t mid = buf.sampled_motion_ids[env];
+    // _sample_ref_state (humanoid_im.py:1000-1023): StateInit.Random -> sample_time_interval; Start / flags.test -> 0
+    const float t = start_at_zero ? 0.f : sample_time_interval(lib, mid, phase[r]);
+    im_reset_lane(model, lib, prm, sim, buf, env, lane, t);
+}
+
+// build_amp_obs_demo: n samples x S history steps.  One 32-lane group per (sample, step).
+__global__ __launch_bounds__(256) void k_amp_obs_demo(phc_model_t model, phc_motion_lib_t lib, phc_im_params_t prm, int n,
+                                                     const int64_t* __restrict__ motion_ids, const float* __restrict__ times0,
+                                                     float* __restrict__ out) {
+    const int lane = threadIdx.x & (GRP - 1);
+    const int64_t g = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+    const int S = prm.num_amp_obs_steps, A = prm.num_amp_obs_per_step;
+    if (g >= (int64_t)n * S) return;
+    const int64_t i = g / S;
+    const int k = (int)(g - i * S);
+    amp_obs_from_ref_lane(lib, prm, model.num_bodies, lane, motion_ids[i], history_time(times0[i], prm.dt, k), out + g * A);
+}
+
+// M9 standalone: get_motion_state for n (id, time) pairs.  One 32-lane group per lookup.
+__global__ __launch_bounds__(256) void k_motion_state(phc_motion_lib_t lib, int n, const int64_t* __restrict__ ids,
+                                                     const float* __restrict__ times, const float* __restrict__ offset,
+                                                     float* rg_pos, float* rb_rot, float* body_vel, float* body_ang_vel,
+                                                     float* dof_pos, float* dof_vel, int64_t* idx0, int64_t* idx1, float* blend) {
+    const int lane = threadIdx.x & (GRP - 1);
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+    if (i >= n) return;
+    const int nb = lib.num_bodies;
+    const FrameRef fr = frame_ref(lib, ids[i], times[i]);
+    if (lane == 0) {
+        if (idx0) idx0[i] = fr.idx0;
+        if (idx1) idx1[i] = fr.idx1;
+        if (blend) blend[i] = fr.blend;
+    }
+    if (lane >= nb) return;
+    BodyState s = ref_body(lib, fr, lane);
+    if (offset) s.pos += ld3(offset + i * 3);
+    if (rg_pos) st3(rg_pos + (i * nb + lane) * 3, s.pos);
+    if (rb_rot) st4(rb_rot + (i * nb + lane) * 4, s.rot);
+    if (body_vel) st3(body_vel + (i * nb + lane) * 3, s.vel);
+    if (body_ang_vel) st3(body_ang_vel + (i * nb + lane) * 3, s.angvel);
+    if (lane >= 1 && (dof_pos || dof_vel)) {
+        V3 dp, dv;
+        ref_joint(lib, fr, lane, &dp, &dv);
+        if (dof_pos) st3(dof_pos + i * (nb - 1) * 3 + (lane - 1) * 3, dp);
+        if (dof_vel) st3(dof_vel + i * (nb - 1) * 3 + (lane - 1) * 3, dv);
+    }
+}
+
+__global__ void k_sample_time_interval(phc_motion_lib_t lib, int n, const int64_t* __restrict__ ids,
+                                       const float* __restrict__ phase, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = sample_time_interval(lib, ids[i], phase[i]);
+}
+
+// P5 GAE: one thread per env, reversed scan over the horizon (common_agent.py:493-505)
+__global__ void k_gae(int T, int n, const float* __restrict__ fdones, const float* __restrict__ values,
+                      const float* __restrict__ rewards, const float* __restrict__ next_values, float gamma, float tau,
+                      float* __restrict__ advs) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float last = 0.f;
+    for (int t = T - 1; t >= 0; --t) {
+        const int64_t k = (int64_t)t * n + i;
+        const float not_done = 1.0f - fdones[k];
+        const float delta = rewards[k] + gamma * next_values[k] - values[k];
+        last = delta + gamma * tau * not_done * last;
+        advs[k] = last;
+    }
+}
+
+// M5 poselib FK (skeleton3d.py:390-426): one thread per frame, bodies in tree order; quat_mul_norm semantics
+// (positive real part, unit norm; rotation3d.py:31-98,195-201).
+__device__ __forceinline__ Q4 pl_quat_mul_norm(Q4 a, Q4 b) {
+    Q4 q = quat_mul16(a, b);
+    if (q.w < 0.f) q = q4(-q.x, -q.y, -q.z, -q.w);
+    float n = fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-9f);
+    return q4(q.x / n, q.y / n, q.z / n, q.w / n);
+}
+__global__ void k_fk(phc_model_t model, int64_t T, const float* __restrict__ local_rot, const float* __restrict__ root_trans,
+                     float* __restrict__ grot, float* __restrict__ gpos) {
+    const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= T) return;
+    const int nb = model.num_bodies;
+    for (int j = 0; j < nb; ++j) {
+        const int p = model_tab(model, 0, j);
+        Q4 lq = ld4(local_rot + (f * nb + j) * 4);
+        if (p < 0) {
+            st4(grot + (f * nb + j) * 4, lq);
+            st3(gpos + (f * nb + j) * 3, ld3(root_trans + f * 3));
+        } else {
+            Q4 pq = ld4(grot + (f * nb + p) * 4);
+            const float* mb = model_body(model, j);
+            // poselib quat_rotate = Im(q * (v,0) * conj(q))
+            V3 off = quat_rotate(pq, v3(mb[0], mb[1], mb[2]));
+            st4(grot + (f * nb + j) * 4, pl_quat_mul_norm(pq, lq));
+            st3(gpos + (f * nb + j) * 3, off + ld3(gpos + (f * nb + p) * 3));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------
+static inline int32_t launch_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int32_t)e;
+}
+static inline int env_blocks(int64_t groups, int block) { return (int)((groups * GRP + block - 1) / block); }
+
+extern "C" {
+
+int32_t phc_abi_version(void) { return PHC_ABI_VERSION; }
+
+int32_t phc_motion_state(const phc_motion_lib_t* lib, int32_t n, const int64_t* motion_ids, const float* motion_times,
+                         const float* offset, float* rg_pos, float* rb_rot, float* body_vel, float* body_ang_vel,
+                         float* dof_pos, float* dof_vel, int64_t* frame_idx0, int64_t* frame_idx1, float* blend, void* stream) {
+    if (!lib || n < 0 || lib->num_bodies > PHC_MAX_BODIES) return PHC_EINVAL;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_motion_state, dim3(env_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, *lib, n, motion_ids,
+                       motion_times, offset, rg_pos, rb_rot, body_vel, body_ang_vel, dof_pos, dof_vel, frame_idx0, frame_idx1, blend);
+    return launch_status();
+}
+
+int32_t phc_sample_time_interval(const phc_motion_lib_t* lib, int32_t n, const int64_t* motion_ids, const float* phase,
+                                 float* motion_times, void* stream) {
+    if (!lib || n < 0) return PHC_EINVAL;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_sample_time_interval, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, *lib, n, motion_ids, phase, motion_times);
+    return launch_status();
+}
+
+static int32_t check_model(const phc_model_t* m) {
+    if (!m || m->num_bodies < 1 || m->num_bodies > PHC_MAX_BODIES || !m->ints || !m->floats) return PHC_EINVAL;
+    if (m->num_dof != 3 * (m->num_bodies - 1)) return PHC_EUNSUPPORTED;  // spherical joints only in this round
+    return 0;
+}
+
+int32_t phc_sim_step(const phc_model_t* model, const phc_sim_params_t* params, const phc_sim_state_t* sim, const float* actions,
+                     const float* pd_action_offset, const float* pd_action_scale, const int32_t* freeze_mask,
+                     int32_t num_sim_calls, void* stream) {
+    int32_t rc = check_model(model);
+    if (rc) return rc;
+    if (!params || !sim || sim->num_envs < 0 || params->substeps < 1 || num_sim_calls < 0) return PHC_EINVAL;
+    if (actions && (!pd_action_offset || !pd_action_scale)) return PHC_EINVAL;
+    if (sim->num_envs == 0) return 0;
+    hipLaunchKernelGGL(k_sim_step<true>, dim3((sim->num_envs + 1) / 2), dim3(64), 0, (hipStream_t)stream, *model, *params, *sim,
+                       actions, pd_action_offset, pd_action_scale, freeze_mask, num_sim_calls);
+    return launch_status();
+}
+
+int32_t phc_refresh_body_state(const phc_model_t* model, const phc_sim_state_t* sim, void* stream) {
+    int32_t rc = check_model(model);
+    if (rc) return rc;
+    if (!sim || sim->num_envs < 0) return PHC_EINVAL;
+    if (sim->num_envs == 0) return 0;
+    phc_sim_params_t prm = {};
+    prm.substeps = 1;
+    hipLaunchKernelGGL(k_sim_step<false>, dim3((sim->num_envs + 1) / 2), dim3(64), 0, (hipStream_t)stream, *model, prm, *sim,
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const int32_t*)nullptr, 0);
+    return launch_status();
+}
+
+static int32_t check_im(const phc_model_t* model, const phc_motion_lib_t* lib, const phc_im_params_t* prm) {
+    int32_t rc = check_model(model);
+    if (rc) return rc;
+    if (!lib || !prm || lib->num_bodies != model->num_bodies) return PHC_EINVAL;
+    if (!prm->track_slot || !prm->reset_mask || !prm->termination_distances || !prm->key_body_ids || !prm->amp_joint_slot) return PHC_EINVAL;
+    if (prm->num_key_bodies > GRP) return PHC_EUNSUPPORTED;
+    return 0;
+}
+
+int32_t phc_im_post_physics(const phc_model_t* model, const phc_motion_lib_t* lib, const phc_im_params_t* prm,
+                            const phc_sim_state_t* sim, const phc_im_buffers_t* buf, void* stream) {
+    int32_t rc = check_im(model, lib, prm);
+    if (rc) return rc;
+    if (!sim || !buf || buf->amp_obs_in == buf->amp_obs_out) return PHC_EINVAL;
+    if (sim->num_envs == 0) return 0;
+    const int n_reset_bodies = prm->num_reset_bodies > 0 ? prm->num_reset_bodies : 1;
+    hipLaunchKernelGGL(k_im_post_physics, dim3(env_blocks(sim->num_envs, 256)), dim3(256), 0, (hipStream_t)stream, *model, *lib,
+                       *prm, *sim, *buf, n_reset_bodies);
+    return launch_status();
+}
+
+int32_t phc_im_reset(const phc_model_t* model, const phc_motion_lib_t* lib, const phc_im_params_t* prm, const phc_sim_state_t* sim,
+                     const phc_im_buffers_t* buf, int32_t num_reset, const int64_t* env_ids, const float* phase,
+                     int32_t start_at_zero, void* stream) {
+    int32_t rc = check_im(model, lib, prm);
+    if (rc) return rc;
+    if (!sim || !buf || num_reset < 0 || (!start_at_zero && !phase)) return PHC_EINVAL;
+    if (num_reset == 0) return 0;
+    hipLaunchKernelGGL(k_im_reset, dim3(env_blocks(num_reset, 256)), dim3(256), 0, (hipStream_t)stream, *model, *lib, *prm, *sim,
+                       *buf, num_reset, env_ids, phase, start_at_zero);
+    return launch_status();
+}
+
+int32_t phc_amp_obs_demo(const phc_model_t* model, const phc_motion_lib_t* lib, const phc_im_params_t* prm, int32_t n,
+                         const int64_t* motion_ids, const float* motion_times0, float* amp_obs_demo, void* stream) {
+    int32_t rc = check_im(model, lib, prm);
+    if (rc) return rc;
+    if (n < 0) return PHC_EINVAL;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_amp_obs_demo, dim3(env_blocks((int64_t)n * prm->num_amp_obs_steps, 256)), dim3(256), 0, (hipStream_t)stream,
+                       *model, *lib, *prm, n, motion_ids, motion_times0, amp_obs_demo);
+    return launch_status();
+}
+
+int32_t phc_gae(int32_t horizon, int32_t n, const float* fdones, const float* values, const float* rewards,
+                const float* next_values, float gamma, float tau, float* advs, void* stream) {
+    if (horizon < 0 || n < 0) return PHC_EINVAL;
+    if (horizon == 0 || n == 0) return 0;
+    hipLaunchKernelGGL(k_gae, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, horizon, n, fdones, values, rewards,
+                       next_values, gamma, tau, advs);
+    return launch_status();
+}
+
+int32_t phc_fk(const phc_model_t* model, int64_t num_frames, const float* local_rot, const float* root_trans, float* global_rot,
+               float* global_pos, void* stream) {
+    if (!model || model->num_bodies < 1 || model->num_bodies > PHC_MAX_BODIES || num_frames < 0) return PHC_EINVAL;
+    if (num_frames == 0) return 0;
+    hipLaunchKernelGGL(k_fk, dim3((unsigned)((num_frames + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *model, num_frames,
+                       local_rot, root_trans, global_rot, global_pos);
+    return launch_status();
+}
+
+}  // extern "C"

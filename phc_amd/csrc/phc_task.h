@@ -1,0 +1,198 @@
+// phc_task.h -- per-lane device functions of the imitation task: reference-motion lookup
+// (M7-M9), imitation reward (R1/R2), reset test (R5), self / task / AMP observations (R6/R7/R9).
+//
+// Mapping: one lane per rigid body, 32 lanes per environment (NB <= 32), two environments per
+// 64-wide wavefront.  Everything a lane needs from "its" body is private; the few per-env
+// quantities (root pose, reward sums, fallen flag) are obtained by broadcast loads and one
+// 32-lane reduction.  All functions are PHC_HD so tests/hostemu can run the same code on CPU.
+#pragma once
+#include "phc_math.h"
+#include "../../include/phc_amd.h"
+
+#if defined(__clang__)
+#define PHC_NO_CONTRACT _Pragma("clang fp contract(off)")
+#else
+#define PHC_NO_CONTRACT
+#endif
+
+namespace phc {
+
+// ---- frame record field offsets (see phc_motion_lib_t) ----
+PHC_HD int fr_pos(int nb) { (void)nb; return 0; }
+PHC_HD int fr_rot(int nb) { return nb * 3; }
+PHC_HD int fr_vel(int nb) { return nb * 7; }
+PHC_HD int fr_angvel(int nb) { return nb * 10; }
+PHC_HD int fr_lrot(int nb) { return nb * 13; }
+PHC_HD int fr_dvel(int nb) { return nb * 17; }
+
+struct FrameRef { int64_t f0, f1; float blend; int64_t idx0, idx1; };
+
+// M8 _calc_frame_blend (motion_lib_base.py:549-559) + the length_starts offset (:447-448).
+// Index arithmetic is the bit-exact part of the contract: no fma contraction in here.
+PHC_HD FrameRef frame_ref(const phc_motion_lib_t& lib, int64_t mid, float time) {
+    PHC_NO_CONTRACT
+    float len = lib.motion_lengths[mid];
+    float dt = lib.motion_dt[mid];
+    int64_t nf = lib.motion_num_frames[mid];
+    float phase = time / len;
+    phase = fminf(fmaxf(phase, 0.0f), 1.0f);  // torch.clip
+    if (time < 0.f) time = 0.f;
+    float nfm1 = (float)(nf - 1);
+    float prod = phase * nfm1;
+    FrameRef r;
+    r.idx0 = (int64_t)prod;
+    r.idx1 = (r.idx0 + 1 < nf - 1) ? r.idx0 + 1 : nf - 1;
+    float sub = (float)r.idx0 * dt;
+    float bl = (time - sub) / dt;
+    r.blend = fminf(fmaxf(bl, 0.0f), 1.0f);
+    int64_t start = lib.length_starts[mid];
+    r.f0 = r.idx0 + start;
+    r.f1 = r.idx1 + start;
+    return r;
+}
+
+// M7 sample_time_interval (motion_lib_base.py:414-423)
+PHC_HD float sample_time_interval(const phc_motion_lib_t& lib, int64_t mid, float phase) {
+    PHC_NO_CONTRACT
+    const float curr_fps = (float)(1.0 / 30.0);
+    float t = (phase * lib.motion_lengths[mid]) / curr_fps;
+    return (float)((int64_t)t) * curr_fps;
+}
+
+// env time (humanoid_im.py:879,752,1118): progress * dt + start + offset, each op rounded to fp32
+PHC_HD float motion_time(int64_t progress, float dt, float start, float start_off) {
+    PHC_NO_CONTRACT
+    float a = (float)progress * dt;
+    float b = a + start;
+    return b + start_off;
+}
+// humanoid_amp.py:575-603 / 253-284: t0 + (-dt * k)
+PHC_HD float history_time(float t0, float dt, int k) {
+    PHC_NO_CONTRACT
+    float ts = (-dt) * (float)k;
+    return t0 + ts;
+}
+
+PHC_HD V3 ld3(const float* p) { return v3(p[0], p[1], p[2]); }
+PHC_HD Q4 ld4(const float* p) { return q4(p[0], p[1], p[2], p[3]); }
+PHC_HD void st3(float* p, V3 v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; }
+PHC_HD void st4(float* p, Q4 q) { p[0] = q.x; p[1] = q.y; p[2] = q.z; p[3] = q.w; }
+PHC_HD V3 lerp3(V3 a, V3 b, float t) {  // (1-t)*a + t*b, the reference's form (motion_lib_base.py:474-480)
+    float s = 1.0f - t;
+    return v3(s * a.x + t * b.x, s * a.y + t * b.y, s * a.z + t * b.z);
+}
+
+struct BodyState { V3 pos; Q4 rot; V3 vel; V3 angvel; };
+
+// M9 get_motion_state, the part of it that belongs to body j (motion_lib_base.py:450-488)
+PHC_HD BodyState ref_body(const phc_motion_lib_t& lib, const FrameRef& fr, int j) {
+    const int nb = lib.num_bodies;
+    const float* a = lib.frames + fr.f0 * (int64_t)lib.frame_stride;
+    const float* b = lib.frames + fr.f1 * (int64_t)lib.frame_stride;
+    BodyState s;
+    s.pos = lerp3(ld3(a + fr_pos(nb) + 3 * j), ld3(b + fr_pos(nb) + 3 * j), fr.blend);
+    s.vel = lerp3(ld3(a + fr_vel(nb) + 3 * j), ld3(b + fr_vel(nb) + 3 * j), fr.blend);
+    s.angvel = lerp3(ld3(a + fr_angvel(nb) + 3 * j), ld3(b + fr_angvel(nb) + 3 * j), fr.blend);
+    s.rot = slerp(ld4(a + fr_rot(nb) + 4 * j), ld4(b + fr_rot(nb) + 4 * j), fr.blend);
+    return s;
+}
+// dof_pos = quat_to_exp_map(slerp(local_rot)) (motion_lib_base.py:483-484,564-567), dof_vel lerp; joint of body j>=1
+PHC_HD void ref_joint(const phc_motion_lib_t& lib, const FrameRef& fr, int j, V3* dof_pos, V3* dof_vel) {
+    const int nb = lib.num_bodies;
+    const float* a = lib.frames + fr.f0 * (int64_t)lib.frame_stride;
+    const float* b = lib.frames + fr.f1 * (int64_t)lib.frame_stride;
+    Q4 lr = slerp(ld4(a + fr_lrot(nb) + 4 * j), ld4(b + fr_lrot(nb) + 4 * j), fr.blend);
+    *dof_pos = quat_to_exp_map(lr);
+    *dof_vel = lerp3(ld3(a + fr_dvel(nb) + 3 * (j - 1)), ld3(b + fr_dvel(nb) + 3 * (j - 1)), fr.blend);
+}
+
+PHC_HD BodyState load_body(const float* rigid_body_state, int64_t env, int nb, int j) {
+    const float* p = rigid_body_state + (env * nb + j) * 13;
+    BodyState s;
+    s.pos = ld3(p); s.rot = ld4(p + 3); s.vel = ld3(p + 7); s.angvel = ld3(p + 10);
+    return s;
+}
+PHC_HD void store_body(float* rigid_body_state, int64_t env, int nb, int j, const BodyState& s) {
+    float* p = rigid_body_state + (env * nb + j) * 13;
+    st3(p, s.pos); st4(p + 3, s.rot); st3(p + 7, s.vel); st3(p + 10, s.angvel);
+}
+
+// ---- R6: compute_humanoid_observations_smpl_max (humanoid.py:1995-2050), lane j's slices ----
+PHC_HD void self_obs_lane(const phc_im_params_t& prm, int nb, int j, const BodyState& body, const BodyState& root,
+                          Q4 hinv, float* obs) {
+    int off = 0;
+    if (prm.root_height_obs) { if (j == 0) obs[0] = root.pos.z; off = 1; }
+    if (j >= 1) st3(obs + off + (j - 1) * 3, quat_rotate(hinv, body.pos - root.pos));
+    float tn[6];
+    if (j == 0 && !prm.local_root_obs) quat_to_tan_norm(root.rot, tn);  // :2026-2028
+    else quat_to_tan_norm(quat_mul(hinv, body.rot), tn);
+    float* pr = obs + off + (nb - 1) * 3 + j * 6;
+    for (int k = 0; k < 6; ++k) pr[k] = tn[k];
+    st3(obs + off + (nb - 1) * 3 + nb * 6 + j * 3, quat_rotate(hinv, body.vel));
+    st3(obs + off + (nb - 1) * 3 + nb * 9 + j * 3, quat_rotate(hinv, body.angvel));
+}
+
+// ---- R7: compute_imitation_observations_v6 (humanoid_im.py:1309-1358), time_steps = 1 ----
+PHC_HD void task_obs_lane(const phc_im_params_t& prm, int slot, const BodyState& body, const BodyState& root,
+                          const BodyState& ref, Q4 hinv, Q4 h, float* tobs) {
+    const int jt = prm.num_track_bodies;
+    st3(tobs + slot * 3, quat_rotate(hinv, ref.pos - body.pos));
+    Q4 drot = quat_mul(ref.rot, quat_conjugate(body.rot));
+    Q4 dl = quat_mul(quat_mul(hinv, drot), h);
+    float tn[6];
+    quat_to_tan_norm(dl, tn);
+    for (int k = 0; k < 6; ++k) tobs[jt * 3 + slot * 6 + k] = tn[k];
+    st3(tobs + jt * 9 + slot * 3, quat_rotate(hinv, ref.vel - body.vel));
+    st3(tobs + jt * 12 + slot * 3, quat_rotate(hinv, ref.angvel - body.angvel));
+    st3(tobs + jt * 15 + slot * 3, quat_rotate(hinv, ref.pos - root.pos));
+    quat_to_tan_norm(quat_mul(hinv, ref.rot), tn);
+    for (int k = 0; k < 6; ++k) tobs[jt * 18 + slot * 6 + k] = tn[k];
+}
+
+// ---- R9: build_amp_observations_smpl (humanoid_amp.py:967-1011), lane j's slices of one 196-float step ----
+// layout: [root_h? | root_rot 6 | root_vel 3 | root_ang_vel 3 | dof_obs 6*NJ | dof_vel 3*NJ | key_pos 3*K]
+PHC_HD void amp_obs_root(const phc_im_params_t& prm, V3 root_pos, Q4 root_rot, V3 root_vel, V3 root_angvel, Q4 hinv, float* a) {
+    int off = 0;
+    if (prm.root_height_obs) { a[0] = root_pos.z; off = 1; }
+    float tn[6];
+    quat_to_tan_norm(prm.local_root_obs ? quat_mul(hinv, root_rot) : root_rot, tn);
+    for (int k = 0; k < 6; ++k) a[off + k] = tn[k];
+    st3(a + off + 6, quat_rotate(hinv, root_vel));
+    st3(a + off + 9, quat_rotate(hinv, root_angvel));
+}
+PHC_HD void amp_obs_joint(const phc_im_params_t& prm, int slot, V3 dof_pos, V3 dof_vel, float* a) {
+    const int off = (prm.root_height_obs ? 1 : 0) + 12;
+    float tn[6];
+    quat_to_tan_norm(exp_map_to_quat(dof_pos), tn);  // dof_to_obs_smpl humanoid.py:1756-1765
+    for (int k = 0; k < 6; ++k) a[off + slot * 6 + k] = tn[k];
+    st3(a + off + prm.num_amp_joints * 6 + slot * 3, dof_vel);
+}
+PHC_HD void amp_obs_key(const phc_im_params_t& prm, int k, V3 key_pos, V3 root_pos, Q4 hinv, float* a) {
+    const int off = (prm.root_height_obs ? 1 : 0) + 12 + prm.num_amp_joints * 9;
+    st3(a + off + k * 3, quat_rotate(hinv, key_pos - root_pos));
+}
+
+// ---- R1/R5 per-lane partials, reduced over the 32-lane group by the caller ----
+struct RewardPartial { float pos, rot, vel, angvel, power, dist; int fallen; };
+
+PHC_HD RewardPartial reward_partial(const phc_im_params_t& prm, int64_t env, int nb, int j, const BodyState& body, const BodyState& ref) {
+    RewardPartial p;
+    V3 d = ref.pos - body.pos;
+    p.pos = (d.x * d.x + d.y * d.y + d.z * d.z) / 3.0f;  // (diff**2).mean(-1)   humanoid_im.py:1530-1531
+    Q4 dq = quat_mul(ref.rot, quat_conjugate(body.rot));
+    float ang = quat_to_angle_axis(dq, nullptr);          // :1535-1537
+    p.rot = ang * ang;
+    d = ref.vel - body.vel;
+    p.vel = (d.x * d.x + d.y * d.y + d.z * d.z) / 3.0f;
+    d = ref.angvel - body.angvel;
+    p.angvel = (d.x * d.x + d.y * d.y + d.z * d.z) / 3.0f;
+    p.power = 0.f;
+    // compute_humanoid_im_reset :1586-1588
+    float dist = norm(body.pos - ref.pos);
+    int in_reset = prm.reset_mask[j];
+    p.dist = in_reset ? dist : 0.f;
+    p.fallen = (in_reset && dist > prm.termination_distances[env * nb + j]) ? 1 : 0;
+    return p;
+}
+
+}  // namespace phc

@@ -1,0 +1,384 @@
+"""Model compiler: MJCF -> flat articulation description consumed by the HIP stepper.
+
+Replaces what the reference gets from Isaac Gym's asset pipeline
+(``gym.load_asset / get_actor_dof_properties / get_actor_rigid_body_properties``,
+reference ``phc/env/tasks/humanoid.py:768-990,1093-1106``) and from
+``SkeletonTree.from_mjcf`` (``poselib/poselib/skeleton/skeleton3d.py:149-193``):
+
+* body order = MJCF depth-first order (identical to ``SkeletonTree.from_mjcf``);
+* the three co-located hinges of a body are merged into one spherical joint whose
+  coordinates are the exponential map of the child-in-parent rotation
+  (Isaac Gym convention the reference relies on, ``humanoid.py:487,1762``);
+* mass / centre of mass / inertia come from geom density x volume
+  (sphere, capsule ``fromto``, box), like MuJoCo / Isaac Gym do for MJCF without
+  ``<inertial>``;  ``<inertial>`` is honoured when present (robots);
+* ground-contact primitives: sphere -> 1 point (r), capsule -> 2 points (r),
+  box -> 8 corners (r = 0).
+
+The compiled model is a plain dict of numpy arrays / lists, serialisable to JSON
+(``phc_amd/assets/*.json`` are compiled once from the reference's MJCF assets by
+``python -m phc_amd.model <mjcf> <out.json>``; the assets are data, the reference
+tree is not needed at run time).
+"""
+import json
+import os
+import sys
+import xml.etree.ElementTree as ET
+
+import numpy as np
+
+JOINT_FREE, JOINT_SPHERICAL, JOINT_REVOLUTE, JOINT_FIXED = 0, 1, 2, 3
+ASSET_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets")
+
+
+def _floats(s, default=None):
+    if s is None:
+        return None if default is None else np.array(default, dtype=np.float64)
+    return np.array([float(x) for x in s.split()], dtype=np.float64)
+
+
+def _quat_wxyz_to_mat(q):
+    w, x, y, z = q / np.linalg.norm(q)
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def _shift_inertia(I_c, m, c):
+    """Inertia about a point displaced by -c from the COM (parallel axis)."""
+    return I_c + m * (np.dot(c, c) * np.eye(3) - np.outer(c, c))
+
+
+def _geom_props(g, defaults):
+    """-> (mass, com[3], I_com[3,3], contact points [(pos[3], radius)])"""
+    gtype = g.attrib.get("type", defaults.get("type", "sphere"))
+    density = float(g.attrib.get("density", defaults.get("density", 1000.0)))
+    size = _floats(g.attrib.get("size"), [0.0])
+    if gtype == "sphere":
+        r = size[0]
+        pos = _floats(g.attrib.get("pos"), [0, 0, 0])
+        m = density * 4.0 / 3.0 * np.pi * r ** 3
+        I = np.eye(3) * 0.4 * m * r * r
+        return m, pos, I, [(pos, r)]
+    if gtype == "capsule":
+        r = size[0]
+        if "fromto" in g.attrib:
+            ft = _floats(g.attrib["fromto"])
+            p0, p1 = ft[:3], ft[3:]
+        else:
+            pos = _floats(g.attrib.get("pos"), [0, 0, 0])
+            R = _quat_wxyz_to_mat(_floats(g.attrib.get("quat"), [1, 0, 0, 0]))
+            half = size[1]
+            p0, p1 = pos - R[:, 2] * half, pos + R[:, 2] * half
+        L = np.linalg.norm(p1 - p0)
+        axis = (p1 - p0) / max(L, 1e-12)
+        m_cyl = density * np.pi * r * r * L
+        m_cap = density * 4.0 / 3.0 * np.pi * r ** 3
+        I_ax = 0.5 * m_cyl * r * r + 0.4 * m_cap * r * r
+        I_tr = m_cyl * (L * L / 12.0 + r * r / 4.0) + m_cap * (0.4 * r * r + L * L / 4.0 + 0.375 * L * r)
+        P = np.outer(axis, axis)
+        I = I_ax * P + I_tr * (np.eye(3) - P)
+        return m_cyl + m_cap, 0.5 * (p0 + p1), I, [(p0, r), (p1, r)]
+    if gtype == "box":
+        pos = _floats(g.attrib.get("pos"), [0, 0, 0])
+        R = _quat_wxyz_to_mat(_floats(g.attrib.get("quat"), [1, 0, 0, 0]))
+        a, b, c = size[:3]
+        m = density * 8.0 * a * b * c
+        I_l = np.diag([b * b + c * c, a * a + c * c, a * a + b * b]) * m / 3.0
+        I = R @ I_l @ R.T
+        pts = []
+        for sx in (-1, 1):
+            for sy in (-1, 1):
+                for sz in (-1, 1):
+                    pts.append((pos + R @ np.array([sx * a, sy * b, sz * c]), 0.0))
+        return m, pos, I, pts
+    raise NotImplementedError(f"geom type {gtype}")
+
+
+def compile_mjcf(path):
+    """Parse an MJCF humanoid (free root + hinge joints) into the flat model dict."""
+    root = ET.parse(path).getroot()
+    wb = root.find("worldbody")
+    body0 = wb.find("body")
+    dflt = root.find("default")
+    geom_defaults, joint_defaults = {}, {}
+    if dflt is not None:
+        if dflt.find("geom") is not None:
+            geom_defaults = dict(dflt.find("geom").attrib)
+        if dflt.find("joint") is not None:
+            joint_defaults = dict(dflt.find("joint").attrib)
+    gears = {}
+    act = root.find("actuator")
+    if act is not None:
+        for mtr in act.findall("motor"):
+            gears[mtr.attrib["joint"]] = float(mtr.attrib.get("gear", "1").split()[0])
+
+    names, parents, local_t = [], [], []
+    mass, com, inertia_o = [], [], []
+    jtype, dof_start, dof_count = [], [], []
+    dof_axis, dof_kp, dof_kd, dof_arm, dof_lo, dof_hi, dof_effort, dof_names = [], [], [], [], [], [], [], []
+    cpts = []
+
+    def add(node, parent):
+        idx = len(names)
+        names.append(node.attrib.get("name"))
+        parents.append(parent)
+        # np.fromstring(..., dtype=float) then float32 cast, as SkeletonTree.from_mjcf does
+        local_t.append(_floats(node.attrib.get("pos"), [0, 0, 0]))
+        m_tot, mc, parts = 0.0, np.zeros(3), []
+        inert = node.find("inertial")
+        if inert is not None:
+            m_tot = float(inert.attrib["mass"])
+            c = _floats(inert.attrib.get("pos"), [0, 0, 0])
+            if "fullinertia" in inert.attrib:
+                xx, yy, zz, xy, xz, yz = _floats(inert.attrib["fullinertia"])
+                Ic = np.array([[xx, xy, xz], [xy, yy, yz], [xz, yz, zz]])
+            else:
+                Ic = np.diag(_floats(inert.attrib.get("diaginertia"), [0, 0, 0]))
+            if "quat" in inert.attrib:
+                R = _quat_wxyz_to_mat(_floats(inert.attrib["quat"]))
+                Ic = R @ Ic @ R.T
+            mc = m_tot * c
+            parts = [(m_tot, c, Ic)]
+        for g in node.findall("geom"):
+            gm, gc, gI, pts = _geom_props(g, geom_defaults)
+            for p, r in pts:
+                cpts.append((idx, np.asarray(p, dtype=np.float64), float(r)))
+            if inert is None:
+                m_tot += gm
+                mc += gm * gc
+                parts.append((gm, gc, gI))
+        c = mc / m_tot if m_tot > 0 else np.zeros(3)
+        Io = np.zeros((3, 3))
+        for gm, gc, gI in parts:
+            Io += _shift_inertia(gI, gm, gc)  # about the body origin (joint anchor)
+        mass.append(m_tot)
+        com.append(c)
+        inertia_o.append(Io)
+        joints = node.findall("joint")
+        if node.find("freejoint") is not None or any(j.attrib.get("type") == "free" for j in joints):
+            jtype.append(JOINT_FREE); dof_start.append(len(dof_axis)); dof_count.append(0)
+        elif len(joints) == 0:
+            jtype.append(JOINT_FIXED); dof_start.append(len(dof_axis)); dof_count.append(0)
+        else:
+            axes = [_floats(j.attrib.get("axis", joint_defaults.get("axis", "0 0 1"))) for j in joints]
+            is_sph = len(joints) == 3 and np.allclose(np.stack(axes), np.eye(3))
+            if not is_sph and len(joints) != 1:
+                raise NotImplementedError(f"body {names[-1]}: {len(joints)} hinge joints that are not x,y,z")
+            jtype.append(JOINT_SPHERICAL if is_sph else JOINT_REVOLUTE)
+            dof_start.append(len(dof_axis)); dof_count.append(len(joints))
+            for j, ax in zip(joints, axes):
+                get = lambda k, d: float(j.attrib.get(k, joint_defaults.get(k, d)))
+                rng = _floats(j.attrib.get("range", joint_defaults.get("range", "0 0")))
+                dof_axis.append(ax / np.linalg.norm(ax))
+                dof_kp.append(get("stiffness", 0.0)); dof_kd.append(get("damping", 0.0)); dof_arm.append(get("armature", 0.0))
+                dof_lo.append(np.deg2rad(rng[0])); dof_hi.append(np.deg2rad(rng[1]))  # MJCF default angle unit: degree
+                dof_effort.append(gears.get(j.attrib.get("name"), 0.0))
+                dof_names.append(j.attrib.get("name"))
+        for child in node.findall("body"):
+            add(child, idx)
+
+    add(body0, -1)
+    nb = len(names)
+    level = [0] * nb
+    for i in range(1, nb):
+        level[i] = level[parents[i]] + 1
+    cpts.sort(key=lambda t: t[0])
+    model = {
+        "source": os.path.basename(path),
+        "body_names": names,
+        "parent": parents,
+        "level": level,
+        "local_translation": np.array(local_t, dtype=np.float32).tolist(),
+        "mass": mass,
+        "com": np.array(com).tolist(),
+        "inertia_origin": np.array(inertia_o).tolist(),
+        "joint_type": jtype,
+        "dof_start": dof_start,
+        "dof_count": dof_count,
+        "dof_names": dof_names,
+        "dof_axis": np.array(dof_axis).tolist(),
+        "dof_kp": dof_kp, "dof_kd": dof_kd, "dof_armature": dof_arm,
+        "dof_lower": dof_lo, "dof_upper": dof_hi, "dof_effort": dof_effort,
+        "contact_body": [c[0] for c in cpts],
+        "contact_pos": [c[1].tolist() for c in cpts],
+        "contact_radius": [c[2] for c in cpts],
+    }
+    return model
+
+
+class ArticulationModel:
+    """Numpy view of a compiled model + the packed fp32 / int32 buffers the kernels read."""
+
+    MAX_BODIES = 32
+
+    def __init__(self, d):
+        self.d = d
+        self.body_names = list(d["body_names"])
+        self.num_bodies = len(self.body_names)
+        assert self.num_bodies <= self.MAX_BODIES, "the stepper maps one body per lane of a 32-lane group"
+        self.parent = np.array(d["parent"], dtype=np.int32)
+        self.level = np.array(d["level"], dtype=np.int32)
+        self.local_translation = np.array(d["local_translation"], dtype=np.float32)
+        self.mass = np.array(d["mass"], dtype=np.float64)
+        self.com = np.array(d["com"], dtype=np.float64)
+        self.inertia_origin = np.array(d["inertia_origin"], dtype=np.float64)
+        self.joint_type = np.array(d["joint_type"], dtype=np.int32)
+        self.dof_start = np.array(d["dof_start"], dtype=np.int32)
+        self.dof_count = np.array(d["dof_count"], dtype=np.int32)
+        self.dof_names = list(d["dof_names"])
+        self.num_dof = len(self.dof_names)
+        self.dof_axis = np.array(d["dof_axis"], dtype=np.float64).reshape(-1, 3)
+        self.dof_kp = np.array(d["dof_kp"], dtype=np.float64)
+        self.dof_kd = np.array(d["dof_kd"], dtype=np.float64)
+        self.dof_armature = np.array(d["dof_armature"], dtype=np.float64)
+        self.dof_lower = np.array(d["dof_lower"], dtype=np.float64)
+        self.dof_upper = np.array(d["dof_upper"], dtype=np.float64)
+        self.dof_effort = np.array(d["dof_effort"], dtype=np.float64)
+        self.contact_body = np.array(d["contact_body"], dtype=np.int32)
+        self.contact_pos = np.array(d["contact_pos"], dtype=np.float64).reshape(-1, 3)
+        self.contact_radius = np.array(d["contact_radius"], dtype=np.float64)
+        self.max_level = int(self.level.max())
+        self.all_spherical = bool(np.all(self.joint_type[1:] == JOINT_SPHERICAL))
+
+    # ---- lookups mirroring the reference task helpers -------------------------------------
+    def body_ids(self, names):
+        """humanoid.py:1674-1691 `_build_key_body_ids_tensor`."""
+        return np.array([self.body_names.index(n) for n in names], dtype=np.int64)
+
+    @property
+    def total_mass(self):
+        return float(self.mass.sum())
+
+    def children(self):
+        ch = [[] for _ in range(self.num_bodies)]
+        for i in range(1, self.num_bodies):
+            ch[self.parent[i]].append(i)
+        return ch
+
+    # ---- packed buffers --------------------------------------------------------------------
+    def pack(self, kp_scale=1.0, kd_scale=1.0):
+        """-> (ints int32[...], floats float32[...]) laid out as csrc/phc_model.h expects.
+
+        ints  : [0]=NB [1]=ND [2]=max_level [3]=NCP then per body (32 slots each):
+                parent, level, joint_type, dof_start, child0, child1, child2, nchild,
+                cp_start, cp_count
+        floats: per body (32 slots x 24): r_local[3], mass, m*com[3], Io(xx,xy,xz,yy,yz,zz)[6],
+                kp[3], kd[3], armature[3], effort[3], axis[3] (revolute) ;
+                then contact points NCP x 4 (pos[3], radius)
+        """
+        NB, MB = self.num_bodies, self.MAX_BODIES
+        ints = np.zeros(4 + 10 * MB, dtype=np.int32)
+        ints[0:4] = [NB, self.num_dof, self.max_level, len(self.contact_body)]
+        tab = ints[4:].reshape(10, MB)
+        tab[0, :] = -1
+        tab[1, :] = -1
+        tab[4:7, :] = -1
+        ch = self.children()
+        for i in range(NB):
+            assert len(ch[i]) <= 3, "at most 3 children per body supported by the sweep"
+            tab[0, i] = self.parent[i]
+            tab[1, i] = self.level[i]
+            tab[2, i] = self.joint_type[i]
+            tab[3, i] = self.dof_start[i]
+            for k, c in enumerate(ch[i]):
+                tab[4 + k, i] = c
+            tab[7, i] = len(ch[i])
+            idx = np.nonzero(self.contact_body == i)[0]
+            tab[8, i] = idx[0] if len(idx) else 0
+            tab[9, i] = len(idx)
+        BF = 28
+        fl = np.zeros((MB, BF), dtype=np.float64)
+        for i in range(NB):
+            fl[i, 0:3] = self.local_translation[i]
+            fl[i, 3] = self.mass[i]
+            fl[i, 4:7] = self.mass[i] * self.com[i]
+            I = self.inertia_origin[i]
+            fl[i, 7:13] = [I[0, 0], I[0, 1], I[0, 2], I[1, 1], I[1, 2], I[2, 2]]
+            s, c = self.dof_start[i], self.dof_count[i]
+            if c > 0:
+                fl[i, 13:13 + c] = self.dof_kp[s:s + c] * kp_scale
+                fl[i, 16:16 + c] = self.dof_kd[s:s + c] * kd_scale
+                fl[i, 19:19 + c] = self.dof_armature[s:s + c]
+                fl[i, 22:22 + c] = self.dof_effort[s:s + c]
+                if self.joint_type[i] == JOINT_REVOLUTE:
+                    fl[i, 25:28] = self.dof_axis[s]
+        cp = np.concatenate([self.contact_pos, self.contact_radius[:, None]], axis=1) if len(self.contact_body) else np.zeros((0, 4))
+        floats = np.concatenate([fl.reshape(-1), cp.reshape(-1)]).astype(np.float32)
+        return ints, floats
+
+    BODY_FLOATS = 28
+
+    # ---- action scaling (A1) ---------------------------------------------------------------
+    def dof_limits(self):
+        """humanoid.py:966-983: swap if lower>upper; equal & zero -> +-pi."""
+        lo, hi = [], []
+        for l, u in zip(self.dof_lower, self.dof_upper):
+            l, u = np.float32(l), np.float32(u)
+            if l > u:
+                lo.append(u); hi.append(l)
+            elif l == u:
+                lo.append(-np.pi); hi.append(np.pi)
+            else:
+                lo.append(l); hi.append(u)
+        return np.array(lo, dtype=np.float32), np.array(hi, dtype=np.float32)
+
+    def pd_action_offset_scale(self, bias_offset=False):
+        """Reference `_build_pd_action_offset_scale` (humanoid.py:1331-1409)."""
+        lim_low, lim_high = self.dof_limits()
+        lim_low, lim_high = lim_low.copy(), lim_high.copy()
+        for i in range(1, self.num_bodies):
+            s, c = self.dof_start[i], self.dof_count[i]
+            if c == 0:
+                continue
+            if not bias_offset:
+                if c == 3:
+                    cl = np.max(np.abs(lim_low[s:s + 3]))
+                    chh = np.max(np.abs(lim_high[s:s + 3]))
+                    sc = min([1.2 * max([cl, chh]), np.pi])
+                    lim_low[s:s + 3] = -sc
+                    lim_high[s:s + 3] = sc
+                elif c == 1:
+                    mid = 0.5 * (lim_high[s] + lim_low[s])
+                    sc = 0.7 * (lim_high[s] - lim_low[s])
+                    lim_low[s] = mid - sc
+                    lim_high[s] = mid + sc
+            else:
+                mid = 0.5 * (lim_high[s:s + c] + lim_low[s:s + c])
+                sc = 0.7 * (lim_high[s:s + c] - lim_low[s:s + c])
+                lim_low[s:s + c] = mid - sc
+                lim_high[s:s + c] = mid + sc
+        offset = (0.5 * (lim_high + lim_low)).astype(np.float32)
+        scale = (0.5 * (lim_high - lim_low)).astype(np.float32)
+        if self.all_spherical and "L_Knee" in self.body_names:
+            jn = self.body_names[1:]
+            scale[jn.index("L_Knee") * 3 + 1] = 5  # "Bumping Kneel" humanoid.py:1387-1394
+            scale[jn.index("R_Knee") * 3 + 1] = 5
+        return offset, scale
+
+    def limb_lengths_and_weights(self, groups):
+        """humanoid.py:1097-1106: per-group summed |local_translation| and masses."""
+        ll = np.linalg.norm(self.local_translation, axis=-1)
+        out = [ll[g].sum() for g in groups] + [self.mass[g].sum() for g in groups]
+        return np.array(out, dtype=np.float32)
+
+
+def load_model(name_or_path):
+    """Load a compiled JSON asset by name ("smpl_humanoid") or path, or compile an MJCF."""
+    p = name_or_path
+    if not os.path.exists(p):
+        p = os.path.join(ASSET_DIR, name_or_path if name_or_path.endswith(".json") else name_or_path + ".json")
+    if p.endswith(".xml"):
+        return ArticulationModel(compile_mjcf(p))
+    with open(p) as f:
+        return ArticulationModel(json.load(f))
+
+
+if __name__ == "__main__":
+    src, dst = sys.argv[1], sys.argv[2]
+    m = compile_mjcf(src)
+    with open(dst, "w") as f:
+        json.dump(m, f, indent=0)
+    am = ArticulationModel(m)
+    print(f"{src}: {am.num_bodies} bodies, {am.num_dof} dof, mass {am.total_mass:.2f} kg, "
+          f"{len(am.contact_body)} contact points, max level {am.max_level}")

@@ -1,0 +1,130 @@
+// hostemu.cpp -- TEST INFRASTRUCTURE ONLY.
+// Compiles the *same* per-lane functions the HIP kernels are made of (phc_amd/csrc/*.h are
+// host+device) with g++ and drives them lane by lane on the CPU, so that the kernel math can be
+// checked against the oracle on a machine without a GPU (`pytest -m "not gpu"`).
+// The product never loads this library: phc_amd/_lib.py only ever opens libphc_amd.so.
+#include <cstring>
+#include <vector>
+#include "../../phc_amd/csrc/phc_aba.h"
+#include "../../phc_amd/csrc/phc_im.h"
+
+using namespace phc;
+
+extern "C" {
+
+int emu_motion_state(const phc_motion_lib_t* lib, int n, const int64_t* ids, const float* times, const float* offset,
+                     float* rg_pos, float* rb_rot, float* body_vel, float* body_ang_vel, float* dof_pos, float* dof_vel,
+                     int64_t* idx0, int64_t* idx1, float* blend) {
+    const int nb = lib->num_bodies;
+    for (int64_t i = 0; i < n; ++i) {
+        FrameRef fr = frame_ref(*lib, ids[i], times[i]);
+        if (idx0) idx0[i] = fr.idx0;
+        if (idx1) idx1[i] = fr.idx1;
+        if (blend) blend[i] = fr.blend;
+        for (int j = 0; j < nb; ++j) {
+            BodyState s = ref_body(*lib, fr, j);
+            if (offset) s.pos += ld3(offset + i * 3);
+            if (rg_pos) st3(rg_pos + (i * nb + j) * 3, s.pos);
+            if (rb_rot) st4(rb_rot + (i * nb + j) * 4, s.rot);
+            if (body_vel) st3(body_vel + (i * nb + j) * 3, s.vel);
+            if (body_ang_vel) st3(body_ang_vel + (i * nb + j) * 3, s.angvel);
+            if (j >= 1 && (dof_pos || dof_vel)) {
+                V3 dp, dv;
+                ref_joint(*lib, fr, j, &dp, &dv);
+                if (dof_pos) st3(dof_pos + i * (nb - 1) * 3 + (j - 1) * 3, dp);
+                if (dof_vel) st3(dof_vel + i * (nb - 1) * 3 + (j - 1) * 3, dv);
+            }
+        }
+    }
+    return 0;
+}
+
+int emu_sample_time_interval(const phc_motion_lib_t* lib, int n, const int64_t* ids, const float* phase, float* out) {
+    for (int i = 0; i < n; ++i) out[i] = sample_time_interval(*lib, ids[i], phase[i]);
+    return 0;
+}
+
+int emu_im_post_physics(const phc_model_t* model, const phc_motion_lib_t* lib, const phc_im_params_t* prm,
+                        const phc_sim_state_t* sim, const phc_im_buffers_t* buf) {
+    for (int64_t env = 0; env < sim->num_envs; ++env) {
+        const int64_t progress = buf->progress_buf[env] + 1;
+        for (int lane = 0; lane < 32; ++lane) amp_shift_lane(*prm, *buf, env, lane);
+        float s[6] = {0, 0, 0, 0, 0, 0};
+        int fallen = 0;
+        for (int lane = 0; lane < 32; ++lane) {
+            RewardPartial rp = im_post_lane(*model, *lib, *prm, *sim, *buf, env, lane, progress);
+            s[0] += rp.pos; s[1] += rp.rot; s[2] += rp.vel; s[3] += rp.angvel; s[4] += rp.power; s[5] += rp.dist;
+            fallen |= rp.fallen;
+        }
+        im_post_finalize(*lib, *prm, *buf, model->num_bodies, env, progress, s[0], s[1], s[2], s[3], s[4], s[5], fallen,
+                         prm->num_reset_bodies > 0 ? prm->num_reset_bodies : 1);
+    }
+    return 0;
+}
+
+int emu_im_reset(const phc_model_t* model, const phc_motion_lib_t* lib, const phc_im_params_t* prm, const phc_sim_state_t* sim,
+                 const phc_im_buffers_t* buf, int num_reset, const int64_t* env_ids, const float* phase, int start_at_zero) {
+    for (int r = 0; r < num_reset; ++r) {
+        const int64_t env = env_ids[r];
+        const int64_t mid = buf->sampled_motion_ids[env];
+        const float t = start_at_zero ? 0.f : sample_time_interval(*lib, mid, phase[r]);
+        for (int lane = 31; lane >= 0; --lane) im_reset_lane(*model, *lib, *prm, *sim, *buf, env, lane, t);
+    }
+    return 0;
+}
+
+int emu_amp_obs_demo(const phc_model_t* model, const phc_motion_lib_t* lib, const phc_im_params_t* prm, int n,
+                     const int64_t* ids, const float* times0, float* out) {
+    const int S = prm->num_amp_obs_steps, A = prm->num_amp_obs_per_step;
+    for (int64_t g = 0; g < (int64_t)n * S; ++g) {
+        const int64_t i = g / S;
+        const int k = (int)(g - i * S);
+        for (int lane = 0; lane < 32; ++lane)
+            amp_obs_from_ref_lane(*lib, *prm, model->num_bodies, lane, ids[i], history_time(times0[i], prm->dt, k), out + g * A);
+    }
+    return 0;
+}
+
+// Stepper: same phase sequence as k_sim_step, lanes looped inside each phase.
+int emu_sim_step(const phc_model_t* model, const phc_sim_params_t* prm, const phc_sim_state_t* sim, const float* actions,
+                 const float* pd_off, const float* pd_scale, const int32_t* freeze, int num_sim_calls, int do_step) {
+    const int nb = model->num_bodies, nd = model->num_dof;
+    std::vector<float> xch(PHC_MAX_BODIES * PHC_XCH_STRIDE);
+    for (int64_t env = 0; env < sim->num_envs; ++env) {
+        AbaLane L[PHC_MAX_BODIES];
+        for (int j = 0; j < PHC_MAX_BODIES; ++j) L[j].level = -1;
+        for (int j = 0; j < nb; ++j) {
+            aba_load_model(L[j], *model, j);
+            if (do_step && actions && j >= 1) {
+                for (int k = 0; k < 3; ++k) {
+                    const int d = L[j].dof_start + k;
+                    volatile float prod = pd_scale[d] * actions[env * nd + d];
+                    float t = pd_off[d] + prod;
+                    if (freeze && freeze[d]) t = 0.f;
+                    sim->pd_target[env * nd + d] = t;
+                }
+            }
+            aba_load_state(L[j], *sim, nd, env, j);
+        }
+        const int ml = model->max_level;
+        if (do_step) {
+            const float dt = prm->sim_dt / (float)prm->substeps;
+            const int nsub = num_sim_calls * prm->substeps;
+            for (int s = 0; s < nsub; ++s) {
+                for (int l = 0; l <= ml; ++l) for (int j = 0; j < nb; ++j) aba_fk_level(L[j], l, j, xch.data());
+                for (int j = 0; j < nb; ++j) aba_body_init(L[j], *model, *prm, dt);
+                for (int l = ml; l >= 0; --l) for (int j = 0; j < nb; ++j) aba_backward_level(L[j], l, j, xch.data());
+                for (int l = 0; l <= ml; ++l) for (int j = 0; j < nb; ++j) aba_forward_level(L[j], l, j, xch.data());
+                for (int j = 0; j < nb; ++j) aba_integrate(L[j], *prm, dt);
+            }
+        }
+        for (int l = 0; l <= ml; ++l) for (int j = 0; j < nb; ++j) aba_fk_level(L[j], l, j, xch.data());
+        for (int j = 0; j < nb; ++j) {
+            if (do_step) aba_store_state(L[j], *sim, nd, env, j);
+            aba_publish_body(L[j], *sim, nb, env, j, do_step != 0);
+        }
+    }
+    return 0;
+}
+
+}  // extern "C"
