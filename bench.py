@@ -1,0 +1,207 @@
+#!/usr/bin/env python
+"""bench.py -- the path's headline metric (BASELINE.json): env-steps/sec at 4096 humanoid envs per GPU.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" is one pass of the hot path over one batch of synthetic input: `VecEnv.step()` for 4096 SMPL-humanoid envs
+(BASELINE.json configs[1]: 69 DoF, 4096 envs, single reference motion) = action -> PD targets -> 4 ABA sub-steps with
+contact -> body-state publication -> reference-motion lookup -> imitation reward -> reset test -> observations -> AMP
+observation, plus the reset of the envs that finished on the previous step (rollout idiom).
+Inputs (motion buffer, state, the fixed random action tensor) are resident in HBM before the timed region.
+
+Envs shard trivially: every rank owns 4096 envs and its own motion-library shard; the env step has
+no data-path collective, so scaling is weak and `value` = sum over ranks of env-steps / max-over-ranks time.
+The one collective of the path (gradient all-reduce per optimizer step) belongs to the PPO update and is timed by
+`--ppo-epochs` (reported as `ppo_samples_per_s` in the same JSON line).
+
+One JSON line is printed by rank 0, with the `roofline` object of the dominant kernel (k_sim_step, timed live with
+HIP events on the launch stream) and the `cpu_baseline` object (CPU port of the same path on the host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")  # cpu_baseline leg: no spinning OpenMP workers next to the GPU driver threads
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (6.3 TB/s achievable)
+# SURVEY.md 8(d) algorithmic bytes per env-step of the stepper launch (SMPL, J=24, D=69, fp32):
+#   ABA sweep 1484 B / env-sub-step x 4 sub-steps (canonical un-fused accounting) + 1812 B state publication
+ABA_BYTES_PER_ENV_SUBSTEP = 1484
+PUBLISH_BYTES_PER_ENV_STEP = 1812
+FLOPS_PER_ENV_SUBSTEP = 40e3   # SURVEY.md 8(d) "algorithmic flops (secondary)"
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--envs", type=int, default=4096, help="envs per GPU (BASELINE configs[1]: 4096)")
+    ap.add_argument("--ppo-epochs", type=int, default=1, help="timed PPO epochs (rollout 32 steps + 36 optimizer steps); 0 = skip")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(num_envs=512, steps=6):
+    """CPU port of the same path on the host cores: oracle/hostemu = the kernels' per-lane functions compiled with
+    g++ -O2 -fopenmp, one env per OpenMP iteration.  (The reference has no CPU dynamics at all -- Isaac Gym is a GPU
+    binary -- and its reward/obs path is Python/torch; this port is the builder's CPU restatement)"""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import hostemu_util as hu
+    from hostemu_util import P, emu
+    from phc_amd import abi
+    from phc_amd.motion_lib import process_clip
+    from phc_amd.utils.synthetic_motion import make_motion_dict
+    F = np.float32
+    model, mstruct, keep = hu.np_model()
+    nb, nd = model.num_bodies, model.num_dof
+    clip = list(make_motion_dict(model.parent, 1, seed=0, body_names=model.body_names).values())[0]
+    proc = process_clip(model.parent, model.local_translation, clip["pose_quat_global"], clip["root_trans_offset"], 30)
+    T = proc["gts"].shape[0]
+    lib = {k: proc[k].astype(F) for k in ("gts", "grs", "gvs", "gavs", "lrs", "dvs")}
+    lib.update(motion_lengths=np.full(num_envs, (T - 1) / 30, F), motion_dt=np.full(num_envs, 1 / 30, F),
+               motion_num_frames=np.full(num_envs, T, np.int64), length_starts=np.zeros(num_envs, np.int64))
+    lstruct, lkeep = hu.np_motion_lib(lib)
+    tabs = abi.task_index_tables(model, model.body_names, [b for b in model.body_names if "Toe" not in b and "Ankle" not in b],
+                                 ["R_Ankle", "L_Ankle", "R_Wrist", "L_Wrist"])
+    td = np.full(32, 0.25, F)
+    prm = abi.im_params_struct(dt=1 / 30, max_episode_length=300, reward_specs=dict(k_pos=100, k_rot=10, k_vel=0.1, k_ang_vel=0.1, w_pos=0.5,
+                               w_rot=0.3, w_vel=0.1, w_ang_vel=0.1), power_reward=True, power_coefficient=0.0005, enable_early_termination=True,
+                               use_mean_termination=False, disable_collision_check=False, local_root_obs=True, root_height_obs=True,
+                               num_track_bodies=nb, track_slot=tabs[0], reset_mask=tabs[1], num_reset_bodies=20, first_reset_body=0,
+                               termination_distances=td, num_key_bodies=4, key_body_ids=tabs[2], num_amp_joints=tabs[4], amp_joint_slot=tabs[3],
+                               num_amp_obs_steps=10, num_amp_obs_per_step=196, num_self_obs=358, num_task_obs=576)
+    N = num_envs
+    a = dict(root=np.zeros((N, 13), F), dof=np.zeros((N, nd, 2), F), rbs=np.zeros((N, nb, 13), F), cf=np.zeros((N, nb, 3), F),
+             df=np.zeros((N, nd), F), pd=np.zeros((N, nd), F))
+    sim = abi.sim_state_struct(N, a["root"], a["dof"], a["rbs"], a["cf"], a["df"], a["pd"])
+    amp = [np.zeros((N, 10, 196), F), np.zeros((N, 10, 196), F)]
+    b = dict(progress=np.zeros(N, np.int64), reset=np.ones(N, np.int64), term=np.zeros(N, np.int64), rew=np.zeros(N, F), raw=np.zeros((N, 5), F),
+             obs=np.zeros((N, 934), F), mids=np.arange(N, dtype=np.int64), st=np.zeros(N, F), so=np.zeros(N, F), goff=np.zeros((N, 3), F))
+    params = abi.sim_params_struct()
+    rng = np.random.default_rng(0)
+    actions = ((rng.random((N, nd)) * 2 - 1) * 0.1).astype(F)
+    off, scale = model.pd_action_offset_scale()
+    e = emu()
+
+    def one(cur):
+        buf_r = abi.im_buffers_struct(b["progress"], b["reset"], b["term"], b["rew"], b["raw"], b["obs"], amp[cur], amp[cur], b["mids"], b["st"], b["so"], b["goff"])
+        phase = rng.random(N).astype(F)
+        e.emu_im_reset(P(mstruct), P(lstruct), P(prm), P(sim), P(buf_r), N, None, abi.ptr(phase), 0)
+        e.emu_sim_step(P(mstruct), P(params), P(sim), abi.ptr(actions), abi.ptr(off), abi.ptr(scale), None, 2, 1)
+        buf = abi.im_buffers_struct(b["progress"], b["reset"], b["term"], b["rew"], b["raw"], b["obs"], amp[cur], amp[1 - cur], b["mids"], b["st"], b["so"], b["goff"])
+        e.emu_im_post_physics(P(mstruct), P(lstruct), P(prm), P(sim), P(buf))
+        return 1 - cur
+
+    cur = one(0)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        cur = one(cur)
+    dt = time.perf_counter() - t0
+    cores = os.cpu_count() or 1
+    return {"value": N * steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} steps x {N} envs (reset+stepper+post-physics), g++ -O2 -fopenmp build of the kernels' per-lane code, "
+                      f"{dt:.1f} s on {cores} host threads"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from phc_amd.config import compose
+    from phc_amd.env.tasks.vec_task import parse_task
+    torch.manual_seed(rank)  # per-rank seed offset, as the reference's horovod path does (run_hydra.py:121)
+    cfg = compose([f"env.num_envs={args.envs}", "env.motion_file=synthetic:1:0", f"device_id={local_rank}", f"rl_device=cuda:{local_rank}"])
+    task, env = parse_task(cfg, device_id=local_rank)
+    dev = task.device
+    N = task.num_envs
+    env.reset()
+    actions = (torch.rand(N, task.num_actions, device=dev) * 2 - 1) * 0.1  # fixed a ~ U(-1,1)*0.1
+
+    def env_step(ev=None):
+        task.reset_done()                 # envs that finished on the previous step (device-side mask, no host sync)
+        task.pre_physics_step(actions)
+        if ev is not None:
+            ev[0].record()
+        task._physics_step()
+        if ev is not None:
+            ev[1].record()
+        task.post_physics_step()
+
+    for _ in range(args.warmup):
+        env_step()
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        env_step(events[k])
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))  # torch's current stream == the launch stream
+    resets = float((task.progress_buf < 5).float().mean().item())
+
+    ppo = None
+    if args.ppo_epochs > 0:
+        try:
+            from phc_amd.learning.bench_ppo import time_ppo_epochs
+            ppo = time_ppo_epochs(task, env, cfg, args.ppo_epochs, dist)
+        except ImportError:
+            ppo = None
+
+    if rank == 0:
+        nsub = task.control_freq_inv * int(cfg.sim.substeps)
+        bytes_per_launch = (ABA_BYTES_PER_ENV_SUBSTEP * nsub + PUBLISH_BYTES_PER_ENV_STEP) * N
+        achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
+        out = {
+            "metric": "env-steps/sec at 4096 humanoid envs per GPU (VecEnv.step incl. resets)",
+            "value": N * world * args.steps / elapsed, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic (AMASS-shaped smooth random clip, seed 0; random-init state from the reference motion)",
+            "config": {"workload": "BASELINE configs[1]: SMPL humanoid 69-DoF, 4096 envs per GPU, single reference motion, "
+                                   "30 Hz control = 2 x simulate @60 Hz x 2 sub-steps", "envs_per_gpu": N, "num_bodies": task.num_bodies,
+                       "obs": task.num_obs, "amp_obs": task.get_num_amp_obs(), "parallelism": f"env-sharded x{world}"},
+            "roofline": {"kernel": "k_sim_step<true> (A2 + 4 ABA sub-steps + S7 publication)", "bound": "hbm", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "note": "latency/ALU-bound tree sweep: SURVEY 8(d) canonical un-fused accounting (1484 B x 4 sub-steps + 1812 B "
+                                 "per env); the fused launch's compulsory traffic is 3296 B/env",
+                         "gflops": FLOPS_PER_ENV_SUBSTEP * nsub * N / (kern_ms * 1e-3) / 1e9},
+        }
+        if ppo is not None:
+            out.update(ppo)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        out["episode_restart_fraction"] = resets
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -102,7 +102,8 @@ typedef struct {
     const int32_t* track_slot;        /* [NB] slot of body in trackBodies or -1 */
     const int32_t* reset_mask;        /* [NB] 1 if body in reset_bodies */
     int32_t num_reset_bodies;         /* len(reset_bodies) */
-    const float* termination_distances; /* [N,NB] (humanoid_im.py:1183-1185) */
+    int32_t first_reset_body;         /* body id of reset_bodies[0]: `termination_distance[0]` of the mean variant (:1586) */
+    const float* termination_distances; /* [NB] per body (humanoid_im.py:539-543), live-editable by the learner (im_amp.py:174) */
     int32_t num_key_bodies;
     const int32_t* key_body_ids;      /* [K] */
     int32_t num_amp_joints;           /* joints in dof_subset (19 for SMPL) */
@@ -169,7 +170,9 @@ int32_t phc_im_post_physics(const phc_model_t* model, const phc_motion_lib_t* li
 /* Humanoid.reset(env_ids) -> _reset_envs (humanoid.py:585-621, humanoid_amp.py:378-398,508-528,559-637,
  * humanoid_im.py:955-1023): per listed env sample a start time from `phase`, impose the reference
  * state on root/dof/body tensors and PD targets, zero progress/reset/terminate/contact, recompute
- * obs for those envs, and rebuild their AMP history from the reference motion. */
+ * obs for those envs, and rebuild their AMP history from the reference motion.
+ * env_ids == NULL selects the MASKED mode: num_reset must be num_envs, phase is [num_envs], and exactly the envs
+ * with reset_buf != 0 are reset (lets a rollout loop reset done envs without a device->host sync). */
 int32_t phc_im_reset(const phc_model_t* model, const phc_motion_lib_t* lib, const phc_im_params_t* prm,
                      const phc_sim_state_t* sim, const phc_im_buffers_t* buf, int32_t num_reset,
                      const int64_t* env_ids, const float* phase /*[num_reset]*/, int32_t start_at_zero, void* stream);

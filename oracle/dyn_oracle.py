@@ -1,0 +1,262 @@
+"""TEST INFRASTRUCTURE ONLY -- fp64 oracle for the articulated-body stepper (S10).
+
+There is no reference implementation of the dynamics (Isaac Gym / PhysX is a closed binary,
+SURVEY.md section 8c): parity for this part of the path is *unpinned* at the PhysX level.  This
+oracle pins the HIP kernel's arithmetic instead, with a formulation that shares nothing with the
+kernel's articulated-body recursion:
+
+    generalized coordinates  nu = [w0 (world), v0 (world, root origin), wJ_1 .. wJ_{NB-1} (child frames)]
+    M(q) nu_dot + h(q, nu) = tau        with M = sum_i J_i^T M_i J_i built from body Jacobians,
+    dense Cholesky-free solve (numpy.linalg.solve) in float64,
+
+plus the same linearly-implicit treatment of the PD drive and of the penalty ground contact
+(diag / J^T C J augmentations of M).  Featherstone's ABA must give the same accelerations as the
+dense solve -- that is the check (tests/test_dynamics.py), together with physical invariants.
+
+Only tests and bench.py's cpu_baseline leg import this file.
+"""
+import numpy as np
+
+
+def skew(a):
+    return np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]], dtype=np.float64)
+
+
+def quat_to_mat(q):
+    x, y, z, w = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]], dtype=np.float64)
+
+
+def quat_mul(a, b):
+    ax, ay, az, aw = a
+    bx, by, bz, bw = b
+    return np.array([aw * bx + ax * bw + ay * bz - az * by, aw * by + ay * bw + az * bx - ax * bz,
+                     aw * bz + az * bw + ax * by - ay * bx, aw * bw - ax * bx - ay * by - az * bz])
+
+
+def quat_conj(q):
+    return np.array([-q[0], -q[1], -q[2], q[3]])
+
+
+def quat_from_rotvec(e):
+    a = np.linalg.norm(e)
+    if a < 1e-12:
+        return np.array([0.5 * e[0], 0.5 * e[1], 0.5 * e[2], 1.0])
+    return np.concatenate([e / a * np.sin(0.5 * a), [np.cos(0.5 * a)]])
+
+
+def quat_to_rotvec(q):
+    if q[3] < 0:
+        q = -q
+    s = np.linalg.norm(q[:3])
+    if s < 1e-12:
+        return 2.0 * q[:3]
+    return q[:3] * (2.0 * np.arctan2(s, q[3]) / s)
+
+
+class State:
+    """Per-env state in the simulator's tensor layout (S1 root_states [13], S2 dof_state [D,2])."""
+
+    def __init__(self, root_states, dof_state):
+        r = np.asarray(root_states, dtype=np.float64)
+        d = np.asarray(dof_state, dtype=np.float64)
+        self.p0 = r[0:3].copy()
+        self.q0 = r[3:7] / np.linalg.norm(r[3:7])
+        self.v0 = r[7:10].copy()
+        self.w0 = r[10:13].copy()
+        nj = d.shape[0] // 3
+        self.q = np.array([quat_from_rotvec(d[3 * j:3 * j + 3, 0]) for j in range(nj)])
+        self.wj = d[:, 1].reshape(nj, 3).copy()
+
+    def root_states(self):
+        return np.concatenate([self.p0, self.q0, self.v0, self.w0])
+
+    def dof_state(self):
+        pos = np.concatenate([quat_to_rotvec(q) for q in self.q])
+        return np.stack([pos, self.wj.reshape(-1)], axis=-1)
+
+
+DEFAULT_PARAMS = dict(gravity_z=-9.81, contact_stiffness=1.0e5, contact_damping=1.0e3, friction=1.0, friction_viscous=2.0e3,
+                      angular_damping=0.01, max_angular_velocity=100.0)
+
+
+def kinematics(model, st):
+    nb = model.num_bodies
+    R = [None] * nb
+    Q = [None] * nb
+    p = np.zeros((nb, 3))
+    for i in range(nb):
+        par = model.parent[i]
+        if par < 0:
+            Q[i] = st.q0
+            p[i] = st.p0
+        else:
+            Q[i] = quat_mul(Q[par], st.q[i - 1])
+            Q[i] = Q[i] / np.linalg.norm(Q[i])
+            p[i] = p[par] + R[par] @ model.local_translation[i].astype(np.float64)
+        R[i] = quat_to_mat(Q[i])
+    return Q, R, p
+
+
+def body_velocities(model, st, R, p):
+    nb = model.num_bodies
+    w = np.zeros((nb, 3))
+    v = np.zeros((nb, 3))
+    for i in range(nb):
+        par = model.parent[i]
+        if par < 0:
+            w[i], v[i] = st.w0, st.v0
+        else:
+            w[i] = w[par] + R[i] @ st.wj[i - 1]
+            v[i] = v[par] + np.cross(w[par], p[i] - p[par])
+    return w, v
+
+
+def accelerations(model, st, target, params, dt, kp_scale=1.0, kd_scale=1.0, return_parts=False):
+    """Generalized accelerations nu_dot = [alpha0, a0, wJdot_1..] of one implicit sub-step."""
+    prm = dict(DEFAULT_PARAMS, **(params or {}))
+    nb = model.num_bodies
+    nv = 6 + 3 * (nb - 1)
+    Q, R, p = kinematics(model, st)
+    w, v = body_velocities(model, st, R, p)
+    nu = np.concatenate([st.w0, st.v0, st.wj.reshape(-1)])
+    Jw = np.zeros((nb, 3, nv))
+    Jv = np.zeros((nb, 3, nv))
+    for i in range(nb):
+        Jw[i][:, 0:3] = np.eye(3)
+        Jv[i][:, 3:6] = np.eye(3)
+        Jv[i][:, 0:3] = -skew(p[i] - p[0])
+        k = i
+        while k > 0:
+            c = slice(6 + 3 * (k - 1), 6 + 3 * k)
+            Jw[i][:, c] = R[k]
+            Jv[i][:, c] = -skew(p[i] - p[k]) @ R[k]
+            k = model.parent[k]
+        assert np.allclose(Jw[i] @ nu, w[i]) and np.allclose(Jv[i] @ nu, v[i])
+    # bias accelerations (nu_dot = 0)
+    ab_w = np.zeros((nb, 3))
+    ab_v = np.zeros((nb, 3))
+    for i in range(1, nb):
+        par = model.parent[i]
+        r = p[i] - p[par]
+        ab_w[i] = ab_w[par] + np.cross(w[par], R[i] @ st.wj[i - 1])
+        ab_v[i] = ab_v[par] + np.cross(ab_w[par], r) + np.cross(w[par], np.cross(w[par], r))
+    M = np.zeros((nv, nv))
+    rhs = np.zeros(nv)
+    g = np.array([0.0, 0.0, prm["gravity_z"]])
+    cn = prm["contact_stiffness"] * dt + prm["contact_damping"]
+    fcontact = np.zeros((nb, 3))
+    for i in range(nb):
+        Io = R[i] @ model.inertia_origin[i] @ R[i].T
+        mc = R[i] @ (model.mass[i] * model.com[i])
+        Mi = np.zeros((6, 6))
+        Mi[:3, :3] = Io
+        Mi[:3, 3:] = skew(mc)
+        Mi[3:, :3] = -skew(mc)
+        Mi[3:, 3:] = model.mass[i] * np.eye(3)
+        J = np.concatenate([Jw[i], Jv[i]], axis=0)
+        bias = np.concatenate([np.cross(w[i], Io @ w[i]), np.cross(w[i], np.cross(w[i], mc))])
+        ext = np.concatenate([np.cross(mc, g), model.mass[i] * g])
+        M += J.T @ Mi @ J
+        rhs -= J.T @ (Mi @ np.concatenate([ab_w[i], ab_v[i]]) + bias - ext)
+        for k in np.nonzero(model.contact_body == i)[0]:
+            arm = R[i] @ model.contact_pos[k]
+            rad = model.contact_radius[k]
+            depth = rad - (p[i][2] + arm[2])
+            if depth <= 0:
+                continue
+            arm = arm - np.array([0, 0, rad])
+            uc = v[i] + np.cross(w[i], arm)
+            fn0 = prm["contact_stiffness"] * depth - cn * uc[2]
+            if fn0 <= 0:
+                continue
+            ut = np.hypot(uc[0], uc[1])
+            ct = min(prm["friction_viscous"], prm["friction"] * fn0 / (ut + 1e-6))
+            Cm = np.diag([ct, ct, cn])
+            F0 = np.array([-ct * uc[0], -ct * uc[1], fn0])
+            fcontact[i] += F0 - dt * Cm @ np.cross(w[i], np.cross(w[i], arm))
+            apb = ab_v[i] + np.cross(ab_w[i], arm) + np.cross(w[i], np.cross(w[i], arm))
+            Jpt = Jv[i] - skew(arm) @ Jw[i]
+            M += dt * Jpt.T @ Cm @ Jpt
+            rhs += Jpt.T @ (F0 - dt * Cm @ apb)
+    tau_all = np.zeros((nb, 3))
+    dimp_all = np.zeros((nb, 3))
+    for i in range(1, nb):
+        s = model.dof_start[i]
+        kp = model.dof_kp[s:s + 3] * kp_scale
+        kd = model.dof_kd[s:s + 3] * kd_scale
+        arm_ = model.dof_armature[s:s + 3]
+        eff = model.dof_effort[s:s + 3]
+        qt = quat_from_rotvec(np.asarray(target[s:s + 3], dtype=np.float64))
+        err = quat_to_rotvec(quat_mul(quat_conj(st.q[i - 1]), qt))
+        tau = kp * err - (kd + dt * kp) * st.wj[i - 1]
+        d = arm_ + dt * kd + dt * dt * kp
+        sat = np.abs(tau) > eff
+        tau = np.where(sat, np.sign(tau) * eff, tau)
+        d = np.where(sat, arm_, d)
+        c = slice(6 + 3 * (i - 1), 6 + 3 * i)
+        M[c, c] += np.diag(d)
+        rhs[c] += tau
+        tau_all[i], dimp_all[i] = tau, d
+    nud = np.linalg.solve(M, rhs)
+    if return_parts:
+        return nud, dict(M=M, rhs=rhs, R=R, p=p, w=w, v=v, Q=Q, tau=tau_all, dimp=dimp_all, fcontact=fcontact)
+    return nud
+
+
+def substep(model, st, target, params, dt, kp_scale=1.0, kd_scale=1.0):
+    """One linearly-implicit sub-step; returns the applied joint torques (S5)."""
+    prm = dict(DEFAULT_PARAMS, **(params or {}))
+    nud, parts = accelerations(model, st, target, prm, dt, kp_scale, kd_scale, return_parts=True)
+    damp = 1.0 / (1.0 + dt * prm["angular_damping"])
+    st.w0 = (st.w0 + dt * nud[0:3]) * damp
+    st.v0 = st.v0 + dt * nud[3:6]
+    st.p0 = st.p0 + dt * st.v0
+    q = quat_mul(quat_from_rotvec(st.w0 * dt), st.q0)
+    st.q0 = q / np.linalg.norm(q)
+    nb = model.num_bodies
+    tau_applied = np.zeros((nb - 1, 3))
+    for i in range(1, nb):
+        qdd = nud[6 + 3 * (i - 1):6 + 3 * i]
+        s = model.dof_start[i]
+        tau_applied[i - 1] = parts["tau"][i] - (parts["dimp"][i] - model.dof_armature[s:s + 3]) * qdd
+        wj = (st.wj[i - 1] + dt * qdd) * damp
+        n = np.linalg.norm(wj)
+        if n > prm["max_angular_velocity"]:
+            wj = wj * (prm["max_angular_velocity"] / n)
+        st.wj[i - 1] = wj
+        q = quat_mul(st.q[i - 1], quat_from_rotvec(wj * dt))
+        st.q[i - 1] = q / np.linalg.norm(q)
+    return tau_applied.reshape(-1), parts["fcontact"]
+
+
+def sim_step(model, root_states, dof_state, pd_target, params=None, sim_dt=1 / 60, substeps=2, num_sim_calls=2,
+             kp_scale=1.0, kd_scale=1.0):
+    """num_sim_calls x gym.simulate, each `substeps` sub-steps of sim_dt/substeps.  Returns new
+    (root_states[13], dof_state[D,2], rigid_body_state[NB,13], dof_force[D], contact_force[NB,3])."""
+    st = State(root_states, dof_state)
+    dt = sim_dt / substeps
+    tau = np.zeros(model.num_dof)
+    fc = np.zeros((model.num_bodies, 3))
+    for _ in range(num_sim_calls * substeps):
+        tau, fc = substep(model, st, pd_target, params, dt, kp_scale, kd_scale)
+    Q, R, p = kinematics(model, st)
+    w, v = body_velocities(model, st, R, p)
+    rbs = np.concatenate([p, np.array(Q), v, w], axis=-1)
+    return st.root_states(), st.dof_state(), rbs, tau, fc
+
+
+def energy(model, st, gravity_z=-9.81):
+    """Total mechanical energy (kinetic + gravitational), armature excluded -- for the invariants tests."""
+    Q, R, p = kinematics(model, st)
+    w, v = body_velocities(model, st, R, p)
+    E = 0.0
+    for i in range(model.num_bodies):
+        Io = R[i] @ model.inertia_origin[i] @ R[i].T
+        mc = R[i] @ (model.mass[i] * model.com[i])
+        E += 0.5 * w[i] @ Io @ w[i] + 0.5 * model.mass[i] * v[i] @ v[i] + v[i] @ np.cross(w[i], mc)
+        com_z = p[i][2] + (R[i] @ model.com[i])[2]
+        E -= model.mass[i] * gravity_z * com_z
+    return E

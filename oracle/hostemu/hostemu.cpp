@@ -1,4 +1,4 @@
-// hostemu.cpp -- TEST INFRASTRUCTURE ONLY.
+// hostemu.cpp -- TEST INFRASTRUCTURE ONLY (lives under oracle/: only tests and bench.py's cpu_baseline leg use it).
 // Compiles the *same* per-lane functions the HIP kernels are made of (phc_amd/csrc/*.h are
 // host+device) with g++ and drives them lane by lane on the CPU, so that the kernel math can be
 // checked against the oracle on a machine without a GPU (`pytest -m "not gpu"`).
@@ -46,6 +46,7 @@ int emu_sample_time_interval(const phc_motion_lib_t* lib, int n, const int64_t* 
 
 int emu_im_post_physics(const phc_model_t* model, const phc_motion_lib_t* lib, const phc_im_params_t* prm,
                         const phc_sim_state_t* sim, const phc_im_buffers_t* buf) {
+#pragma omp parallel for schedule(static)
     for (int64_t env = 0; env < sim->num_envs; ++env) {
         const int64_t progress = buf->progress_buf[env] + 1;
         for (int lane = 0; lane < 32; ++lane) amp_shift_lane(*prm, *buf, env, lane);
@@ -65,7 +66,8 @@ int emu_im_post_physics(const phc_model_t* model, const phc_motion_lib_t* lib, c
 int emu_im_reset(const phc_model_t* model, const phc_motion_lib_t* lib, const phc_im_params_t* prm, const phc_sim_state_t* sim,
                  const phc_im_buffers_t* buf, int num_reset, const int64_t* env_ids, const float* phase, int start_at_zero) {
     for (int r = 0; r < num_reset; ++r) {
-        const int64_t env = env_ids[r];
+        const int64_t env = env_ids ? env_ids[r] : r;
+        if (!env_ids && buf->reset_buf[env] == 0) continue;
         const int64_t mid = buf->sampled_motion_ids[env];
         const float t = start_at_zero ? 0.f : sample_time_interval(*lib, mid, phase[r]);
         for (int lane = 31; lane >= 0; --lane) im_reset_lane(*model, *lib, *prm, *sim, *buf, env, lane, t);
@@ -89,8 +91,9 @@ int emu_amp_obs_demo(const phc_model_t* model, const phc_motion_lib_t* lib, cons
 int emu_sim_step(const phc_model_t* model, const phc_sim_params_t* prm, const phc_sim_state_t* sim, const float* actions,
                  const float* pd_off, const float* pd_scale, const int32_t* freeze, int num_sim_calls, int do_step) {
     const int nb = model->num_bodies, nd = model->num_dof;
-    std::vector<float> xch(PHC_MAX_BODIES * PHC_XCH_STRIDE);
+#pragma omp parallel for schedule(static)
     for (int64_t env = 0; env < sim->num_envs; ++env) {
+        std::vector<float> xch(PHC_MAX_BODIES * PHC_XCH_STRIDE);
         AbaLane L[PHC_MAX_BODIES];
         for (int j = 0; j < PHC_MAX_BODIES; ++j) L[j].level = -1;
         for (int j = 0; j < nb; ++j) {

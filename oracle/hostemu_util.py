@@ -1,4 +1,6 @@
-"""TEST INFRASTRUCTURE: ctypes access to tests/hostemu (the g++ build of the kernels' per-lane functions)."""
+"""TEST INFRASTRUCTURE ONLY: ctypes access to oracle/hostemu -- the g++ (OpenMP) build of the very per-lane functions the
+HIP kernels are made of (phc_amd/csrc/*.h are host+device).  Used by `pytest -m "not gpu"` to check the kernel math on a
+machine without a GPU, and by bench.py's `cpu_baseline` leg as the CPU port of the path.  The product never loads it."""
 import ctypes as C
 import os
 import subprocess
@@ -11,7 +13,7 @@ from phc_amd.model import load_model
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "hostemu", "hostemu.cpp")
-OUT = os.path.join(HERE, "hostemu", "_build", "libphc_hostemu.so")
+OUT = os.path.join(HERE, "_build", "libphc_hostemu.so")
 CSRC = os.path.join(os.path.dirname(HERE), "phc_amd", "csrc")
 
 
@@ -21,7 +23,7 @@ def build():
     if os.path.exists(OUT) and all(os.path.getmtime(d) <= os.path.getmtime(OUT) for d in deps):
         return OUT
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", SRC, "-o", OUT], check=True)
+    subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fopenmp", "-ffp-contract=off", SRC, "-o", OUT], check=True)
     return OUT
 
 

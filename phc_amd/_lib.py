@@ -44,7 +44,7 @@ class ImParams(C.Structure):
                 ("power_reward", c_i32), ("power_coefficient", c_f),
                 ("enable_early_termination", c_i32), ("use_mean_termination", c_i32), ("disable_collision_check", c_i32),
                 ("local_root_obs", c_i32), ("root_height_obs", c_i32),
-                ("num_track_bodies", c_i32), ("track_slot", c_p), ("reset_mask", c_p), ("num_reset_bodies", c_i32),
+                ("num_track_bodies", c_i32), ("track_slot", c_p), ("reset_mask", c_p), ("num_reset_bodies", c_i32), ("first_reset_body", c_i32),
                 ("termination_distances", c_p),
                 ("num_key_bodies", c_i32), ("key_body_ids", c_p),
                 ("num_amp_joints", c_i32), ("amp_joint_slot", c_p),

@@ -1,6 +1,6 @@
 """Helpers that fill the C-ABI structs of include/phc_amd.h from array objects.
 
-Works for torch tensors (product: device pointers) and for numpy arrays (tests/hostemu: host
+Works for torch tensors (product: device pointers) and for numpy arrays (oracle/hostemu: host
 pointers) -- the structs only carry raw addresses and sizes.
 """
 import ctypes as C
@@ -83,7 +83,7 @@ def pack_frames(gts, grs, gvs, gavs, lrs, dvs, xp=np):
 
 def im_params_struct(dt, max_episode_length, reward_specs, power_reward, power_coefficient, enable_early_termination,
                      use_mean_termination, disable_collision_check, local_root_obs, root_height_obs, num_track_bodies,
-                     track_slot, reset_mask, num_reset_bodies, termination_distances, num_key_bodies, key_body_ids,
+                     track_slot, reset_mask, num_reset_bodies, first_reset_body, termination_distances, num_key_bodies, key_body_ids,
                      num_amp_joints, amp_joint_slot, num_amp_obs_steps, num_amp_obs_per_step, num_self_obs, num_task_obs):
     p = L.ImParams()
     p.dt = float(np.float32(dt))
@@ -97,6 +97,7 @@ def im_params_struct(dt, max_episode_length, reward_specs, power_reward, power_c
     p.local_root_obs, p.root_height_obs = int(bool(local_root_obs)), int(bool(root_height_obs))
     p.num_track_bodies, p.track_slot = int(num_track_bodies), ptr(track_slot)
     p.reset_mask, p.num_reset_bodies = ptr(reset_mask), int(num_reset_bodies)
+    p.first_reset_body = int(first_reset_body)
     p.termination_distances = ptr(termination_distances)
     p.num_key_bodies, p.key_body_ids = int(num_key_bodies), ptr(key_body_ids)
     p.num_amp_joints, p.amp_joint_slot = int(num_amp_joints), ptr(amp_joint_slot)

@@ -1,0 +1,105 @@
+"""Built-in configuration groups for the hot path, keyed like the reference's hydra tree
+(`phc/data/cfg/{config,env/*,robot/*,learning/*,sim/*,control/*,domain_rand/*}.yaml`).
+
+Users of the reference keep using THEIR yaml tree unchanged: `compose(..., cfg_dir="<PHC>/phc/data/cfg")`
+(or `PHC_CFG_DIR`).  These built-ins exist so that the package runs where that tree is absent (the
+GPU box, CI); `tests/test_config.py` checks them key-by-key against the reference's yamls when the
+reference checkout is present.  Only the groups of the imitation path are provided.
+"""
+import copy
+
+_SMPL_RESET_BODIES = ['Pelvis', 'L_Hip', 'L_Knee', 'R_Hip', 'R_Knee', 'Torso', 'Spine', 'Chest', 'Neck', 'Head', 'L_Thorax',
+                      'L_Shoulder', 'L_Elbow', 'L_Wrist', 'L_Hand', 'R_Thorax', 'R_Shoulder', 'R_Elbow', 'R_Wrist', 'R_Hand']
+
+ROOT = {  # config.yaml
+    "project_name": "PHC", "notes": "Default Notes", "exp_name": "humanoid_smpl", "headless": True, "seed": 0, "no_log": False,
+    "resume_str": None, "num_threads": 64, "test": False, "dataset": False, "mlp": False,
+    "output_path": "output/HumanoidIm/${exp_name}", "torch_deterministic": False, "epoch": 0, "im_eval": False, "horovod": False,
+    "rl_device": "cuda:0", "device": "cuda", "device_id": 0, "metadata": False, "play": "${test}", "train": True,
+    "collect_dataset": False, "disable_multiprocessing": True, "server_mode": False, "has_eval": True, "no_virtual_display": True,
+    "render_o3d": False, "debug": False, "follow": False, "add_proj": False, "real_traj": False,
+}
+DEFAULTS = {"env": "env_im", "robot": "smpl_humanoid", "learning": "im", "sim": "default_sim", "control": "default_control",
+            "domain_rand": "default_dr"}
+
+_ENV_IM = {  # env/env_im.yaml
+    "task": "HumanoidIm", "project_name": "PHC", "notes": "", "motion_file": "", "num_envs": 3072, "env_spacing": 5,
+    "episode_length": 300, "is_flag_run": False, "enable_debug_vis": False, "fut_tracks": False, "self_obs_v": 1, "obs_v": 6,
+    "auto_pmcp": False, "auto_pmcp_soft": True, "cycle_motion": False, "hard_negative": False, "min_length": 5, "kp_scale": 1,
+    "power_reward": True, "shape_resampling_interval": 500, "control_mode": "isaac_pd", "power_scale": 1.0,
+    "controlFrequencyInv": 2, "stateInit": "Random", "hybridInitProb": 0.5, "numAMPObsSteps": 10, "local_root_obs": True,
+    "root_height_obs": True, "key_bodies": ["R_Ankle", "L_Ankle", "R_Wrist", "L_Wrist"],
+    "contact_bodies": ["R_Ankle", "L_Ankle", "R_Toe", "L_Toe"], "reset_bodies": _SMPL_RESET_BODIES, "terminationHeight": 0.15,
+    "enableEarlyTermination": True, "terminationDistance": 0.25, "numTrajSamples": 3, "trajSampleTimestepInv": 3,
+    "enableTaskObs": True, "plane": {"staticFriction": 1.0, "dynamicFriction": 1.0, "restitution": 0.0},
+}
+_ENV_IM_PNN = dict(_ENV_IM, notes=" ", has_pnn=True, fitting=False, num_prim=3, training_prim=0, actors_to_load=0,
+                   has_lateral=False, models=[], zero_out_far=False, zero_out_far_train=False, getup_udpate_epoch=78750)
+
+_ROBOT_SMPL = {  # robot/smpl_humanoid.yaml
+    "humanoid_type": "smpl", "bias_offset": False, "has_self_collision": True, "has_mesh": False, "has_jt_limit": False,
+    "has_dof_subset": True, "has_upright_start": True, "has_smpl_pd_offset": False, "remove_toe": False, "motion_sym_loss": False,
+    "sym_loss_coef": 1, "big_ankle": True, "has_shape_obs": False, "has_shape_obs_disc": False, "has_shape_variation": False,
+    "masterfoot": False, "freeze_toe": False, "freeze_hand": False, "box_body": True, "real_weight": True,
+    "real_weight_porpotion_capsules": True, "real_weight_porpotion_boxes": True,
+    "asset": {"assetRoot": "/", "assetFileName": "mjcf/smpl_humanoid.xml"},
+}
+
+_SIM_DEFAULT = {  # sim/default_sim.yaml
+    "sim_device": "cuda:0", "pipeline": "gpu", "graphics_device_id": 0, "subscenes": 0, "slices": 0, "use_flex": False, "substeps": 2,
+    "physx": {"step_dt": "1/60", "num_threads": 4, "solver_type": 1, "num_position_iterations": 4, "num_velocity_iterations": 0,
+              "contact_offset": 0.02, "rest_offset": 0.0, "bounce_threshold_velocity": 0.2, "max_depenetration_velocity": 10.0,
+              "default_buffer_size_multiplier": 10.0},
+    "flex": {"num_inner_iterations": 10, "warm_start": 0.25},
+}
+_CONTROL_DEFAULT = {"action_filter": False, "action_scale": 1, "decimation": 2, "action_cutfreq": 4.0, "control_mode": "isaac_pd"}
+_DR_DEFAULT = {"has_domain_rand": False, "push_robots": False, "randomize_friction": False, "randomize_base_mass": False,
+               "randomize_base_com": False, "randomize_link_mass": False, "randomize_pd_gain": False, "randomize_torque_rfi": False,
+               "randomize_ctrl_delay": False, "add_noise": False}
+
+
+def _learning(units, activation, net_name="amp", extra_cfg=None):
+    cfg = {  # learning/im.yaml `params.config`
+        "name": "Humanoid", "env_name": "rlgpu", "multi_gpu": False, "ppo": True, "mixed_precision": False, "normalize_input": True,
+        "normalize_value": True, "reward_shaper": {"scale_value": 1}, "normalize_advantage": True, "gamma": 0.99, "tau": 0.95,
+        "learning_rate": 2e-5, "lr_schedule": "constant", "score_to_win": 20000, "max_epochs": 10000000, "save_best_after": 100,
+        "save_frequency": 2500, "print_stats": False, "save_intermediate": True, "entropy_coef": 0.0, "truncate_grads": True,
+        "grad_norm": 50.0, "e_clip": 0.2, "horizon_length": 32, "minibatch_size": 16384, "mini_epochs": 6, "critic_coef": 5,
+        "clip_value": False, "bounds_loss_coef": 10, "amp_obs_demo_buffer_size": 200000, "amp_replay_buffer_size": 200000,
+        "amp_replay_keep_prob": 0.01, "amp_batch_size": 512, "amp_minibatch_size": 4096, "disc_coef": 5, "disc_logit_reg": 0.01,
+        "disc_grad_penalty": 5, "disc_reward_scale": 2, "disc_weight_decay": 0.0001, "normalize_amp_input": True,
+        "task_reward_w": 0.5, "disc_reward_w": 0.5, "player": {"games_num": 50000000},
+    }
+    cfg.update(extra_cfg or {})
+    return {"params": {
+        "seed": 0, "algo": {"name": "im_amp"}, "model": {"name": "amp"},
+        "network": {
+            "name": net_name, "separate": True, "discrete": False,
+            "space": {"continuous": {"mu_activation": "None", "sigma_activation": "None", "mu_init": {"name": "default"},
+                                     "sigma_init": {"name": "const_initializer", "val": -2.9}, "fixed_sigma": True, "learn_sigma": False}},
+            "mlp": {"units": list(units), "activation": activation, "d2rl": False, "initializer": {"name": "default"},
+                    "regularizer": {"name": "None"}},
+            "disc": {"units": [1024, 512], "activation": "relu", "initializer": {"name": "default"}},
+        },
+        "load_checkpoint": False, "config": cfg,
+    }}
+
+
+_BIG = [2048, 1536, 1024, 1024, 512, 512]
+GROUPS = {
+    "env": {"env_im": _ENV_IM, "env_im_pnn": _ENV_IM_PNN},
+    "robot": {"smpl_humanoid": _ROBOT_SMPL},
+    "learning": {"im": _learning([1024, 512], "relu"), "im_big": _learning(_BIG, "silu", extra_cfg={"save_frequency": 1500}),
+                 "im_pnn": _learning([1024, 512], "relu", "amp_pnn"),
+                 "im_pnn_big": _learning(_BIG, "silu", "amp_pnn", {"amp_dropout": False, "save_frequency": 1500})},
+    "sim": {"default_sim": _SIM_DEFAULT},
+    "control": {"default_control": _CONTROL_DEFAULT},
+    "domain_rand": {"default_dr": _DR_DEFAULT},
+}
+
+
+def builtin_group(group, name):
+    try:
+        return copy.deepcopy(GROUPS[group][name])
+    except KeyError:
+        raise FileNotFoundError(f"no built-in config '{group}/{name}'; point PHC_CFG_DIR / cfg_dir at the reference's phc/data/cfg tree")

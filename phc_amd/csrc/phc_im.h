@@ -1,5 +1,5 @@
 // phc_im.h -- per-lane bodies of the imitation-task kernels (post-physics step, reset, AMP demo).
-// One lane per rigid body, 32 lanes per environment.  PHC_HD so tests/hostemu can drive the same
+// One lane per rigid body, 32 lanes per environment.  PHC_HD so oracle/hostemu can drive the same
 // code lane-by-lane on the CPU.  Reference call sites are cited at each step.
 #pragma once
 #include "phc_task.h"
@@ -139,11 +139,9 @@ PHC_HD void im_post_finalize(const phc_motion_lib_t& lib, const phc_im_params_t&
     const bool pass_time = t0 >= lib.motion_lengths[mid];
     int fallen = any_fallen;
     if (prm.use_mean_termination) {
-        // torch.norm(...).mean(-1, keepdim) > termination_distance[0]  (row of env 0, any over reset bodies)
+        // torch.norm(...).mean(-1, keepdim=True) > termination_distance[0]  (humanoid_im.py:1586)
         float mean = s_dist / (float)n_reset_bodies;
-        fallen = 0;
-        for (int j = 0; j < nb; ++j)
-            if (prm.reset_mask[j] && mean > prm.termination_distances[j]) fallen = 1;
+        fallen = mean > prm.termination_distances[prm.first_reset_body] ? 1 : 0;
     }
     int64_t terminated = 0;
     if (prm.enable_early_termination) {

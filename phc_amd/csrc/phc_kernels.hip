@@ -101,7 +101,9 @@ __global__ __launch_bounds__(256) void k_im_reset(phc_model_t model, phc_motion_
     const int lane = threadIdx.x & (GRP - 1);
     const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
     if (r >= num_reset) return;
-    const int64_t env = env_ids[r];
+    // env_ids == NULL: masked mode over all envs (reset every env whose reset_buf is set) -- no host sync needed
+    const int64_t env = env_ids ? env_ids[r] : r;
+    if (!env_ids && buf.reset_buf[env] == 0) return;
     const int64_t mid = buf.sampled_motion_ids[env];
     // _sample_ref_state (humanoid_im.py:1000-1023): StateInit.Random -> sample_time_interval; Start / flags.test -> 0
     const float t = start_at_zero ? 0.f : sample_time_interval(lib, mid, phase[r]);

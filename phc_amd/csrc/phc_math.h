@@ -5,7 +5,7 @@
 // Convention: xyzw, w last.  Every function cites the reference lines it follows; operation
 // ORDER is kept the same as the reference so that fp32 results stay within a few ulp of it.
 //
-// The header is PHC_HD (host + device) so that tests/hostemu can compile the very same
+// The header is PHC_HD (host + device) so that oracle/hostemu can compile the very same
 // per-lane math with g++ and check it against the oracle on a machine without a GPU.
 // That host build is test infrastructure only; the product always runs the HIP kernels.
 #pragma once
@@ -17,7 +17,7 @@
 #define PHC_HD __host__ __device__ __forceinline__
 #else
 #define PHC_HD inline
-struct float4 { float x, y, z, w; };  // host build only (tests/hostemu)
+struct float4 { float x, y, z, w; };  // host build only (oracle/hostemu)
 #endif
 
 namespace phc {

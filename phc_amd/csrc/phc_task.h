@@ -4,7 +4,7 @@
 // Mapping: one lane per rigid body, 32 lanes per environment (NB <= 32), two environments per
 // 64-wide wavefront.  Everything a lane needs from "its" body is private; the few per-env
 // quantities (root pose, reward sums, fallen flag) are obtained by broadcast loads and one
-// 32-lane reduction.  All functions are PHC_HD so tests/hostemu can run the same code on CPU.
+// 32-lane reduction.  All functions are PHC_HD so oracle/hostemu can run the same code on CPU.
 #pragma once
 #include "phc_math.h"
 #include "../../include/phc_amd.h"
@@ -191,7 +191,7 @@ PHC_HD RewardPartial reward_partial(const phc_im_params_t& prm, int64_t env, int
     float dist = norm(body.pos - ref.pos);
     int in_reset = prm.reset_mask[j];
     p.dist = in_reset ? dist : 0.f;
-    p.fallen = (in_reset && dist > prm.termination_distances[env * nb + j]) ? 1 : 0;
+    p.fallen = (in_reset && dist > prm.termination_distances[j]) ? 1 : 0;
     return p;
 }
 

@@ -1,0 +1,530 @@
+"""HumanoidIm: host-side mirror of the reference's imitation task, backed by the HIP hot path.
+
+The reference builds this task as the class chain
+`BaseTask -> Humanoid -> HumanoidAMP -> HumanoidAMPTask -> HumanoidIm`
+(phc/env/tasks/{base_task,humanoid,humanoid_amp,humanoid_amp_task,humanoid_im}.py) on top of the
+closed Isaac Gym tensor API.  This class keeps the SAME public surface -- constructor signature,
+buffer names, `step / reset / fetch_amp_obs_demo / resample_motions`, the attributes the learner
+reaches into (`phc/learning/amp_agent.py:54-59,509-519`) -- but one env step is three device
+launches behind the C ABI of include/phc_amd.h:
+
+    pre_physics_step + _physics_step  -> phc_sim_step        (A2, S8, S10, S7)
+    post_physics_step                 -> phc_im_post_physics (R1,R2,R5,R6,R7,R9 + progress_buf)
+    reset(env_ids)                    -> phc_im_reset        (R11)
+
+All simulator tensors keep Isaac Gym's layouts (humanoid.py:201-235), allocated by torch in HBM.
+There is no CPU fallback: constructing the task without a HIP device raises.
+"""
+from collections import OrderedDict
+from enum import Enum
+
+import numpy as np
+import torch
+
+from ... import _lib as L
+from ... import abi
+from ...model import load_model
+from ...motion_lib import FixHeightMode, MotionLibSMPL
+from ...utils.flags import flags
+from ...utils.synthetic_motion import make_motion_dict
+
+SMPL_MUJOCO_NAMES = ['Pelvis', 'L_Hip', 'L_Knee', 'L_Ankle', 'L_Toe', 'R_Hip', 'R_Knee', 'R_Ankle', 'R_Toe', 'Torso', 'Spine',
+                     'Chest', 'Neck', 'Head', 'L_Thorax', 'L_Shoulder', 'L_Elbow', 'L_Wrist', 'L_Hand', 'R_Thorax', 'R_Shoulder',
+                     'R_Elbow', 'R_Wrist', 'R_Hand']
+
+
+class SkeletonTree:
+    """The three fields of poselib's SkeletonTree the path uses (skeleton3d.py:149-193)."""
+
+    def __init__(self, node_names, parent_indices, local_translation):
+        self.node_names = list(node_names)
+        self.parent_indices = torch.as_tensor(np.asarray(parent_indices), dtype=torch.int32)
+        self.local_translation = torch.as_tensor(np.asarray(local_translation), dtype=torch.float32)
+
+    def __len__(self):
+        return len(self.node_names)
+
+    @property
+    def num_joints(self):
+        return len(self.node_names)
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class HumanoidIm:
+
+    class StateInit(Enum):  # humanoid_amp.py:73-78
+        Default = 0
+        Start = 1
+        Random = 2
+        Hybrid = 3
+
+    # ------------------------------------------------------------------ construction
+    def __init__(self, cfg, sim_params=None, physics_engine=None, device_type="cuda", device_id=0, headless=True):
+        self.cfg = cfg
+        self.sim_params = sim_params
+        self.physics_engine = physics_engine
+        self.headless = headless
+        self.device_type, self.device_id = device_type, device_id
+        if device_type not in ("cuda", "GPU"):
+            raise RuntimeError("phc_amd.HumanoidIm runs on the HIP device only (device_type='cuda'); there is no CPU path")
+        if not torch.cuda.is_available():
+            raise RuntimeError("no HIP device visible: phc_amd has no CPU fallback")
+        self.device = f"cuda:{device_id}"
+        self._lib = L.load()  # fails loudly if libphc_amd.so is missing
+        torch.cuda.set_device(device_id)
+        env = cfg["env"]
+        robot = cfg["robot"]
+
+        # ---- load_humanoid_configs (humanoid.py:250-420) ----
+        self.humanoid_type = robot.get("humanoid_type", "smpl")
+        if self.humanoid_type != "smpl":
+            raise NotImplementedError(f"humanoid_type={self.humanoid_type!r}: only the SMPL humanoid is built in this round")
+        unsupported = dict(fut_tracks=False, zero_out_far=False, cycle_motion=False, occl_training=False, res_action=False,
+                           kin_loss=False, z_readout=False, distill=False, has_shape_variation=False)
+        for k, off in unsupported.items():
+            v = env.get(k, robot.get(k, off))
+            if v != off:
+                raise NotImplementedError(f"config option {k}={v!r} is outside the hot path built so far")
+        if env.get("obs_v", 1) != 6 or env.get("self_obs_v", 1) != 1 or env.get("amp_obs_v", 1) != 1:
+            raise NotImplementedError("only obs_v=6 / self_obs_v=1 / amp_obs_v=1 (the shipped env_im* configs) are built")
+        self.has_task = True
+        self.obs_v, self.self_obs_v, self.amp_obs_v = 6, 1, 1
+        self._body_names_orig = list(SMPL_MUJOCO_NAMES)
+        self._body_names = self._body_names_orig
+        self._dof_names = self._body_names[1:]
+        self._full_track_bodies = self._body_names_orig.copy()
+        self._eval_bodies = [b for b in self._body_names_orig if b not in ("L_Toe", "R_Toe", "L_Hand", "R_Hand")]
+        self._has_upright_start = robot.get("has_upright_start", True)
+        if not self._has_upright_start:
+            raise NotImplementedError("has_upright_start=False is not built")
+        self._has_shape_obs = robot.get("has_shape_obs", False)
+        self._has_shape_obs_disc = robot.get("has_shape_obs_disc", False)
+        self._has_limb_weight_obs = robot.get("has_weight_obs", False)
+        self._has_limb_weight_obs_disc = robot.get("has_weight_obs_disc", False)
+        if self._has_shape_obs or self._has_shape_obs_disc or self._has_limb_weight_obs or self._has_limb_weight_obs_disc:
+            raise NotImplementedError("shape / limb-weight observations are not built")
+        self.has_shape_variation = False
+        self._has_dof_subset = robot.get("has_dof_subset", False)
+        self._has_self_collision = robot.get("has_self_collision", False)  # ground contact only in this round (SURVEY f-1)
+        self._freeze_toe = robot.get("freeze_toe", True)
+        self._freeze_hand = robot.get("freeze_hand", True)
+        self._bias_offset = robot.get("bias_offset", False)
+        self._has_smpl_pd_offset = robot.get("has_smpl_pd_offset", False)
+        self.shape_resampling_interval = env.get("shape_resampling_interval", 100)
+        self.getup_schedule = env.get("getup_schedule", False)
+        self._kp_scale = env.get("kp_scale", 1.0)
+        self._kd_scale = env.get("kd_scale", self._kp_scale)
+        self.hard_negative = env.get("hard_negative", False)
+        self.cycle_motion = False
+        self.power_reward = env.get("power_reward", False)
+        self.power_coefficient = env.get("power_coefficient", 0.0005)
+        self.kin_lr = env.get("kin_lr", 5e-4)
+        self.fitting = env.get("fitting", False)
+        self.z_readout = self.z_read = self.z_uniform = self.z_model = self.distill = self.kin_loss = False
+        self.zero_out_far = False
+        self.max_len = env.get("max_len", -1)
+        self.models_path = env.get("models", [])
+        self.eval_full = env.get("eval_full", False)
+        self.auto_pmcp = env.get("auto_pmcp", False)
+        self.auto_pmcp_soft = env.get("auto_pmcp_soft", False)
+        self.strict_eval = env.get("strict_eval", False)
+        self.add_obs_noise = env.get("add_obs_noise", False)
+        self.start_idx = env.get("start_idx", 0)
+        self.seq_motions = env.get("seq_motions", False)
+        self.collect_dataset = cfg.get("collect_dataset", False)
+        self.temp_running_mean = env.get("temp_running_mean", True)
+        self.partial_running_mean = env.get("partial_running_mean", False)
+        self._full_body_reward = env.get("full_body_reward", True)
+        if not self._full_body_reward:
+            raise NotImplementedError("full_body_reward=False is not built")
+        self._min_motion_len = env.get("min_length", -1)
+        self.reward_specs = dict(env.get("reward_specs", {"k_pos": 100, "k_rot": 10, "k_vel": 0.1, "k_ang_vel": 0.1,
+                                                          "w_pos": 0.5, "w_rot": 0.3, "w_vel": 0.1, "w_ang_vel": 0.1}))
+
+        # ---- Humanoid.__init__ (humanoid.py:81-131) ----
+        self.control_mode = cfg["control"]["control_mode"]
+        if self.control_mode != "isaac_pd":
+            raise NotImplementedError(f"control_mode={self.control_mode!r}: only the implicit 'isaac_pd' drive is built")
+        self._pd_control = True
+        self.max_episode_length = env["episode_length"]
+        self._local_root_obs = env["local_root_obs"]
+        self._root_height_obs = env.get("root_height_obs", True)
+        self._enable_early_termination = env["enableEarlyTermination"]
+        self.key_bodies = env["key_bodies"]
+        self._enable_task_obs = env["enableTaskObs"]
+        self._state_init = HumanoidIm.StateInit[env["stateInit"]]
+        if self._state_init not in (HumanoidIm.StateInit.Random, HumanoidIm.StateInit.Start):
+            raise NotImplementedError("stateInit must be Random or Start on the imitation path (humanoid_im.py:1003-1008)")
+        self._hybrid_init_prob = env["hybridInitProb"]
+        self._num_amp_obs_steps = env["numAMPObsSteps"]
+        self._amp_root_height_obs = env.get("ampRootHeightObs", self._root_height_obs)
+        if self._amp_root_height_obs != self._root_height_obs:
+            raise NotImplementedError("ampRootHeightObs != root_height_obs is not built")
+        self._num_amp_obs_enc_steps = env.get("numAMPEncObsSteps", self._num_amp_obs_steps)
+        self.num_envs = env["num_envs"]
+
+        # ---- model (replaces create_sim / load_asset, humanoid.py:528-535,768-990) ----
+        asset = robot.get("asset", {}).get("assetFileName", "mjcf/smpl_humanoid.xml")
+        self.model = load_model(cfg.get("model_asset", "smpl_humanoid"))
+        assert self.model.body_names == self._body_names, f"asset {asset} does not have the SMPL body order"
+        self.num_bodies, self.num_dof = self.model.num_bodies, self.model.num_dof
+        self.skeleton_trees = [SkeletonTree(self.model.body_names, self.model.parent, self.model.local_translation)] * self.num_envs
+        ints, floats = self.model.pack(self._kp_scale, self._kd_scale)
+        self._model_ints = torch.from_numpy(ints).to(self.device)
+        self._model_floats = torch.from_numpy(floats).to(self.device)
+        self._model_struct = abi.model_struct(self._model_ints, self._model_floats, self.num_bodies, self.num_dof,
+                                              self.model.max_level, len(self.model.contact_body))
+        self.humanoid_masses = [self.model.total_mass] * min(self.num_envs, 10)
+        self.limb_weight_group = [[self._body_names.index(g) for g in grp] for grp in (
+            ['L_Hip', 'L_Knee', 'L_Ankle', 'L_Toe'], ['R_Hip', 'R_Knee', 'R_Ankle', 'R_Toe'],
+            ['Pelvis', 'Torso', 'Spine', 'Chest', 'Neck', 'Head'], ['L_Thorax', 'L_Shoulder', 'L_Elbow', 'L_Wrist', 'L_Hand'],
+            ['R_Thorax', 'R_Shoulder', 'R_Elbow', 'R_Wrist', 'R_Hand'])]
+        lw = self.model.limb_lengths_and_weights(self.limb_weight_group)
+        self.humanoid_limb_and_weights = torch.from_numpy(lw).to(self.device).repeat(self.num_envs, 1)
+        self.humanoid_shapes = torch.zeros(self.num_envs, 17, device=self.device)
+
+        # ---- _setup_character_props (humanoid.py:636-706, humanoid_amp.py:290-329) ----
+        self._dof_body_ids = np.arange(1, len(self._body_names))
+        self._dof_offsets = np.linspace(0, len(self._dof_names) * 3, len(self._body_names)).astype(int)
+        self._dof_obs_size = len(self._dof_names) * 6
+        self._dof_size = len(self._dof_names) * 3
+        self._num_actions = self._dof_size
+        self._num_self_obs = 1 + len(self._body_names) * (3 + 6 + 3 + 3) - 3
+        if not self._root_height_obs:
+            self._num_self_obs -= 1
+        self._track_bodies = env.get("trackBodies", self._full_track_bodies)
+        self._reset_bodies = env.get("reset_bodies", self._track_bodies)
+        track_slot, reset_mask, key_ids, amp_slot, n_amp_joints = abi.task_index_tables(
+            self.model, self._track_bodies, self._reset_bodies, self.key_bodies, has_dof_subset=self._has_dof_subset)
+        self._num_amp_obs_per_step = 13 + n_amp_joints * 9 + 3 * len(self.key_bodies) - (0 if self._amp_root_height_obs else 1)
+        dof_sub = [np.arange(3 * (j - 1), 3 * j) for j in range(1, self.num_bodies) if amp_slot[j] >= 0]
+        self.dof_subset = torch.from_numpy(np.concatenate(dof_sub)) if self._has_dof_subset else torch.tensor([]).long()
+        self._track_bodies_id = self._build_key_body_ids_tensor(self._track_bodies)
+        self._reset_bodies_id = self._build_key_body_ids_tensor(self._reset_bodies)
+        self._full_track_bodies_id = self._build_key_body_ids_tensor(self._full_track_bodies)
+        self._eval_track_bodies_id = self._build_key_body_ids_tensor(self._eval_bodies)
+        self._key_body_ids = self._build_key_body_ids_tensor(self.key_bodies)
+        self._contact_body_ids = self._build_key_body_ids_tensor(env["contact_bodies"])
+
+        # ---- BaseTask buffers (base_task.py:62-117) ----
+        self.control_freq_inv = cfg["control"].get("decimation", 2)
+        sim_cfg = cfg["sim"]
+        step_dt = sim_cfg["physx"]["step_dt"]
+        self.sim_dt = float(eval(step_dt)) if isinstance(step_dt, str) else float(step_dt)  # run_hydra.py:79
+        self.dt = self.control_freq_inv * self.sim_dt  # humanoid.py:122
+        self.num_obs = self.get_obs_size()
+        self.num_states = env.get("numStates", 0)
+        self.num_actions = self.get_action_size()
+        cfg["env"]["numObservations"] = self.num_obs
+        cfg["env"]["numActions"] = self.num_actions
+        N, dev = self.num_envs, self.device
+        f32 = dict(device=dev, dtype=torch.float32)
+        i64 = dict(device=dev, dtype=torch.long)
+        self.obs_buf = torch.zeros((N, self.num_obs), **f32)
+        self.states_buf = torch.zeros((N, self.num_states), **f32)
+        self.rew_buf = torch.zeros(N, **f32)
+        self.reset_buf = torch.ones(N, **i64)
+        self.progress_buf = torch.zeros(N, **i64)
+        self.randomize_buf = torch.zeros(N, **i64)
+        self.extras = {}
+        self.viewer = None
+        self.paused = False
+
+        # ---- _setup_tensors (humanoid.py:179-247): Isaac Gym layouts ----
+        NB, D = self.num_bodies, self.num_dof
+        self._root_states = torch.zeros((N, 13), **f32)
+        self._root_states[:, 2] = 0.89  # char_h, humanoid.py:1065
+        self._root_states[:, 6] = 1.0
+        self._humanoid_root_states = self._root_states.view(N, 1, 13)[..., 0, :]
+        self._initial_humanoid_root_states = self._humanoid_root_states.clone()
+        self._initial_humanoid_root_states[:, 7:13] = 0
+        self._humanoid_actor_ids = torch.arange(N, device=dev, dtype=torch.int32)
+        self._dof_state = torch.zeros((N * D, 2), **f32)
+        self._dof_pos = self._dof_state.view(N, D, 2)[..., 0]
+        self._dof_vel = self._dof_state.view(N, D, 2)[..., 1]
+        self._initial_dof_pos = torch.zeros((N, D), **f32)
+        self._initial_dof_vel = torch.zeros((N, D), **f32)
+        self._rigid_body_state = torch.zeros((N * NB, 13), **f32)
+        self._rigid_body_state_reshaped = self._rigid_body_state.view(N, NB, 13)
+        self._rigid_body_pos = self._rigid_body_state_reshaped[..., 0:3]
+        self._rigid_body_rot = self._rigid_body_state_reshaped[..., 3:7]
+        self._rigid_body_vel = self._rigid_body_state_reshaped[..., 7:10]
+        self._rigid_body_ang_vel = self._rigid_body_state_reshaped[..., 10:13]
+        self._contact_forces = torch.zeros((N, NB, 3), **f32)
+        self.dof_force_tensor = torch.zeros((N, D), **f32)
+        self._pd_target = torch.zeros((N, D), **f32)
+        self._terminate_buf = torch.ones(N, **i64)
+        self._sim_struct = abi.sim_state_struct(N, self._root_states, self._dof_state, self._rigid_body_state, self._contact_forces,
+                                                self.dof_force_tensor, self._pd_target)
+        physx = sim_cfg["physx"]
+        plane = env.get("plane", {})
+        solver = cfg.get("solver", {})  # phc_amd-specific knobs of the penalty contact model (not in the reference)
+        self._sim_params = abi.sim_params_struct(
+            sim_dt=self.sim_dt, substeps=int(sim_cfg.get("substeps", 2)), control_freq_inv=self.control_freq_inv, gravity_z=-9.81,
+            contact_stiffness=float(solver.get("contact_stiffness", 1.0e5)), contact_damping=float(solver.get("contact_damping", 1.0e3)),
+            friction=float(plane.get("dynamicFriction", 1.0)), friction_viscous=float(solver.get("friction_viscous", 2.0e3)),
+            angular_damping=0.01, max_angular_velocity=100.0, contact_offset=float(physx.get("contact_offset", 0.02)))
+
+        # ---- action scaling (A1) + freeze masks (humanoid.py:1331-1409,1549-1554) ----
+        self.dof_limits_lower, self.dof_limits_upper = (torch.from_numpy(x).to(dev) for x in self.model.dof_limits())
+        self.dof_limits = torch.stack([self.dof_limits_lower, self.dof_limits_upper], dim=-1)
+        self.torque_limits = torch.from_numpy(self.model.dof_effort.astype(np.float32)).to(dev)
+        self.motor_efforts = self.torque_limits.clone()
+        off, scale = self.model.pd_action_offset_scale(self._bias_offset)
+        self._pd_action_offset = torch.from_numpy(off).to(dev)
+        self._pd_action_scale = torch.from_numpy(scale).to(dev)
+        freeze = np.zeros(D, dtype=np.int32)
+        for names, on in ((("L_Hand", "R_Hand"), self._freeze_hand), (("L_Toe", "R_Toe"), self._freeze_toe)):
+            if on:
+                for n in names:
+                    i = self._dof_names.index(n) * 3
+                    freeze[i:i + 3] = 1
+        self._freeze_mask = torch.from_numpy(freeze).to(dev)
+        self.actions = torch.zeros((N, self.num_actions), **f32)
+
+        # ---- termination (humanoid.py:708-724, humanoid_im.py:539-543) ----
+        self._termination_heights = torch.full((NB,), float(env["terminationHeight"]), **f32)
+        self._termination_heights[self._body_names.index("Head")] = max(0.3, float(env["terminationHeight"]))
+        self._termination_distances_full = torch.full((32,), float(env.get("terminationDistance", 0.5)), **f32)  # PHC_MAX_BODIES slots
+        self._termination_distances = self._termination_distances_full[:NB]  # learner edits this view in place (im_amp.py:174)
+
+        # ---- HumanoidAMP / HumanoidIm state (humanoid_amp.py:109-136, humanoid_im.py:71-123) ----
+        self._motion_start_times = torch.zeros(N, **f32)
+        self._motion_start_times_offset = torch.zeros(N, **f32)
+        self._sampled_motion_ids = torch.arange(N, **i64)  # humanoid_im.py:121
+        self._global_offset = torch.zeros((N, 3), **f32)
+        self._cycle_counter = torch.zeros(N, device=dev, dtype=torch.int)
+        S, A = self._num_amp_obs_steps, self._num_amp_obs_per_step
+        self._amp_bufs = [torch.zeros((N, S, A), **f32), torch.zeros((N, S, A), **f32)]
+        self._amp_cur = 0
+        self._amp_obs_demo_buf = None
+        self.self_obs_buf = self.obs_buf[:, :self._num_self_obs]
+        self.reward_raw = torch.zeros((N, 5 if self.power_reward else 4), **f32)
+        self.ref_body_pos = torch.zeros((N, NB, 3), **f32)
+        self.ref_body_vel = torch.zeros((N, NB, 3), **f32)
+        self.ref_body_rot = torch.zeros((N, NB, 4), **f32)
+        self.ref_dof_pos = torch.zeros((N, D), **f32)
+        self.ref_motion_cache = {}
+        self._tab = [torch.from_numpy(t).to(dev) for t in (track_slot, reset_mask, key_ids, amp_slot)]
+        self._n_amp_joints = n_amp_joints
+        self._im_params = None
+        self._rebuild_im_params()
+
+        # ---- reference motions (humanoid_im.py:316-367) ----
+        self._load_motion(env["motion_file"])
+        return
+
+    # ------------------------------------------------------------------ small helpers
+    def _build_key_body_ids_tensor(self, names):
+        return torch.tensor([self._body_names.index(n) for n in names], device=self.device, dtype=torch.long)
+
+    def _rebuild_im_params(self):
+        track_slot, reset_mask, key_ids, amp_slot = self._tab
+        self._im_params = abi.im_params_struct(
+            dt=self.dt, max_episode_length=self.max_episode_length, reward_specs=self.reward_specs, power_reward=self.power_reward,
+            power_coefficient=self.power_coefficient, enable_early_termination=self._enable_early_termination,
+            use_mean_termination=bool(flags.im_eval and (not self.strict_eval)), disable_collision_check=flags.no_collision_check,
+            local_root_obs=self._local_root_obs, root_height_obs=self._root_height_obs, num_track_bodies=len(self._track_bodies),
+            track_slot=track_slot, reset_mask=reset_mask, num_reset_bodies=len(self._reset_bodies),
+            first_reset_body=self._body_names.index(self._reset_bodies[0]), termination_distances=self._termination_distances_full,
+            num_key_bodies=len(self.key_bodies), key_body_ids=key_ids, num_amp_joints=self._n_amp_joints, amp_joint_slot=amp_slot,
+            num_amp_obs_steps=self._num_amp_obs_steps, num_amp_obs_per_step=self._num_amp_obs_per_step,
+            num_self_obs=self._num_self_obs, num_task_obs=self.get_task_obs_size())
+        self._flag_state = (flags.im_eval, flags.no_collision_check)
+
+    def _buffers(self, amp_in, amp_out):
+        return abi.im_buffers_struct(self.progress_buf, self.reset_buf, self._terminate_buf, self.rew_buf, self.reward_raw, self.obs_buf,
+                                     amp_in, amp_out, self._sampled_motion_ids, self._motion_start_times, self._motion_start_times_offset,
+                                     self._global_offset, self.ref_body_pos, self.ref_body_rot, self.ref_body_vel, self.ref_dof_pos)
+
+    @property
+    def _amp_obs_buf(self):
+        return self._amp_bufs[self._amp_cur]
+
+    @property
+    def _curr_amp_obs_buf(self):
+        return self._amp_obs_buf[:, 0]
+
+    @property
+    def _hist_amp_obs_buf(self):
+        return self._amp_obs_buf[:, 1:]
+
+    # ------------------------------------------------------------------ sizes (humanoid.py:504-526, humanoid_amp_task.py:47-55)
+    def get_self_obs_size(self):
+        return self._num_self_obs
+
+    def get_task_obs_size(self):
+        return len(self._track_bodies) * 24 if self._enable_task_obs else 0  # obs_v 6: humanoid_im.py:505-506
+
+    def get_obs_size(self):
+        return self.get_self_obs_size() + self.get_task_obs_size()
+
+    def get_running_mean_size(self):
+        return (self.get_obs_size(),)
+
+    def get_action_size(self):
+        return self._num_actions
+
+    def get_dof_action_size(self):
+        return self._dof_size
+
+    def get_num_actors_per_env(self):
+        return 1
+
+    def get_num_amp_obs(self):
+        return self._num_amp_obs_steps * self._num_amp_obs_per_step
+
+    def get_num_enc_amp_obs(self):
+        return self._num_amp_obs_enc_steps * self._num_amp_obs_per_step
+
+    def get_task_obs_size_detail(self):
+        return OrderedDict()
+
+    def get_states(self):
+        return self.states_buf
+
+    # ------------------------------------------------------------------ motions
+    def _load_motion(self, motion_train_file, motion_test_file=[]):
+        assert self._dof_offsets[-1] == self.num_dof
+        mf = motion_train_file
+        if isinstance(mf, str) and mf.startswith("synthetic"):
+            # "synthetic[:num_clips[:seed[:mean_seconds]]]" -- AMASS-shaped smooth random clips
+            parts = mf.split(":")
+            nclips = int(parts[1]) if len(parts) > 1 else 1
+            seed = int(parts[2]) if len(parts) > 2 else 0
+            mean_s = float(parts[3]) if len(parts) > 3 else 8.0
+            mf = make_motion_dict(self.model.parent, nclips, seed=seed, body_names=self._body_names, mean_seconds=mean_s,
+                                  min_frames=max(30, int(self._min_motion_len) if self._min_motion_len > 0 else 30))
+        from ...config import EasyDict
+        motion_lib_cfg = EasyDict({"motion_file": mf, "device": self.device, "fix_height": FixHeightMode.full_fix,
+                                   "min_length": self._min_motion_len, "max_length": -1, "im_eval": flags.im_eval,
+                                   "multi_thread": False, "smpl_type": self.humanoid_type, "randomrize_heading": True, "step_dt": self.dt})
+        self._motion_train_lib = MotionLibSMPL(motion_lib_cfg)
+        self._motion_eval_lib = self._motion_train_lib
+        self._motion_lib = self._motion_train_lib
+        self._motion_lib.load_motions(skeleton_trees=self.skeleton_trees, gender_betas=self.humanoid_shapes.cpu(),
+                                      limb_weights=self.humanoid_limb_and_weights.cpu(),
+                                      random_sample=(not flags.test) and (not self.seq_motions),
+                                      max_len=-1 if flags.test else self.max_len, start_idx=self.start_idx)
+
+    def resample_motions(self):
+        """humanoid_im.py:369-396: re-sample one clip per env, then reset everything."""
+        self._motion_lib.load_motions(skeleton_trees=self.skeleton_trees, limb_weights=self.humanoid_limb_and_weights.cpu(),
+                                      gender_betas=self.humanoid_shapes.cpu(), random_sample=(not flags.test) and (not self.seq_motions),
+                                      max_len=-1 if flags.test else self.max_len)
+        self.reset()
+
+    # ------------------------------------------------------------------ step (base_task.py:216-234)
+    def step(self, actions):
+        self.pre_physics_step(actions)
+        self._physics_step()
+        self.post_physics_step()
+
+    def pre_physics_step(self, actions):
+        # humanoid.py:1522-1572: the action -> PD-target map itself runs inside phc_sim_step
+        self.actions = actions.to(self.device).clone()
+        if self.actions.dim() == 1:
+            self.actions = self.actions[None]
+
+    def _physics_step(self):
+        a = self.actions.contiguous()
+        L.check(self._lib.phc_sim_step(self._model_struct, self._sim_params, self._sim_struct, a.data_ptr(),
+                                       self._pd_action_offset.data_ptr(), self._pd_action_scale.data_ptr(),
+                                       self._freeze_mask.data_ptr(), self.control_freq_inv, _stream()), "phc_sim_step")
+
+    def post_physics_step(self):
+        if (flags.im_eval, flags.no_collision_check) != self._flag_state:
+            self._rebuild_im_params()
+        amp_in = self._amp_bufs[self._amp_cur]
+        amp_out = self._amp_bufs[1 - self._amp_cur]
+        buf = self._buffers(amp_in, amp_out)
+        L.check(self._lib.phc_im_post_physics(self._model_struct, self._motion_lib.struct, self._im_params, self._sim_struct, buf,
+                                              _stream()), "phc_im_post_physics")
+        self._amp_cur = 1 - self._amp_cur
+        self.extras["terminate"] = self._terminate_buf         # humanoid.py:1649-1650
+        self.extras["reward_raw"] = self.reward_raw.detach()
+        self.extras["amp_obs"] = self._amp_obs_buf.view(-1, self.get_num_amp_obs())  # humanoid_amp.py:208-209
+        if flags.im_eval:  # humanoid_im.py:674-680
+            t = self.progress_buf * self.dt + self._motion_start_times + self._motion_start_times_offset
+            res = self._motion_lib.get_motion_state(self._sampled_motion_ids, t, self._global_offset)
+            self.extras["mpjpe"] = (self._rigid_body_pos - res["rg_pos"]).norm(dim=-1).mean(dim=-1)
+            self.extras["body_pos"] = self._rigid_body_pos.cpu().numpy()
+            self.extras["body_pos_gt"] = res["rg_pos"].cpu().numpy()
+
+    # ------------------------------------------------------------------ reset (humanoid.py:537-621)
+    def reset(self, env_ids=None):
+        safe_reset = (env_ids is None) or len(env_ids) == self.num_envs
+        if env_ids is None:
+            env_ids = torch.arange(self.num_envs, device=self.device, dtype=torch.long)
+        self._reset_envs(env_ids)
+        if safe_reset:
+            # "simulate one step, then reset again" (humanoid.py:544-550)
+            L.check(self._lib.phc_sim_step(self._model_struct, self._sim_params, self._sim_struct, None, None, None, None, 1, _stream()),
+                    "phc_sim_step")
+            self._reset_envs(env_ids)
+        return
+
+    def _reset_envs(self, env_ids):
+        n = len(env_ids)
+        if n == 0:
+            return
+        env_ids = torch.as_tensor(env_ids, device=self.device).to(torch.long).contiguous()
+        start_at_zero = (self._state_init == HumanoidIm.StateInit.Start) or flags.test  # humanoid_im.py:1003-1011
+        phase = torch.rand(env_ids.shape, device=self.device) if self._state_init != HumanoidIm.StateInit.Start else None
+        cur = self._amp_bufs[self._amp_cur]
+        buf = self._buffers(cur, cur)
+        L.check(self._lib.phc_im_reset(self._model_struct, self._motion_lib.struct, self._im_params, self._sim_struct, buf, n,
+                                       env_ids.data_ptr(), abi.ptr(phase), int(bool(start_at_zero)), _stream()), "phc_im_reset")
+        self._reset_ref_env_ids = env_ids
+        self._reset_ref_motion_ids = self._sampled_motion_ids[env_ids]
+        self._reset_ref_motion_times = self._motion_start_times[env_ids]
+
+    def reset_done(self):
+        """MI355X-first variant of the rollout idiom `env.reset(reset_buf.nonzero())` (amp_agent.py:318-319): resets
+        exactly the envs whose reset_buf is set, on the device, without the device->host sync of `.nonzero()`.
+        One torch.rand(num_envs) is drawn per call (the reference draws len(env_ids) numbers)."""
+        start_at_zero = (self._state_init == HumanoidIm.StateInit.Start) or flags.test
+        phase = torch.rand(self.num_envs, device=self.device)
+        cur = self._amp_bufs[self._amp_cur]
+        buf = self._buffers(cur, cur)
+        L.check(self._lib.phc_im_reset(self._model_struct, self._motion_lib.struct, self._im_params, self._sim_struct, buf, self.num_envs,
+                                       None, phase.data_ptr(), int(bool(start_at_zero)), _stream()), "phc_im_reset")
+
+    # ------------------------------------------------------------------ AMP demo observations (humanoid_amp.py:215-284)
+    def fetch_amp_obs_demo(self, num_samples):
+        if self._amp_obs_demo_buf is None:
+            self._amp_obs_demo_buf = torch.zeros((num_samples, self._num_amp_obs_steps, self._num_amp_obs_per_step),
+                                                 device=self.device, dtype=torch.float32)
+        else:
+            assert self._amp_obs_demo_buf.shape[0] == num_samples
+        motion_ids = self._motion_lib.sample_motions(num_samples)
+        motion_times0 = self._motion_lib.sample_time_interval(motion_ids)
+        self.build_amp_obs_demo(motion_ids, motion_times0, out=self._amp_obs_demo_buf)
+        return self._amp_obs_demo_buf.view(-1, self.get_num_amp_obs())
+
+    def build_amp_obs_demo(self, motion_ids, motion_times0, out=None):
+        n = motion_ids.shape[0]
+        if out is None:
+            out = torch.empty((n, self._num_amp_obs_steps, self._num_amp_obs_per_step), device=self.device, dtype=torch.float32)
+        ids = motion_ids.to(torch.long).contiguous()
+        t0 = motion_times0.to(torch.float32).contiguous()
+        L.check(self._lib.phc_amp_obs_demo(self._model_struct, self._motion_lib.struct, self._im_params, n, ids.data_ptr(),
+                                           t0.data_ptr(), out.data_ptr(), _stream()), "phc_amp_obs_demo")
+        return out
+
+    # ------------------------------------------------------------------ misc API kept for the learner
+    def _get_state_from_motionlib_cache(self, motion_ids, motion_times, offset=None):
+        return self._motion_lib.get_motion_state(motion_ids, motion_times, offset=offset)
+
+    def _refresh_sim_tensors(self):
+        """Recompute rigid-body state from root/dof state (gym.refresh_rigid_body_state_tensor)."""
+        L.check(self._lib.phc_refresh_body_state(self._model_struct, self._sim_struct, _stream()), "phc_refresh_body_state")
+
+    def render(self, sync_frame_time=False):
+        return
+
+    def close(self):
+        return

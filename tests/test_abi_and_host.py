@@ -1,0 +1,170 @@
+"""CPU-only checks of the boundary and of the host logic:
+  * libphc_amd.so loads and exports every symbol include/phc_amd.h declares (no compute calls without a GPU);
+  * the ctypes structs match the C structs' sizes;
+  * the product refuses to run without a HIP device (no silent CPU fallback);
+  * model compiler, config composer and the motion-library loader (host side) against reference goldens."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "phc_amd.h")
+
+
+def _declared_symbols():
+    txt = open(HEADER).read()
+    return sorted(set(re.findall(r"^int32_t\s+(phc_\w+)\s*\(", txt, flags=re.M)))
+
+
+def test_library_exports_every_declared_symbol():
+    from phc_amd import _lib
+    lib = _lib.load()
+    declared = _declared_symbols()
+    assert len(declared) >= 10
+    assert sorted(_lib.EXPORTED_SYMBOLS) == declared, "ctypes table and header disagree"
+    for name in declared:
+        assert hasattr(lib, name), f"libphc_amd.so does not export {name}"
+    assert lib.phc_abi_version() == 1
+
+
+def test_struct_sizes_match_the_header():
+    """Compile a tiny C program against include/phc_amd.h and compare sizeof() with the ctypes mirrors."""
+    from phc_amd import _lib
+    names = {"phc_model_t": _lib.Model, "phc_motion_lib_t": _lib.MotionLib, "phc_sim_state_t": _lib.SimState,
+             "phc_sim_params_t": _lib.SimParams, "phc_im_params_t": _lib.ImParams, "phc_im_buffers_t": _lib.ImBuffers}
+    src = '#include <stdio.h>\n#include "phc_amd.h"\nint main(){' + "".join(f'printf("{n} %zu\\n", sizeof({n}));' for n in names) + "return 0;}"
+    with tempfile.TemporaryDirectory() as d:
+        c = os.path.join(d, "s.c")
+        open(c, "w").write(src)
+        exe = os.path.join(d, "s")
+        subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe], check=True)
+        out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
+    for line in out.strip().splitlines():
+        n, sz = line.split()
+        assert C.sizeof(names[n]) == int(sz), f"{n}: ctypes {C.sizeof(names[n])} vs C {sz}"
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_product_fails_loudly_without_a_gpu():
+    from phc_amd.config import compose
+    from phc_amd.env.tasks.humanoid_im import HumanoidIm
+    cfg = compose(["env.num_envs=4", "env.motion_file=synthetic:1:0"])
+    with pytest.raises(RuntimeError, match="no CPU"):
+        HumanoidIm(cfg, device_type="cuda", device_id=0)
+    with pytest.raises(RuntimeError, match="no CPU"):
+        HumanoidIm(cfg, device_type="cpu", device_id=0)
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under phc_amd/, bench.py's timed path aside, may reference it."""
+    bad = []
+    for dp, _, fs in os.walk(os.path.join(ROOT, "phc_amd")):
+        for f in fs:
+            if f.endswith((".py", ".h", ".hip")):
+                txt = open(os.path.join(dp, f)).read()
+                if re.search(r"^\s*(from|import)\s+(oracle|phc_oracle|dyn_oracle|ref_shim|hostemu)", txt, flags=re.M) or "libphc_hostemu" in txt:
+                    bad.append(os.path.join(dp, f))
+    assert not bad, bad
+
+
+def test_model_compiler_matches_reference_skeleton(golden):
+    """parent indices + local translations bit-exact vs SkeletonTree.from_mjcf (skeleton3d.py:149-193)."""
+    from phc_amd.model import load_model
+    sk = golden("skeleton_smpl")
+    m = load_model("smpl_humanoid")
+    assert m.body_names == list(sk["node_names"])
+    np.testing.assert_array_equal(m.parent, sk["parent_indices"])
+    np.testing.assert_array_equal(m.local_translation, sk["local_translation"])
+    assert m.num_dof == 69 and m.all_spherical
+    assert 60 < m.total_mass < 90
+    # every inertia about the origin must be positive definite, and the packed tables self-consistent
+    for I in m.inertia_origin:
+        assert np.all(np.linalg.eigvalsh(I) > 0)
+    ints, floats = m.pack()
+    assert ints[0] == 24 and ints[1] == 69 and ints[2] == m.max_level
+    off, scale = m.pd_action_offset_scale()
+    import phc_oracle as po
+    lo, hi = m.dof_limits()
+    o2, s2 = po.build_pd_action_offset_scale_smpl(lo, hi, m.body_names[1:])
+    np.testing.assert_array_equal(off, o2)
+    np.testing.assert_array_equal(scale, s2)
+    assert scale[m.body_names[1:].index("L_Knee") * 3 + 1] == 5
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/phc/data/cfg"), reason="reference checkout not present")
+def test_model_asset_is_what_the_compiler_produces_from_the_reference_mjcf():
+    from phc_amd.model import ArticulationModel, compile_mjcf, load_model
+    a = ArticulationModel(compile_mjcf("/root/reference/phc/data/assets/mjcf/smpl_0_humanoid.xml"))
+    b = load_model("smpl_humanoid")
+    for x, y in zip(a.pack(), b.pack()):
+        np.testing.assert_array_equal(x, y)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/phc/data/cfg"), reason="reference checkout not present")
+@pytest.mark.parametrize("ov", [[], ["learning=im_big"], ["learning=im_pnn", "env=env_im_pnn"], ["learning=im_pnn_big"]])
+def test_builtin_config_equals_reference_yaml_tree(ov):
+    """B3: the reference's yaml tree loads unchanged, and the built-in groups agree with it key by key."""
+    from phc_amd.config import compose
+
+    def diff(x, y, path=""):
+        bad = []
+        if isinstance(y, dict):
+            for k in y:
+                if k not in x:
+                    if not path.startswith("domain_rand"):
+                        bad.append(path + "." + k + " missing")
+                    continue
+                bad += diff(x[k], y[k], path + "." + k if path else k)
+        elif x != y:
+            bad.append(f"{path}: {x!r} != {y!r}")
+        return bad
+
+    ours = compose(ov)
+    ref = compose(ov, cfg_dir="/root/reference/phc/data/cfg")
+    assert diff(ours, ref) == []
+    assert isinstance(ref.learning.params.config.learning_rate, float)
+    assert compose(["env.num_envs=17", "+env.foo=[1,2]"]).env.num_envs == 17
+
+
+def _clips_dict(golden):
+    c = golden("motion_clips")
+    return {str(k): {"pose_quat_global": c[f"{k}/pose_quat_global"], "root_trans_offset": c[f"{k}/root_trans_offset"],
+                     "pose_aa": c[f"{k}/pose_aa"], "fps": 30, "beta": np.zeros(10)} for k in c["keys"]}
+
+
+@pytest.mark.parametrize("heading", [False, True])
+def test_motion_lib_loader_vs_reference(golden, heading):
+    """M2-M6 host side: MotionLibSMPL.load_motions == reference (FK, velocities, concatenation, random heading)."""
+    from phc_amd.config import EasyDict
+    from phc_amd.env.tasks.humanoid_im import SkeletonTree
+    from phc_amd.motion_lib import MotionLibSMPL
+    from phc_amd.utils.flags import flags
+    sk = golden("skeleton_smpl")
+    g = golden("motion_lib_heading" if heading else "motion_lib_eval")
+    tree = SkeletonTree(sk["node_names"], sk["parent_indices"], sk["local_translation"])
+    flags.test = not heading
+    try:
+        lib = MotionLibSMPL(EasyDict({"motion_file": _clips_dict(golden), "device": "cpu", "min_length": -1, "im_eval": False, "step_dt": 1 / 30}))
+        lib.load_motions(skeleton_trees=[tree] * 6, random_sample=False)
+    finally:
+        flags.test = False
+    np.testing.assert_array_equal(lib._curr_motion_ids.numpy(), g["curr_motion_ids"])
+    np.testing.assert_array_equal(lib._motion_num_frames.numpy(), g["motion_num_frames"])
+    np.testing.assert_array_equal(lib.length_starts.numpy(), g["length_starts"])
+    np.testing.assert_array_equal(lib._motion_lengths.numpy(), g["motion_lengths"])
+    np.testing.assert_array_equal(lib._motion_dt.numpy(), g["motion_dt"])
+    for k in ("gts", "gvs", "gavs", "dvs"):
+        np.testing.assert_allclose(getattr(lib, k).numpy(), g[k], atol=1e-4, err_msg=k)
+    for k in ("grs", "lrs"):  # rotations up to the quaternion double cover
+        a, b = getattr(lib, k).numpy(), g[k]
+        np.testing.assert_allclose(np.abs((a * b).sum(-1)), 1.0, atol=1e-5, err_msg=k)
+    np.testing.assert_array_equal(lib.get_motion_num_steps().numpy(), golden("motion_lib_eval")["num_steps"])
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        lib.get_motion_state(torch.zeros(2, dtype=torch.long), torch.zeros(2))

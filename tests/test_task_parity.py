@@ -1,0 +1,182 @@
+"""Parity of the task kernels (reference-motion lookup, reward, reset, observations, AMP obs, env reset) against
+  * golden vectors produced by the reference's own code (tests/golden), and
+  * the numpy oracle for compositions the reference cannot run without Isaac Gym.
+Each test runs on two backends (tests/backends.py): `hostemu` = the kernels' per-lane functions compiled
+with g++ (CPU, test infrastructure) and `hip` = the real kernels through the C ABI on an MI355X (-m gpu)."""
+import numpy as np
+import pytest
+
+import phc_oracle as po
+from backends import BACKENDS, get_backend, model_on, motion_lib_on
+from phc_amd import abi
+
+F = np.float32
+ENV_IM = dict(
+    key_bodies=["R_Ankle", "L_Ankle", "R_Wrist", "L_Wrist"],
+    reset_bodies=['Pelvis', 'L_Hip', 'L_Knee', 'R_Hip', 'R_Knee', 'Torso', 'Spine', 'Chest', 'Neck', 'Head', 'L_Thorax',
+                  'L_Shoulder', 'L_Elbow', 'L_Wrist', 'L_Hand', 'R_Thorax', 'R_Shoulder', 'R_Elbow', 'R_Wrist', 'R_Hand'],
+)
+SPECS = po.DEFAULT_REWARD_SPECS
+
+
+def make_im_params(be, model, n_envs, use_mean=False, power_reward=True):
+    tabs = abi.task_index_tables(model, model.body_names, ENV_IM["reset_bodies"], ENV_IM["key_bodies"])
+    n_amp = tabs[4]
+    amp_slot_np = tabs[3]
+    track_slot, reset_mask, key_ids, amp_slot = (be.arr(t) for t in tabs[:4])
+    td = be.arr(np.full(32, 0.25, dtype=F))
+    prm = abi.im_params_struct(dt=2 * (1 / 60), max_episode_length=300, reward_specs=SPECS, power_reward=power_reward,
+                               power_coefficient=0.0005, enable_early_termination=True, use_mean_termination=use_mean,
+                               disable_collision_check=False, local_root_obs=True, root_height_obs=True,
+                               num_track_bodies=model.num_bodies, track_slot=track_slot, reset_mask=reset_mask,
+                               num_reset_bodies=len(ENV_IM["reset_bodies"]), first_reset_body=model.body_names.index(ENV_IM["reset_bodies"][0]),
+                               termination_distances=td,
+                               num_key_bodies=len(ENV_IM["key_bodies"]), key_body_ids=key_ids, num_amp_joints=n_amp, amp_joint_slot=amp_slot,
+                               num_amp_obs_steps=10, num_amp_obs_per_step=196, num_self_obs=358, num_task_obs=576)
+    prm._keepalive = (track_slot, reset_mask, key_ids, amp_slot, td)  # the struct only holds raw addresses
+    return prm, (track_slot, reset_mask, be.np(key_ids), amp_slot_np, td)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_motion_state_vs_reference_golden(golden, backend):
+    be = get_backend(backend)
+    g = golden("motion_lib_eval")
+    lib, keep = motion_lib_on(be, g)
+    n = len(g["ms_ids"])
+    nb = 24
+    out = {k: be.zeros(s) for k, s in dict(rg_pos=(n, nb, 3), rb_rot=(n, nb, 4), body_vel=(n, nb, 3), body_ang_vel=(n, nb, 3),
+                                           dof_pos=(n, 69), dof_vel=(n, 69), blend=(n,)).items()}
+    i0, i1 = be.zeros(n, np.int64), be.zeros(n, np.int64)
+    ids = be.arr(g["ms_ids"].astype(np.int64))
+    times = be.arr(g["ms_times"].astype(F))
+    off = be.arr(g["ms_offset"].astype(F))
+    assert be.motion_state(lib, n, ids, times, off, *[out[k] for k in ("rg_pos", "rb_rot", "body_vel", "body_ang_vel", "dof_pos", "dof_vel")],
+                           i0, i1, out["blend"]) == 0
+    be.sync()
+    np.testing.assert_array_equal(be.np(i0), g["ms_idx0"])   # bit-exact indexing
+    np.testing.assert_array_equal(be.np(i1), g["ms_idx1"])
+    np.testing.assert_array_equal(be.np(out["blend"]), g["ms_blend"])
+    for k in ("rg_pos", "rb_rot", "body_vel", "body_ang_vel", "dof_pos", "dof_vel"):
+        np.testing.assert_allclose(be.np(out[k]), g["ms_" + k], atol=2e-5, rtol=0, err_msg=k)
+    t = be.zeros(n)
+    assert be.sample_time_interval(lib, n, ids, be.arr(g["sti_phase"].astype(F)), t) == 0
+    be.sync()
+    np.testing.assert_array_equal(be.np(t), g["sti_time"])
+
+
+def _sim_arrays(be, g, N, nb=24, nd=69):
+    rbs = np.concatenate([g["body_pos"], g["body_rot"], g["body_vel"], g["body_ang_vel"]], axis=-1).astype(F)
+    dof_state = np.stack([g["dof_pos"], g["dof_vel"]], axis=-1).astype(F)
+    arrs = dict(root=be.arr(rbs[:, 0, :]), dof=be.arr(dof_state), rbs=be.arr(rbs), cf=be.zeros((N, nb, 3)),
+                df=be.arr(g["dof_force"].astype(F)), pd=be.zeros((N, nd)))
+    return arrs, abi.sim_state_struct(N, arrs["root"], arrs["dof"], arrs["rbs"], arrs["cf"], arrs["df"], arrs["pd"])
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("use_mean", [False, True])
+def test_post_physics_vs_reference_golden(golden, backend, use_mean):
+    """reward / reset / self obs / task obs v6 / AMP obs of one post_physics_step == reference jit functions."""
+    be = get_backend(backend)
+    g = golden("task_fns")
+    gl = golden("motion_lib_eval")
+    model, mstruct, keepm = model_on(be)
+    lib, keep = motion_lib_on(be, gl)
+    N = g["body_pos"].shape[0]
+    prm, keepp = make_im_params(be, model, N, use_mean=use_mean)
+    arrs, sim = _sim_arrays(be, g, N)
+    rng = np.random.default_rng(0)
+    amp_in_np = rng.standard_normal((N, 10, 196)).astype(F)
+    amp_in, amp_out = be.arr(amp_in_np), be.zeros((N, 10, 196))
+    b = dict(progress=be.arr((g["progress"] - 1).astype(np.int64)), reset=be.zeros(N, np.int64), term=be.zeros(N, np.int64), rew=be.zeros(N),
+             raw=be.zeros((N, 5)), obs=be.zeros((N, 934)), mids=be.arr(g["env_motion"].astype(np.int64)),
+             st=be.arr(g["start_times"].astype(F)), so=be.zeros(N), goff=be.zeros((N, 3)),
+             rbp=be.zeros((N, 24, 3)), rbr=be.zeros((N, 24, 4)), rbv=be.zeros((N, 24, 3)), rdp=be.zeros((N, 69)))
+    buf = abi.im_buffers_struct(b["progress"], b["reset"], b["term"], b["rew"], b["raw"], b["obs"], amp_in, amp_out, b["mids"], b["st"],
+                                b["so"], b["goff"], b["rbp"], b["rbr"], b["rbv"], b["rdp"])
+    assert be.im_post_physics(mstruct, lib, prm, sim, buf) == 0
+    be.sync()
+    o = {k: be.np(v) for k, v in b.items()}
+    amp_out = be.np(amp_out)
+    np.testing.assert_array_equal(o["progress"], g["progress"])
+    np.testing.assert_allclose(o["raw"][:, :4], g["reward_raw"], atol=1e-5)
+    np.testing.assert_allclose(o["raw"][:, 4], g["power_reward"], atol=1e-5, rtol=1e-5)
+    np.testing.assert_allclose(o["rew"], g["reward"] + g["power_reward"], atol=1e-5)
+    np.testing.assert_array_equal(o["reset"], g["reset_mean" if use_mean else "reset"])       # bit-exact flags
+    np.testing.assert_array_equal(o["term"], g["terminate_mean" if use_mean else "terminate"])
+    np.testing.assert_allclose(o["obs"][:, :358], g["self_obs"], atol=1e-5)
+    np.testing.assert_allclose(o["obs"][:, 358:], g["task_obs"], atol=1e-5)
+    np.testing.assert_allclose(amp_out[:, 0], g["amp_obs"], atol=1e-5)
+    np.testing.assert_array_equal(amp_out[:, 1:], amp_in_np[:, :-1])                           # history shift
+    np.testing.assert_allclose(o["rbp"], g["ref1_pos"], atol=2e-5)                              # side-effect buffers (:855-868)
+    np.testing.assert_allclose(o["rbv"], g["ref1_vel"], atol=2e-5)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_amp_demo_and_reset_vs_oracle(golden, backend):
+    """build_amp_obs_demo and the reset composition, against the numpy oracle driven the reference's way."""
+    be = get_backend(backend)
+    gl = golden("motion_lib_eval")
+    model, mstruct, keepm = model_on(be)
+    lib, keep = motion_lib_on(be, gl)
+    N = 6
+    prm, keepp = make_im_params(be, model, N)
+    track_slot, reset_mask, key_ids, amp_slot, td = keepp
+    dof_subset = np.concatenate([np.arange(3 * (j - 1), 3 * j) for j in range(1, 24) if amp_slot[j] >= 0])
+    rng = np.random.default_rng(3)
+    n = 16
+    ids = rng.integers(0, N, n).astype(np.int64)
+    t0 = (rng.random(n).astype(F) * gl["motion_lengths"][ids]).astype(F)
+    out = be.zeros((n, 10, 196))
+    assert be.amp_obs_demo(mstruct, lib, prm, n, be.arr(ids), be.arr(t0), out) == 0
+    be.sync()
+    dt = F(2 * (1 / 60))
+    times = (t0[:, None] + (-dt) * np.arange(10, dtype=F)[None]).astype(F)       # humanoid_amp.py:258-260
+    ms = po.get_motion_state(gl, np.repeat(ids, 10), times.reshape(-1))
+    want = po.build_amp_observations_smpl(ms["root_pos"], ms["root_rot"], ms["root_vel"], ms["root_ang_vel"], ms["dof_pos"], ms["dof_vel"],
+                                          ms["rg_pos"][:, key_ids], dof_subset).reshape(n, 10, 196)
+    np.testing.assert_allclose(be.np(out), want, atol=2e-5)
+
+    # ---- reset of a subset of envs ----
+    nb, nd = 24, 69
+    arrs = dict(root=be.zeros((N, 13)), dof=be.zeros((N, nd, 2)), rbs=be.zeros((N, nb, 13)), cf=be.arr(np.ones((N, nb, 3), F)),
+                df=be.arr(np.ones((N, nd), F)), pd=be.zeros((N, nd)))
+    sim = abi.sim_state_struct(N, arrs["root"], arrs["dof"], arrs["rbs"], arrs["cf"], arrs["df"], arrs["pd"])
+    amp = be.zeros((N, 10, 196))
+    b = dict(progress=be.arr(np.full(N, 7, np.int64)), reset=be.arr(np.ones(N, np.int64)), term=be.arr(np.ones(N, np.int64)), rew=be.zeros(N),
+             raw=be.zeros((N, 5)), obs=be.zeros((N, 934)), mids=be.arr(np.arange(N, dtype=np.int64)), st=be.arr(np.full(N, -1, F)),
+             so=be.arr(np.full(N, 3, F)), goff=be.arr(np.ones((N, 3), F)))
+    buf = abi.im_buffers_struct(b["progress"], b["reset"], b["term"], b["rew"], b["raw"], b["obs"], amp, amp, b["mids"], b["st"], b["so"], b["goff"])
+    env_ids = np.array([4, 1, 2], dtype=np.int64)
+    phase = rng.random(3).astype(F)
+    assert be.im_reset(mstruct, lib, prm, sim, buf, 3, be.arr(env_ids), be.arr(phase), 0) == 0
+    be.sync()
+    b = {k: be.np(v) for k, v in b.items()}
+    arrs = {k: be.np(v) for k, v in arrs.items()}
+    amp = be.np(amp)
+    t = po.sample_time_interval(phase, gl["motion_lengths"][env_ids])
+    np.testing.assert_array_equal(b["st"][env_ids], t)
+    np.testing.assert_array_equal(b["st"][[0, 3, 5]], F(-1))      # untouched envs
+    assert (b["progress"][env_ids] == 0).all() and (b["reset"][env_ids] == 0).all() and (b["term"][env_ids] == 0).all()
+    assert (b["so"][env_ids] == 0).all() and (b["goff"][env_ids] == 0).all() and (b["progress"][[0, 3, 5]] == 7).all()
+    ms = po.get_motion_state(gl, env_ids, t, np.zeros((3, 3), F))
+    np.testing.assert_allclose(arrs["root"][env_ids, 0:3], ms["root_pos"], atol=2e-5)
+    np.testing.assert_allclose(arrs["root"][env_ids, 3:7], ms["root_rot"], atol=2e-5)
+    np.testing.assert_allclose(arrs["root"][env_ids, 7:10], ms["root_vel"], atol=2e-5)
+    np.testing.assert_allclose(arrs["dof"][env_ids, :, 0], ms["dof_pos"], atol=2e-5)
+    np.testing.assert_allclose(arrs["dof"][env_ids, :, 1], ms["dof_vel"], atol=2e-5)
+    np.testing.assert_allclose(arrs["pd"][env_ids], ms["dof_pos"], atol=2e-5)
+    np.testing.assert_allclose(arrs["rbs"][env_ids, :, 0:3], ms["rg_pos"], atol=2e-5)
+    np.testing.assert_allclose(arrs["rbs"][env_ids, :, 3:7], ms["rb_rot"], atol=2e-5)
+    assert (arrs["cf"][env_ids] == 0).all() and (arrs["cf"][[0, 3, 5]] == 1).all()
+    ms1 = po.get_motion_state(gl, env_ids, (np.int64(1) * dt + t + F(0)).astype(F), np.zeros((3, 3), F))
+    so = po.compute_humanoid_observations_smpl_max(ms["rg_pos"], ms["rb_rot"], ms["body_vel"], ms["body_ang_vel"])
+    to = po.compute_imitation_observations_v6(ms["rg_pos"][:, 0], ms["rb_rot"][:, 0], ms["rg_pos"], ms["rb_rot"], ms["body_vel"],
+                                              ms["body_ang_vel"], ms1["rg_pos"], ms1["rb_rot"], ms1["body_vel"], ms1["body_ang_vel"])
+    np.testing.assert_allclose(b["obs"][env_ids, :358], so, atol=2e-5)
+    np.testing.assert_allclose(b["obs"][env_ids, 358:], to, atol=2e-5)
+    assert (b["obs"][[0, 3, 5]] == 0).all()
+    times = (t[:, None] + (-dt) * np.arange(10, dtype=F)[None]).astype(F)
+    msh = po.get_motion_state(gl, np.repeat(env_ids, 10), times.reshape(-1))
+    want = po.build_amp_observations_smpl(msh["root_pos"], msh["root_rot"], msh["root_vel"], msh["root_ang_vel"], msh["dof_pos"],
+                                          msh["dof_vel"], msh["rg_pos"][:, key_ids], dof_subset).reshape(3, 10, 196)
+    np.testing.assert_allclose(amp[env_ids], want, atol=2e-5)
