@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU (BASELINE configs[1]: 4096)")
     ap.add_argument("--ppo-epochs", type=int, default=1, help="timed PPO epochs (rollout 32 steps + 36 optimizer steps); 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--actions", choices=["random", "tracking"], default="random",
+                    help="random: fixed a ~ U(-1,1)*0.1 tensor (SURVEY 8d protocol; zero-pose targets -> episodes end after a few steps); "
+                         "tracking: PD target = reference pose of the next frame (episodes last like a trained policy's)")
     return ap.parse_args()
 
 
@@ -136,9 +139,12 @@ def main():
     env.reset()
     actions = (torch.rand(N, task.num_actions, device=dev) * 2 - 1) * 0.1  # fixed a ~ U(-1,1)*0.1
 
+    inv_scale = 1.0 / task._pd_action_scale
+
     def env_step(ev=None):
         task.reset_done()                 # envs that finished on the previous step (device-side mask, no host sync)
-        task.pre_physics_step(actions)
+        a = actions if args.actions == "random" else (task.ref_dof_pos - task._pd_action_offset) * inv_scale
+        task.pre_physics_step(a)
         if ev is not None:
             ev[0].record()
         task._physics_step()
@@ -197,7 +203,8 @@ def main():
             out.update(ppo)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
-        out["episode_restart_fraction"] = resets
+        out["actions"] = args.actions
+        out["envs_within_5_steps_of_a_reset"] = resets
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

@@ -191,11 +191,8 @@ def accelerations(model, st, target, params, dt, kp_scale=1.0, kd_scale=1.0, ret
         eff = model.dof_effort[s:s + 3]
         qt = quat_from_rotvec(np.asarray(target[s:s + 3], dtype=np.float64))
         err = quat_to_rotvec(quat_mul(quat_conj(st.q[i - 1]), qt))
-        tau = kp * err - (kd + dt * kp) * st.wj[i - 1]
+        tau = np.clip(kp * err, -eff, eff) - (kd + dt * kp) * st.wj[i - 1]  # spring saturates, damping stays implicit
         d = arm_ + dt * kd + dt * dt * kp
-        sat = np.abs(tau) > eff
-        tau = np.where(sat, np.sign(tau) * eff, tau)
-        d = np.where(sat, arm_, d)
         c = slice(6 + 3 * (i - 1), 6 + 3 * i)
         M[c, c] += np.diag(d)
         rhs[c] += tau

@@ -6,6 +6,11 @@ fallback: if the shared library is missing or a symbol is absent the import fail
 import ctypes as C
 import os
 
+# torch bundles its own libamdhip64.so: it must be in the process BEFORE libphc_amd.so is dlopen'ed, otherwise the
+# system copy from /opt/rocm gets loaded next to it and kernels are registered with a runtime that owns no device
+# (launches then fail with hipErrorNoDevice).  PyTorch is plumbing here: device memory, streams, torch.distributed.
+import torch  # noqa: F401
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libphc_amd.so")
 

@@ -12,12 +12,13 @@
 //     level l work; parent/child hand-off goes through a 28-float LDS slot per body.
 //   * everything stiff is integrated LINEARLY IMPLICITLY by augmenting the articulated inertia:
 //       - PD drive (kp,kd) + armature:  D += R diag(armature + dt*kd + dt^2*kp) R^T,
-//         tau_explicit = kp*err - (kd + dt*kp)*w_joint              (Isaac Gym "isaac_pd" drive, S8)
+//         tau_explicit = clamp(kp*err, +-effort) - (kd + dt*kp)*w_joint   (Isaac Gym "isaac_pd" drive, S8)
 //       - penalty ground contact with regularised Coulomb friction at sphere / capsule-end / box-corner
 //         points: I^A += dt * J^T C J,  p^A -= J^T F0               (C = diag(ct,ct,kn*dt+dn))
 //     so kp=800 / kd=80 at dt=1/120 s on light distal links stays stable (explicit PD would not).
 // There is no reference implementation of this arithmetic (PhysX is closed): the oracle is
-// oracle/aba_ref.c (fp64, body-sequential) + physical invariants -- "parity unpinned" at the PhysX level.
+// oracle/dyn_oracle.py (fp64 dense mass-matrix solve, an independent formulation) + physical invariants --
+// "parity unpinned" at the PhysX level.
 #pragma once
 #include "phc_math.h"
 #include "../../include/phc_amd.h"
@@ -226,15 +227,15 @@ PHC_HD void aba_body_init(AbaLane& L, const phc_model_t& m, const phc_sim_params
     if (L.level > 0) {
         Q4 qt = quat_from_rotvec(L.target);
         V3 err = quat_to_rotvec(quat_mul16(quat_conjugate(L.q), qt));
-        V3 tau = v3(L.kp.x * err.x - (L.kd.x + dt * L.kp.x) * L.wj.x,
-                    L.kp.y * err.y - (L.kd.y + dt * L.kp.y) * L.wj.y,
-                    L.kp.z * err.z - (L.kd.z + dt * L.kp.z) * L.wj.z);
+        // effort limit (gear=500): the SPRING term saturates; the damping term stays fully implicit, so a saturated
+        // drive can never inject energy (a hard clamp of the total would turn the drive into a constant torque on a
+        // 0.02 kg m^2 armature -> 1e4 rad/s^2)
+        V3 sp = v3(fminf(fmaxf(L.kp.x * err.x, -L.effort.x), L.effort.x), fminf(fmaxf(L.kp.y * err.y, -L.effort.y), L.effort.y),
+                   fminf(fmaxf(L.kp.z * err.z, -L.effort.z), L.effort.z));
+        V3 tau = v3(sp.x - (L.kd.x + dt * L.kp.x) * L.wj.x, sp.y - (L.kd.y + dt * L.kp.y) * L.wj.y,
+                    sp.z - (L.kd.z + dt * L.kp.z) * L.wj.z);
         V3 d = v3(L.arm.x + dt * L.kd.x + dt * dt * L.kp.x, L.arm.y + dt * L.kd.y + dt * dt * L.kp.y,
                   L.arm.z + dt * L.kd.z + dt * dt * L.kp.z);
-        // effort saturation: a saturated axis is a constant torque, no implicit stiffness
-        if (fabsf(tau.x) > L.effort.x) { tau.x = copysignf(L.effort.x, tau.x); d.x = L.arm.x; }
-        if (fabsf(tau.y) > L.effort.y) { tau.y = copysignf(L.effort.y, tau.y); d.y = L.arm.y; }
-        if (fabsf(tau.z) > L.effort.z) { tau.z = copysignf(L.effort.z, tau.z); d.z = L.arm.z; }
         L.tau_local = tau;
         L.dimp = d;
     }
