@@ -52,7 +52,7 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(num_envs=512, steps=6):
+def cpu_baseline(num_envs=4096, steps=100):
     """CPU port of the same path on the host cores: oracle/hostemu = the kernels' per-lane functions compiled with
     g++ -O2 -fopenmp, one env per OpenMP iteration.  (The reference has no CPU dynamics at all -- Isaac Gym is a GPU
     binary -- and its reward/obs path is Python/torch; this port is the builder's CPU restatement)"""

@@ -1,0 +1,468 @@
+"""P4-P10: the PPO + AMP learner (`im_amp`), PyTorch-ROCm on the same device as the env.
+
+Follows the reference's agent chain `IMAmpAgent -> AMPAgent -> CommonAgent` (phc/learning/im_amp.py,
+amp_agent.py, common_agent.py; base classes from rl-games 1.1.4 are not vendored there -- their behaviour is
+restated from PHC's call sites):
+
+  train_epoch (amp_agent.py:413-504)
+    play_steps (:309-397)           rollout of `horizon_length` steps, 3 MLP forwards per step
+    _calc_amp_rewards (:859-878)    -log(max(1-sigmoid(D),1e-4)) * disc_reward_scale
+    _combine_rewards (:848-853)     task_reward_w * r_task + disc_reward_w * r_disc
+    discount_values (common_agent.py:493-505)   GAE -> `phc_gae` HIP kernel
+    prepare_dataset (:399-411, common_agent.py:357-398)  advantage / value normalisation
+    calc_gradients (:554-688)       PPO clip + critic + bound + discriminator (BCE, logit reg, grad penalty, weight decay)
+    Adam (lr 2e-5), clip_grad_norm_(50)
+
+MI355X-first differences (results-preserving):
+  * GEMMs run in bf16 on MFMA under torch.autocast; parameters, Adam state and all losses stay fp32;
+    running statistics stay fp64 (running_mean_std.py).
+  * done envs are reset on the device from `reset_buf` (`task.reset_done()`), no `.nonzero()` host sync per step
+    (set `faithful_reset=True` to get the reference's `env.reset(done_indices)` call sequence and RNG stream).
+  * data parallelism: one process per GPU, envs sharded, ONE all-reduce (mean) of a single flat fp32 gradient
+    bucket per optimizer step over RCCL (`FlatGradBucket`); it replaces horovod's `optimizer.synchronize()`
+    (amp_agent.py:667-668).  Running-stat moments are averaged once per epoch (`hvd.sync_stats`).
+"""
+import copy
+import time
+
+import numpy as np
+import torch
+from torch import nn
+
+from .. import _lib as L
+from .network import A2CNetwork, ModelAMPContinuous, policy_kl
+from .replay_buffer import ReplayBuffer
+from .running_mean_std import RunningMeanStd
+
+
+def swap_and_flatten01(arr):
+    """rl_games a2c_common.swap_and_flatten01: [T, N, ...] -> [N*T, ...] (env-major)."""
+    if arr is None:
+        return arr
+    s = arr.size()
+    return arr.transpose(0, 1).reshape(s[0] * s[1], *s[2:])
+
+
+def discount_values(mb_fdones, mb_values, mb_rewards, mb_next_values, gamma, tau):
+    """P5 GAE (common_agent.py:493-505).  [T,N,1] tensors.  On the HIP device this is one `phc_gae` launch;
+    for CPU tensors (unit tests of the learner logic under gloo) the same recurrence runs as torch ops."""
+    T, N = mb_rewards.shape[0], mb_rewards.shape[1]
+    advs = torch.empty_like(mb_rewards)
+    if mb_rewards.is_cuda:
+        fd = mb_fdones.reshape(T, N).float().contiguous()
+        v, r, nv = (x.reshape(T, N).float().contiguous() for x in (mb_values, mb_rewards, mb_next_values))
+        out = advs.view(T, N)
+        L.check(L.load().phc_gae(T, N, fd.data_ptr(), v.data_ptr(), r.data_ptr(), nv.data_ptr(), float(gamma), float(tau), out.data_ptr(),
+                                 torch.cuda.current_stream().cuda_stream), "phc_gae")
+        return advs
+    last = 0
+    for t in reversed(range(T)):
+        not_done = (1.0 - mb_fdones[t].float()).reshape(N, 1)
+        delta = mb_rewards[t] + gamma * mb_next_values[t] - mb_values[t]
+        last = delta + gamma * tau * not_done * last
+        advs[t] = last
+    return advs
+
+
+class FlatGradBucket:
+    """All parameters' gradients as views of ONE flat fp32 buffer -> one all-reduce per optimizer step.
+
+    22.1 MB (`im`) / 78 MB (`im_big`) per step: over the 7 point-to-point xGMI links of an MI355X node RCCL moves
+    that in well under a millisecond, so there is nothing to overlap with and one bucket is the right size."""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        n = sum(p.numel() for p in self.params)
+        dev = self.params[0].device
+        self.flat = torch.zeros(n, device=dev, dtype=torch.float32)
+        o = 0
+        for p in self.params:
+            p.grad = self.flat[o:o + p.numel()].view_as(p)
+            o += p.numel()
+
+    def zero(self):
+        self.flat.zero_()
+
+    def all_reduce_mean(self, dist):
+        if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            self.flat.div_(dist.get_world_size())
+
+
+class IMAmpAgent:
+    def __init__(self, vec_env, cfg, dist=None, faithful_reset=False, bf16=True):
+        self.vec_env = vec_env
+        self.task = vec_env.task
+        self.dist = dist
+        self.rank = dist.get_rank() if dist is not None and dist.is_initialized() else 0
+        self.world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
+        self.multi_gpu = self.world > 1
+        self.faithful_reset = faithful_reset
+        params = cfg["learning"]["params"]
+        c = params["config"]
+        self.config = c
+        self.device = self.task.device if hasattr(self.task, "device") else "cpu"
+        self.ppo_device = self.device
+        self.bf16 = bf16 and str(self.device).startswith("cuda")
+        self.num_actors = vec_env.num_envs
+        self.horizon_length = c["horizon_length"]
+        self.batch_size = self.horizon_length * self.num_actors
+        self.minibatch_size = min(c["minibatch_size"], self.batch_size)
+        assert self.batch_size % self.minibatch_size == 0
+        self.num_minibatches = self.batch_size // self.minibatch_size
+        self.mini_epochs_num = c["mini_epochs"]
+        self.gamma, self.tau = c["gamma"], c["tau"]
+        self.e_clip, self.critic_coef, self.entropy_coef = c["e_clip"], c["critic_coef"], c["entropy_coef"]
+        self.bounds_loss_coef = c.get("bounds_loss_coef", None)
+        self.clip_value = c["clip_value"]
+        self.truncate_grads, self.grad_norm = c["truncate_grads"], c["grad_norm"]
+        self.normalize_input, self.normalize_value = c["normalize_input"], c["normalize_value"]
+        self.normalize_advantage = c["normalize_advantage"]
+        self.last_lr = float(c["learning_rate"])
+        self.reward_scale = c.get("reward_shaper", {}).get("scale_value", 1)
+        # AMP (_load_config_params amp_agent.py:690-707)
+        self._task_reward_w, self._disc_reward_w = c["task_reward_w"], c["disc_reward_w"]
+        self._amp_batch_size = int(c["amp_batch_size"])
+        self._amp_minibatch_size = min(int(c["amp_minibatch_size"]), self.minibatch_size)
+        self._disc_coef, self._disc_logit_reg = c["disc_coef"], c["disc_logit_reg"]
+        self._disc_grad_penalty, self._disc_weight_decay = c["disc_grad_penalty"], c["disc_weight_decay"]
+        self._disc_reward_scale = c["disc_reward_scale"]
+        self._normalize_amp_input = c.get("normalize_amp_input", True)
+        self.temp_running_mean = getattr(self.task, "temp_running_mean", True)
+
+        obs_dim = vec_env.num_obs
+        amp_dim = self.task.get_num_amp_obs()
+        self.obs_shape, self.actions_num = (obs_dim,), vec_env.num_actions
+        net = A2CNetwork(params["network"], self.actions_num, (obs_dim,), (amp_dim,))
+        self.model = ModelAMPContinuous(net).to(self.device)
+        if self.multi_gpu:  # hvd.setup_algo: broadcast rank 0's initial parameters (common_agent.py:112-113)
+            for p in self.model.parameters():
+                dist.broadcast(p.data, src=0)
+        self.running_mean_std = RunningMeanStd((obs_dim,)).to(self.device) if self.normalize_input else None
+        self.value_mean_std = RunningMeanStd((1,)).to(self.device) if self.normalize_value else None
+        self._amp_input_mean_std = RunningMeanStd((amp_dim,)).to(self.device) if self._normalize_amp_input else None
+        self.running_mean_std_temp = None
+        self.grads = FlatGradBucket(self.model.parameters())
+        self.optimizer = torch.optim.Adam(self.grads.params, self.last_lr, eps=1e-08, weight_decay=c.get("weight_decay", 0.0))
+
+        T, N, dev = self.horizon_length, self.num_actors, self.device
+        f = lambda *s: torch.zeros(*s, device=dev, dtype=torch.float32)
+        self.exp = {"obses": f(T, N, obs_dim), "next_obses": f(T, N, obs_dim), "rewards": f(T, N, 1), "values": f(T, N, 1),
+                    "next_values": f(T, N, 1), "neglogpacs": f(T, N), "dones": torch.zeros(T, N, device=dev, dtype=torch.uint8),
+                    "actions": f(T, N, self.actions_num), "mus": f(T, N, self.actions_num), "sigmas": f(T, N, self.actions_num),
+                    "amp_obs": f(T, N, amp_dim)}
+        self._amp_obs_demo_buffer = ReplayBuffer(int(c["amp_obs_demo_buffer_size"]), dev)
+        self._amp_replay_buffer = ReplayBuffer(int(c["amp_replay_buffer_size"]), dev)
+        self._amp_replay_keep_prob = c["amp_replay_keep_prob"]
+        self._idx_buf = torch.randperm(self.batch_size, device=dev)
+        self.current_rewards = f(N, 1)
+        self.current_lengths = f(N)
+        self.epoch_num = 0
+        self.frame = 0
+        self.obs = None
+        self.dones = torch.zeros(N, device=dev, dtype=torch.long)
+        self.mean_rewards = []
+
+    # ------------------------------------------------------------------ modes (rl_games set_eval / set_train + amp_agent.py:63-82)
+    def _norms(self):
+        return [m for m in (self.running_mean_std, self.value_mean_std, self._amp_input_mean_std) if m is not None]
+
+    def set_eval(self):
+        self.model.eval()
+        for m in self._norms():
+            m.eval()
+
+    def set_train(self):
+        self.model.train()
+        for m in self._norms():
+            m.train()
+
+    def _autocast(self):
+        return torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.bf16)
+
+    # ------------------------------------------------------------------ observation pre-processing (amp_agent.py:535-552)
+    def _preproc_obs(self, obs_batch, use_temp=False):
+        if not self.normalize_input:
+            return obs_batch
+        if use_temp:
+            out = self.running_mean_std_temp(obs_batch)
+            self.running_mean_std(obs_batch)  # statistics keep updating, the frozen copy provides the values
+            return out
+        return self.running_mean_std(obs_batch)
+
+    def _preproc_amp_obs(self, amp_obs):
+        return self._amp_input_mean_std(amp_obs) if self._normalize_amp_input else amp_obs
+
+    # ------------------------------------------------------------------ rollout (amp_agent.py:309-397)
+    def get_action_values(self, obs):
+        processed = self._preproc_obs(obs)
+        with torch.no_grad(), self._autocast():
+            res = self.model({"is_train": False, "prev_actions": None, "obs": processed})
+        if self.normalize_value:
+            res["values"] = self.value_mean_std(res["values"], True)
+        return res
+
+    def _eval_critic(self, obs):
+        processed = self._preproc_obs(obs)
+        with torch.no_grad(), self._autocast():
+            value = self.model.a2c_network.eval_critic(processed).float()
+        if self.normalize_value:
+            value = self.value_mean_std(value, True)
+        return value
+
+    def env_reset(self, env_ids=None):
+        return self.vec_env.reset(env_ids)
+
+    def play_steps(self):
+        self.set_eval()
+        e = self.exp
+        task = self.task
+        terminated_flags = torch.zeros(self.num_actors, device=self.device)
+        reward_raw = None
+        done_indices = []
+        for n in range(self.horizon_length):
+            if self.faithful_reset or not hasattr(task, "reset_done"):
+                self.obs = self.env_reset(done_indices)
+            else:
+                task.reset_done()
+                self.obs = torch.clamp(task.obs_buf, -self.vec_env.clip_obs, self.vec_env.clip_obs) if np.isfinite(self.vec_env.clip_obs) else task.obs_buf
+            e["obses"][n].copy_(self.obs)
+            res = self.get_action_values(self.obs)
+            for k in ("values", "neglogpacs", "actions", "mus", "sigmas"):
+                e[k][n].copy_(res[k])
+            self.obs, rewards, self.dones, infos = self.vec_env.step(res["actions"])
+            rewards = rewards.unsqueeze(1) if rewards.dim() == 1 else rewards
+            e["rewards"][n].copy_(rewards * self.reward_scale)
+            e["next_obses"][n].copy_(self.obs)
+            e["dones"][n].copy_(self.dones)
+            e["amp_obs"][n].copy_(infos["amp_obs"])
+            terminated = infos["terminate"].float()
+            terminated_flags += terminated
+            rr = infos["reward_raw"].mean(dim=0)
+            reward_raw = rr if reward_raw is None else reward_raw + rr
+            next_vals = self._eval_critic(self.obs)
+            next_vals = next_vals * (1.0 - terminated.unsqueeze(-1))
+            e["next_values"][n].copy_(next_vals)
+            self.current_rewards += rewards
+            self.current_lengths += 1
+            if self.faithful_reset:
+                done_indices = self.dones.nonzero(as_tuple=False)[:, 0]
+            not_dones = 1.0 - self.dones.float()
+            self.current_rewards = self.current_rewards * not_dones.unsqueeze(1)
+            self.current_lengths = self.current_lengths * not_dones
+        mb_fdones = e["dones"].float()
+        amp_rewards = self._calc_amp_rewards(e["amp_obs"])
+        mb_rewards = self._combine_rewards(e["rewards"], amp_rewards)
+        mb_advs = discount_values(mb_fdones, e["values"], mb_rewards, e["next_values"], self.gamma, self.tau)
+        mb_returns = mb_advs + e["values"]
+        batch = {k: swap_and_flatten01(e[k]) for k in ("obses", "rewards", "values", "neglogpacs", "dones", "actions", "mus", "sigmas", "amp_obs")}
+        batch["returns"] = swap_and_flatten01(mb_returns)
+        batch["terminated_flags"] = terminated_flags
+        batch["reward_raw"] = reward_raw / self.horizon_length
+        batch["played_frames"] = self.batch_size
+        batch["disc_rewards"] = swap_and_flatten01(amp_rewards["disc_rewards"])
+        batch["mb_rewards"] = swap_and_flatten01(mb_rewards)
+        return batch
+
+    def _eval_disc(self, amp_obs):
+        with self._autocast():
+            return self.model.a2c_network.eval_disc(self._preproc_amp_obs(amp_obs)).float()
+
+    def _calc_amp_rewards(self, amp_obs):
+        with torch.no_grad():
+            T, N, A = amp_obs.shape
+            logits = self._eval_disc(amp_obs.reshape(T * N, A)).reshape(T, N, 1)
+            prob = 1 / (1 + torch.exp(-logits))
+            disc_r = -torch.log(torch.maximum(1 - prob, torch.tensor(0.0001, device=amp_obs.device)))
+            disc_r = disc_r * self._disc_reward_scale
+        return {"disc_rewards": disc_r}
+
+    def _combine_rewards(self, task_rewards, amp_rewards):
+        return self._task_reward_w * task_rewards + self._disc_reward_w * amp_rewards["disc_rewards"]
+
+    # ------------------------------------------------------------------ dataset (common_agent.py:357-398,589-599; amp_agent.py:399-411)
+    def prepare_dataset(self, b):
+        advantages = torch.sum(b["returns"] - b["values"], axis=1)
+        if self.normalize_advantage:
+            advantages = (advantages - advantages.mean()) / (advantages.std() + 1e-8)  # per rank, as the reference (common_agent.py:596-597)
+        values, returns = b["values"], b["returns"]
+        if self.normalize_value:
+            values = self.value_mean_std(values)
+            returns = self.value_mean_std(returns)
+        self.dataset = {"old_values": values, "old_logp_actions": b["neglogpacs"], "advantages": advantages, "returns": returns,
+                        "actions": b["actions"], "obs": b["obses"], "mu": b["mus"], "sigma": b["sigmas"], "amp_obs": b["amp_obs"],
+                        "amp_obs_demo": b["amp_obs_demo"], "amp_obs_replay": b["amp_obs_replay"]}
+
+    def _get_item(self, idx):
+        s, e = idx * self.minibatch_size, (idx + 1) * self.minibatch_size
+        sample_idx = self._idx_buf[s:e]
+        out = {k: v[sample_idx] for k, v in self.dataset.items()}
+        if e >= self.batch_size:
+            self._idx_buf[:] = torch.randperm(self.batch_size, device=self._idx_buf.device)
+        return out
+
+    # ------------------------------------------------------------------ losses (common_agent.py:512-520,564-587; amp_agent.py:732-808)
+    def bound_loss(self, mu):
+        if self.bounds_loss_coef is None:
+            return torch.zeros((), device=mu.device)
+        soft_bound = 1.0
+        hi = torch.clamp_min(mu - soft_bound, 0.0) ** 2
+        lo = torch.clamp_max(mu + soft_bound, 0.0) ** 2
+        return (lo + hi).sum(axis=-1)
+
+    def _disc_loss(self, disc_agent_logit, disc_demo_logit, obs_demo):
+        bce = torch.nn.BCEWithLogitsLoss()
+        disc_loss = 0.5 * (bce(disc_agent_logit, torch.zeros_like(disc_agent_logit)) + bce(disc_demo_logit, torch.ones_like(disc_demo_logit)))
+        net = self.model.a2c_network
+        disc_logit_loss = torch.sum(torch.square(net.get_disc_logit_weights()))
+        disc_loss = disc_loss + self._disc_logit_reg * disc_logit_loss
+        grad = torch.autograd.grad(disc_demo_logit, obs_demo, grad_outputs=torch.ones_like(disc_demo_logit), create_graph=True,
+                                   retain_graph=True, only_inputs=True)[0]
+        disc_grad_penalty = torch.mean(torch.sum(torch.square(grad), dim=-1))
+        disc_loss = disc_loss + self._disc_grad_penalty * disc_grad_penalty
+        if self._disc_weight_decay != 0:
+            w = torch.cat(net.get_disc_weights(), dim=-1)
+            disc_loss = disc_loss + self._disc_weight_decay * torch.sum(torch.square(w))
+        return {"disc_loss": disc_loss, "disc_grad_penalty": disc_grad_penalty.detach(), "disc_logit_loss": disc_logit_loss.detach(),
+                "disc_agent_acc": (disc_agent_logit < 0).float().mean().detach(), "disc_demo_acc": (disc_demo_logit > 0).float().mean().detach()}
+
+    def calc_gradients(self, d):
+        self.set_train()
+        obs = self._preproc_obs(d["obs"], use_temp=self.temp_running_mean)
+        m = self._amp_minibatch_size
+        amp_obs = self._preproc_amp_obs(d["amp_obs"][0:m])
+        amp_obs_replay = self._preproc_amp_obs(d["amp_obs_replay"][0:m])
+        amp_obs_demo = self._preproc_amp_obs(d["amp_obs_demo"][0:m])
+        amp_obs_demo.requires_grad_(True)
+        with self._autocast():
+            res = self.model({"is_train": True, "prev_actions": d["actions"], "obs": obs, "amp_obs": amp_obs,
+                              "amp_obs_replay": amp_obs_replay, "amp_obs_demo": amp_obs_demo})
+        ratio = torch.exp(d["old_logp_actions"] - res["prev_neglogp"])
+        adv = d["advantages"]
+        a_loss = torch.max(-adv * ratio, -adv * torch.clamp(ratio, 1.0 - self.e_clip, 1.0 + self.e_clip))
+        values, ret, vp = res["values"], d["returns"], d["old_values"]
+        if self.clip_value:
+            vpc = vp + (values - vp).clamp(-self.e_clip, self.e_clip)
+            c_loss = torch.max((values - ret) ** 2, (vpc - ret) ** 2)
+        else:
+            c_loss = (ret - values) ** 2
+        b_loss = self.bound_loss(res["mus"])
+        a_loss, c_loss, b_loss, entropy = a_loss.mean(), c_loss.mean(), b_loss.mean(), res["entropy"].mean()
+        disc_info = self._disc_loss(torch.cat([res["disc_agent_logit"], res["disc_agent_replay_logit"]], dim=0), res["disc_demo_logit"], amp_obs_demo)
+        bl = self.bounds_loss_coef if self.bounds_loss_coef is not None else 0.0
+        loss = a_loss + self.critic_coef * c_loss - self.entropy_coef * entropy + bl * b_loss + self._disc_coef * disc_info["disc_loss"]
+        self.grads.zero()
+        loss.backward()
+        with torch.no_grad():
+            kl = policy_kl(res["mus"].detach(), res["sigmas"].detach(), d["mu"], d["sigma"])
+        self.grads.all_reduce_mean(self.dist)  # the path's one collective: replaces optimizer.synchronize() (amp_agent.py:667-668)
+        if self.truncate_grads:
+            nn.utils.clip_grad_norm_(self.grads.params, self.grad_norm)
+        self.optimizer.step()
+        info = {"actor_loss": a_loss.detach(), "critic_loss": c_loss.detach(), "b_loss": b_loss.detach(), "entropy": entropy.detach(), "kl": kl}
+        info.update({k: (v.detach() if torch.is_tensor(v) else v) for k, v in disc_info.items()})
+        return info
+
+    # ------------------------------------------------------------------ epoch (amp_agent.py:413-532)
+    def _init_amp_demo_buf(self):
+        n = int(np.ceil(self._amp_obs_demo_buffer.get_buffer_size() / self._amp_batch_size))
+        for _ in range(n):
+            self._amp_obs_demo_buffer.store({"amp_obs": self.vec_env.fetch_amp_obs_demo(self._amp_batch_size)})
+
+    def _update_amp_demos(self):
+        self._amp_obs_demo_buffer.store({"amp_obs": self.vec_env.fetch_amp_obs_demo(self._amp_batch_size)})
+
+    def _store_replay_amp_obs(self, amp_obs):
+        size = self._amp_replay_buffer.get_buffer_size()
+        if self._amp_replay_buffer.get_total_count() > size:
+            keep = torch.bernoulli(torch.full((amp_obs.shape[0],), self._amp_replay_keep_prob, device=amp_obs.device)) == 1.0
+            amp_obs = amp_obs[keep]
+        if amp_obs.shape[0] > size:
+            amp_obs = amp_obs[torch.randperm(amp_obs.shape[0], device=amp_obs.device)[:size]]
+        self._amp_replay_buffer.store({"amp_obs": amp_obs})
+
+    def pre_epoch(self, epoch_num):
+        t = self.task
+        if (epoch_num > 1) and epoch_num % getattr(t, "shape_resampling_interval", 10 ** 9) == 1 and hasattr(t, "resample_motions"):
+            t.resample_motions()
+        if self.running_mean_std is not None:
+            self.running_mean_std_temp = copy.deepcopy(self.running_mean_std)
+            self.running_mean_std_temp.freeze()
+
+    def post_epoch(self, epoch_num):
+        if self.running_mean_std is not None:
+            self.running_mean_std_temp = copy.deepcopy(self.running_mean_std)
+            self.running_mean_std_temp.freeze()
+        for m in self._norms():
+            m.sync(self.dist)
+
+    def init_train(self):
+        self.obs = self.env_reset()
+        self._init_amp_demo_buf()
+
+    def train_epoch(self):
+        self.epoch_num += 1
+        self.pre_epoch(self.epoch_num)
+        sync = torch.cuda.synchronize if str(self.device).startswith("cuda") else (lambda: None)
+        sync()
+        t0 = time.time()
+        with torch.no_grad():
+            batch = self.play_steps()
+        sync()
+        t1 = time.time()
+        self._update_amp_demos()
+        n = batch["amp_obs"].shape[0]
+        batch["amp_obs_demo"] = self._amp_obs_demo_buffer.sample(n)["amp_obs"]
+        batch["amp_obs_replay"] = batch["amp_obs"] if self._amp_replay_buffer.get_total_count() == 0 else self._amp_replay_buffer.sample(n)["amp_obs"]
+        self.set_train()
+        self.prepare_dataset(batch)
+        infos = []
+        for _ in range(self.mini_epochs_num):
+            for i in range(self.num_minibatches):
+                infos.append(self.calc_gradients(self._get_item(i)))
+        self._store_replay_amp_obs(batch["amp_obs"])
+        self.post_epoch(self.epoch_num)
+        sync()
+        t2 = time.time()
+        self.frame += self.batch_size * self.world
+        info = {k: torch.stack([i[k] for i in infos]).mean().item() for k in infos[0]}
+        info.update(play_time=t1 - t0, update_time=t2 - t1, total_time=t2 - t0, mean_task_reward=batch["rewards"].mean().item(),
+                    mean_disc_reward=batch["disc_rewards"].mean().item(), reward_raw=batch["reward_raw"].tolist(),
+                    step_fps=self.batch_size / (t1 - t0), total_fps=self.batch_size / (t2 - t0))  # common_agent.py:134-138
+        return info
+
+    def train(self, max_epochs, log=print):
+        self.init_train()
+        for _ in range(max_epochs):
+            info = self.train_epoch()
+            if self.rank == 0 and log is not None:
+                log(f"epoch {self.epoch_num}: total_fps {info['total_fps']:.0f} step_fps {info['step_fps']:.0f} task_r {info['mean_task_reward']:.4f} "
+                    f"disc_r {info['mean_disc_reward']:.4f} a_loss {info['actor_loss']:.4f} c_loss {info['critic_loss']:.4f} disc_loss {info['disc_loss']:.4f}")
+        return info
+
+    # ------------------------------------------------------------------ checkpoint (amp_agent.py:69-108; SURVEY B4 key names)
+    def get_full_state_weights(self):
+        s = {"model": self.model.state_dict(), "epoch": self.epoch_num, "optimizer": self.optimizer.state_dict(), "frame": self.frame}
+        if self.running_mean_std is not None:
+            s["running_mean_std"] = self.running_mean_std.state_dict()
+        if self.value_mean_std is not None:
+            s["reward_mean_std"] = self.value_mean_std.state_dict()
+        if self._amp_input_mean_std is not None:
+            s["amp_input_mean_std"] = self._amp_input_mean_std.state_dict()
+        return s
+
+    def set_full_state_weights(self, w):
+        self.model.load_state_dict(w["model"])
+        self.epoch_num = w.get("epoch", 0)
+        self.frame = w.get("frame", 0)
+        if "optimizer" in w:
+            self.optimizer.load_state_dict(w["optimizer"])
+        for key, mod in (("running_mean_std", self.running_mean_std), ("reward_mean_std", self.value_mean_std), ("amp_input_mean_std", self._amp_input_mean_std)):
+            if mod is not None and key in w:
+                mod.load_state_dict(w[key])
+
+    def save(self, path):
+        torch.save(self.get_full_state_weights(), path)
+
+    def restore(self, path):
+        self.set_full_state_weights(torch.load(path, map_location=self.device))

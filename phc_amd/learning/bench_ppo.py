@@ -1,0 +1,37 @@
+"""PPO samples/s for bench.py: the reference's `performance/total_fps = batch_size / (play_time + update_time)`
+(phc/learning/common_agent.py:134-138) of full `train_epoch`s -- rollout of horizon_length steps with policy
+inference, discriminator rewards, GAE, then mini_epochs x minibatches optimizer steps, each with ONE gradient
+all-reduce when more than one rank runs."""
+import time
+
+import torch
+
+
+def time_ppo_epochs(task, env, cfg, epochs, dist=None, warmup=1):
+    from .amp_agent import IMAmpAgent
+    # bench-sized replay buffers: the 200k x 1960 fp32 buffers of the shipped yaml are kept (1.57 GB each, HBM is 288 GB)
+    agent = IMAmpAgent(env, cfg, dist=dist)
+    agent.init_train()
+    for _ in range(warmup):
+        agent.train_epoch()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    infos = [agent.train_epoch() for _ in range(epochs)]
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    world = 1
+    if dist is not None:
+        t = torch.tensor([el], device=task.device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+        world = dist.get_world_size()
+    n_opt = agent.mini_epochs_num * agent.num_minibatches
+    return {"ppo_samples_per_s": agent.batch_size * world * epochs / el, "ppo_epoch_ms": el / epochs * 1e3,
+            "ppo_play_ms": 1e3 * sum(i["play_time"] for i in infos) / epochs, "ppo_update_ms": 1e3 * sum(i["update_time"] for i in infos) / epochs,
+            "ppo_config": {"horizon": agent.horizon_length, "batch_per_gpu": agent.batch_size, "minibatch": agent.minibatch_size,
+                           "optimizer_steps_per_epoch": n_opt, "gemm_dtype": "bf16" if agent.bf16 else "f32",
+                           "grad_allreduce_bytes": int(agent.grads.flat.numel() * 4), "collectives_per_epoch": n_opt if world > 1 else 0}}

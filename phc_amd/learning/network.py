@@ -1,0 +1,107 @@
+"""P2: actor / critic / discriminator networks of the AMP agent.
+
+Architecture and parameter NAMES follow the reference (`AMPBuilder.Network`, phc/learning/amp_network_builder.py:17-249,
+on rl_games' A2CBuilder / ModelA2CContinuousLogStd): separate actor and critic MLPs, a linear `mu` head, a fixed
+non-trainable log-sigma (-2.9, learn_sigma False), a linear `value` head, and the `_disc_mlp` + `_disc_logits`
+discriminator.  The state-dict keys are the ones the reference's checkpoints use
+(`a2c_network.actor_mlp.0.weight`, `a2c_network.mu.weight`, `a2c_network.sigma`, `a2c_network.critic_mlp.*`,
+`a2c_network.value.*`, `a2c_network._disc_mlp.*`, `a2c_network._disc_logits.*`).
+
+MI355X: weights are fp32 masters; the GEMMs run as bf16 MFMA under torch.autocast (hipBLASLt) -- the only
+dense contraction on the path."""
+import math
+
+import torch
+from torch import nn
+
+DISC_LOGIT_INIT_SCALE = 1.0  # amp_network_builder.py:12
+
+_ACT = {"relu": nn.ReLU, "silu": nn.SiLU, "tanh": nn.Tanh, "elu": nn.ELU, "gelu": nn.GELU, "None": nn.Identity}
+
+
+def build_mlp(input_size, units, activation):
+    """network_builder.py:126-137 `_build_sequential_mlp`: Linear, act, Linear, act ... (indices 0,2,4,..)."""
+    layers, n = [], input_size
+    for u in units:
+        layers += [nn.Linear(n, u), _ACT[activation]()]
+        n = u
+    return nn.Sequential(*layers)
+
+
+class A2CNetwork(nn.Module):
+    def __init__(self, params, actions_num, input_shape, amp_input_shape, value_size=1):
+        super().__init__()
+        mlp, disc = params["mlp"], params["disc"]
+        assert params.get("separate", True), "the shipped PHC configs use separate actor / critic networks"
+        space = params["space"]["continuous"]
+        assert space["fixed_sigma"] and not space["learn_sigma"]
+        self.units, self.activation = list(mlp["units"]), mlp["activation"]
+        self.actor_mlp = build_mlp(input_shape[0], self.units, self.activation)
+        self.critic_mlp = build_mlp(input_shape[0], self.units, self.activation)
+        self.value = nn.Linear(self.units[-1], value_size)
+        self.mu = nn.Linear(self.units[-1], actions_num)
+        self.sigma = nn.Parameter(torch.full((actions_num,), float(space["sigma_init"]["val"]), dtype=torch.float32), requires_grad=False)
+        self._disc_mlp = build_mlp(amp_input_shape[0], list(disc["units"]), disc["activation"])
+        self._disc_logits = nn.Linear(list(disc["units"])[-1], 1)
+        # initializer "default" == torch's Linear default; biases of the discriminator zeroed, logit layer U(-1,1)
+        for m in self._disc_mlp.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.zeros_(m.bias)
+        nn.init.uniform_(self._disc_logits.weight, -DISC_LOGIT_INIT_SCALE, DISC_LOGIT_INIT_SCALE)
+        nn.init.zeros_(self._disc_logits.bias)
+
+    def eval_actor(self, obs):
+        mu = self.mu(self.actor_mlp(obs))
+        return mu, mu * 0.0 + self.sigma  # amp_network_builder.py:143-151 (logstd broadcast)
+
+    def eval_critic(self, obs):
+        return self.value(self.critic_mlp(obs))
+
+    def eval_disc(self, amp_obs):
+        return self._disc_logits(self._disc_mlp(amp_obs))
+
+    def get_disc_logit_weights(self):
+        return torch.flatten(self._disc_logits.weight)
+
+    def get_disc_weights(self):
+        w = [torch.flatten(m.weight) for m in self._disc_mlp.modules() if isinstance(m, nn.Linear)]
+        w.append(torch.flatten(self._disc_logits.weight))
+        return w
+
+
+class ModelAMPContinuous(nn.Module):
+    """`ModelAMPContinuous.Network` (phc/learning/amp_models.py:6-59) over rl_games' ModelA2CContinuousLogStd:
+    Normal(mu, exp(logstd)) policy; neglogp / entropy as rl_games computes them."""
+
+    def __init__(self, a2c_network):
+        super().__init__()
+        self.a2c_network = a2c_network
+
+    @staticmethod
+    def neglogp(x, mean, std, logstd):
+        return 0.5 * (((x - mean) / std) ** 2).sum(dim=-1) + 0.5 * math.log(2.0 * math.pi) * x.size()[-1] + logstd.sum(dim=-1)
+
+    def forward(self, input_dict):
+        is_train = input_dict.get("is_train", True)
+        obs = input_dict["obs"]
+        mu, logstd = self.a2c_network.eval_actor(obs)
+        value = self.a2c_network.eval_critic(obs)
+        mu, logstd, value = mu.float(), logstd.float(), value.float()
+        sigma = torch.exp(logstd)
+        if is_train:
+            prev_actions = input_dict["prev_actions"]
+            entropy = (0.5 + 0.5 * math.log(2 * math.pi) + logstd).sum(dim=-1)
+            res = {"prev_neglogp": self.neglogp(prev_actions, mu, sigma, logstd), "values": value, "entropy": entropy, "mus": mu, "sigmas": sigma}
+            res["disc_agent_logit"] = self.a2c_network.eval_disc(input_dict["amp_obs"]).float()
+            res["disc_agent_replay_logit"] = self.a2c_network.eval_disc(input_dict["amp_obs_replay"]).float()
+            res["disc_demo_logit"] = self.a2c_network.eval_disc(input_dict["amp_obs_demo"]).float()
+            return res
+        action = mu + sigma * torch.randn_like(mu)
+        return {"neglogpacs": self.neglogp(action, mu, sigma, logstd), "values": value, "actions": action, "mus": mu, "sigmas": sigma}
+
+
+def policy_kl(p0_mu, p0_sigma, p1_mu, p1_sigma):
+    """rl_games torch_ext.policy_kl (mean over the batch)."""
+    c1 = torch.log(p1_sigma / p0_sigma + 1e-5)
+    c2 = (p0_sigma ** 2 + (p1_mu - p0_mu) ** 2) / (2.0 * (p1_sigma ** 2 + 1e-5))
+    return (c1 + c2 - 0.5).sum(dim=-1).mean()

@@ -1,0 +1,84 @@
+"""P1: running mean / variance normaliser with fp64 statistics.
+
+Same behaviour as the reference `RunningMeanStd` (phc/utils/running_mean_std.py:10-111): fp64 buffers `running_mean`,
+`running_var`, `count`; forward normalises and clamps to +-5 (or un-normalises with `unnorm=True`), and in train mode
+(unless frozen) folds the batch moments in with the parallel-variance update (:56-67) AFTER computing the output.
+`sync()` averages the moments across ranks (the reference's `hvd.sync_stats`, common_agent.py:126-127).
+"""
+import torch
+from torch import nn
+
+
+class RunningMeanStd(nn.Module):
+    def __init__(self, insize, epsilon=1e-05, per_channel=False, norm_only=False):
+        super().__init__()
+        self.insize = insize
+        self.mean_size = insize[0] if isinstance(insize, (tuple, list)) else insize
+        self.epsilon = epsilon
+        self.norm_only = norm_only
+        self.per_channel = per_channel
+        if per_channel:
+            raise NotImplementedError("per_channel normalisation is not used on this path")
+        self.axis = [0]
+        self.register_buffer("running_mean", torch.zeros(self.mean_size, dtype=torch.float64))
+        self.register_buffer("running_var", torch.ones(self.mean_size, dtype=torch.float64))
+        self.register_buffer("count", torch.ones((), dtype=torch.float64))
+        self.forzen = False  # (sic) attribute names of the reference
+        self.forzen_partial = False
+
+    def freeze(self):
+        self.forzen = True
+
+    def unfreeze(self):
+        self.forzen = False
+
+    def freeze_partial(self, diff):
+        self.forzen_partial = True
+        self.diff = diff
+
+    @staticmethod
+    def _update_mean_var_count_from_moments(mean, var, count, batch_mean, batch_var, batch_count):
+        delta = batch_mean - mean
+        tot_count = count + batch_count
+        new_mean = mean + delta * batch_count / tot_count
+        m_a = var * count
+        m_b = batch_var * batch_count
+        M2 = m_a + m_b + delta ** 2 * count * batch_count / tot_count
+        return new_mean, M2 / tot_count, tot_count
+
+    def forward(self, input, unnorm=False):
+        mean, var = self.running_mean, self.running_var
+        if unnorm:
+            y = torch.clamp(input, min=-5.0, max=5.0)
+            y = torch.sqrt(var.float() + self.epsilon) * y + mean.float()
+        elif self.norm_only:
+            y = input / torch.sqrt(var.float() + self.epsilon)
+        else:
+            y = (input - mean.float()) / torch.sqrt(var.float() + self.epsilon)
+            y = torch.clamp(y, min=-5.0, max=5.0)
+        if self.training and not self.forzen:
+            with torch.no_grad():
+                bm = input.mean(self.axis)
+                bv = input.var(self.axis)
+                nm, nv, nc = self._update_mean_var_count_from_moments(self.running_mean, self.running_var, self.count, bm, bv, input.size()[0])
+                if self.forzen_partial:
+                    self.running_mean[-self.diff:], self.running_var[-self.diff:] = nm[-self.diff:], nv[-self.diff:]
+                    self.count.copy_(nc)
+                else:
+                    self.running_mean.copy_(nm)
+                    self.running_var.copy_(nv)
+                    self.count.copy_(nc)
+        return y
+
+    @torch.no_grad()
+    def sync(self, dist):
+        """Average (mean, var, count) over ranks so that every replica normalises identically."""
+        if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+            return
+        flat = torch.cat([self.running_mean, self.running_var, self.count.reshape(1)])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat /= dist.get_world_size()
+        n = self.mean_size
+        self.running_mean.copy_(flat[:n])
+        self.running_var.copy_(flat[n:2 * n])
+        self.count.copy_(flat[2 * n])

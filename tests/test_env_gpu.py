@@ -222,3 +222,21 @@ def test_fk_kernel_vs_oracle(golden):
     assert be.lib.phc_fk(mstruct, T, lr.data_ptr(), rt.data_ptr(), grot.data_ptr(), gpos.data_ptr(), be._s()) == 0
     be.sync()
     np.testing.assert_allclose(be.np(gpos), gts, atol=1e-4)
+
+
+def test_ppo_train_epoch_on_device():
+    """P4-P9 on the device: two full train_epochs (rollout with policy inference, disc rewards, phc_gae, bf16 MFMA
+    GEMMs, Adam) at 256 envs; finite losses, parameters move, statistics update."""
+    from phc_amd.learning.amp_agent import IMAmpAgent
+    task, env = make_task(256, motion="synthetic:2:3", **{"learning.params.config.minibatch_size": 2048,
+                                                         "learning.params.config.amp_obs_demo_buffer_size": 4096,
+                                                         "learning.params.config.amp_replay_buffer_size": 4096})
+    agent = IMAmpAgent(env, task.cfg)
+    agent.init_train()
+    w0 = agent.model.a2c_network.mu.weight.clone()
+    for _ in range(2):
+        info = agent.train_epoch()
+        assert np.isfinite([info["actor_loss"], info["critic_loss"], info["disc_loss"], info["kl"], info["mean_task_reward"]]).all(), info
+    assert not torch.equal(w0, agent.model.a2c_network.mu.weight)
+    assert agent.batch_size == 256 * 32 and agent.num_minibatches == 4
+    assert info["total_fps"] > 0

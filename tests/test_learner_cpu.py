@@ -1,0 +1,207 @@
+"""P1-P9 on the CPU: the learner is PyTorch and runs without a GPU against a small synthetic VecEnv.
+Covers: RunningMeanStd vs the reference's class (imported through the shim when the reference is present),
+GAE vs the oracle, loss terms, the replay buffer, one full train_epoch, checkpoint key names (B4), and the
+world_size-2 gloo path: flat-bucket gradient all-reduce keeps replicas bit-identical."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import phc_oracle as po
+from phc_amd.config import compose
+from phc_amd.learning.amp_agent import FlatGradBucket, IMAmpAgent, discount_values, swap_and_flatten01
+from phc_amd.learning.network import A2CNetwork, ModelAMPContinuous, policy_kl
+from phc_amd.learning.replay_buffer import ReplayBuffer
+from phc_amd.learning.running_mean_std import RunningMeanStd
+
+
+class FakeTask:
+    """Tiny stand-in with the attributes the agent reads (no physics): obs 20, amp 3x6, actions 5."""
+    device = "cpu"
+    temp_running_mean = True
+    shape_resampling_interval = 500
+
+    def __init__(self, n, seed=0):
+        self.num_envs = n
+        self.g = torch.Generator().manual_seed(seed)
+        self.obs_buf = torch.randn(n, 20, generator=self.g)
+        self.reset_buf = torch.zeros(n, dtype=torch.long)
+
+    def get_num_amp_obs(self):
+        return 18
+
+    def reset_done(self):
+        self.reset_buf.zero_()
+
+
+class FakeVecEnv:
+    clip_obs = np.inf
+
+    def __init__(self, n, seed=0):
+        self.task = FakeTask(n, seed)
+        self.num_envs, self.num_obs, self.num_actions = n, 20, 5
+
+    def reset(self, env_ids=None):
+        return self.task.obs_buf
+
+    def step(self, actions):
+        t = self.task
+        t.obs_buf = 0.9 * t.obs_buf + 0.1 * torch.randn(t.num_envs, 20, generator=t.g)
+        rew = torch.exp(-actions.pow(2).mean(-1))
+        done = (torch.rand(t.num_envs, generator=t.g) < 0.1).long()
+        t.reset_buf = done
+        info = {"amp_obs": torch.randn(t.num_envs, 18, generator=t.g), "terminate": done * (torch.rand(t.num_envs, generator=t.g) < 0.5).long(),
+                "reward_raw": torch.rand(t.num_envs, 5, generator=t.g)}
+        return t.obs_buf, rew, done, info
+
+    def fetch_amp_obs_demo(self, n):
+        return torch.randn(n, 18, generator=self.task.g) + 0.5
+
+
+def small_cfg():
+    cfg = compose(["learning.params.config.horizon_length=8", "learning.params.config.minibatch_size=64", "learning.params.config.mini_epochs=2",
+                   "learning.params.config.amp_minibatch_size=32", "learning.params.config.amp_batch_size=16",
+                   "learning.params.config.amp_obs_demo_buffer_size=256", "learning.params.config.amp_replay_buffer_size=256",
+                   "learning.params.network.mlp.units=[32,16]", "learning.params.network.disc.units=[32,16]"])
+    return cfg
+
+
+def test_running_mean_std_matches_reference():
+    torch.manual_seed(0)
+    ours = RunningMeanStd((7,))
+    ours.train()
+    ref = None
+    if os.path.isdir("/root/reference"):
+        import ref_shim
+        ref = ref_shim.ref_module("phc.utils.running_mean_std").RunningMeanStd((7,))
+        ref.train()
+    xs = [torch.randn(50, 7) * (i + 1) + i for i in range(4)]
+    for x in xs:
+        y = ours(x)
+        if ref is not None:
+            assert torch.equal(y, ref(x))
+    assert ours.running_mean.dtype == torch.float64 and ours.count.item() == 201
+    allx = torch.cat(xs).double()
+    np.testing.assert_allclose(ours.running_mean.numpy(), allx.sum(0).numpy() / 201, rtol=1e-4, atol=1e-5)  # count starts at 1 with mean 0; batch moments are fp32
+    if ref is not None:
+        assert torch.equal(ours.running_mean, ref.running_mean) and torch.equal(ours.running_var, ref.running_var)
+    ours.eval()
+    m = ours.running_mean.clone()
+    y = ours(xs[0])
+    assert torch.equal(m, ours.running_mean) and y.abs().max() <= 5.0
+    np.testing.assert_allclose(ours(ours(xs[1]), unnorm=True).numpy(), xs[1].clamp(-1e9, 1e9).numpy(), atol=2e-2, rtol=1e-2)
+    ours.train(); ours.freeze()
+    ours(xs[2] * 100)
+    assert torch.equal(m, ours.running_mean)
+
+
+def test_gae_matches_oracle():
+    g = torch.Generator().manual_seed(0)
+    T, N = 16, 33
+    fd = (torch.rand(T, N, generator=g) < 0.15).float()
+    v, r, nv = (torch.randn(T, N, 1, generator=g) for _ in range(3))
+    adv = discount_values(fd, v, r, nv, 0.99, 0.95)
+    want = po.discount_values(fd.numpy(), v.numpy(), r.numpy(), nv.numpy())
+    np.testing.assert_allclose(adv.numpy(), want, atol=1e-5)
+    x = torch.arange(24).reshape(2, 3, 4)
+    assert torch.equal(swap_and_flatten01(x)[1], x[1, 0])  # env-major flattening
+
+
+def test_network_shapes_names_and_policy_math():
+    cfg = compose([])
+    net = A2CNetwork(cfg.learning.params.network, 69, (934,), (1960,))
+    keys = set(ModelAMPContinuous(net).state_dict().keys())
+    for k in ("a2c_network.actor_mlp.0.weight", "a2c_network.actor_mlp.2.bias", "a2c_network.mu.weight", "a2c_network.sigma",
+              "a2c_network.critic_mlp.0.weight", "a2c_network.value.weight", "a2c_network._disc_mlp.0.weight", "a2c_network._disc_logits.bias"):
+        assert k in keys, k
+    n_params = sum(p.numel() for p in net.parameters() if p.requires_grad)
+    assert n_params == 1517637 - 0 + 1482753 + 2533377 - 0, n_params  # actor + critic + disc of `learning=im`
+    assert not net.sigma.requires_grad and torch.allclose(net.sigma, torch.full((69,), -2.9))
+    model = ModelAMPContinuous(net)
+    obs = torch.randn(4, 934)
+    out = model({"is_train": False, "obs": obs})
+    mu, sigma, a = out["mus"], out["sigmas"], out["actions"]
+    nlp = -torch.distributions.Normal(mu, sigma).log_prob(a).sum(-1)
+    np.testing.assert_allclose(out["neglogpacs"].detach().numpy(), nlp.detach().numpy(), rtol=1e-5)
+    assert policy_kl(mu, sigma, mu, sigma).abs() < 0.2  # rl_games formula: the 1e-5 epsilons give -0.11 at sigma=exp(-2.9), D=69
+
+
+def test_replay_buffer_wraps_and_samples():
+    torch.manual_seed(0)
+    rb = ReplayBuffer(10, "cpu")
+    rb.store({"amp_obs": torch.arange(6).float()[:, None]})
+    s = rb.sample(50)["amp_obs"]
+    assert s.max() <= 5 and rb.get_total_count() == 6
+    rb.store({"amp_obs": 10 + torch.arange(7).float()[:, None]})
+    assert rb.get_total_count() == 13 and rb._head == 3
+    vals = set(rb._data_buf["amp_obs"].flatten().tolist())
+    assert vals == {14., 15., 16., 3., 4., 5., 10., 11., 12., 13.}
+
+
+def test_train_epoch_runs_and_learns_something():
+    torch.manual_seed(0)
+    env = FakeVecEnv(32)
+    agent = IMAmpAgent(env, small_cfg(), bf16=False)
+    agent.init_train()
+    w0 = agent.model.a2c_network.mu.weight.clone()
+    infos = [agent.train_epoch() for _ in range(3)]
+    for i in infos:
+        assert np.isfinite([i["actor_loss"], i["critic_loss"], i["disc_loss"], i["kl"]]).all()
+    assert not torch.equal(w0, agent.model.a2c_network.mu.weight)
+    assert agent.running_mean_std.count.item() > 1 and agent._amp_input_mean_std.count.item() > 1
+    assert agent._amp_replay_buffer.get_total_count() >= 2 * 32 * 8  # third store is thinned by amp_replay_keep_prob (amp_agent.py:880-894)
+    st = agent.get_full_state_weights()
+    assert {"model", "running_mean_std", "reward_mean_std", "amp_input_mean_std"} <= set(st)  # amp_agent.py:69-108
+    agent2 = IMAmpAgent(FakeVecEnv(32), small_cfg(), bf16=False)
+    agent2.set_full_state_weights(st)
+    assert torch.equal(agent2.model.a2c_network.mu.weight, agent.model.a2c_network.mu.weight)
+
+
+def _ddp_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(100 + rank)  # different init + different env data per rank
+    env = FakeVecEnv(32, seed=rank)
+    agent = IMAmpAgent(env, small_cfg(), dist=dist, bf16=False)
+    agent.init_train()
+    for _ in range(2):
+        agent.train_epoch()
+    flat = torch.cat([p.data.flatten() for p in agent.model.parameters()])
+    gather = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(gather, flat)
+    stats = torch.cat([agent.running_mean_std.running_mean, agent.running_mean_std.running_var])
+    sg = [torch.zeros_like(stats) for _ in range(world)]
+    dist.all_gather(sg, stats)
+    if rank == 0:
+        q.put((bool(torch.equal(gather[0], gather[1])), bool(torch.allclose(sg[0], sg[1])), float(flat.abs().sum())))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_gradient_allreduce_keeps_replicas_identical():
+    """N>1 path on CPU: broadcast of initial params, one flat-bucket all-reduce(mean) per optimizer step, running-stat sync."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 500)
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=240)
+        assert p.exitcode == 0
+    same_params, same_stats, norm = q.get(timeout=10)
+    assert same_params, "replicas diverged: the gradient all-reduce is not keeping them in lock-step"
+    assert same_stats and norm > 0
+
+
+def test_flat_grad_bucket_is_one_buffer():
+    lin = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.Linear(3, 2))
+    b = FlatGradBucket(lin.parameters())
+    lin(torch.randn(5, 4)).sum().backward()
+    assert b.flat.numel() == 4 * 3 + 3 + 3 * 2 + 2 and b.flat.abs().sum() > 0
+    assert lin[0].weight.grad.data_ptr() == b.flat.data_ptr()
+    b.zero()
+    assert lin[1].bias.grad.abs().sum() == 0
