@@ -103,15 +103,37 @@ def cpu_baseline(num_envs=4096, steps=100):
         e.emu_im_post_physics(P(mstruct), P(lstruct), P(prm), P(sim), P(buf))
         return 1 - cur
 
+    def usable_cores():
+        n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        try:  # container CPU quota (cgroup v2), which sched_getaffinity does not show
+            q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+            if q != "max":
+                n = max(1, min(n, int(float(q) / float(per) + 0.5)))
+        except Exception:
+            pass
+        return n
+
+    def rate(threads, nsteps, cur):
+        e.emu_set_threads(int(threads))
+        t0 = time.perf_counter()
+        for _ in range(nsteps):
+            cur = one(cur)
+        return N * nsteps / (time.perf_counter() - t0), cur
+
     cur = one(0)
+    cores = usable_cores()
+    cands = sorted({c for c in (1, 4, 8, 16, 32, 64, 128, cores) if c <= cores})
+    best, best_rate = 1, 0.0
+    for c in cands:  # short calibration: oversubscribed or quota-limited hosts are common in containers
+        r, cur = rate(c, 2, cur)
+        if r > best_rate:
+            best, best_rate = c, r
     t0 = time.perf_counter()
-    for _ in range(steps):
-        cur = one(cur)
+    val, cur = rate(best, steps, cur)
     dt = time.perf_counter() - t0
-    cores = os.cpu_count() or 1
-    return {"value": N * steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{steps} steps x {N} envs (reset+stepper+post-physics), g++ -O2 -fopenmp build of the kernels' per-lane code, "
-                      f"{dt:.1f} s on {cores} host threads"}
+    return {"value": val, "unit": "env-steps/s", "cores": best, "kind": "port",
+            "sample": f"{steps} steps x {N} envs (reset+stepper+post-physics), g++ -O2 -fopenmp build of the kernels' per-lane code "
+                      f"(oracle/hostemu), {dt:.1f} s wall on {best} OpenMP threads (best of {cands}; host reports {os.cpu_count()} cpus)"}
 
 
 def main():

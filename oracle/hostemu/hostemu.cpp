@@ -5,12 +5,16 @@
 // The product never loads this library: phc_amd/_lib.py only ever opens libphc_amd.so.
 #include <cstring>
 #include <vector>
+#include <omp.h>
 #include "../../phc_amd/csrc/phc_aba.h"
 #include "../../phc_amd/csrc/phc_im.h"
 
 using namespace phc;
 
 extern "C" {
+
+void emu_set_threads(int n) { omp_set_num_threads(n > 0 ? n : 1); }
+int emu_max_threads(void) { return omp_get_max_threads(); }
 
 int emu_motion_state(const phc_motion_lib_t* lib, int n, const int64_t* ids, const float* times, const float* offset,
                      float* rg_pos, float* rb_rot, float* body_vel, float* body_ang_vel, float* dof_pos, float* dof_vel,
@@ -65,6 +69,7 @@ int emu_im_post_physics(const phc_model_t* model, const phc_motion_lib_t* lib, c
 
 int emu_im_reset(const phc_model_t* model, const phc_motion_lib_t* lib, const phc_im_params_t* prm, const phc_sim_state_t* sim,
                  const phc_im_buffers_t* buf, int num_reset, const int64_t* env_ids, const float* phase, int start_at_zero) {
+#pragma omp parallel for schedule(dynamic, 8)
     for (int r = 0; r < num_reset; ++r) {
         const int64_t env = env_ids ? env_ids[r] : r;
         if (!env_ids && buf->reset_buf[env] == 0) continue;
