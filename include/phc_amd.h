@@ -172,7 +172,8 @@ int32_t phc_im_post_physics(const phc_model_t* model, const phc_motion_lib_t* li
  * state on root/dof/body tensors and PD targets, zero progress/reset/terminate/contact, recompute
  * obs for those envs, and rebuild their AMP history from the reference motion.
  * env_ids == NULL selects the MASKED mode: num_reset must be num_envs, phase is [num_envs], and exactly the envs
- * with reset_buf != 0 are reset (lets a rollout loop reset done envs without a device->host sync). */
+ * with reset_buf != 0 are reset (lets a rollout loop reset done envs without a device->host sync); in this mode
+ * reset_buf itself is left untouched (the caller zeroes it after the launch). */
 int32_t phc_im_reset(const phc_model_t* model, const phc_motion_lib_t* lib, const phc_im_params_t* prm,
                      const phc_sim_state_t* sim, const phc_im_buffers_t* buf, int32_t num_reset,
                      const int64_t* env_ids, const float* phase /*[num_reset]*/, int32_t start_at_zero, void* stream);

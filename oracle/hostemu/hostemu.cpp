@@ -75,7 +75,9 @@ int emu_im_reset(const phc_model_t* model, const phc_motion_lib_t* lib, const ph
         if (!env_ids && buf->reset_buf[env] == 0) continue;
         const int64_t mid = buf->sampled_motion_ids[env];
         const float t = start_at_zero ? 0.f : sample_time_interval(*lib, mid, phase[r]);
-        for (int lane = 31; lane >= 0; --lane) im_reset_lane(*model, *lib, *prm, *sim, *buf, env, lane, t);
+        for (int k = 0; k < prm->num_amp_obs_steps; ++k)
+            for (int lane = 0; lane < 32; ++lane) im_reset_amp_lane(*lib, *prm, *buf, model->num_bodies, env, lane, t, k);
+        for (int lane = 31; lane >= 0; --lane) im_reset_lane(*model, *lib, *prm, *sim, *buf, env, lane, t, true);
     }
     return 0;
 }
@@ -115,18 +117,18 @@ int emu_sim_step(const phc_model_t* model, const phc_sim_params_t* prm, const ph
             aba_load_state(L[j], *sim, nd, env, j);
         }
         const int ml = model->max_level;
+        Xch x;
+        x.base = xch.data(); x.bs = PHC_XCH_STRIDE; x.es = 1;
+        for (int l = 0; l <= ml; ++l) for (int j = 0; j < nb; ++j) aba_fk_level(L[j], l, j, x);
         if (do_step) {
             const float dt = prm->sim_dt / (float)prm->substeps;
             const int nsub = num_sim_calls * prm->substeps;
             for (int s = 0; s < nsub; ++s) {
-                for (int l = 0; l <= ml; ++l) for (int j = 0; j < nb; ++j) aba_fk_level(L[j], l, j, xch.data());
-                for (int j = 0; j < nb; ++j) aba_body_init(L[j], *model, *prm, dt);
-                for (int l = ml; l >= 0; --l) for (int j = 0; j < nb; ++j) aba_backward_level(L[j], l, j, xch.data());
-                for (int l = 0; l <= ml; ++l) for (int j = 0; j < nb; ++j) aba_forward_level(L[j], l, j, xch.data());
-                for (int j = 0; j < nb; ++j) aba_integrate(L[j], *prm, dt);
+                for (int j = 0; j < nb; ++j) aba_body_init(L[j], *model, *prm, dt, j);
+                for (int l = ml; l >= 0; --l) for (int j = 0; j < nb; ++j) aba_backward_level(L[j], l, j, x);
+                for (int l = 0; l <= ml; ++l) for (int j = 0; j < nb; ++j) aba_forward_level(L[j], l, j, x, *prm, dt);
             }
         }
-        for (int l = 0; l <= ml; ++l) for (int j = 0; j < nb; ++j) aba_fk_level(L[j], l, j, xch.data());
         for (int j = 0; j < nb; ++j) {
             if (do_step) aba_store_state(L[j], *sim, nd, env, j);
             aba_publish_body(L[j], *sim, nb, env, j, do_step != 0);

@@ -9,7 +9,8 @@
 //     (fp32-friendly), and the spherical-joint motion subspace is simply S = [1_3; 0].
 //   * the three sweeps (kinematics root->leaves, articulated inertia leaves->root, accelerations
 //     root->leaves) run level-synchronously: at tree level l only the lanes whose body sits at
-//     level l work; parent/child hand-off goes through a 28-float LDS slot per body.
+//     level l work; parent/child hand-off goes through a 28-float LDS slot per body.  A sub-step is TWO sweeps:
+//     the accelerations sweep also integrates each joint and produces the next kinematics on its way down.
 //   * everything stiff is integrated LINEARLY IMPLICITLY by augmenting the articulated inertia:
 //       - PD drive (kp,kd) + armature:  D += R diag(armature + dt*kd + dt^2*kp) R^T,
 //         tau_explicit = clamp(kp*err, +-effort) - (kd + dt*kp)*w_joint   (Isaac Gym "isaac_pd" drive, S8)
@@ -27,7 +28,7 @@ namespace phc {
 
 #define PHC_XCH_STRIDE 28      // floats per exchange slot
 #define PHC_BODY_FLOATS 28     // floats per body in phc_model_t.floats (model.py pack())
-#define PHC_NTAB 10            // int tables per model
+#define PHC_NTAB 11            // int tables per model (parent level jtype dof_start child0-2 nchild cp_start cp_count order)
 
 struct Sym3 { float xx, xy, xz, yy, yz, zz; };
 
@@ -92,13 +93,10 @@ PHC_HD V3 Bt_mul(const float* B, V3 v) {
 
 // Per-lane registers of the stepper.
 struct AbaLane {
-    // --- constants (model) ---
-    int parent, level, jtype, dof_start, nchild, child[3], cp_start, cp_count;
+    // --- constants (model); everything only body_init needs (mass, inertia, gains, contact points) is re-read
+    //     from the L2-resident model there instead of being pinned in registers across the sweeps ---
+    int parent, level, dof_start, nchild, child[3];
     V3 r_local;       // offset from parent origin, parent frame
-    float mass;
-    V3 mc_b;          // mass * com, body frame
-    Sym3 Io_b;        // inertia about body origin, body frame
-    V3 kp, kd, arm, effort;
     // --- state ---
     Q4 q;             // joint rotation child-in-parent (root: world rotation)
     V3 wj;            // joint velocity, child frame (root: unused)
@@ -109,9 +107,9 @@ struct AbaLane {
     // --- articulated quantities kept between the sweeps ---
     Inertia6 IA; Force6 pA;
     Sym3 Di; V3 u;    // D^-1 and tau_w - p_omega
-    V3 alpha, a;      // accelerations
     V3 tau_local;     // explicit joint torque (child frame), for dof_force publication
-    V3 dimp;          // implicit diagonal (armature + dt kd + dt^2 kp), child frame
+    V3 dimp;          // implicit PD diagonal dt kd + dt^2 kp (WITHOUT the armature), child frame
+    V3 arm;           // armature
     V3 fcontact;      // net explicit contact force on the body (S4)
 };
 
@@ -119,15 +117,13 @@ PHC_HD const float* model_body(const phc_model_t& m, int j) { return m.floats + 
 PHC_HD int model_tab(const phc_model_t& m, int table, int j) { return m.ints[4 + table * PHC_MAX_BODIES + j]; }
 
 PHC_HD void aba_load_model(AbaLane& L, const phc_model_t& m, int j) {
-    L.parent = model_tab(m, 0, j); L.level = model_tab(m, 1, j); L.jtype = model_tab(m, 2, j);
+    L.parent = model_tab(m, 0, j); L.level = model_tab(m, 1, j);
     L.dof_start = model_tab(m, 3, j);
     L.child[0] = model_tab(m, 4, j); L.child[1] = model_tab(m, 5, j); L.child[2] = model_tab(m, 6, j);
-    L.nchild = model_tab(m, 7, j); L.cp_start = model_tab(m, 8, j); L.cp_count = model_tab(m, 9, j);
+    L.nchild = model_tab(m, 7, j);
     const float* f = model_body(m, j);
-    L.r_local = v3(f[0], f[1], f[2]); L.mass = f[3]; L.mc_b = v3(f[4], f[5], f[6]);
-    L.Io_b.xx = f[7]; L.Io_b.xy = f[8]; L.Io_b.xz = f[9]; L.Io_b.yy = f[10]; L.Io_b.yz = f[11]; L.Io_b.zz = f[12];
-    L.kp = v3(f[13], f[14], f[15]); L.kd = v3(f[16], f[17], f[18]);
-    L.arm = v3(f[19], f[20], f[21]); L.effort = v3(f[22], f[23], f[24]);
+    L.r_local = v3(f[0], f[1], f[2]);
+    L.arm = v3(f[19], f[20], f[21]);
 }
 
 // State load: S1 root_states [N,13], S2 dof_state [N,D,2] (exp-map, joint velocity), S8 pd_target [N,D]
@@ -147,51 +143,71 @@ PHC_HD void aba_load_state(AbaLane& L, const phc_sim_state_t& s, int nd, int64_t
     }
 }
 
-// ---- sweep 1: kinematics, one tree level.  Slot layout: Q(4) p(3) w(3) v(3). ----
-PHC_HD void aba_fk_level(AbaLane& L, int level, int j, float* xch) {
+// Exchange buffer addressing: body b's slot starts at base + b*bs, its k-th float sits at [k*es].
+//   32-lane-per-env mapping (host emulation): bs = 28, es = 1
+//   level-major mapping (k_sim_step): lanes of one wavefront hold the SAME body of E different envs, the slot is
+//   stored env-fastest (bs = 28*E, es = E, base = block base + env_local) -> conflict-free LDS access.
+struct Xch { float* base; int bs; int es; };
+PHC_HD float* xslot(const Xch& x, int body) { return x.base + body * x.bs; }
+
+// new kinematics of body (level > 0) from its parent's: shared by the initial sweep and the merged forward sweep
+PHC_HD void aba_kinematics_from_parent(AbaLane& L, Q4 Qp, V3 pp, V3 wp, V3 vp) {
+    L.rw = quat_rotate(Qp, L.r_local);
+    L.p = pp + L.rw;
+    L.Q = quat_normalize(quat_mul16(Qp, L.q));
+    V3 wJw = quat_rotate(L.Q, L.wj);
+    L.w = wp + wJw;
+    L.v = vp + cross(wp, L.rw);
+    L.cw = cross(wp, wJw);
+    L.ca = cross(wp, cross(wp, L.rw));
+}
+PHC_HD void aba_write_kin(const AbaLane& L, float* s, int es, int o) {
+    s[(o + 0) * es] = L.Q.x; s[(o + 1) * es] = L.Q.y; s[(o + 2) * es] = L.Q.z; s[(o + 3) * es] = L.Q.w;
+    s[(o + 4) * es] = L.p.x; s[(o + 5) * es] = L.p.y; s[(o + 6) * es] = L.p.z;
+    s[(o + 7) * es] = L.w.x; s[(o + 8) * es] = L.w.y; s[(o + 9) * es] = L.w.z;
+    s[(o + 10) * es] = L.v.x; s[(o + 11) * es] = L.v.y; s[(o + 12) * es] = L.v.z;
+}
+
+// ---- initial kinematics sweep (once per launch), one tree level.  Slot layout: [6..19) = Q(4) p(3) w(3) v(3). ----
+PHC_HD void aba_fk_level(AbaLane& L, int level, int j, const Xch& x) {
     if (L.level != level) return;
+    const int es = x.es;
     if (level == 0) {
         L.Q = L.q; L.p = L.p0; L.w = L.w0; L.v = L.v0;
         L.rw = L.cw = L.ca = v3(0.f, 0.f, 0.f);
     } else {
-        const float* ps = xch + L.parent * PHC_XCH_STRIDE;
-        Q4 Qp = q4(ps[0], ps[1], ps[2], ps[3]);
-        V3 pp = v3(ps[4], ps[5], ps[6]), wp = v3(ps[7], ps[8], ps[9]), vp = v3(ps[10], ps[11], ps[12]);
-        L.rw = quat_rotate(Qp, L.r_local);
-        L.p = pp + L.rw;
-        L.Q = quat_normalize(quat_mul16(Qp, L.q));
-        V3 wJw = quat_rotate(L.Q, L.wj);
-        L.w = wp + wJw;
-        L.v = vp + cross(wp, L.rw);
-        L.cw = cross(wp, wJw);
-        L.ca = cross(wp, cross(wp, L.rw));
+        const float* ps = xslot(x, L.parent);
+        aba_kinematics_from_parent(L, q4(ps[6 * es], ps[7 * es], ps[8 * es], ps[9 * es]), v3(ps[10 * es], ps[11 * es], ps[12 * es]),
+                                   v3(ps[13 * es], ps[14 * es], ps[15 * es]), v3(ps[16 * es], ps[17 * es], ps[18 * es]));
     }
-    float* s = xch + j * PHC_XCH_STRIDE;
-    s[0] = L.Q.x; s[1] = L.Q.y; s[2] = L.Q.z; s[3] = L.Q.w;
-    s[4] = L.p.x; s[5] = L.p.y; s[6] = L.p.z; s[7] = L.w.x; s[8] = L.w.y; s[9] = L.w.z;
-    s[10] = L.v.x; s[11] = L.v.y; s[12] = L.v.z;
+    aba_write_kin(L, xslot(x, j), es, 6);
 }
 
 // ---- per-body initialisation of I^A, p^A and of the joint drive (no communication) ----
-PHC_HD void aba_body_init(AbaLane& L, const phc_model_t& m, const phc_sim_params_t& prm, float dt) {
+PHC_HD void aba_body_init(AbaLane& L, const phc_model_t& m, const phc_sim_params_t& prm, float dt, int j) {
+    const float* f = model_body(m, j);
+    const float mass = f[3];
+    Sym3 Io_b;
+    Io_b.xx = f[7]; Io_b.xy = f[8]; Io_b.xz = f[9]; Io_b.yy = f[10]; Io_b.yz = f[11]; Io_b.zz = f[12];
     M3 R = quat_to_mat(L.Q);
-    Sym3 Io = rot_sym(R, L.Io_b);
-    V3 mc = mat_mul(R, L.mc_b);
+    Sym3 Io = rot_sym(R, Io_b);
+    V3 mc = mat_mul(R, v3(f[4], f[5], f[6]));
     // rigid-body inertia about the origin: [[Io, [mc]x], [[mc]x^T, m 1]]
     L.IA.A = Io;
     L.IA.B[0] = 0.f;   L.IA.B[1] = -mc.z; L.IA.B[2] = mc.y;
     L.IA.B[3] = mc.z;  L.IA.B[4] = 0.f;   L.IA.B[5] = -mc.x;
     L.IA.B[6] = -mc.y; L.IA.B[7] = mc.x;  L.IA.B[8] = 0.f;
-    L.IA.C.xx = L.IA.C.yy = L.IA.C.zz = L.mass; L.IA.C.xy = L.IA.C.xz = L.IA.C.yz = 0.f;
+    L.IA.C.xx = L.IA.C.yy = L.IA.C.zz = mass; L.IA.C.xy = L.IA.C.xz = L.IA.C.yz = 0.f;
     // bias force + gravity (external forces enter p^A with a minus sign)
     V3 g = v3(0.f, 0.f, prm.gravity_z);
     L.pA.n = cross(L.w, sym_mul(Io, L.w)) - cross(mc, g);
-    L.pA.f = cross(L.w, cross(L.w, mc)) - g * L.mass;
+    L.pA.f = cross(L.w, cross(L.w, mc)) - g * mass;
     // ground contact: plane z = 0, normal +z
     L.fcontact = v3(0.f, 0.f, 0.f);
     const float cn = prm.contact_stiffness * dt + prm.contact_damping;
-    const float* cp = m.floats + PHC_MAX_BODIES * PHC_BODY_FLOATS + L.cp_start * 4;
-    for (int k = 0; k < L.cp_count; ++k) {
+    const float* cp = m.floats + PHC_MAX_BODIES * PHC_BODY_FLOATS + model_tab(m, 8, j) * 4;
+    const int cp_count = model_tab(m, 9, j);
+    for (int k = 0; k < cp_count; ++k) {
         V3 arm = mat_mul(R, v3(cp[4 * k], cp[4 * k + 1], cp[4 * k + 2]));
         float rad = cp[4 * k + 3];
         float depth = rad - (L.p.z + arm.z);
@@ -230,19 +246,17 @@ PHC_HD void aba_body_init(AbaLane& L, const phc_model_t& m, const phc_sim_params
         // effort limit (gear=500): the SPRING term saturates; the damping term stays fully implicit, so a saturated
         // drive can never inject energy (a hard clamp of the total would turn the drive into a constant torque on a
         // 0.02 kg m^2 armature -> 1e4 rad/s^2)
-        V3 sp = v3(fminf(fmaxf(L.kp.x * err.x, -L.effort.x), L.effort.x), fminf(fmaxf(L.kp.y * err.y, -L.effort.y), L.effort.y),
-                   fminf(fmaxf(L.kp.z * err.z, -L.effort.z), L.effort.z));
-        V3 tau = v3(sp.x - (L.kd.x + dt * L.kp.x) * L.wj.x, sp.y - (L.kd.y + dt * L.kp.y) * L.wj.y,
-                    sp.z - (L.kd.z + dt * L.kp.z) * L.wj.z);
-        V3 d = v3(L.arm.x + dt * L.kd.x + dt * dt * L.kp.x, L.arm.y + dt * L.kd.y + dt * dt * L.kp.y,
-                  L.arm.z + dt * L.kd.z + dt * dt * L.kp.z);
+        const V3 kp = v3(f[13], f[14], f[15]), kd = v3(f[16], f[17], f[18]), eff = v3(f[22], f[23], f[24]);
+        V3 sp = v3(fminf(fmaxf(kp.x * err.x, -eff.x), eff.x), fminf(fmaxf(kp.y * err.y, -eff.y), eff.y), fminf(fmaxf(kp.z * err.z, -eff.z), eff.z));
+        V3 tau = v3(sp.x - (kd.x + dt * kp.x) * L.wj.x, sp.y - (kd.y + dt * kp.y) * L.wj.y, sp.z - (kd.z + dt * kp.z) * L.wj.z);
+        V3 d = v3(dt * kd.x + dt * dt * kp.x, dt * kd.y + dt * dt * kp.y, dt * kd.z + dt * dt * kp.z);
         L.tau_local = tau;
         L.dimp = d;
     }
 }
 
 // 6x6 congruence T^T I T and T^T p for a pure translation r (child origin - parent origin)
-PHC_HD void shift_to_parent(const Inertia6& I, const Force6& p, V3 r, float* out /*27*/) {
+PHC_HD void shift_to_parent(const Inertia6& I, const Force6& p, V3 r, float* out /*27 floats, stride es*/, int es) {
     // Y = [r]x C ; B' = B + Y
     V3 c0 = v3(I.C.xx, I.C.xy, I.C.xz), c1 = v3(I.C.xy, I.C.yy, I.C.yz), c2 = v3(I.C.xz, I.C.yz, I.C.zz);
     V3 y0 = cross(r, c0), y1 = cross(r, c1), y2 = cross(r, c2);  // columns of Y
@@ -256,35 +270,35 @@ PHC_HD void shift_to_parent(const Inertia6& I, const Force6& p, V3 r, float* out
     V3 bp0 = v3(Bp[0], Bp[1], Bp[2]), bp1 = v3(Bp[3], Bp[4], Bp[5]), bp2 = v3(Bp[6], Bp[7], Bp[8]);
     V3 z0 = cross(r, bp0), z1 = cross(r, bp1), z2 = cross(r, bp2);  // columns of Z = [r]x B'^T
     // (X^T)_{ij} = X_{ji} = (x_i)_j ; Z_{ij} = (z_j)_i
-    out[0] = I.A.xx + x0.x + z0.x;
-    out[1] = I.A.xy + x0.y + z1.x;
-    out[2] = I.A.xz + x0.z + z2.x;
-    out[3] = I.A.yy + x1.y + z1.y;
-    out[4] = I.A.yz + x1.z + z2.y;
-    out[5] = I.A.zz + x2.z + z2.z;
-    for (int k = 0; k < 9; ++k) out[6 + k] = Bp[k];
-    out[15] = I.C.xx; out[16] = I.C.xy; out[17] = I.C.xz; out[18] = I.C.yy; out[19] = I.C.yz; out[20] = I.C.zz;
+    out[0 * es] = I.A.xx + x0.x + z0.x;
+    out[1 * es] = I.A.xy + x0.y + z1.x;
+    out[2 * es] = I.A.xz + x0.z + z2.x;
+    out[3 * es] = I.A.yy + x1.y + z1.y;
+    out[4 * es] = I.A.yz + x1.z + z2.y;
+    out[5 * es] = I.A.zz + x2.z + z2.z;
+    for (int k = 0; k < 9; ++k) out[(6 + k) * es] = Bp[k];
+    out[15 * es] = I.C.xx; out[16 * es] = I.C.xy; out[17 * es] = I.C.xz; out[18 * es] = I.C.yy; out[19 * es] = I.C.yz; out[20 * es] = I.C.zz;
     V3 n = p.n + cross(r, p.f);
-    out[21] = n.x; out[22] = n.y; out[23] = n.z; out[24] = p.f.x; out[25] = p.f.y; out[26] = p.f.z;
+    out[21 * es] = n.x; out[22 * es] = n.y; out[23 * es] = n.z; out[24 * es] = p.f.x; out[25 * es] = p.f.y; out[26 * es] = p.f.z;
 }
 
-PHC_HD void accumulate_child(Inertia6& I, Force6& p, const float* s) {
-    I.A.xx += s[0]; I.A.xy += s[1]; I.A.xz += s[2]; I.A.yy += s[3]; I.A.yz += s[4]; I.A.zz += s[5];
-    for (int k = 0; k < 9; ++k) I.B[k] += s[6 + k];
-    I.C.xx += s[15]; I.C.xy += s[16]; I.C.xz += s[17]; I.C.yy += s[18]; I.C.yz += s[19]; I.C.zz += s[20];
-    p.n.x += s[21]; p.n.y += s[22]; p.n.z += s[23]; p.f.x += s[24]; p.f.y += s[25]; p.f.z += s[26];
+PHC_HD void accumulate_child(Inertia6& I, Force6& p, const float* s, int es) {
+    I.A.xx += s[0 * es]; I.A.xy += s[1 * es]; I.A.xz += s[2 * es]; I.A.yy += s[3 * es]; I.A.yz += s[4 * es]; I.A.zz += s[5 * es];
+    for (int k = 0; k < 9; ++k) I.B[k] += s[(6 + k) * es];
+    I.C.xx += s[15 * es]; I.C.xy += s[16 * es]; I.C.xz += s[17 * es]; I.C.yy += s[18 * es]; I.C.yz += s[19 * es]; I.C.zz += s[20 * es];
+    p.n.x += s[21 * es]; p.n.y += s[22 * es]; p.n.z += s[23 * es]; p.f.x += s[24 * es]; p.f.y += s[25 * es]; p.f.z += s[26 * es];
 }
 
-// ---- sweep 2: articulated inertia, one tree level (leaves -> root) ----
+// ---- backward sweep: articulated inertia, one tree level (leaves -> root) ----
 // Lanes at `level` first absorb their children's contributions (written at level+1), then, unless
 // they are the root, reduce over their own joint and publish T^T I^a T, T^T p^a for their parent.
-PHC_HD void aba_backward_level(AbaLane& L, int level, int j, float* xch) {
+PHC_HD void aba_backward_level(AbaLane& L, int level, int j, const Xch& x) {
     if (L.level != level) return;
     for (int k = 0; k < 3; ++k)
-        if (k < L.nchild) accumulate_child(L.IA, L.pA, xch + L.child[k] * PHC_XCH_STRIDE);
+        if (k < L.nchild) accumulate_child(L.IA, L.pA, xslot(x, L.child[k]), x.es);
     if (level == 0) return;
     M3 R = quat_to_mat(L.Q);
-    Sym3 D = rot_diag(R, L.dimp);
+    Sym3 D = rot_diag(R, L.dimp + L.arm);
     D.xx += L.IA.A.xx; D.xy += L.IA.A.xy; D.xz += L.IA.A.xz; D.yy += L.IA.A.yy; D.yz += L.IA.A.yz; D.zz += L.IA.A.zz;
     L.Di = sym_inv(D);
     L.u = mat_mul(R, L.tau_local) - L.pA.n;
@@ -311,12 +325,17 @@ PHC_HD void aba_backward_level(AbaLane& L, int level, int j, float* xch) {
     Force6 pa;
     pa.n = L.pA.n + sym_mul(Ia.A, L.cw) + B_mul(Ia.B, L.ca) + sym_mul(A, du);
     pa.f = L.pA.f + Bt_mul(Ia.B, L.cw) + sym_mul(Ia.C, L.ca) + Bt_mul(B, du);
-    shift_to_parent(Ia, pa, L.rw, xch + j * PHC_XCH_STRIDE);
+    shift_to_parent(Ia, pa, L.rw, xslot(x, j), x.es);
 }
 
-// ---- sweep 3: accelerations, one tree level (root -> leaves).  Slot layout: alpha(3) a(3). ----
-PHC_HD void aba_forward_level(AbaLane& L, int level, int j, float* xch) {
+// ---- forward sweep, one tree level (root -> leaves): accelerations, semi-implicit Euler on this body's joint, and
+// the NEW kinematics (from the parent's new kinematics) in the same pass -- the separate integration step and the next
+// sub-step's kinematics sweep are folded in, so a sub-step is two sweeps.  Slot: alpha(3) a(3) | Q(4) p(3) w(3) v(3).
+PHC_HD void aba_forward_level(AbaLane& L, int level, int j, const Xch& x, const phc_sim_params_t& prm, float dt) {
     if (L.level != level) return;
+    const int es = x.es;
+    const float damp = 1.0f / (1.0f + dt * prm.angular_damping);
+    V3 alpha, a;
     if (level == 0) {
         // free root: [A B; B^T C] [alpha; a] = -[n; f]  by block elimination on C
         Sym3 Ci = sym_inv(L.IA.C);
@@ -331,43 +350,36 @@ PHC_HD void aba_forward_level(AbaLane& L, int level, int j, float* xch) {
         S.xx = L.IA.A.xx - dot(w0, br0); S.xy = L.IA.A.xy - dot(w0, br1); S.xz = L.IA.A.xz - dot(w0, br2);
         S.yy = L.IA.A.yy - dot(w1, br1); S.yz = L.IA.A.yz - dot(w1, br2); S.zz = L.IA.A.zz - dot(w2, br2);
         V3 rhs = v3(-L.pA.n.x + dot(w0, L.pA.f), -L.pA.n.y + dot(w1, L.pA.f), -L.pA.n.z + dot(w2, L.pA.f));
-        L.alpha = sym_mul(sym_inv(S), rhs);
-        L.a = -sym_mul(Ci, L.pA.f + Bt_mul(B, L.alpha));
-    } else {
-        const float* ps = xch + L.parent * PHC_XCH_STRIDE;
-        V3 alp = v3(ps[0], ps[1], ps[2]), ap = v3(ps[3], ps[4], ps[5]);
-        V3 al1 = alp + L.cw;
-        V3 a1 = ap + cross(alp, L.rw) + L.ca;
-        V3 beta = sym_mul(L.Di, L.u - sym_mul(L.IA.A, al1) - B_mul(L.IA.B, a1));
-        L.alpha = al1 + beta;
-        L.a = a1;
-        // joint acceleration in the child frame; semi-implicit Euler on the joint
-        // (done here so that `beta` need not be kept)
-        L.u = beta;  // reuse: world-frame joint angular acceleration
-    }
-    float* s = xch + j * PHC_XCH_STRIDE;
-    s[0] = L.alpha.x; s[1] = L.alpha.y; s[2] = L.alpha.z; s[3] = L.a.x; s[4] = L.a.y; s[5] = L.a.z;
-}
-
-// ---- integration (semi-implicit Euler), no communication ----
-PHC_HD void aba_integrate(AbaLane& L, const phc_sim_params_t& prm, float dt) {
-    const float damp = 1.0f / (1.0f + dt * prm.angular_damping);
-    if (L.level == 0) {
-        L.v0 = L.v0 + L.a * dt;
-        L.w0 = (L.w0 + L.alpha * dt) * damp;
+        alpha = sym_mul(sym_inv(S), rhs);
+        a = -sym_mul(Ci, L.pA.f + Bt_mul(B, alpha));
+        // integrate the root, new kinematics
+        L.v0 = L.v0 + a * dt;
+        L.w0 = (L.w0 + alpha * dt) * damp;
         L.p0 = L.p0 + L.v0 * dt;
         L.q = quat_normalize(quat_mul16(quat_from_rotvec(L.w0 * dt), L.q));
+        L.Q = L.q; L.p = L.p0; L.w = L.w0; L.v = L.v0;
     } else {
+        const float* ps = xslot(x, L.parent);
+        V3 alp = v3(ps[0 * es], ps[1 * es], ps[2 * es]), ap = v3(ps[3 * es], ps[4 * es], ps[5 * es]);
+        V3 al1 = alp + L.cw;
+        V3 a1 = ap + cross(alp, L.rw) + L.ca;
+        V3 beta = sym_mul(L.Di, L.u - sym_mul(L.IA.A, al1) - B_mul(L.IA.B, a1));  // world-frame joint angular acceleration
+        alpha = al1 + beta;
+        a = a1;
         M3 R = quat_to_mat(L.Q);
-        V3 qdd = mat_tmul(R, L.u);  // child-frame joint acceleration
+        V3 qdd = mat_tmul(R, beta);  // child-frame joint acceleration
         // torque actually applied over the step (explicit part minus the implicit augmentation), S5
-        L.tau_local = v3(L.tau_local.x - (L.dimp.x - L.arm.x) * qdd.x, L.tau_local.y - (L.dimp.y - L.arm.y) * qdd.y,
-                         L.tau_local.z - (L.dimp.z - L.arm.z) * qdd.z);
+        L.tau_local = v3(L.tau_local.x - L.dimp.x * qdd.x, L.tau_local.y - L.dimp.y * qdd.y, L.tau_local.z - L.dimp.z * qdd.z);
         L.wj = (L.wj + qdd * dt) * damp;
         float wn = norm(L.wj);
         if (wn > prm.max_angular_velocity) L.wj = L.wj * (prm.max_angular_velocity / wn);
         L.q = quat_normalize(quat_mul16(L.q, quat_from_rotvec(L.wj * dt)));
+        aba_kinematics_from_parent(L, q4(ps[6 * es], ps[7 * es], ps[8 * es], ps[9 * es]), v3(ps[10 * es], ps[11 * es], ps[12 * es]),
+                                   v3(ps[13 * es], ps[14 * es], ps[15 * es]), v3(ps[16 * es], ps[17 * es], ps[18 * es]));
     }
+    float* s = xslot(x, j);
+    s[0 * es] = alpha.x; s[1 * es] = alpha.y; s[2 * es] = alpha.z; s[3 * es] = a.x; s[4 * es] = a.y; s[5 * es] = a.z;
+    aba_write_kin(L, s, es, 6);
 }
 
 // ---- state store: S1/S2 (+S5 dof force), and S3/S4 publication from the last kinematics sweep ----

@@ -157,7 +157,7 @@ PHC_HD void im_post_finalize(const phc_motion_lib_t& lib, const phc_im_params_t&
 // Reset of one env, lane j: HumanoidIm._reset_envs (humanoid.py:585-621; humanoid_amp.py:378-398,508-528,
 // 559-637; humanoid_im.py:955-1023).  `t` = sampled start time.
 PHC_HD void im_reset_lane(const phc_model_t& model, const phc_motion_lib_t& lib, const phc_im_params_t& prm,
-                          const phc_sim_state_t& sim, const phc_im_buffers_t& buf, int64_t env, int j, float t) {
+                          const phc_sim_state_t& sim, const phc_im_buffers_t& buf, int64_t env, int j, float t, bool clear_reset_flag) {
     const int nb = model.num_bodies, nd = model.num_dof;
     const int64_t mid = buf.sampled_motion_ids[env];
     if (j < nb) {
@@ -197,17 +197,23 @@ PHC_HD void im_reset_lane(const phc_model_t& model, const phc_motion_lib_t& lib,
             st3(buf.ref_dof_pos + env * nd + model.ints[4 + 3 * PHC_MAX_BODIES + j], dp);
         }
     }
-    // AMP history: slot 0 from the (just imposed) state == reference at t; slots 1..S-1 from the
-    // reference motion at t - k dt (humanoid_amp.py:559-603)
-    const int A = prm.num_amp_obs_per_step, S = prm.num_amp_obs_steps;
-    float* amp = buf.amp_obs_out + env * (int64_t)(S * A);
-    for (int k = 0; k < S; ++k) amp_obs_from_ref_lane(lib, prm, nb, j, mid, history_time(t, prm.dt, k), amp + k * A);
     if (j == 0) {
         buf.motion_start_times[env] = t;           // humanoid_amp.py:524
         buf.motion_start_times_offset[env] = 0.f;  // humanoid_im.py:956
         st3(buf.global_offset + env * 3, v3(0.f, 0.f, 0.f));
-        buf.progress_buf[env] = 0; buf.reset_buf[env] = 0; buf.terminate_buf[env] = 0;  // humanoid.py:616-618
+        buf.progress_buf[env] = 0; buf.terminate_buf[env] = 0;  // humanoid.py:616-618
+        if (clear_reset_flag) buf.reset_buf[env] = 0;
     }
+}
+
+// AMP history frame k of a reset env: slot 0 from the (just imposed) state == reference at t; slots 1..S-1 from
+// the reference motion at t - k dt (humanoid_amp.py:559-603).  Independent of im_reset_lane, so the kernel gives
+// every (env, k) pair its own 32-lane group.
+PHC_HD void im_reset_amp_lane(const phc_motion_lib_t& lib, const phc_im_params_t& prm, const phc_im_buffers_t& buf, int nb,
+                              int64_t env, int j, float t, int k) {
+    const int A = prm.num_amp_obs_per_step, S = prm.num_amp_obs_steps;
+    float* amp = buf.amp_obs_out + env * (int64_t)(S * A);
+    amp_obs_from_ref_lane(lib, prm, nb, j, buf.sampled_motion_ids[env], history_time(t, prm.dt, k), amp + k * A);
 }
 
 }  // namespace phc

@@ -1,10 +1,10 @@
 // phc_kernels.hip -- gfx950 kernels + the extern "C" entry points declared in include/phc_amd.h.
 //
 // Thread mapping used by every env kernel: ONE LANE PER RIGID BODY, 32 lanes per environment,
-// two environments per 64-wide wavefront.  The stepper runs one wavefront per workgroup so that
-// its level-synchronous tree sweeps synchronise with a (free) single-wave barrier; the task
-// kernels use 256-thread workgroups (8 envs).  Per-env sums use 32-lane butterfly shuffles.
+// two environments per 64-wide wavefront, in the task kernels (256-thread workgroups = 8 envs; per-env sums use
+// 32-lane butterfly shuffles).  The stepper uses a level-major variant of the same idea (see k_sim_step).
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include "phc_aba.h"
 #include "phc_im.h"
 
@@ -24,28 +24,33 @@ __device__ __forceinline__ int group_or(int v) {
 }
 
 // ------------------------------------------------------------------------------------------
-// S10: the stepper.  blockDim = 64 (one wavefront, two envs).
+// S10: the stepper.  LEVEL-MAJOR mapping: a workgroup owns E = 2^log2e environments; thread t handles body
+// order[t / E] (bodies sorted by tree level) of env (t % E).  The lanes of one wavefront therefore hold the SAME body
+// (or two neighbouring tree levels) of many envs, so at each level-step of a sweep only the wavefronts that own that
+// level execute it (wave-uniform skip) instead of every wavefront executing every level with 1/9 of its lanes.
+// Parent/child hand-off: LDS slots stored env-fastest (conflict-free), one workgroup barrier per level-step.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void wave_sync() { __syncthreads(); }  // single-wave workgroup: no cross-wave wait
-
-template <bool STEP>
-__global__ __launch_bounds__(64) void k_sim_step(phc_model_t model, phc_sim_params_t prm, phc_sim_state_t sim,
-                                                const float* __restrict__ actions, const float* __restrict__ pd_off,
-                                                const float* __restrict__ pd_scale, const int32_t* __restrict__ freeze,
-                                                int num_sim_calls) {
-    __shared__ float xch_all[2 * PHC_MAX_BODIES * PHC_XCH_STRIDE];
-    const int lane = threadIdx.x & (GRP - 1);
-    const int grp = threadIdx.x >> 5;
-    const int64_t env = (int64_t)blockIdx.x * 2 + grp;
-    float* xch = xch_all + grp * PHC_MAX_BODIES * PHC_XCH_STRIDE;
+template <bool STEP, int MAXT>
+__global__ __launch_bounds__(MAXT) void k_sim_step(phc_model_t model, phc_sim_params_t prm, phc_sim_state_t sim,
+                                                 const float* __restrict__ actions, const float* __restrict__ pd_off,
+                                                 const float* __restrict__ pd_scale, const int32_t* __restrict__ freeze,
+                                                 int num_sim_calls, int log2e) {
+    extern __shared__ __attribute__((aligned(16))) float xch_all[];
+    const int E = 1 << log2e;
+    const int slot = threadIdx.x >> log2e;
+    const int el = threadIdx.x & (E - 1);
+    const int64_t env = (int64_t)blockIdx.x * E + el;
     const int nb = model.num_bodies, nd = model.num_dof;
-    const bool active = env < sim.num_envs && lane < nb;
+    const bool active = slot < nb && env < sim.num_envs;
+    const int j = active ? model_tab(model, 10, slot) : 0;  // level-sorted body order
+    Xch x;
+    x.base = xch_all + el; x.bs = PHC_XCH_STRIDE * E; x.es = E;
 
     AbaLane L;
     L.level = -1;
     if (active) {
-        aba_load_model(L, model, lane);
-        if (STEP && actions != nullptr && lane >= 1) {
+        aba_load_model(L, model, j);
+        if (STEP && actions != nullptr && j >= 1) {
             // A2: pd_tar = offset + scale * action, frozen DoFs -> 0 (humanoid.py:1711-1713,1549-1554)
             for (int k = 0; k < 3; ++k) {
                 const int d = L.dof_start + k;
@@ -54,26 +59,50 @@ __global__ __launch_bounds__(64) void k_sim_step(phc_model_t model, phc_sim_para
                 sim.pd_target[env * nd + d] = t;
             }
         }
-        aba_load_state(L, sim, nd, env, lane);
+        aba_load_state(L, sim, nd, env, j);
     }
     const int max_level = model.max_level;
+    for (int l = 0; l <= max_level; ++l) { aba_fk_level(L, l, j, x); __syncthreads(); }
     if (STEP) {
         const float dt = prm.sim_dt / (float)prm.substeps;
         const int nsub = num_sim_calls * prm.substeps;
         for (int s = 0; s < nsub; ++s) {
-            for (int l = 0; l <= max_level; ++l) { aba_fk_level(L, l, lane, xch); wave_sync(); }
-            if (active) aba_body_init(L, model, prm, dt);
-            for (int l = max_level; l >= 0; --l) { aba_backward_level(L, l, lane, xch); wave_sync(); }
-            for (int l = 0; l <= max_level; ++l) { aba_forward_level(L, l, lane, xch); wave_sync(); }
-            if (active) aba_integrate(L, prm, dt);
+            if (active) aba_body_init(L, model, prm, dt, j);
+            for (int l = max_level; l >= 0; --l) { aba_backward_level(L, l, j, x); __syncthreads(); }
+            for (int l = 0; l <= max_level; ++l) { aba_forward_level(L, l, j, x, prm, dt); __syncthreads(); }
         }
     }
-    // S7: publish the end-of-step state (one more kinematics sweep on the integrated state)
-    for (int l = 0; l <= max_level; ++l) { aba_fk_level(L, l, lane, xch); wave_sync(); }
+    // S7: the last forward sweep already produced the end-of-step kinematics
     if (active) {
-        if (STEP) aba_store_state(L, sim, nd, env, lane);
-        aba_publish_body(L, sim, nb, env, lane, STEP);
+        if (STEP) aba_store_state(L, sim, nd, env, j);
+        aba_publish_body(L, sim, nb, env, j, STEP);
     }
+}
+
+static inline void sim_launch_geometry(const phc_model_t* m, int num_envs, int* log2e, int* threads, int* blocks, size_t* lds) {
+    // E envs per workgroup.  Default E = 16 (384 threads for the 24-body SMPL humanoid); PHC_SIM_LOG2E overrides for tuning.
+    int e = 4;
+    const char* ov = getenv("PHC_SIM_LOG2E");
+    if (ov) e = atoi(ov);
+    if (e < 3) e = 3;
+    while (e > 3 && (1 << e) * m->num_bodies > 512) --e;
+    *log2e = e;
+    const int E = 1 << e;
+    *threads = ((E * m->num_bodies + 63) / 64) * 64;
+    *blocks = (num_envs + E - 1) / E;
+    *lds = (size_t)PHC_MAX_BODIES * PHC_XCH_STRIDE * E * sizeof(float);
+}
+
+template <bool STEP>
+static void sim_launch(const phc_model_t* model, const phc_sim_params_t& prm, const phc_sim_state_t* sim, const float* actions,
+                       const float* off, const float* scale, const int32_t* freeze, int num_sim_calls, hipStream_t stream) {
+    int log2e, threads, blocks;
+    size_t lds;
+    sim_launch_geometry(model, sim->num_envs, &log2e, &threads, &blocks, &lds);
+    if (threads <= 256)
+        hipLaunchKernelGGL((k_sim_step<STEP, 256>), dim3(blocks), dim3(threads), lds, stream, *model, prm, *sim, actions, off, scale, freeze, num_sim_calls, log2e);
+    else
+        hipLaunchKernelGGL((k_sim_step<STEP, 512>), dim3(blocks), dim3(threads), lds, stream, *model, prm, *sim, actions, off, scale, freeze, num_sim_calls, log2e);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -94,20 +123,26 @@ __global__ __launch_bounds__(256) void k_im_post_physics(phc_model_t model, phc_
         im_post_finalize(lib, prm, buf, model.num_bodies, env, progress, s_pos, s_rot, s_vel, s_ang, s_pow, s_dist, fallen, n_reset_bodies);
 }
 
-// Reset of a list of envs.  blockDim = 256 (8 envs).
+// Reset of a list of envs.  One 32-lane group per (env, AMP history frame k): group k == 0 also imposes the state
+// and recomputes the observations.  blockDim = 256.
 __global__ __launch_bounds__(256) void k_im_reset(phc_model_t model, phc_motion_lib_t lib, phc_im_params_t prm, phc_sim_state_t sim,
                                                  phc_im_buffers_t buf, int num_reset, const int64_t* __restrict__ env_ids,
                                                  const float* __restrict__ phase, int start_at_zero) {
     const int lane = threadIdx.x & (GRP - 1);
-    const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
-    if (r >= num_reset) return;
-    // env_ids == NULL: masked mode over all envs (reset every env whose reset_buf is set) -- no host sync needed
+    const int64_t g = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+    const int S = prm.num_amp_obs_steps;
+    if (g >= (int64_t)num_reset * S) return;
+    const int64_t r = g / S;
+    const int k = (int)(g - r * S);
+    // env_ids == NULL: masked mode over all envs (reset every env whose reset_buf is set) -- no host sync needed.
+    // The flag is NOT cleared here (other groups of the same env still read it): the caller zeroes reset_buf afterwards.
     const int64_t env = env_ids ? env_ids[r] : r;
     if (!env_ids && buf.reset_buf[env] == 0) return;
     const int64_t mid = buf.sampled_motion_ids[env];
     // _sample_ref_state (humanoid_im.py:1000-1023): StateInit.Random -> sample_time_interval; Start / flags.test -> 0
     const float t = start_at_zero ? 0.f : sample_time_interval(lib, mid, phase[r]);
-    im_reset_lane(model, lib, prm, sim, buf, env, lane, t);
+    if (k == 0) im_reset_lane(model, lib, prm, sim, buf, env, lane, t, env_ids != nullptr);
+    im_reset_amp_lane(lib, prm, buf, model.num_bodies, env, lane, t, k);
 }
 
 // build_amp_obs_demo: n samples x S history steps.  One 32-lane group per (sample, step).
@@ -250,8 +285,7 @@ int32_t phc_sim_step(const phc_model_t* model, const phc_sim_params_t* params, c
     if (!params || !sim || sim->num_envs < 0 || params->substeps < 1 || num_sim_calls < 0) return PHC_EINVAL;
     if (actions && (!pd_action_offset || !pd_action_scale)) return PHC_EINVAL;
     if (sim->num_envs == 0) return 0;
-    hipLaunchKernelGGL(k_sim_step<true>, dim3((sim->num_envs + 1) / 2), dim3(64), 0, (hipStream_t)stream, *model, *params, *sim,
-                       actions, pd_action_offset, pd_action_scale, freeze_mask, num_sim_calls);
+    sim_launch<true>(model, *params, sim, actions, pd_action_offset, pd_action_scale, freeze_mask, num_sim_calls, (hipStream_t)stream);
     return launch_status();
 }
 
@@ -262,8 +296,7 @@ int32_t phc_refresh_body_state(const phc_model_t* model, const phc_sim_state_t* 
     if (sim->num_envs == 0) return 0;
     phc_sim_params_t prm = {};
     prm.substeps = 1;
-    hipLaunchKernelGGL(k_sim_step<false>, dim3((sim->num_envs + 1) / 2), dim3(64), 0, (hipStream_t)stream, *model, prm, *sim,
-                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const int32_t*)nullptr, 0);
+    sim_launch<false>(model, prm, sim, nullptr, nullptr, nullptr, nullptr, 0, (hipStream_t)stream);
     return launch_status();
 }
 
@@ -295,7 +328,7 @@ int32_t phc_im_reset(const phc_model_t* model, const phc_motion_lib_t* lib, cons
     if (rc) return rc;
     if (!sim || !buf || num_reset < 0 || (!start_at_zero && !phase)) return PHC_EINVAL;
     if (num_reset == 0) return 0;
-    hipLaunchKernelGGL(k_im_reset, dim3(env_blocks(num_reset, 256)), dim3(256), 0, (hipStream_t)stream, *model, *lib, *prm, *sim,
+    hipLaunchKernelGGL(k_im_reset, dim3(env_blocks((int64_t)num_reset * prm->num_amp_obs_steps, 256)), dim3(256), 0, (hipStream_t)stream, *model, *lib, *prm, *sim,
                        *buf, num_reset, env_ids, phase, start_at_zero);
     return launch_status();
 }

@@ -492,6 +492,7 @@ class HumanoidIm:
         buf = self._buffers(cur, cur)
         L.check(self._lib.phc_im_reset(self._model_struct, self._motion_lib.struct, self._im_params, self._sim_struct, buf, self.num_envs,
                                        None, phase.data_ptr(), int(bool(start_at_zero)), _stream()), "phc_im_reset")
+        self.reset_buf.zero_()  # only the envs just reset had the flag set (humanoid.py:617)
 
     # ------------------------------------------------------------------ AMP demo observations (humanoid_amp.py:215-284)
     def fetch_amp_obs_demo(self, num_samples):

@@ -262,15 +262,15 @@ class ArticulationModel:
 
         ints  : [0]=NB [1]=ND [2]=max_level [3]=NCP then per body (32 slots each):
                 parent, level, joint_type, dof_start, child0, child1, child2, nchild,
-                cp_start, cp_count
+                cp_start, cp_count, order (bodies sorted by level)
         floats: per body (32 slots x 24): r_local[3], mass, m*com[3], Io(xx,xy,xz,yy,yz,zz)[6],
                 kp[3], kd[3], armature[3], effort[3], axis[3] (revolute) ;
                 then contact points NCP x 4 (pos[3], radius)
         """
         NB, MB = self.num_bodies, self.MAX_BODIES
-        ints = np.zeros(4 + 10 * MB, dtype=np.int32)
+        ints = np.zeros(4 + 11 * MB, dtype=np.int32)
         ints[0:4] = [NB, self.num_dof, self.max_level, len(self.contact_body)]
-        tab = ints[4:].reshape(10, MB)
+        tab = ints[4:].reshape(11, MB)
         tab[0, :] = -1
         tab[1, :] = -1
         tab[4:7, :] = -1
@@ -287,6 +287,7 @@ class ArticulationModel:
             idx = np.nonzero(self.contact_body == i)[0]
             tab[8, i] = idx[0] if len(idx) else 0
             tab[9, i] = len(idx)
+        tab[10, :NB] = np.argsort(self.level, kind="stable")  # bodies sorted by tree level (level-major stepper mapping)
         BF = 28
         fl = np.zeros((MB, BF), dtype=np.float64)
         for i in range(NB):
