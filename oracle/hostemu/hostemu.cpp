@@ -118,7 +118,7 @@ int emu_sim_step(const phc_model_t* model, const phc_sim_params_t* prm, const ph
         }
         const int ml = model->max_level;
         Xch x;
-        x.base = xch.data(); x.bs = PHC_XCH_STRIDE; x.es = 1;
+        x.base = xch.data();
         for (int l = 0; l <= ml; ++l) for (int j = 0; j < nb; ++j) aba_fk_level(L[j], l, j, x);
         if (do_step) {
             const float dt = prm->sim_dt / (float)prm->substeps;

@@ -143,12 +143,14 @@ PHC_HD void aba_load_state(AbaLane& L, const phc_sim_state_t& s, int nd, int64_t
     }
 }
 
-// Exchange buffer addressing: body b's slot starts at base + b*bs, its k-th float sits at [k*es].
-//   32-lane-per-env mapping (host emulation): bs = 28, es = 1
-//   level-major mapping (k_sim_step): lanes of one wavefront hold the SAME body of E different envs, the slot is
-//   stored env-fastest (bs = 28*E, es = E, base = block base + env_local) -> conflict-free LDS access.
-struct Xch { float* base; int bs; int es; };
-PHC_HD float* xslot(const Xch& x, int body) { return x.base + body * x.bs; }
+// Exchange buffer: body b's slot is the 28 contiguous floats at base + 28*b (LDS on the device, a stack array in the
+// host emulation).  Strides are compile-time constants so slot traffic becomes wide ds_read/ds_write with immediate offsets.
+struct Xch {
+    float* base;
+    static constexpr int bs = PHC_XCH_STRIDE;
+    static constexpr int es = 1;
+};
+PHC_HD float* xslot(const Xch& x, int body) { return x.base + body * Xch::bs; }
 
 // new kinematics of body (level > 0) from its parent's: shared by the initial sweep and the merged forward sweep
 PHC_HD void aba_kinematics_from_parent(AbaLane& L, Q4 Qp, V3 pp, V3 wp, V3 vp) {
@@ -171,7 +173,7 @@ PHC_HD void aba_write_kin(const AbaLane& L, float* s, int es, int o) {
 // ---- initial kinematics sweep (once per launch), one tree level.  Slot layout: [6..19) = Q(4) p(3) w(3) v(3). ----
 PHC_HD void aba_fk_level(AbaLane& L, int level, int j, const Xch& x) {
     if (L.level != level) return;
-    const int es = x.es;
+    constexpr int es = Xch::es;
     if (level == 0) {
         L.Q = L.q; L.p = L.p0; L.w = L.w0; L.v = L.v0;
         L.rw = L.cw = L.ca = v3(0.f, 0.f, 0.f);
@@ -295,7 +297,7 @@ PHC_HD void accumulate_child(Inertia6& I, Force6& p, const float* s, int es) {
 PHC_HD void aba_backward_level(AbaLane& L, int level, int j, const Xch& x) {
     if (L.level != level) return;
     for (int k = 0; k < 3; ++k)
-        if (k < L.nchild) accumulate_child(L.IA, L.pA, xslot(x, L.child[k]), x.es);
+        if (k < L.nchild) accumulate_child(L.IA, L.pA, xslot(x, L.child[k]), Xch::es);
     if (level == 0) return;
     M3 R = quat_to_mat(L.Q);
     Sym3 D = rot_diag(R, L.dimp + L.arm);
@@ -325,7 +327,7 @@ PHC_HD void aba_backward_level(AbaLane& L, int level, int j, const Xch& x) {
     Force6 pa;
     pa.n = L.pA.n + sym_mul(Ia.A, L.cw) + B_mul(Ia.B, L.ca) + sym_mul(A, du);
     pa.f = L.pA.f + Bt_mul(Ia.B, L.cw) + sym_mul(Ia.C, L.ca) + Bt_mul(B, du);
-    shift_to_parent(Ia, pa, L.rw, xslot(x, j), x.es);
+    shift_to_parent(Ia, pa, L.rw, xslot(x, j), Xch::es);
 }
 
 // ---- forward sweep, one tree level (root -> leaves): accelerations, semi-implicit Euler on this body's joint, and
@@ -333,7 +335,7 @@ PHC_HD void aba_backward_level(AbaLane& L, int level, int j, const Xch& x) {
 // sub-step's kinematics sweep are folded in, so a sub-step is two sweeps.  Slot: alpha(3) a(3) | Q(4) p(3) w(3) v(3).
 PHC_HD void aba_forward_level(AbaLane& L, int level, int j, const Xch& x, const phc_sim_params_t& prm, float dt) {
     if (L.level != level) return;
-    const int es = x.es;
+    constexpr int es = Xch::es;
     const float damp = 1.0f / (1.0f + dt * prm.angular_damping);
     V3 alpha, a;
     if (level == 0) {

@@ -1,8 +1,8 @@
 // phc_kernels.hip -- gfx950 kernels + the extern "C" entry points declared in include/phc_amd.h.
 //
 // Thread mapping used by every env kernel: ONE LANE PER RIGID BODY, 32 lanes per environment,
-// two environments per 64-wide wavefront, in the task kernels (256-thread workgroups = 8 envs; per-env sums use
-// 32-lane butterfly shuffles).  The stepper uses a level-major variant of the same idea (see k_sim_step).
+// two environments per 64-wide wavefront.  Task kernels: 256-thread workgroups (8 envs), per-env sums by 32-lane
+// butterfly shuffles.  Stepper: one wavefront per workgroup (see k_sim_step).
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 #include "phc_aba.h"
@@ -24,33 +24,33 @@ __device__ __forceinline__ int group_or(int v) {
 }
 
 // ------------------------------------------------------------------------------------------
-// S10: the stepper.  LEVEL-MAJOR mapping: a workgroup owns E = 2^log2e environments; thread t handles body
-// order[t / E] (bodies sorted by tree level) of env (t % E).  The lanes of one wavefront therefore hold the SAME body
-// (or two neighbouring tree levels) of many envs, so at each level-step of a sweep only the wavefronts that own that
-// level execute it (wave-uniform skip) instead of every wavefront executing every level with 1/9 of its lanes.
-// Parent/child hand-off: LDS slots stored env-fastest (conflict-free), one workgroup barrier per level-step.
+// S10: the stepper.  One lane per body, 32 lanes per env, blockDim = 64: ONE wavefront (two envs) per workgroup, so
+// the level-synchronous tree sweeps synchronise with a single-wave barrier and every SIMD of the chip carries
+// two independent dependency chains (2048 wavefronts at N = 4096).
+// Measured alternative (round 1, profiles/r01_notes.md): a level-major mapping (workgroup = 16 envs, wavefront = same
+// body of many envs, multi-wave barriers) runs ~100 % of its lanes but leaves 3 of 4 SIMDs idle at N = 4096 and needs
+// >256 VGPRs: 214-252 us vs 158 us for this mapping.  __launch_bounds__(64, 2): two wavefronts per SIMD (<= 256 VGPRs,
+// 68 B/lane of scratch) beats one (272 registers, no scratch: 195 us) and three (168 VGPRs, 412 B scratch: 280 us).
 // ------------------------------------------------------------------------------------------
-template <bool STEP, int MAXT>
-__global__ __launch_bounds__(MAXT) void k_sim_step(phc_model_t model, phc_sim_params_t prm, phc_sim_state_t sim,
-                                                 const float* __restrict__ actions, const float* __restrict__ pd_off,
-                                                 const float* __restrict__ pd_scale, const int32_t* __restrict__ freeze,
-                                                 int num_sim_calls, int log2e) {
-    extern __shared__ __attribute__((aligned(16))) float xch_all[];
-    const int E = 1 << log2e;
-    const int slot = threadIdx.x >> log2e;
-    const int el = threadIdx.x & (E - 1);
-    const int64_t env = (int64_t)blockIdx.x * E + el;
+template <bool STEP>
+__global__ __launch_bounds__(64, 2) void k_sim_step(phc_model_t model, phc_sim_params_t prm, phc_sim_state_t sim,
+                                                const float* __restrict__ actions, const float* __restrict__ pd_off,
+                                                const float* __restrict__ pd_scale, const int32_t* __restrict__ freeze,
+                                                int num_sim_calls) {
+    __shared__ float xch_all[2 * PHC_MAX_BODIES * PHC_XCH_STRIDE];
+    const int lane = threadIdx.x & (GRP - 1);
+    const int grp = threadIdx.x >> 5;
+    const int64_t env = (int64_t)blockIdx.x * 2 + grp;
     const int nb = model.num_bodies, nd = model.num_dof;
-    const bool active = slot < nb && env < sim.num_envs;
-    const int j = active ? model_tab(model, 10, slot) : 0;  // level-sorted body order
+    const bool active = env < sim.num_envs && lane < nb;
     Xch x;
-    x.base = xch_all + el; x.bs = PHC_XCH_STRIDE * E; x.es = E;
+    x.base = xch_all + grp * PHC_MAX_BODIES * PHC_XCH_STRIDE;
 
     AbaLane L;
     L.level = -1;
     if (active) {
-        aba_load_model(L, model, j);
-        if (STEP && actions != nullptr && j >= 1) {
+        aba_load_model(L, model, lane);
+        if (STEP && actions != nullptr && lane >= 1) {
             // A2: pd_tar = offset + scale * action, frozen DoFs -> 0 (humanoid.py:1711-1713,1549-1554)
             for (int k = 0; k < 3; ++k) {
                 const int d = L.dof_start + k;
@@ -59,50 +59,31 @@ __global__ __launch_bounds__(MAXT) void k_sim_step(phc_model_t model, phc_sim_pa
                 sim.pd_target[env * nd + d] = t;
             }
         }
-        aba_load_state(L, sim, nd, env, j);
+        aba_load_state(L, sim, nd, env, lane);
     }
     const int max_level = model.max_level;
-    for (int l = 0; l <= max_level; ++l) { aba_fk_level(L, l, j, x); __syncthreads(); }
+    for (int l = 0; l <= max_level; ++l) { aba_fk_level(L, l, lane, x); __syncthreads(); }
     if (STEP) {
         const float dt = prm.sim_dt / (float)prm.substeps;
         const int nsub = num_sim_calls * prm.substeps;
         for (int s = 0; s < nsub; ++s) {
-            if (active) aba_body_init(L, model, prm, dt, j);
-            for (int l = max_level; l >= 0; --l) { aba_backward_level(L, l, j, x); __syncthreads(); }
-            for (int l = 0; l <= max_level; ++l) { aba_forward_level(L, l, j, x, prm, dt); __syncthreads(); }
+            if (active) aba_body_init(L, model, prm, dt, lane);
+            for (int l = max_level; l >= 0; --l) { aba_backward_level(L, l, lane, x); __syncthreads(); }
+            for (int l = 0; l <= max_level; ++l) { aba_forward_level(L, l, lane, x, prm, dt); __syncthreads(); }
         }
     }
     // S7: the last forward sweep already produced the end-of-step kinematics
     if (active) {
-        if (STEP) aba_store_state(L, sim, nd, env, j);
-        aba_publish_body(L, sim, nb, env, j, STEP);
+        if (STEP) aba_store_state(L, sim, nd, env, lane);
+        aba_publish_body(L, sim, nb, env, lane, STEP);
     }
-}
-
-static inline void sim_launch_geometry(const phc_model_t* m, int num_envs, int* log2e, int* threads, int* blocks, size_t* lds) {
-    // E envs per workgroup.  Default E = 16 (384 threads for the 24-body SMPL humanoid); PHC_SIM_LOG2E overrides for tuning.
-    int e = 4;
-    const char* ov = getenv("PHC_SIM_LOG2E");
-    if (ov) e = atoi(ov);
-    if (e < 3) e = 3;
-    while (e > 3 && (1 << e) * m->num_bodies > 512) --e;
-    *log2e = e;
-    const int E = 1 << e;
-    *threads = ((E * m->num_bodies + 63) / 64) * 64;
-    *blocks = (num_envs + E - 1) / E;
-    *lds = (size_t)PHC_MAX_BODIES * PHC_XCH_STRIDE * E * sizeof(float);
 }
 
 template <bool STEP>
 static void sim_launch(const phc_model_t* model, const phc_sim_params_t& prm, const phc_sim_state_t* sim, const float* actions,
                        const float* off, const float* scale, const int32_t* freeze, int num_sim_calls, hipStream_t stream) {
-    int log2e, threads, blocks;
-    size_t lds;
-    sim_launch_geometry(model, sim->num_envs, &log2e, &threads, &blocks, &lds);
-    if (threads <= 256)
-        hipLaunchKernelGGL((k_sim_step<STEP, 256>), dim3(blocks), dim3(threads), lds, stream, *model, prm, *sim, actions, off, scale, freeze, num_sim_calls, log2e);
-    else
-        hipLaunchKernelGGL((k_sim_step<STEP, 512>), dim3(blocks), dim3(threads), lds, stream, *model, prm, *sim, actions, off, scale, freeze, num_sim_calls, log2e);
+    hipLaunchKernelGGL(k_sim_step<STEP>, dim3((sim->num_envs + 1) / 2), dim3(64), 0, stream, *model, prm, *sim, actions, off, scale,
+                       freeze, num_sim_calls);
 }
 
 // ------------------------------------------------------------------------------------------
