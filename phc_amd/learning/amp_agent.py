@@ -23,6 +23,7 @@ MI355X-first differences (results-preserving):
     (amp_agent.py:667-668).  Running-stat moments are averaged once per epoch (`hvd.sync_stats`).
 """
 import copy
+import os
 import time
 
 import numpy as np
@@ -65,20 +66,29 @@ def discount_values(mb_fdones, mb_values, mb_rewards, mb_next_values, gamma, tau
 
 
 class FlatGradBucket:
-    """All parameters' gradients as views of ONE flat fp32 buffer -> one all-reduce per optimizer step.
+    """All trainable parameters AND their gradients as views of two flat fp32 buffers.
 
-    22.1 MB (`im`) / 78 MB (`im_big`) per step: over the 7 point-to-point xGMI links of an MI355X node RCCL moves
-    that in well under a millisecond, so there is nothing to overlap with and one bucket is the right size."""
+    * one all-reduce per optimizer step (22.1 MB for `im`, 78 MB for `im_big`): over the 7 point-to-point xGMI links of
+      an MI355X node RCCL moves that in well under a millisecond, so there is nothing to overlap with and one bucket is
+      the right size;
+    * gradient clipping is one norm + one scale of the flat gradient (`clip_grad_norm_` semantics, max-norm 50);
+    * Adam updates ONE tensor (the flat parameter) instead of 22 -- three launches instead of a foreach over all of them.
+    Modules keep seeing their own `weight` / `bias` (views), so state_dicts are unchanged."""
 
     def __init__(self, params):
         self.params = [p for p in params if p.requires_grad]
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device
+        self.flat_param = torch.zeros(n, device=dev, dtype=torch.float32)
         self.flat = torch.zeros(n, device=dev, dtype=torch.float32)
         o = 0
         for p in self.params:
-            p.grad = self.flat[o:o + p.numel()].view_as(p)
-            o += p.numel()
+            k = p.numel()
+            self.flat_param[o:o + k].copy_(p.data.reshape(-1))
+            p.data = self.flat_param[o:o + k].view_as(p)
+            p.grad = self.flat[o:o + k].view_as(p)
+            o += k
+        self.flat_param.grad = self.flat
 
     def zero(self):
         self.flat.zero_()
@@ -87,6 +97,12 @@ class FlatGradBucket:
         if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
             self.flat.div_(dist.get_world_size())
+
+    def clip_grad_norm_(self, max_norm):
+        """torch.nn.utils.clip_grad_norm_ on the flat view: same total norm, same clip coefficient (clamped to 1)."""
+        total = torch.linalg.vector_norm(self.flat)
+        self.flat.mul_(torch.clamp(max_norm / (total + 1e-6), max=1.0))
+        return total
 
 
 class IMAmpAgent:
@@ -143,7 +159,10 @@ class IMAmpAgent:
         self._amp_input_mean_std = RunningMeanStd((amp_dim,)).to(self.device) if self._normalize_amp_input else None
         self.running_mean_std_temp = None
         self.grads = FlatGradBucket(self.model.parameters())
-        self.optimizer = torch.optim.Adam(self.grads.params, self.last_lr, eps=1e-08, weight_decay=c.get("weight_decay", 0.0))
+        self.use_graphs = str(self.device).startswith("cuda") and os.environ.get("PHC_NO_GRAPH", "0") != "1"
+        self.graph_warmup, self._calls, self._graphs = 3, 0, None
+        self.optimizer = torch.optim.Adam([self.grads.flat_param], self.last_lr, eps=1e-08, weight_decay=c.get("weight_decay", 0.0),
+                                          capturable=self.use_graphs)
 
         T, N, dev = self.horizon_length, self.num_actors, self.device
         f = lambda *s: torch.zeros(*s, device=dev, dtype=torch.float32)
@@ -296,7 +315,8 @@ class IMAmpAgent:
     def _get_item(self, idx):
         s, e = idx * self.minibatch_size, (idx + 1) * self.minibatch_size
         sample_idx = self._idx_buf[s:e]
-        out = {k: v[sample_idx] for k, v in self.dataset.items()}
+        amp_idx = sample_idx[:self._amp_minibatch_size]  # calc_gradients only reads rows [0:amp_minibatch_size] (amp_agent.py:570-577)
+        out = {k: v[amp_idx if k.startswith("amp_obs") else sample_idx] for k, v in self.dataset.items()}
         if e >= self.batch_size:
             self._idx_buf[:] = torch.randperm(self.batch_size, device=self._idx_buf.device)
         return out
@@ -326,13 +346,13 @@ class IMAmpAgent:
         return {"disc_loss": disc_loss, "disc_grad_penalty": disc_grad_penalty.detach(), "disc_logit_loss": disc_logit_loss.detach(),
                 "disc_agent_acc": (disc_agent_logit < 0).float().mean().detach(), "disc_demo_acc": (disc_demo_logit > 0).float().mean().detach()}
 
-    def calc_gradients(self, d):
-        self.set_train()
+    def _fwd_bwd(self, d):
+        """Forward + losses + backward into the flat gradient bucket (amp_agent.py:554-655).  Static shapes, no host sync:
+        this body is what gets captured into a hipGraph."""
         obs = self._preproc_obs(d["obs"], use_temp=self.temp_running_mean)
-        m = self._amp_minibatch_size
-        amp_obs = self._preproc_amp_obs(d["amp_obs"][0:m])
-        amp_obs_replay = self._preproc_amp_obs(d["amp_obs_replay"][0:m])
-        amp_obs_demo = self._preproc_amp_obs(d["amp_obs_demo"][0:m])
+        amp_obs = self._preproc_amp_obs(d["amp_obs"])
+        amp_obs_replay = self._preproc_amp_obs(d["amp_obs_replay"])
+        amp_obs_demo = self._preproc_amp_obs(d["amp_obs_demo"])
         amp_obs_demo.requires_grad_(True)
         with self._autocast():
             res = self.model({"is_train": True, "prev_actions": d["actions"], "obs": obs, "amp_obs": amp_obs,
@@ -355,13 +375,60 @@ class IMAmpAgent:
         loss.backward()
         with torch.no_grad():
             kl = policy_kl(res["mus"].detach(), res["sigmas"].detach(), d["mu"], d["sigma"])
-        self.grads.all_reduce_mean(self.dist)  # the path's one collective: replaces optimizer.synchronize() (amp_agent.py:667-668)
-        if self.truncate_grads:
-            nn.utils.clip_grad_norm_(self.grads.params, self.grad_norm)
-        self.optimizer.step()
         info = {"actor_loss": a_loss.detach(), "critic_loss": c_loss.detach(), "b_loss": b_loss.detach(), "entropy": entropy.detach(), "kl": kl}
         info.update({k: (v.detach() if torch.is_tensor(v) else v) for k, v in disc_info.items()})
         return info
+
+    def _clip_and_step(self):
+        if self.truncate_grads:
+            self.grads.clip_grad_norm_(self.grad_norm)
+        self.optimizer.step()
+
+    def _amp_rows(self, d):
+        m = self._amp_minibatch_size
+        return {k: (v[0:m] if k.startswith("amp_obs") else v) for k, v in d.items()}
+
+    def calc_gradients(self, d):
+        """One optimizer step.  Eager for the first `graph_warmup` calls, then replayed as two hipGraphs
+        (forward/backward, clip + Adam) with the path's one collective -- the flat gradient all-reduce -- in between."""
+        self.set_train()
+        d = self._amp_rows(d)
+        if not self.use_graphs:
+            info = self._fwd_bwd(d)
+            self.grads.all_reduce_mean(self.dist)  # replaces optimizer.synchronize() (amp_agent.py:667-668)
+            self._clip_and_step()
+            return info
+        self._calls += 1
+        if self._graphs is None and self._calls > self.graph_warmup:
+            self._capture(d)
+        if self._graphs is None:
+            info = self._fwd_bwd(d)
+            self.grads.all_reduce_mean(self.dist)
+            self._clip_and_step()
+            return info
+        g1, g2, static_in, static_out = self._graphs
+        for k, v in d.items():
+            static_in[k].copy_(v)
+        g1.replay()
+        self.grads.all_reduce_mean(self.dist)
+        g2.replay()
+        return {k: v.clone() for k, v in static_out.items()}
+
+    def _capture(self, d):
+        try:
+            static_in = {k: v.clone() for k, v in d.items()}
+            g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g1):
+                static_out = self._fwd_bwd(static_in)
+            with torch.cuda.graph(g2, pool=g1.pool()):
+                self._clip_and_step()
+            self._graphs = (g1, g2, static_in, static_out)
+        except Exception as e:  # keep training eagerly if this torch/ROCm build cannot capture the step
+            torch.cuda.synchronize()
+            self.use_graphs = False
+            self._graphs = None
+            if self.rank == 0:
+                print(f"[phc_amd] hipGraph capture of the optimizer step failed ({type(e).__name__}: {e}); running eagerly")
 
     # ------------------------------------------------------------------ epoch (amp_agent.py:413-532)
     def _init_amp_demo_buf(self):
@@ -385,14 +452,22 @@ class IMAmpAgent:
         t = self.task
         if (epoch_num > 1) and epoch_num % getattr(t, "shape_resampling_interval", 10 ** 9) == 1 and hasattr(t, "resample_motions"):
             t.resample_motions()
-        if self.running_mean_std is not None:
+        self._snapshot_running_mean_std()
+
+    def _snapshot_running_mean_std(self):
+        """`self.running_mean_std_temp = copy.deepcopy(self.running_mean_std); .freeze()` (amp_agent.py:527-532), done as an
+        in-place copy into ONE persistent module so that captured graphs keep valid buffer addresses."""
+        if self.running_mean_std is None:
+            return
+        if self.running_mean_std_temp is None:
             self.running_mean_std_temp = copy.deepcopy(self.running_mean_std)
             self.running_mean_std_temp.freeze()
+        else:
+            for a, b in zip(self.running_mean_std_temp.buffers(), self.running_mean_std.buffers()):
+                a.copy_(b)
 
     def post_epoch(self, epoch_num):
-        if self.running_mean_std is not None:
-            self.running_mean_std_temp = copy.deepcopy(self.running_mean_std)
-            self.running_mean_std_temp.freeze()
+        self._snapshot_running_mean_std()
         for m in self._norms():
             m.sync(self.dist)
 

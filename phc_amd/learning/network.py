@@ -92,9 +92,11 @@ class ModelAMPContinuous(nn.Module):
             prev_actions = input_dict["prev_actions"]
             entropy = (0.5 + 0.5 * math.log(2 * math.pi) + logstd).sum(dim=-1)
             res = {"prev_neglogp": self.neglogp(prev_actions, mu, sigma, logstd), "values": value, "entropy": entropy, "mus": mu, "sigmas": sigma}
-            res["disc_agent_logit"] = self.a2c_network.eval_disc(input_dict["amp_obs"]).float()
-            res["disc_agent_replay_logit"] = self.a2c_network.eval_disc(input_dict["amp_obs_replay"]).float()
-            res["disc_demo_logit"] = self.a2c_network.eval_disc(input_dict["amp_obs_demo"]).float()
+            # one discriminator pass over [agent; replay; demo] (the reference runs three, amp_models.py:40-48): same logits,
+            # a third of the GEMM launches; the gradient penalty still differentiates w.r.t. the demo rows only
+            a, r, d = input_dict["amp_obs"], input_dict["amp_obs_replay"], input_dict["amp_obs_demo"]
+            logits = self.a2c_network.eval_disc(torch.cat([a, r, d], dim=0)).float()
+            res["disc_agent_logit"], res["disc_agent_replay_logit"], res["disc_demo_logit"] = torch.split(logits, [a.shape[0], r.shape[0], d.shape[0]], dim=0)
             return res
         action = mu + sigma * torch.randn_like(mu)
         return {"neglogpacs": self.neglogp(action, mu, sigma, logstd), "values": value, "actions": action, "mus": mu, "sigmas": sigma}
