@@ -23,7 +23,6 @@ MI355X-first differences (results-preserving):
     (amp_agent.py:667-668).  Running-stat moments are averaged once per epoch (`hvd.sync_stats`).
 """
 import copy
-import os
 import time
 
 import numpy as np
@@ -159,10 +158,7 @@ class IMAmpAgent:
         self._amp_input_mean_std = RunningMeanStd((amp_dim,)).to(self.device) if self._normalize_amp_input else None
         self.running_mean_std_temp = None
         self.grads = FlatGradBucket(self.model.parameters())
-        self.use_graphs = str(self.device).startswith("cuda") and os.environ.get("PHC_NO_GRAPH", "0") != "1"
-        self.graph_warmup, self._calls, self._graphs = 3, 0, None
-        self.optimizer = torch.optim.Adam([self.grads.flat_param], self.last_lr, eps=1e-08, weight_decay=c.get("weight_decay", 0.0),
-                                          capturable=self.use_graphs)
+        self.optimizer = torch.optim.Adam([self.grads.flat_param], self.last_lr, eps=1e-08, weight_decay=c.get("weight_decay", 0.0))
 
         T, N, dev = self.horizon_length, self.num_actors, self.device
         f = lambda *s: torch.zeros(*s, device=dev, dtype=torch.float32)
@@ -347,8 +343,7 @@ class IMAmpAgent:
                 "disc_agent_acc": (disc_agent_logit < 0).float().mean().detach(), "disc_demo_acc": (disc_demo_logit > 0).float().mean().detach()}
 
     def _fwd_bwd(self, d):
-        """Forward + losses + backward into the flat gradient bucket (amp_agent.py:554-655).  Static shapes, no host sync:
-        this body is what gets captured into a hipGraph."""
+        """Forward + losses + backward into the flat gradient bucket (amp_agent.py:554-655); no host sync."""
         obs = self._preproc_obs(d["obs"], use_temp=self.temp_running_mean)
         amp_obs = self._preproc_amp_obs(d["amp_obs"])
         amp_obs_replay = self._preproc_amp_obs(d["amp_obs_replay"])
@@ -389,46 +384,16 @@ class IMAmpAgent:
         return {k: (v[0:m] if k.startswith("amp_obs") else v) for k, v in d.items()}
 
     def calc_gradients(self, d):
-        """One optimizer step.  Eager for the first `graph_warmup` calls, then replayed as two hipGraphs
-        (forward/backward, clip + Adam) with the path's one collective -- the flat gradient all-reduce -- in between."""
+        """One optimizer step (amp_agent.py:554-688): forward/backward, the path's one collective -- the flat gradient
+        all-reduce, replacing `optimizer.synchronize()` (:667-668) -- then clip + Adam on the flat parameter.
+        (Capturing the step into hipGraphs was tried in round 1: no gain -- the step is GPU-bound by ~400 small
+        elementwise kernels, not launch-bound -- and `hipGraph` capture_end crashed at small batch sizes on ROCm 7.2.)"""
         self.set_train()
         d = self._amp_rows(d)
-        if not self.use_graphs:
-            info = self._fwd_bwd(d)
-            self.grads.all_reduce_mean(self.dist)  # replaces optimizer.synchronize() (amp_agent.py:667-668)
-            self._clip_and_step()
-            return info
-        self._calls += 1
-        if self._graphs is None and self._calls > self.graph_warmup:
-            self._capture(d)
-        if self._graphs is None:
-            info = self._fwd_bwd(d)
-            self.grads.all_reduce_mean(self.dist)
-            self._clip_and_step()
-            return info
-        g1, g2, static_in, static_out = self._graphs
-        for k, v in d.items():
-            static_in[k].copy_(v)
-        g1.replay()
+        info = self._fwd_bwd(d)
         self.grads.all_reduce_mean(self.dist)
-        g2.replay()
-        return {k: v.clone() for k, v in static_out.items()}
-
-    def _capture(self, d):
-        try:
-            static_in = {k: v.clone() for k, v in d.items()}
-            g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g1):
-                static_out = self._fwd_bwd(static_in)
-            with torch.cuda.graph(g2, pool=g1.pool()):
-                self._clip_and_step()
-            self._graphs = (g1, g2, static_in, static_out)
-        except Exception as e:  # keep training eagerly if this torch/ROCm build cannot capture the step
-            torch.cuda.synchronize()
-            self.use_graphs = False
-            self._graphs = None
-            if self.rank == 0:
-                print(f"[phc_amd] hipGraph capture of the optimizer step failed ({type(e).__name__}: {e}); running eagerly")
+        self._clip_and_step()
+        return info
 
     # ------------------------------------------------------------------ epoch (amp_agent.py:413-532)
     def _init_amp_demo_buf(self):
