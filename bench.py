@@ -205,6 +205,12 @@ def main():
     if rank == 0:
         nsub = task.control_freq_inv * int(cfg.sim.substeps)
         bytes_per_launch = (ABA_BYTES_PER_ENV_SUBSTEP * nsub + PUBLISH_BYTES_PER_ENV_STEP) * N
+        traffic, traffic_src = None, None  # HBM bytes per launch from the PMC passes (profiles/collect_pmc.sh), not measurable live
+        pmc = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json"))
+        if pmc and N == 4096:
+            rec = json.load(open(os.path.join(ROOT, "profiles", pmc[-1]))).get("k_sim_step<true>")
+            if rec:
+                traffic, traffic_src = rec["traffic_bytes"], "profiles/" + pmc[-1]
         achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
         out = {
             "metric": "env-steps/sec at 4096 humanoid envs per GPU (VecEnv.step incl. resets)",
@@ -215,7 +221,7 @@ def main():
                                    "30 Hz control = 2 x simulate @60 Hz x 2 sub-steps", "envs_per_gpu": N, "num_bodies": task.num_bodies,
                        "obs": task.num_obs, "amp_obs": task.get_num_amp_obs(), "parallelism": f"env-sharded x{world}"},
             "roofline": {"kernel": "k_sim_step<true> (A2 + 4 ABA sub-steps + S7 publication)", "bound": "hbm", "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
                          "note": "latency/ALU-bound tree sweep: SURVEY 8(d) canonical un-fused accounting (1484 B x 4 sub-steps + 1812 B "
                                  "per env); the fused launch's compulsory traffic is 3296 B/env",

@@ -1,0 +1,41 @@
+"""Per-kernel HBM traffic from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; values are KiB per dispatch).
+
+gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE counts 128-B fabric requests at 64 B -> read bytes = 2 x FETCH_SIZE;
+WRITE_SIZE is taken as is.  Both factors are CALIBRATED here on a kernel of this very path whose byte count is known:
+k_im_post_physics reads 14 124 B/env (body 1248 + dof 552 + dof_force 276 + 4 reference frames x 1248 + AMP history 7056) and
+writes 12 872 B/env (obs 3736 + AMP history 7840 + ref_* side buffers 1236 + flags 60); the table prints measured/expected."""
+import collections
+import csv
+import json
+import sys
+
+
+def load(path, name):
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == name:
+            agg[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]))
+    return agg
+
+
+def main(fetch_csv, write_csv, n_envs=4096):
+    f, w = load(fetch_csv, "FETCH_SIZE"), load(write_csv, "WRITE_SIZE")
+    out = {}
+    print(f"# {'kernel':28s} {'calls':>5s} {'FETCH_KiB':>10s} {'WRITE_KiB':>10s} {'read_MB(2x)':>12s} {'write_MB':>9s} {'total_MB':>9s} {'B/env':>8s}")
+    for k in ("k_sim_step<true>", "k_im_post_physics", "k_im_reset"):
+        if k not in f:
+            continue
+        # steady state: drop the first dispatches (full reset of all envs) by taking the median
+        fv, wv = sorted(f[k])[len(f[k]) // 2], sorted(w[k])[len(w[k]) // 2]
+        rd, wr = 2 * fv * 1024, wv * 1024
+        out[k] = {"fetch_kib": fv, "write_kib": wv, "read_bytes": rd, "write_bytes": wr, "traffic_bytes": rd + wr}
+        print(f"  {k:28s} {len(f[k]):5d} {fv:10.1f} {wv:10.1f} {rd / 1e6:12.2f} {wr / 1e6:9.2f} {(rd + wr) / 1e6:9.2f} {(rd + wr) / n_envs:8.0f}")
+    if "k_im_post_physics" in out:
+        o = out["k_im_post_physics"]
+        print(f"# calibration on k_im_post_physics: read {o['read_bytes'] / n_envs:.0f} B/env measured vs 14124 expected "
+              f"({o['read_bytes'] / n_envs / 14124:.2f}x), write {o['write_bytes'] / n_envs:.0f} vs 12872 ({o['write_bytes'] / n_envs / 12872:.2f}x)")
+    print("JSON " + json.dumps(out))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])
