@@ -7,7 +7,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libphc_amd.so")
-SOURCES = ["phc_kernels.hip"]
+# source -> extra flags (see the header of phc_sim.hip for why the stepper is compiled differently)
+SOURCES = {"phc_kernels.hip": [], "phc_sim.hip": ["-ffast-math", "-fno-slp-vectorize"]}
 HEADERS = ["phc_math.h", "phc_task.h", "phc_im.h", "phc_aba.h", os.path.join("..", "..", "include", "phc_amd.h")]
 
 
@@ -22,20 +23,32 @@ def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in list(SOURCES) + HEADERS)
 
 
 def build(force=False, verbose=False):
     """Compile every HIP source for gfx950 into phc_amd/libphc_amd.so."""
     if not force and not needs_build():
         return LIB
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-comment",
-           *[os.path.join(CSRC, s) for s in SOURCES], "-o", LIB]
+    hipcc = _hipcc()
+    common = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-comment"]
+    objs = []
+    os.makedirs(os.path.join(HERE, "_obj"), exist_ok=True)
+    for src, extra in SOURCES.items():
+        obj = os.path.join(HERE, "_obj", src.replace(".hip", ".o"))
+        cmd = [hipcc, *common, *extra, "-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n" + r.stdout + r.stderr)
+        objs.append(obj)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
     if verbose:
         print(" ".join(cmd))
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
+        raise RuntimeError("hipcc link failed:\n" + r.stdout + r.stderr)
     return LIB
 
 

@@ -1,0 +1,117 @@
+// phc_sim.hip -- the articulated-body stepper kernel (S10) and its two C-ABI entry points.
+//
+// Own translation unit because it is compiled with different code-generation flags than the task kernels
+// (phc_amd/build.py): `-ffast-math -fno-slp-vectorize`.
+//   * -fno-slp-vectorize: the SLP vectoriser packs the 3-vector algebra into v_pk_fma_f32 and then needs ~840 v_mov to
+//     marshal register pairs (3975 static instructions, 16 scratch ops); without it 3466 instructions and no scratch;
+//   * -ffast-math: v_rcp / v_sqrt / hardware sin-cos instead of the IEEE division and libm expansions: 1949 static
+//     instructions.  The stepper has no reference arithmetic to match bit-for-bit (Isaac Gym is closed); its oracle
+//     tolerances (tests/test_dynamics.py) hold with these approximations.  The task kernels, which ARE pinned to the
+//     reference at 1e-5 and rely on IEEE NaN/division semantics, are NOT compiled this way.
+#include <hip/hip_runtime.h>
+#include "phc_aba.h"
+
+using namespace phc;
+
+#define GRP 32  // lanes per environment
+
+// ------------------------------------------------------------------------------------------
+// S10: the stepper.  One lane per body, 32 lanes per env, blockDim = 64: ONE wavefront (two envs) per workgroup, so
+// the level-synchronous tree sweeps synchronise with a single-wave barrier and every SIMD of the chip carries
+// two independent dependency chains (2048 wavefronts at N = 4096).
+// Measured alternative (round 1, profiles/r01_notes.md): a level-major mapping (workgroup = 16 envs, wavefront = same
+// body of many envs, multi-wave barriers) runs ~100 % of its lanes but leaves 3 of 4 SIMDs idle at N = 4096 and needs
+// >256 VGPRs: 214-252 us vs 158 us for this mapping.  __launch_bounds__(64, 2): two wavefronts per SIMD (<= 256 VGPRs,
+// 68 B/lane of scratch) beats one (272 registers, no scratch: 195 us) and three (168 VGPRs, 412 B scratch: 280 us).
+// ------------------------------------------------------------------------------------------
+template <bool STEP>
+__global__ __launch_bounds__(64, 2) void k_sim_step(phc_model_t model, phc_sim_params_t prm, phc_sim_state_t sim,
+                                                const float* __restrict__ actions, const float* __restrict__ pd_off,
+                                                const float* __restrict__ pd_scale, const int32_t* __restrict__ freeze,
+                                                int num_sim_calls) {
+    __shared__ float xch_all[2 * PHC_MAX_BODIES * PHC_XCH_STRIDE];
+    const int lane = threadIdx.x & (GRP - 1);
+    const int grp = threadIdx.x >> 5;
+    const int64_t env = (int64_t)blockIdx.x * 2 + grp;
+    const int nb = model.num_bodies, nd = model.num_dof;
+    const bool active = env < sim.num_envs && lane < nb;
+    Xch x;
+    x.base = xch_all + grp * PHC_MAX_BODIES * PHC_XCH_STRIDE;
+
+    AbaLane L;
+    L.level = -1;
+    if (active) {
+        aba_load_model(L, model, lane);
+        if (STEP && actions != nullptr && lane >= 1) {
+            // A2: pd_tar = offset + scale * action, frozen DoFs -> 0 (humanoid.py:1711-1713,1549-1554)
+            for (int k = 0; k < 3; ++k) {
+                const int d = L.dof_start + k;
+                float t = __fadd_rn(pd_off[d], __fmul_rn(pd_scale[d], actions[env * nd + d]));
+                if (freeze != nullptr && freeze[d]) t = 0.f;
+                sim.pd_target[env * nd + d] = t;
+            }
+        }
+        aba_load_state(L, sim, nd, env, lane);
+    }
+    const int max_level = model.max_level;
+    for (int l = 0; l <= max_level; ++l) { aba_fk_level(L, l, lane, x); __syncthreads(); }
+    if (STEP) {
+        const float dt = prm.sim_dt / (float)prm.substeps;
+        const int nsub = num_sim_calls * prm.substeps;
+        for (int s = 0; s < nsub; ++s) {
+            if (active) aba_body_init(L, model, prm, dt, lane);
+            for (int l = max_level; l >= 0; --l) { aba_backward_level(L, l, lane, x); __syncthreads(); }
+            for (int l = 0; l <= max_level; ++l) { aba_forward_level(L, l, lane, x, prm, dt); __syncthreads(); }
+        }
+    }
+    // S7: the last forward sweep already produced the end-of-step kinematics
+    if (active) {
+        if (STEP) aba_store_state(L, sim, nd, env, lane);
+        aba_publish_body(L, sim, nb, env, lane, STEP);
+    }
+}
+
+template <bool STEP>
+static void sim_launch(const phc_model_t* model, const phc_sim_params_t& prm, const phc_sim_state_t* sim, const float* actions,
+                       const float* off, const float* scale, const int32_t* freeze, int num_sim_calls, hipStream_t stream) {
+    hipLaunchKernelGGL(k_sim_step<STEP>, dim3((sim->num_envs + 1) / 2), dim3(64), 0, stream, *model, prm, *sim, actions, off, scale,
+                       freeze, num_sim_calls);
+}
+
+static inline int32_t launch_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int32_t)e;
+}
+
+extern "C" {
+
+static int32_t check_model(const phc_model_t* m) {
+    if (!m || m->num_bodies < 1 || m->num_bodies > PHC_MAX_BODIES || !m->ints || !m->floats) return PHC_EINVAL;
+    if (m->num_dof != 3 * (m->num_bodies - 1)) return PHC_EUNSUPPORTED;  // spherical joints only in this round
+    return 0;
+}
+
+int32_t phc_sim_step(const phc_model_t* model, const phc_sim_params_t* params, const phc_sim_state_t* sim, const float* actions,
+                     const float* pd_action_offset, const float* pd_action_scale, const int32_t* freeze_mask,
+                     int32_t num_sim_calls, void* stream) {
+    int32_t rc = check_model(model);
+    if (rc) return rc;
+    if (!params || !sim || sim->num_envs < 0 || params->substeps < 1 || num_sim_calls < 0) return PHC_EINVAL;
+    if (actions && (!pd_action_offset || !pd_action_scale)) return PHC_EINVAL;
+    if (sim->num_envs == 0) return 0;
+    sim_launch<true>(model, *params, sim, actions, pd_action_offset, pd_action_scale, freeze_mask, num_sim_calls, (hipStream_t)stream);
+    return launch_status();
+}
+
+int32_t phc_refresh_body_state(const phc_model_t* model, const phc_sim_state_t* sim, void* stream) {
+    int32_t rc = check_model(model);
+    if (rc) return rc;
+    if (!sim || sim->num_envs < 0) return PHC_EINVAL;
+    if (sim->num_envs == 0) return 0;
+    phc_sim_params_t prm = {};
+    prm.substeps = 1;
+    sim_launch<false>(model, prm, sim, nullptr, nullptr, nullptr, nullptr, 0, (hipStream_t)stream);
+    return launch_status();
+}
+
+}  // extern "C"
