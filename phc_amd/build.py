@@ -7,8 +7,12 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libphc_amd.so")
-# source -> extra flags (see the header of phc_sim.hip for why the stepper is compiled differently)
-SOURCES = {"phc_kernels.hip": [], "phc_sim.hip": ["-ffast-math", "-fno-slp-vectorize"]}
+# source -> extra flags.
+#   task kernels: parity with the reference's torch ops is pinned at 1e-5 and torch does not fuse multiply-add, so
+#     -ffp-contract=off (e.g. sqrt(1 - w*w) in quat_to_angle_axis is cancellation-prone: a contracted fma moves exp-map
+#     outputs by 1e-3); -fno-slp-vectorize avoids v_pk_* register marshalling (reset 68 -> 49 us, post-physics 35 -> 27 us).
+#   stepper: see the header of phc_sim.hip (-ffast-math -fno-slp-vectorize: 158 -> 109 us).
+SOURCES = {"phc_kernels.hip": ["-fno-slp-vectorize", "-ffp-contract=off"], "phc_sim.hip": ["-ffast-math", "-fno-slp-vectorize"]}
 HEADERS = ["phc_math.h", "phc_task.h", "phc_im.h", "phc_aba.h", os.path.join("..", "..", "include", "phc_amd.h")]
 
 
