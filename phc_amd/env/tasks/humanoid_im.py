@@ -381,7 +381,20 @@ class HumanoidIm:
         return self._num_amp_obs_enc_steps * self._num_amp_obs_per_step
 
     def get_task_obs_size_detail(self):
-        return OrderedDict()
+        """humanoid_im.py:522-537."""
+        d = OrderedDict()
+        d["target"] = self.get_task_obs_size()
+        d["fut_tracks"] = False
+        d["num_traj_samples"] = 1
+        d["obs_v"] = self.obs_v
+        d["track_bodies"] = self._track_bodies
+        d["models_path"] = self.models_path
+        env = self.cfg["env"]
+        d["num_prim"] = env.get("num_prim", 2)
+        d["training_prim"] = env.get("training_prim", 1)
+        d["actors_to_load"] = env.get("actors_to_load", 2)
+        d["has_lateral"] = env.get("has_lateral", True)
+        return d
 
     def get_states(self):
         return self.states_buf

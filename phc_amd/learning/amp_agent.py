@@ -30,7 +30,7 @@ import torch
 from torch import nn
 
 from .. import _lib as L
-from .network import A2CNetwork, ModelAMPContinuous, policy_kl
+from .network import A2CNetwork, A2CPNNNetwork, ModelAMPContinuous, policy_kl
 from .replay_buffer import ReplayBuffer
 from .running_mean_std import RunningMeanStd
 
@@ -148,7 +148,13 @@ class IMAmpAgent:
         obs_dim = vec_env.num_obs
         amp_dim = self.task.get_num_amp_obs()
         self.obs_shape, self.actions_num = (obs_dim,), vec_env.num_actions
-        net = A2CNetwork(params["network"], self.actions_num, (obs_dim,), (amp_dim,))
+        net_name = params["network"].get("name", "amp")
+        if net_name == "amp":
+            net = A2CNetwork(params["network"], self.actions_num, (obs_dim,), (amp_dim,))
+        elif net_name == "amp_pnn":  # run_hydra.py:259: model_builder.register_network('amp_pnn', ...)
+            net = A2CPNNNetwork(params["network"], self.actions_num, (obs_dim,), (amp_dim,), self.task.get_task_obs_size_detail())
+        else:
+            raise NotImplementedError(f"network '{net_name}' (amp_mcp needs the MCP task) is not built yet")
         self.model = ModelAMPContinuous(net).to(self.device)
         if self.multi_gpu:  # hvd.setup_algo: broadcast rank 0's initial parameters (common_agent.py:112-113)
             for p in self.model.parameters():

@@ -69,6 +69,76 @@ class A2CNetwork(nn.Module):
         return w
 
 
+class PNN(nn.Module):
+    """Progressive-network actor (phc/learning/pnn.py:10-131): `numCols` full actor MLPs ("primitives") sharing the input;
+    column k's output layer IS the action head (no separate `mu`).  `freeze_pnn(idx)` freezes columns < idx (:40-45).
+    Lateral connections exist in the reference but are disabled in every shipped yaml (`has_lateral: False`,
+    env_im_pnn.yaml); they are not built here."""
+
+    def __init__(self, input_size, units, activation, output_size, num_cols, has_lateral=False):
+        super().__init__()
+        if has_lateral:
+            raise NotImplementedError("PNN lateral connections are not built (has_lateral is False in the shipped configs)")
+        self.numCols = num_cols
+        self.actors = nn.ModuleList()
+        for _ in range(num_cols):
+            mlp = build_mlp(input_size, units, activation)
+            mlp.append(nn.Linear(units[-1], output_size))
+            self.actors.append(mlp)
+
+    def freeze_pnn(self, idx):
+        for p in self.actors[:idx].parameters():
+            p.requires_grad = False
+
+    def load_actor(self, checkpoint, idx=0):
+        """pnn.py:52-59: initialise column idx from a plain (non-PNN) checkpoint's actor + mu head."""
+        sd, m = self.actors[idx].state_dict(), checkpoint["model"]
+        n_hidden = (len(sd) - 2) // 2
+        for k in range(n_hidden):
+            sd[f"{2 * k}.weight"].copy_(m[f"a2c_network.actor_mlp.{2 * k}.weight"])
+            sd[f"{2 * k}.bias"].copy_(m[f"a2c_network.actor_mlp.{2 * k}.bias"])
+        sd[f"{2 * n_hidden}.weight"].copy_(m["a2c_network.mu.weight"])
+        sd[f"{2 * n_hidden}.bias"].copy_(m["a2c_network.mu.bias"])
+
+    def forward(self, x, idx=-1):
+        if idx != -1:
+            a = self.actors[idx](x)
+            return a, [a]
+        acts = [actor(x) for actor in self.actors]
+        return acts, acts
+
+
+class A2CPNNNetwork(A2CNetwork):
+    """`AMPPNNBuilder.Network` (phc/learning/amp_network_pnn_builder.py:25-87): the actor MLP + mu head are replaced by a
+    PNN whose column `training_prim` produces the action mean; columns below it are frozen.  State-dict keys:
+    `a2c_network.pnn.actors.{k}.{0,2,4}.*` (what scripts/pmcp/forward_pmcp.py copies between columns)."""
+
+    def __init__(self, params, actions_num, input_shape, amp_input_shape, task_obs_size_detail, value_size=1):
+        super().__init__(params, actions_num, input_shape, amp_input_shape, value_size)
+        d = task_obs_size_detail
+        self.num_prim, self.training_prim = d["num_prim"], d["training_prim"]
+        del self.actor_mlp
+        del self.mu
+        self.pnn = PNN(input_shape[0], self.units, self.activation, actions_num, self.num_prim, d.get("has_lateral", False))
+        self.pnn.freeze_pnn(self.training_prim)
+
+    def eval_actor(self, obs):
+        mu, _ = self.pnn(obs, idx=self.training_prim)
+        return mu, mu * 0.0 + self.sigma
+
+
+def forward_pmcp(checkpoint, trained_idx):
+    """scripts/pmcp/forward_pmcp.py:44-51: copy PNN column `trained_idx` into column `trained_idx + 1` (the next primitive
+    starts from the previous one).  Operates on a checkpoint dict in place and returns it."""
+    prefix = "a2c_network.pnn.actors"
+    src = [k for k in checkpoint["model"] if k.startswith(f"{prefix}.{trained_idx}.")]
+    dst = [k for k in checkpoint["model"] if k.startswith(f"{prefix}.{trained_idx + 1}.")]
+    assert len(src) == len(dst) and len(src) > 0, "checkpoint has no such PNN columns"
+    for s_key, d_key in zip(src, dst):
+        checkpoint["model"][d_key].copy_(checkpoint["model"][s_key])
+    return checkpoint
+
+
 class ModelAMPContinuous(nn.Module):
     """`ModelAMPContinuous.Network` (phc/learning/amp_models.py:6-59) over rl_games' ModelA2CContinuousLogStd:
     Normal(mu, exp(logstd)) policy; neglogp / entropy as rl_games computes them."""

@@ -205,3 +205,38 @@ def test_flat_grad_bucket_is_one_buffer():
     assert lin[0].weight.grad.data_ptr() == b.flat.data_ptr()
     b.zero()
     assert lin[1].bias.grad.abs().sum() == 0
+
+
+def test_pnn_network_and_forward_pmcp():
+    """P3: PNN actor columns (key names, freezing, column selection) and the forward_pmcp column copy."""
+    from phc_amd.learning.network import A2CPNNNetwork, forward_pmcp
+    cfg = compose(["learning=im_pnn", "env=env_im_pnn"])
+    detail = {"num_prim": 3, "training_prim": 1, "has_lateral": False}
+    net = A2CPNNNetwork(cfg.learning.params.network, 69, (934,), (1960,), detail)
+    model = ModelAMPContinuous(net)
+    keys = set(model.state_dict())
+    assert "a2c_network.pnn.actors.2.4.weight" in keys and "a2c_network.actor_mlp.0.weight" not in keys and "a2c_network.mu.weight" not in keys
+    assert not any(p.requires_grad for p in net.pnn.actors[0].parameters())          # columns < training_prim frozen (pnn.py:40-45)
+    assert all(p.requires_grad for p in net.pnn.actors[1].parameters())
+    obs = torch.randn(5, 934)
+    mu, logstd = net.eval_actor(obs)
+    assert torch.equal(mu, net.pnn.actors[1](obs)) and mu.shape == (5, 69)
+    ck = {"model": {k: v.clone() for k, v in model.state_dict().items()}}
+    forward_pmcp(ck, 1)
+    assert torch.equal(ck["model"]["a2c_network.pnn.actors.2.0.weight"], ck["model"]["a2c_network.pnn.actors.1.0.weight"])
+    assert not torch.equal(ck["model"]["a2c_network.pnn.actors.0.0.weight"], ck["model"]["a2c_network.pnn.actors.1.0.weight"])
+    # a PNN agent trains only the active column (and critic / disc)
+    class T(FakeTask):
+        def get_task_obs_size_detail(self):
+            return {"num_prim": 2, "training_prim": 1, "has_lateral": False}
+    env = FakeVecEnv(32)
+    env.task = T(32)
+    c = small_cfg()
+    c.learning.params.network.name = "amp_pnn"
+    agent = IMAmpAgent(env, c, bf16=False)
+    agent.init_train()
+    w_frozen = agent.model.a2c_network.pnn.actors[0][0].weight.clone()
+    w_active = agent.model.a2c_network.pnn.actors[1][0].weight.clone()
+    agent.train_epoch()
+    assert torch.equal(w_frozen, agent.model.a2c_network.pnn.actors[0][0].weight)
+    assert not torch.equal(w_active, agent.model.a2c_network.pnn.actors[1][0].weight)
