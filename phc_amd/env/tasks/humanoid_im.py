@@ -416,12 +416,36 @@ class HumanoidIm:
                                    "min_length": self._min_motion_len, "max_length": -1, "im_eval": flags.im_eval,
                                    "multi_thread": False, "smpl_type": self.humanoid_type, "randomrize_heading": True, "step_dt": self.dt})
         self._motion_train_lib = MotionLibSMPL(motion_lib_cfg)
-        self._motion_eval_lib = self._motion_train_lib
+        self._motion_eval_lib = None  # built lazily by get_eval_motion_lib()
         self._motion_lib = self._motion_train_lib
         self._motion_lib.load_motions(skeleton_trees=self.skeleton_trees, gender_betas=self.humanoid_shapes.cpu(),
                                       limb_weights=self.humanoid_limb_and_weights.cpu(),
                                       random_sample=(not flags.test) and (not self.seq_motions),
                                       max_len=-1 if flags.test else self.max_len, start_idx=self.start_idx)
+
+    def get_eval_motion_lib(self):
+        """The reference's `_motion_eval_lib` (humanoid_im.py:333-336): same data, `im_eval=True` -> clips sorted by length."""
+        if self._motion_eval_lib is None:
+            from ...config import EasyDict
+            cfg = EasyDict(dict(self._motion_train_lib.m_cfg))
+            cfg.im_eval = True
+            cfg.motion_file = self._motion_train_lib._motion_data_load
+            self._motion_eval_lib = MotionLibSMPL(cfg)
+        return self._motion_eval_lib
+
+    def begin_seq_motion_samples(self):
+        """humanoid_im.py:468-472."""
+        self.start_idx = 0
+        self._motion_lib.load_motions(skeleton_trees=self.skeleton_trees, gender_betas=self.humanoid_shapes.cpu(),
+                                      limb_weights=self.humanoid_limb_and_weights.cpu(), random_sample=False, start_idx=self.start_idx)
+        self.reset()
+
+    def forward_motion_samples(self):
+        """humanoid_im.py:474-477."""
+        self.start_idx += self.num_envs
+        self._motion_lib.load_motions(skeleton_trees=self.skeleton_trees, gender_betas=self.humanoid_shapes.cpu(),
+                                      limb_weights=self.humanoid_limb_and_weights.cpu(), random_sample=False, start_idx=self.start_idx)
+        self.reset()
 
     def resample_motions(self):
         """humanoid_im.py:369-396: re-sample one clip per env, then reset everything."""

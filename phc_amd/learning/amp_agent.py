@@ -486,6 +486,11 @@ class IMAmpAgent:
                     f"disc_r {info['mean_disc_reward']:.4f} a_loss {info['actor_loss']:.4f} c_loss {info['critic_loss']:.4f} disc_loss {info['disc_loss']:.4f}")
         return info
 
+    def eval(self, output_dir=None, log=print):
+        """IMAmpAgent.eval (im_amp.py:136-242): success rate / MPJPE over the whole motion set + auto-PMCP re-weighting."""
+        from .im_eval import evaluate
+        return evaluate(self, output_dir=output_dir, log=log if self.rank == 0 else None)
+
     # ------------------------------------------------------------------ checkpoint (amp_agent.py:69-108; SURVEY B4 key names)
     def get_full_state_weights(self):
         s = {"model": self.model.state_dict(), "epoch": self.epoch_num, "optimizer": self.optimizer.state_dict(), "frame": self.frame}

@@ -240,3 +240,37 @@ def test_ppo_train_epoch_on_device():
     assert not torch.equal(w0, agent.model.a2c_network.mu.weight)
     assert agent.batch_size == 256 * 32 and agent.num_minibatches == 4
     assert info["total_fps"] > 0
+
+
+def test_im_eval_sweep_and_auto_pmcp():
+    """P10: evaluation sweep over all clips (5 clips, 2 envs -> 3 batches), metrics, failed keys, sampler re-weighting,
+    training state restored afterwards."""
+    from phc_amd.learning.amp_agent import IMAmpAgent
+    from phc_amd.utils.flags import flags
+    task, env = make_task(2, motion="synthetic:5:4:1.2", **{"learning.params.config.minibatch_size": 64, "env.auto_pmcp_soft": True,
+                                                           "learning.params.config.amp_obs_demo_buffer_size": 512,
+                                                           "learning.params.config.amp_replay_buffer_size": 512})
+    agent = IMAmpAgent(env, task.cfg)
+    td0 = task._termination_distances.clone()
+    lib0 = task._motion_lib
+    info, failed = agent.eval()
+    assert 0.0 <= info["eval/success_rate"] <= 1.0 and np.isfinite(info["eval/mpjpe_all"]) and info["eval/mpjpe_all"] > 0
+    assert len(failed) == round((1 - info["eval/success_rate"]) * 5)
+    assert torch.equal(task._termination_distances, td0) and task._motion_lib is lib0 and not flags.im_eval and not flags.test
+    if len(failed):  # soft auto-PMCP: sampling mass moved onto the failed clips (motion_lib_base.py:365-387)
+        p = task._motion_lib._sampling_prob.cpu().numpy()
+        keys = task._motion_lib._motion_data_keys
+        assert p[[list(keys).index(k) for k in failed]].sum() > 0.99
+    obs, rew, done, _ = env.step(torch.zeros(2, 69, device=task.device))
+    assert torch.isfinite(obs).all()
+
+
+def test_metrics_lite_procrustes():
+    from phc_amd.learning.im_eval import compute_metrics_lite
+    rng = np.random.default_rng(0)
+    gt = rng.normal(size=(6, 24, 3))
+    c, s = np.cos(0.3), np.sin(0.3)
+    R = np.array([[c, -s, 0], [s, c, 0], [0, 0, 1.0]])
+    pred = 1.1 * gt @ R.T + np.array([0.5, -0.2, 0.1])
+    m = compute_metrics_lite([pred], [gt])
+    assert m["mpjpe_g"][0] > 100 and m["mpjpe_pa"][0] < 1e-6
