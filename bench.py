@@ -44,15 +44,16 @@ def parse():
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU (BASELINE configs[1]: 4096)")
-    ap.add_argument("--ppo-epochs", type=int, default=1, help="timed PPO epochs (rollout 32 steps + 36 optimizer steps); 0 = skip")
+    ap.add_argument("--ppo-epochs", type=int, default=3, help="timed PPO epochs (rollout 32 steps + 36 optimizer steps); 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--motion-clips", type=int, default=1, help="synthetic clips in the motion library (configs[1]: 1; configs[2]/[3] shape: thousands)")
     ap.add_argument("--actions", choices=["random", "tracking"], default="random",
                     help="random: fixed a ~ U(-1,1)*0.1 tensor (SURVEY 8d protocol; zero-pose targets -> episodes end after a few steps); "
                          "tracking: PD target = reference pose of the next frame (episodes last like a trained policy's)")
     return ap.parse_args()
 
 
-def cpu_baseline(num_envs=4096, steps=100):
+def cpu_baseline(num_envs=4096, budget_s=12.0, max_steps=4000):
     """CPU port of the same path on the host cores: oracle/hostemu = the kernels' per-lane functions compiled with
     g++ -O2 -fopenmp, one env per OpenMP iteration.  (The reference has no CPU dynamics at all -- Isaac Gym is a GPU
     binary -- and its reward/obs path is Python/torch; this port is the builder's CPU restatement)"""
@@ -128,9 +129,14 @@ def cpu_baseline(num_envs=4096, steps=100):
         r, cur = rate(c, 2, cur)
         if r > best_rate:
             best, best_rate = c, r
-    t0 = time.perf_counter()
-    val, cur = rate(best, steps, cur)
+    e.emu_set_threads(int(best))
+    steps, t0 = 0, time.perf_counter()
+    while steps < max_steps and time.perf_counter() - t0 < budget_s:  # bounded sample: ~budget_s of CPU work
+        for _ in range(10):
+            cur = one(cur)
+        steps += 10
     dt = time.perf_counter() - t0
+    val = N * steps / dt
     return {"value": val, "unit": "env-steps/s", "cores": best, "kind": "port",
             "sample": f"{steps} steps x {N} envs (reset+stepper+post-physics), g++ -O2 -fopenmp build of the kernels' per-lane code "
                       f"(oracle/hostemu), {dt:.1f} s wall on {best} OpenMP threads (best of {cands}; host reports {os.cpu_count()} cpus)"}
@@ -154,7 +160,7 @@ def main():
     from phc_amd.config import compose
     from phc_amd.env.tasks.vec_task import parse_task
     torch.manual_seed(rank)  # per-rank seed offset, as the reference's horovod path does (run_hydra.py:121)
-    cfg = compose([f"env.num_envs={args.envs}", "env.motion_file=synthetic:1:0", f"device_id={local_rank}", f"rl_device=cuda:{local_rank}"])
+    cfg = compose([f"env.num_envs={args.envs}", f"env.motion_file=synthetic:{args.motion_clips}:0", f"device_id={local_rank}", f"rl_device=cuda:{local_rank}"])
     task, env = parse_task(cfg, device_id=local_rank)
     dev = task.device
     N = task.num_envs
