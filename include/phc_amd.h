@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PHC_ABI_VERSION 1
+#define PHC_ABI_VERSION 2
 #define PHC_MAX_BODIES 32
 #define PHC_EINVAL (-1)
 #define PHC_EUNSUPPORTED (-2)
@@ -111,6 +111,11 @@ typedef struct {
     int32_t num_amp_obs_steps;        /* numAMPObsSteps 10 */
     int32_t num_amp_obs_per_step;     /* 196 */
     int32_t num_self_obs, num_task_obs; /* 358, 576 */
+    /* config 3 (getup / MCP composer envs, env_im_getup_mcp.yaml) */
+    int32_t cycle_motion;             /* env.cycle_motion: restart the clip in place instead of ending the episode (:1120-1150) */
+    int32_t zero_out_far;             /* env.zero_out_far: point-goal reward + task-obs gating when far from the reference (:783-797,890-905) */
+    float close_distance;             /* humanoid.py:328 (0.25) */
+    float far_distance;               /* humanoid.py:329 (3) */
 } phc_im_params_t;
 
 /* Task-owned per-env buffers (phc/env/tasks/base_task.py:99-105, humanoid_amp.py:109-116,
@@ -132,6 +137,10 @@ typedef struct {
     float* ref_body_rot;              /* [N,NB,4] nullable */
     float* ref_body_vel;              /* [N,NB,3] nullable */
     float* ref_dof_pos;               /* [N,D] nullable */
+    int32_t* cycle_counter;           /* [N] humanoid_im.py:72,1077-1078,1128,1186; nullable unless cycle_motion */
+    int32_t* recovery_counter;        /* [N] humanoid_im_getup.py:62,203-216; nullable (plain HumanoidIm) */
+    float* point_goal;                /* [N] humanoid_im.py:95,792,898; nullable unless zero_out_far */
+    const float* cycle_phase;         /* [N] the caller's torch.rand draw for _sample_time of cycled envs (:1127); nullable unless cycle_motion */
 } phc_im_buffers_t;
 
 int32_t phc_abi_version(void);
@@ -161,6 +170,10 @@ int32_t phc_sim_step(const phc_model_t* model, const phc_sim_params_t* params, c
 /* S7 alone: forward kinematics from (root_states, dof_state) to rigid_body_state. */
 int32_t phc_refresh_body_state(const phc_model_t* model, const phc_sim_state_t* sim, void* stream);
 
+/* S7 for a list of envs (after a teleport of root_states / dof_state: gym.set_*_indexed + refresh). */
+int32_t phc_refresh_body_state_indexed(const phc_model_t* model, const phc_sim_state_t* sim, int32_t num, const int64_t* env_ids,
+                                       void* stream);
+
 /* post_physics_step of HumanoidIm in one launch (humanoid.py:1634-1650, humanoid_amp.py:194-210,
  * humanoid_im.py:694-948,1117-1190): progress_buf += 1, reference lookup at t and t+dt,
  * imitation + power reward, reset / terminate, self obs, task obs v6, AMP obs + history shift. */
@@ -177,6 +190,17 @@ int32_t phc_im_post_physics(const phc_model_t* model, const phc_motion_lib_t* li
 int32_t phc_im_reset(const phc_model_t* model, const phc_motion_lib_t* lib, const phc_im_params_t* prm,
                      const phc_sim_state_t* sim, const phc_im_buffers_t* buf, int32_t num_reset,
                      const int64_t* env_ids, const float* phase /*[num_reset]*/, int32_t start_at_zero, void* stream);
+
+/* HumanoidImGetup._reset_fall_episode + the shared tail of _reset_envs (humanoid_im_getup.py:166-196, humanoid.py:585-621,
+ * humanoid_amp.py:559-573): the caller has written root_states / dof_state of the listed envs (a stored fall state);
+ * after phc_refresh_body_state_indexed made their rigid_body_state current, this call zeroes
+ * progress/reset/terminate/contact, sets the PD target to the joint positions, recomputes their observations against
+ * the reference at the env's (unchanged) motion clock and recomputes the current AMP observation; fill_history != 0
+ * copies it into every history slot (_init_amp_obs_default) -- 0 is the "recovery episode" case (:160-164) where the
+ * env keeps its state and its AMP history. */
+int32_t phc_im_reset_from_state(const phc_model_t* model, const phc_motion_lib_t* lib, const phc_im_params_t* prm,
+                                const phc_sim_state_t* sim, const phc_im_buffers_t* buf, int32_t num_reset,
+                                const int64_t* env_ids, int32_t fill_history, void* stream);
 
 /* HumanoidAMP.build_amp_obs_demo (humanoid_amp.py:253-284): n samples x S steps back in time. */
 int32_t phc_amp_obs_demo(const phc_model_t* model, const phc_motion_lib_t* lib, const phc_im_params_t* prm, int32_t n,

@@ -1,0 +1,160 @@
+"""TEST INFRASTRUCTURE ONLY -- golden vectors for the config-3 branches of post_physics_step (cycle_motion, zero_out_far,
+cycle counter), produced by driving the reference's OWN jit functions / motion library in the order the reference's methods
+do (the methods themselves need Isaac Gym):
+
+    _compute_reward   humanoid_im.py:876-948   (zero_out_far branch :890-905, compute_point_goal_reward :1558-1562)
+    _compute_reset    humanoid_im.py:1117-1190 (cycle_motion branch :1123-1150, is_recovery :1186-1188)
+    _compute_task_obs humanoid_im.py:728-871   (zero_out_far gating :783-797)
+
+Run in the build container:  python oracle/gen_golden_cfg3.py   -> tests/golden/task_fns_cfg3.npz
+"""
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+import ref_shim  # noqa: E402
+
+ref_shim.install()
+import joblib  # noqa: E402
+import torch  # noqa: E402
+
+from gen_golden import MJCF, OUT, RESET_BODIES, t2n  # noqa: E402
+from phc_amd.utils.synthetic_motion import make_motion_dict  # noqa: E402
+
+
+def main():
+    torch.set_num_threads(1)
+    itu = ref_shim.ref_module("phc.utils.isaacgym_torch_utils")
+    him = ref_shim.ref_module("phc.env.tasks.humanoid_im")
+    from phc.utils.flags import flags
+    from phc.utils.motion_lib_base import FixHeightMode
+    from phc.utils.motion_lib_smpl import MotionLibSMPL
+    from poselib.poselib.skeleton.skeleton3d import SkeletonTree
+    from easydict import EasyDict
+
+    tree = SkeletonTree.from_mjcf(MJCF)
+    names = list(tree.node_names)
+    parents = t2n(tree.parent_indices).astype(np.int32)
+    # the SAME three clips as gen_golden.py (motion_clips.npz / motion_lib_eval.npz)
+    clips = make_motion_dict(parents, 3, seed=7, body_names=names, lengths=[31, 45, 38])
+    for v in clips.values():
+        v["root_trans_offset"] = torch.from_numpy(np.asarray(v["root_trans_offset"], np.float64))
+    tmp = tempfile.mkdtemp()
+    pkl = os.path.join(tmp, "clips.pkl")
+    joblib.dump(clips, pkl)
+    N = 6
+    os.chdir(tmp)
+    cfg = EasyDict({"motion_file": pkl, "device": torch.device("cpu"), "fix_height": FixHeightMode.full_fix, "min_length": -1, "max_length": -1,
+                    "im_eval": False, "multi_thread": False, "smpl_type": "smpl", "randomrize_heading": True, "step_dt": 1 / 30})
+    flags.test, flags.im_eval = True, False
+    lib = MotionLibSMPL(cfg)
+    lib.load_motions(skeleton_trees=[tree] * N, gender_betas=torch.zeros(N, 17), limb_weights=np.zeros((N, 10)), random_sample=False, start_idx=0, max_len=-1)
+    ref = np.load(os.path.join(OUT, "motion_lib_eval.npz"))
+    assert np.array_equal(t2n(lib.gts), ref["gts"]), "clips differ from the ones behind motion_lib_eval.npz"
+
+    g = torch.Generator().manual_seed(77)
+    E, dt, max_ep = 48, 1 / 30, 300
+    ids = torch.arange(E) % N
+    progress = torch.randint(2, 15, (E,), generator=g)         # value AFTER progress_buf += 1
+    progress[:4] = torch.tensor([1, 2, 3, 299])
+    progress[4:6] = torch.tensor([298, 300])
+    st = lib.sample_time_interval(ids)
+    so = torch.zeros(E)
+    # envs 20..27: clip runs out this step (time >= motion length) -> cycled
+    st[20:28] = lib._motion_lengths[ids[20:28]] - progress[20:28] * dt + torch.tensor([0.0, 0.01, 0.3, 1.0, 0.0, 0.02, 0.5, 2.0])
+    goff = torch.zeros(E, 3)
+    goff[6:10, :2] = torch.randn(4, 2, generator=g)
+    cycle_counter0 = torch.randint(0, 3, (E,), generator=g).int()  # value BEFORE pre_physics_step's decrement
+    cycle_counter0[30:34] = torch.tensor([5, 1, 2, 0]).int()
+    point_goal_prev = torch.rand(E, generator=g) * 0.5
+
+    t = progress * dt + st + so
+    r0 = lib.get_motion_state(ids, t, offset=goff)
+    noise = lambda shape, s: torch.randn(*shape, generator=g) * s
+    body_pos = r0["rg_pos"] + noise((E, 24, 3), 0.03)
+    body_pos[10:14] += torch.tensor([0.5, 0.0, 0.0])      # beyond close_distance
+    body_pos[14:16] += torch.tensor([0.0, 4.0, 0.0])      # beyond far_distance
+    body_pos[30:34] += noise((4, 24, 3), 0.3)             # would terminate, cycle counter decides
+    body_pos[40:44] += noise((4, 24, 3), 0.3)             # terminates
+    body_rot = itu.quat_mul(itu.exp_map_to_quat(noise((E * 24, 3), 0.15)).view(E, 24, 4), r0["rb_rot"])
+    body_vel = r0["body_vel"] + noise((E, 24, 3), 0.3)
+    body_ang_vel = r0["body_ang_vel"] + noise((E, 24, 3), 0.5)
+    dof_vel = r0["dof_vel"] + noise((E, 69), 0.5)
+    dof_force = noise((E, 69), 40.0)
+    root_pos, root_rot = body_pos[:, 0], body_rot[:, 0]
+    specs = {"k_pos": 100., "k_rot": 10., "k_vel": 0.1, "k_ang_vel": 0.1, "w_pos": 0.5, "w_rot": 0.3, "w_vel": 0.1, "w_ang_vel": 0.1}
+
+    # ---- _compute_reward, zero_out_far branch (:890-905) ----
+    distance = torch.norm(root_pos - r0["root_pos"], dim=-1)
+    zs = distance > 0.25
+    raw = torch.zeros(E, 4)
+    rew, raw[:, 0] = him.compute_point_goal_reward(point_goal_prev, distance)
+    im_rew, im_raw = him.compute_imitation_reward(root_pos[~zs], root_rot[~zs], body_pos[~zs], body_rot[~zs], body_vel[~zs], body_ang_vel[~zs],
+                                                  r0["rg_pos"][~zs], r0["rb_rot"][~zs], r0["body_vel"][~zs], r0["body_ang_vel"][~zs], specs)
+    rew[~zs] = rew[~zs] + im_rew * 0.5
+    raw[~zs, :4] = raw[~zs, :4] + im_raw * 0.5
+    power_reward = -0.00005 * torch.abs(dof_force * dof_vel).sum(dim=-1)
+    power_reward[progress <= 3] = 0
+    rew = rew + power_reward
+    raw = torch.cat([raw, power_reward[:, None]], dim=-1)
+
+    # ---- pre_physics_step: _update_cycle_count (:1076-1079) ----
+    cyc = torch.clamp_min(cycle_counter0 - 1, 0)
+    # ---- _compute_reset, cycle_motion branch (:1117-1190) ----
+    st2, so2, goff2 = st.clone(), so.clone(), goff.clone()
+    pass_time_max = progress >= max_ep - 1
+    pass_len = t >= lib._motion_lengths[ids]
+    assert pass_len[20:28].all()
+    so2[pass_len] = -progress[pass_len] * dt
+    torch.manual_seed(11)
+    st2[pass_len] = lib.sample_time_interval(ids[pass_len])
+    torch.manual_seed(11)
+    phase_c = torch.rand(int(pass_len.sum()))
+    cycle_phase = torch.zeros(E)
+    cycle_phase[pass_len] = phase_c
+    cyc[pass_len] = 60
+    rr = lib.get_root_pos_smpl(ids[pass_len], st2[pass_len])
+    goff2[pass_len, :2] = root_pos[pass_len, :2] - rr["root_pos"][:, :2]
+    t2 = progress * dt + st2 + so2
+    rc = lib.get_motion_state(ids, t2, offset=goff2)
+    rid = torch.tensor([names.index(b) for b in RESET_BODIES])
+    td = torch.full((E, 24), 0.25)
+    reset, term = him.compute_humanoid_im_reset(torch.zeros(E, dtype=torch.long), progress, torch.zeros(E, 24, 3), torch.zeros(4, dtype=torch.long),
+                                                body_pos[:, rid].clone(), rc["rg_pos"][:, rid].clone(), pass_time_max, True, td[:, rid], False, False)
+    is_rec = torch.logical_and(~pass_time_max, cyc > 0)
+    reset[is_rec] = 0
+    term[is_rec] = 0
+
+    # ---- _compute_task_obs, zero_out_far gating (:745-797) then v6 ----
+    t1 = (progress + 1) * dt + st2 + so2
+    r1 = lib.get_motion_state(ids, t1, offset=goff2)
+    rp, rq, rv, rw = r1["rg_pos"].clone(), r1["rb_rot"].clone(), r1["body_vel"].clone(), r1["body_ang_vel"].clone()
+    d1 = torch.norm(root_pos - rp[:, 0], dim=-1)
+    z1 = d1 > 0.25
+    rp[z1, 1:] = body_pos[z1, 1:]
+    rq[z1, 1:] = body_rot[z1, 1:]
+    rv[z1, :] = body_vel[z1, :]
+    rw[z1, :] = body_ang_vel[z1, :]
+    vz = d1 > 3.0
+    rp[vz, 0] = ((rp[vz, 0] - body_pos[vz, 0]) / d1[vz, None] * 3.0) + body_pos[vz, 0]
+    task_obs = him.compute_imitation_observations_v6(root_pos, root_rot, body_pos, body_rot, body_vel, body_ang_vel, rp, rq, rv, rw, 1, True)
+
+    np.savez_compressed(os.path.join(OUT, "task_fns_cfg3.npz"), env_motion=t2n(ids), progress=t2n(progress), start_times=t2n(st), start_off=t2n(so),
+                        global_offset=t2n(goff), cycle_counter_in=t2n(cycle_counter0), point_goal_prev=t2n(point_goal_prev), cycle_phase=t2n(cycle_phase),
+                        body_pos=t2n(body_pos), body_rot=t2n(body_rot), body_vel=t2n(body_vel), body_ang_vel=t2n(body_ang_vel),
+                        dof_vel=t2n(dof_vel), dof_force=t2n(dof_force),
+                        reward=t2n(rew), reward_raw=t2n(raw), reset=t2n(reset), terminate=t2n(term), cycle_counter_out=t2n(cyc),
+                        start_times_out=t2n(st2), start_off_out=t2n(so2), global_offset_out=t2n(goff2), pass_len=t2n(pass_len),
+                        point_goal_out=t2n(d1), task_obs=t2n(task_obs), zeros_subset=t2n(z1), far_subset=t2n(vz), reward_far=t2n(zs))
+    print("cycled", int(pass_len.sum()), "reward-far", int(zs.sum()), "obs-zeroed", int(z1.sum()), "obs-far", int(vz.sum()),
+          "reset", int(reset.sum()), "terminated", int(term.sum()), "recovering", int(is_rec.sum()))
+
+
+if __name__ == "__main__":
+    main()

@@ -53,17 +53,28 @@ int emu_im_post_physics(const phc_model_t* model, const phc_motion_lib_t* lib, c
 #pragma omp parallel for schedule(static)
     for (int64_t env = 0; env < sim->num_envs; ++env) {
         const int64_t progress = buf->progress_buf[env] + 1;
+        const ImStepCtx c = im_post_prologue(*lib, *prm, *sim, *buf, env, progress);
+        const float prev_goal = (prm->zero_out_far && buf->point_goal) ? buf->point_goal[env] : 0.f;
         for (int lane = 0; lane < 32; ++lane) amp_shift_lane(*prm, *buf, env, lane);
         float s[6] = {0, 0, 0, 0, 0, 0};
+        float root_dist = 0.f;
         int fallen = 0;
         for (int lane = 0; lane < 32; ++lane) {
-            RewardPartial rp = im_post_lane(*model, *lib, *prm, *sim, *buf, env, lane, progress);
+            RewardPartial rp = im_post_lane(*model, *lib, *prm, *sim, *buf, env, lane, c);
             s[0] += rp.pos; s[1] += rp.rot; s[2] += rp.vel; s[3] += rp.angvel; s[4] += rp.power; s[5] += rp.dist;
+            if (lane == 0) root_dist = rp.root_dist;
             fallen |= rp.fallen;
         }
-        im_post_finalize(*lib, *prm, *buf, model->num_bodies, env, progress, s[0], s[1], s[2], s[3], s[4], s[5], fallen,
-                         prm->num_reset_bodies > 0 ? prm->num_reset_bodies : 1);
+        im_post_finalize(*lib, *prm, *buf, model->num_bodies, env, c, progress, s[0], s[1], s[2], s[3], s[4], s[5], root_dist, prev_goal,
+                         fallen, prm->num_reset_bodies > 0 ? prm->num_reset_bodies : 1);
     }
+    return 0;
+}
+
+int emu_im_reset_from_state(const phc_model_t* model, const phc_motion_lib_t* lib, const phc_im_params_t* prm, const phc_sim_state_t* sim,
+                            const phc_im_buffers_t* buf, int num_reset, const int64_t* env_ids, int fill_history) {
+    for (int r = 0; r < num_reset; ++r)
+        for (int lane = 31; lane >= 0; --lane) im_reset_from_state_lane(*model, *lib, *prm, *sim, *buf, env_ids[r], lane, fill_history);
     return 0;
 }
 

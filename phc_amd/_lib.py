@@ -54,14 +54,16 @@ class ImParams(C.Structure):
                 ("num_key_bodies", c_i32), ("key_body_ids", c_p),
                 ("num_amp_joints", c_i32), ("amp_joint_slot", c_p),
                 ("num_amp_obs_steps", c_i32), ("num_amp_obs_per_step", c_i32),
-                ("num_self_obs", c_i32), ("num_task_obs", c_i32)]
+                ("num_self_obs", c_i32), ("num_task_obs", c_i32),
+                ("cycle_motion", c_i32), ("zero_out_far", c_i32), ("close_distance", c_f), ("far_distance", c_f)]
 
 
 class ImBuffers(C.Structure):
     _fields_ = [("progress_buf", c_p), ("reset_buf", c_p), ("terminate_buf", c_p), ("rew_buf", c_p), ("reward_raw", c_p),
                 ("obs_buf", c_p), ("amp_obs_in", c_p), ("amp_obs_out", c_p), ("sampled_motion_ids", c_p),
                 ("motion_start_times", c_p), ("motion_start_times_offset", c_p), ("global_offset", c_p),
-                ("ref_body_pos", c_p), ("ref_body_rot", c_p), ("ref_body_vel", c_p), ("ref_dof_pos", c_p)]
+                ("ref_body_pos", c_p), ("ref_body_rot", c_p), ("ref_body_vel", c_p), ("ref_dof_pos", c_p),
+                ("cycle_counter", c_p), ("recovery_counter", c_p), ("point_goal", c_p), ("cycle_phase", c_p)]
 
 
 P = C.POINTER
@@ -73,6 +75,8 @@ _SIGNATURES = {
     "phc_refresh_body_state": ([P(Model), P(SimState), c_p], c_i32),
     "phc_im_post_physics": ([P(Model), P(MotionLib), P(ImParams), P(SimState), P(ImBuffers), c_p], c_i32),
     "phc_im_reset": ([P(Model), P(MotionLib), P(ImParams), P(SimState), P(ImBuffers), c_i32, c_p, c_p, c_i32, c_p], c_i32),
+    "phc_im_reset_from_state": ([P(Model), P(MotionLib), P(ImParams), P(SimState), P(ImBuffers), c_i32, c_p, c_i32, c_p], c_i32),
+    "phc_refresh_body_state_indexed": ([P(Model), P(SimState), c_i32, c_p, c_p], c_i32),
     "phc_amp_obs_demo": ([P(Model), P(MotionLib), P(ImParams), c_i32, c_p, c_p, c_p, c_p], c_i32),
     "phc_gae": ([c_i32, c_i32, c_p, c_p, c_p, c_p, c_f, c_f, c_p, c_p], c_i32),
     "phc_fk": ([P(Model), c_i64, c_p, c_p, c_p, c_p, c_p], c_i32),
@@ -95,7 +99,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the .so does not export the symbol
         fn.argtypes = argtypes
         fn.restype = restype
-    if lib.phc_abi_version() != 1:
+    if lib.phc_abi_version() != 2:
         raise ImportError("libphc_amd.so ABI version mismatch")
     _lib = lib
     return lib

@@ -84,7 +84,8 @@ def pack_frames(gts, grs, gvs, gavs, lrs, dvs, xp=np):
 def im_params_struct(dt, max_episode_length, reward_specs, power_reward, power_coefficient, enable_early_termination,
                      use_mean_termination, disable_collision_check, local_root_obs, root_height_obs, num_track_bodies,
                      track_slot, reset_mask, num_reset_bodies, first_reset_body, termination_distances, num_key_bodies, key_body_ids,
-                     num_amp_joints, amp_joint_slot, num_amp_obs_steps, num_amp_obs_per_step, num_self_obs, num_task_obs):
+                     num_amp_joints, amp_joint_slot, num_amp_obs_steps, num_amp_obs_per_step, num_self_obs, num_task_obs,
+                     cycle_motion=False, zero_out_far=False, close_distance=0.25, far_distance=3.0):
     p = L.ImParams()
     p.dt = float(np.float32(dt))
     p.max_episode_length = int(max_episode_length)
@@ -103,12 +104,15 @@ def im_params_struct(dt, max_episode_length, reward_specs, power_reward, power_c
     p.num_amp_joints, p.amp_joint_slot = int(num_amp_joints), ptr(amp_joint_slot)
     p.num_amp_obs_steps, p.num_amp_obs_per_step = int(num_amp_obs_steps), int(num_amp_obs_per_step)
     p.num_self_obs, p.num_task_obs = int(num_self_obs), int(num_task_obs)
+    p.cycle_motion, p.zero_out_far = int(bool(cycle_motion)), int(bool(zero_out_far))
+    p.close_distance, p.far_distance = float(close_distance), float(far_distance)
     return p
 
 
 def im_buffers_struct(progress_buf, reset_buf, terminate_buf, rew_buf, reward_raw, obs_buf, amp_obs_in, amp_obs_out,
                       sampled_motion_ids, motion_start_times, motion_start_times_offset, global_offset,
-                      ref_body_pos=None, ref_body_rot=None, ref_body_vel=None, ref_dof_pos=None):
+                      ref_body_pos=None, ref_body_rot=None, ref_body_vel=None, ref_dof_pos=None,
+                      cycle_counter=None, recovery_counter=None, point_goal=None, cycle_phase=None):
     b = L.ImBuffers()
     b.progress_buf, b.reset_buf, b.terminate_buf = ptr(progress_buf), ptr(reset_buf), ptr(terminate_buf)
     b.rew_buf, b.reward_raw, b.obs_buf = ptr(rew_buf), ptr(reward_raw), ptr(obs_buf)
@@ -117,6 +121,8 @@ def im_buffers_struct(progress_buf, reset_buf, terminate_buf, rew_buf, reward_ra
     b.motion_start_times, b.motion_start_times_offset = ptr(motion_start_times), ptr(motion_start_times_offset)
     b.global_offset = ptr(global_offset)
     b.ref_body_pos, b.ref_body_rot, b.ref_body_vel, b.ref_dof_pos = ptr(ref_body_pos), ptr(ref_body_rot), ptr(ref_body_vel), ptr(ref_dof_pos)
+    b.cycle_counter, b.recovery_counter = ptr(cycle_counter), ptr(recovery_counter)
+    b.point_goal, b.cycle_phase = ptr(point_goal), ptr(cycle_phase)
     return b
 
 

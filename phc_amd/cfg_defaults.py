@@ -36,6 +36,15 @@ _ENV_IM = {  # env/env_im.yaml
 _ENV_IM_PNN = dict(_ENV_IM, notes=" ", has_pnn=True, fitting=False, num_prim=3, training_prim=0, actors_to_load=0,
                    has_lateral=False, models=[], zero_out_far=False, zero_out_far_train=False, getup_udpate_epoch=78750)
 
+_ENV_IM_GETUP_MCP = dict(  # env/env_im_getup_mcp.yaml
+    _ENV_IM, task="HumanoidImMCPGetup", notes="Progressive MCP without softmax, zero out far", num_envs=1024, env_spacing=2,
+    sym_loss_coef=1, add_obs_noise=False, add_action_noise=False, action_noise_std=0.05, mlp_bypass=False, mlp_model_path="",
+    start_idx=0, collect_dataset=False, has_pnn=True, fitting=True, num_prim=4, training_prim=0, actors_to_load=4, has_lateral=False,
+    models=[], zero_out_far=True, zero_out_far_train=False, cycle_motion=True, getup_udpate_epoch=1000, getup_schedule=True,
+    recoverySteps=90, zero_out_far_steps=90, recoveryEpisodeProb=0.5, fallInitProb=0.3, hard_negative=False, z_activation="silu",
+    power_coefficient=0.00005)
+_ENV_IM_GETUP_MCP.pop("min_length", None)
+
 _ROBOT_SMPL = {  # robot/smpl_humanoid.yaml
     "humanoid_type": "smpl", "bias_offset": False, "has_self_collision": True, "has_mesh": False, "has_jt_limit": False,
     "has_dof_subset": True, "has_upright_start": True, "has_smpl_pd_offset": False, "remove_toe": False, "motion_sym_loss": False,
@@ -58,7 +67,7 @@ _DR_DEFAULT = {"has_domain_rand": False, "push_robots": False, "randomize_fricti
                "randomize_ctrl_delay": False, "add_noise": False}
 
 
-def _learning(units, activation, net_name="amp", extra_cfg=None):
+def _learning(units, activation, net_name="amp", extra_cfg=None, extra_net=None):
     cfg = {  # learning/im.yaml `params.config`
         "name": "Humanoid", "env_name": "rlgpu", "multi_gpu": False, "ppo": True, "mixed_precision": False, "normalize_input": True,
         "normalize_value": True, "reward_shaper": {"scale_value": 1}, "normalize_advantage": True, "gamma": 0.99, "tau": 0.95,
@@ -82,16 +91,28 @@ def _learning(units, activation, net_name="amp", extra_cfg=None):
             "disc": {"units": [1024, 512], "activation": "relu", "initializer": {"name": "default"}},
         },
         "load_checkpoint": False, "config": cfg,
-    }}
+    }} if not extra_net else _with_net(units, activation, net_name, cfg, extra_net)
+
+
+def _with_net(units, activation, net_name, cfg, extra_net):
+    base = _learning(units, activation, net_name)
+    base["params"]["config"] = cfg
+    base["params"]["network"].update(extra_net)
+    return base
 
 
 _BIG = [2048, 1536, 1024, 1024, 512, 512]
 GROUPS = {
-    "env": {"env_im": _ENV_IM, "env_im_pnn": _ENV_IM_PNN},
+    "env": {"env_im": _ENV_IM, "env_im_pnn": _ENV_IM_PNN, "env_im_getup_mcp": _ENV_IM_GETUP_MCP},
     "robot": {"smpl_humanoid": _ROBOT_SMPL},
     "learning": {"im": _learning([1024, 512], "relu"), "im_big": _learning(_BIG, "silu", extra_cfg={"save_frequency": 1500}),
                  "im_pnn": _learning([1024, 512], "relu", "amp_pnn"),
-                 "im_pnn_big": _learning(_BIG, "silu", "amp_pnn", {"amp_dropout": False, "save_frequency": 1500})},
+                 "im_pnn_big": _learning(_BIG, "silu", "amp_pnn", {"amp_dropout": False, "save_frequency": 1500}),
+                 "im_mcp": _learning([1024, 512], "relu", "amp_mcp", {"player": {"games_num": 999999999999999999999999}},
+                                     {"has_softmax": False, "ending_act": True}),
+                 "im_mcp_big": _learning(_BIG, "silu", "amp_mcp", {"player": {"games_num": 999999999999999999999999},
+                                                                  "save_frequency": 500, "amp_dropout": True},
+                                         {"has_softmax": False, "ending_act": True})},
     "sim": {"default_sim": _SIM_DEFAULT},
     "control": {"default_control": _CONTROL_DEFAULT},
     "domain_rand": {"default_dr": _DR_DEFAULT},

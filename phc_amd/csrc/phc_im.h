@@ -63,27 +63,100 @@ PHC_HD void amp_shift_lane(const phc_im_params_t& prm, const phc_im_buffers_t& b
     }
 }
 
+// Per-env scalar state of one post-physics step, computed redundantly by every lane of the env (a handful of loads)
+// BEFORE any lane work, because the config-3 options change what the lanes look up:
+//   cycle_motion  (humanoid_im.py:1120-1150): an env whose clip ran out restarts the clip in place -- new start time,
+//                 time offset cancelling progress, global xy offset pinning the clip's root to the humanoid's root;
+//                 the reward still uses the old time/offset (it is computed before _compute_reset, humanoid.py:1642-1645);
+//   getup         (humanoid_im_getup.py:203-216): while recovery_counter > 0 the env is neither reset nor advanced.
+struct ImStepCtx {
+    int64_t progress;     // progress_buf value written back (getup recovery: not advanced)
+    float t_rew; V3 goff_rew;    // reward lookup
+    float t0; V3 goff;           // reset lookup and everything after it
+    float t1;                    // observation lookup ("next frame")
+    float start, start_off;      // motion_start_times / _offset after cycling
+    int pass_time;               // the pass_time handed to compute_humanoid_im_reset
+    int cycled, cycle_cnt, recovery_cnt;
+};
+
+PHC_HD ImStepCtx im_post_prologue(const phc_motion_lib_t& lib, const phc_im_params_t& prm, const phc_sim_state_t& sim,
+                                  const phc_im_buffers_t& buf, int64_t env, int64_t progress) {
+    ImStepCtx c;
+    const int64_t mid = buf.sampled_motion_ids[env];
+    c.start = buf.motion_start_times[env];
+    c.start_off = buf.motion_start_times_offset[env];
+    c.goff_rew = ld3(buf.global_offset + env * 3);
+    c.goff = c.goff_rew;
+    c.t_rew = motion_time(progress, prm.dt, c.start, c.start_off);  // humanoid_im.py:879
+    c.t0 = c.t_rew;
+    // pre_physics_step: _update_cycle_count / _update_recovery_count (humanoid_im.py:1076-1079,1110; humanoid_im_getup.py:198-201)
+    c.cycle_cnt = buf.cycle_counter ? (buf.cycle_counter[env] > 1 ? buf.cycle_counter[env] - 1 : 0) : 0;
+    c.recovery_cnt = buf.recovery_counter ? (buf.recovery_counter[env] > 1 ? buf.recovery_counter[env] - 1 : 0) : 0;
+    c.cycled = 0;
+    const bool pass_len = c.t_rew >= lib.motion_lengths[mid];
+    c.pass_time = pass_len ? 1 : 0;
+    if (prm.cycle_motion) {
+        c.pass_time = (progress >= (int64_t)prm.max_episode_length - 1) ? 1 : 0;  // :1120,1124
+        if (pass_len) {
+            c.cycled = 1;
+            c.start_off = neg_progress_time(progress, prm.dt);                       // :1126
+            c.start = sample_time_interval(lib, mid, buf.cycle_phase[env]);         // :1127
+            c.cycle_cnt = 60;                                                       // :1128
+            const FrameRef fr = frame_ref(lib, mid, c.start);
+            const V3 rp = ref_root_pos_lerp(lib, fr);                               // get_root_pos_smpl motion_lib_base.py:522-547
+            const float* rs = sim.root_states + env * 13;
+            c.goff.x = rs[0] - rp.x; c.goff.y = rs[1] - rp.y;                       // :1146 (z keeps its value)
+            c.t0 = motion_time(progress, prm.dt, c.start, c.start_off);             // :1148
+        }
+    }
+    c.progress = progress;
+    if (c.recovery_cnt > 0) c.progress = progress - 1;  // humanoid_im_getup.py:215
+    c.t1 = motion_time(c.progress + 1, prm.dt, c.start, c.start_off);  // humanoid_im.py:752
+    return c;
+}
+
+// zero_out_far gating of the task-obs reference (humanoid_im.py:783-797): beyond close_distance only the root target
+// survives (the other bodies' targets collapse onto the current pose -> zero differences), beyond far_distance the root
+// target becomes a far_distance-long direction.  Returns the distance (-> _point_goal).
+PHC_HD float zero_out_far_ref(const phc_im_params_t& prm, int slot, const BodyState& body, const BodyState& root,
+                              const BodyState& ref_root, BodyState* ref) {
+    const float distance = norm(root.pos - ref_root.pos);
+    if (distance > prm.close_distance) {
+        if (slot >= 1) { ref->pos = body.pos; ref->rot = body.rot; }
+        ref->vel = body.vel; ref->angvel = body.angvel;
+    }
+    if (distance > prm.far_distance && slot == 0) {
+        V3 d = ref->pos - body.pos;
+        ref->pos = v3(d.x / distance * prm.far_distance, d.y / distance * prm.far_distance, d.z / distance * prm.far_distance) + body.pos;
+    }
+    return distance;
+}
+
 // post_physics_step for lane (env, j); `progress` is the already incremented progress_buf value
 // (humanoid.py:1637).  Writes obs / AMP slices, returns the partials the caller reduces over the env.
 PHC_HD RewardPartial im_post_lane(const phc_model_t& model, const phc_motion_lib_t& lib, const phc_im_params_t& prm,
-                                  const phc_sim_state_t& sim, const phc_im_buffers_t& buf, int64_t env, int j, int64_t progress) {
+                                  const phc_sim_state_t& sim, const phc_im_buffers_t& buf, int64_t env, int j, const ImStepCtx& c) {
     const int nb = model.num_bodies, nd = model.num_dof;
     RewardPartial rp;
-    rp.pos = rp.rot = rp.vel = rp.angvel = rp.power = rp.dist = 0.f; rp.fallen = 0;
+    rp.pos = rp.rot = rp.vel = rp.angvel = rp.power = rp.dist = rp.root_dist = 0.f; rp.fallen = 0;
     if (j >= nb) return rp;
     const int64_t mid = buf.sampled_motion_ids[env];
-    const float st = buf.motion_start_times[env], so = buf.motion_start_times_offset[env];
-    const V3 goff = ld3(buf.global_offset + env * 3);
-    // humanoid_im.py:879 (reward / reset time) and :752 (observation time, "next frame so +1")
-    const float t0 = motion_time(progress, prm.dt, st, so);
-    const float t1 = motion_time(progress + 1, prm.dt, st, so);
-    const FrameRef fr0 = frame_ref(lib, mid, t0), fr1 = frame_ref(lib, mid, t1);
+    const FrameRef fr0 = frame_ref(lib, mid, c.t0), fr1 = frame_ref(lib, mid, c.t1);
     BodyState body = load_body(sim.rigid_body_state, env, nb, j);
     BodyState root = load_body(sim.rigid_body_state, env, nb, 0);
     BodyState r0 = ref_body(lib, fr0, j), r1 = ref_body(lib, fr1, j);
-    r0.pos += goff; r1.pos += goff;  // motion_lib_base.py:476
+    r0.pos += c.goff; r1.pos += c.goff;  // motion_lib_base.py:476
     // R1 / R5 partials
     rp = reward_partial(prm, env, nb, j, body, r0);
+    if (c.cycled) {  // the reward was computed before the clip restarted: old time, old offset (humanoid.py:1644-1645)
+        BodyState rr = ref_body(lib, frame_ref(lib, mid, c.t_rew), j);
+        rr.pos += c.goff_rew;
+        RewardPartial q = reward_partial(prm, env, nb, j, body, rr);
+        rp.pos = q.pos; rp.rot = q.rot; rp.vel = q.vel; rp.angvel = q.angvel;
+        if (j == 0) rp.root_dist = norm(body.pos - rr.pos);
+    } else if (j == 0) {
+        rp.root_dist = norm(body.pos - r0.pos);  // humanoid_im.py:892
+    }
     // R2 power partial: sum |tau * qdot| over this body's joint (humanoid_im.py:939-946)
     if (prm.power_reward && j >= 1) {
         int ds = model.ints[4 + 3 * PHC_MAX_BODIES + j];
@@ -96,7 +169,16 @@ PHC_HD RewardPartial im_post_lane(const phc_model_t& model, const phc_motion_lib
     float* obs = buf.obs_buf + env * (int64_t)(prm.num_self_obs + prm.num_task_obs);
     self_obs_lane(prm, nb, j, body, root, hinv, obs);
     int slot = prm.track_slot[j];
-    if (slot >= 0) task_obs_lane(prm, slot, body, root, r1, hinv, h, obs + prm.num_self_obs);
+    if (slot >= 0) {
+        BodyState rt = r1;
+        if (prm.zero_out_far) {
+            BodyState rroot = (j == 0) ? r1 : ref_body(lib, fr1, 0);
+            if (j != 0) rroot.pos += c.goff;
+            const float dist = zero_out_far_ref(prm, slot, body, root, rroot, &rt);
+            if (j == 0 && buf.point_goal) buf.point_goal[env] = dist;  // :792
+        }
+        task_obs_lane(prm, slot, body, root, rt, hinv, h, obs + prm.num_self_obs);
+    }
     // side-effect buffers of _compute_task_obs (humanoid_im.py:855-868)
     if (buf.ref_body_pos) st3(buf.ref_body_pos + (env * nb + j) * 3, r1.pos);
     if (buf.ref_body_rot) st4(buf.ref_body_rot + (env * nb + j) * 4, r1.rot);
@@ -115,8 +197,8 @@ PHC_HD RewardPartial im_post_lane(const phc_model_t& model, const phc_motion_lib
 // Per-env epilogue (lane 0) once the partials are reduced: reward (humanoid_im.py:1524-1554, 939-946),
 // reset / terminate (:1117-1190, 1581-1608), progress write-back.
 PHC_HD void im_post_finalize(const phc_motion_lib_t& lib, const phc_im_params_t& prm, const phc_im_buffers_t& buf, int nb,
-                             int64_t env, int64_t progress, float s_pos, float s_rot, float s_vel, float s_angvel,
-                             float s_power, float s_dist, int any_fallen, int n_reset_bodies) {
+                             int64_t env, const ImStepCtx& c, int64_t progress, float s_pos, float s_rot, float s_vel, float s_angvel,
+                             float s_power, float s_dist, float root_dist, float prev_point_goal, int any_fallen, int n_reset_bodies) {
     const float J = (float)nb;
     float r_pos = expf(-prm.k_pos * (s_pos / J));
     float r_rot = expf(-prm.k_rot * (s_rot / J));
@@ -125,7 +207,16 @@ PHC_HD void im_post_finalize(const phc_motion_lib_t& lib, const phc_im_params_t&
     float rew = prm.w_pos * r_pos + prm.w_rot * r_rot + prm.w_vel * r_vel + prm.w_ang_vel * r_ang;
     const int nraw = prm.power_reward ? 5 : 4;
     float* raw = buf.reward_raw + env * nraw;
-    raw[0] = r_pos; raw[1] = r_rot; raw[2] = r_vel; raw[3] = r_ang;
+    if (prm.zero_out_far) {
+        // compute_point_goal_reward + half-weight imitation reward inside the transition radius (humanoid_im.py:890-905,1558-1562)
+        const float pg = fminf(prev_point_goal - root_dist, 1.0f / 3.0f) * 9.0f;
+        const bool far = root_dist > 0.25f;  // transition_distance :891
+        raw[0] = pg + (far ? 0.f : r_pos * 0.5f);
+        raw[1] = far ? 0.f : r_rot * 0.5f; raw[2] = far ? 0.f : r_vel * 0.5f; raw[3] = far ? 0.f : r_ang * 0.5f;
+        rew = pg + (far ? 0.f : rew * 0.5f);
+    } else {
+        raw[0] = r_pos; raw[1] = r_rot; raw[2] = r_vel; raw[3] = r_ang;
+    }
     if (prm.power_reward) {
         float pr = -prm.power_coefficient * s_power;
         if (progress <= 3) pr = 0.f;
@@ -134,9 +225,6 @@ PHC_HD void im_post_finalize(const phc_motion_lib_t& lib, const phc_im_params_t&
     }
     buf.rew_buf[env] = rew;
     // _compute_reset
-    const int64_t mid = buf.sampled_motion_ids[env];
-    const float t0 = motion_time(progress, prm.dt, buf.motion_start_times[env], buf.motion_start_times_offset[env]);
-    const bool pass_time = t0 >= lib.motion_lengths[mid];
     int fallen = any_fallen;
     if (prm.use_mean_termination) {
         // torch.norm(...).mean(-1, keepdim=True) > termination_distance[0]  (humanoid_im.py:1586)
@@ -149,9 +237,19 @@ PHC_HD void im_post_finalize(const phc_motion_lib_t& lib, const phc_im_params_t&
         if (prm.disable_collision_check) fallen = 0;
         terminated = fallen ? 1 : 0;
     }
+    int64_t reset = c.pass_time ? 1 : terminated;
+    if (!c.pass_time && c.cycle_cnt > 0) { reset = 0; terminated = 0; }  // humanoid_im.py:1186-1188
+    if (c.recovery_cnt > 0) { reset = 0; terminated = 0; }               // humanoid_im_getup.py:212-214
     buf.terminate_buf[env] = terminated;
-    buf.reset_buf[env] = pass_time ? 1 : terminated;
-    buf.progress_buf[env] = progress;
+    buf.reset_buf[env] = reset;
+    buf.progress_buf[env] = c.progress;
+    if (buf.cycle_counter) buf.cycle_counter[env] = c.cycle_cnt;
+    if (buf.recovery_counter) buf.recovery_counter[env] = c.recovery_cnt;
+    if (c.cycled) {
+        buf.motion_start_times[env] = c.start;
+        buf.motion_start_times_offset[env] = c.start_off;
+        st3(buf.global_offset + env * 3, c.goff);
+    }
 }
 
 // Reset of one env, lane j: HumanoidIm._reset_envs (humanoid.py:585-621; humanoid_amp.py:378-398,508-528,
@@ -187,7 +285,14 @@ PHC_HD void im_reset_lane(const phc_model_t& model, const phc_motion_lib_t& lib,
         float* obs = buf.obs_buf + env * (int64_t)(prm.num_self_obs + prm.num_task_obs);
         self_obs_lane(prm, nb, j, rs, root, hinv, obs);
         int slot = prm.track_slot[j];
-        if (slot >= 0) task_obs_lane(prm, slot, rs, root, r1, hinv, h, obs + prm.num_self_obs);
+        if (slot >= 0) {
+            BodyState rt = r1;
+            if (prm.zero_out_far) {
+                const float dist = zero_out_far_ref(prm, slot, rs, root, (j == 0) ? r1 : ref_body(lib, fr1, 0), &rt);
+                if (j == 0 && buf.point_goal) buf.point_goal[env] = dist;
+            }
+            task_obs_lane(prm, slot, rs, root, rt, hinv, h, obs + prm.num_self_obs);
+        }
         if (buf.ref_body_pos) st3(buf.ref_body_pos + (env * nb + j) * 3, r1.pos);
         if (buf.ref_body_rot) st4(buf.ref_body_rot + (env * nb + j) * 4, r1.rot);
         if (buf.ref_body_vel) st3(buf.ref_body_vel + (env * nb + j) * 3, r1.vel);
@@ -203,6 +308,65 @@ PHC_HD void im_reset_lane(const phc_model_t& model, const phc_motion_lib_t& lib,
         st3(buf.global_offset + env * 3, v3(0.f, 0.f, 0.f));
         buf.progress_buf[env] = 0; buf.terminate_buf[env] = 0;  // humanoid.py:616-618
         if (clear_reset_flag) buf.reset_buf[env] = 0;
+        if (buf.cycle_counter) buf.cycle_counter[env] = 0;        // humanoid_im.py:960
+        if (buf.recovery_counter) buf.recovery_counter[env] = 0;  // humanoid_im_getup.py:155
+    }
+}
+
+// Reset of one env that KEEPS the simulator state the caller put there (HumanoidImGetup fall / recovery episodes,
+// humanoid_im_getup.py:136-196): the shared tail of _reset_envs (humanoid.py:585-621) -- PD target := joint positions,
+// progress / reset / terminate / contact cleared -- then _compute_observations(env_ids) against the reference at the
+// env's unchanged motion clock with progress 0, and (fill_history) _init_amp_obs_default (humanoid_amp.py:569-573).
+// rigid_body_state of the env must already be current (phc_refresh_body_state_indexed).
+PHC_HD void im_reset_from_state_lane(const phc_model_t& model, const phc_motion_lib_t& lib, const phc_im_params_t& prm,
+                                     const phc_sim_state_t& sim, const phc_im_buffers_t& buf, int64_t env, int j, int fill_history) {
+    const int nb = model.num_bodies, nd = model.num_dof;
+    const int64_t mid = buf.sampled_motion_ids[env];
+    const int S = prm.num_amp_obs_steps, A = prm.num_amp_obs_per_step;
+    if (j < nb) {
+        BodyState body = load_body(sim.rigid_body_state, env, nb, j);
+        BodyState root = load_body(sim.rigid_body_state, env, nb, 0);
+        if (sim.contact_force) st3(sim.contact_force + (env * nb + j) * 3, v3(0.f, 0.f, 0.f));
+        if (j >= 1) {
+            const int ds = model.ints[4 + 3 * PHC_MAX_BODIES + j];
+            const float* d = sim.dof_state + (env * nd + ds) * 2;
+            st3(sim.pd_target + env * nd + ds, v3(d[0], d[2], d[4]));  // humanoid.py:605
+        }
+        const V3 goff = ld3(buf.global_offset + env * 3);
+        const float t1 = motion_time(1, prm.dt, buf.motion_start_times[env], buf.motion_start_times_offset[env]);
+        const FrameRef fr1 = frame_ref(lib, mid, t1);
+        BodyState r1 = ref_body(lib, fr1, j);
+        r1.pos += goff;
+        Q4 hinv = calc_heading_quat_inv(root.rot), h = calc_heading_quat(root.rot);
+        float* obs = buf.obs_buf + env * (int64_t)(prm.num_self_obs + prm.num_task_obs);
+        self_obs_lane(prm, nb, j, body, root, hinv, obs);
+        int slot = prm.track_slot[j];
+        if (slot >= 0) {
+            BodyState rt = r1;
+            if (prm.zero_out_far) {
+                BodyState rroot = (j == 0) ? r1 : ref_body(lib, fr1, 0);
+                if (j != 0) rroot.pos += goff;
+                const float dist = zero_out_far_ref(prm, slot, body, root, rroot, &rt);
+                if (j == 0 && buf.point_goal) buf.point_goal[env] = dist;
+            }
+            task_obs_lane(prm, slot, body, root, rt, hinv, h, obs + prm.num_self_obs);
+        }
+        if (buf.ref_body_pos) st3(buf.ref_body_pos + (env * nb + j) * 3, r1.pos);
+        if (buf.ref_body_rot) st4(buf.ref_body_rot + (env * nb + j) * 4, r1.rot);
+        if (buf.ref_body_vel) st3(buf.ref_body_vel + (env * nb + j) * 3, r1.vel);
+        if (buf.ref_dof_pos && j >= 1) {
+            V3 dp, dv;
+            ref_joint(lib, fr1, j, &dp, &dv);
+            st3(buf.ref_dof_pos + env * nd + model.ints[4 + 3 * PHC_MAX_BODIES + j], dp);
+        }
+        // _compute_amp_observations(env_ids) -> slot 0; _init_amp_obs_default copies it into every history slot
+        float* amp = buf.amp_obs_out + env * (int64_t)(S * A);
+        const int nfill = fill_history ? S : 1;
+        for (int k = 0; k < nfill; ++k)
+            amp_obs_from_sim_lane(prm, sim, nb, nd, env, j, root, hinv, model.ints + 4 + 3 * PHC_MAX_BODIES, amp + k * A);
+    }
+    if (j == 0) {
+        buf.progress_buf[env] = 0; buf.terminate_buf[env] = 0; buf.reset_buf[env] = 0;  // humanoid.py:616-618
     }
 }
 

@@ -32,13 +32,26 @@ __global__ __launch_bounds__(256) void k_im_post_physics(phc_model_t model, phc_
     const int64_t env = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
     if (env >= sim.num_envs) return;  // whole 32-lane group exits together
     const int64_t progress = buf.progress_buf[env] + 1;  // humanoid.py:1637
+    const ImStepCtx c = im_post_prologue(lib, prm, sim, buf, env, progress);
+    const float prev_goal = (prm.zero_out_far && buf.point_goal) ? buf.point_goal[env] : 0.f;  // read before lane 0 overwrites it
     amp_shift_lane(prm, buf, env, lane);
-    RewardPartial rp = im_post_lane(model, lib, prm, sim, buf, env, lane, progress);
+    RewardPartial rp = im_post_lane(model, lib, prm, sim, buf, env, lane, c);
     float s_pos = group_sum(rp.pos), s_rot = group_sum(rp.rot), s_vel = group_sum(rp.vel), s_ang = group_sum(rp.angvel);
     float s_pow = group_sum(rp.power), s_dist = group_sum(rp.dist);
     int fallen = group_or(rp.fallen);
     if (lane == 0)
-        im_post_finalize(lib, prm, buf, model.num_bodies, env, progress, s_pos, s_rot, s_vel, s_ang, s_pow, s_dist, fallen, n_reset_bodies);
+        im_post_finalize(lib, prm, buf, model.num_bodies, env, c, progress, s_pos, s_rot, s_vel, s_ang, s_pow, s_dist, rp.root_dist,
+                         prev_goal, fallen, n_reset_bodies);
+}
+
+// HumanoidImGetup fall / recovery resets: one 32-lane group per listed env (state kept, see im_reset_from_state_lane).
+__global__ __launch_bounds__(256) void k_im_reset_from_state(phc_model_t model, phc_motion_lib_t lib, phc_im_params_t prm, phc_sim_state_t sim,
+                                                            phc_im_buffers_t buf, int num_reset, const int64_t* __restrict__ env_ids,
+                                                            int fill_history) {
+    const int lane = threadIdx.x & (GRP - 1);
+    const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+    if (r >= num_reset) return;
+    im_reset_from_state_lane(model, lib, prm, sim, buf, env_ids[r], lane, fill_history);
 }
 
 // Reset of a list of envs.  One 32-lane group per (env, AMP history frame k): group k == 0 also imposes the state
@@ -209,6 +222,8 @@ int32_t phc_im_post_physics(const phc_model_t* model, const phc_motion_lib_t* li
     int32_t rc = check_im(model, lib, prm);
     if (rc) return rc;
     if (!sim || !buf || buf->amp_obs_in == buf->amp_obs_out) return PHC_EINVAL;
+    if (prm->cycle_motion && (!buf->cycle_counter || !buf->cycle_phase)) return PHC_EINVAL;
+    if (prm->zero_out_far && (!buf->point_goal || prm->track_slot == nullptr)) return PHC_EINVAL;
     if (sim->num_envs == 0) return 0;
     const int n_reset_bodies = prm->num_reset_bodies > 0 ? prm->num_reset_bodies : 1;
     hipLaunchKernelGGL(k_im_post_physics, dim3(env_blocks(sim->num_envs, 256)), dim3(256), 0, (hipStream_t)stream, *model, *lib,
@@ -225,6 +240,18 @@ int32_t phc_im_reset(const phc_model_t* model, const phc_motion_lib_t* lib, cons
     if (num_reset == 0) return 0;
     hipLaunchKernelGGL(k_im_reset, dim3(env_blocks((int64_t)num_reset * prm->num_amp_obs_steps, 256)), dim3(256), 0, (hipStream_t)stream, *model, *lib, *prm, *sim,
                        *buf, num_reset, env_ids, phase, start_at_zero);
+    return launch_status();
+}
+
+int32_t phc_im_reset_from_state(const phc_model_t* model, const phc_motion_lib_t* lib, const phc_im_params_t* prm,
+                                const phc_sim_state_t* sim, const phc_im_buffers_t* buf, int32_t num_reset, const int64_t* env_ids,
+                                int32_t fill_history, void* stream) {
+    int32_t rc = check_im(model, lib, prm);
+    if (rc) return rc;
+    if (!sim || !buf || num_reset < 0 || (num_reset > 0 && !env_ids)) return PHC_EINVAL;
+    if (num_reset == 0) return 0;
+    hipLaunchKernelGGL(k_im_reset_from_state, dim3(env_blocks(num_reset, 256)), dim3(256), 0, (hipStream_t)stream, *model, *lib, *prm,
+                       *sim, *buf, num_reset, env_ids, fill_history);
     return launch_status();
 }
 

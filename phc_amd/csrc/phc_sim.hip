@@ -28,11 +28,13 @@ template <bool STEP>
 __global__ __launch_bounds__(64, 2) void k_sim_step(phc_model_t model, phc_sim_params_t prm, phc_sim_state_t sim,
                                                 const float* __restrict__ actions, const float* __restrict__ pd_off,
                                                 const float* __restrict__ pd_scale, const int32_t* __restrict__ freeze,
-                                                int num_sim_calls) {
+                                                int num_sim_calls, const int64_t* __restrict__ env_ids, int num_listed) {
     __shared__ float xch_all[2 * PHC_MAX_BODIES * PHC_XCH_STRIDE];
     const int lane = threadIdx.x & (GRP - 1);
     const int grp = threadIdx.x >> 5;
-    const int64_t env = (int64_t)blockIdx.x * 2 + grp;
+    const int64_t slot = (int64_t)blockIdx.x * 2 + grp;
+    // env_ids (refresh of a teleported subset only): slot -> listed env
+    const int64_t env = (!STEP && env_ids != nullptr) ? (slot < num_listed ? env_ids[slot] : sim.num_envs) : slot;
     const int nb = model.num_bodies, nd = model.num_dof;
     const bool active = env < sim.num_envs && lane < nb;
     Xch x;
@@ -73,9 +75,11 @@ __global__ __launch_bounds__(64, 2) void k_sim_step(phc_model_t model, phc_sim_p
 
 template <bool STEP>
 static void sim_launch(const phc_model_t* model, const phc_sim_params_t& prm, const phc_sim_state_t* sim, const float* actions,
-                       const float* off, const float* scale, const int32_t* freeze, int num_sim_calls, hipStream_t stream) {
-    hipLaunchKernelGGL(k_sim_step<STEP>, dim3((sim->num_envs + 1) / 2), dim3(64), 0, stream, *model, prm, *sim, actions, off, scale,
-                       freeze, num_sim_calls);
+                       const float* off, const float* scale, const int32_t* freeze, int num_sim_calls, hipStream_t stream,
+                       const int64_t* env_ids = nullptr, int num_listed = 0) {
+    const int64_t groups = env_ids ? num_listed : sim->num_envs;
+    hipLaunchKernelGGL(k_sim_step<STEP>, dim3((groups + 1) / 2), dim3(64), 0, stream, *model, prm, *sim, actions, off, scale,
+                       freeze, num_sim_calls, env_ids, num_listed);
 }
 
 static inline int32_t launch_status() {
@@ -111,6 +115,18 @@ int32_t phc_refresh_body_state(const phc_model_t* model, const phc_sim_state_t* 
     phc_sim_params_t prm = {};
     prm.substeps = 1;
     sim_launch<false>(model, prm, sim, nullptr, nullptr, nullptr, nullptr, 0, (hipStream_t)stream);
+    return launch_status();
+}
+
+int32_t phc_refresh_body_state_indexed(const phc_model_t* model, const phc_sim_state_t* sim, int32_t num, const int64_t* env_ids,
+                                       void* stream) {
+    int32_t rc = check_model(model);
+    if (rc) return rc;
+    if (!sim || num < 0 || (num > 0 && !env_ids)) return PHC_EINVAL;
+    if (num == 0) return 0;
+    phc_sim_params_t prm = {};
+    prm.substeps = 1;
+    sim_launch<false>(model, prm, sim, nullptr, nullptr, nullptr, nullptr, 0, (hipStream_t)stream, env_ids, num);
     return launch_status();
 }
 

@@ -66,6 +66,11 @@ PHC_HD float motion_time(int64_t progress, float dt, float start, float start_of
     float b = a + start;
     return b + start_off;
 }
+// humanoid_im.py:1126: -progress_buf * dt
+PHC_HD float neg_progress_time(int64_t progress, float dt) {
+    PHC_NO_CONTRACT
+    return (float)(-progress) * dt;
+}
 // humanoid_amp.py:575-603 / 253-284: t0 + (-dt * k)
 PHC_HD float history_time(float t0, float dt, int k) {
     PHC_NO_CONTRACT
@@ -95,6 +100,13 @@ PHC_HD BodyState ref_body(const phc_motion_lib_t& lib, const FrameRef& fr, int j
     s.angvel = lerp3(ld3(a + fr_angvel(nb) + 3 * j), ld3(b + fr_angvel(nb) + 3 * j), fr.blend);
     s.rot = slerp(ld4(a + fr_rot(nb) + 4 * j), ld4(b + fr_rot(nb) + 4 * j), fr.blend);
     return s;
+}
+// get_root_pos_smpl (motion_lib_base.py:522-547): position-only lookup of the root
+PHC_HD V3 ref_root_pos_lerp(const phc_motion_lib_t& lib, const FrameRef& fr) {
+    const int nb = lib.num_bodies;
+    const float* a = lib.frames + fr.f0 * (int64_t)lib.frame_stride;
+    const float* b = lib.frames + fr.f1 * (int64_t)lib.frame_stride;
+    return lerp3(ld3(a + fr_pos(nb)), ld3(b + fr_pos(nb)), fr.blend);
 }
 // dof_pos = quat_to_exp_map(slerp(local_rot)) (motion_lib_base.py:483-484,564-567), dof_vel lerp; joint of body j>=1
 PHC_HD void ref_joint(const phc_motion_lib_t& lib, const FrameRef& fr, int j, V3* dof_pos, V3* dof_vel) {
@@ -173,7 +185,7 @@ PHC_HD void amp_obs_key(const phc_im_params_t& prm, int k, V3 key_pos, V3 root_p
 }
 
 // ---- R1/R5 per-lane partials, reduced over the 32-lane group by the caller ----
-struct RewardPartial { float pos, rot, vel, angvel, power, dist; int fallen; };
+struct RewardPartial { float pos, rot, vel, angvel, power, dist, root_dist; int fallen; };
 
 PHC_HD RewardPartial reward_partial(const phc_im_params_t& prm, int64_t env, int nb, int j, const BodyState& body, const BodyState& ref) {
     RewardPartial p;
@@ -186,7 +198,7 @@ PHC_HD RewardPartial reward_partial(const phc_im_params_t& prm, int64_t env, int
     p.vel = (d.x * d.x + d.y * d.y + d.z * d.z) / 3.0f;
     d = ref.angvel - body.angvel;
     p.angvel = (d.x * d.x + d.y * d.y + d.z * d.z) / 3.0f;
-    p.power = 0.f;
+    p.power = 0.f; p.root_dist = 0.f;
     // compute_humanoid_im_reset :1586-1588
     float dist = norm(body.pos - ref.pos);
     int in_reset = prm.reset_mask[j];

@@ -82,7 +82,7 @@ class HumanoidIm:
         self.humanoid_type = robot.get("humanoid_type", "smpl")
         if self.humanoid_type != "smpl":
             raise NotImplementedError(f"humanoid_type={self.humanoid_type!r}: only the SMPL humanoid is built in this round")
-        unsupported = dict(fut_tracks=False, zero_out_far=False, cycle_motion=False, occl_training=False, res_action=False,
+        unsupported = dict(fut_tracks=False, zero_out_far_train=False, cycle_motion_xp=False, occl_training=False, res_action=False,
                            kin_loss=False, z_readout=False, distill=False, has_shape_variation=False)
         for k, off in unsupported.items():
             v = env.get(k, robot.get(k, off))
@@ -118,13 +118,18 @@ class HumanoidIm:
         self._kp_scale = env.get("kp_scale", 1.0)
         self._kd_scale = env.get("kd_scale", self._kp_scale)
         self.hard_negative = env.get("hard_negative", False)
-        self.cycle_motion = False
+        self.cycle_motion = env.get("cycle_motion", False)       # humanoid.py:316
+        self.cycle_motion_xp = False
         self.power_reward = env.get("power_reward", False)
         self.power_coefficient = env.get("power_coefficient", 0.0005)
         self.kin_lr = env.get("kin_lr", 5e-4)
         self.fitting = env.get("fitting", False)
         self.z_readout = self.z_read = self.z_uniform = self.z_model = self.distill = self.kin_loss = False
-        self.zero_out_far = False
+        self.zero_out_far = env.get("zero_out_far", False)       # humanoid.py:325-330
+        self.zero_out_far_train = False
+        self.close_distance = env.get("close_distance", 0.25)
+        self.far_distance = env.get("far_distance", 3)
+        self._zero_out_far_steps = env.get("zero_out_far_steps", 90)
         self.max_len = env.get("max_len", -1)
         self.models_path = env.get("models", [])
         self.eval_full = env.get("eval_full", False)
@@ -297,6 +302,12 @@ class HumanoidIm:
         self._sampled_motion_ids = torch.arange(N, **i64)  # humanoid_im.py:121
         self._global_offset = torch.zeros((N, 3), **f32)
         self._cycle_counter = torch.zeros(N, device=dev, dtype=torch.int)
+        self._point_goal = torch.zeros(N, **f32)                 # humanoid_im.py:95
+        self._cycle_phase = torch.zeros(N, **f32) if self.cycle_motion else None
+        if not hasattr(self, "_recovery_counter"):
+            self._recovery_counter = None                        # HumanoidImGetup owns one
+        if self.zero_out_far and self._track_bodies[0] != self._body_names[0]:
+            raise NotImplementedError("zero_out_far needs the root as the first track body (humanoid_im.py:785)")
         S, A = self._num_amp_obs_steps, self._num_amp_obs_per_step
         self._amp_bufs = [torch.zeros((N, S, A), **f32), torch.zeros((N, S, A), **f32)]
         self._amp_cur = 0
@@ -332,13 +343,16 @@ class HumanoidIm:
             first_reset_body=self._body_names.index(self._reset_bodies[0]), termination_distances=self._termination_distances_full,
             num_key_bodies=len(self.key_bodies), key_body_ids=key_ids, num_amp_joints=self._n_amp_joints, amp_joint_slot=amp_slot,
             num_amp_obs_steps=self._num_amp_obs_steps, num_amp_obs_per_step=self._num_amp_obs_per_step,
-            num_self_obs=self._num_self_obs, num_task_obs=self.get_task_obs_size())
+            num_self_obs=self._num_self_obs, num_task_obs=self.get_task_obs_size(), cycle_motion=self.cycle_motion,
+            zero_out_far=self.zero_out_far, close_distance=self.close_distance, far_distance=self.far_distance)
         self._flag_state = (flags.im_eval, flags.no_collision_check)
 
     def _buffers(self, amp_in, amp_out):
         return abi.im_buffers_struct(self.progress_buf, self.reset_buf, self._terminate_buf, self.rew_buf, self.reward_raw, self.obs_buf,
                                      amp_in, amp_out, self._sampled_motion_ids, self._motion_start_times, self._motion_start_times_offset,
-                                     self._global_offset, self.ref_body_pos, self.ref_body_rot, self.ref_body_vel, self.ref_dof_pos)
+                                     self._global_offset, self.ref_body_pos, self.ref_body_rot, self.ref_body_vel, self.ref_dof_pos,
+                                     cycle_counter=self._cycle_counter, recovery_counter=self._recovery_counter,
+                                     point_goal=self._point_goal, cycle_phase=self._cycle_phase)
 
     @property
     def _amp_obs_buf(self):
@@ -449,10 +463,13 @@ class HumanoidIm:
 
     def resample_motions(self):
         """humanoid_im.py:369-396: re-sample one clip per env, then reset everything."""
+        self._reload_motions()
+        self.reset()
+
+    def _reload_motions(self):
         self._motion_lib.load_motions(skeleton_trees=self.skeleton_trees, limb_weights=self.humanoid_limb_and_weights.cpu(),
                                       gender_betas=self.humanoid_shapes.cpu(), random_sample=(not flags.test) and (not self.seq_motions),
                                       max_len=-1 if flags.test else self.max_len)
-        self.reset()
 
     # ------------------------------------------------------------------ step (base_task.py:216-234)
     def step(self, actions):
@@ -477,6 +494,10 @@ class HumanoidIm:
             self._rebuild_im_params()
         amp_in = self._amp_bufs[self._amp_cur]
         amp_out = self._amp_bufs[1 - self._amp_cur]
+        if self.cycle_motion:
+            # the draw behind `_sample_time` of the envs whose clip restarts this step (humanoid_im.py:1127); one value per
+            # env is drawn (the reference draws only as many as restart, so the RNG streams differ in length, not in law)
+            torch.rand(self.num_envs, out=self._cycle_phase)
         buf = self._buffers(amp_in, amp_out)
         L.check(self._lib.phc_im_post_physics(self._model_struct, self._motion_lib.struct, self._im_params, self._sim_struct, buf,
                                               _stream()), "phc_im_post_physics")

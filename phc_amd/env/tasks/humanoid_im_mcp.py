@@ -1,0 +1,88 @@
+"""HumanoidImMCP: the policy outputs mixing weights over frozen motor primitives (reference:
+phc/env/tasks/humanoid_im_mcp.py:14-114).  The primitives are the columns of a trained PNN checkpoint
+(`env.models[0]`, loaded like phc/learning/network_loader.py:54-72); `step(weights)` normalises the observation with the
+checkpoint's running statistics, runs every column, mixes `sum_k w_k * a_k` and feeds the result to the usual
+pre-physics / physics / post-physics launches.  The PNN forward is `num_prim` small bf16-free fp32 GEMM chains in torch.
+"""
+import torch
+
+from ...learning.network import PNN
+from .humanoid_im import HumanoidIm
+
+
+def load_pnn(checkpoint, num_prim, has_lateral, activation="relu", device="cpu"):
+    """network_loader.py:54-72: rebuild the PNN from `a2c_network.pnn.actors.*` and freeze every column."""
+    sd = checkpoint["model"]
+    biases = [k for k in sd if k.startswith("a2c_network.pnn.actors.0") and k.endswith("bias")]
+    sizes = [sd[k].shape[0] for k in biases]
+    pnn = PNN(sd["a2c_network.pnn.actors.0.0.weight"].shape[1], sizes[:-1], activation, sizes[-1], num_prim, has_lateral)
+    own = pnn.state_dict()
+    for k, v in sd.items():
+        if "pnn." in k:
+            own[k.split("pnn.")[1]].copy_(v)
+    pnn.freeze_pnn(num_prim)
+    return pnn.to(device).eval()
+
+
+class MCPMixin:
+    """Shared by HumanoidImMCP and HumanoidImMCPGetup."""
+
+    def _mcp_config(self, cfg):
+        env = cfg["env"]
+        self.num_prim = env.get("num_prim", 3)
+        self.discrete_mcp = env.get("discrete_moe", False)
+        self.has_pnn = env.get("has_pnn", False)
+        self.has_lateral = env.get("has_lateral", False)
+        self.z_activation = env.get("z_activation", "relu")
+        self.mlp_bypass = env.get("mlp_bypass", False)
+        if self.mlp_bypass:
+            raise NotImplementedError("mlp_bypass (distilled MLP in place of the primitives) is not built")
+        if not self.has_pnn:
+            raise NotImplementedError("HumanoidImMCP needs has_pnn=True: the primitives come from a PNN checkpoint")
+
+    def _mcp_load(self):
+        self.pnn = None
+        if len(self.models_path) == 1:
+            self.load_primitives(torch.load(self.models_path[0], map_location=self.device, weights_only=False))
+        elif len(self.models_path) > 1:
+            raise AssertionError("exactly one PNN checkpoint is expected in env.models (humanoid_im_mcp.py:26)")
+
+    def load_primitives(self, checkpoint):
+        """Install the frozen primitives from a PNN checkpoint dict (`model` + `running_mean_std`)."""
+        self.pnn = load_pnn(checkpoint, num_prim=self.num_prim, has_lateral=self.has_lateral, activation=self.z_activation, device=self.device)
+        rms = checkpoint["running_mean_std"]
+        self.running_mean = rms["running_mean"].float().to(self.device)
+        self.running_var = rms["running_var"].float().to(self.device)
+
+    def get_action_size(self):
+        return self.num_prim                      # humanoid_im_mcp.py:45-48
+
+    def get_task_obs_size_detail(self):
+        d = super().get_task_obs_size_detail()
+        d["num_prim"] = self.num_prim
+        return d
+
+    def compose_actions(self, weights):
+        if self.pnn is None:
+            raise RuntimeError("no primitives loaded: set env.models=[<pnn checkpoint>] or call load_primitives()")
+        with torch.no_grad():
+            obs = torch.clamp((self.obs_buf - self.running_mean) / torch.sqrt(self.running_var + 1e-05), min=-5.0, max=5.0)
+            if self.discrete_mcp:
+                weights = torch.nn.functional.one_hot(torch.argmax(weights, dim=1), num_classes=self.num_prim).float()
+            _, acts = self.pnn(obs)
+            return torch.sum(weights[:, :, None] * torch.stack(acts, dim=1), dim=1)
+
+    def step(self, weights):
+        actions = self.compose_actions(weights.to(self.device))
+        self.pre_physics_step(actions)
+        self._physics_step()
+        self.post_physics_step()
+
+
+class HumanoidImMCP(MCPMixin, HumanoidIm):
+
+    def __init__(self, cfg, sim_params=None, physics_engine=None, device_type="cuda", device_id=0, headless=True):
+        self._mcp_config(cfg)
+        super().__init__(cfg=cfg, sim_params=sim_params, physics_engine=physics_engine, device_type=device_type, device_id=device_id,
+                         headless=headless)
+        self._mcp_load()

@@ -159,7 +159,11 @@ def register_task(name, cls):
 def parse_task(cfg, rl_device=None, device_id=None, headless=True):
     """phc/utils/parse_task.py:50-63: build the task named cfg.env.task and wrap it."""
     from .humanoid_im import HumanoidIm
-    TASKS.setdefault("HumanoidIm", HumanoidIm)
+    from .humanoid_im_getup import HumanoidImGetup
+    from .humanoid_im_mcp import HumanoidImMCP
+    from .humanoid_im_mcp_getup import HumanoidImMCPGetup
+    for cls in (HumanoidIm, HumanoidImGetup, HumanoidImMCP, HumanoidImMCPGetup):
+        TASKS.setdefault(cls.__name__, cls)
     name = cfg["env"]["task"]
     if name not in TASKS:
         raise Exception(f"Unrecognized task {name!r}! Built so far: {sorted(TASKS)}")

@@ -30,7 +30,7 @@ import torch
 from torch import nn
 
 from .. import _lib as L
-from .network import A2CNetwork, A2CPNNNetwork, ModelAMPContinuous, policy_kl
+from .network import A2CMCPNetwork, A2CNetwork, A2CPNNNetwork, ModelAMPContinuous, policy_kl
 from .replay_buffer import ReplayBuffer
 from .running_mean_std import RunningMeanStd
 
@@ -153,8 +153,10 @@ class IMAmpAgent:
             net = A2CNetwork(params["network"], self.actions_num, (obs_dim,), (amp_dim,))
         elif net_name == "amp_pnn":  # run_hydra.py:259: model_builder.register_network('amp_pnn', ...)
             net = A2CPNNNetwork(params["network"], self.actions_num, (obs_dim,), (amp_dim,), self.task.get_task_obs_size_detail())
+        elif net_name == "amp_mcp":  # run_hydra.py:258
+            net = A2CMCPNetwork(params["network"], self.actions_num, (obs_dim,), (amp_dim,), self.task.get_task_obs_size_detail())
         else:
-            raise NotImplementedError(f"network '{net_name}' (amp_mcp needs the MCP task) is not built yet")
+            raise NotImplementedError(f"network '{net_name}' is not built")
         self.model = ModelAMPContinuous(net).to(self.device)
         if self.multi_gpu:  # hvd.setup_algo: broadcast rank 0's initial parameters (common_agent.py:112-113)
             for p in self.model.parameters():
@@ -423,6 +425,10 @@ class IMAmpAgent:
         t = self.task
         if (epoch_num > 1) and epoch_num % getattr(t, "shape_resampling_interval", 10 ** 9) == 1 and hasattr(t, "resample_motions"):
             t.resample_motions()
+        if getattr(t, "getup_schedule", False) and hasattr(t, "update_getup_schedule"):  # amp_agent.py:518-525
+            t.update_getup_schedule(epoch_num, getup_udpate_epoch=t.getup_udpate_epoch)
+            warm = epoch_num > t.getup_udpate_epoch
+            self._task_reward_w, self._disc_reward_w = (0.5, 0.5) if warm else (0, 1)
         self._snapshot_running_mean_std()
 
     def _snapshot_running_mean_std(self):

@@ -127,6 +127,29 @@ class A2CPNNNetwork(A2CNetwork):
         return mu, mu * 0.0 + self.sigma
 
 
+class A2CMCPNetwork(A2CNetwork):
+    """`AMPMCPBuilder.Network` (phc/learning/amp_network_mcp_builder.py:25-91): the action is the vector of mixing weights over
+    `num_prim` frozen primitives, produced by a `composer` MLP = units + [num_prim], every layer (also the last, `ending_act`)
+    followed by the activation, optionally a softmax (`has_softmax`; False in im_mcp.yaml).  The plain actor_mlp / mu of the
+    parent stay in the state dict (as in the reference) but are not used."""
+
+    def __init__(self, params, actions_num, input_shape, amp_input_shape, task_obs_size_detail, value_size=1):
+        super().__init__(params, actions_num, input_shape, amp_input_shape, value_size)
+        self.num_primitive = task_obs_size_detail.get("num_prim", 4)
+        assert actions_num == self.num_primitive, "the MCP task's action space is the primitive weights"
+        self.composer = build_mlp(input_shape[0], self.units + [self.num_primitive], self.activation)
+        if params.get("has_softmax", True):
+            self.composer.append(nn.Softmax(dim=1))
+        if not params.get("ending_act", True):
+            self.composer = self.composer[:-1]
+        for p in list(self.actor_mlp.parameters()) + list(self.mu.parameters()):
+            p.requires_grad = False
+
+    def eval_actor(self, obs):
+        mu = self.composer(obs)
+        return mu, mu * 0.0 + self.sigma
+
+
 def forward_pmcp(checkpoint, trained_idx):
     """scripts/pmcp/forward_pmcp.py:44-51: copy PNN column `trained_idx` into column `trained_idx + 1` (the next primitive
     starts from the previous one).  Operates on a checkpoint dict in place and returns it."""

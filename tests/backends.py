@@ -41,6 +41,9 @@ class HostEmu:
     def im_reset(self, model, lib, prm, sim, buf, n, env_ids, phase, start_at_zero):
         return emu().emu_im_reset(P(model), P(lib), P(prm), P(sim), P(buf), n, abi.ptr(env_ids), abi.ptr(phase), start_at_zero)
 
+    def im_reset_from_state(self, model, lib, prm, sim, buf, n, env_ids, fill_history):
+        return emu().emu_im_reset_from_state(P(model), P(lib), P(prm), P(sim), P(buf), n, abi.ptr(env_ids), fill_history)
+
     def amp_obs_demo(self, model, lib, prm, n, ids, t0, out):
         return emu().emu_amp_obs_demo(P(model), P(lib), P(prm), n, abi.ptr(ids), abi.ptr(t0), abi.ptr(out))
 
@@ -89,6 +92,9 @@ class Hip:
 
     def im_reset(self, model, lib, prm, sim, buf, n, env_ids, phase, start_at_zero):
         return self.lib.phc_im_reset(model, lib, prm, sim, buf, n, abi.ptr(env_ids), abi.ptr(phase), start_at_zero, self._s())
+
+    def im_reset_from_state(self, model, lib, prm, sim, buf, n, env_ids, fill_history):
+        return self.lib.phc_im_reset_from_state(model, lib, prm, sim, buf, n, abi.ptr(env_ids), fill_history, self._s())
 
     def amp_obs_demo(self, model, lib, prm, n, ids, t0, out):
         return self.lib.phc_amp_obs_demo(model, lib, prm, n, abi.ptr(ids), abi.ptr(t0), abi.ptr(out), self._s())

@@ -274,3 +274,90 @@ def test_metrics_lite_procrustes():
     pred = 1.1 * gt @ R.T + np.array([0.5, -0.2, 0.1])
     m = compute_metrics_lite([pred], [gt])
     assert m["mpjpe_g"][0] > 100 and m["mpjpe_pa"][0] < 1e-6
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# config 3: getup / MCP composer tasks (env_im_getup_mcp.yaml)
+# ---------------------------------------------------------------------------------------------------------------
+def _pnn_checkpoint(task, num_prim, seed=0):
+    """A PNN checkpoint in the reference's key layout (what `learning=im_pnn` training saves)."""
+    from phc_amd.learning.network import PNN
+    torch.manual_seed(seed)
+    pnn = PNN(task.num_obs, [64, 32], "silu", task.num_dof, num_prim)
+    model = {f"a2c_network.pnn.{k}": v.clone() for k, v in pnn.state_dict().items()}
+    return {"model": model, "running_mean_std": {"running_mean": torch.zeros(task.num_obs, dtype=torch.float64),
+                                                 "running_var": torch.ones(task.num_obs, dtype=torch.float64)}}, pnn
+
+
+def test_getup_task_fall_states_and_recovery_gating():
+    """HumanoidImGetup: fall states come out of the stepper lying on the ground; a reset mixes fall / recovery / reference
+    episodes; while the recovery counter runs an env is not reset and its motion clock does not advance."""
+    task, env = make_task(256, motion="synthetic:3:2", **{"env.task": "HumanoidImGetup", "env.recoveryEpisodeProb": 0.5, "env.recoverySteps": 8,
+                                                         "env.fallInitProb": 0.5, "env.getup_schedule": True})
+    assert type(task).__name__ == "HumanoidImGetup"
+    fall = task._fall_root_states.cpu().numpy()
+    assert np.isfinite(fall).all() and np.isfinite(task._fall_dof_pos.cpu().numpy()).all()
+    assert (fall[:, 2] < 0.6).mean() > 0.8, "after 2.5 s of random torques from a random orientation most humanoids lie on the ground"
+    assert (fall[:, 7:13] == 0).all()
+    env.reset()
+    rc = task._recovery_counter.cpu().numpy()
+    assert ((rc == 0) | (rc == 8)).all() and 0.2 < (rc == 8).mean() < 0.9
+    fall_envs = np.nonzero(rc == 8)[0]
+    amp = task._amp_obs_buf.cpu().numpy()
+    assert np.abs(amp[fall_envs] - amp[fall_envs][:, :1]).max() == 0, "fall episodes: AMP history = current obs repeated"
+    root_h = task._rigid_body_pos[:, 0, 2].cpu().numpy()
+    np.testing.assert_allclose(root_h[fall_envs], task._humanoid_root_states[fall_envs, 2].cpu().numpy(), atol=1e-6)
+    prog0 = task.progress_buf.clone()
+    for k in range(5):
+        env.step(torch.zeros(256, 69, device=task.device))
+    rc2 = task._recovery_counter.cpu().numpy()
+    np.testing.assert_array_equal(rc2[fall_envs], 3)
+    assert (task.progress_buf[fall_envs] == prog0[fall_envs]).all(), "progress frozen during recovery"
+    assert (task.reset_buf[fall_envs] == 0).all() and (task._terminate_buf[fall_envs] == 0).all()
+    for k in range(40):
+        task.reset_done()
+        env.step((torch.rand(256, 69, device=task.device) - 0.5) * 0.4)
+    assert torch.isfinite(task.obs_buf).all() and torch.isfinite(task.rew_buf).all()
+    task.update_getup_schedule(1, getup_udpate_epoch=5)
+    assert task._recovery_episode_prob == 0 and task._fall_init_prob == 1
+    task.update_getup_schedule(6, getup_udpate_epoch=5)
+    assert task._recovery_episode_prob == 0.5 and task._fall_init_prob == 0.5
+
+
+def test_mcp_getup_task_composes_primitives_and_trains():
+    """HumanoidImMCPGetup (env_im_getup_mcp + learning=im_mcp): actions are mixing weights over the frozen PNN columns;
+    cycle_motion keeps episodes alive past the clip end; one PPO epoch of the composer runs on the device."""
+    from phc_amd.learning.amp_agent import IMAmpAgent
+    task, env = make_task(128, motion="synthetic:2:5:1.5", **{"env": "env_im_getup_mcp", "learning": "im_mcp", "env.num_prim": 3,
+                                                             "learning.params.config.minibatch_size": 1024,
+                                                             "learning.params.config.amp_obs_demo_buffer_size": 2048,
+                                                             "learning.params.config.amp_replay_buffer_size": 2048})
+    assert type(task).__name__ == "HumanoidImMCPGetup" and task.num_actions == 3 and task.cycle_motion and task.zero_out_far
+    ck, pnn = _pnn_checkpoint(task, 3)
+    task.load_primitives(ck)
+    env.reset()
+    w = torch.softmax(torch.randn(128, 3, device=task.device), dim=-1)
+    obs_n = torch.clamp(task.obs_buf, -5, 5)
+    want = sum(w[:, k:k + 1] * pnn.to(task.device).actors[k](obs_n) for k in range(3))
+    np.testing.assert_allclose(task.compose_actions(w).cpu().numpy(), want.detach().cpu().numpy(), atol=1e-5)
+    # one-hot weights select one primitive
+    np.testing.assert_allclose(task.compose_actions(torch.eye(3, device=task.device)[torch.ones(128, dtype=torch.long)]).cpu().numpy(),
+                               pnn.actors[1](obs_n).detach().cpu().numpy(), atol=1e-5)
+    lengths = task._motion_lib._motion_lengths[task._sampled_motion_ids]
+    cycled = torch.zeros(128, dtype=torch.bool, device=task.device)
+    for k in range(70):   # clips are ~1.5 s = 45 steps: with cycle_motion the clock wraps instead of ending the episode
+        st0 = task._motion_start_times_offset.clone()
+        task.reset_done()
+        obs, rew, done, info = env.step(w)
+        cycled |= (task._motion_start_times_offset != st0) & (task.progress_buf > 1)
+        t = task.progress_buf * task.dt + task._motion_start_times + task._motion_start_times_offset
+        assert (t < lengths + 1e-4).all()
+    assert cycled.float().mean() > 0.02 and torch.isfinite(obs).all() and torch.isfinite(rew).all()
+    assert (task._point_goal >= 0).all()
+    agent = IMAmpAgent(env, task.cfg)
+    agent.init_train()
+    c0 = agent.model.a2c_network.composer[0].weight.clone()
+    info = agent.train_epoch()
+    assert np.isfinite([info["actor_loss"], info["critic_loss"], info["disc_loss"]]).all(), info
+    assert not torch.equal(c0, agent.model.a2c_network.composer[0].weight)
+    assert agent._task_reward_w == 0 and agent._disc_reward_w == 1   # getup schedule warm-up (amp_agent.py:518-525)

@@ -19,20 +19,20 @@ ENV_IM = dict(
 SPECS = po.DEFAULT_REWARD_SPECS
 
 
-def make_im_params(be, model, n_envs, use_mean=False, power_reward=True):
+def make_im_params(be, model, n_envs, use_mean=False, power_reward=True, power_coefficient=0.0005, **extra):
     tabs = abi.task_index_tables(model, model.body_names, ENV_IM["reset_bodies"], ENV_IM["key_bodies"])
     n_amp = tabs[4]
     amp_slot_np = tabs[3]
     track_slot, reset_mask, key_ids, amp_slot = (be.arr(t) for t in tabs[:4])
     td = be.arr(np.full(32, 0.25, dtype=F))
     prm = abi.im_params_struct(dt=2 * (1 / 60), max_episode_length=300, reward_specs=SPECS, power_reward=power_reward,
-                               power_coefficient=0.0005, enable_early_termination=True, use_mean_termination=use_mean,
+                               power_coefficient=power_coefficient, enable_early_termination=True, use_mean_termination=use_mean,
                                disable_collision_check=False, local_root_obs=True, root_height_obs=True,
                                num_track_bodies=model.num_bodies, track_slot=track_slot, reset_mask=reset_mask,
                                num_reset_bodies=len(ENV_IM["reset_bodies"]), first_reset_body=model.body_names.index(ENV_IM["reset_bodies"][0]),
                                termination_distances=td,
                                num_key_bodies=len(ENV_IM["key_bodies"]), key_body_ids=key_ids, num_amp_joints=n_amp, amp_joint_slot=amp_slot,
-                               num_amp_obs_steps=10, num_amp_obs_per_step=196, num_self_obs=358, num_task_obs=576)
+                               num_amp_obs_steps=10, num_amp_obs_per_step=196, num_self_obs=358, num_task_obs=576, **extra)
     prm._keepalive = (track_slot, reset_mask, key_ids, amp_slot, td)  # the struct only holds raw addresses
     return prm, (track_slot, reset_mask, be.np(key_ids), amp_slot_np, td)
 
@@ -112,6 +112,45 @@ def test_post_physics_vs_reference_golden(golden, backend, use_mean):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
+def test_post_physics_cycle_motion_zero_out_far_vs_reference_golden(golden, backend):
+    """Config-3 branches of post_physics_step (env_im_getup_mcp.yaml: cycle_motion + zero_out_far): point-goal reward,
+    in-place clip restart with its new start time / time offset / global offset, cycle-counter gating of reset, and the
+    task-obs gating -- against the reference's own functions driven in the reference's order (oracle/gen_golden_cfg3.py)."""
+    be = get_backend(backend)
+    g = golden("task_fns_cfg3")
+    gl = golden("motion_lib_eval")
+    model, mstruct, keepm = model_on(be)
+    lib, keep = motion_lib_on(be, gl)
+    N = g["body_pos"].shape[0]
+    prm, keepp = make_im_params(be, model, N, power_coefficient=0.00005, cycle_motion=True, zero_out_far=True, close_distance=0.25, far_distance=3.0)
+    gg = dict(g)
+    gg["dof_pos"] = np.zeros((N, 69), F)
+    arrs, sim = _sim_arrays(be, gg, N)
+    amp_in, amp_out = be.zeros((N, 10, 196)), be.zeros((N, 10, 196))
+    b = dict(progress=be.arr((g["progress"] - 1).astype(np.int64)), reset=be.zeros(N, np.int64), term=be.zeros(N, np.int64), rew=be.zeros(N),
+             raw=be.zeros((N, 5)), obs=be.zeros((N, 934)), mids=be.arr(g["env_motion"].astype(np.int64)),
+             st=be.arr(g["start_times"].astype(F)), so=be.arr(g["start_off"].astype(F)), goff=be.arr(g["global_offset"].astype(F)),
+             cyc=be.arr(g["cycle_counter_in"].astype(np.int32)), pg=be.arr(g["point_goal_prev"].astype(F)), ph=be.arr(g["cycle_phase"].astype(F)))
+    buf = abi.im_buffers_struct(b["progress"], b["reset"], b["term"], b["rew"], b["raw"], b["obs"], amp_in, amp_out, b["mids"], b["st"],
+                                b["so"], b["goff"], cycle_counter=b["cyc"], point_goal=b["pg"], cycle_phase=b["ph"])
+    assert be.im_post_physics(mstruct, lib, prm, sim, buf) == 0
+    be.sync()
+    o = {k: be.np(v) for k, v in b.items()}
+    np.testing.assert_array_equal(o["progress"], g["progress"])
+    np.testing.assert_array_equal(o["cyc"], g["cycle_counter_out"])
+    np.testing.assert_array_equal(o["st"], g["start_times_out"])          # sample_time_interval of the cycled envs: bit-exact
+    np.testing.assert_array_equal(o["so"], g["start_off_out"])
+    np.testing.assert_allclose(o["goff"], g["global_offset_out"], atol=1e-6)
+    np.testing.assert_allclose(o["raw"], g["reward_raw"], atol=2e-5)
+    np.testing.assert_allclose(o["rew"], g["reward"], atol=3e-5)
+    np.testing.assert_array_equal(o["reset"], g["reset"])
+    np.testing.assert_array_equal(o["term"], g["terminate"])
+    np.testing.assert_allclose(o["pg"], g["point_goal_out"], atol=1e-5)
+    np.testing.assert_allclose(o["obs"][:, 358:], g["task_obs"], atol=2e-5)
+    assert g["pass_len"].sum() > 4 and g["zeros_subset"].sum() > 4 and g["far_subset"].sum() >= 1 and g["reward_far"].sum() > 4
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
 def test_amp_demo_and_reset_vs_oracle(golden, backend):
     """build_amp_obs_demo and the reset composition, against the numpy oracle driven the reference's way."""
     be = get_backend(backend)
@@ -180,3 +219,57 @@ def test_amp_demo_and_reset_vs_oracle(golden, backend):
     want = po.build_amp_observations_smpl(msh["root_pos"], msh["root_rot"], msh["root_vel"], msh["root_ang_vel"], msh["dof_pos"],
                                           msh["dof_vel"], msh["rg_pos"][:, key_ids], dof_subset).reshape(3, 10, 196)
     np.testing.assert_allclose(amp[env_ids], want, atol=2e-5)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_reset_from_state_vs_oracle(golden, backend):
+    """HumanoidImGetup fall / recovery resets (phc_im_reset_from_state): the env keeps the state it was given; progress /
+    reset / terminate / contact cleared, PD target := joint positions, observations recomputed against the reference at the
+    env's own motion clock with progress 0, AMP history filled with (fall) or topped by (recovery) the current AMP obs."""
+    be = get_backend(backend)
+    g = golden("task_fns")
+    gl = golden("motion_lib_eval")
+    model, mstruct, keepm = model_on(be)
+    lib, keep = motion_lib_on(be, gl)
+    N = g["body_pos"].shape[0]
+    prm, keepp = make_im_params(be, model, N)
+    track_slot, reset_mask, key_ids, amp_slot, td = keepp
+    dof_subset = np.concatenate([np.arange(3 * (j - 1), 3 * j) for j in range(1, 24) if amp_slot[j] >= 0])
+    arrs, sim = _sim_arrays(be, g, N)
+    rng = np.random.default_rng(5)
+    amp0 = rng.standard_normal((N, 10, 196)).astype(F)
+    amp = be.arr(amp0)
+    st = g["start_times"].astype(F)
+    goff = np.zeros((N, 3), F)
+    goff[:, :2] = rng.standard_normal((N, 2)).astype(F) * 0.1
+    b = dict(progress=be.arr(np.full(N, 9, np.int64)), reset=be.arr(np.ones(N, np.int64)), term=be.arr(np.ones(N, np.int64)), rew=be.zeros(N),
+             raw=be.zeros((N, 5)), obs=be.zeros((N, 934)), mids=be.arr(g["env_motion"].astype(np.int64)), st=be.arr(st), so=be.zeros(N),
+             goff=be.arr(goff))
+    buf = abi.im_buffers_struct(b["progress"], b["reset"], b["term"], b["rew"], b["raw"], b["obs"], amp, amp, b["mids"], b["st"], b["so"], b["goff"])
+    fall_ids = np.array([3, 11, 40], dtype=np.int64)
+    rec_ids = np.array([7, 20], dtype=np.int64)
+    assert be.im_reset_from_state(mstruct, lib, prm, sim, buf, 3, be.arr(fall_ids), 1) == 0
+    assert be.im_reset_from_state(mstruct, lib, prm, sim, buf, 2, be.arr(rec_ids), 0) == 0
+    be.sync()
+    o = {k: be.np(v) for k, v in b.items()}
+    a = {k: be.np(v) for k, v in arrs.items()}
+    amp = be.np(amp)
+    ids = np.concatenate([fall_ids, rec_ids])
+    others = np.setdiff1d(np.arange(N), ids)
+    assert (o["progress"][ids] == 0).all() and (o["reset"][ids] == 0).all() and (o["term"][ids] == 0).all()
+    assert (o["progress"][others] == 9).all() and (o["reset"][others] == 1).all() and (o["obs"][others] == 0).all()
+    np.testing.assert_array_equal(a["pd"][ids], g["dof_pos"][ids].astype(F))
+    np.testing.assert_array_equal(a["rbs"], np.concatenate([g["body_pos"], g["body_rot"], g["body_vel"], g["body_ang_vel"]], -1).astype(F))  # state kept
+    t1 = (F(1) * F(2 * (1 / 60)) + st[ids]).astype(F)
+    ms = po.get_motion_state(gl, g["env_motion"][ids], t1, goff[ids])
+    bp, br, bv, bw = (g[k][ids].astype(F) for k in ("body_pos", "body_rot", "body_vel", "body_ang_vel"))
+    want_self = po.compute_humanoid_observations_smpl_max(bp, br, bv, bw, True, True)
+    want_task = po.compute_imitation_observations_v6(bp[:, 0], br[:, 0], bp, br, bv, bw, ms["rg_pos"], ms["rb_rot"], ms["body_vel"], ms["body_ang_vel"])
+    np.testing.assert_allclose(o["obs"][ids, :358], want_self, atol=2e-5)
+    np.testing.assert_allclose(o["obs"][ids, 358:], want_task, atol=2e-5)
+    want_amp = po.build_amp_observations_smpl(bp[:, 0], br[:, 0], bv[:, 0], bw[:, 0], g["dof_pos"][ids].astype(F), g["dof_vel"][ids].astype(F),
+                                              bp[:, key_ids], dof_subset)
+    np.testing.assert_allclose(amp[fall_ids], np.repeat(want_amp[:3, None], 10, axis=1), atol=2e-5)   # _init_amp_obs_default
+    np.testing.assert_allclose(amp[rec_ids, 0], want_amp[3:], atol=2e-5)
+    np.testing.assert_array_equal(amp[rec_ids, 1:], amp0[rec_ids, 1:])                                   # recovery keeps its history
+    np.testing.assert_array_equal(amp[others], amp0[others])
