@@ -85,6 +85,13 @@ typedef struct {
     float angular_damping;            /* asset_options.angular_damping 0.01 (humanoid.py:819-822) */
     float max_angular_velocity;       /* 100 */
     float contact_offset;             /* 0.02: contact activates this far above the plane with zero force */
+    int32_t control_mode;             /* 0: implicit position drive (`isaac_pd`, S8); 1: `pd` -- explicit torque
+                                         clip(kp (target - q) - kd qd, +-limit) recomputed every simulate call (S9,
+                                         humanoid.py:1575-1599,1608-1616; robot_control.yaml); 2: as 1 but only the spring
+                                         term is held, the damper follows the joint rate implicitly (stable on light
+                                         links).  1 and 2: revolute models only. */
+    float limit_stiffness;            /* joint-limit penalty spring N m/rad outside [lower, upper] (revolute models; 0 = off) */
+    float limit_damping;              /* N m s/rad */
 } phc_sim_params_t;
 
 /* Imitation-task parameters (phc/env/tasks/humanoid_im.py:37-123, env_im.yaml). */

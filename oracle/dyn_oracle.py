@@ -56,30 +56,65 @@ def quat_to_rotvec(q):
     return q[:3] * (2.0 * np.arctan2(s, q[3]) / s)
 
 
-class State:
-    """Per-env state in the simulator's tensor layout (S1 root_states [13], S2 dof_state [D,2])."""
+def quat_wxyz_to_xyzw(q):
+    return np.array([q[1], q[2], q[3], q[0]], dtype=np.float64)
 
-    def __init__(self, root_states, dof_state):
+
+class State:
+    """Per-env state in the simulator's tensor layout (S1 root_states [13], S2 dof_state [D,2]).  Spherical joints carry
+    an exp-map triple per joint, revolute joints one angle; `q[i-1]` is always the child-in-parent rotation of body i
+    (for a revolute joint: rest rotation * rot(axis, theta))."""
+
+    def __init__(self, root_states, dof_state, model=None):
         r = np.asarray(root_states, dtype=np.float64)
         d = np.asarray(dof_state, dtype=np.float64)
         self.p0 = r[0:3].copy()
         self.q0 = r[3:7] / np.linalg.norm(r[3:7])
         self.v0 = r[7:10].copy()
         self.w0 = r[10:13].copy()
-        nj = d.shape[0] // 3
-        self.q = np.array([quat_from_rotvec(d[3 * j:3 * j + 3, 0]) for j in range(nj)])
-        self.wj = d[:, 1].reshape(nj, 3).copy()
+        self.model = model
+        if model is None or model.all_spherical:
+            nj = d.shape[0] // 3
+            self.nd = [3] * nj
+            self.q = np.array([quat_from_rotvec(d[3 * j:3 * j + 3, 0]) for j in range(nj)])
+            self.qd = [d[3 * j:3 * j + 3, 1].copy() for j in range(nj)]
+            self.theta = None
+        else:
+            nj = model.num_bodies - 1
+            self.nd = [int(model.dof_count[i]) for i in range(1, model.num_bodies)]
+            assert all(n == 1 for n in self.nd), "mixed joint types are not built"
+            self.theta = d[:, 0].copy()
+            self.qd = [d[j:j + 1, 1].copy() for j in range(nj)]
+            self.q = np.array([self._rev_quat(j) for j in range(nj)])
+
+    def _rev_quat(self, j):
+        m = self.model
+        rest = quat_wxyz_to_xyzw(m.local_rotation[j + 1])
+        return quat_mul(rest, quat_from_rotvec(m.dof_axis[m.dof_start[j + 1]] * self.theta[j]))
+
+    @property
+    def wj(self):  # spherical joints: [NJ, 3] view kept for the existing tests
+        return np.array(self.qd)
+
+    def S(self, j):
+        """Motion subspace of joint j (body j+1) in the child frame: 3 x nd."""
+        if self.nd[j] == 3:
+            return np.eye(3)
+        return self.model.dof_axis[self.model.dof_start[j + 1]][:, None]
 
     def root_states(self):
         return np.concatenate([self.p0, self.q0, self.v0, self.w0])
 
     def dof_state(self):
-        pos = np.concatenate([quat_to_rotvec(q) for q in self.q])
-        return np.stack([pos, self.wj.reshape(-1)], axis=-1)
+        if self.theta is None:
+            pos = np.concatenate([quat_to_rotvec(q) for q in self.q])
+        else:
+            pos = self.theta.copy()
+        return np.stack([pos, np.concatenate(self.qd)], axis=-1)
 
 
 DEFAULT_PARAMS = dict(gravity_z=-9.81, contact_stiffness=1.0e5, contact_damping=1.0e3, friction=1.0, friction_viscous=2.0e3,
-                      angular_damping=0.01, max_angular_velocity=100.0)
+                      angular_damping=0.01, max_angular_velocity=100.0, control_mode=0, limit_stiffness=0.0, limit_damping=0.0)
 
 
 def kinematics(model, st):
@@ -93,7 +128,7 @@ def kinematics(model, st):
             Q[i] = st.q0
             p[i] = st.p0
         else:
-            Q[i] = quat_mul(Q[par], st.q[i - 1])
+            Q[i] = quat_mul(Q[par], st.q[i - 1])   # st.q already contains a revolute joint's rest rotation
             Q[i] = Q[i] / np.linalg.norm(Q[i])
             p[i] = p[par] + R[par] @ model.local_translation[i].astype(np.float64)
         R[i] = quat_to_mat(Q[i])
@@ -109,19 +144,33 @@ def body_velocities(model, st, R, p):
         if par < 0:
             w[i], v[i] = st.w0, st.v0
         else:
-            w[i] = w[par] + R[i] @ st.wj[i - 1]
+            w[i] = w[par] + R[i] @ (st.S(i - 1) @ st.qd[i - 1])
             v[i] = v[par] + np.cross(w[par], p[i] - p[par])
     return w, v
 
 
-def accelerations(model, st, target, params, dt, kp_scale=1.0, kd_scale=1.0, return_parts=False):
-    """Generalized accelerations nu_dot = [alpha0, a0, wJdot_1..] of one implicit sub-step."""
+def explicit_torque(model, st, target, kp_scale=1.0, kd_scale=1.0):
+    """`pd` control mode (humanoid.py:1575-1599): tau = clip(kp (target - q) - kd qd, +-limit), recomputed once per
+    gym.simulate call and held over its sub-steps.  Revolute joints only (H1 / G1)."""
+    th = st.theta
+    qd = np.concatenate(st.qd)
+    sp = model.dof_kp * kp_scale * (np.asarray(target, np.float64) - th)
+    tau = sp - model.dof_kd * kd_scale * qd
+    sat = np.abs(tau) >= model.dof_effort
+    # (held torque of mode 1, [spring-or-limit, saturated flag] of mode 2)
+    return np.clip(tau, -model.dof_effort, model.dof_effort), np.where(sat, np.sign(tau) * model.dof_effort, sp), sat
+
+
+def accelerations(model, st, target, params, dt, kp_scale=1.0, kd_scale=1.0, return_parts=False, tau_hold=None):
+    """Generalized accelerations nu_dot = [alpha0, a0, qdd_1..] of one implicit sub-step."""
     prm = dict(DEFAULT_PARAMS, **(params or {}))
     nb = model.num_bodies
-    nv = 6 + 3 * (nb - 1)
+    offs = np.concatenate([[6], 6 + np.cumsum(st.nd)]).astype(int)
+    nv = int(offs[-1])
+    col = lambda i: slice(offs[i - 1], offs[i])   # columns of body i's joint
     Q, R, p = kinematics(model, st)
     w, v = body_velocities(model, st, R, p)
-    nu = np.concatenate([st.w0, st.v0, st.wj.reshape(-1)])
+    nu = np.concatenate([st.w0, st.v0] + list(st.qd))
     Jw = np.zeros((nb, 3, nv))
     Jv = np.zeros((nb, 3, nv))
     for i in range(nb):
@@ -130,9 +179,9 @@ def accelerations(model, st, target, params, dt, kp_scale=1.0, kd_scale=1.0, ret
         Jv[i][:, 0:3] = -skew(p[i] - p[0])
         k = i
         while k > 0:
-            c = slice(6 + 3 * (k - 1), 6 + 3 * k)
-            Jw[i][:, c] = R[k]
-            Jv[i][:, c] = -skew(p[i] - p[k]) @ R[k]
+            Sw = R[k] @ st.S(k - 1)
+            Jw[i][:, col(k)] = Sw
+            Jv[i][:, col(k)] = -skew(p[i] - p[k]) @ Sw
             k = model.parent[k]
         assert np.allclose(Jw[i] @ nu, w[i]) and np.allclose(Jv[i] @ nu, v[i])
     # bias accelerations (nu_dot = 0)
@@ -141,7 +190,7 @@ def accelerations(model, st, target, params, dt, kp_scale=1.0, kd_scale=1.0, ret
     for i in range(1, nb):
         par = model.parent[i]
         r = p[i] - p[par]
-        ab_w[i] = ab_w[par] + np.cross(w[par], R[i] @ st.wj[i - 1])
+        ab_w[i] = ab_w[par] + np.cross(w[par], R[i] @ (st.S(i - 1) @ st.qd[i - 1]))
         ab_v[i] = ab_v[par] + np.cross(ab_w[par], r) + np.cross(w[par], np.cross(w[par], r))
     M = np.zeros((nv, nv))
     rhs = np.zeros(nv)
@@ -181,32 +230,54 @@ def accelerations(model, st, target, params, dt, kp_scale=1.0, kd_scale=1.0, ret
             Jpt = Jv[i] - skew(arm) @ Jw[i]
             M += dt * Jpt.T @ Cm @ Jpt
             rhs += Jpt.T @ (F0 - dt * Cm @ apb)
-    tau_all = np.zeros((nb, 3))
-    dimp_all = np.zeros((nb, 3))
+    tau_all = [None] * nb
+    dimp_all = [None] * nb
     for i in range(1, nb):
-        s = model.dof_start[i]
-        kp = model.dof_kp[s:s + 3] * kp_scale
-        kd = model.dof_kd[s:s + 3] * kd_scale
-        arm_ = model.dof_armature[s:s + 3]
-        eff = model.dof_effort[s:s + 3]
-        qt = quat_from_rotvec(np.asarray(target[s:s + 3], dtype=np.float64))
-        err = quat_to_rotvec(quat_mul(quat_conj(st.q[i - 1]), qt))
-        tau = np.clip(kp * err, -eff, eff) - (kd + dt * kp) * st.wj[i - 1]  # spring saturates, damping stays implicit
-        d = arm_ + dt * kd + dt * dt * kp
-        c = slice(6 + 3 * (i - 1), 6 + 3 * i)
-        M[c, c] += np.diag(d)
-        rhs[c] += tau
+        s, n = model.dof_start[i], st.nd[i - 1]
+        kp = model.dof_kp[s:s + n] * kp_scale
+        kd = model.dof_kd[s:s + n] * kd_scale
+        arm_ = model.dof_armature[s:s + n]
+        eff = model.dof_effort[s:s + n]
+        qd = st.qd[i - 1]
+        if n == 3:
+            qt = quat_from_rotvec(np.asarray(target[s:s + 3], dtype=np.float64))
+            err = quat_to_rotvec(quat_mul(quat_conj(st.q[i - 1]), qt))
+        else:
+            err = np.asarray(target[s:s + 1], dtype=np.float64) - st.theta[i - 1]
+        if prm["control_mode"] == 1:   # explicit torque held over the simulate call
+            tau = np.array(tau_hold[0][s:s + n], dtype=np.float64)
+            d = arm_.copy()
+        elif prm["control_mode"] == 2:  # spring sampled per simulate call, damper continuous (implicit) unless saturated
+            if tau_hold[2][s]:
+                tau = np.array(tau_hold[1][s:s + n], dtype=np.float64)
+                d = arm_.copy()
+            else:
+                tau = tau_hold[1][s:s + n] - kd * qd
+                d = arm_ + dt * kd
+        else:
+            tau = np.clip(kp * err, -eff, eff) - (kd + dt * kp) * qd  # spring saturates, damping stays implicit
+            d = arm_ + dt * kd + dt * dt * kp
+        if n == 1 and prm["limit_stiffness"] > 0:  # joint limit: implicit penalty spring-damper beyond [lo, hi]
+            lo, hi = model.dof_limits()
+            th = st.theta[i - 1]
+            e = (lo[s] - th) if th < lo[s] else ((hi[s] - th) if th > hi[s] else 0.0)
+            if e != 0.0:
+                kl, dl = prm["limit_stiffness"], prm["limit_damping"]
+                tau = tau + kl * e - (dl + dt * kl) * qd
+                d = d + dt * dl + dt * dt * kl
+        M[col(i), col(i)] += np.diag(d)
+        rhs[col(i)] += tau
         tau_all[i], dimp_all[i] = tau, d
     nud = np.linalg.solve(M, rhs)
     if return_parts:
-        return nud, dict(M=M, rhs=rhs, R=R, p=p, w=w, v=v, Q=Q, tau=tau_all, dimp=dimp_all, fcontact=fcontact)
+        return nud, dict(M=M, rhs=rhs, R=R, p=p, w=w, v=v, Q=Q, tau=tau_all, dimp=dimp_all, fcontact=fcontact, offs=offs)
     return nud
 
 
-def substep(model, st, target, params, dt, kp_scale=1.0, kd_scale=1.0):
+def substep(model, st, target, params, dt, kp_scale=1.0, kd_scale=1.0, tau_hold=None):
     """One linearly-implicit sub-step; returns the applied joint torques (S5)."""
     prm = dict(DEFAULT_PARAMS, **(params or {}))
-    nud, parts = accelerations(model, st, target, prm, dt, kp_scale, kd_scale, return_parts=True)
+    nud, parts = accelerations(model, st, target, prm, dt, kp_scale, kd_scale, return_parts=True, tau_hold=tau_hold)
     damp = 1.0 / (1.0 + dt * prm["angular_damping"])
     st.w0 = (st.w0 + dt * nud[0:3]) * damp
     st.v0 = st.v0 + dt * nud[3:6]
@@ -214,31 +285,40 @@ def substep(model, st, target, params, dt, kp_scale=1.0, kd_scale=1.0):
     q = quat_mul(quat_from_rotvec(st.w0 * dt), st.q0)
     st.q0 = q / np.linalg.norm(q)
     nb = model.num_bodies
-    tau_applied = np.zeros((nb - 1, 3))
+    offs = parts["offs"]
+    tau_applied = []
     for i in range(1, nb):
-        qdd = nud[6 + 3 * (i - 1):6 + 3 * i]
-        s = model.dof_start[i]
-        tau_applied[i - 1] = parts["tau"][i] - (parts["dimp"][i] - model.dof_armature[s:s + 3]) * qdd
-        wj = (st.wj[i - 1] + dt * qdd) * damp
-        n = np.linalg.norm(wj)
-        if n > prm["max_angular_velocity"]:
-            wj = wj * (prm["max_angular_velocity"] / n)
-        st.wj[i - 1] = wj
-        q = quat_mul(st.q[i - 1], quat_from_rotvec(wj * dt))
-        st.q[i - 1] = q / np.linalg.norm(q)
-    return tau_applied.reshape(-1), parts["fcontact"]
+        qdd = nud[offs[i - 1]:offs[i]]
+        s, n = model.dof_start[i], st.nd[i - 1]
+        tau_applied.append(parts["tau"][i] - (parts["dimp"][i] - model.dof_armature[s:s + n]) * qdd)
+        wj = (st.qd[i - 1] + dt * qdd) * damp
+        nrm = np.linalg.norm(wj)
+        if nrm > prm["max_angular_velocity"]:
+            wj = wj * (prm["max_angular_velocity"] / nrm)
+        st.qd[i - 1] = wj
+        if n == 3:
+            q = quat_mul(st.q[i - 1], quat_from_rotvec(wj * dt))
+            st.q[i - 1] = q / np.linalg.norm(q)
+        else:
+            st.theta[i - 1] += wj[0] * dt
+            st.q[i - 1] = st._rev_quat(i - 1)
+    return np.concatenate(tau_applied), parts["fcontact"]
 
 
 def sim_step(model, root_states, dof_state, pd_target, params=None, sim_dt=1 / 60, substeps=2, num_sim_calls=2,
              kp_scale=1.0, kd_scale=1.0):
     """num_sim_calls x gym.simulate, each `substeps` sub-steps of sim_dt/substeps.  Returns new
     (root_states[13], dof_state[D,2], rigid_body_state[NB,13], dof_force[D], contact_force[NB,3])."""
-    st = State(root_states, dof_state)
+    st = State(root_states, dof_state, model)
     dt = sim_dt / substeps
     tau = np.zeros(model.num_dof)
     fc = np.zeros((model.num_bodies, 3))
-    for _ in range(num_sim_calls * substeps):
-        tau, fc = substep(model, st, pd_target, params, dt, kp_scale, kd_scale)
+    explicit = dict(DEFAULT_PARAMS, **(params or {}))["control_mode"] in (1, 2)
+    hold = None
+    for k in range(num_sim_calls * substeps):
+        if explicit and k % substeps == 0:
+            hold = explicit_torque(model, st, pd_target, kp_scale, kd_scale)
+        tau, fc = substep(model, st, pd_target, params, dt, kp_scale, kd_scale, tau_hold=hold)
     Q, R, p = kinematics(model, st)
     w, v = body_velocities(model, st, R, p)
     rbs = np.concatenate([p, np.array(Q), v, w], axis=-1)

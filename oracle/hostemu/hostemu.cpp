@@ -11,6 +11,52 @@
 
 using namespace phc;
 
+// Stepper: same phase sequence as k_sim_step, lanes looped inside each phase.
+template <int JT>
+static int emu_sim_step_t(const phc_model_t* model, const phc_sim_params_t* prm, const phc_sim_state_t* sim, const float* actions,
+                          const float* pd_off, const float* pd_scale, const int32_t* freeze, int num_sim_calls, int do_step) {
+    const int nb = model->num_bodies, nd = model->num_dof;
+    const int ndj = JT == PHC_JT_REVOLUTE ? 1 : 3;
+#pragma omp parallel for schedule(static)
+    for (int64_t env = 0; env < sim->num_envs; ++env) {
+        std::vector<float> xch(PHC_MAX_BODIES * PHC_XCH_STRIDE);
+        AbaLane L[PHC_MAX_BODIES];
+        for (int j = 0; j < PHC_MAX_BODIES; ++j) L[j].level = -1;
+        for (int j = 0; j < nb; ++j) {
+            aba_load_model(L[j], *model, j);
+            if (JT == PHC_JT_REVOLUTE) aba_load_model_rev(L[j], *model, j);
+            if (do_step && actions && j >= 1) {
+                for (int k = 0; k < ndj; ++k) {
+                    const int d = L[j].dof_start + k;
+                    volatile float prod = pd_scale[d] * actions[env * nd + d];
+                    float t = pd_off[d] + prod;
+                    if (freeze && freeze[d]) t = 0.f;
+                    sim->pd_target[env * nd + d] = t;
+                }
+            }
+            aba_load_state<JT>(L[j], *sim, nd, env, j);
+        }
+        const int ml = model->max_level;
+        Xch x;
+        x.base = xch.data();
+        for (int l = 0; l <= ml; ++l) for (int j = 0; j < nb; ++j) aba_fk_level(L[j], l, j, x);
+        if (do_step) {
+            const float dt = prm->sim_dt / (float)prm->substeps;
+            const int nsub = num_sim_calls * prm->substeps;
+            for (int s = 0; s < nsub; ++s) {
+                for (int j = 0; j < nb; ++j) aba_body_init<JT>(L[j], *model, *prm, dt, j, s % prm->substeps == 0);
+                for (int l = ml; l >= 0; --l) for (int j = 0; j < nb; ++j) aba_backward_level<JT>(L[j], l, j, x);
+                for (int l = 0; l <= ml; ++l) for (int j = 0; j < nb; ++j) aba_forward_level<JT>(L[j], l, j, x, *prm, dt);
+            }
+        }
+        for (int j = 0; j < nb; ++j) {
+            if (do_step) aba_store_state<JT>(L[j], *sim, nd, env, j);
+            aba_publish_body(L[j], *sim, nb, env, j, do_step != 0);
+        }
+    }
+    return 0;
+}
+
 extern "C" {
 
 void emu_set_threads(int n) { omp_set_num_threads(n > 0 ? n : 1); }
@@ -105,47 +151,11 @@ int emu_amp_obs_demo(const phc_model_t* model, const phc_motion_lib_t* lib, cons
     return 0;
 }
 
-// Stepper: same phase sequence as k_sim_step, lanes looped inside each phase.
 int emu_sim_step(const phc_model_t* model, const phc_sim_params_t* prm, const phc_sim_state_t* sim, const float* actions,
                  const float* pd_off, const float* pd_scale, const int32_t* freeze, int num_sim_calls, int do_step) {
-    const int nb = model->num_bodies, nd = model->num_dof;
-#pragma omp parallel for schedule(static)
-    for (int64_t env = 0; env < sim->num_envs; ++env) {
-        std::vector<float> xch(PHC_MAX_BODIES * PHC_XCH_STRIDE);
-        AbaLane L[PHC_MAX_BODIES];
-        for (int j = 0; j < PHC_MAX_BODIES; ++j) L[j].level = -1;
-        for (int j = 0; j < nb; ++j) {
-            aba_load_model(L[j], *model, j);
-            if (do_step && actions && j >= 1) {
-                for (int k = 0; k < 3; ++k) {
-                    const int d = L[j].dof_start + k;
-                    volatile float prod = pd_scale[d] * actions[env * nd + d];
-                    float t = pd_off[d] + prod;
-                    if (freeze && freeze[d]) t = 0.f;
-                    sim->pd_target[env * nd + d] = t;
-                }
-            }
-            aba_load_state(L[j], *sim, nd, env, j);
-        }
-        const int ml = model->max_level;
-        Xch x;
-        x.base = xch.data();
-        for (int l = 0; l <= ml; ++l) for (int j = 0; j < nb; ++j) aba_fk_level(L[j], l, j, x);
-        if (do_step) {
-            const float dt = prm->sim_dt / (float)prm->substeps;
-            const int nsub = num_sim_calls * prm->substeps;
-            for (int s = 0; s < nsub; ++s) {
-                for (int j = 0; j < nb; ++j) aba_body_init(L[j], *model, *prm, dt, j);
-                for (int l = ml; l >= 0; --l) for (int j = 0; j < nb; ++j) aba_backward_level(L[j], l, j, x);
-                for (int l = 0; l <= ml; ++l) for (int j = 0; j < nb; ++j) aba_forward_level(L[j], l, j, x, *prm, dt);
-            }
-        }
-        for (int j = 0; j < nb; ++j) {
-            if (do_step) aba_store_state(L[j], *sim, nd, env, j);
-            aba_publish_body(L[j], *sim, nb, env, j, do_step != 0);
-        }
-    }
-    return 0;
+    if (model->num_dof == model->num_bodies - 1 && model->num_bodies > 2)
+        return emu_sim_step_t<PHC_JT_REVOLUTE>(model, prm, sim, actions, pd_off, pd_scale, freeze, num_sim_calls, do_step);
+    return emu_sim_step_t<PHC_JT_SPHERICAL>(model, prm, sim, actions, pd_off, pd_scale, freeze, num_sim_calls, do_step);
 }
 
 }  // extern "C"

@@ -39,7 +39,8 @@ class SimState(C.Structure):
 class SimParams(C.Structure):
     _fields_ = [("sim_dt", c_f), ("substeps", c_i32), ("control_freq_inv", c_i32), ("gravity_z", c_f),
                 ("contact_stiffness", c_f), ("contact_damping", c_f), ("friction", c_f), ("friction_viscous", c_f),
-                ("angular_damping", c_f), ("max_angular_velocity", c_f), ("contact_offset", c_f)]
+                ("angular_damping", c_f), ("max_angular_velocity", c_f), ("contact_offset", c_f),
+                ("control_mode", c_i32), ("limit_stiffness", c_f), ("limit_damping", c_f)]
 
 
 class ImParams(C.Structure):

@@ -50,11 +50,12 @@ def sim_state_struct(num_envs, root_states, dof_state, rigid_body_state, contact
 
 def sim_params_struct(sim_dt=1 / 60, substeps=2, control_freq_inv=2, gravity_z=-9.81, contact_stiffness=1.0e5,
                       contact_damping=1.0e3, friction=1.0, friction_viscous=2.0e3, angular_damping=0.01,
-                      max_angular_velocity=100.0, contact_offset=0.02):
+                      max_angular_velocity=100.0, contact_offset=0.02, control_mode=0, limit_stiffness=0.0, limit_damping=0.0):
     p = L.SimParams()
     p.sim_dt, p.substeps, p.control_freq_inv, p.gravity_z = sim_dt, substeps, control_freq_inv, gravity_z
     p.contact_stiffness, p.contact_damping, p.friction, p.friction_viscous = contact_stiffness, contact_damping, friction, friction_viscous
     p.angular_damping, p.max_angular_velocity, p.contact_offset = angular_damping, max_angular_velocity, contact_offset
+    p.control_mode, p.limit_stiffness, p.limit_damping = int(control_mode), float(limit_stiffness), float(limit_damping)
     return p
 
 

@@ -27,7 +27,9 @@
 namespace phc {
 
 #define PHC_XCH_STRIDE 28      // floats per exchange slot
-#define PHC_BODY_FLOATS 28     // floats per body in phc_model_t.floats (model.py pack())
+#define PHC_BODY_FLOATS 36     // floats per body in phc_model_t.floats (model.py pack())
+#define PHC_JT_SPHERICAL 1     // joint types as model.py numbers them
+#define PHC_JT_REVOLUTE 2
 #define PHC_NTAB 11            // int tables per model (parent level jtype dof_start child0-2 nchild cp_start cp_count order)
 
 struct Sym3 { float xx, xy, xz, yy, yz, zz; };
@@ -111,6 +113,11 @@ struct AbaLane {
     V3 dimp;          // implicit PD diagonal dt kd + dt^2 kp (WITHOUT the armature), child frame
     V3 arm;           // armature
     V3 fcontact;      // net explicit contact force on the body (S4)
+    // --- revolute joints only (robots: H1 / G1); for them target.x, dimp.x, arm.x, tau_local = axis * tau carry the scalars ---
+    V3 axis;          // joint axis, child (= parent-rest) frame
+    Q4 qrest;         // rest rotation child-in-parent (MJCF body quat)
+    float th, thd;    // joint angle and rate
+    float tau_hold;   // explicit `pd` torque of the current simulate call (control_mode 1)
 };
 
 PHC_HD const float* model_body(const phc_model_t& m, int j) { return m.floats + j * PHC_BODY_FLOATS; }
@@ -125,14 +132,32 @@ PHC_HD void aba_load_model(AbaLane& L, const phc_model_t& m, int j) {
     L.r_local = v3(f[0], f[1], f[2]);
     L.arm = v3(f[19], f[20], f[21]);
 }
+// revolute extras (template JT == PHC_JT_REVOLUTE paths only)
+PHC_HD void aba_load_model_rev(AbaLane& L, const phc_model_t& m, int j) {
+    const float* f = model_body(m, j);
+    L.axis = v3(f[25], f[26], f[27]);
+    L.qrest = q4(f[28], f[29], f[30], f[31]);
+    L.tau_hold = 0.f;
+}
+PHC_HD Q4 rev_joint_quat(const AbaLane& L) { return quat_mul16(L.qrest, quat_from_rotvec(L.axis * L.th)); }
 
-// State load: S1 root_states [N,13], S2 dof_state [N,D,2] (exp-map, joint velocity), S8 pd_target [N,D]
+// State load: S1 root_states [N,13], S2 dof_state [N,D,2] (spherical: exp-map triple + joint velocity; revolute: angle +
+// rate), S8 pd_target [N,D]
+template <int JT>
 PHC_HD void aba_load_state(AbaLane& L, const phc_sim_state_t& s, int nd, int64_t env, int j) {
     if (j == 0) {
         const float* r = s.root_states + env * 13;
         L.p0 = v3(r[0], r[1], r[2]); L.q = quat_normalize(q4(r[3], r[4], r[5], r[6]));
         L.v0 = v3(r[7], r[8], r[9]); L.w0 = v3(r[10], r[11], r[12]);
         L.wj = v3(0.f, 0.f, 0.f); L.target = v3(0.f, 0.f, 0.f);
+        if (JT == PHC_JT_REVOLUTE) { L.th = L.thd = 0.f; }
+    } else if (JT == PHC_JT_REVOLUTE) {
+        const float* d = s.dof_state + (env * nd + L.dof_start) * 2;
+        L.th = d[0]; L.thd = d[1];
+        L.q = rev_joint_quat(L);
+        L.wj = L.axis * L.thd;
+        L.target = v3(s.pd_target[env * nd + L.dof_start], 0.f, 0.f);
+        L.p0 = L.v0 = L.w0 = v3(0.f, 0.f, 0.f);
     } else {
         const float* d = s.dof_state + (env * nd + L.dof_start) * 2;
         L.q = quat_from_rotvec(v3(d[0], d[2], d[4]));
@@ -186,7 +211,9 @@ PHC_HD void aba_fk_level(AbaLane& L, int level, int j, const Xch& x) {
 }
 
 // ---- per-body initialisation of I^A, p^A and of the joint drive (no communication) ----
-PHC_HD void aba_body_init(AbaLane& L, const phc_model_t& m, const phc_sim_params_t& prm, float dt, int j) {
+// `new_sim_call`: first sub-step of a gym.simulate call -- the explicit `pd` torque is recomputed there (humanoid.py:1608-1616).
+template <int JT>
+PHC_HD void aba_body_init(AbaLane& L, const phc_model_t& m, const phc_sim_params_t& prm, float dt, int j, bool new_sim_call) {
     const float* f = model_body(m, j);
     const float mass = f[3];
     Sym3 Io_b;
@@ -241,6 +268,48 @@ PHC_HD void aba_body_init(AbaLane& L, const phc_model_t& m, const phc_sim_params
         // C += C
         L.IA.C.xx += c1; L.IA.C.yy += c1; L.IA.C.zz += c3;
     }
+    if (JT == PHC_JT_REVOLUTE) {
+        if (L.level > 0) {
+            // joint drive (revolute).  control_mode 0 = Isaac Gym's implicit position drive (`isaac_pd`), linearly implicit as
+            // for spherical joints; 1 = `pd`: explicit torque clip(kp (target - q) - kd qd, +-limit) recomputed once per
+            // simulate call from the state at that instant and held over its sub-steps (humanoid.py:1575-1599,1608-1616).
+            const float kp = f[13], kd = f[16], eff = f[22];
+            float tau, d;
+            if (prm.control_mode == 1) {
+                if (new_sim_call) L.tau_hold = fminf(fmaxf(kp * (L.target.x - L.th) - kd * L.thd, -eff), eff);
+                tau = L.tau_hold;
+                d = 0.f;
+            } else if (prm.control_mode == 2) {
+                // `pd` with the damper kept continuous: the spring term is sampled once per simulate call (zero-order hold, as
+                // the reference's controller does), the -kd*qd term follows the joint rate implicitly.  A held damper torque
+                // on H1's 0.45 kg foot (kd 5 N m s, I 0.005 kg m^2, dt 5 ms: dt kd / I = 4.9 > 2) is an unstable explicit
+                // integrator whenever the foot is unloaded; saturated drives are held (constant +-limit), like mode 1.
+                if (new_sim_call) {
+                    const float sp = kp * (L.target.x - L.th);
+                    const float t0 = sp - kd * L.thd;
+                    L.tau_hold = (fabsf(t0) >= eff) ? (t0 > 0.f ? eff : -eff) : sp;
+                    L.target.y = (fabsf(t0) >= eff) ? 1.f : 0.f;  // saturated flag (target.y is unused by revolute joints)
+                }
+                if (L.target.y != 0.f) { tau = L.tau_hold; d = 0.f; }
+                else { tau = L.tau_hold - kd * L.thd; d = dt * kd; }
+            } else {
+                tau = fminf(fmaxf(kp * (L.target.x - L.th), -eff), eff) - (kd + dt * kp) * L.thd;
+                d = dt * kd + dt * dt * kp;
+            }
+            // joint limit (URDF <limit lower upper>, enforced by PhysX): implicit penalty spring-damper outside [lo, hi]
+            if (prm.limit_stiffness > 0.f) {
+                const float lo = f[32], hi = f[33];
+                const float e = L.th < lo ? lo - L.th : (L.th > hi ? hi - L.th : 0.f);
+                if (e != 0.f) {
+                    tau += prm.limit_stiffness * e - (prm.limit_damping + dt * prm.limit_stiffness) * L.thd;
+                    d += dt * prm.limit_damping + dt * dt * prm.limit_stiffness;
+                }
+            }
+            L.tau_local = L.axis * tau;
+            L.dimp = v3(d, 0.f, 0.f);
+        }
+        return;
+    }
     // joint drive (spherical): geodesic error in the child frame
     if (L.level > 0) {
         Q4 qt = quat_from_rotvec(L.target);
@@ -294,15 +363,25 @@ PHC_HD void accumulate_child(Inertia6& I, Force6& p, const float* s, int es) {
 // ---- backward sweep: articulated inertia, one tree level (leaves -> root) ----
 // Lanes at `level` first absorb their children's contributions (written at level+1), then, unless
 // they are the root, reduce over their own joint and publish T^T I^a T, T^T p^a for their parent.
+template <int JT>
 PHC_HD void aba_backward_level(AbaLane& L, int level, int j, const Xch& x) {
     if (L.level != level) return;
     for (int k = 0; k < 3; ++k)
         if (k < L.nchild) accumulate_child(L.IA, L.pA, xslot(x, L.child[k]), Xch::es);
     if (level == 0) return;
     M3 R = quat_to_mat(L.Q);
-    Sym3 D = rot_diag(R, L.dimp + L.arm);
-    D.xx += L.IA.A.xx; D.xy += L.IA.A.xy; D.xz += L.IA.A.xz; D.yy += L.IA.A.yy; D.yz += L.IA.A.yz; D.zz += L.IA.A.zz;
-    L.Di = sym_inv(D);
+    if (JT == PHC_JT_REVOLUTE) {
+        // one free axis a (world): D = a^T A a + d is a scalar and D^-1 acts as the rank-1 matrix a a^T / D; with it the
+        // spherical-joint expressions below hold unchanged (U D^-1 U^T removes exactly the a-component)
+        const V3 a = mat_mul(R, L.axis);
+        const float ids = 1.0f / (dot(a, sym_mul(L.IA.A, a)) + L.dimp.x + L.arm.x);
+        L.Di.xx = a.x * a.x * ids; L.Di.xy = a.x * a.y * ids; L.Di.xz = a.x * a.z * ids;
+        L.Di.yy = a.y * a.y * ids; L.Di.yz = a.y * a.z * ids; L.Di.zz = a.z * a.z * ids;
+    } else {
+        Sym3 D = rot_diag(R, L.dimp + L.arm);
+        D.xx += L.IA.A.xx; D.xy += L.IA.A.xy; D.xz += L.IA.A.xz; D.yy += L.IA.A.yy; D.yz += L.IA.A.yz; D.zz += L.IA.A.zz;
+        L.Di = sym_inv(D);
+    }
     L.u = mat_mul(R, L.tau_local) - L.pA.n;
     // G = Di A (3x3), H = Di B (3x3)
     const Sym3& A = L.IA.A;
@@ -333,6 +412,7 @@ PHC_HD void aba_backward_level(AbaLane& L, int level, int j, const Xch& x) {
 // ---- forward sweep, one tree level (root -> leaves): accelerations, semi-implicit Euler on this body's joint, and
 // the NEW kinematics (from the parent's new kinematics) in the same pass -- the separate integration step and the next
 // sub-step's kinematics sweep are folded in, so a sub-step is two sweeps.  Slot: alpha(3) a(3) | Q(4) p(3) w(3) v(3).
+template <int JT>
 PHC_HD void aba_forward_level(AbaLane& L, int level, int j, const Xch& x, const phc_sim_params_t& prm, float dt) {
     if (L.level != level) return;
     constexpr int es = Xch::es;
@@ -370,12 +450,23 @@ PHC_HD void aba_forward_level(AbaLane& L, int level, int j, const Xch& x, const 
         a = a1;
         M3 R = quat_to_mat(L.Q);
         V3 qdd = mat_tmul(R, beta);  // child-frame joint acceleration
-        // torque actually applied over the step (explicit part minus the implicit augmentation), S5
-        L.tau_local = v3(L.tau_local.x - L.dimp.x * qdd.x, L.tau_local.y - L.dimp.y * qdd.y, L.tau_local.z - L.dimp.z * qdd.z);
-        L.wj = (L.wj + qdd * dt) * damp;
-        float wn = norm(L.wj);
-        if (wn > prm.max_angular_velocity) L.wj = L.wj * (prm.max_angular_velocity / wn);
-        L.q = quat_normalize(quat_mul16(L.q, quat_from_rotvec(L.wj * dt)));
+        if (JT == PHC_JT_REVOLUTE) {
+            const float thdd = dot(L.axis, qdd);
+            // torque actually applied over the step (explicit part minus the implicit augmentation), S5 -- kept in tau_local.x
+            L.tau_local = v3(dot(L.axis, L.tau_local) - L.dimp.x * thdd, 0.f, 0.f);
+            L.thd = (L.thd + thdd * dt) * damp;
+            L.thd = fminf(fmaxf(L.thd, -prm.max_angular_velocity), prm.max_angular_velocity);
+            L.th += L.thd * dt;
+            L.wj = L.axis * L.thd;
+            L.q = rev_joint_quat(L);
+        } else {
+            // torque actually applied over the step (explicit part minus the implicit augmentation), S5
+            L.tau_local = v3(L.tau_local.x - L.dimp.x * qdd.x, L.tau_local.y - L.dimp.y * qdd.y, L.tau_local.z - L.dimp.z * qdd.z);
+            L.wj = (L.wj + qdd * dt) * damp;
+            float wn = norm(L.wj);
+            if (wn > prm.max_angular_velocity) L.wj = L.wj * (prm.max_angular_velocity / wn);
+            L.q = quat_normalize(quat_mul16(L.q, quat_from_rotvec(L.wj * dt)));
+        }
         aba_kinematics_from_parent(L, q4(ps[6 * es], ps[7 * es], ps[8 * es], ps[9 * es]), v3(ps[10 * es], ps[11 * es], ps[12 * es]),
                                    v3(ps[13 * es], ps[14 * es], ps[15 * es]), v3(ps[16 * es], ps[17 * es], ps[18 * es]));
     }
@@ -385,11 +476,16 @@ PHC_HD void aba_forward_level(AbaLane& L, int level, int j, const Xch& x, const 
 }
 
 // ---- state store: S1/S2 (+S5 dof force), and S3/S4 publication from the last kinematics sweep ----
+template <int JT>
 PHC_HD void aba_store_state(const AbaLane& L, const phc_sim_state_t& s, int nd, int64_t env, int j) {
     if (j == 0) {
         float* r = s.root_states + env * 13;
         r[0] = L.p0.x; r[1] = L.p0.y; r[2] = L.p0.z; r[3] = L.q.x; r[4] = L.q.y; r[5] = L.q.z; r[6] = L.q.w;
         r[7] = L.v0.x; r[8] = L.v0.y; r[9] = L.v0.z; r[10] = L.w0.x; r[11] = L.w0.y; r[12] = L.w0.z;
+    } else if (JT == PHC_JT_REVOLUTE) {
+        float* d = s.dof_state + (env * nd + L.dof_start) * 2;
+        d[0] = L.th; d[1] = L.thd;
+        if (s.dof_force) s.dof_force[env * nd + L.dof_start] = L.tau_local.x;
     } else {
         float* d = s.dof_state + (env * nd + L.dof_start) * 2;
         V3 e = quat_to_rotvec(L.q);

@@ -24,7 +24,7 @@ using namespace phc;
 // >256 VGPRs: 214-252 us vs 158 us for this mapping.  __launch_bounds__(64, 2): two wavefronts per SIMD (<= 256 VGPRs,
 // 68 B/lane of scratch) beats one (272 registers, no scratch: 195 us) and three (168 VGPRs, 412 B scratch: 280 us).
 // ------------------------------------------------------------------------------------------
-template <bool STEP>
+template <bool STEP, int JT>
 __global__ __launch_bounds__(64, 2) void k_sim_step(phc_model_t model, phc_sim_params_t prm, phc_sim_state_t sim,
                                                 const float* __restrict__ actions, const float* __restrict__ pd_off,
                                                 const float* __restrict__ pd_scale, const int32_t* __restrict__ freeze,
@@ -44,16 +44,17 @@ __global__ __launch_bounds__(64, 2) void k_sim_step(phc_model_t model, phc_sim_p
     L.level = -1;
     if (active) {
         aba_load_model(L, model, lane);
+        if (JT == PHC_JT_REVOLUTE) aba_load_model_rev(L, model, lane);
         if (STEP && actions != nullptr && lane >= 1) {
             // A2: pd_tar = offset + scale * action, frozen DoFs -> 0 (humanoid.py:1711-1713,1549-1554)
-            for (int k = 0; k < 3; ++k) {
+            for (int k = 0; k < (JT == PHC_JT_REVOLUTE ? 1 : 3); ++k) {
                 const int d = L.dof_start + k;
                 float t = __fadd_rn(pd_off[d], __fmul_rn(pd_scale[d], actions[env * nd + d]));
                 if (freeze != nullptr && freeze[d]) t = 0.f;
                 sim.pd_target[env * nd + d] = t;
             }
         }
-        aba_load_state(L, sim, nd, env, lane);
+        aba_load_state<JT>(L, sim, nd, env, lane);
     }
     const int max_level = model.max_level;
     for (int l = 0; l <= max_level; ++l) { aba_fk_level(L, l, lane, x); __syncthreads(); }
@@ -61,14 +62,14 @@ __global__ __launch_bounds__(64, 2) void k_sim_step(phc_model_t model, phc_sim_p
         const float dt = prm.sim_dt / (float)prm.substeps;
         const int nsub = num_sim_calls * prm.substeps;
         for (int s = 0; s < nsub; ++s) {
-            if (active) aba_body_init(L, model, prm, dt, lane);
-            for (int l = max_level; l >= 0; --l) { aba_backward_level(L, l, lane, x); __syncthreads(); }
-            for (int l = 0; l <= max_level; ++l) { aba_forward_level(L, l, lane, x, prm, dt); __syncthreads(); }
+            if (active) aba_body_init<JT>(L, model, prm, dt, lane, s % prm.substeps == 0);
+            for (int l = max_level; l >= 0; --l) { aba_backward_level<JT>(L, l, lane, x); __syncthreads(); }
+            for (int l = 0; l <= max_level; ++l) { aba_forward_level<JT>(L, l, lane, x, prm, dt); __syncthreads(); }
         }
     }
     // S7: the last forward sweep already produced the end-of-step kinematics
     if (active) {
-        if (STEP) aba_store_state(L, sim, nd, env, lane);
+        if (STEP) aba_store_state<JT>(L, sim, nd, env, lane);
         aba_publish_body(L, sim, nb, env, lane, STEP);
     }
 }
@@ -78,8 +79,12 @@ static void sim_launch(const phc_model_t* model, const phc_sim_params_t& prm, co
                        const float* off, const float* scale, const int32_t* freeze, int num_sim_calls, hipStream_t stream,
                        const int64_t* env_ids = nullptr, int num_listed = 0) {
     const int64_t groups = env_ids ? num_listed : sim->num_envs;
-    hipLaunchKernelGGL(k_sim_step<STEP>, dim3((groups + 1) / 2), dim3(64), 0, stream, *model, prm, *sim, actions, off, scale,
-                       freeze, num_sim_calls, env_ids, num_listed);
+    if (model->num_dof == model->num_bodies - 1 && model->num_bodies > 2)  // one revolute joint per body (robots)
+        hipLaunchKernelGGL((k_sim_step<STEP, PHC_JT_REVOLUTE>), dim3((groups + 1) / 2), dim3(64), 0, stream, *model, prm, *sim, actions, off,
+                           scale, freeze, num_sim_calls, env_ids, num_listed);
+    else
+        hipLaunchKernelGGL((k_sim_step<STEP, PHC_JT_SPHERICAL>), dim3((groups + 1) / 2), dim3(64), 0, stream, *model, prm, *sim, actions, off,
+                           scale, freeze, num_sim_calls, env_ids, num_listed);
 }
 
 static inline int32_t launch_status() {
@@ -91,7 +96,8 @@ extern "C" {
 
 static int32_t check_model(const phc_model_t* m) {
     if (!m || m->num_bodies < 1 || m->num_bodies > PHC_MAX_BODIES || !m->ints || !m->floats) return PHC_EINVAL;
-    if (m->num_dof != 3 * (m->num_bodies - 1)) return PHC_EUNSUPPORTED;  // spherical joints only in this round
+    // all-spherical (SMPL family) or all-revolute (H1 / G1) articulations
+    if (m->num_dof != 3 * (m->num_bodies - 1) && m->num_dof != m->num_bodies - 1) return PHC_EUNSUPPORTED;
     return 0;
 }
 

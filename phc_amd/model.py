@@ -49,9 +49,38 @@ def _shift_inertia(I_c, m, c):
     return I_c + m * (np.dot(c, c) * np.eye(3) - np.outer(c, c))
 
 
-def _geom_props(g, defaults):
+_HULL_DIRS = np.array([d for d in np.ndindex(3, 3, 3)], dtype=np.float64) - 1.0
+_HULL_DIRS = _HULL_DIRS[(np.abs(_HULL_DIRS).sum(1) == 1) | (np.abs(_HULL_DIRS).sum(1) == 3)]  # 6 axes + 8 diagonals
+
+
+def _stl_vertices(path):
+    """Vertices of a binary STL (80-byte header, uint32 count, 50-byte records)."""
+    raw = open(path, "rb").read()
+    n = int(np.frombuffer(raw, dtype="<u4", count=1, offset=80)[0])
+    rec = np.frombuffer(raw, dtype=np.dtype([("n", "<f4", 3), ("v", "<f4", (3, 3)), ("a", "<u2")]), count=n, offset=84)
+    return rec["v"].reshape(-1, 3).astype(np.float64)
+
+
+def _mesh_contact_points(verts):
+    """Support points of the mesh's convex hull along 14 directions (Isaac Gym collides the convex hull of a URDF mesh):
+    what ground contact and the start-height fix need of the link's shape."""
+    idx = sorted({int(np.argmax(verts @ d)) for d in _HULL_DIRS})
+    return [(verts[i], 0.0) for i in idx]
+
+
+def _geom_props(g, defaults, meshes=None):
     """-> (mass, com[3], I_com[3,3], contact points [(pos[3], radius)])"""
     gtype = g.attrib.get("type", defaults.get("type", "sphere"))
+    if gtype == "mesh":
+        # robots carry <inertial>; the mesh only contributes contact points (pos/quat of the geom applied)
+        verts = meshes[g.attrib["mesh"]]
+        pos = _floats(g.attrib.get("pos"), [0, 0, 0])
+        R = _quat_wxyz_to_mat(_floats(g.attrib.get("quat"), [1, 0, 0, 0]))
+        return 0.0, pos, np.zeros((3, 3)), [(pos + R @ p, r) for p, r in _mesh_contact_points(verts)]
+    if gtype == "cylinder":
+        # asset_options.replace_cylinder_with_capsule = True (humanoid.py:894): two sphere points on the axis
+        g = _Attr(dict(g.attrib, type="capsule"))
+        gtype = "capsule"
     density = float(g.attrib.get("density", defaults.get("density", 1000.0)))
     size = _floats(g.attrib.get("size"), [0.0])
     if gtype == "sphere":
@@ -95,10 +124,24 @@ def _geom_props(g, defaults):
     raise NotImplementedError(f"geom type {gtype}")
 
 
+class _Attr:
+    def __init__(self, attrib):
+        self.attrib = attrib
+
+
 def compile_mjcf(path):
     """Parse an MJCF humanoid (free root + hinge joints) into the flat model dict."""
     root = ET.parse(path).getroot()
     wb = root.find("worldbody")
+    comp = root.find("compiler")
+    radian = comp is not None and comp.attrib.get("angle", "degree") == "radian"
+    meshdir = os.path.join(os.path.dirname(path), comp.attrib.get("meshdir", "")) if comp is not None else os.path.dirname(path)
+    meshes = {}
+    if root.find("asset") is not None:
+        for me in root.find("asset").findall("mesh"):
+            f = os.path.join(meshdir, me.attrib["file"])
+            if os.path.exists(f):
+                meshes[me.attrib.get("name", os.path.splitext(me.attrib["file"])[0])] = _stl_vertices(f)
     body0 = wb.find("body")
     dflt = root.find("default")
     geom_defaults, joint_defaults = {}, {}
@@ -113,7 +156,7 @@ def compile_mjcf(path):
         for mtr in act.findall("motor"):
             gears[mtr.attrib["joint"]] = float(mtr.attrib.get("gear", "1").split()[0])
 
-    names, parents, local_t = [], [], []
+    names, parents, local_t, local_q = [], [], [], []
     mass, com, inertia_o = [], [], []
     jtype, dof_start, dof_count = [], [], []
     dof_axis, dof_kp, dof_kd, dof_arm, dof_lo, dof_hi, dof_effort, dof_names = [], [], [], [], [], [], [], []
@@ -125,6 +168,7 @@ def compile_mjcf(path):
         parents.append(parent)
         # np.fromstring(..., dtype=float) then float32 cast, as SkeletonTree.from_mjcf does
         local_t.append(_floats(node.attrib.get("pos"), [0, 0, 0]))
+        local_q.append(_floats(node.attrib.get("quat"), [1, 0, 0, 0]))  # rest rotation child-in-parent (wxyz, MJCF order)
         m_tot, mc, parts = 0.0, np.zeros(3), []
         inert = node.find("inertial")
         if inert is not None:
@@ -141,7 +185,11 @@ def compile_mjcf(path):
             mc = m_tot * c
             parts = [(m_tot, c, Ic)]
         for g in node.findall("geom"):
-            gm, gc, gI, pts = _geom_props(g, geom_defaults)
+            if g.attrib.get("contype") == "0" and g.attrib.get("conaffinity") == "0":
+                continue  # visual-only geom (robots)
+            if g.attrib.get("type") == "mesh" and g.attrib.get("mesh") not in meshes:
+                continue
+            gm, gc, gI, pts = _geom_props(g, geom_defaults, meshes)
             for p, r in pts:
                 cpts.append((idx, np.asarray(p, dtype=np.float64), float(r)))
             if inert is None:
@@ -172,7 +220,8 @@ def compile_mjcf(path):
                 rng = _floats(j.attrib.get("range", joint_defaults.get("range", "0 0")))
                 dof_axis.append(ax / np.linalg.norm(ax))
                 dof_kp.append(get("stiffness", 0.0)); dof_kd.append(get("damping", 0.0)); dof_arm.append(get("armature", 0.0))
-                dof_lo.append(np.deg2rad(rng[0])); dof_hi.append(np.deg2rad(rng[1]))  # MJCF default angle unit: degree
+                dof_lo.append(rng[0] if radian else np.deg2rad(rng[0]))  # MJCF default angle unit: degree
+                dof_hi.append(rng[1] if radian else np.deg2rad(rng[1]))
                 dof_effort.append(gears.get(j.attrib.get("name"), 0.0))
                 dof_names.append(j.attrib.get("name"))
         for child in node.findall("body"):
@@ -190,6 +239,7 @@ def compile_mjcf(path):
         "parent": parents,
         "level": level,
         "local_translation": np.array(local_t, dtype=np.float32).tolist(),
+        "local_rotation": np.array(local_q, dtype=np.float64).tolist(),
         "mass": mass,
         "com": np.array(com).tolist(),
         "inertia_origin": np.array(inertia_o).tolist(),
@@ -220,6 +270,8 @@ class ArticulationModel:
         self.parent = np.array(d["parent"], dtype=np.int32)
         self.level = np.array(d["level"], dtype=np.int32)
         self.local_translation = np.array(d["local_translation"], dtype=np.float32)
+        lq = np.array(d.get("local_rotation", [[1.0, 0, 0, 0]] * self.num_bodies), dtype=np.float64)
+        self.local_rotation = lq / np.linalg.norm(lq, axis=-1, keepdims=True)   # wxyz
         self.mass = np.array(d["mass"], dtype=np.float64)
         self.com = np.array(d["com"], dtype=np.float64)
         self.inertia_origin = np.array(d["inertia_origin"], dtype=np.float64)
@@ -240,6 +292,7 @@ class ArticulationModel:
         self.contact_radius = np.array(d["contact_radius"], dtype=np.float64)
         self.max_level = int(self.level.max())
         self.all_spherical = bool(np.all(self.joint_type[1:] == JOINT_SPHERICAL))
+        self.all_revolute = bool(np.all(self.joint_type[1:] == JOINT_REVOLUTE))
 
     # ---- lookups mirroring the reference task helpers -------------------------------------
     def body_ids(self, names):
@@ -263,8 +316,8 @@ class ArticulationModel:
         ints  : [0]=NB [1]=ND [2]=max_level [3]=NCP then per body (32 slots each):
                 parent, level, joint_type, dof_start, child0, child1, child2, nchild,
                 cp_start, cp_count, order (bodies sorted by level)
-        floats: per body (32 slots x 24): r_local[3], mass, m*com[3], Io(xx,xy,xz,yy,yz,zz)[6],
-                kp[3], kd[3], armature[3], effort[3], axis[3] (revolute) ;
+        floats: per body (32 slots x 36): r_local[3], mass, m*com[3], Io(xx,xy,xz,yy,yz,zz)[6],
+                kp[3], kd[3], armature[3], effort[3], axis[3] (revolute), rest rotation xyzw[4], limit lo/hi [2], pad[2] ;
                 then contact points NCP x 4 (pos[3], radius)
         """
         NB, MB = self.num_bodies, self.MAX_BODIES
@@ -288,8 +341,9 @@ class ArticulationModel:
             tab[8, i] = idx[0] if len(idx) else 0
             tab[9, i] = len(idx)
         tab[10, :NB] = np.argsort(self.level, kind="stable")  # bodies sorted by tree level (level-major stepper mapping)
-        BF = 28
+        BF = self.BODY_FLOATS
         fl = np.zeros((MB, BF), dtype=np.float64)
+        fl[:, 31] = 1.0  # identity rest rotation (xyzw)
         for i in range(NB):
             fl[i, 0:3] = self.local_translation[i]
             fl[i, 3] = self.mass[i]
@@ -304,11 +358,15 @@ class ArticulationModel:
                 fl[i, 22:22 + c] = self.dof_effort[s:s + c]
                 if self.joint_type[i] == JOINT_REVOLUTE:
                     fl[i, 25:28] = self.dof_axis[s]
+                    lo, hi = self.dof_limits()
+                    fl[i, 32], fl[i, 33] = lo[s], hi[s]
+            w, x, y, z = self.local_rotation[i]
+            fl[i, 28:32] = [x, y, z, w]
         cp = np.concatenate([self.contact_pos, self.contact_radius[:, None]], axis=1) if len(self.contact_body) else np.zeros((0, 4))
         floats = np.concatenate([fl.reshape(-1), cp.reshape(-1)]).astype(np.float32)
         return ints, floats
 
-    BODY_FLOATS = 28
+    BODY_FLOATS = 36
 
     # ---- action scaling (A1) ---------------------------------------------------------------
     def dof_limits(self):
