@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PHC_ABI_VERSION 2
+#define PHC_ABI_VERSION 3
 #define PHC_MAX_BODIES 32
 #define PHC_EINVAL (-1)
 #define PHC_EUNSUPPORTED (-2)
@@ -45,9 +45,12 @@ typedef struct {
 } phc_model_t;
 
 /* Flat reference-motion buffer.  Replaces MotionLibBase's gts/grs/lrs/gvs/gavs/dvs tensors
- * (phc/utils/motion_lib_base.py:300-318).  One record per frame, fields contiguous:
- *   [pos NB*3 | rot NB*4 | vel NB*3 | angvel NB*3 | local_rot NB*4 | dof_vel (NB-1)*3 | pad]
- * so that one lookup touches one contiguous run instead of six separate tensors. */
+ * (phc/utils/motion_lib_base.py:300-318; H1/G1: motion_lib_real.py:196-215).  One record per frame, fields contiguous:
+ *   [pos (NB+E)*3 | rot (NB+E)*4 | vel NB*3 | angvel NB*3 | joints | dof_vel | pad]
+ *   joints / dof_vel = local_rot NB*4 / (NB-1)*3 for spherical models (dofs_per_joint 3: dof_pos is the exp-map of the
+ *   slerped local rotation), dof_pos ND / ND for revolute models (dofs_per_joint 1: linear blend, motion_lib_real.py:285-291);
+ *   E = num_ext_bodies reference-only bodies (H1 hands / head) appended to the position and rotation blocks.
+ * One lookup touches one contiguous run instead of six (ten) separate tensors. */
 typedef struct {
     const float* frames;              /* [F, frame_stride] */
     int64_t num_frames_total;         /* F */
@@ -58,6 +61,8 @@ typedef struct {
     const float* motion_dt;           /* [M] */
     const int64_t* motion_num_frames; /* [M] */
     const int64_t* length_starts;     /* [M] first frame of each clip */
+    int32_t num_ext_bodies;           /* E (0 for SMPL) */
+    int32_t dofs_per_joint;           /* 3 spherical (0 is read as 3), 1 revolute */
 } phc_motion_lib_t;
 
 /* Simulator-owned state tensors (S1-S5, S8). */
@@ -123,6 +128,11 @@ typedef struct {
     int32_t zero_out_far;             /* env.zero_out_far: point-goal reward + task-obs gating when far from the reference (:783-797,890-905) */
     float close_distance;             /* humanoid.py:328 (0.25) */
     float far_distance;               /* humanoid.py:329 (3) */
+    /* config 5 (H1 / G1 robots) */
+    int32_t dofs_per_joint;           /* 3 spherical (0 is read as 3), 1 revolute: DoF layout of dof_state / AMP obs (humanoid_amp.py:1063-1104) */
+    int32_t num_ext_bodies;           /* robot.extend_config entries used by the full-body reward (humanoid_im.py:74-82,916-923) */
+    const int32_t* ext_parent;        /* [E] body id of each extended body's parent */
+    const float* ext_offset;          /* [E,3] position in the parent frame */
 } phc_im_params_t;
 
 /* Task-owned per-env buffers (phc/env/tasks/base_task.py:99-105, humanoid_amp.py:109-116,
@@ -152,13 +162,14 @@ typedef struct {
 
 int32_t phc_abi_version(void);
 
-/* M9: MotionLibBase.get_motion_state (phc/utils/motion_lib_base.py:437-520) incl. M8
- * _calc_frame_blend (:549-559).  Outputs nullable.  n lookups; offset nullable [n,3]. */
+/* M9: MotionLibBase.get_motion_state (phc/utils/motion_lib_base.py:437-520; robots: MotionLibReal.get_motion_state,
+ * motion_lib_real.py:236-361) incl. M8 _calc_frame_blend (:549-559).  Outputs nullable.  n lookups; offset nullable [n,3].
+ * dof_pos / dof_vel are [n,ND]; rg_pos_ext / rb_rot_ext [n,E,3/4] are the extended bodies' part of rg_pos_t / rg_rot_t. */
 int32_t phc_motion_state(const phc_motion_lib_t* lib, int32_t n, const int64_t* motion_ids, const float* motion_times,
                          const float* offset, float* rg_pos /*[n,NB,3]*/, float* rb_rot /*[n,NB,4]*/,
-                         float* body_vel /*[n,NB,3]*/, float* body_ang_vel /*[n,NB,3]*/, float* dof_pos /*[n,(NB-1)*3]*/,
-                         float* dof_vel /*[n,(NB-1)*3]*/, int64_t* frame_idx0 /*[n]*/, int64_t* frame_idx1 /*[n]*/,
-                         float* blend /*[n]*/, void* stream);
+                         float* body_vel /*[n,NB,3]*/, float* body_ang_vel /*[n,NB,3]*/, float* dof_pos /*[n,ND]*/,
+                         float* dof_vel /*[n,ND]*/, int64_t* frame_idx0 /*[n]*/, int64_t* frame_idx1 /*[n]*/,
+                         float* blend /*[n]*/, float* rg_pos_ext /*[n,E,3]*/, float* rb_rot_ext /*[n,E,4]*/, void* stream);
 
 /* M7: MotionLibBase.sample_time_interval (motion_lib_base.py:414-423); `phase` is the
  * caller's torch.rand draw so the reference RNG stream is preserved. */

@@ -64,13 +64,20 @@ int emu_max_threads(void) { return omp_get_max_threads(); }
 
 int emu_motion_state(const phc_motion_lib_t* lib, int n, const int64_t* ids, const float* times, const float* offset,
                      float* rg_pos, float* rb_rot, float* body_vel, float* body_ang_vel, float* dof_pos, float* dof_vel,
-                     int64_t* idx0, int64_t* idx1, float* blend) {
-    const int nb = lib->num_bodies;
+                     int64_t* idx0, int64_t* idx1, float* blend, float* rg_pos_ext, float* rb_rot_ext) {
+    const int nb = lib->num_bodies, ne = lib->num_ext_bodies;
     for (int64_t i = 0; i < n; ++i) {
         FrameRef fr = frame_ref(*lib, ids[i], times[i]);
         if (idx0) idx0[i] = fr.idx0;
         if (idx1) idx1[i] = fr.idx1;
         if (blend) blend[i] = fr.blend;
+        for (int e = 0; e < ne; ++e) {
+            V3 p; Q4 q;
+            ref_body_ext(*lib, fr, e, &p, &q);
+            if (offset) p += ld3(offset + i * 3);
+            if (rg_pos_ext) st3(rg_pos_ext + (i * ne + e) * 3, p);
+            if (rb_rot_ext) st4(rb_rot_ext + (i * ne + e) * 4, q);
+        }
         for (int j = 0; j < nb; ++j) {
             BodyState s = ref_body(*lib, fr, j);
             if (offset) s.pos += ld3(offset + i * 3);
@@ -81,8 +88,9 @@ int emu_motion_state(const phc_motion_lib_t* lib, int n, const int64_t* ids, con
             if (j >= 1 && (dof_pos || dof_vel)) {
                 V3 dp, dv;
                 ref_joint(*lib, fr, j, &dp, &dv);
-                if (dof_pos) st3(dof_pos + i * (nb - 1) * 3 + (j - 1) * 3, dp);
-                if (dof_vel) st3(dof_vel + i * (nb - 1) * 3 + (j - 1) * 3, dv);
+                const int dpj = lib->dofs_per_joint == 1 ? 1 : 3;
+                if (dof_pos) st_joint(dof_pos + (i * (nb - 1) + (j - 1)) * dpj, dpj, dp);
+                if (dof_vel) st_joint(dof_vel + (i * (nb - 1) + (j - 1)) * dpj, dpj, dv);
             }
         }
     }

@@ -36,7 +36,7 @@ def emu():
         lib = C.CDLL(build())
         vp, i32 = C.c_void_p, C.c_int32
         PS = C.POINTER
-        lib.emu_motion_state.argtypes = [PS(L.MotionLib), i32] + [vp] * 12
+        lib.emu_motion_state.argtypes = [PS(L.MotionLib), i32] + [vp] * 14
         lib.emu_sample_time_interval.argtypes = [PS(L.MotionLib), i32, vp, vp, vp]
         lib.emu_im_post_physics.argtypes = [PS(L.Model), PS(L.MotionLib), PS(L.ImParams), PS(L.SimState), PS(L.ImBuffers)]
         lib.emu_im_reset.argtypes = [PS(L.Model), PS(L.MotionLib), PS(L.ImParams), PS(L.SimState), PS(L.ImBuffers), i32, vp, vp, i32]

@@ -41,7 +41,10 @@ class _EasyDict(dict):
     def __setitem__(self, k, v):
         if isinstance(v, dict) and not isinstance(v, _EasyDict):
             v = _EasyDict(v)
+        elif isinstance(v, (list, tuple)):  # easydict converts dicts inside sequences too
+            v = type(v)(_EasyDict(x) if isinstance(x, dict) and not isinstance(x, _EasyDict) else x for x in v)
         super().__setitem__(k, v)
+        self.__dict__[k] = v   # the real EasyDict mirrors items as attributes; motion_lib_real.py:211,217 tests `in m.__dict__`
 
     __setattr__ = __setitem__
 
@@ -110,11 +113,48 @@ def install():
     te = importlib.import_module("smpl_sim.utils.torch_ext")
     te.to_torch = to_torch
 
+    # smpl_sim.poselib is the same poselib the reference vendors at /root/reference/poselib (torch_humanoid_batch.py:18)
+    try:
+        pr = importlib.import_module("poselib.poselib.core.rotation3d")
+        sys.modules["smpl_sim.poselib.core.rotation3d"] = pr
+        importlib.import_module("smpl_sim.poselib.core").rotation3d = pr
+    except Exception:
+        pass
+    _install_lxml_stand_in()
+
     # numpy-2 removed aliases that the reference still uses at import/run time
     for name, val in (("Inf", np.inf), ("int", int), ("float", float), ("bool", bool)):
         if not hasattr(np, name):
             setattr(np, name, val)
     _installed = True
+
+
+def _install_lxml_stand_in():
+    """`lxml` is not installed here; Humanoid_Batch (torch_humanoid_batch.py:19,39-45) only needs parse / find / findall /
+    getchildren, which a PRIVATE pure-python copy of xml.etree.ElementTree provides (its Element is a Python class, so the
+    lxml-only `getchildren()` can be added without touching the interpreter's own ElementTree)."""
+    import importlib.util
+    saved = sys.modules.get("_elementtree", "absent")
+    sys.modules["_elementtree"] = None
+    try:
+        spec = importlib.util.find_spec("xml.etree.ElementTree")
+        pyet = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(pyet)
+    finally:
+        if saved == "absent":
+            del sys.modules["_elementtree"]
+        else:
+            sys.modules["_elementtree"] = saved
+    pyet.Element.getchildren = lambda self: list(self)
+    m = types.ModuleType("lxml.etree")
+    m.XMLParser = lambda **kw: pyet.XMLParser()
+    m.parse = lambda f, parser=None: pyet.parse(f)
+    m.ElementTree, m.Element, m.SubElement = pyet.ElementTree, pyet.Element, pyet.SubElement
+    pkg = types.ModuleType("lxml")
+    pkg.__path__ = []
+    pkg.etree = m
+    sys.modules["lxml"] = pkg
+    sys.modules["lxml.etree"] = m
 
 
 def ref_module(name):

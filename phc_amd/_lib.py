@@ -28,7 +28,7 @@ class Model(C.Structure):
 class MotionLib(C.Structure):
     _fields_ = [("frames", c_p), ("num_frames_total", c_i64), ("frame_stride", c_i32), ("num_bodies", c_i32),
                 ("num_motions", c_i32), ("motion_lengths", c_p), ("motion_dt", c_p), ("motion_num_frames", c_p),
-                ("length_starts", c_p)]
+                ("length_starts", c_p), ("num_ext_bodies", c_i32), ("dofs_per_joint", c_i32)]
 
 
 class SimState(C.Structure):
@@ -56,7 +56,8 @@ class ImParams(C.Structure):
                 ("num_amp_joints", c_i32), ("amp_joint_slot", c_p),
                 ("num_amp_obs_steps", c_i32), ("num_amp_obs_per_step", c_i32),
                 ("num_self_obs", c_i32), ("num_task_obs", c_i32),
-                ("cycle_motion", c_i32), ("zero_out_far", c_i32), ("close_distance", c_f), ("far_distance", c_f)]
+                ("cycle_motion", c_i32), ("zero_out_far", c_i32), ("close_distance", c_f), ("far_distance", c_f),
+                ("dofs_per_joint", c_i32), ("num_ext_bodies", c_i32), ("ext_parent", c_p), ("ext_offset", c_p)]
 
 
 class ImBuffers(C.Structure):
@@ -70,7 +71,7 @@ class ImBuffers(C.Structure):
 P = C.POINTER
 _SIGNATURES = {
     "phc_abi_version": ([], c_i32),
-    "phc_motion_state": ([P(MotionLib), c_i32, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p], c_i32),
+    "phc_motion_state": ([P(MotionLib), c_i32] + [c_p] * 15, c_i32),
     "phc_sample_time_interval": ([P(MotionLib), c_i32, c_p, c_p, c_p, c_p], c_i32),
     "phc_sim_step": ([P(Model), P(SimParams), P(SimState), c_p, c_p, c_p, c_p, c_i32, c_p], c_i32),
     "phc_refresh_body_state": ([P(Model), P(SimState), c_p], c_i32),
@@ -100,7 +101,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the .so does not export the symbol
         fn.argtypes = argtypes
         fn.restype = restype
-    if lib.phc_abi_version() != 2:
+    if lib.phc_abi_version() != 3:
         raise ImportError("libphc_amd.so ABI version mismatch")
     _lib = lib
     return lib

@@ -28,8 +28,10 @@ def model_struct(ints, floats, num_bodies, num_dof, max_level, num_contact_pts):
     return m
 
 
-def motion_lib_struct(frames, frame_stride, num_bodies, motion_lengths, motion_dt, motion_num_frames, length_starts):
+def motion_lib_struct(frames, frame_stride, num_bodies, motion_lengths, motion_dt, motion_num_frames, length_starts,
+                      num_ext_bodies=0, dofs_per_joint=3):
     s = L.MotionLib()
+    s.num_ext_bodies, s.dofs_per_joint = int(num_ext_bodies), int(dofs_per_joint)
     s.frames = ptr(frames)
     s.num_frames_total = int(frames.shape[0])
     s.frame_stride = int(frame_stride)
@@ -59,26 +61,37 @@ def sim_params_struct(sim_dt=1 / 60, substeps=2, control_freq_inv=2, gravity_z=-
     return p
 
 
-def frame_stride_for(num_bodies):
-    """Floats per frame record: pos 3 | rot 4 | vel 3 | angvel 3 | local_rot 4 per body + dof_vel 3 per joint,
-    padded to a multiple of 4 floats (16 B) so every record starts float4-aligned."""
-    n = num_bodies * 17 + (num_bodies - 1) * 3
+def frame_stride_for(num_bodies, num_ext_bodies=0, dofs_per_joint=3):
+    """Floats per frame record (layout in include/phc_amd.h): pos 3 | rot 4 per body incl. the extended ones, vel 3 | angvel 3
+    per simulated body, then local_rot 4 per body + dof_vel 3 per joint (spherical models) or dof_pos + dof_vel per DoF
+    (revolute models); padded to a multiple of 4 floats (16 B) so every record starts float4-aligned."""
+    nbe = num_bodies + num_ext_bodies
+    n = nbe * 7 + num_bodies * 6 + ((num_bodies - 1) * 2 if dofs_per_joint == 1 else num_bodies * 4 + (num_bodies - 1) * 3)
     return (n + 3) // 4 * 4
 
 
-def pack_frames(gts, grs, gvs, gavs, lrs, dvs, xp=np):
-    """[F,NB,3/4] field tensors -> [F, stride] records (layout of phc_motion_lib_t)."""
+def pack_frames(gts, grs, gvs, gavs, lrs, dvs, xp=np, gts_ext=None, grs_ext=None, dof_pos=None):
+    """[F,NB,3/4] field tensors -> [F, stride] records (layout of phc_motion_lib_t).  Spherical models pass `lrs` (local
+    rotations); revolute models pass `dof_pos` [F,ND] instead (and `dvs` [F,ND]); `gts_ext / grs_ext` [F,E,3/4] are the
+    extended reference bodies."""
     F_, nb = gts.shape[0], gts.shape[1]
-    stride = frame_stride_for(nb)
+    ne = 0 if gts_ext is None else gts_ext.shape[1]
+    dpj = 1 if dof_pos is not None else 3
+    stride = frame_stride_for(nb, ne, dpj)
     if xp is np:
         out = np.zeros((F_, stride), dtype=np.float32)
+        cat = lambda a, b: np.concatenate([a, b], axis=1)
     else:
         out = xp.zeros((F_, stride), dtype=xp.float32, device=gts.device)
+        cat = lambda a, b: xp.cat([a, b], dim=1)
+    pos = gts if ne == 0 else cat(gts, gts_ext)
+    rot = grs if ne == 0 else cat(grs, grs_ext)
     o = 0
-    for arr, w in ((gts, 3), (grs, 4), (gvs, 3), (gavs, 3), (lrs, 4)):
-        out[:, o:o + nb * w] = arr.reshape(F_, nb * w)
-        o += nb * w
-    out[:, o:o + (nb - 1) * 3] = dvs.reshape(F_, (nb - 1) * 3)
+    fields = [(pos, (nb + ne) * 3), (rot, (nb + ne) * 4), (gvs, nb * 3), (gavs, nb * 3)]
+    fields += [(dof_pos, nb - 1), (dvs, nb - 1)] if dpj == 1 else [(lrs, nb * 4), (dvs, (nb - 1) * 3)]
+    for arr, w in fields:
+        out[:, o:o + w] = arr.reshape(F_, w)
+        o += w
     return out
 
 
@@ -86,8 +99,12 @@ def im_params_struct(dt, max_episode_length, reward_specs, power_reward, power_c
                      use_mean_termination, disable_collision_check, local_root_obs, root_height_obs, num_track_bodies,
                      track_slot, reset_mask, num_reset_bodies, first_reset_body, termination_distances, num_key_bodies, key_body_ids,
                      num_amp_joints, amp_joint_slot, num_amp_obs_steps, num_amp_obs_per_step, num_self_obs, num_task_obs,
-                     cycle_motion=False, zero_out_far=False, close_distance=0.25, far_distance=3.0):
+                     cycle_motion=False, zero_out_far=False, close_distance=0.25, far_distance=3.0,
+                     dofs_per_joint=3, ext_parent=None, ext_offset=None):
     p = L.ImParams()
+    p.dofs_per_joint = int(dofs_per_joint)
+    p.num_ext_bodies = 0 if ext_parent is None else int(ext_parent.shape[0])
+    p.ext_parent, p.ext_offset = ptr(ext_parent), ptr(ext_offset)
     p.dt = float(np.float32(dt))
     p.max_episode_length = int(max_episode_length)
     for k in ("k_pos", "k_rot", "k_vel", "k_ang_vel", "w_pos", "w_rot", "w_vel", "w_ang_vel"):

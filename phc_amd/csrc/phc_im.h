@@ -37,8 +37,9 @@ PHC_HD void amp_obs_from_sim_lane(const phc_im_params_t& prm, const phc_sim_stat
     if (j >= 1 && j < nb) {
         int slot = prm.amp_joint_slot[j];
         if (slot >= 0) {
-            const float* d = sim.dof_state + (env * nd + dof_start_tab[j]) * 2;
-            amp_obs_joint(prm, slot, v3(d[0], d[2], d[4]), v3(d[1], d[3], d[5]), a);
+            V3 dp, dv;
+            ld_joint_state(sim, nd, env, dof_start_tab[j], prm.dofs_per_joint, &dp, &dv);
+            amp_obs_joint(prm, slot, dp, dv, a);
         }
     }
     if (j < prm.num_key_bodies) {
@@ -139,8 +140,26 @@ PHC_HD RewardPartial im_post_lane(const phc_model_t& model, const phc_motion_lib
     const int nb = model.num_bodies, nd = model.num_dof;
     RewardPartial rp;
     rp.pos = rp.rot = rp.vel = rp.angvel = rp.power = rp.dist = rp.root_dist = 0.f; rp.fallen = 0;
-    if (j >= nb) return rp;
     const int64_t mid = buf.sampled_motion_ids[env];
+    if (j >= nb) {
+        // R3: extended bodies of the full-body reward (humanoid_im.py:916-923) -- lane NB+e carries extended body e: current
+        // pose = parent pose composed with a fixed offset, reference from the extended record slots; only the position
+        // and rotation terms include them (body_vel / body_ang_vel stay NB wide).
+        const int e = j - nb;
+        if (e >= prm.num_ext_bodies) return rp;
+        const BodyState par = load_body(sim.rigid_body_state, env, nb, prm.ext_parent[e]);
+        BodyState cur;
+        cur.pos = quat_rotate(par.rot, ld3(prm.ext_offset + 3 * e)) + par.pos;
+        cur.rot = par.rot;
+        BodyState ref;
+        ref_body_ext(lib, frame_ref(lib, mid, c.cycled ? c.t_rew : c.t0), e, &ref.pos, &ref.rot);
+        ref.pos += c.cycled ? c.goff_rew : c.goff;
+        const V3 d = ref.pos - cur.pos;
+        rp.pos = (d.x * d.x + d.y * d.y + d.z * d.z) / 3.0f;
+        const float ang = quat_to_angle_axis(quat_mul(ref.rot, quat_conjugate(cur.rot)), nullptr);
+        rp.rot = ang * ang;
+        return rp;
+    }
     const FrameRef fr0 = frame_ref(lib, mid, c.t0), fr1 = frame_ref(lib, mid, c.t1);
     BodyState body = load_body(sim.rigid_body_state, env, nb, j);
     BodyState root = load_body(sim.rigid_body_state, env, nb, 0);
@@ -162,7 +181,8 @@ PHC_HD RewardPartial im_post_lane(const phc_model_t& model, const phc_motion_lib
         int ds = model.ints[4 + 3 * PHC_MAX_BODIES + j];
         const float* d = sim.dof_state + (env * nd + ds) * 2;
         const float* f = sim.dof_force + env * nd + ds;
-        rp.power = fabsf(f[0] * d[1]) + fabsf(f[1] * d[3]) + fabsf(f[2] * d[5]);
+        rp.power = fabsf(f[0] * d[1]);
+        if (prm.dofs_per_joint != 1) rp.power += fabsf(f[1] * d[3]) + fabsf(f[2] * d[5]);
     }
     // observations for the next policy step (humanoid_im.py:694-726)
     Q4 hinv = calc_heading_quat_inv(root.rot), h = calc_heading_quat(root.rot);
@@ -186,7 +206,7 @@ PHC_HD RewardPartial im_post_lane(const phc_model_t& model, const phc_motion_lib
     if (buf.ref_dof_pos && j >= 1) {
         V3 dp, dv;
         ref_joint(lib, fr1, j, &dp, &dv);
-        st3(buf.ref_dof_pos + env * nd + model.ints[4 + 3 * PHC_MAX_BODIES + j], dp);
+        st_joint(buf.ref_dof_pos + env * nd + model.ints[4 + 3 * PHC_MAX_BODIES + j], prm.dofs_per_joint, dp);
     }
     // AMP observation of this step -> slot 0 of the new history (humanoid_amp.py:204-209)
     float* amp = buf.amp_obs_out + env * (int64_t)(prm.num_amp_obs_steps * prm.num_amp_obs_per_step);
@@ -199,9 +219,9 @@ PHC_HD RewardPartial im_post_lane(const phc_model_t& model, const phc_motion_lib
 PHC_HD void im_post_finalize(const phc_motion_lib_t& lib, const phc_im_params_t& prm, const phc_im_buffers_t& buf, int nb,
                              int64_t env, const ImStepCtx& c, int64_t progress, float s_pos, float s_rot, float s_vel, float s_angvel,
                              float s_power, float s_dist, float root_dist, float prev_point_goal, int any_fallen, int n_reset_bodies) {
-    const float J = (float)nb;
-    float r_pos = expf(-prm.k_pos * (s_pos / J));
-    float r_rot = expf(-prm.k_rot * (s_rot / J));
+    const float J = (float)nb, JE = (float)(nb + prm.num_ext_bodies);  // position / rotation means include the extended bodies
+    float r_pos = expf(-prm.k_pos * (s_pos / JE));
+    float r_rot = expf(-prm.k_rot * (s_rot / JE));
     float r_vel = expf(-prm.k_vel * (s_vel / J));
     float r_ang = expf(-prm.k_ang_vel * (s_angvel / J));
     float rew = prm.w_pos * r_pos + prm.w_rot * r_rot + prm.w_vel * r_vel + prm.w_ang_vel * r_ang;
@@ -273,9 +293,10 @@ PHC_HD void im_reset_lane(const phc_model_t& model, const phc_motion_lib_t& lib,
             ref_joint(lib, fr, j, &dp, &dv);
             const int ds = model.ints[4 + 3 * PHC_MAX_BODIES + j];
             float* d = sim.dof_state + (env * nd + ds) * 2;
-            d[0] = dp.x; d[1] = dv.x; d[2] = dp.y; d[3] = dv.y; d[4] = dp.z; d[5] = dv.z;
-            st3(sim.pd_target + env * nd + ds, dp);  // set_dof_position_target_tensor_indexed(dof_pos) humanoid.py:605
-            if (sim.dof_force) st3(sim.dof_force + env * nd + ds, v3(0.f, 0.f, 0.f));
+            d[0] = dp.x; d[1] = dv.x;
+            if (prm.dofs_per_joint != 1) { d[2] = dp.y; d[3] = dv.y; d[4] = dp.z; d[5] = dv.z; }
+            st_joint(sim.pd_target + env * nd + ds, prm.dofs_per_joint, dp);  // set_dof_position_target_tensor_indexed(dof_pos) humanoid.py:605
+            if (sim.dof_force) st_joint(sim.dof_force + env * nd + ds, prm.dofs_per_joint, v3(0.f, 0.f, 0.f));
         }
         // observations of the reset envs (humanoid.py:595 -> humanoid_im.py:694-726), progress_buf == 0
         const float t1 = motion_time(1, prm.dt, t, 0.f);
@@ -299,7 +320,7 @@ PHC_HD void im_reset_lane(const phc_model_t& model, const phc_motion_lib_t& lib,
         if (buf.ref_dof_pos && j >= 1) {
             V3 dp, dv;
             ref_joint(lib, fr1, j, &dp, &dv);
-            st3(buf.ref_dof_pos + env * nd + model.ints[4 + 3 * PHC_MAX_BODIES + j], dp);
+            st_joint(buf.ref_dof_pos + env * nd + model.ints[4 + 3 * PHC_MAX_BODIES + j], prm.dofs_per_joint, dp);
         }
     }
     if (j == 0) {
@@ -329,8 +350,9 @@ PHC_HD void im_reset_from_state_lane(const phc_model_t& model, const phc_motion_
         if (sim.contact_force) st3(sim.contact_force + (env * nb + j) * 3, v3(0.f, 0.f, 0.f));
         if (j >= 1) {
             const int ds = model.ints[4 + 3 * PHC_MAX_BODIES + j];
-            const float* d = sim.dof_state + (env * nd + ds) * 2;
-            st3(sim.pd_target + env * nd + ds, v3(d[0], d[2], d[4]));  // humanoid.py:605
+            V3 dp, dv;
+            ld_joint_state(sim, nd, env, ds, prm.dofs_per_joint, &dp, &dv);
+            st_joint(sim.pd_target + env * nd + ds, prm.dofs_per_joint, dp);  // humanoid.py:605
         }
         const V3 goff = ld3(buf.global_offset + env * 3);
         const float t1 = motion_time(1, prm.dt, buf.motion_start_times[env], buf.motion_start_times_offset[env]);
@@ -357,7 +379,7 @@ PHC_HD void im_reset_from_state_lane(const phc_model_t& model, const phc_motion_
         if (buf.ref_dof_pos && j >= 1) {
             V3 dp, dv;
             ref_joint(lib, fr1, j, &dp, &dv);
-            st3(buf.ref_dof_pos + env * nd + model.ints[4 + 3 * PHC_MAX_BODIES + j], dp);
+            st_joint(buf.ref_dof_pos + env * nd + model.ints[4 + 3 * PHC_MAX_BODIES + j], prm.dofs_per_joint, dp);
         }
         // _compute_amp_observations(env_ids) -> slot 0; _init_amp_obs_default copies it into every history slot
         float* amp = buf.amp_obs_out + env * (int64_t)(S * A);

@@ -93,7 +93,8 @@ __global__ __launch_bounds__(256) void k_amp_obs_demo(phc_model_t model, phc_mot
 __global__ __launch_bounds__(256) void k_motion_state(phc_motion_lib_t lib, int n, const int64_t* __restrict__ ids,
                                                      const float* __restrict__ times, const float* __restrict__ offset,
                                                      float* rg_pos, float* rb_rot, float* body_vel, float* body_ang_vel,
-                                                     float* dof_pos, float* dof_vel, int64_t* idx0, int64_t* idx1, float* blend) {
+                                                     float* dof_pos, float* dof_vel, int64_t* idx0, int64_t* idx1, float* blend,
+                                                     float* rg_pos_ext, float* rb_rot_ext) {
     const int lane = threadIdx.x & (GRP - 1);
     const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
     if (i >= n) return;
@@ -104,7 +105,17 @@ __global__ __launch_bounds__(256) void k_motion_state(phc_motion_lib_t lib, int 
         if (idx1) idx1[i] = fr.idx1;
         if (blend) blend[i] = fr.blend;
     }
-    if (lane >= nb) return;
+    if (lane >= nb) {
+        const int e = lane - nb, ne = lib.num_ext_bodies;
+        if (e < ne && (rg_pos_ext || rb_rot_ext)) {
+            V3 p; Q4 q;
+            ref_body_ext(lib, fr, e, &p, &q);
+            if (offset) p += ld3(offset + i * 3);
+            if (rg_pos_ext) st3(rg_pos_ext + (i * ne + e) * 3, p);
+            if (rb_rot_ext) st4(rb_rot_ext + (i * ne + e) * 4, q);
+        }
+        return;
+    }
     BodyState s = ref_body(lib, fr, lane);
     if (offset) s.pos += ld3(offset + i * 3);
     if (rg_pos) st3(rg_pos + (i * nb + lane) * 3, s.pos);
@@ -114,8 +125,9 @@ __global__ __launch_bounds__(256) void k_motion_state(phc_motion_lib_t lib, int 
     if (lane >= 1 && (dof_pos || dof_vel)) {
         V3 dp, dv;
         ref_joint(lib, fr, lane, &dp, &dv);
-        if (dof_pos) st3(dof_pos + i * (nb - 1) * 3 + (lane - 1) * 3, dp);
-        if (dof_vel) st3(dof_vel + i * (nb - 1) * 3 + (lane - 1) * 3, dv);
+        const int dpj = lib.dofs_per_joint == 1 ? 1 : 3;
+        if (dof_pos) st_joint(dof_pos + (i * (nb - 1) + (lane - 1)) * dpj, dpj, dp);
+        if (dof_vel) st_joint(dof_vel + (i * (nb - 1) + (lane - 1)) * dpj, dpj, dv);
     }
 }
 
@@ -186,11 +198,12 @@ int32_t phc_abi_version(void) { return PHC_ABI_VERSION; }
 
 int32_t phc_motion_state(const phc_motion_lib_t* lib, int32_t n, const int64_t* motion_ids, const float* motion_times,
                          const float* offset, float* rg_pos, float* rb_rot, float* body_vel, float* body_ang_vel,
-                         float* dof_pos, float* dof_vel, int64_t* frame_idx0, int64_t* frame_idx1, float* blend, void* stream) {
-    if (!lib || n < 0 || lib->num_bodies > PHC_MAX_BODIES) return PHC_EINVAL;
+                         float* dof_pos, float* dof_vel, int64_t* frame_idx0, int64_t* frame_idx1, float* blend, float* rg_pos_ext,
+                         float* rb_rot_ext, void* stream) {
+    if (!lib || n < 0 || lib->num_bodies + lib->num_ext_bodies > PHC_MAX_BODIES) return PHC_EINVAL;
     if (n == 0) return 0;
     hipLaunchKernelGGL(k_motion_state, dim3(env_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, *lib, n, motion_ids,
-                       motion_times, offset, rg_pos, rb_rot, body_vel, body_ang_vel, dof_pos, dof_vel, frame_idx0, frame_idx1, blend);
+                       motion_times, offset, rg_pos, rb_rot, body_vel, body_ang_vel, dof_pos, dof_vel, frame_idx0, frame_idx1, blend, rg_pos_ext, rb_rot_ext);
     return launch_status();
 }
 
@@ -212,6 +225,10 @@ static int32_t check_im(const phc_model_t* model, const phc_motion_lib_t* lib, c
     int32_t rc = check_model(model);
     if (rc) return rc;
     if (!lib || !prm || lib->num_bodies != model->num_bodies) return PHC_EINVAL;
+    const int dpj = model->num_dof == model->num_bodies - 1 && model->num_bodies > 2 ? 1 : 3;
+    if ((lib->dofs_per_joint == 1 ? 1 : 3) != dpj || (prm->dofs_per_joint == 1 ? 1 : 3) != dpj) return PHC_EINVAL;
+    if (prm->num_ext_bodies < 0 || prm->num_ext_bodies != lib->num_ext_bodies || model->num_bodies + prm->num_ext_bodies > GRP) return PHC_EINVAL;
+    if (prm->num_ext_bodies > 0 && (!prm->ext_parent || !prm->ext_offset)) return PHC_EINVAL;
     if (!prm->track_slot || !prm->reset_mask || !prm->termination_distances || !prm->key_body_ids || !prm->amp_joint_slot) return PHC_EINVAL;
     if (prm->num_key_bodies > GRP) return PHC_EUNSUPPORTED;
     return 0;

@@ -18,12 +18,19 @@
 namespace phc {
 
 // ---- frame record field offsets (see phc_motion_lib_t) ----
-PHC_HD int fr_pos(int nb) { (void)nb; return 0; }
-PHC_HD int fr_rot(int nb) { return nb * 3; }
-PHC_HD int fr_vel(int nb) { return nb * 7; }
-PHC_HD int fr_angvel(int nb) { return nb * 10; }
-PHC_HD int fr_lrot(int nb) { return nb * 13; }
-PHC_HD int fr_dvel(int nb) { return nb * 17; }
+//   pos (NB+E)*3 | rot (NB+E)*4 | vel NB*3 | angvel NB*3 | joints | dof_vel
+//   joints: local_rot NB*4 (spherical models: dof_pos = exp-map of the slerped local rotation, motion_lib_base.py:483-484)
+//           or dof_pos ND (revolute models: linear blend of the stored angles, motion_lib_real.py:285-291)
+// E = extended reference-only bodies (H1 hands / head, motion_lib_real.py:211-215), appended after the NB simulated ones.
+PHC_HD int fr_nbe(const phc_motion_lib_t& l) { return l.num_bodies + l.num_ext_bodies; }
+PHC_HD int fr_pos(const phc_motion_lib_t& l) { (void)l; return 0; }
+PHC_HD int fr_rot(const phc_motion_lib_t& l) { return fr_nbe(l) * 3; }
+PHC_HD int fr_vel(const phc_motion_lib_t& l) { return fr_nbe(l) * 7; }
+PHC_HD int fr_angvel(const phc_motion_lib_t& l) { return fr_nbe(l) * 7 + l.num_bodies * 3; }
+PHC_HD int fr_lrot(const phc_motion_lib_t& l) { return fr_nbe(l) * 7 + l.num_bodies * 6; }
+PHC_HD int fr_dvel(const phc_motion_lib_t& l) {
+    return fr_lrot(l) + (l.dofs_per_joint == 1 ? (l.num_bodies - 1) : l.num_bodies * 4);
+}
 
 struct FrameRef { int64_t f0, f1; float blend; int64_t idx0, idx1; };
 
@@ -91,31 +98,53 @@ struct BodyState { V3 pos; Q4 rot; V3 vel; V3 angvel; };
 
 // M9 get_motion_state, the part of it that belongs to body j (motion_lib_base.py:450-488)
 PHC_HD BodyState ref_body(const phc_motion_lib_t& lib, const FrameRef& fr, int j) {
-    const int nb = lib.num_bodies;
     const float* a = lib.frames + fr.f0 * (int64_t)lib.frame_stride;
     const float* b = lib.frames + fr.f1 * (int64_t)lib.frame_stride;
     BodyState s;
-    s.pos = lerp3(ld3(a + fr_pos(nb) + 3 * j), ld3(b + fr_pos(nb) + 3 * j), fr.blend);
-    s.vel = lerp3(ld3(a + fr_vel(nb) + 3 * j), ld3(b + fr_vel(nb) + 3 * j), fr.blend);
-    s.angvel = lerp3(ld3(a + fr_angvel(nb) + 3 * j), ld3(b + fr_angvel(nb) + 3 * j), fr.blend);
-    s.rot = slerp(ld4(a + fr_rot(nb) + 4 * j), ld4(b + fr_rot(nb) + 4 * j), fr.blend);
+    s.pos = lerp3(ld3(a + fr_pos(lib) + 3 * j), ld3(b + fr_pos(lib) + 3 * j), fr.blend);
+    s.vel = lerp3(ld3(a + fr_vel(lib) + 3 * j), ld3(b + fr_vel(lib) + 3 * j), fr.blend);
+    s.angvel = lerp3(ld3(a + fr_angvel(lib) + 3 * j), ld3(b + fr_angvel(lib) + 3 * j), fr.blend);
+    s.rot = slerp(ld4(a + fr_rot(lib) + 4 * j), ld4(b + fr_rot(lib) + 4 * j), fr.blend);
     return s;
+}
+// extended reference body e (record slot NB+e): position and rotation only (rg_pos_t / rg_rot_t, motion_lib_real.py:300-312)
+PHC_HD void ref_body_ext(const phc_motion_lib_t& lib, const FrameRef& fr, int e, V3* pos, Q4* rot) {
+    const int j = lib.num_bodies + e;
+    const float* a = lib.frames + fr.f0 * (int64_t)lib.frame_stride;
+    const float* b = lib.frames + fr.f1 * (int64_t)lib.frame_stride;
+    *pos = lerp3(ld3(a + fr_pos(lib) + 3 * j), ld3(b + fr_pos(lib) + 3 * j), fr.blend);
+    *rot = slerp(ld4(a + fr_rot(lib) + 4 * j), ld4(b + fr_rot(lib) + 4 * j), fr.blend);
 }
 // get_root_pos_smpl (motion_lib_base.py:522-547): position-only lookup of the root
 PHC_HD V3 ref_root_pos_lerp(const phc_motion_lib_t& lib, const FrameRef& fr) {
-    const int nb = lib.num_bodies;
     const float* a = lib.frames + fr.f0 * (int64_t)lib.frame_stride;
     const float* b = lib.frames + fr.f1 * (int64_t)lib.frame_stride;
-    return lerp3(ld3(a + fr_pos(nb)), ld3(b + fr_pos(nb)), fr.blend);
+    return lerp3(ld3(a + fr_pos(lib)), ld3(b + fr_pos(lib)), fr.blend);
 }
-// dof_pos = quat_to_exp_map(slerp(local_rot)) (motion_lib_base.py:483-484,564-567), dof_vel lerp; joint of body j>=1
+// joint of body j >= 1.  Spherical: dof_pos = quat_to_exp_map(slerp(local_rot)) (motion_lib_base.py:483-484,564-567), dof_vel
+// lerp.  Revolute (dofs_per_joint 1): both are linear blends of the stored scalars (motion_lib_real.py:285-291), carried in .x.
 PHC_HD void ref_joint(const phc_motion_lib_t& lib, const FrameRef& fr, int j, V3* dof_pos, V3* dof_vel) {
-    const int nb = lib.num_bodies;
     const float* a = lib.frames + fr.f0 * (int64_t)lib.frame_stride;
     const float* b = lib.frames + fr.f1 * (int64_t)lib.frame_stride;
-    Q4 lr = slerp(ld4(a + fr_lrot(nb) + 4 * j), ld4(b + fr_lrot(nb) + 4 * j), fr.blend);
+    if (lib.dofs_per_joint == 1) {
+        const float s = 1.0f - fr.blend;
+        *dof_pos = v3(s * a[fr_lrot(lib) + j - 1] + fr.blend * b[fr_lrot(lib) + j - 1], 0.f, 0.f);
+        *dof_vel = v3(s * a[fr_dvel(lib) + j - 1] + fr.blend * b[fr_dvel(lib) + j - 1], 0.f, 0.f);
+        return;
+    }
+    Q4 lr = slerp(ld4(a + fr_lrot(lib) + 4 * j), ld4(b + fr_lrot(lib) + 4 * j), fr.blend);
     *dof_pos = quat_to_exp_map(lr);
-    *dof_vel = lerp3(ld3(a + fr_dvel(nb) + 3 * (j - 1)), ld3(b + fr_dvel(nb) + 3 * (j - 1)), fr.blend);
+    *dof_vel = lerp3(ld3(a + fr_dvel(lib) + 3 * (j - 1)), ld3(b + fr_dvel(lib) + 3 * (j - 1)), fr.blend);
+}
+// joint coordinates in the simulator tensors: 3 (exp-map) or 1 (angle) consecutive DoFs starting at ds
+PHC_HD void ld_joint_state(const phc_sim_state_t& sim, int nd, int64_t env, int ds, int dpj, V3* pos, V3* vel) {
+    const float* d = sim.dof_state + (env * nd + ds) * 2;
+    if (dpj == 1) { *pos = v3(d[0], 0.f, 0.f); *vel = v3(d[1], 0.f, 0.f); }
+    else { *pos = v3(d[0], d[2], d[4]); *vel = v3(d[1], d[3], d[5]); }
+}
+PHC_HD void st_joint(float* p, int dpj, V3 v) {
+    p[0] = v.x;
+    if (dpj != 1) { p[1] = v.y; p[2] = v.z; }
 }
 
 PHC_HD BodyState load_body(const float* rigid_body_state, int64_t env, int nb, int j) {
@@ -174,13 +203,18 @@ PHC_HD void amp_obs_root(const phc_im_params_t& prm, V3 root_pos, Q4 root_rot, V
 }
 PHC_HD void amp_obs_joint(const phc_im_params_t& prm, int slot, V3 dof_pos, V3 dof_vel, float* a) {
     const int off = (prm.root_height_obs ? 1 : 0) + 12;
+    if (prm.dofs_per_joint == 1) {  // build_amp_observations_robot (humanoid_amp.py:1063-1104): dof_obs = dof_pos
+        a[off + slot] = dof_pos.x;
+        a[off + prm.num_amp_joints + slot] = dof_vel.x;
+        return;
+    }
     float tn[6];
     quat_to_tan_norm(exp_map_to_quat(dof_pos), tn);  // dof_to_obs_smpl humanoid.py:1756-1765
     for (int k = 0; k < 6; ++k) a[off + slot * 6 + k] = tn[k];
     st3(a + off + prm.num_amp_joints * 6 + slot * 3, dof_vel);
 }
 PHC_HD void amp_obs_key(const phc_im_params_t& prm, int k, V3 key_pos, V3 root_pos, Q4 hinv, float* a) {
-    const int off = (prm.root_height_obs ? 1 : 0) + 12 + prm.num_amp_joints * 9;
+    const int off = (prm.root_height_obs ? 1 : 0) + 12 + prm.num_amp_joints * (prm.dofs_per_joint == 1 ? 2 : 9);
     st3(a + off + k * 3, quat_rotate(hinv, key_pos - root_pos));
 }
 

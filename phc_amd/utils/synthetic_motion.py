@@ -91,3 +91,46 @@ def make_motion_dict(parents, num_clips, seed=0, min_frames=30, max_frames=1800,
             T = int(np.clip(rng.lognormal(np.log(mean_seconds), 0.5) * fps, min_frames, max_frames))
         out[f"synthetic_{i:05d}"] = make_clip(rng, parents, T, body_names=body_names, fps=fps)
     return out
+
+
+def make_robot_clip(rng, model, num_frames, num_extend=3, fps=30, root_height=1.0):
+    """One smooth random clip in the schema of the reference's retargeted robot pkls (read by
+    ``phc/utils/motion_lib_real.py:381-389``): ``pose_aa [T, NB+E, 3]`` = root axis-angle, then one axis*angle row per
+    revolute joint, then zero rows for the extended bodies; ``root_trans_offset [T,3]``; ``dof [T,ND]``; ``fps``."""
+    T, nd = int(num_frames), model.num_dof
+    lo, hi = model.dof_limits()
+    mid, half = 0.5 * (lo + hi), 0.5 * (hi - lo)
+    walk = gaussian_filter1d(np.cumsum(rng.normal(0.0, 0.05, size=(T, nd)), axis=0), 3, axis=0, mode="nearest")
+    dof = mid + np.clip(walk, -1.0, 1.0) * np.minimum(half, 0.8) * 0.6
+    pose_aa = np.zeros((T, model.num_bodies + num_extend, 3))
+    for i in range(1, model.num_bodies):
+        s = model.dof_start[i]
+        pose_aa[:, i] = model.dof_axis[s][None] * dof[:, s:s + 1]
+    yaw = rng.uniform(-np.pi, np.pi) + gaussian_filter1d(np.cumsum(rng.normal(0, 0.03, size=T)), 3, mode="nearest")
+    tilt = gaussian_filter1d(np.cumsum(rng.normal(0, 0.01, size=(T, 2)), axis=0), 3, axis=0, mode="nearest")
+    e = np.concatenate([np.clip(tilt, -0.15, 0.15), np.zeros((T, 1))], axis=-1)
+    yaw_q = np.stack([np.zeros(T), np.zeros(T), np.sin(0.5 * yaw), np.cos(0.5 * yaw)], axis=-1)
+    q_root = _quat_mul(yaw_q, _exp_map_to_quat(e))
+    w = np.clip(q_root[..., 3], -1, 1)
+    ang = 2 * np.arccos(np.abs(w))
+    s_ = np.sqrt(np.maximum(1 - w * w, 1e-16))
+    pose_aa[:, 0] = q_root[..., :3] / s_[..., None] * (ang * np.sign(w + 1e-30))[..., None]
+    vel_xy = gaussian_filter1d(rng.normal(0, 1.0, size=(T, 2)), 5, axis=0, mode="nearest") * 1.5
+    trans = np.zeros((T, 3))
+    trans[:, :2] = np.cumsum(vel_xy, axis=0) / fps
+    trans[:, 2] = root_height + np.clip(gaussian_filter1d(rng.normal(0, 0.05, size=T), 5, mode="nearest") * 3, -0.04, 0.04)
+    return {"pose_aa": pose_aa.astype(np.float32), "root_trans_offset": trans.astype(np.float64), "dof": dof.astype(np.float32), "fps": fps}
+
+
+def make_robot_motion_dict(model, num_clips, seed=0, mean_seconds=8.0, fps=30, lengths=None, num_extend=3, min_frames=30):
+    """`make_motion_dict` for a revolute-joint robot (H1)."""
+    rng = np.random.default_rng(seed)
+    out = {}
+    for i in range(num_clips):
+        if lengths is not None:
+            T = int(lengths[i])
+        else:
+            sec = float(np.clip(rng.lognormal(np.log(mean_seconds), 0.5), 1.0, 60.0))
+            T = max(int(round(sec * fps)), min_frames)
+        out[f"synthetic_{i:05d}"] = make_robot_clip(rng, model, T, num_extend=num_extend, fps=fps)
+    return out

@@ -1,7 +1,8 @@
 #!/bin/bash
-# quick GPU check: gpu tests + cfg3-shape bench
+# quick GPU check: gpu tests + short env bench
 mkdir -p gpurun_out/check
 O=gpurun_out/check
 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; tail -25 $O/pytest_gpu.log
-( time python bench.py --envs 8192 --motion-clips 2048 --steps 100 --warmup 10 --ppo-epochs 0 --no-cpu-baseline > $O/bench_cfg3_shape.json ) 2> $O/bench_cfg3_shape.err
-tail -4 $O/bench_cfg3_shape.err; cut -c1-400 $O/bench_cfg3_shape.json
+python bench.py --steps 200 --warmup 20 --ppo-epochs 0 --no-cpu-baseline > $O/bench.json 2> $O/bench.err; tail -3 $O/bench.err
+python -c "
+import json; d=json.load(open('$O/bench.json')); print('env-steps/s %.2fM  ms/step %.4f  k_sim_step %.1f us' % (d['value']/1e6, d['ms_per_step'], d['roofline']['kernel_ms']*1e3))"

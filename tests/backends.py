@@ -29,8 +29,8 @@ class HostEmu:
     def sync(self):
         pass
 
-    def motion_state(self, lib, n, ids, times, off, rg_pos, rb_rot, bv, bav, dp, dv, i0, i1, bl):
-        return emu().emu_motion_state(P(lib), n, *[abi.ptr(a) for a in (ids, times, off, rg_pos, rb_rot, bv, bav, dp, dv, i0, i1, bl)])
+    def motion_state(self, lib, n, ids, times, off, rg_pos, rb_rot, bv, bav, dp, dv, i0, i1, bl, pe=None, re=None):
+        return emu().emu_motion_state(P(lib), n, *[abi.ptr(a) for a in (ids, times, off, rg_pos, rb_rot, bv, bav, dp, dv, i0, i1, bl, pe, re)])
 
     def sample_time_interval(self, lib, n, ids, phase, out):
         return emu().emu_sample_time_interval(P(lib), n, abi.ptr(ids), abi.ptr(phase), abi.ptr(out))
@@ -81,8 +81,8 @@ class Hip:
     def _s(self):
         return self.torch.cuda.current_stream().cuda_stream
 
-    def motion_state(self, lib, n, ids, times, off, rg_pos, rb_rot, bv, bav, dp, dv, i0, i1, bl):
-        return self.lib.phc_motion_state(lib, n, *[abi.ptr(a) for a in (ids, times, off, rg_pos, rb_rot, bv, bav, dp, dv, i0, i1, bl)], self._s())
+    def motion_state(self, lib, n, ids, times, off, rg_pos, rb_rot, bv, bav, dp, dv, i0, i1, bl, pe=None, re=None):
+        return self.lib.phc_motion_state(lib, n, *[abi.ptr(a) for a in (ids, times, off, rg_pos, rb_rot, bv, bav, dp, dv, i0, i1, bl, pe, re)], self._s())
 
     def sample_time_interval(self, lib, n, ids, phase, out):
         return self.lib.phc_sample_time_interval(lib, n, abi.ptr(ids), abi.ptr(phase), abi.ptr(out), self._s())
@@ -132,8 +132,16 @@ def model_on(be, name="smpl_humanoid", kp_scale=1.0, kd_scale=1.0, zero_armature
 
 
 def motion_lib_on(be, lib):
-    frames = be.arr(abi.pack_frames(lib["gts"], lib["grs"], lib["gvs"], lib["gavs"], lib["lrs"], lib["dvs"]))
     nb = lib["gts"].shape[1]
+    if "dof_pos" in lib:   # robot library (H1): extended bodies + scalar joint coordinates
+        ne = lib["gts_t"].shape[1] - nb
+        frames = be.arr(abi.pack_frames(lib["gts"], lib["grs"], lib["gvs"], lib["gavs"], None, lib["dvs"], gts_ext=lib["gts_t"][:, nb:],
+                                        grs_ext=lib["grs_t"][:, nb:], dof_pos=lib["dof_pos"]))
+        keep = dict(frames=frames, ml=be.arr(lib["motion_lengths"].astype(np.float32)), mdt=be.arr(lib["motion_dt"].astype(np.float32)),
+                    mnf=be.arr(lib["motion_num_frames"].astype(np.int64)), ls=be.arr(lib["length_starts"].astype(np.int64)))
+        return abi.motion_lib_struct(frames, frames.shape[1], nb, keep["ml"], keep["mdt"], keep["mnf"], keep["ls"], num_ext_bodies=ne,
+                                     dofs_per_joint=1), keep
+    frames = be.arr(abi.pack_frames(lib["gts"], lib["grs"], lib["gvs"], lib["gavs"], lib["lrs"], lib["dvs"]))
     keep = dict(frames=frames, ml=be.arr(lib["motion_lengths"].astype(np.float32)), mdt=be.arr(lib["motion_dt"].astype(np.float32)),
                 mnf=be.arr(lib["motion_num_frames"].astype(np.int64)), ls=be.arr(lib["length_starts"].astype(np.int64)))
     s = abi.motion_lib_struct(frames, frames.shape[1], nb, keep["ml"], keep["mdt"], keep["mnf"], keep["ls"])

@@ -1,0 +1,133 @@
+"""H1 robot path (BASELINE config 5) against golden vectors produced by the reference's own code (oracle/gen_golden_h1.py):
+model constants vs Humanoid_Batch's reading of h1.xml, clip FK vs `Humanoid_Batch.fk_batch` / `MotionLibReal.load_motions`,
+the lookup kernel vs `MotionLibReal.get_motion_state`, and one post-physics step (extended-body reward, 20-body observations,
+robot AMP observation) vs the reference's jit functions.  Kernel tests run on both backends of tests/backends.py."""
+import numpy as np
+import pytest
+
+from backends import BACKENDS, get_backend, model_on, motion_lib_on
+from phc_amd import abi
+from phc_amd.model import load_model
+from phc_amd.motion_lib import process_clip_real
+
+F = np.float32
+H1_KEY_BODIES = ["left_ankle_link", "right_ankle_link", "left_elbow_link", "right_elbow_link"]
+
+
+def test_h1_model_matches_reference_skeleton(golden):
+    sk = golden("skeleton_h1")
+    m = load_model("h1_humanoid")
+    assert m.body_names == list(sk["node_names"]) and m.all_revolute
+    np.testing.assert_array_equal(m.parent, sk["parents"])
+    np.testing.assert_allclose(m.local_translation, sk["local_translation"], atol=1e-7)
+    np.testing.assert_allclose(m.local_rotation, sk["local_rotation"], atol=1e-6)       # wxyz
+    np.testing.assert_allclose(m.dof_axis, sk["dof_axis"], atol=1e-12)
+    np.testing.assert_allclose(np.stack([m.dof_lower, m.dof_upper], -1), sk["joints_range"], atol=1e-9)
+    assert abs(m.total_mass - 51.436) < 2e-3                                               # env_im_h1_phc.yaml default_humanoid_mass
+
+
+def _ext(golden):
+    sk = golden("skeleton_h1")
+    e_rot = np.tile(np.array([1.0, 0, 0, 0]), (len(sk["ext_parents"]), 1))
+    return sk["ext_parents"], sk["ext_offsets"], e_rot
+
+
+def test_h1_clip_fk_matches_reference(golden):
+    """process_clip_real == Humanoid_Batch.fk_batch(return_full=True) as concatenated by MotionLibReal.load_motions."""
+    g = golden("motion_lib_h1")
+    c = golden("motion_clips_h1")
+    m = load_model("h1_humanoid")
+    ep, eo, er = _ext(golden)
+    per = [process_clip_real(m.parent, m.local_translation, m.local_rotation, ep, eo, er, c[f"{k}/pose_aa"], c[f"{k}/root_trans_offset"], 30)
+           for k in c["keys"]]
+    order = [0, 1, 2, 0, 1, 2]   # 6 envs, sequential sampling
+    # gavs: the reference differentiates fp32 quaternions with arccos(2 w^2 - 1) (rotation3d.py quat_angle_axis), which for the
+    # ~3 mrad frame-to-frame rotations of these clips is conditioned like 1/angle: its own output carries ~1e-3..1e-2 rad/s of
+    # rounding noise.  The fp64 restatement is compared at that level (and is the more accurate of the two).
+    for k, tol in (("gts", 2e-6), ("gts_t", 2e-6), ("gvs", 2e-4), ("gavs", 1e-2), ("dof_pos", 1e-6), ("dvs", 2e-5)):
+        np.testing.assert_allclose(np.concatenate([per[i][k] for i in order]), g[k], atol=tol, err_msg=k)
+    for k in ("grs", "grs_t"):   # same rotation AND same sign convention as matrix_to_quaternion
+        np.testing.assert_allclose(np.concatenate([per[i][k] for i in order]), g[k], atol=2e-6, err_msg=k)
+
+
+def _lib_from_golden(golden):
+    g = golden("motion_lib_h1")
+    return {k: g[k] for k in ("gts", "grs", "gvs", "gavs", "dvs", "dof_pos", "gts_t", "grs_t", "motion_lengths", "motion_dt", "motion_num_frames",
+                              "length_starts")}
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_h1_motion_state_vs_reference_golden(golden, backend):
+    be = get_backend(backend)
+    g = golden("motion_lib_h1")
+    lib, keep = motion_lib_on(be, _lib_from_golden(golden))
+    n = len(g["ms_ids"])
+    out = dict(rg_pos=be.zeros((n, 20, 3)), rb_rot=be.zeros((n, 20, 4)), body_vel=be.zeros((n, 20, 3)), body_ang_vel=be.zeros((n, 20, 3)),
+               dof_pos=be.zeros((n, 19)), dof_vel=be.zeros((n, 19)), pe=be.zeros((n, 3, 3)), re=be.zeros((n, 3, 4)))
+    assert be.motion_state(lib, n, be.arr(g["ms_ids"].astype(np.int64)), be.arr(g["ms_times"].astype(F)), be.arr(g["ms_offset"].astype(F)),
+                           out["rg_pos"], out["rb_rot"], out["body_vel"], out["body_ang_vel"], out["dof_pos"], out["dof_vel"], None, None, None,
+                           out["pe"], out["re"]) == 0
+    be.sync()
+    o = {k: be.np(v) for k, v in out.items()}
+    for k in ("rg_pos", "body_vel", "body_ang_vel", "dof_pos", "dof_vel"):
+        np.testing.assert_allclose(o[k], g["ms_" + k], atol=2e-5, err_msg=k)
+    np.testing.assert_allclose(o["rb_rot"], g["ms_rb_rot"], atol=2e-5)       # same slerp on the same (not re-normalised) stored quaternions
+    np.testing.assert_allclose(o["pe"], g["ms_rg_pos_t"][:, 20:], atol=2e-5)
+    np.testing.assert_allclose(o["re"], g["ms_rg_rot_t"][:, 20:], atol=2e-5)
+
+
+def h1_im_params(be, model, ext_parent, ext_pos, **extra):
+    names = model.body_names
+    tabs = abi.task_index_tables(model, names, names, H1_KEY_BODIES, has_dof_subset=False)
+    track_slot, reset_mask, key_ids, amp_slot = (be.arr(t) for t in tabs[:4])
+    td = be.arr(np.full(32, 0.25, dtype=F))
+    ep, eo = be.arr(np.asarray(ext_parent, np.int32)), be.arr(np.asarray(ext_pos, F))
+    specs = dict(k_pos=100, k_rot=10, k_vel=0.1, k_ang_vel=0.1, w_pos=0.5, w_rot=0.3, w_vel=0.1, w_ang_vel=0.1)
+    prm = abi.im_params_struct(dt=4 * (1 / 200), max_episode_length=300, reward_specs=specs, power_reward=True, power_coefficient=0.0005,
+                               enable_early_termination=True, use_mean_termination=False, disable_collision_check=False, local_root_obs=True,
+                               root_height_obs=True, num_track_bodies=20, track_slot=track_slot, reset_mask=reset_mask, num_reset_bodies=20,
+                               first_reset_body=0, termination_distances=td, num_key_bodies=4, key_body_ids=key_ids, num_amp_joints=tabs[4],
+                               amp_joint_slot=amp_slot, num_amp_obs_steps=10, num_amp_obs_per_step=63, num_self_obs=298, num_task_obs=480,
+                               dofs_per_joint=1, ext_parent=ep, ext_offset=eo, **extra)
+    prm._keepalive = (track_slot, reset_mask, key_ids, amp_slot, td, ep, eo)
+    return prm
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_h1_post_physics_vs_reference_golden(golden, backend):
+    """Reward incl. the three extended bodies (humanoid_im.py:916-923), power reward over 19 scalar DoFs, reset flags, 298 self-obs +
+    480 task-obs floats and the 63-float robot AMP observation == the reference's functions on the same inputs."""
+    be = get_backend(backend)
+    g = golden("task_fns_h1")
+    lib, keep = motion_lib_on(be, _lib_from_golden(golden))
+    model, mstruct, keepm = model_on(be, "h1_humanoid")
+    N = g["body_pos"].shape[0]
+    prm = h1_im_params(be, model, g["ext_parent"], g["ext_pos"])
+    assert prm.num_amp_joints == 19 and prm.num_ext_bodies == 3
+    rbs = np.concatenate([g["body_pos"], g["body_rot"], g["body_vel"], g["body_ang_vel"]], axis=-1).astype(F)
+    arrs = dict(root=be.arr(rbs[:, 0, :]), dof=be.arr(np.stack([g["dof_pos"], g["dof_vel"]], -1).astype(F)), rbs=be.arr(rbs), cf=be.zeros((N, 20, 3)),
+                df=be.arr(g["dof_force"].astype(F)), pd=be.zeros((N, 19)))
+    sim = abi.sim_state_struct(N, arrs["root"], arrs["dof"], arrs["rbs"], arrs["cf"], arrs["df"], arrs["pd"])
+    rng = np.random.default_rng(0)
+    amp_in_np = rng.standard_normal((N, 10, 63)).astype(F)
+    amp_in, amp_out = be.arr(amp_in_np), be.zeros((N, 10, 63))
+    b = dict(progress=be.arr((g["progress"] - 1).astype(np.int64)), reset=be.zeros(N, np.int64), term=be.zeros(N, np.int64), rew=be.zeros(N),
+             raw=be.zeros((N, 5)), obs=be.zeros((N, 778)), mids=be.arr(g["env_motion"].astype(np.int64)), st=be.arr(g["start_times"].astype(F)),
+             so=be.zeros(N), goff=be.zeros((N, 3)), rbp=be.zeros((N, 20, 3)), rdp=be.zeros((N, 19)))
+    buf = abi.im_buffers_struct(b["progress"], b["reset"], b["term"], b["rew"], b["raw"], b["obs"], amp_in, amp_out, b["mids"], b["st"], b["so"],
+                                b["goff"], ref_body_pos=b["rbp"], ref_dof_pos=b["rdp"])
+    assert be.im_post_physics(mstruct, lib, prm, sim, buf) == 0
+    be.sync()
+    o = {k: be.np(v) for k, v in b.items()}
+    amp_out = be.np(amp_out)
+    np.testing.assert_allclose(o["raw"][:, :4], g["reward_raw"], atol=1e-5)
+    np.testing.assert_allclose(o["raw"][:, 4], g["power_reward"], atol=1e-5, rtol=1e-5)
+    np.testing.assert_allclose(o["rew"], g["reward"] + g["power_reward"], atol=1e-5)
+    np.testing.assert_array_equal(o["reset"], g["reset"])
+    np.testing.assert_array_equal(o["term"], g["terminate"])
+    np.testing.assert_allclose(o["obs"][:, :298], g["self_obs"], atol=1e-5)
+    np.testing.assert_allclose(o["obs"][:, 298:], g["task_obs"], atol=2e-5)
+    np.testing.assert_allclose(amp_out[:, 0], g["amp_obs"], atol=1e-5)
+    np.testing.assert_array_equal(amp_out[:, 1:], amp_in_np[:, :-1])
+    np.testing.assert_allclose(o["rbp"], g["ref1_pos"], atol=2e-5)
+    np.testing.assert_allclose(o["rdp"], g["ref1_dof_pos"], atol=2e-5)
