@@ -45,6 +45,40 @@ _ENV_IM_GETUP_MCP = dict(  # env/env_im_getup_mcp.yaml
     power_coefficient=0.00005)
 _ENV_IM_GETUP_MCP.pop("min_length", None)
 
+_H1_BODIES = ['pelvis', 'left_hip_yaw_link', 'left_hip_roll_link', 'left_hip_pitch_link', 'left_knee_link', 'left_ankle_link',
+              'right_hip_yaw_link', 'right_hip_roll_link', 'right_hip_pitch_link', 'right_knee_link', 'right_ankle_link', 'torso_link',
+              'left_shoulder_pitch_link', 'left_shoulder_roll_link', 'left_shoulder_yaw_link', 'left_elbow_link',
+              'right_shoulder_pitch_link', 'right_shoulder_roll_link', 'right_shoulder_yaw_link', 'right_elbow_link']
+_ENV_IM_H1 = {  # env/env_im_h1_phc.yaml
+    "task": "HumanoidIm", "motion_file": "", "num_envs": 4096, "env_spacing": 5, "episode_length": 300, "is_flag_run": False,
+    "enable_debug_vis": False, "sym_loss_coef": 1, "big_ankle": True, "fut_tracks": False, "obs_v": 6, "self_obs_v": 1, "auto_pmcp": False,
+    "auto_pmcp_soft": True, "cycle_motion": False, "hard_negative": False, "masterfoot": False, "freeze_toe": False, "has_pnn": True,
+    "num_prim": 3, "training_prim": 0, "has_lateral": False, "actors_to_load": 0, "fitting": False, "getup_schedule": False,
+    "recoverySteps": 90, "recoveryEpisodeProb": 0.5, "fallInitProb": 0.3, "getup_udpate_epoch": 270171, "zero_out_far": False,
+    "zero_out_far_train": False, "default_humanoid_mass": 51.436, "real_weight": True, "kp_scale": 1, "remove_toe_im": False,
+    "power_reward": True, "power_coefficient": 0.0005, "powerScale": 1.0, "stateInit": "Random", "hybridInitProb": 0.5, "numAMPObsSteps": 10,
+    "local_root_obs": True, "root_height_obs": True, "key_bodies": ["left_ankle_link", "right_ankle_link", "left_elbow_link", "right_elbow_link"],
+    "contact_bodies": ["left_ankle_link", "right_ankle_link"], "reset_bodies": _H1_BODIES, "terminationHeight": 0.15,
+    "enableEarlyTermination": True, "terminationDistance": 0.25, "numTrajSamples": 3, "trajSampleTimestepInv": 30, "enableTaskObs": True,
+    "plane": {"staticFriction": 1.0, "dynamicFriction": 1.0, "restitution": 0.0},
+}
+_ROBOT_H1 = {  # robot/unitree_h1.yaml
+    "humanoid_type": "h1", "bias_offset": False, "has_self_collision": True, "has_mesh": False, "has_jt_limit": False, "has_dof_subset": True,
+    "has_upright_start": True, "has_smpl_pd_offset": False, "remove_toe": False, "motion_sym_loss": False, "sym_loss_coef": 1, "big_ankle": True,
+    "has_shape_obs": False, "has_shape_obs_disc": False, "has_shape_variation": False, "masterfoot": False, "freeze_toe": False,
+    "freeze_hand": False, "box_body": True, "real_weight": True, "real_weight_porpotion_capsules": True, "real_weight_porpotion_boxes": True,
+    "body_names": _H1_BODIES,
+    "limb_weight_group": [_H1_BODIES[1:6], _H1_BODIES[6:11], ['pelvis', 'torso_link'], ['right_shoulder_pitch_link', 'right_shoulder_roll_link'],
+                          ['left_shoulder_yaw_link', 'left_elbow_link']],
+    "dof_names": _H1_BODIES[1:], "right_foot_name": "right_ankle_link", "left_foot_name": "left_ankle_link", "sim_with_urdf": True,
+    "asset": {"assetRoot": "./", "assetFileName": "phc/data/assets/robot/unitree_h1/h1.xml",
+              "urdfFileName": "phc/data/assets/robot/unitree_h1/urdf/h1.urdf"},
+    "extend_config": [{"joint_name": "left_hand_link", "parent_name": "left_elbow_link", "pos": [0.3, 0.0, 0.0], "rot": [1.0, 0.0, 0.0, 0.0]},
+                      {"joint_name": "right_hand_link", "parent_name": "right_elbow_link", "pos": [0.3, 0.0, 0.0], "rot": [1.0, 0.0, 0.0, 0.0]},
+                      {"joint_name": "head_link", "parent_name": "pelvis", "pos": [0.0, 0.0, 0.6], "rot": [1.0, 0.0, 0.0, 0.0]}],
+    "base_link": "torso_link",
+}
+
 _ROBOT_SMPL = {  # robot/smpl_humanoid.yaml
     "humanoid_type": "smpl", "bias_offset": False, "has_self_collision": True, "has_mesh": False, "has_jt_limit": False,
     "has_dof_subset": True, "has_upright_start": True, "has_smpl_pd_offset": False, "remove_toe": False, "motion_sym_loss": False,
@@ -61,6 +95,9 @@ _SIM_DEFAULT = {  # sim/default_sim.yaml
               "default_buffer_size_multiplier": 10.0},
     "flex": {"num_inner_iterations": 10, "warm_start": 0.25},
 }
+_SIM_ROBOT = copy.deepcopy(_SIM_DEFAULT)   # sim/robot_sim.yaml: 200 Hz, no explicit substeps key (gymapi default 2)
+_SIM_ROBOT["physx"]["step_dt"] = "1/200"
+_SIM_ROBOT.pop("substeps", None)
 _CONTROL_DEFAULT = {"action_filter": False, "action_scale": 1, "decimation": 2, "action_cutfreq": 4.0, "control_mode": "isaac_pd"}
 _DR_DEFAULT = {"has_domain_rand": False, "push_robots": False, "randomize_friction": False, "randomize_base_mass": False,
                "randomize_base_com": False, "randomize_link_mass": False, "randomize_pd_gain": False, "randomize_torque_rfi": False,
@@ -103,8 +140,8 @@ def _with_net(units, activation, net_name, cfg, extra_net):
 
 _BIG = [2048, 1536, 1024, 1024, 512, 512]
 GROUPS = {
-    "env": {"env_im": _ENV_IM, "env_im_pnn": _ENV_IM_PNN, "env_im_getup_mcp": _ENV_IM_GETUP_MCP},
-    "robot": {"smpl_humanoid": _ROBOT_SMPL},
+    "env": {"env_im": _ENV_IM, "env_im_pnn": _ENV_IM_PNN, "env_im_getup_mcp": _ENV_IM_GETUP_MCP, "env_im_h1_phc": _ENV_IM_H1},
+    "robot": {"smpl_humanoid": _ROBOT_SMPL, "unitree_h1": _ROBOT_H1},
     "learning": {"im": _learning([1024, 512], "relu"), "im_big": _learning(_BIG, "silu", extra_cfg={"save_frequency": 1500}),
                  "im_pnn": _learning([1024, 512], "relu", "amp_pnn"),
                  "im_pnn_big": _learning(_BIG, "silu", "amp_pnn", {"amp_dropout": False, "save_frequency": 1500}),
@@ -113,8 +150,8 @@ GROUPS = {
                  "im_mcp_big": _learning(_BIG, "silu", "amp_mcp", {"player": {"games_num": 999999999999999999999999},
                                                                   "save_frequency": 500, "amp_dropout": True},
                                          {"has_softmax": False, "ending_act": True})},
-    "sim": {"default_sim": _SIM_DEFAULT},
-    "control": {"default_control": _CONTROL_DEFAULT},
+    "sim": {"default_sim": _SIM_DEFAULT, "robot_sim": _SIM_ROBOT},
+    "control": {"default_control": _CONTROL_DEFAULT, "robot_control": dict(_CONTROL_DEFAULT, decimation=4, control_mode="pd")},
     "domain_rand": {"default_dr": _DR_DEFAULT},
 }
 

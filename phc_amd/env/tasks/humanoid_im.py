@@ -24,9 +24,10 @@ import torch
 from ... import _lib as L
 from ... import abi
 from ...model import load_model
-from ...motion_lib import FixHeightMode, MotionLibSMPL
+from ...motion_lib import FixHeightMode, MotionLibReal, MotionLibSMPL
+from ... import robots
 from ...utils.flags import flags
-from ...utils.synthetic_motion import make_motion_dict
+from ...utils.synthetic_motion import make_motion_dict, make_robot_motion_dict
 
 SMPL_MUJOCO_NAMES = ['Pelvis', 'L_Hip', 'L_Knee', 'L_Ankle', 'L_Toe', 'R_Hip', 'R_Knee', 'R_Ankle', 'R_Toe', 'Torso', 'Spine',
                      'Chest', 'Neck', 'Head', 'L_Thorax', 'L_Shoulder', 'L_Elbow', 'L_Wrist', 'L_Hand', 'R_Thorax', 'R_Shoulder',
@@ -80,8 +81,9 @@ class HumanoidIm:
 
         # ---- load_humanoid_configs (humanoid.py:250-420) ----
         self.humanoid_type = robot.get("humanoid_type", "smpl")
-        if self.humanoid_type != "smpl":
-            raise NotImplementedError(f"humanoid_type={self.humanoid_type!r}: only the SMPL humanoid is built in this round")
+        if self.humanoid_type not in ("smpl", "h1"):
+            raise NotImplementedError(f"humanoid_type={self.humanoid_type!r}: built so far: smpl, h1")
+        self._is_robot = self.humanoid_type == "h1"
         unsupported = dict(fut_tracks=False, zero_out_far_train=False, cycle_motion_xp=False, occl_training=False, res_action=False,
                            kin_loss=False, z_readout=False, distill=False, has_shape_variation=False)
         for k, off in unsupported.items():
@@ -92,11 +94,18 @@ class HumanoidIm:
             raise NotImplementedError("only obs_v=6 / self_obs_v=1 / amp_obs_v=1 (the shipped env_im* configs) are built")
         self.has_task = True
         self.obs_v, self.self_obs_v, self.amp_obs_v = 6, 1, 1
-        self._body_names_orig = list(SMPL_MUJOCO_NAMES)
-        self._body_names = self._body_names_orig
-        self._dof_names = self._body_names[1:]
-        self._full_track_bodies = self._body_names_orig.copy()
-        self._eval_bodies = [b for b in self._body_names_orig if b not in ("L_Toe", "R_Toe", "L_Hand", "R_Hand")]
+        if self._is_robot:  # load_robot_configs, humanoid.py:422-439
+            self._body_names_orig = list(robot["body_names"])
+            self._body_names = self._body_names_orig
+            self._dof_names = list(robot["dof_names"])
+            self._full_track_bodies = self._body_names_orig.copy()
+            self._eval_bodies = self._body_names_orig.copy()
+        else:
+            self._body_names_orig = list(SMPL_MUJOCO_NAMES)
+            self._body_names = self._body_names_orig
+            self._dof_names = self._body_names[1:]
+            self._full_track_bodies = self._body_names_orig.copy()
+            self._eval_bodies = [b for b in self._body_names_orig if b not in ("L_Toe", "R_Toe", "L_Hand", "R_Hand")]
         self._has_upright_start = robot.get("has_upright_start", True)
         if not self._has_upright_start:
             raise NotImplementedError("has_upright_start=False is not built")
@@ -151,9 +160,10 @@ class HumanoidIm:
 
         # ---- Humanoid.__init__ (humanoid.py:81-131) ----
         self.control_mode = cfg["control"]["control_mode"]
-        if self.control_mode != "isaac_pd":
-            raise NotImplementedError(f"control_mode={self.control_mode!r}: only the implicit 'isaac_pd' drive is built")
-        self._pd_control = True
+        if self.control_mode not in (("isaac_pd", "pd") if self._is_robot else ("isaac_pd",)):
+            raise NotImplementedError(f"control_mode={self.control_mode!r} for humanoid_type={self.humanoid_type!r} is not built "
+                                      "(isaac_pd: implicit position drive; pd: explicit torques, revolute robots only)")
+        self._pd_control = self.control_mode == "isaac_pd"   # humanoid.py:96-99
         self.max_episode_length = env["episode_length"]
         self._local_root_obs = env["local_root_obs"]
         self._root_height_obs = env.get("root_height_obs", True)
@@ -173,8 +183,15 @@ class HumanoidIm:
 
         # ---- model (replaces create_sim / load_asset, humanoid.py:528-535,768-990) ----
         asset = robot.get("asset", {}).get("assetFileName", "mjcf/smpl_humanoid.xml")
-        self.model = load_model(cfg.get("model_asset", "smpl_humanoid"))
-        assert self.model.body_names == self._body_names, f"asset {asset} does not have the SMPL body order"
+        self.model = load_model(cfg.get("model_asset", "h1_humanoid" if self._is_robot else "smpl_humanoid"))
+        assert self.model.body_names == self._body_names, f"asset {asset} does not have the body order of robot.body_names"
+        if self._is_robot:
+            # gains / default pose / torque limit live in the reference's task code (humanoid.py:1112-1121,1016-1022)
+            self._robot_consts = robots.H1
+            robots.apply_robot_gains(self.model, self._robot_consts, env.get("pd_v", 1))
+            self.p_gains = torch.tensor(self._robot_consts["p_gains"][env.get("pd_v", 1)], dtype=torch.float32, device=self.device)
+            self.d_gains = torch.tensor(self._robot_consts["d_gains"][env.get("pd_v", 1)], dtype=torch.float32, device=self.device)
+            self.default_dof_pos = torch.tensor([self._robot_consts["default_dof_pos"]], dtype=torch.float32, device=self.device)
         self.num_bodies, self.num_dof = self.model.num_bodies, self.model.num_dof
         self.skeleton_trees = [SkeletonTree(self.model.body_names, self.model.parent, self.model.local_translation)] * self.num_envs
         ints, floats = self.model.pack(self._kp_scale, self._kd_scale)
@@ -183,19 +200,25 @@ class HumanoidIm:
         self._model_struct = abi.model_struct(self._model_ints, self._model_floats, self.num_bodies, self.num_dof,
                                               self.model.max_level, len(self.model.contact_body))
         self.humanoid_masses = [self.model.total_mass] * min(self.num_envs, 10)
-        self.limb_weight_group = [[self._body_names.index(g) for g in grp] for grp in (
+        groups = robot.get("limb_weight_group", []) if self._is_robot else (
             ['L_Hip', 'L_Knee', 'L_Ankle', 'L_Toe'], ['R_Hip', 'R_Knee', 'R_Ankle', 'R_Toe'],
             ['Pelvis', 'Torso', 'Spine', 'Chest', 'Neck', 'Head'], ['L_Thorax', 'L_Shoulder', 'L_Elbow', 'L_Wrist', 'L_Hand'],
-            ['R_Thorax', 'R_Shoulder', 'R_Elbow', 'R_Wrist', 'R_Hand'])]
+            ['R_Thorax', 'R_Shoulder', 'R_Elbow', 'R_Wrist', 'R_Hand'])
+        self.limb_weight_group = [[self._body_names.index(g) for g in grp] for grp in groups]
         lw = self.model.limb_lengths_and_weights(self.limb_weight_group)
         self.humanoid_limb_and_weights = torch.from_numpy(lw).to(self.device).repeat(self.num_envs, 1)
         self.humanoid_shapes = torch.zeros(self.num_envs, 17, device=self.device)
 
         # ---- _setup_character_props (humanoid.py:636-706, humanoid_amp.py:290-329) ----
         self._dof_body_ids = np.arange(1, len(self._body_names))
-        self._dof_offsets = np.linspace(0, len(self._dof_names) * 3, len(self._body_names)).astype(int)
-        self._dof_obs_size = len(self._dof_names) * 6
-        self._dof_size = len(self._dof_names) * 3
+        if self._is_robot:  # humanoid.py:684-687: one DoF per joint
+            self._dof_obs_size = len(self._dof_names)
+            self._dof_offsets = np.arange(len(self._dof_names) + 1)
+            self._dof_size = len(self._dof_names)
+        else:
+            self._dof_offsets = np.linspace(0, len(self._dof_names) * 3, len(self._body_names)).astype(int)
+            self._dof_obs_size = len(self._dof_names) * 6
+            self._dof_size = len(self._dof_names) * 3
         self._num_actions = self._dof_size
         self._num_self_obs = 1 + len(self._body_names) * (3 + 6 + 3 + 3) - 3
         if not self._root_height_obs:
@@ -203,10 +226,22 @@ class HumanoidIm:
         self._track_bodies = env.get("trackBodies", self._full_track_bodies)
         self._reset_bodies = env.get("reset_bodies", self._track_bodies)
         track_slot, reset_mask, key_ids, amp_slot, n_amp_joints = abi.task_index_tables(
-            self.model, self._track_bodies, self._reset_bodies, self.key_bodies, has_dof_subset=self._has_dof_subset)
-        self._num_amp_obs_per_step = 13 + n_amp_joints * 9 + 3 * len(self.key_bodies) - (0 if self._amp_root_height_obs else 1)
-        dof_sub = [np.arange(3 * (j - 1), 3 * j) for j in range(1, self.num_bodies) if amp_slot[j] >= 0]
-        self.dof_subset = torch.from_numpy(np.concatenate(dof_sub)) if self._has_dof_subset else torch.tensor([]).long()
+            self.model, self._track_bodies, self._reset_bodies, self.key_bodies, has_dof_subset=self._has_dof_subset and not self._is_robot)
+        if self._is_robot:  # humanoid_amp.py:315-322: [root_h, root_rot 6, root_vel 3, root_ang_vel 3, dof_pos, dof_vel, key_body_pos]
+            self._num_amp_obs_per_step = 13 + self._dof_obs_size + len(self._dof_names) + 3 * len(self.key_bodies) - (0 if self._amp_root_height_obs else 1)
+            self.dof_subset = torch.tensor([]).long()
+        else:
+            self._num_amp_obs_per_step = 13 + n_amp_joints * 9 + 3 * len(self.key_bodies) - (0 if self._amp_root_height_obs else 1)
+            dof_sub = [np.arange(3 * (j - 1), 3 * j) for j in range(1, self.num_bodies) if amp_slot[j] >= 0]
+            self.dof_subset = torch.from_numpy(np.concatenate(dof_sub)) if self._has_dof_subset else torch.tensor([]).long()
+        # extended bodies of the full-body reward (humanoid_im.py:74-82)
+        ext = list(robot.get("extend_config", [])) if self._is_robot else []
+        self.num_extend_bodies = len(ext)
+        self.extend_body_parent_ids = self._build_key_body_ids_tensor([e["parent_name"] for e in ext]) if ext else None
+        self.extend_body_pos_in_parent = (torch.tensor([e["pos"] for e in ext], dtype=torch.float32, device=self.device).repeat(self.num_envs, 1, 1)
+                                          if ext else None)
+        self._ext_parent_i32 = self.extend_body_parent_ids.to(torch.int32).contiguous() if ext else None
+        self._ext_offset_f32 = self.extend_body_pos_in_parent[0].contiguous() if ext else None
         self._track_bodies_id = self._build_key_body_ids_tensor(self._track_bodies)
         self._reset_bodies_id = self._build_key_body_ids_tensor(self._reset_bodies)
         self._full_track_bodies_id = self._build_key_body_ids_tensor(self._full_track_bodies)
@@ -271,7 +306,12 @@ class HumanoidIm:
             sim_dt=self.sim_dt, substeps=int(sim_cfg.get("substeps", 2)), control_freq_inv=self.control_freq_inv, gravity_z=-9.81,
             contact_stiffness=float(solver.get("contact_stiffness", 1.0e5)), contact_damping=float(solver.get("contact_damping", 1.0e3)),
             friction=float(plane.get("dynamicFriction", 1.0)), friction_viscous=float(solver.get("friction_viscous", 2.0e3)),
-            angular_damping=0.01, max_angular_velocity=100.0, contact_offset=float(physx.get("contact_offset", 0.02)))
+            angular_damping=0.01, max_angular_velocity=100.0, contact_offset=float(physx.get("contact_offset", 0.02)),
+            # `pd` (robot_control.yaml): explicit torque per simulate call; solver.pd_damping "continuous" (default, mode 2: only the
+            # spring term is held) or "held" (mode 1: the reference's letter, unstable on unloaded light links -- DESIGN.md)
+            control_mode=0 if self.control_mode == "isaac_pd" else (1 if solver.get("pd_damping", "continuous") == "held" else 2),
+            limit_stiffness=float(solver.get("joint_limit_stiffness", 2000.0 if self._is_robot else 0.0)),
+            limit_damping=float(solver.get("joint_limit_damping", 20.0 if self._is_robot else 0.0)))
 
         # ---- action scaling (A1) + freeze masks (humanoid.py:1331-1409,1549-1554) ----
         self.dof_limits_lower, self.dof_limits_upper = (torch.from_numpy(x).to(dev) for x in self.model.dof_limits())
@@ -279,11 +319,18 @@ class HumanoidIm:
         self.torque_limits = torch.from_numpy(self.model.dof_effort.astype(np.float32)).to(dev)
         self.motor_efforts = self.torque_limits.clone()
         off, scale = self.model.pd_action_offset_scale(self._bias_offset)
+        if self._is_robot:
+            off = np.zeros_like(off)  # humanoid.py:1406-1407
         self._pd_action_offset = torch.from_numpy(off).to(dev)
         self._pd_action_scale = torch.from_numpy(scale).to(dev)
+        if self.control_mode == "pd":
+            # torques = p_gains * (actions * action_scale + default_dof_pos - dof_pos) - d_gains * dof_vel (humanoid.py:1585-1590):
+            # the PD target the stepper sees is default_dof_pos + action_scale * clip(action, +-10)
+            self._torque_target_offset = self.default_dof_pos[0].contiguous()
+            self._torque_target_scale = torch.full((D,), float(cfg["control"].get("action_scale", 1.0)), **f32)
         freeze = np.zeros(D, dtype=np.int32)
         for names, on in ((("L_Hand", "R_Hand"), self._freeze_hand), (("L_Toe", "R_Toe"), self._freeze_toe)):
-            if on:
+            if on and not self._is_robot:
                 for n in names:
                     i = self._dof_names.index(n) * 3
                     freeze[i:i + 3] = 1
@@ -292,7 +339,8 @@ class HumanoidIm:
 
         # ---- termination (humanoid.py:708-724, humanoid_im.py:539-543) ----
         self._termination_heights = torch.full((NB,), float(env["terminationHeight"]), **f32)
-        self._termination_heights[self._body_names.index("Head")] = max(0.3, float(env["terminationHeight"]))
+        if "Head" in self._body_names:
+            self._termination_heights[self._body_names.index("Head")] = max(0.3, float(env["terminationHeight"]))
         self._termination_distances_full = torch.full((32,), float(env.get("terminationDistance", 0.5)), **f32)  # PHC_MAX_BODIES slots
         self._termination_distances = self._termination_distances_full[:NB]  # learner edits this view in place (im_amp.py:174)
 
@@ -344,7 +392,8 @@ class HumanoidIm:
             num_key_bodies=len(self.key_bodies), key_body_ids=key_ids, num_amp_joints=self._n_amp_joints, amp_joint_slot=amp_slot,
             num_amp_obs_steps=self._num_amp_obs_steps, num_amp_obs_per_step=self._num_amp_obs_per_step,
             num_self_obs=self._num_self_obs, num_task_obs=self.get_task_obs_size(), cycle_motion=self.cycle_motion,
-            zero_out_far=self.zero_out_far, close_distance=self.close_distance, far_distance=self.far_distance)
+            zero_out_far=self.zero_out_far, close_distance=self.close_distance, far_distance=self.far_distance,
+            dofs_per_joint=1 if self._is_robot else 3, ext_parent=self._ext_parent_i32, ext_offset=self._ext_offset_f32)
         self._flag_state = (flags.im_eval, flags.no_collision_check)
 
     def _buffers(self, amp_in, amp_out):
@@ -423,13 +472,22 @@ class HumanoidIm:
             nclips = int(parts[1]) if len(parts) > 1 else 1
             seed = int(parts[2]) if len(parts) > 2 else 0
             mean_s = float(parts[3]) if len(parts) > 3 else 8.0
-            mf = make_motion_dict(self.model.parent, nclips, seed=seed, body_names=self._body_names, mean_seconds=mean_s,
-                                  min_frames=max(30, int(self._min_motion_len) if self._min_motion_len > 0 else 30))
+            min_frames = max(30, int(self._min_motion_len) if self._min_motion_len > 0 else 30)
+            if self._is_robot:
+                mf = make_robot_motion_dict(self.model, nclips, seed=seed, mean_seconds=mean_s, num_extend=self.num_extend_bodies, min_frames=min_frames)
+            else:
+                mf = make_motion_dict(self.model.parent, nclips, seed=seed, body_names=self._body_names, mean_seconds=mean_s, min_frames=min_frames)
         from ...config import EasyDict
         motion_lib_cfg = EasyDict({"motion_file": mf, "device": self.device, "fix_height": FixHeightMode.full_fix,
                                    "min_length": self._min_motion_len, "max_length": -1, "im_eval": flags.im_eval,
                                    "multi_thread": False, "smpl_type": self.humanoid_type, "randomrize_heading": True, "step_dt": self.dt})
-        self._motion_train_lib = MotionLibSMPL(motion_lib_cfg)
+        if self._is_robot:  # humanoid_im.py:342-359
+            motion_lib_cfg["robot"] = self.cfg["robot"]
+            motion_lib_cfg["robot_model"] = self.model
+            self._motion_lib_cls = MotionLibReal
+        else:
+            self._motion_lib_cls = MotionLibSMPL
+        self._motion_train_lib = self._motion_lib_cls(motion_lib_cfg)
         self._motion_eval_lib = None  # built lazily by get_eval_motion_lib()
         self._motion_lib = self._motion_train_lib
         self._motion_lib.load_motions(skeleton_trees=self.skeleton_trees, gender_betas=self.humanoid_shapes.cpu(),
@@ -444,7 +502,7 @@ class HumanoidIm:
             cfg = EasyDict(dict(self._motion_train_lib.m_cfg))
             cfg.im_eval = True
             cfg.motion_file = self._motion_train_lib._motion_data_load
-            self._motion_eval_lib = MotionLibSMPL(cfg)
+            self._motion_eval_lib = self._motion_lib_cls(cfg)
         return self._motion_eval_lib
 
     def begin_seq_motion_samples(self):
@@ -482,11 +540,16 @@ class HumanoidIm:
         self.actions = actions.to(self.device).clone()
         if self.actions.dim() == 1:
             self.actions = self.actions[None]
+        if self.control_mode == "pd":
+            self.actions = torch.clip(self.actions, -10, 10)   # humanoid.py:1568-1570
 
     def _physics_step(self):
         a = self.actions.contiguous()
-        L.check(self._lib.phc_sim_step(self._model_struct, self._sim_params, self._sim_struct, a.data_ptr(),
-                                       self._pd_action_offset.data_ptr(), self._pd_action_scale.data_ptr(),
+        if self.control_mode == "pd":  # _compute_torques every simulate call (humanoid.py:1602-1616) happens inside the stepper
+            off, scale = self._torque_target_offset, self._torque_target_scale
+        else:
+            off, scale = self._pd_action_offset, self._pd_action_scale
+        L.check(self._lib.phc_sim_step(self._model_struct, self._sim_params, self._sim_struct, a.data_ptr(), off.data_ptr(), scale.data_ptr(),
                                        self._freeze_mask.data_ptr(), self.control_freq_inv, _stream()), "phc_sim_step")
 
     def post_physics_step(self):

@@ -361,3 +361,64 @@ def test_mcp_getup_task_composes_primitives_and_trains():
     assert np.isfinite([info["actor_loss"], info["critic_loss"], info["disc_loss"]]).all(), info
     assert not torch.equal(c0, agent.model.a2c_network.composer[0].weight)
     assert agent._task_reward_w == 0 and agent._disc_reward_w == 1   # getup schedule warm-up (amp_agent.py:518-525)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# config 5: Unitree H1 (robot=unitree_h1 env=env_im_h1_phc sim=robot_sim control=robot_control, README.MD:311)
+# ---------------------------------------------------------------------------------------------------------------
+H1_OVER = {"robot": "unitree_h1", "env": "env_im_h1_phc", "sim": "robot_sim", "control": "robot_control"}
+
+
+def test_h1_env_end_to_end():
+    """H1 task on the device: 20 bodies / 19 revolute DoFs, 200 Hz x 4 `pd` torque control, obs 298 + 480, AMP obs 63 x 10,
+    extended-body reward, MotionLibReal lookups; body state == FK of the joint state (fp64 oracle kinematics)."""
+    import dyn_oracle as do
+    task, env = make_task(256, motion="synthetic:3:2:2.0", **H1_OVER)
+    assert task.humanoid_type == "h1" and task.num_bodies == 20 and task.num_dof == 19 and task.num_actions == 19
+    assert task.num_obs == 298 + 480 and task.get_num_amp_obs() == 630 and task.control_freq_inv == 4 and abs(task.dt - 0.02) < 1e-9
+    assert task.num_extend_bodies == 3 and task._motion_lib.num_ext_bodies == 3 and task._motion_lib.dofs_per_joint == 1
+    obs = env.reset()
+    assert obs.shape == (256, 778) and torch.isfinite(obs).all()
+    # reset state == reference state: joint angles straight from the clip, body state from the clip's FK
+    res = task._motion_lib.get_motion_state(task._sampled_motion_ids, task._motion_start_times)
+    np.testing.assert_allclose(task._dof_pos.cpu().numpy(), res["dof_pos"].cpu().numpy(), atol=1e-6)
+    np.testing.assert_allclose(task._rigid_body_pos.cpu().numpy(), res["rg_pos"].cpu().numpy(), atol=1e-5)
+    assert res["rg_pos_t"].shape == (256, 23, 3) and res["rg_rot_t"].shape == (256, 23, 4)
+    lo, hi = task.model.dof_limits()
+    rew_sum = torch.zeros(256, device=task.device)
+    n_done = 0
+    for k in range(40):
+        task.reset_done()
+        obs, rew, done, info = env.step(torch.randn(256, 19, device=task.device) * 0.3)
+        rew_sum += rew
+        n_done += int(done.sum())
+    torch.cuda.synchronize()
+    assert torch.isfinite(obs).all() and torch.isfinite(rew_sum).all() and info["amp_obs"].shape == (256, 630)
+    assert n_done > 0 and (task.progress_buf.max() > 5)
+    assert (task._dof_pos.cpu().numpy() > lo - 0.35).all() and (task._dof_pos.cpu().numpy() < hi + 0.35).all(), "joint limits hold the joints"
+    assert task.dof_force_tensor.abs().max() <= 350.0 + 2000.0 * 0.4 + 1e-3   # torque limit (+ limit spring when outside the range)
+    root, dof = task._root_states.cpu().numpy(), task._dof_state.view(256, 19, 2).cpu().numpy()
+    bp, br = task._rigid_body_pos.cpu().numpy(), task._rigid_body_rot.cpu().numpy()
+    for e in (0, 100, 255):
+        st = do.State(root[e], dof[e], task.model)
+        Q, R, p = do.kinematics(task.model, st)
+        np.testing.assert_allclose(bp[e], p, atol=2e-5)
+        np.testing.assert_allclose(np.abs((br[e] * np.array(Q)).sum(-1)), 1.0, atol=1e-5)
+    demo = task.fetch_amp_obs_demo(64)
+    assert demo.shape == (64, 630) and torch.isfinite(demo).all()
+
+
+def test_h1_ppo_epoch():
+    """README.MD:311 training line at small size: PNN actor on the H1 task, one PPO + AMP epoch on the device."""
+    from phc_amd.learning.amp_agent import IMAmpAgent
+    task, env = make_task(128, motion="synthetic:2:1:2.0", **dict(H1_OVER, **{"learning": "im_pnn", "learning.params.config.minibatch_size": 1024,
+                                                                           "learning.params.config.amp_obs_demo_buffer_size": 2048,
+                                                                           "learning.params.config.amp_replay_buffer_size": 2048,
+                                                                           "learning.params.network.space.continuous.sigma_init.val": -1.7}))
+    agent = IMAmpAgent(env, task.cfg)
+    agent.init_train()
+    w0 = agent.model.a2c_network.pnn.actors[0][0].weight.clone()
+    info = agent.train_epoch()
+    assert np.isfinite([info["actor_loss"], info["critic_loss"], info["disc_loss"], info["mean_task_reward"]]).all(), info
+    assert not torch.equal(w0, agent.model.a2c_network.pnn.actors[0][0].weight)
+    assert abs(float(agent.model.a2c_network.sigma[0]) + 1.7) < 1e-6
