@@ -162,15 +162,14 @@ def _angular_velocity(g, dt):
     return gaussian_filter1d(ax * ang[..., None] / dt, 2, axis=0, mode="nearest")
 
 
-def process_clip_real(parents, local_translation, local_rotation_wxyz, ext_parent, ext_pos, ext_rot_wxyz, pose_aa, root_trans, fps):
-    """Robot clips (H1 / G1): `Humanoid_Batch.fk_batch(..., return_full=True)` (torch_humanoid_batch.py:163-257) in fp64 numpy.
-    pose_aa [T, NB+E, 3]: root axis-angle, one axis*angle row per joint, (zero) rows for the E extended bodies.
-    Returns NB-wide gts/grs/gvs/gavs, (NB+E)-wide gts_t/grs_t, dof_pos / dvs [T,ND], lrs [T,NB+E,4]."""
+def robot_fk(parents, local_translation, local_rotation_wxyz, ext_parent, ext_pos, ext_rot_wxyz, pose_aa, root_trans):
+    """`Humanoid_Batch.forward_kinematics_batch` (torch_humanoid_batch.py:224-257) in fp64 numpy: world position / rotation
+    matrix of the NB simulated + E extended bodies; also returns the per-body pose quaternions (xyzw)."""
     par = list(np.asarray(parents)) + list(np.asarray(ext_parent))
     off = np.concatenate([np.asarray(local_translation, np.float64), np.asarray(ext_pos, np.float64).reshape(-1, 3)], axis=0)
     rest = np.concatenate([np.asarray(local_rotation_wxyz, np.float64), np.asarray(ext_rot_wxyz, np.float64).reshape(-1, 4)], axis=0)
     rest_m = _quat_xyzw_to_mat(rest[:, [1, 2, 3, 0]])
-    nb, J = len(parents), len(par)
+    J = len(par)
     pose = np.asarray(pose_aa, np.float64)[:, :J]
     T = pose.shape[0]
     pq = _aa_to_quat_xyzw(pose)
@@ -184,6 +183,15 @@ def process_clip_real(parents, local_translation, local_rotation_wxyz, ext_paren
         else:
             wpos[:, i] = wmat[:, par[i]] @ off[i] + wpos[:, par[i]]
             wmat[:, i] = wmat[:, par[i]] @ (rest_m[i] @ pm[:, i])   # :248: parent * rest rotation * joint rotation
+    return wpos, wmat, pq, pose
+
+
+def process_clip_real(parents, local_translation, local_rotation_wxyz, ext_parent, ext_pos, ext_rot_wxyz, pose_aa, root_trans, fps):
+    """Robot clips (H1 / G1): `Humanoid_Batch.fk_batch(..., return_full=True)` (torch_humanoid_batch.py:163-257) in fp64 numpy.
+    pose_aa [T, NB+E, 3]: root axis-angle, one axis*angle row per joint, (zero) rows for the E extended bodies.
+    Returns NB-wide gts/grs/gvs/gavs, (NB+E)-wide gts_t/grs_t, dof_pos / dvs [T,ND], lrs [T,NB+E,4]."""
+    nb = len(parents)
+    wpos, wmat, pq, pose = robot_fk(parents, local_translation, local_rotation_wxyz, ext_parent, ext_pos, ext_rot_wxyz, pose_aa, root_trans)
     wrot = _mat_to_quat_xyzw(wmat)
     dt = 1.0 / fps
     vel = lambda p: gaussian_filter1d(np.gradient(p, axis=0) / dt, 2, axis=0, mode="nearest")
@@ -503,9 +511,8 @@ class MotionLibReal(MotionLibBase):
         if self.fix_height == FixHeightMode.no_fix:
             return trans, 0.0
         m = self.robot_model
-        p = process_clip_real(m.parent, m.local_translation, m.local_rotation, self.ext_parent, self.ext_pos, self.ext_rot, pose_aa[:1], trans[:1], 30)
-        R = _quat_xyzw_to_mat(p["grs"][0])                                          # [NB,3,3]
-        z = p["gts"][0][m.contact_body, 2] + np.einsum("kj,kj->k", R[m.contact_body][:, 2, :], m.contact_pos) - m.contact_radius
+        wpos, wmat, _, _ = robot_fk(m.parent, m.local_translation, m.local_rotation, self.ext_parent, self.ext_pos, self.ext_rot, pose_aa[:1], trans[:1])
+        z = wpos[0][m.contact_body, 2] + np.einsum("kj,kj->k", wmat[0][m.contact_body][:, 2, :], m.contact_pos) - m.contact_radius
         diff = float(z.min())
         trans = trans.copy()
         trans[:, 2] -= diff
