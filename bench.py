@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU (BASELINE configs[1]: 4096)")
     ap.add_argument("--ppo-epochs", type=int, default=3, help="timed PPO epochs (rollout 32 steps + 36 optimizer steps); 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--robot", choices=["smpl", "h1"], default="smpl", help="smpl: BASELINE configs[1] (the bench line); h1: configs[4] morphology "
+                    "(Unitree H1, 19 revolute DoFs, 200 Hz x 4 pd-torque control) -- a parity-test configuration, timed for reference only")
     ap.add_argument("--motion-clips", type=int, default=1, help="synthetic clips in the motion library (configs[1]: 1; configs[2]/[3] shape: thousands)")
     ap.add_argument("--actions", choices=["random", "tracking"], default="random",
                     help="random: fixed a ~ U(-1,1)*0.1 tensor (SURVEY 8d protocol; zero-pose targets -> episodes end after a few steps); "
@@ -160,7 +162,9 @@ def main():
     from phc_amd.config import compose
     from phc_amd.env.tasks.vec_task import parse_task
     torch.manual_seed(rank)  # per-rank seed offset, as the reference's horovod path does (run_hydra.py:121)
-    cfg = compose([f"env.num_envs={args.envs}", f"env.motion_file=synthetic:{args.motion_clips}:0", f"device_id={local_rank}", f"rl_device=cuda:{local_rank}"])
+    robot_over = ["robot=unitree_h1", "env=env_im_h1_phc", "sim=robot_sim", "control=robot_control"] if args.robot == "h1" else []
+    cfg = compose(robot_over + [f"env.num_envs={args.envs}", f"env.motion_file=synthetic:{args.motion_clips}:0", f"device_id={local_rank}",
+                                f"rl_device=cuda:{local_rank}"])
     task, env = parse_task(cfg, device_id=local_rank)
     dev = task.device
     N = task.num_envs
@@ -171,7 +175,12 @@ def main():
 
     def env_step(ev=None):
         task.reset_done()                 # envs that finished on the previous step (device-side mask, no host sync)
-        a = actions if args.actions == "random" else (task.ref_dof_pos - task._pd_action_offset) * inv_scale
+        if args.actions == "random":
+            a = actions
+        elif args.robot == "h1":
+            a = task.ref_dof_pos - task.default_dof_pos
+        else:
+            a = (task.ref_dof_pos - task._pd_action_offset) * inv_scale
         task.pre_physics_step(a)
         if ev is not None:
             ev[0].record()
@@ -210,10 +219,14 @@ def main():
 
     if rank == 0:
         nsub = task.control_freq_inv * int(cfg.sim.substeps)
-        bytes_per_launch = (ABA_BYTES_PER_ENV_SUBSTEP * nsub + PUBLISH_BYTES_PER_ENV_STEP) * N
+        D_, NB_ = task.num_dof, task.num_bodies
+        aba_bytes = 4 * ((13 + 2 * D_ + D_) + (13 + 2 * D_))          # read root+dof+target, write root+dof (1484 B for SMPL)
+        pub_bytes = 4 * (NB_ * 13 + D_ + NB_ * 3)                      # body state + dof force + contact force (1812 B for SMPL)
+        assert args.robot != "smpl" or (aba_bytes, pub_bytes) == (ABA_BYTES_PER_ENV_SUBSTEP, PUBLISH_BYTES_PER_ENV_STEP)
+        bytes_per_launch = (aba_bytes * nsub + pub_bytes) * N
         traffic, traffic_src = None, None  # HBM bytes per launch from the PMC passes (profiles/collect_pmc.sh), not measurable live
         pmc = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json"))
-        if pmc and N == 4096:
+        if pmc and N == 4096 and args.robot == "smpl":
             rec = json.load(open(os.path.join(ROOT, "profiles", pmc[-1]))).get("k_sim_step<true>")
             if rec:
                 traffic, traffic_src = rec["traffic_bytes"], "profiles/" + pmc[-1]
@@ -223,8 +236,11 @@ def main():
             "value": N * world * args.steps / elapsed, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic (AMASS-shaped smooth random clip, seed 0; random-init state from the reference motion)",
-            "config": {"workload": "BASELINE configs[1]: SMPL humanoid 69-DoF, 4096 envs per GPU, single reference motion, "
-                                   "30 Hz control = 2 x simulate @60 Hz x 2 sub-steps", "envs_per_gpu": N, "num_bodies": task.num_bodies,
+            "config": {"workload": ("BASELINE configs[1]: SMPL humanoid 69-DoF, 4096 envs per GPU, single reference motion, "
+                                    "30 Hz control = 2 x simulate @60 Hz x 2 sub-steps") if args.robot == "smpl" else
+                                   ("BASELINE configs[4]: Unitree H1 19-DoF, envs per GPU as given, synthetic retargeted-shape clips, "
+                                    "50 Hz control = 4 x simulate @200 Hz x 2 sub-steps, pd torque mode"),
+                       "envs_per_gpu": N, "num_bodies": task.num_bodies,
                        "obs": task.num_obs, "amp_obs": task.get_num_amp_obs(), "parallelism": f"env-sharded x{world}"},
             "roofline": {"kernel": "k_sim_step<true> (A2 + 4 ABA sub-steps + S7 publication)", "bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,

@@ -26,8 +26,18 @@ __device__ __forceinline__ int group_or(int v) {
 // ------------------------------------------------------------------------------------------
 // post_physics_step of the imitation task.  blockDim = 256 (8 envs).
 // ------------------------------------------------------------------------------------------
+// The task kernels are instantiated per joint family (DPJ = DoFs per joint: 3 spherical / 1 revolute) with the struct fields
+// that select the family pinned to compile-time constants, so the SMPL instantiation carries none of the robot branches.
+template <int DPJ>
+__device__ __forceinline__ void pin_family(phc_motion_lib_t& lib, phc_im_params_t& prm) {
+    lib.dofs_per_joint = DPJ; prm.dofs_per_joint = DPJ;
+    if (DPJ == 3) { lib.num_ext_bodies = 0; prm.num_ext_bodies = 0; }
+}
+
+template <int DPJ>
 __global__ __launch_bounds__(256) void k_im_post_physics(phc_model_t model, phc_motion_lib_t lib, phc_im_params_t prm,
                                                         phc_sim_state_t sim, phc_im_buffers_t buf, int n_reset_bodies) {
+    pin_family<DPJ>(lib, prm);
     const int lane = threadIdx.x & (GRP - 1);
     const int64_t env = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
     if (env >= sim.num_envs) return;  // whole 32-lane group exits together
@@ -56,9 +66,11 @@ __global__ __launch_bounds__(256) void k_im_reset_from_state(phc_model_t model, 
 
 // Reset of a list of envs.  One 32-lane group per (env, AMP history frame k): group k == 0 also imposes the state
 // and recomputes the observations.  blockDim = 256.
+template <int DPJ>
 __global__ __launch_bounds__(256) void k_im_reset(phc_model_t model, phc_motion_lib_t lib, phc_im_params_t prm, phc_sim_state_t sim,
                                                  phc_im_buffers_t buf, int num_reset, const int64_t* __restrict__ env_ids,
                                                  const float* __restrict__ phase, int start_at_zero) {
+    pin_family<DPJ>(lib, prm);
     const int lane = threadIdx.x & (GRP - 1);
     const int64_t g = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
     const int S = prm.num_amp_obs_steps;
@@ -217,7 +229,8 @@ int32_t phc_sample_time_interval(const phc_motion_lib_t* lib, int32_t n, const i
 
 static int32_t check_model(const phc_model_t* m) {
     if (!m || m->num_bodies < 1 || m->num_bodies > PHC_MAX_BODIES || !m->ints || !m->floats) return PHC_EINVAL;
-    if (m->num_dof != 3 * (m->num_bodies - 1)) return PHC_EUNSUPPORTED;  // spherical joints only in this round
+    // all-spherical (SMPL family) or all-revolute (H1 / G1) articulations
+    if (m->num_dof != 3 * (m->num_bodies - 1) && m->num_dof != m->num_bodies - 1) return PHC_EUNSUPPORTED;
     return 0;
 }
 
@@ -243,8 +256,12 @@ int32_t phc_im_post_physics(const phc_model_t* model, const phc_motion_lib_t* li
     if (prm->zero_out_far && (!buf->point_goal || prm->track_slot == nullptr)) return PHC_EINVAL;
     if (sim->num_envs == 0) return 0;
     const int n_reset_bodies = prm->num_reset_bodies > 0 ? prm->num_reset_bodies : 1;
-    hipLaunchKernelGGL(k_im_post_physics, dim3(env_blocks(sim->num_envs, 256)), dim3(256), 0, (hipStream_t)stream, *model, *lib,
-                       *prm, *sim, *buf, n_reset_bodies);
+    if (prm->dofs_per_joint == 1)
+        hipLaunchKernelGGL(k_im_post_physics<1>, dim3(env_blocks(sim->num_envs, 256)), dim3(256), 0, (hipStream_t)stream, *model, *lib,
+                           *prm, *sim, *buf, n_reset_bodies);
+    else
+        hipLaunchKernelGGL(k_im_post_physics<3>, dim3(env_blocks(sim->num_envs, 256)), dim3(256), 0, (hipStream_t)stream, *model, *lib,
+                           *prm, *sim, *buf, n_reset_bodies);
     return launch_status();
 }
 
@@ -255,8 +272,11 @@ int32_t phc_im_reset(const phc_model_t* model, const phc_motion_lib_t* lib, cons
     if (rc) return rc;
     if (!sim || !buf || num_reset < 0 || (!start_at_zero && !phase)) return PHC_EINVAL;
     if (num_reset == 0) return 0;
-    hipLaunchKernelGGL(k_im_reset, dim3(env_blocks((int64_t)num_reset * prm->num_amp_obs_steps, 256)), dim3(256), 0, (hipStream_t)stream, *model, *lib, *prm, *sim,
-                       *buf, num_reset, env_ids, phase, start_at_zero);
+    const dim3 grid(env_blocks((int64_t)num_reset * prm->num_amp_obs_steps, 256));
+    if (prm->dofs_per_joint == 1)
+        hipLaunchKernelGGL(k_im_reset<1>, grid, dim3(256), 0, (hipStream_t)stream, *model, *lib, *prm, *sim, *buf, num_reset, env_ids, phase, start_at_zero);
+    else
+        hipLaunchKernelGGL(k_im_reset<3>, grid, dim3(256), 0, (hipStream_t)stream, *model, *lib, *prm, *sim, *buf, num_reset, env_ids, phase, start_at_zero);
     return launch_status();
 }
 

@@ -389,12 +389,14 @@ def test_h1_env_end_to_end():
     n_done = 0
     for k in range(40):
         task.reset_done()
-        obs, rew, done, info = env.step(torch.randn(256, 19, device=task.device) * 0.3)
+        # PD target = next reference pose (+ noise): torques = p_gains * (action + default_dof_pos - q) - d_gains * qd (humanoid.py:1590)
+        act = task.ref_dof_pos - task.default_dof_pos + torch.randn(256, 19, device=task.device) * 0.05
+        obs, rew, done, info = env.step(act)
         rew_sum += rew
         n_done += int(done.sum())
     torch.cuda.synchronize()
     assert torch.isfinite(obs).all() and torch.isfinite(rew_sum).all() and info["amp_obs"].shape == (256, 630)
-    assert n_done > 0 and (task.progress_buf.max() > 5)
+    assert (task.progress_buf.max() > 5) and rew_sum.mean() > 0.2 * 40 * 0.5, (n_done, float(rew_sum.mean()))
     assert (task._dof_pos.cpu().numpy() > lo - 0.35).all() and (task._dof_pos.cpu().numpy() < hi + 0.35).all(), "joint limits hold the joints"
     assert task.dof_force_tensor.abs().max() <= 350.0 + 2000.0 * 0.4 + 1e-3   # torque limit (+ limit spring when outside the range)
     root, dof = task._root_states.cpu().numpy(), task._dof_state.view(256, 19, 2).cpu().numpy()
