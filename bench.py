@@ -218,7 +218,7 @@ def main():
             ppo = None
 
     if rank == 0:
-        nsub = task.control_freq_inv * int(cfg.sim.substeps)
+        nsub = task.control_freq_inv * int(cfg.sim.get("substeps", 2))
         D_, NB_ = task.num_dof, task.num_bodies
         aba_bytes = 4 * ((13 + 2 * D_ + D_) + (13 + 2 * D_))          # read root+dof+target, write root+dof (1484 B for SMPL)
         pub_bytes = 4 * (NB_ * 13 + D_ + NB_ * 3)                      # body state + dof force + contact force (1812 B for SMPL)
