@@ -209,6 +209,14 @@ int32_t phc_im_reset(const phc_model_t* model, const phc_motion_lib_t* lib, cons
                      const phc_sim_state_t* sim, const phc_im_buffers_t* buf, int32_t num_reset,
                      const int64_t* env_ids, const float* phase /*[num_reset]*/, int32_t start_at_zero, void* stream);
 
+/* `reset_done()`: phc_im_reset's masked mode with the start-time phase drawn INSIDE the kernel, so that the rollout idiom
+ * "reset the envs that are done" is one launch with no host round trip and no auxiliary torch kernels:
+ * phase(env) = 24-bit uniform from a 32-bit avalanche hash of env under the stream key splitmix64(seed, counter) (like
+ * torch.rand: 24 mantissa bits).  The caller advances `counter` per call. */
+int32_t phc_im_reset_done(const phc_model_t* model, const phc_motion_lib_t* lib, const phc_im_params_t* prm,
+                          const phc_sim_state_t* sim, const phc_im_buffers_t* buf, uint64_t seed, uint64_t counter,
+                          int32_t start_at_zero, void* stream);
+
 /* HumanoidImGetup._reset_fall_episode + the shared tail of _reset_envs (humanoid_im_getup.py:166-196, humanoid.py:585-621,
  * humanoid_amp.py:559-573): the caller has written root_states / dof_state of the listed envs (a stored fall state);
  * after phc_refresh_body_state_indexed made their rigid_body_state current, this call zeroes

@@ -77,6 +77,7 @@ _SIGNATURES = {
     "phc_refresh_body_state": ([P(Model), P(SimState), c_p], c_i32),
     "phc_im_post_physics": ([P(Model), P(MotionLib), P(ImParams), P(SimState), P(ImBuffers), c_p], c_i32),
     "phc_im_reset": ([P(Model), P(MotionLib), P(ImParams), P(SimState), P(ImBuffers), c_i32, c_p, c_p, c_i32, c_p], c_i32),
+    "phc_im_reset_done": ([P(Model), P(MotionLib), P(ImParams), P(SimState), P(ImBuffers), C.c_uint64, C.c_uint64, c_i32, c_p], c_i32),
     "phc_im_reset_from_state": ([P(Model), P(MotionLib), P(ImParams), P(SimState), P(ImBuffers), c_i32, c_p, c_i32, c_p], c_i32),
     "phc_refresh_body_state_indexed": ([P(Model), P(SimState), c_i32, c_p, c_p], c_i32),
     "phc_amp_obs_demo": ([P(Model), P(MotionLib), P(ImParams), c_i32, c_p, c_p, c_p, c_p], c_i32),

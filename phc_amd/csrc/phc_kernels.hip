@@ -66,10 +66,26 @@ __global__ __launch_bounds__(256) void k_im_reset_from_state(phc_model_t model, 
 
 // Reset of a list of envs.  One 32-lane group per (env, AMP history frame k): group k == 0 also imposes the state
 // and recomputes the observations.  blockDim = 256.
-template <int DPJ>
+// counter-based uniform in [0,1): the host folds (seed, counter) into one 64-bit stream key (splitmix64); per env a 32-bit
+// avalanche hash (murmur3 finaliser rounds) of the env id under that key, top 24 bits -> float like torch.rand
+__device__ __forceinline__ float hash_u01(uint64_t key, uint32_t env) {
+    uint32_t x = env * 0x9E3779B1u ^ (uint32_t)key;
+    x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+    x += (uint32_t)(key >> 32);
+    x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 12; x *= 0x297A2D39u; x ^= x >> 15;
+    return (float)(x >> 8) * (1.0f / 16777216.0f);
+}
+static inline uint64_t splitmix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+template <int DPJ, bool RNG>
 __global__ __launch_bounds__(256) void k_im_reset(phc_model_t model, phc_motion_lib_t lib, phc_im_params_t prm, phc_sim_state_t sim,
                                                  phc_im_buffers_t buf, int num_reset, const int64_t* __restrict__ env_ids,
-                                                 const float* __restrict__ phase, int start_at_zero) {
+                                                 const float* __restrict__ phase, int start_at_zero, uint64_t rng_key) {
     pin_family<DPJ>(lib, prm);
     const int lane = threadIdx.x & (GRP - 1);
     const int64_t g = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
@@ -83,7 +99,8 @@ __global__ __launch_bounds__(256) void k_im_reset(phc_model_t model, phc_motion_
     if (!env_ids && buf.reset_buf[env] == 0) return;
     const int64_t mid = buf.sampled_motion_ids[env];
     // _sample_ref_state (humanoid_im.py:1000-1023): StateInit.Random -> sample_time_interval; Start / flags.test -> 0
-    const float t = start_at_zero ? 0.f : sample_time_interval(lib, mid, phase[r]);
+    // (start_at_zero with a null phase array is only legal in the RNG-free instantiation's list mode)
+    const float t = start_at_zero ? 0.f : sample_time_interval(lib, mid, RNG ? hash_u01(rng_key, (uint32_t)env) : phase[r]);
     if (k == 0) im_reset_lane(model, lib, prm, sim, buf, env, lane, t, env_ids != nullptr);
     im_reset_amp_lane(lib, prm, buf, model.num_bodies, env, lane, t, k);
 }
@@ -274,9 +291,25 @@ int32_t phc_im_reset(const phc_model_t* model, const phc_motion_lib_t* lib, cons
     if (num_reset == 0) return 0;
     const dim3 grid(env_blocks((int64_t)num_reset * prm->num_amp_obs_steps, 256));
     if (prm->dofs_per_joint == 1)
-        hipLaunchKernelGGL(k_im_reset<1>, grid, dim3(256), 0, (hipStream_t)stream, *model, *lib, *prm, *sim, *buf, num_reset, env_ids, phase, start_at_zero);
+        hipLaunchKernelGGL((k_im_reset<1, false>), grid, dim3(256), 0, (hipStream_t)stream, *model, *lib, *prm, *sim, *buf, num_reset, env_ids, phase, start_at_zero, 0ull);
     else
-        hipLaunchKernelGGL(k_im_reset<3>, grid, dim3(256), 0, (hipStream_t)stream, *model, *lib, *prm, *sim, *buf, num_reset, env_ids, phase, start_at_zero);
+        hipLaunchKernelGGL((k_im_reset<3, false>), grid, dim3(256), 0, (hipStream_t)stream, *model, *lib, *prm, *sim, *buf, num_reset, env_ids, phase, start_at_zero, 0ull);
+    return launch_status();
+}
+
+int32_t phc_im_reset_done(const phc_model_t* model, const phc_motion_lib_t* lib, const phc_im_params_t* prm, const phc_sim_state_t* sim,
+                          const phc_im_buffers_t* buf, uint64_t seed, uint64_t counter, int32_t start_at_zero, void* stream) {
+    int32_t rc = check_im(model, lib, prm);
+    if (rc) return rc;
+    if (!sim || !buf) return PHC_EINVAL;
+    if (sim->num_envs == 0) return 0;
+    const int n = sim->num_envs;
+    const uint64_t key = splitmix64(splitmix64(seed) ^ (counter * 0xD1342543DE82EF95ull));
+    const dim3 grid(env_blocks((int64_t)n * prm->num_amp_obs_steps, 256));
+    if (prm->dofs_per_joint == 1)
+        hipLaunchKernelGGL((k_im_reset<1, true>), grid, dim3(256), 0, (hipStream_t)stream, *model, *lib, *prm, *sim, *buf, n, nullptr, nullptr, start_at_zero, key);
+    else
+        hipLaunchKernelGGL((k_im_reset<3, true>), grid, dim3(256), 0, (hipStream_t)stream, *model, *lib, *prm, *sim, *buf, n, nullptr, nullptr, start_at_zero, key);
     return launch_status();
 }
 

@@ -351,6 +351,8 @@ class HumanoidIm:
         self._global_offset = torch.zeros((N, 3), **f32)
         self._cycle_counter = torch.zeros(N, device=dev, dtype=torch.int)
         self._point_goal = torch.zeros(N, **f32)                 # humanoid_im.py:95
+        self._reset_seed = int(torch.initial_seed()) & 0x7FFFFFFFFFFFFFFF
+        self._reset_counter = 0
         self._cycle_phase = torch.zeros(N, **f32) if self.cycle_motion else None
         if not hasattr(self, "_recovery_counter"):
             self._recovery_counter = None                        # HumanoidImGetup owns one
@@ -537,7 +539,8 @@ class HumanoidIm:
 
     def pre_physics_step(self, actions):
         # humanoid.py:1522-1572: the action -> PD-target map itself runs inside phc_sim_step
-        self.actions = actions.to(self.device).clone()
+        # (the reference clones; the stepper only reads the tensor during this call, so the caller's buffer is used as is)
+        self.actions = actions.to(self.device)
         if self.actions.dim() == 1:
             self.actions = self.actions[None]
         if self.control_mode == "pd":
@@ -604,16 +607,15 @@ class HumanoidIm:
         self._reset_ref_motion_times = self._motion_start_times[env_ids]
 
     def reset_done(self):
-        """MI355X-first variant of the rollout idiom `env.reset(reset_buf.nonzero())` (amp_agent.py:318-319): resets
-        exactly the envs whose reset_buf is set, on the device, without the device->host sync of `.nonzero()`.
-        One torch.rand(num_envs) is drawn per call (the reference draws len(env_ids) numbers)."""
+        """MI355X-first variant of the rollout idiom `env.reset(reset_buf.nonzero())` (amp_agent.py:318-319): ONE launch resets
+        exactly the envs whose reset_buf is set -- no `.nonzero()` device->host sync, the start-time phase is drawn in the kernel
+        (counter-based hash seeded from torch's seed; the reference draws torch.rand(len(env_ids))), and the flags are not
+        zeroed afterwards: nothing reads reset_buf before the next post-physics launch rewrites every entry of it."""
         start_at_zero = (self._state_init == HumanoidIm.StateInit.Start) or flags.test
-        phase = torch.rand(self.num_envs, device=self.device)
         cur = self._amp_bufs[self._amp_cur]
-        buf = self._buffers(cur, cur)
-        L.check(self._lib.phc_im_reset(self._model_struct, self._motion_lib.struct, self._im_params, self._sim_struct, buf, self.num_envs,
-                                       None, phase.data_ptr(), int(bool(start_at_zero)), _stream()), "phc_im_reset")
-        self.reset_buf.zero_()  # only the envs just reset had the flag set (humanoid.py:617)
+        self._reset_counter += 1
+        L.check(self._lib.phc_im_reset_done(self._model_struct, self._motion_lib.struct, self._im_params, self._sim_struct, self._buffers(cur, cur),
+                                            self._reset_seed, self._reset_counter, int(bool(start_at_zero)), _stream()), "phc_im_reset_done")
 
     # ------------------------------------------------------------------ AMP demo observations (humanoid_amp.py:215-284)
     def fetch_amp_obs_demo(self, num_samples):

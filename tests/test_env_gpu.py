@@ -166,8 +166,14 @@ def test_rollout_episode_bookkeeping_and_reset_done():
             task.reset_done()
         torch.cuda.synchronize()
         if len(ids):
-            assert (task.progress_buf[ids] == 0).all() and (task.reset_buf[ids] == 0).all()
+            assert (task.progress_buf[ids] == 0).all()
+            if it % 2 == 0:
+                assert (task.reset_buf[ids] == 0).all()      # reset(env_ids) clears the flags; reset_done() leaves them to the next step
             t = task._motion_start_times[ids]
+            lens = task._motion_lib._motion_lengths[task._sampled_motion_ids[ids]]
+            assert (t >= 0).all() and (t < lens).all() and torch.allclose(t * 30, torch.round(t * 30), atol=1e-3)   # sample_time_interval grid
+            if len(ids) > 8:
+                assert t.unique().numel() > 2, "in-kernel phase draw must vary across envs"
             res = task._motion_lib.get_motion_state(task._sampled_motion_ids[ids], t)
             assert torch.allclose(task._rigid_body_pos[ids], res["rg_pos"], atol=1e-5)
             assert torch.allclose(task._dof_pos[ids], res["dof_pos"], atol=1e-5)
