@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--robot", choices=["smpl", "h1"], default="smpl", help="smpl: BASELINE configs[1] (the bench line); h1: configs[4] morphology "
                     "(Unitree H1, 19 revolute DoFs, 200 Hz x 4 pd-torque control) -- a parity-test configuration, timed for reference only")
+    ap.add_argument("--lane-mapping", type=int, default=0, help="stepper thread mapping (phc_sim_params_t.lane_mapping): 0 auto, 1 one body "
+                    "per lane (32 lanes/env), 2 two bodies per lane (16 lanes/env)")
     ap.add_argument("--motion-clips", type=int, default=1, help="synthetic clips in the motion library (configs[1]: 1; configs[2]/[3] shape: thousands)")
     ap.add_argument("--actions", choices=["random", "tracking"], default="random",
                     help="random: fixed a ~ U(-1,1)*0.1 tensor (SURVEY 8d protocol; zero-pose targets -> episodes end after a few steps); "
@@ -164,7 +166,7 @@ def main():
     torch.manual_seed(rank)  # per-rank seed offset, as the reference's horovod path does (run_hydra.py:121)
     robot_over = ["robot=unitree_h1", "env=env_im_h1_phc", "sim=robot_sim", "control=robot_control"] if args.robot == "h1" else []
     cfg = compose(robot_over + [f"env.num_envs={args.envs}", f"env.motion_file=synthetic:{args.motion_clips}:0", f"device_id={local_rank}",
-                                f"rl_device=cuda:{local_rank}"])
+                                f"rl_device=cuda:{local_rank}", f"+solver.lane_mapping={args.lane_mapping}"])
     task, env = parse_task(cfg, device_id=local_rank)
     dev = task.device
     N = task.num_envs

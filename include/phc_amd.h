@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PHC_ABI_VERSION 3
+#define PHC_ABI_VERSION 4
 #define PHC_MAX_BODIES 32
 #define PHC_EINVAL (-1)
 #define PHC_EUNSUPPORTED (-2)
@@ -42,6 +42,8 @@ typedef struct {
     int32_t num_contact_pts;
     const int32_t* ints;      /* packed tables, see model.py pack() */
     const float* floats;
+    int32_t split_level;      /* two-slot stepper mapping: bodies of tree levels < split_level share lanes with the deeper ones; */
+    int32_t num_below_split;  /* -1 / 0 when the tree has no split with both halves <= 16 bodies (ArticulationModel.two_slot_split) */
 } phc_model_t;
 
 /* Flat reference-motion buffer.  Replaces MotionLibBase's gts/grs/lrs/gvs/gavs/dvs tensors
@@ -97,6 +99,8 @@ typedef struct {
                                          links).  1 and 2: revolute models only. */
     float limit_stiffness;            /* joint-limit penalty spring N m/rad outside [lower, upper] (revolute models; 0 = off) */
     float limit_damping;              /* N m s/rad */
+    int32_t lane_mapping;             /* stepper thread mapping: 2 = 16 lanes per env, two bodies per lane, 4 envs per wavefront;
+                                         1 = 32 lanes per env, one body per lane, 2 envs per wavefront; 0 = pick by env count */
 } phc_sim_params_t;
 
 /* Imitation-task parameters (phc/env/tasks/humanoid_im.py:37-123, env_im.yaml). */

@@ -54,7 +54,7 @@ def P(s):
 def np_model(name="smpl_humanoid", kp_scale=1.0, kd_scale=1.0):
     m = load_model(name)
     ints, floats = m.pack(kp_scale, kd_scale)
-    return m, abi.model_struct(ints, floats, m.num_bodies, m.num_dof, m.max_level, len(m.contact_body)), (ints, floats)
+    return m, abi.model_struct(ints, floats, m.num_bodies, m.num_dof, m.max_level, len(m.contact_body), split=m.two_slot_split()), (ints, floats)
 
 
 def np_motion_lib(lib):

@@ -30,7 +30,7 @@ namespace phc {
 #define PHC_BODY_FLOATS 36     // floats per body in phc_model_t.floats (model.py pack())
 #define PHC_JT_SPHERICAL 1     // joint types as model.py numbers them
 #define PHC_JT_REVOLUTE 2
-#define PHC_NTAB 11            // int tables per model (parent level jtype dof_start child0-2 nchild cp_start cp_count order)
+#define PHC_NTAB 12            // int tables per model (parent level jtype dof_start child0-2 nchild cp_start cp_count order misc)
 
 struct Sym3 { float xx, xy, xz, yy, yz, zz; };
 

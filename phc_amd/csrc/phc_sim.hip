@@ -74,11 +74,87 @@ __global__ __launch_bounds__(64, 2) void k_sim_step(phc_model_t model, phc_sim_p
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Two-slot variant of the step kernel: 16 lanes per env, FOUR envs per wavefront, each lane carries two bodies -- slot A a
+// body of the shallow tree levels (< split), slot B one of the deep levels.  At any tree level all active bodies sit in one
+// slot, so a level-step executes exactly one copy of the level code (wave-uniform branch), as in the 32-lane kernel, but the
+// launch has half the wavefronts.  Measured on MI355X (scripts/gpu_sweep_small.sh): the 32-lane kernel takes 76-85 us with
+// one wavefront per SIMD (<= 2048 envs) and 106 us with two or three (4096-6144 envs) -- it is bound by the latency of one
+// wavefront's 72 dependent level-steps, so halving the wavefront count at N = 4096 moves it onto the one-per-SIMD plateau.
+// ------------------------------------------------------------------------------------------
+template <int JT>
+__global__ __launch_bounds__(64, 1) void k_sim_step16(phc_model_t model, phc_sim_params_t prm, phc_sim_state_t sim,
+                                                  const float* __restrict__ actions, const float* __restrict__ pd_off,
+                                                  const float* __restrict__ pd_scale, const int32_t* __restrict__ freeze,
+                                                  int num_sim_calls) {
+    __shared__ float xch_all[4 * PHC_MAX_BODIES * PHC_XCH_STRIDE];
+    const int lane = threadIdx.x & 15;
+    const int grp = threadIdx.x >> 4;
+    const int64_t env = (int64_t)blockIdx.x * 4 + grp;
+    const int nb = model.num_bodies, nd = model.num_dof;
+    const int split = model.split_level, nA = model.num_below_split;
+    const bool env_ok = env < sim.num_envs;
+    const int jA = (env_ok && lane < nA) ? model_tab(model, 10, lane) : -1;
+    const int jB = (env_ok && lane < nb - nA) ? model_tab(model, 10, nA + lane) : -1;
+    Xch x;
+    x.base = xch_all + grp * PHC_MAX_BODIES * PHC_XCH_STRIDE;
+    constexpr int ndj = JT == PHC_JT_REVOLUTE ? 1 : 3;
+
+    AbaLane LA, LB;
+    LA.level = LB.level = -1;
+    auto load = [&](AbaLane& L, int j) {
+        aba_load_model(L, model, j);
+        if (JT == PHC_JT_REVOLUTE) aba_load_model_rev(L, model, j);
+        if (actions != nullptr && j >= 1) {
+            for (int k = 0; k < ndj; ++k) {  // A2: pd_tar = offset + scale * action, frozen DoFs -> 0 (humanoid.py:1711-1713,1549-1554)
+                const int d = L.dof_start + k;
+                float t = __fadd_rn(pd_off[d], __fmul_rn(pd_scale[d], actions[env * nd + d]));
+                if (freeze != nullptr && freeze[d]) t = 0.f;
+                sim.pd_target[env * nd + d] = t;
+            }
+        }
+        aba_load_state<JT>(L, sim, nd, env, j);
+    };
+    if (jA >= 0) load(LA, jA);
+    if (jB >= 0) load(LB, jB);
+    const int max_level = model.max_level;
+    for (int l = 0; l <= max_level; ++l) {
+        if (l < split) aba_fk_level(LA, l, jA, x); else aba_fk_level(LB, l, jB, x);
+        __syncthreads();
+    }
+    const float dt = prm.sim_dt / (float)prm.substeps;
+    const int nsub = num_sim_calls * prm.substeps;
+    for (int s = 0; s < nsub; ++s) {
+        const bool fresh = s % prm.substeps == 0;
+        if (jA >= 0) aba_body_init<JT>(LA, model, prm, dt, jA, fresh);
+        if (jB >= 0) aba_body_init<JT>(LB, model, prm, dt, jB, fresh);
+        for (int l = max_level; l >= 0; --l) {
+            if (l < split) aba_backward_level<JT>(LA, l, jA, x); else aba_backward_level<JT>(LB, l, jB, x);
+            __syncthreads();
+        }
+        for (int l = 0; l <= max_level; ++l) {
+            if (l < split) aba_forward_level<JT>(LA, l, jA, x, prm, dt); else aba_forward_level<JT>(LB, l, jB, x, prm, dt);
+            __syncthreads();
+        }
+    }
+    if (jA >= 0) { aba_store_state<JT>(LA, sim, nd, env, jA); aba_publish_body(LA, sim, nb, env, jA, true); }
+    if (jB >= 0) { aba_store_state<JT>(LB, sim, nd, env, jB); aba_publish_body(LB, sim, nb, env, jB, true); }
+}
+
 template <bool STEP>
 static void sim_launch(const phc_model_t* model, const phc_sim_params_t& prm, const phc_sim_state_t* sim, const float* actions,
                        const float* off, const float* scale, const int32_t* freeze, int num_sim_calls, hipStream_t stream,
-                       const int64_t* env_ids = nullptr, int num_listed = 0) {
+                       const int64_t* env_ids = nullptr, int num_listed = 0, bool two_slot = false) {
     const int64_t groups = env_ids ? num_listed : sim->num_envs;
+    if (STEP && two_slot) {
+        if (model->num_dof == model->num_bodies - 1 && model->num_bodies > 2)
+            hipLaunchKernelGGL((k_sim_step16<PHC_JT_REVOLUTE>), dim3((groups + 3) / 4), dim3(64), 0, stream, *model, prm, *sim, actions, off, scale,
+                               freeze, num_sim_calls);
+        else
+            hipLaunchKernelGGL((k_sim_step16<PHC_JT_SPHERICAL>), dim3((groups + 3) / 4), dim3(64), 0, stream, *model, prm, *sim, actions, off, scale,
+                               freeze, num_sim_calls);
+        return;
+    }
     if (model->num_dof == model->num_bodies - 1 && model->num_bodies > 2)  // one revolute joint per body (robots)
         hipLaunchKernelGGL((k_sim_step<STEP, PHC_JT_REVOLUTE>), dim3((groups + 1) / 2), dim3(64), 0, stream, *model, prm, *sim, actions, off,
                            scale, freeze, num_sim_calls, env_ids, num_listed);
@@ -109,7 +185,22 @@ int32_t phc_sim_step(const phc_model_t* model, const phc_sim_params_t* params, c
     if (!params || !sim || sim->num_envs < 0 || params->substeps < 1 || num_sim_calls < 0) return PHC_EINVAL;
     if (actions && (!pd_action_offset || !pd_action_scale)) return PHC_EINVAL;
     if (sim->num_envs == 0) return 0;
-    sim_launch<true>(model, *params, sim, actions, pd_action_offset, pd_action_scale, freeze_mask, num_sim_calls, (hipStream_t)stream);
+    // lane_mapping 1 / 2 force a kernel; 0 picks.  Measured on MI355X at N = 4096 (scripts/gpu_map.sh): SMPL (tree depth 8, 2.8 contact
+    // points per body) 106 us one-body-per-lane vs 89 us two-slot; H1 (depth 5, 12.8 contact points per body, 8 sub-steps) 104 vs
+    // 126 us -- the two-slot kernel runs the per-body initialisation (inertia rotation, contacts, drive) twice per sub-step, which
+    // only pays off when the level sweeps dominate, and it needs ~320 registers per lane (one wavefront per SIMD), so it only wins
+    // while its N/4 wavefronts fit the chip in one round (N <= 4 x #SIMDs = 4096 on MI355X; profiles/r01_env_count_sweep.json).
+    static int num_simds = 0;
+    if (num_simds == 0) {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        num_simds = 4 * (cus > 0 ? cus : 256);
+    }
+    const bool can_split = model->split_level > 0 && model->num_below_split <= 16 && model->num_bodies - model->num_below_split <= 16;
+    const bool two_slot = can_split && (params->lane_mapping == 2 || (params->lane_mapping == 0 && model->max_level >= 7 &&
+                                                                      (int64_t)sim->num_envs <= 4 * (int64_t)num_simds));
+    sim_launch<true>(model, *params, sim, actions, pd_action_offset, pd_action_scale, freeze_mask, num_sim_calls, (hipStream_t)stream, nullptr, 0,
+                     two_slot);
     return launch_status();
 }
 

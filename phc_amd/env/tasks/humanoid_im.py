@@ -198,7 +198,7 @@ class HumanoidIm:
         self._model_ints = torch.from_numpy(ints).to(self.device)
         self._model_floats = torch.from_numpy(floats).to(self.device)
         self._model_struct = abi.model_struct(self._model_ints, self._model_floats, self.num_bodies, self.num_dof,
-                                              self.model.max_level, len(self.model.contact_body))
+                                              self.model.max_level, len(self.model.contact_body), split=self.model.two_slot_split())
         self.humanoid_masses = [self.model.total_mass] * min(self.num_envs, 10)
         groups = robot.get("limb_weight_group", []) if self._is_robot else (
             ['L_Hip', 'L_Knee', 'L_Ankle', 'L_Toe'], ['R_Hip', 'R_Knee', 'R_Ankle', 'R_Toe'],
@@ -311,7 +311,8 @@ class HumanoidIm:
             # spring term is held) or "held" (mode 1: the reference's letter, unstable on unloaded light links -- DESIGN.md)
             control_mode=0 if self.control_mode == "isaac_pd" else (1 if solver.get("pd_damping", "continuous") == "held" else 2),
             limit_stiffness=float(solver.get("joint_limit_stiffness", 2000.0 if self._is_robot else 0.0)),
-            limit_damping=float(solver.get("joint_limit_damping", 20.0 if self._is_robot else 0.0)))
+            limit_damping=float(solver.get("joint_limit_damping", 20.0 if self._is_robot else 0.0)),
+            lane_mapping=int(solver.get("lane_mapping", 0)))
 
         # ---- action scaling (A1) + freeze masks (humanoid.py:1331-1409,1549-1554) ----
         self.dof_limits_lower, self.dof_limits_upper = (torch.from_numpy(x).to(dev) for x in self.model.dof_limits())

@@ -309,21 +309,32 @@ class ArticulationModel:
             ch[self.parent[i]].append(i)
         return ch
 
+    def two_slot_split(self):
+        """(split level, bodies below it) for the stepper's two-slot mapping: slot A = bodies of levels < split, slot B = the rest,
+        both <= 16 bodies, as balanced as possible; (-1, 0) when the tree admits no such split (the 32-lane kernel is used)."""
+        best = (-1, 0)
+        for split in range(1, self.max_level + 1):
+            nA = int((self.level < split).sum())
+            if nA <= 16 and self.num_bodies - nA <= 16 and (best[0] < 0 or abs(2 * nA - self.num_bodies) < abs(2 * best[1] - self.num_bodies)):
+                best = (split, nA)
+        return best
+
     # ---- packed buffers --------------------------------------------------------------------
     def pack(self, kp_scale=1.0, kd_scale=1.0):
         """-> (ints int32[...], floats float32[...]) laid out as csrc/phc_model.h expects.
 
         ints  : [0]=NB [1]=ND [2]=max_level [3]=NCP then per body (32 slots each):
                 parent, level, joint_type, dof_start, child0, child1, child2, nchild,
-                cp_start, cp_count, order (bodies sorted by level)
+                cp_start, cp_count, order (bodies sorted by level), misc [split level, bodies below it]
         floats: per body (32 slots x 36): r_local[3], mass, m*com[3], Io(xx,xy,xz,yy,yz,zz)[6],
                 kp[3], kd[3], armature[3], effort[3], axis[3] (revolute), rest rotation xyzw[4], limit lo/hi [2], pad[2] ;
                 then contact points NCP x 4 (pos[3], radius)
         """
         NB, MB = self.num_bodies, self.MAX_BODIES
-        ints = np.zeros(4 + 11 * MB, dtype=np.int32)
+        NT = 12
+        ints = np.zeros(4 + NT * MB, dtype=np.int32)
         ints[0:4] = [NB, self.num_dof, self.max_level, len(self.contact_body)]
-        tab = ints[4:].reshape(11, MB)
+        tab = ints[4:].reshape(NT, MB)
         tab[0, :] = -1
         tab[1, :] = -1
         tab[4:7, :] = -1
@@ -340,7 +351,10 @@ class ArticulationModel:
             idx = np.nonzero(self.contact_body == i)[0]
             tab[8, i] = idx[0] if len(idx) else 0
             tab[9, i] = len(idx)
-        tab[10, :NB] = np.argsort(self.level, kind="stable")  # bodies sorted by tree level (level-major stepper mapping)
+        tab[10, :NB] = np.argsort(self.level, kind="stable")  # bodies sorted by tree level
+        # two-slot mapping of the stepper (16 lanes per env, 4 envs per wavefront): slot A = bodies of levels < split, slot B = the
+        # rest, both <= 16 bodies, so that at every tree level all active bodies sit in the same slot.  tab[11] = [split, nA].
+        tab[11, 0:2] = self.two_slot_split()
         BF = self.BODY_FLOATS
         fl = np.zeros((MB, BF), dtype=np.float64)
         fl[:, 31] = 1.0  # identity rest rotation (xyzw)

@@ -248,3 +248,24 @@ def test_h1_settles_on_its_feet(backend, control_mode):
     np.testing.assert_allclose(np.mean(fz[8:], axis=0), 51.436 * 9.81, rtol=0.25)   # feet carry the weight
     cf = be.np(a["cf"])
     assert (np.abs(cf[:, [5, 10], 2]).sum(-1) > 0.9 * np.abs(cf[:, :, 2]).sum(-1)).all(), "only the ankle links touch the ground"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,nd", [("smpl_humanoid", 69), ("h1_humanoid", 19)])
+def test_two_slot_mapping_equals_one_body_per_lane(name, nd):
+    """k_sim_step16 (16 lanes per env, two bodies per lane, 4 envs per wavefront) runs the same per-lane functions in the same
+    order as k_sim_step (one body per lane), also for env counts that do not fill the last wavefront.  The stepper TU is built with
+    -ffast-math, so the two instantiations may contract / reassociate differently: equality to a few ulp, not bit-identity."""
+    be = get_backend("hip")
+    model, mstruct, keep = model_on(be, name)
+    rng = np.random.default_rng(5)
+    for n in (1, 7, 64):
+        root, dof, target = random_states(model, n, rng, height=0.9, pose=0.3 if nd == 19 else 0.5)
+        outs = []
+        for mapping in (1, 2):
+            kw = dict(sim_dt=1 / 200, control_freq_inv=4, control_mode=2, limit_stiffness=2000.0, limit_damping=20.0) if nd == 19 else {}
+            params = abi.sim_params_struct(lane_mapping=mapping, **kw)
+            outs.append(run_step(be, model, mstruct, root, dof, target, params, 2))
+        for k in ("root", "dof", "rbs", "cf", "df"):
+            np.testing.assert_allclose(outs[0][k], outs[1][k], rtol=1e-4, atol={"cf": 5e-2, "df": 5e-3}.get(k, 1e-4), err_msg=f"{name} n={n} {k}")
+        assert np.isfinite(outs[0]["rbs"]).all()
