@@ -229,7 +229,8 @@ def main():
         traffic, traffic_src = None, None  # HBM bytes per launch from the PMC passes (profiles/collect_pmc.sh), not measurable live
         pmc = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json"))
         if pmc and N == 4096 and args.robot == "smpl":
-            rec = json.load(open(os.path.join(ROOT, "profiles", pmc[-1]))).get("k_sim_step<true>")
+            tab = json.load(open(os.path.join(ROOT, "profiles", pmc[-1])))
+            rec = next((v for k, v in tab.items() if k.startswith("k_sim_step16")), None) or next((v for k, v in tab.items() if k.startswith("k_sim_step<true")), None)
             if rec:
                 traffic, traffic_src = rec["traffic_bytes"], "profiles/" + pmc[-1]
         achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
@@ -244,7 +245,7 @@ def main():
                                     "50 Hz control = 4 x simulate @200 Hz x 2 sub-steps, pd torque mode"),
                        "envs_per_gpu": N, "num_bodies": task.num_bodies,
                        "obs": task.num_obs, "amp_obs": task.get_num_amp_obs(), "parallelism": f"env-sharded x{world}"},
-            "roofline": {"kernel": "k_sim_step<true> (A2 + 4 ABA sub-steps + S7 publication)", "bound": "hbm", "achieved": achieved,
+            "roofline": {"kernel": "phc_sim_step: k_sim_step16 / k_sim_step (A2 + %d ABA sub-steps + S7 publication)" % nsub, "bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
                          "note": "latency/ALU-bound tree sweep: SURVEY 8(d) canonical un-fused accounting (1484 B x 4 sub-steps + 1812 B "
