@@ -235,7 +235,8 @@ PHC_HD void aba_body_init(AbaLane& L, const phc_model_t& m, const phc_sim_params
     L.fcontact = v3(0.f, 0.f, 0.f);
     const float cn = prm.contact_stiffness * dt + prm.contact_damping;
     const float* cp = m.floats + PHC_MAX_BODIES * PHC_BODY_FLOATS + model_tab(m, 8, j) * 4;
-    const int cp_count = model_tab(m, 9, j);
+    // broad phase: f[34] bounds |contact point| + radius, so above that height nothing of this body reaches the plane
+    const int cp_count = (L.p.z < f[34]) ? model_tab(m, 9, j) : 0;
     for (int k = 0; k < cp_count; ++k) {
         V3 arm = mat_mul(R, v3(cp[4 * k], cp[4 * k + 1], cp[4 * k + 2]));
         float rad = cp[4 * k + 3];

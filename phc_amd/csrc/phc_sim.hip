@@ -126,16 +126,14 @@ __global__ __launch_bounds__(64, 1) void k_sim_step16(phc_model_t model, phc_sim
     const int nsub = num_sim_calls * prm.substeps;
     for (int s = 0; s < nsub; ++s) {
         const bool fresh = s % prm.substeps == 0;
-        if (jA >= 0) aba_body_init<JT>(LA, model, prm, dt, jA, fresh);
+        // slot A's articulated quantities are initialised only when the sweep reaches its levels: while the deep (slot B) levels
+        // run, slot A holds kinematic state only (27 fewer live registers)
         if (jB >= 0) aba_body_init<JT>(LB, model, prm, dt, jB, fresh);
-        for (int l = max_level; l >= 0; --l) {
-            if (l < split) aba_backward_level<JT>(LA, l, jA, x); else aba_backward_level<JT>(LB, l, jB, x);
-            __syncthreads();
-        }
-        for (int l = 0; l <= max_level; ++l) {
-            if (l < split) aba_forward_level<JT>(LA, l, jA, x, prm, dt); else aba_forward_level<JT>(LB, l, jB, x, prm, dt);
-            __syncthreads();
-        }
+        for (int l = max_level; l >= split; --l) { aba_backward_level<JT>(LB, l, jB, x); __syncthreads(); }
+        if (jA >= 0) aba_body_init<JT>(LA, model, prm, dt, jA, fresh);
+        for (int l = split - 1; l >= 0; --l) { aba_backward_level<JT>(LA, l, jA, x); __syncthreads(); }
+        for (int l = 0; l < split; ++l) { aba_forward_level<JT>(LA, l, jA, x, prm, dt); __syncthreads(); }
+        for (int l = split; l <= max_level; ++l) { aba_forward_level<JT>(LB, l, jB, x, prm, dt); __syncthreads(); }
     }
     if (jA >= 0) { aba_store_state<JT>(LA, sim, nd, env, jA); aba_publish_body(LA, sim, nb, env, jA, true); }
     if (jB >= 0) { aba_store_state<JT>(LB, sim, nd, env, jB); aba_publish_body(LB, sim, nb, env, jB, true); }

@@ -327,7 +327,7 @@ class ArticulationModel:
                 parent, level, joint_type, dof_start, child0, child1, child2, nchild,
                 cp_start, cp_count, order (bodies sorted by level), misc [split level, bodies below it]
         floats: per body (32 slots x 36): r_local[3], mass, m*com[3], Io(xx,xy,xz,yy,yz,zz)[6],
-                kp[3], kd[3], armature[3], effort[3], axis[3] (revolute), rest rotation xyzw[4], limit lo/hi [2], pad[2] ;
+                kp[3], kd[3], armature[3], effort[3], axis[3] (revolute), rest rotation xyzw[4], limit lo/hi [2], contact bound radius, pad ;
                 then contact points NCP x 4 (pos[3], radius)
         """
         NB, MB = self.num_bodies, self.MAX_BODIES
@@ -376,6 +376,9 @@ class ArticulationModel:
                     fl[i, 32], fl[i, 33] = lo[s], hi[s]
             w, x, y, z = self.local_rotation[i]
             fl[i, 28:32] = [x, y, z, w]
+            idx = np.nonzero(self.contact_body == i)[0]
+            # contact broad phase: no point of the body can touch z = 0 while the body origin is higher than this
+            fl[i, 34] = (np.linalg.norm(self.contact_pos[idx], axis=-1) + self.contact_radius[idx]).max() * 1.0001 if len(idx) else 0.0
         cp = np.concatenate([self.contact_pos, self.contact_radius[:, None]], axis=1) if len(self.contact_body) else np.zeros((0, 4))
         floats = np.concatenate([fl.reshape(-1), cp.reshape(-1)]).astype(np.float32)
         return ints, floats
