@@ -88,11 +88,9 @@ __global__ __launch_bounds__(256) void k_im_reset(phc_model_t model, phc_motion_
                                                  const float* __restrict__ phase, int start_at_zero, uint64_t rng_key) {
     pin_family<DPJ>(lib, prm);
     const int lane = threadIdx.x & (GRP - 1);
-    const int64_t g = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
-    const int S = prm.num_amp_obs_steps;
-    if (g >= (int64_t)num_reset * S) return;
-    const int64_t r = g / S;
-    const int k = (int)(g - r * S);
+    const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;   // listed env (grid.x), AMP history frame k (grid.y)
+    const int k = (int)blockIdx.y;
+    if (r >= num_reset) return;
     // env_ids == NULL: masked mode over all envs (reset every env whose reset_buf is set) -- no host sync needed.
     // The flag is NOT cleared here (other groups of the same env still read it): the caller zeroes reset_buf afterwards.
     const int64_t env = env_ids ? env_ids[r] : r;
@@ -110,12 +108,11 @@ __global__ __launch_bounds__(256) void k_amp_obs_demo(phc_model_t model, phc_mot
                                                      const int64_t* __restrict__ motion_ids, const float* __restrict__ times0,
                                                      float* __restrict__ out) {
     const int lane = threadIdx.x & (GRP - 1);
-    const int64_t g = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;   // sample (grid.x), history step k (grid.y)
+    const int k = (int)blockIdx.y;
     const int S = prm.num_amp_obs_steps, A = prm.num_amp_obs_per_step;
-    if (g >= (int64_t)n * S) return;
-    const int64_t i = g / S;
-    const int k = (int)(g - i * S);
-    amp_obs_from_ref_lane(lib, prm, model.num_bodies, lane, motion_ids[i], history_time(times0[i], prm.dt, k), out + g * A);
+    if (i >= n) return;
+    amp_obs_from_ref_lane(lib, prm, model.num_bodies, lane, motion_ids[i], history_time(times0[i], prm.dt, k), out + (i * S + k) * A);
 }
 
 // M9 standalone: get_motion_state for n (id, time) pairs.  One 32-lane group per lookup.
@@ -289,7 +286,7 @@ int32_t phc_im_reset(const phc_model_t* model, const phc_motion_lib_t* lib, cons
     if (rc) return rc;
     if (!sim || !buf || num_reset < 0 || (!start_at_zero && !phase)) return PHC_EINVAL;
     if (num_reset == 0) return 0;
-    const dim3 grid(env_blocks((int64_t)num_reset * prm->num_amp_obs_steps, 256));
+    const dim3 grid(env_blocks(num_reset, 256), prm->num_amp_obs_steps);
     if (prm->dofs_per_joint == 1)
         hipLaunchKernelGGL((k_im_reset<1, false>), grid, dim3(256), 0, (hipStream_t)stream, *model, *lib, *prm, *sim, *buf, num_reset, env_ids, phase, start_at_zero, 0ull);
     else
@@ -305,7 +302,7 @@ int32_t phc_im_reset_done(const phc_model_t* model, const phc_motion_lib_t* lib,
     if (sim->num_envs == 0) return 0;
     const int n = sim->num_envs;
     const uint64_t key = splitmix64(splitmix64(seed) ^ (counter * 0xD1342543DE82EF95ull));
-    const dim3 grid(env_blocks((int64_t)n * prm->num_amp_obs_steps, 256));
+    const dim3 grid(env_blocks(n, 256), prm->num_amp_obs_steps);
     if (prm->dofs_per_joint == 1)
         hipLaunchKernelGGL((k_im_reset<1, true>), grid, dim3(256), 0, (hipStream_t)stream, *model, *lib, *prm, *sim, *buf, n, nullptr, nullptr, start_at_zero, key);
     else
@@ -331,7 +328,7 @@ int32_t phc_amp_obs_demo(const phc_model_t* model, const phc_motion_lib_t* lib, 
     if (rc) return rc;
     if (n < 0) return PHC_EINVAL;
     if (n == 0) return 0;
-    hipLaunchKernelGGL(k_amp_obs_demo, dim3(env_blocks((int64_t)n * prm->num_amp_obs_steps, 256)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(k_amp_obs_demo, dim3(env_blocks(n, 256), prm->num_amp_obs_steps), dim3(256), 0, (hipStream_t)stream,
                        *model, *lib, *prm, n, motion_ids, motion_times0, amp_obs_demo);
     return launch_status();
 }

@@ -40,16 +40,20 @@ PHC_HD FrameRef frame_ref(const phc_motion_lib_t& lib, int64_t mid, float time) 
     PHC_NO_CONTRACT
     float len = lib.motion_lengths[mid];
     float dt = lib.motion_dt[mid];
-    int64_t nf = lib.motion_num_frames[mid];
+    // frame counts are far below 2^24, so 32-bit integers and their float conversions give the same values as torch's int64
+    // arithmetic (the 64-bit conversions cost ~10 instructions each on the device)
+    const int nf = (int)lib.motion_num_frames[mid];
     float phase = time / len;
     phase = fminf(fmaxf(phase, 0.0f), 1.0f);  // torch.clip
     if (time < 0.f) time = 0.f;
     float nfm1 = (float)(nf - 1);
     float prod = phase * nfm1;
     FrameRef r;
-    r.idx0 = (int64_t)prod;
-    r.idx1 = (r.idx0 + 1 < nf - 1) ? r.idx0 + 1 : nf - 1;
-    float sub = (float)r.idx0 * dt;
+    const int i0 = (int)prod;                 // .long(): truncation, prod >= 0
+    const int i1 = (i0 + 1 < nf - 1) ? i0 + 1 : nf - 1;
+    r.idx0 = i0;
+    r.idx1 = i1;
+    float sub = (float)i0 * dt;
     float bl = (time - sub) / dt;
     r.blend = fminf(fmaxf(bl, 0.0f), 1.0f);
     int64_t start = lib.length_starts[mid];
@@ -63,7 +67,7 @@ PHC_HD float sample_time_interval(const phc_motion_lib_t& lib, int64_t mid, floa
     PHC_NO_CONTRACT
     const float curr_fps = (float)(1.0 / 30.0);
     float t = (phase * lib.motion_lengths[mid]) / curr_fps;
-    return (float)((int64_t)t) * curr_fps;
+    return (float)((int)t) * curr_fps;   // .long(): t < 2^24 frames
 }
 
 // env time (humanoid_im.py:879,752,1118): progress * dt + start + offset, each op rounded to fp32
