@@ -27,10 +27,12 @@
 extern "C" {
 #endif
 
-#define PHC_ABI_VERSION 4
+#define PHC_ABI_VERSION 5
 #define PHC_MAX_BODIES 32
 #define PHC_EINVAL (-1)
 #define PHC_EUNSUPPORTED (-2)
+#define PHC_RESET_SUBLISTS 16
+#define PHC_RESET_COUNT_STRIDE 32   /* ints between two sub-list counters: one 128-byte line each */
 
 /* Compiled articulation (phc_amd/model.py: ArticulationModel.pack()).  Replaces
  * gym.load_asset / get_actor_dof_properties / get_actor_rigid_body_properties
@@ -162,6 +164,15 @@ typedef struct {
     int32_t* recovery_counter;        /* [N] humanoid_im_getup.py:62,203-216; nullable (plain HumanoidIm) */
     float* point_goal;                /* [N] humanoid_im.py:95,792,898; nullable unless zero_out_far */
     const float* cycle_phase;         /* [N] the caller's torch.rand draw for _sample_time of cycled envs (:1127); nullable unless cycle_motion */
+    /* device-side lists of the envs that finished in the last post-physics launch (nullable): phc_im_post_physics appends every
+     * env whose reset flag it sets to one of PHC_RESET_SUBLISTS sub-lists (sub-list = (env / 8) % 16, capacity reset_sublist_cap
+     * each) and counts them in reset_count[reset_slot][sub]; phc_im_reset_done then works on exactly those envs (dense wavefronts
+     * instead of a masked sweep over all envs) and zeroes reset_count[(reset_slot + 1) % 3][*] for the next step -- the caller
+     * rotates reset_slot 0,1,2 per step. */
+    int32_t* reset_list;              /* [PHC_RESET_SUBLISTS * reset_sublist_cap] */
+    int32_t* reset_count;             /* [3, PHC_RESET_SUBLISTS, PHC_RESET_COUNT_STRIDE], counter in element 0 */
+    int32_t reset_slot;
+    int32_t reset_sublist_cap;        /* >= 8 * ceil(ceil(N / 8) / PHC_RESET_SUBLISTS) */
 } phc_im_buffers_t;
 
 int32_t phc_abi_version(void);

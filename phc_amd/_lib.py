@@ -65,7 +65,8 @@ class ImBuffers(C.Structure):
                 ("obs_buf", c_p), ("amp_obs_in", c_p), ("amp_obs_out", c_p), ("sampled_motion_ids", c_p),
                 ("motion_start_times", c_p), ("motion_start_times_offset", c_p), ("global_offset", c_p),
                 ("ref_body_pos", c_p), ("ref_body_rot", c_p), ("ref_body_vel", c_p), ("ref_dof_pos", c_p),
-                ("cycle_counter", c_p), ("recovery_counter", c_p), ("point_goal", c_p), ("cycle_phase", c_p)]
+                ("cycle_counter", c_p), ("recovery_counter", c_p), ("point_goal", c_p), ("cycle_phase", c_p),
+                ("reset_list", c_p), ("reset_count", c_p), ("reset_slot", c_i32), ("reset_sublist_cap", c_i32)]
 
 
 P = C.POINTER
@@ -102,7 +103,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the .so does not export the symbol
         fn.argtypes = argtypes
         fn.restype = restype
-    if lib.phc_abi_version() != 4:
+    if lib.phc_abi_version() != 5:
         raise ImportError("libphc_amd.so ABI version mismatch")
     _lib = lib
     return lib

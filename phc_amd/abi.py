@@ -129,11 +129,24 @@ def im_params_struct(dt, max_episode_length, reward_specs, power_reward, power_c
     return p
 
 
+RESET_SUBLISTS = 16  # PHC_RESET_SUBLISTS
+RESET_COUNT_STRIDE = 32  # PHC_RESET_COUNT_STRIDE
+
+
+def reset_sublist_cap(num_envs):
+    """Capacity of one device reset sub-list (include/phc_amd.h: phc_im_buffers_t.reset_sublist_cap)."""
+    blocks = (num_envs + 7) // 8
+    return 8 * ((blocks + RESET_SUBLISTS - 1) // RESET_SUBLISTS)
+
+
 def im_buffers_struct(progress_buf, reset_buf, terminate_buf, rew_buf, reward_raw, obs_buf, amp_obs_in, amp_obs_out,
                       sampled_motion_ids, motion_start_times, motion_start_times_offset, global_offset,
                       ref_body_pos=None, ref_body_rot=None, ref_body_vel=None, ref_dof_pos=None,
-                      cycle_counter=None, recovery_counter=None, point_goal=None, cycle_phase=None):
+                      cycle_counter=None, recovery_counter=None, point_goal=None, cycle_phase=None, reset_list=None, reset_count=None,
+                      reset_slot=0):
     b = L.ImBuffers()
+    b.reset_list, b.reset_count, b.reset_slot = ptr(reset_list), ptr(reset_count), int(reset_slot)
+    b.reset_sublist_cap = 0 if reset_list is None else int(reset_list.shape[0]) // RESET_SUBLISTS
     b.progress_buf, b.reset_buf, b.terminate_buf = ptr(progress_buf), ptr(reset_buf), ptr(terminate_buf)
     b.rew_buf, b.reward_raw, b.obs_buf = ptr(rew_buf), ptr(reward_raw), ptr(obs_buf)
     b.amp_obs_in, b.amp_obs_out = ptr(amp_obs_in), ptr(amp_obs_out)

@@ -6,6 +6,18 @@
 
 namespace phc {
 
+// fetch-and-increment (device: one atomic per finished env; host emulation: OpenMP atomic capture)
+PHC_HD int phc_atomic_inc(int32_t* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return atomicAdd(p, 1);
+#else
+    int v;
+#pragma omp atomic capture
+    v = (*p)++;
+    return v;
+#endif
+}
+
 // AMP observation of one time step computed from the *reference motion* (no offset):
 // HumanoidAMP._init_amp_obs_ref / build_amp_obs_demo (humanoid_amp.py:575-603,253-284).
 // Lane j writes its slices of a[0..A).
@@ -262,6 +274,12 @@ PHC_HD void im_post_finalize(const phc_motion_lib_t& lib, const phc_im_params_t&
     if (c.recovery_cnt > 0) { reset = 0; terminated = 0; }               // humanoid_im_getup.py:212-214
     buf.terminate_buf[env] = terminated;
     buf.reset_buf[env] = reset;
+    if (reset && buf.reset_list) {
+        // PHC_RESET_SUBLISTS sub-lists (envs of workgroup b go to sub-list b % 16) keep the atomics off a single hot address
+        const int sub = (int)((env >> 3) & (PHC_RESET_SUBLISTS - 1));
+        const int i = phc_atomic_inc(buf.reset_count + (buf.reset_slot * PHC_RESET_SUBLISTS + sub) * PHC_RESET_COUNT_STRIDE);
+        buf.reset_list[sub * buf.reset_sublist_cap + i] = (int32_t)env;
+    }
     buf.progress_buf[env] = c.progress;
     if (buf.cycle_counter) buf.cycle_counter[env] = c.cycle_cnt;
     if (buf.recovery_counter) buf.recovery_counter[env] = c.recovery_cnt;

@@ -90,11 +90,24 @@ __global__ __launch_bounds__(256) void k_im_reset(phc_model_t model, phc_motion_
     const int lane = threadIdx.x & (GRP - 1);
     const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;   // listed env (grid.x), AMP history frame k (grid.y)
     const int k = (int)blockIdx.y;
-    if (r >= num_reset) return;
-    // env_ids == NULL: masked mode over all envs (reset every env whose reset_buf is set) -- no host sync needed.
-    // The flag is NOT cleared here (other groups of the same env still read it): the caller zeroes reset_buf afterwards.
-    const int64_t env = env_ids ? env_ids[r] : r;
-    if (!env_ids && buf.reset_buf[env] == 0) return;
+    int64_t env;
+    if (RNG && buf.reset_list) {
+        // reset_done() on the device-built list of finished envs: dense wavefronts, blocks beyond the count leave at once
+        const int cap = buf.reset_sublist_cap, r32 = (int)r;
+        // group r works on entry r / 16 of sub-list r % 16: concurrently running wavefronts draw from all sub-lists (a sub-list holds
+        // envs of every 16th workgroup, whose clips sit at a fixed stride in HBM -- walking one sub-list at a time camps on channels)
+        const int sub = r32 & (PHC_RESET_SUBLISTS - 1), i = r32 >> 4;
+        if (r32 < PHC_RESET_SUBLISTS && k == 0 && lane == 0)   // next step's counters
+            buf.reset_count[(((buf.reset_slot + 1) % 3) * PHC_RESET_SUBLISTS + r32) * PHC_RESET_COUNT_STRIDE] = 0;
+        if (i >= cap || i >= buf.reset_count[(buf.reset_slot * PHC_RESET_SUBLISTS + sub) * PHC_RESET_COUNT_STRIDE]) return;
+        env = buf.reset_list[sub * cap + i];
+    } else {
+        if (r >= num_reset) return;
+        // env_ids == NULL: masked mode over all envs (reset every env whose reset_buf is set) -- no host sync needed.
+        // The flag is NOT cleared here (other groups of the same env still read it).
+        env = env_ids ? env_ids[r] : r;
+        if (!env_ids && buf.reset_buf[env] == 0) return;
+    }
     const int64_t mid = buf.sampled_motion_ids[env];
     // _sample_ref_state (humanoid_im.py:1000-1023): StateInit.Random -> sample_time_interval; Start / flags.test -> 0
     // (start_at_zero with a null phase array is only legal in the RNG-free instantiation's list mode)
@@ -300,7 +313,8 @@ int32_t phc_im_reset_done(const phc_model_t* model, const phc_motion_lib_t* lib,
     if (rc) return rc;
     if (!sim || !buf) return PHC_EINVAL;
     if (sim->num_envs == 0) return 0;
-    const int n = sim->num_envs;
+    if (buf->reset_list && (!buf->reset_count || buf->reset_sublist_cap * PHC_RESET_SUBLISTS < sim->num_envs)) return PHC_EINVAL;
+    const int n = buf->reset_list ? buf->reset_sublist_cap * PHC_RESET_SUBLISTS : sim->num_envs;   // groups to launch
     const uint64_t key = splitmix64(splitmix64(seed) ^ (counter * 0xD1342543DE82EF95ull));
     const dim3 grid(env_blocks(n, 256), prm->num_amp_obs_steps);
     if (prm->dofs_per_joint == 1)

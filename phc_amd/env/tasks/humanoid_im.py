@@ -354,6 +354,11 @@ class HumanoidIm:
         self._point_goal = torch.zeros(N, **f32)                 # humanoid_im.py:95
         self._reset_seed = int(torch.initial_seed()) & 0x7FFFFFFFFFFFFFFF
         self._reset_counter = 0
+        # device-built list of the envs that finished in the last step (phc_im_buffers_t.reset_list): reset_done() works on it
+        self._use_reset_list = getattr(self, "_use_reset_list", True)
+        self._reset_list = torch.zeros(abi.RESET_SUBLISTS * abi.reset_sublist_cap(N), device=dev, dtype=torch.int32) if self._use_reset_list else None
+        self._reset_count = torch.zeros((3, abi.RESET_SUBLISTS, abi.RESET_COUNT_STRIDE), device=dev, dtype=torch.int32) if self._use_reset_list else None
+        self._reset_slot, self._reset_list_pending = 0, False
         self._cycle_phase = torch.zeros(N, **f32) if self.cycle_motion else None
         if not hasattr(self, "_recovery_counter"):
             self._recovery_counter = None                        # HumanoidImGetup owns one
@@ -404,7 +409,8 @@ class HumanoidIm:
                                      amp_in, amp_out, self._sampled_motion_ids, self._motion_start_times, self._motion_start_times_offset,
                                      self._global_offset, self.ref_body_pos, self.ref_body_rot, self.ref_body_vel, self.ref_dof_pos,
                                      cycle_counter=self._cycle_counter, recovery_counter=self._recovery_counter,
-                                     point_goal=self._point_goal, cycle_phase=self._cycle_phase)
+                                     point_goal=self._point_goal, cycle_phase=self._cycle_phase, reset_list=self._reset_list,
+                                     reset_count=self._reset_count, reset_slot=self._reset_slot)
 
     @property
     def _amp_obs_buf(self):
@@ -565,6 +571,10 @@ class HumanoidIm:
             # the draw behind `_sample_time` of the envs whose clip restarts this step (humanoid_im.py:1127); one value per
             # env is drawn (the reference draws only as many as restart, so the RNG streams differ in length, not in law)
             torch.rand(self.num_envs, out=self._cycle_phase)
+        if self._use_reset_list:
+            if self._reset_list_pending:   # the previous step's list was never consumed (reset(env_ids) idiom): start this one empty
+                self._reset_count[self._reset_slot].zero_()
+            self._reset_list_pending = True
         buf = self._buffers(amp_in, amp_out)
         L.check(self._lib.phc_im_post_physics(self._model_struct, self._motion_lib.struct, self._im_params, self._sim_struct, buf,
                                               _stream()), "phc_im_post_physics")
@@ -611,12 +621,20 @@ class HumanoidIm:
         """MI355X-first variant of the rollout idiom `env.reset(reset_buf.nonzero())` (amp_agent.py:318-319): ONE launch resets
         exactly the envs whose reset_buf is set -- no `.nonzero()` device->host sync, the start-time phase is drawn in the kernel
         (counter-based hash seeded from torch's seed; the reference draws torch.rand(len(env_ids))), and the flags are not
-        zeroed afterwards: nothing reads reset_buf before the next post-physics launch rewrites every entry of it."""
+        zeroed afterwards: nothing reads reset_buf before the next post-physics launch rewrites every entry of it.  The envs come
+        from the list the post-physics kernel built on the device (dense wavefronts; a masked sweep over all envs is the fallback)."""
         start_at_zero = (self._state_init == HumanoidIm.StateInit.Start) or flags.test
         cur = self._amp_bufs[self._amp_cur]
         self._reset_counter += 1
-        L.check(self._lib.phc_im_reset_done(self._model_struct, self._motion_lib.struct, self._im_params, self._sim_struct, self._buffers(cur, cur),
+        use_list = self._use_reset_list and self._reset_list_pending
+        buf = self._buffers(cur, cur)
+        if not use_list:   # nothing appended since the last consumption (e.g. right after reset()): masked sweep over reset_buf
+            buf.reset_list = None
+        L.check(self._lib.phc_im_reset_done(self._model_struct, self._motion_lib.struct, self._im_params, self._sim_struct, buf,
                                             self._reset_seed, self._reset_counter, int(bool(start_at_zero)), _stream()), "phc_im_reset_done")
+        if use_list:
+            self._reset_slot = (self._reset_slot + 1) % 3   # the kernel zeroed that counter for the next post-physics launch
+            self._reset_list_pending = False
 
     # ------------------------------------------------------------------ AMP demo observations (humanoid_amp.py:215-284)
     def fetch_amp_obs_demo(self, num_samples):

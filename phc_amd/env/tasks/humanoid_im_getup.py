@@ -32,6 +32,7 @@ class HumanoidImGetup(HumanoidIm):
         self.availalbe_fall_states = torch.zeros(n, device=dev, dtype=torch.long)
         self.fall_id_assignments = torch.zeros(n, device=dev, dtype=torch.long)
         self._reset_fall_env_ids = []
+        self._use_reset_list = False   # episode kinds are decided on the host: the done envs are listed there
         super().__init__(cfg=cfg, sim_params=sim_params, physics_engine=physics_engine, device_type=device_type, device_id=device_id,
                          headless=headless)
         self._generate_fall_states()

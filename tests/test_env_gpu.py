@@ -430,3 +430,24 @@ def test_h1_ppo_epoch():
     assert np.isfinite([info["actor_loss"], info["critic_loss"], info["disc_loss"], info["mean_task_reward"]]).all(), info
     assert not torch.equal(w0, agent.model.a2c_network.pnn.actors[0][0].weight)
     assert abs(float(agent.model.a2c_network.sigma[0]) + 1.7) < 1e-6
+
+
+def test_reset_done_resets_exactly_the_finished_envs():
+    """reset_done() consumes the device-built list of the envs the last post-physics launch flagged: after it exactly those envs
+    (and no stale list entries from earlier steps) sit at progress 0; a masked fallback serves calls with no fresh list."""
+    task, env = make_task(1024, motion="synthetic:4:2:1.5")
+    env.reset()
+    total = 0
+    for it in range(60):
+        obs, rew, done, info = env.step((torch.rand(1024, 69, device=task.device) * 2 - 1))
+        done_ids = set(done.nonzero(as_tuple=False).flatten().tolist())
+        total += len(done_ids)
+        task.reset_done()
+        zero_ids = set((task.progress_buf == 0).nonzero(as_tuple=False).flatten().tolist())
+        assert zero_ids == done_ids, (it, len(zero_ids), len(done_ids))
+        if it == 30:   # a second call without a step in between: no fresh list -> masked sweep over the (unchanged) flags, same envs
+            st = task._motion_start_times.clone()
+            task.reset_done()
+            assert set((task.progress_buf == 0).nonzero(as_tuple=False).flatten().tolist()) == done_ids
+            assert (task._motion_start_times != st).sum() <= len(done_ids)
+    assert total > 100

@@ -91,12 +91,20 @@ def test_post_physics_vs_reference_golden(golden, backend, use_mean):
              raw=be.zeros((N, 5)), obs=be.zeros((N, 934)), mids=be.arr(g["env_motion"].astype(np.int64)),
              st=be.arr(g["start_times"].astype(F)), so=be.zeros(N), goff=be.zeros((N, 3)),
              rbp=be.zeros((N, 24, 3)), rbr=be.zeros((N, 24, 4)), rbv=be.zeros((N, 24, 3)), rdp=be.zeros((N, 69)))
+    cap = abi.reset_sublist_cap(N)
+    rl, rc = be.zeros(abi.RESET_SUBLISTS * cap, np.int32), be.zeros((3, abi.RESET_SUBLISTS, abi.RESET_COUNT_STRIDE), np.int32)
     buf = abi.im_buffers_struct(b["progress"], b["reset"], b["term"], b["rew"], b["raw"], b["obs"], amp_in, amp_out, b["mids"], b["st"],
-                                b["so"], b["goff"], b["rbp"], b["rbr"], b["rbv"], b["rdp"])
+                                b["so"], b["goff"], b["rbp"], b["rbr"], b["rbv"], b["rdp"], reset_list=rl, reset_count=rc, reset_slot=1)
     assert be.im_post_physics(mstruct, lib, prm, sim, buf) == 0
     be.sync()
     o = {k: be.np(v) for k, v in b.items()}
     amp_out = be.np(amp_out)
+    # device-built lists of the finished envs: sub-list (env / 8) % 16, counted in slot 1, together exactly the envs with the flag set
+    rl, rc = be.np(rl).reshape(abi.RESET_SUBLISTS, cap), be.np(rc)[:, :, 0]
+    assert (rc[0] == 0).all() and (rc[2] == 0).all()
+    listed = np.concatenate([rl[s_, :rc[1, s_]] for s_ in range(abi.RESET_SUBLISTS)])
+    np.testing.assert_array_equal(np.sort(listed), np.nonzero(g["reset_mean" if use_mean else "reset"])[0])
+    assert all(((rl[s_, :rc[1, s_]] >> 3) % abi.RESET_SUBLISTS == s_).all() for s_ in range(abi.RESET_SUBLISTS))
     np.testing.assert_array_equal(o["progress"], g["progress"])
     np.testing.assert_allclose(o["raw"][:, :4], g["reward_raw"], atol=1e-5)
     np.testing.assert_allclose(o["raw"][:, 4], g["power_reward"], atol=1e-5, rtol=1e-5)
