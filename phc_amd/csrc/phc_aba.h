@@ -133,6 +133,10 @@ PHC_HD void aba_load_model(AbaLane& L, const phc_model_t& m, int j) {
     L.arm = v3(f[19], f[20], f[21]);
 }
 // revolute extras (template JT == PHC_JT_REVOLUTE paths only)
+// convenience overload: constants read from the model at every call
+template <int JT>
+PHC_HD void aba_body_init(AbaLane& L, const phc_model_t& m, const phc_sim_params_t& prm, float dt, int j, bool new_sim_call);
+
 PHC_HD void aba_load_model_rev(AbaLane& L, const phc_model_t& m, int j) {
     const float* f = model_body(m, j);
     L.axis = v3(f[25], f[26], f[27]);
@@ -212,9 +216,11 @@ PHC_HD void aba_fk_level(AbaLane& L, int level, int j, const Xch& x) {
 
 // ---- per-body initialisation of I^A, p^A and of the joint drive (no communication) ----
 // `new_sim_call`: first sub-step of a gym.simulate call -- the explicit `pd` torque is recomputed there (humanoid.py:1608-1616).
+// `f`: the body's PHC_BODY_FLOATS constants -- straight from the model (L2) or a register copy the caller made once per launch;
+// `cp_start / cp_total`: the body's slice of the contact-point table.
 template <int JT>
-PHC_HD void aba_body_init(AbaLane& L, const phc_model_t& m, const phc_sim_params_t& prm, float dt, int j, bool new_sim_call) {
-    const float* f = model_body(m, j);
+PHC_HD void aba_body_init(AbaLane& L, const phc_model_t& m, const phc_sim_params_t& prm, float dt, int j, bool new_sim_call,
+                          const float* f, int cp_start, int cp_total) {
     const float mass = f[3];
     Sym3 Io_b;
     Io_b.xx = f[7]; Io_b.xy = f[8]; Io_b.xz = f[9]; Io_b.yy = f[10]; Io_b.yz = f[11]; Io_b.zz = f[12];
@@ -234,9 +240,9 @@ PHC_HD void aba_body_init(AbaLane& L, const phc_model_t& m, const phc_sim_params
     // ground contact: plane z = 0, normal +z
     L.fcontact = v3(0.f, 0.f, 0.f);
     const float cn = prm.contact_stiffness * dt + prm.contact_damping;
-    const float* cp = m.floats + PHC_MAX_BODIES * PHC_BODY_FLOATS + model_tab(m, 8, j) * 4;
+    const float* cp = m.floats + PHC_MAX_BODIES * PHC_BODY_FLOATS + cp_start * 4;
     // broad phase: f[34] bounds |contact point| + radius, so above that height nothing of this body reaches the plane
-    const int cp_count = (L.p.z < f[34]) ? model_tab(m, 9, j) : 0;
+    const int cp_count = (L.p.z < f[34]) ? cp_total : 0;
     for (int k = 0; k < cp_count; ++k) {
         V3 arm = mat_mul(R, v3(cp[4 * k], cp[4 * k + 1], cp[4 * k + 2]));
         float rad = cp[4 * k + 3];
@@ -325,6 +331,11 @@ PHC_HD void aba_body_init(AbaLane& L, const phc_model_t& m, const phc_sim_params
         L.tau_local = tau;
         L.dimp = d;
     }
+}
+
+template <int JT>
+PHC_HD void aba_body_init(AbaLane& L, const phc_model_t& m, const phc_sim_params_t& prm, float dt, int j, bool new_sim_call) {
+    aba_body_init<JT>(L, m, prm, dt, j, new_sim_call, model_body(m, j), model_tab(m, 8, j), model_tab(m, 9, j));
 }
 
 // 6x6 congruence T^T I T and T^T p for a pure translation r (child origin - parent origin)
