@@ -475,6 +475,10 @@ class HumanoidIm:
     def _load_motion(self, motion_train_file, motion_test_file=[]):
         assert self._dof_offsets[-1] == self.num_dof
         mf = motion_train_file
+        if isinstance(mf, str) and mf.startswith("stand") and not self._is_robot:
+            # "stand[:seconds]" -- the rest pose standing still (a physically feasible clip for end-to-end sanity runs)
+            from ...utils.synthetic_motion import make_stand_clip
+            mf = {"stand_00000": make_stand_clip(self.model, float(mf.split(":")[1]) if ":" in mf else 10.0)}
         if isinstance(mf, str) and mf.startswith("synthetic"):
             # "synthetic[:num_clips[:seed[:mean_seconds]]]" -- AMASS-shaped smooth random clips
             parts = mf.split(":")

@@ -134,3 +134,18 @@ def make_robot_motion_dict(model, num_clips, seed=0, mean_seconds=8.0, fps=30, l
             T = max(int(round(sec * fps)), min_frames)
         out[f"synthetic_{i:05d}"] = make_robot_clip(rng, model, T, num_extend=num_extend, fps=fps)
     return out
+
+
+def make_stand_clip(model, seconds=10.0, fps=30):
+    """A physically feasible clip for end-to-end sanity runs: the SMPL rest pose standing still, soles on the ground."""
+    T, J = int(round(seconds * fps)) + 1, model.num_bodies
+    origin = np.zeros((J, 3))
+    for j in range(1, J):
+        origin[j] = origin[model.parent[j]] + model.local_translation[j]
+    lowest = (origin[model.contact_body, 2] + model.contact_pos[:, 2] - model.contact_radius).min()
+    q = np.zeros((T, J, 4))
+    q[..., 3] = 1.0
+    trans = np.zeros((T, 3))
+    trans[:, 2] = -lowest + 0.002
+    return {"pose_quat_global": q, "pose_quat": q.copy(), "root_trans_offset": trans, "trans_orig": trans.copy(),
+            "pose_aa": np.zeros((T, J * 3)), "beta": np.zeros(10), "gender": "neutral", "fps": fps}
