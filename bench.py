@@ -254,7 +254,7 @@ def main():
         }
         if ppo is not None:
             out.update(ppo)
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.robot == "smpl":
             out["cpu_baseline"] = cpu_baseline()
         out["actions"] = args.actions
         out["envs_within_5_steps_of_a_reset"] = resets

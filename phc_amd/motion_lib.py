@@ -530,7 +530,7 @@ class MotionLibReal(MotionLibBase):
         m = self.robot_model
         fps = clip.get("fps", 30)
         proc = process_clip_real(m.parent, m.local_translation, m.local_rotation, self.ext_parent, self.ext_pos, self.ext_rot, pose_aa, trans, fps)
-        return proc, int(1 / (1.0 / fps)), trans.shape[0]
+        return proc, int(fps), trans.shape[0]   # fk_batch returns fps = int(1 / dt) (torch_humanoid_batch.py:219)
 
     def _per_env_variant(self, proc, rs):
         return proc
