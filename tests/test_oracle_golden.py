@@ -98,3 +98,19 @@ def test_reward_reset_obs(golden):
                                          g["dof_pos"], g["dof_vel"], g["body_pos"][:, kid], g["dof_subset"])
     assert amp.shape[1] == 196
     np.testing.assert_allclose(amp, g["amp_obs"], atol=1e-5)
+
+
+def test_amass_conversion_matches_reference_poselib(golden):
+    """f-4: AMASS -> motion pkl (phc_amd.utils.convert_amass) == the reference's poselib calls driven as its converter script does."""
+    from phc_amd.utils.convert_amass import convert
+    g = golden("amass_convert")
+    out = convert({"clip": {"pose_aa": g["pose_aa_in"], "trans": g["trans"], "betas": np.ones((1, 10)), "gender": "male"}})["clip"]
+    np.testing.assert_allclose(out["root_trans_offset"], g["root_trans_offset"], atol=1e-6)   # float32 pelvis offset of the tree
+    np.testing.assert_array_equal(out["pose_aa"], g["pose_aa"])
+    for k in ("pose_quat_global", "pose_quat"):   # rotations equal up to the quaternion sign (scipy does not canonicalise)
+        np.testing.assert_allclose(np.abs((out[k] * g[k]).sum(-1)), 1.0, atol=1e-6, err_msg=k)
+    assert (out["beta"] == 0).all() and out["gender"] == "neutral" and out["fps"] == 30.0
+    # and the result loads: global rotations -> local -> global round trip of the motion library's clip processing
+    sk = golden("skeleton_smpl")
+    lib = po.build_motion_lib(sk["parent_indices"], sk["local_translation"], [dict(out, fps=30)])
+    np.testing.assert_allclose(np.abs((lib["grs"] * out["pose_quat_global"]).sum(-1)), 1.0, atol=1e-6)
