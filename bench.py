@@ -50,6 +50,7 @@ def parse():
                     "(Unitree H1, 19 revolute DoFs, 200 Hz x 4 pd-torque control) -- a parity-test configuration, timed for reference only")
     ap.add_argument("--lane-mapping", type=int, default=0, help="stepper thread mapping (phc_sim_params_t.lane_mapping): 0 auto, 1 one body "
                     "per lane (32 lanes/env), 2 two bodies per lane (16 lanes/env)")
+    ap.add_argument("--self-collision", type=int, default=-1, help="-1: as the robot yaml says (has_self_collision: True); 0/1 force")
     ap.add_argument("--motion-clips", type=int, default=1, help="synthetic clips in the motion library (configs[1]: 1; configs[2]/[3] shape: thousands)")
     ap.add_argument("--actions", choices=["random", "tracking"], default="random",
                     help="random: fixed a ~ U(-1,1)*0.1 tensor (SURVEY 8d protocol; zero-pose targets -> episodes end after a few steps); "
@@ -93,7 +94,7 @@ def cpu_baseline(num_envs=4096, budget_s=12.0, max_steps=4000):
     amp = [np.zeros((N, 10, 196), F), np.zeros((N, 10, 196), F)]
     b = dict(progress=np.zeros(N, np.int64), reset=np.ones(N, np.int64), term=np.zeros(N, np.int64), rew=np.zeros(N, F), raw=np.zeros((N, 5), F),
              obs=np.zeros((N, 934), F), mids=np.arange(N, dtype=np.int64), st=np.zeros(N, F), so=np.zeros(N, F), goff=np.zeros((N, 3), F))
-    params = abi.sim_params_struct()
+    params = abi.sim_params_struct(self_collision=1)   # as the GPU run: robot.has_self_collision is True in smpl_humanoid.yaml
     rng = np.random.default_rng(0)
     actions = ((rng.random((N, nd)) * 2 - 1) * 0.1).astype(F)
     off, scale = model.pd_action_offset_scale()
@@ -166,7 +167,7 @@ def main():
     torch.manual_seed(rank)  # per-rank seed offset, as the reference's horovod path does (run_hydra.py:121)
     robot_over = ["robot=unitree_h1", "env=env_im_h1_phc", "sim=robot_sim", "control=robot_control"] if args.robot == "h1" else []
     cfg = compose(robot_over + [f"env.num_envs={args.envs}", f"env.motion_file=synthetic:{args.motion_clips}:0", f"device_id={local_rank}",
-                                f"rl_device=cuda:{local_rank}", f"+solver.lane_mapping={args.lane_mapping}"])
+                                f"rl_device=cuda:{local_rank}", f"+solver.lane_mapping={args.lane_mapping}"] + ([f"+solver.self_collision={args.self_collision}"] if args.self_collision >= 0 else []))
     task, env = parse_task(cfg, device_id=local_rank)
     dev = task.device
     N = task.num_envs
@@ -244,7 +245,8 @@ def main():
                                    ("BASELINE configs[4]: Unitree H1 19-DoF, envs per GPU as given, synthetic retargeted-shape clips, "
                                     "50 Hz control = 4 x simulate @200 Hz x 2 sub-steps, pd torque mode"),
                        "envs_per_gpu": N, "num_bodies": task.num_bodies,
-                       "obs": task.num_obs, "amp_obs": task.get_num_amp_obs(), "parallelism": f"env-sharded x{world}"},
+                       "obs": task.num_obs, "amp_obs": task.get_num_amp_obs(), "parallelism": f"env-sharded x{world}",
+                       "self_collision": bool(task._sim_params.self_collision)},
             "roofline": {"kernel": "phc_sim_step: k_sim_step16 / k_sim_step (A2 + %d ABA sub-steps + S7 publication)" % nsub, "bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_per_launch,

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PHC_ABI_VERSION 5
+#define PHC_ABI_VERSION 7
 #define PHC_MAX_BODIES 32
 #define PHC_EINVAL (-1)
 #define PHC_EUNSUPPORTED (-2)
@@ -46,6 +46,7 @@ typedef struct {
     const float* floats;
     int32_t split_level;      /* two-slot stepper mapping: bodies of tree levels < split_level share lanes with the deeper ones; */
     int32_t num_below_split;  /* -1 / 0 when the tree has no split with both halves <= 16 bodies (ArticulationModel.two_slot_split) */
+    int32_t num_collision_pairs; /* body pairs that may collide (listed after the int tables); <= 288 */
 } phc_model_t;
 
 /* Flat reference-motion buffer.  Replaces MotionLibBase's gts/grs/lrs/gvs/gavs/dvs tensors
@@ -101,6 +102,11 @@ typedef struct {
                                          links).  1 and 2: revolute models only. */
     float limit_stiffness;            /* joint-limit penalty spring N m/rad outside [lower, upper] (revolute models; 0 = off) */
     float limit_damping;              /* N m s/rad */
+    int32_t self_collision;           /* 1: penalty contact between the collision capsules of non-adjacent bodies (robot.has_self_collision,
+                                         humanoid.py:1205-1226), explicit in time with k = self_stiffness_scale * mu / dt^2 per pair
+                                         (mu = reduced mass) and damping ratio self_damping_ratio */
+    float self_stiffness_scale;       /* <= 1 (explicit stability bound is 4); default 0.25 */
+    float self_damping_ratio;         /* default 0.5 */
     int32_t lane_mapping;             /* stepper thread mapping: 2 = 16 lanes per env, two bodies per lane, 4 envs per wavefront;
                                          1 = 32 lanes per env, one body per lane, 2 envs per wavefront; 0 = pick by env count */
 } phc_sim_params_t;

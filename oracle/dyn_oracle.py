@@ -114,7 +114,8 @@ class State:
 
 
 DEFAULT_PARAMS = dict(gravity_z=-9.81, contact_stiffness=1.0e5, contact_damping=1.0e3, friction=1.0, friction_viscous=2.0e3,
-                      angular_damping=0.01, max_angular_velocity=100.0, control_mode=0, limit_stiffness=0.0, limit_damping=0.0)
+                      angular_damping=0.01, max_angular_velocity=100.0, control_mode=0, limit_stiffness=0.0, limit_damping=0.0,
+                      self_collision=0, self_stiffness_scale=0.25, self_damping_ratio=0.5)
 
 
 def kinematics(model, st):
@@ -147,6 +148,64 @@ def body_velocities(model, st, R, p):
             w[i] = w[par] + R[i] @ (st.S(i - 1) @ st.qd[i - 1])
             v[i] = v[par] + np.cross(w[par], p[i] - p[par])
     return w, v
+
+
+def seg_seg_closest(p1, q1, p2, q2):
+    """Closest points of two segments (Ericson, Real-Time Collision Detection 5.1.9); degenerate segments are points."""
+    d1, d2, r = q1 - p1, q2 - p2, p1 - p2
+    a, e, f = d1 @ d1, d2 @ d2, d2 @ r
+    EPS = 1e-10
+    s = t = 0.0
+    if a <= EPS and e <= EPS:
+        pass
+    elif a <= EPS:
+        t = min(max(f / e, 0.0), 1.0)
+    else:
+        c = d1 @ r
+        if e <= EPS:
+            s = min(max(-c / a, 0.0), 1.0)
+        else:
+            b = d1 @ d2
+            denom = a * e - b * b
+            s = min(max((b * f - c * e) / denom, 0.0), 1.0) if denom > 1e-7 * a * e else 0.0
+            t = (b * s + f) / e
+            if t < 0:
+                t, s = 0.0, min(max(-c / a, 0.0), 1.0)
+            elif t > 1:
+                t, s = 1.0, min(max((b - c) / a, 0.0), 1.0)
+    return p1 + d1 * s, p2 + d2 * t
+
+
+def self_collision_wrenches(model, R, p, w, v, prm, dt):
+    """Explicit capsule-capsule penalty forces between bodies that may collide: (F[NB,3], N[NB,3] about each body origin)."""
+    nb = model.num_bodies
+    F, N = np.zeros((nb, 3)), np.zeros((nb, 3))
+    masks = model.collision_allow_masks()
+    cap = model.collision_capsule
+    A = np.array([p[i] + R[i] @ cap[i, 0:3] for i in range(nb)])
+    B = np.array([p[i] + R[i] @ cap[i, 3:6] for i in range(nb)])
+    for i in range(nb):
+        for k in range(nb):
+            if not (int(masks[i]) >> k) & 1:
+                continue
+            c1, c2 = seg_seg_closest(A[i], B[i], A[k], B[k])
+            n = c1 - c2
+            dist = np.linalg.norm(n)
+            pen = cap[i, 6] + cap[k, 6] - dist
+            if pen <= 0:
+                continue
+            n = n / dist if dist > 1e-6 else np.array([0.0, 0.0, 1.0])
+            cp = c2 + n * (cap[k, 6] - 0.5 * pen)
+            vrel = (v[i] + np.cross(w[i], cp - p[i])) - (v[k] + np.cross(w[k], cp - p[k]))
+            mu = model.mass[i] * model.mass[k] / (model.mass[i] + model.mass[k])
+            kk = prm["self_stiffness_scale"] * mu / (dt * dt)
+            cc = 2.0 * prm["self_damping_ratio"] * np.sqrt(kk * mu)
+            fn = kk * pen - cc * (vrel @ n)
+            if fn <= 0:
+                continue
+            F[i] += n * fn
+            N[i] += np.cross(cp - p[i], n * fn)
+    return F, N
 
 
 def explicit_torque(model, st, target, kp_scale=1.0, kd_scale=1.0):
@@ -230,6 +289,11 @@ def accelerations(model, st, target, params, dt, kp_scale=1.0, kd_scale=1.0, ret
             Jpt = Jv[i] - skew(arm) @ Jw[i]
             M += dt * Jpt.T @ Cm @ Jpt
             rhs += Jpt.T @ (F0 - dt * Cm @ apb)
+    if prm["self_collision"]:
+        Fs, Ns = self_collision_wrenches(model, R, p, w, v, prm, dt)
+        for i in range(nb):
+            rhs += Jw[i].T @ Ns[i] + Jv[i].T @ Fs[i]
+            fcontact[i] += Fs[i]
     tau_all = [None] * nb
     dimp_all = [None] * nb
     for i in range(1, nb):

@@ -43,7 +43,14 @@ static int emu_sim_step_t(const phc_model_t* model, const phc_sim_params_t* prm,
         if (do_step) {
             const float dt = prm->sim_dt / (float)prm->substeps;
             const int nsub = num_sim_calls * prm->substeps;
+            std::vector<float> caps(PHC_MAX_BODIES * PHC_CAP_STRIDE);
             for (int s = 0; s < nsub; ++s) {
+                if (prm->self_collision) {
+                    for (int j = 0; j < nb; ++j) aba_publish_capsule(L[j], model_body(*model, j), caps.data() + PHC_CAP_STRIDE * j);
+                    for (int q = 0, np = model_num_pairs(*model); q < np; ++q)
+                        aba_collide_pair(*prm, dt, model_pair(*model, q) & 0xff, model_pair(*model, q) >> 8, x, caps.data());
+                    for (int j = 0; j < nb; ++j) aba_collect_self(L[j], j, caps.data());
+                }
                 for (int j = 0; j < nb; ++j) aba_body_init<JT>(L[j], *model, *prm, dt, j, s % prm->substeps == 0);
                 for (int l = ml; l >= 0; --l) for (int j = 0; j < nb; ++j) aba_backward_level<JT>(L[j], l, j, x);
                 for (int l = 0; l <= ml; ++l) for (int j = 0; j < nb; ++j) aba_forward_level<JT>(L[j], l, j, x, *prm, dt);

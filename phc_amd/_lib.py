@@ -22,7 +22,7 @@ c_p = C.c_void_p
 
 class Model(C.Structure):
     _fields_ = [("num_bodies", c_i32), ("num_dof", c_i32), ("max_level", c_i32), ("num_contact_pts", c_i32),
-                ("ints", c_p), ("floats", c_p), ("split_level", c_i32), ("num_below_split", c_i32)]
+                ("ints", c_p), ("floats", c_p), ("split_level", c_i32), ("num_below_split", c_i32), ("num_collision_pairs", c_i32)]
 
 
 class MotionLib(C.Structure):
@@ -40,7 +40,8 @@ class SimParams(C.Structure):
     _fields_ = [("sim_dt", c_f), ("substeps", c_i32), ("control_freq_inv", c_i32), ("gravity_z", c_f),
                 ("contact_stiffness", c_f), ("contact_damping", c_f), ("friction", c_f), ("friction_viscous", c_f),
                 ("angular_damping", c_f), ("max_angular_velocity", c_f), ("contact_offset", c_f),
-                ("control_mode", c_i32), ("limit_stiffness", c_f), ("limit_damping", c_f), ("lane_mapping", c_i32)]
+                ("control_mode", c_i32), ("limit_stiffness", c_f), ("limit_damping", c_f),
+                ("self_collision", c_i32), ("self_stiffness_scale", c_f), ("self_damping_ratio", c_f), ("lane_mapping", c_i32)]
 
 
 class ImParams(C.Structure):
@@ -103,7 +104,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the .so does not export the symbol
         fn.argtypes = argtypes
         fn.restype = restype
-    if lib.phc_abi_version() != 5:
+    if lib.phc_abi_version() != 7:
         raise ImportError("libphc_amd.so ABI version mismatch")
     _lib = lib
     return lib

@@ -23,6 +23,7 @@ def ptr(x):
 
 def model_struct(ints, floats, num_bodies, num_dof, max_level, num_contact_pts, split=(-1, 0)):
     m = L.Model()
+    m.num_collision_pairs = int(ints[4 + 13 * 32])   # count stored right after the 13 int tables (model.py pack())
     m.split_level, m.num_below_split = int(split[0]), int(split[1])
     m.num_bodies, m.num_dof, m.max_level, m.num_contact_pts = num_bodies, num_dof, max_level, num_contact_pts
     m.ints, m.floats = ptr(ints), ptr(floats)
@@ -53,13 +54,15 @@ def sim_state_struct(num_envs, root_states, dof_state, rigid_body_state, contact
 
 def sim_params_struct(sim_dt=1 / 60, substeps=2, control_freq_inv=2, gravity_z=-9.81, contact_stiffness=1.0e5,
                       contact_damping=1.0e3, friction=1.0, friction_viscous=2.0e3, angular_damping=0.01,
-                      max_angular_velocity=100.0, contact_offset=0.02, control_mode=0, limit_stiffness=0.0, limit_damping=0.0, lane_mapping=0):
+                      max_angular_velocity=100.0, contact_offset=0.02, control_mode=0, limit_stiffness=0.0, limit_damping=0.0, lane_mapping=0,
+                      self_collision=0, self_stiffness_scale=0.25, self_damping_ratio=0.5):
     p = L.SimParams()
     p.sim_dt, p.substeps, p.control_freq_inv, p.gravity_z = sim_dt, substeps, control_freq_inv, gravity_z
     p.contact_stiffness, p.contact_damping, p.friction, p.friction_viscous = contact_stiffness, contact_damping, friction, friction_viscous
     p.angular_damping, p.max_angular_velocity, p.contact_offset = angular_damping, max_angular_velocity, contact_offset
     p.control_mode, p.limit_stiffness, p.limit_damping = int(control_mode), float(limit_stiffness), float(limit_damping)
     p.lane_mapping = int(lane_mapping)
+    p.self_collision, p.self_stiffness_scale, p.self_damping_ratio = int(self_collision), float(self_stiffness_scale), float(self_damping_ratio)
     return p
 
 

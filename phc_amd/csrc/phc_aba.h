@@ -27,10 +27,13 @@
 namespace phc {
 
 #define PHC_XCH_STRIDE 28      // floats per exchange slot
-#define PHC_BODY_FLOATS 36     // floats per body in phc_model_t.floats (model.py pack())
+#define PHC_BODY_FLOATS 44     // floats per body in phc_model_t.floats (model.py pack())
+#define PHC_CAP_STRIDE 20       // 32-bit words per body in the per-env world-capsule exchange area (self-collision)
+#define PHC_SC_FSCALE 1024.0f    // fixed-point scales of the body-body force / moment accumulators (1/1024 N, 1/4096 N m)
+#define PHC_SC_NSCALE 4096.0f
 #define PHC_JT_SPHERICAL 1     // joint types as model.py numbers them
 #define PHC_JT_REVOLUTE 2
-#define PHC_NTAB 12            // int tables per model (parent level jtype dof_start child0-2 nchild cp_start cp_count order misc)
+#define PHC_NTAB 13            // int tables per model (parent level jtype dof_start child0-2 nchild cp_start cp_count order misc collide-mask)
 
 struct Sym3 { float xx, xy, xz, yy, yz, zz; };
 
@@ -118,6 +121,8 @@ struct AbaLane {
     Q4 qrest;         // rest rotation child-in-parent (MJCF body quat)
     float th, thd;    // joint angle and rate
     float tau_hold;   // explicit `pd` torque of the current simulate call (control_mode 1)
+    // --- body-body contact (self-collision): net explicit force / moment about the origin on this body, set by aba_self_collision ---
+    V3 fself, nself;
 };
 
 PHC_HD const float* model_body(const phc_model_t& m, int j) { return m.floats + j * PHC_BODY_FLOATS; }
@@ -131,6 +136,7 @@ PHC_HD void aba_load_model(AbaLane& L, const phc_model_t& m, int j) {
     const float* f = model_body(m, j);
     L.r_local = v3(f[0], f[1], f[2]);
     L.arm = v3(f[19], f[20], f[21]);
+    L.fself = L.nself = v3(0.f, 0.f, 0.f);
 }
 // revolute extras (template JT == PHC_JT_REVOLUTE paths only)
 // convenience overload: constants read from the model at every call
@@ -275,6 +281,10 @@ PHC_HD void aba_body_init(AbaLane& L, const phc_model_t& m, const phc_sim_params
         // C += C
         L.IA.C.xx += c1; L.IA.C.yy += c1; L.IA.C.zz += c3;
     }
+    // body-body contact forces of this sub-step (explicit; zero unless sim_params.self_collision)
+    L.fcontact += L.fself;
+    L.pA.n -= L.nself;
+    L.pA.f -= L.fself;
     if (JT == PHC_JT_REVOLUTE) {
         if (L.level > 0) {
             // joint drive (revolute).  control_mode 0 = Isaac Gym's implicit position drive (`isaac_pd`), linearly implicit as
@@ -336,6 +346,124 @@ PHC_HD void aba_body_init(AbaLane& L, const phc_model_t& m, const phc_sim_params
 template <int JT>
 PHC_HD void aba_body_init(AbaLane& L, const phc_model_t& m, const phc_sim_params_t& prm, float dt, int j, bool new_sim_call) {
     aba_body_init<JT>(L, m, prm, dt, j, new_sim_call, model_body(m, j), model_tab(m, 8, j), model_tab(m, 9, j));
+}
+
+// ---- body-body contact (SURVEY f-1; the reference runs with robot.has_self_collision: True, humanoid.py:1205-1226) ----
+// Every body carries one collision capsule (model.py _geom_capsule).  Penalty contact between the capsules of bodies that may
+// collide (ArticulationModel.collision_allow_masks: not joint neighbours, no common Isaac Gym filter bit), EXPLICIT in time -- it
+// couples bodies across the tree, which the O(n) recursion cannot absorb implicitly -- hence soft and stable by construction:
+//     k = alpha * mu / dt^2,  c = 2 zeta sqrt(k mu),  mu = m_i m_j / (m_i + m_j)   (alpha = self_stiffness_scale <= 1: explicit
+// Euler on a spring of the pair's reduced mass is stable for k < 4 mu / dt^2).  Each lane evaluates the pairs of its own body;
+// lane j evaluates the mirrored pair with the same arithmetic, so forces come out equal and opposite.
+PHC_HD void seg_seg_closest(V3 p1, V3 q1, V3 p2, V3 q2, V3* c1, V3* c2) {
+    const V3 d1 = q1 - p1, d2 = q2 - p2, r = p1 - p2;
+    const float a = dot(d1, d1), e = dot(d2, d2), f = dot(d2, r);
+    const float EPS = 1e-10f;
+    float s = 0.f, t = 0.f;
+    if (a <= EPS && e <= EPS) {
+    } else if (a <= EPS) {
+        t = fminf(fmaxf(f / e, 0.f), 1.f);
+    } else {
+        const float c = dot(d1, r);
+        if (e <= EPS) {
+            s = fminf(fmaxf(-c / a, 0.f), 1.f);
+        } else {
+            const float b = dot(d1, d2), denom = a * e - b * b;
+            s = denom > 1e-7f * a * e ? fminf(fmaxf((b * f - c * e) / denom, 0.f), 1.f) : 0.f;
+            t = (b * s + f) / e;
+            if (t < 0.f) { t = 0.f; s = fminf(fmaxf(-c / a, 0.f), 1.f); }
+            else if (t > 1.f) { t = 1.f; s = fminf(fmaxf((b - c) / a, 0.f), 1.f); }
+        }
+    }
+    *c1 = p1 + d1 * s;
+    *c2 = p2 + d2 * t;
+}
+// Pair-parallel evaluation: the candidate pairs (model ints: count, i | k << 8, ...) are dealt round-robin to the lanes of the
+// env's group, so every lane tests different pairs (no redundant work, no per-body imbalance).  A contact adds +-F and the moments
+// to the two bodies' accumulators with INTEGER (fixed-point) LDS atomics: integer addition is associative, so the sums do not
+// depend on the order lanes arrive in -- bit-reproducible and exactly antisymmetric.
+// Per-body record in the exchange area (PHC_CAP_STRIDE words): [0..4) bounding sphere (centre, radius) | [4..8) a, radius |
+// [8..12) b, mass | [12..18) int32 accumulators F(3) N(3).
+PHC_HD int model_num_pairs(const phc_model_t& m) { return m.ints[4 + PHC_NTAB * PHC_MAX_BODIES]; }
+PHC_HD int model_pair(const phc_model_t& m, int q) { return m.ints[4 + PHC_NTAB * PHC_MAX_BODIES + 1 + q]; }
+PHC_HD void sc_atomic_add(int32_t* p, int32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    atomicAdd(p, v);
+#else
+    *p += v;   // the host emulation walks the pairs sequentially
+#endif
+}
+PHC_HD void aba_publish_capsule(const AbaLane& L, const float* f, float* cap) {
+    const M3 R = quat_to_mat(L.Q);
+    const V3 a = L.p + mat_mul(R, v3(f[36], f[37], f[38])), b = L.p + mat_mul(R, v3(f[39], f[40], f[41]));
+    const V3 mid = (a + b) * 0.5f;
+    cap[0] = mid.x; cap[1] = mid.y; cap[2] = mid.z; cap[3] = 0.5f * norm(b - a) + f[42];
+    cap[4] = a.x; cap[5] = a.y; cap[6] = a.z; cap[7] = f[42];
+    cap[8] = b.x; cap[9] = b.y; cap[10] = b.z; cap[11] = f[3];
+    int32_t* acc = reinterpret_cast<int32_t*>(cap + 12);
+    for (int k = 0; k < 6; ++k) acc[k] = 0;
+}
+// one candidate pair (bodies i < k): bounding spheres, then the capsule-capsule test, then the penalty force into both accumulators.
+// Needs both bodies' capsules in `caps` and kinematics (p w v at slot floats [10..19)) in the exchange slots.
+PHC_HD void aba_collide_pair(const phc_sim_params_t& prm, float dt, int i, int k, const Xch& x, float* caps) {
+    const float* ci = caps + PHC_CAP_STRIDE * i;
+    const float* ck = caps + PHC_CAP_STRIDE * k;
+    const V3 dm = v3(ci[0] - ck[0], ci[1] - ck[1], ci[2] - ck[2]);
+    const float R = ci[3] + ck[3];
+    if (dot(dm, dm) > R * R) return;                         // broad phase
+    const V3 a1 = v3(ci[4], ci[5], ci[6]), b1 = v3(ci[8], ci[9], ci[10]), a2 = v3(ck[4], ck[5], ck[6]), b2 = v3(ck[8], ck[9], ck[10]);
+    const float r1 = ci[7], m1 = ci[11], r2 = ck[7], m2 = ck[11];
+    V3 c1, c2;
+    seg_seg_closest(a1, b1, a2, b2, &c1, &c2);
+    V3 n = c1 - c2;
+    const float dist = norm(n), pen = r1 + r2 - dist;
+    if (pen <= 0.f) return;
+    n = dist > 1e-6f ? n * (1.0f / dist) : v3(0.f, 0.f, 1.f);
+    const V3 cp = c2 + n * (r2 - 0.5f * pen);                // middle of the overlap
+    constexpr int es = Xch::es;
+    const float* si = xslot(x, i);
+    const float* sk = xslot(x, k);
+    const V3 pi = v3(si[10 * es], si[11 * es], si[12 * es]), wi = v3(si[13 * es], si[14 * es], si[15 * es]), vi = v3(si[16 * es], si[17 * es], si[18 * es]);
+    const V3 pk = v3(sk[10 * es], sk[11 * es], sk[12 * es]), wk = v3(sk[13 * es], sk[14 * es], sk[15 * es]), vk = v3(sk[16 * es], sk[17 * es], sk[18 * es]);
+    const V3 vrel = (vi + cross(wi, cp - pi)) - (vk + cross(wk, cp - pk));
+    const float mu = m1 * m2 / (m1 + m2);
+    const float kk = prm.self_stiffness_scale * mu / (dt * dt);
+    const float cc = 2.0f * prm.self_damping_ratio * sqrtf(kk * mu);
+    const float fn = kk * pen - cc * dot(vrel, n);
+    if (fn <= 0.f) return;                                   // non-adhesive
+    // force on body i (+) and body k (-), quantised once so that both bodies see exactly opposite values
+    const int32_t fx = (int32_t)rintf(n.x * fn * PHC_SC_FSCALE), fy = (int32_t)rintf(n.y * fn * PHC_SC_FSCALE), fz = (int32_t)rintf(n.z * fn * PHC_SC_FSCALE);
+    const V3 F = v3((float)fx, (float)fy, (float)fz) * (1.0f / PHC_SC_FSCALE);
+    const V3 ni = cross(cp - pi, F), nk = cross(cp - pk, F);
+    int32_t* ai = reinterpret_cast<int32_t*>(caps + PHC_CAP_STRIDE * i + 12);
+    int32_t* ak = reinterpret_cast<int32_t*>(caps + PHC_CAP_STRIDE * k + 12);
+    sc_atomic_add(ai + 0, fx); sc_atomic_add(ai + 1, fy); sc_atomic_add(ai + 2, fz);
+    sc_atomic_add(ak + 0, -fx); sc_atomic_add(ak + 1, -fy); sc_atomic_add(ak + 2, -fz);
+    sc_atomic_add(ai + 3, (int32_t)rintf(ni.x * PHC_SC_NSCALE)); sc_atomic_add(ai + 4, (int32_t)rintf(ni.y * PHC_SC_NSCALE)); sc_atomic_add(ai + 5, (int32_t)rintf(ni.z * PHC_SC_NSCALE));
+    sc_atomic_add(ak + 3, -(int32_t)rintf(nk.x * PHC_SC_NSCALE)); sc_atomic_add(ak + 4, -(int32_t)rintf(nk.y * PHC_SC_NSCALE)); sc_atomic_add(ak + 5, -(int32_t)rintf(nk.z * PHC_SC_NSCALE));
+}
+// lane `l` of `nl` lanes of the env's group: its share of the candidate pairs, fetched ONCE per launch into registers (the list
+// sits in global memory; a dependent L2 round trip per pair and sub-step was the largest part of the first version's cost)
+#define PHC_SC_MAX_PER_LANE 18
+struct PairList { int pr[PHC_SC_MAX_PER_LANE]; };
+PHC_HD void aba_load_pairs(PairList& P, const phc_model_t& m, int l, int nl) {
+    const int np = model_num_pairs(m);
+#pragma unroll
+    for (int t = 0; t < PHC_SC_MAX_PER_LANE; ++t) {
+        const int q = t * nl + l;
+        P.pr[t] = q < np ? model_pair(m, q) : -1;
+    }
+}
+PHC_HD void aba_collide_pairs(const PairList& P, const phc_sim_params_t& prm, float dt, const Xch& x, float* caps) {
+#pragma unroll
+    for (int t = 0; t < PHC_SC_MAX_PER_LANE; ++t)
+        if (P.pr[t] >= 0) aba_collide_pair(prm, dt, P.pr[t] & 0xff, P.pr[t] >> 8, x, caps);
+}
+// net body-body contact force / moment of body j from its accumulators
+PHC_HD void aba_collect_self(AbaLane& L, int j, const float* caps) {
+    const int32_t* acc = reinterpret_cast<const int32_t*>(caps + PHC_CAP_STRIDE * j + 12);
+    L.fself = v3((float)acc[0], (float)acc[1], (float)acc[2]) * (1.0f / PHC_SC_FSCALE);
+    L.nself = v3((float)acc[3], (float)acc[4], (float)acc[5]) * (1.0f / PHC_SC_NSCALE);
 }
 
 // 6x6 congruence T^T I T and T^T p for a pure translation r (child origin - parent origin)

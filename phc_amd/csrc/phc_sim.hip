@@ -30,6 +30,7 @@ __global__ __launch_bounds__(64, 2) void k_sim_step(phc_model_t model, phc_sim_p
                                                 const float* __restrict__ pd_scale, const int32_t* __restrict__ freeze,
                                                 int num_sim_calls, const int64_t* __restrict__ env_ids, int num_listed) {
     __shared__ float xch_all[2 * PHC_MAX_BODIES * PHC_XCH_STRIDE];
+    __shared__ float cap_all[2 * PHC_MAX_BODIES * PHC_CAP_STRIDE];
     const int lane = threadIdx.x & (GRP - 1);
     const int grp = threadIdx.x >> 5;
     const int64_t slot = (int64_t)blockIdx.x * 2 + grp;
@@ -61,7 +62,17 @@ __global__ __launch_bounds__(64, 2) void k_sim_step(phc_model_t model, phc_sim_p
     if (STEP) {
         const float dt = prm.sim_dt / (float)prm.substeps;
         const int nsub = num_sim_calls * prm.substeps;
+        float* caps = cap_all + grp * PHC_MAX_BODIES * PHC_CAP_STRIDE;
+        PairList pairs;
+        if (prm.self_collision) aba_load_pairs(pairs, model, lane, GRP);
         for (int s = 0; s < nsub; ++s) {
+            if (prm.self_collision) {   // body-body contact from the kinematics the last sweep left in the exchange slots
+                if (active) aba_publish_capsule(L, model_body(model, lane), caps + PHC_CAP_STRIDE * lane);
+                __syncthreads();
+                if (env < sim.num_envs) aba_collide_pairs(pairs, prm, dt, x, caps);
+                __syncthreads();
+                if (active) aba_collect_self(L, lane, caps);
+            }
             if (active) aba_body_init<JT>(L, model, prm, dt, lane, s % prm.substeps == 0);
             for (int l = max_level; l >= 0; --l) { aba_backward_level<JT>(L, l, lane, x); __syncthreads(); }
             for (int l = 0; l <= max_level; ++l) { aba_forward_level<JT>(L, l, lane, x, prm, dt); __syncthreads(); }
@@ -88,6 +99,7 @@ __global__ __launch_bounds__(64, 1) void k_sim_step16(phc_model_t model, phc_sim
                                                   const float* __restrict__ pd_scale, const int32_t* __restrict__ freeze,
                                                   int num_sim_calls) {
     __shared__ float xch_all[4 * PHC_MAX_BODIES * PHC_XCH_STRIDE];
+    __shared__ float cap_all[4 * PHC_MAX_BODIES * PHC_CAP_STRIDE];
     const int lane = threadIdx.x & 15;
     const int grp = threadIdx.x >> 4;
     const int64_t env = (int64_t)blockIdx.x * 4 + grp;
@@ -124,8 +136,20 @@ __global__ __launch_bounds__(64, 1) void k_sim_step16(phc_model_t model, phc_sim
     }
     const float dt = prm.sim_dt / (float)prm.substeps;
     const int nsub = num_sim_calls * prm.substeps;
+    PairList pairs;
+    if (prm.self_collision) aba_load_pairs(pairs, model, lane, 16);
     for (int s = 0; s < nsub; ++s) {
         const bool fresh = s % prm.substeps == 0;
+        if (prm.self_collision) {   // body-body contact from the kinematics the last sweep left in the exchange slots
+            float* caps = cap_all + grp * PHC_MAX_BODIES * PHC_CAP_STRIDE;
+            if (jA >= 0) aba_publish_capsule(LA, model_body(model, jA), caps + PHC_CAP_STRIDE * jA);
+            if (jB >= 0) aba_publish_capsule(LB, model_body(model, jB), caps + PHC_CAP_STRIDE * jB);
+            __syncthreads();
+            if (env_ok) aba_collide_pairs(pairs, prm, dt, x, caps);
+            __syncthreads();
+            if (jA >= 0) aba_collect_self(LA, jA, caps);
+            if (jB >= 0) aba_collect_self(LB, jB, caps);
+        }
         // slot A's articulated quantities are initialised only when the sweep reaches its levels: while the deep (slot B) levels
         // run, slot A holds kinematic state only (27 fewer live registers)
         if (jB >= 0) aba_body_init<JT>(LB, model, prm, dt, jB, fresh);
@@ -183,6 +207,7 @@ int32_t phc_sim_step(const phc_model_t* model, const phc_sim_params_t* params, c
     if (!params || !sim || sim->num_envs < 0 || params->substeps < 1 || num_sim_calls < 0) return PHC_EINVAL;
     if (actions && (!pd_action_offset || !pd_action_scale)) return PHC_EINVAL;
     if (sim->num_envs == 0) return 0;
+    if (params->self_collision && model->num_collision_pairs > PHC_SC_MAX_PER_LANE * 16) return PHC_EUNSUPPORTED;
     // lane_mapping 1 / 2 force a kernel; 0 picks.  Measured on MI355X at N = 4096 (scripts/gpu_map.sh): SMPL (tree depth 8, 2.8 contact
     // points per body) 106 us one-body-per-lane vs 89 us two-slot; H1 (depth 5, 12.8 contact points per body, 8 sub-steps) 104 vs
     // 126 us -- the two-slot kernel runs the per-body initialisation (inertia rotation, contacts, drive) twice per sub-step, which

@@ -117,7 +117,7 @@ class HumanoidIm:
             raise NotImplementedError("shape / limb-weight observations are not built")
         self.has_shape_variation = False
         self._has_dof_subset = robot.get("has_dof_subset", False)
-        self._has_self_collision = robot.get("has_self_collision", False)  # ground contact only in this round (SURVEY f-1)
+        self._has_self_collision = robot.get("has_self_collision", False)
         self._freeze_toe = robot.get("freeze_toe", True)
         self._freeze_hand = robot.get("freeze_hand", True)
         self._bias_offset = robot.get("bias_offset", False)
@@ -192,6 +192,7 @@ class HumanoidIm:
             self.p_gains = torch.tensor(self._robot_consts["p_gains"][env.get("pd_v", 1)], dtype=torch.float32, device=self.device)
             self.d_gains = torch.tensor(self._robot_consts["d_gains"][env.get("pd_v", 1)], dtype=torch.float32, device=self.device)
             self.default_dof_pos = torch.tensor([self._robot_consts["default_dof_pos"]], dtype=torch.float32, device=self.device)
+        robots.apply_collision_filter(self.model, self.humanoid_type)   # humanoid.py:1205-1226
         self.num_bodies, self.num_dof = self.model.num_bodies, self.model.num_dof
         self.skeleton_trees = [SkeletonTree(self.model.body_names, self.model.parent, self.model.local_translation)] * self.num_envs
         ints, floats = self.model.pack(self._kp_scale, self._kd_scale)
@@ -312,7 +313,10 @@ class HumanoidIm:
             control_mode=0 if self.control_mode == "isaac_pd" else (1 if solver.get("pd_damping", "continuous") == "held" else 2),
             limit_stiffness=float(solver.get("joint_limit_stiffness", 2000.0 if self._is_robot else 0.0)),
             limit_damping=float(solver.get("joint_limit_damping", 20.0 if self._is_robot else 0.0)),
-            lane_mapping=int(solver.get("lane_mapping", 0)))
+            lane_mapping=int(solver.get("lane_mapping", 0)),
+            # body-body contact between non-adjacent links (robot.has_self_collision, on in the shipped robot yamls)
+            self_collision=int(bool(solver.get("self_collision", self._has_self_collision))),
+            self_stiffness_scale=float(solver.get("self_stiffness_scale", 0.25)), self_damping_ratio=float(solver.get("self_damping_ratio", 0.5)))
 
         # ---- action scaling (A1) + freeze masks (humanoid.py:1331-1409,1549-1554) ----
         self.dof_limits_lower, self.dof_limits_upper = (torch.from_numpy(x).to(dev) for x in self.model.dof_limits())

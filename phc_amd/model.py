@@ -129,6 +129,35 @@ class _Attr:
         self.attrib = attrib
 
 
+def _geom_capsule(g, defaults, pts):
+    """Collision capsule (a[3], b[3], radius) standing in for a body's geom in body-body contact: spheres and capsules are
+    exact, a box becomes the capsule along its longest axis with the mean of the two other half extents as radius, a mesh the
+    capsule spanned by its two farthest hull support points with the median distance of the others to that axis."""
+    gtype = g.attrib.get("type", defaults.get("type", "sphere"))
+    size = _floats(g.attrib.get("size"), [0.0])
+    if gtype == "sphere":
+        c = _floats(g.attrib.get("pos"), [0, 0, 0])
+        return np.concatenate([c, c, [size[0]]])
+    if gtype in ("capsule", "cylinder"):
+        (p0, r), (p1, _) = pts[0], pts[1]
+        return np.concatenate([p0, p1, [r]])
+    if gtype == "box":
+        pos = _floats(g.attrib.get("pos"), [0, 0, 0])
+        R = _quat_wxyz_to_mat(_floats(g.attrib.get("quat"), [1, 0, 0, 0]))
+        h = size[:3]
+        k = int(np.argmax(h))
+        r = float(np.mean(np.delete(h, k)))
+        half = max(h[k] - r, 0.0)
+        return np.concatenate([pos - R[:, k] * half, pos + R[:, k] * half, [r]])
+    P = np.array([p for p, _ in pts])
+    d = np.linalg.norm(P[:, None] - P[None], axis=-1)
+    i, j = np.unravel_index(np.argmax(d), d.shape)
+    ax = (P[j] - P[i]) / max(d[i, j], 1e-9)
+    off = P - P[i]
+    rad = float(np.median(np.linalg.norm(off - np.outer(off @ ax, ax), axis=-1)))
+    return np.concatenate([P[i] + ax * rad, P[j] - ax * rad, [rad]]) if d[i, j] > 2 * rad else np.concatenate([0.5 * (P[i] + P[j])] * 2 + [[0.5 * d[i, j]]])
+
+
 def compile_mjcf(path):
     """Parse an MJCF humanoid (free root + hinge joints) into the flat model dict."""
     root = ET.parse(path).getroot()
@@ -161,6 +190,7 @@ def compile_mjcf(path):
     jtype, dof_start, dof_count = [], [], []
     dof_axis, dof_kp, dof_kd, dof_arm, dof_lo, dof_hi, dof_effort, dof_names = [], [], [], [], [], [], [], []
     cpts = []
+    capsules = []
 
     def add(node, parent):
         idx = len(names)
@@ -184,12 +214,17 @@ def compile_mjcf(path):
                 Ic = R @ Ic @ R.T
             mc = m_tot * c
             parts = [(m_tot, c, Ic)]
+        capsules.append(np.zeros(7))
+        first_geom = True
         for g in node.findall("geom"):
             if g.attrib.get("contype") == "0" and g.attrib.get("conaffinity") == "0":
                 continue  # visual-only geom (robots)
             if g.attrib.get("type") == "mesh" and g.attrib.get("mesh") not in meshes:
                 continue
             gm, gc, gI, pts = _geom_props(g, geom_defaults, meshes)
+            if first_geom:
+                capsules[idx] = _geom_capsule(g, geom_defaults, pts)
+                first_geom = False
             for p, r in pts:
                 cpts.append((idx, np.asarray(p, dtype=np.float64), float(r)))
             if inert is None:
@@ -253,6 +288,7 @@ def compile_mjcf(path):
         "contact_body": [c[0] for c in cpts],
         "contact_pos": [c[1].tolist() for c in cpts],
         "contact_radius": [c[2] for c in cpts],
+        "collision_capsule": np.array(capsules).tolist(),
     }
     return model
 
@@ -290,6 +326,8 @@ class ArticulationModel:
         self.contact_body = np.array(d["contact_body"], dtype=np.int32)
         self.contact_pos = np.array(d["contact_pos"], dtype=np.float64).reshape(-1, 3)
         self.contact_radius = np.array(d["contact_radius"], dtype=np.float64)
+        self.collision_capsule = np.array(d.get("collision_capsule", np.zeros((self.num_bodies, 7))), dtype=np.float64).reshape(-1, 7)
+        self.collision_filter = np.zeros(self.num_bodies, dtype=np.int64)   # Isaac Gym shape filter bits (robots.py installs them)
         self.max_level = int(self.level.max())
         self.all_spherical = bool(np.all(self.joint_type[1:] == JOINT_SPHERICAL))
         self.all_revolute = bool(np.all(self.joint_type[1:] == JOINT_REVOLUTE))
@@ -309,6 +347,19 @@ class ArticulationModel:
             ch[self.parent[i]].append(i)
         return ch
 
+    def collision_allow_masks(self):
+        """Bit j of entry i: bodies i and j may collide -- not the same body, not joined by a joint (PhysX articulations never
+        collide parent and child), no common Isaac Gym filter bit (humanoid.py:1205-1226: shapes collide iff (fa & fb) == 0),
+        and both carry a collision capsule."""
+        nb = self.num_bodies
+        has = self.collision_capsule[:, 6] > 0
+        m = np.zeros(nb, dtype=np.int64)
+        for i in range(nb):
+            for j in range(nb):
+                if i != j and has[i] and has[j] and self.parent[i] != j and self.parent[j] != i and (self.collision_filter[i] & self.collision_filter[j]) == 0:
+                    m[i] |= 1 << j
+        return m
+
     def two_slot_split(self):
         """(split level, bodies below it) for the stepper's two-slot mapping: slot A = bodies of levels < split, slot B = the rest,
         both <= 16 bodies, as balanced as possible; (-1, 0) when the tree admits no such split (the 32-lane kernel is used)."""
@@ -325,13 +376,14 @@ class ArticulationModel:
 
         ints  : [0]=NB [1]=ND [2]=max_level [3]=NCP then per body (32 slots each):
                 parent, level, joint_type, dof_start, child0, child1, child2, nchild,
-                cp_start, cp_count, order (bodies sorted by level), misc [split level, bodies below it]
+                cp_start, cp_count, order (bodies sorted by level), misc [split level, bodies below it],
+                self-collision partner mask
         floats: per body (32 slots x 36): r_local[3], mass, m*com[3], Io(xx,xy,xz,yy,yz,zz)[6],
-                kp[3], kd[3], armature[3], effort[3], axis[3] (revolute), rest rotation xyzw[4], limit lo/hi [2], contact bound radius, pad ;
+                kp[3], kd[3], armature[3], effort[3], axis[3] (revolute), rest rotation xyzw[4], limit lo/hi [2], contact bound radius, pad, collision capsule a[3] b[3] radius, pad ;
                 then contact points NCP x 4 (pos[3], radius)
         """
         NB, MB = self.num_bodies, self.MAX_BODIES
-        NT = 12
+        NT = 13
         ints = np.zeros(4 + NT * MB, dtype=np.int32)
         ints[0:4] = [NB, self.num_dof, self.max_level, len(self.contact_body)]
         tab = ints[4:].reshape(NT, MB)
@@ -355,6 +407,21 @@ class ArticulationModel:
         # two-slot mapping of the stepper (16 lanes per env, 4 envs per wavefront): slot A = bodies of levels < split, slot B = the
         # rest, both <= 16 bodies, so that at every tree level all active bodies sit in the same slot.  tab[11] = [split, nA].
         tab[11, 0:2] = self.two_slot_split()
+        tab[12, :NB] = self.collision_allow_masks().astype(np.uint32).view(np.int32)   # self-collision partner bit masks
+        # self-collision candidate pairs (i < k, may collide), appended after the tables: [count, i | k << 8, ...]; lane l of a
+        # group evaluates pairs l, l + L, l + 2L, ... so the list is ordered to spread each body's pairs over many lanes
+        masks = self.collision_allow_masks()
+        pairs = [(i, k) for i in range(NB) for k in range(i + 1, NB) if (int(masks[i]) >> k) & 1]
+        # lanes work through the list in lock step (pair t * L + l in round t): sorted by the gap between the bounding spheres in
+        # the rest pose, a round holds pairs that are either all near (everyone runs the capsule test) or all far (nobody does)
+        org = np.zeros((NB, 3))
+        for j in range(1, NB):
+            org[j] = org[self.parent[j]] + self.local_translation[j]
+        cap = self.collision_capsule
+        mid = org + 0.5 * (cap[:, 0:3] + cap[:, 3:6])
+        rad = 0.5 * np.linalg.norm(cap[:, 3:6] - cap[:, 0:3], axis=-1) + cap[:, 6]
+        pairs.sort(key=lambda ik: np.linalg.norm(mid[ik[0]] - mid[ik[1]]) - rad[ik[0]] - rad[ik[1]])
+        ints = np.concatenate([ints, np.array([len(pairs)] + [i | (k << 8) for i, k in pairs], dtype=np.int32)])
         BF = self.BODY_FLOATS
         fl = np.zeros((MB, BF), dtype=np.float64)
         fl[:, 31] = 1.0  # identity rest rotation (xyzw)
@@ -379,11 +446,12 @@ class ArticulationModel:
             idx = np.nonzero(self.contact_body == i)[0]
             # contact broad phase: no point of the body can touch z = 0 while the body origin is higher than this
             fl[i, 34] = (np.linalg.norm(self.contact_pos[idx], axis=-1) + self.contact_radius[idx]).max() * 1.0001 if len(idx) else 0.0
+            fl[i, 36:43] = self.collision_capsule[i]
         cp = np.concatenate([self.contact_pos, self.contact_radius[:, None]], axis=1) if len(self.contact_body) else np.zeros((0, 4))
         floats = np.concatenate([fl.reshape(-1), cp.reshape(-1)]).astype(np.float32)
         return ints, floats
 
-    BODY_FLOATS = 36
+    BODY_FLOATS = 44
 
     # ---- action scaling (A1) ---------------------------------------------------------------
     def dof_limits(self):

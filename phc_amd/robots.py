@@ -22,3 +22,16 @@ def apply_robot_gains(model, robot, pd_v=1):
     model.dof_kd[:] = np.asarray(robot["d_gains"][pd_v], dtype=np.float64)
     model.dof_effort[:] = robot["torque_limit"]
     return model
+
+
+# Isaac Gym rigid-shape collision filters the reference sets when robot.has_self_collision (humanoid.py:1205-1226): two shapes
+# of one actor collide iff (filter_a & filter_b) == 0; body order of the respective asset.
+COLLISION_FILTERS = {
+    "smpl": [0, 0, 7, 16, 12, 0, 56, 2, 33, 128, 0, 192, 0, 64, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0],
+    "h1": [0, 2, 0, 2, 0, 0, 1, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0],
+}
+
+
+def apply_collision_filter(model, humanoid_type):
+    model.collision_filter[:] = np.asarray(COLLISION_FILTERS[humanoid_type], dtype=np.int64)
+    return model

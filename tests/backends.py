@@ -121,6 +121,8 @@ BACKENDS = ["hostemu", pytest.param("hip", marks=pytest.mark.gpu)]
 def model_on(be, name="smpl_humanoid", kp_scale=1.0, kd_scale=1.0, zero_armature=False):
     from phc_amd.model import load_model
     m = load_model(name)
+    from phc_amd.robots import apply_collision_filter
+    apply_collision_filter(m, "h1" if name == "h1_humanoid" else "smpl")
     if name == "h1_humanoid":
         from phc_amd.robots import H1, apply_robot_gains
         apply_robot_gains(m, H1)

@@ -269,3 +269,74 @@ def test_two_slot_mapping_equals_one_body_per_lane(name, nd):
         for k in ("root", "dof", "rbs", "cf", "df"):
             np.testing.assert_allclose(outs[0][k], outs[1][k], rtol=1e-4, atol={"cf": 5e-2, "df": 5e-3}.get(k, 1e-4), err_msg=f"{name} n={n} {k}")
         assert np.isfinite(outs[0]["rbs"]).all()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# body-body contact (SURVEY f-1)
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("name", ["smpl_humanoid", "h1_humanoid"])
+def test_self_collision_matches_dense_oracle(backend, name):
+    """Capsule-capsule penalty contact between non-adjacent bodies: kernel == fp64 dense oracle with the same explicit forces,
+    on folded poses that make limbs overlap."""
+    be = get_backend(backend)
+    model, mstruct, keep = model_on(be, name)
+    rng = np.random.default_rng(8)
+    n = 6
+    root, dof, target = random_states(model, n, rng, height=1.5, vel=0.5, pose=0.9)
+    h1 = name == "h1_humanoid"
+    kw = dict(sim_dt=1 / 200, control_freq_inv=4, control_mode=2) if h1 else {}
+    params = abi.sim_params_struct(self_collision=1, **kw)
+    out = run_step(be, model, mstruct, root, dof, target, params, 1)
+    hits = 0
+    for e in range(n):
+        st = do.State(root[e], dof[e], model)
+        Q, R, p = do.kinematics(model, st)
+        w, v = do.body_velocities(model, st, R, p)
+        Fs, _ = do.self_collision_wrenches(model, R, p, w, v, dict(do.DEFAULT_PARAMS), (1 / 200 if h1 else 1 / 60) / 2)
+        hits += int((np.abs(Fs).sum(-1) > 0).sum())
+        r, d, rbs, tau, fc = do.sim_step(model, root[e], dof[e], target[e], params=dict(self_collision=1, control_mode=2 if h1 else 0),
+                                         sim_dt=1 / 200 if h1 else 1 / 60, substeps=2, num_sim_calls=1)
+        np.testing.assert_allclose(out["root"][e], r, atol=5e-4, rtol=2e-4, err_msg=f"root env {e}")
+        np.testing.assert_allclose(out["dof"][e, :, 1], d[:, 1], atol=2e-2, rtol=2e-3, err_msg=f"dof vel env {e}")
+        np.testing.assert_allclose(out["rbs"][e][:, 0:3], rbs[:, 0:3], atol=5e-4, err_msg="body pos")
+        np.testing.assert_allclose(out["cf"][e], fc, atol=1.0, rtol=1e-2, err_msg="contact force (incl. body-body)")
+    assert hits >= 6, f"the folded poses must produce overlapping limbs ({hits})"
+
+
+def _max_penetration(model, root, dof):
+    st = do.State(root, dof, model)
+    Q, R, p = do.kinematics(model, st)
+    cap, masks, worst = model.collision_capsule, model.collision_allow_masks(), 0.0
+    for i in range(model.num_bodies):
+        for k in range(i + 1, model.num_bodies):
+            if (int(masks[i]) >> k) & 1:
+                c1, c2 = do.seg_seg_closest(p[i] + R[i] @ cap[i, 0:3], p[i] + R[i] @ cap[i, 3:6], p[k] + R[k] @ cap[k, 0:3], p[k] + R[k] @ cap[k, 3:6])
+                worst = max(worst, cap[i, 6] + cap[k, 6] - np.linalg.norm(c1 - c2))
+    return worst
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_self_collision_forces_are_internal_and_separate_the_limbs(backend):
+    """Each lane evaluates its half of a colliding pair with the same arithmetic: the published net contact forces of an env
+    (no ground in reach) sum to zero; with passive joints and no gravity the overlapping limbs are pushed apart."""
+    be = get_backend(backend)
+    model, mstruct, keep = model_on(be, "smpl_humanoid", kp_scale=0.0, kd_scale=0.0)
+    rng = np.random.default_rng(3)
+    n = 8
+    root, dof, target = random_states(model, n, rng, height=5.0, vel=0.0, pose=1.0)
+    dof[:, :, 1] = 0
+    root[:, 7:13] = 0
+    params = abi.sim_params_struct(self_collision=1, gravity_z=0.0)
+    pen0 = np.array([_max_penetration(model, root[e], dof[e]) for e in range(n)])
+    assert (pen0 > 0.02).sum() >= 4, pen0
+    out = run_step(be, model, mstruct, root, dof, target, params, 2)
+    cf = out["cf"]
+    assert np.abs(cf).sum(axis=(1, 2)).max() > 50.0
+    np.testing.assert_allclose(cf.sum(axis=1), 0.0, atol=2e-3 * np.abs(cf).sum(axis=1).max())
+    r, d = out["root"], out["dof"]
+    for _ in range(14):   # 0.5 s in total
+        o = run_step(be, model, mstruct, r, d, target, params, 2)
+        r, d = o["root"], o["dof"]
+    pen1 = np.array([_max_penetration(model, r[e], d[e]) for e in range(n)])
+    assert np.isfinite(r).all() and (pen1 < 0.6 * pen0 + 0.005).all(), (pen0, pen1)
