@@ -166,7 +166,11 @@ class IMAmpAgent:
         self._amp_input_mean_std = RunningMeanStd((amp_dim,)).to(self.device) if self._normalize_amp_input else None
         self.running_mean_std_temp = None
         self.grads = FlatGradBucket(self.model.parameters())
-        self.optimizer = torch.optim.Adam([self.grads.flat_param], self.last_lr, eps=1e-08, weight_decay=c.get("weight_decay", 0.0))
+        # one flat fp32 parameter: the fused implementation is a single launch per step (the default foreach path ran ~10
+        # elementwise passes over the 22 MB buffer: 323 -> ~30 us per step)
+        on_gpu = str(self.device).startswith("cuda")
+        self.optimizer = torch.optim.Adam([self.grads.flat_param], self.last_lr, eps=1e-08, weight_decay=c.get("weight_decay", 0.0),
+                                          **({"fused": True} if on_gpu else {}))
 
         T, N, dev = self.horizon_length, self.num_actors, self.device
         f = lambda *s: torch.zeros(*s, device=dev, dtype=torch.float32)
