@@ -79,6 +79,9 @@ _ROBOT_H1 = {  # robot/unitree_h1.yaml
     "base_link": "torso_link",
 }
 
+_ENV_VR = dict(_ENV_IM, notes="VR modell, three point tracking", reset_bodies=["Head", "L_Hand", "R_Hand"],   # env/env_vr.yaml
+               trackBodies=["Head", "L_Hand", "R_Hand"])
+
 _ROBOT_SMPL = {  # robot/smpl_humanoid.yaml
     "humanoid_type": "smpl", "bias_offset": False, "has_self_collision": True, "has_mesh": False, "has_jt_limit": False,
     "has_dof_subset": True, "has_upright_start": True, "has_smpl_pd_offset": False, "remove_toe": False, "motion_sym_loss": False,
@@ -140,7 +143,7 @@ def _with_net(units, activation, net_name, cfg, extra_net):
 
 _BIG = [2048, 1536, 1024, 1024, 512, 512]
 GROUPS = {
-    "env": {"env_im": _ENV_IM, "env_im_pnn": _ENV_IM_PNN, "env_im_getup_mcp": _ENV_IM_GETUP_MCP, "env_im_h1_phc": _ENV_IM_H1},
+    "env": {"env_im": _ENV_IM, "env_im_pnn": _ENV_IM_PNN, "env_im_getup_mcp": _ENV_IM_GETUP_MCP, "env_im_h1_phc": _ENV_IM_H1, "env_vr": _ENV_VR},
     "robot": {"smpl_humanoid": _ROBOT_SMPL, "unitree_h1": _ROBOT_H1},
     "learning": {"im": _learning([1024, 512], "relu"), "im_big": _learning(_BIG, "silu", extra_cfg={"save_frequency": 1500}),
                  "im_pnn": _learning([1024, 512], "relu", "amp_pnn"),

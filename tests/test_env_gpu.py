@@ -451,3 +451,15 @@ def test_reset_done_resets_exactly_the_finished_envs():
             assert set((task.progress_buf == 0).nonzero(as_tuple=False).flatten().tolist()) == done_ids
             assert (task._motion_start_times != st).sum() <= len(done_ids)
     assert total > 100
+
+
+def test_env_vr_three_point_tracking_config():
+    """env=env_vr (trackBodies = reset_bodies = Head, L_Hand, R_Hand): obs 358 + 72, episodes run, resets follow the three bodies."""
+    task, env = make_task(128, motion="synthetic:2:3:2.0", **{"env": "env_vr"})
+    assert task.num_obs == 358 + 72 and task._track_bodies == ["Head", "L_Hand", "R_Hand"]
+    obs = env.reset()
+    assert obs.shape == (128, 430) and torch.isfinite(obs).all()
+    for _ in range(20):
+        task.reset_done()
+        obs, rew, done, info = env.step((task.ref_dof_pos - task._pd_action_offset) / task._pd_action_scale)
+    assert torch.isfinite(obs).all() and torch.isfinite(rew).all() and task.progress_buf.max() > 5

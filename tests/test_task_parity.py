@@ -19,8 +19,10 @@ ENV_IM = dict(
 SPECS = po.DEFAULT_REWARD_SPECS
 
 
-def make_im_params(be, model, n_envs, use_mean=False, power_reward=True, power_coefficient=0.0005, **extra):
-    tabs = abi.task_index_tables(model, model.body_names, ENV_IM["reset_bodies"], ENV_IM["key_bodies"])
+def make_im_params(be, model, n_envs, use_mean=False, power_reward=True, power_coefficient=0.0005, track_bodies=None, reset_bodies=None, **extra):
+    track_bodies = track_bodies or model.body_names
+    reset_bodies = reset_bodies or ENV_IM["reset_bodies"]
+    tabs = abi.task_index_tables(model, track_bodies, reset_bodies, ENV_IM["key_bodies"])
     n_amp = tabs[4]
     amp_slot_np = tabs[3]
     track_slot, reset_mask, key_ids, amp_slot = (be.arr(t) for t in tabs[:4])
@@ -28,11 +30,11 @@ def make_im_params(be, model, n_envs, use_mean=False, power_reward=True, power_c
     prm = abi.im_params_struct(dt=2 * (1 / 60), max_episode_length=300, reward_specs=SPECS, power_reward=power_reward,
                                power_coefficient=power_coefficient, enable_early_termination=True, use_mean_termination=use_mean,
                                disable_collision_check=False, local_root_obs=True, root_height_obs=True,
-                               num_track_bodies=model.num_bodies, track_slot=track_slot, reset_mask=reset_mask,
-                               num_reset_bodies=len(ENV_IM["reset_bodies"]), first_reset_body=model.body_names.index(ENV_IM["reset_bodies"][0]),
+                               num_track_bodies=len(track_bodies), track_slot=track_slot, reset_mask=reset_mask,
+                               num_reset_bodies=len(reset_bodies), first_reset_body=model.body_names.index(reset_bodies[0]),
                                termination_distances=td,
                                num_key_bodies=len(ENV_IM["key_bodies"]), key_body_ids=key_ids, num_amp_joints=n_amp, amp_joint_slot=amp_slot,
-                               num_amp_obs_steps=10, num_amp_obs_per_step=196, num_self_obs=358, num_task_obs=576, **extra)
+                               num_amp_obs_steps=10, num_amp_obs_per_step=196, num_self_obs=358, num_task_obs=24 * len(track_bodies), **extra)
     prm._keepalive = (track_slot, reset_mask, key_ids, amp_slot, td)  # the struct only holds raw addresses
     return prm, (track_slot, reset_mask, be.np(key_ids), amp_slot_np, td)
 
@@ -281,3 +283,32 @@ def test_reset_from_state_vs_oracle(golden, backend):
     np.testing.assert_allclose(amp[rec_ids, 0], want_amp[3:], atol=2e-5)
     np.testing.assert_array_equal(amp[rec_ids, 1:], amp0[rec_ids, 1:])                                   # recovery keeps its history
     np.testing.assert_array_equal(amp[others], amp0[others])
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_three_point_tracking_vs_reference_golden(golden, backend):
+    """env_vr.yaml: trackBodies = reset_bodies = [Head, L_Hand, R_Hand] -- 72-float task obs in the trackBodies order and a reset
+    test on those three bodies only == the reference's functions on the subsets; the reward stays full-body (full_body_reward)."""
+    be = get_backend(backend)
+    g, gv = golden("task_fns"), golden("task_fns_vr")
+    gl = golden("motion_lib_eval")
+    model, mstruct, keepm = model_on(be)
+    lib, keep = motion_lib_on(be, gl)
+    N = g["body_pos"].shape[0]
+    vr = ["Head", "L_Hand", "R_Hand"]
+    prm, keepp = make_im_params(be, model, N, track_bodies=vr, reset_bodies=vr)
+    arrs, sim = _sim_arrays(be, g, N)
+    amp_in, amp_out = be.zeros((N, 10, 196)), be.zeros((N, 10, 196))
+    b = dict(progress=be.arr((g["progress"] - 1).astype(np.int64)), reset=be.zeros(N, np.int64), term=be.zeros(N, np.int64), rew=be.zeros(N),
+             raw=be.zeros((N, 5)), obs=be.zeros((N, 358 + 72)), mids=be.arr(g["env_motion"].astype(np.int64)),
+             st=be.arr(g["start_times"].astype(F)), so=be.zeros(N), goff=be.zeros((N, 3)))
+    buf = abi.im_buffers_struct(b["progress"], b["reset"], b["term"], b["rew"], b["raw"], b["obs"], amp_in, amp_out, b["mids"], b["st"], b["so"], b["goff"])
+    assert be.im_post_physics(mstruct, lib, prm, sim, buf) == 0
+    be.sync()
+    o = {k: be.np(v) for k, v in b.items()}
+    np.testing.assert_allclose(o["obs"][:, :358], g["self_obs"], atol=1e-5)
+    np.testing.assert_allclose(o["obs"][:, 358:], gv["task_obs"], atol=1e-5)
+    np.testing.assert_array_equal(o["reset"], gv["reset"])
+    np.testing.assert_array_equal(o["term"], gv["terminate"])
+    np.testing.assert_allclose(o["raw"][:, :4], g["reward_raw"], atol=1e-5)     # full-body reward unchanged
+    assert gv["terminate"].sum() > 0
