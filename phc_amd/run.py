@@ -39,8 +39,27 @@ def main(argv=None):
     vec_env = RLGPUEnv(env)
     agent = IMAmpAgent(env, cfg, dist=dist)
     ckpt = cfg.get("checkpoint", None)
+    if not ckpt and (cfg.test or cfg.get("epoch", 0) != 0):
+        # run_hydra.py:312-318: epoch=-1 -> output_path/Humanoid.pth, epoch=N -> Humanoid_{N:08d}.pth
+        ep = int(cfg.get("epoch", 0))
+        cand = os.path.join(cfg.output_path, "Humanoid.pth" if ep <= 0 else f"Humanoid_{ep:08d}.pth")
+        ckpt = cand if os.path.exists(cand) else None
     if ckpt:
         agent.restore(ckpt)
+    if cfg.test:
+        # player mode (phc/learning/im_amp_players.py:25-384): no learning; im_eval=True sweeps the whole motion set and reports the
+        # success rate / MPJPE table, otherwise a deterministic-policy rollout of `games` env steps reports episode statistics
+        if cfg.im_eval:
+            info, failed = agent.eval(output_dir=cfg.output_path)
+            if rank == 0:
+                print({k: (round(v, 4) if isinstance(v, float) else v) for k, v in info.items()}, "failed clips:", len(failed))
+        else:
+            info = play(agent, task, env, steps=int(cfg.get("games", 300)))
+            if rank == 0:
+                print(info)
+        if dist is not None:
+            dist.destroy_process_group()
+        return info
     info = agent.train(max_epochs)
     if rank == 0:
         out = os.path.join(cfg.output_path, "Humanoid.pth")
@@ -50,6 +69,30 @@ def main(argv=None):
     if dist is not None:
         dist.destroy_process_group()
     return info
+
+
+def play(agent, task, env, steps=300):
+    """Deterministic-policy rollout (players.PpoPlayerContinuous with is_determenistic=True): mean reward and episode length."""
+    agent.set_eval()
+    obs = env.reset()
+    rew_sum = torch.zeros(task.num_envs, device=task.device)
+    ep_len = torch.zeros(task.num_envs, device=task.device)
+    lens, rews = [], []
+    with torch.no_grad():
+        for _ in range(steps):
+            obs, r, done, info = env.step(agent.get_action_values(obs)["mus"])
+            rew_sum += r
+            ep_len += 1
+            ids = done.nonzero(as_tuple=False).flatten()
+            if len(ids):
+                lens.append(ep_len[ids].clone())
+                rews.append(rew_sum[ids].clone())
+                rew_sum[ids] = 0
+                ep_len[ids] = 0
+                obs = env.reset(ids)
+    lens = torch.cat(lens) if lens else ep_len
+    rews = torch.cat(rews) if rews else rew_sum
+    return {"episodes": int(lens.numel()), "mean_episode_length": float(lens.mean()), "mean_episode_reward": float(rews.mean()), "steps": steps}
 
 
 if __name__ == "__main__":

@@ -463,3 +463,21 @@ def test_env_vr_three_point_tracking_config():
         task.reset_done()
         obs, rew, done, info = env.step((task.ref_dof_pos - task._pd_action_offset) / task._pd_action_scale)
     assert torch.isfinite(obs).all() and torch.isfinite(rew).all() and task.progress_buf.max() > 5
+
+
+def test_run_entry_trains_saves_and_plays(tmp_path):
+    """`python -m phc_amd.run ...` the way run_hydra.py is used: a short training run saves Humanoid.pth; `test=True epoch=-1`
+    restores it and plays (deterministic policy); `test=True im_eval=True` runs the evaluation sweep."""
+    from phc_amd.run import main
+    from phc_amd.utils.flags import flags
+    common = ["env.num_envs=64", "env.motion_file=synthetic:3:4:1.5", f"output_path={tmp_path}", "learning.params.config.minibatch_size=512",
+              "learning.params.config.amp_obs_demo_buffer_size=1024", "learning.params.config.amp_replay_buffer_size=1024"]
+    try:
+        info = main(common + ["max_epochs=2"])
+        assert np.isfinite(info["actor_loss"]) and (tmp_path / "Humanoid.pth").exists()
+        played = main(common + ["test=True", "epoch=-1", "+games=40"])
+        assert played["steps"] == 40 and played["mean_episode_length"] > 0 and np.isfinite(played["mean_episode_reward"])
+        ev = main(common + ["test=True", "im_eval=True", "epoch=-1"])
+        assert 0.0 <= ev["eval/success_rate"] <= 1.0
+    finally:
+        flags.test = flags.im_eval = False
