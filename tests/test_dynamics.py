@@ -340,3 +340,34 @@ def test_self_collision_forces_are_internal_and_separate_the_limbs(backend):
         r, d = o["root"], o["dof"]
     pen1 = np.array([_max_penetration(model, r[e], d[e]) for e in range(n)])
     assert np.isfinite(r).all() and (pen1 < 0.6 * pen0 + 0.005).all(), (pen0, pen1)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_sliding_friction_decelerates_at_mu_g(backend):
+    """Regularised Coulomb friction: a humanoid lying on its back in the rest pose (stiff PD holds the pose) and sliding at 2 m/s
+    decelerates at mu * g (mu = 1) until it sticks; with mu = 0.5 at half that."""
+    be = get_backend(backend)
+    model, mstruct, keep = model_on(be)
+    for mu in (1.0, 0.5):
+        n = 2
+        root = np.zeros((n, 13), F)
+        root[:, 2] = 0.12
+        root[:, 3:7] = np.array([0.0, -np.sqrt(0.5), 0.0, np.sqrt(0.5)], F)   # lying on the back: body z axis along world -x... (pitch -90 deg)
+        dof = np.zeros((n, 69, 2), F)
+        target = np.zeros((n, 69), F)
+        params = abi.sim_params_struct(friction=mu)
+        out = dict(root=root, dof=dof)
+        for _ in range(10):   # settle on the ground (1/3 s)
+            out = run_step(be, model, mstruct, out["root"], out["dof"], target, params, 2)
+        r = out["root"].copy()
+        assert (r[:, 2] < 0.2).all() and np.abs(r[:, 7:10]).max() < 0.5, r
+        r[:, 7] = 2.0                     # push: 2 m/s along world x
+        r[:, 8:13] = 0
+        d = out["dof"].copy()
+        d[:, :, 1] = 0
+        o = run_step(be, model, mstruct, r, d, target, params, 2)          # one env step = 1/30 s
+        o = run_step(be, model, mstruct, o["root"], o["dof"], target, params, 2)
+        o = run_step(be, model, mstruct, o["root"], o["dof"], target, params, 2)   # 0.1 s in total
+        v = o["root"][:, 7]
+        expect = 2.0 - mu * 9.81 * 0.1
+        assert np.all(np.abs(v - expect) < 0.25 * mu * 9.81 * 0.1 + 0.05), (mu, v, expect)
