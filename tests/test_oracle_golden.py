@@ -1,5 +1,7 @@
 """Pin the numpy oracle (oracle/phc_oracle.py) against golden vectors produced by the
 reference's own code (oracle/gen_golden.py).  CPU only."""
+import os
+
 import numpy as np
 import pytest
 
@@ -114,3 +116,35 @@ def test_amass_conversion_matches_reference_poselib(golden):
     sk = golden("skeleton_smpl")
     lib = po.build_motion_lib(sk["parent_indices"], sk["local_translation"], [dict(out, fps=30)])
     np.testing.assert_allclose(np.abs((lib["grs"] * out["pose_quat_global"]).sum(-1)), 1.0, atol=1e-6)
+
+
+def test_poselib_rotation_kat(golden):
+    """The oracle's poselib restatements on the inputs of the reference's own rotation check (core/tests/test_rotation.py): quat_normalize,
+    quat_rotate, the rotate / inverse-rotate round trip it asserts, quat_mul_norm and quat_angle_axis."""
+    g = golden("poselib_kat")
+    np.testing.assert_allclose(po._pl_quat_normalize(g["q"].astype(np.float64)), g["q_normalized"], atol=1e-6)
+    np.testing.assert_allclose(po._pl_quat_rotate(g["q_normalized"].astype(np.float64), g["x"].astype(np.float64)), g["rotated"], atol=1e-6)
+    rot = np.broadcast_to(g["rot"].astype(np.float64), g["xs"].shape[:-1] + (4,))
+    back = po._pl_quat_rotate(po.quat_conjugate(rot), po._pl_quat_rotate(rot, g["xs"]))
+    np.testing.assert_allclose(back, g["xs"], atol=1e-6)          # the reference's own assertion (:30), rot is a unit quaternion
+    np.testing.assert_allclose(g["roundtrip"], g["xs"], atol=1e-6)
+    qa_n = po._pl_quat_normalize(g["qa"])
+    np.testing.assert_allclose(qa_n, g["qa_n"], atol=1e-12)
+    qb_n = po._pl_quat_normalize(g["qb"])
+    np.testing.assert_allclose(po._pl_quat_mul_norm(qa_n, qb_n), g["mul_norm"], atol=1e-12)
+    ang, ax = po._pl_quat_angle_axis(po._pl_quat_mul_norm(qa_n, po.quat_conjugate(qb_n)))
+    np.testing.assert_allclose(ang, g["diff_angle"], atol=1e-9)
+    np.testing.assert_allclose(ax, g["diff_axis"], atol=1e-9)
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/poselib/poselib/skeleton/tests/ant.xml"), reason="reference fixture only exists in the build container")
+def test_model_compiler_on_the_reference_ant_fixture(golden):
+    """compile_mjcf on the reference's only skeleton fixture (ant.xml: fixed bodies, single hinges, degrees, no free joint) gives the
+    tree SkeletonTree.from_mjcf reads from it."""
+    from phc_amd.model import compile_mjcf
+    g = golden("poselib_kat")
+    m = compile_mjcf("/root/reference/poselib/poselib/skeleton/tests/ant.xml")
+    assert m["body_names"] == list(g["ant_names"])
+    np.testing.assert_array_equal(np.array(m["parent"]), g["ant_parents"])
+    np.testing.assert_allclose(np.array(m["local_translation"]), g["ant_local_translation"], atol=1e-7)
+    assert len(m["dof_names"]) == 8 and abs(m["dof_upper"][0] - np.deg2rad(40)) < 1e-9
