@@ -80,7 +80,7 @@ def cpu_baseline(num_envs=4096, budget_s=12.0, max_steps=4000):
     lstruct, lkeep = hu.np_motion_lib(lib)
     tabs = abi.task_index_tables(model, model.body_names, [b for b in model.body_names if "Toe" not in b and "Ankle" not in b],
                                  ["R_Ankle", "L_Ankle", "R_Wrist", "L_Wrist"])
-    td = np.full(32, 0.25, F)
+    td = np.full(64, 0.25, F)
     prm = abi.im_params_struct(dt=1 / 30, max_episode_length=300, reward_specs=dict(k_pos=100, k_rot=10, k_vel=0.1, k_ang_vel=0.1, w_pos=0.5,
                                w_rot=0.3, w_vel=0.1, w_ang_vel=0.1), power_reward=True, power_coefficient=0.0005, enable_early_termination=True,
                                use_mean_termination=False, disable_collision_check=False, local_root_obs=True, root_height_obs=True,

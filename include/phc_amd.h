@@ -27,8 +27,8 @@
 extern "C" {
 #endif
 
-#define PHC_ABI_VERSION 7
-#define PHC_MAX_BODIES 32
+#define PHC_ABI_VERSION 8
+#define PHC_MAX_BODIES 64   /* bodies (incl. extended reference bodies) per articulation; also the slot count of the model tables */
 #define PHC_EINVAL (-1)
 #define PHC_EUNSUPPORTED (-2)
 #define PHC_RESET_SUBLISTS 16
@@ -38,14 +38,14 @@ extern "C" {
  * gym.load_asset / get_actor_dof_properties / get_actor_rigid_body_properties
  * (phc/env/tasks/humanoid.py:768-990,1093-1106). */
 typedef struct {
-    int32_t num_bodies;       /* NB <= 32 */
+    int32_t num_bodies;       /* NB <= PHC_MAX_BODIES; up to 32 bodies an env takes 32 lanes (two envs per wavefront), above one wavefront */
     int32_t num_dof;          /* D */
     int32_t max_level;        /* tree depth */
     int32_t num_contact_pts;
     const int32_t* ints;      /* packed tables, see model.py pack() */
     const float* floats;
     int32_t split_level;      /* two-slot stepper mapping: bodies of tree levels < split_level share lanes with the deeper ones; */
-    int32_t num_below_split;  /* -1 / 0 when the tree has no split with both halves <= 16 bodies (ArticulationModel.two_slot_split) */
+    int32_t num_below_split;  /* -1 / 0 when the tree has no split with both halves <= 16 (NB <= 32) or <= 32 bodies (ArticulationModel.two_slot_split) */
     int32_t num_collision_pairs; /* body pairs that may collide (listed after the int tables); <= 288 */
 } phc_model_t;
 
@@ -107,8 +107,8 @@ typedef struct {
                                          (mu = reduced mass) and damping ratio self_damping_ratio */
     float self_stiffness_scale;       /* <= 1 (explicit stability bound is 4); default 0.25 */
     float self_damping_ratio;         /* default 0.5 */
-    int32_t lane_mapping;             /* stepper thread mapping: 2 = 16 lanes per env, two bodies per lane, 4 envs per wavefront;
-                                         1 = 32 lanes per env, one body per lane, 2 envs per wavefront; 0 = pick by env count */
+    int32_t lane_mapping;             /* stepper thread mapping: 2 = two bodies per lane (16 lanes per env, 4 envs per wavefront; NB > 32: 32 lanes, 2 envs);
+                                         1 = one body per lane (32 lanes per env, 2 envs per wavefront; NB > 32: 64 lanes, 1 env); 0 = pick by env count */
 } phc_sim_params_t;
 
 /* Imitation-task parameters (phc/env/tasks/humanoid_im.py:37-123, env_im.yaml). */

@@ -116,11 +116,11 @@ int emu_im_post_physics(const phc_model_t* model, const phc_motion_lib_t* lib, c
         const int64_t progress = buf->progress_buf[env] + 1;
         const ImStepCtx c = im_post_prologue(*lib, *prm, *sim, *buf, env, progress);
         const float prev_goal = (prm->zero_out_far && buf->point_goal) ? buf->point_goal[env] : 0.f;
-        for (int lane = 0; lane < 32; ++lane) amp_shift_lane(*prm, *buf, env, lane);
+        for (int lane = 0; lane < PHC_MAX_BODIES; ++lane) amp_shift_lane(*prm, *buf, env, lane, PHC_MAX_BODIES);
         float s[6] = {0, 0, 0, 0, 0, 0};
         float root_dist = 0.f;
         int fallen = 0;
-        for (int lane = 0; lane < 32; ++lane) {
+        for (int lane = 0; lane < PHC_MAX_BODIES; ++lane) {
             RewardPartial rp = im_post_lane(*model, *lib, *prm, *sim, *buf, env, lane, c);
             s[0] += rp.pos; s[1] += rp.rot; s[2] += rp.vel; s[3] += rp.angvel; s[4] += rp.power; s[5] += rp.dist;
             if (lane == 0) root_dist = rp.root_dist;
@@ -135,7 +135,7 @@ int emu_im_post_physics(const phc_model_t* model, const phc_motion_lib_t* lib, c
 int emu_im_reset_from_state(const phc_model_t* model, const phc_motion_lib_t* lib, const phc_im_params_t* prm, const phc_sim_state_t* sim,
                             const phc_im_buffers_t* buf, int num_reset, const int64_t* env_ids, int fill_history) {
     for (int r = 0; r < num_reset; ++r)
-        for (int lane = 31; lane >= 0; --lane) im_reset_from_state_lane(*model, *lib, *prm, *sim, *buf, env_ids[r], lane, fill_history);
+        for (int lane = PHC_MAX_BODIES - 1; lane >= 0; --lane) im_reset_from_state_lane(*model, *lib, *prm, *sim, *buf, env_ids[r], lane, fill_history);
     return 0;
 }
 
@@ -148,8 +148,8 @@ int emu_im_reset(const phc_model_t* model, const phc_motion_lib_t* lib, const ph
         const int64_t mid = buf->sampled_motion_ids[env];
         const float t = start_at_zero ? 0.f : sample_time_interval(*lib, mid, phase[r]);
         for (int k = 0; k < prm->num_amp_obs_steps; ++k)
-            for (int lane = 0; lane < 32; ++lane) im_reset_amp_lane(*lib, *prm, *buf, model->num_bodies, env, lane, t, k);
-        for (int lane = 31; lane >= 0; --lane) im_reset_lane(*model, *lib, *prm, *sim, *buf, env, lane, t, true);
+            for (int lane = 0; lane < PHC_MAX_BODIES; ++lane) im_reset_amp_lane(*lib, *prm, *buf, model->num_bodies, env, lane, t, k);
+        for (int lane = PHC_MAX_BODIES - 1; lane >= 0; --lane) im_reset_lane(*model, *lib, *prm, *sim, *buf, env, lane, t, true);
     }
     return 0;
 }
@@ -160,7 +160,7 @@ int emu_amp_obs_demo(const phc_model_t* model, const phc_motion_lib_t* lib, cons
     for (int64_t g = 0; g < (int64_t)n * S; ++g) {
         const int64_t i = g / S;
         const int k = (int)(g - i * S);
-        for (int lane = 0; lane < 32; ++lane)
+        for (int lane = 0; lane < PHC_MAX_BODIES; ++lane)
             amp_obs_from_ref_lane(*lib, *prm, model->num_bodies, lane, ids[i], history_time(times0[i], prm->dt, k), out + g * A);
     }
     return 0;

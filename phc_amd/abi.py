@@ -9,6 +9,8 @@ import numpy as np
 
 from . import _lib as L
 
+MAX_BODIES = 64  # PHC_MAX_BODIES
+
 
 def ptr(x):
     """Raw address of a torch tensor / numpy array (must be contiguous), or None."""
@@ -23,7 +25,7 @@ def ptr(x):
 
 def model_struct(ints, floats, num_bodies, num_dof, max_level, num_contact_pts, split=(-1, 0)):
     m = L.Model()
-    m.num_collision_pairs = int(ints[4 + 13 * 32])   # count stored right after the 13 int tables (model.py pack())
+    m.num_collision_pairs = int(ints[4 + 13 * MAX_BODIES])   # count stored right after the 13 int tables (model.py pack())
     m.split_level, m.num_below_split = int(split[0]), int(split[1])
     m.num_bodies, m.num_dof, m.max_level, m.num_contact_pts = num_bodies, num_dof, max_level, num_contact_pts
     m.ints, m.floats = ptr(ints), ptr(floats)
@@ -164,11 +166,11 @@ def im_buffers_struct(progress_buf, reset_buf, terminate_buf, rew_buf, reward_ra
 
 def task_index_tables(model, track_bodies, reset_bodies, key_bodies, amp_remove_names=("L_Hand", "R_Hand", "L_Toe", "R_Toe"),
                       has_dof_subset=True):
-    """Per-body index tables the task kernels use (all int32 numpy, length 32).
+    """Per-body index tables the task kernels use (all int32 numpy, length PHC_MAX_BODIES).
 
     track_slot / reset_mask follow `_build_key_body_ids_tensor` (humanoid.py:1674-1691) on cfg.env.trackBodies /
     reset_bodies; amp_joint_slot follows the dof_subset construction (humanoid.py:388-413)."""
-    MB = 32
+    MB = MAX_BODIES
     names = model.body_names
     track_slot = np.full(MB, -1, dtype=np.int32)
     for s, n in enumerate(track_bodies):

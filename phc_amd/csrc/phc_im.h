@@ -1,5 +1,5 @@
 // phc_im.h -- per-lane bodies of the imitation-task kernels (post-physics step, reset, AMP demo).
-// One lane per rigid body, 32 lanes per environment.  PHC_HD so oracle/hostemu can drive the same
+// One lane per rigid body, 32 (or, above 32 bodies, 64) lanes per environment.  PHC_HD so oracle/hostemu can drive the same
 // code lane-by-lane on the CPU.  Reference call sites are cited at each step.
 #pragma once
 #include "phc_task.h"
@@ -61,8 +61,8 @@ PHC_HD void amp_obs_from_sim_lane(const phc_im_params_t& prm, const phc_sim_stat
 }
 
 // History shift of HumanoidAMP._update_hist_amp_obs (humanoid_amp.py:662-670), ping-pong:
-// out[env][1..S) = in[env][0..S-1).  Cooperative over the 32 lanes of the env, float4 wide.
-PHC_HD void amp_shift_lane(const phc_im_params_t& prm, const phc_im_buffers_t& buf, int64_t env, int lane) {
+// out[env][1..S) = in[env][0..S-1).  Cooperative over the `nl` lanes of the env, float4 wide.
+PHC_HD void amp_shift_lane(const phc_im_params_t& prm, const phc_im_buffers_t& buf, int64_t env, int lane, int nl) {
     const int A = prm.num_amp_obs_per_step, S = prm.num_amp_obs_steps;
     const float* src = buf.amp_obs_in + env * (int64_t)(S * A);
     float* dst = buf.amp_obs_out + env * (int64_t)(S * A) + A;
@@ -70,9 +70,9 @@ PHC_HD void amp_shift_lane(const phc_im_params_t& prm, const phc_im_buffers_t& b
     if ((A & 3) == 0) {
         const float4* s4 = reinterpret_cast<const float4*>(src);
         float4* d4 = reinterpret_cast<float4*>(dst);
-        for (int i = lane; i < n / 4; i += 32) d4[i] = s4[i];
+        for (int i = lane; i < n / 4; i += nl) d4[i] = s4[i];
     } else {
-        for (int i = lane; i < n; i += 32) dst[i] = src[i];
+        for (int i = lane; i < n; i += nl) dst[i] = src[i];
     }
 }
 

@@ -1,8 +1,9 @@
 // phc_kernels.hip -- gfx950 kernels + the extern "C" entry points declared in include/phc_amd.h.
 //
-// Thread mapping used by every env kernel: ONE LANE PER RIGID BODY, 32 lanes per environment,
-// two environments per 64-wide wavefront.  Task kernels: 256-thread workgroups (8 envs), per-env sums by 32-lane
-// butterfly shuffles.  Stepper: one wavefront per workgroup (see k_sim_step).
+// Thread mapping used by every env kernel: ONE LANE PER RIGID BODY, G = 32 lanes per environment (two environments per
+// 64-wide wavefront) for articulations of up to 32 bodies incl. the extended reference bodies, G = 64 (one environment per
+// wavefront) above.  Task kernels: 256-thread workgroups (8 or 4 envs), per-env sums by G-lane butterfly shuffles.
+// Stepper: one wavefront per workgroup (phc_sim.hip).
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 #include "phc_aba.h"  // model table accessors (k_fk)
@@ -10,16 +11,16 @@
 
 using namespace phc;
 
-#define GRP 32  // lanes per environment
-
+template <int G>
 __device__ __forceinline__ float group_sum(float v) {
 #pragma unroll
-    for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m, GRP);
+    for (int m = G / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, G);
     return v;
 }
+template <int G>
 __device__ __forceinline__ int group_or(int v) {
 #pragma unroll
-    for (int m = 16; m >= 1; m >>= 1) v |= __shfl_xor(v, m, GRP);
+    for (int m = G / 2; m >= 1; m >>= 1) v |= __shfl_xor(v, m, G);
     return v;
 }
 
@@ -34,37 +35,38 @@ __device__ __forceinline__ void pin_family(phc_motion_lib_t& lib, phc_im_params_
     if (DPJ == 3) { lib.num_ext_bodies = 0; prm.num_ext_bodies = 0; }
 }
 
-template <int DPJ>
+template <int DPJ, int G>
 __global__ __launch_bounds__(256) void k_im_post_physics(phc_model_t model, phc_motion_lib_t lib, phc_im_params_t prm,
                                                         phc_sim_state_t sim, phc_im_buffers_t buf, int n_reset_bodies) {
     pin_family<DPJ>(lib, prm);
-    const int lane = threadIdx.x & (GRP - 1);
-    const int64_t env = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
-    if (env >= sim.num_envs) return;  // whole 32-lane group exits together
+    const int lane = threadIdx.x & (G - 1);
+    const int64_t env = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+    if (env >= sim.num_envs) return;  // whole lane group exits together
     const int64_t progress = buf.progress_buf[env] + 1;  // humanoid.py:1637
     const ImStepCtx c = im_post_prologue(lib, prm, sim, buf, env, progress);
     const float prev_goal = (prm.zero_out_far && buf.point_goal) ? buf.point_goal[env] : 0.f;  // read before lane 0 overwrites it
-    amp_shift_lane(prm, buf, env, lane);
+    amp_shift_lane(prm, buf, env, lane, G);
     RewardPartial rp = im_post_lane(model, lib, prm, sim, buf, env, lane, c);
-    float s_pos = group_sum(rp.pos), s_rot = group_sum(rp.rot), s_vel = group_sum(rp.vel), s_ang = group_sum(rp.angvel);
-    float s_pow = group_sum(rp.power), s_dist = group_sum(rp.dist);
-    int fallen = group_or(rp.fallen);
+    float s_pos = group_sum<G>(rp.pos), s_rot = group_sum<G>(rp.rot), s_vel = group_sum<G>(rp.vel), s_ang = group_sum<G>(rp.angvel);
+    float s_pow = group_sum<G>(rp.power), s_dist = group_sum<G>(rp.dist);
+    int fallen = group_or<G>(rp.fallen);
     if (lane == 0)
         im_post_finalize(lib, prm, buf, model.num_bodies, env, c, progress, s_pos, s_rot, s_vel, s_ang, s_pow, s_dist, rp.root_dist,
                          prev_goal, fallen, n_reset_bodies);
 }
 
-// HumanoidImGetup fall / recovery resets: one 32-lane group per listed env (state kept, see im_reset_from_state_lane).
+// HumanoidImGetup fall / recovery resets: one lane group per listed env (state kept, see im_reset_from_state_lane).
+template <int G>
 __global__ __launch_bounds__(256) void k_im_reset_from_state(phc_model_t model, phc_motion_lib_t lib, phc_im_params_t prm, phc_sim_state_t sim,
                                                             phc_im_buffers_t buf, int num_reset, const int64_t* __restrict__ env_ids,
                                                             int fill_history) {
-    const int lane = threadIdx.x & (GRP - 1);
-    const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+    const int lane = threadIdx.x & (G - 1);
+    const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
     if (r >= num_reset) return;
     im_reset_from_state_lane(model, lib, prm, sim, buf, env_ids[r], lane, fill_history);
 }
 
-// Reset of a list of envs.  One 32-lane group per (env, AMP history frame k): group k == 0 also imposes the state
+// Reset of a list of envs.  One lane group per (env, AMP history frame k): group k == 0 also imposes the state
 // and recomputes the observations.  blockDim = 256.
 // counter-based uniform in [0,1): the host folds (seed, counter) into one 64-bit stream key (splitmix64); per env a 32-bit
 // avalanche hash (murmur3 finaliser rounds) of the env id under that key, top 24 bits -> float like torch.rand
@@ -82,13 +84,13 @@ static inline uint64_t splitmix64(uint64_t z) {
     return z ^ (z >> 31);
 }
 
-template <int DPJ, bool RNG>
+template <int DPJ, bool RNG, int G>
 __global__ __launch_bounds__(256) void k_im_reset(phc_model_t model, phc_motion_lib_t lib, phc_im_params_t prm, phc_sim_state_t sim,
                                                  phc_im_buffers_t buf, int num_reset, const int64_t* __restrict__ env_ids,
                                                  const float* __restrict__ phase, int start_at_zero, uint64_t rng_key) {
     pin_family<DPJ>(lib, prm);
-    const int lane = threadIdx.x & (GRP - 1);
-    const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;   // listed env (grid.x), AMP history frame k (grid.y)
+    const int lane = threadIdx.x & (G - 1);
+    const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;   // listed env (grid.x), AMP history frame k (grid.y)
     const int k = (int)blockIdx.y;
     int64_t env;
     if (RNG && buf.reset_list) {
@@ -116,26 +118,28 @@ __global__ __launch_bounds__(256) void k_im_reset(phc_model_t model, phc_motion_
     im_reset_amp_lane(lib, prm, buf, model.num_bodies, env, lane, t, k);
 }
 
-// build_amp_obs_demo: n samples x S history steps.  One 32-lane group per (sample, step).
+// build_amp_obs_demo: n samples x S history steps.  One lane group per (sample, step).
+template <int G>
 __global__ __launch_bounds__(256) void k_amp_obs_demo(phc_model_t model, phc_motion_lib_t lib, phc_im_params_t prm, int n,
                                                      const int64_t* __restrict__ motion_ids, const float* __restrict__ times0,
                                                      float* __restrict__ out) {
-    const int lane = threadIdx.x & (GRP - 1);
-    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;   // sample (grid.x), history step k (grid.y)
+    const int lane = threadIdx.x & (G - 1);
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;   // sample (grid.x), history step k (grid.y)
     const int k = (int)blockIdx.y;
     const int S = prm.num_amp_obs_steps, A = prm.num_amp_obs_per_step;
     if (i >= n) return;
     amp_obs_from_ref_lane(lib, prm, model.num_bodies, lane, motion_ids[i], history_time(times0[i], prm.dt, k), out + (i * S + k) * A);
 }
 
-// M9 standalone: get_motion_state for n (id, time) pairs.  One 32-lane group per lookup.
+// M9 standalone: get_motion_state for n (id, time) pairs.  One lane group per lookup.
+template <int G>
 __global__ __launch_bounds__(256) void k_motion_state(phc_motion_lib_t lib, int n, const int64_t* __restrict__ ids,
                                                      const float* __restrict__ times, const float* __restrict__ offset,
                                                      float* rg_pos, float* rb_rot, float* body_vel, float* body_ang_vel,
                                                      float* dof_pos, float* dof_vel, int64_t* idx0, int64_t* idx1, float* blend,
                                                      float* rg_pos_ext, float* rb_rot_ext) {
-    const int lane = threadIdx.x & (GRP - 1);
-    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+    const int lane = threadIdx.x & (G - 1);
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
     if (i >= n) return;
     const int nb = lib.num_bodies;
     const FrameRef fr = frame_ref(lib, ids[i], times[i]);
@@ -229,7 +233,9 @@ static inline int32_t launch_status() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int32_t)e;
 }
-static inline int env_blocks(int64_t groups, int block) { return (int)((groups * GRP + block - 1) / block); }
+static inline int env_blocks(int64_t groups, int lanes) { return (int)((groups * lanes + 255) / 256); }
+// lanes per env: 32 while the articulation (with its extended reference bodies) fits, else 64
+static inline int group_lanes(int num_bodies, int num_ext) { return num_bodies + num_ext > 32 ? 64 : 32; }
 
 extern "C" {
 
@@ -241,8 +247,12 @@ int32_t phc_motion_state(const phc_motion_lib_t* lib, int32_t n, const int64_t* 
                          float* rb_rot_ext, void* stream) {
     if (!lib || n < 0 || lib->num_bodies + lib->num_ext_bodies > PHC_MAX_BODIES) return PHC_EINVAL;
     if (n == 0) return 0;
-    hipLaunchKernelGGL(k_motion_state, dim3(env_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, *lib, n, motion_ids,
-                       motion_times, offset, rg_pos, rb_rot, body_vel, body_ang_vel, dof_pos, dof_vel, frame_idx0, frame_idx1, blend, rg_pos_ext, rb_rot_ext);
+    if (group_lanes(lib->num_bodies, lib->num_ext_bodies) == 64)
+        hipLaunchKernelGGL(k_motion_state<64>, dim3(env_blocks(n, 64)), dim3(256), 0, (hipStream_t)stream, *lib, n, motion_ids, motion_times, offset,
+                           rg_pos, rb_rot, body_vel, body_ang_vel, dof_pos, dof_vel, frame_idx0, frame_idx1, blend, rg_pos_ext, rb_rot_ext);
+    else
+        hipLaunchKernelGGL(k_motion_state<32>, dim3(env_blocks(n, 32)), dim3(256), 0, (hipStream_t)stream, *lib, n, motion_ids, motion_times, offset,
+                           rg_pos, rb_rot, body_vel, body_ang_vel, dof_pos, dof_vel, frame_idx0, frame_idx1, blend, rg_pos_ext, rb_rot_ext);
     return launch_status();
 }
 
@@ -267,10 +277,10 @@ static int32_t check_im(const phc_model_t* model, const phc_motion_lib_t* lib, c
     if (!lib || !prm || lib->num_bodies != model->num_bodies) return PHC_EINVAL;
     const int dpj = model->num_dof == model->num_bodies - 1 && model->num_bodies > 2 ? 1 : 3;
     if ((lib->dofs_per_joint == 1 ? 1 : 3) != dpj || (prm->dofs_per_joint == 1 ? 1 : 3) != dpj) return PHC_EINVAL;
-    if (prm->num_ext_bodies < 0 || prm->num_ext_bodies != lib->num_ext_bodies || model->num_bodies + prm->num_ext_bodies > GRP) return PHC_EINVAL;
+    if (prm->num_ext_bodies < 0 || prm->num_ext_bodies != lib->num_ext_bodies || model->num_bodies + prm->num_ext_bodies > PHC_MAX_BODIES) return PHC_EINVAL;
     if (prm->num_ext_bodies > 0 && (!prm->ext_parent || !prm->ext_offset)) return PHC_EINVAL;
     if (!prm->track_slot || !prm->reset_mask || !prm->termination_distances || !prm->key_body_ids || !prm->amp_joint_slot) return PHC_EINVAL;
-    if (prm->num_key_bodies > GRP) return PHC_EUNSUPPORTED;
+    if (prm->num_key_bodies > 32) return PHC_EUNSUPPORTED;
     return 0;
 }
 
@@ -283,12 +293,12 @@ int32_t phc_im_post_physics(const phc_model_t* model, const phc_motion_lib_t* li
     if (prm->zero_out_far && (!buf->point_goal || prm->track_slot == nullptr)) return PHC_EINVAL;
     if (sim->num_envs == 0) return 0;
     const int n_reset_bodies = prm->num_reset_bodies > 0 ? prm->num_reset_bodies : 1;
-    if (prm->dofs_per_joint == 1)
-        hipLaunchKernelGGL(k_im_post_physics<1>, dim3(env_blocks(sim->num_envs, 256)), dim3(256), 0, (hipStream_t)stream, *model, *lib,
-                           *prm, *sim, *buf, n_reset_bodies);
-    else
-        hipLaunchKernelGGL(k_im_post_physics<3>, dim3(env_blocks(sim->num_envs, 256)), dim3(256), 0, (hipStream_t)stream, *model, *lib,
-                           *prm, *sim, *buf, n_reset_bodies);
+    const int g = group_lanes(model->num_bodies, prm->num_ext_bodies);
+    const dim3 grid(env_blocks(sim->num_envs, g));
+#define PHC_POST(DPJ, G) hipLaunchKernelGGL((k_im_post_physics<DPJ, G>), grid, dim3(256), 0, (hipStream_t)stream, *model, *lib, *prm, *sim, *buf, n_reset_bodies)
+    if (prm->dofs_per_joint == 1) { if (g == 64) PHC_POST(1, 64); else PHC_POST(1, 32); }
+    else { if (g == 64) PHC_POST(3, 64); else PHC_POST(3, 32); }
+#undef PHC_POST
     return launch_status();
 }
 
@@ -299,11 +309,12 @@ int32_t phc_im_reset(const phc_model_t* model, const phc_motion_lib_t* lib, cons
     if (rc) return rc;
     if (!sim || !buf || num_reset < 0 || (!start_at_zero && !phase)) return PHC_EINVAL;
     if (num_reset == 0) return 0;
-    const dim3 grid(env_blocks(num_reset, 256), prm->num_amp_obs_steps);
-    if (prm->dofs_per_joint == 1)
-        hipLaunchKernelGGL((k_im_reset<1, false>), grid, dim3(256), 0, (hipStream_t)stream, *model, *lib, *prm, *sim, *buf, num_reset, env_ids, phase, start_at_zero, 0ull);
-    else
-        hipLaunchKernelGGL((k_im_reset<3, false>), grid, dim3(256), 0, (hipStream_t)stream, *model, *lib, *prm, *sim, *buf, num_reset, env_ids, phase, start_at_zero, 0ull);
+    const int g = group_lanes(model->num_bodies, prm->num_ext_bodies);
+    const dim3 grid(env_blocks(num_reset, g), prm->num_amp_obs_steps);
+#define PHC_RESET(DPJ, G) hipLaunchKernelGGL((k_im_reset<DPJ, false, G>), grid, dim3(256), 0, (hipStream_t)stream, *model, *lib, *prm, *sim, *buf, num_reset, env_ids, phase, start_at_zero, 0ull)
+    if (prm->dofs_per_joint == 1) { if (g == 64) PHC_RESET(1, 64); else PHC_RESET(1, 32); }
+    else { if (g == 64) PHC_RESET(3, 64); else PHC_RESET(3, 32); }
+#undef PHC_RESET
     return launch_status();
 }
 
@@ -316,11 +327,12 @@ int32_t phc_im_reset_done(const phc_model_t* model, const phc_motion_lib_t* lib,
     if (buf->reset_list && (!buf->reset_count || buf->reset_sublist_cap * PHC_RESET_SUBLISTS < sim->num_envs)) return PHC_EINVAL;
     const int n = buf->reset_list ? buf->reset_sublist_cap * PHC_RESET_SUBLISTS : sim->num_envs;   // groups to launch
     const uint64_t key = splitmix64(splitmix64(seed) ^ (counter * 0xD1342543DE82EF95ull));
-    const dim3 grid(env_blocks(n, 256), prm->num_amp_obs_steps);
-    if (prm->dofs_per_joint == 1)
-        hipLaunchKernelGGL((k_im_reset<1, true>), grid, dim3(256), 0, (hipStream_t)stream, *model, *lib, *prm, *sim, *buf, n, nullptr, nullptr, start_at_zero, key);
-    else
-        hipLaunchKernelGGL((k_im_reset<3, true>), grid, dim3(256), 0, (hipStream_t)stream, *model, *lib, *prm, *sim, *buf, n, nullptr, nullptr, start_at_zero, key);
+    const int g = group_lanes(model->num_bodies, prm->num_ext_bodies);
+    const dim3 grid(env_blocks(n, g), prm->num_amp_obs_steps);
+#define PHC_RESET(DPJ, G) hipLaunchKernelGGL((k_im_reset<DPJ, true, G>), grid, dim3(256), 0, (hipStream_t)stream, *model, *lib, *prm, *sim, *buf, n, nullptr, nullptr, start_at_zero, key)
+    if (prm->dofs_per_joint == 1) { if (g == 64) PHC_RESET(1, 64); else PHC_RESET(1, 32); }
+    else { if (g == 64) PHC_RESET(3, 64); else PHC_RESET(3, 32); }
+#undef PHC_RESET
     return launch_status();
 }
 
@@ -331,8 +343,12 @@ int32_t phc_im_reset_from_state(const phc_model_t* model, const phc_motion_lib_t
     if (rc) return rc;
     if (!sim || !buf || num_reset < 0 || (num_reset > 0 && !env_ids)) return PHC_EINVAL;
     if (num_reset == 0) return 0;
-    hipLaunchKernelGGL(k_im_reset_from_state, dim3(env_blocks(num_reset, 256)), dim3(256), 0, (hipStream_t)stream, *model, *lib, *prm,
-                       *sim, *buf, num_reset, env_ids, fill_history);
+    if (group_lanes(model->num_bodies, prm->num_ext_bodies) == 64)
+        hipLaunchKernelGGL(k_im_reset_from_state<64>, dim3(env_blocks(num_reset, 64)), dim3(256), 0, (hipStream_t)stream, *model, *lib, *prm, *sim,
+                           *buf, num_reset, env_ids, fill_history);
+    else
+        hipLaunchKernelGGL(k_im_reset_from_state<32>, dim3(env_blocks(num_reset, 32)), dim3(256), 0, (hipStream_t)stream, *model, *lib, *prm, *sim,
+                           *buf, num_reset, env_ids, fill_history);
     return launch_status();
 }
 
@@ -342,8 +358,12 @@ int32_t phc_amp_obs_demo(const phc_model_t* model, const phc_motion_lib_t* lib, 
     if (rc) return rc;
     if (n < 0) return PHC_EINVAL;
     if (n == 0) return 0;
-    hipLaunchKernelGGL(k_amp_obs_demo, dim3(env_blocks(n, 256), prm->num_amp_obs_steps), dim3(256), 0, (hipStream_t)stream,
-                       *model, *lib, *prm, n, motion_ids, motion_times0, amp_obs_demo);
+    if (group_lanes(model->num_bodies, prm->num_ext_bodies) == 64)
+        hipLaunchKernelGGL(k_amp_obs_demo<64>, dim3(env_blocks(n, 64), prm->num_amp_obs_steps), dim3(256), 0, (hipStream_t)stream, *model, *lib,
+                           *prm, n, motion_ids, motion_times0, amp_obs_demo);
+    else
+        hipLaunchKernelGGL(k_amp_obs_demo<32>, dim3(env_blocks(n, 32), prm->num_amp_obs_steps), dim3(256), 0, (hipStream_t)stream, *model, *lib,
+                           *prm, n, motion_ids, motion_times0, amp_obs_demo);
     return launch_status();
 }
 

@@ -13,10 +13,9 @@
 
 using namespace phc;
 
-#define GRP 32  // lanes per environment
-
 // ------------------------------------------------------------------------------------------
-// S10: the stepper.  One lane per body, 32 lanes per env, blockDim = 64: ONE wavefront (two envs) per workgroup, so
+// S10: the stepper.  One lane per body, GRP = 32 lanes per env (articulations of up to 32 bodies: two envs per wavefront) or
+// GRP = 64 (up to 64 bodies -- Unitree G1 has 38: one env per wavefront), blockDim = 64: ONE wavefront per workgroup, so
 // the level-synchronous tree sweeps synchronise with a single-wave barrier and every SIMD of the chip carries
 // two independent dependency chains (2048 wavefronts at N = 4096).
 // Measured alternative (round 1, profiles/r01_notes.md): a level-major mapping (workgroup = 16 envs, wavefront = same
@@ -24,22 +23,22 @@ using namespace phc;
 // >256 VGPRs: 214-252 us vs 158 us for this mapping.  __launch_bounds__(64, 2): two wavefronts per SIMD (<= 256 VGPRs,
 // 68 B/lane of scratch) beats one (272 registers, no scratch: 195 us) and three (168 VGPRs, 412 B scratch: 280 us).
 // ------------------------------------------------------------------------------------------
-template <bool STEP, int JT>
+template <bool STEP, int JT, int GRP>
 __global__ __launch_bounds__(64, 2) void k_sim_step(phc_model_t model, phc_sim_params_t prm, phc_sim_state_t sim,
                                                 const float* __restrict__ actions, const float* __restrict__ pd_off,
                                                 const float* __restrict__ pd_scale, const int32_t* __restrict__ freeze,
                                                 int num_sim_calls, const int64_t* __restrict__ env_ids, int num_listed) {
-    __shared__ float xch_all[2 * PHC_MAX_BODIES * PHC_XCH_STRIDE];
-    __shared__ float cap_all[2 * PHC_MAX_BODIES * PHC_CAP_STRIDE];
+    __shared__ float xch_all[64 * PHC_XCH_STRIDE];   // one exchange slot per lane == body
+    __shared__ float cap_all[64 * PHC_CAP_STRIDE];
     const int lane = threadIdx.x & (GRP - 1);
-    const int grp = threadIdx.x >> 5;
-    const int64_t slot = (int64_t)blockIdx.x * 2 + grp;
+    const int grp = threadIdx.x / GRP;
+    const int64_t slot = (int64_t)blockIdx.x * (64 / GRP) + grp;
     // env_ids (refresh of a teleported subset only): slot -> listed env
     const int64_t env = (!STEP && env_ids != nullptr) ? (slot < num_listed ? env_ids[slot] : sim.num_envs) : slot;
     const int nb = model.num_bodies, nd = model.num_dof;
     const bool active = env < sim.num_envs && lane < nb;
     Xch x;
-    x.base = xch_all + grp * PHC_MAX_BODIES * PHC_XCH_STRIDE;
+    x.base = xch_all + grp * GRP * PHC_XCH_STRIDE;
 
     AbaLane L;
     L.level = -1;
@@ -62,7 +61,7 @@ __global__ __launch_bounds__(64, 2) void k_sim_step(phc_model_t model, phc_sim_p
     if (STEP) {
         const float dt = prm.sim_dt / (float)prm.substeps;
         const int nsub = num_sim_calls * prm.substeps;
-        float* caps = cap_all + grp * PHC_MAX_BODIES * PHC_CAP_STRIDE;
+        float* caps = cap_all + grp * GRP * PHC_CAP_STRIDE;
         PairList pairs;
         if (prm.self_collision) aba_load_pairs(pairs, model, lane, GRP);
         for (int s = 0; s < nsub; ++s) {
@@ -86,30 +85,31 @@ __global__ __launch_bounds__(64, 2) void k_sim_step(phc_model_t model, phc_sim_p
 }
 
 // ------------------------------------------------------------------------------------------
-// Two-slot variant of the step kernel: 16 lanes per env, FOUR envs per wavefront, each lane carries two bodies -- slot A a
+// Two-slot variant of the step kernel: GRP = 16 lanes per env, FOUR envs per wavefront (GRP = 32, two envs, for articulations
+// of more than 32 bodies), each lane carries two bodies -- slot A a
 // body of the shallow tree levels (< split), slot B one of the deep levels.  At any tree level all active bodies sit in one
 // slot, so a level-step executes exactly one copy of the level code (wave-uniform branch), as in the 32-lane kernel, but the
 // launch has half the wavefronts.  Measured on MI355X (scripts/gpu_sweep_small.sh): the 32-lane kernel takes 76-85 us with
 // one wavefront per SIMD (<= 2048 envs) and 106 us with two or three (4096-6144 envs) -- it is bound by the latency of one
 // wavefront's 72 dependent level-steps, so halving the wavefront count at N = 4096 moves it onto the one-per-SIMD plateau.
 // ------------------------------------------------------------------------------------------
-template <int JT>
+template <int JT, int GRP>
 __global__ __launch_bounds__(64, 1) void k_sim_step16(phc_model_t model, phc_sim_params_t prm, phc_sim_state_t sim,
                                                   const float* __restrict__ actions, const float* __restrict__ pd_off,
                                                   const float* __restrict__ pd_scale, const int32_t* __restrict__ freeze,
                                                   int num_sim_calls) {
-    __shared__ float xch_all[4 * PHC_MAX_BODIES * PHC_XCH_STRIDE];
-    __shared__ float cap_all[4 * PHC_MAX_BODIES * PHC_CAP_STRIDE];
-    const int lane = threadIdx.x & 15;
-    const int grp = threadIdx.x >> 4;
-    const int64_t env = (int64_t)blockIdx.x * 4 + grp;
+    __shared__ float xch_all[128 * PHC_XCH_STRIDE];   // two exchange slots (bodies) per lane
+    __shared__ float cap_all[128 * PHC_CAP_STRIDE];
+    const int lane = threadIdx.x & (GRP - 1);
+    const int grp = threadIdx.x / GRP;
+    const int64_t env = (int64_t)blockIdx.x * (64 / GRP) + grp;
     const int nb = model.num_bodies, nd = model.num_dof;
     const int split = model.split_level, nA = model.num_below_split;
     const bool env_ok = env < sim.num_envs;
     const int jA = (env_ok && lane < nA) ? model_tab(model, 10, lane) : -1;
     const int jB = (env_ok && lane < nb - nA) ? model_tab(model, 10, nA + lane) : -1;
     Xch x;
-    x.base = xch_all + grp * PHC_MAX_BODIES * PHC_XCH_STRIDE;
+    x.base = xch_all + grp * 2 * GRP * PHC_XCH_STRIDE;
     constexpr int ndj = JT == PHC_JT_REVOLUTE ? 1 : 3;
 
     AbaLane LA, LB;
@@ -137,11 +137,11 @@ __global__ __launch_bounds__(64, 1) void k_sim_step16(phc_model_t model, phc_sim
     const float dt = prm.sim_dt / (float)prm.substeps;
     const int nsub = num_sim_calls * prm.substeps;
     PairList pairs;
-    if (prm.self_collision) aba_load_pairs(pairs, model, lane, 16);
+    if (prm.self_collision) aba_load_pairs(pairs, model, lane, GRP);
     for (int s = 0; s < nsub; ++s) {
         const bool fresh = s % prm.substeps == 0;
         if (prm.self_collision) {   // body-body contact from the kinematics the last sweep left in the exchange slots
-            float* caps = cap_all + grp * PHC_MAX_BODIES * PHC_CAP_STRIDE;
+            float* caps = cap_all + grp * 2 * GRP * PHC_CAP_STRIDE;
             if (jA >= 0) aba_publish_capsule(LA, model_body(model, jA), caps + PHC_CAP_STRIDE * jA);
             if (jB >= 0) aba_publish_capsule(LB, model_body(model, jB), caps + PHC_CAP_STRIDE * jB);
             __syncthreads();
@@ -163,26 +163,37 @@ __global__ __launch_bounds__(64, 1) void k_sim_step16(phc_model_t model, phc_sim
     if (jB >= 0) { aba_store_state<JT>(LB, sim, nd, env, jB); aba_publish_body(LB, sim, nb, env, jB, true); }
 }
 
+template <bool STEP, int JT>
+static void sim_launch_jt(const phc_model_t* model, const phc_sim_params_t& prm, const phc_sim_state_t* sim, const float* actions,
+                          const float* off, const float* scale, const int32_t* freeze, int num_sim_calls, hipStream_t stream,
+                          const int64_t* env_ids, int num_listed, bool two_slot) {
+    const int64_t groups = env_ids ? num_listed : sim->num_envs;
+    const bool wide = model->num_bodies > 32;   // more bodies than a 32-lane group holds: one env per wavefront (two in the two-slot mapping)
+    if (STEP && two_slot) {
+        if (wide)
+            hipLaunchKernelGGL((k_sim_step16<JT, 32>), dim3((groups + 1) / 2), dim3(64), 0, stream, *model, prm, *sim, actions, off, scale, freeze,
+                               num_sim_calls);
+        else
+            hipLaunchKernelGGL((k_sim_step16<JT, 16>), dim3((groups + 3) / 4), dim3(64), 0, stream, *model, prm, *sim, actions, off, scale, freeze,
+                               num_sim_calls);
+        return;
+    }
+    if (wide)
+        hipLaunchKernelGGL((k_sim_step<STEP, JT, 64>), dim3(groups), dim3(64), 0, stream, *model, prm, *sim, actions, off, scale, freeze,
+                           num_sim_calls, env_ids, num_listed);
+    else
+        hipLaunchKernelGGL((k_sim_step<STEP, JT, 32>), dim3((groups + 1) / 2), dim3(64), 0, stream, *model, prm, *sim, actions, off, scale, freeze,
+                           num_sim_calls, env_ids, num_listed);
+}
+
 template <bool STEP>
 static void sim_launch(const phc_model_t* model, const phc_sim_params_t& prm, const phc_sim_state_t* sim, const float* actions,
                        const float* off, const float* scale, const int32_t* freeze, int num_sim_calls, hipStream_t stream,
                        const int64_t* env_ids = nullptr, int num_listed = 0, bool two_slot = false) {
-    const int64_t groups = env_ids ? num_listed : sim->num_envs;
-    if (STEP && two_slot) {
-        if (model->num_dof == model->num_bodies - 1 && model->num_bodies > 2)
-            hipLaunchKernelGGL((k_sim_step16<PHC_JT_REVOLUTE>), dim3((groups + 3) / 4), dim3(64), 0, stream, *model, prm, *sim, actions, off, scale,
-                               freeze, num_sim_calls);
-        else
-            hipLaunchKernelGGL((k_sim_step16<PHC_JT_SPHERICAL>), dim3((groups + 3) / 4), dim3(64), 0, stream, *model, prm, *sim, actions, off, scale,
-                               freeze, num_sim_calls);
-        return;
-    }
     if (model->num_dof == model->num_bodies - 1 && model->num_bodies > 2)  // one revolute joint per body (robots)
-        hipLaunchKernelGGL((k_sim_step<STEP, PHC_JT_REVOLUTE>), dim3((groups + 1) / 2), dim3(64), 0, stream, *model, prm, *sim, actions, off,
-                           scale, freeze, num_sim_calls, env_ids, num_listed);
+        sim_launch_jt<STEP, PHC_JT_REVOLUTE>(model, prm, sim, actions, off, scale, freeze, num_sim_calls, stream, env_ids, num_listed, two_slot);
     else
-        hipLaunchKernelGGL((k_sim_step<STEP, PHC_JT_SPHERICAL>), dim3((groups + 1) / 2), dim3(64), 0, stream, *model, prm, *sim, actions, off,
-                           scale, freeze, num_sim_calls, env_ids, num_listed);
+        sim_launch_jt<STEP, PHC_JT_SPHERICAL>(model, prm, sim, actions, off, scale, freeze, num_sim_calls, stream, env_ids, num_listed, two_slot);
 }
 
 static inline int32_t launch_status() {
@@ -207,7 +218,8 @@ int32_t phc_sim_step(const phc_model_t* model, const phc_sim_params_t* params, c
     if (!params || !sim || sim->num_envs < 0 || params->substeps < 1 || num_sim_calls < 0) return PHC_EINVAL;
     if (actions && (!pd_action_offset || !pd_action_scale)) return PHC_EINVAL;
     if (sim->num_envs == 0) return 0;
-    if (params->self_collision && model->num_collision_pairs > PHC_SC_MAX_PER_LANE * 16) return PHC_EUNSUPPORTED;
+    const int wide = model->num_bodies > 32;
+    if (params->self_collision && model->num_collision_pairs > PHC_SC_MAX_PER_LANE * (wide ? 32 : 16)) return PHC_EUNSUPPORTED;
     // lane_mapping 1 / 2 force a kernel; 0 picks.  Measured on MI355X at N = 4096 (scripts/gpu_map.sh): SMPL (tree depth 8, 2.8 contact
     // points per body) 106 us one-body-per-lane vs 89 us two-slot; H1 (depth 5, 12.8 contact points per body, 8 sub-steps) 104 vs
     // 126 us -- the two-slot kernel runs the per-body initialisation (inertia rotation, contacts, drive) twice per sub-step, which
@@ -219,9 +231,10 @@ int32_t phc_sim_step(const phc_model_t* model, const phc_sim_params_t* params, c
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         num_simds = 4 * (cus > 0 ? cus : 256);
     }
-    const bool can_split = model->split_level > 0 && model->num_below_split <= 16 && model->num_bodies - model->num_below_split <= 16;
+    const int half = wide ? 32 : 16;   // lanes per env of the two-slot mapping
+    const bool can_split = model->split_level > 0 && model->num_below_split <= half && model->num_bodies - model->num_below_split <= half;
     const bool two_slot = can_split && (params->lane_mapping == 2 || (params->lane_mapping == 0 && model->max_level >= 7 &&
-                                                                      (int64_t)sim->num_envs <= 4 * (int64_t)num_simds));
+                                                                      (int64_t)sim->num_envs <= (64 / half) * (int64_t)num_simds));
     sim_launch<true>(model, *params, sim, actions, pd_action_offset, pd_action_scale, freeze_mask, num_sim_calls, (hipStream_t)stream, nullptr, 0,
                      two_slot);
     return launch_status();

@@ -346,7 +346,7 @@ class HumanoidIm:
         self._termination_heights = torch.full((NB,), float(env["terminationHeight"]), **f32)
         if "Head" in self._body_names:
             self._termination_heights[self._body_names.index("Head")] = max(0.3, float(env["terminationHeight"]))
-        self._termination_distances_full = torch.full((32,), float(env.get("terminationDistance", 0.5)), **f32)  # PHC_MAX_BODIES slots
+        self._termination_distances_full = torch.full((abi.MAX_BODIES,), float(env.get("terminationDistance", 0.5)), **f32)  # PHC_MAX_BODIES slots
         self._termination_distances = self._termination_distances_full[:NB]  # learner edits this view in place (im_amp.py:174)
 
         # ---- HumanoidAMP / HumanoidIm state (humanoid_amp.py:109-136, humanoid_im.py:71-123) ----

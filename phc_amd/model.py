@@ -296,13 +296,13 @@ def compile_mjcf(path):
 class ArticulationModel:
     """Numpy view of a compiled model + the packed fp32 / int32 buffers the kernels read."""
 
-    MAX_BODIES = 32
+    MAX_BODIES = 64   # PHC_MAX_BODIES: slots per model table
 
     def __init__(self, d):
         self.d = d
         self.body_names = list(d["body_names"])
         self.num_bodies = len(self.body_names)
-        assert self.num_bodies <= self.MAX_BODIES, "the stepper maps one body per lane of a 32-lane group"
+        assert self.num_bodies <= self.MAX_BODIES, "the stepper maps one body per lane of a 32- or 64-lane group"
         self.parent = np.array(d["parent"], dtype=np.int32)
         self.level = np.array(d["level"], dtype=np.int32)
         self.local_translation = np.array(d["local_translation"], dtype=np.float32)
@@ -353,7 +353,7 @@ class ArticulationModel:
         and both carry a collision capsule."""
         nb = self.num_bodies
         has = self.collision_capsule[:, 6] > 0
-        m = np.zeros(nb, dtype=np.int64)
+        m = [0] * nb   # Python ints: bit 63 does not fit a signed 64-bit numpy scalar
         for i in range(nb):
             for j in range(nb):
                 if i != j and has[i] and has[j] and self.parent[i] != j and self.parent[j] != i and (self.collision_filter[i] & self.collision_filter[j]) == 0:
@@ -362,11 +362,13 @@ class ArticulationModel:
 
     def two_slot_split(self):
         """(split level, bodies below it) for the stepper's two-slot mapping: slot A = bodies of levels < split, slot B = the rest,
-        both <= 16 bodies, as balanced as possible; (-1, 0) when the tree admits no such split (the 32-lane kernel is used)."""
+        both <= 16 bodies (<= 32 for articulations of more than 32 bodies), as balanced as possible; (-1, 0) when the tree admits
+        no such split (the one-body-per-lane kernel is used)."""
         best = (-1, 0)
+        half = 16 if self.num_bodies <= 32 else 32
         for split in range(1, self.max_level + 1):
             nA = int((self.level < split).sum())
-            if nA <= 16 and self.num_bodies - nA <= 16 and (best[0] < 0 or abs(2 * nA - self.num_bodies) < abs(2 * best[1] - self.num_bodies)):
+            if nA <= half and self.num_bodies - nA <= half and (best[0] < 0 or abs(2 * nA - self.num_bodies) < abs(2 * best[1] - self.num_bodies)):
                 best = (split, nA)
         return best
 
@@ -374,11 +376,11 @@ class ArticulationModel:
     def pack(self, kp_scale=1.0, kd_scale=1.0):
         """-> (ints int32[...], floats float32[...]) laid out as csrc/phc_model.h expects.
 
-        ints  : [0]=NB [1]=ND [2]=max_level [3]=NCP then per body (32 slots each):
+        ints  : [0]=NB [1]=ND [2]=max_level [3]=NCP then per body (MAX_BODIES slots each):
                 parent, level, joint_type, dof_start, child0, child1, child2, nchild,
                 cp_start, cp_count, order (bodies sorted by level), misc [split level, bodies below it],
                 self-collision partner mask
-        floats: per body (32 slots x 36): r_local[3], mass, m*com[3], Io(xx,xy,xz,yy,yz,zz)[6],
+        floats: per body (MAX_BODIES slots x BODY_FLOATS): r_local[3], mass, m*com[3], Io(xx,xy,xz,yy,yz,zz)[6],
                 kp[3], kd[3], armature[3], effort[3], axis[3] (revolute), rest rotation xyzw[4], limit lo/hi [2], contact bound radius, pad, collision capsule a[3] b[3] radius, pad ;
                 then contact points NCP x 4 (pos[3], radius)
         """
@@ -404,10 +406,10 @@ class ArticulationModel:
             tab[8, i] = idx[0] if len(idx) else 0
             tab[9, i] = len(idx)
         tab[10, :NB] = np.argsort(self.level, kind="stable")  # bodies sorted by tree level
-        # two-slot mapping of the stepper (16 lanes per env, 4 envs per wavefront): slot A = bodies of levels < split, slot B = the
-        # rest, both <= 16 bodies, so that at every tree level all active bodies sit in the same slot.  tab[11] = [split, nA].
+        # two-slot mapping of the stepper (16 lanes per env, 4 envs per wavefront; 32 and 2 above 32 bodies): slot A = bodies of
+        # levels < split, slot B = the rest, both <= 16 (32) bodies, so that at every tree level all active bodies sit in the same slot.  tab[11] = [split, nA].
         tab[11, 0:2] = self.two_slot_split()
-        tab[12, :NB] = self.collision_allow_masks().astype(np.uint32).view(np.int32)   # self-collision partner bit masks
+        tab[12, :NB] = np.array([v & 0xffffffff for v in self.collision_allow_masks()], dtype=np.uint32).view(np.int32)   # partner bit masks (bodies 0-31; informative)
         # self-collision candidate pairs (i < k, may collide), appended after the tables: [count, i | k << 8, ...]; lane l of a
         # group evaluates pairs l, l + L, l + 2L, ... so the list is ordered to spread each body's pairs over many lanes
         masks = self.collision_allow_masks()

@@ -80,7 +80,7 @@ def h1_im_params(be, model, ext_parent, ext_pos, **extra):
     names = model.body_names
     tabs = abi.task_index_tables(model, names, names, H1_KEY_BODIES, has_dof_subset=False)
     track_slot, reset_mask, key_ids, amp_slot = (be.arr(t) for t in tabs[:4])
-    td = be.arr(np.full(32, 0.25, dtype=F))
+    td = be.arr(np.full(64, 0.25, dtype=F))
     ep, eo = be.arr(np.asarray(ext_parent, np.int32)), be.arr(np.asarray(ext_pos, F))
     specs = dict(k_pos=100, k_rot=10, k_vel=0.1, k_ang_vel=0.1, w_pos=0.5, w_rot=0.3, w_vel=0.1, w_ang_vel=0.1)
     prm = abi.im_params_struct(dt=4 * (1 / 200), max_episode_length=300, reward_specs=specs, power_reward=True, power_coefficient=0.0005,

@@ -26,7 +26,7 @@ def make_im_params(be, model, n_envs, use_mean=False, power_reward=True, power_c
     n_amp = tabs[4]
     amp_slot_np = tabs[3]
     track_slot, reset_mask, key_ids, amp_slot = (be.arr(t) for t in tabs[:4])
-    td = be.arr(np.full(32, 0.25, dtype=F))
+    td = be.arr(np.full(64, 0.25, dtype=F))
     prm = abi.im_params_struct(dt=2 * (1 / 60), max_episode_length=300, reward_specs=SPECS, power_reward=power_reward,
                                power_coefficient=power_coefficient, enable_early_termination=True, use_mean_termination=use_mean,
                                disable_collision_check=False, local_root_obs=True, root_height_obs=True,
