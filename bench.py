@@ -46,8 +46,9 @@ def parse():
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU (BASELINE configs[1]: 4096)")
     ap.add_argument("--ppo-epochs", type=int, default=3, help="timed PPO epochs (rollout 32 steps + 36 optimizer steps); 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--robot", choices=["smpl", "h1"], default="smpl", help="smpl: BASELINE configs[1] (the bench line); h1: configs[4] morphology "
-                    "(Unitree H1, 19 revolute DoFs, 200 Hz x 4 pd-torque control) -- a parity-test configuration, timed for reference only")
+    ap.add_argument("--robot", choices=["smpl", "h1", "g1"], default="smpl", help="smpl: BASELINE configs[1] (the bench line); h1: configs[4] morphology "
+                    "(Unitree H1, 19 revolute DoFs, 200 Hz x 4 pd-torque control); g1: Unitree G1 (38 bodies, the 64-lane kernels) -- parity-test "
+                    "configurations, timed for reference only")
     ap.add_argument("--lane-mapping", type=int, default=0, help="stepper thread mapping (phc_sim_params_t.lane_mapping): 0 auto, 1 one body "
                     "per lane (32 lanes/env), 2 two bodies per lane (16 lanes/env)")
     ap.add_argument("--self-collision", type=int, default=-1, help="-1: as the robot yaml says (has_self_collision: True); 0/1 force")
@@ -165,7 +166,7 @@ def main():
     from phc_amd.config import compose
     from phc_amd.env.tasks.vec_task import parse_task
     torch.manual_seed(rank)  # per-rank seed offset, as the reference's horovod path does (run_hydra.py:121)
-    robot_over = ["robot=unitree_h1", "env=env_im_h1_phc", "sim=robot_sim", "control=robot_control"] if args.robot == "h1" else []
+    robot_over = [f"robot=unitree_{args.robot}", f"env=env_im_{args.robot}_phc", "sim=robot_sim", "control=robot_control"] if args.robot != "smpl" else []
     cfg = compose(robot_over + [f"env.num_envs={args.envs}", f"env.motion_file=synthetic:{args.motion_clips}:0", f"device_id={local_rank}",
                                 f"rl_device=cuda:{local_rank}", f"+solver.lane_mapping={args.lane_mapping}"] + ([f"+solver.self_collision={args.self_collision}"] if args.self_collision >= 0 else []))
     task, env = parse_task(cfg, device_id=local_rank)
@@ -180,7 +181,7 @@ def main():
         task.reset_done()                 # envs that finished on the previous step (device-side mask, no host sync)
         if args.actions == "random":
             a = actions
-        elif args.robot == "h1":
+        elif args.robot != "smpl":
             a = task.ref_dof_pos - task.default_dof_pos
         else:
             a = (task.ref_dof_pos - task._pd_action_offset) * inv_scale
@@ -242,8 +243,8 @@ def main():
             "dtype": "f32", "data": "synthetic (AMASS-shaped smooth random clip, seed 0; random-init state from the reference motion)",
             "config": {"workload": ("BASELINE configs[1]: SMPL humanoid 69-DoF, 4096 envs per GPU, single reference motion, "
                                     "30 Hz control = 2 x simulate @60 Hz x 2 sub-steps") if args.robot == "smpl" else
-                                   ("BASELINE configs[4]: Unitree H1 19-DoF, envs per GPU as given, synthetic retargeted-shape clips, "
-                                    "50 Hz control = 4 x simulate @200 Hz x 2 sub-steps, pd torque mode"),
+                                   (("BASELINE configs[4]: Unitree H1 19-DoF" if args.robot == "h1" else "env_im_g1_phc: Unitree G1 37-DoF, 38 bodies") +
+                                    ", envs per GPU as given, synthetic retargeted-shape clips, 50 Hz control = 4 x simulate @200 Hz x 2 sub-steps, pd torque mode"),
                        "envs_per_gpu": N, "num_bodies": task.num_bodies,
                        "obs": task.num_obs, "amp_obs": task.get_num_amp_obs(), "parallelism": f"env-sharded x{world}",
                        "self_collision": bool(task._sim_params.self_collision)},

@@ -1,4 +1,5 @@
-"""TEST INFRASTRUCTURE ONLY -- golden vectors for the H1 robot path (config 5) from the reference's own code:
+"""TEST INFRASTRUCTURE ONLY -- golden vectors for the robot path (H1: config 5; G1: `python oracle/gen_golden_h1.py g1`, 38 bodies ->
+the 64-lane kernels) from the reference's own code:
 
   * `Humanoid_Batch.fk_batch` + `MotionLibReal.load_motions / get_motion_state`  (phc/utils/torch_humanoid_batch.py,
     phc/utils/motion_lib_real.py) on synthetic robot clips -> tests/golden/motion_lib_h1.npz
@@ -6,7 +7,7 @@
     observation (humanoid_amp.py:1063-1104), reset -> tests/golden/task_fns_h1.npz
   * the skeleton constants Humanoid_Batch reads from h1.xml (model-compiler pin) -> tests/golden/skeleton_h1.npz
 
-Run in the build container:  python oracle/gen_golden_h1.py
+Run in the build container:  python oracle/gen_golden_h1.py [h1|g1]
 (lxml / open3d / stl are absent here: ref_shim provides an ElementTree-based lxml stand-in and mocks the mesh loaders;
  the mesh-based start-height fix is therefore switched off -- FixHeightMode.no_fix.)
 """
@@ -31,15 +32,16 @@ from gen_golden import OUT, t2n  # noqa: E402
 from phc_amd.model import load_model  # noqa: E402
 from phc_amd.utils.synthetic_motion import make_robot_motion_dict  # noqa: E402
 
-H1_KEY_BODIES = ["left_ankle_link", "right_ankle_link", "left_elbow_link", "right_elbow_link"]
+KEY_BODIES = {"h1": ["left_ankle_link", "right_ankle_link", "left_elbow_link", "right_elbow_link"],                # env_im_h1_phc.yaml
+              "g1": ["left_ankle_roll_link", "right_ankle_roll_link", "left_zero_link", "right_zero_link"]}      # env_im_g1_phc.yaml
 
 
-def main():
+def main(rb="h1"):
     torch.set_num_threads(1)
     from easydict import EasyDict
     cwd = os.getcwd()
     os.chdir(ref_shim.REFERENCE_ROOT)   # robot.asset.assetFileName is relative to the reference root
-    robot = EasyDict(yaml.safe_load(open("phc/data/cfg/robot/unitree_h1.yaml")))
+    robot = EasyDict(yaml.safe_load(open(f"phc/data/cfg/robot/unitree_{rb}.yaml")))
     him = ref_shim.ref_module("phc.env.tasks.humanoid_im")
     hum = ref_shim.ref_module("phc.env.tasks.humanoid")
     hamp = ref_shim.ref_module("phc.env.tasks.humanoid_amp")
@@ -50,23 +52,25 @@ def main():
     from poselib.poselib.skeleton.skeleton3d import SkeletonTree
 
     hb = Humanoid_Batch(robot)
-    np.savez_compressed(os.path.join(OUT, "skeleton_h1.npz"), node_names=np.array(hb.body_names), parents=t2n(hb._parents[:20]).astype(np.int32),
-                        local_translation=t2n(hb._offsets[0, :20]), local_rotation=t2n(hb._local_rotation[0, :20]), dof_axis=t2n(hb.dof_axis),
-                        joints_range=t2n(hb.joints_range), ext_parents=t2n(hb._parents[20:]).astype(np.int32),
-                        ext_offsets=t2n(hb._offsets[0, 20:]), body_names_augment=np.array(hb.body_names_augment))
+    NB = len(hb.body_names)
+    ND = NB - 1
+    np.savez_compressed(os.path.join(OUT, f"skeleton_{rb}.npz"), node_names=np.array(hb.body_names), parents=t2n(hb._parents[:NB]).astype(np.int32),
+                        local_translation=t2n(hb._offsets[0, :NB]), local_rotation=t2n(hb._local_rotation[0, :NB]), dof_axis=t2n(hb.dof_axis),
+                        joints_range=t2n(hb.joints_range), ext_parents=t2n(hb._parents[NB:]).astype(np.int32),
+                        ext_offsets=t2n(hb._offsets[0, NB:]), body_names_augment=np.array(hb.body_names_augment))
 
-    model = load_model("h1_humanoid")
+    model = load_model(f"{rb}_humanoid")
     clips = make_robot_motion_dict(model, 3, seed=9, lengths=[33, 47, 40])
     tmp = tempfile.mkdtemp()
-    pkl = os.path.join(tmp, "h1_clips.pkl")
+    pkl = os.path.join(tmp, f"{rb}_clips.pkl")
     joblib.dump({k: dict(v, root_trans_offset=torch.from_numpy(v["root_trans_offset"]), pose_aa=v["pose_aa"]) for k, v in clips.items()}, pkl)
-    np.savez_compressed(os.path.join(OUT, "motion_clips_h1.npz"), keys=np.array(list(clips.keys())),
+    np.savez_compressed(os.path.join(OUT, f"motion_clips_{rb}.npz"), keys=np.array(list(clips.keys())),
                         **{f"{k}/pose_aa": v["pose_aa"] for k, v in clips.items()},
                         **{f"{k}/root_trans_offset": v["root_trans_offset"] for k, v in clips.items()})
     tree = SkeletonTree.from_mjcf(robot.asset.assetFileName)
     N = 6
     cfg = EasyDict({"motion_file": pkl, "device": torch.device("cpu"), "fix_height": FixHeightMode.no_fix, "min_length": -1, "max_length": -1,
-                    "im_eval": False, "multi_thread": False, "smpl_type": "h1", "randomrize_heading": True, "robot": robot, "step_dt": 1 / 50})
+                    "im_eval": False, "multi_thread": False, "smpl_type": rb, "randomrize_heading": True, "robot": robot, "step_dt": 1 / 50})
     flags.test, flags.im_eval, flags.real_traj = False, False, False
     lib = MotionLibReal(cfg)
     lib.load_motions(skeleton_trees=[tree] * N, gender_betas=torch.zeros(N, 17), limb_weights=np.zeros((N, 10)), random_sample=False, start_idx=0, max_len=-1)
@@ -83,7 +87,7 @@ def main():
     res = lib.get_motion_state(ids, times, offset=offs)
     d.update({f"ms_{k}": t2n(v) for k, v in res.items()})
     d.update(ms_ids=t2n(ids), ms_times=t2n(times), ms_offset=t2n(offs))
-    np.savez_compressed(os.path.join(OUT, "motion_lib_h1.npz"), **d)
+    np.savez_compressed(os.path.join(OUT, f"motion_lib_{rb}.npz"), **d)
 
     # ---------------- task functions on H1 shapes ----------------
     gr = torch.Generator().manual_seed(555)
@@ -99,15 +103,14 @@ def main():
     r1 = lib.get_motion_state(env_motion, (progress + 1) * dt + start_times, offset=goff)
     itu = ref_shim.ref_module("phc.utils.isaacgym_torch_utils")
     noise = lambda shape, s: torch.randn(*shape, generator=gr) * s
-    NB = 20
     body_pos = r0["rg_pos"] + noise((E, NB, 3), 0.03)
     body_pos[5:9] += noise((4, NB, 3), 0.25)
     body_rot = itu.quat_mul(itu.exp_map_to_quat(noise((E * NB, 3), 0.15)).view(E, NB, 4), r0["rb_rot"])
     body_vel = r0["body_vel"] + noise((E, NB, 3), 0.3)
     body_ang_vel = r0["body_ang_vel"] + noise((E, NB, 3), 0.5)
-    dof_pos = r0["dof_pos"] + noise((E, 19), 0.1)
-    dof_vel = r0["dof_vel"] + noise((E, 19), 0.5)
-    dof_force = noise((E, 19), 40.0)
+    dof_pos = r0["dof_pos"] + noise((E, ND), 0.1)
+    dof_vel = r0["dof_vel"] + noise((E, ND), 0.5)
+    dof_force = noise((E, ND), 40.0)
     names = list(hb.body_names)
     ext_parent = torch.tensor([names.index(e["parent_name"]) for e in robot.extend_config])
     ext_pos = torch.tensor([e["pos"] for e in robot.extend_config]).float().repeat(E, 1, 1)
@@ -130,18 +133,18 @@ def main():
                                                           True, True, True, False, False)
     task_obs = him.compute_imitation_observations_v6(body_pos[:, 0], body_rot[:, 0], body_pos, body_rot, body_vel, body_ang_vel,
                                                      r1["rg_pos"], r1["rb_rot"], r1["body_vel"], r1["body_ang_vel"], 1, True)
-    kid = torch.tensor([names.index(b) for b in H1_KEY_BODIES])
+    kid = torch.tensor([names.index(b) for b in KEY_BODIES[rb]])
     amp = hamp.build_amp_observations_robot(body_pos[:, 0], body_rot[:, 0], body_vel[:, 0], body_ang_vel[:, 0], dof_pos, dof_vel, body_pos[:, kid],
                                             torch.zeros(E, 17), torch.zeros(E, 10), torch.zeros(0, dtype=torch.long), True, True, True, False, False, True)
-    np.savez_compressed(os.path.join(OUT, "task_fns_h1.npz"), env_motion=t2n(env_motion), progress=t2n(progress), start_times=t2n(start_times),
+    np.savez_compressed(os.path.join(OUT, f"task_fns_{rb}.npz"), env_motion=t2n(env_motion), progress=t2n(progress), start_times=t2n(start_times),
                         body_pos=t2n(body_pos), body_rot=t2n(body_rot), body_vel=t2n(body_vel), body_ang_vel=t2n(body_ang_vel), dof_pos=t2n(dof_pos),
                         dof_vel=t2n(dof_vel), dof_force=t2n(dof_force), reward=t2n(rew), reward_raw=t2n(rew_raw), power_reward=t2n(power_reward),
                         reset=t2n(reset), terminate=t2n(term), self_obs=t2n(self_obs), task_obs=t2n(task_obs), amp_obs=t2n(amp), key_body_ids=t2n(kid),
                         ext_parent=t2n(ext_parent), ext_pos=t2n(ext_pos[0]), ref1_pos=t2n(r1["rg_pos"]), ref1_dof_pos=t2n(r1["dof_pos"]))
     os.chdir(cwd)
-    print("h1 goldens:", {f: os.path.getsize(os.path.join(OUT, f)) // 1024 for f in sorted(os.listdir(OUT)) if "h1" in f}, "KiB;",
+    print(rb, "goldens:", {f: os.path.getsize(os.path.join(OUT, f)) // 1024 for f in sorted(os.listdir(OUT)) if f"_{rb}." in f}, "KiB;",
           "self_obs", tuple(self_obs.shape), "task_obs", tuple(task_obs.shape), "amp", tuple(amp.shape), "terminated", int(term.sum()))
 
 
 if __name__ == "__main__":
-    main()
+    main(sys.argv[1] if len(sys.argv) > 1 else "h1")

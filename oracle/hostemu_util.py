@@ -54,7 +54,7 @@ def P(s):
 def np_model(name="smpl_humanoid", kp_scale=1.0, kd_scale=1.0):
     m = load_model(name)
     from phc_amd.robots import apply_collision_filter
-    apply_collision_filter(m, "h1" if name == "h1_humanoid" else "smpl")
+    apply_collision_filter(m, name.split("_")[0] if name in ("h1_humanoid", "g1_humanoid") else "smpl")
     ints, floats = m.pack(kp_scale, kd_scale)
     return m, abi.model_struct(ints, floats, m.num_bodies, m.num_dof, m.max_level, len(m.contact_body), split=m.two_slot_split()), (ints, floats)
 

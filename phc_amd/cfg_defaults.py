@@ -79,6 +79,21 @@ _ROBOT_H1 = {  # robot/unitree_h1.yaml
     "base_link": "torso_link",
 }
 
+_G1_HAND = ["zero", "one", "two", "three", "four", "five", "six"]
+_G1_LEG = ["hip_pitch", "hip_roll", "hip_yaw", "knee", "ankle_pitch", "ankle_roll"]
+_G1_ARM = ["shoulder_pitch", "shoulder_roll", "shoulder_yaw", "elbow_pitch", "elbow_roll"] + _G1_HAND
+_G1_BODIES = (["pelvis"] + [f"left_{n}_link" for n in _G1_LEG] + [f"right_{n}_link" for n in _G1_LEG] + ["torso_link"]
+              + [f"left_{n}_link" for n in _G1_ARM] + [f"right_{n}_link" for n in _G1_ARM])
+_ENV_IM_G1 = dict(_ENV_IM_H1, num_envs=3072, key_bodies=["left_ankle_roll_link", "right_ankle_roll_link", "left_zero_link", "right_zero_link"],   # env/env_im_g1_phc.yaml
+                  contact_bodies=["left_ankle_roll_link", "right_ankle_roll_link"], reset_bodies=_G1_BODIES)
+_ROBOT_G1 = dict(_ROBOT_H1, humanoid_type="g1", body_names=_G1_BODIES, dof_names=_G1_BODIES[1:],   # robot/unitree_g1.yaml
+                 limb_weight_group=[_G1_BODIES[1:7], _G1_BODIES[7:13], ["pelvis", "torso_link"], _G1_BODIES[14:26], _G1_BODIES[26:38]],
+                 right_foot_name="r_foot_roll", left_foot_name="l_foot_roll",
+                 asset={"assetRoot": "./", "assetFileName": "phc/data/assets/robot/unitree_g1/g1.xml",
+                        "urdfFileName": "phc/data/assets/robot/unitree_g1/g1.xml"},
+                 extend_config=[{"joint_name": "head_link", "parent_name": "pelvis", "pos": [0.0, 0.0, 0.4], "rot": [1.0, 0.0, 0.0, 0.0]}])
+_ROBOT_G1.pop("sim_with_urdf", None)
+
 _ENV_VR = dict(_ENV_IM, notes="VR modell, three point tracking", reset_bodies=["Head", "L_Hand", "R_Hand"],   # env/env_vr.yaml
                trackBodies=["Head", "L_Hand", "R_Hand"])
 
@@ -143,8 +158,8 @@ def _with_net(units, activation, net_name, cfg, extra_net):
 
 _BIG = [2048, 1536, 1024, 1024, 512, 512]
 GROUPS = {
-    "env": {"env_im": _ENV_IM, "env_im_pnn": _ENV_IM_PNN, "env_im_getup_mcp": _ENV_IM_GETUP_MCP, "env_im_h1_phc": _ENV_IM_H1, "env_vr": _ENV_VR},
-    "robot": {"smpl_humanoid": _ROBOT_SMPL, "unitree_h1": _ROBOT_H1},
+    "env": {"env_im": _ENV_IM, "env_im_pnn": _ENV_IM_PNN, "env_im_getup_mcp": _ENV_IM_GETUP_MCP, "env_im_h1_phc": _ENV_IM_H1, "env_im_g1_phc": _ENV_IM_G1, "env_vr": _ENV_VR},
+    "robot": {"smpl_humanoid": _ROBOT_SMPL, "unitree_h1": _ROBOT_H1, "unitree_g1": _ROBOT_G1},
     "learning": {"im": _learning([1024, 512], "relu"), "im_big": _learning(_BIG, "silu", extra_cfg={"save_frequency": 1500}),
                  "im_pnn": _learning([1024, 512], "relu", "amp_pnn"),
                  "im_pnn_big": _learning(_BIG, "silu", "amp_pnn", {"amp_dropout": False, "save_frequency": 1500}),

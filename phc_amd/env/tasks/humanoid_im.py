@@ -81,9 +81,9 @@ class HumanoidIm:
 
         # ---- load_humanoid_configs (humanoid.py:250-420) ----
         self.humanoid_type = robot.get("humanoid_type", "smpl")
-        if self.humanoid_type not in ("smpl", "h1"):
-            raise NotImplementedError(f"humanoid_type={self.humanoid_type!r}: built so far: smpl, h1")
-        self._is_robot = self.humanoid_type == "h1"
+        if self.humanoid_type not in ("smpl", "h1", "g1"):
+            raise NotImplementedError(f"humanoid_type={self.humanoid_type!r}: built so far: smpl, h1, g1")
+        self._is_robot = self.humanoid_type in ("h1", "g1")
         unsupported = dict(fut_tracks=False, zero_out_far_train=False, cycle_motion_xp=False, occl_training=False, res_action=False,
                            kin_loss=False, z_readout=False, distill=False, has_shape_variation=False)
         for k, off in unsupported.items():
@@ -183,11 +183,11 @@ class HumanoidIm:
 
         # ---- model (replaces create_sim / load_asset, humanoid.py:528-535,768-990) ----
         asset = robot.get("asset", {}).get("assetFileName", "mjcf/smpl_humanoid.xml")
-        self.model = load_model(cfg.get("model_asset", "h1_humanoid" if self._is_robot else "smpl_humanoid"))
+        self.model = load_model(cfg.get("model_asset", f"{self.humanoid_type}_humanoid"))
         assert self.model.body_names == self._body_names, f"asset {asset} does not have the body order of robot.body_names"
         if self._is_robot:
             # gains / default pose / torque limit live in the reference's task code (humanoid.py:1112-1121,1016-1022)
-            self._robot_consts = robots.H1
+            self._robot_consts = robots.ROBOTS[self.humanoid_type]
             robots.apply_robot_gains(self.model, self._robot_consts, env.get("pd_v", 1))
             self.p_gains = torch.tensor(self._robot_consts["p_gains"][env.get("pd_v", 1)], dtype=torch.float32, device=self.device)
             self.d_gains = torch.tensor(self._robot_consts["d_gains"][env.get("pd_v", 1)], dtype=torch.float32, device=self.device)

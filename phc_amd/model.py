@@ -179,6 +179,20 @@ def compile_mjcf(path):
             geom_defaults = dict(dflt.find("geom").attrib)
         if dflt.find("joint") is not None:
             joint_defaults = dict(dflt.find("joint").attrib)
+    # named default classes (<default class="visual"><geom contype="0" .../></default>, nested classes inherit their parent's)
+    geom_classes = {}
+
+    def walk_defaults(node, inherited):
+        for d in node.findall("default"):
+            attrs = dict(inherited)
+            if d.find("geom") is not None:
+                attrs.update(d.find("geom").attrib)
+            if "class" in d.attrib:
+                geom_classes[d.attrib["class"]] = attrs
+            walk_defaults(d, attrs)
+
+    if dflt is not None:
+        walk_defaults(dflt, geom_defaults)
     gears = {}
     act = root.find("actuator")
     if act is not None:
@@ -217,6 +231,8 @@ def compile_mjcf(path):
         capsules.append(np.zeros(7))
         first_geom = True
         for g in node.findall("geom"):
+            if "class" in g.attrib:   # effective attributes: class defaults, then the geom's own
+                g = _Attr({**geom_classes.get(g.attrib["class"], {}), **g.attrib})
             if g.attrib.get("contype") == "0" and g.attrib.get("conaffinity") == "0":
                 continue  # visual-only geom (robots)
             if g.attrib.get("type") == "mesh" and g.attrib.get("mesh") not in meshes:

@@ -122,10 +122,10 @@ def model_on(be, name="smpl_humanoid", kp_scale=1.0, kd_scale=1.0, zero_armature
     from phc_amd.model import load_model
     m = load_model(name)
     from phc_amd.robots import apply_collision_filter
-    apply_collision_filter(m, "h1" if name == "h1_humanoid" else "smpl")
-    if name == "h1_humanoid":
-        from phc_amd.robots import H1, apply_robot_gains
-        apply_robot_gains(m, H1)
+    apply_collision_filter(m, name.split("_")[0] if name in ("h1_humanoid", "g1_humanoid") else "smpl")
+    if name in ("h1_humanoid", "g1_humanoid"):
+        from phc_amd.robots import ROBOTS, apply_robot_gains
+        apply_robot_gains(m, ROBOTS[name.split("_")[0]])
     if zero_armature:
         m.dof_armature[:] = 0
     ints, floats = m.pack(kp_scale, kd_scale)

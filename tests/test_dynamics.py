@@ -179,15 +179,19 @@ def test_standing_pose_is_stable_under_pd(backend):
 # H1 (config 5): revolute joints with rest rotations, `pd` explicit-torque mode, joint limits
 # ---------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("backend", BACKENDS)
-@pytest.mark.parametrize("control_mode,limits,height", [(0, False, 1.05), (1, False, 1.05), (2, False, 1.05), (1, True, 1.05), (2, True, 0.9), (0, True, 0.9), (1, False, 3.0)])
-def test_h1_aba_matches_dense_oracle(backend, control_mode, limits, height):
+@pytest.mark.parametrize("name,control_mode,limits,height", [
+    ("h1_humanoid", 0, False, 1.05), ("h1_humanoid", 1, False, 1.05), ("h1_humanoid", 2, False, 1.05), ("h1_humanoid", 1, True, 1.05),
+    ("h1_humanoid", 2, True, 0.9), ("h1_humanoid", 0, True, 0.9), ("h1_humanoid", 1, False, 3.0),
+    ("g1_humanoid", 0, False, 0.8), ("g1_humanoid", 2, True, 0.7), ("g1_humanoid", 1, False, 3.0)])
+def test_robot_aba_matches_dense_oracle(backend, name, control_mode, limits, height):
     """H1: 19 revolute joints (rest rotations on the shoulder links), implicit position drive (`isaac_pd`) and the
-    explicit `pd` torque mode (recomputed once per simulate call), joint-limit penalty; 1/200 s x 2 sub-steps x 4 calls."""
+    explicit `pd` torque mode (recomputed once per simulate call), joint-limit penalty; 1/200 s x 2 sub-steps x 4 calls.
+    G1: 37 revolute joints on 38 bodies (tree depth 10, 14-gram finger links) -- the one-env-per-wavefront instantiation."""
     be = get_backend(backend)
-    model, mstruct, keep = model_on(be, "h1_humanoid")
-    assert model.all_revolute and model.num_bodies == 20 and model.num_dof == 19
+    model, mstruct, keep = model_on(be, name)
+    assert model.all_revolute and (model.num_bodies, model.num_dof) == {"h1_humanoid": (20, 19), "g1_humanoid": (38, 37)}[name]
     rng = np.random.default_rng(21)
-    n = 5
+    n = 5 if name == "h1_humanoid" else 3
     root, dof, target = random_states(model, n, rng, height=height, vel=0.7, pose=0.6 if limits else 0.3)
     lim = dict(limit_stiffness=2000.0, limit_damping=20.0) if limits else {}
     params = abi.sim_params_struct(sim_dt=1 / 200, substeps=2, control_freq_inv=4, control_mode=control_mode, **lim)
@@ -216,23 +220,28 @@ def test_h1_aba_matches_dense_oracle(backend, control_mode, limits, height):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
-@pytest.mark.parametrize("control_mode", [0, 2])
-def test_h1_settles_on_its_feet(backend, control_mode):
-    """0.4 s of holding the reference's default pose (humanoid.py:1121) after a 5 cm drop: the feet carry the weight, no
+@pytest.mark.parametrize("rb,control_mode", [("h1", 0), ("h1", 2), ("g1", 0), ("g1", 2)])
+def test_robot_settles_on_its_feet(backend, rb, control_mode):
+    """0.4 s of holding the reference's default pose (humanoid.py:1121,1181) after a 5 cm drop: the feet carry the weight, no
     chatter, joints quiet (an un-balanced humanoid tips over later -- that is physics, not tested).  Modes: implicit
     position drive and `pd` with the continuous damper (the held-damper variant, mode 1, chatters on the unloaded foot)."""
     be = get_backend(backend)
-    from phc_amd.robots import H1
-    model, mstruct, keep = model_on(be, "h1_humanoid")
+    from phc_amd.robots import ROBOTS
+    model, mstruct, keep = model_on(be, f"{rb}_humanoid")
     n = 4
+    nb, nd = model.num_bodies, model.num_dof
     root = np.zeros((n, 13), F)
-    root[:, 2] = 1.0
     root[:, 6] = 1.0
-    dof = np.zeros((n, 19, 2), F)
-    dof[:, :, 0] = np.asarray(H1["default_dof_pos"], F)
+    dof = np.zeros((n, nd, 2), F)
+    dof[:, :, 0] = np.asarray(ROBOTS[rb]["default_dof_pos"], F)
+    # pelvis height that puts the lowest contact point of the default pose 5 cm above the ground
+    st = do.State(root[0], dof[0], model)
+    Q, R, p = do.kinematics(model, st)
+    low = min(float((p[b] + R[b] @ c)[2] - r) for b, c, r in zip(model.contact_body, model.contact_pos, model.contact_radius))
+    h0 = 1.0 if rb == "h1" else 0.05 - low   # H1: the height the test has always used (a ~5 cm drop as well)
+    root[:, 2] = h0
     target = dof[:, :, 0].copy()
     params = abi.sim_params_struct(sim_dt=1 / 200, substeps=2, control_freq_inv=4, control_mode=control_mode, limit_stiffness=2000.0, limit_damping=20.0)
-    nb, nd = 20, 19
     a = dict(root=be.arr(root), dof=be.arr(dof), rbs=be.zeros((n, nb, 13)), cf=be.zeros((n, nb, 3)), df=be.zeros((n, nd)), pd=be.arr(target))
     sim = abi.sim_state_struct(n, a["root"], a["dof"], a["rbs"], a["cf"], a["df"], a["pd"])
     fz = []
@@ -242,16 +251,17 @@ def test_h1_settles_on_its_feet(backend, control_mode):
         fz.append(be.np(a["cf"])[:, :, 2].sum(-1))
     r = be.np(a["root"])
     assert np.isfinite(r).all()
-    assert (r[:, 2] > 0.85).all() and (r[:, 2] < 1.0).all(), r[:, 2]
+    assert (r[:, 2] > h0 - 0.15).all() and (r[:, 2] < h0).all(), (h0, r[:, 2])
     assert (np.abs(r[:, 6]) > 0.98).all(), "pelvis still upright"
     assert np.abs(be.np(a["dof"])[:, :, 1]).max() < 3.0, "joint rates quiet"
-    np.testing.assert_allclose(np.mean(fz[8:], axis=0), 51.436 * 9.81, rtol=0.25)   # feet carry the weight
+    np.testing.assert_allclose(np.mean(fz[8:], axis=0), model.total_mass * 9.81, rtol=0.25)   # feet carry the weight
     cf = be.np(a["cf"])
-    assert (np.abs(cf[:, [5, 10], 2]).sum(-1) > 0.9 * np.abs(cf[:, :, 2]).sum(-1)).all(), "only the ankle links touch the ground"
+    feet = {"h1": [5, 10], "g1": [6, 12]}[rb]   # ankle (roll) links
+    assert (np.abs(cf[:, feet, 2]).sum(-1) > 0.9 * np.abs(cf[:, :, 2]).sum(-1)).all(), "only the ankle links touch the ground"
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,nd", [("smpl_humanoid", 69), ("h1_humanoid", 19)])
+@pytest.mark.parametrize("name,nd", [("smpl_humanoid", 69), ("h1_humanoid", 19), ("g1_humanoid", 37)])
 def test_two_slot_mapping_equals_one_body_per_lane(name, nd):
     """k_sim_step16 (16 lanes per env, two bodies per lane, 4 envs per wavefront) runs the same per-lane functions in the same
     order as k_sim_step (one body per lane), also for env counts that do not fill the last wavefront.  The stepper TU is built with
@@ -260,10 +270,10 @@ def test_two_slot_mapping_equals_one_body_per_lane(name, nd):
     model, mstruct, keep = model_on(be, name)
     rng = np.random.default_rng(5)
     for n in (1, 7, 64):
-        root, dof, target = random_states(model, n, rng, height=0.9, pose=0.3 if nd == 19 else 0.5)
+        root, dof, target = random_states(model, n, rng, height=0.9, pose=0.5 if nd == 69 else 0.3)
         outs = []
         for mapping in (1, 2):
-            kw = dict(sim_dt=1 / 200, control_freq_inv=4, control_mode=2, limit_stiffness=2000.0, limit_damping=20.0) if nd == 19 else {}
+            kw = dict(sim_dt=1 / 200, control_freq_inv=4, control_mode=2, limit_stiffness=2000.0, limit_damping=20.0) if nd != 69 else {}
             params = abi.sim_params_struct(lane_mapping=mapping, **kw)
             outs.append(run_step(be, model, mstruct, root, dof, target, params, 2))
         for k in ("root", "dof", "rbs", "cf", "df"):
@@ -275,7 +285,7 @@ def test_two_slot_mapping_equals_one_body_per_lane(name, nd):
 # body-body contact (SURVEY f-1)
 # ---------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("backend", BACKENDS)
-@pytest.mark.parametrize("name", ["smpl_humanoid", "h1_humanoid"])
+@pytest.mark.parametrize("name", ["smpl_humanoid", "h1_humanoid", "g1_humanoid"])
 def test_self_collision_matches_dense_oracle(backend, name):
     """Capsule-capsule penalty contact between non-adjacent bodies: kernel == fp64 dense oracle with the same explicit forces,
     on folded poses that make limbs overlap."""
@@ -284,7 +294,7 @@ def test_self_collision_matches_dense_oracle(backend, name):
     rng = np.random.default_rng(8)
     n = 6
     root, dof, target = random_states(model, n, rng, height=1.5, vel=0.5, pose=0.9)
-    h1 = name == "h1_humanoid"
+    h1 = name != "smpl_humanoid"   # robots: 200 Hz, pd control
     kw = dict(sim_dt=1 / 200, control_freq_inv=4, control_mode=2) if h1 else {}
     params = abi.sim_params_struct(self_collision=1, **kw)
     out = run_step(be, model, mstruct, root, dof, target, params, 1)

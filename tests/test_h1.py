@@ -1,6 +1,7 @@
-"""H1 robot path (BASELINE config 5) against golden vectors produced by the reference's own code (oracle/gen_golden_h1.py):
-model constants vs Humanoid_Batch's reading of h1.xml, clip FK vs `Humanoid_Batch.fk_batch` / `MotionLibReal.load_motions`,
-the lookup kernel vs `MotionLibReal.get_motion_state`, and one post-physics step (extended-body reward, 20-body observations,
+"""Robot path -- Unitree H1 (BASELINE config 5, 20 bodies) and G1 (env_im_g1_phc, 38 bodies: the 64-lane kernel instantiations) --
+against golden vectors produced by the reference's own code (oracle/gen_golden_h1.py [h1|g1]):
+model constants vs Humanoid_Batch's reading of the robot's MJCF, clip FK vs `Humanoid_Batch.fk_batch` / `MotionLibReal.load_motions`,
+the lookup kernel vs `MotionLibReal.get_motion_state`, and one post-physics step (extended-body reward, per-body observations,
 robot AMP observation) vs the reference's jit functions.  Kernel tests run on both backends of tests/backends.py."""
 import numpy as np
 import pytest
@@ -11,33 +12,42 @@ from phc_amd.model import load_model
 from phc_amd.motion_lib import process_clip_real
 
 F = np.float32
-H1_KEY_BODIES = ["left_ankle_link", "right_ankle_link", "left_elbow_link", "right_elbow_link"]
+KEY_BODIES = {"h1": ["left_ankle_link", "right_ankle_link", "left_elbow_link", "right_elbow_link"],
+              "g1": ["left_ankle_roll_link", "right_ankle_roll_link", "left_zero_link", "right_zero_link"]}
+ROBOTS = ["h1", "g1"]
 
 
-def test_h1_model_matches_reference_skeleton(golden):
-    sk = golden("skeleton_h1")
-    m = load_model("h1_humanoid")
+@pytest.mark.parametrize("rb", ROBOTS)
+def test_robot_model_matches_reference_skeleton(golden, rb):
+    sk = golden(f"skeleton_{rb}")
+    m = load_model(f"{rb}_humanoid")
     assert m.body_names == list(sk["node_names"]) and m.all_revolute
     np.testing.assert_array_equal(m.parent, sk["parents"])
     np.testing.assert_allclose(m.local_translation, sk["local_translation"], atol=1e-7)
-    np.testing.assert_allclose(m.local_rotation, sk["local_rotation"], atol=1e-6)       # wxyz
+    # wxyz; g1.xml writes quat="1 0 0 1" for the thumb links: Humanoid_Batch keeps it as read and lets quaternion_to_matrix (2 / |q|^2)
+    # absorb the norm, the model compiler normalises
+    np.testing.assert_allclose(m.local_rotation, sk["local_rotation"] / np.linalg.norm(sk["local_rotation"], axis=-1, keepdims=True), atol=1e-6)
     np.testing.assert_allclose(m.dof_axis, sk["dof_axis"], atol=1e-12)
     np.testing.assert_allclose(np.stack([m.dof_lower, m.dof_upper], -1), sk["joints_range"], atol=1e-9)
-    assert abs(m.total_mass - 51.436) < 2e-3                                               # env_im_h1_phc.yaml default_humanoid_mass
+    if rb == "h1":
+        assert abs(m.total_mass - 51.436) < 2e-3                                           # env_im_h1_phc.yaml default_humanoid_mass
+    else:
+        assert m.num_bodies == 38 and m.max_level == 9 and m.two_slot_split()[0] > 0        # two bodies per lane on 32 lanes
 
 
-def _ext(golden):
-    sk = golden("skeleton_h1")
+def _ext(golden, rb):
+    sk = golden(f"skeleton_{rb}")
     e_rot = np.tile(np.array([1.0, 0, 0, 0]), (len(sk["ext_parents"]), 1))
     return sk["ext_parents"], sk["ext_offsets"], e_rot
 
 
-def test_h1_clip_fk_matches_reference(golden):
+@pytest.mark.parametrize("rb", ROBOTS)
+def test_robot_clip_fk_matches_reference(golden, rb):
     """process_clip_real == Humanoid_Batch.fk_batch(return_full=True) as concatenated by MotionLibReal.load_motions."""
-    g = golden("motion_lib_h1")
-    c = golden("motion_clips_h1")
-    m = load_model("h1_humanoid")
-    ep, eo, er = _ext(golden)
+    g = golden(f"motion_lib_{rb}")
+    c = golden(f"motion_clips_{rb}")
+    m = load_model(f"{rb}_humanoid")
+    ep, eo, er = _ext(golden, rb)
     per = [process_clip_real(m.parent, m.local_translation, m.local_rotation, ep, eo, er, c[f"{k}/pose_aa"], c[f"{k}/root_trans_offset"], 30)
            for k in c["keys"]]
     order = [0, 1, 2, 0, 1, 2]   # 6 envs, sequential sampling
@@ -50,20 +60,22 @@ def test_h1_clip_fk_matches_reference(golden):
         np.testing.assert_allclose(np.concatenate([per[i][k] for i in order]), g[k], atol=2e-6, err_msg=k)
 
 
-def _lib_from_golden(golden):
-    g = golden("motion_lib_h1")
+def _lib_from_golden(golden, rb):
+    g = golden(f"motion_lib_{rb}")
     return {k: g[k] for k in ("gts", "grs", "gvs", "gavs", "dvs", "dof_pos", "gts_t", "grs_t", "motion_lengths", "motion_dt", "motion_num_frames",
                               "length_starts")}
 
 
+@pytest.mark.parametrize("rb", ROBOTS)
 @pytest.mark.parametrize("backend", BACKENDS)
-def test_h1_motion_state_vs_reference_golden(golden, backend):
+def test_robot_motion_state_vs_reference_golden(golden, backend, rb):
     be = get_backend(backend)
-    g = golden("motion_lib_h1")
-    lib, keep = motion_lib_on(be, _lib_from_golden(golden))
+    g = golden(f"motion_lib_{rb}")
+    lib, keep = motion_lib_on(be, _lib_from_golden(golden, rb))
     n = len(g["ms_ids"])
-    out = dict(rg_pos=be.zeros((n, 20, 3)), rb_rot=be.zeros((n, 20, 4)), body_vel=be.zeros((n, 20, 3)), body_ang_vel=be.zeros((n, 20, 3)),
-               dof_pos=be.zeros((n, 19)), dof_vel=be.zeros((n, 19)), pe=be.zeros((n, 3, 3)), re=be.zeros((n, 3, 4)))
+    NB, NE = g["ms_rg_pos"].shape[1], g["ms_rg_pos_t"].shape[1] - g["ms_rg_pos"].shape[1]
+    out = dict(rg_pos=be.zeros((n, NB, 3)), rb_rot=be.zeros((n, NB, 4)), body_vel=be.zeros((n, NB, 3)), body_ang_vel=be.zeros((n, NB, 3)),
+               dof_pos=be.zeros((n, NB - 1)), dof_vel=be.zeros((n, NB - 1)), pe=be.zeros((n, NE, 3)), re=be.zeros((n, NE, 4)))
     assert be.motion_state(lib, n, be.arr(g["ms_ids"].astype(np.int64)), be.arr(g["ms_times"].astype(F)), be.arr(g["ms_offset"].astype(F)),
                            out["rg_pos"], out["rb_rot"], out["body_vel"], out["body_ang_vel"], out["dof_pos"], out["dof_vel"], None, None, None,
                            out["pe"], out["re"]) == 0
@@ -72,48 +84,52 @@ def test_h1_motion_state_vs_reference_golden(golden, backend):
     for k in ("rg_pos", "body_vel", "body_ang_vel", "dof_pos", "dof_vel"):
         np.testing.assert_allclose(o[k], g["ms_" + k], atol=2e-5, err_msg=k)
     np.testing.assert_allclose(o["rb_rot"], g["ms_rb_rot"], atol=2e-5)       # same slerp on the same (not re-normalised) stored quaternions
-    np.testing.assert_allclose(o["pe"], g["ms_rg_pos_t"][:, 20:], atol=2e-5)
-    np.testing.assert_allclose(o["re"], g["ms_rg_rot_t"][:, 20:], atol=2e-5)
+    np.testing.assert_allclose(o["pe"], g["ms_rg_pos_t"][:, NB:], atol=2e-5)
+    np.testing.assert_allclose(o["re"], g["ms_rg_rot_t"][:, NB:], atol=2e-5)
 
 
-def h1_im_params(be, model, ext_parent, ext_pos, **extra):
+def robot_im_params(be, model, ext_parent, ext_pos, rb="h1", **extra):
     names = model.body_names
-    tabs = abi.task_index_tables(model, names, names, H1_KEY_BODIES, has_dof_subset=False)
+    NB = len(names)
+    tabs = abi.task_index_tables(model, names, names, KEY_BODIES[rb], has_dof_subset=False)
     track_slot, reset_mask, key_ids, amp_slot = (be.arr(t) for t in tabs[:4])
     td = be.arr(np.full(64, 0.25, dtype=F))
     ep, eo = be.arr(np.asarray(ext_parent, np.int32)), be.arr(np.asarray(ext_pos, F))
     specs = dict(k_pos=100, k_rot=10, k_vel=0.1, k_ang_vel=0.1, w_pos=0.5, w_rot=0.3, w_vel=0.1, w_ang_vel=0.1)
     prm = abi.im_params_struct(dt=4 * (1 / 200), max_episode_length=300, reward_specs=specs, power_reward=True, power_coefficient=0.0005,
                                enable_early_termination=True, use_mean_termination=False, disable_collision_check=False, local_root_obs=True,
-                               root_height_obs=True, num_track_bodies=20, track_slot=track_slot, reset_mask=reset_mask, num_reset_bodies=20,
+                               root_height_obs=True, num_track_bodies=NB, track_slot=track_slot, reset_mask=reset_mask, num_reset_bodies=NB,
                                first_reset_body=0, termination_distances=td, num_key_bodies=4, key_body_ids=key_ids, num_amp_joints=tabs[4],
-                               amp_joint_slot=amp_slot, num_amp_obs_steps=10, num_amp_obs_per_step=63, num_self_obs=298, num_task_obs=480,
+                               amp_joint_slot=amp_slot, num_amp_obs_steps=10, num_amp_obs_per_step=13 + 2 * (NB - 1) + 12, num_self_obs=NB * 15 - 2,
+                               num_task_obs=NB * 24,
                                dofs_per_joint=1, ext_parent=ep, ext_offset=eo, **extra)
     prm._keepalive = (track_slot, reset_mask, key_ids, amp_slot, td, ep, eo)
     return prm
 
 
+@pytest.mark.parametrize("rb", ROBOTS)
 @pytest.mark.parametrize("backend", BACKENDS)
-def test_h1_post_physics_vs_reference_golden(golden, backend):
-    """Reward incl. the three extended bodies (humanoid_im.py:916-923), power reward over 19 scalar DoFs, reset flags, 298 self-obs +
-    480 task-obs floats and the 63-float robot AMP observation == the reference's functions on the same inputs."""
+def test_robot_post_physics_vs_reference_golden(golden, backend, rb):
+    """Reward incl. the extended bodies (humanoid_im.py:916-923), power reward over the scalar DoFs, reset flags, self-obs + task-obs
+    (H1 298 + 480, G1 568 + 912 floats) and the robot AMP observation (63 / 99) == the reference's functions on the same inputs."""
     be = get_backend(backend)
-    g = golden("task_fns_h1")
-    lib, keep = motion_lib_on(be, _lib_from_golden(golden))
-    model, mstruct, keepm = model_on(be, "h1_humanoid")
-    N = g["body_pos"].shape[0]
-    prm = h1_im_params(be, model, g["ext_parent"], g["ext_pos"])
-    assert prm.num_amp_joints == 19 and prm.num_ext_bodies == 3
+    g = golden(f"task_fns_{rb}")
+    lib, keep = motion_lib_on(be, _lib_from_golden(golden, rb))
+    model, mstruct, keepm = model_on(be, f"{rb}_humanoid")
+    N, NB = g["body_pos"].shape[:2]
+    ND, A, SO = NB - 1, 13 + 2 * (NB - 1) + 12, NB * 15 - 2
+    prm = robot_im_params(be, model, g["ext_parent"], g["ext_pos"], rb)
+    assert prm.num_amp_joints == ND and prm.num_ext_bodies == {"h1": 3, "g1": 1}[rb]
     rbs = np.concatenate([g["body_pos"], g["body_rot"], g["body_vel"], g["body_ang_vel"]], axis=-1).astype(F)
-    arrs = dict(root=be.arr(rbs[:, 0, :]), dof=be.arr(np.stack([g["dof_pos"], g["dof_vel"]], -1).astype(F)), rbs=be.arr(rbs), cf=be.zeros((N, 20, 3)),
-                df=be.arr(g["dof_force"].astype(F)), pd=be.zeros((N, 19)))
+    arrs = dict(root=be.arr(rbs[:, 0, :]), dof=be.arr(np.stack([g["dof_pos"], g["dof_vel"]], -1).astype(F)), rbs=be.arr(rbs), cf=be.zeros((N, NB, 3)),
+                df=be.arr(g["dof_force"].astype(F)), pd=be.zeros((N, ND)))
     sim = abi.sim_state_struct(N, arrs["root"], arrs["dof"], arrs["rbs"], arrs["cf"], arrs["df"], arrs["pd"])
     rng = np.random.default_rng(0)
-    amp_in_np = rng.standard_normal((N, 10, 63)).astype(F)
-    amp_in, amp_out = be.arr(amp_in_np), be.zeros((N, 10, 63))
+    amp_in_np = rng.standard_normal((N, 10, A)).astype(F)
+    amp_in, amp_out = be.arr(amp_in_np), be.zeros((N, 10, A))
     b = dict(progress=be.arr((g["progress"] - 1).astype(np.int64)), reset=be.zeros(N, np.int64), term=be.zeros(N, np.int64), rew=be.zeros(N),
-             raw=be.zeros((N, 5)), obs=be.zeros((N, 778)), mids=be.arr(g["env_motion"].astype(np.int64)), st=be.arr(g["start_times"].astype(F)),
-             so=be.zeros(N), goff=be.zeros((N, 3)), rbp=be.zeros((N, 20, 3)), rdp=be.zeros((N, 19)))
+             raw=be.zeros((N, 5)), obs=be.zeros((N, SO + NB * 24)), mids=be.arr(g["env_motion"].astype(np.int64)), st=be.arr(g["start_times"].astype(F)),
+             so=be.zeros(N), goff=be.zeros((N, 3)), rbp=be.zeros((N, NB, 3)), rdp=be.zeros((N, ND)))
     buf = abi.im_buffers_struct(b["progress"], b["reset"], b["term"], b["rew"], b["raw"], b["obs"], amp_in, amp_out, b["mids"], b["st"], b["so"],
                                 b["goff"], ref_body_pos=b["rbp"], ref_dof_pos=b["rdp"])
     assert be.im_post_physics(mstruct, lib, prm, sim, buf) == 0
@@ -125,8 +141,8 @@ def test_h1_post_physics_vs_reference_golden(golden, backend):
     np.testing.assert_allclose(o["rew"], g["reward"] + g["power_reward"], atol=1e-5)
     np.testing.assert_array_equal(o["reset"], g["reset"])
     np.testing.assert_array_equal(o["term"], g["terminate"])
-    np.testing.assert_allclose(o["obs"][:, :298], g["self_obs"], atol=1e-5)
-    np.testing.assert_allclose(o["obs"][:, 298:], g["task_obs"], atol=2e-5)
+    np.testing.assert_allclose(o["obs"][:, :SO], g["self_obs"], atol=1e-5)
+    np.testing.assert_allclose(o["obs"][:, SO:], g["task_obs"], atol=2e-5)
     np.testing.assert_allclose(amp_out[:, 0], g["amp_obs"], atol=1e-5)
     np.testing.assert_array_equal(amp_out[:, 1:], amp_in_np[:, :-1])
     np.testing.assert_allclose(o["rbp"], g["ref1_pos"], atol=2e-5)
