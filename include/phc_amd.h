@@ -46,7 +46,7 @@ typedef struct {
     const float* floats;
     int32_t split_level;      /* two-slot stepper mapping: bodies of tree levels < split_level share lanes with the deeper ones; */
     int32_t num_below_split;  /* -1 / 0 when the tree has no split with both halves <= 16 (NB <= 32) or <= 32 bodies (ArticulationModel.two_slot_split) */
-    int32_t num_collision_pairs; /* body pairs that may collide (listed after the int tables); <= 288 */
+    int32_t num_collision_pairs; /* body pairs that may collide (listed after the int tables); capacity 576 (NB <= 32) / 1152, see phc_sim_step */
 } phc_model_t;
 
 /* Flat reference-motion buffer.  Replaces MotionLibBase's gts/grs/lrs/gvs/gavs/dvs tensors

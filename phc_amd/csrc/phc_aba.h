@@ -446,19 +446,24 @@ PHC_HD void aba_collide_pair(const phc_sim_params_t& prm, float dt, int i, int k
 }
 // lane `l` of `nl` lanes of the env's group: its share of the candidate pairs, fetched ONCE per launch into registers (the list
 // sits in global memory; a dependent L2 round trip per pair and sub-step was the largest part of the first version's cost)
+// pairs per lane: 18 x 16 lanes hold the 245 pairs of the SMPL humanoid; a wide group (32 lanes x 2 bodies) takes 24 (G1: 589)
 #define PHC_SC_MAX_PER_LANE 18
-struct PairList { int pr[PHC_SC_MAX_PER_LANE]; };
-PHC_HD void aba_load_pairs(PairList& P, const phc_model_t& m, int l, int nl) {
+#define PHC_SC_MAX_PER_LANE_WIDE 24
+template <int NP>
+struct PairList { int pr[NP]; };
+template <int NP>
+PHC_HD void aba_load_pairs(PairList<NP>& P, const phc_model_t& m, int l, int nl) {
     const int np = model_num_pairs(m);
 #pragma unroll
-    for (int t = 0; t < PHC_SC_MAX_PER_LANE; ++t) {
+    for (int t = 0; t < NP; ++t) {
         const int q = t * nl + l;
         P.pr[t] = q < np ? model_pair(m, q) : -1;
     }
 }
-PHC_HD void aba_collide_pairs(const PairList& P, const phc_sim_params_t& prm, float dt, const Xch& x, float* caps) {
+template <int NP>
+PHC_HD void aba_collide_pairs(const PairList<NP>& P, const phc_sim_params_t& prm, float dt, const Xch& x, float* caps) {
 #pragma unroll
-    for (int t = 0; t < PHC_SC_MAX_PER_LANE; ++t)
+    for (int t = 0; t < NP; ++t)
         if (P.pr[t] >= 0) aba_collide_pair(prm, dt, P.pr[t] & 0xff, P.pr[t] >> 8, x, caps);
 }
 // net body-body contact force / moment of body j from its accumulators

@@ -62,7 +62,7 @@ __global__ __launch_bounds__(64, 2) void k_sim_step(phc_model_t model, phc_sim_p
         const float dt = prm.sim_dt / (float)prm.substeps;
         const int nsub = num_sim_calls * prm.substeps;
         float* caps = cap_all + grp * GRP * PHC_CAP_STRIDE;
-        PairList pairs;
+        PairList<PHC_SC_MAX_PER_LANE> pairs;
         if (prm.self_collision) aba_load_pairs(pairs, model, lane, GRP);
         for (int s = 0; s < nsub; ++s) {
             if (prm.self_collision) {   // body-body contact from the kinematics the last sweep left in the exchange slots
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(64, 1) void k_sim_step16(phc_model_t model, phc_sim
     }
     const float dt = prm.sim_dt / (float)prm.substeps;
     const int nsub = num_sim_calls * prm.substeps;
-    PairList pairs;
+    PairList<(GRP == 32 ? PHC_SC_MAX_PER_LANE_WIDE : PHC_SC_MAX_PER_LANE)> pairs;
     if (prm.self_collision) aba_load_pairs(pairs, model, lane, GRP);
     for (int s = 0; s < nsub; ++s) {
         const bool fresh = s % prm.substeps == 0;
@@ -219,7 +219,9 @@ int32_t phc_sim_step(const phc_model_t* model, const phc_sim_params_t* params, c
     if (actions && (!pd_action_offset || !pd_action_scale)) return PHC_EINVAL;
     if (sim->num_envs == 0) return 0;
     const int wide = model->num_bodies > 32;
-    if (params->self_collision && model->num_collision_pairs > PHC_SC_MAX_PER_LANE * (wide ? 32 : 16)) return PHC_EUNSUPPORTED;
+    // pair capacity of the two mappings (pairs are dealt round-robin to the lanes of an env's group)
+    const int cap_one = PHC_SC_MAX_PER_LANE * (wide ? 64 : 32), cap_two = wide ? PHC_SC_MAX_PER_LANE_WIDE * 32 : PHC_SC_MAX_PER_LANE * 16;
+    if (params->self_collision && model->num_collision_pairs > cap_one) return PHC_EUNSUPPORTED;
     // lane_mapping 1 / 2 force a kernel; 0 picks.  Measured on MI355X at N = 4096 (scripts/gpu_map.sh): SMPL (tree depth 8, 2.8 contact
     // points per body) 106 us one-body-per-lane vs 89 us two-slot; H1 (depth 5, 12.8 contact points per body, 8 sub-steps) 104 vs
     // 126 us -- the two-slot kernel runs the per-body initialisation (inertia rotation, contacts, drive) twice per sub-step, which
@@ -232,7 +234,8 @@ int32_t phc_sim_step(const phc_model_t* model, const phc_sim_params_t* params, c
         num_simds = 4 * (cus > 0 ? cus : 256);
     }
     const int half = wide ? 32 : 16;   // lanes per env of the two-slot mapping
-    const bool can_split = model->split_level > 0 && model->num_below_split <= half && model->num_bodies - model->num_below_split <= half;
+    const bool can_split = model->split_level > 0 && model->num_below_split <= half && model->num_bodies - model->num_below_split <= half &&
+                           !(params->self_collision && model->num_collision_pairs > cap_two);
     const bool two_slot = can_split && (params->lane_mapping == 2 || (params->lane_mapping == 0 && model->max_level >= 7 &&
                                                                       (int64_t)sim->num_envs <= (64 / half) * (int64_t)num_simds));
     sim_launch<true>(model, *params, sim, actions, pd_action_offset, pd_action_scale, freeze_mask, num_sim_calls, (hipStream_t)stream, nullptr, 0,
