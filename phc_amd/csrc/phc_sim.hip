@@ -236,8 +236,9 @@ int32_t phc_sim_step(const phc_model_t* model, const phc_sim_params_t* params, c
     const int half = wide ? 32 : 16;   // lanes per env of the two-slot mapping
     const bool can_split = model->split_level > 0 && model->num_below_split <= half && model->num_bodies - model->num_below_split <= half &&
                            !(params->self_collision && model->num_collision_pairs > cap_two);
-    const bool two_slot = can_split && (params->lane_mapping == 2 || (params->lane_mapping == 0 && model->max_level >= 7 &&
-                                                                      (int64_t)sim->num_envs <= (64 / half) * (int64_t)num_simds));
+    // wide articulations (G1, N = 4096, scripts/gpu_g1.sh): 434 us one body per lane vs 515 us two-slot -> never picked automatically
+    const bool two_slot = can_split && (params->lane_mapping == 2 || (params->lane_mapping == 0 && !wide && model->max_level >= 7 &&
+                                                                      (int64_t)sim->num_envs <= 4 * (int64_t)num_simds));
     sim_launch<true>(model, *params, sim, actions, pd_action_offset, pd_action_scale, freeze_mask, num_sim_calls, (hipStream_t)stream, nullptr, 0,
                      two_slot);
     return launch_status();
