@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PHC_ABI_VERSION 8
+#define PHC_ABI_VERSION 9
 #define PHC_MAX_BODIES 64   /* bodies (incl. extended reference bodies) per articulation; also the slot count of the model tables */
 #define PHC_EINVAL (-1)
 #define PHC_EUNSUPPORTED (-2)
@@ -262,6 +262,17 @@ int32_t phc_gae(int32_t horizon, int32_t n, const float* fdones, const float* va
  * root_trans [T,3] -> global_rot [T,NB,4], global_pos [T,NB,3]. */
 int32_t phc_fk(const phc_model_t* model, int64_t num_frames, const float* local_rot, const float* root_trans,
                float* global_rot, float* global_pos, void* stream);
+
+/* P1: RunningMeanStd.forward in train mode (phc/utils/running_mean_std.py:69-111) on a device batch x [rows, cols] fp32:
+ *   out = clamp((x - float(norm_mean)) / sqrt(float(norm_var) + epsilon), -clamp, clamp)      (:95-96; fp32 or bf16 [rows, cols], may be NULL)
+ *   run_mean / run_var / run_count (fp64, in place; NULL = no update, eval mode or frozen) <- parallel-variance update with the batch
+ *   mean and unbiased variance (:56-67,100-104).  norm_* may alias run_* (output from the statistics BEFORE the update, as the
+ *   reference computes it) or be a frozen copy (amp_agent.py:527-532 `running_mean_std_temp`).
+ * workspace: phc_running_norm_workspace(rows, cols) bytes of device memory (only read / written when updating). */
+int64_t phc_running_norm_workspace(int64_t rows, int32_t cols);
+int32_t phc_running_norm(const float* x, int64_t rows, int32_t cols, const double* norm_mean, const double* norm_var, float epsilon,
+                         float clamp, void* out, int32_t out_bf16, double* run_mean, double* run_var, double* run_count,
+                         double* workspace, void* stream);
 
 #ifdef __cplusplus
 }

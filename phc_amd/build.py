@@ -12,7 +12,9 @@ LIB = os.path.join(HERE, "libphc_amd.so")
 #     -ffp-contract=off (e.g. sqrt(1 - w*w) in quat_to_angle_axis is cancellation-prone: a contracted fma moves exp-map
 #     outputs by 1e-3); -fno-slp-vectorize avoids v_pk_* register marshalling (reset 68 -> 49 us, post-physics 35 -> 27 us).
 #   stepper: see the header of phc_sim.hip (-ffast-math -fno-slp-vectorize: 158 -> 109 us).
-SOURCES = {"phc_kernels.hip": ["-fno-slp-vectorize", "-ffp-contract=off"], "phc_sim.hip": ["-ffast-math", "-fno-slp-vectorize"]}
+#   learner kernels: bandwidth-bound passes; IEEE division / no contraction so the normalised values equal torch's.
+SOURCES = {"phc_kernels.hip": ["-fno-slp-vectorize", "-ffp-contract=off"], "phc_sim.hip": ["-ffast-math", "-fno-slp-vectorize"],
+           "phc_learn.hip": ["-ffp-contract=off"]}
 HEADERS = ["phc_math.h", "phc_task.h", "phc_im.h", "phc_aba.h", os.path.join("..", "..", "include", "phc_amd.h")]
 
 

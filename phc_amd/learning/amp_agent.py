@@ -211,14 +211,14 @@ class IMAmpAgent:
     def _preproc_obs(self, obs_batch, use_temp=False):
         if not self.normalize_input:
             return obs_batch
-        if use_temp:
-            out = self.running_mean_std_temp(obs_batch)
-            self.running_mean_std(obs_batch)  # statistics keep updating, the frozen copy provides the values
-            return out
-        return self.running_mean_std(obs_batch)
+        # bf16 runs: the normaliser writes the bf16 tensor the GEMMs read (the same values autocast's cast would produce)
+        dt = torch.bfloat16 if self.bf16 else None
+        if use_temp:  # statistics keep updating, the frozen copy provides the values (amp_agent.py:527-532)
+            return self.running_mean_std(obs_batch, norm_from=self.running_mean_std_temp, out_dtype=dt)
+        return self.running_mean_std(obs_batch, out_dtype=dt)
 
     def _preproc_amp_obs(self, amp_obs):
-        return self._amp_input_mean_std(amp_obs) if self._normalize_amp_input else amp_obs
+        return self._amp_input_mean_std(amp_obs, out_dtype=torch.bfloat16 if self.bf16 else None) if self._normalize_amp_input else amp_obs
 
     # ------------------------------------------------------------------ rollout (amp_agent.py:309-397)
     def get_action_values(self, obs):
@@ -345,7 +345,7 @@ class IMAmpAgent:
         disc_logit_loss = torch.sum(torch.square(net.get_disc_logit_weights()))
         disc_loss = disc_loss + self._disc_logit_reg * disc_logit_loss
         grad = torch.autograd.grad(disc_demo_logit, obs_demo, grad_outputs=torch.ones_like(disc_demo_logit), create_graph=True,
-                                   retain_graph=True, only_inputs=True)[0]
+                                   retain_graph=True, only_inputs=True)[0].float()   # bf16 leaf (device normaliser output): penalty in fp32
         disc_grad_penalty = torch.mean(torch.sum(torch.square(grad), dim=-1))
         disc_loss = disc_loss + self._disc_grad_penalty * disc_grad_penalty
         if self._disc_weight_decay != 0:

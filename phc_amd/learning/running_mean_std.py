@@ -4,6 +4,12 @@ Same behaviour as the reference `RunningMeanStd` (phc/utils/running_mean_std.py:
 `running_var`, `count`; forward normalises and clamps to +-5 (or un-normalises with `unnorm=True`), and in train mode
 (unless frozen) folds the batch moments in with the parallel-variance update (:56-67) AFTER computing the output.
 `sync()` averages the moments across ranks (the reference's `hvd.sync_stats`, common_agent.py:126-127).
+
+On the device the whole forward -- normalise + clamp, batch mean / variance, the fp64 moment update -- is one HIP pass over the
+batch plus a one-block finish (`phc_running_norm`, csrc/phc_learn.hip) instead of ~40 torch launches; `norm_from` lets the
+output come from a frozen copy while this module's statistics keep updating (amp_agent.py:527-532), `out_dtype=torch.bfloat16`
+writes the tensor the bf16 GEMMs read.  The torch expressions below remain the CPU path and the definition the kernel is tested
+against.
 """
 import torch
 from torch import nn
@@ -46,8 +52,36 @@ class RunningMeanStd(nn.Module):
         M2 = m_a + m_b + delta ** 2 * count * batch_count / tot_count
         return new_mean, M2 / tot_count, tot_count
 
-    def forward(self, input, unnorm=False):
-        mean, var = self.running_mean, self.running_var
+    def _fused_ok(self, input, unnorm):
+        return (input.is_cuda and input.dtype == torch.float32 and input.dim() == 2 and input.is_contiguous() and not unnorm
+                and not self.norm_only and not self.forzen_partial and input.shape[1] == self.mean_size)
+
+    def _forward_fused(self, input, src, out_dtype, want_output):
+        from .. import _lib as L
+        lib = L.load()
+        rows, cols = input.shape
+        update = self.training and not self.forzen
+        out = torch.empty((rows, cols), dtype=out_dtype, device=input.device) if want_output else None
+        ws = None
+        if update:
+            need = lib.phc_running_norm_workspace(rows, cols) // 8
+            if getattr(self, "_ws", None) is None or self._ws.numel() < need or self._ws.device != input.device:
+                self._ws = torch.empty(need, dtype=torch.float64, device=input.device)
+            ws = self._ws
+        ptr = lambda t: None if t is None else t.data_ptr()
+        L.check(lib.phc_running_norm(input.data_ptr(), rows, cols, src.running_mean.data_ptr(), src.running_var.data_ptr(), float(src.epsilon), 5.0,
+                                     ptr(out), int(out_dtype == torch.bfloat16), ptr(self.running_mean if update else None),
+                                     ptr(self.running_var if update else None), ptr(self.count if update else None), ptr(ws),
+                                     torch.cuda.current_stream(input.device).cuda_stream), "phc_running_norm")
+        return out
+
+    def forward(self, input, unnorm=False, norm_from=None, out_dtype=None, want_output=True):
+        """`norm_from`: module whose statistics produce the output (default: this one, before its update); `out_dtype`: fp32
+        (default) or bf16; `want_output=False`: only fold the batch into the statistics (device path skips the store)."""
+        src = norm_from if norm_from is not None else self
+        if self._fused_ok(input, unnorm):
+            return self._forward_fused(input, src, out_dtype or torch.float32, want_output)
+        mean, var = src.running_mean, src.running_var
         if unnorm:
             y = torch.clamp(input, min=-5.0, max=5.0)
             y = torch.sqrt(var.float() + self.epsilon) * y + mean.float()
@@ -68,7 +102,7 @@ class RunningMeanStd(nn.Module):
                     self.running_mean.copy_(nm)
                     self.running_var.copy_(nv)
                     self.count.copy_(nc)
-        return y
+        return y if out_dtype is None else y.to(out_dtype)
 
     @torch.no_grad()
     def sync(self, dist):

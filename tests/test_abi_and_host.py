@@ -20,7 +20,7 @@ HEADER = os.path.join(ROOT, "include", "phc_amd.h")
 
 def _declared_symbols():
     txt = open(HEADER).read()
-    return sorted(set(re.findall(r"^int32_t\s+(phc_\w+)\s*\(", txt, flags=re.M)))
+    return sorted(set(re.findall(r"^int(?:32|64)_t\s+(phc_\w+)\s*\(", txt, flags=re.M)))
 
 
 def test_library_exports_every_declared_symbol():
@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     assert sorted(_lib.EXPORTED_SYMBOLS) == declared, "ctypes table and header disagree"
     for name in declared:
         assert hasattr(lib, name), f"libphc_amd.so does not export {name}"
-    assert lib.phc_abi_version() == 8
+    assert lib.phc_abi_version() == 9
 
 
 def test_struct_sizes_match_the_header():
