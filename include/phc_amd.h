@@ -265,14 +265,28 @@ int32_t phc_fk(const phc_model_t* model, int64_t num_frames, const float* local_
 
 /* P1: RunningMeanStd.forward in train mode (phc/utils/running_mean_std.py:69-111) on a device batch x [rows, cols] fp32:
  *   out = clamp((x - float(norm_mean)) / sqrt(float(norm_var) + epsilon), -clamp, clamp)      (:95-96; fp32 or bf16 [rows, cols], may be NULL)
- *   run_mean / run_var / run_count (fp64, in place; NULL = no update, eval mode or frozen) <- parallel-variance update with the batch
- *   mean and unbiased variance (:56-67,100-104).  norm_* may alias run_* (output from the statistics BEFORE the update, as the
+ *   run_mean / run_var (fp64, in place; NULL = no update, eval mode or frozen) <- parallel-variance update with the batch mean and
+ *   unbiased variance (:56-67,100-104); run_count is READ only: the caller adds `rows` to it afterwards (stream-ordered).  norm_* may alias run_* (output from the statistics BEFORE the update, as the
  *   reference computes it) or be a frozen copy (amp_agent.py:527-532 `running_mean_std_temp`).
  * workspace: phc_running_norm_workspace(rows, cols) bytes of device memory (only read / written when updating). */
 int64_t phc_running_norm_workspace(int64_t rows, int32_t cols);
 int32_t phc_running_norm(const float* x, int64_t rows, int32_t cols, const double* norm_mean, const double* norm_var, float epsilon,
-                         float clamp, void* out, int32_t out_bf16, double* run_mean, double* run_var, double* run_count,
+                         float clamp, void* out, int32_t out_bf16, double* run_mean, double* run_var, const double* run_count,
                          double* workspace, void* stream);
+
+/* Column sums of a bf16 matrix x [rows, cols] -> out fp32 [cols]: the bias gradient of a linear layer (autograd's `sum(0)` of
+ * the output gradient, AddmmBackward).  workspace: phc_colsum_workspace(rows, cols) bytes. */
+int64_t phc_colsum_workspace(int64_t rows, int32_t cols);
+int32_t phc_colsum_bf16(const void* x, int64_t rows, int32_t cols, float* out, float* workspace, void* stream);
+
+/* P9: gradient clipping + optimizer step on the flat fp32 parameter (phc/learning/amp_agent.py:669-676: `clip_grad_norm_(grad_norm)`
+ * then `optimizer.step()` with torch.optim.Adam): grad *= min(1, max_norm / (|grad| + 1e-6)) in place (max_norm <= 0: no clipping),
+ * then Adam with L2 weight decay; `step` is the 1-based step count (bias corrections computed on the host in fp64).
+ * grad_norm_out (optional, device) receives |grad| before clipping.  workspace: phc_adam_workspace() bytes. */
+int64_t phc_adam_workspace(void);
+int32_t phc_adam_clip_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
+                           float eps, float weight_decay, int64_t step, float max_norm, double* workspace, float* grad_norm_out,
+                           void* stream);
 
 #ifdef __cplusplus
 }

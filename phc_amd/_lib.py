@@ -87,6 +87,10 @@ _SIGNATURES = {
     "phc_fk": ([P(Model), c_i64, c_p, c_p, c_p, c_p, c_p], c_i32),
     "phc_running_norm_workspace": ([c_i64, c_i32], c_i64),
     "phc_running_norm": ([c_p, c_i64, c_i32, c_p, c_p, c_f, c_f, c_p, c_i32, c_p, c_p, c_p, c_p, c_p], c_i32),
+    "phc_colsum_workspace": ([c_i64, c_i32], c_i64),
+    "phc_colsum_bf16": ([c_p, c_i64, c_i32, c_p, c_p, c_p], c_i32),
+    "phc_adam_workspace": ([], c_i64),
+    "phc_adam_clip_step": ([c_p, c_p, c_p, c_p, c_i64, c_f, c_f, c_f, c_f, c_f, c_i64, c_f, c_p, c_p, c_p], c_i32),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 

@@ -32,6 +32,7 @@ from torch import nn
 from .. import _lib as L
 from .network import A2CMCPNetwork, A2CNetwork, A2CPNNNetwork, ModelAMPContinuous, policy_kl
 from .replay_buffer import ReplayBuffer
+from .fast_ops import adam_clip_step
 from .running_mean_std import RunningMeanStd
 
 
@@ -166,11 +167,9 @@ class IMAmpAgent:
         self._amp_input_mean_std = RunningMeanStd((amp_dim,)).to(self.device) if self._normalize_amp_input else None
         self.running_mean_std_temp = None
         self.grads = FlatGradBucket(self.model.parameters())
-        # one flat fp32 parameter: the fused implementation is a single launch per step (the default foreach path ran ~10
-        # elementwise passes over the 22 MB buffer: 323 -> ~30 us per step)
-        on_gpu = str(self.device).startswith("cuda")
-        self.optimizer = torch.optim.Adam([self.grads.flat_param], self.last_lr, eps=1e-08, weight_decay=c.get("weight_decay", 0.0),
-                                          **({"fused": True} if on_gpu else {}))
+        # one flat fp32 parameter; on the device clip + step are two HIP launches over it (fast_ops.adam_clip_step) and this object
+        # only holds the state (checkpoint format unchanged)
+        self.optimizer = torch.optim.Adam([self.grads.flat_param], self.last_lr, eps=1e-08, weight_decay=c.get("weight_decay", 0.0))
 
         T, N, dev = self.horizon_length, self.num_actors, self.device
         f = lambda *s: torch.zeros(*s, device=dev, dtype=torch.float32)
@@ -387,6 +386,9 @@ class IMAmpAgent:
         return info
 
     def _clip_and_step(self):
+        if self.grads.flat.is_cuda:
+            adam_clip_step(self.optimizer, self.grads.flat_param, self.grads.flat, self.grad_norm if self.truncate_grads else None)
+            return
         if self.truncate_grads:
             self.grads.clip_grad_norm_(self.grad_norm)
         self.optimizer.step()

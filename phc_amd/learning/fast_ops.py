@@ -1,0 +1,109 @@
+"""Device-side pieces of the PPO update that are not GEMMs (csrc/phc_learn.hip) and the layer that uses them.
+
+`FastLinear` is `nn.Linear` (same parameters, same state-dict keys) whose TRAINING pass under bf16 autocast on the device goes through
+one autograd node built for this shape of problem -- batch of 16 384 rows, 10^2..10^3 features:
+  * forward: bf16 addmm (hipBLASLt), as autocast does it;
+  * weight gradient dY^T X: the reduction dimension is the batch, 16x longer than the output is wide, and the library kernel picked
+    for it (MT64x64x256, no split-K) runs 240 workgroups for 105-115 us; as a batched GEMM over 8 row chunks + an fp32 sum it takes
+    44-68 us (scripts/gemm_probe2.py);
+  * bias gradient: `phc_colsum_bf16` instead of torch's generic column reduction (25 us for 1024 columns, 95 us for 69).
+It is used for the actor and critic (amp_agent.py:554-655); the discriminator keeps nn.Linear because its gradient penalty
+differentiates the backward pass itself (create_graph=True).  Anywhere else (CPU, fp32, no_grad rollouts, frozen columns) it is
+exactly nn.Linear.  `adam_clip_step` = clip_grad_norm_ + torch.optim.Adam.step on the flat parameter in two launches."""
+import torch
+from torch import nn
+from torch.autograd.function import once_differentiable
+
+from .. import _lib as L
+
+_ws = {}
+
+
+def _workspace(key, nbytes, device, dtype):
+    n = (nbytes + dtype.itemsize - 1) // dtype.itemsize
+    t = _ws.get((key, device))
+    if t is None or t.numel() < n:
+        t = torch.empty(max(n, 1), dtype=dtype, device=device)
+        _ws[(key, device)] = t
+    return t
+
+
+def _stream(device):
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def colsum_bf16(x):
+    """x bf16 [rows, cols] (contiguous, device) -> fp32 [cols]"""
+    lib = L.load()
+    rows, cols = x.shape
+    out = torch.empty(cols, dtype=torch.float32, device=x.device)
+    ws = _workspace("colsum", lib.phc_colsum_workspace(rows, cols), x.device, torch.float32)
+    L.check(lib.phc_colsum_bf16(x.data_ptr(), rows, cols, out.data_ptr(), ws.data_ptr(), _stream(x.device)), "phc_colsum_bf16")
+    return out
+
+
+SPLIT_K = 8
+
+
+def wgrad_split_k(gy, x):
+    """gy^T x for gy [B, N], x [B, K] bf16 -> fp32 [N, K]; the batch is cut into SPLIT_K chunks that run as one batched GEMM."""
+    B, N = gy.shape
+    K = x.shape[1]
+    if B % SPLIT_K == 0 and B >= 2048:
+        part = torch.bmm(gy.view(SPLIT_K, B // SPLIT_K, N).transpose(1, 2), x.view(SPLIT_K, B // SPLIT_K, K))
+        return part.sum(0, dtype=torch.float32)
+    return (gy.t() @ x).float()
+
+
+class _LinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        with torch.autocast("cuda", enabled=False):
+            xb = x.to(torch.bfloat16)
+            wb = weight.to(torch.bfloat16)
+            y = torch.addmm(bias.to(torch.bfloat16), xb, wb.t())
+        ctx.save_for_backward(xb, wb)
+        ctx.x_dtype = x.dtype
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        xb, wb = ctx.saved_tensors
+        gy = gy.contiguous()
+        with torch.autocast("cuda", enabled=False):
+            gx = (gy @ wb).to(ctx.x_dtype) if ctx.needs_input_grad[0] else None
+            gw = wgrad_split_k(gy, xb) if ctx.needs_input_grad[1] else None
+            gb = colsum_bf16(gy) if ctx.needs_input_grad[2] else None
+        return gx, gw, gb
+
+
+class FastLinear(nn.Linear):
+    def forward(self, x):
+        if (x.is_cuda and x.dim() == 2 and torch.is_grad_enabled() and self.weight.requires_grad and self.bias is not None
+                and torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16 and x.is_contiguous()):
+            return _LinearFn.apply(x, self.weight, self.bias)
+        return nn.functional.linear(x, self.weight, self.bias)
+
+
+def adam_clip_step(optimizer, flat_param, flat_grad, max_norm):
+    """`clip_grad_norm_(max_norm)` (None / <= 0: no clipping) + `optimizer.step()` for a torch.optim.Adam that holds the single flat
+    parameter, on the device: its state (`step`, `exp_avg`, `exp_avg_sq`) stays the optimizer's, so checkpoints are unchanged."""
+    lib = L.load()
+    group = optimizer.param_groups[0]
+    assert len(optimizer.param_groups) == 1 and len(group["params"]) == 1 and group["params"][0] is flat_param
+    assert not group.get("amsgrad", False) and not group.get("maximize", False)
+    st = optimizer.state[flat_param]
+    if len(st) == 0:
+        st["step"] = torch.tensor(0.0, dtype=torch.float32)
+        st["exp_avg"] = torch.zeros_like(flat_param)
+        st["exp_avg_sq"] = torch.zeros_like(flat_param)
+    if st["step"].is_cuda:   # state restored from a checkpoint written by a fused / capturable optimizer
+        st["step"] = st["step"].detach().cpu()
+    st["step"] += 1
+    b1, b2 = group["betas"]
+    ws = _workspace("adam", lib.phc_adam_workspace(), flat_param.device, torch.float64)
+    L.check(lib.phc_adam_clip_step(flat_param.data_ptr(), flat_grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
+                                   flat_param.numel(), float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]),
+                                   int(st["step"].item()), float(max_norm) if max_norm else 0.0, ws.data_ptr(), None, _stream(flat_param.device)),
+            "phc_adam_clip_step")

@@ -14,16 +14,18 @@ import math
 import torch
 from torch import nn
 
+from .fast_ops import FastLinear
+
 DISC_LOGIT_INIT_SCALE = 1.0  # amp_network_builder.py:12
 
 _ACT = {"relu": nn.ReLU, "silu": nn.SiLU, "tanh": nn.Tanh, "elu": nn.ELU, "gelu": nn.GELU, "None": nn.Identity}
 
 
-def build_mlp(input_size, units, activation):
+def build_mlp(input_size, units, activation, linear=nn.Linear):
     """network_builder.py:126-137 `_build_sequential_mlp`: Linear, act, Linear, act ... (indices 0,2,4,..)."""
     layers, n = [], input_size
     for u in units:
-        layers += [nn.Linear(n, u), _ACT[activation]()]
+        layers += [linear(n, u), _ACT[activation]()]
         n = u
     return nn.Sequential(*layers)
 
@@ -36,10 +38,11 @@ class A2CNetwork(nn.Module):
         space = params["space"]["continuous"]
         assert space["fixed_sigma"] and not space["learn_sigma"]
         self.units, self.activation = list(mlp["units"]), mlp["activation"]
-        self.actor_mlp = build_mlp(input_shape[0], self.units, self.activation)
-        self.critic_mlp = build_mlp(input_shape[0], self.units, self.activation)
-        self.value = nn.Linear(self.units[-1], value_size)
-        self.mu = nn.Linear(self.units[-1], actions_num)
+        # actor / critic: nn.Linear with a device training pass of its own (fast_ops.FastLinear); the discriminator stays nn.Linear
+        self.actor_mlp = build_mlp(input_shape[0], self.units, self.activation, FastLinear)
+        self.critic_mlp = build_mlp(input_shape[0], self.units, self.activation, FastLinear)
+        self.value = FastLinear(self.units[-1], value_size)
+        self.mu = FastLinear(self.units[-1], actions_num)
         self.sigma = nn.Parameter(torch.full((actions_num,), float(space["sigma_init"]["val"]), dtype=torch.float32), requires_grad=False)
         self._disc_mlp = build_mlp(amp_input_shape[0], list(disc["units"]), disc["activation"])
         self._disc_logits = nn.Linear(list(disc["units"])[-1], 1)
@@ -82,8 +85,8 @@ class PNN(nn.Module):
         self.numCols = num_cols
         self.actors = nn.ModuleList()
         for _ in range(num_cols):
-            mlp = build_mlp(input_size, units, activation)
-            mlp.append(nn.Linear(units[-1], output_size))
+            mlp = build_mlp(input_size, units, activation, FastLinear)
+            mlp.append(FastLinear(units[-1], output_size))
             self.actors.append(mlp)
 
     def freeze_pnn(self, idx):

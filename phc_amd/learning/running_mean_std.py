@@ -73,6 +73,8 @@ class RunningMeanStd(nn.Module):
                                      ptr(out), int(out_dtype == torch.bfloat16), ptr(self.running_mean if update else None),
                                      ptr(self.running_var if update else None), ptr(self.count if update else None), ptr(ws),
                                      torch.cuda.current_stream(input.device).cuda_stream), "phc_running_norm")
+        if update:
+            self.count += rows   # after the kernel read the old count (same stream)
         return out
 
     def forward(self, input, unnorm=False, norm_from=None, out_dtype=None, want_output=True):

@@ -68,3 +68,75 @@ def test_running_norm_frozen_source_and_update_only():
     x[5, 7] = float("nan")
     dev.eval()
     assert torch.isnan(dev(x.cuda())[5, 7])
+
+
+@pytest.mark.parametrize("rows,cols", [(16384, 1024), (16384, 69), (4096, 1), (1000, 513)])
+def test_colsum_kernel(rows, cols):
+    from phc_amd.learning.fast_ops import colsum_bf16
+    x = (torch.randn(rows, cols, device="cuda") * 0.1).to(torch.bfloat16)
+    ref = x.double().sum(0)
+    got = colsum_bf16(x)
+    assert got.dtype == torch.float32
+    np.testing.assert_allclose(got.cpu().numpy(), ref.cpu().numpy(), rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("B,K,N", [(16384, 934, 1024), (16384, 512, 69), (1000, 130, 7)])
+def test_fast_linear_matches_autocast_linear(B, K, N):
+    """FastLinear's training pass == nn.Linear under bf16 autocast: same forward values; weight / bias / input gradients equal to the
+    fp32 gradients within bf16 GEMM accuracy, and at least as close to them as autograd's own bf16 path."""
+    from phc_amd.learning.fast_ops import FastLinear
+    torch.manual_seed(0)
+    ref = torch.nn.Linear(K, N).cuda()
+    fast = FastLinear(K, N).cuda()
+    fast.load_state_dict(ref.state_dict())
+    x = torch.randn(B, K, device="cuda")
+    gy = torch.randn(B, N, device="cuda") / B
+    outs = {}
+    for name, mod in (("ref", ref), ("fast", fast)):
+        xi = x.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = mod(xi)
+        assert y.dtype == torch.bfloat16
+        (y.float() * gy).sum().backward()
+        outs[name] = (y.float(), mod.weight.grad.clone(), mod.bias.grad.clone(), xi.grad.clone())
+    assert torch.equal(outs["ref"][0], outs["fast"][0])
+    x64 = x.double().requires_grad_(True)
+    y64 = x64 @ ref.weight.double().t() + ref.bias.double()
+    (y64 * gy.double()).sum().backward(inputs=[x64])
+    gw64, gb64 = gy.double().t() @ x.double(), gy.double().sum(0)
+    for k, exact in ((1, gw64), (2, gb64), (3, x64.grad)):
+        scale = exact.abs().max().item()
+        e_fast = (outs["fast"][k].double() - exact).abs().max().item() / scale
+        e_ref = (outs["ref"][k].double() - exact).abs().max().item() / scale
+        assert e_fast < 2e-2 and e_fast <= 1.5 * e_ref + 1e-4, (k, e_fast, e_ref)
+    # no_grad / frozen / fp32 paths are plain nn.Linear
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        assert torch.equal(fast(x), ref(x))
+    assert torch.equal(fast(x), ref(x))
+
+
+def test_adam_clip_step_equals_torch():
+    """phc_adam_clip_step == clip_grad_norm_ + torch.optim.Adam.step on the flat parameter (three steps, clipping active and
+    inactive, weight decay on), and the optimizer's state_dict stays loadable by a plain torch Adam."""
+    from phc_amd.learning.fast_ops import adam_clip_step
+    torch.manual_seed(1)
+    n = 1_000_003
+    p0 = torch.randn(n, device="cuda")
+    pa, pb = p0.clone().requires_grad_(True), p0.clone().requires_grad_(True)
+    oa = torch.optim.Adam([pa], 3e-3, eps=1e-8, weight_decay=1e-3)
+    ob = torch.optim.Adam([pb], 3e-3, eps=1e-8, weight_decay=1e-3)
+    pb.grad = torch.zeros_like(pb)
+    for it, gscale in enumerate((1.0, 1e-3, 0.05)):
+        g = torch.randn(n, device="cuda") * gscale
+        pa.grad = g.clone()
+        torch.nn.utils.clip_grad_norm_([pa], 50.0)
+        oa.step()
+        pb.grad.copy_(g)
+        adam_clip_step(ob, pb, pb.grad, 50.0)
+        torch.testing.assert_close(pb.grad, pa.grad, rtol=1e-5, atol=1e-9)
+        torch.testing.assert_close(pb.detach(), pa.detach(), rtol=1e-5, atol=2e-6)
+    sa, sb = oa.state[pa], ob.state[pb]
+    assert float(sb["step"]) == 3.0 == float(sa["step"])
+    torch.testing.assert_close(sb["exp_avg_sq"], sa["exp_avg_sq"], rtol=1e-5, atol=1e-12)
+    oc = torch.optim.Adam([p0.clone().requires_grad_(True)], 3e-3)
+    oc.load_state_dict(ob.state_dict())
