@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PHC_ABI_VERSION 9
+#define PHC_ABI_VERSION 10
 #define PHC_MAX_BODIES 64   /* bodies (incl. extended reference bodies) per articulation; also the slot count of the model tables */
 #define PHC_EINVAL (-1)
 #define PHC_EUNSUPPORTED (-2)
@@ -287,6 +287,23 @@ int64_t phc_adam_workspace(void);
 int32_t phc_adam_clip_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
                            float eps, float weight_decay, int64_t step, float max_norm, double* workspace, float* grad_norm_out,
                            void* stream);
+
+/* P8: actor + critic part of the PPO loss and its gradient (phc/learning/amp_agent.py:598-640 with rl_games' neglogp, bound_loss
+ * common_agent.py:512-520 and torch_ext.policy_kl), tensors on the device, value_size 1:
+ *   loss = mean(max(-adv r, -adv clamp(r, 1 -+ e_clip))) + critic_coef mean(c_loss) - entropy_coef entropy + bounds_loss_coef mean(b_loss),
+ *   r = exp(old_neglogp - neglogp(actions | mu, exp(logstd)))
+ * mu [B, D] and value [B] are the network heads (bf16 when is_bf16, else fp32); grad_mu / grad_value receive d loss / d mu, d loss / d value
+ * in the same type; stats[6] = loss, mean a_loss, mean c_loss, mean b_loss, entropy, mean kl(policy || old policy).
+ * old_values is only read when clip_value.  workspace: phc_ppo_loss_workspace() bytes. */
+typedef struct {
+    float e_clip, critic_coef, entropy_coef, bounds_loss_coef;
+    int32_t clip_value;
+} phc_ppo_params_t;
+int64_t phc_ppo_loss_workspace(void);
+int32_t phc_ppo_loss(const void* mu, const void* value, int32_t is_bf16, const float* logstd, const float* actions, const float* old_neglogp,
+                     const float* advantages, const float* returns, const float* old_values, const float* old_mu, const float* old_sigma,
+                     int64_t batch, int32_t num_actions, const phc_ppo_params_t* prm, void* grad_mu, void* grad_value, float* stats,
+                     double* workspace, void* stream);
 
 #ifdef __cplusplus
 }

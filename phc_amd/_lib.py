@@ -70,6 +70,10 @@ class ImBuffers(C.Structure):
                 ("reset_list", c_p), ("reset_count", c_p), ("reset_slot", c_i32), ("reset_sublist_cap", c_i32)]
 
 
+class PpoParams(C.Structure):
+    _fields_ = [("e_clip", c_f), ("critic_coef", c_f), ("entropy_coef", c_f), ("bounds_loss_coef", c_f), ("clip_value", c_i32)]
+
+
 P = C.POINTER
 _SIGNATURES = {
     "phc_abi_version": ([], c_i32),
@@ -91,6 +95,8 @@ _SIGNATURES = {
     "phc_colsum_bf16": ([c_p, c_i64, c_i32, c_p, c_p, c_p], c_i32),
     "phc_adam_workspace": ([], c_i64),
     "phc_adam_clip_step": ([c_p, c_p, c_p, c_p, c_i64, c_f, c_f, c_f, c_f, c_f, c_i64, c_f, c_p, c_p, c_p], c_i32),
+    "phc_ppo_loss_workspace": ([], c_i64),
+    "phc_ppo_loss": ([c_p, c_p, c_i32] + [c_p] * 8 + [c_i64, c_i32, P(PpoParams), c_p, c_p, c_p, c_p, c_p], c_i32),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
@@ -110,7 +116,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the .so does not export the symbol
         fn.argtypes = argtypes
         fn.restype = restype
-    if lib.phc_abi_version() != 9:
+    if lib.phc_abi_version() != 10:
         raise ImportError("libphc_amd.so ABI version mismatch")
     _lib = lib
     return lib

@@ -111,12 +111,20 @@ __global__ __launch_bounds__(256) void k_colsum_bf16(const __hip_bfloat16* __res
     __syncthreads();
     if (ry == 0 && c < cols) partial[(int64_t)blockIdx.y * cols + c] = (l[0][cx] + l[1][cx]) + (l[2][cx] + l[3][cx]);
 }
-__global__ void k_colsum_finish(const float* __restrict__ partial, int nchunks, int cols, float* __restrict__ out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= cols) return;
-    float a = 0.f;
-    for (int k = 0; k < nchunks; ++k) a += partial[(int64_t)k * cols + c];
-    out[c] = a;
+// block = 64 columns x 4 slices of the chunk list
+__global__ __launch_bounds__(256) void k_colsum_finish(const float* __restrict__ partial, int nchunks, int cols, float* __restrict__ out) {
+    __shared__ float l[4][64];
+    const int cx = threadIdx.x & 63, sy = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
+    float a = 0.f, b = 0.f;
+    if (c < cols) {
+        int k = sy;
+        for (; k + 4 < nchunks; k += 8) { a += partial[(int64_t)k * cols + c]; b += partial[(int64_t)(k + 4) * cols + c]; }
+        if (k < nchunks) a += partial[(int64_t)k * cols + c];
+    }
+    l[sy][cx] = a + b;
+    __syncthreads();
+    if (sy == 0 && c < cols) out[c] = (l[0][cx] + l[1][cx]) + (l[2][cx] + l[3][cx]);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -184,6 +192,116 @@ __global__ __launch_bounds__(AD_BLOCK) void k_adam(float* __restrict__ p, float*
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// P8: the actor / critic part of the PPO loss and its gradient in one pass (amp_agent.py:598-640 `calc_gradients`, rl_games
+// `neglogp`, common_agent.py:512-520 `bound_loss`, torch_ext.policy_kl):
+//   neglogp = 0.5 sum_d ((a - mu) / sigma)^2 + 0.5 log(2 pi) D + sum_d logstd,  ratio = exp(old_neglogp - neglogp)
+//   a_loss  = max(-adv ratio, -adv clamp(ratio, 1 - e, 1 + e));  c_loss = (ret - v)^2  (or the clipped variant);
+//   b_loss  = sum_d clamp_min(mu - 1, 0)^2 + clamp_max(mu + 1, 0)^2;  entropy = sum_d (0.5 + 0.5 log(2 pi) + logstd)
+//   loss    = mean(a_loss) + critic_coef mean(c_loss) - entropy_coef mean(entropy) + bounds_loss_coef mean(b_loss)
+// and d loss / d mu [B, D], d loss / d value [B] -- ~100 torch launches forward + backward otherwise.  One wavefront per row,
+// lanes over the action dimension; batch sums in fp64 through per-block partials (deterministic).
+// ------------------------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ float ld_f(const T* p, int64_t i);
+template <> __device__ __forceinline__ float ld_f<float>(const float* p, int64_t i) { return p[i]; }
+template <> __device__ __forceinline__ float ld_f<__hip_bfloat16>(const __hip_bfloat16* p, int64_t i) { return __bfloat162float(p[i]); }
+template <typename T> __device__ __forceinline__ void st_f(T* p, int64_t i, float v);
+template <> __device__ __forceinline__ void st_f<float>(float* p, int64_t i, float v) { p[i] = v; }
+template <> __device__ __forceinline__ void st_f<__hip_bfloat16>(__hip_bfloat16* p, int64_t i, float v) { p[i] = __float2bfloat16(v); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+#define PPO_NSUM 4   // a_loss, c_loss, b_loss, kl
+template <typename T>
+__global__ __launch_bounds__(256) void k_ppo_loss(const T* __restrict__ mu, const T* __restrict__ value, const float* __restrict__ logstd,
+                                                  const float* __restrict__ actions, const float* __restrict__ old_neglogp,
+                                                  const float* __restrict__ adv, const float* __restrict__ ret, const float* __restrict__ old_value,
+                                                  const float* __restrict__ old_mu, const float* __restrict__ old_sigma, int64_t B, int D,
+                                                  phc_ppo_params_t prm, T* __restrict__ grad_mu, T* __restrict__ grad_value, double* __restrict__ partial) {
+    __shared__ double lsum[4][PPO_NSUM];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const float invB = 1.0f / (float)B;
+    float sum_logstd = 0.f;
+    for (int d = lane; d < D; d += 64) sum_logstd += logstd[d];
+    sum_logstd = wave_sum(sum_logstd);
+    const float nlp_const = 0.5f * 1.8378770664093453f * (float)D + sum_logstd;   // log(2 pi)
+    double acc[PPO_NSUM] = {0.0, 0.0, 0.0, 0.0};
+    for (int64_t r = (int64_t)blockIdx.x * 4 + w; r < B; r += (int64_t)gridDim.x * 4) {
+        float s_nlp = 0.f, s_b = 0.f, s_kl = 0.f;
+        for (int d = lane; d < D; d += 64) {
+            const float m = ld_f(mu, r * D + d), a = actions[r * D + d], sg = expf(logstd[d]);
+            const float z = (a - m) / sg;
+            s_nlp += z * z;
+            const float hi = fmaxf(m - 1.0f, 0.f), lo = fminf(m + 1.0f, 0.f);
+            s_b += lo * lo + hi * hi;
+            const float m1 = old_mu[r * D + d], s1 = old_sigma[r * D + d];
+            s_kl += logf(s1 / sg + 1e-5f) + (sg * sg + (m1 - m) * (m1 - m)) / (2.0f * (s1 * s1 + 1e-5f)) - 0.5f;
+        }
+        s_nlp = wave_sum(s_nlp); s_b = wave_sum(s_b); s_kl = wave_sum(s_kl);
+        const float neglogp = 0.5f * s_nlp + nlp_const;
+        const float ratio = expf(old_neglogp[r] - neglogp);
+        const float A = adv[r];
+        const float lo_r = 1.0f - prm.e_clip, hi_r = 1.0f + prm.e_clip;
+        const float t1 = -A * ratio, t2 = -A * fminf(fmaxf(ratio, lo_r), hi_r);
+        const float a_loss = fmaxf(t1, t2);
+        // torch.max backward: the larger operand takes the gradient (ties: half each); clamp passes it inside [lo, hi]
+        const float w1 = t1 > t2 ? 1.0f : (t1 == t2 ? 0.5f : 0.f);
+        const float inside = (ratio >= lo_r && ratio <= hi_r) ? 1.0f : 0.f;
+        const float c_mu = -A * (w1 + (1.0f - w1) * inside) * ratio * invB;
+        const float v = ld_f(value, r), R = ret[r];
+        float c_loss, dC;
+        if (prm.clip_value) {
+            const float vp = old_value[r];
+            const float dv = v - vp, vpc = vp + fminf(fmaxf(dv, -prm.e_clip), prm.e_clip);
+            const float l1 = (v - R) * (v - R), l2 = (vpc - R) * (vpc - R);
+            c_loss = fmaxf(l1, l2);
+            const float u1 = l1 > l2 ? 1.0f : (l1 == l2 ? 0.5f : 0.f);
+            const float in2 = (dv >= -prm.e_clip && dv <= prm.e_clip) ? 1.0f : 0.f;
+            dC = u1 * 2.0f * (v - R) + (1.0f - u1) * 2.0f * (vpc - R) * in2;
+        } else {
+            c_loss = (R - v) * (R - v);
+            dC = 2.0f * (v - R);
+        }
+        if (lane == 0) {
+            st_f(grad_value, r, prm.critic_coef * dC * invB);
+            acc[0] += (double)a_loss; acc[1] += (double)c_loss; acc[2] += (double)s_b; acc[3] += (double)s_kl;
+        }
+        const float cb = prm.bounds_loss_coef * invB;
+        for (int d = lane; d < D; d += 64) {
+            const float m = ld_f(mu, r * D + d), a = actions[r * D + d], sg = expf(logstd[d]);
+            const float g = c_mu * (a - m) / (sg * sg) + cb * (2.0f * fmaxf(m - 1.0f, 0.f) + 2.0f * fminf(m + 1.0f, 0.f));
+            st_f(grad_mu, r * D + d, g);
+        }
+    }
+    if (lane == 0)
+        for (int k = 0; k < PPO_NSUM; ++k) lsum[w][k] = acc[k];
+    __syncthreads();
+    if (threadIdx.x < PPO_NSUM)
+        partial[(int64_t)blockIdx.x * PPO_NSUM + threadIdx.x] = (lsum[0][threadIdx.x] + lsum[1][threadIdx.x]) + (lsum[2][threadIdx.x] + lsum[3][threadIdx.x]);
+}
+
+// stats[0..5] = loss, mean a_loss, mean c_loss, mean b_loss, entropy, mean kl
+__global__ void k_ppo_loss_finish(const double* __restrict__ partial, int nblocks, int64_t B, int D, const float* __restrict__ logstd,
+                                  phc_ppo_params_t prm, float* __restrict__ stats) {
+    __shared__ double l[PPO_NSUM][64];
+    const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;   // 256 threads: one wavefront per sum
+    double t = 0.0;
+    for (int b = lane; b < nblocks; b += 64) t += partial[(int64_t)b * PPO_NSUM + k];
+    l[k][lane] = t;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    double s[PPO_NSUM];
+    for (int q = 0; q < PPO_NSUM; ++q) { s[q] = 0.0; for (int i = 0; i < 64; ++i) s[q] += l[q][i]; s[q] /= (double)B; }
+    float ent = 0.f;
+    for (int d = 0; d < D; ++d) ent += 0.5f + 0.5f * 1.8378770664093453f + logstd[d];
+    stats[1] = (float)s[0]; stats[2] = (float)s[1]; stats[3] = (float)s[2]; stats[4] = ent; stats[5] = (float)s[3];
+    stats[0] = (float)s[0] + prm.critic_coef * (float)s[1] - prm.entropy_coef * ent + prm.bounds_loss_coef * (float)s[2];
+}
+
 extern "C" {
 
 int64_t phc_running_norm_workspace(int64_t rows, int32_t cols) {
@@ -220,7 +338,7 @@ int32_t phc_colsum_bf16(const void* x, int64_t rows, int32_t cols, float* out, f
     if (nchunks > 65535) return PHC_EUNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_colsum_bf16, dim3((cols + 63) / 64, (unsigned)nchunks), dim3(256), 0, st, reinterpret_cast<const __hip_bfloat16*>(x), rows, cols, workspace);
-    hipLaunchKernelGGL(k_colsum_finish, dim3((cols + 255) / 256), dim3(256), 0, st, workspace, (int)nchunks, cols, out);
+    hipLaunchKernelGGL(k_colsum_finish, dim3((cols + 63) / 64), dim3(256), 0, st, workspace, (int)nchunks, cols, out);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int32_t)e;
 }
@@ -237,6 +355,31 @@ int32_t phc_adam_clip_step(float* param, float* grad, float* exp_avg, float* exp
     const int64_t blocks = (n + AD_BLOCK * 4 - 1) / (AD_BLOCK * 4);
     hipLaunchKernelGGL(k_adam, dim3((unsigned)blocks), dim3(AD_BLOCK), 0, st, param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay,
                        (float)b1, (float)sqrt(b2), max_norm, workspace, AD_NORM_BLOCKS, grad_norm_out);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int32_t)e;
+}
+
+#define PPO_BLOCKS 1024
+int64_t phc_ppo_loss_workspace(void) { return PPO_BLOCKS * PPO_NSUM * (int64_t)sizeof(double); }
+
+int32_t phc_ppo_loss(const void* mu, const void* value, int32_t is_bf16, const float* logstd, const float* actions, const float* old_neglogp,
+                     const float* advantages, const float* returns, const float* old_values, const float* old_mu, const float* old_sigma,
+                     int64_t batch, int32_t num_actions, const phc_ppo_params_t* prm, void* grad_mu, void* grad_value, float* stats,
+                     double* workspace, void* stream) {
+    if (!mu || !value || !logstd || !actions || !old_neglogp || !advantages || !returns || !old_mu || !old_sigma || !prm || !grad_mu || !grad_value ||
+        !stats || !workspace || batch < 1 || num_actions < 1)
+        return PHC_EINVAL;
+    if (prm->clip_value && !old_values) return PHC_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int nblocks = (int)((batch + 3) / 4 < PPO_BLOCKS ? (batch + 3) / 4 : PPO_BLOCKS);
+    if (is_bf16)
+        hipLaunchKernelGGL(k_ppo_loss<__hip_bfloat16>, dim3(nblocks), dim3(256), 0, st, (const __hip_bfloat16*)mu, (const __hip_bfloat16*)value, logstd, actions,
+                           old_neglogp, advantages, returns, old_values, old_mu, old_sigma, batch, num_actions, *prm, (__hip_bfloat16*)grad_mu,
+                           (__hip_bfloat16*)grad_value, workspace);
+    else
+        hipLaunchKernelGGL(k_ppo_loss<float>, dim3(nblocks), dim3(256), 0, st, (const float*)mu, (const float*)value, logstd, actions, old_neglogp,
+                           advantages, returns, old_values, old_mu, old_sigma, batch, num_actions, *prm, (float*)grad_mu, (float*)grad_value, workspace);
+    hipLaunchKernelGGL(k_ppo_loss_finish, dim3(1), dim3(256), 0, st, workspace, nblocks, batch, num_actions, logstd, *prm, stats);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int32_t)e;
 }

@@ -32,7 +32,7 @@ from torch import nn
 from .. import _lib as L
 from .network import A2CMCPNetwork, A2CNetwork, A2CPNNNetwork, ModelAMPContinuous, policy_kl
 from .replay_buffer import ReplayBuffer
-from .fast_ops import adam_clip_step
+from .fast_ops import adam_clip_step, ppo_loss
 from .running_mean_std import RunningMeanStd
 
 
@@ -360,9 +360,29 @@ class IMAmpAgent:
         amp_obs_replay = self._preproc_amp_obs(d["amp_obs_replay"])
         amp_obs_demo = self._preproc_amp_obs(d["amp_obs_demo"])
         amp_obs_demo.requires_grad_(True)
+        fused = obs.is_cuda
         with self._autocast():
-            res = self.model({"is_train": True, "prev_actions": d["actions"], "obs": obs, "amp_obs": amp_obs,
-                              "amp_obs_replay": amp_obs_replay, "amp_obs_demo": amp_obs_demo})
+            inp = {"is_train": True, "prev_actions": d["actions"], "obs": obs, "amp_obs": amp_obs, "amp_obs_replay": amp_obs_replay,
+                   "amp_obs_demo": amp_obs_demo}
+            res = self.model.forward_heads(inp) if fused else self.model(inp)
+        disc_info = self._disc_loss(torch.cat([res["disc_agent_logit"], res["disc_agent_replay_logit"]], dim=0), res["disc_demo_logit"], amp_obs_demo)
+        if fused:
+            # actor / critic losses and their gradients w.r.t. the two heads: one HIP pass (phc_ppo_loss) instead of ~100 launches
+            ppo, st = ppo_loss(res["mu"].contiguous(), res["value"].contiguous(), res["logstd"], d["actions"], d["old_logp_actions"], d["advantages"],
+                               d["returns"], d["old_values"], d["mu"], d["sigma"], self.e_clip, self.critic_coef, self.entropy_coef,
+                               self.bounds_loss_coef, self.clip_value, unit_grad=True)
+            loss = ppo + self._disc_coef * disc_info["disc_loss"]   # `ppo` enters with weight one (unit_grad)
+            info = {"actor_loss": st[0], "critic_loss": st[1], "b_loss": st[2], "entropy": st[3], "kl": st[4]}
+        else:
+            loss, info = self._ppo_loss_torch(res, d, disc_info)
+        self.grads.zero()
+        loss.backward()
+        info.update({k: (v.detach() if torch.is_tensor(v) else v) for k, v in disc_info.items()})
+        return info
+
+    def _ppo_loss_torch(self, res, d, disc_info):
+        """The actor / critic losses as torch expressions (amp_agent.py:598-640): the CPU path and the definition `phc_ppo_loss` is
+        tested against."""
         ratio = torch.exp(d["old_logp_actions"] - res["prev_neglogp"])
         adv = d["advantages"]
         a_loss = torch.max(-adv * ratio, -adv * torch.clamp(ratio, 1.0 - self.e_clip, 1.0 + self.e_clip))
@@ -374,16 +394,11 @@ class IMAmpAgent:
             c_loss = (ret - values) ** 2
         b_loss = self.bound_loss(res["mus"])
         a_loss, c_loss, b_loss, entropy = a_loss.mean(), c_loss.mean(), b_loss.mean(), res["entropy"].mean()
-        disc_info = self._disc_loss(torch.cat([res["disc_agent_logit"], res["disc_agent_replay_logit"]], dim=0), res["disc_demo_logit"], amp_obs_demo)
         bl = self.bounds_loss_coef if self.bounds_loss_coef is not None else 0.0
         loss = a_loss + self.critic_coef * c_loss - self.entropy_coef * entropy + bl * b_loss + self._disc_coef * disc_info["disc_loss"]
-        self.grads.zero()
-        loss.backward()
         with torch.no_grad():
             kl = policy_kl(res["mus"].detach(), res["sigmas"].detach(), d["mu"], d["sigma"])
-        info = {"actor_loss": a_loss.detach(), "critic_loss": c_loss.detach(), "b_loss": b_loss.detach(), "entropy": entropy.detach(), "kl": kl}
-        info.update({k: (v.detach() if torch.is_tensor(v) else v) for k, v in disc_info.items()})
-        return info
+        return loss, {"actor_loss": a_loss.detach(), "critic_loss": c_loss.detach(), "b_loss": b_loss.detach(), "entropy": entropy.detach(), "kl": kl}
 
     def _clip_and_step(self):
         if self.grads.flat.is_cuda:

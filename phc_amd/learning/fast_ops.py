@@ -10,6 +10,8 @@ one autograd node built for this shape of problem -- batch of 16 384 rows, 10^2.
 It is used for the actor and critic (amp_agent.py:554-655); the discriminator keeps nn.Linear because its gradient penalty
 differentiates the backward pass itself (create_graph=True).  Anywhere else (CPU, fp32, no_grad rollouts, frozen columns) it is
 exactly nn.Linear.  `adam_clip_step` = clip_grad_norm_ + torch.optim.Adam.step on the flat parameter in two launches."""
+import ctypes as C
+
 import torch
 from torch import nn
 from torch.autograd.function import once_differentiable
@@ -49,7 +51,7 @@ def wgrad_split_k(gy, x):
     """gy^T x for gy [B, N], x [B, K] bf16 -> fp32 [N, K]; the batch is cut into SPLIT_K chunks that run as one batched GEMM."""
     B, N = gy.shape
     K = x.shape[1]
-    if B % SPLIT_K == 0 and B >= 2048:
+    if B % SPLIT_K == 0 and B >= 2048 and N >= 16:   # (a 1-row batched GEMM -- the value head -- stalls the host for 11 ms in hipBLASLt)
         part = torch.bmm(gy.view(SPLIT_K, B // SPLIT_K, N).transpose(1, 2), x.view(SPLIT_K, B // SPLIT_K, K))
         return part.sum(0, dtype=torch.float32)
     return (gy.t() @ x).float()
@@ -84,6 +86,50 @@ class FastLinear(nn.Linear):
                 and torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16 and x.is_contiguous()):
             return _LinearFn.apply(x, self.weight, self.bias)
         return nn.functional.linear(x, self.weight, self.bias)
+
+
+class _PPOLossFn(torch.autograd.Function):
+    """Actor + critic part of the PPO loss (`phc_ppo_loss`): forward computes the loss, its statistics AND the gradients w.r.t. the
+    two network heads; backward hands those out.  The loss must enter the total with weight one (`unit_grad`): the incoming
+    gradient is then 1 and the stored gradients are returned as they are (no extra pass over [B, D])."""
+
+    @staticmethod
+    def forward(ctx, mu, value, logstd, actions, old_neglogp, adv, returns, old_values, old_mu, old_sigma, prm, unit_grad):
+        lib = L.load()
+        B, D = mu.shape
+        assert value.numel() == B and mu.dtype == value.dtype and mu.dtype in (torch.bfloat16, torch.float32)
+        assert mu.is_contiguous() and value.is_contiguous()
+        f32 = lambda t: t if (t.dtype == torch.float32 and t.is_contiguous()) else t.float().contiguous()
+        logstd, actions, old_neglogp, adv, returns, old_mu, old_sigma = map(f32, (logstd, actions, old_neglogp, adv, returns, old_mu, old_sigma))
+        old_values = f32(old_values) if old_values is not None else None
+        gmu, gval = torch.empty_like(mu), torch.empty_like(value)
+        buf = torch.empty(6, dtype=torch.float32, device=mu.device)
+        ws = _workspace("ppo", lib.phc_ppo_loss_workspace(), mu.device, torch.float64)
+        p = L.PpoParams(float(prm["e_clip"]), float(prm["critic_coef"]), float(prm["entropy_coef"]), float(prm["bounds_loss_coef"]), int(prm["clip_value"]))
+        L.check(lib.phc_ppo_loss(mu.data_ptr(), value.data_ptr(), int(mu.dtype == torch.bfloat16), logstd.data_ptr(), actions.data_ptr(),
+                                 old_neglogp.data_ptr(), adv.data_ptr(), returns.data_ptr(), None if old_values is None else old_values.data_ptr(),
+                                 old_mu.data_ptr(), old_sigma.data_ptr(), B, D, C.byref(p), gmu.data_ptr(), gval.data_ptr(), buf.data_ptr(),
+                                 ws.data_ptr(), _stream(mu.device)), "phc_ppo_loss")
+        ctx.save_for_backward(gmu, gval)
+        ctx.unit_grad = unit_grad
+        loss, stats = buf.narrow(0, 0, 1).view(()), buf.narrow(0, 1, 5)   # disjoint views of the kernel's output
+        ctx.mark_non_differentiable(stats)
+        return loss, stats
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_loss, _g_stats):
+        gmu, gval = ctx.saved_tensors
+        if not ctx.unit_grad:
+            gmu, gval = gmu * g_loss.to(gmu.dtype), gval * g_loss.to(gval.dtype)
+        return (gmu, gval) + (None,) * 10
+
+
+def ppo_loss(mu, value, logstd, actions, old_neglogp, adv, returns, old_values, old_mu, old_sigma, e_clip, critic_coef, entropy_coef,
+             bounds_loss_coef, clip_value, unit_grad=False):
+    """-> (loss, stats[5] = a_loss, c_loss, b_loss, entropy, kl); mu [B, D] / value [B, 1] are the (bf16 or fp32) network heads."""
+    prm = dict(e_clip=e_clip, critic_coef=critic_coef, entropy_coef=entropy_coef, bounds_loss_coef=bounds_loss_coef or 0.0, clip_value=bool(clip_value))
+    return _PPOLossFn.apply(mu, value, logstd, actions, old_neglogp, adv, returns, old_values if clip_value else None, old_mu, old_sigma, prm, unit_grad)
 
 
 def adam_clip_step(optimizer, flat_param, flat_grad, max_norm):

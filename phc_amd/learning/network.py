@@ -197,6 +197,18 @@ class ModelAMPContinuous(nn.Module):
         action = mu + sigma * torch.randn_like(mu)
         return {"neglogpacs": self.neglogp(action, mu, sigma, logstd), "values": value, "actions": action, "mus": mu, "sigmas": sigma}
 
+    def forward_heads(self, input_dict):
+        """Training pass that stops at the network heads -- `mu` [B, D] and `value` [B, 1] as the GEMMs produce them (bf16 under
+        autocast), `logstd` [D] and the three discriminator logit blocks -- for the fused loss (fast_ops.ppo_loss)."""
+        obs = input_dict["obs"]
+        mu, logstd = self.a2c_network.eval_actor(obs)
+        value = self.a2c_network.eval_critic(obs)
+        a, r, d = input_dict["amp_obs"], input_dict["amp_obs_replay"], input_dict["amp_obs_demo"]
+        logits = self.a2c_network.eval_disc(torch.cat([a, r, d], dim=0)).float()
+        la, lr_, ld = torch.split(logits, [a.shape[0], r.shape[0], d.shape[0]], dim=0)
+        return {"mu": mu, "value": value, "logstd": logstd[0] if logstd.dim() == 2 else logstd, "disc_agent_logit": la,
+                "disc_agent_replay_logit": lr_, "disc_demo_logit": ld}
+
 
 def policy_kl(p0_mu, p0_sigma, p1_mu, p1_sigma):
     """rl_games torch_ext.policy_kl (mean over the batch)."""

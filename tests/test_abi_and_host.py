@@ -31,14 +31,14 @@ def test_library_exports_every_declared_symbol():
     assert sorted(_lib.EXPORTED_SYMBOLS) == declared, "ctypes table and header disagree"
     for name in declared:
         assert hasattr(lib, name), f"libphc_amd.so does not export {name}"
-    assert lib.phc_abi_version() == 9
+    assert lib.phc_abi_version() == 10
 
 
 def test_struct_sizes_match_the_header():
     """Compile a tiny C program against include/phc_amd.h and compare sizeof() with the ctypes mirrors."""
     from phc_amd import _lib
     names = {"phc_model_t": _lib.Model, "phc_motion_lib_t": _lib.MotionLib, "phc_sim_state_t": _lib.SimState,
-             "phc_sim_params_t": _lib.SimParams, "phc_im_params_t": _lib.ImParams, "phc_im_buffers_t": _lib.ImBuffers}
+             "phc_sim_params_t": _lib.SimParams, "phc_im_params_t": _lib.ImParams, "phc_im_buffers_t": _lib.ImBuffers, "phc_ppo_params_t": _lib.PpoParams}
     src = '#include <stdio.h>\n#include "phc_amd.h"\nint main(){' + "".join(f'printf("{n} %zu\\n", sizeof({n}));' for n in names) + "return 0;}"
     with tempfile.TemporaryDirectory() as d:
         c = os.path.join(d, "s.c")

@@ -30,7 +30,7 @@ def test_running_norm_kernel_equals_torch_path(rows, cols):
     for it in range(3):
         x = torch.randn(rows, cols, generator=g) * (1 + it) + 0.3 * it
         x[0, 0] = 40.0   # clamped
-        m32, v32 = cpu.running_mean.numpy().astype(np.float32), cpu.running_var.numpy().astype(np.float32)
+        m32, v32 = dev.running_mean.cpu().numpy().astype(np.float32), dev.running_var.cpu().numpy().astype(np.float32)   # the kernel's own statistics
         exact = np.clip((x.numpy() - m32) / np.sqrt(v32 + np.float32(1e-5)), -5.0, 5.0)
         y_ref = cpu(x)
         y = dev(x.cuda())
@@ -140,3 +140,57 @@ def test_adam_clip_step_equals_torch():
     torch.testing.assert_close(sb["exp_avg_sq"], sa["exp_avg_sq"], rtol=1e-5, atol=1e-12)
     oc = torch.optim.Adam([p0.clone().requires_grad_(True)], 3e-3)
     oc.load_state_dict(ob.state_dict())
+
+
+@pytest.mark.parametrize("dtype,clip_value,D", [(torch.bfloat16, False, 69), (torch.float32, True, 37), (torch.float32, False, 153)])
+def test_fused_ppo_loss_equals_torch_losses(dtype, clip_value, D):
+    """phc_ppo_loss == the torch expressions of IMAmpAgent._ppo_loss_torch (amp_agent.py:598-640): loss, the five statistics and the
+    gradients w.r.t. the mu and value heads (autograd of the torch path), incl. rows outside the clip range and actions beyond +-1."""
+    from phc_amd.learning.fast_ops import ppo_loss
+    from phc_amd.learning.network import ModelAMPContinuous, policy_kl
+    torch.manual_seed(4)
+    B, dev = 5000, "cuda"
+    e_clip, cc, ec, bl = 0.2, 5.0, 0.01, 10.0
+    logstd = torch.full((D,), -2.9, device=dev) + torch.randn(D, device=dev) * 0.1
+    mu0 = (torch.randn(B, D, device=dev) * 0.7).to(dtype)
+    val0 = torch.randn(B, 1, device=dev).to(dtype)
+    old_mu = mu0.float() + torch.randn(B, D, device=dev) * 0.02
+    old_sigma = torch.exp(logstd).expand(B, D).contiguous()
+    actions = old_mu + old_sigma * torch.randn(B, D, device=dev)
+    old_nlp = ModelAMPContinuous.neglogp(actions, old_mu, old_sigma, logstd.expand(B, D))
+    adv = torch.randn(B, device=dev)
+    ret = torch.randn(B, 1, device=dev)
+    old_val = val0.float() + torch.randn(B, 1, device=dev) * 0.3
+
+    mu_t, val_t = mu0.clone().requires_grad_(True), val0.clone().requires_grad_(True)
+    mu, value = mu_t.float(), val_t.float()
+    sigma = torch.exp(logstd).expand(B, D)
+    nlp = ModelAMPContinuous.neglogp(actions, mu, sigma, logstd.expand(B, D))
+    ratio = torch.exp(old_nlp - nlp)
+    a_loss = torch.max(-adv * ratio, -adv * torch.clamp(ratio, 1 - e_clip, 1 + e_clip)).mean()
+    if clip_value:
+        vpc = old_val + (value - old_val).clamp(-e_clip, e_clip)
+        c_loss = torch.max((value - ret) ** 2, (vpc - ret) ** 2).mean()
+    else:
+        c_loss = ((ret - value) ** 2).mean()
+    b_loss = ((torch.clamp_min(mu - 1, 0) ** 2) + (torch.clamp_max(mu + 1, 0) ** 2)).sum(-1).mean()
+    ent = (0.5 + 0.5 * np.log(2 * np.pi) + logstd).sum()
+    ref = a_loss + cc * c_loss - ec * ent + bl * b_loss
+    ref.backward()
+    kl = policy_kl(mu.detach(), sigma, old_mu, old_sigma)
+    assert ((ratio < 1 - e_clip) | (ratio > 1 + e_clip)).float().mean() > 0.05 and (mu0.float().abs() > 1).any()
+
+    mu_f, val_f = mu0.clone().requires_grad_(True), val0.clone().requires_grad_(True)
+    loss, st = ppo_loss(mu_f, val_f, logstd, actions, old_nlp, adv, ret, old_val, old_mu, old_sigma, e_clip, cc, ec, bl, clip_value, unit_grad=True)
+    (loss * 1.0).backward()
+    tol = dict(rtol=2e-4, atol=2e-5)
+    torch.testing.assert_close(loss, ref.detach(), **tol)
+    torch.testing.assert_close(st, torch.stack([a_loss, c_loss, b_loss, ent, kl]).detach(), **tol)
+    gtol = dict(rtol=2e-2, atol=2e-6) if dtype == torch.bfloat16 else dict(rtol=2e-4, atol=1e-8)
+    torch.testing.assert_close(mu_f.grad.float(), mu_t.grad.float(), **gtol)
+    torch.testing.assert_close(val_f.grad.float(), val_t.grad.float(), **gtol)
+    # general incoming gradient
+    mu_g, val_g = mu0.clone().requires_grad_(True), val0.clone().requires_grad_(True)
+    loss2, _ = ppo_loss(mu_g, val_g, logstd, actions, old_nlp, adv, ret, old_val, old_mu, old_sigma, e_clip, cc, ec, bl, clip_value)
+    (3.0 * loss2).backward()
+    torch.testing.assert_close(mu_g.grad.float(), 3.0 * mu_t.grad.float(), rtol=3e-2 if dtype == torch.bfloat16 else 2e-4, atol=1e-5)
