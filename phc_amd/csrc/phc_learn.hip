@@ -160,7 +160,7 @@ __global__ __launch_bounds__(AD_BLOCK) void k_sumsq(const float* __restrict__ g,
 __global__ __launch_bounds__(AD_BLOCK) void k_adam(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                                    int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay, float bias1,
                                                    float bias2_sqrt, float max_norm, const double* __restrict__ partial, int npartial,
-                                                   float* __restrict__ norm_out) {
+                                                   float* __restrict__ norm_out, __hip_bfloat16* __restrict__ shadow) {
     float coef = 1.f;
     if (max_norm > 0.f) {   // every block re-reduces the npartial (512) L2-resident partial sums: cheaper than a third launch
         __shared__ double l[AD_BLOCK / 64];
@@ -188,7 +188,9 @@ __global__ __launch_bounds__(AD_BLOCK) void k_adam(float* __restrict__ p, float*
         const float mi = beta1 * m[i] + (1.f - beta1) * gi;      // exp_avg.lerp_(grad, 1 - beta1)
         const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
         m[i] = mi; v[i] = vi;
-        p[i] = pi - step_size * (mi / (sqrtf(vi) / bias2_sqrt + eps));
+        const float pn = pi - step_size * (mi / (sqrtf(vi) / bias2_sqrt + eps));
+        p[i] = pn;
+        if (shadow) shadow[i] = __float2bfloat16(pn);   // the copy the bf16 GEMMs of the next step read
     }
 }
 
@@ -347,14 +349,14 @@ int32_t phc_colsum_bf16(const void* x, int64_t rows, int32_t cols, float* out, f
 int64_t phc_adam_workspace(void) { return AD_NORM_BLOCKS * (int64_t)sizeof(double); }
 
 int32_t phc_adam_clip_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2, float eps,
-                           float weight_decay, int64_t step, float max_norm, double* workspace, float* grad_norm_out, void* stream) {
+                           float weight_decay, int64_t step, float max_norm, double* workspace, float* grad_norm_out, void* param_bf16, void* stream) {
     if (!param || !grad || !exp_avg || !exp_avg_sq || n < 1 || step < 1 || (max_norm > 0.f && !workspace)) return PHC_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     if (max_norm > 0.f) hipLaunchKernelGGL(k_sumsq, dim3(AD_NORM_BLOCKS), dim3(AD_BLOCK), 0, st, grad, n, workspace);
     const double b1 = 1.0 - pow((double)beta1, (double)step), b2 = 1.0 - pow((double)beta2, (double)step);
     const int64_t blocks = (n + AD_BLOCK * 4 - 1) / (AD_BLOCK * 4);
     hipLaunchKernelGGL(k_adam, dim3((unsigned)blocks), dim3(AD_BLOCK), 0, st, param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay,
-                       (float)b1, (float)sqrt(b2), max_norm, workspace, AD_NORM_BLOCKS, grad_norm_out);
+                       (float)b1, (float)sqrt(b2), max_norm, workspace, AD_NORM_BLOCKS, grad_norm_out, (__hip_bfloat16*)param_bf16);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int32_t)e;
 }

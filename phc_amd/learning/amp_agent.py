@@ -89,6 +89,30 @@ class FlatGradBucket:
             p.grad = self.flat[o:o + k].view_as(p)
             o += k
         self.flat_param.grad = self.flat
+        # bf16 copy of the flat parameter for the GEMMs of the update phase: refreshed on entering shadow_scope(), then kept current
+        # by the optimizer kernel; `_shadow_live` is the flag the layers look at (fast_ops.FastLinear)
+        self.shadow, self._shadow_live = None, [False]
+        if dev.type == "cuda":
+            self.shadow = torch.zeros(n, device=dev, dtype=torch.bfloat16)
+            o = 0
+            for p in self.params:
+                k = p.numel()
+                p._bf16_shadow, p._shadow_live = self.shadow[o:o + k].view_as(p), self._shadow_live
+                o += k
+
+    def shadow_scope(self):
+        """Context of the minibatch loop: inside it only the optimizer kernel changes the parameters, so their bf16 copies stay valid."""
+        bucket = self
+
+        class _Scope:
+            def __enter__(self_):
+                if bucket.shadow is not None:
+                    bucket.shadow.copy_(bucket.flat_param)
+                    bucket._shadow_live[0] = True
+
+            def __exit__(self_, *a):
+                bucket._shadow_live[0] = False
+        return _Scope()
 
     def zero(self):
         self.flat.zero_()
@@ -402,7 +426,8 @@ class IMAmpAgent:
 
     def _clip_and_step(self):
         if self.grads.flat.is_cuda:
-            adam_clip_step(self.optimizer, self.grads.flat_param, self.grads.flat, self.grad_norm if self.truncate_grads else None)
+            adam_clip_step(self.optimizer, self.grads.flat_param, self.grads.flat, self.grad_norm if self.truncate_grads else None,
+                           shadow=self.grads.shadow)
             return
         if self.truncate_grads:
             self.grads.clip_grad_norm_(self.grad_norm)
@@ -490,9 +515,10 @@ class IMAmpAgent:
         self.set_train()
         self.prepare_dataset(batch)
         infos = []
-        for _ in range(self.mini_epochs_num):
-            for i in range(self.num_minibatches):
-                infos.append(self.calc_gradients(self._get_item(i)))
+        with self.grads.shadow_scope():
+            for _ in range(self.mini_epochs_num):
+                for i in range(self.num_minibatches):
+                    infos.append(self.calc_gradients(self._get_item(i)))
         self._store_replay_amp_obs(batch["amp_obs"])
         self.post_epoch(self.epoch_num)
         sync()

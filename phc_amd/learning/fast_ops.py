@@ -62,8 +62,13 @@ class _LinearFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias):
         with torch.autocast("cuda", enabled=False):
             xb = x.to(torch.bfloat16)
-            wb = weight.to(torch.bfloat16)
-            y = torch.addmm(bias.to(torch.bfloat16), xb, wb.t())
+            # inside FlatGradBucket.shadow_scope() the optimizer kernel keeps a bf16 copy of every parameter up to date
+            live = getattr(weight, "_shadow_live", None)
+            if live is not None and live[0]:
+                wb, bb = weight._bf16_shadow, bias._bf16_shadow
+            else:
+                wb, bb = weight.to(torch.bfloat16), bias.to(torch.bfloat16)
+            y = torch.addmm(bb, xb, wb.t())
         ctx.save_for_backward(xb, wb)
         ctx.x_dtype = x.dtype
         return y
@@ -132,9 +137,10 @@ def ppo_loss(mu, value, logstd, actions, old_neglogp, adv, returns, old_values, 
     return _PPOLossFn.apply(mu, value, logstd, actions, old_neglogp, adv, returns, old_values if clip_value else None, old_mu, old_sigma, prm, unit_grad)
 
 
-def adam_clip_step(optimizer, flat_param, flat_grad, max_norm):
+def adam_clip_step(optimizer, flat_param, flat_grad, max_norm, shadow=None):
     """`clip_grad_norm_(max_norm)` (None / <= 0: no clipping) + `optimizer.step()` for a torch.optim.Adam that holds the single flat
-    parameter, on the device: its state (`step`, `exp_avg`, `exp_avg_sq`) stays the optimizer's, so checkpoints are unchanged."""
+    parameter, on the device: its state (`step`, `exp_avg`, `exp_avg_sq`) stays the optimizer's, so checkpoints are unchanged.
+    `shadow`: bf16 tensor of the same length that receives the updated parameter (FlatGradBucket.shadow_scope)."""
     lib = L.load()
     group = optimizer.param_groups[0]
     assert len(optimizer.param_groups) == 1 and len(group["params"]) == 1 and group["params"][0] is flat_param
@@ -151,5 +157,6 @@ def adam_clip_step(optimizer, flat_param, flat_grad, max_norm):
     ws = _workspace("adam", lib.phc_adam_workspace(), flat_param.device, torch.float64)
     L.check(lib.phc_adam_clip_step(flat_param.data_ptr(), flat_grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
                                    flat_param.numel(), float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]),
-                                   int(st["step"].item()), float(max_norm) if max_norm else 0.0, ws.data_ptr(), None, _stream(flat_param.device)),
+                                   int(st["step"].item()), float(max_norm) if max_norm else 0.0, ws.data_ptr(), None,
+                                   None if shadow is None else shadow.data_ptr(), _stream(flat_param.device)),
             "phc_adam_clip_step")

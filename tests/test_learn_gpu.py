@@ -126,13 +126,15 @@ def test_adam_clip_step_equals_torch():
     oa = torch.optim.Adam([pa], 3e-3, eps=1e-8, weight_decay=1e-3)
     ob = torch.optim.Adam([pb], 3e-3, eps=1e-8, weight_decay=1e-3)
     pb.grad = torch.zeros_like(pb)
+    shadow = torch.zeros(n, device="cuda", dtype=torch.bfloat16)
     for it, gscale in enumerate((1.0, 1e-3, 0.05)):
         g = torch.randn(n, device="cuda") * gscale
         pa.grad = g.clone()
         torch.nn.utils.clip_grad_norm_([pa], 50.0)
         oa.step()
         pb.grad.copy_(g)
-        adam_clip_step(ob, pb, pb.grad, 50.0)
+        adam_clip_step(ob, pb, pb.grad, 50.0, shadow=shadow)
+        assert torch.equal(shadow, pb.detach().to(torch.bfloat16))
         torch.testing.assert_close(pb.grad, pa.grad, rtol=1e-5, atol=1e-9)
         torch.testing.assert_close(pb.detach(), pa.detach(), rtol=1e-5, atol=2e-6)
     sa, sb = oa.state[pa], ob.state[pb]
