@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PHC_ABI_VERSION 11
+#define PHC_ABI_VERSION 12
 #define PHC_MAX_BODIES 64   /* bodies (incl. extended reference bodies) per articulation; also the slot count of the model tables */
 #define PHC_EINVAL (-1)
 #define PHC_EUNSUPPORTED (-2)
@@ -263,14 +263,16 @@ int32_t phc_gae(int32_t horizon, int32_t n, const float* fdones, const float* va
 int32_t phc_fk(const phc_model_t* model, int64_t num_frames, const float* local_rot, const float* root_trans,
                float* global_rot, float* global_pos, void* stream);
 
-/* P1: RunningMeanStd.forward in train mode (phc/utils/running_mean_std.py:69-111) on a device batch x [rows, cols] fp32:
+/* P1: RunningMeanStd.forward in train mode (phc/utils/running_mean_std.py:69-111) on a device batch x [rows, cols] fp32 -- or, with
+ * row_index [rows] (int64), on the minibatch x[row_index] of a larger tensor without materialising it (the dataset gather of
+ * common_agent.py:357-398 folded into the pass):
  *   out = clamp((x - float(norm_mean)) / sqrt(float(norm_var) + epsilon), -clamp, clamp)      (:95-96; fp32 or bf16 [rows, cols], may be NULL)
  *   run_mean / run_var (fp64, in place; NULL = no update, eval mode or frozen) <- parallel-variance update with the batch mean and
  *   unbiased variance (:56-67,100-104); run_count is READ only: the caller adds `rows` to it afterwards (stream-ordered).  norm_* may alias run_* (output from the statistics BEFORE the update, as the
  *   reference computes it) or be a frozen copy (amp_agent.py:527-532 `running_mean_std_temp`).
  * workspace: phc_running_norm_workspace(rows, cols) bytes of device memory (only read / written when updating). */
 int64_t phc_running_norm_workspace(int64_t rows, int32_t cols);
-int32_t phc_running_norm(const float* x, int64_t rows, int32_t cols, const double* norm_mean, const double* norm_var, float epsilon,
+int32_t phc_running_norm(const float* x, const int64_t* row_index, int64_t rows, int32_t cols, const double* norm_mean, const double* norm_var, float epsilon,
                          float clamp, void* out, int32_t out_bf16, double* run_mean, double* run_var, const double* run_count,
                          double* workspace, void* stream);
 
@@ -295,7 +297,9 @@ int32_t phc_adam_clip_step(float* param, float* grad, float* exp_avg, float* exp
  *   r = exp(old_neglogp - neglogp(actions | mu, exp(logstd)))
  * mu [B, D] and value [B] are the network heads (bf16 when is_bf16, else fp32); grad_mu / grad_value receive d loss / d mu, d loss / d value
  * in the same type; stats[6] = loss, mean a_loss, mean c_loss, mean b_loss, entropy, mean kl(policy || old policy).
- * old_values is only read when clip_value.  workspace: phc_ppo_loss_workspace() bytes. */
+ * old_values is only read when clip_value.  row_index (optional, [B] int64): minibatch row r takes actions / old_* / advantages /
+ * returns from row row_index[r] of the rollout tensors (mu, value and the gradients stay minibatch-ordered).
+ * workspace: phc_ppo_loss_workspace() bytes. */
 typedef struct {
     float e_clip, critic_coef, entropy_coef, bounds_loss_coef;
     int32_t clip_value;
@@ -303,7 +307,7 @@ typedef struct {
 int64_t phc_ppo_loss_workspace(void);
 int32_t phc_ppo_loss(const void* mu, const void* value, int32_t is_bf16, const float* logstd, const float* actions, const float* old_neglogp,
                      const float* advantages, const float* returns, const float* old_values, const float* old_mu, const float* old_sigma,
-                     int64_t batch, int32_t num_actions, const phc_ppo_params_t* prm, void* grad_mu, void* grad_value, float* stats,
+                     const int64_t* row_index, int64_t batch, int32_t num_actions, const phc_ppo_params_t* prm, void* grad_mu, void* grad_value, float* stats,
                      double* workspace, void* stream);
 
 #ifdef __cplusplus

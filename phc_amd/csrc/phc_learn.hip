@@ -16,9 +16,9 @@
 // One pass over x [rows, cols]: y = clamp((x - mean) / sqrt(var + eps), -c, c)  (running_mean_std.py:95-96, fp32 like the reference:
 // the fp64 statistics are rounded to fp32 first) and, when `partial` is given, per-block column sums of x and x^2 in fp64.
 template <bool BF16>
-__global__ __launch_bounds__(RN_COLS) void k_running_norm(const float* __restrict__ x, int64_t rows, int cols, const double* __restrict__ mean,
-                                                          const double* __restrict__ var, float eps, float clampv, void* __restrict__ out,
-                                                          double* __restrict__ partial) {
+__global__ __launch_bounds__(RN_COLS) void k_running_norm(const float* __restrict__ x, const int64_t* __restrict__ idx, int64_t rows, int cols,
+                                                          const double* __restrict__ mean, const double* __restrict__ var, float eps, float clampv,
+                                                          void* __restrict__ out, double* __restrict__ partial) {
     const int c = blockIdx.x * RN_COLS + threadIdx.x;
     if (c >= cols) return;
     const int64_t r0 = (int64_t)blockIdx.y * RN_ROWS;
@@ -40,11 +40,11 @@ __global__ __launch_bounds__(RN_COLS) void k_running_norm(const float* __restric
     for (; r + RN_UNROLL <= r1; r += RN_UNROLL) {
         float v[RN_UNROLL];
 #pragma unroll
-        for (int k = 0; k < RN_UNROLL; ++k) v[k] = x[(r + k) * cols + c];
+        for (int k = 0; k < RN_UNROLL; ++k) v[k] = x[(idx ? idx[r + k] : r + k) * cols + c];   // minibatch row r = dataset row idx[r]
 #pragma unroll
         for (int k = 0; k < RN_UNROLL; ++k) one(r + k, v[k]);
     }
-    for (; r < r1; ++r) one(r, x[r * cols + c]);
+    for (; r < r1; ++r) one(r, x[(idx ? idx[r] : r) * cols + c]);
     if (partial) {
         partial[((int64_t)blockIdx.y * 2 + 0) * cols + c] = sum;
         partial[((int64_t)blockIdx.y * 2 + 1) * cols + c] = sq;
@@ -222,8 +222,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_ppo_loss(const T* __restrict__ mu, const T* __restrict__ value, const float* __restrict__ logstd,
                                                   const float* __restrict__ actions, const float* __restrict__ old_neglogp,
                                                   const float* __restrict__ adv, const float* __restrict__ ret, const float* __restrict__ old_value,
-                                                  const float* __restrict__ old_mu, const float* __restrict__ old_sigma, int64_t B, int D,
-                                                  phc_ppo_params_t prm, T* __restrict__ grad_mu, T* __restrict__ grad_value, double* __restrict__ partial) {
+                                                  const float* __restrict__ old_mu, const float* __restrict__ old_sigma,
+                                                  const int64_t* __restrict__ idx, int64_t B, int D, phc_ppo_params_t prm, T* __restrict__ grad_mu, T* __restrict__ grad_value, double* __restrict__ partial) {
     __shared__ double lsum[4][PPO_NSUM];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const float invB = 1.0f / (float)B;
@@ -234,19 +234,20 @@ __global__ __launch_bounds__(256) void k_ppo_loss(const T* __restrict__ mu, cons
     double acc[PPO_NSUM] = {0.0, 0.0, 0.0, 0.0};
     for (int64_t r = (int64_t)blockIdx.x * 4 + w; r < B; r += (int64_t)gridDim.x * 4) {
         float s_nlp = 0.f, s_b = 0.f, s_kl = 0.f;
+        const int64_t q = idx ? idx[r] : r;   // row of the rollout tensors (actions, old_*, adv, ret); mu / value are minibatch-ordered
         for (int d = lane; d < D; d += 64) {
-            const float m = ld_f(mu, r * D + d), a = actions[r * D + d], sg = expf(logstd[d]);
+            const float m = ld_f(mu, r * D + d), a = actions[q * D + d], sg = expf(logstd[d]);
             const float z = (a - m) / sg;
             s_nlp += z * z;
             const float hi = fmaxf(m - 1.0f, 0.f), lo = fminf(m + 1.0f, 0.f);
             s_b += lo * lo + hi * hi;
-            const float m1 = old_mu[r * D + d], s1 = old_sigma[r * D + d];
+            const float m1 = old_mu[q * D + d], s1 = old_sigma[q * D + d];
             s_kl += logf(s1 / sg + 1e-5f) + (sg * sg + (m1 - m) * (m1 - m)) / (2.0f * (s1 * s1 + 1e-5f)) - 0.5f;
         }
         s_nlp = wave_sum(s_nlp); s_b = wave_sum(s_b); s_kl = wave_sum(s_kl);
         const float neglogp = 0.5f * s_nlp + nlp_const;
-        const float ratio = expf(old_neglogp[r] - neglogp);
-        const float A = adv[r];
+        const float ratio = expf(old_neglogp[q] - neglogp);
+        const float A = adv[q];
         const float lo_r = 1.0f - prm.e_clip, hi_r = 1.0f + prm.e_clip;
         const float t1 = -A * ratio, t2 = -A * fminf(fmaxf(ratio, lo_r), hi_r);
         const float a_loss = fmaxf(t1, t2);
@@ -254,10 +255,10 @@ __global__ __launch_bounds__(256) void k_ppo_loss(const T* __restrict__ mu, cons
         const float w1 = t1 > t2 ? 1.0f : (t1 == t2 ? 0.5f : 0.f);
         const float inside = (ratio >= lo_r && ratio <= hi_r) ? 1.0f : 0.f;
         const float c_mu = -A * (w1 + (1.0f - w1) * inside) * ratio * invB;
-        const float v = ld_f(value, r), R = ret[r];
+        const float v = ld_f(value, r), R = ret[q];
         float c_loss, dC;
         if (prm.clip_value) {
-            const float vp = old_value[r];
+            const float vp = old_value[q];
             const float dv = v - vp, vpc = vp + fminf(fmaxf(dv, -prm.e_clip), prm.e_clip);
             const float l1 = (v - R) * (v - R), l2 = (vpc - R) * (vpc - R);
             c_loss = fmaxf(l1, l2);
@@ -274,7 +275,7 @@ __global__ __launch_bounds__(256) void k_ppo_loss(const T* __restrict__ mu, cons
         }
         const float cb = prm.bounds_loss_coef * invB;
         for (int d = lane; d < D; d += 64) {
-            const float m = ld_f(mu, r * D + d), a = actions[r * D + d], sg = expf(logstd[d]);
+            const float m = ld_f(mu, r * D + d), a = actions[q * D + d], sg = expf(logstd[d]);
             const float g = c_mu * (a - m) / (sg * sg) + cb * (2.0f * fmaxf(m - 1.0f, 0.f) + 2.0f * fminf(m + 1.0f, 0.f));
             st_f(grad_mu, r * D + d, g);
         }
@@ -310,7 +311,7 @@ int64_t phc_running_norm_workspace(int64_t rows, int32_t cols) {
     return ((rows + RN_ROWS - 1) / RN_ROWS) * 2 * (int64_t)cols * (int64_t)sizeof(double);
 }
 
-int32_t phc_running_norm(const float* x, int64_t rows, int32_t cols, const double* norm_mean, const double* norm_var, float epsilon,
+int32_t phc_running_norm(const float* x, const int64_t* row_index, int64_t rows, int32_t cols, const double* norm_mean, const double* norm_var, float epsilon,
                          float clamp, void* out, int32_t out_bf16, double* run_mean, double* run_var, const double* run_count,
                          double* workspace, void* stream) {
     if (!x || rows < 0 || cols < 1 || !norm_mean || !norm_var) return PHC_EINVAL;
@@ -323,9 +324,9 @@ int32_t phc_running_norm(const float* x, int64_t rows, int32_t cols, const doubl
     const dim3 grid((cols + RN_COLS - 1) / RN_COLS, (unsigned)nchunks);
     hipStream_t st = (hipStream_t)stream;
     if (out_bf16)
-        hipLaunchKernelGGL(k_running_norm<true>, grid, dim3(RN_COLS), 0, st, x, rows, cols, norm_mean, norm_var, epsilon, clamp, out, update ? workspace : nullptr);
+        hipLaunchKernelGGL(k_running_norm<true>, grid, dim3(RN_COLS), 0, st, x, row_index, rows, cols, norm_mean, norm_var, epsilon, clamp, out, update ? workspace : nullptr);
     else
-        hipLaunchKernelGGL(k_running_norm<false>, grid, dim3(RN_COLS), 0, st, x, rows, cols, norm_mean, norm_var, epsilon, clamp, out, update ? workspace : nullptr);
+        hipLaunchKernelGGL(k_running_norm<false>, grid, dim3(RN_COLS), 0, st, x, row_index, rows, cols, norm_mean, norm_var, epsilon, clamp, out, update ? workspace : nullptr);
     if (update)
         hipLaunchKernelGGL(k_running_norm_finish, dim3((cols + 63) / 64), dim3(1024), 0, st, workspace, (int)nchunks, rows, cols, run_mean, run_var, run_count);
     hipError_t e = hipGetLastError();
@@ -366,7 +367,7 @@ int64_t phc_ppo_loss_workspace(void) { return PPO_BLOCKS * PPO_NSUM * (int64_t)s
 
 int32_t phc_ppo_loss(const void* mu, const void* value, int32_t is_bf16, const float* logstd, const float* actions, const float* old_neglogp,
                      const float* advantages, const float* returns, const float* old_values, const float* old_mu, const float* old_sigma,
-                     int64_t batch, int32_t num_actions, const phc_ppo_params_t* prm, void* grad_mu, void* grad_value, float* stats,
+                     const int64_t* row_index, int64_t batch, int32_t num_actions, const phc_ppo_params_t* prm, void* grad_mu, void* grad_value, float* stats,
                      double* workspace, void* stream) {
     if (!mu || !value || !logstd || !actions || !old_neglogp || !advantages || !returns || !old_mu || !old_sigma || !prm || !grad_mu || !grad_value ||
         !stats || !workspace || batch < 1 || num_actions < 1)
@@ -376,11 +377,11 @@ int32_t phc_ppo_loss(const void* mu, const void* value, int32_t is_bf16, const f
     const int nblocks = (int)((batch + 3) / 4 < PPO_BLOCKS ? (batch + 3) / 4 : PPO_BLOCKS);
     if (is_bf16)
         hipLaunchKernelGGL(k_ppo_loss<__hip_bfloat16>, dim3(nblocks), dim3(256), 0, st, (const __hip_bfloat16*)mu, (const __hip_bfloat16*)value, logstd, actions,
-                           old_neglogp, advantages, returns, old_values, old_mu, old_sigma, batch, num_actions, *prm, (__hip_bfloat16*)grad_mu,
+                           old_neglogp, advantages, returns, old_values, old_mu, old_sigma, row_index, batch, num_actions, *prm, (__hip_bfloat16*)grad_mu,
                            (__hip_bfloat16*)grad_value, workspace);
     else
         hipLaunchKernelGGL(k_ppo_loss<float>, dim3(nblocks), dim3(256), 0, st, (const float*)mu, (const float*)value, logstd, actions, old_neglogp,
-                           advantages, returns, old_values, old_mu, old_sigma, batch, num_actions, *prm, (float*)grad_mu, (float*)grad_value, workspace);
+                           advantages, returns, old_values, old_mu, old_sigma, row_index, batch, num_actions, *prm, (float*)grad_mu, (float*)grad_value, workspace);
     hipLaunchKernelGGL(k_ppo_loss_finish, dim3(1), dim3(256), 0, st, workspace, nblocks, batch, num_actions, logstd, *prm, stats);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int32_t)e;

@@ -231,17 +231,19 @@ class IMAmpAgent:
         return torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.bf16)
 
     # ------------------------------------------------------------------ observation pre-processing (amp_agent.py:535-552)
-    def _preproc_obs(self, obs_batch, use_temp=False):
+    def _preproc_obs(self, obs_batch, use_temp=False, row_index=None):
         if not self.normalize_input:
-            return obs_batch
+            return obs_batch if row_index is None else obs_batch[row_index]
         # bf16 runs: the normaliser writes the bf16 tensor the GEMMs read (the same values autocast's cast would produce)
         dt = torch.bfloat16 if self.bf16 else None
         if use_temp:  # statistics keep updating, the frozen copy provides the values (amp_agent.py:527-532)
-            return self.running_mean_std(obs_batch, norm_from=self.running_mean_std_temp, out_dtype=dt)
-        return self.running_mean_std(obs_batch, out_dtype=dt)
+            return self.running_mean_std(obs_batch, norm_from=self.running_mean_std_temp, out_dtype=dt, row_index=row_index)
+        return self.running_mean_std(obs_batch, out_dtype=dt, row_index=row_index)
 
-    def _preproc_amp_obs(self, amp_obs):
-        return self._amp_input_mean_std(amp_obs, out_dtype=torch.bfloat16 if self.bf16 else None) if self._normalize_amp_input else amp_obs
+    def _preproc_amp_obs(self, amp_obs, row_index=None):
+        if not self._normalize_amp_input:
+            return amp_obs if row_index is None else amp_obs[row_index]
+        return self._amp_input_mean_std(amp_obs, out_dtype=torch.bfloat16 if self.bf16 else None, row_index=row_index)
 
     # ------------------------------------------------------------------ rollout (amp_agent.py:309-397)
     def get_action_values(self, obs):
@@ -347,7 +349,12 @@ class IMAmpAgent:
         s, e = idx * self.minibatch_size, (idx + 1) * self.minibatch_size
         sample_idx = self._idx_buf[s:e]
         amp_idx = sample_idx[:self._amp_minibatch_size]  # calc_gradients only reads rows [0:amp_minibatch_size] (amp_agent.py:570-577)
-        out = {k: v[amp_idx if k.startswith("amp_obs") else sample_idx] for k, v in self.dataset.items()}
+        if sample_idx.is_cuda:
+            # the device kernels read the dataset rows in place (phc_running_norm / phc_ppo_loss take the row index): nothing is gathered
+            sample_idx = sample_idx.clone()   # _idx_buf is re-drawn below, before this minibatch's kernels have run
+            out = {"_dataset": self.dataset, "_idx": sample_idx, "_amp_idx": sample_idx[:self._amp_minibatch_size]}
+        else:
+            out = {k: v[amp_idx if k.startswith("amp_obs") else sample_idx] for k, v in self.dataset.items()}
         if e >= self.batch_size:
             self._idx_buf[:] = torch.randperm(self.batch_size, device=self._idx_buf.device)
         return out
@@ -379,10 +386,13 @@ class IMAmpAgent:
 
     def _fwd_bwd(self, d):
         """Forward + losses + backward into the flat gradient bucket (amp_agent.py:554-655); no host sync."""
-        obs = self._preproc_obs(d["obs"], use_temp=self.temp_running_mean)
-        amp_obs = self._preproc_amp_obs(d["amp_obs"])
-        amp_obs_replay = self._preproc_amp_obs(d["amp_obs_replay"])
-        amp_obs_demo = self._preproc_amp_obs(d["amp_obs_demo"])
+        idx = amp_idx = None
+        if "_dataset" in d:   # device: minibatch = (dataset, row index); the kernels below read the rows in place
+            d, idx, amp_idx = d["_dataset"], d["_idx"], d["_amp_idx"]
+        obs = self._preproc_obs(d["obs"], use_temp=self.temp_running_mean, row_index=idx)
+        amp_obs = self._preproc_amp_obs(d["amp_obs"], amp_idx)
+        amp_obs_replay = self._preproc_amp_obs(d["amp_obs_replay"], amp_idx)
+        amp_obs_demo = self._preproc_amp_obs(d["amp_obs_demo"], amp_idx)
         amp_obs_demo.requires_grad_(True)
         fused = obs.is_cuda
         with self._autocast():
@@ -394,10 +404,11 @@ class IMAmpAgent:
             # actor / critic losses and their gradients w.r.t. the two heads: one HIP pass (phc_ppo_loss) instead of ~100 launches
             ppo, st = ppo_loss(res["mu"].contiguous(), res["value"].contiguous(), res["logstd"], d["actions"], d["old_logp_actions"], d["advantages"],
                                d["returns"], d["old_values"], d["mu"], d["sigma"], self.e_clip, self.critic_coef, self.entropy_coef,
-                               self.bounds_loss_coef, self.clip_value, unit_grad=True)
+                               self.bounds_loss_coef, self.clip_value, unit_grad=True, row_index=idx)
             loss = ppo + self._disc_coef * disc_info["disc_loss"]   # `ppo` enters with weight one (unit_grad)
             info = {"actor_loss": st[0], "critic_loss": st[1], "b_loss": st[2], "entropy": st[3], "kl": st[4]}
         else:
+            assert idx is None
             loss, info = self._ppo_loss_torch(res, d, disc_info)
         self.grads.zero()
         loss.backward()
@@ -435,6 +446,8 @@ class IMAmpAgent:
 
     def _amp_rows(self, d):
         m = self._amp_minibatch_size
+        if "_dataset" in d:
+            return d
         return {k: (v[0:m] if k.startswith("amp_obs") else v) for k, v in d.items()}
 
     def calc_gradients(self, d):

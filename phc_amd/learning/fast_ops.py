@@ -99,7 +99,7 @@ class _PPOLossFn(torch.autograd.Function):
     gradient is then 1 and the stored gradients are returned as they are (no extra pass over [B, D])."""
 
     @staticmethod
-    def forward(ctx, mu, value, logstd, actions, old_neglogp, adv, returns, old_values, old_mu, old_sigma, prm, unit_grad):
+    def forward(ctx, mu, value, logstd, actions, old_neglogp, adv, returns, old_values, old_mu, old_sigma, prm, unit_grad, row_index):
         lib = L.load()
         B, D = mu.shape
         assert value.numel() == B and mu.dtype == value.dtype and mu.dtype in (torch.bfloat16, torch.float32)
@@ -113,7 +113,7 @@ class _PPOLossFn(torch.autograd.Function):
         p = L.PpoParams(float(prm["e_clip"]), float(prm["critic_coef"]), float(prm["entropy_coef"]), float(prm["bounds_loss_coef"]), int(prm["clip_value"]))
         L.check(lib.phc_ppo_loss(mu.data_ptr(), value.data_ptr(), int(mu.dtype == torch.bfloat16), logstd.data_ptr(), actions.data_ptr(),
                                  old_neglogp.data_ptr(), adv.data_ptr(), returns.data_ptr(), None if old_values is None else old_values.data_ptr(),
-                                 old_mu.data_ptr(), old_sigma.data_ptr(), B, D, C.byref(p), gmu.data_ptr(), gval.data_ptr(), buf.data_ptr(),
+                                 old_mu.data_ptr(), old_sigma.data_ptr(), None if row_index is None else row_index.data_ptr(), B, D, C.byref(p), gmu.data_ptr(), gval.data_ptr(), buf.data_ptr(),
                                  ws.data_ptr(), _stream(mu.device)), "phc_ppo_loss")
         ctx.save_for_backward(gmu, gval)
         ctx.unit_grad = unit_grad
@@ -127,14 +127,15 @@ class _PPOLossFn(torch.autograd.Function):
         gmu, gval = ctx.saved_tensors
         if not ctx.unit_grad:
             gmu, gval = gmu * g_loss.to(gmu.dtype), gval * g_loss.to(gval.dtype)
-        return (gmu, gval) + (None,) * 10
+        return (gmu, gval) + (None,) * 11
 
 
 def ppo_loss(mu, value, logstd, actions, old_neglogp, adv, returns, old_values, old_mu, old_sigma, e_clip, critic_coef, entropy_coef,
-             bounds_loss_coef, clip_value, unit_grad=False):
-    """-> (loss, stats[5] = a_loss, c_loss, b_loss, entropy, kl); mu [B, D] / value [B, 1] are the (bf16 or fp32) network heads."""
+             bounds_loss_coef, clip_value, unit_grad=False, row_index=None):
+    """-> (loss, stats[5] = a_loss, c_loss, b_loss, entropy, kl); mu [B, D] / value [B, 1] are the (bf16 or fp32) network heads;
+    with `row_index` [B] the rollout tensors (actions ... old_sigma) are the whole dataset and row r of the minibatch is row_index[r]."""
     prm = dict(e_clip=e_clip, critic_coef=critic_coef, entropy_coef=entropy_coef, bounds_loss_coef=bounds_loss_coef or 0.0, clip_value=bool(clip_value))
-    return _PPOLossFn.apply(mu, value, logstd, actions, old_neglogp, adv, returns, old_values if clip_value else None, old_mu, old_sigma, prm, unit_grad)
+    return _PPOLossFn.apply(mu, value, logstd, actions, old_neglogp, adv, returns, old_values if clip_value else None, old_mu, old_sigma, prm, unit_grad, row_index)
 
 
 def adam_clip_step(optimizer, flat_param, flat_grad, max_norm, shadow=None):

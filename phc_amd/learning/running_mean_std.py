@@ -56,10 +56,13 @@ class RunningMeanStd(nn.Module):
         return (input.is_cuda and input.dtype == torch.float32 and input.dim() == 2 and input.is_contiguous() and not unnorm
                 and not self.norm_only and not self.forzen_partial and input.shape[1] == self.mean_size)
 
-    def _forward_fused(self, input, src, out_dtype, want_output):
+    def _forward_fused(self, input, src, out_dtype, want_output, row_index=None):
         from .. import _lib as L
         lib = L.load()
         rows, cols = input.shape
+        if row_index is not None:
+            assert row_index.dtype == torch.int64 and row_index.is_contiguous() and row_index.device == input.device
+            rows = row_index.numel()
         update = self.training and not self.forzen
         out = torch.empty((rows, cols), dtype=out_dtype, device=input.device) if want_output else None
         ws = None
@@ -69,7 +72,7 @@ class RunningMeanStd(nn.Module):
                 self._ws = torch.empty(need, dtype=torch.float64, device=input.device)
             ws = self._ws
         ptr = lambda t: None if t is None else t.data_ptr()
-        L.check(lib.phc_running_norm(input.data_ptr(), rows, cols, src.running_mean.data_ptr(), src.running_var.data_ptr(), float(src.epsilon), 5.0,
+        L.check(lib.phc_running_norm(input.data_ptr(), ptr(row_index), rows, cols, src.running_mean.data_ptr(), src.running_var.data_ptr(), float(src.epsilon), 5.0,
                                      ptr(out), int(out_dtype == torch.bfloat16), ptr(self.running_mean if update else None),
                                      ptr(self.running_var if update else None), ptr(self.count if update else None), ptr(ws),
                                      torch.cuda.current_stream(input.device).cuda_stream), "phc_running_norm")
@@ -77,12 +80,15 @@ class RunningMeanStd(nn.Module):
             self.count += rows   # after the kernel read the old count (same stream)
         return out
 
-    def forward(self, input, unnorm=False, norm_from=None, out_dtype=None, want_output=True):
+    def forward(self, input, unnorm=False, norm_from=None, out_dtype=None, want_output=True, row_index=None):
         """`norm_from`: module whose statistics produce the output (default: this one, before its update); `out_dtype`: fp32
-        (default) or bf16; `want_output=False`: only fold the batch into the statistics (device path skips the store)."""
+        (default) or bf16; `want_output=False`: only fold the batch into the statistics (device path skips the store);
+        `row_index`: operate on input[row_index] (the device pass reads the rows in place)."""
         src = norm_from if norm_from is not None else self
         if self._fused_ok(input, unnorm):
-            return self._forward_fused(input, src, out_dtype or torch.float32, want_output)
+            return self._forward_fused(input, src, out_dtype or torch.float32, want_output, row_index)
+        if row_index is not None:
+            input = input[row_index]
         mean, var = src.running_mean, src.running_var
         if unnorm:
             y = torch.clamp(input, min=-5.0, max=5.0)

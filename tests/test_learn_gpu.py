@@ -135,8 +135,8 @@ def test_adam_clip_step_equals_torch():
         pb.grad.copy_(g)
         adam_clip_step(ob, pb, pb.grad, 50.0, shadow=shadow)
         assert torch.equal(shadow, pb.detach().to(torch.bfloat16))
-        torch.testing.assert_close(pb.grad, pa.grad, rtol=1e-5, atol=1e-9)
-        torch.testing.assert_close(pb.detach(), pa.detach(), rtol=1e-5, atol=2e-6)
+        torch.testing.assert_close(pb.grad, pa.grad, rtol=5e-5, atol=1e-9)   # clip coefficient: fp64 sum of squares here, fp32 norm in torch
+        torch.testing.assert_close(pb.detach(), pa.detach(), rtol=5e-5, atol=2e-6)
     sa, sb = oa.state[pa], ob.state[pb]
     assert float(sb["step"]) == 3.0 == float(sa["step"])
     torch.testing.assert_close(sb["exp_avg_sq"], sa["exp_avg_sq"], rtol=1e-5, atol=1e-12)
@@ -188,7 +188,7 @@ def test_fused_ppo_loss_equals_torch_losses(dtype, clip_value, D):
     tol = dict(rtol=2e-4, atol=2e-5)
     torch.testing.assert_close(loss, ref.detach(), **tol)
     torch.testing.assert_close(st, torch.stack([a_loss, c_loss, b_loss, ent, kl]).detach(), **tol)
-    gtol = dict(rtol=2e-2, atol=2e-6) if dtype == torch.bfloat16 else dict(rtol=2e-4, atol=1e-8)
+    gtol = dict(rtol=2e-2, atol=2e-6) if dtype == torch.bfloat16 else dict(rtol=2e-4, atol=2e-7)
     torch.testing.assert_close(mu_f.grad.float(), mu_t.grad.float(), **gtol)
     torch.testing.assert_close(val_f.grad.float(), val_t.grad.float(), **gtol)
     # general incoming gradient
@@ -196,3 +196,31 @@ def test_fused_ppo_loss_equals_torch_losses(dtype, clip_value, D):
     loss2, _ = ppo_loss(mu_g, val_g, logstd, actions, old_nlp, adv, ret, old_val, old_mu, old_sigma, e_clip, cc, ec, bl, clip_value)
     (3.0 * loss2).backward()
     torch.testing.assert_close(mu_g.grad.float(), 3.0 * mu_t.grad.float(), rtol=3e-2 if dtype == torch.bfloat16 else 2e-4, atol=1e-5)
+
+
+def test_row_index_variants_equal_gathered_inputs():
+    """phc_running_norm / phc_ppo_loss with a row index == the same kernels on the gathered minibatch (bit-identical: same arithmetic,
+    rows read in place)."""
+    from phc_amd.learning.fast_ops import ppo_loss
+    torch.manual_seed(7)
+    dev = "cuda"
+    N, B, C, D = 20000, 4096, 358, 69
+    x = torch.randn(N, C, device=dev)
+    idx = torch.randperm(N, device=dev)[:B]
+    a, b = RunningMeanStd(C).cuda().train(), RunningMeanStd(C).cuda().train()
+    ya, yb = a(x, row_index=idx, out_dtype=torch.bfloat16), b(x[idx].contiguous(), out_dtype=torch.bfloat16)
+    assert torch.equal(ya, yb) and torch.equal(a.running_mean, b.running_mean) and torch.equal(a.running_var, b.running_var) and float(a.count) == float(b.count)
+    logstd = torch.full((D,), -2.9, device=dev)
+    mu, val = (torch.randn(B, D, device=dev) * 0.5).to(torch.bfloat16), torch.randn(B, 1, device=dev).to(torch.bfloat16)
+    act, omu = torch.randn(N, D, device=dev) * 0.5, torch.randn(N, D, device=dev) * 0.5
+    osig = torch.exp(logstd).expand(N, D).contiguous()
+    onlp, adv, ret, oval = torch.randn(N, device=dev) * 3 + 60, torch.randn(N, device=dev), torch.randn(N, 1, device=dev), torch.randn(N, 1, device=dev)
+    outs = []
+    for ri in (idx, None):
+        g = (lambda t: t) if ri is not None else (lambda t: t[idx].contiguous())
+        m, v = mu.clone().requires_grad_(True), val.clone().requires_grad_(True)
+        loss, st = ppo_loss(m, v, logstd, g(act), g(onlp), g(adv), g(ret), g(oval), g(omu), g(osig), 0.2, 5.0, 0.0, 10.0, True, unit_grad=True, row_index=ri)
+        loss.backward()
+        outs.append((loss.detach(), st, m.grad, v.grad))
+    for p, q in zip(*outs):
+        assert torch.equal(p, q)
