@@ -139,7 +139,7 @@ def test_adam_clip_step_equals_torch():
         torch.testing.assert_close(pb.detach(), pa.detach(), rtol=5e-5, atol=2e-6)
     sa, sb = oa.state[pa], ob.state[pb]
     assert float(sb["step"]) == 3.0 == float(sa["step"])
-    torch.testing.assert_close(sb["exp_avg_sq"], sa["exp_avg_sq"], rtol=1e-5, atol=1e-12)
+    torch.testing.assert_close(sb["exp_avg_sq"], sa["exp_avg_sq"], rtol=1e-4, atol=1e-12)   # squares of the clipped gradient: twice its relative difference
     oc = torch.optim.Adam([p0.clone().requires_grad_(True)], 3e-3)
     oc.load_state_dict(ob.state_dict())
 
