@@ -287,22 +287,28 @@ __global__ __launch_bounds__(256) void k_ppo_loss(const T* __restrict__ mu, cons
         partial[(int64_t)blockIdx.x * PPO_NSUM + threadIdx.x] = (lsum[0][threadIdx.x] + lsum[1][threadIdx.x]) + (lsum[2][threadIdx.x] + lsum[3][threadIdx.x]);
 }
 
-// stats[0..5] = loss, mean a_loss, mean c_loss, mean b_loss, entropy, mean kl
-__global__ void k_ppo_loss_finish(const double* __restrict__ partial, int nblocks, int64_t B, int D, const float* __restrict__ logstd,
-                                  phc_ppo_params_t prm, float* __restrict__ stats) {
-    __shared__ double l[PPO_NSUM][64];
-    const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;   // 256 threads: one wavefront per sum
+// stats[0..5] = loss, mean a_loss, mean c_loss, mean b_loss, entropy, mean kl.  256 threads: wavefront k reduces sum k; wavefront 0
+// also the entropy.
+__global__ __launch_bounds__(256) void k_ppo_loss_finish(const double* __restrict__ partial, int nblocks, int64_t B, int D,
+                                                         const float* __restrict__ logstd, phc_ppo_params_t prm, float* __restrict__ stats) {
+    __shared__ double l[PPO_NSUM];
+    __shared__ float lent;
+    const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
     double t = 0.0;
     for (int b = lane; b < nblocks; b += 64) t += partial[(int64_t)b * PPO_NSUM + k];
-    l[k][lane] = t;
+    for (int m = 32; m >= 1; m >>= 1) t += __shfl_xor(t, m, 64);
+    if (lane == 0) l[k] = t / (double)B;
+    if (k == 0) {
+        float e = 0.f;
+        for (int d = lane; d < D; d += 64) e += 0.5f + 0.5f * 1.8378770664093453f + logstd[d];
+        e = wave_sum(e);
+        if (lane == 0) lent = e;
+    }
     __syncthreads();
     if (threadIdx.x != 0) return;
-    double s[PPO_NSUM];
-    for (int q = 0; q < PPO_NSUM; ++q) { s[q] = 0.0; for (int i = 0; i < 64; ++i) s[q] += l[q][i]; s[q] /= (double)B; }
-    float ent = 0.f;
-    for (int d = 0; d < D; ++d) ent += 0.5f + 0.5f * 1.8378770664093453f + logstd[d];
-    stats[1] = (float)s[0]; stats[2] = (float)s[1]; stats[3] = (float)s[2]; stats[4] = ent; stats[5] = (float)s[3];
-    stats[0] = (float)s[0] + prm.critic_coef * (float)s[1] - prm.entropy_coef * ent + prm.bounds_loss_coef * (float)s[2];
+    const float ent = lent;
+    stats[1] = (float)l[0]; stats[2] = (float)l[1]; stats[3] = (float)l[2]; stats[4] = ent; stats[5] = (float)l[3];
+    stats[0] = (float)l[0] + prm.critic_coef * (float)l[1] - prm.entropy_coef * ent + prm.bounds_loss_coef * (float)l[2];
 }
 
 extern "C" {

@@ -56,7 +56,7 @@ class RunningMeanStd(nn.Module):
         return (input.is_cuda and input.dtype == torch.float32 and input.dim() == 2 and input.is_contiguous() and not unnorm
                 and not self.norm_only and not self.forzen_partial and input.shape[1] == self.mean_size)
 
-    def _forward_fused(self, input, src, out_dtype, want_output, row_index=None):
+    def _forward_fused(self, input, src, out_dtype, want_output, row_index=None, out=None):
         from .. import _lib as L
         lib = L.load()
         rows, cols = input.shape
@@ -64,7 +64,10 @@ class RunningMeanStd(nn.Module):
             assert row_index.dtype == torch.int64 and row_index.is_contiguous() and row_index.device == input.device
             rows = row_index.numel()
         update = self.training and not self.forzen
-        out = torch.empty((rows, cols), dtype=out_dtype, device=input.device) if want_output else None
+        if out is not None:
+            assert out.shape == (rows, cols) and out.dtype == out_dtype and out.is_contiguous() and out.device == input.device
+        elif want_output:
+            out = torch.empty((rows, cols), dtype=out_dtype, device=input.device)
         ws = None
         if update:
             need = lib.phc_running_norm_workspace(rows, cols) // 8
@@ -80,13 +83,14 @@ class RunningMeanStd(nn.Module):
             self.count += rows   # after the kernel read the old count (same stream)
         return out
 
-    def forward(self, input, unnorm=False, norm_from=None, out_dtype=None, want_output=True, row_index=None):
+    def forward(self, input, unnorm=False, norm_from=None, out_dtype=None, want_output=True, row_index=None, out=None):
         """`norm_from`: module whose statistics produce the output (default: this one, before its update); `out_dtype`: fp32
         (default) or bf16; `want_output=False`: only fold the batch into the statistics (device path skips the store);
-        `row_index`: operate on input[row_index] (the device pass reads the rows in place)."""
+        `row_index`: operate on input[row_index] (the device pass reads the rows in place); `out`: device path only, the tensor
+        (e.g. a row block of a larger buffer) that receives the output."""
         src = norm_from if norm_from is not None else self
         if self._fused_ok(input, unnorm):
-            return self._forward_fused(input, src, out_dtype or torch.float32, want_output, row_index)
+            return self._forward_fused(input, src, out_dtype or torch.float32, want_output, row_index, out)
         if row_index is not None:
             input = input[row_index]
         mean, var = src.running_mean, src.running_var
