@@ -23,6 +23,7 @@ MI355X-first differences (results-preserving):
     (amp_agent.py:667-668).  Running-stat moments are averaged once per epoch (`hvd.sync_stats`).
 """
 import copy
+import os
 import time
 
 import numpy as np
@@ -368,19 +369,14 @@ class IMAmpAgent:
         lo = torch.clamp_max(mu + soft_bound, 0.0) ** 2
         return (lo + hi).sum(axis=-1)
 
-    def _disc_loss(self, disc_agent_logit, disc_demo_logit, obs_demo, demo_rows=None):
-        """`obs_demo`: the leaf the gradient penalty differentiates to -- the demo batch, or (device path) the [agent; replay; demo]
-        buffer, of which `demo_rows` (a slice) are the demo rows: the logits of the demo block do not depend on the other rows."""
+    def _disc_loss(self, disc_agent_logit, disc_demo_logit, obs_demo):
         bce = torch.nn.BCEWithLogitsLoss()
         disc_loss = 0.5 * (bce(disc_agent_logit, torch.zeros_like(disc_agent_logit)) + bce(disc_demo_logit, torch.ones_like(disc_demo_logit)))
         net = self.model.a2c_network
         disc_logit_loss = torch.sum(torch.square(net.get_disc_logit_weights()))
         disc_loss = disc_loss + self._disc_logit_reg * disc_logit_loss
         grad = torch.autograd.grad(disc_demo_logit, obs_demo, grad_outputs=torch.ones_like(disc_demo_logit), create_graph=True,
-                                   retain_graph=True, only_inputs=True)[0]
-        if demo_rows is not None:
-            grad = grad[demo_rows]
-        grad = grad.float()   # bf16 leaf (device normaliser output): penalty in fp32
+                                   retain_graph=True, only_inputs=True)[0].float()   # bf16 leaf (device normaliser output): penalty in fp32
         disc_grad_penalty = torch.mean(torch.sum(torch.square(grad), dim=-1))
         disc_loss = disc_loss + self._disc_grad_penalty * disc_grad_penalty
         if self._disc_weight_decay != 0:
@@ -396,28 +392,18 @@ class IMAmpAgent:
             d, idx, amp_idx = d["_dataset"], d["_idx"], d["_amp_idx"]
         obs = self._preproc_obs(d["obs"], use_temp=self.temp_running_mean, row_index=idx)
         fused = obs.is_cuda
-        demo_rows = None
-        if fused and self._normalize_amp_input:
-            # the normaliser writes the three AMP batches into the row blocks of ONE buffer: no torch.cat in front of the discriminator
-            m = amp_idx.numel() if amp_idx is not None else d["amp_obs"].shape[0]
-            dt = torch.bfloat16 if self.bf16 else torch.float32
-            cat = torch.empty((3 * m, d["amp_obs"].shape[1]), dtype=dt, device=obs.device)
-            for k, key in enumerate(("amp_obs", "amp_obs_replay", "amp_obs_demo")):
-                self._amp_input_mean_std(d[key], out_dtype=dt, row_index=amp_idx, out=cat[k * m:(k + 1) * m])
-            cat.requires_grad_(True)
-            amp_obs_demo, demo_rows = cat, slice(2 * m, 3 * m)
-            inp = {"is_train": True, "obs": obs, "amp_obs_cat": cat}
-        else:
-            amp_obs = self._preproc_amp_obs(d["amp_obs"], amp_idx)
-            amp_obs_replay = self._preproc_amp_obs(d["amp_obs_replay"], amp_idx)
-            amp_obs_demo = self._preproc_amp_obs(d["amp_obs_demo"], amp_idx)
-            amp_obs_demo.requires_grad_(True)
-            inp = {"is_train": True, "prev_actions": d["actions"], "obs": obs, "amp_obs": amp_obs, "amp_obs_replay": amp_obs_replay,
-                   "amp_obs_demo": amp_obs_demo}
+        # (writing the three AMP batches straight into one [agent; replay; demo] buffer and differentiating the penalty to that
+        # buffer saves the torch.cat but measured slower -- 170 vs 145 ms per update, scripts/gpu_ab.sh: the penalty's double
+        # backward then carries 3x the rows)
+        amp_obs = self._preproc_amp_obs(d["amp_obs"], amp_idx)
+        amp_obs_replay = self._preproc_amp_obs(d["amp_obs_replay"], amp_idx)
+        amp_obs_demo = self._preproc_amp_obs(d["amp_obs_demo"], amp_idx)
+        amp_obs_demo.requires_grad_(True)
+        inp = {"is_train": True, "prev_actions": d["actions"], "obs": obs, "amp_obs": amp_obs, "amp_obs_replay": amp_obs_replay,
+               "amp_obs_demo": amp_obs_demo}
         with self._autocast():
             res = self.model.forward_heads(inp) if fused else self.model(inp)
-        disc_info = self._disc_loss(torch.cat([res["disc_agent_logit"], res["disc_agent_replay_logit"]], dim=0), res["disc_demo_logit"], amp_obs_demo,
-                                    demo_rows)
+        disc_info = self._disc_loss(torch.cat([res["disc_agent_logit"], res["disc_agent_replay_logit"]], dim=0), res["disc_demo_logit"], amp_obs_demo)
         if fused:
             # actor / critic losses and their gradients w.r.t. the two heads: one HIP pass (phc_ppo_loss) instead of ~100 launches
             ppo, st = ppo_loss(res["mu"].contiguous(), res["value"].contiguous(), res["logstd"], d["actions"], d["old_logp_actions"], d["advantages"],

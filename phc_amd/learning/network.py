@@ -203,14 +203,9 @@ class ModelAMPContinuous(nn.Module):
         obs = input_dict["obs"]
         mu, logstd = self.a2c_network.eval_actor(obs)
         value = self.a2c_network.eval_critic(obs)
-        if "amp_obs_cat" in input_dict:   # [agent; replay; demo] already in one buffer (the normaliser wrote the three row blocks)
-            x = input_dict["amp_obs_cat"]
-            n = x.shape[0] // 3
-            la, lr_, ld = torch.split(self.a2c_network.eval_disc(x).float(), [n, n, n], dim=0)
-        else:
-            a, r, d = input_dict["amp_obs"], input_dict["amp_obs_replay"], input_dict["amp_obs_demo"]
-            logits = self.a2c_network.eval_disc(torch.cat([a, r, d], dim=0)).float()
-            la, lr_, ld = torch.split(logits, [a.shape[0], r.shape[0], d.shape[0]], dim=0)
+        a, r, d = input_dict["amp_obs"], input_dict["amp_obs_replay"], input_dict["amp_obs_demo"]
+        logits = self.a2c_network.eval_disc(torch.cat([a, r, d], dim=0)).float()
+        la, lr_, ld = torch.split(logits, [a.shape[0], r.shape[0], d.shape[0]], dim=0)
         return {"mu": mu, "value": value, "logstd": logstd[0] if logstd.dim() == 2 else logstd, "disc_agent_logit": la,
                 "disc_agent_replay_logit": lr_, "disc_demo_logit": ld}
 
