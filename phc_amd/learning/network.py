@@ -204,6 +204,8 @@ class ModelAMPContinuous(nn.Module):
         mu, logstd = self.a2c_network.eval_actor(obs)
         value = self.a2c_network.eval_critic(obs)
         a, r, d = input_dict["amp_obs"], input_dict["amp_obs_replay"], input_dict["amp_obs_demo"]
+        # one discriminator pass over [agent; replay; demo] (the reference runs three, amp_models.py:40-48); a separate demo pass would
+        # shrink the gradient penalty's double backward to a third of the rows but adds nine launches: no gain measured (scripts/gpu_ab.sh)
         logits = self.a2c_network.eval_disc(torch.cat([a, r, d], dim=0)).float()
         la, lr_, ld = torch.split(logits, [a.shape[0], r.shape[0], d.shape[0]], dim=0)
         return {"mu": mu, "value": value, "logstd": logstd[0] if logstd.dim() == 2 else logstd, "disc_agent_logit": la,
