@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PHC_ABI_VERSION 12
+#define PHC_ABI_VERSION 13
 #define PHC_MAX_BODIES 64   /* bodies (incl. extended reference bodies) per articulation; also the slot count of the model tables */
 #define PHC_EINVAL (-1)
 #define PHC_EUNSUPPORTED (-2)
@@ -285,11 +285,13 @@ int32_t phc_colsum_bf16(const void* x, int64_t rows, int32_t cols, float* out, f
  * then `optimizer.step()` with torch.optim.Adam): grad *= min(1, max_norm / (|grad| + 1e-6)) in place (max_norm <= 0: no clipping),
  * then Adam with L2 weight decay; `step` is the 1-based step count (bias corrections computed on the host in fp64).
  * grad_norm_out (optional, device) receives |grad| before clipping; param_bf16 (optional, [n] bf16) receives the updated parameter
- * rounded to bf16 -- the copy the next step's GEMMs read.  workspace: phc_adam_workspace() bytes. */
+ * rounded to bf16 -- the copy the next step's GEMMs read.  step_device (optional, device int64): incremented by one and used for the
+ * bias corrections instead of `step` -- for launches replayed from a captured hipGraph, whose by-value arguments are frozen.
+ * workspace: phc_adam_workspace() bytes. */
 int64_t phc_adam_workspace(void);
 int32_t phc_adam_clip_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
                            float eps, float weight_decay, int64_t step, float max_norm, double* workspace, float* grad_norm_out,
-                           void* param_bf16, void* stream);
+                           void* param_bf16, int64_t* step_device, void* stream);
 
 /* P8: actor + critic part of the PPO loss and its gradient (phc/learning/amp_agent.py:598-640 with rl_games' neglogp, bound_loss
  * common_agent.py:512-520 and torch_ext.policy_kl), tensors on the device, value_size 1:

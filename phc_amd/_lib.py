@@ -94,7 +94,7 @@ _SIGNATURES = {
     "phc_colsum_workspace": ([c_i64, c_i32], c_i64),
     "phc_colsum_bf16": ([c_p, c_i64, c_i32, c_p, c_p, c_p], c_i32),
     "phc_adam_workspace": ([], c_i64),
-    "phc_adam_clip_step": ([c_p, c_p, c_p, c_p, c_i64, c_f, c_f, c_f, c_f, c_f, c_i64, c_f, c_p, c_p, c_p, c_p], c_i32),
+    "phc_adam_clip_step": ([c_p, c_p, c_p, c_p, c_i64, c_f, c_f, c_f, c_f, c_f, c_i64, c_f, c_p, c_p, c_p, c_p, c_p], c_i32),
     "phc_ppo_loss_workspace": ([], c_i64),
     "phc_ppo_loss": ([c_p, c_p, c_i32] + [c_p] * 9 + [c_i64, c_i32, P(PpoParams), c_p, c_p, c_p, c_p, c_p], c_i32),
 }
@@ -116,7 +116,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the .so does not export the symbol
         fn.argtypes = argtypes
         fn.restype = restype
-    if lib.phc_abi_version() != 12:
+    if lib.phc_abi_version() != 13:
         raise ImportError("libphc_amd.so ABI version mismatch")
     _lib = lib
     return lib

@@ -134,8 +134,9 @@ __global__ __launch_bounds__(256) void k_colsum_finish(const float* __restrict__
 // ------------------------------------------------------------------------------------------
 #define AD_BLOCK 256
 #define AD_PER_THREAD 8
-__global__ __launch_bounds__(AD_BLOCK) void k_sumsq(const float* __restrict__ g, int64_t n, double* __restrict__ partial) {
+__global__ __launch_bounds__(AD_BLOCK) void k_sumsq(const float* __restrict__ g, int64_t n, double* __restrict__ partial, int64_t* __restrict__ step_dev) {
     __shared__ double l[AD_BLOCK / 64];
+    if (step_dev && blockIdx.x == 0 && threadIdx.x == 0) *step_dev += 1;   // device-resident step count (graph replays): read by k_adam
     const int64_t base = ((int64_t)blockIdx.x * AD_BLOCK + threadIdx.x) * 4;
     const int64_t stride = (int64_t)gridDim.x * AD_BLOCK * 4;
     float a = 0.f;
@@ -160,7 +161,13 @@ __global__ __launch_bounds__(AD_BLOCK) void k_sumsq(const float* __restrict__ g,
 __global__ __launch_bounds__(AD_BLOCK) void k_adam(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                                    int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay, float bias1,
                                                    float bias2_sqrt, float max_norm, const double* __restrict__ partial, int npartial,
-                                                   float* __restrict__ norm_out, __hip_bfloat16* __restrict__ shadow) {
+                                                   float* __restrict__ norm_out, __hip_bfloat16* __restrict__ shadow,
+                                                   const int64_t* __restrict__ step_dev) {
+    if (step_dev) {   // bias corrections from the device step count (the host-computed ones are baked into a captured graph)
+        const double t = (double)*step_dev;
+        bias1 = (float)(1.0 - pow((double)beta1, t));
+        bias2_sqrt = (float)sqrt(1.0 - pow((double)beta2, t));
+    }
     float coef = 1.f;
     if (max_norm > 0.f) {   // every block re-reduces the npartial (512) L2-resident partial sums: cheaper than a third launch
         __shared__ double l[AD_BLOCK / 64];
@@ -356,14 +363,16 @@ int32_t phc_colsum_bf16(const void* x, int64_t rows, int32_t cols, float* out, f
 int64_t phc_adam_workspace(void) { return AD_NORM_BLOCKS * (int64_t)sizeof(double); }
 
 int32_t phc_adam_clip_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2, float eps,
-                           float weight_decay, int64_t step, float max_norm, double* workspace, float* grad_norm_out, void* param_bf16, void* stream) {
-    if (!param || !grad || !exp_avg || !exp_avg_sq || n < 1 || step < 1 || (max_norm > 0.f && !workspace)) return PHC_EINVAL;
+                           float weight_decay, int64_t step, float max_norm, double* workspace, float* grad_norm_out, void* param_bf16,
+                           int64_t* step_device, void* stream) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq || n < 1 || (step < 1 && !step_device) || !workspace) return PHC_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    if (max_norm > 0.f) hipLaunchKernelGGL(k_sumsq, dim3(AD_NORM_BLOCKS), dim3(AD_BLOCK), 0, st, grad, n, workspace);
+    if (max_norm > 0.f || step_device) hipLaunchKernelGGL(k_sumsq, dim3(AD_NORM_BLOCKS), dim3(AD_BLOCK), 0, st, grad, n, workspace, step_device);
+    if (step < 1) step = 1;
     const double b1 = 1.0 - pow((double)beta1, (double)step), b2 = 1.0 - pow((double)beta2, (double)step);
     const int64_t blocks = (n + AD_BLOCK * 4 - 1) / (AD_BLOCK * 4);
     hipLaunchKernelGGL(k_adam, dim3((unsigned)blocks), dim3(AD_BLOCK), 0, st, param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay,
-                       (float)b1, (float)sqrt(b2), max_norm, workspace, AD_NORM_BLOCKS, grad_norm_out, (__hip_bfloat16*)param_bf16);
+                       (float)b1, (float)sqrt(b2), max_norm, workspace, AD_NORM_BLOCKS, grad_norm_out, (__hip_bfloat16*)param_bf16, step_device);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int32_t)e;
 }

@@ -192,6 +192,9 @@ class IMAmpAgent:
         self._amp_input_mean_std = RunningMeanStd((amp_dim,)).to(self.device) if self._normalize_amp_input else None
         self.running_mean_std_temp = None
         self.grads = FlatGradBucket(self.model.parameters())
+        self._use_graph = bool(c.get("hip_graph", True))
+        self._graph = self._g_data = self._g_idx = self._g_step = self._g_info = None
+        self._graph_failed = False
         # one flat fp32 parameter; on the device clip + step are two HIP launches over it (fast_ops.adam_clip_step) and this object
         # only holds the state (checkpoint format unchanged)
         self.optimizer = torch.optim.Adam([self.grads.flat_param], self.last_lr, eps=1e-08, weight_decay=c.get("weight_decay", 0.0))
@@ -456,15 +459,97 @@ class IMAmpAgent:
 
     def calc_gradients(self, d):
         """One optimizer step (amp_agent.py:554-688): forward/backward, the path's one collective -- the flat gradient
-        all-reduce, replacing `optimizer.synchronize()` (:667-668) -- then clip + Adam on the flat parameter.
-        (Capturing the step into hipGraphs was tried in round 1: no gain -- the step is GPU-bound by ~400 small
-        elementwise kernels, not launch-bound -- and `hipGraph` capture_end crashed at small batch sizes on ROCm 7.2.)"""
+        all-reduce, replacing `optimizer.synchronize()` (:667-668) -- then clip + Adam on the flat parameter."""
         self.set_train()
         d = self._amp_rows(d)
         info = self._fwd_bwd(d)
         self.grads.all_reduce_mean(self.dist)
         self._clip_and_step()
         return info
+
+    # ------------------------------------------------------------------ the optimizer step as a hipGraph
+    # With the loss, normaliser and optimizer kernels fused, a step is ~210 launches of 2.5 ms total device time and the host needs
+    # 2.7-3.9 ms to issue them (it varies with the box): launch-bound.  Single-GPU device runs therefore capture ONE step -- minibatch
+    # given by a row-index buffer into persistent dataset tensors, Adam's step count on the device -- and replay it 48 times per epoch.
+    def _graph_enabled(self):
+        return (self.grads.flat.is_cuda and self.world == 1 and self._use_graph and not self._graph_failed and self.minibatch_size >= 2048
+                and not os.environ.get("PHC_NO_GRAPH"))
+
+    def _graph_static_dataset(self):
+        """The dataset of this epoch behind fixed addresses (a captured graph keeps reading the same buffers)."""
+        if self._g_data is None:
+            # the tensors of the first graphed epoch BECOME the persistent buffers (the dict keeps them alive): rollout-buffer views
+            # keep their address from epoch to epoch and are never copied, per-epoch temporaries are copied into these
+            self._g_data = dict(self.dataset)
+        for k, v in self.dataset.items():
+            g = self._g_data[k]
+            if g.shape != v.shape:
+                raise RuntimeError("dataset shape changed under a captured update graph")
+            if g.data_ptr() != v.data_ptr():
+                g.copy_(v)
+        return self._g_data
+
+    def _graph_step_body(self):
+        info = self._fwd_bwd({"_dataset": self._g_data, "_idx": self._g_idx, "_amp_idx": self._g_idx[:self._amp_minibatch_size]})
+        adam_clip_step(self.optimizer, self.grads.flat_param, self.grads.flat, self.grad_norm if self.truncate_grads else None,
+                       shadow=self.grads.shadow, step_device=self._g_step, count_host=False)
+        self._g_keys = list(info)
+        self._g_info += torch.stack([info[k].float().reshape(()) for k in self._g_keys])
+
+    def _graph_update(self):
+        """All mini-epochs of one epoch through the captured step; returns the mean info dict (device tensors, no host sync)."""
+        self.set_train()
+        self._graph_static_dataset()
+        if self._g_idx is None:
+            self._g_idx = torch.zeros(self.minibatch_size, dtype=torch.int64, device=self.device)
+            self._g_step = torch.zeros((), dtype=torch.int64, device=self.device)
+            self._g_info = torch.zeros(len(self._probe_info_keys()), dtype=torch.float32, device=self.device)
+        st = self.optimizer.state[self.grads.flat_param]
+        if len(st) == 0:   # let the eager path create the optimizer state first
+            return None
+        self._g_step.fill_(int(st["step"].item()))
+        if self._graph is None:
+            self._g_idx.copy_(self._idx_buf[:self.minibatch_size])
+            # throw-away state for the warm-up steps torch asks for before a capture: parameters, optimizer and normaliser
+            # statistics are restored afterwards, so that capturing does not train
+            keep = [t.clone() for t in (self.grads.flat_param, st["exp_avg"], st["exp_avg_sq"])]
+            norms = [(m, [b.clone() for b in m.buffers()]) for m in self._norms()]
+            try:
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    for _ in range(2):
+                        self._graph_step_body()
+                torch.cuda.current_stream().wait_stream(side)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._graph_step_body()
+            finally:
+                for t, k in zip((self.grads.flat_param, st["exp_avg"], st["exp_avg_sq"]), keep):
+                    t.copy_(k)
+                for m, bufs in norms:
+                    for b, k in zip(m.buffers(), bufs):
+                        b.copy_(k)
+                self.grads.shadow.copy_(self.grads.flat_param)
+                self._g_step.fill_(int(st["step"].item()))
+            self._graph = g
+        self._g_info.zero_()
+        n = 0
+        for _ in range(self.mini_epochs_num):
+            for i in range(self.num_minibatches):
+                s, e = i * self.minibatch_size, (i + 1) * self.minibatch_size
+                self._g_idx.copy_(self._idx_buf[s:e])
+                if e >= self.batch_size:
+                    self._idx_buf[:] = torch.randperm(self.batch_size, device=self._idx_buf.device)
+                self._graph.replay()
+                st["step"] += 1
+                n += 1
+        mean = self._g_info / n
+        return {k: mean[j] for j, k in enumerate(self._g_keys)}
+
+    def _probe_info_keys(self):
+        return ["actor_loss", "critic_loss", "b_loss", "entropy", "kl", "disc_loss", "disc_grad_penalty", "disc_logit_loss", "disc_agent_acc",
+                "disc_demo_acc"]
 
     # ------------------------------------------------------------------ epoch (amp_agent.py:413-532)
     def _init_amp_demo_buf(self):
@@ -531,17 +616,27 @@ class IMAmpAgent:
         batch["amp_obs_replay"] = batch["amp_obs"] if self._amp_replay_buffer.get_total_count() == 0 else self._amp_replay_buffer.sample(n)["amp_obs"]
         self.set_train()
         self.prepare_dataset(batch)
-        infos = []
+        infos, ginfo = [], None
         with self.grads.shadow_scope():
-            for _ in range(self.mini_epochs_num):
-                for i in range(self.num_minibatches):
-                    infos.append(self.calc_gradients(self._get_item(i)))
+            if self._graph_enabled():
+                try:
+                    ginfo = self._graph_update()
+                except Exception as exc:   # capture not possible on this stack: eager launches from here on
+                    if self._graph is not None:
+                        raise
+                    self._graph_failed = True
+                    torch.cuda.synchronize()
+                    print(f"[phc_amd] update graph disabled ({type(exc).__name__}: {exc})", flush=True)
+            if ginfo is None:
+                for _ in range(self.mini_epochs_num):
+                    for i in range(self.num_minibatches):
+                        infos.append(self.calc_gradients(self._get_item(i)))
         self._store_replay_amp_obs(batch["amp_obs"])
         self.post_epoch(self.epoch_num)
         sync()
         t2 = time.time()
         self.frame += self.batch_size * self.world
-        info = {k: torch.stack([i[k] for i in infos]).mean().item() for k in infos[0]}
+        info = {k: v.item() for k, v in ginfo.items()} if ginfo is not None else {k: torch.stack([i[k] for i in infos]).mean().item() for k in infos[0]}
         info.update(play_time=t1 - t0, update_time=t2 - t1, total_time=t2 - t0, mean_task_reward=batch["rewards"].mean().item(),
                     mean_disc_reward=batch["disc_rewards"].mean().item(), reward_raw=batch["reward_raw"].tolist(),
                     step_fps=self.batch_size / (t1 - t0), total_fps=self.batch_size / (t2 - t0))  # common_agent.py:134-138

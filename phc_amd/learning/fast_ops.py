@@ -138,10 +138,12 @@ def ppo_loss(mu, value, logstd, actions, old_neglogp, adv, returns, old_values, 
     return _PPOLossFn.apply(mu, value, logstd, actions, old_neglogp, adv, returns, old_values if clip_value else None, old_mu, old_sigma, prm, unit_grad, row_index)
 
 
-def adam_clip_step(optimizer, flat_param, flat_grad, max_norm, shadow=None):
+def adam_clip_step(optimizer, flat_param, flat_grad, max_norm, shadow=None, step_device=None, count_host=True):
     """`clip_grad_norm_(max_norm)` (None / <= 0: no clipping) + `optimizer.step()` for a torch.optim.Adam that holds the single flat
     parameter, on the device: its state (`step`, `exp_avg`, `exp_avg_sq`) stays the optimizer's, so checkpoints are unchanged.
-    `shadow`: bf16 tensor of the same length that receives the updated parameter (FlatGradBucket.shadow_scope)."""
+    `shadow`: bf16 tensor of the same length that receives the updated parameter (FlatGradBucket.shadow_scope).
+    `step_device` (int64 device scalar): the kernels count the step there and derive the bias corrections from it -- the form a captured
+    graph needs; `count_host=False` leaves the optimizer's host-side `step` to the caller (one increment per replay)."""
     lib = L.load()
     group = optimizer.param_groups[0]
     assert len(optimizer.param_groups) == 1 and len(group["params"]) == 1 and group["params"][0] is flat_param
@@ -153,11 +155,13 @@ def adam_clip_step(optimizer, flat_param, flat_grad, max_norm, shadow=None):
         st["exp_avg_sq"] = torch.zeros_like(flat_param)
     if st["step"].is_cuda:   # state restored from a checkpoint written by a fused / capturable optimizer
         st["step"] = st["step"].detach().cpu()
-    st["step"] += 1
+    if count_host:
+        st["step"] += 1
     b1, b2 = group["betas"]
     ws = _workspace("adam", lib.phc_adam_workspace(), flat_param.device, torch.float64)
     L.check(lib.phc_adam_clip_step(flat_param.data_ptr(), flat_grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
                                    flat_param.numel(), float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]),
                                    int(st["step"].item()), float(max_norm) if max_norm else 0.0, ws.data_ptr(), None,
-                                   None if shadow is None else shadow.data_ptr(), _stream(flat_param.device)),
+                                   None if shadow is None else shadow.data_ptr(), None if step_device is None else step_device.data_ptr(),
+                                   _stream(flat_param.device)),
             "phc_adam_clip_step")
