@@ -192,7 +192,9 @@ class IMAmpAgent:
         self._amp_input_mean_std = RunningMeanStd((amp_dim,)).to(self.device) if self._normalize_amp_input else None
         self.running_mean_std_temp = None
         self.grads = FlatGradBucket(self.model.parameters())
-        self._use_graph = bool(c.get("hip_graph", True))
+        # opt-in (`learning.params.config.hip_graph=True`, bench.py sets it): capture works in plain processes at every size tried
+        # (scripts/graph_probe.py, graph_bisect.py) but `hipStreamEndCapture` segfaults inside pytest-hosted processes on ROCm 7.2
+        self._use_graph = bool(c.get("hip_graph", False))
         self._graph = self._g_data = self._g_idx = self._g_step = self._g_info = None
         self._graph_failed = False
         # one flat fp32 parameter; on the device clip + step are two HIP launches over it (fast_ops.adam_clip_step) and this object
@@ -480,7 +482,10 @@ class IMAmpAgent:
         if self._g_data is None:
             # the tensors of the first graphed epoch BECOME the persistent buffers (the dict keeps them alive): rollout-buffer views
             # keep their address from epoch to epoch and are never copied, per-epoch temporaries are copied into these
-            self._g_data = dict(self.dataset)
+            self._g_data, seen = {}, set()
+            for k, v in self.dataset.items():   # (two keys may share one tensor: the replay batch IS the agent batch while the buffer is empty)
+                self._g_data[k] = v.clone() if v.data_ptr() in seen else v
+                seen.add(v.data_ptr())
         for k, v in self.dataset.items():
             g = self._g_data[k]
             if g.shape != v.shape:

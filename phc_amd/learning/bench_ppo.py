@@ -12,6 +12,8 @@ def time_ppo_epochs(task, env, cfg, epochs, dist=None, warmup=1):
     # bench-sized replay buffers: the 200k x 1960 fp32 buffers of the shipped yaml are kept (1.57 GB each, HBM is 288 GB)
     agent = IMAmpAgent(env, cfg, dist=dist)
     agent.init_train()
+    if agent._graph_enabled():
+        warmup = max(warmup, 2)   # epoch 1 creates the optimizer state eagerly, epoch 2 captures the update graph
     for _ in range(warmup):
         agent.train_epoch()
     if dist is not None:
@@ -34,4 +36,5 @@ def time_ppo_epochs(task, env, cfg, epochs, dist=None, warmup=1):
             "ppo_play_ms": 1e3 * sum(i["play_time"] for i in infos) / epochs, "ppo_update_ms": 1e3 * sum(i["update_time"] for i in infos) / epochs,
             "ppo_config": {"horizon": agent.horizon_length, "batch_per_gpu": agent.batch_size, "minibatch": agent.minibatch_size,
                            "optimizer_steps_per_epoch": n_opt, "gemm_dtype": "bf16" if agent.bf16 else "f32",
-                           "grad_allreduce_bytes": int(agent.grads.flat.numel() * 4), "collectives_per_epoch": n_opt if world > 1 else 0}}
+                           "grad_allreduce_bytes": int(agent.grads.flat.numel() * 4), "collectives_per_epoch": n_opt if world > 1 else 0,
+                           "update_graph": agent._graph is not None}}
