@@ -611,7 +611,7 @@ class IMAmpAgent:
         sync = torch.cuda.synchronize if str(self.device).startswith("cuda") else (lambda: None)
         sync()
         t0 = time.time()
-        with torch.no_grad():
+        with torch.no_grad(), self.grads.shadow_scope():   # rollout inference reads the bf16 parameter copies
             batch = self.play_steps()
         sync()
         t1 = time.time()

@@ -90,6 +90,10 @@ class FastLinear(nn.Linear):
         if (x.is_cuda and x.dim() == 2 and torch.is_grad_enabled() and self.weight.requires_grad and self.bias is not None
                 and torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16 and x.is_contiguous()):
             return _LinearFn.apply(x, self.weight, self.bias)
+        live = getattr(self.weight, "_shadow_live", None)
+        if live is not None and live[0] and x.is_cuda and x.dtype == torch.bfloat16 and not torch.is_grad_enabled() and self.bias is not None:
+            # rollout inference inside FlatGradBucket.shadow_scope(): the bf16 parameter copies are current, no per-call casts
+            return nn.functional.linear(x, self.weight._bf16_shadow, self.bias._bf16_shadow)
         return nn.functional.linear(x, self.weight, self.bias)
 
 
