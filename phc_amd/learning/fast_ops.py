@@ -85,6 +85,79 @@ class _LinearFn(torch.autograd.Function):
         return gx, gw, gb
 
 
+def _bf16_params(weight, bias):
+    live = getattr(weight, "_shadow_live", None)
+    if live is not None and live[0]:
+        return weight._bf16_shadow, bias._bf16_shadow
+    return weight.to(torch.bfloat16), bias.to(torch.bfloat16)
+
+
+class _LinearDDFn(torch.autograd.Function):
+    """The same layer for the discriminator, whose gradient penalty differentiates the backward pass (create_graph=True): the
+    backward is itself an autograd node (`_LinearDDBwdFn`) with an explicit second-order rule, so both the first- and the
+    second-order weight gradients -- four reductions over the 12 288-row batch per step -- run as split-K batched GEMMs."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        wb, bb = _bf16_params(weight, bias)
+        ctx.save_for_backward(x, weight, bias)
+        return torch.addmm(bb, x.to(torch.bfloat16), wb.t())
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, bias = ctx.saved_tensors
+        gx, gw, gb = _LinearDDBwdFn.apply(gy, x, weight, bias, ctx.needs_input_grad[0])
+        return gx if ctx.needs_input_grad[0] else None, gw, gb
+
+
+class _LinearDDBwdFn(torch.autograd.Function):
+    """(gy, x, W) -> gx = gy W, gW = gy^T x, gb = 1^T gy; its own backward for cotangents (ggx, ggW, ggb):
+    d gy = ggx W^T + x ggW^T + ggb,  d x = gy ggW,  d W = gy^T ggx."""
+
+    @staticmethod
+    def forward(ctx, gy, x, weight, bias, need_gx):
+        gy = gy.contiguous()
+        xb = x.to(torch.bfloat16)
+        wb, _ = _bf16_params(weight, bias)
+        ctx.save_for_backward(gy, xb, wb)
+        ctx.x_dtype, ctx.need_gx = x.dtype, need_gx
+        gx = (gy @ wb).to(x.dtype) if need_gx else gy.new_zeros(())
+        return gx, wgrad_split_k(gy, xb), colsum_bf16(gy)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, ggx, ggw, ggb):
+        gy, xb, wb = ctx.saved_tensors
+        d_gy = d_x = d_w = None
+        if ggx is not None and ctx.need_gx:
+            ggx = ggx.to(torch.bfloat16).contiguous()
+            d_gy = ggx @ wb.t()
+            d_w = wgrad_split_k(gy, ggx)
+        if ggw is not None:
+            gwb = ggw.to(torch.bfloat16)
+            t = xb @ gwb.t()
+            d_gy = t if d_gy is None else d_gy + t
+            d_x = (gy @ gwb).to(ctx.x_dtype)
+        if ggb is not None:
+            t = ggb.to(torch.bfloat16).expand_as(gy)
+            d_gy = t if d_gy is None else d_gy + t
+        return d_gy, d_x, d_w, None, None
+
+
+def _device_training_pass(mod, x):
+    return (x.is_cuda and x.dim() == 2 and torch.is_grad_enabled() and mod.weight.requires_grad and mod.bias is not None
+            and torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16 and x.is_contiguous())
+
+
+class FastLinearDD(nn.Linear):
+    """nn.Linear for layers that are differentiated twice (the discriminator MLP): see _LinearDDFn."""
+
+    def forward(self, x):
+        if _device_training_pass(self, x):
+            return _LinearDDFn.apply(x, self.weight, self.bias)
+        return nn.functional.linear(x, self.weight, self.bias)
+
+
 class FastLinear(nn.Linear):
     def forward(self, x):
         if (x.is_cuda and x.dim() == 2 and torch.is_grad_enabled() and self.weight.requires_grad and self.bias is not None

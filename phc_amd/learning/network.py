@@ -14,7 +14,7 @@ import math
 import torch
 from torch import nn
 
-from .fast_ops import FastLinear
+from .fast_ops import FastLinear, FastLinearDD
 
 DISC_LOGIT_INIT_SCALE = 1.0  # amp_network_builder.py:12
 
@@ -44,7 +44,7 @@ class A2CNetwork(nn.Module):
         self.value = FastLinear(self.units[-1], value_size)
         self.mu = FastLinear(self.units[-1], actions_num)
         self.sigma = nn.Parameter(torch.full((actions_num,), float(space["sigma_init"]["val"]), dtype=torch.float32), requires_grad=False)
-        self._disc_mlp = build_mlp(amp_input_shape[0], list(disc["units"]), disc["activation"])
+        self._disc_mlp = build_mlp(amp_input_shape[0], list(disc["units"]), disc["activation"], FastLinearDD)
         self._disc_logits = nn.Linear(list(disc["units"])[-1], 1)
         # initializer "default" == torch's Linear default; biases of the discriminator zeroed, logit layer U(-1,1)
         for m in self._disc_mlp.modules():

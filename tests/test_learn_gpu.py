@@ -224,3 +224,45 @@ def test_row_index_variants_equal_gathered_inputs():
         outs.append((loss.detach(), st, m.grad, v.grad))
     for p, q in zip(*outs):
         assert torch.equal(p, q)
+
+
+def test_twice_differentiable_linear_matches_autograd():
+    """FastLinearDD (discriminator MLP): loss + gradient penalty -- which differentiates the backward pass -- give the same parameter
+    gradients as nn.Linear under bf16 autocast, within bf16 GEMM accuracy of the fp64 result."""
+    from phc_amd.learning.fast_ops import FastLinearDD
+    torch.manual_seed(3)
+    B, m, K = 6144, 2048, 1960
+
+    def build(linear, dtype=torch.float32):
+        net = torch.nn.Sequential(linear(K, 1024), torch.nn.ReLU(), linear(1024, 512), torch.nn.ReLU(), torch.nn.Linear(512, 1)).cuda().to(dtype)
+        return net
+    ref = build(torch.nn.Linear)
+    fast = build(FastLinearDD)
+    fast.load_state_dict(ref.state_dict())
+    ref64 = build(torch.nn.Linear, torch.float64)
+    ref64.load_state_dict(ref.state_dict())
+    xa = (torch.randn(B - m, K, device="cuda") * 0.5).to(torch.bfloat16)
+    xd = (torch.randn(m, K, device="cuda") * 0.5).to(torch.bfloat16)
+
+    def run(net, f64=False):
+        d = (xd.double() if f64 else xd.clone()).requires_grad_(True)
+        a = xa.double() if f64 else xa
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=not f64):
+            lg = net(torch.cat([a, d], 0))
+        lg = lg if f64 else lg.float()
+        la, ld = lg[:B - m], lg[B - m:]
+        bce = torch.nn.BCEWithLogitsLoss()
+        loss = 0.5 * (bce(la, torch.zeros_like(la)) + bce(ld, torch.ones_like(ld)))
+        g = torch.autograd.grad(ld, d, grad_outputs=torch.ones_like(ld), create_graph=True, retain_graph=True)[0]
+        g = g if f64 else g.float()
+        pen = g.square().sum(-1).mean()
+        (loss + 5.0 * pen).backward()
+        return float(loss), float(pen), [p.grad.double().clone() for p in net.parameters()]
+    l64, p64, g64 = run(ref64, True)
+    lr_, pr, gr = run(ref)
+    lf, pf, gf = run(fast)
+    assert abs(lf - lr_) < 1e-6 and abs(pf - pr) <= 2e-3 * abs(pr) + 1e-9, (lf, lr_, pf, pr)
+    for k, (a, b, e) in enumerate(zip(gf, gr, g64)):
+        scale = e.abs().max().item() + 1e-12
+        ef, er = (a - e).abs().max().item() / scale, (b - e).abs().max().item() / scale
+        assert ef < 3e-2 and ef <= 1.5 * er + 2e-3, (k, ef, er)
