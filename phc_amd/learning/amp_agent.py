@@ -33,7 +33,7 @@ from torch import nn
 from .. import _lib as L
 from .network import A2CMCPNetwork, A2CNetwork, A2CPNNNetwork, ModelAMPContinuous, policy_kl
 from .replay_buffer import ReplayBuffer
-from .fast_ops import adam_clip_step, ppo_loss
+from .fast_ops import adam_clip_step, input_grad_only, ppo_loss
 from .running_mean_std import RunningMeanStd
 
 
@@ -380,8 +380,9 @@ class IMAmpAgent:
         net = self.model.a2c_network
         disc_logit_loss = torch.sum(torch.square(net.get_disc_logit_weights()))
         disc_loss = disc_loss + self._disc_logit_reg * disc_logit_loss
-        grad = torch.autograd.grad(disc_demo_logit, obs_demo, grad_outputs=torch.ones_like(disc_demo_logit), create_graph=True,
-                                   retain_graph=True, only_inputs=True)[0].float()   # bf16 leaf (device normaliser output): penalty in fp32
+        with input_grad_only():
+            grad = torch.autograd.grad(disc_demo_logit, obs_demo, grad_outputs=torch.ones_like(disc_demo_logit), create_graph=True,
+                                       retain_graph=True, only_inputs=True)[0].float()   # bf16 leaf (device normaliser output): penalty in fp32
         disc_grad_penalty = torch.mean(torch.sum(torch.square(grad), dim=-1))
         disc_loss = disc_loss + self._disc_grad_penalty * disc_grad_penalty
         if self._disc_weight_decay != 0:

@@ -11,6 +11,7 @@ It is used for the actor and critic (amp_agent.py:554-655); the discriminator ke
 differentiates the backward pass itself (create_graph=True).  Anywhere else (CPU, fp32, no_grad rollouts, frozen columns) it is
 exactly nn.Linear.  `adam_clip_step` = clip_grad_norm_ + torch.optim.Adam.step on the flat parameter in two launches."""
 import ctypes as C
+import os
 
 import torch
 from torch import nn
@@ -92,6 +93,21 @@ def _bf16_params(weight, bias):
     return weight.to(torch.bfloat16), bias.to(torch.bfloat16)
 
 
+_INPUT_GRAD_ONLY = [False]
+
+
+class input_grad_only:
+    """Context for a `torch.autograd.grad(outputs, inputs=<activations>)` call (the gradient penalty): tells the twice-differentiable
+    layers that no parameter gradient is asked for -- a custom Function cannot see which of its gradients the engine needs, and
+    computing the weight / bias gradients there cost 10 ms per update.  (Module-level flag: the backward runs on the autograd thread.)"""
+
+    def __enter__(self):
+        _INPUT_GRAD_ONLY[0] = True
+
+    def __exit__(self, *a):
+        _INPUT_GRAD_ONLY[0] = False
+
+
 class _LinearDDFn(torch.autograd.Function):
     """The same layer for the discriminator, whose gradient penalty differentiates the backward pass (create_graph=True): the
     backward is itself an autograd node (`_LinearDDBwdFn`) with an explicit second-order rule, so both the first- and the
@@ -106,8 +122,9 @@ class _LinearDDFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         x, weight, bias = ctx.saved_tensors
-        gx, gw, gb = _LinearDDBwdFn.apply(gy, x, weight, bias, ctx.needs_input_grad[0])
-        return gx if ctx.needs_input_grad[0] else None, gw, gb
+        only_x = _INPUT_GRAD_ONLY[0]
+        gx, gw, gb = _LinearDDBwdFn.apply(gy, x, weight, bias, ctx.needs_input_grad[0], only_x)
+        return gx if ctx.needs_input_grad[0] else None, None if only_x else gw, None if only_x else gb
 
 
 class _LinearDDBwdFn(torch.autograd.Function):
@@ -115,13 +132,15 @@ class _LinearDDBwdFn(torch.autograd.Function):
     d gy = ggx W^T + x ggW^T + ggb,  d x = gy ggW,  d W = gy^T ggx."""
 
     @staticmethod
-    def forward(ctx, gy, x, weight, bias, need_gx):
+    def forward(ctx, gy, x, weight, bias, need_gx, only_x):
         gy = gy.contiguous()
         xb = x.to(torch.bfloat16)
         wb, _ = _bf16_params(weight, bias)
         ctx.save_for_backward(gy, xb, wb)
         ctx.x_dtype, ctx.need_gx = x.dtype, need_gx
         gx = (gy @ wb).to(x.dtype) if need_gx else gy.new_zeros(())
+        if only_x:
+            return gx, gy.new_zeros(()), gy.new_zeros(())
         return gx, wgrad_split_k(gy, xb), colsum_bf16(gy)
 
     @staticmethod
@@ -141,7 +160,7 @@ class _LinearDDBwdFn(torch.autograd.Function):
         if ggb is not None:
             t = ggb.to(torch.bfloat16).expand_as(gy)
             d_gy = t if d_gy is None else d_gy + t
-        return d_gy, d_x, d_w, None, None
+        return d_gy, d_x, d_w, None, None, None
 
 
 def _device_training_pass(mod, x):
@@ -153,7 +172,7 @@ class FastLinearDD(nn.Linear):
     """nn.Linear for layers that are differentiated twice (the discriminator MLP): see _LinearDDFn."""
 
     def forward(self, x):
-        if _device_training_pass(self, x):
+        if _device_training_pass(self, x) and not os.environ.get("PHC_DISC_PLAIN"):
             return _LinearDDFn.apply(x, self.weight, self.bias)
         return nn.functional.linear(x, self.weight, self.bias)
 

