@@ -137,7 +137,8 @@ class _LinearDDBwdFn(torch.autograd.Function):
         xb = x.to(torch.bfloat16)
         wb, _ = _bf16_params(weight, bias)
         ctx.save_for_backward(gy, xb, wb)
-        ctx.x_dtype, ctx.need_gx = x.dtype, need_gx
+        ctx.x_dtype, ctx.need_gx, ctx.only_x = x.dtype, need_gx, only_x
+        ctx.set_materialize_grads(False)   # cotangents nobody produced arrive as None, not as zeros
         gx = (gy @ wb).to(x.dtype) if need_gx else gy.new_zeros(())
         if only_x:
             return gx, gy.new_zeros(()), gy.new_zeros(())
@@ -148,6 +149,8 @@ class _LinearDDBwdFn(torch.autograd.Function):
     def backward(ctx, ggx, ggw, ggb):
         gy, xb, wb = ctx.saved_tensors
         d_gy = d_x = d_w = None
+        if ctx.only_x:   # the weight / bias outputs were placeholders
+            ggw = ggb = None
         if ggx is not None and ctx.need_gx:
             ggx = ggx.to(torch.bfloat16).contiguous()
             d_gy = ggx @ wb.t()
