@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PHC_ABI_VERSION 13
+#define PHC_ABI_VERSION 14
 #define PHC_MAX_BODIES 64   /* bodies (incl. extended reference bodies) per articulation; also the slot count of the model tables */
 #define PHC_EINVAL (-1)
 #define PHC_EUNSUPPORTED (-2)
@@ -280,6 +280,13 @@ int32_t phc_running_norm(const float* x, const int64_t* row_index, int64_t rows,
  * the output gradient, AddmmBackward).  workspace: phc_colsum_workspace(rows, cols) bytes. */
 int64_t phc_colsum_workspace(int64_t rows, int32_t cols);
 int32_t phc_colsum_bf16(const void* x, int64_t rows, int32_t cols, float* out, float* workspace, void* stream);
+
+/* Linear layer with one output (the value head `a2c_network.value`, 512 -> 1), bf16: y [rows] = x [rows, cols] w [cols] + b[0];
+ * backward: gx [rows, cols] = gy w^T (optional), gw_gb fp32 [cols + 1] = (gy^T x, sum gy).  workspace: phc_linear1_workspace(). */
+int64_t phc_linear1_workspace(int64_t rows, int32_t cols);
+int32_t phc_linear1_forward(const void* x, const void* w, const void* b, int64_t rows, int32_t cols, void* y, void* stream);
+int32_t phc_linear1_backward(const void* x, const void* w, const void* gy, int64_t rows, int32_t cols, void* gx, float* gw_gb,
+                             float* workspace, void* stream);
 
 /* P9: gradient clipping + optimizer step on the flat fp32 parameter (phc/learning/amp_agent.py:669-676: `clip_grad_norm_(grad_norm)`
  * then `optimizer.step()` with torch.optim.Adam): grad *= min(1, max_norm / (|grad| + 1e-6)) in place (max_norm <= 0: no clipping),

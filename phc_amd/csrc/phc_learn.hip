@@ -9,6 +9,12 @@
 #include <stdint.h>
 #include "../../include/phc_amd.h"
 
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
 #define RN_COLS 256   // columns per block == threads per block (thread <-> column: loads coalesce across the block)
 #define RN_ROWS 128   // rows per block
 #define RN_UNROLL 8   // independent loads in flight per thread
@@ -128,6 +134,44 @@ __global__ __launch_bounds__(256) void k_colsum_finish(const float* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------
+// Linear layer with ONE output (the value head, 512 -> 1): as library GEMMs its forward, input gradient and weight gradient are
+// three 1-row / 1-column problems of 40-50 us each; they are a dot product per row, a scaled copy and a weighted column sum.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_linear1_fwd(const __hip_bfloat16* __restrict__ x, const __hip_bfloat16* __restrict__ w,
+                                                     const __hip_bfloat16* __restrict__ b, int64_t rows, int cols, __hip_bfloat16* __restrict__ y) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    float a = 0.f;
+    for (int k = lane; k < cols; k += 64) a += __bfloat162float(x[r * cols + k]) * __bfloat162float(w[k]);
+    a = wave_sum(a);
+    if (lane == 0) y[r] = __float2bfloat16(a + __bfloat162float(b[0]));
+}
+#define L1_ROWS 64
+// gx[r, k] = gy[r] w[k] (optional) and per-chunk partial sums of gy[r] x[r, k] (columns 0..cols-1) and gy[r] (column `cols`)
+__global__ __launch_bounds__(256) void k_linear1_bwd(const __hip_bfloat16* __restrict__ x, const __hip_bfloat16* __restrict__ w,
+                                                     const __hip_bfloat16* __restrict__ gy, int64_t rows, int cols,
+                                                     __hip_bfloat16* __restrict__ gx, float* __restrict__ partial) {
+    const int64_t r0 = (int64_t)blockIdx.x * L1_ROWS;
+    const int64_t r1 = r0 + L1_ROWS < rows ? r0 + L1_ROWS : rows;
+    for (int k = threadIdx.x; k < cols; k += 256) {
+        const float wk = __bfloat162float(w[k]);
+        float a = 0.f;
+        for (int64_t r = r0; r < r1; ++r) {
+            const float g = __bfloat162float(gy[r]);
+            a += g * __bfloat162float(x[r * cols + k]);
+            if (gx) gx[r * cols + k] = __float2bfloat16(g * wk);
+        }
+        partial[(int64_t)blockIdx.x * (cols + 1) + k] = a;
+    }
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (int64_t r = r0; r < r1; ++r) s += __bfloat162float(gy[r]);
+        partial[(int64_t)blockIdx.x * (cols + 1) + cols] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // clip_grad_norm_ + Adam on the flat fp32 parameter (FlatGradBucket): torch.nn.utils.clip_grad_norm_ (coefficient
 // min(1, max_norm / (|g| + 1e-6))) followed by torch.optim.Adam's update (L2 weight decay, bias corrections, eps outside the
 // square root of the corrected second moment) -- two launches over 4 arrays instead of norm + scale + fused multi-tensor Adam.
@@ -218,11 +262,6 @@ template <typename T> __device__ __forceinline__ void st_f(T* p, int64_t i, floa
 template <> __device__ __forceinline__ void st_f<float>(float* p, int64_t i, float v) { p[i] = v; }
 template <> __device__ __forceinline__ void st_f<__hip_bfloat16>(__hip_bfloat16* p, int64_t i, float v) { p[i] = __float2bfloat16(v); }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-    return v;
-}
 
 #define PPO_NSUM 4   // a_loss, c_loss, b_loss, kl
 template <typename T>
@@ -355,6 +394,28 @@ int32_t phc_colsum_bf16(const void* x, int64_t rows, int32_t cols, float* out, f
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_colsum_bf16, dim3((cols + 63) / 64, (unsigned)nchunks), dim3(256), 0, st, reinterpret_cast<const __hip_bfloat16*>(x), rows, cols, workspace);
     hipLaunchKernelGGL(k_colsum_finish, dim3((cols + 63) / 64), dim3(256), 0, st, workspace, (int)nchunks, cols, out);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int32_t)e;
+}
+
+int64_t phc_linear1_workspace(int64_t rows, int32_t cols) { return ((rows + L1_ROWS - 1) / L1_ROWS) * (int64_t)(cols + 1) * (int64_t)sizeof(float); }
+
+int32_t phc_linear1_forward(const void* x, const void* w, const void* b, int64_t rows, int32_t cols, void* y, void* stream) {
+    if (!x || !w || !b || !y || rows < 1 || cols < 1) return PHC_EINVAL;
+    hipLaunchKernelGGL(k_linear1_fwd, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const __hip_bfloat16*)x, (const __hip_bfloat16*)w,
+                       (const __hip_bfloat16*)b, rows, cols, (__hip_bfloat16*)y);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int32_t)e;
+}
+
+int32_t phc_linear1_backward(const void* x, const void* w, const void* gy, int64_t rows, int32_t cols, void* gx, float* gw_gb, float* workspace,
+                             void* stream) {
+    if (!x || !w || !gy || !gw_gb || !workspace || rows < 1 || cols < 1) return PHC_EINVAL;
+    const int64_t nchunks = (rows + L1_ROWS - 1) / L1_ROWS;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_linear1_bwd, dim3((unsigned)nchunks), dim3(256), 0, st, (const __hip_bfloat16*)x, (const __hip_bfloat16*)w, (const __hip_bfloat16*)gy,
+                       rows, cols, (__hip_bfloat16*)gx, workspace);
+    hipLaunchKernelGGL(k_colsum_finish, dim3((cols + 1 + 63) / 64), dim3(256), 0, st, workspace, (int)nchunks, cols + 1, gw_gb);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int32_t)e;
 }

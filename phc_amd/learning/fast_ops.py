@@ -175,13 +175,53 @@ class FastLinearDD(nn.Linear):
     """nn.Linear for layers that are differentiated twice (the discriminator MLP): see _LinearDDFn."""
 
     def forward(self, x):
-        if _device_training_pass(self, x) and not os.environ.get("PHC_DISC_PLAIN"):
+        if _device_training_pass(self, x):
             return _LinearDDFn.apply(x, self.weight, self.bias)
         return nn.functional.linear(x, self.weight, self.bias)
 
 
+def _linear1_forward(xb, wb, bb):
+    lib = L.load()
+    rows, cols = xb.shape
+    y = torch.empty((rows, 1), dtype=torch.bfloat16, device=xb.device)
+    L.check(lib.phc_linear1_forward(xb.data_ptr(), wb.data_ptr(), bb.data_ptr(), rows, cols, y.data_ptr(), _stream(xb.device)), "phc_linear1_forward")
+    return y
+
+
+class _Linear1Fn(torch.autograd.Function):
+    """FastLinear with a single output (the value head): dot product per row, scaled copy, weighted column sum (phc_linear1_*)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        xb = x.to(torch.bfloat16)
+        wb, bb = _bf16_params(weight, bias)
+        ctx.save_for_backward(xb, wb)
+        ctx.x_dtype = x.dtype
+        return _linear1_forward(xb, wb, bb)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        xb, wb = ctx.saved_tensors
+        lib = L.load()
+        rows, cols = xb.shape
+        gy = gy.contiguous()
+        gx = torch.empty_like(xb) if ctx.needs_input_grad[0] else None
+        gwb = torch.empty(cols + 1, dtype=torch.float32, device=xb.device)
+        ws = _workspace("lin1", lib.phc_linear1_workspace(rows, cols), xb.device, torch.float32)
+        L.check(lib.phc_linear1_backward(xb.data_ptr(), wb.data_ptr(), gy.data_ptr(), rows, cols, None if gx is None else gx.data_ptr(), gwb.data_ptr(),
+                                         ws.data_ptr(), _stream(xb.device)), "phc_linear1_backward")
+        return (gx.to(ctx.x_dtype) if gx is not None else None), gwb[:cols].view(1, cols), gwb[cols:]
+
+
 class FastLinear(nn.Linear):
     def forward(self, x):
+        if self.out_features == 1 and x.is_cuda and x.dim() == 2 and x.dtype == torch.bfloat16 and x.is_contiguous() and self.bias is not None:
+            if _device_training_pass(self, x):
+                return _Linear1Fn.apply(x, self.weight, self.bias)
+            live = getattr(self.weight, "_shadow_live", None)
+            if not torch.is_grad_enabled() and live is not None and live[0]:
+                return _linear1_forward(x, self.weight._bf16_shadow, self.bias._bf16_shadow)
         if (x.is_cuda and x.dim() == 2 and torch.is_grad_enabled() and self.weight.requires_grad and self.bias is not None
                 and torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16 and x.is_contiguous()):
             return _LinearFn.apply(x, self.weight, self.bias)

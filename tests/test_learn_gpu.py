@@ -268,3 +268,28 @@ def test_twice_differentiable_linear_matches_autograd():
         scale = e.abs().max().item() + 1e-12
         ef, er = (a - e).abs().max().item() / scale, (b - e).abs().max().item() / scale
         assert ef < 0.1 and ef <= 1.5 * er + 2e-3, (k, ef, er)   # er: what stock autograd's bf16 path achieves (~5 % on the small bias gradients)
+
+
+def test_one_output_linear_kernels():
+    """FastLinear with out_features == 1 (the value head): phc_linear1_forward / _backward == nn.Linear under bf16 autocast."""
+    from phc_amd.learning.fast_ops import FastLinear
+    torch.manual_seed(5)
+    B, K = 5000, 512
+    ref, fast = torch.nn.Linear(K, 1).cuda(), FastLinear(K, 1).cuda()
+    fast.load_state_dict(ref.state_dict())
+    x = torch.randn(B, K, device="cuda").to(torch.bfloat16)
+    gy = torch.randn(B, 1, device="cuda") / B
+    outs = {}
+    for name, mod in (("ref", ref), ("fast", fast)):
+        xi = x.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = mod(xi)
+        (y.float() * gy).sum().backward()
+        outs[name] = (y.float(), mod.weight.grad.clone(), mod.bias.grad.clone(), xi.grad.float().clone())
+    exact_y = x.double() @ ref.weight.double().t() + ref.bias.double()
+    assert (outs["fast"][0].double() - exact_y).abs().max() <= (outs["ref"][0].double() - exact_y).abs().max() + 2e-2
+    gw64, gb64, gx64 = gy.double().t() @ x.double(), gy.double().sum(0), gy.double() @ ref.weight.double()
+    for k, exact in ((1, gw64), (2, gb64), (3, gx64)):
+        scale = exact.abs().max().item()
+        e_fast, e_ref = ((outs[n][k].double() - exact).abs().max().item() / scale for n in ("fast", "ref"))
+        assert e_fast < 2e-2 and e_fast <= 1.5 * e_ref + 1e-3, (k, e_fast, e_ref)
