@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PHC_ABI_VERSION 14
+#define PHC_ABI_VERSION 15
 #define PHC_MAX_BODIES 64   /* bodies (incl. extended reference bodies) per articulation; also the slot count of the model tables */
 #define PHC_EINVAL (-1)
 #define PHC_EUNSUPPORTED (-2)
@@ -280,6 +280,15 @@ int32_t phc_running_norm(const float* x, const int64_t* row_index, int64_t rows,
  * the output gradient, AddmmBackward).  workspace: phc_colsum_workspace(rows, cols) bytes. */
 int64_t phc_colsum_workspace(int64_t rows, int32_t cols);
 int32_t phc_colsum_bf16(const void* x, int64_t rows, int32_t cols, float* out, float* workspace, void* stream);
+
+/* Rollout policy step (phc/learning/amp_agent.py:309-341 with rl_games' ModelA2CContinuousLogStd in eval mode), per env r:
+ *   actions = mu + exp(logstd) * noise, mus = mu, sigmas = exp(logstd), neglogp = neglogp(actions | mu, sigma)            (mu != NULL)
+ *   values[r] = unnorm(value[r]) = sqrt(float(value_var) + epsilon) * clamp(value[r], -5, 5) + float(value_mean)             (value != NULL;
+ *               value_mean == NULL: no un-normalisation), times (1 - mask[r]) when mask is given (next_values of terminated envs).
+ * mu [N, D] / value [N] are the network heads (bf16 when is_bf16, else fp32); outputs fp32 (rows of the experience buffer). */
+int32_t phc_policy_sample(const void* mu, const void* value, int32_t is_bf16, const float* logstd, const float* noise, const double* value_mean,
+                          const double* value_var, float epsilon, const float* mask, int64_t num_envs, int32_t num_actions, float* actions, float* mus,
+                          float* sigmas, float* neglogp, float* values, void* stream);
 
 /* Linear layer with one output (the value head `a2c_network.value`, 512 -> 1), bf16: y [rows] = x [rows, cols] w [cols] + b[0];
  * backward: gx [rows, cols] = gy w^T (optional), gw_gb fp32 [cols + 1] = (gy^T x, sum gy).  workspace: phc_linear1_workspace(). */

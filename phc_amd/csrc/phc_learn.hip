@@ -357,6 +357,41 @@ __global__ __launch_bounds__(256) void k_ppo_loss_finish(const double* __restric
     stats[0] = (float)l[0] + prm.critic_coef * (float)l[1] - prm.entropy_coef * ent + prm.bounds_loss_coef * (float)l[2];
 }
 
+// ------------------------------------------------------------------------------------------
+// Rollout: sample the action and everything the experience buffer stores about it in one pass (amp_agent.py:309-341 `play_steps` /
+// rl_games ModelA2CContinuousLogStd in eval mode): action = mu + sigma * noise, neglogp(action), sigma, and the critic's value
+// un-normalised (RunningMeanStd.forward(unnorm=True), running_mean_std.py:87-90) -- ~25 torch launches per rollout step otherwise.
+// One wavefront per env.  `mask` (optional): value *= 1 - mask[r]  (next_values of terminated envs, amp_agent.py:352-354).
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_policy_sample(const T* __restrict__ mu, const float* __restrict__ logstd, const float* __restrict__ noise,
+                                                       const T* __restrict__ value, const double* __restrict__ vmean, const double* __restrict__ vvar,
+                                                       float eps, const float* __restrict__ mask, int64_t N, int D, float* __restrict__ actions,
+                                                       float* __restrict__ mus, float* __restrict__ sigmas, float* __restrict__ neglogp,
+                                                       float* __restrict__ values) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= N) return;
+    if (mu) {
+        float s = 0.f, sl = 0.f;
+        for (int d = lane; d < D; d += 64) {
+            const float m = ld_f(mu, r * D + d), ls = logstd[d], sg = expf(ls);
+            const float a = m + sg * noise[r * D + d];
+            const float z = (a - m) / sg;
+            s += z * z; sl += ls;
+            actions[r * D + d] = a; mus[r * D + d] = m; sigmas[r * D + d] = sg;
+        }
+        s = wave_sum(s); sl = wave_sum(sl);
+        if (lane == 0) neglogp[r] = 0.5f * s + 0.5f * 1.8378770664093453f * (float)D + sl;
+    }
+    if (lane == 0 && value) {
+        float v = ld_f(value, r);
+        if (vmean) v = sqrtf((float)vvar[0] + eps) * fminf(fmaxf(v, -5.0f), 5.0f) + (float)vmean[0];
+        if (mask) v *= 1.0f - mask[r];
+        values[r] = v;
+    }
+}
+
 extern "C" {
 
 int64_t phc_running_norm_workspace(int64_t rows, int32_t cols) {
@@ -416,6 +451,23 @@ int32_t phc_linear1_backward(const void* x, const void* w, const void* gy, int64
     hipLaunchKernelGGL(k_linear1_bwd, dim3((unsigned)nchunks), dim3(256), 0, st, (const __hip_bfloat16*)x, (const __hip_bfloat16*)w, (const __hip_bfloat16*)gy,
                        rows, cols, (__hip_bfloat16*)gx, workspace);
     hipLaunchKernelGGL(k_colsum_finish, dim3((cols + 1 + 63) / 64), dim3(256), 0, st, workspace, (int)nchunks, cols + 1, gw_gb);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int32_t)e;
+}
+
+int32_t phc_policy_sample(const void* mu, const void* value, int32_t is_bf16, const float* logstd, const float* noise, const double* value_mean,
+                          const double* value_var, float epsilon, const float* mask, int64_t num_envs, int32_t num_actions, float* actions, float* mus,
+                          float* sigmas, float* neglogp, float* values, void* stream) {
+    if (num_envs < 1 || (!mu && !value)) return PHC_EINVAL;
+    if (mu && (!logstd || !noise || !actions || !mus || !sigmas || !neglogp || num_actions < 1)) return PHC_EINVAL;
+    if (value && (!values || ((value_mean == nullptr) != (value_var == nullptr)))) return PHC_EINVAL;
+    const dim3 grid((unsigned)((num_envs + 3) / 4));
+    if (is_bf16)
+        hipLaunchKernelGGL(k_policy_sample<__hip_bfloat16>, grid, dim3(256), 0, (hipStream_t)stream, (const __hip_bfloat16*)mu, logstd, noise,
+                           (const __hip_bfloat16*)value, value_mean, value_var, epsilon, mask, num_envs, num_actions, actions, mus, sigmas, neglogp, values);
+    else
+        hipLaunchKernelGGL(k_policy_sample<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)mu, logstd, noise, (const float*)value, value_mean,
+                           value_var, epsilon, mask, num_envs, num_actions, actions, mus, sigmas, neglogp, values);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int32_t)e;
 }

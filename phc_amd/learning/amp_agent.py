@@ -33,7 +33,7 @@ from torch import nn
 from .. import _lib as L
 from .network import A2CMCPNetwork, A2CNetwork, A2CPNNNetwork, ModelAMPContinuous, policy_kl
 from .replay_buffer import ReplayBuffer
-from .fast_ops import adam_clip_step, input_grad_only, ppo_loss
+from .fast_ops import adam_clip_step, input_grad_only, policy_sample, ppo_loss
 from .running_mean_std import RunningMeanStd
 
 
@@ -278,6 +278,8 @@ class IMAmpAgent:
         terminated_flags = torch.zeros(self.num_actors, device=self.device)
         reward_raw = None
         done_indices = []
+        net = self.model.a2c_network
+        fused = e["obses"].is_cuda
         for n in range(self.horizon_length):
             if self.faithful_reset or not hasattr(task, "reset_done"):
                 self.obs = self.env_reset(done_indices)
@@ -285,9 +287,21 @@ class IMAmpAgent:
                 task.reset_done()
                 self.obs = torch.clamp(task.obs_buf, -self.vec_env.clip_obs, self.vec_env.clip_obs) if np.isfinite(self.vec_env.clip_obs) else task.obs_buf
             e["obses"][n].copy_(self.obs)
-            res = self.get_action_values(self.obs)
-            for k in ("values", "neglogpacs", "actions", "mus", "sigmas"):
-                e[k][n].copy_(res[k])
+            if fused:
+                # heads as the GEMMs produce them; sampling, neglogp, sigma and the value un-normalisation in one kernel that
+                # writes the rows of the experience buffer
+                processed = self._preproc_obs(self.obs)
+                with self._autocast():
+                    mu, logstd = net.eval_actor(processed)
+                    value = net.eval_critic(processed)
+                policy_sample(mu.contiguous(), value.contiguous(), (logstd[0] if logstd.dim() == 2 else logstd).float().contiguous(),
+                              self.value_mean_std if self.normalize_value else None, e["actions"][n], e["mus"][n], e["sigmas"][n],
+                              e["neglogpacs"][n], e["values"][n])
+                res = {"actions": e["actions"][n]}
+            else:
+                res = self.get_action_values(self.obs)
+                for k in ("values", "neglogpacs", "actions", "mus", "sigmas"):
+                    e[k][n].copy_(res[k])
             self.obs, rewards, self.dones, infos = self.vec_env.step(res["actions"])
             rewards = rewards.unsqueeze(1) if rewards.dim() == 1 else rewards
             e["rewards"][n].copy_(rewards * self.reward_scale)
@@ -298,9 +312,15 @@ class IMAmpAgent:
             terminated_flags += terminated
             rr = infos["reward_raw"].mean(dim=0)
             reward_raw = rr if reward_raw is None else reward_raw + rr
-            next_vals = self._eval_critic(self.obs)
-            next_vals = next_vals * (1.0 - terminated.unsqueeze(-1))
-            e["next_values"][n].copy_(next_vals)
+            if fused:
+                with self._autocast():
+                    value = net.eval_critic(self._preproc_obs(self.obs))
+                policy_sample(None, value.contiguous(), None, self.value_mean_std if self.normalize_value else None, None, None, None, None,
+                              e["next_values"][n], mask=terminated)
+            else:
+                next_vals = self._eval_critic(self.obs)
+                next_vals = next_vals * (1.0 - terminated.unsqueeze(-1))
+                e["next_values"][n].copy_(next_vals)
             self.current_rewards += rewards
             self.current_lengths += 1
             if self.faithful_reset:

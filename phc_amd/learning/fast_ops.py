@@ -277,6 +277,26 @@ def ppo_loss(mu, value, logstd, actions, old_neglogp, adv, returns, old_values, 
     return _PPOLossFn.apply(mu, value, logstd, actions, old_neglogp, adv, returns, old_values if clip_value else None, old_mu, old_sigma, prm, unit_grad, row_index)
 
 
+def policy_sample(mu, value, logstd, value_norm, out_actions, out_mus, out_sigmas, out_neglogp, out_values, mask=None):
+    """One rollout policy step on the device (`phc_policy_sample`): samples the action (torch.randn noise, the generator stream of
+    `torch.randn_like(mu)`) and writes action / mu / sigma / neglogp / un-normalised value straight into rows of the experience
+    buffer.  `mu=None`: only the value part (next_values), optionally masked.  `value_norm`: the value RunningMeanStd or None."""
+    lib = L.load()
+    head = mu if mu is not None else value
+    N = head.shape[0]
+    D = mu.shape[1] if mu is not None else 0
+    ptr = lambda t: None if t is None else t.data_ptr()
+    noise = torch.randn((N, D), dtype=torch.float32, device=head.device) if mu is not None else None
+    for t in (out_actions, out_mus, out_sigmas, out_neglogp, out_values):
+        assert t is None or (t.dtype == torch.float32 and t.is_contiguous())
+    assert (mu is None or mu.is_contiguous()) and (value is None or value.is_contiguous())
+    L.check(lib.phc_policy_sample(ptr(mu), ptr(value), int(head.dtype == torch.bfloat16), ptr(logstd), ptr(noise),
+                                  ptr(value_norm.running_mean) if value_norm is not None else None,
+                                  ptr(value_norm.running_var) if value_norm is not None else None,
+                                  float(value_norm.epsilon) if value_norm is not None else 0.0, ptr(mask), N, D, ptr(out_actions), ptr(out_mus),
+                                  ptr(out_sigmas), ptr(out_neglogp), ptr(out_values), _stream(head.device)), "phc_policy_sample")
+
+
 def adam_clip_step(optimizer, flat_param, flat_grad, max_norm, shadow=None, step_device=None, count_host=True):
     """`clip_grad_norm_(max_norm)` (None / <= 0: no clipping) + `optimizer.step()` for a torch.optim.Adam that holds the single flat
     parameter, on the device: its state (`step`, `exp_avg`, `exp_avg_sq`) stays the optimizer's, so checkpoints are unchanged.

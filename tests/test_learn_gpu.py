@@ -293,3 +293,33 @@ def test_one_output_linear_kernels():
         scale = exact.abs().max().item()
         e_fast, e_ref = ((outs[n][k].double() - exact).abs().max().item() / scale for n in ("fast", "ref"))
         assert e_fast < 2e-2 and e_fast <= 1.5 * e_ref + 1e-3, (k, e_fast, e_ref)
+
+
+def test_policy_sample_kernel_equals_model_eval_path():
+    """phc_policy_sample == ModelAMPContinuous.forward(is_train=False) + value un-normalisation (amp_agent.py:309-341): same noise
+    stream as torch.randn_like, same action / neglogp / sigma, un-normalised value; masked value variant."""
+    from phc_amd.learning.fast_ops import policy_sample
+    from phc_amd.learning.network import ModelAMPContinuous
+    N, D, dev = 3001, 69, "cuda"
+    g = torch.Generator(device=dev).manual_seed(2)
+    mu = (torch.randn(N, D, device=dev, generator=g) * 0.5).to(torch.bfloat16)
+    value = (torch.randn(N, 1, device=dev, generator=g) * 3).to(torch.bfloat16)
+    logstd = torch.full((D,), -2.9, device=dev) + torch.randn(D, device=dev, generator=g) * 0.1
+    vms = RunningMeanStd((1,)).cuda().eval()
+    vms.running_mean.fill_(0.7); vms.running_var.fill_(2.5)
+    out = dict(a=torch.zeros(N, D, device=dev), m=torch.zeros(N, D, device=dev), s=torch.zeros(N, D, device=dev), n=torch.zeros(N, device=dev),
+               v=torch.zeros(N, 1, device=dev))
+    torch.manual_seed(9)
+    policy_sample(mu, value, logstd, vms, out["a"], out["m"], out["s"], out["n"], out["v"])
+    torch.manual_seed(9)
+    muf, sigma = mu.float(), torch.exp(logstd).expand(N, D)
+    action = muf + sigma * torch.randn_like(muf)
+    nlp = ModelAMPContinuous.neglogp(action, muf, sigma, logstd.expand(N, D))
+    torch.testing.assert_close(out["a"], action, rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(out["n"], nlp, rtol=1e-5, atol=1e-3)   # sum of 69 squared ~N(0,1) / sigma round-offs around 190
+    assert torch.equal(out["m"], muf) and torch.allclose(out["s"], sigma)
+    torch.testing.assert_close(out["v"], vms(value.float(), True), rtol=1e-6, atol=1e-6)
+    mask = (torch.rand(N, device=dev) < 0.3).float()
+    nv = torch.zeros(N, 1, device=dev)
+    policy_sample(None, value, None, vms, None, None, None, None, nv, mask=mask)
+    torch.testing.assert_close(nv, vms(value.float(), True) * (1 - mask.unsqueeze(-1)), rtol=1e-6, atol=1e-6)
