@@ -192,8 +192,10 @@ class IMAmpAgent:
         self._amp_input_mean_std = RunningMeanStd((amp_dim,)).to(self.device) if self._normalize_amp_input else None
         self.running_mean_std_temp = None
         self.grads = FlatGradBucket(self.model.parameters())
-        # opt-in (`learning.params.config.hip_graph=True`, bench.py sets it): capture works in plain processes at every size tried
-        # (scripts/graph_probe.py, graph_bisect.py) but `hipStreamEndCapture` segfaults inside pytest-hosted processes on ROCm 7.2
+        # opt-in (`learning.params.config.hip_graph=True`, bench.py sets it).  Known hazard (scripts/graph_repro2.py): if the caller keeps
+        # an autograd-tracked copy of a parameter alive (`w0 = p.clone()` instead of `p.detach().clone()`), that parameter's
+        # AccumulateGrad node lives on the stream it was created on; the captured backward then has to hand the gradient to a stream
+        # that is not capturing and `hipStreamEndCapture` segfaults on ROCm 7.2 instead of raising.
         self._use_graph = bool(c.get("hip_graph", False))
         self._graph = self._g_data = self._g_idx = self._g_step = self._g_info = None
         self._graph_failed = False

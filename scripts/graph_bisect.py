@@ -1,6 +1,6 @@
 """dev tool: bisect which stage of the real optimizer step breaks hipGraph capture at a small batch (each stage in its own process)"""
 import os, subprocess, sys
-STAGES = ["A_preproc", "B_forward", "C_disc_loss", "D_backward", "E_full", "F_train_epoch", "G_as_test"]
+STAGES = ["A_preproc", "B_forward", "C_disc_loss", "D_backward", "E_full", "F_train_epoch", "G_as_test", "H_deep_stack"]
 if len(sys.argv) > 1 and sys.argv[1] in STAGES:
     import torch
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -9,15 +9,25 @@ if len(sys.argv) > 1 and sys.argv[1] in STAGES:
     from phc_amd.learning.amp_agent import IMAmpAgent
     from phc_amd.learning.fast_ops import adam_clip_step, ppo_loss
     stage = sys.argv[1]
-    if stage != "G_as_test":
+    if stage not in ("G_as_test", "H_deep_stack"):
         os.environ["PHC_NO_GRAPH"] = "1"
     n_envs, mb = int(sys.argv[2]), int(sys.argv[3])
-    cfg = compose([f"env.num_envs={n_envs}", "env.motion_file=synthetic:2:3", f"learning.params.config.minibatch_size={mb}",
+    cfg = compose([f"env.num_envs={n_envs}", "env.motion_file=synthetic:2:3", f"learning.params.config.minibatch_size={mb}", "+learning.params.config.hip_graph=True",
                    "learning.params.config.amp_obs_demo_buffer_size=4096", "learning.params.config.amp_replay_buffer_size=4096"])
     task, env = parse_task(cfg)
     ag = IMAmpAgent(env, cfg)
     ag.init_train()
     ag.train_epoch()
+    if stage == "H_deep_stack":   # is it the depth of the host stack at capture_end (pytest runs tests ~60 Python frames deep)?
+        sys.setrecursionlimit(10000)
+        def deep(k):
+            if k == 0:
+                ag.train_epoch()
+                return
+            deep(k - 1)
+        deep(int(os.environ.get("DEPTH", "400")))
+        print("graph" if ag._graph is not None else "eager", "ok")
+        sys.exit(0)
     if stage == "G_as_test":
         ag.train_epoch()
         print("graph" if ag._graph is not None else "eager", "ok")

@@ -239,7 +239,7 @@ def test_ppo_train_epoch_on_device():
                                                          "learning.params.config.amp_replay_buffer_size": 4096})
     agent = IMAmpAgent(env, task.cfg)
     agent.init_train()
-    w0 = agent.model.a2c_network.mu.weight.clone()
+    w0 = agent.model.a2c_network.mu.weight.detach().clone()
     for _ in range(2):
         info = agent.train_epoch()
         assert np.isfinite([info["actor_loss"], info["critic_loss"], info["disc_loss"], info["kl"], info["mean_task_reward"]]).all(), info
@@ -251,7 +251,7 @@ def test_ppo_train_epoch_on_device():
 def test_update_graph_equals_eager_launches():
     """The captured optimizer step (hipGraph, replayed per minibatch with the row-index buffer and the device-side Adam step
     count) trains like the eager launch sequence: same parameters and normaliser statistics after three epochs.  Runs in a child
-    process (tests/graph_equivalence_main.py): stream capture segfaults inside pytest-hosted processes on this ROCm stack."""
+    process (tests/graph_equivalence_main.py): a failed stream capture takes the process down on this ROCm stack."""
     import json
     import os
     import subprocess
@@ -381,7 +381,7 @@ def test_mcp_getup_task_composes_primitives_and_trains():
     assert (task._point_goal >= 0).all()
     agent = IMAmpAgent(env, task.cfg)
     agent.init_train()
-    c0 = agent.model.a2c_network.composer[0].weight.clone()
+    c0 = agent.model.a2c_network.composer[0].weight.detach().clone()
     info = agent.train_epoch()
     assert np.isfinite([info["actor_loss"], info["critic_loss"], info["disc_loss"]]).all(), info
     assert not torch.equal(c0, agent.model.a2c_network.composer[0].weight)
@@ -478,7 +478,7 @@ def test_h1_ppo_epoch():
                                                                            "learning.params.network.space.continuous.sigma_init.val": -1.7}))
     agent = IMAmpAgent(env, task.cfg)
     agent.init_train()
-    w0 = agent.model.a2c_network.pnn.actors[0][0].weight.clone()
+    w0 = agent.model.a2c_network.pnn.actors[0][0].weight.detach().clone()
     info = agent.train_epoch()
     assert np.isfinite([info["actor_loss"], info["critic_loss"], info["disc_loss"], info["mean_task_reward"]]).all(), info
     assert not torch.equal(w0, agent.model.a2c_network.pnn.actors[0][0].weight)
