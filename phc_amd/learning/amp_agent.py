@@ -500,6 +500,15 @@ class IMAmpAgent:
         return (self.grads.flat.is_cuda and self.world == 1 and self._use_graph and not self._graph_failed and self.minibatch_size >= 2048
                 and not os.environ.get("PHC_NO_GRAPH"))
 
+    def _stale_grad_accumulators(self):
+        """True if some parameter's AccumulateGrad node is kept alive by a graph outside this update (e.g. `w0 = p.clone()` held by
+        the caller): such a node is bound to the stream it was created on and breaks stream capture.  A parameter caches its
+        accumulator weakly, so a node nobody else holds is gone once we drop it -- a tag we leave on it tells the two cases apart."""
+        from torch.autograd.graph import get_gradient_edge
+        for p in self.grads.params:
+            get_gradient_edge(p).node.metadata["phc_probe"] = True
+        return any("phc_probe" in get_gradient_edge(p).node.metadata for p in self.grads.params)
+
     def _graph_static_dataset(self):
         """The dataset of this epoch behind fixed addresses (a captured graph keeps reading the same buffers)."""
         if self._g_data is None:
@@ -537,6 +546,9 @@ class IMAmpAgent:
             return None
         self._g_step.fill_(int(st["step"].item()))
         if self._graph is None:
+            if self._stale_grad_accumulators():
+                raise RuntimeError("an autograd graph outside the update holds a parameter's gradient accumulator (e.g. `p.clone()` kept "
+                                   "alive: use `p.detach().clone()`); stream capture would crash")
             self._g_idx.copy_(self._idx_buf[:self.minibatch_size])
             # throw-away state for the warm-up steps torch asks for before a capture: parameters, optimizer and normaliser
             # statistics are restored afterwards, so that capturing does not train

@@ -240,3 +240,16 @@ def test_pnn_network_and_forward_pmcp():
     agent.train_epoch()
     assert torch.equal(w_frozen, agent.model.a2c_network.pnn.actors[0][0].weight)
     assert not torch.equal(w_active, agent.model.a2c_network.pnn.actors[1][0].weight)
+
+
+def test_stale_gradient_accumulator_probe():
+    """The guard in front of the update-graph capture: an autograd-tracked copy of a parameter held by the caller keeps that parameter's
+    AccumulateGrad node alive (bound to the stream it was created on) and must be detected; detached snapshots are fine."""
+    agent = IMAmpAgent(FakeVecEnv(32), small_cfg(), bf16=False)
+    assert not agent._stale_grad_accumulators()
+    snap = agent.model.a2c_network.mu.weight.detach().clone()
+    assert not agent._stale_grad_accumulators()
+    tracked = agent.model.a2c_network.mu.weight.clone()
+    assert agent._stale_grad_accumulators()
+    del tracked
+    assert not agent._stale_grad_accumulators() and snap is not None
