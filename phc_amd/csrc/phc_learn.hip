@@ -16,7 +16,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 #define RN_COLS 256   // columns per block == threads per block (thread <-> column: loads coalesce across the block)
-#define RN_ROWS 128   // rows per block
+#define RN_ROWS 32    // rows per block (4096 x 1960 -> 1024 blocks: four per CU; 128 rows left one wavefront per SIMD, latency-bound)
 #define RN_UNROLL 8   // independent loads in flight per thread
 
 // One pass over x [rows, cols]: y = clamp((x - mean) / sqrt(var + eps), -c, c)  (running_mean_std.py:95-96, fp32 like the reference:
@@ -147,27 +147,34 @@ __global__ __launch_bounds__(256) void k_linear1_fwd(const __hip_bfloat16* __res
     a = wave_sum(a);
     if (lane == 0) y[r] = __float2bfloat16(a + __bfloat162float(b[0]));
 }
-#define L1_ROWS 64
+#define L1_ROWS 16   // rows per block: 16 384 rows -> 1024 blocks (64 rows per block ran 256 latency-bound blocks: 69 us)
 // gx[r, k] = gy[r] w[k] (optional) and per-chunk partial sums of gy[r] x[r, k] (columns 0..cols-1) and gy[r] (column `cols`)
 __global__ __launch_bounds__(256) void k_linear1_bwd(const __hip_bfloat16* __restrict__ x, const __hip_bfloat16* __restrict__ w,
                                                      const __hip_bfloat16* __restrict__ gy, int64_t rows, int cols,
                                                      __hip_bfloat16* __restrict__ gx, float* __restrict__ partial) {
     const int64_t r0 = (int64_t)blockIdx.x * L1_ROWS;
-    const int64_t r1 = r0 + L1_ROWS < rows ? r0 + L1_ROWS : rows;
+    const int nr = (int)(r0 + L1_ROWS < rows ? L1_ROWS : rows - r0);
+    float g[L1_ROWS];
+#pragma unroll
+    for (int i = 0; i < L1_ROWS; ++i) g[i] = i < nr ? __bfloat162float(gy[r0 + i]) : 0.f;
     for (int k = threadIdx.x; k < cols; k += 256) {
         const float wk = __bfloat162float(w[k]);
+        float xv[L1_ROWS];
+#pragma unroll
+        for (int i = 0; i < L1_ROWS; ++i) xv[i] = i < nr ? __bfloat162float(x[(r0 + i) * cols + k]) : 0.f;   // all loads in flight
         float a = 0.f;
-        for (int64_t r = r0; r < r1; ++r) {
-            const float g = __bfloat162float(gy[r]);
-            a += g * __bfloat162float(x[r * cols + k]);
-            if (gx) gx[r * cols + k] = __float2bfloat16(g * wk);
+#pragma unroll
+        for (int i = 0; i < L1_ROWS; ++i) {
+            a += g[i] * xv[i];
+            if (gx && i < nr) gx[(r0 + i) * cols + k] = __float2bfloat16(g[i] * wk);
         }
         partial[(int64_t)blockIdx.x * (cols + 1) + k] = a;
     }
     if (threadIdx.x == 0) {
-        float s = 0.f;
-        for (int64_t r = r0; r < r1; ++r) s += __bfloat162float(gy[r]);
-        partial[(int64_t)blockIdx.x * (cols + 1) + cols] = s;
+        float s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < L1_ROWS; ++i) s2 += g[i];
+        partial[(int64_t)blockIdx.x * (cols + 1) + cols] = s2;
     }
 }
 
