@@ -117,20 +117,28 @@ __global__ __launch_bounds__(256) void k_colsum_bf16(const __hip_bfloat16* __res
     __syncthreads();
     if (ry == 0 && c < cols) partial[(int64_t)blockIdx.y * cols + c] = (l[0][cx] + l[1][cx]) + (l[2][cx] + l[3][cx]);
 }
-// block = 64 columns x 4 slices of the chunk list
-__global__ __launch_bounds__(256) void k_colsum_finish(const float* __restrict__ partial, int nchunks, int cols, float* __restrict__ out) {
-    __shared__ float l[4][64];
+// block = 64 columns x 16 slices of the chunk list (up to 1024 chunks: 64 loads per thread, four in flight)
+__global__ __launch_bounds__(1024) void k_colsum_finish(const float* __restrict__ partial, int nchunks, int cols, float* __restrict__ out) {
+    __shared__ float l[16][64];
     const int cx = threadIdx.x & 63, sy = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cx;
-    float a = 0.f, b = 0.f;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     if (c < cols) {
         int k = sy;
-        for (; k + 4 < nchunks; k += 8) { a += partial[(int64_t)k * cols + c]; b += partial[(int64_t)(k + 4) * cols + c]; }
-        if (k < nchunks) a += partial[(int64_t)k * cols + c];
+        for (; k + 48 < nchunks; k += 64) {
+            a0 += partial[(int64_t)k * cols + c]; a1 += partial[(int64_t)(k + 16) * cols + c];
+            a2 += partial[(int64_t)(k + 32) * cols + c]; a3 += partial[(int64_t)(k + 48) * cols + c];
+        }
+        for (; k < nchunks; k += 16) a0 += partial[(int64_t)k * cols + c];
     }
-    l[sy][cx] = a + b;
+    l[sy][cx] = (a0 + a1) + (a2 + a3);
     __syncthreads();
-    if (sy == 0 && c < cols) out[c] = (l[0][cx] + l[1][cx]) + (l[2][cx] + l[3][cx]);
+    if (sy == 0 && c < cols) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += l[i][cx];
+        out[c] = t;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -435,7 +443,7 @@ int32_t phc_colsum_bf16(const void* x, int64_t rows, int32_t cols, float* out, f
     if (nchunks > 65535) return PHC_EUNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_colsum_bf16, dim3((cols + 63) / 64, (unsigned)nchunks), dim3(256), 0, st, reinterpret_cast<const __hip_bfloat16*>(x), rows, cols, workspace);
-    hipLaunchKernelGGL(k_colsum_finish, dim3((cols + 63) / 64), dim3(256), 0, st, workspace, (int)nchunks, cols, out);
+    hipLaunchKernelGGL(k_colsum_finish, dim3((cols + 63) / 64), dim3(1024), 0, st, workspace, (int)nchunks, cols, out);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int32_t)e;
 }
@@ -457,7 +465,7 @@ int32_t phc_linear1_backward(const void* x, const void* w, const void* gy, int64
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_linear1_bwd, dim3((unsigned)nchunks), dim3(256), 0, st, (const __hip_bfloat16*)x, (const __hip_bfloat16*)w, (const __hip_bfloat16*)gy,
                        rows, cols, (__hip_bfloat16*)gx, workspace);
-    hipLaunchKernelGGL(k_colsum_finish, dim3((cols + 1 + 63) / 64), dim3(256), 0, st, workspace, (int)nchunks, cols + 1, gw_gb);
+    hipLaunchKernelGGL(k_colsum_finish, dim3((cols + 1 + 63) / 64), dim3(1024), 0, st, workspace, (int)nchunks, cols + 1, gw_gb);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int32_t)e;
 }
