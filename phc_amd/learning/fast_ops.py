@@ -11,7 +11,6 @@ It is used for the actor and critic (amp_agent.py:554-655); the discriminator ke
 differentiates the backward pass itself (create_graph=True).  Anywhere else (CPU, fp32, no_grad rollouts, frozen columns) it is
 exactly nn.Linear.  `adam_clip_step` = clip_grad_norm_ + torch.optim.Adam.step on the flat parameter in two launches."""
 import ctypes as C
-import os
 
 import torch
 from torch import nn
