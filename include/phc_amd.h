@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PHC_ABI_VERSION 15
+#define PHC_ABI_VERSION 16
 #define PHC_MAX_BODIES 64   /* bodies (incl. extended reference bodies) per articulation; also the slot count of the model tables */
 #define PHC_EINVAL (-1)
 #define PHC_EUNSUPPORTED (-2)
@@ -280,6 +280,19 @@ int32_t phc_running_norm(const float* x, const int64_t* row_index, int64_t rows,
  * the output gradient, AddmmBackward).  workspace: phc_colsum_workspace(rows, cols) bytes. */
 int64_t phc_colsum_workspace(int64_t rows, int32_t cols);
 int32_t phc_colsum_bf16(const void* x, int64_t rows, int32_t cols, float* out, float* workspace, void* stream);
+
+/* Discriminator loss pieces (phc/learning/amp_agent.py:732-808 `_disc_loss`).
+ * phc_disc_bce: logits [n_agent + n_demo] (agent and replay rows first, demo rows last; bf16 or fp32):
+ *   stats[0] = scale * 0.5 (BCEWithLogits(agent, 0) + BCEWithLogits(demo, 1)), stats[1] = mean(agent < 0), stats[2] = mean(demo > 0);
+ *   grad [same shape / type] = d stats[0] / d logits.
+ * phc_weighted_sumsq: out[0] = sum_i coefs[i] * |tensors[i]|^2 over count <= 4 device tensors of sizes[i] elements (all fp32 or all
+ *   bf16): the logit regulariser + weight decay in one pass, or -- one bf16 tensor, coef = c / rows -- the gradient penalty
+ *   c * mean_rows(sum_cols g^2).  workspace: phc_sumsq_workspace() bytes. */
+int32_t phc_disc_bce(const void* logits, int32_t is_bf16, int32_t n_agent, int32_t n_demo, float scale, void* grad, float* stats,
+                     void* stream);
+int64_t phc_sumsq_workspace(void);
+int32_t phc_weighted_sumsq(int32_t count, const void* const* tensors, const int64_t* sizes, const float* coefs, int32_t is_bf16, float* out,
+                           double* workspace, void* stream);
 
 /* Rollout policy step (phc/learning/amp_agent.py:309-341 with rl_games' ModelA2CContinuousLogStd in eval mode), per env r:
  *   actions = mu + exp(logstd) * noise, mus = mu, sigmas = exp(logstd), neglogp = neglogp(actions | mu, sigma)            (mu != NULL)

@@ -93,6 +93,9 @@ _SIGNATURES = {
     "phc_running_norm": ([c_p, c_p, c_i64, c_i32, c_p, c_p, c_f, c_f, c_p, c_i32, c_p, c_p, c_p, c_p, c_p], c_i32),
     "phc_colsum_workspace": ([c_i64, c_i32], c_i64),
     "phc_colsum_bf16": ([c_p, c_i64, c_i32, c_p, c_p, c_p], c_i32),
+    "phc_disc_bce": ([c_p, c_i32, c_i32, c_i32, c_f, c_p, c_p, c_p], c_i32),
+    "phc_sumsq_workspace": ([], c_i64),
+    "phc_weighted_sumsq": ([c_i32, c_p, c_p, c_p, c_i32, c_p, c_p, c_p], c_i32),
     "phc_policy_sample": ([c_p, c_p, c_i32, c_p, c_p, c_p, c_p, c_f, c_p, c_i64, c_i32, c_p, c_p, c_p, c_p, c_p, c_p], c_i32),
     "phc_linear1_workspace": ([c_i64, c_i32], c_i64),
     "phc_linear1_forward": ([c_p, c_p, c_p, c_i64, c_i32, c_p, c_p], c_i32),
@@ -120,7 +123,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the .so does not export the symbol
         fn.argtypes = argtypes
         fn.restype = restype
-    if lib.phc_abi_version() != 15:
+    if lib.phc_abi_version() != 16:
         raise ImportError("libphc_amd.so ABI version mismatch")
     _lib = lib
     return lib

@@ -407,6 +407,70 @@ __global__ __launch_bounds__(256) void k_policy_sample(const T* __restrict__ mu,
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Discriminator loss pieces (amp_agent.py:732-808 `_disc_loss`), each one or two launches instead of a dozen tiny torch kernels:
+//   k_disc_bce:   0.5 (BCEWithLogits(agent rows, 0) + BCEWithLogits(demo rows, 1)), both accuracies, and d loss / d logit
+//   k_sumsq_multi (+ finish): sum_i coef_i |w_i|^2 over up to 4 tensors (logit regulariser + weight decay), or with one bf16 tensor
+//                 the gradient penalty coef * mean_rows(sum_cols g^2)
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(1024) void k_disc_bce(const T* __restrict__ logits, int n_agent, int n_demo, float scale, T* __restrict__ grad,
+                                                   float* __restrict__ stats) {
+    __shared__ float l[4][16];
+    float la = 0.f, ld = 0.f, ca = 0.f, cd = 0.f;
+    const int n = n_agent + n_demo;
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        const float x = ld_f(logits, i);
+        const float sp = fmaxf(x, 0.f) + log1pf(expf(-fabsf(x)));   // softplus(x) = BCEWithLogits(x, 0); BCEWithLogits(x, 1) = softplus(x) - x
+        const float sg = 1.0f / (1.0f + expf(-x));
+        if (i < n_agent) { la += sp; ca += x < 0.f ? 1.f : 0.f; st_f(grad, i, scale * 0.5f * sg / (float)n_agent); }
+        else { ld += sp - x; cd += x > 0.f ? 1.f : 0.f; st_f(grad, i, scale * 0.5f * (sg - 1.0f) / (float)n_demo); }
+    }
+    la = wave_sum(la); ld = wave_sum(ld); ca = wave_sum(ca); cd = wave_sum(cd);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { l[0][w] = la; l[1][w] = ld; l[2][w] = ca; l[3][w] = cd; }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        float t = 0.f;
+        for (int k = 0; k < 16; ++k) t += l[threadIdx.x][k];
+        l[threadIdx.x][0] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        stats[0] = scale * 0.5f * (l[0][0] / (float)n_agent + l[1][0] / (float)n_demo);
+        stats[1] = l[2][0] / (float)n_agent;
+        stats[2] = l[3][0] / (float)n_demo;
+    }
+}
+
+struct SumsqArgs { const void* ptr[4]; int64_t n[4]; float coef[4]; int count; int is_bf16; };
+#define SSM_BLOCKS 256
+__global__ __launch_bounds__(256) void k_sumsq_multi(SumsqArgs a, double* __restrict__ partial) {
+    __shared__ double l[4];
+    double acc = 0.0;
+    for (int t = 0; t < a.count; ++t) {
+        float s = 0.f;
+        const int64_t n = a.n[t];
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)SSM_BLOCKS * 256) {
+            const float v = a.is_bf16 ? __bfloat162float(reinterpret_cast<const __hip_bfloat16*>(a.ptr[t])[i]) : reinterpret_cast<const float*>(a.ptr[t])[i];
+            s += v * v;
+        }
+        acc += (double)a.coef[t] * (double)s;
+    }
+    for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
+    if ((threadIdx.x & 63) == 0) l[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (l[0] + l[1]) + (l[2] + l[3]);
+}
+__global__ __launch_bounds__(256) void k_sumsq_multi_finish(const double* __restrict__ partial, float* __restrict__ out) {
+    __shared__ double l[4];
+    double t = partial[threadIdx.x];   // SSM_BLOCKS == blockDim.x
+    for (int m = 32; m >= 1; m >>= 1) t += __shfl_xor(t, m, 64);
+    if ((threadIdx.x & 63) == 0) l[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = (float)((l[0] + l[1]) + (l[2] + l[3]));
+}
+
 extern "C" {
 
 int64_t phc_running_norm_workspace(int64_t rows, int32_t cols) {
@@ -483,6 +547,33 @@ int32_t phc_policy_sample(const void* mu, const void* value, int32_t is_bf16, co
     else
         hipLaunchKernelGGL(k_policy_sample<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)mu, logstd, noise, (const float*)value, value_mean,
                            value_var, epsilon, mask, num_envs, num_actions, actions, mus, sigmas, neglogp, values);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int32_t)e;
+}
+
+int32_t phc_disc_bce(const void* logits, int32_t is_bf16, int32_t n_agent, int32_t n_demo, float scale, void* grad, float* stats, void* stream) {
+    if (!logits || !grad || !stats || n_agent < 1 || n_demo < 1) return PHC_EINVAL;
+    if (is_bf16)
+        hipLaunchKernelGGL(k_disc_bce<__hip_bfloat16>, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const __hip_bfloat16*)logits, n_agent, n_demo, scale,
+                           (__hip_bfloat16*)grad, stats);
+    else
+        hipLaunchKernelGGL(k_disc_bce<float>, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const float*)logits, n_agent, n_demo, scale, (float*)grad, stats);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int32_t)e;
+}
+
+int64_t phc_sumsq_workspace(void) { return SSM_BLOCKS * (int64_t)sizeof(double); }
+
+int32_t phc_weighted_sumsq(int32_t count, const void* const* tensors, const int64_t* sizes, const float* coefs, int32_t is_bf16, float* out,
+                           double* workspace, void* stream) {
+    if (count < 1 || count > 4 || !tensors || !sizes || !coefs || !out || !workspace) return PHC_EINVAL;
+    SumsqArgs a;
+    a.count = count; a.is_bf16 = is_bf16;
+    for (int t = 0; t < 4; ++t) { a.ptr[t] = t < count ? tensors[t] : nullptr; a.n[t] = t < count ? sizes[t] : 0; a.coef[t] = t < count ? coefs[t] : 0.f; }
+    for (int t = 0; t < count; ++t) if (!a.ptr[t] || a.n[t] < 0) return PHC_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_sumsq_multi, dim3(SSM_BLOCKS), dim3(256), 0, st, a, workspace);
+    hipLaunchKernelGGL(k_sumsq_multi_finish, dim3(1), dim3(256), 0, st, workspace, out);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int32_t)e;
 }

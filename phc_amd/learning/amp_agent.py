@@ -33,7 +33,7 @@ from torch import nn
 from .. import _lib as L
 from .network import A2CMCPNetwork, A2CNetwork, A2CPNNNetwork, ModelAMPContinuous, policy_kl
 from .replay_buffer import ReplayBuffer
-from .fast_ops import adam_clip_step, input_grad_only, policy_sample, ppo_loss
+from .fast_ops import adam_clip_step, disc_bce, input_grad_only, policy_sample, ppo_loss, weighted_sumsq
 from .running_mean_std import RunningMeanStd
 
 
@@ -413,6 +413,34 @@ class IMAmpAgent:
         return {"disc_loss": disc_loss, "disc_grad_penalty": disc_grad_penalty.detach(), "disc_logit_loss": disc_logit_loss.detach(),
                 "disc_agent_acc": (disc_agent_logit < 0).float().mean().detach(), "disc_demo_acc": (disc_demo_logit > 0).float().mean().detach()}
 
+    def _disc_loss_fused(self, logits, m, obs_demo):
+        """`_disc_loss` on the device with the pieces as kernels (fast_ops.disc_bce / weighted_sumsq): every term already carries
+        `disc_coef` and enters the total loss with weight one.  `logits` [3m, 1]: agent, replay, demo rows."""
+        net = self.model.a2c_network
+        k = self._disc_coef
+        bce, acc = disc_bce(logits, 2 * m, k)
+        ws = [p for p in net.get_disc_weights_raw()]
+        coefs = [self._disc_weight_decay * k] * len(ws)
+        coefs[-1] += self._disc_logit_reg * k   # the logit layer: regulariser + weight decay
+        l2 = weighted_sumsq(ws, coefs)
+        with input_grad_only():
+            grad = torch.autograd.grad(logits[2 * m:], obs_demo, grad_outputs=self._ones_like_cached(m, logits), create_graph=True, retain_graph=True,
+                                       only_inputs=True)[0]
+        pen = weighted_sumsq([grad], [self._disc_grad_penalty * k / m])
+        total = bce + l2 + pen
+        with torch.no_grad():
+            logit_w = net.get_disc_logit_weights()
+            disc_logit_loss = torch.sum(torch.square(logit_w))
+            info = {"disc_loss": total / k, "disc_grad_penalty": pen / (self._disc_grad_penalty * k), "disc_logit_loss": disc_logit_loss,
+                    "disc_agent_acc": acc[0], "disc_demo_acc": acc[1]}
+        return total, info
+
+    def _ones_like_cached(self, m, like):
+        key = (m, like.dtype, like.device)
+        if getattr(self, "_ones_key", None) != key:
+            self._ones_key, self._ones = key, torch.ones((m, 1), dtype=like.dtype, device=like.device)
+        return self._ones
+
     def _fwd_bwd(self, d):
         """Forward + losses + backward into the flat gradient bucket (amp_agent.py:554-655); no host sync."""
         idx = amp_idx = None
@@ -427,17 +455,22 @@ class IMAmpAgent:
         amp_obs_replay = self._preproc_amp_obs(d["amp_obs_replay"], amp_idx)
         amp_obs_demo = self._preproc_amp_obs(d["amp_obs_demo"], amp_idx)
         amp_obs_demo.requires_grad_(True)
+        fused_disc = fused and self._disc_grad_penalty > 0
         inp = {"is_train": True, "prev_actions": d["actions"], "obs": obs, "amp_obs": amp_obs, "amp_obs_replay": amp_obs_replay,
-               "amp_obs_demo": amp_obs_demo}
+               "amp_obs_demo": amp_obs_demo, "raw_disc_logits": fused_disc}
         with self._autocast():
             res = self.model.forward_heads(inp) if fused else self.model(inp)
-        disc_info = self._disc_loss(torch.cat([res["disc_agent_logit"], res["disc_agent_replay_logit"]], dim=0), res["disc_demo_logit"], amp_obs_demo)
+        if fused_disc:
+            disc_term, disc_info = self._disc_loss_fused(res["disc_logits"], amp_obs.shape[0], amp_obs_demo)
+        else:
+            disc_info = self._disc_loss(torch.cat([res["disc_agent_logit"], res["disc_agent_replay_logit"]], dim=0), res["disc_demo_logit"], amp_obs_demo)
+            disc_term = self._disc_coef * disc_info["disc_loss"]
         if fused:
             # actor / critic losses and their gradients w.r.t. the two heads: one HIP pass (phc_ppo_loss) instead of ~100 launches
             ppo, st = ppo_loss(res["mu"].contiguous(), res["value"].contiguous(), res["logstd"], d["actions"], d["old_logp_actions"], d["advantages"],
                                d["returns"], d["old_values"], d["mu"], d["sigma"], self.e_clip, self.critic_coef, self.entropy_coef,
                                self.bounds_loss_coef, self.clip_value, unit_grad=True, row_index=idx)
-            loss = ppo + self._disc_coef * disc_info["disc_loss"]   # `ppo` enters with weight one (unit_grad)
+            loss = ppo + disc_term   # `ppo` (and the fused discriminator terms) enter with weight one (unit_grad)
             info = {"actor_loss": st[0], "critic_loss": st[1], "b_loss": st[2], "entropy": st[3], "kl": st[4]}
         else:
             assert idx is None

@@ -276,6 +276,73 @@ def ppo_loss(mu, value, logstd, actions, old_neglogp, adv, returns, old_values, 
     return _PPOLossFn.apply(mu, value, logstd, actions, old_neglogp, adv, returns, old_values if clip_value else None, old_mu, old_sigma, prm, unit_grad, row_index)
 
 
+class _DiscBCEFn(torch.autograd.Function):
+    """0.5 (BCEWithLogits(agent rows, 0) + BCEWithLogits(demo rows, 1)) * scale, the two accuracies, and the gradient w.r.t. the
+    logits in one launch (`phc_disc_bce`).  Unit-weight convention as `_PPOLossFn`: the result is added to the total loss as it is."""
+
+    @staticmethod
+    def forward(ctx, logits, n_agent, scale):
+        lib = L.load()
+        n = logits.shape[0]
+        assert logits.is_contiguous() and logits.numel() == n and logits.dtype in (torch.bfloat16, torch.float32)
+        grad = torch.empty_like(logits)
+        stats = torch.empty(3, dtype=torch.float32, device=logits.device)
+        L.check(lib.phc_disc_bce(logits.data_ptr(), int(logits.dtype == torch.bfloat16), n_agent, n - n_agent, float(scale), grad.data_ptr(), stats.data_ptr(),
+                                 _stream(logits.device)), "phc_disc_bce")
+        ctx.save_for_backward(grad)
+        acc = stats.narrow(0, 1, 2)
+        ctx.mark_non_differentiable(acc)
+        return stats.narrow(0, 0, 1).view(()), acc
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g, _):
+        (grad,) = ctx.saved_tensors
+        return grad, None, None
+
+
+def disc_bce(logits, n_agent, scale=1.0):
+    """-> (scale * 0.5 (bce(agent, 0) + bce(demo, 1)), [agent_acc, demo_acc]); logits [n, 1]: agent (+ replay) rows first, demo rows last."""
+    return _DiscBCEFn.apply(logits, n_agent, scale)
+
+
+def _weighted_sumsq(tensors, coefs):
+    lib = L.load()
+    dev = tensors[0].device
+    is_bf16 = tensors[0].dtype == torch.bfloat16
+    for t in tensors:
+        assert t.is_contiguous() and t.device == dev and t.dtype == tensors[0].dtype and t.dtype in (torch.bfloat16, torch.float32)
+    n = len(tensors)
+    out = torch.empty(1, dtype=torch.float32, device=dev)
+    ws = _workspace("sumsq", lib.phc_sumsq_workspace(), dev, torch.float64)
+    ptrs = (C.c_void_p * n)(*[t.data_ptr() for t in tensors])
+    sizes = (C.c_int64 * n)(*[t.numel() for t in tensors])
+    cf = (C.c_float * n)(*[float(c) for c in coefs])
+    L.check(lib.phc_weighted_sumsq(n, ptrs, sizes, cf, int(is_bf16), out.data_ptr(), ws.data_ptr(), _stream(dev)), "phc_weighted_sumsq")
+    return out.view(())
+
+
+class _WeightedSumsqFn(torch.autograd.Function):
+    """sum_i coefs[i] |t_i|^2 over up to four tensors in two launches (`phc_weighted_sumsq`); gradient 2 coefs[i] t_i.  Unit-weight
+    convention: the result enters the total loss as it is."""
+
+    @staticmethod
+    def forward(ctx, coefs, *tensors):
+        ctx.save_for_backward(*tensors)
+        ctx.coefs = [float(c) for c in coefs]
+        return _weighted_sumsq(tensors, coefs)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        ts = ctx.saved_tensors
+        return (None,) + tuple(torch._foreach_mul(list(ts), [2.0 * c for c in ctx.coefs]))
+
+
+def weighted_sumsq(tensors, coefs):
+    return _WeightedSumsqFn.apply(list(coefs), *tensors)
+
+
 def policy_sample(mu, value, logstd, value_norm, out_actions, out_mus, out_sigmas, out_neglogp, out_values, mask=None):
     """One rollout policy step on the device (`phc_policy_sample`): samples the action (torch.randn noise, the generator stream of
     `torch.randn_like(mu)`) and writes action / mu / sigma / neglogp / un-normalised value straight into rows of the experience

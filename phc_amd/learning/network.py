@@ -66,6 +66,10 @@ class A2CNetwork(nn.Module):
     def get_disc_logit_weights(self):
         return torch.flatten(self._disc_logits.weight)
 
+    def get_disc_weights_raw(self):
+        """The weight tensors `get_disc_weights` flattens (hidden layers, then the logit layer)."""
+        return [m.weight for m in self._disc_mlp.modules() if isinstance(m, nn.Linear)] + [self._disc_logits.weight]
+
     def get_disc_weights(self):
         w = [torch.flatten(m.weight) for m in self._disc_mlp.modules() if isinstance(m, nn.Linear)]
         w.append(torch.flatten(self._disc_logits.weight))
@@ -206,9 +210,12 @@ class ModelAMPContinuous(nn.Module):
         a, r, d = input_dict["amp_obs"], input_dict["amp_obs_replay"], input_dict["amp_obs_demo"]
         # one discriminator pass over [agent; replay; demo] (the reference runs three, amp_models.py:40-48); a separate demo pass would
         # shrink the gradient penalty's double backward to a third of the rows but adds nine launches: no gain measured (scripts/gpu_ab.sh)
-        logits = self.a2c_network.eval_disc(torch.cat([a, r, d], dim=0)).float()
-        la, lr_, ld = torch.split(logits, [a.shape[0], r.shape[0], d.shape[0]], dim=0)
-        return {"mu": mu, "value": value, "logstd": logstd[0] if logstd.dim() == 2 else logstd, "disc_agent_logit": la,
+        logits_raw = self.a2c_network.eval_disc(torch.cat([a, r, d], dim=0))
+        if input_dict.get("raw_disc_logits", False):   # the fused discriminator loss takes the [3m, 1] logits as the GEMM wrote them
+            la = lr_ = ld = None
+        else:
+            la, lr_, ld = torch.split(logits_raw.float(), [a.shape[0], r.shape[0], d.shape[0]], dim=0)
+        return {"mu": mu, "value": value, "logstd": logstd[0] if logstd.dim() == 2 else logstd, "disc_logits": logits_raw, "disc_agent_logit": la,
                 "disc_agent_replay_logit": lr_, "disc_demo_logit": ld}
 
 

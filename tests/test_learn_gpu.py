@@ -323,3 +323,38 @@ def test_policy_sample_kernel_equals_model_eval_path():
     nv = torch.zeros(N, 1, device=dev)
     policy_sample(None, value, None, vms, None, None, None, None, nv, mask=mask)
     torch.testing.assert_close(nv, vms(value.float(), True) * (1 - mask.unsqueeze(-1)), rtol=1e-6, atol=1e-6)
+
+
+def test_discriminator_loss_kernels():
+    """phc_disc_bce / phc_weighted_sumsq == the torch expressions of IMAmpAgent._disc_loss (amp_agent.py:732-808)."""
+    from phc_amd.learning.fast_ops import disc_bce, weighted_sumsq
+    torch.manual_seed(6)
+    m, dev = 1500, "cuda"
+    for dtype in (torch.bfloat16, torch.float32):
+        x0 = (torch.randn(3 * m, 1, device=dev) * 3).to(dtype)
+        xr = x0.clone().requires_grad_(True)
+        xf = xr.float()
+        bce = torch.nn.BCEWithLogitsLoss()
+        ref = 2.5 * 0.5 * (bce(xf[:2 * m], torch.zeros(2 * m, 1, device=dev)) + bce(xf[2 * m:], torch.ones(m, 1, device=dev)))
+        ref.backward()
+        xk = x0.clone().requires_grad_(True)
+        loss, acc = disc_bce(xk, 2 * m, 2.5)
+        loss.backward()
+        torch.testing.assert_close(loss, ref.detach(), rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(acc, torch.stack([(xf[:2 * m] < 0).float().mean(), (xf[2 * m:] > 0).float().mean()]).detach())
+        torch.testing.assert_close(xk.grad.float(), xr.grad.float(), rtol=1e-2 if dtype == torch.bfloat16 else 1e-5, atol=1e-9)
+    ws = [torch.randn(1024, 1960, device=dev, requires_grad=True), torch.randn(512, 1024, device=dev, requires_grad=True),
+          torch.randn(1, 512, device=dev, requires_grad=True)]
+    coefs = [1e-4, 1e-4, 1e-4 + 0.01]
+    out = weighted_sumsq(ws, coefs)
+    out.backward()
+    ref = sum(c * w.detach().double().square().sum() for c, w in zip(coefs, ws))
+    assert abs(float(out) - float(ref)) <= 1e-5 * float(ref)
+    for c, w in zip(coefs, ws):
+        torch.testing.assert_close(w.grad, 2 * c * w.detach())
+    g = (torch.randn(m, 1960, device=dev) * 0.1).to(torch.bfloat16).requires_grad_(True)
+    pen = weighted_sumsq([g], [5.0 / m])
+    pen.backward()
+    ref = 5.0 * g.detach().float().square().sum(-1).mean()
+    torch.testing.assert_close(pen, ref, rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(g.grad.float(), (2 * 5.0 / m) * g.detach().float(), rtol=1e-2, atol=1e-9)
