@@ -58,11 +58,11 @@ __global__ __launch_bounds__(RN_COLS) void k_running_norm(const float* __restric
 }
 
 // Batch moments from the partial sums and the parallel-variance update of the running statistics
-// (running_mean_std.py:56-67,100-104).  Block = 64 columns x 16 slices of the chunk list; `run_count` is only READ (the caller
-// adds the batch size afterwards, stream-ordered), so blocks need no ordering among themselves.
+// (running_mean_std.py:56-67,100-104).  Block = 64 columns x 16 slices of the chunk list.  Every block reads the old count; the
+// block that finishes LAST (a ticket counter behind the partial sums, left at zero again) writes the new one.
 __global__ __launch_bounds__(1024) void k_running_norm_finish(const double* __restrict__ partial, int nchunks, int64_t rows, int cols,
                                                               double* __restrict__ run_mean, double* __restrict__ run_var,
-                                                              const double* __restrict__ run_count) {
+                                                              double* __restrict__ run_count, unsigned int* __restrict__ ticket) {
     __shared__ double ls[16][64], lq[16][64];
     const int cx = threadIdx.x & 63, sy = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cx;
@@ -73,13 +73,17 @@ __global__ __launch_bounds__(1024) void k_running_norm_finish(const double* __re
             q += partial[((int64_t)k * 2 + 1) * cols + c];
         }
     ls[sy][cx] = s; lq[sy][cx] = q;
-    __syncthreads();
-    if (sy != 0 || c >= cols) return;
-    s = 0.0; q = 0.0;
-    for (int k = 0; k < 16; ++k) { s += ls[k][cx]; q += lq[k][cx]; }
     const double count = *run_count;
     const double n = (double)rows;
     const double tot = count + n;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(ticket, 1u) == gridDim.x - 1) { *run_count = tot; *ticket = 0u; }   // all blocks have read the old count by now
+    }
+    if (sy != 0 || c >= cols) return;
+    s = 0.0; q = 0.0;
+    for (int k = 0; k < 16; ++k) { s += ls[k][cx]; q += lq[k][cx]; }
     // input.mean(0), input.var(0) are fp32 tensors in the reference: round the batch moments to fp32 before the fp64 update
     const double bm = (double)(float)(s / n);
     const double bv = (double)(float)((q - s * s / n) / (n - 1.0));
@@ -473,12 +477,13 @@ __global__ __launch_bounds__(256) void k_sumsq_multi_finish(const double* __rest
 
 extern "C" {
 
+// partial sums + 8 bytes holding the finish kernel's ticket counter, which must be ZERO before the first call (it is left at zero)
 int64_t phc_running_norm_workspace(int64_t rows, int32_t cols) {
-    return ((rows + RN_ROWS - 1) / RN_ROWS) * 2 * (int64_t)cols * (int64_t)sizeof(double);
+    return ((rows + RN_ROWS - 1) / RN_ROWS) * 2 * (int64_t)cols * (int64_t)sizeof(double) + 8;
 }
 
 int32_t phc_running_norm(const float* x, const int64_t* row_index, int64_t rows, int32_t cols, const double* norm_mean, const double* norm_var, float epsilon,
-                         float clamp, void* out, int32_t out_bf16, double* run_mean, double* run_var, const double* run_count,
+                         float clamp, void* out, int32_t out_bf16, double* run_mean, double* run_var, double* run_count,
                          double* workspace, void* stream) {
     if (!x || rows < 0 || cols < 1 || !norm_mean || !norm_var) return PHC_EINVAL;
     const bool update = run_mean != nullptr;
@@ -494,7 +499,8 @@ int32_t phc_running_norm(const float* x, const int64_t* row_index, int64_t rows,
     else
         hipLaunchKernelGGL(k_running_norm<false>, grid, dim3(RN_COLS), 0, st, x, row_index, rows, cols, norm_mean, norm_var, epsilon, clamp, out, update ? workspace : nullptr);
     if (update)
-        hipLaunchKernelGGL(k_running_norm_finish, dim3((cols + 63) / 64), dim3(1024), 0, st, workspace, (int)nchunks, rows, cols, run_mean, run_var, run_count);
+        hipLaunchKernelGGL(k_running_norm_finish, dim3((cols + 63) / 64), dim3(1024), 0, st, workspace, (int)nchunks, rows, cols, run_mean, run_var, run_count,
+                           reinterpret_cast<unsigned int*>(workspace + nchunks * 2 * (int64_t)cols));
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int32_t)e;
 }

@@ -90,6 +90,9 @@ class FlatGradBucket:
             p.grad = self.flat[o:o + k].view_as(p)
             o += k
         self.flat_param.grad = self.flat
+        self.gen = 0   # bumped by zero(): lets a layer's backward store the first gradient of a step directly (fast_ops._first_write)
+        for p in self.params:
+            p._bucket = self
         # bf16 copy of the flat parameter for the GEMMs of the update phase: refreshed on entering shadow_scope(), then kept current
         # by the optimizer kernel; `_shadow_live` is the flag the layers look at (fast_ops.FastLinear)
         self.shadow, self._shadow_live = None, [False]
@@ -117,6 +120,7 @@ class FlatGradBucket:
 
     def zero(self):
         self.flat.zero_()
+        self.gen += 1
 
     def all_reduce_mean(self, dist):
         if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:

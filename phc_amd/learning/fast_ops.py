@@ -34,11 +34,27 @@ def _stream(device):
     return torch.cuda.current_stream(device).cuda_stream
 
 
-def colsum_bf16(x):
-    """x bf16 [rows, cols] (contiguous, device) -> fp32 [cols]"""
+def _first_write(p):
+    """True when parameter `p` lives in a FlatGradBucket and nothing has been written into its `.grad` since the bucket was last
+    zeroed: the layer's backward may then store its result there directly and return None instead of handing autograd a tensor to add
+    (one launch per parameter and step saved); later contributions in the same step take the normal accumulate path."""
+    b = getattr(p, "_bucket", None)
+    if b is None or p.grad is None:
+        return False
+    if getattr(p, "_grad_gen", -1) == b.gen:
+        return False
+    p._grad_gen = b.gen
+    return True
+
+
+def colsum_bf16(x, out=None):
+    """x bf16 [rows, cols] (contiguous, device) -> fp32 [cols] (written into `out` when given)"""
     lib = L.load()
     rows, cols = x.shape
-    out = torch.empty(cols, dtype=torch.float32, device=x.device)
+    if out is None:
+        out = torch.empty(cols, dtype=torch.float32, device=x.device)
+    else:
+        assert out.numel() == cols and out.dtype == torch.float32 and out.is_contiguous()
     ws = _workspace("colsum", lib.phc_colsum_workspace(rows, cols), x.device, torch.float32)
     L.check(lib.phc_colsum_bf16(x.data_ptr(), rows, cols, out.data_ptr(), ws.data_ptr(), _stream(x.device)), "phc_colsum_bf16")
     return out
@@ -47,13 +63,18 @@ def colsum_bf16(x):
 SPLIT_K = 8
 
 
-def wgrad_split_k(gy, x):
-    """gy^T x for gy [B, N], x [B, K] bf16 -> fp32 [N, K]; the batch is cut into SPLIT_K chunks that run as one batched GEMM."""
+def wgrad_split_k(gy, x, out=None):
+    """gy^T x for gy [B, N], x [B, K] bf16 -> fp32 [N, K] (into `out` when given); the batch is cut into SPLIT_K chunks that run as
+    one batched GEMM."""
     B, N = gy.shape
     K = x.shape[1]
     if B % SPLIT_K == 0 and B >= 2048 and N >= 16:   # (a 1-row batched GEMM -- the value head -- stalls the host for 11 ms in hipBLASLt)
         part = torch.bmm(gy.view(SPLIT_K, B // SPLIT_K, N).transpose(1, 2), x.view(SPLIT_K, B // SPLIT_K, K))
+        if out is not None:
+            return torch.sum(part, 0, dtype=torch.float32, out=out)
         return part.sum(0, dtype=torch.float32)
+    if out is not None:
+        return out.copy_(gy.t() @ x)
     return (gy.t() @ x).float()
 
 
@@ -70,18 +91,27 @@ class _LinearFn(torch.autograd.Function):
                 wb, bb = weight.to(torch.bfloat16), bias.to(torch.bfloat16)
             y = torch.addmm(bb, xb, wb.t())
         ctx.save_for_backward(xb, wb)
-        ctx.x_dtype = x.dtype
+        ctx.x_dtype, ctx.params = x.dtype, (weight, bias)
         return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, gy):
         xb, wb = ctx.saved_tensors
+        weight, bias = ctx.params
         gy = gy.contiguous()
-        with torch.autocast("cuda", enabled=False):
-            gx = (gy @ wb).to(ctx.x_dtype) if ctx.needs_input_grad[0] else None
-            gw = wgrad_split_k(gy, xb) if ctx.needs_input_grad[1] else None
-            gb = colsum_bf16(gy) if ctx.needs_input_grad[2] else None
+        gx = (gy @ wb).to(ctx.x_dtype) if ctx.needs_input_grad[0] else None
+        gw = gb = None
+        if ctx.needs_input_grad[1]:
+            if _first_write(weight):
+                wgrad_split_k(gy, xb, out=weight.grad)
+            else:
+                gw = wgrad_split_k(gy, xb)
+        if ctx.needs_input_grad[2]:
+            if _first_write(bias):
+                colsum_bf16(gy, out=bias.grad)
+            else:
+                gb = colsum_bf16(gy)
         return gx, gw, gb
 
 
@@ -195,7 +225,7 @@ class _Linear1Fn(torch.autograd.Function):
         xb = x.to(torch.bfloat16)
         wb, bb = _bf16_params(weight, bias)
         ctx.save_for_backward(xb, wb)
-        ctx.x_dtype = x.dtype
+        ctx.x_dtype, ctx.params = x.dtype, (weight, bias)
         return _linear1_forward(xb, wb, bb)
 
     @staticmethod
@@ -206,11 +236,19 @@ class _Linear1Fn(torch.autograd.Function):
         rows, cols = xb.shape
         gy = gy.contiguous()
         gx = torch.empty_like(xb) if ctx.needs_input_grad[0] else None
-        gwb = torch.empty(cols + 1, dtype=torch.float32, device=xb.device)
+        weight, bias = ctx.params
+        # weight [1, cols] and bias [1] sit next to each other in the flat gradient buffer: the kernel's [cols + 1] result goes there
+        b = getattr(weight, "_bucket", None)
+        direct = (b is not None and weight.grad is not None and bias.grad is not None and bias.grad.data_ptr() == weight.grad.data_ptr() + 4 * cols
+                  and getattr(weight, "_grad_gen", -1) != b.gen and getattr(bias, "_grad_gen", -1) != b.gen)
+        if direct:
+            weight._grad_gen = bias._grad_gen = b.gen
+        gwb = None if direct else torch.empty(cols + 1, dtype=torch.float32, device=xb.device)
         ws = _workspace("lin1", lib.phc_linear1_workspace(rows, cols), xb.device, torch.float32)
-        L.check(lib.phc_linear1_backward(xb.data_ptr(), wb.data_ptr(), gy.data_ptr(), rows, cols, None if gx is None else gx.data_ptr(), gwb.data_ptr(),
-                                         ws.data_ptr(), _stream(xb.device)), "phc_linear1_backward")
-        return (gx.to(ctx.x_dtype) if gx is not None else None), gwb[:cols].view(1, cols), gwb[cols:]
+        L.check(lib.phc_linear1_backward(xb.data_ptr(), wb.data_ptr(), gy.data_ptr(), rows, cols, None if gx is None else gx.data_ptr(),
+                                         weight.grad.data_ptr() if direct else gwb.data_ptr(), ws.data_ptr(), _stream(xb.device)), "phc_linear1_backward")
+        gx = gx.to(ctx.x_dtype) if gx is not None else None
+        return (gx, None, None) if direct else (gx, gwb[:cols].view(1, cols), gwb[cols:])
 
 
 class FastLinear(nn.Linear):
@@ -336,7 +374,7 @@ class _WeightedSumsqFn(torch.autograd.Function):
     @once_differentiable
     def backward(ctx, g):
         ts = ctx.saved_tensors
-        return (None,) + tuple(torch._foreach_mul(list(ts), [2.0 * c for c in ctx.coefs]))
+        return (None,) + tuple(t * (2.0 * c) for t, c in zip(ts, ctx.coefs))   # (torch._foreach_mul: 49 us for these three tensors)
 
 
 def weighted_sumsq(tensors, coefs):

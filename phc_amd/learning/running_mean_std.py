@@ -71,16 +71,15 @@ class RunningMeanStd(nn.Module):
         ws = None
         if update:
             need = lib.phc_running_norm_workspace(rows, cols) // 8
-            if getattr(self, "_ws", None) is None or self._ws.numel() < need or self._ws.device != input.device:
-                self._ws = torch.empty(need, dtype=torch.float64, device=input.device)
+            if getattr(self, "_ws_need", None) != need or self._ws.device != input.device:
+                # exact size: the kernel's ticket counter sits in the last 8 bytes (zero-initialised here, left at zero by the kernel)
+                self._ws, self._ws_need = torch.zeros(need, dtype=torch.float64, device=input.device), need
             ws = self._ws
         ptr = lambda t: None if t is None else t.data_ptr()
         L.check(lib.phc_running_norm(input.data_ptr(), ptr(row_index), rows, cols, src.running_mean.data_ptr(), src.running_var.data_ptr(), float(src.epsilon), 5.0,
                                      ptr(out), int(out_dtype == torch.bfloat16), ptr(self.running_mean if update else None),
                                      ptr(self.running_var if update else None), ptr(self.count if update else None), ptr(ws),
                                      torch.cuda.current_stream(input.device).cuda_stream), "phc_running_norm")
-        if update:
-            self.count += rows   # after the kernel read the old count (same stream)
         return out
 
     def forward(self, input, unnorm=False, norm_from=None, out_dtype=None, want_output=True, row_index=None, out=None):
