@@ -1,15 +1,17 @@
-"""Device-side pieces of the PPO update that are not GEMMs (csrc/phc_learn.hip) and the layer that uses them.
+"""Device-side pieces of the PPO / AMP update that are not GEMMs (csrc/phc_learn.hip) and the layers that use them.
 
-`FastLinear` is `nn.Linear` (same parameters, same state-dict keys) whose TRAINING pass under bf16 autocast on the device goes through
-one autograd node built for this shape of problem -- batch of 16 384 rows, 10^2..10^3 features:
-  * forward: bf16 addmm (hipBLASLt), as autocast does it;
-  * weight gradient dY^T X: the reduction dimension is the batch, 16x longer than the output is wide, and the library kernel picked
-    for it (MT64x64x256, no split-K) runs 240 workgroups for 105-115 us; as a batched GEMM over 8 row chunks + an fp32 sum it takes
-    44-68 us (scripts/gemm_probe2.py);
-  * bias gradient: `phc_colsum_bf16` instead of torch's generic column reduction (25 us for 1024 columns, 95 us for 69).
-It is used for the actor and critic (amp_agent.py:554-655); the discriminator keeps nn.Linear because its gradient penalty
-differentiates the backward pass itself (create_graph=True).  Anywhere else (CPU, fp32, no_grad rollouts, frozen columns) it is
-exactly nn.Linear.  `adam_clip_step` = clip_grad_norm_ + torch.optim.Adam.step on the flat parameter in two launches."""
+* `FastLinear` -- `nn.Linear` (same parameters, same state-dict keys) whose TRAINING pass under bf16 autocast on the device is one
+  autograd node built for this problem shape (16 384-row batches, 10^2..10^3 features): bf16 addmm forward; weight gradient dY^T X
+  as a batched GEMM over 8 row chunks + fp32 sum (the library's pick for a 16 384-long reduction is a 240-workgroup kernel without
+  split-K: 105-115 us vs 44-68 us, scripts/gemm_probe2.py); bias gradient by `phc_colsum_bf16`; one-output layers (the value head)
+  by `phc_linear1_*`.  Used for actor, critic, PNN columns.
+* `FastLinearDD` -- the same, differentiable twice, for the discriminator MLP whose gradient penalty differentiates the backward pass.
+* `ppo_loss`, `disc_bce`, `weighted_sumsq` -- the loss terms with their gradients as kernels (unit-weight convention, see `_PPOLossFn`).
+* `policy_sample` -- the rollout's sampling / neglogp / value un-normalisation in one kernel.
+* `adam_clip_step` -- clip_grad_norm_ + torch.optim.Adam.step on the flat parameter in two launches, also maintaining the bf16
+  parameter copy the layers read inside `FlatGradBucket.shadow_scope()`.
+Anywhere else (CPU, fp32, frozen columns) the layers are exactly nn.Linear and the agent uses the torch expressions the kernels are
+tested against (tests/test_learn_gpu.py)."""
 import ctypes as C
 
 import torch
