@@ -253,3 +253,18 @@ def test_stale_gradient_accumulator_probe():
     assert agent._stale_grad_accumulators()
     del tracked
     assert not agent._stale_grad_accumulators() and snap is not None
+
+
+def test_first_write_protocol_of_the_flat_bucket():
+    """fast_ops._first_write: a layer may store the first gradient of a step straight into `p.grad` exactly once per `zero()`; a
+    second contribution in the same step, a parameter outside a bucket, or one without a gradient buffer take the accumulate path."""
+    from phc_amd.learning.fast_ops import _first_write
+    lin = torch.nn.Linear(4, 3)
+    assert not _first_write(lin.weight)                      # not in a bucket
+    b = FlatGradBucket(lin.parameters())
+    b.zero()
+    assert _first_write(lin.weight) and not _first_write(lin.weight)
+    assert _first_write(lin.bias)
+    b.zero()
+    assert _first_write(lin.weight) and _first_write(lin.bias) and not _first_write(lin.bias)
+    assert b.shadow is None and lin.weight.grad.data_ptr() == b.flat.data_ptr()
