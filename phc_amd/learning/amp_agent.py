@@ -33,7 +33,7 @@ from torch import nn
 from .. import _lib as L
 from .network import A2CMCPNetwork, A2CNetwork, A2CPNNNetwork, ModelAMPContinuous, policy_kl
 from .replay_buffer import ReplayBuffer
-from .fast_ops import adam_clip_step, disc_bce, input_grad_only, policy_sample, ppo_loss, weighted_sumsq
+from .fast_ops import adam_clip_step, disc_bce, input_grad_only, policy_sample, ppo_loss, rows_with_grad, weighted_sumsq
 from .running_mean_std import RunningMeanStd
 
 
@@ -452,16 +452,25 @@ class IMAmpAgent:
             d, idx, amp_idx = d["_dataset"], d["_idx"], d["_amp_idx"]
         obs = self._preproc_obs(d["obs"], use_temp=self.temp_running_mean, row_index=idx)
         fused = obs.is_cuda
-        # (writing the three AMP batches straight into one [agent; replay; demo] buffer and differentiating the penalty to that
-        # buffer saves the torch.cat but measured slower -- 170 vs 145 ms per update, scripts/gpu_ab.sh: the penalty's double
-        # backward then carries 3x the rows)
-        amp_obs = self._preproc_amp_obs(d["amp_obs"], amp_idx)
-        amp_obs_replay = self._preproc_amp_obs(d["amp_obs_replay"], amp_idx)
-        amp_obs_demo = self._preproc_amp_obs(d["amp_obs_demo"], amp_idx)
-        amp_obs_demo.requires_grad_(True)
-        fused_disc = fused and self._disc_grad_penalty > 0
-        inp = {"is_train": True, "prev_actions": d["actions"], "obs": obs, "amp_obs": amp_obs, "amp_obs_replay": amp_obs_replay,
-               "amp_obs_demo": amp_obs_demo, "raw_disc_logits": fused_disc}
+        fused_disc = fused and self._disc_grad_penalty > 0 and self._normalize_amp_input
+        if fused_disc:
+            # the normaliser writes the three AMP batches into the row blocks of ONE [agent; replay; demo] buffer (no torch.cat in front
+            # of the discriminator); the demo block is also the leaf the gradient penalty differentiates to
+            m = amp_idx.numel() if amp_idx is not None else d["amp_obs"].shape[0]
+            dt = torch.bfloat16 if self.bf16 else torch.float32
+            cat = torch.empty((3 * m, d["amp_obs"].shape[1]), dtype=dt, device=obs.device)
+            for k, key in enumerate(("amp_obs", "amp_obs_replay", "amp_obs_demo")):
+                self._amp_input_mean_std(d[key], out_dtype=dt, row_index=amp_idx, out=cat[k * m:(k + 1) * m])
+            amp_obs = cat[:m]
+            amp_obs_demo = cat[2 * m:].requires_grad_(True)
+            inp = {"is_train": True, "obs": obs, "amp_obs_cat": rows_with_grad(cat, amp_obs_demo, 2 * m), "raw_disc_logits": True}
+        else:
+            amp_obs = self._preproc_amp_obs(d["amp_obs"], amp_idx)
+            amp_obs_replay = self._preproc_amp_obs(d["amp_obs_replay"], amp_idx)
+            amp_obs_demo = self._preproc_amp_obs(d["amp_obs_demo"], amp_idx)
+            amp_obs_demo.requires_grad_(True)
+            inp = {"is_train": True, "prev_actions": d["actions"], "obs": obs, "amp_obs": amp_obs, "amp_obs_replay": amp_obs_replay,
+                   "amp_obs_demo": amp_obs_demo, "raw_disc_logits": False}
         with self._autocast():
             res = self.model.forward_heads(inp) if fused else self.model(inp)
         if fused_disc:

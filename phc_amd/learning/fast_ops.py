@@ -316,6 +316,25 @@ def ppo_loss(mu, value, logstd, actions, old_neglogp, adv, returns, old_values, 
     return _PPOLossFn.apply(mu, value, logstd, actions, old_neglogp, adv, returns, old_values if clip_value else None, old_mu, old_sigma, prm, unit_grad, row_index)
 
 
+class _RowsWithGradFn(torch.autograd.Function):
+    """`buf` [n, A] already holds all rows (written in place by the normaliser); rows [start:] additionally ARE the leaf `rows_leaf`
+    (same memory).  Forward is a view of `buf` -- no `torch.cat` of the discriminator's three input batches -- and backward hands the
+    leaf its row block of the incoming gradient (differentiable again: the gradient penalty differentiates through it)."""
+
+    @staticmethod
+    def forward(ctx, buf, rows_leaf, start):
+        ctx.start = start
+        return buf.view_as(buf)
+
+    @staticmethod
+    def backward(ctx, g):
+        return None, g[ctx.start:], None
+
+
+def rows_with_grad(buf, rows_leaf, start):
+    return _RowsWithGradFn.apply(buf, rows_leaf, start)
+
+
 class _DiscBCEFn(torch.autograd.Function):
     """0.5 (BCEWithLogits(agent rows, 0) + BCEWithLogits(demo rows, 1)) * scale, the two accuracies, and the gradient w.r.t. the
     logits in one launch (`phc_disc_bce`).  Unit-weight convention as `_PPOLossFn`: the result is added to the total loss as it is."""

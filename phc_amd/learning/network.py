@@ -207,10 +207,14 @@ class ModelAMPContinuous(nn.Module):
         obs = input_dict["obs"]
         mu, logstd = self.a2c_network.eval_actor(obs)
         value = self.a2c_network.eval_critic(obs)
-        a, r, d = input_dict["amp_obs"], input_dict["amp_obs_replay"], input_dict["amp_obs_demo"]
+        if "amp_obs_cat" in input_dict:   # [agent; replay; demo] already assembled in one buffer (fast_ops.rows_with_grad)
+            x = input_dict["amp_obs_cat"]
+        else:
+            a, r, d = input_dict["amp_obs"], input_dict["amp_obs_replay"], input_dict["amp_obs_demo"]
+            x = torch.cat([a, r, d], dim=0)
         # one discriminator pass over [agent; replay; demo] (the reference runs three, amp_models.py:40-48); a separate demo pass would
         # shrink the gradient penalty's double backward to a third of the rows but adds nine launches: no gain measured (scripts/gpu_ab.sh)
-        logits_raw = self.a2c_network.eval_disc(torch.cat([a, r, d], dim=0))
+        logits_raw = self.a2c_network.eval_disc(x)
         if input_dict.get("raw_disc_logits", False):   # the fused discriminator loss takes the [3m, 1] logits as the GEMM wrote them
             la = lr_ = ld = None
         else:
