@@ -291,8 +291,12 @@ class IMAmpAgent:
                 self.obs = self.env_reset(done_indices)
             else:
                 task.reset_done()
-                self.obs = torch.clamp(task.obs_buf, -self.vec_env.clip_obs, self.vec_env.clip_obs) if np.isfinite(self.vec_env.clip_obs) else task.obs_buf
-            e["obses"][n].copy_(self.obs)
+                if np.isfinite(self.vec_env.clip_obs):   # clamp straight into the experience buffer row
+                    self.obs = torch.clamp(task.obs_buf, -self.vec_env.clip_obs, self.vec_env.clip_obs, out=e["obses"][n])
+                else:
+                    self.obs = task.obs_buf
+            if self.obs.data_ptr() != e["obses"][n].data_ptr():
+                e["obses"][n].copy_(self.obs)
             if fused:
                 # heads as the GEMMs produce them; sampling, neglogp, sigma and the value un-normalisation in one kernel that
                 # writes the rows of the experience buffer
@@ -310,7 +314,7 @@ class IMAmpAgent:
                     e[k][n].copy_(res[k])
             self.obs, rewards, self.dones, infos = self.vec_env.step(res["actions"])
             rewards = rewards.unsqueeze(1) if rewards.dim() == 1 else rewards
-            e["rewards"][n].copy_(rewards * self.reward_scale)
+            e["rewards"][n].copy_(rewards if self.reward_scale == 1 else rewards * self.reward_scale)
             e["next_obses"][n].copy_(self.obs)
             e["dones"][n].copy_(self.dones)
             e["amp_obs"][n].copy_(infos["amp_obs"])

@@ -55,7 +55,7 @@ class A2CNetwork(nn.Module):
 
     def eval_actor(self, obs):
         mu = self.mu(self.actor_mlp(obs))
-        return mu, mu * 0.0 + self.sigma  # amp_network_builder.py:143-151 (logstd broadcast)
+        return mu, self.sigma.expand_as(mu)  # amp_network_builder.py:143-151 (`mu * 0.0 + sigma`: the logstd broadcast, as a view)
 
     def eval_critic(self, obs):
         return self.value(self.critic_mlp(obs))
@@ -131,7 +131,7 @@ class A2CPNNNetwork(A2CNetwork):
 
     def eval_actor(self, obs):
         mu, _ = self.pnn(obs, idx=self.training_prim)
-        return mu, mu * 0.0 + self.sigma
+        return mu, self.sigma.expand_as(mu)
 
 
 class A2CMCPNetwork(A2CNetwork):
@@ -154,7 +154,7 @@ class A2CMCPNetwork(A2CNetwork):
 
     def eval_actor(self, obs):
         mu = self.composer(obs)
-        return mu, mu * 0.0 + self.sigma
+        return mu, self.sigma.expand_as(mu)
 
 
 def forward_pmcp(checkpoint, trained_idx):
