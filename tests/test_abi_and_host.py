@@ -168,3 +168,23 @@ def test_motion_lib_loader_vs_reference(golden, heading):
     np.testing.assert_array_equal(lib.get_motion_num_steps().numpy(), golden("motion_lib_eval")["num_steps"])
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         lib.get_motion_state(torch.zeros(2, dtype=torch.long), torch.zeros(2))
+
+
+def test_learner_entry_points_validate_arguments_before_launching():
+    """The learner-side entry points reject null / non-positive arguments with PHC_EINVAL before touching the device (runs without a GPU)."""
+    from phc_amd import _lib
+    lib = _lib.load()
+    EINVAL = -1
+    assert lib.phc_running_norm(None, None, 4, 3, None, None, 1e-5, 5.0, None, 0, None, None, None, None, None) == EINVAL
+    assert lib.phc_colsum_bf16(None, 4, 3, None, None, None) == EINVAL
+    assert lib.phc_adam_clip_step(None, None, None, None, 10, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1, 50.0, None, None, None, None, None) == EINVAL
+    prm = _lib.PpoParams(0.2, 5.0, 0.0, 10.0, 0)
+    assert lib.phc_ppo_loss(None, None, 1, None, None, None, None, None, None, None, None, None, 8, 3, C.byref(prm), None, None, None, None, None) == EINVAL
+    assert lib.phc_policy_sample(None, None, 1, None, None, None, None, 1e-5, None, 8, 3, None, None, None, None, None, None) == EINVAL
+    assert lib.phc_linear1_forward(None, None, None, 8, 3, None, None) == EINVAL
+    assert lib.phc_linear1_backward(None, None, None, 8, 3, None, None, None, None) == EINVAL
+    assert lib.phc_disc_bce(None, 1, 4, 2, 1.0, None, None, None) == EINVAL
+    assert lib.phc_weighted_sumsq(0, None, None, None, 0, None, None, None) == EINVAL
+    assert lib.phc_weighted_sumsq(5, None, None, None, 0, None, None, None) == EINVAL
+    assert lib.phc_running_norm_workspace(16384, 934) == (16384 // 32) * 2 * 934 * 8 + 8
+    assert lib.phc_colsum_workspace(16384, 1024) > 0 and lib.phc_adam_workspace() > 0 and lib.phc_ppo_loss_workspace() > 0 and lib.phc_sumsq_workspace() > 0
