@@ -42,7 +42,12 @@ _ENV_IM_GETUP_MCP = dict(  # env/env_im_getup_mcp.yaml
     start_idx=0, collect_dataset=False, has_pnn=True, fitting=True, num_prim=4, training_prim=0, actors_to_load=4, has_lateral=False,
     models=[], zero_out_far=True, zero_out_far_train=False, cycle_motion=True, getup_udpate_epoch=1000, getup_schedule=True,
     recoverySteps=90, zero_out_far_steps=90, recoveryEpisodeProb=0.5, fallInitProb=0.3, hard_negative=False, z_activation="silu",
-    power_coefficient=0.00005)
+    power_coefficient=0.00005,
+    # legacy keys of that yaml (the simulator settings actually used come from the sim group)
+    asset={"assetRoot": "/", "assetFileName": "mjcf/smpl_humanoid.xml"}, sim=None, substeps=2,
+    physx={"num_threads": 4, "solver_type": 1, "num_position_iterations": 4, "num_velocity_iterations": 0, "contact_offset": 0.02,
+           "rest_offset": 0.0, "bounce_threshold_velocity": 0.2, "max_depenetration_velocity": 10.0, "default_buffer_size_multiplier": 10.0},
+    flex={"num_inner_iterations": 10, "warm_start": 0.25})
 _ENV_IM_GETUP_MCP.pop("min_length", None)
 
 _H1_BODIES = ['pelvis', 'left_hip_yaw_link', 'left_hip_roll_link', 'left_hip_pitch_link', 'left_knee_link', 'left_ankle_link',
@@ -77,6 +82,13 @@ _ROBOT_H1 = {  # robot/unitree_h1.yaml
                       {"joint_name": "right_hand_link", "parent_name": "right_elbow_link", "pos": [0.3, 0.0, 0.0], "rot": [1.0, 0.0, 0.0, 0.0]},
                       {"joint_name": "head_link", "parent_name": "pelvis", "pos": [0.0, 0.0, 0.6], "rot": [1.0, 0.0, 0.0, 0.0]}],
     "base_link": "torso_link",
+    # read by the reference's retargeting scripts only (scripts/data_process/fit_smpl_*.py); kept so that the yaml tree is complete
+    "joint_matches": [["pelvis", "Pelvis"], ["left_hip_yaw_link", "L_Hip"], ["left_knee_link", "L_Knee"], ["left_ankle_link", "L_Ankle"],
+                      ["right_hip_yaw_link", "R_Hip"], ["right_knee_link", "R_Knee"], ["right_ankle_link", "R_Ankle"],
+                      ["left_shoulder_roll_link", "L_Shoulder"], ["left_elbow_link", "L_Elbow"], ["left_hand_link", "L_Hand"],
+                      ["right_shoulder_roll_link", "R_Shoulder"], ["right_elbow_link", "R_Elbow"], ["right_hand_link", "R_Hand"], ["head_link", "Head"]],
+    "smpl_pose_modifier": [{"Pelvis": "[np.pi/2, 0, np.pi/2]"}, {"L_Shoulder": "[0, 0, -np.pi/2]"}, {"R_Shoulder": "[0, 0, np.pi/2]"},
+                           {"L_Elbow": "[0, -np.pi/2, 0]"}, {"R_Elbow": "[0, np.pi/2, 0]"}],
 }
 
 _G1_HAND = ["zero", "one", "two", "three", "four", "five", "six"]
@@ -91,7 +103,12 @@ _ROBOT_G1 = dict(_ROBOT_H1, humanoid_type="g1", body_names=_G1_BODIES, dof_names
                  right_foot_name="r_foot_roll", left_foot_name="l_foot_roll",
                  asset={"assetRoot": "./", "assetFileName": "phc/data/assets/robot/unitree_g1/g1.xml",
                         "urdfFileName": "phc/data/assets/robot/unitree_g1/g1.xml"},
-                 extend_config=[{"joint_name": "head_link", "parent_name": "pelvis", "pos": [0.0, 0.0, 0.4], "rot": [1.0, 0.0, 0.0, 0.0]}])
+                 extend_config=[{"joint_name": "head_link", "parent_name": "pelvis", "pos": [0.0, 0.0, 0.4], "rot": [1.0, 0.0, 0.0, 0.0]}],
+                 joint_matches=[["pelvis", "Pelvis"], ["left_hip_pitch_link", "L_Hip"], ["left_knee_link", "L_Knee"], ["left_ankle_roll_link", "L_Ankle"],
+                                ["right_hip_pitch_link", "R_Hip"], ["right_knee_link", "R_Knee"], ["right_ankle_roll_link", "R_Ankle"],
+                                ["left_shoulder_roll_link", "L_Shoulder"], ["left_elbow_pitch_link", "L_Elbow"], ["left_zero_link", "L_Hand"],
+                                ["right_shoulder_roll_link", "R_Shoulder"], ["right_elbow_pitch_link", "R_Elbow"], ["right_zero_link", "R_Hand"],
+                                ["head_link", "Head"]])
 _ROBOT_G1.pop("sim_with_urdf", None)
 
 _ENV_VR = dict(_ENV_IM, notes="VR modell, three point tracking", reset_bodies=["Head", "L_Hand", "R_Hand"],   # env/env_vr.yaml

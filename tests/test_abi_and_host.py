@@ -105,10 +105,17 @@ def test_model_asset_is_what_the_compiler_produces_from_the_reference_mjcf():
     b = load_model("smpl_humanoid")
     for x, y in zip(a.pack(), b.pack()):
         np.testing.assert_array_equal(x, y)
+    for name, xml in (("h1_humanoid", "unitree_h1/h1.xml"), ("g1_humanoid", "unitree_g1/g1.xml")):   # robots: mesh hulls from the shipped STLs
+        a = ArticulationModel(compile_mjcf("/root/reference/phc/data/assets/robot/" + xml))
+        for x, y in zip(a.pack(), load_model(name).pack()):
+            np.testing.assert_array_equal(x, y)
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/phc/data/cfg"), reason="reference checkout not present")
-@pytest.mark.parametrize("ov", [[], ["learning=im_big"], ["learning=im_pnn", "env=env_im_pnn"], ["learning=im_pnn_big"]])
+@pytest.mark.parametrize("ov", [[], ["learning=im_big"], ["learning=im_pnn", "env=env_im_pnn"], ["learning=im_pnn_big"],
+                                ["learning=im_mcp", "env=env_im_getup_mcp"], ["env=env_vr"],
+                                ["robot=unitree_h1", "env=env_im_h1_phc", "sim=robot_sim", "control=robot_control"],
+                                ["robot=unitree_g1", "env=env_im_g1_phc", "sim=robot_sim", "control=robot_control", "learning=im_pnn_big"]])
 def test_builtin_config_equals_reference_yaml_tree(ov):
     """B3: the reference's yaml tree loads unchanged, and the built-in groups agree with it key by key."""
     from phc_amd.config import compose
