@@ -91,6 +91,9 @@ _ROBOT_H1 = {  # robot/unitree_h1.yaml
                            {"L_Elbow": "[0, -np.pi/2, 0]"}, {"R_Elbow": "[0, np.pi/2, 0]"}],
 }
 
+_ROBOT_H1_NOHEAD = dict(_ROBOT_H1, extend_config=_ROBOT_H1["extend_config"][:2],   # robot/unitree_h1_nohead.yaml: hands only
+                        joint_matches=[m for m in _ROBOT_H1["joint_matches"] if m[0] not in ("left_hand_link", "right_hand_link")])
+
 _G1_HAND = ["zero", "one", "two", "three", "four", "five", "six"]
 _G1_LEG = ["hip_pitch", "hip_roll", "hip_yaw", "knee", "ankle_pitch", "ankle_roll"]
 _G1_ARM = ["shoulder_pitch", "shoulder_roll", "shoulder_yaw", "elbow_pitch", "elbow_roll"] + _G1_HAND
@@ -176,7 +179,7 @@ def _with_net(units, activation, net_name, cfg, extra_net):
 _BIG = [2048, 1536, 1024, 1024, 512, 512]
 GROUPS = {
     "env": {"env_im": _ENV_IM, "env_im_pnn": _ENV_IM_PNN, "env_im_getup_mcp": _ENV_IM_GETUP_MCP, "env_im_h1_phc": _ENV_IM_H1, "env_im_g1_phc": _ENV_IM_G1, "env_vr": _ENV_VR},
-    "robot": {"smpl_humanoid": _ROBOT_SMPL, "unitree_h1": _ROBOT_H1, "unitree_g1": _ROBOT_G1},
+    "robot": {"smpl_humanoid": _ROBOT_SMPL, "unitree_h1": _ROBOT_H1, "unitree_h1_nohead": _ROBOT_H1_NOHEAD, "unitree_g1": _ROBOT_G1},
     "learning": {"im": _learning([1024, 512], "relu"), "im_big": _learning(_BIG, "silu", extra_cfg={"save_frequency": 1500}),
                  "im_pnn": _learning([1024, 512], "relu", "amp_pnn"),
                  "im_pnn_big": _learning(_BIG, "silu", "amp_pnn", {"amp_dropout": False, "save_frequency": 1500}),

@@ -115,6 +115,7 @@ def test_model_asset_is_what_the_compiler_produces_from_the_reference_mjcf():
 @pytest.mark.parametrize("ov", [[], ["learning=im_big"], ["learning=im_pnn", "env=env_im_pnn"], ["learning=im_pnn_big"],
                                 ["learning=im_mcp", "env=env_im_getup_mcp"], ["env=env_vr"],
                                 ["robot=unitree_h1", "env=env_im_h1_phc", "sim=robot_sim", "control=robot_control"],
+                                ["robot=unitree_h1_nohead", "env=env_im_h1_phc", "sim=robot_sim", "control=robot_control"],
                                 ["robot=unitree_g1", "env=env_im_g1_phc", "sim=robot_sim", "control=robot_control", "learning=im_pnn_big"]])
 def test_builtin_config_equals_reference_yaml_tree(ov):
     """B3: the reference's yaml tree loads unchanged, and the built-in groups agree with it key by key."""
