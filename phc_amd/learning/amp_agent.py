@@ -201,7 +201,7 @@ class IMAmpAgent:
         # AccumulateGrad node lives on the stream it was created on; the captured backward then has to hand the gradient to a stream
         # that is not capturing and `hipStreamEndCapture` segfaults on ROCm 7.2 instead of raising.
         self._use_graph = bool(c.get("hip_graph", False))
-        self._graph = self._g_data = self._g_idx = self._g_step = self._g_info = None
+        self._graph = self._g_data = self._g_idx = self._g_info = None
         self._graph_failed = False
         # one flat fp32 parameter; on the device clip + step are two HIP launches over it (fast_ops.adam_clip_step) and this object
         # only holds the state (checkpoint format unchanged)
@@ -543,11 +543,12 @@ class IMAmpAgent:
         return info
 
     # ------------------------------------------------------------------ the optimizer step as a hipGraph
-    # With the loss, normaliser and optimizer kernels fused, a step is ~210 launches of 2.5 ms total device time and the host needs
-    # 2.7-3.9 ms to issue them (it varies with the box): launch-bound.  Single-GPU device runs therefore capture ONE step -- minibatch
-    # given by a row-index buffer into persistent dataset tensors, Adam's step count on the device -- and replay it 48 times per epoch.
+    # With the loss, normaliser and optimizer kernels fused, a step is ~140 launches of 2 ms total device time and the host needs
+    # 2.7-3.9 ms to issue them (it varies with the box): launch-bound.  Device runs can therefore capture the forward / backward part of
+    # ONE step -- minibatch given by a row-index buffer into persistent dataset tensors -- and replay it 48 times per epoch; the
+    # gradient all-reduce (multi-GPU) and the two optimizer launches follow each replay eagerly, so the graph holds no collective.
     def _graph_enabled(self):
-        return (self.grads.flat.is_cuda and self.world == 1 and self._use_graph and not self._graph_failed and self.minibatch_size >= 2048
+        return (self.grads.flat.is_cuda and self._use_graph and not self._graph_failed and self.minibatch_size >= 2048
                 and not os.environ.get("PHC_NO_GRAPH"))
 
     def _stale_grad_accumulators(self):
@@ -578,31 +579,23 @@ class IMAmpAgent:
 
     def _graph_step_body(self):
         info = self._fwd_bwd({"_dataset": self._g_data, "_idx": self._g_idx, "_amp_idx": self._g_idx[:self._amp_minibatch_size]})
-        adam_clip_step(self.optimizer, self.grads.flat_param, self.grads.flat, self.grad_norm if self.truncate_grads else None,
-                       shadow=self.grads.shadow, step_device=self._g_step, count_host=False)
         self._g_keys = list(info)
         self._g_info += torch.stack([info[k].float().reshape(()) for k in self._g_keys])
 
     def _graph_update(self):
-        """All mini-epochs of one epoch through the captured step; returns the mean info dict (device tensors, no host sync)."""
+        """All mini-epochs of one epoch through the captured forward / backward; returns the mean info dict (device tensors)."""
         self.set_train()
         self._graph_static_dataset()
         if self._g_idx is None:
             self._g_idx = torch.zeros(self.minibatch_size, dtype=torch.int64, device=self.device)
-            self._g_step = torch.zeros((), dtype=torch.int64, device=self.device)
             self._g_info = torch.zeros(len(self._probe_info_keys()), dtype=torch.float32, device=self.device)
-        st = self.optimizer.state[self.grads.flat_param]
-        if len(st) == 0:   # let the eager path create the optimizer state first
-            return None
-        self._g_step.fill_(int(st["step"].item()))
         if self._graph is None:
             if self._stale_grad_accumulators():
                 raise RuntimeError("an autograd graph outside the update holds a parameter's gradient accumulator (e.g. `p.clone()` kept "
                                    "alive: use `p.detach().clone()`); stream capture would crash")
             self._g_idx.copy_(self._idx_buf[:self.minibatch_size])
-            # throw-away state for the warm-up steps torch asks for before a capture: parameters, optimizer and normaliser
-            # statistics are restored afterwards, so that capturing does not train
-            keep = [t.clone() for t in (self.grads.flat_param, st["exp_avg"], st["exp_avg_sq"])]
+            # the warm-up passes torch asks for before a capture must not train: they only touch the gradients (zeroed by every step)
+            # and the normaliser statistics, which are restored afterwards
             norms = [(m, [b.clone() for b in m.buffers()]) for m in self._norms()]
             try:
                 side = torch.cuda.Stream()
@@ -615,13 +608,9 @@ class IMAmpAgent:
                 with torch.cuda.graph(g):
                     self._graph_step_body()
             finally:
-                for t, k in zip((self.grads.flat_param, st["exp_avg"], st["exp_avg_sq"]), keep):
-                    t.copy_(k)
                 for m, bufs in norms:
                     for b, k in zip(m.buffers(), bufs):
                         b.copy_(k)
-                self.grads.shadow.copy_(self.grads.flat_param)
-                self._g_step.fill_(int(st["step"].item()))
             self._graph = g
         self._g_info.zero_()
         n = 0
@@ -632,7 +621,8 @@ class IMAmpAgent:
                 if e >= self.batch_size:
                     self._idx_buf[:] = torch.randperm(self.batch_size, device=self._idx_buf.device)
                 self._graph.replay()
-                st["step"] += 1
+                self.grads.all_reduce_mean(self.dist)
+                self._clip_and_step()
                 n += 1
         mean = self._g_info / n
         return {k: mean[j] for j, k in enumerate(self._g_keys)}
