@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PHC_ABI_VERSION 17
+#define PHC_ABI_VERSION 18
 #define PHC_MAX_BODIES 64   /* bodies (incl. extended reference bodies) per articulation; also the slot count of the model tables */
 #define PHC_EINVAL (-1)
 #define PHC_EUNSUPPORTED (-2)
@@ -145,6 +145,8 @@ typedef struct {
     int32_t num_ext_bodies;           /* robot.extend_config entries used by the full-body reward (humanoid_im.py:74-82,916-923) */
     const int32_t* ext_parent;        /* [E] body id of each extended body's parent */
     const float* ext_offset;          /* [E,3] position in the parent frame */
+    int32_t obs_v;                    /* task-observation version: 6 (0 is read as 6; `compute_imitation_observations_v6`, humanoid_im.py:1300-1360: 24 floats per
+                                         tracked body) or 7 (`_v7`, :1362-1393, the keypoint models: position / velocity differences + reference positions, 9) */
 } phc_im_params_t;
 
 /* Task-owned per-env buffers (phc/env/tasks/base_task.py:99-105, humanoid_amp.py:109-116,

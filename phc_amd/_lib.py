@@ -58,7 +58,7 @@ class ImParams(C.Structure):
                 ("num_amp_obs_steps", c_i32), ("num_amp_obs_per_step", c_i32),
                 ("num_self_obs", c_i32), ("num_task_obs", c_i32),
                 ("cycle_motion", c_i32), ("zero_out_far", c_i32), ("close_distance", c_f), ("far_distance", c_f),
-                ("dofs_per_joint", c_i32), ("num_ext_bodies", c_i32), ("ext_parent", c_p), ("ext_offset", c_p)]
+                ("dofs_per_joint", c_i32), ("num_ext_bodies", c_i32), ("ext_parent", c_p), ("ext_offset", c_p), ("obs_v", c_i32)]
 
 
 class ImBuffers(C.Structure):
@@ -123,7 +123,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the .so does not export the symbol
         fn.argtypes = argtypes
         fn.restype = restype
-    if lib.phc_abi_version() != 17:
+    if lib.phc_abi_version() != 18:
         raise ImportError("libphc_amd.so ABI version mismatch")
     _lib = lib
     return lib

@@ -107,8 +107,9 @@ def im_params_struct(dt, max_episode_length, reward_specs, power_reward, power_c
                      track_slot, reset_mask, num_reset_bodies, first_reset_body, termination_distances, num_key_bodies, key_body_ids,
                      num_amp_joints, amp_joint_slot, num_amp_obs_steps, num_amp_obs_per_step, num_self_obs, num_task_obs,
                      cycle_motion=False, zero_out_far=False, close_distance=0.25, far_distance=3.0,
-                     dofs_per_joint=3, ext_parent=None, ext_offset=None):
+                     dofs_per_joint=3, ext_parent=None, ext_offset=None, obs_v=6):
     p = L.ImParams()
+    p.obs_v = int(obs_v)
     p.dofs_per_joint = int(dofs_per_joint)
     p.num_ext_bodies = 0 if ext_parent is None else int(ext_parent.shape[0])
     p.ext_parent, p.ext_offset = ptr(ext_parent), ptr(ext_offset)

@@ -181,6 +181,13 @@ PHC_HD void self_obs_lane(const phc_im_params_t& prm, int nb, int j, const BodyS
 PHC_HD void task_obs_lane(const phc_im_params_t& prm, int slot, const BodyState& body, const BodyState& root,
                           const BodyState& ref, Q4 hinv, Q4 h, float* tobs) {
     const int jt = prm.num_track_bodies;
+    if (prm.obs_v == 7) {
+        // compute_imitation_observations_v7 (humanoid_im.py:1362-1393, the keypoint models): no rotation terms
+        st3(tobs + slot * 3, quat_rotate(hinv, ref.pos - body.pos));
+        st3(tobs + jt * 3 + slot * 3, quat_rotate(hinv, ref.vel - body.vel));
+        st3(tobs + jt * 6 + slot * 3, quat_rotate(hinv, ref.pos - root.pos));
+        return;
+    }
     st3(tobs + slot * 3, quat_rotate(hinv, ref.pos - body.pos));
     Q4 drot = quat_mul(ref.rot, quat_conjugate(body.rot));
     Q4 dl = quat_mul(quat_mul(hinv, drot), h);

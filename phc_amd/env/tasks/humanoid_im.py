@@ -90,10 +90,10 @@ class HumanoidIm:
             v = env.get(k, robot.get(k, off))
             if v != off:
                 raise NotImplementedError(f"config option {k}={v!r} is outside the hot path built so far")
-        if env.get("obs_v", 1) != 6 or env.get("self_obs_v", 1) != 1 or env.get("amp_obs_v", 1) != 1:
-            raise NotImplementedError("only obs_v=6 / self_obs_v=1 / amp_obs_v=1 (the shipped env_im* configs) are built")
+        if env.get("obs_v", 1) not in (6, 7) or env.get("self_obs_v", 1) != 1 or env.get("amp_obs_v", 1) != 1:
+            raise NotImplementedError("only obs_v=6 (the shipped env_im* configs) / obs_v=7 (the keypoint models), self_obs_v=1, amp_obs_v=1 are built")
         self.has_task = True
-        self.obs_v, self.self_obs_v, self.amp_obs_v = 6, 1, 1
+        self.obs_v, self.self_obs_v, self.amp_obs_v = int(env.get("obs_v", 6)), 1, 1
         if self._is_robot:  # load_robot_configs, humanoid.py:422-439
             self._body_names_orig = list(robot["body_names"])
             self._body_names = self._body_names_orig
@@ -403,7 +403,7 @@ class HumanoidIm:
             first_reset_body=self._body_names.index(self._reset_bodies[0]), termination_distances=self._termination_distances_full,
             num_key_bodies=len(self.key_bodies), key_body_ids=key_ids, num_amp_joints=self._n_amp_joints, amp_joint_slot=amp_slot,
             num_amp_obs_steps=self._num_amp_obs_steps, num_amp_obs_per_step=self._num_amp_obs_per_step,
-            num_self_obs=self._num_self_obs, num_task_obs=self.get_task_obs_size(), cycle_motion=self.cycle_motion,
+            num_self_obs=self._num_self_obs, num_task_obs=self.get_task_obs_size(), obs_v=self.obs_v, cycle_motion=self.cycle_motion,
             zero_out_far=self.zero_out_far, close_distance=self.close_distance, far_distance=self.far_distance,
             dofs_per_joint=1 if self._is_robot else 3, ext_parent=self._ext_parent_i32, ext_offset=self._ext_offset_f32)
         self._flag_state = (flags.im_eval, flags.no_collision_check)
@@ -433,7 +433,7 @@ class HumanoidIm:
         return self._num_self_obs
 
     def get_task_obs_size(self):
-        return len(self._track_bodies) * 24 if self._enable_task_obs else 0  # obs_v 6: humanoid_im.py:505-506
+        return len(self._track_bodies) * (9 if self.obs_v == 7 else 24) if self._enable_task_obs else 0  # humanoid_im.py:505-509
 
     def get_obs_size(self):
         return self.get_self_obs_size() + self.get_task_obs_size()

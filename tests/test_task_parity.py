@@ -312,3 +312,31 @@ def test_three_point_tracking_vs_reference_golden(golden, backend):
     np.testing.assert_array_equal(o["term"], gv["terminate"])
     np.testing.assert_allclose(o["raw"][:, :4], g["reward_raw"], atol=1e-5)     # full-body reward unchanged
     assert gv["terminate"].sum() > 0
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("vr", [False, True])
+def test_task_obs_v7_vs_reference_golden(golden, backend, vr):
+    """`env.obs_v=7` (the reference's keypoint models): 9 floats per tracked body -- position / velocity differences and reference
+    positions in the heading frame -- == compute_imitation_observations_v7, for all bodies and for the three-point subset."""
+    be = get_backend(backend)
+    g, g7 = golden("task_fns"), golden("task_fns_v7")
+    model, mstruct, keepm = model_on(be)
+    lib, keep = motion_lib_on(be, golden("motion_lib_eval"))
+    N = g["body_pos"].shape[0]
+    bodies = ["Head", "L_Hand", "R_Hand"] if vr else None
+    nt = 3 if vr else 24
+    prm, keepp = make_im_params(be, model, N, track_bodies=bodies, obs_v=7)
+    prm.num_task_obs = 9 * nt
+    arrs, sim = _sim_arrays(be, g, N)
+    amp_in, amp_out = be.zeros((N, 10, 196)), be.zeros((N, 10, 196))
+    b = dict(progress=be.arr((g["progress"] - 1).astype(np.int64)), reset=be.zeros(N, np.int64), term=be.zeros(N, np.int64), rew=be.zeros(N),
+             raw=be.zeros((N, 5)), obs=be.zeros((N, 358 + 9 * nt)), mids=be.arr(g["env_motion"].astype(np.int64)),
+             st=be.arr(g["start_times"].astype(F)), so=be.zeros(N), goff=be.zeros((N, 3)))
+    buf = abi.im_buffers_struct(b["progress"], b["reset"], b["term"], b["rew"], b["raw"], b["obs"], amp_in, amp_out, b["mids"], b["st"], b["so"], b["goff"])
+    assert be.im_post_physics(mstruct, lib, prm, sim, buf) == 0
+    be.sync()
+    obs = be.np(b["obs"])
+    np.testing.assert_allclose(obs[:, :358], g["self_obs"], atol=1e-5)
+    np.testing.assert_allclose(obs[:, 358:], g7["task_obs_vr" if vr else "task_obs"], atol=1e-5)
+    np.testing.assert_allclose(be.np(b["raw"])[:, :4], g["reward_raw"], atol=1e-5)     # the reward does not depend on the observation version
