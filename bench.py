@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU (BASELINE configs[1]: 4096)")
     ap.add_argument("--no-update-graph", action="store_true", help="PPO update with eager launches instead of the captured hipGraph "
                     "(learning.params.config.hip_graph; single-GPU runs only)")
+    ap.add_argument("--multi-gpu-update-graph", action="store_true", help="use the captured update graph also with more than one rank")
     ap.add_argument("--ppo-epochs", type=int, default=3, help="timed PPO epochs (rollout 32 steps + 36 optimizer steps); 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--robot", choices=["smpl", "h1", "g1"], default="smpl", help="smpl: BASELINE configs[1] (the bench line); h1: configs[4] morphology "
@@ -169,7 +170,9 @@ def main():
     from phc_amd.env.tasks.vec_task import parse_task
     torch.manual_seed(rank)  # per-rank seed offset, as the reference's horovod path does (run_hydra.py:121)
     robot_over = [f"robot=unitree_{args.robot}", f"env=env_im_{args.robot}_phc", "sim=robot_sim", "control=robot_control"] if args.robot != "smpl" else []
-    graph_over = [] if args.no_update_graph else ["+learning.params.config.hip_graph=True"]
+    # the captured update graph has been exercised on one GPU only (no multi-GPU box in development): runs with more ranks keep the
+    # eager launch sequence unless asked otherwise
+    graph_over = ["+learning.params.config.hip_graph=True"] if (not args.no_update_graph and (world == 1 or args.multi_gpu_update_graph)) else []
     cfg = compose(robot_over + graph_over + [f"env.num_envs={args.envs}", f"env.motion_file=synthetic:{args.motion_clips}:0", f"device_id={local_rank}",
                                 f"rl_device=cuda:{local_rank}", f"+solver.lane_mapping={args.lane_mapping}"] + ([f"+solver.self_collision={args.self_collision}"] if args.self_collision >= 0 else []))
     task, env = parse_task(cfg, device_id=local_rank)
