@@ -267,6 +267,23 @@ def test_update_graph_equals_eager_launches():
         assert abs(a - b) <= 2e-3 * max(1.0, abs(b)), (k, a, b)
 
 
+@pytest.mark.parametrize("mode", ["eager", "graph"])
+def test_two_rank_update_on_one_gpu(mode):
+    """The learner's multi-rank path ON THE DEVICE (tests/two_rank_gpu_main.py: two gloo ranks sharing cuda:0, different seeds and
+    clips per rank): initial broadcast, one flat-gradient all-reduce per optimizer step between the (optionally captured) forward /
+    backward and the optimizer kernels, normaliser sync -- the replicas stay bit-identical."""
+    import json
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, os.path.join(here, "two_rank_gpu_main.py")] + (["graph"] if mode == "graph" else []),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert out["exitcodes"] == [0, 0] and out["same_params"] and out["same_stats"] and out["finite"] and out["graph"] == (mode == "graph"), out
+
+
 def test_im_eval_sweep_and_auto_pmcp():
     """P10: evaluation sweep over all clips (5 clips, 2 envs -> 3 batches), metrics, failed keys, sampler re-weighting,
     training state restored afterwards."""

@@ -1,0 +1,53 @@
+"""Child of test_two_rank_update_on_one_gpu: two ranks (gloo, both on cuda:0) run the multi-rank code path of the learner on the device --
+eager all-reduce between the captured forward / backward and the optimizer launches -- and report whether the replicas stayed identical."""
+import json
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def worker(rank, world, port, graph, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from phc_amd.config import compose
+    from phc_amd.env.tasks.vec_task import parse_task
+    from phc_amd.learning.amp_agent import IMAmpAgent
+    torch.manual_seed(100 + rank)
+    cfg = compose(["env.num_envs=128", f"env.motion_file=synthetic:2:{rank}", "learning.params.config.minibatch_size=2048",
+                   "learning.params.config.amp_minibatch_size=1024", "learning.params.config.amp_obs_demo_buffer_size=4096",
+                   "learning.params.config.amp_replay_buffer_size=4096", f"+learning.params.config.hip_graph={graph}"])
+    task, env = parse_task(cfg)
+    agent = IMAmpAgent(env, cfg, dist=dist)
+    agent.init_train()
+    for _ in range(2):
+        info = agent.train_epoch()
+    flat = agent.grads.flat_param.detach().cpu()
+    gather = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(gather, flat)
+    stats = agent.running_mean_std.running_mean.cpu()
+    sg = [torch.zeros_like(stats) for _ in range(world)]
+    dist.all_gather(sg, stats)
+    if rank == 0:
+        q.put({"same_params": bool(torch.equal(gather[0], gather[1])), "same_stats": bool(torch.allclose(sg[0], sg[1])),
+               "graph": agent._graph is not None, "finite": bool(torch.isfinite(flat).all()), "actor_loss": info["actor_loss"]})
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    graph = len(sys.argv) > 1 and sys.argv[1] == "graph"
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + (os.getpid() % 300)
+    procs = [ctx.Process(target=worker, args=(r, 2, port, graph, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=500)
+    out = q.get(timeout=10)
+    out["exitcodes"] = [p.exitcode for p in procs]
+    print(json.dumps(out))
