@@ -70,7 +70,12 @@ PHC_HD void amp_shift_lane(const phc_im_params_t& prm, const phc_im_buffers_t& b
     if ((A & 3) == 0) {
         const float4* s4 = reinterpret_cast<const float4*>(src);
         float4* d4 = reinterpret_cast<float4*>(dst);
-        for (int i = lane; i < n / 4; i += nl) d4[i] = s4[i];
+        int i = lane;
+        for (; i + 3 * nl < n / 4; i += 4 * nl) {   // four independent 16-byte loads in flight per lane
+            const float4 a = s4[i], b = s4[i + nl], c = s4[i + 2 * nl], e = s4[i + 3 * nl];
+            d4[i] = a; d4[i + nl] = b; d4[i + 2 * nl] = c; d4[i + 3 * nl] = e;
+        }
+        for (; i < n / 4; i += nl) d4[i] = s4[i];
     } else {
         for (int i = lane; i < n; i += nl) dst[i] = src[i];
     }
