@@ -340,3 +340,65 @@ def test_task_obs_v7_vs_reference_golden(golden, backend, vr):
     np.testing.assert_allclose(obs[:, :358], g["self_obs"], atol=1e-5)
     np.testing.assert_allclose(obs[:, 358:], g7["task_obs_vr" if vr else "task_obs"], atol=1e-5)
     np.testing.assert_allclose(be.np(b["raw"])[:, :4], g["reward_raw"], atol=1e-5)     # the reward does not depend on the observation version
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_multi_step_rollout_vs_reference_env(golden, backend):
+    """16 consecutive env steps against the thin CPU reference env of oracle/gen_golden_rollout.py (the reference's own jit functions and
+    motion library driven in its method order, kinematic stand-in for the physics): per step the reset of the envs the previous step
+    flagged (state, observations, re-initialised AMP history), then post-physics on the golden's body state -- progress, reward, flags,
+    observations and the ping-ponged AMP history all track the reference across resets, time-outs and terminations."""
+    be = get_backend(backend)
+    g, gl = golden("rollout_ref_env"), golden("motion_lib_eval")
+    model, mstruct, keepm = model_on(be)
+    lib, keep = motion_lib_on(be, gl)
+    K, N = g["obs"].shape[:2]
+    nb, nd = 24, 69
+    prm, keepp = make_im_params(be, model, N)
+    arrs = dict(root=be.zeros((N, 13)), dof=be.zeros((N, nd, 2)), rbs=be.zeros((N, nb, 13)), cf=be.zeros((N, nb, 3)), df=be.zeros((N, nd)), pd=be.zeros((N, nd)))
+    sim = abi.sim_state_struct(N, arrs["root"], arrs["dof"], arrs["rbs"], arrs["cf"], arrs["df"], arrs["pd"])
+    amp = [be.zeros((N, 10, 196)), be.zeros((N, 10, 196))]
+    cur = 0
+    b = dict(progress=be.zeros(N, np.int64), reset=be.arr(np.ones(N, np.int64)), term=be.zeros(N, np.int64), rew=be.zeros(N), raw=be.zeros((N, 5)),
+             obs=be.zeros((N, 934)), mids=be.arr(g["motion_ids"].astype(np.int64)), st=be.zeros(N), so=be.zeros(N), goff=be.zeros((N, 3)))
+
+    def bufs(a_in, a_out):
+        return abi.im_buffers_struct(b["progress"], b["reset"], b["term"], b["rew"], b["raw"], b["obs"], a_in, a_out, b["mids"], b["st"], b["so"], b["goff"])
+
+    def put(dst, src):   # host -> backend array, in place
+        if isinstance(dst, np.ndarray):
+            dst[...] = src
+        else:
+            dst.copy_(be.arr(np.ascontiguousarray(src)))
+    n_resets = n_term = 0
+    for k in range(K):
+        ids = g["reset_ids"][k]
+        ids = ids[ids >= 0].astype(np.int64)
+        if len(ids):
+            flagged = np.nonzero(be.np(b["reset"]))[0]
+            np.testing.assert_array_equal(np.sort(ids), flagged, err_msg=f"step {k}: envs to reset")
+            assert be.im_reset(mstruct, lib, prm, sim, bufs(amp[cur], amp[cur]), len(ids), be.arr(ids), be.arr(g["reset_phase"][k][:len(ids)].astype(F)), 0) == 0
+            be.sync()
+            n_resets += len(ids)
+            np.testing.assert_array_equal(be.np(b["st"])[ids], g["start_after_reset"][k][ids], err_msg=f"step {k}: start times")
+            np.testing.assert_allclose(be.np(b["obs"])[ids], g["obs_after_reset"][k][ids], atol=2e-5, err_msg=f"step {k}: obs after reset")
+            np.testing.assert_allclose(be.np(arrs["root"])[ids], g["root_after_reset"][k][ids], atol=2e-5)
+            np.testing.assert_allclose(be.np(arrs["dof"])[ids], g["dof_after_reset"][k][ids], atol=2e-5)
+            assert (be.np(b["progress"])[ids] == 0).all() and (be.np(b["reset"]) == 0).all()
+        # physics stand-in: the golden's body / joint state of this step
+        put(arrs["rbs"], g["state_in"][k].astype(F))
+        put(arrs["root"], g["state_in"][k][:, 0].astype(F))
+        put(arrs["dof"], g["dof_in"][k].astype(F))
+        put(arrs["df"], g["dof_force"][k].astype(F))
+        assert be.im_post_physics(mstruct, lib, prm, sim, bufs(amp[cur], amp[1 - cur])) == 0
+        be.sync()
+        cur = 1 - cur
+        np.testing.assert_array_equal(be.np(b["progress"]), g["progress"][k], err_msg=f"step {k}")
+        np.testing.assert_array_equal(be.np(b["reset"]), g["reset"][k], err_msg=f"step {k}: reset flags")
+        np.testing.assert_array_equal(be.np(b["term"]), g["terminate"][k], err_msg=f"step {k}: terminate flags")
+        np.testing.assert_allclose(be.np(b["rew"]), g["rew"][k], atol=1e-5, err_msg=f"step {k}")
+        np.testing.assert_allclose(be.np(b["raw"]), g["rew_raw"][k], atol=1e-5, rtol=1e-5, err_msg=f"step {k}")
+        np.testing.assert_allclose(be.np(b["obs"]), g["obs"][k], atol=2e-5, err_msg=f"step {k}: observations")
+        np.testing.assert_allclose(be.np(amp[cur]), g["amp"][k], atol=2e-5, err_msg=f"step {k}: AMP history")
+        n_term += int(g["terminate"][k].sum())
+    assert n_resets >= N + 8 and n_term >= 5      # the sequence really exercises resets after time-outs and after terminations
