@@ -147,3 +147,61 @@ def test_robot_post_physics_vs_reference_golden(golden, backend, rb):
     np.testing.assert_array_equal(amp_out[:, 1:], amp_in_np[:, :-1])
     np.testing.assert_allclose(o["rbp"], g["ref1_pos"], atol=2e-5)
     np.testing.assert_allclose(o["rdp"], g["ref1_dof_pos"], atol=2e-5)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_h1_multi_step_rollout_vs_reference_env(golden, backend):
+    """14 consecutive H1 env steps against the thin CPU reference env of oracle/gen_golden_rollout_h1.py (the reference's `MotionLibReal`,
+    extended-body reward, robot AMP observation ... in its method order, kinematic stand-in for the physics): resets from the clip's
+    joint angles, re-initialised 63 x 10 AMP history, progress / flags / observations across resets, time-outs and terminations."""
+    rb = "h1"
+    be = get_backend(backend)
+    g = golden("rollout_ref_env_h1")
+    lib, keep = motion_lib_on(be, _lib_from_golden(golden, rb))
+    model, mstruct, keepm = model_on(be, f"{rb}_humanoid")
+    K, N = g["obs"].shape[:2]
+    NB = g["state_in"].shape[2]
+    ND, A, NO = NB - 1, g["amp"].shape[-1], g["obs"].shape[-1]
+    prm = robot_im_params(be, model, g["ext_parent"], g["ext_pos"], rb)
+    arrs = dict(root=be.zeros((N, 13)), dof=be.zeros((N, ND, 2)), rbs=be.zeros((N, NB, 13)), cf=be.zeros((N, NB, 3)), df=be.zeros((N, ND)), pd=be.zeros((N, ND)))
+    sim = abi.sim_state_struct(N, arrs["root"], arrs["dof"], arrs["rbs"], arrs["cf"], arrs["df"], arrs["pd"])
+    amp = [be.zeros((N, 10, A)), be.zeros((N, 10, A))]
+    cur = 0
+    b = dict(progress=be.zeros(N, np.int64), reset=be.arr(np.ones(N, np.int64)), term=be.zeros(N, np.int64), rew=be.zeros(N), raw=be.zeros((N, 5)),
+             obs=be.zeros((N, NO)), mids=be.arr(g["motion_ids"].astype(np.int64)), st=be.zeros(N), so=be.zeros(N), goff=be.zeros((N, 3)))
+    bufs = lambda a_in, a_out: abi.im_buffers_struct(b["progress"], b["reset"], b["term"], b["rew"], b["raw"], b["obs"], a_in, a_out, b["mids"], b["st"],
+                                                     b["so"], b["goff"])
+
+    def put(dst, src):
+        if isinstance(dst, np.ndarray):
+            dst[...] = src
+        else:
+            dst.copy_(be.arr(np.ascontiguousarray(src)))
+    n_resets = 0
+    for k in range(K):
+        ids = g["reset_ids"][k]
+        ids = ids[ids >= 0].astype(np.int64)
+        if len(ids):
+            np.testing.assert_array_equal(np.sort(ids), np.nonzero(be.np(b["reset"]))[0], err_msg=f"step {k}: envs to reset")
+            assert be.im_reset(mstruct, lib, prm, sim, bufs(amp[cur], amp[cur]), len(ids), be.arr(ids), be.arr(g["reset_phase"][k][:len(ids)].astype(F)), 0) == 0
+            be.sync()
+            n_resets += len(ids)
+            np.testing.assert_array_equal(be.np(b["st"])[ids], g["start_after_reset"][k][ids], err_msg=f"step {k}: start times")
+            np.testing.assert_allclose(be.np(b["obs"])[ids], g["obs_after_reset"][k][ids], atol=3e-5, err_msg=f"step {k}: obs after reset")
+            np.testing.assert_allclose(be.np(arrs["root"])[ids], g["root_after_reset"][k][ids], atol=3e-5)
+            np.testing.assert_allclose(be.np(arrs["dof"])[ids], g["dof_after_reset"][k][ids], atol=3e-5)
+        put(arrs["rbs"], g["state_in"][k].astype(F))
+        put(arrs["root"], g["state_in"][k][:, 0].astype(F))
+        put(arrs["dof"], g["dof_in"][k].astype(F))
+        put(arrs["df"], g["dof_force"][k].astype(F))
+        assert be.im_post_physics(mstruct, lib, prm, sim, bufs(amp[cur], amp[1 - cur])) == 0
+        be.sync()
+        cur = 1 - cur
+        np.testing.assert_array_equal(be.np(b["progress"]), g["progress"][k], err_msg=f"step {k}")
+        np.testing.assert_array_equal(be.np(b["reset"]), g["reset"][k], err_msg=f"step {k}: reset flags")
+        np.testing.assert_array_equal(be.np(b["term"]), g["terminate"][k], err_msg=f"step {k}: terminate flags")
+        np.testing.assert_allclose(be.np(b["rew"]), g["rew"][k], atol=1e-5, err_msg=f"step {k}")
+        np.testing.assert_allclose(be.np(b["raw"]), g["rew_raw"][k], atol=1e-5, rtol=1e-5, err_msg=f"step {k}")
+        np.testing.assert_allclose(be.np(b["obs"]), g["obs"][k], atol=3e-5, err_msg=f"step {k}: observations")
+        np.testing.assert_allclose(be.np(amp[cur]), g["amp"][k], atol=3e-5, err_msg=f"step {k}: AMP history")
+    assert n_resets >= N + 6 and g["terminate"].sum() >= 5
