@@ -268,3 +268,28 @@ def test_first_write_protocol_of_the_flat_bucket():
     b.zero()
     assert _first_write(lin.weight) and _first_write(lin.bias) and not _first_write(lin.bias)
     assert b.shadow is None and lin.weight.grad.data_ptr() == b.flat.data_ptr()
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/phc/learning/replay_buffer.py"), reason="reference checkout not present")
+def test_replay_buffer_equals_the_reference_class():
+    """P9: the same store / sample sequence (wrap-around stores, sampling before and after the buffer fills, index re-shuffles) through
+    the reference's own `ReplayBuffer` (phc/learning/replay_buffer.py, pure torch: imported as is) and through ours, same torch seed:
+    identical storage, identical samples."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_replay_buffer", "/root/reference/phc/learning/replay_buffer.py")
+    ref_mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref_mod)
+    outs = []
+    for cls in (ref_mod.ReplayBuffer, ReplayBuffer):
+        torch.manual_seed(42)
+        rb = cls(37, "cpu")
+        g = torch.Generator().manual_seed(1)
+        seq = []
+        for n_store, n_sample in ((10, 5), (20, 16), (15, 30), (37, 8), (3, 50), (9, 37)):
+            rb.store({"amp_obs": torch.randn(n_store, 4, generator=g)})
+            seq.append(rb.sample(n_sample)["amp_obs"].clone())
+        outs.append((rb._data_buf["amp_obs"].clone(), seq, rb.get_total_count(), rb._head))
+    (da, sa, ca, ha), (db, sb, cb, hb) = outs
+    assert ca == cb and ha == hb and torch.equal(da, db)
+    for x, y in zip(sa, sb):
+        assert torch.equal(x, y)
