@@ -149,14 +149,15 @@ def test_robot_post_physics_vs_reference_golden(golden, backend, rb):
     np.testing.assert_allclose(o["rdp"], g["ref1_dof_pos"], atol=2e-5)
 
 
+@pytest.mark.parametrize("rb", ROBOTS)
 @pytest.mark.parametrize("backend", BACKENDS)
-def test_h1_multi_step_rollout_vs_reference_env(golden, backend):
-    """14 consecutive H1 env steps against the thin CPU reference env of oracle/gen_golden_rollout_h1.py (the reference's `MotionLibReal`,
-    extended-body reward, robot AMP observation ... in its method order, kinematic stand-in for the physics): resets from the clip's
-    joint angles, re-initialised 63 x 10 AMP history, progress / flags / observations across resets, time-outs and terminations."""
-    rb = "h1"
+def test_robot_multi_step_rollout_vs_reference_env(golden, backend, rb):
+    """14 consecutive H1 / G1 env steps against the thin CPU reference env of oracle/gen_golden_rollout_h1.py [h1|g1] (the reference's
+    `MotionLibReal`, extended-body reward, robot AMP observation ... in its method order, kinematic stand-in for the physics): resets from
+    the clip's joint angles, re-initialised AMP history (63 / 99 x 10), progress / flags / observations across resets, time-outs and
+    terminations (G1: the 64-lane instantiations of the reset and post-physics kernels)."""
     be = get_backend(backend)
-    g = golden("rollout_ref_env_h1")
+    g = golden(f"rollout_ref_env_{rb}")
     lib, keep = motion_lib_on(be, _lib_from_golden(golden, rb))
     model, mstruct, keepm = model_on(be, f"{rb}_humanoid")
     K, N = g["obs"].shape[:2]
