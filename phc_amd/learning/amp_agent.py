@@ -722,13 +722,32 @@ class IMAmpAgent:
                     step_fps=self.batch_size / (t1 - t0), total_fps=self.batch_size / (t2 - t0))  # common_agent.py:134-138
         return info
 
-    def train(self, max_epochs, log=print):
+    def train(self, max_epochs, log=print, output_dir=None):
+        """Training loop with the reference's checkpoint / evaluation cadence (common_agent.py:142-165): with `output_dir`,
+        `Humanoid.pth` every min(50, save_best_after) epochs; every `save_frequency` epochs (save_intermediate) also
+        `Humanoid_{epoch:08d}.pth` and the evaluation sweep `eval()`, which re-weights the clip sampling (auto-PMCP, im_amp.py:126-132)
+        and writes `failed_{epoch:010d}.pkl`."""
         self.init_train()
+        c = self.config
+        save_freq, save_best_after = int(c.get("save_frequency", 0)), int(c.get("save_best_after", 100))
+        save_intermediate = bool(c.get("save_intermediate", False))
+        info = {}
         for _ in range(max_epochs):
             info = self.train_epoch()
             if self.rank == 0 and log is not None:
                 log(f"epoch {self.epoch_num}: total_fps {info['total_fps']:.0f} step_fps {info['step_fps']:.0f} task_r {info['mean_task_reward']:.4f} "
                     f"disc_r {info['mean_disc_reward']:.4f} a_loss {info['actor_loss']:.4f} c_loss {info['critic_loss']:.4f} disc_loss {info['disc_loss']:.4f}")
+            if output_dir is not None and save_freq > 0:
+                if self.epoch_num % min(50, save_best_after) == 0 and self.rank == 0:
+                    os.makedirs(output_dir, exist_ok=True)
+                    self.save(os.path.join(output_dir, "Humanoid.pth"))
+                if save_intermediate and self.epoch_num % save_freq == 0:
+                    if self.rank == 0:
+                        os.makedirs(output_dir, exist_ok=True)
+                        self.save(os.path.join(output_dir, f"Humanoid_{self.epoch_num:08d}.pth"))
+                    if hasattr(self.task, "_motion_lib") and hasattr(self.task, "_termination_distances"):
+                        eval_info, _ = self.eval(output_dir=output_dir, log=log)
+                        info.update(eval_info)
         return info
 
     def eval(self, output_dir=None, log=print):
@@ -761,4 +780,16 @@ class IMAmpAgent:
         torch.save(self.get_full_state_weights(), path)
 
     def restore(self, path):
+        """`IMAmpAgent.restore` (im_amp.py:101-117): the checkpoint, then the newest `failed_*.pkl` next to it -- the termination
+        history of the last evaluation sweep -- back into the motion library's sampling probabilities."""
         self.set_full_state_weights(torch.load(path, map_location=self.device))
+        import glob
+        fails = glob.glob(os.path.join(os.path.dirname(os.path.abspath(path)), "failed_*"))
+        lib = getattr(self.task, "_motion_lib", None)
+        if fails and lib is not None and hasattr(lib, "update_sampling_prob"):
+            import joblib
+            newest = sorted(fails, key=lambda x: int(x.split("_")[-1].split(".")[0]))[-1]
+            hist = joblib.load(newest)["termination_history"]
+            ok = lib.update_sampling_prob(torch.as_tensor(hist, dtype=lib._termination_history.dtype, device=lib._termination_history.device))
+            if self.rank == 0:
+                print(f"[phc_amd] termination history {'restored from' if ok else 'does not match the motion set:'} {newest}", flush=True)

@@ -60,7 +60,7 @@ def main(argv=None):
         if dist is not None:
             dist.destroy_process_group()
         return info
-    info = agent.train(max_epochs)
+    info = agent.train(max_epochs, output_dir=cfg.output_path)
     if rank == 0:
         out = os.path.join(cfg.output_path, "Humanoid.pth")
         os.makedirs(cfg.output_path, exist_ok=True)

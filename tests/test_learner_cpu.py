@@ -293,3 +293,37 @@ def test_replay_buffer_equals_the_reference_class():
     assert ca == cb and ha == hb and torch.equal(da, db)
     for x, y in zip(sa, sb):
         assert torch.equal(x, y)
+
+
+def test_train_checkpoint_cadence_and_termination_history_restore(tmp_path):
+    """The reference's save cadence (common_agent.py:142-150: `Humanoid.pth` every min(50, save_best_after) epochs, numbered
+    checkpoints every save_frequency) and `IMAmpAgent.restore` re-installing the newest `failed_*.pkl` termination history into the
+    motion library's sampling probabilities (im_amp.py:101-117)."""
+    import joblib
+    cfg = small_cfg()
+    cfg.learning.params.config.save_frequency = 2
+    cfg.learning.params.config.save_best_after = 3
+    cfg.learning.params.config.save_intermediate = True
+    agent = IMAmpAgent(FakeVecEnv(32), cfg, bf16=False)
+    agent.train(4, log=None, output_dir=str(tmp_path))
+    assert sorted(os.listdir(tmp_path)) == ["Humanoid.pth", "Humanoid_00000002.pth", "Humanoid_00000004.pth"]   # Humanoid.pth written at epoch 3
+
+    class Lib:
+        def __init__(self):
+            self._termination_history = torch.zeros(5)
+            self._sampling_prob = torch.ones(5) / 5
+
+        def update_sampling_prob(self, h):
+            if len(h) == len(self._termination_history) and h.sum() > 0:
+                self._sampling_prob[:] = h / h.sum()
+                self._termination_history = h
+                return True
+            return False
+    joblib.dump({"failed_keys": ["a"], "termination_history": torch.tensor([0., 1, 0, 0, 0])}, tmp_path / "failed_0000000002.pkl")
+    joblib.dump({"failed_keys": ["a", "c"], "termination_history": torch.tensor([0., 2, 0, 2, 0])}, tmp_path / "failed_0000000004.pkl")
+    agent2 = IMAmpAgent(FakeVecEnv(32), cfg, bf16=False)
+    agent2.task._motion_lib = Lib()
+    agent2.restore(str(tmp_path / "Humanoid_00000004.pth"))
+    assert agent2.epoch_num == 4
+    assert torch.equal(agent2.task._motion_lib._sampling_prob, torch.tensor([0., 0.5, 0, 0.5, 0]))
+    assert torch.equal(agent2.model.a2c_network.mu.weight, agent.model.a2c_network.mu.weight)
