@@ -66,6 +66,28 @@ def discount_values(mb_fdones, mb_values, mb_rewards, mb_next_values, gamma, tau
     return advs
 
 
+class _marker:
+    """roctx range (shows up in `rocprofv3 --marker-trace`) around the two phases of an epoch; a no-op off the device."""
+
+    usable = True
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        self.on = False
+        if _marker.usable and torch.cuda.is_available():
+            try:
+                torch.cuda.nvtx.range_push(self.name)
+                self.on = True
+            except Exception:   # no roctx in this build: markers off, training unaffected
+                _marker.usable = False
+
+    def __exit__(self, *a):
+        if self.on:
+            torch.cuda.nvtx.range_pop()
+
+
 class FlatGradBucket:
     """All trainable parameters AND their gradients as views of two flat fp32 buffers.
 
@@ -686,7 +708,7 @@ class IMAmpAgent:
         sync = torch.cuda.synchronize if str(self.device).startswith("cuda") else (lambda: None)
         sync()
         t0 = time.time()
-        with torch.no_grad(), self.grads.shadow_scope():   # rollout inference reads the bf16 parameter copies
+        with torch.no_grad(), self.grads.shadow_scope(), _marker("phc:rollout"):   # rollout inference reads the bf16 parameter copies
             batch = self.play_steps()
         sync()
         t1 = time.time()
@@ -697,7 +719,7 @@ class IMAmpAgent:
         self.set_train()
         self.prepare_dataset(batch)
         infos, ginfo = [], None
-        with self.grads.shadow_scope():
+        with self.grads.shadow_scope(), _marker("phc:update"):
             if self._graph_enabled():
                 try:
                     ginfo = self._graph_update()
