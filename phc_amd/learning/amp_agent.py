@@ -21,6 +21,12 @@ MI355X-first differences (results-preserving):
   * data parallelism: one process per GPU, envs sharded, ONE all-reduce (mean) of a single flat fp32 gradient
     bucket per optimizer step over RCCL (`FlatGradBucket`); it replaces horovod's `optimizer.synchronize()`
     (amp_agent.py:667-668).  Running-stat moments are averaged once per epoch (`hvd.sync_stats`).
+  * on the device everything of the update that is not a GEMM runs as HIP kernels (csrc/phc_learn.hip via learning/fast_ops.py,
+    DESIGN.md 4.3): observation normalisers incl. the minibatch gather, actor / critic and discriminator losses with their
+    gradients, bias and split-K weight gradients of the layers, clip + Adam on the flat parameter, the rollout's sampling step;
+    optionally (`hip_graph`) the forward / backward of a step is replayed from one captured hipGraph.  The torch expressions in
+    this file (`_ppo_loss_torch`, `_disc_loss`, RunningMeanStd's CPU branch) remain the CPU path and the definition those kernels
+    are tested against.
 """
 import copy
 import os
