@@ -497,7 +497,8 @@ class HumanoidIm:
         from ...config import EasyDict
         motion_lib_cfg = EasyDict({"motion_file": mf, "device": self.device, "fix_height": FixHeightMode.full_fix,
                                    "min_length": self._min_motion_len, "max_length": -1, "im_eval": flags.im_eval,
-                                   "multi_thread": False, "smpl_type": self.humanoid_type, "randomrize_heading": True, "step_dt": self.dt})
+                                   "multi_thread": False, "smpl_type": self.humanoid_type, "randomrize_heading": True, "step_dt": self.dt,
+                                   "heading_rng": self.cfg["env"].get("heading_rng", "persistent")})
         if self._is_robot:  # humanoid_im.py:342-359
             motion_lib_cfg["robot"] = self.cfg["robot"]
             motion_lib_cfg["robot_model"] = self.model

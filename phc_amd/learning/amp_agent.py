@@ -150,10 +150,20 @@ class FlatGradBucket:
         self.flat.zero_()
         self.gen += 1
 
-    def all_reduce_mean(self, dist):
-        if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+    def all_reduce_mean(self, dist, force=False, timing=None):
+        """The path's one collective.  `force`: issue it also in a one-rank group (exercises RCCL + the captured update on a 1-GPU box);
+        `timing`: a list that receives (start, end) event pairs on the launch stream (bench.py: per-all-reduce time)."""
+        if dist is not None and dist.is_initialized() and (dist.get_world_size() > 1 or force):
+            ev = None
+            if timing is not None and self.flat.is_cuda and len(timing) < 4096:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-            self.flat.div_(dist.get_world_size())
+            if dist.get_world_size() > 1:
+                self.flat.div_(dist.get_world_size())
+            if ev is not None:
+                ev[1].record()
+                timing.append(ev)
 
     def clip_grad_norm_(self, max_norm):
         """torch.nn.utils.clip_grad_norm_ on the flat view: same total norm, same clip coefficient (clamped to 1)."""
@@ -173,6 +183,10 @@ class IMAmpAgent:
         self.faithful_reset = faithful_reset
         params = cfg["learning"]["params"]
         c = params["config"]
+        # `force_collectives`: run the gradient all-reduce also in a one-rank process group (tests: RCCL next to the captured update on one GPU)
+        self._force_collectives = bool(c.get("force_collectives", False))
+        self.allreduce_timing = None   # bench.py sets a list: (start, end) events of every gradient all-reduce
+        self.num_collectives = 0       # gradient all-reduces issued so far
         self.config = c
         self.device = self.task.device if hasattr(self.task, "device") else "cpu"
         self.ppo_device = self.device
@@ -566,9 +580,14 @@ class IMAmpAgent:
         self.set_train()
         d = self._amp_rows(d)
         info = self._fwd_bwd(d)
-        self.grads.all_reduce_mean(self.dist)
+        self._grad_all_reduce()
         self._clip_and_step()
         return info
+
+    def _grad_all_reduce(self):
+        if self.multi_gpu or (self._force_collectives and self.dist is not None):
+            self.grads.all_reduce_mean(self.dist, force=self._force_collectives, timing=self.allreduce_timing)
+            self.num_collectives += 1
 
     # ------------------------------------------------------------------ the optimizer step as a hipGraph
     # With the loss, normaliser and optimizer kernels fused, a step is ~140 launches of 2 ms total device time and the host needs
@@ -633,7 +652,14 @@ class IMAmpAgent:
                         self._graph_step_body()
                 torch.cuda.current_stream().wait_stream(side)
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                # with a process group alive its watchdog thread polls events while we capture: thread-local capture mode keeps
+                # those calls from invalidating the capture (the graph itself holds no collective)
+                in_group = self.dist is not None and self.dist.is_initialized()
+                if in_group:   # nothing of the group may be in flight on this device while the capture starts
+                    torch.cuda.synchronize()
+                    self.dist.barrier()
+                    torch.cuda.synchronize()
+                with torch.cuda.graph(g, capture_error_mode="thread_local" if in_group else "global"):
                     self._graph_step_body()
             finally:
                 for m, bufs in norms:
@@ -649,7 +675,7 @@ class IMAmpAgent:
                 if e >= self.batch_size:
                     self._idx_buf[:] = torch.randperm(self.batch_size, device=self._idx_buf.device)
                 self._graph.replay()
-                self.grads.all_reduce_mean(self.dist)
+                self._grad_all_reduce()
                 self._clip_and_step()
                 n += 1
         mean = self._g_info / n
@@ -784,8 +810,71 @@ class IMAmpAgent:
         return evaluate(self, output_dir=output_dir, log=log if self.rank == 0 else None)
 
     # ------------------------------------------------------------------ checkpoint (amp_agent.py:69-108; SURVEY B4 key names)
+    def _optimizer_state_dict(self):
+        """The flat Adam state in the layout of the reference's `Adam(model.parameters())` (one entry per parameter, in
+        `model.parameters()` order, common_agent.py:67): `exp_avg` / `exp_avg_sq` split at the bucket offsets.  Parameters that do
+        not train (frozen PNN columns, the fixed sigma) appear in `params` without state, as torch writes them."""
+        sd = self.optimizer.state_dict()
+        flat_state = sd["state"].get(0, {})
+        all_params = list(self.model.parameters())
+        index = {id(p): i for i, p in enumerate(all_params)}
+        state, o = {}, 0
+        for p in self.grads.params:
+            k = p.numel()
+            if flat_state:
+                state[index[id(p)]] = {"step": flat_state["step"].clone() if torch.is_tensor(flat_state["step"]) else flat_state["step"],
+                                       "exp_avg": flat_state["exp_avg"][o:o + k].view_as(p).clone(),
+                                       "exp_avg_sq": flat_state["exp_avg_sq"][o:o + k].view_as(p).clone()}
+            o += k
+        group = dict(sd["param_groups"][0])
+        group["params"] = list(range(len(all_params)))
+        return {"state": state, "param_groups": [group]}
+
+    def _load_optimizer_state_dict(self, sd):
+        """Inverse of `_optimizer_state_dict`; also accepts the one-entry flat layout of round-1 checkpoints.  A state that does not
+        fit the current set of trainable parameters (another PNN stage, another network) is skipped with a warning, never mis-applied."""
+        groups = sd.get("param_groups", [])
+        n_entries = sum(len(g["params"]) for g in groups)
+        if n_entries == 1 and len(list(self.model.parameters())) != 1:   # flat layout
+            st = sd["state"].get(0)
+            if st is not None and st["exp_avg"].numel() != self.grads.flat_param.numel():
+                return self._skip_optimizer("flat optimizer state of another size")
+            self.optimizer.load_state_dict(sd)
+            return True
+        all_params = list(self.model.parameters())
+        if n_entries != len(all_params):
+            return self._skip_optimizer(f"optimizer state for {n_entries} parameters, the model has {len(all_params)}")
+        index = {id(p): i for i, p in enumerate(all_params)}
+        state = sd["state"]
+        mine = [index[id(p)] for p in self.grads.params]
+        have = [i for i in mine if i in state]
+        if not state:         # a checkpoint saved before the first optimizer step
+            return True
+        if len(have) != len(mine) or any(i not in mine for i in state):
+            return self._skip_optimizer("optimizer state belongs to another set of trainable parameters (e.g. another PNN stage)")
+        for p, i in zip(self.grads.params, mine):
+            if tuple(state[i]["exp_avg"].shape) != tuple(p.shape):
+                return self._skip_optimizer(f"optimizer state shape mismatch at parameter {i}")
+        dev = self.grads.flat_param.device
+        step = state[mine[0]]["step"]
+        flat = {"step": (step.clone().float() if torch.is_tensor(step) else torch.tensor(float(step))),
+                "exp_avg": torch.cat([state[i]["exp_avg"].reshape(-1).float() for i in mine]).to(dev),
+                "exp_avg_sq": torch.cat([state[i]["exp_avg_sq"].reshape(-1).float() for i in mine]).to(dev)}
+        group = {k: v for k, v in groups[0].items() if k != "params"}
+        cur = self.optimizer.state_dict()["param_groups"][0]
+        merged = dict(cur)
+        merged.update({k: v for k, v in group.items() if k in cur})
+        merged["params"] = [0]
+        self.optimizer.load_state_dict({"state": {0: flat}, "param_groups": [merged]})
+        return True
+
+    def _skip_optimizer(self, why):
+        if self.rank == 0:
+            print(f"[phc_amd] optimizer state not restored: {why}", flush=True)
+        return False
+
     def get_full_state_weights(self):
-        s = {"model": self.model.state_dict(), "epoch": self.epoch_num, "optimizer": self.optimizer.state_dict(), "frame": self.frame}
+        s = {"model": self.model.state_dict(), "epoch": self.epoch_num, "optimizer": self._optimizer_state_dict(), "frame": self.frame}
         if self.running_mean_std is not None:
             s["running_mean_std"] = self.running_mean_std.state_dict()
         if self.value_mean_std is not None:
@@ -794,23 +883,26 @@ class IMAmpAgent:
             s["amp_input_mean_std"] = self._amp_input_mean_std.state_dict()
         return s
 
-    def set_full_state_weights(self, w):
+    def set_full_state_weights(self, w, load_optimizer=True):
         self.model.load_state_dict(w["model"])
         self.epoch_num = w.get("epoch", 0)
         self.frame = w.get("frame", 0)
-        if "optimizer" in w:
-            self.optimizer.load_state_dict(w["optimizer"])
+        if "optimizer" in w and load_optimizer:
+            self._load_optimizer_state_dict(w["optimizer"])
         for key, mod in (("running_mean_std", self.running_mean_std), ("reward_mean_std", self.value_mean_std), ("amp_input_mean_std", self._amp_input_mean_std)):
             if mod is not None and key in w:
                 mod.load_state_dict(w[key])
+        if self.grads.shadow is not None:
+            self.grads.shadow.copy_(self.grads.flat_param)
 
     def save(self, path):
         torch.save(self.get_full_state_weights(), path)
 
-    def restore(self, path):
+    def restore(self, path, load_optimizer=True):
         """`IMAmpAgent.restore` (im_amp.py:101-117): the checkpoint, then the newest `failed_*.pkl` next to it -- the termination
-        history of the last evaluation sweep -- back into the motion library's sampling probabilities."""
-        self.set_full_state_weights(torch.load(path, map_location=self.device))
+        history of the last evaluation sweep -- back into the motion library's sampling probabilities.  Players (`test=True`) pass
+        `load_optimizer=False`, as the reference's `set_weights` path (amp_agent.py:84-90) does not touch the optimizer."""
+        self.set_full_state_weights(torch.load(path, map_location=self.device, weights_only=False), load_optimizer=load_optimizer)
         import glob
         fails = glob.glob(os.path.join(os.path.dirname(os.path.abspath(path)), "failed_*"))
         lib = getattr(self.task, "_motion_lib", None)

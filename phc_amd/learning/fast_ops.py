@@ -21,12 +21,15 @@ from torch.autograd.function import once_differentiable
 from .. import _lib as L
 
 _ws = {}
+_ws_retired = []   # outgrown workspaces are kept alive: a captured hipGraph may still hold their address
 
 
 def _workspace(key, nbytes, device, dtype):
     n = (nbytes + dtype.itemsize - 1) // dtype.itemsize
     t = _ws.get((key, device))
     if t is None or t.numel() < n:
+        if t is not None:
+            _ws_retired.append(t)
         t = torch.empty(max(n, 1), dtype=dtype, device=device)
         _ws[(key, device)] = t
     return t

@@ -114,8 +114,15 @@ def evaluate(agent, output_dir=None, log=print):
         lib_train.update_hard_sampling_weight(list(failed_keys))
     elif task.auto_pmcp_soft:
         lib_train.update_soft_sampling_weight(list(failed_keys))
-    if output_dir is not None:
+    # every rank runs the sweep (the sampler weights must stay in step), rank 0 alone writes -- atomically, so that `restore()` can
+    # never pick up a torn file (the reference evaluates and writes on rank 0 only, im_amp.py:136-242)
+    if output_dir is not None and getattr(agent, "rank", 0) == 0:
         os.makedirs(output_dir, exist_ok=True)
-        joblib.dump({"failed_keys": failed_keys, "termination_history": lib_train._termination_history.cpu()},
-                    os.path.join(output_dir, f"failed_{agent.epoch_num:010d}.pkl"))
+        final = os.path.join(output_dir, f"failed_{agent.epoch_num:010d}.pkl")
+        tmp = os.path.join(output_dir, f".tmp_failed_{agent.epoch_num:010d}.{os.getpid()}")
+        joblib.dump({"failed_keys": failed_keys, "termination_history": lib_train._termination_history.cpu()}, tmp)
+        os.replace(tmp, final)
+    dist = getattr(agent, "dist", None)
+    if output_dir is not None and dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
     return eval_info, failed_keys

@@ -46,8 +46,11 @@ class A2CNetwork(nn.Module):
         self.sigma = nn.Parameter(torch.full((actions_num,), float(space["sigma_init"]["val"]), dtype=torch.float32), requires_grad=False)
         self._disc_mlp = build_mlp(amp_input_shape[0], list(disc["units"]), disc["activation"], FastLinearDD)
         self._disc_logits = nn.Linear(list(disc["units"])[-1], 1)
-        # initializer "default" == torch's Linear default; biases of the discriminator zeroed, logit layer U(-1,1)
-        for m in self._disc_mlp.modules():
+        # initializer "default" leaves the weights at torch's Linear default; the builder then zeroes the bias of EVERY nn.Linear that
+        # exists at that point -- actor_mlp, critic_mlp, value, mu (network_builder.py:277-284) -- and the AMP builder those of the
+        # discriminator (amp_network_builder.py:230-249), logit layer U(-1,1).  PNN columns and the MCP composer are created after that
+        # loop and keep torch's default biases (amp_network_pnn_builder.py:42-55, amp_network_mcp_builder.py:38-52).
+        for m in self.modules():
             if isinstance(m, nn.Linear):
                 nn.init.zeros_(m.bias)
         nn.init.uniform_(self._disc_logits.weight, -DISC_LOGIT_INIT_SCALE, DISC_LOGIT_INIT_SCALE)

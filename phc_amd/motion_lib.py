@@ -263,9 +263,16 @@ class MotionLibBase:
         idx_np = sample_idxes.cpu().numpy()
         cache = {}
         per = []
-        # the reference seeds numpy with randint(5000) * pid and pid == 0 in the single-process path
-        # (motion_lib_smpl.py:106) -> RandomState(0) for the heading draws
-        rs = np.random.RandomState(0)
+        # the reference seeds numpy with randint(5000) * pid (motion_lib_smpl.py:106): in its single-process path pid == 0, i.e. seed 0
+        # on EVERY call (`heading_rng: seed0_per_call`, what the golden fixtures were generated with); its default multi-worker path
+        # gives every worker and call a different seed -> default here: one persistent stream per library (seed + rank), advanced
+        # across calls, so that `resample_motions()` draws new headings / crops
+        if self.m_cfg.get("heading_rng", "persistent") == "seed0_per_call":
+            rs = np.random.RandomState(0)
+        else:
+            if getattr(self, "_heading_rs", None) is None:
+                self._heading_rs = np.random.RandomState((int(torch.initial_seed()) + 7919 * int(self.m_cfg.get("rank", 0))) % (2 ** 32))
+            rs = self._heading_rs
         aa_list, nfs, fpss = [], [], []
         for i, u in enumerate(idx_np):
             clip = self._motion_data_list[u]

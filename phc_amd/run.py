@@ -45,7 +45,7 @@ def main(argv=None):
         cand = os.path.join(cfg.output_path, "Humanoid.pth" if ep <= 0 else f"Humanoid_{ep:08d}.pth")
         ckpt = cand if os.path.exists(cand) else None
     if ckpt:
-        agent.restore(ckpt)
+        agent.restore(ckpt, load_optimizer=not cfg.test)
     if cfg.test:
         # player mode (phc/learning/im_amp_players.py:25-384): no learning; im_eval=True sweeps the whole motion set and reports the
         # success rate / MPJPE table, otherwise a deterministic-policy rollout of `games` env steps reports episode statistics

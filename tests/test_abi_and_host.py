@@ -159,7 +159,8 @@ def test_motion_lib_loader_vs_reference(golden, heading):
     tree = SkeletonTree(sk["node_names"], sk["parent_indices"], sk["local_translation"])
     flags.test = not heading
     try:
-        lib = MotionLibSMPL(EasyDict({"motion_file": _clips_dict(golden), "device": "cpu", "min_length": -1, "im_eval": False, "step_dt": 1 / 30}))
+        lib = MotionLibSMPL(EasyDict({"motion_file": _clips_dict(golden), "device": "cpu", "min_length": -1, "im_eval": False, "step_dt": 1 / 30,
+                                      "heading_rng": "seed0_per_call"}))
         lib.load_motions(skeleton_trees=[tree] * 6, random_sample=False)
     finally:
         flags.test = False

@@ -327,3 +327,67 @@ def test_train_checkpoint_cadence_and_termination_history_restore(tmp_path):
     assert agent2.epoch_num == 4
     assert torch.equal(agent2.task._motion_lib._sampling_prob, torch.tensor([0., 0.5, 0, 0.5, 0]))
     assert torch.equal(agent2.model.a2c_network.mu.weight, agent.model.a2c_network.mu.weight)
+
+
+def test_checkpoint_optimizer_state_is_per_parameter_and_loads_plain_adam_checkpoints(tmp_path):
+    """B4: the checkpoint's optimizer entry has the reference's layout -- `Adam(model.parameters())` (common_agent.py:67), one state
+    entry per parameter -- although the agent steps ONE flat parameter.  (a) save -> load round trip restores the flat moments
+    bit for bit; (b) a checkpoint written by a plain torch Adam over `model.parameters()` loads and continues identically to an
+    agent that kept training; (c) a state that belongs to another set of trainable parameters is skipped, not mis-applied."""
+    torch.manual_seed(0)
+    env = FakeVecEnv(16)
+    agent = IMAmpAgent(env, small_cfg())
+    agent.init_train()
+    agent.train_epoch()
+    w = agent.get_full_state_weights()
+    params = list(agent.model.parameters())
+    trainable = [i for i, p in enumerate(params) if p.requires_grad]
+    assert w["optimizer"]["param_groups"][0]["params"] == list(range(len(params)))
+    assert sorted(w["optimizer"]["state"]) == trainable
+    for i in trainable:
+        assert tuple(w["optimizer"]["state"][i]["exp_avg"].shape) == tuple(params[i].shape)
+    path = str(tmp_path / "Humanoid.pth")
+    agent.save(path)
+    # (a)
+    torch.manual_seed(1)
+    other = IMAmpAgent(FakeVecEnv(16), small_cfg())
+    other.restore(path)
+    sa, sb = agent.optimizer.state[agent.grads.flat_param], other.optimizer.state[other.grads.flat_param]
+    assert torch.equal(sa["exp_avg"], sb["exp_avg"]) and torch.equal(sa["exp_avg_sq"], sb["exp_avg_sq"]) and float(sa["step"]) == float(sb["step"])
+    assert torch.equal(agent.grads.flat_param, other.grads.flat_param)
+    # (b) the reference's own optimizer object over the same model: its state_dict must load
+    ref_model = ModelAMPContinuous(A2CNetwork(small_cfg()["learning"]["params"]["network"], 5, (20,), (18,)))
+    ref_model.load_state_dict(w["model"])
+    ref_opt = torch.optim.Adam(ref_model.parameters(), 2e-5, eps=1e-8)
+    ref_opt.load_state_dict(w["optimizer"])       # our file is readable by the reference's optimizer ...
+    g = torch.Generator().manual_seed(5)
+    grads = [torch.randn(p.shape, generator=g) for p in ref_model.parameters()]
+    for p, gr in zip(ref_model.parameters(), grads):
+        p.grad = gr.clone() if p.requires_grad else None
+    ref_opt.step()
+    ck = {"model": w["model"], "optimizer": ref_opt.state_dict(), "epoch": 3, "frame": 7}
+    third = IMAmpAgent(FakeVecEnv(16), small_cfg())
+    third.set_full_state_weights(ck)              # ... and the reference's file by us
+    st = third.optimizer.state[third.grads.flat_param]
+    ref_flat = torch.cat([ref_opt.state[p]["exp_avg"].reshape(-1) for p in ref_model.parameters() if p.requires_grad])
+    assert torch.equal(st["exp_avg"], ref_flat) and float(st["step"]) == float(sa["step"]) + 1
+    # one more step on both sides with the same gradient: same parameters
+    for p, gr in zip(third.model.parameters(), grads):
+        if p.requires_grad:
+            p.grad.copy_(gr)
+    third.optimizer.step()
+    third2 = torch.cat([p.detach().reshape(-1) for p in third.model.parameters() if p.requires_grad])
+    for p, gr in zip(ref_model.parameters(), grads):
+        p.grad = gr.clone() if p.requires_grad else None
+    ref_opt.step()
+    # (third loaded the pre-step weights `w["model"]`, ref_model has stepped twice) -> compare the moments instead of the weights
+    st = third.optimizer.state[third.grads.flat_param]
+    ref_flat = torch.cat([ref_opt.state[p]["exp_avg_sq"].reshape(-1) for p in ref_model.parameters() if p.requires_grad])
+    assert torch.allclose(st["exp_avg_sq"], ref_flat, rtol=1e-6, atol=1e-12) and third2.shape == ref_flat.shape
+    # (c) state of a different trainable set: skipped
+    bad = {"state": {0: w["optimizer"]["state"][trainable[0]]}, "param_groups": [dict(w["optimizer"]["param_groups"][0])]}
+    fresh = IMAmpAgent(FakeVecEnv(16), small_cfg())
+    assert fresh._load_optimizer_state_dict(bad) is False and len(fresh.optimizer.state) == 0
+    # players do not touch the optimizer
+    fresh.restore(path, load_optimizer=False)
+    assert len(fresh.optimizer.state) == 0 and torch.equal(fresh.grads.flat_param, agent.grads.flat_param)
