@@ -1,7 +1,9 @@
 #!/usr/bin/env python
 """bench.py -- the path's headline metric (BASELINE.json): env-steps/sec at 4096 humanoid envs per GPU.
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W          (N > 1: one rank per GPU over RCCL -- either launched by
+                                                            torch.distributed.run, or, when WORLD_SIZE is not set, bench.py
+                                                            re-executes itself under torch.distributed.run with N ranks)
 
 A "step" is one pass of the hot path over one batch of synthetic input: `VecEnv.step()` for 4096 SMPL-humanoid envs
 (BASELINE.json configs[1]: 69 DoF, 4096 envs, single reference motion) = action -> PD targets -> 4 ABA sub-steps with
@@ -46,7 +48,12 @@ def parse():
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU (BASELINE configs[1]: 4096)")
     ap.add_argument("--no-update-graph", action="store_true", help="PPO update with eager launches instead of the captured hipGraph "
                     "(learning.params.config.hip_graph; single-GPU runs only)")
-    ap.add_argument("--multi-gpu-update-graph", action="store_true", help="use the captured update graph also with more than one rank")
+    ap.add_argument("--multi-gpu-update-graph", action="store_true", help="(default since round 2; kept for compatibility) captured update "
+                    "graph also with more than one rank: the graph holds no collective, the all-reduce follows each replay eagerly")
+    ap.add_argument("--force-rccl", action="store_true", help="single-GPU self-test of the multi-GPU code path: a ONE-rank nccl (=RCCL) "
+                    "process group, the gradient all-reduce issued after every optimizer step's captured forward / backward")
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 5], help="BASELINE.json configs preset (1-based): 2 = SMPL 4096 envs single "
+                    "clip (the bench line), 3 = 8192 envs + AMASS-sized synthetic library (--motion-clips, default 11313), 5 = H1 4096 envs")
     ap.add_argument("--ppo-epochs", type=int, default=3, help="timed PPO epochs (rollout 32 steps + 36 optimizer steps); 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--robot", choices=["smpl", "h1", "g1"], default="smpl", help="smpl: BASELINE configs[1] (the bench line); h1: configs[4] morphology "
@@ -151,28 +158,63 @@ def cpu_baseline(num_envs=4096, budget_s=12.0, max_steps=4000):
                       f"(oracle/hostemu), {dt:.1f} s wall on {best} OpenMP threads (best of {cands}; host reports {os.cpu_count()} cpus)"}
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run, one rank per GPU (RCCL)."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n:
+        raise SystemExit(f"bench.py --gpus {n}: only {have} GPU(s) visible on this node -- refusing to report an {n}-GPU line from fewer devices")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (the host driver's only mode): RCCL needs it across processes
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        spawn_ranks(args.gpus)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the path has no CPU fallback")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if torch.cuda.device_count() < min(world, int(os.environ.get("LOCAL_WORLD_SIZE", world))):
+        raise SystemExit(f"bench.py: {world} ranks but only {torch.cuda.device_count()} GPU(s) visible")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_rccl:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 400))
+            os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if args.config == 3:      # configs[2]: full-AMASS-sized library, 8192 envs (defaults only: explicit flags win)
+        if "--envs" not in " ".join(sys.argv):
+            args.envs = 8192
+        if "--motion-clips" not in " ".join(sys.argv):
+            args.motion_clips = 11313
+    elif args.config == 5:    # configs[4]: H1 morphology
+        args.robot = "h1"
 
     from phc_amd.config import compose
     from phc_amd.env.tasks.vec_task import parse_task
     torch.manual_seed(rank)  # per-rank seed offset, as the reference's horovod path does (run_hydra.py:121)
     robot_over = [f"robot=unitree_{args.robot}", f"env=env_im_{args.robot}_phc", "sim=robot_sim", "control=robot_control"] if args.robot != "smpl" else []
-    # the captured update graph has been exercised on one GPU only (no multi-GPU box in development): runs with more ranks keep the
-    # eager launch sequence unless asked otherwise
-    graph_over = ["+learning.params.config.hip_graph=True"] if (not args.no_update_graph and (world == 1 or args.multi_gpu_update_graph)) else []
+    # the captured update graph holds no collective (the flat-gradient all-reduce follows each replay eagerly), so one and many ranks
+    # replay the same graph; --no-update-graph falls back to eager launches
+    graph_over = ["+learning.params.config.hip_graph=True"] if not args.no_update_graph else []
+    if args.force_rccl:
+        graph_over.append("+learning.params.config.force_collectives=True")
     cfg = compose(robot_over + graph_over + [f"env.num_envs={args.envs}", f"env.motion_file=synthetic:{args.motion_clips}:0", f"device_id={local_rank}",
                                 f"rl_device=cuda:{local_rank}", f"+solver.lane_mapping={args.lane_mapping}"] + ([f"+solver.self_collision={args.self_collision}"] if args.self_collision >= 0 else []))
     task, env = parse_task(cfg, device_id=local_rank)

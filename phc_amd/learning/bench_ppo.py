@@ -19,6 +19,8 @@ def time_ppo_epochs(task, env, cfg, epochs, dist=None, warmup=1):
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
+    agent.allreduce_timing = [] if dist is not None else None
+    c0 = agent.num_collectives
     t0 = time.perf_counter()
     infos = [agent.train_epoch() for _ in range(epochs)]
     torch.cuda.synchronize()
@@ -32,9 +34,24 @@ def time_ppo_epochs(task, env, cfg, epochs, dist=None, warmup=1):
         el = float(t.item())
         world = dist.get_world_size()
     n_opt = agent.mini_epochs_num * agent.num_minibatches
-    return {"ppo_samples_per_s": agent.batch_size * world * epochs / el, "ppo_epoch_ms": el / epochs * 1e3,
+    comm = {}
+    if dist is not None:
+        # evidence of the path's one collective: world size as every rank sees it, all-reduces actually issued, time of each
+        ws = [None] * world
+        dist.all_gather_object(ws, {"rank": dist.get_rank(), "world": dist.get_world_size(), "backend": dist.get_backend(),
+                                    "device": torch.cuda.current_device(), "collectives": agent.num_collectives - c0})
+        ar = sorted(a.elapsed_time(b) for a, b in agent.allreduce_timing)
+        nbytes = int(agent.grads.flat.numel() * 4)
+        med = ar[len(ar) // 2] if ar else None
+        comm = {"ppo_comm": {"backend": dist.get_backend(), "ranks": ws, "grad_allreduces_per_epoch": (agent.num_collectives - c0) / epochs,
+                             "allreduce_bytes": nbytes, "allreduce_ms_median": med, "allreduce_ms_mean": (sum(ar) / len(ar)) if ar else None,
+                             "allreduce_ms_max": ar[-1] if ar else None,
+                             # ring all-reduce moves 2 (G-1)/G x bytes per rank
+                             "allreduce_busbw_GBs": (2 * (world - 1) / world * nbytes / (med * 1e-3) / 1e9) if med else None,
+                             "allreduce_ms_per_epoch": (sum(ar) / epochs) if ar else None}}
+    return {**comm, "ppo_samples_per_s": agent.batch_size * world * epochs / el, "ppo_epoch_ms": el / epochs * 1e3,
             "ppo_play_ms": 1e3 * sum(i["play_time"] for i in infos) / epochs, "ppo_update_ms": 1e3 * sum(i["update_time"] for i in infos) / epochs,
             "ppo_config": {"horizon": agent.horizon_length, "batch_per_gpu": agent.batch_size, "minibatch": agent.minibatch_size,
                            "optimizer_steps_per_epoch": n_opt, "gemm_dtype": "bf16" if agent.bf16 else "f32",
-                           "grad_allreduce_bytes": int(agent.grads.flat.numel() * 4), "collectives_per_epoch": n_opt if world > 1 else 0,
+                           "grad_allreduce_bytes": int(agent.grads.flat.numel() * 4), "collectives_per_epoch": int((agent.num_collectives - c0) / epochs),
                            "update_graph": agent._graph is not None}}

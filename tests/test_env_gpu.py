@@ -30,18 +30,33 @@ def lib_dict(task):
     return d
 
 
-def test_step_matches_oracle_small():
-    """One full env step at N=64: post-physics outputs recomputed by the numpy oracle from the task's own
-    post-step simulator tensors (reference order: reward/reset at t, observations at t+dt)."""
-    task, env = make_task(64)
+@pytest.mark.parametrize("n,motion,iters", [(64, "synthetic:3:1", 3), (4096, "synthetic:1:0", 6)])
+def test_step_matches_oracle(n, motion, iters):
+    """Full env steps at N=64 and at BASELINE configs[1]'s own size (4096 envs, single clip -- the benchmarked configuration, incl. the
+    grid tail and the reset sub-lists that only exist at scale): post-physics outputs recomputed by the numpy oracle from the task's own
+    post-step simulator tensors (reference order: reward/reset at t, observations at t+dt); at 4096 the stepper itself is also checked
+    against the fp64 dense oracle on envs spread over the launch (first / last wavefront, freshly reset ones)."""
+    import dyn_oracle as do
+    task, env = make_task(n, motion=motion)
     env.reset()
     n = task.num_envs
     dt = F(task.dt)
-    for it in range(3):
+    for it in range(iters):
         amp_before = task._amp_obs_buf.clone().cpu().numpy()
         prog_before = task.progress_buf.cpu().numpy()
         actions = (torch.rand(n, 69, device=task.device) * 2 - 1) * 0.3
+        root0 = task._root_states.cpu().numpy().copy()
+        dof0 = task._dof_state.view(n, task.num_dof, 2).cpu().numpy().copy()
         obs, rew, done, info = env.step(actions)
+        if n >= 4096 and it in (0, iters - 1):
+            tgt = (task._pd_action_offset + task._pd_action_scale * actions).cpu().numpy()
+            tgt[:, task._freeze_mask.cpu().numpy() != 0] = 0
+            fresh = np.flatnonzero(prog_before == 0)
+            for e in sorted({0, 1, 63, n // 2 + 5, n - 64, n - 1, *fresh[:2].tolist()}):
+                r, d, rbs, tau, fc = do.sim_step(task.model, root0[e], dof0[e], tgt[e], params=dict(self_collision=int(task._sim_params.self_collision)),
+                                                 sim_dt=task.sim_dt, substeps=2, num_sim_calls=task.control_freq_inv)
+                np.testing.assert_allclose(task._rigid_body_pos[e].cpu().numpy(), rbs[:, 0:3], atol=1e-3, err_msg=f"env {e}")
+                np.testing.assert_allclose(task._root_states[e].cpu().numpy(), r, atol=2e-3, rtol=1e-3, err_msg=f"env {e}")
         torch.cuda.synchronize()
         lib = lib_dict(task)
         prog = task.progress_buf.cpu().numpy()
@@ -74,7 +89,10 @@ def test_step_matches_oracle_small():
         a = info["amp_obs"].cpu().numpy().reshape(n, 10, 196)
         np.testing.assert_allclose(a[:, 0], amp, atol=1e-4)
         np.testing.assert_array_equal(a[:, 1:], amp_before[:, :-1])
-        env.reset(done.nonzero(as_tuple=False).squeeze(-1))
+        if it % 2 == 0:
+            env.reset(done.nonzero(as_tuple=False).squeeze(-1))     # the reference's call
+        else:
+            task.reset_done()                                        # the rollout loop's device-side form (16 sub-lists at scale)
     assert obs.shape == (n, 934) and info["amp_obs"].shape == (n, 1960)
 
 
@@ -282,6 +300,29 @@ def test_two_rank_update_on_one_gpu(mode):
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
     assert out["exitcodes"] == [0, 0] and out["same_params"] and out["same_stats"] and out["finite"] and out["graph"] == (mode == "graph"), out
+    assert out["collectives"] == out["expected_collectives"]
+
+
+@pytest.mark.parametrize("world", [1, 2])
+@pytest.mark.parametrize("mode", ["eager", "graph"])
+def test_rccl_gradient_allreduce_next_to_the_update(mode, world):
+    """The same under the REAL backend (`nccl` = RCCL): world 2 needs two GPUs (skipped on a 1-GPU box -- the driver's scaling run is
+    the multi-GPU evidence); world 1 runs everywhere: a one-rank RCCL communicator with the all-reduce forced after every optimizer
+    step's forward / backward, i.e. RCCL's kernels, its watchdog thread and the captured update graph side by side on one device."""
+    import json
+    import os
+    import subprocess
+    import sys
+    if world > torch.cuda.device_count():
+        pytest.skip(f"needs {world} GPUs")
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, os.path.join(here, "two_rank_gpu_main.py"), "nccl", f"world={world}"] + (["graph"] if mode == "graph" else []),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert out["exitcodes"] == [0] * world and out["backend"] == "nccl" and out["world"] == world, out
+    assert out["same_params"] and out["same_stats"] and out["finite"] and out["graph"] == (mode == "graph"), out
+    assert out["collectives"] == out["expected_collectives"] > 0
 
 
 def test_im_eval_sweep_and_auto_pmcp():
