@@ -64,6 +64,7 @@ def main():
     progress = torch.randint(2, 15, (E,), generator=g)         # value AFTER progress_buf += 1
     progress[:4] = torch.tensor([1, 2, 3, 299])
     progress[4:6] = torch.tensor([298, 300])
+    torch.manual_seed(770)      # sample_time_interval draws from the GLOBAL generator (motion_lib_base.py:414-423): seed it, or the fixture cannot be regenerated
     st = lib.sample_time_interval(ids)
     so = torch.zeros(E)
     # envs 20..27: clip runs out this step (time >= motion length) -> cycled

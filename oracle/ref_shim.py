@@ -12,6 +12,9 @@ What is stubbed:
                               the reference's own ``phc/utils/isaacgym_torch_utils.py``
   * ``easydict.EasyDict``  -> 15-line attribute dict
   * ``smpl_sim.utils.torch_ext.to_torch`` -> tensor passthrough / from_numpy
+  * ``rl_games``           -> oracle/rl_games_stub.py: a real ObjectFactory, torch_ext.policy_kl, ModelA2CContinuousLogStd and
+                              EMPTY agent / player base classes, so that the reference's learner modules import and their
+                              method bodies can be called on `__new__`-made instances (oracle/gen_golden_learner.py)
   * every other missing third-party package -> auto-mocked on import
 """
 import importlib
@@ -98,6 +101,14 @@ def install():
     ed = types.ModuleType("easydict")
     ed.EasyDict = _EasyDict
     sys.modules.setdefault("easydict", ed)
+
+    # rl_games: real minimal stand-ins for the pieces the reference's learner executes (oracle/rl_games_stub.py); every other
+    # rl_games.* submodule stays an auto-mock
+    here = os.path.dirname(os.path.abspath(__file__))
+    if here not in sys.path:
+        sys.path.insert(0, here)
+    import rl_games_stub
+    rl_games_stub.register()
 
     sys.meta_path.append(_MockFinder())
 

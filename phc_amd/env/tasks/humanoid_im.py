@@ -323,7 +323,7 @@ class HumanoidIm:
         self.dof_limits = torch.stack([self.dof_limits_lower, self.dof_limits_upper], dim=-1)
         self.torque_limits = torch.from_numpy(self.model.dof_effort.astype(np.float32)).to(dev)
         self.motor_efforts = self.torque_limits.clone()
-        off, scale = self.model.pd_action_offset_scale(self._bias_offset)
+        off, scale = self.model.pd_action_offset_scale(self._bias_offset, self._has_smpl_pd_offset, self._has_upright_start)
         if self._is_robot:
             off = np.zeros_like(off)  # humanoid.py:1406-1407
         self._pd_action_offset = torch.from_numpy(off).to(dev)

@@ -24,6 +24,42 @@ def load_pnn(checkpoint, num_prim, has_lateral, activation="relu", device="cpu")
     return pnn.to(device).eval()
 
 
+_ACTIVATIONS = {"relu": torch.nn.ReLU, "silu": torch.nn.SiLU, "tanh": torch.nn.Tanh, "elu": torch.nn.ELU, "gelu": torch.nn.GELU,
+                "selu": torch.nn.SELU, "sigmoid": torch.nn.Sigmoid}
+
+
+def load_mcp_mlp(checkpoint, activation="relu", device="cpu", mlp_name="actor_mlp"):
+    """network_loader.py:11-52: a frozen copy of one plain (non-PNN) policy's actor -- `a2c_network.{mlp_name}.*` followed by the
+    `mu` head (or, for `composer`, a trailing activation) -- as one nn.Sequential.  One primitive of the `has_pnn=False` form of
+    the MCP task: `env.models` then lists one such checkpoint per primitive."""
+    sd = checkpoint["model"]
+    keys = [k for k in sd if k.startswith(f"a2c_network.{mlp_name}")]
+    if mlp_name != "composer":
+        keys += ["a2c_network.mu.weight", "a2c_network.mu.bias"]
+    wkeys = [k for k in keys if k.endswith("weight")]
+    act = _ACTIVATIONS[activation]
+    layers = []
+    for i, k in enumerate(wkeys):
+        w = sd[k]
+        if w.dim() == 1:
+            layers.append(torch.nn.LayerNorm(w.shape[0]))
+        elif w.dim() == 2:
+            layers.append(torch.nn.Linear(w.shape[1], w.shape[0]))
+            if i < len(wkeys) - 1:
+                layers.append(act())
+        else:
+            raise NotImplementedError(k)
+    mlp = torch.nn.Sequential(*layers)
+    if mlp_name == "composer":
+        mlp.append(act())
+    own = mlp.state_dict()
+    for dst, src in zip(own.keys(), keys):
+        own[dst].copy_(sd[src])
+    for p in mlp.parameters():
+        p.requires_grad = False
+    return mlp.to(device).eval()
+
+
 class MCPMixin:
     """Shared by HumanoidImMCP and HumanoidImMCPGetup."""
 
@@ -37,15 +73,27 @@ class MCPMixin:
         self.mlp_bypass = env.get("mlp_bypass", False)
         if self.mlp_bypass:
             raise NotImplementedError("mlp_bypass (distilled MLP in place of the primitives) is not built")
-        if not self.has_pnn:
-            raise NotImplementedError("HumanoidImMCP needs has_pnn=True: the primitives come from a PNN checkpoint")
 
     def _mcp_load(self):
-        self.pnn = None
+        self.pnn, self.actors = None, None
+        if not self.has_pnn:
+            # one plain checkpoint per primitive, each rebuilt by load_mcp_mlp (network_loader.py:11-52); the observation statistics
+            # are those of the first one
+            if self.models_path:
+                cks = [torch.load(p, map_location=self.device, weights_only=False) for p in self.models_path]
+                self.load_primitive_mlps(cks)
+            return
         if len(self.models_path) == 1:
             self.load_primitives(torch.load(self.models_path[0], map_location=self.device, weights_only=False))
         elif len(self.models_path) > 1:
             raise AssertionError("exactly one PNN checkpoint is expected in env.models (humanoid_im_mcp.py:26)")
+
+    def load_primitive_mlps(self, checkpoints):
+        assert len(checkpoints) == self.num_prim, "one checkpoint per primitive"
+        self.actors = [load_mcp_mlp(ck, activation=self.z_activation, device=self.device) for ck in checkpoints]
+        rms = checkpoints[0]["running_mean_std"]
+        self.running_mean = rms["running_mean"].float().to(self.device)
+        self.running_var = rms["running_var"].float().to(self.device)
 
     def load_primitives(self, checkpoint):
         """Install the frozen primitives from a PNN checkpoint dict (`model` + `running_mean_std`)."""
@@ -63,13 +111,16 @@ class MCPMixin:
         return d
 
     def compose_actions(self, weights):
-        if self.pnn is None:
+        if self.pnn is None and self.actors is None:
             raise RuntimeError("no primitives loaded: set env.models=[<pnn checkpoint>] or call load_primitives()")
         with torch.no_grad():
             obs = torch.clamp((self.obs_buf - self.running_mean) / torch.sqrt(self.running_var + 1e-05), min=-5.0, max=5.0)
             if self.discrete_mcp:
                 weights = torch.nn.functional.one_hot(torch.argmax(weights, dim=1), num_classes=self.num_prim).float()
-            _, acts = self.pnn(obs)
+            if self.pnn is not None:
+                _, acts = self.pnn(obs)
+            else:
+                acts = [net(obs) for net in self.actors]      # humanoid_im_mcp.py:78-79
             return torch.sum(weights[:, :, None] * torch.stack(acts, dim=1), dim=1)
 
     def step(self, weights):

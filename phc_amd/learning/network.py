@@ -121,14 +121,19 @@ class PNN(nn.Module):
 class A2CPNNNetwork(A2CNetwork):
     """`AMPPNNBuilder.Network` (phc/learning/amp_network_pnn_builder.py:25-87): the actor MLP + mu head are replaced by a
     PNN whose column `training_prim` produces the action mean; columns below it are frozen.  State-dict keys:
-    `a2c_network.pnn.actors.{k}.{0,2,4}.*` (what scripts/pmcp/forward_pmcp.py copies between columns)."""
+    `a2c_network.pnn.actors.{k}.{0,2,4}.*` (what scripts/pmcp/forward_pmcp.py copies between columns) next to the parent's
+    `critic_mlp / value / mu / sigma / _disc_*` -- exactly the reference's key set (tests/test_learner_parity.py)."""
 
     def __init__(self, params, actions_num, input_shape, amp_input_shape, task_obs_size_detail, value_size=1):
         super().__init__(params, actions_num, input_shape, amp_input_shape, value_size)
         d = task_obs_size_detail
         self.num_prim, self.training_prim = d["num_prim"], d["training_prim"]
         del self.actor_mlp
-        del self.mu
+        # `mu` STAYS in the module (and in the state dict) although the PNN columns carry their own output layer: the reference deletes
+        # only actor_mlp (amp_network_pnn_builder.py:51), and its env-side loader reads `a2c_network.mu.bias` for the action size
+        # (network_loader.py:65).  It takes no part in the forward pass, so it does not train.
+        for p in self.mu.parameters():
+            p.requires_grad = False
         self.pnn = PNN(input_shape[0], self.units, self.activation, actions_num, self.num_prim, d.get("has_lateral", False))
         self.pnn.freeze_pnn(self.training_prim)
 

@@ -485,8 +485,9 @@ class ArticulationModel:
                 lo.append(l); hi.append(u)
         return np.array(lo, dtype=np.float32), np.array(hi, dtype=np.float32)
 
-    def pd_action_offset_scale(self, bias_offset=False):
-        """Reference `_build_pd_action_offset_scale` (humanoid.py:1331-1409)."""
+    def pd_action_offset_scale(self, bias_offset=False, has_smpl_pd_offset=False, has_upright_start=True):
+        """Reference `_build_pd_action_offset_scale` (humanoid.py:1331-1409); pinned to the reference's own method by
+        tests/golden/pd_offset_scale.npz (oracle/gen_golden_learner.py)."""
         lim_low, lim_high = self.dof_limits()
         lim_low, lim_high = lim_low.copy(), lim_high.copy()
         for i in range(1, self.num_bodies):
@@ -516,6 +517,15 @@ class ArticulationModel:
             jn = self.body_names[1:]
             scale[jn.index("L_Knee") * 3 + 1] = 5  # "Bumping Kneel" humanoid.py:1387-1394
             scale[jn.index("R_Knee") * 3 + 1] = 5
+            if has_smpl_pd_offset:   # humanoid.py:1396-1404
+                ls, rs = jn.index("L_Shoulder") * 3, jn.index("R_Shoulder") * 3
+                if has_upright_start:
+                    offset[ls], offset[rs] = -np.pi / 2, np.pi / 2
+                else:
+                    offset[ls], offset[ls + 2] = -np.pi / 6, -np.pi / 2
+                    offset[rs], offset[rs + 2] = -np.pi / 3, np.pi / 2
+        elif not self.all_spherical:
+            offset[:] = 0            # humanoid.py:1406-1407 (h1 / g1)
         return offset, scale
 
     def limb_lengths_and_weights(self, groups):

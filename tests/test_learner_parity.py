@@ -1,0 +1,301 @@
+"""Learner rows pinned to the REFERENCE'S OWN method bodies (A1, P2, P3, P5, P6, P8; 8b: B4).
+
+The fixtures `tests/golden/learner_{fns,step,pnn}.npz` and `pd_offset_scale.npz` are outputs of the unmodified reference classes --
+`CommonAgent.discount_values / _actor_loss / _critic_loss / bound_loss / _calc_advs`, one whole `AMPAgent.calc_gradients` (forward through
+the reference's `AMPBuilder` network and `ModelAMPContinuous`, `_disc_loss` with the gradient penalty, backward, `clip_grad_norm_`, Adam),
+`AMPAgent._calc_disc_rewards / _combine_rewards`, the PNN / MCP builders, `network_loader.load_pnn / load_mcp_mlp`,
+`Humanoid._build_pd_action_offset_scale` -- produced by `oracle/gen_golden_learner.py` in the build container.
+
+CPU tests: the agent's torch path (which is also the definition the HIP kernels are tested against elsewhere).
+`-m gpu` tests: the SAME comparisons through the product path on the device -- `phc_gae`, `phc_running_norm`, `phc_ppo_loss`,
+`phc_disc_bce`, `phc_weighted_sumsq`, FastLinear / FastLinearDD, `phc_adam_clip_step` -- in fp32 (tight tolerance) and with bf16 GEMMs.
+
+Loading the reference's state dict with `strict=True` is the B4 check: the key sets are identical."""
+import numpy as np
+import pytest
+import torch
+
+import phc_oracle as po
+from phc_amd.config import compose
+from phc_amd.learning.amp_agent import IMAmpAgent, discount_values
+
+O, M, A, T, N, MB, AMB = 40, 36, 9, 8, 16, 64, 32
+
+
+class _Task:
+    temp_running_mean = True
+    shape_resampling_interval = 500
+
+    def __init__(self, device, actions=A):
+        self.device, self.num_envs, self._a = device, N, actions
+        self.obs_buf = torch.zeros(N, O, device=device)
+        self.reset_buf = torch.zeros(N, dtype=torch.long, device=device)
+
+    def get_num_amp_obs(self):
+        return M
+
+    def get_task_obs_size_detail(self):
+        return {"num_prim": 3, "training_prim": 1, "has_lateral": False}
+
+
+class _Env:
+    clip_obs = np.inf
+
+    def __init__(self, device="cpu", actions=A):
+        self.task = _Task(device, actions)
+        self.num_envs, self.num_obs, self.num_actions = N, O, actions
+
+
+def _cfg(learning="im", extra=()):
+    return compose([f"learning={learning}", f"learning.params.config.horizon_length={T}", f"learning.params.config.minibatch_size={MB}",
+                    f"learning.params.config.amp_minibatch_size={AMB}", "learning.params.config.amp_batch_size=16",
+                    "learning.params.config.amp_obs_demo_buffer_size=256", "learning.params.config.amp_replay_buffer_size=256",
+                    "learning.params.network.mlp.units=[64,32]", "learning.params.network.disc.units=[48,24]"] + list(extra))
+
+
+def _sub(g, prefix):
+    return {k[len(prefix):]: torch.from_numpy(np.asarray(g[k])) for k in g if k.startswith(prefix)}
+
+
+def _agent_from_golden(g, device="cpu", bf16=False):
+    torch.manual_seed(0)
+    agent = IMAmpAgent(_Env(device), _cfg(), bf16=bf16)
+    agent.model.load_state_dict(_sub(g, "model/"), strict=True)          # B4: the reference's key set, nothing missing, nothing extra
+    if agent.grads.shadow is not None:
+        agent.grads.shadow.copy_(agent.grads.flat_param)
+    agent.running_mean_std.load_state_dict(_sub(g, "running_mean_std/"))
+    agent.value_mean_std.load_state_dict(_sub(g, "reward_mean_std/"))
+    agent._amp_input_mean_std.load_state_dict(_sub(g, "amp_input_mean_std/"))
+    agent._snapshot_running_mean_std()
+    agent.running_mean_std_temp.load_state_dict(_sub(g, "running_mean_std_temp/"))
+    return agent
+
+
+# ------------------------------------------------------------------------------------------------------------------ A1
+def test_pd_action_offset_scale_equals_the_reference_method(golden):
+    from phc_amd.model import load_model
+    g = golden("pd_offset_scale")
+    tags = sorted({k.rsplit("/", 1)[0] for k in g if k.endswith("/offset")})
+    assert len(tags) == 8
+    for tag in tags:
+        htype, flags_ = tag.split("/")
+        m = load_model({"smpl": "smpl_humanoid", "h1": "h1_humanoid", "g1": "g1_humanoid"}[htype])
+        lo, hi = m.dof_limits()
+        np.testing.assert_array_equal(lo, g[f"{htype}/lim_low"])
+        bias, pdoff, upright = (bool(int(f[-1])) for f in flags_.split("_"))
+        off, scale = m.pd_action_offset_scale(bias, pdoff, upright)
+        np.testing.assert_allclose(off, g[tag + "/offset"], rtol=0, atol=1e-7, err_msg=tag)
+        np.testing.assert_allclose(scale, g[tag + "/scale"], rtol=1e-7, atol=0, err_msg=tag)
+        if tag == "smpl/bias0_pdoff0_upright1":    # the numpy oracle's restatement (shipped SMPL configuration) against the same fixture
+            o2, s2 = po.build_pd_action_offset_scale_smpl(lo, hi, m.body_names[1:])
+            np.testing.assert_allclose(o2, g[tag + "/offset"], atol=1e-7)
+            np.testing.assert_allclose(s2, g[tag + "/scale"], rtol=1e-7)
+
+
+# ------------------------------------------------------------------------------------------------------------------ P5 + loss pieces
+def test_gae_and_loss_terms_equal_the_reference_methods(golden):
+    g = golden("learner_fns")
+    t = lambda k: torch.from_numpy(g[k])
+    advs = discount_values(t("gae_fdones"), t("gae_values"), t("gae_rewards"), t("gae_next_values"), float(g["gamma"]), float(g["tau"]))
+    np.testing.assert_allclose(advs.numpy(), g["gae_advs"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(po.discount_values(g["gae_fdones"], g["gae_values"], g["gae_rewards"], g["gae_next_values"], float(g["gamma"]), float(g["tau"])),
+                               g["gae_advs"], rtol=1e-6, atol=1e-6)
+    agent = IMAmpAgent(_Env(), _cfg())
+    for clip_value, key in ((True, "cl_loss_clip"), (False, "cl_loss_noclip")):
+        agent.clip_value = clip_value
+        B = g["al_adv"].shape[0]
+        res = {"prev_neglogp": t("al_logp"), "values": t("cl_values"), "mus": t("bl_mu"), "sigmas": torch.ones(B, A), "entropy": torch.zeros(B)}
+        d = {"old_logp_actions": t("al_old_logp"), "advantages": t("al_adv"), "returns": t("cl_returns"), "old_values": t("cl_value_preds"),
+             "mu": t("bl_mu"), "sigma": torch.ones(B, A)}
+        _, info = agent._ppo_loss_torch(res, d, {"disc_loss": torch.zeros(())})
+        np.testing.assert_allclose(float(info["actor_loss"]), g["al_loss"].mean(), rtol=1e-6)
+        np.testing.assert_allclose(float(info["critic_loss"]), g[key].mean(), rtol=1e-6)
+        np.testing.assert_allclose(float(info["b_loss"]), g["bl_loss"].mean(), rtol=1e-6)
+    np.testing.assert_allclose(agent.bound_loss(t("bl_mu")).numpy(), g["bl_loss"], rtol=1e-6)
+    # _calc_advs (common_agent.py:589-599) is the first two lines of prepare_dataset
+    ret, val = t("adv_returns"), t("adv_values")
+    a = torch.sum(ret - val, axis=1)
+    np.testing.assert_allclose(((a - a.mean()) / (a.std() + 1e-8)).numpy(), g["adv_out"], rtol=1e-6, atol=1e-7)
+
+
+def _run_step(agent, g, device, dataset_form):
+    d = {k: v.to(device) for k, v in _sub(g, "in/").items()}
+    if dataset_form:   # the device form: persistent dataset + row index, the kernels gather in place
+        idx = torch.arange(MB, device=device)
+        return agent.calc_gradients({"_dataset": d, "_idx": idx, "_amp_idx": idx[:AMB]})
+    return agent.calc_gradients(d)
+
+
+def _check_step(agent, g, info, rtol_loss, grad_rtol, grad_atol, param_atol):
+    for k in ("actor_loss", "critic_loss", "b_loss", "entropy", "kl", "disc_loss", "disc_grad_penalty", "disc_logit_loss"):
+        np.testing.assert_allclose(float(info[k]), float(g["res/" + k]), rtol=rtol_loss, atol=rtol_loss * 1e-2, err_msg=k)
+    for k in ("disc_agent_acc", "disc_demo_acc"):
+        assert abs(float(info[k]) - float(g["res/" + k])) <= (0.0 if rtol_loss < 1e-3 else 2.0 / AMB), k
+    names = [str(n) for n in g["param_names"]]
+    params = dict(agent.model.named_parameters())
+    assert list(params) == names                                        # same parameters, same ORDER (optimizer state layout, B4)
+    assert [bool(p.requires_grad) for p in params.values()] == [bool(x) for x in g["param_requires_grad"]]
+    worst = 0.0
+    for n in names:
+        if "grad/" + n not in g:
+            assert not params[n].requires_grad or params[n].grad is None or float(params[n].grad.abs().max()) == 0, n
+            continue
+        ref = g["grad/" + n]
+        got = params[n].grad.detach().float().cpu().numpy()
+        scale = max(np.abs(ref).max(), 1e-12)
+        worst = max(worst, float(np.abs(got - ref).max() / scale))
+        np.testing.assert_allclose(got, ref, rtol=grad_rtol, atol=grad_atol + grad_rtol * scale, err_msg="grad " + n)
+    after = _sub(g, "model_after/")
+    before = _sub(g, "model/")
+    for n, p in agent.model.state_dict().items():
+        ref = after[n].numpy()
+        np.testing.assert_allclose(p.detach().float().cpu().numpy(), ref, rtol=0, atol=param_atol, err_msg="param " + n)
+    moved = max(float((after[n] - before[n]).abs().max()) for n in names)
+    assert moved > 1e-5            # lr 2e-5: Adam's first step moves every weight by ~lr
+    for nm, mod in (("running_mean_std", agent.running_mean_std), ("amp_input_mean_std", agent._amp_input_mean_std)):
+        for k, v in _sub(g, nm + "_after/").items():
+            np.testing.assert_allclose(getattr(mod, k).detach().cpu().numpy(), v.numpy(), rtol=1e-9, atol=1e-12, err_msg=f"{nm}.{k}")
+    return worst
+
+
+# ------------------------------------------------------------------------------------------------------------------ P2 + P6 + P8 + B4 (CPU)
+def test_calc_gradients_equals_the_reference_agent_cpu(golden):
+    g = golden("learner_step")
+    agent = _agent_from_golden(g)
+    # P6 first (evaluation mode, statistics untouched)
+    agent.set_eval()
+    amp_r = agent._calc_amp_rewards(torch.from_numpy(g["p6_amp_obs"]))
+    np.testing.assert_allclose(amp_r["disc_rewards"].numpy(), g["p6_disc_rewards"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(agent._combine_rewards(torch.from_numpy(g["p6_task_rewards"]), amp_r).numpy(), g["p6_combined"], rtol=1e-5, atol=1e-6)
+    info = _run_step(agent, g, "cpu", dataset_form=False)
+    _check_step(agent, g, info, rtol_loss=2e-5, grad_rtol=2e-4, grad_atol=1e-7, param_atol=2e-7)
+    # the optimizer state this step produced, in the checkpoint's per-parameter layout == the reference optimizer's state
+    sd = agent.get_full_state_weights()["optimizer"]
+    assert sd["param_groups"][0]["params"] == list(g["opt/param_ids"]) and sorted(sd["state"]) == list(g["opt/state_ids"])
+    for i in g["opt/state_ids"]:
+        np.testing.assert_allclose(sd["state"][int(i)]["exp_avg"].numpy(), g[f"opt/{i}/exp_avg"], rtol=2e-4, atol=1e-9)
+        np.testing.assert_allclose(sd["state"][int(i)]["exp_avg_sq"].numpy(), g[f"opt/{i}/exp_avg_sq"], rtol=4e-4, atol=1e-12)
+        assert float(sd["state"][int(i)]["step"]) == float(g[f"opt/{i}/step"]) == 1.0
+
+
+# ------------------------------------------------------------------------------------------------------------------ P3 + B4
+def test_pnn_and_mcp_networks_and_checkpoint_loaders_equal_the_reference(golden):
+    from phc_amd.env.tasks.humanoid_im_mcp import load_mcp_mlp, load_pnn
+    from phc_amd.learning.network import A2CMCPNetwork, A2CNetwork, A2CPNNNetwork, ModelAMPContinuous, forward_pmcp
+    g = golden("learner_pnn")
+    x = torch.from_numpy(g["pnn_x"])
+    detail = {"num_prim": 3, "training_prim": 1, "has_lateral": False}
+    # PNN network: key set, trainable set, forward
+    net = ModelAMPContinuous(A2CPNNNetwork(_cfg("im_pnn")["learning"]["params"]["network"], A, (O,), (M,), detail))
+    assert [n for n, _ in net.named_parameters()] == [str(s) for s in g["pnn_param_names"]]
+    assert [bool(p.requires_grad) for _, p in net.named_parameters() if "pnn" in _] == \
+        [bool(r) for n, r in zip(g["pnn_param_names"], g["pnn_requires_grad"]) if "pnn" in str(n)]
+    net.load_state_dict(_sub(g, "pnn_model/"), strict=True)
+    net.eval()
+    with torch.no_grad():
+        mu, logstd = net.a2c_network.eval_actor(x)
+        np.testing.assert_allclose(mu.numpy(), g["pnn_mu"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(logstd.numpy(), g["pnn_sigma"], rtol=0, atol=0)
+        np.testing.assert_allclose(net.a2c_network.eval_critic(x).numpy(), g["pnn_value"], rtol=1e-5, atol=1e-6)
+    # env-side loader on the reference-shaped checkpoint (network_loader.py:54-74)
+    ck = {"model": _sub(g, "pnn_model/")}
+    pnn = load_pnn(ck, num_prim=3, has_lateral=False, activation="relu", device="cpu")
+    with torch.no_grad():
+        _, acts = pnn(x)
+    np.testing.assert_allclose(torch.stack(acts, dim=1).numpy(), g["load_pnn_actions"], rtol=1e-5, atol=1e-6)
+    assert not any(p.requires_grad for p in pnn.parameters())
+    # scripts/pmcp/forward_pmcp.py: column 1 -> column 2
+    ck2 = forward_pmcp({"model": {k: v.clone() for k, v in ck["model"].items()}}, 1)
+    want = _sub(g, "pmcp_model/")
+    assert set(ck2["model"]) == set(want)
+    for k, v in want.items():
+        assert torch.equal(ck2["model"][k], v), k
+    # MCP composer network
+    pm = _cfg("im_mcp")["learning"]["params"]["network"]
+    assert bool(pm.get("has_softmax", True)) == bool(g["mcp_has_softmax"]) and bool(pm.get("ending_act", True)) == bool(g["mcp_ending_act"])
+    mcp = ModelAMPContinuous(A2CMCPNetwork(pm, 3, (O,), (M,), detail))
+    assert [n for n, _ in mcp.named_parameters()] == [str(s) for s in g["mcp_param_names"]]
+    mcp.load_state_dict(_sub(g, "mcp_model/"), strict=True)
+    mcp.eval()
+    with torch.no_grad():
+        np.testing.assert_allclose(mcp.a2c_network.eval_actor(x)[0].numpy(), g["mcp_mu"], rtol=1e-5, atol=1e-6)
+    # load_mcp_mlp on a plain `amp` checkpoint (network_loader.py:11-52) and the plain network itself
+    plain = ModelAMPContinuous(A2CNetwork(_cfg()["learning"]["params"]["network"], A, (O,), (M,)))
+    plain.load_state_dict(_sub(g, "amp_model/"), strict=True)
+    plain.eval()
+    mlp = load_mcp_mlp({"model": _sub(g, "amp_model/")}, activation="relu", device="cpu", mlp_name="actor_mlp")
+    with torch.no_grad():
+        np.testing.assert_allclose(mlp(x).numpy(), g["load_mcp_mlp_out"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(plain.a2c_network.eval_actor(x)[0].numpy(), g["amp_mu"], rtol=1e-5, atol=1e-6)
+
+
+def test_released_checkpoint_layout_round_trip(golden, tmp_path):
+    """B4 / f-2: a file with the reference's full checkpoint layout (`get_full_state_weights`, common_agent.py:405-433: model, epoch,
+    optimizer = Adam(model.parameters()).state_dict(), frame, running_mean_std, reward_mean_std, amp_input_mean_std) restores through
+    `IMAmpAgent.restore`, acts identically to the reference network on fixed observations, and what we save loads back into a plain
+    torch module + optimizer with the reference's layout."""
+    g = golden("learner_step")
+    agent = _agent_from_golden(g)
+    ref_opt_state = {int(i): {"step": torch.tensor(float(g[f"opt/{i}/step"])), "exp_avg": torch.from_numpy(g[f"opt/{i}/exp_avg"]),
+                              "exp_avg_sq": torch.from_numpy(g[f"opt/{i}/exp_avg_sq"])} for i in g["opt/state_ids"]}
+    group = dict(torch.optim.Adam([torch.zeros(1, requires_grad=True)], 2e-5, eps=1e-8).state_dict()["param_groups"][0])
+    group["params"] = [int(i) for i in g["opt/param_ids"]]
+    ck = {"model": _sub(g, "model_after/"), "epoch": 12, "frame": 34, "optimizer": {"state": ref_opt_state, "param_groups": [group]},
+          "running_mean_std": _sub(g, "running_mean_std_after/"), "reward_mean_std": _sub(g, "reward_mean_std/"),
+          "amp_input_mean_std": _sub(g, "amp_input_mean_std_after/")}
+    path = str(tmp_path / "Humanoid.pth")
+    torch.save(ck, path)
+    torch.manual_seed(5)
+    fresh = IMAmpAgent(_Env(), _cfg(), bf16=False)
+    fresh.restore(path)
+    assert fresh.epoch_num == 12 and fresh.frame == 34
+    st = fresh.optimizer.state[fresh.grads.flat_param]
+    want = torch.cat([ref_opt_state[int(i)]["exp_avg"].reshape(-1) for i in g["opt/state_ids"]])
+    assert torch.equal(st["exp_avg"], want) and float(st["step"]) == 1.0
+    for n, p in fresh.model.state_dict().items():
+        assert torch.equal(p, ck["model"][n]), n
+    # second step from the restored state == continuing an agent that took the first step itself
+    fresh._snapshot_running_mean_std()
+    fresh.running_mean_std_temp.load_state_dict(_sub(g, "running_mean_std_temp/"))
+    _run_step(agent, g, "cpu", False)                # step 1 (== the reference's, test above)
+    info_a = _run_step(agent, g, "cpu", False)       # step 2
+    info_b = _run_step(fresh, g, "cpu", False)       # step 2 from the reference's checkpoint after step 1
+    for (n, p), (_, q) in zip(agent.model.state_dict().items(), fresh.model.state_dict().items()):
+        np.testing.assert_allclose(p.numpy(), q.numpy(), rtol=0, atol=5e-7, err_msg=n)
+    assert abs(float(info_a["disc_loss"]) - float(info_b["disc_loss"])) < 1e-5
+    # and back: our file -> plain torch objects with the reference's layout
+    out = str(tmp_path / "ours.pth")
+    fresh.save(out)
+    w = torch.load(out, weights_only=False)
+    assert set(w) >= {"model", "epoch", "optimizer", "frame", "running_mean_std", "reward_mean_std", "amp_input_mean_std"}
+    assert set(w["model"]) == set(ck["model"]) and w["optimizer"]["param_groups"][0]["params"] == group["params"]
+    assert sorted(w["optimizer"]["state"]) == sorted(ref_opt_state)
+
+
+# ------------------------------------------------------------------------------------------------------------------ the product path on the device
+@pytest.mark.gpu
+def test_gae_kernel_equals_the_reference_method(golden):
+    g = golden("learner_fns")
+    t = lambda k: torch.from_numpy(g[k]).cuda()
+    advs = discount_values(t("gae_fdones"), t("gae_values"), t("gae_rewards"), t("gae_next_values"), float(g["gamma"]), float(g["tau"]))
+    np.testing.assert_allclose(advs.cpu().numpy(), g["gae_advs"], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bf16", [False, True])
+def test_calc_gradients_equals_the_reference_agent_on_hip(golden, bf16):
+    """P8 through the fused kernels: phc_running_norm (row-indexed, frozen source), FastLinear / FastLinearDD, phc_ppo_loss,
+    phc_disc_bce, phc_weighted_sumsq (logit reg, weight decay, gradient penalty through the double backward), phc_adam_clip_step."""
+    g = golden("learner_step")
+    agent = _agent_from_golden(g, device="cuda", bf16=bf16)
+    agent.set_eval()
+    amp_r = agent._calc_amp_rewards(torch.from_numpy(g["p6_amp_obs"]).cuda())
+    tol = 5e-2 if bf16 else 1e-4
+    np.testing.assert_allclose(amp_r["disc_rewards"].cpu().numpy(), g["p6_disc_rewards"], rtol=tol, atol=tol)
+    info = _run_step(agent, g, "cuda", dataset_form=True)
+    torch.cuda.synchronize()
+    if bf16:     # GEMM inputs rounded to 8 mantissa bits: losses to a few percent, the update direction stays the reference's
+        worst = _check_step(agent, g, info, rtol_loss=6e-2, grad_rtol=0.25, grad_atol=1e-4, param_atol=4.1e-5)
+    else:
+        worst = _check_step(agent, g, info, rtol_loss=2e-4, grad_rtol=2e-3, grad_atol=1e-6, param_atol=2e-6)
+    assert worst < (0.25 if bf16 else 2e-3)
