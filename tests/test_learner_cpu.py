@@ -215,7 +215,7 @@ def test_pnn_network_and_forward_pmcp():
     net = A2CPNNNetwork(cfg.learning.params.network, 69, (934,), (1960,), detail)
     model = ModelAMPContinuous(net)
     keys = set(model.state_dict())
-    assert "a2c_network.pnn.actors.2.4.weight" in keys and "a2c_network.actor_mlp.0.weight" not in keys and "a2c_network.mu.weight" not in keys
+    assert "a2c_network.pnn.actors.2.4.weight" in keys and "a2c_network.actor_mlp.0.weight" not in keys and "a2c_network.mu.weight" in keys  # the reference keeps mu (amp_network_pnn_builder.py:51)
     assert not any(p.requires_grad for p in net.pnn.actors[0].parameters())          # columns < training_prim frozen (pnn.py:40-45)
     assert all(p.requires_grad for p in net.pnn.actors[1].parameters())
     obs = torch.randn(5, 934)
