@@ -56,6 +56,9 @@ def parse():
                     "clip (the bench line), 3 = 8192 envs + AMASS-sized synthetic library (--motion-clips, default 11313), 5 = H1 4096 envs")
     ap.add_argument("--ppo-epochs", type=int, default=3, help="timed PPO epochs (rollout 32 steps + 36 optimizer steps); 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the live HBM-traffic measurement (two rocprofv3 --pmc passes of a 20-step "
+                    "child run, FETCH_SIZE and WRITE_SIZE separately as MI355X_MICROARCH.md prescribes); `roofline.traffic` then falls "
+                    "back to the newest committed profiles/*_pmc_traffic.json")
     ap.add_argument("--robot", choices=["smpl", "h1", "g1"], default="smpl", help="smpl: BASELINE configs[1] (the bench line); h1: configs[4] morphology "
                     "(Unitree H1, 19 revolute DoFs, 200 Hz x 4 pd-torque control); g1: Unitree G1 (38 bodies, the 64-lane kernels) -- parity-test "
                     "configurations, timed for reference only")
@@ -156,6 +159,63 @@ def cpu_baseline(num_envs=4096, budget_s=12.0, max_steps=4000):
     return {"value": val, "unit": "env-steps/s", "cores": best, "kind": "port",
             "sample": f"{steps} steps x {N} envs (reset+stepper+post-physics), g++ -O2 -fopenmp build of the kernels' per-lane code "
                       f"(oracle/hostemu), {dt:.1f} s wall on {best} OpenMP threads (best of {cands}; host reports {os.cpu_count()} cpus)"}
+
+
+def cpu_reference():
+    """The REFERENCE'S OWN CPU path (stages C1-C3: motion lookup x2, imitation reward + reset, self / task / AMP
+    observations; C0 load_motions) as measured by oracle/time_reference.py.  The reference is a Python checkout that exists in the build
+    container only, so these numbers are measured there (host stated inside) and shipped as a committed file -- not re-measured on the
+    GPU box.  There is no reference CPU number for C4 (dynamics: closed Isaac Gym binary); `cpu_baseline` (kind "port") covers it."""
+    files = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_reference_cpu_stages.json"))
+    if not files:
+        return None
+    d = json.load(open(os.path.join(ROOT, "profiles", files[-1])))
+    st = d["stages"]
+    return {"kind": "reference", "what": "phc MotionLibSMPL.get_motion_state x2 + compute_imitation_reward + compute_humanoid_im_reset + "
+            "compute_humanoid_observations_smpl_max + compute_imitation_observations_v6 + build_amp_observations_smpl (no dynamics: C4 has no CPU code)",
+            "value": st["4096"]["env_steps_per_s_reward_obs_only"], "unit": "env-steps/s", "cores": d["host"]["threads"], "host": d["host"]["model"],
+            "stages_ms": {n: {k: v for k, v in st[n].items() if k.endswith("_ms")} for n in st}, "load_motions_ms_per_clip": d["load_motions"]["ms_per_clip"],
+            "protocol": d.get("protocol", "5 warm-up + 50 timed iterations, median"), "measured_in": d.get("measured_in", "build container"),
+            "source": "profiles/" + files[-1]}
+
+
+def live_pmc_traffic(argv_tail, kernel_prefixes):
+    """HBM bytes per launch of the dominant kernel from the PMC counters, measured NOW: two child runs of this script under
+    `rocprofv3 --pmc <counter> --kernel-trace` (FETCH_SIZE and WRITE_SIZE in separate passes: TCC slot limit), corrected as
+    MI355X_MICROARCH.md prescribes for gfx950 (read bytes = 2 x FETCH_SIZE KiB; WRITE_SIZE as is; calibration on k_im_post_physics in
+    profiles/pmc_summary.py).  Returns (bytes, detail) or (None, reason)."""
+    import csv
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 not on PATH"
+    vals = {}
+    env = dict(os.environ, PHC_BENCH_CHILD="1", TMPDIR="/tmp")
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="phc_pmc_", dir="/tmp")
+        cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "pmc", "--", sys.executable,
+               os.path.abspath(__file__), "--steps", "20", "--warmup", "5", "--ppo-epochs", "0", "--no-cpu-baseline", "--no-pmc"] + argv_tail
+        try:
+            r = subprocess.run(cmd, env=env, cwd="/tmp", capture_output=True, text=True, timeout=240)
+        except Exception as exc:   # noqa: BLE001
+            return None, f"{counter} pass failed: {type(exc).__name__}"
+        path = next((os.path.join(dp, f) for dp, _, fs in os.walk(d) for f in fs if f.endswith("counter_collection.csv")), None)
+        if r.returncode != 0 or path is None:
+            return None, f"{counter} pass rc={r.returncode}"
+        per = {}
+        for row in csv.DictReader(open(path)):
+            if row["Counter_Name"] == counter:
+                per.setdefault(row["Kernel_Name"].split("(")[0].replace("void ", ""), []).append(float(row["Counter_Value"]))
+        k = next((k for pre in kernel_prefixes for k in per if k.startswith(pre)), None)
+        if k is None:
+            return None, f"no stepper dispatch in the {counter} pass"
+        v = sorted(per[k])
+        vals[counter] = (k, v[len(v) // 2], len(v))
+        shutil.rmtree(d, ignore_errors=True)
+    rd, wr = 2.0 * vals["FETCH_SIZE"][1] * 1024.0, vals["WRITE_SIZE"][1] * 1024.0
+    return rd + wr, {"kernel": vals["FETCH_SIZE"][0], "read_bytes": rd, "write_bytes": wr, "dispatches": vals["FETCH_SIZE"][2],
+                     "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, --kernel-trace), median per dispatch; gfx950: read = 2 x FETCH_SIZE"}
 
 
 def spawn_ranks(n):
@@ -276,9 +336,16 @@ def main():
         pub_bytes = 4 * (NB_ * 13 + D_ + NB_ * 3)                      # body state + dof force + contact force (1812 B for SMPL)
         assert args.robot != "smpl" or (aba_bytes, pub_bytes) == (ABA_BYTES_PER_ENV_SUBSTEP, PUBLISH_BYTES_PER_ENV_STEP)
         bytes_per_launch = (aba_bytes * nsub + pub_bytes) * N
-        traffic, traffic_src = None, None  # HBM bytes per launch from the PMC passes (profiles/collect_pmc.sh), not measurable live
+        traffic, traffic_src = None, None  # HBM bytes per launch of the stepper from the PMC counters
+        if world == 1 and not args.no_pmc and not os.environ.get("PHC_BENCH_CHILD"):
+            tail = ["--envs", str(args.envs), "--robot", args.robot, "--lane-mapping", str(args.lane_mapping), "--actions", args.actions,
+                    "--motion-clips", str(args.motion_clips), "--self-collision", str(args.self_collision)]
+            traffic, detail = live_pmc_traffic(tail, ("k_sim_quad", "k_sim_step16", "k_sim_step<true"))
+            traffic_src = {"live": detail} if traffic is not None else None
+            if traffic is None:
+                print(f"[bench] live PMC traffic unavailable ({detail}); falling back to the committed profile", file=sys.stderr)
         pmc = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json"))
-        if pmc and N == 4096 and args.robot == "smpl":
+        if traffic is None and pmc and N == 4096 and args.robot == "smpl":
             tab = json.load(open(os.path.join(ROOT, "profiles", pmc[-1])))
             rec = next((v for k, v in tab.items() if k.startswith("k_sim_step16")), None) or next((v for k, v in tab.items() if k.startswith("k_sim_step<true")), None)
             if rec:
@@ -307,6 +374,9 @@ def main():
             out.update(ppo)
         if world == 1 and not args.no_cpu_baseline and args.robot == "smpl":
             out["cpu_baseline"] = cpu_baseline()
+            ref = cpu_reference()
+            if ref is not None:
+                out["cpu_reference"] = ref
         out["actions"] = args.actions
         out["envs_within_5_steps_of_a_reset"] = resets
         print(json.dumps(out))

@@ -2,7 +2,8 @@
 beside it"): the unmodified reference functions imported through ``oracle/ref_shim.py``, on the host cores of the machine
 this runs on.  /root/reference does not exist on the GPU box, so this runs in the build container only:
 
-    python oracle/time_reference.py            # -> profiles/r01_reference_cpu_stages.json
+    python oracle/time_reference.py [rNN]      # -> profiles/rNN_reference_cpu_stages.json (default r02); bench.py ships the newest
+                                               #    of these files as the `cpu_reference` object of its JSON line
 
 Stages (5 warm-up + 50 timed iterations, median), at N = 64 and N = 4096 on the synthetic AMASS-shaped clips:
   (1) MotionLibSMPL.load_motions (poselib FK + finite differences; start-up cost, timed once for 64 clips)
@@ -120,7 +121,10 @@ def main():
         a, b, c = median_ms(s2), median_ms(s3), median_ms(s4)
         out["stages"][str(N)] = {"get_motion_state_x2_ms": a, "reward_reset_ms": b, "observations_ms": c, "sum_ms": a + b + c,
                                  "env_steps_per_s_reward_obs_only": N / ((a + b + c) * 1e-3)}
-    dst = os.path.join(ROOT, "profiles", "r01_reference_cpu_stages.json")
+    out["protocol"] = "BASELINE.md section 2: 5 warm-up + 50 timed iterations, median; torch.set_num_threads(all usable cores); fp32"
+    out["measured_in"] = "build container (the reference is a Python checkout under /root/reference and cannot travel to the GPU box)"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+    dst = os.path.join(ROOT, "profiles", f"{tag}_reference_cpu_stages.json")
     json.dump(out, open(dst, "w"), indent=1)
     print(json.dumps(out, indent=1))
 
