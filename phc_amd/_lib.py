@@ -12,7 +12,8 @@ import os
 import torch  # noqa: F401
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libphc_amd.so")
+# PHC_AMD_LIB: load another build of the SAME library (scripts/sim_phase_profile.py: the instrumented stepper); never a fallback
+LIB_PATH = os.environ.get("PHC_AMD_LIB") or os.path.join(HERE, "libphc_amd.so")
 
 c_f = C.c_float
 c_i32 = C.c_int32

@@ -84,6 +84,9 @@ static inline uint64_t splitmix64(uint64_t z) {
     return z ^ (z >> 31);
 }
 
+// Measured alternative (round 2, profiles/r02_notes.md): ONE workgroup per listed env with its S history-frame groups side by side
+// (blockDim = G * S), so that the S lookups of an env -- S + 1 consecutive clip frames -- share a CU's L1: 46.6 us vs 34 us for this
+// geometry (the ten groups of an env then hit one clip region, i.e. the same HBM channels, at the same instant).  Not kept.
 template <int DPJ, bool RNG, int G>
 __global__ __launch_bounds__(256) void k_im_reset(phc_model_t model, phc_motion_lib_t lib, phc_im_params_t prm, phc_sim_state_t sim,
                                                  phc_im_buffers_t buf, int num_reset, const int64_t* __restrict__ env_ids,

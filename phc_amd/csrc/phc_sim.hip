@@ -13,6 +13,24 @@
 
 using namespace phc;
 
+// Phase profile of the two-slot stepper (scripts/sim_phase_profile.py builds a SEPARATE library with -DPHC_SIM_PROFILE; the product
+// library never contains this): per-wavefront s_memtime deltas accumulated per phase, summed over wavefronts into a device array.
+#ifdef PHC_SIM_PROFILE
+__device__ unsigned long long g_phc_prof[16];
+extern "C" int32_t phc_debug_profile(unsigned long long* out16, int32_t reset) {
+    if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_phc_prof), sizeof(g_phc_prof)) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_phc_prof), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#define PHC_PROF_DECL unsigned long long prof_acc[10] = {0}; unsigned long long prof_t = __builtin_readcyclecounter();
+#define PHC_PROF(i) { const unsigned long long t_ = __builtin_readcyclecounter(); prof_acc[i] += t_ - prof_t; prof_t = t_; }
+#define PHC_PROF_FLUSH if (threadIdx.x == 0) { for (int i_ = 0; i_ < 10; ++i_) atomicAdd(&g_phc_prof[i_], prof_acc[i_]); atomicAdd(&g_phc_prof[15], 1ull); }
+#else
+#define PHC_PROF_DECL
+#define PHC_PROF(i)
+#define PHC_PROF_FLUSH
+#endif
+
 // ------------------------------------------------------------------------------------------
 // S10: the stepper.  One lane per body, GRP = 32 lanes per env (articulations of up to 32 bodies: two envs per wavefront) or
 // GRP = 64 (up to 64 bodies -- Unitree G1 has 38: one env per wavefront), blockDim = 64: ONE wavefront per workgroup, so
@@ -114,6 +132,7 @@ __global__ __launch_bounds__(64, 1) void k_sim_step16(phc_model_t model, phc_sim
 
     AbaLane LA, LB;
     LA.level = LB.level = -1;
+    PHC_PROF_DECL
     auto load = [&](AbaLane& L, int j) {
         aba_load_model(L, model, j);
         if (JT == PHC_JT_REVOLUTE) aba_load_model_rev(L, model, j);
@@ -138,6 +157,7 @@ __global__ __launch_bounds__(64, 1) void k_sim_step16(phc_model_t model, phc_sim
     const int nsub = num_sim_calls * prm.substeps;
     PairList<(GRP == 32 ? PHC_SC_MAX_PER_LANE_WIDE : PHC_SC_MAX_PER_LANE)> pairs;
     if (prm.self_collision) aba_load_pairs(pairs, model, lane, GRP);
+    PHC_PROF(0)
     for (int s = 0; s < nsub; ++s) {
         const bool fresh = s % prm.substeps == 0;
         if (prm.self_collision) {   // body-body contact from the kinematics the last sweep left in the exchange slots
@@ -150,17 +170,26 @@ __global__ __launch_bounds__(64, 1) void k_sim_step16(phc_model_t model, phc_sim
             if (jA >= 0) aba_collect_self(LA, jA, caps);
             if (jB >= 0) aba_collect_self(LB, jB, caps);
         }
+        PHC_PROF(1)
         // slot A's articulated quantities are initialised only when the sweep reaches its levels: while the deep (slot B) levels
         // run, slot A holds kinematic state only (27 fewer live registers)
         if (jB >= 0) aba_body_init<JT>(LB, model, prm, dt, jB, fresh);
+        PHC_PROF(2)
         for (int l = max_level; l >= split; --l) { aba_backward_level<JT>(LB, l, jB, x); __syncthreads(); }
+        PHC_PROF(3)
         if (jA >= 0) aba_body_init<JT>(LA, model, prm, dt, jA, fresh);
+        PHC_PROF(4)
         for (int l = split - 1; l >= 0; --l) { aba_backward_level<JT>(LA, l, jA, x); __syncthreads(); }
+        PHC_PROF(5)
         for (int l = 0; l < split; ++l) { aba_forward_level<JT>(LA, l, jA, x, prm, dt); __syncthreads(); }
+        PHC_PROF(6)
         for (int l = split; l <= max_level; ++l) { aba_forward_level<JT>(LB, l, jB, x, prm, dt); __syncthreads(); }
+        PHC_PROF(7)
     }
     if (jA >= 0) { aba_store_state<JT>(LA, sim, nd, env, jA); aba_publish_body(LA, sim, nb, env, jA, true); }
     if (jB >= 0) { aba_store_state<JT>(LB, sim, nd, env, jB); aba_publish_body(LB, sim, nb, env, jB, true); }
+    PHC_PROF(8)
+    PHC_PROF_FLUSH
 }
 
 template <bool STEP, int JT>

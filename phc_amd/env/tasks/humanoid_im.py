@@ -483,6 +483,10 @@ class HumanoidIm:
             # "stand[:seconds]" -- the rest pose standing still (a physically feasible clip for end-to-end sanity runs)
             from ...utils.synthetic_motion import make_stand_clip
             mf = {"stand_00000": make_stand_clip(self.model, float(mf.split(":")[1]) if ":" in mf else 10.0)}
+        if isinstance(mf, str) and mf.startswith("armswing") and not self._is_robot:
+            # "armswing[:seconds]" -- standing with swinging arms (the second feasible sanity clip)
+            from ...utils.synthetic_motion import make_armswing_clip
+            mf = {"armswing_00000": make_armswing_clip(self.model, float(mf.split(":")[1]) if ":" in mf else 10.0)}
         if isinstance(mf, str) and mf.startswith("synthetic"):
             # "synthetic[:num_clips[:seed[:mean_seconds]]]" -- AMASS-shaped smooth random clips
             parts = mf.split(":")

@@ -149,3 +149,39 @@ def make_stand_clip(model, seconds=10.0, fps=30):
     trans[:, 2] = -lowest + 0.002
     return {"pose_quat_global": q, "pose_quat": q.copy(), "root_trans_offset": trans, "trans_orig": trans.copy(),
             "pose_aa": np.zeros((T, J * 3)), "beta": np.zeros(10), "gender": "neutral", "fps": fps}
+
+
+def make_armswing_clip(model, seconds=10.0, fps=30, swing=0.6, freq=0.4):
+    """A second physically feasible sanity clip: standing on the spot while both arms swing horizontally (shoulder yaw +-`swing` rad
+    at `freq` Hz, in antiphase), elbows flexing with them, the torso counter-twisting slightly.  Built from joint rotations through
+    the model's own tree (FK of the local rotations), soles on the ground as in `make_stand_clip`."""
+    T, J = int(round(seconds * fps)) + 1, model.num_bodies
+    names = list(model.body_names)
+    t = np.arange(T) / fps
+    ph = 2 * np.pi * freq * t
+    ramp = np.clip(t / 1.0, 0.0, 1.0)               # start from the rest pose (the reset imposes the clip's first frame)
+    e = np.zeros((T, J, 3))
+    for side, sgn in (("L", 1.0), ("R", -1.0)):
+        e[:, names.index(f"{side}_Shoulder"), 2] = sgn * swing * np.sin(ph) * ramp           # yaw: arm forward / backward
+        e[:, names.index(f"{side}_Shoulder"), 0] = -sgn * 0.35 * ramp                        # lowered a little from the T pose
+        e[:, names.index(f"{side}_Elbow"), 2] = sgn * 0.4 * (0.5 + 0.5 * np.sin(ph)) * ramp  # elbows flex on the forward swing
+    e[:, names.index("Torso"), 2] = -0.08 * np.sin(ph) * ramp
+    e[:, names.index("Spine"), 2] = -0.06 * np.sin(ph) * ramp
+    q_local = _exp_map_to_quat(e)
+    q_global = np.zeros_like(q_local)
+    for j in range(J):
+        p = model.parent[j]
+        q_global[:, j] = q_local[:, j] if p < 0 else _quat_mul(q_global[:, p], q_local[:, j])
+    q_global /= np.linalg.norm(q_global, axis=-1, keepdims=True)
+    origin = np.zeros((J, 3))
+    for j in range(1, J):
+        origin[j] = origin[model.parent[j]] + model.local_translation[j]
+    lowest = (origin[model.contact_body, 2] + model.contact_pos[:, 2] - model.contact_radius).min()
+    trans = np.zeros((T, 3))
+    trans[:, 2] = -lowest + 0.002
+    w = np.clip(q_local[..., 3], -1, 1)
+    ang = 2 * np.arccos(np.abs(w))
+    s_ = np.sqrt(np.maximum(1 - w * w, 1e-16))
+    aa = q_local[..., :3] / s_[..., None] * (ang * np.sign(w + 1e-30))[..., None]
+    return {"pose_quat_global": q_global, "pose_quat": q_local, "root_trans_offset": trans, "trans_orig": trans.copy(),
+            "pose_aa": aa.reshape(T, J * 3), "beta": np.zeros(10), "gender": "neutral", "fps": fps}
