@@ -31,6 +31,60 @@ extern "C" int32_t phc_debug_profile(unsigned long long* out16, int32_t reset) {
 #define PHC_PROF_FLUSH
 #endif
 
+
+// ------------------------------------------------------------------------------------------
+// Staged epilogue (round 2).  The phase profile of the two-slot kernel (scripts/sim_phase_profile.py, profiles/r02_notes.md) put
+// 20 % of a wavefront's cycles into "store + publish": ~50 scattered 4-byte global stores per lane, issued by all 1024 wavefronts
+// at the same instant.  The output slices of the E consecutive envs of ONE wavefront are contiguous and 16-byte aligned in every
+// simulator tensor (E * 13, E * NB * 13, E * ND * 2, ... floats), so the lanes first write their values into the (now idle) LDS
+// exchange area in exactly that layout and the wavefront then streams each slice out with coalesced dwordx4 / dwordx2 stores.
+// ------------------------------------------------------------------------------------------
+struct StageLayout { int root, dof, force, contact, rbs, total; };
+__device__ __forceinline__ StageLayout stage_layout(int E, int nb, int nd, bool with_force, bool with_contact) {
+    StageLayout o;
+    o.root = 0;
+    o.dof = o.root + ((E * 13 + 3) & ~3);
+    o.force = o.dof + ((E * nd * 2 + 3) & ~3);
+    o.contact = o.force + (with_force ? ((E * nd + 3) & ~3) : 0);
+    o.rbs = o.contact + (with_contact ? ((E * nb * 3 + 3) & ~3) : 0);
+    o.total = o.rbs + ((E * nb * 13 + 3) & ~3);
+    return o;
+}
+// a phc_sim_state_t whose tensors are the staging slices, indexed by the env's position in the wavefront
+__device__ __forceinline__ phc_sim_state_t stage_state(const phc_sim_state_t& sim, float* stage, const StageLayout& o) {
+    phc_sim_state_t st = sim;
+    st.root_states = stage + o.root;
+    st.dof_state = stage + o.dof;
+    st.dof_force = sim.dof_force ? stage + o.force : nullptr;
+    st.contact_force = sim.contact_force ? stage + o.contact : nullptr;
+    st.rigid_body_state = stage + o.rbs;
+    return st;
+}
+template <int W>
+__device__ __forceinline__ void stage_copy_out(float* __restrict__ dst, const float* __restrict__ src, int n, int tid, int nthreads) {
+    if (W == 4) {
+        for (int i = tid; i < n / 4; i += nthreads) reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(src)[i];
+    } else {
+        for (int i = tid; i < n / 2; i += nthreads) reinterpret_cast<float2*>(dst)[i] = reinterpret_cast<const float2*>(src)[i];
+    }
+}
+// all lanes of the wavefront: stream the staged slices of envs [env0, env0 + E) to the simulator tensors
+template <int E>
+__device__ __forceinline__ void stage_flush(const phc_sim_state_t& sim, const float* stage, const StageLayout& o, int64_t env0, int nb, int nd) {
+    constexpr int W = (E % 4 == 0) ? 4 : 2;
+    const int tid = threadIdx.x;
+    stage_copy_out<W>(sim.root_states + env0 * 13, stage + o.root, E * 13, tid, 64);
+    stage_copy_out<W>(sim.dof_state + env0 * nd * 2, stage + o.dof, E * nd * 2, tid, 64);
+    if (sim.dof_force) stage_copy_out<W>(sim.dof_force + env0 * nd, stage + o.force, E * nd, tid, 64);
+    if (sim.contact_force) stage_copy_out<W>(sim.contact_force + env0 * nb * 3, stage + o.contact, E * nb * 3, tid, 64);
+    stage_copy_out<W>(sim.rigid_body_state + env0 * nb * 13, stage + o.rbs, E * nb * 13, tid, 64);
+}
+__device__ __forceinline__ bool stage_aligned(const phc_sim_state_t& sim) {
+    const uintptr_t a = (uintptr_t)sim.root_states | (uintptr_t)sim.dof_state | (uintptr_t)sim.rigid_body_state |
+                        (uintptr_t)sim.dof_force | (uintptr_t)sim.contact_force;
+    return (a & 15) == 0;
+}
+
 // ------------------------------------------------------------------------------------------
 // S10: the stepper.  One lane per body, GRP = 32 lanes per env (articulations of up to 32 bodies: two envs per wavefront) or
 // GRP = 64 (up to 64 bodies -- Unitree G1 has 38: one env per wavefront), blockDim = 64: ONE wavefront per workgroup, so
@@ -96,7 +150,18 @@ __global__ __launch_bounds__(64, 2) void k_sim_step(phc_model_t model, phc_sim_p
         }
     }
     // S7: the last forward sweep already produced the end-of-step kinematics
-    if (active) {
+    constexpr int E = 64 / GRP;
+    const int64_t env0 = (int64_t)blockIdx.x * E;
+    const StageLayout so = stage_layout(E, nb, nd, sim.dof_force != nullptr, sim.contact_force != nullptr);
+    if (STEP && E >= 2 && env0 + E <= sim.num_envs && stage_aligned(sim) && so.total <= 64 * PHC_XCH_STRIDE) {   // staged epilogue, see above
+        const phc_sim_state_t st = stage_state(sim, xch_all, so);
+        if (active) {
+            aba_store_state<JT>(L, st, nd, grp, lane);
+            aba_publish_body(L, st, nb, grp, lane, true);
+        }
+        __syncthreads();
+        stage_flush<E>(sim, xch_all, so, env0, nb, nd);
+    } else if (active) {
         if (STEP) aba_store_state<JT>(L, sim, nd, env, lane);
         aba_publish_body(L, sim, nb, env, lane, STEP);
     }
@@ -186,8 +251,20 @@ __global__ __launch_bounds__(64, 1) void k_sim_step16(phc_model_t model, phc_sim
         for (int l = split; l <= max_level; ++l) { aba_forward_level<JT>(LB, l, jB, x, prm, dt); __syncthreads(); }
         PHC_PROF(7)
     }
-    if (jA >= 0) { aba_store_state<JT>(LA, sim, nd, env, jA); aba_publish_body(LA, sim, nb, env, jA, true); }
-    if (jB >= 0) { aba_store_state<JT>(LB, sim, nd, env, jB); aba_publish_body(LB, sim, nb, env, jB, true); }
+    constexpr int E = 64 / GRP;                       // envs per wavefront
+    const int64_t env0 = (int64_t)blockIdx.x * E;
+    const StageLayout so = stage_layout(E, nb, nd, sim.dof_force != nullptr, sim.contact_force != nullptr);
+    if (env0 + E <= sim.num_envs && stage_aligned(sim) && so.total <= 128 * PHC_XCH_STRIDE) {   // wave-uniform
+        float* stage = xch_all;                           // the exchange slots are dead after the last forward level-step
+        const phc_sim_state_t st = stage_state(sim, stage, so);
+        if (jA >= 0) { aba_store_state<JT>(LA, st, nd, grp, jA); aba_publish_body(LA, st, nb, grp, jA, true); }
+        if (jB >= 0) { aba_store_state<JT>(LB, st, nd, grp, jB); aba_publish_body(LB, st, nb, grp, jB, true); }
+        __syncthreads();
+        stage_flush<E>(sim, stage, so, env0, nb, nd);
+    } else {
+        if (jA >= 0) { aba_store_state<JT>(LA, sim, nd, env, jA); aba_publish_body(LA, sim, nb, env, jA, true); }
+        if (jB >= 0) { aba_store_state<JT>(LB, sim, nd, env, jB); aba_publish_body(LB, sim, nb, env, jB, true); }
+    }
     PHC_PROF(8)
     PHC_PROF_FLUSH
 }
