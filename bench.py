@@ -277,10 +277,23 @@ def main():
         graph_over.append("+learning.params.config.force_collectives=True")
     cfg = compose(robot_over + graph_over + [f"env.num_envs={args.envs}", f"env.motion_file=synthetic:{args.motion_clips}:0", f"device_id={local_rank}",
                                 f"rl_device=cuda:{local_rank}", f"+solver.lane_mapping={args.lane_mapping}"] + ([f"+solver.self_collision={args.self_collision}"] if args.self_collision >= 0 else []))
+    t_build = time.perf_counter()
     task, env = parse_task(cfg, device_id=local_rank)
+    t_build = time.perf_counter() - t_build
     dev = task.device
     N = task.num_envs
     env.reset()
+    cfg3 = None
+    if args.config == 3:   # configs[2]: time what the reference does every 500 epochs (amp_agent.py:511-515): re-sample one clip per env
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        task.resample_motions()
+        torch.cuda.synchronize()
+        lib_ = task._motion_lib
+        cfg3 = {"library_clips": int(lib_._num_unique_motions), "distinct_clips_sampled": int(torch.unique(lib_._curr_motion_ids).numel()),
+                "task_build_s_incl_synthetic_library_and_first_load": t_build, "resample_motions_s": time.perf_counter() - t0,
+                "motion_frames": int(lib_.frames.shape[0]), "motion_bytes_on_device": int(lib_.frames.numel() * 4),
+                "host_workers": int(lib_.m_cfg.get("num_workers", 0)) or min(32, max(1, (os.cpu_count() or 1) // 2))}
     actions = (torch.rand(N, task.num_actions, device=dev) * 2 - 1) * 0.1  # fixed a ~ U(-1,1)*0.1
 
     inv_scale = 1.0 / task._pd_action_scale
@@ -356,7 +369,8 @@ def main():
             "value": N * world * args.steps / elapsed, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic (AMASS-shaped smooth random clip, seed 0; random-init state from the reference motion)",
-            "config": {"workload": ("BASELINE configs[1]: SMPL humanoid 69-DoF, 4096 envs per GPU, single reference motion, "
+            "config": {"workload": (("BASELINE configs[1]: SMPL humanoid 69-DoF, 4096 envs per GPU, single reference motion, " if args.config != 3 else
+                                     f"BASELINE configs[2] shape: SMPL humanoid, {N} envs, AMASS-sized synthetic library of {args.motion_clips} clips, ") +
                                     "30 Hz control = 2 x simulate @60 Hz x 2 sub-steps") if args.robot == "smpl" else
                                    (("BASELINE configs[4]: Unitree H1 19-DoF" if args.robot == "h1" else "env_im_g1_phc: Unitree G1 37-DoF, 38 bodies") +
                                     ", envs per GPU as given, synthetic retargeted-shape clips, 50 Hz control = 4 x simulate @200 Hz x 2 sub-steps, pd torque mode"),
@@ -377,6 +391,8 @@ def main():
             ref = cpu_reference()
             if ref is not None:
                 out["cpu_reference"] = ref
+        if cfg3 is not None:
+            out["config3_motion_library"] = cfg3
         out["actions"] = args.actions
         out["envs_within_5_steps_of_a_reset"] = resets
         print(json.dumps(out))

@@ -328,11 +328,13 @@ int32_t phc_sim_step(const phc_model_t* model, const phc_sim_params_t* params, c
     // pair capacity of the two mappings (pairs are dealt round-robin to the lanes of an env's group)
     const int cap_one = PHC_SC_MAX_PER_LANE * (wide ? 64 : 32), cap_two = wide ? PHC_SC_MAX_PER_LANE_WIDE * 32 : PHC_SC_MAX_PER_LANE * 16;
     if (params->self_collision && model->num_collision_pairs > cap_one) return PHC_EUNSUPPORTED;
-    // lane_mapping 1 / 2 force a kernel; 0 picks.  Measured on MI355X at N = 4096 (scripts/gpu_map.sh): SMPL (tree depth 8, 2.8 contact
-    // points per body) 106 us one-body-per-lane vs 89 us two-slot; H1 (depth 5, 12.8 contact points per body, 8 sub-steps) 104 vs
-    // 126 us -- the two-slot kernel runs the per-body initialisation (inertia rotation, contacts, drive) twice per sub-step, which
-    // only pays off when the level sweeps dominate, and it needs ~320 registers per lane (one wavefront per SIMD), so it only wins
-    // while its N/4 wavefronts fit the chip in one round (N <= 4 x #SIMDs = 4096 on MI355X; profiles/r01_env_count_sweep.json).
+    // lane_mapping 1 / 2 force a kernel; 0 picks.  Measured on MI355X at N = 4096 (scripts/sim_substep_scan.py, round 2, same box, 4 sub-steps):
+    //   SMPL, body-body contact ON  (the shipped configuration): one body per lane 97.0 us (2 wavefronts / SIMD, VALU-issue bound at
+    //         4.1 cycles per VALU instruction), two-slot 100.9 us (1 wavefront / SIMD, latency bound at 6.7) -> one body per lane;
+    //   SMPL, body-body contact OFF: two-slot 84 us vs 92 us (round 1) -> two-slot while its N/4 wavefronts fit the chip in one round
+    //         (N <= 4 x #SIMDs = 4096; profiles/r01_env_count_sweep.json);
+    //   H1 (depth 5, 12.8 contact points per body, 8 sub-steps): 104 vs 126 us -> one body per lane (the two-slot kernel runs the
+    //         per-body initialisation twice per sub-step, which only pays off when the level sweeps dominate).
     static int num_simds = 0;
     if (num_simds == 0) {
         int dev = 0, cus = 256;
@@ -344,6 +346,7 @@ int32_t phc_sim_step(const phc_model_t* model, const phc_sim_params_t* params, c
                            !(params->self_collision && model->num_collision_pairs > cap_two);
     // wide articulations (G1, N = 4096, scripts/gpu_g1.sh): 434 us one body per lane vs 515 us two-slot -> never picked automatically
     const bool two_slot = can_split && (params->lane_mapping == 2 || (params->lane_mapping == 0 && !wide && model->max_level >= 7 &&
+                                                                      !params->self_collision &&
                                                                       (int64_t)sim->num_envs <= 4 * (int64_t)num_simds));
     sim_launch<true>(model, *params, sim, actions, pd_action_offset, pd_action_scale, freeze_mask, num_sim_calls, (hipStream_t)stream, nullptr, 0,
                      two_slot);

@@ -202,6 +202,16 @@ def process_clip_real(parents, local_translation, local_rotation_wxyz, ext_paren
                 gts_t=wpos, grs_t=wrot, gvs_t=vel(wpos), gavs_t=_angular_velocity(wrot, dt), dof_pos=dof_pos, dvs=dvs, lrs=pq)
 
 
+_JOB_CTX = None   # (library, tree, max_len) of the load_motions call in flight: forked workers inherit it (nothing big is pickled)
+
+
+def _process_job(job):
+    """One distinct clip (worker of the fork pool in load_motions; numpy only -- the forked children never touch the device)."""
+    u, start = job
+    lib, tree, max_len = _JOB_CTX
+    return lib._process_unique_clip(lib._motion_data_list[u], tree, max_len, start)
+
+
 class MotionLibBase:
     """See module docstring.  Mirrors reference MotionLibBase (motion_lib_base.py:114-567)."""
 
@@ -273,20 +283,49 @@ class MotionLibBase:
             if getattr(self, "_heading_rs", None) is None:
                 self._heading_rs = np.random.RandomState((int(torch.initial_seed()) + 7919 * int(self.m_cfg.get("rank", 0))) % (2 ** 32))
             rs = self._heading_rs
-        aa_list, nfs, fpss = [], [], []
-        for i, u in enumerate(idx_np):
-            clip = self._motion_data_list[u]
-            if u not in cache:
-                cache[u] = self._process_unique_clip(clip, tree, max_len, rs)
-            proc, fps, nf = cache[u]
-            proc = self._per_env_variant(proc, rs)
-            per.append(proc)
-            nfs.append(nf)
-            fpss.append(fps)
-            aa_list.append(self._clip_pose_aa(clip, nf))
+        # pass 1 -- every random draw, in the reference's order (per env: the crop of a not-yet-seen clip, then the heading), so that
+        # the stream does not depend on how the work below is scheduled
+        uniq, crop, yaws = [], {}, []
+        for u in idx_np:
+            u = int(u)
+            if u not in crop:
+                crop[u] = self._draw_crop(self._motion_data_list[u], max_len, rs)
+                uniq.append(u)
+            yaws.append(self._draw_heading(rs))
+        # pass 2 -- FK + velocities ONCE per distinct clip (fp64 on the host cores; a fork pool when there are many: cfg 3 samples
+        # ~5 800 distinct clips of the 11 313 for 8 192 envs, 17 ms each)
+        global _JOB_CTX
+        _JOB_CTX = (self, tree, max_len)
+        jobs = [(u, crop[u]) for u in uniq]
+        workers = int(self.m_cfg.get("num_workers", 0)) or min(32, max(1, (os.cpu_count() or 1) // 2))
+        if len(jobs) >= 256 and workers > 1:
+            import multiprocessing as mp
+            with mp.get_context("fork").Pool(workers) as pool:
+                done = pool.map(_process_job, jobs, chunksize=max(1, len(jobs) // (workers * 8)))
+        else:
+            done = [_process_job(j) for j in jobs]
+        _JOB_CTX = None
+        slot = {u: k for k, u in enumerate(uniq)}
+        # pass 3 -- one packed fp32 record array per DISTINCT clip goes to the device once; the per-env copies (the reference keeps one
+        # clip copy per env, motion_lib_base.py:300-307) are a device-side gather, and the per-env heading a device-side rotation
         dev = self._device
         self.num_bodies = self.num_joints
-        self._pack(per, dev)
+        packed = [self._pack_one(proc) for proc, _, _ in done]
+        u_nf = np.array([p.shape[0] for p in packed], dtype=np.int64)
+        u_start = np.concatenate([[0], np.cumsum(u_nf)[:-1]])
+        uniq_frames = torch.from_numpy(np.concatenate(packed, axis=0)).to(dev)
+        e_slot = np.array([slot[int(u)] for u in idx_np], dtype=np.int64)
+        nfs = [int(u_nf[k]) for k in e_slot]
+        fpss = [done[k][1] for k in e_slot]
+        src = torch.from_numpy(np.concatenate([np.arange(u_nf[k], dtype=np.int64) + u_start[k] for k in e_slot])).to(dev)
+        self.frames = uniq_frames.index_select(0, src)
+        del uniq_frames, src
+        if yaws[0] is not None:
+            yaw_f = torch.repeat_interleave(torch.tensor(yaws, dtype=torch.float32, device=dev), torch.tensor(nfs, device=dev))
+            self._apply_heading_device(yaw_f)
+        self._make_views()
+        aa_list = [self._clip_pose_aa(self._motion_data_list[int(u)], nf, crop[int(u)]) for u, nf in zip(idx_np, nfs)]
+        per = None
         self.grvs, self.gravs = self.gvs[:, 0], self.gavs[:, 0]
         self._motion_aa = torch.from_numpy(np.concatenate(aa_list)).to(dev)
         nf_t = torch.tensor(nfs, dtype=torch.int64)
@@ -312,31 +351,38 @@ class MotionLibBase:
     num_ext_bodies = 0
     dofs_per_joint = 3
 
-    def _process_unique_clip(self, clip, tree, max_len, rs):
+    def _draw_crop(self, clip, max_len, rs):
+        """Random crop start of a clip longer than max_len (motion_lib_smpl.py:124-128), or None."""
+        T = np.asarray(clip["pose_quat_global"]).shape[0]
+        return int(rs.randint(0, T - max_len + 1)) if (max_len != -1 and T > max_len) else None
+
+    def _draw_heading(self, rs):
+        """Random heading about +z per env (motion_lib_smpl.py:137-146), or None when headings are off."""
+        randomize = (not flags.im_eval) and (not flags.test) and self.m_cfg.get("randomrize_heading", True)
+        return float(np.pi * (2 * rs.random_sample() - 1.0)) if randomize else None
+
+    def _process_unique_clip(self, clip, tree, max_len, start):
         """motion_lib_smpl.py:101-180 up to (not including) the per-env heading."""
         trans = clip["root_trans_offset"]
         trans = trans.numpy() if isinstance(trans, torch.Tensor) else np.asarray(trans)
         g = np.asarray(clip["pose_quat_global"])
-        if max_len != -1 and g.shape[0] > max_len:
-            start = rs.randint(0, g.shape[0] - max_len + 1)
+        if start is not None:
             g, trans = g[start:start + max_len], trans[start:start + max_len]
         proc = process_clip(np.asarray(tree.parent_indices), np.asarray(tree.local_translation), g, trans, clip.get("fps", 30))
         return proc, clip.get("fps", 30), g.shape[0]
 
-    def _per_env_variant(self, proc, rs):
-        randomize = (not flags.im_eval) and (not flags.test) and self.m_cfg.get("randomrize_heading", True)
-        return apply_heading(proc, np.pi * (2 * rs.random_sample() - 1.0)) if randomize else proc
-
-    def _clip_pose_aa(self, clip, nf):
+    def _clip_pose_aa(self, clip, nf, start=None):
         if "pose_aa" in clip:
-            return np.asarray(clip["pose_aa"], dtype=np.float32).reshape(-1, self.num_joints * 3)[:nf]
+            aa = np.asarray(clip["pose_aa"], dtype=np.float32).reshape(-1, self.num_joints * 3)
+            return aa[:nf] if start is None else aa[start:start + nf]
         return np.zeros((nf, self.num_joints * 3), dtype=np.float32)
 
-    def _pack(self, per, dev):
+    def _pack_one(self, proc):
+        f = {k: proc[k].astype(np.float32) for k in ("gts", "grs", "gvs", "gavs", "lrs", "dvs")}
+        return abi.pack_frames(f["gts"], f["grs"], f["gvs"], f["gavs"], f["lrs"], f["dvs"])
+
+    def _make_views(self):
         nb = self.num_bodies
-        fields = {k: np.concatenate([p[k] for p in per], axis=0).astype(np.float32) for k in ("gts", "grs", "gvs", "gavs", "lrs", "dvs")}
-        frames = abi.pack_frames(fields["gts"], fields["grs"], fields["gvs"], fields["gavs"], fields["lrs"], fields["dvs"])
-        self.frames = torch.from_numpy(frames).to(dev)
         F_ = self.frames.shape[0]
         o = 0
         views = {}
@@ -345,6 +391,26 @@ class MotionLibBase:
             o += nb * w
         views["dvs"] = self.frames[:, o:o + (nb - 1) * 3].view(F_, nb - 1, 3)
         self.gts, self.grs, self.gvs, self.gavs, self.lrs, self.dvs = (views[k] for k in ("gts", "grs", "gvs", "gavs", "lrs", "dvs"))
+
+    def _apply_heading_device(self, yaw):
+        """`apply_heading` on the packed per-env records, on the device: yaw [F] (one value per frame).  Positions and velocities are
+        rotated about +z, rotations left-multiplied by the yaw quaternion, the root's local rotation follows its global one
+        (motion_lib_smpl.py:137-146 commutes with FK, np.gradient and the gaussian filter: tests/test_abi_and_host.py heading golden)."""
+        self._make_views()
+        c, s_ = torch.cos(yaw)[:, None], torch.sin(yaw)[:, None]
+        for v in (self.gts, self.gvs, self.gavs):
+            x, y = v[..., 0].clone(), v[..., 1].clone()
+            v[..., 0] = c * x - s_ * y
+            v[..., 1] = s_ * x + c * y
+        hz, hw = torch.sin(0.5 * yaw)[:, None], torch.cos(0.5 * yaw)[:, None]
+        q = self.grs
+        x, y, z, w = (q[..., k].clone() for k in range(4))
+        # (0, 0, hz, hw) * (x, y, z, w)
+        q[..., 0] = hw * x - hz * y
+        q[..., 1] = hw * y + hz * x
+        q[..., 2] = hw * z + hz * w
+        q[..., 3] = hw * w - hz * z
+        self.lrs[:, 0] = self.grs[:, 0]
 
     # ---- small accessors (motion_lib_base.py:328-435) ----
     def num_motions(self):
@@ -525,13 +591,19 @@ class MotionLibReal(MotionLibBase):
         trans[:, 2] -= diff
         return trans, diff
 
-    def _process_unique_clip(self, clip, tree, max_len, rs):
+    def _draw_crop(self, clip, max_len, rs):
+        T = np.asarray(clip["root_trans_offset"]).shape[0]
+        return int(rs.randint(0, T - max_len + 1)) if (max_len != -1 and T >= max_len) else None       # motion_lib_real.py:381-386
+
+    def _draw_heading(self, rs):
+        return None
+
+    def _process_unique_clip(self, clip, tree, max_len, start):
         trans = clip["root_trans_offset"]
         trans = (trans.numpy() if isinstance(trans, torch.Tensor) else np.asarray(trans)).astype(np.float64)
         pose_aa = clip["pose_aa"]
         pose_aa = (pose_aa.numpy() if isinstance(pose_aa, torch.Tensor) else np.asarray(pose_aa)).astype(np.float64)
-        if max_len != -1 and trans.shape[0] >= max_len:       # motion_lib_real.py:381-386
-            start = rs.randint(0, trans.shape[0] - max_len + 1)
+        if start is not None:
             trans, pose_aa = trans[start:start + max_len], pose_aa[start:start + max_len]
         trans, _ = self.fix_trans_height(pose_aa, trans)
         m = self.robot_model
@@ -539,18 +611,17 @@ class MotionLibReal(MotionLibBase):
         proc = process_clip_real(m.parent, m.local_translation, m.local_rotation, self.ext_parent, self.ext_pos, self.ext_rot, pose_aa, trans, fps)
         return proc, int(fps), trans.shape[0]   # fk_batch returns fps = int(1 / dt) (torch_humanoid_batch.py:219)
 
-    def _per_env_variant(self, proc, rs):
-        return proc
-
-    def _clip_pose_aa(self, clip, nf):
+    def _clip_pose_aa(self, clip, nf, start=None):
         return np.zeros((nf, self.num_joints * 3), dtype=np.float32)   # motion_lib_real.py:171-173: no "beta" -> zeros
 
-    def _pack(self, per, dev):
+    def _pack_one(self, proc):
+        nb = self.num_bodies
+        f = {k: proc[k].astype(np.float32) for k in ("gts", "grs", "gvs", "gavs", "dof_pos", "dvs", "gts_t", "grs_t")}
+        return abi.pack_frames(f["gts"], f["grs"], f["gvs"], f["gavs"], None, f["dvs"], gts_ext=f["gts_t"][:, nb:], grs_ext=f["grs_t"][:, nb:],
+                               dof_pos=f["dof_pos"])
+
+    def _make_views(self):
         nb, ne = self.num_bodies, self.num_ext_bodies
-        cat = lambda k: np.concatenate([p[k] for p in per], axis=0).astype(np.float32)
-        gts, grs, gvs, gavs, dof_pos, dvs, gts_t, grs_t = (cat(k) for k in ("gts", "grs", "gvs", "gavs", "dof_pos", "dvs", "gts_t", "grs_t"))
-        frames = abi.pack_frames(gts, grs, gvs, gavs, None, dvs, gts_ext=gts_t[:, nb:], grs_ext=grs_t[:, nb:], dof_pos=dof_pos)
-        self.frames = torch.from_numpy(frames).to(dev)
         F_, nbe = self.frames.shape[0], nb + ne
         self.gts_t = self.frames[:, 0:nbe * 3].view(F_, nbe, 3)
         self.grs_t = self.frames[:, nbe * 3:nbe * 7].view(F_, nbe, 4)
