@@ -277,7 +277,9 @@ def test_two_slot_mapping_equals_one_body_per_lane(name, nd):
             params = abi.sim_params_struct(lane_mapping=mapping, **kw)
             outs.append(run_step(be, model, mstruct, root, dof, target, params, 2))
         for k in ("root", "dof", "rbs", "cf", "df"):
-            np.testing.assert_allclose(outs[0][k], outs[1][k], rtol=1e-4, atol={"cf": 5e-2, "df": 5e-3}.get(k, 3e-4), err_msg=f"{name} n={n} {k}")
+            # contact forces are stiffness x penetration (1e-6 m of rounding noise in the pose is 0.1 N on H1's feet): relative 5e-3
+            np.testing.assert_allclose(outs[0][k], outs[1][k], rtol=5e-3 if k == "cf" else 1e-4, atol={"cf": 5e-2, "df": 5e-3}.get(k, 3e-4),
+                                       err_msg=f"{name} n={n} {k}")
         assert np.isfinite(outs[0]["rbs"]).all()
 
 
