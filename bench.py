@@ -218,6 +218,39 @@ def live_pmc_traffic(argv_tail, kernel_prefixes):
                      "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, --kernel-trace), median per dispatch; gfx950: read = 2 x FETCH_SIZE"}
 
 
+def device_state(dev):
+    """What kind of box is this?  The pool shows two populations (profiles/r01_notes.md, r02_notes.md: memory-bound kernels 1.6 x apart);
+    a 1 GiB device-to-device copy rate and the driver's clock / power readings make a line interpretable without a second run."""
+    import shutil
+    import subprocess
+    p = torch.cuda.get_device_properties(dev)
+    out = {"name": p.name, "compute_units": p.multi_processor_count, "hbm_GiB": round(p.total_memory / 2 ** 30, 1), "hip": torch.version.hip}
+    try:
+        a = torch.empty(2 ** 28, dtype=torch.float32, device=dev)
+        b = torch.empty_like(a)
+        for _ in range(3):
+            b.copy_(a)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            b.copy_(a)
+        e1.record()
+        torch.cuda.synchronize()
+        out["d2d_copy_GBs_read_plus_write"] = 10 * 2 * a.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del a, b
+    except Exception as exc:   # noqa: BLE001
+        out["d2d_copy_error"] = type(exc).__name__
+    smi = shutil.which("rocm-smi")
+    if smi:
+        try:
+            r = subprocess.run([smi, "--showclocks", "--showpower", "--showperflevel", "--json"], capture_output=True, text=True, timeout=20)
+            card = next(iter(json.loads(r.stdout).values()))
+            out["rocm_smi"] = {k: v for k, v in card.items() if any(t in k.lower() for t in ("sclk", "mclk", "fclk", "power", "performance"))}
+        except Exception as exc:   # noqa: BLE001
+            out["rocm_smi_error"] = type(exc).__name__
+    return out
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run, one rank per GPU (RCCL)."""
     import socket
@@ -394,6 +427,8 @@ def main():
         if cfg3 is not None:
             out["config3_motion_library"] = cfg3
         out["actions"] = args.actions
+        if not os.environ.get("PHC_BENCH_CHILD"):
+            out["device"] = device_state(dev)
         out["envs_within_5_steps_of_a_reset"] = resets
         print(json.dumps(out))
     if dist is not None:
