@@ -319,15 +319,74 @@ class IMAmpAgent:
     def env_reset(self, env_ids=None):
         return self.vec_env.reset(env_ids)
 
+    # ---- rollout segments as hipGraphs ----------------------------------------------------------------------------------------------
+    # scripts/profile_rollout.py: the rollout is HOST-bound (32 steps: 16.0 ms of launch / Python time for ~9.6 ms of device work).  With
+    # `hip_graph` the two policy segments of every rollout step -- (A) normalise + actor + critic + sampling into row n of the experience
+    # buffer, (B) the copies of the step's outputs, the next-value critic and the episode bookkeeping -- are captured once per row n (their
+    # inputs are the task's static buffers, their outputs rows of the persistent experience buffer) and replayed; the env itself (reset of
+    # finished envs, stepper, post-physics) keeps its three eager launches, since its host side carries state (RNG counter, reset lists).
+    def _rollout_graphs_enabled(self):
+        return (self.exp["obses"].is_cuda and self._use_graph and not self._graph_failed and self.epoch_num >= 2 and not self.faithful_reset
+                and hasattr(self.task, "reset_done") and not np.isfinite(self.vec_env.clip_obs) and not os.environ.get("PHC_NO_GRAPH")
+                and not os.environ.get("PHC_NO_ROLLOUT_GRAPH"))
+
+    def _replay(self, key, fn):
+        g = self._roll_graphs.get(key)
+        if g is None:
+            in_group = self.dist is not None and self.dist.is_initialized()
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local" if in_group else "global"):
+                fn()
+            self._roll_graphs[key] = g
+        g.replay()
+
     def play_steps(self):
         self.set_eval()
         e = self.exp
         task = self.task
-        terminated_flags = torch.zeros(self.num_actors, device=self.device)
-        reward_raw = None
+        if getattr(self, "_terminated_flags", None) is None:
+            self._terminated_flags = torch.zeros(self.num_actors, device=self.device)
+            self._reward_raw_acc = None
+            self._roll_graphs = {}
+        terminated_flags = self._terminated_flags.zero_()
+        if self._reward_raw_acc is not None:
+            self._reward_raw_acc.zero_()
         done_indices = []
         net = self.model.a2c_network
         fused = e["obses"].is_cuda
+        graphed = fused and self._rollout_graphs_enabled()
+        vnorm = self.value_mean_std if self.normalize_value else None
+
+        def seg_policy(n):
+            """(A) observation row, policy + value heads, sampling -> row n of the experience buffer."""
+            if self.obs.data_ptr() != e["obses"][n].data_ptr():
+                e["obses"][n].copy_(self.obs)
+            processed = self._preproc_obs(self.obs)
+            with self._autocast():
+                mu, logstd = net.eval_actor(processed)
+                value = net.eval_critic(processed)
+            policy_sample(mu.contiguous(), value.contiguous(), (logstd[0] if logstd.dim() == 2 else logstd).float().contiguous(), vnorm,
+                          e["actions"][n], e["mus"][n], e["sigmas"][n], e["neglogpacs"][n], e["values"][n])
+
+        def seg_after(n, rewards, terminate, reward_raw):
+            """(B) the step's outputs into row n, next-value critic (zeroed where the episode terminated), episode bookkeeping."""
+            e["rewards"][n].copy_(rewards if self.reward_scale == 1 else rewards * self.reward_scale)
+            e["next_obses"][n].copy_(self.obs)
+            e["dones"][n].copy_(self.dones)
+            terminated = terminate.float()
+            terminated_flags.add_(terminated)
+            rr = reward_raw.mean(dim=0)
+            if self._reward_raw_acc is None:
+                self._reward_raw_acc = torch.zeros_like(rr)
+            self._reward_raw_acc.add_(rr)
+            with self._autocast():
+                value = net.eval_critic(self._preproc_obs(self.obs))
+            policy_sample(None, value.contiguous(), None, vnorm, None, None, None, None, e["next_values"][n], mask=terminated)
+            not_dones = 1.0 - self.dones.float()
+            self.current_rewards.add_(rewards).mul_(not_dones.unsqueeze(1))
+            self.current_lengths.add_(1).mul_(not_dones)
+
         for n in range(self.horizon_length):
             if self.faithful_reset or not hasattr(task, "reset_done"):
                 self.obs = self.env_reset(done_indices)
@@ -337,49 +396,49 @@ class IMAmpAgent:
                     self.obs = torch.clamp(task.obs_buf, -self.vec_env.clip_obs, self.vec_env.clip_obs, out=e["obses"][n])
                 else:
                     self.obs = task.obs_buf
-            if self.obs.data_ptr() != e["obses"][n].data_ptr():
-                e["obses"][n].copy_(self.obs)
             if fused:
-                # heads as the GEMMs produce them; sampling, neglogp, sigma and the value un-normalisation in one kernel that
-                # writes the rows of the experience buffer
-                processed = self._preproc_obs(self.obs)
-                with self._autocast():
-                    mu, logstd = net.eval_actor(processed)
-                    value = net.eval_critic(processed)
-                policy_sample(mu.contiguous(), value.contiguous(), (logstd[0] if logstd.dim() == 2 else logstd).float().contiguous(),
-                              self.value_mean_std if self.normalize_value else None, e["actions"][n], e["mus"][n], e["sigmas"][n],
-                              e["neglogpacs"][n], e["values"][n])
+                if graphed:
+                    self._replay(("policy", n, self.obs.data_ptr()), lambda: seg_policy(n))
+                else:
+                    seg_policy(n)
                 res = {"actions": e["actions"][n]}
             else:
+                if self.obs.data_ptr() != e["obses"][n].data_ptr():
+                    e["obses"][n].copy_(self.obs)
                 res = self.get_action_values(self.obs)
                 for k in ("values", "neglogpacs", "actions", "mus", "sigmas"):
                     e[k][n].copy_(res[k])
             self.obs, rewards, self.dones, infos = self.vec_env.step(res["actions"])
             rewards = rewards.unsqueeze(1) if rewards.dim() == 1 else rewards
-            e["rewards"][n].copy_(rewards if self.reward_scale == 1 else rewards * self.reward_scale)
-            e["next_obses"][n].copy_(self.obs)
-            e["dones"][n].copy_(self.dones)
-            e["amp_obs"][n].copy_(infos["amp_obs"])
-            terminated = infos["terminate"].float()
-            terminated_flags += terminated
-            rr = infos["reward_raw"].mean(dim=0)
-            reward_raw = rr if reward_raw is None else reward_raw + rr
+            e["amp_obs"][n].copy_(infos["amp_obs"])   # (eager: the task's AMP buffer is a ping-pong pair, its address alternates)
             if fused:
-                with self._autocast():
-                    value = net.eval_critic(self._preproc_obs(self.obs))
-                policy_sample(None, value.contiguous(), None, self.value_mean_std if self.normalize_value else None, None, None, None, None,
-                              e["next_values"][n], mask=terminated)
+                if self._reward_raw_acc is None:       # first rollout: creates the accumulator eagerly
+                    seg_after(n, rewards, infos["terminate"], infos["reward_raw"])
+                elif graphed:
+                    key = ("after", n, self.obs.data_ptr(), rewards.data_ptr(), self.dones.data_ptr(), infos["terminate"].data_ptr(),
+                           infos["reward_raw"].data_ptr())
+                    self._replay(key, lambda: seg_after(n, rewards, infos["terminate"], infos["reward_raw"]))
+                else:
+                    seg_after(n, rewards, infos["terminate"], infos["reward_raw"])
             else:
+                e["rewards"][n].copy_(rewards if self.reward_scale == 1 else rewards * self.reward_scale)
+                e["next_obses"][n].copy_(self.obs)
+                e["dones"][n].copy_(self.dones)
+                terminated = infos["terminate"].float()
+                terminated_flags += terminated
+                rr = infos["reward_raw"].mean(dim=0)
+                self._reward_raw_acc = rr.clone() if self._reward_raw_acc is None else self._reward_raw_acc.add_(rr)
                 next_vals = self._eval_critic(self.obs)
                 next_vals = next_vals * (1.0 - terminated.unsqueeze(-1))
                 e["next_values"][n].copy_(next_vals)
-            self.current_rewards += rewards
-            self.current_lengths += 1
+                self.current_rewards += rewards
+                self.current_lengths += 1
+                not_dones = 1.0 - self.dones.float()
+                self.current_rewards = self.current_rewards * not_dones.unsqueeze(1)
+                self.current_lengths = self.current_lengths * not_dones
             if self.faithful_reset:
                 done_indices = self.dones.nonzero(as_tuple=False)[:, 0]
-            not_dones = 1.0 - self.dones.float()
-            self.current_rewards = self.current_rewards * not_dones.unsqueeze(1)
-            self.current_lengths = self.current_lengths * not_dones
+        reward_raw = self._reward_raw_acc
         mb_fdones = e["dones"].float()
         amp_rewards = self._calc_amp_rewards(e["amp_obs"])
         mb_rewards = self._combine_rewards(e["rewards"], amp_rewards)

@@ -4,7 +4,7 @@
 cd /tmp && export TMPDIR=/tmp; cd "${GRAFT_REPO_ROOT:-$OLDPWD}"
 for grp in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS"; do
   tag=$(echo $grp | tr ' ' '_' | cut -c1-40)
-  rocprofv3 --pmc $grp --kernel-trace --output-format csv -d /tmp/pmcv_$tag -o pmc -- python bench.py --steps 20 --warmup 5 --ppo-epochs 0 --no-cpu-baseline > /dev/null 2>/tmp/pmcv_$tag.err || tail -3 /tmp/pmcv_$tag.err
+  rocprofv3 --pmc $grp --kernel-trace --output-format csv -d /tmp/pmcv_$tag -o pmc -- python bench.py --steps 20 --warmup 5 --ppo-epochs 0 --no-cpu-baseline --no-pmc --lane-mapping ${LANE_MAPPING:-0} > /dev/null 2>/tmp/pmcv_$tag.err || tail -3 /tmp/pmcv_$tag.err
 done
 python - <<'PY'
 import collections, csv, glob
