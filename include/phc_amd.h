@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PHC_ABI_VERSION 18
+#define PHC_ABI_VERSION 19
 #define PHC_MAX_BODIES 64   /* bodies (incl. extended reference bodies) per articulation; also the slot count of the model tables */
 #define PHC_EINVAL (-1)
 #define PHC_EUNSUPPORTED (-2)
@@ -79,6 +79,10 @@ typedef struct {
     float* contact_force;
     float* dof_force;
     float* pd_target;                 /* [N,D] set_dof_position_target_tensor (humanoid.py:1559-1560) */
+    float* force_sensor;              /* [N,S,6] S6: gym.acquire_force_sensor_tensor (humanoid.py:183-190), force then torque of each sensor in
+                                         the sensor body's LOCAL frame (create_humanoid_force_sensors :1031-1040: identity pose on the
+                                         body, use_world_frame False); nullable.  Written by phc_sim_step at the end of the step: the net
+                                         ground-contact wrench on the body about its origin (PhysX's reading is closed: parity unpinned) */
 } phc_sim_state_t;
 
 /* Solver parameters.  Replaces gymapi.SimParams as filled by parse_sim_params
@@ -109,6 +113,8 @@ typedef struct {
     float self_damping_ratio;         /* default 0.5 */
     int32_t lane_mapping;             /* stepper thread mapping: 2 = two bodies per lane (16 lanes per env, 4 envs per wavefront; NB > 32: 32 lanes, 2 envs);
                                          1 = one body per lane (32 lanes per env, 2 envs per wavefront; NB > 32: 64 lanes, 1 env); 0 = pick by env count */
+    int32_t num_force_sensors;        /* S <= 4: force sensors (env.force_sensor_joints, default L_Ankle / R_Ankle, humanoid.py:268) */
+    int32_t force_sensor_body[4];     /* body id of each sensor */
 } phc_sim_params_t;
 
 /* Imitation-task parameters (phc/env/tasks/humanoid_im.py:37-123, env_im.yaml). */
@@ -147,6 +153,9 @@ typedef struct {
     const float* ext_offset;          /* [E,3] position in the parent frame */
     int32_t obs_v;                    /* task-observation version: 6 (0 is read as 6; `compute_imitation_observations_v6`, humanoid_im.py:1300-1360: 24 floats per
                                          tracked body) or 7 (`_v7`, :1362-1393, the keypoint models: position / velocity differences + reference positions, 9) */
+    int32_t self_obs_v;               /* 1 (0 is read as 1): compute_humanoid_observations_smpl_max; 3: `_v3` (humanoid.py:2113-2169) = the same
+                                         followed by the force-sensor readings [S*6] (num_self_obs grows by 6 S, humanoid.py:683) */
+    int32_t num_force_sensors;        /* S of phc_sim_state_t.force_sensor (self_obs_v 3) */
 } phc_im_params_t;
 
 /* Task-owned per-env buffers (phc/env/tasks/base_task.py:99-105, humanoid_amp.py:109-116,

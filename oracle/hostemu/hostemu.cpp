@@ -59,6 +59,7 @@ static int emu_sim_step_t(const phc_model_t* model, const phc_sim_params_t* prm,
         for (int j = 0; j < nb; ++j) {
             if (do_step) aba_store_state<JT>(L[j], *sim, nd, env, j);
             aba_publish_body(L[j], *sim, nb, env, j, do_step != 0);
+            if (do_step) aba_publish_sensors(L[j], *model, *prm, *sim, prm->sim_dt / (float)prm->substeps, env, j);
         }
     }
     return 0;

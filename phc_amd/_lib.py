@@ -34,7 +34,7 @@ class MotionLib(C.Structure):
 
 class SimState(C.Structure):
     _fields_ = [("num_envs", c_i32), ("root_states", c_p), ("dof_state", c_p), ("rigid_body_state", c_p),
-                ("contact_force", c_p), ("dof_force", c_p), ("pd_target", c_p)]
+                ("contact_force", c_p), ("dof_force", c_p), ("pd_target", c_p), ("force_sensor", c_p)]
 
 
 class SimParams(C.Structure):
@@ -42,7 +42,8 @@ class SimParams(C.Structure):
                 ("contact_stiffness", c_f), ("contact_damping", c_f), ("friction", c_f), ("friction_viscous", c_f),
                 ("angular_damping", c_f), ("max_angular_velocity", c_f), ("contact_offset", c_f),
                 ("control_mode", c_i32), ("limit_stiffness", c_f), ("limit_damping", c_f),
-                ("self_collision", c_i32), ("self_stiffness_scale", c_f), ("self_damping_ratio", c_f), ("lane_mapping", c_i32)]
+                ("self_collision", c_i32), ("self_stiffness_scale", c_f), ("self_damping_ratio", c_f), ("lane_mapping", c_i32),
+                ("num_force_sensors", c_i32), ("force_sensor_body", c_i32 * 4)]
 
 
 class ImParams(C.Structure):
@@ -59,7 +60,8 @@ class ImParams(C.Structure):
                 ("num_amp_obs_steps", c_i32), ("num_amp_obs_per_step", c_i32),
                 ("num_self_obs", c_i32), ("num_task_obs", c_i32),
                 ("cycle_motion", c_i32), ("zero_out_far", c_i32), ("close_distance", c_f), ("far_distance", c_f),
-                ("dofs_per_joint", c_i32), ("num_ext_bodies", c_i32), ("ext_parent", c_p), ("ext_offset", c_p), ("obs_v", c_i32)]
+                ("dofs_per_joint", c_i32), ("num_ext_bodies", c_i32), ("ext_parent", c_p), ("ext_offset", c_p), ("obs_v", c_i32),
+                ("self_obs_v", c_i32), ("num_force_sensors", c_i32)]
 
 
 class ImBuffers(C.Structure):
@@ -124,7 +126,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the .so does not export the symbol
         fn.argtypes = argtypes
         fn.restype = restype
-    if lib.phc_abi_version() != 18:
+    if lib.phc_abi_version() != 19:
         raise ImportError("libphc_amd.so ABI version mismatch")
     _lib = lib
     return lib

@@ -46,8 +46,9 @@ def motion_lib_struct(frames, frame_stride, num_bodies, motion_lengths, motion_d
     return s
 
 
-def sim_state_struct(num_envs, root_states, dof_state, rigid_body_state, contact_force, dof_force, pd_target):
+def sim_state_struct(num_envs, root_states, dof_state, rigid_body_state, contact_force, dof_force, pd_target, force_sensor=None):
     s = L.SimState()
+    s.force_sensor = ptr(force_sensor)
     s.num_envs = int(num_envs)
     s.root_states, s.dof_state, s.rigid_body_state = ptr(root_states), ptr(dof_state), ptr(rigid_body_state)
     s.contact_force, s.dof_force, s.pd_target = ptr(contact_force), ptr(dof_force), ptr(pd_target)
@@ -57,8 +58,12 @@ def sim_state_struct(num_envs, root_states, dof_state, rigid_body_state, contact
 def sim_params_struct(sim_dt=1 / 60, substeps=2, control_freq_inv=2, gravity_z=-9.81, contact_stiffness=1.0e5,
                       contact_damping=1.0e3, friction=1.0, friction_viscous=2.0e3, angular_damping=0.01,
                       max_angular_velocity=100.0, contact_offset=0.02, control_mode=0, limit_stiffness=0.0, limit_damping=0.0, lane_mapping=0,
-                      self_collision=0, self_stiffness_scale=0.25, self_damping_ratio=0.5):
+                      self_collision=0, self_stiffness_scale=0.25, self_damping_ratio=0.5, force_sensor_bodies=()):
     p = L.SimParams()
+    assert len(force_sensor_bodies) <= 4, "at most 4 force sensors"
+    p.num_force_sensors = len(force_sensor_bodies)
+    for i, b in enumerate(force_sensor_bodies):
+        p.force_sensor_body[i] = int(b)
     p.sim_dt, p.substeps, p.control_freq_inv, p.gravity_z = sim_dt, substeps, control_freq_inv, gravity_z
     p.contact_stiffness, p.contact_damping, p.friction, p.friction_viscous = contact_stiffness, contact_damping, friction, friction_viscous
     p.angular_damping, p.max_angular_velocity, p.contact_offset = angular_damping, max_angular_velocity, contact_offset
@@ -107,9 +112,10 @@ def im_params_struct(dt, max_episode_length, reward_specs, power_reward, power_c
                      track_slot, reset_mask, num_reset_bodies, first_reset_body, termination_distances, num_key_bodies, key_body_ids,
                      num_amp_joints, amp_joint_slot, num_amp_obs_steps, num_amp_obs_per_step, num_self_obs, num_task_obs,
                      cycle_motion=False, zero_out_far=False, close_distance=0.25, far_distance=3.0,
-                     dofs_per_joint=3, ext_parent=None, ext_offset=None, obs_v=6):
+                     dofs_per_joint=3, ext_parent=None, ext_offset=None, obs_v=6, self_obs_v=1, num_force_sensors=0):
     p = L.ImParams()
     p.obs_v = int(obs_v)
+    p.self_obs_v, p.num_force_sensors = int(self_obs_v), int(num_force_sensors)
     p.dofs_per_joint = int(dofs_per_joint)
     p.num_ext_bodies = 0 if ext_parent is None else int(ext_parent.shape[0])
     p.ext_parent, p.ext_offset = ptr(ext_parent), ptr(ext_offset)

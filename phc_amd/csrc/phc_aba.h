@@ -643,6 +643,42 @@ PHC_HD void aba_store_state(const AbaLane& L, const phc_sim_state_t& s, int nd, 
         }
     }
 }
+// S6 force sensor on body j (gym.acquire_force_sensor_tensor, humanoid.py:183-190,1031-1040): net ground-contact wrench on the body
+// about its origin, in the body's local frame, evaluated on the END-of-step state with the contact law of aba_body_init (explicit
+// part: penalty normal force + regularised Coulomb friction).  Runs once per launch on the lanes of the sensor bodies only.
+PHC_HD void aba_force_sensor(const AbaLane& L, const phc_model_t& m, const phc_sim_params_t& prm, float dt, int j, float* out6) {
+    const float* f = model_body(m, j);
+    const M3 R = quat_to_mat(L.Q);
+    V3 F = v3(0.f, 0.f, 0.f), N = v3(0.f, 0.f, 0.f);
+    const float cn = prm.contact_stiffness * dt + prm.contact_damping;
+    const int cp_start = model_tab(m, 8, j), cp_total = model_tab(m, 9, j);
+    const float* cp = m.floats + PHC_MAX_BODIES * PHC_BODY_FLOATS + cp_start * 4;
+    const int cp_count = (L.p.z < f[34]) ? cp_total : 0;
+    for (int k = 0; k < cp_count; ++k) {
+        V3 arm = mat_mul(R, v3(cp[4 * k], cp[4 * k + 1], cp[4 * k + 2]));
+        const float rad = cp[4 * k + 3];
+        const float depth = rad - (L.p.z + arm.z);
+        if (depth <= 0.f) continue;
+        arm.z -= rad;
+        const V3 uc = L.v + cross(L.w, arm);
+        const float fn0 = prm.contact_stiffness * depth - cn * uc.z;
+        if (fn0 <= 0.f) continue;
+        const float ut = sqrtf(uc.x * uc.x + uc.y * uc.y);
+        const float ct = fminf(prm.friction_viscous, prm.friction * fn0 / (ut + 1e-6f));
+        const V3 F0 = v3(-ct * uc.x, -ct * uc.y, fn0);
+        F += F0;
+        N += cross(arm, F0);
+    }
+    const V3 Fl = mat_tmul(R, F), Nl = mat_tmul(R, N);
+    out6[0] = Fl.x; out6[1] = Fl.y; out6[2] = Fl.z; out6[3] = Nl.x; out6[4] = Nl.y; out6[5] = Nl.z;
+}
+PHC_HD void aba_publish_sensors(const AbaLane& L, const phc_model_t& m, const phc_sim_params_t& prm, const phc_sim_state_t& s, float dt,
+                                int64_t env, int j) {
+    if (s.force_sensor == nullptr) return;
+    for (int k = 0; k < prm.num_force_sensors; ++k)
+        if (prm.force_sensor_body[k] == j) aba_force_sensor(L, m, prm, dt, j, s.force_sensor + (env * prm.num_force_sensors + k) * 6);
+}
+
 PHC_HD void aba_publish_body(const AbaLane& L, const phc_sim_state_t& s, int nb, int64_t env, int j, bool with_contact) {
     float* b = s.rigid_body_state + (env * nb + j) * 13;
     b[0] = L.p.x; b[1] = L.p.y; b[2] = L.p.z; b[3] = L.Q.x; b[4] = L.Q.y; b[5] = L.Q.z; b[6] = L.Q.w;

@@ -204,7 +204,7 @@ PHC_HD RewardPartial im_post_lane(const phc_model_t& model, const phc_motion_lib
     // observations for the next policy step (humanoid_im.py:694-726)
     Q4 hinv = calc_heading_quat_inv(root.rot), h = calc_heading_quat(root.rot);
     float* obs = buf.obs_buf + env * (int64_t)(prm.num_self_obs + prm.num_task_obs);
-    self_obs_lane(prm, nb, j, body, root, hinv, obs);
+    self_obs_lane(prm, nb, j, body, root, hinv, obs, (sim.force_sensor && prm.self_obs_v == 3) ? sim.force_sensor + env * (int64_t)(prm.num_force_sensors * 6) : nullptr);
     int slot = prm.track_slot[j];
     if (slot >= 0) {
         BodyState rt = r1;
@@ -327,7 +327,8 @@ PHC_HD void im_reset_lane(const phc_model_t& model, const phc_motion_lib_t& lib,
         BodyState r1 = ref_body(lib, fr1, j);
         Q4 hinv = calc_heading_quat_inv(root.rot), h = calc_heading_quat(root.rot);
         float* obs = buf.obs_buf + env * (int64_t)(prm.num_self_obs + prm.num_task_obs);
-        self_obs_lane(prm, nb, j, rs, root, hinv, obs);
+        // (reset envs: the sensor tensor keeps its last reading until the next simulate call, as gym's does -- humanoid.py:1463)
+        self_obs_lane(prm, nb, j, rs, root, hinv, obs, (sim.force_sensor && prm.self_obs_v == 3) ? sim.force_sensor + env * (int64_t)(prm.num_force_sensors * 6) : nullptr);
         int slot = prm.track_slot[j];
         if (slot >= 0) {
             BodyState rt = r1;
@@ -384,7 +385,7 @@ PHC_HD void im_reset_from_state_lane(const phc_model_t& model, const phc_motion_
         r1.pos += goff;
         Q4 hinv = calc_heading_quat_inv(root.rot), h = calc_heading_quat(root.rot);
         float* obs = buf.obs_buf + env * (int64_t)(prm.num_self_obs + prm.num_task_obs);
-        self_obs_lane(prm, nb, j, body, root, hinv, obs);
+        self_obs_lane(prm, nb, j, body, root, hinv, obs, (sim.force_sensor && prm.self_obs_v == 3) ? sim.force_sensor + env * (int64_t)(prm.num_force_sensors * 6) : nullptr);
         int slot = prm.track_slot[j];
         if (slot >= 0) {
             BodyState rt = r1;

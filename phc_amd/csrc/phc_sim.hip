@@ -165,6 +165,7 @@ __global__ __launch_bounds__(64, 2) void k_sim_step(phc_model_t model, phc_sim_p
         if (STEP) aba_store_state<JT>(L, sim, nd, env, lane);
         aba_publish_body(L, sim, nb, env, lane, STEP);
     }
+    if (STEP && active && sim.force_sensor != nullptr) aba_publish_sensors(L, model, prm, sim, prm.sim_dt / (float)prm.substeps, env, lane);   // S6
 }
 
 // ------------------------------------------------------------------------------------------
@@ -264,6 +265,10 @@ __global__ __launch_bounds__(64, 1) void k_sim_step16(phc_model_t model, phc_sim
     } else {
         if (jA >= 0) { aba_store_state<JT>(LA, sim, nd, env, jA); aba_publish_body(LA, sim, nb, env, jA, true); }
         if (jB >= 0) { aba_store_state<JT>(LB, sim, nd, env, jB); aba_publish_body(LB, sim, nb, env, jB, true); }
+    }
+    if (sim.force_sensor != nullptr) {   // S6 (wave-uniform branch; the sensor bodies' lanes only)
+        if (jA >= 0) aba_publish_sensors(LA, model, prm, sim, dt, env, jA);
+        if (jB >= 0) aba_publish_sensors(LB, model, prm, sim, dt, env, jB);
     }
     PHC_PROF(8)
     PHC_PROF_FLUSH

@@ -163,8 +163,10 @@ PHC_HD void store_body(float* rigid_body_state, int64_t env, int nb, int j, cons
 }
 
 // ---- R6: compute_humanoid_observations_smpl_max (humanoid.py:1995-2050), lane j's slices ----
+// `sensors`: the env's S6 force-sensor readings [S*6] (self_obs_v 3: compute_humanoid_observations_smpl_max_v3, humanoid.py:2113-2169,
+// appends them after the angular-velocity block) or nullptr.
 PHC_HD void self_obs_lane(const phc_im_params_t& prm, int nb, int j, const BodyState& body, const BodyState& root,
-                          Q4 hinv, float* obs) {
+                          Q4 hinv, float* obs, const float* sensors = nullptr) {
     int off = 0;
     if (prm.root_height_obs) { if (j == 0) obs[0] = root.pos.z; off = 1; }
     if (j >= 1) st3(obs + off + (j - 1) * 3, quat_rotate(hinv, body.pos - root.pos));
@@ -175,6 +177,10 @@ PHC_HD void self_obs_lane(const phc_im_params_t& prm, int nb, int j, const BodyS
     for (int k = 0; k < 6; ++k) pr[k] = tn[k];
     st3(obs + off + (nb - 1) * 3 + nb * 6 + j * 3, quat_rotate(hinv, body.vel));
     st3(obs + off + (nb - 1) * 3 + nb * 9 + j * 3, quat_rotate(hinv, body.angvel));
+    if (prm.self_obs_v == 3 && sensors != nullptr && j < prm.num_force_sensors) {   // lane s copies sensor s
+        float* o = obs + off + (nb - 1) * 3 + nb * 12 + j * 6;
+        for (int k = 0; k < 6; ++k) o[k] = sensors[j * 6 + k];
+    }
 }
 
 // ---- R7: compute_imitation_observations_v6 (humanoid_im.py:1309-1358), time_steps = 1 ----

@@ -90,10 +90,13 @@ class HumanoidIm:
             v = env.get(k, robot.get(k, off))
             if v != off:
                 raise NotImplementedError(f"config option {k}={v!r} is outside the hot path built so far")
-        if env.get("obs_v", 1) not in (6, 7) or env.get("self_obs_v", 1) != 1 or env.get("amp_obs_v", 1) != 1:
-            raise NotImplementedError("only obs_v=6 (the shipped env_im* configs) / obs_v=7 (the keypoint models), self_obs_v=1, amp_obs_v=1 are built")
+        if env.get("obs_v", 1) not in (6, 7) or env.get("self_obs_v", 1) not in (1, 3) or env.get("amp_obs_v", 1) != 1:
+            raise NotImplementedError("only obs_v=6 (the shipped env_im* configs) / obs_v=7 (the keypoint models), self_obs_v=1 / 3 (force "
+                                      "sensors), amp_obs_v=1 are built")
         self.has_task = True
-        self.obs_v, self.self_obs_v, self.amp_obs_v = int(env.get("obs_v", 6)), 1, 1
+        self.obs_v, self.self_obs_v, self.amp_obs_v = int(env.get("obs_v", 6)), int(env.get("self_obs_v", 1)), 1
+        # S6: force sensors at the feet (humanoid.py:268,1031-1040), read by self_obs_v 3 only (:683,1449,1481)
+        self.force_sensor_joints = list(env.get("force_sensor_joints", ["L_Ankle", "R_Ankle"]))
         if self._is_robot:  # load_robot_configs, humanoid.py:422-439
             self._body_names_orig = list(robot["body_names"])
             self._body_names = self._body_names_orig
@@ -224,6 +227,10 @@ class HumanoidIm:
         self._num_self_obs = 1 + len(self._body_names) * (3 + 6 + 3 + 3) - 3
         if not self._root_height_obs:
             self._num_self_obs -= 1
+        if self.self_obs_v == 3:   # humanoid.py:683
+            if self._is_robot:
+                raise NotImplementedError("self_obs_v=3 (foot force sensors) is an SMPL-family option (humanoid.py:1449-1481)")
+            self._num_self_obs += 6 * len(self.force_sensor_joints)
         self._track_bodies = env.get("trackBodies", self._full_track_bodies)
         self._reset_bodies = env.get("reset_bodies", self._track_bodies)
         track_slot, reset_mask, key_ids, amp_slot, n_amp_joints = abi.task_index_tables(
@@ -298,8 +305,11 @@ class HumanoidIm:
         self.dof_force_tensor = torch.zeros((N, D), **f32)
         self._pd_target = torch.zeros((N, D), **f32)
         self._terminate_buf = torch.ones(N, **i64)
+        # S6 (gym.acquire_force_sensor_tensor, humanoid.py:183-190): [N, S*6], force then torque per sensor in the sensor body's frame
+        sensors_on = self.self_obs_v == 3 and not self._is_robot
+        self.vec_sensor_tensor = torch.zeros((N, 6 * len(self.force_sensor_joints)), **f32) if sensors_on else None
         self._sim_struct = abi.sim_state_struct(N, self._root_states, self._dof_state, self._rigid_body_state, self._contact_forces,
-                                                self.dof_force_tensor, self._pd_target)
+                                                self.dof_force_tensor, self._pd_target, force_sensor=self.vec_sensor_tensor)
         physx = sim_cfg["physx"]
         plane = env.get("plane", {})
         solver = cfg.get("solver", {})  # phc_amd-specific knobs of the penalty contact model (not in the reference)
@@ -316,7 +326,8 @@ class HumanoidIm:
             lane_mapping=int(solver.get("lane_mapping", 0)),
             # body-body contact between non-adjacent links (robot.has_self_collision, on in the shipped robot yamls)
             self_collision=int(bool(solver.get("self_collision", self._has_self_collision))),
-            self_stiffness_scale=float(solver.get("self_stiffness_scale", 0.25)), self_damping_ratio=float(solver.get("self_damping_ratio", 0.5)))
+            self_stiffness_scale=float(solver.get("self_stiffness_scale", 0.25)), self_damping_ratio=float(solver.get("self_damping_ratio", 0.5)),
+            force_sensor_bodies=[self._body_names.index(b) for b in self.force_sensor_joints] if sensors_on else ())
 
         # ---- action scaling (A1) + freeze masks (humanoid.py:1331-1409,1549-1554) ----
         self.dof_limits_lower, self.dof_limits_upper = (torch.from_numpy(x).to(dev) for x in self.model.dof_limits())
@@ -405,7 +416,8 @@ class HumanoidIm:
             num_amp_obs_steps=self._num_amp_obs_steps, num_amp_obs_per_step=self._num_amp_obs_per_step,
             num_self_obs=self._num_self_obs, num_task_obs=self.get_task_obs_size(), obs_v=self.obs_v, cycle_motion=self.cycle_motion,
             zero_out_far=self.zero_out_far, close_distance=self.close_distance, far_distance=self.far_distance,
-            dofs_per_joint=1 if self._is_robot else 3, ext_parent=self._ext_parent_i32, ext_offset=self._ext_offset_f32)
+            dofs_per_joint=1 if self._is_robot else 3, ext_parent=self._ext_parent_i32, ext_offset=self._ext_offset_f32,
+            self_obs_v=self.self_obs_v, num_force_sensors=len(self.force_sensor_joints) if self.self_obs_v == 3 else 0)
         self._flag_state = (flags.im_eval, flags.no_collision_check)
 
     def _buffers(self, amp_in, amp_out):

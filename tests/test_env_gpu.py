@@ -592,3 +592,29 @@ def test_run_entry_trains_saves_and_plays(tmp_path):
         assert 0.0 <= ev["eval/success_rate"] <= 1.0
     finally:
         flags.test = flags.im_eval = False
+
+
+def test_force_sensors_and_self_obs_v3():
+    """S6 + self_obs_v 3 end to end: standing still under zero actions, the foot sensors (L_Ankle, R_Ankle) read the ground-contact
+    wrench of their body in the body frame -- rotated to the world it equals the stepper's net contact force on those bodies (steady
+    state) and carries a good part of the weight (the toes carry the rest); the readings are the last 12 floats of the self observation."""
+    task, env = make_task(64, motion="stand:4", **{"env.self_obs_v": 3})
+    assert task.get_self_obs_size() == 370 and task.num_obs == 370 + 576
+    env.reset()
+    task._motion_start_times[:] = 0
+    for _ in range(45):
+        obs, rew, done, info = env.step(torch.zeros(64, 69, device=task.device))
+    torch.cuda.synchronize()
+    s = task.vec_sensor_tensor.view(64, 2, 6)
+    assert torch.equal(obs[:, 358:370], task.vec_sensor_tensor)
+    ids = [task._body_names.index(b) for b in task.force_sensor_joints]
+    rot = task._rigid_body_rot[:, ids]                                # [N, 2, 4] xyzw
+    q, f = rot.reshape(-1, 4), s[..., :3].reshape(-1, 3)
+    qv, qw = q[:, :3], q[:, 3:]
+    t = 2 * torch.cross(qv, f, dim=-1)
+    f_world = (f + qw * t + torch.cross(qv, t, dim=-1)).view(64, 2, 3)
+    weight = float(task.model.mass.sum()) * 9.81
+    fz = f_world[..., 2].sum(-1)
+    assert (fz > 0.3 * weight).all() and (fz < 1.05 * weight).all(), (float(fz.min()), float(fz.max()), weight)
+    np.testing.assert_allclose(f_world.cpu().numpy(), task._contact_forces[:, ids].cpu().numpy(), rtol=0.05, atol=0.02 * weight)
+    assert torch.isfinite(s).all() and float(s[..., 3:].abs().max()) < 200.0     # torques about the ankle origin: N m scale

@@ -19,7 +19,8 @@ ENV_IM = dict(
 SPECS = po.DEFAULT_REWARD_SPECS
 
 
-def make_im_params(be, model, n_envs, use_mean=False, power_reward=True, power_coefficient=0.0005, track_bodies=None, reset_bodies=None, **extra):
+def make_im_params(be, model, n_envs, use_mean=False, power_reward=True, power_coefficient=0.0005, track_bodies=None, reset_bodies=None,
+                   num_self_obs=358, **extra):
     track_bodies = track_bodies or model.body_names
     reset_bodies = reset_bodies or ENV_IM["reset_bodies"]
     tabs = abi.task_index_tables(model, track_bodies, reset_bodies, ENV_IM["key_bodies"])
@@ -34,7 +35,7 @@ def make_im_params(be, model, n_envs, use_mean=False, power_reward=True, power_c
                                num_reset_bodies=len(reset_bodies), first_reset_body=model.body_names.index(reset_bodies[0]),
                                termination_distances=td,
                                num_key_bodies=len(ENV_IM["key_bodies"]), key_body_ids=key_ids, num_amp_joints=n_amp, amp_joint_slot=amp_slot,
-                               num_amp_obs_steps=10, num_amp_obs_per_step=196, num_self_obs=358, num_task_obs=24 * len(track_bodies), **extra)
+                               num_amp_obs_steps=10, num_amp_obs_per_step=196, num_self_obs=num_self_obs, num_task_obs=24 * len(track_bodies), **extra)
     prm._keepalive = (track_slot, reset_mask, key_ids, amp_slot, td)  # the struct only holds raw addresses
     return prm, (track_slot, reset_mask, be.np(key_ids), amp_slot_np, td)
 
@@ -119,6 +120,34 @@ def test_post_physics_vs_reference_golden(golden, backend, use_mean):
     np.testing.assert_array_equal(amp_out[:, 1:], amp_in_np[:, :-1])                           # history shift
     np.testing.assert_allclose(o["rbp"], g["ref1_pos"], atol=2e-5)                              # side-effect buffers (:855-868)
     np.testing.assert_allclose(o["rbv"], g["ref1_vel"], atol=2e-5)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_self_obs_v3_force_sensors_vs_reference_golden(golden, backend):
+    """S6 + R6 `_v3`: with env.self_obs_v=3 the self observation is compute_humanoid_observations_smpl_max_v3 (humanoid.py:2113-2169) =
+    the v1 block followed by the force-sensor readings (2 x 6); the task observation moves behind it.  Sensor tensor given here."""
+    be = get_backend(backend)
+    g, g3, gl = golden("task_fns"), golden("self_obs_v3"), golden("motion_lib_eval")
+    model, mstruct, keepm = model_on(be)
+    lib, keep = motion_lib_on(be, gl)
+    N = g["body_pos"].shape[0]
+    prm, keepp = make_im_params(be, model, N, num_self_obs=370, self_obs_v=3, num_force_sensors=2)
+    arrs, sim = _sim_arrays(be, g, N)
+    sens = be.arr(g3["sensors"].astype(F))
+    sim.force_sensor = abi.ptr(sens)
+    amp_in, amp_out = be.zeros((N, 10, 196)), be.zeros((N, 10, 196))
+    b = dict(progress=be.arr((g["progress"] - 1).astype(np.int64)), reset=be.zeros(N, np.int64), term=be.zeros(N, np.int64), rew=be.zeros(N),
+             raw=be.zeros((N, 5)), obs=be.zeros((N, 946)), mids=be.arr(g["env_motion"].astype(np.int64)),
+             st=be.arr(g["start_times"].astype(F)), so=be.zeros(N), goff=be.zeros((N, 3)))
+    buf = abi.im_buffers_struct(b["progress"], b["reset"], b["term"], b["rew"], b["raw"], b["obs"], amp_in, amp_out, b["mids"], b["st"],
+                                b["so"], b["goff"])
+    assert be.im_post_physics(mstruct, lib, prm, sim, buf) == 0
+    be.sync()
+    obs = be.np(b["obs"])
+    np.testing.assert_allclose(obs[:, :370], g3["self_obs_v3"], atol=1e-5)
+    np.testing.assert_array_equal(obs[:, 358:370], g3["sensors"])                 # readings pass through untouched
+    np.testing.assert_allclose(obs[:, 370:], g["task_obs"], atol=1e-5)            # the task block follows the longer self block
+    np.testing.assert_allclose(be.np(b["rew"]), g["reward"] + g["power_reward"], atol=1e-5)
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
