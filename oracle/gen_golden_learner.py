@@ -257,6 +257,18 @@ def gen_pnn():
     with torch.no_grad():
         out["load_mcp_mlp_out"] = mlp(x).numpy()
         out["amp_mu"] = m0.a2c_network.eval_actor({"obs": x})[0].numpy()
+    # lateral connections (pnn.py:25-38,84-126; off in the shipped yamls)
+    torch.manual_seed(14)
+    pnn_mod = ref_shim.ref_module("phc.learning.pnn")
+    lat = pnn_mod.PNN({"input_size": O, "units": [64, 32], "activation": "relu", "dense_func": torch.nn.Linear}, output_size=A, numCols=3, has_lateral=True)
+    out.update({"lat_model/" + k: v for k, v in np_state(lat.state_dict()).items()})
+    lat.eval()
+    with torch.no_grad():
+        a_all, outs = lat(x, idx=-1)
+        out["lat_out_all"] = torch.stack(outs, dim=1).numpy()
+        a1, outs1 = lat(x, idx=1)
+        out["lat_out_idx1"], out["lat_n_idx1"] = a1.numpy(), np.asarray(len(outs1))
+        out["lat_out_idx0"] = lat(x, idx=0)[0].numpy()
     np.savez_compressed(os.path.join(OUT, "learner_pnn.npz"), **out)
 
 

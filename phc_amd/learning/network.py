@@ -82,19 +82,32 @@ class A2CNetwork(nn.Module):
 class PNN(nn.Module):
     """Progressive-network actor (phc/learning/pnn.py:10-131): `numCols` full actor MLPs ("primitives") sharing the input;
     column k's output layer IS the action head (no separate `mu`).  `freeze_pnn(idx)` freezes columns < idx (:40-45).
-    Lateral connections exist in the reference but are disabled in every shipped yaml (`has_lateral: False`,
-    env_im_pnn.yaml); they are not built here."""
+    `has_lateral` (off in every shipped yaml, env_im_pnn.yaml): bias-free adapters `u[i][j]` from the first hidden activation of every
+    earlier column j <= i into the second hidden layer of column i + 1 (:25-38,84-126; the output-layer adapters `u[i][j][1]` exist in
+    the state dict but the reference's forward leaves them unused: "disable action space transfer")."""
 
     def __init__(self, input_size, units, activation, output_size, num_cols, has_lateral=False):
         super().__init__()
-        if has_lateral:
-            raise NotImplementedError("PNN lateral connections are not built (has_lateral is False in the shipped configs)")
         self.numCols = num_cols
+        self.has_lateral = bool(has_lateral)
         self.actors = nn.ModuleList()
         for _ in range(num_cols):
             mlp = build_mlp(input_size, units, activation, FastLinear)
             mlp.append(FastLinear(units[-1], output_size))
             self.actors.append(mlp)
+        if self.has_lateral:
+            assert len(units) == 2, "lateral connections: the reference supports two hidden layers (pnn.py:98)"
+            self.u = nn.ModuleList()
+            for i in range(num_cols - 1):
+                self.u.append(nn.ModuleList())
+                for _ in range(i + 1):
+                    seq = nn.Sequential()
+                    n = units[0]
+                    for unit in units[1:]:
+                        seq.append(nn.Linear(n, unit, bias=False))
+                        n = unit
+                    seq.append(nn.Linear(units[-1], output_size, bias=False))
+                    self.u[i].append(seq)
 
     def freeze_pnn(self, idx):
         for p in self.actors[:idx].parameters():
@@ -111,6 +124,22 @@ class PNN(nn.Module):
         sd[f"{2 * n_hidden}.bias"].copy_(m["a2c_network.mu.bias"])
 
     def forward(self, x, idx=-1):
+        if self.has_lateral:   # pnn.py:85-126
+            if idx == 0:
+                a = self.actors[0](x)
+                return a, [a]
+            if idx == -1:
+                idx = self.numCols - 1
+            first, outs = [], []
+            for k in range(idx + 1):
+                col = self.actors[k]
+                a1 = col[1](col[0](x))
+                lateral = sum(self.u[k - 1][j][0](first[j]) for j in range(len(first))) if first else 0
+                a2 = col[3](col[2](a1) + lateral)
+                actions = col[4](a2)
+                first.append(a1)
+                outs.append(actions)
+            return actions, outs
         if idx != -1:
             a = self.actors[idx](x)
             return a, [a]

@@ -233,6 +233,25 @@ def test_pnn_and_mcp_networks_and_checkpoint_loaders_equal_the_reference(golden)
         np.testing.assert_allclose(plain.a2c_network.eval_actor(x)[0].numpy(), g["amp_mu"], rtol=1e-5, atol=1e-6)
 
 
+def test_pnn_lateral_connections_equal_the_reference(golden):
+    """pnn.py:25-38,84-126 (has_lateral: off in the shipped yamls): same key set, same outputs for idx = -1 / 0 / 1."""
+    from phc_amd.learning.network import PNN
+    g = golden("learner_pnn")
+    x = torch.from_numpy(g["pnn_x"])
+    pnn = PNN(O, [64, 32], "relu", A, 3, has_lateral=True)
+    sd = _sub(g, "lat_model/")
+    assert set(pnn.state_dict()) == set(sd)
+    pnn.load_state_dict(sd, strict=True)
+    pnn.eval()
+    with torch.no_grad():
+        a_all, outs = pnn(x, idx=-1)
+        np.testing.assert_allclose(torch.stack(outs, dim=1).numpy(), g["lat_out_all"], rtol=1e-5, atol=1e-6)
+        a1, outs1 = pnn(x, idx=1)
+        np.testing.assert_allclose(a1.numpy(), g["lat_out_idx1"], rtol=1e-5, atol=1e-6)
+        assert len(outs1) == int(g["lat_n_idx1"])
+        np.testing.assert_allclose(pnn(x, idx=0)[0].numpy(), g["lat_out_idx0"], rtol=1e-5, atol=1e-6)
+
+
 def test_released_checkpoint_layout_round_trip(golden, tmp_path):
     """B4 / f-2: a file with the reference's full checkpoint layout (`get_full_state_weights`, common_agent.py:405-433: model, epoch,
     optimizer = Adam(model.parameters()).state_dict(), frame, running_mean_std, reward_mean_std, amp_input_mean_std) restores through
