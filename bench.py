@@ -52,6 +52,8 @@ def parse():
                     "graph also with more than one rank: the graph holds no collective, the all-reduce follows each replay eagerly")
     ap.add_argument("--force-rccl", action="store_true", help="single-GPU self-test of the multi-GPU code path: a ONE-rank nccl (=RCCL) "
                     "process group, the gradient all-reduce issued after every optimizer step's captured forward / backward")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="process-group backend: nccl (= RCCL, the product path); gloo "
+                    "exists to exercise the multi-rank logic of this script with several ranks SHARING one GPU (tests on 1-GPU boxes)")
     ap.add_argument("--config", type=int, default=2, choices=[2, 3, 5], help="BASELINE.json configs preset (1-based): 2 = SMPL 4096 envs single "
                     "clip (the bench line), 3 = 8192 envs + AMASS-sized synthetic library (--motion-clips, default 11313), 5 = H1 4096 envs")
     ap.add_argument("--ppo-epochs", type=int, default=3, help="timed PPO epochs (rollout 32 steps + 36 optimizer steps); 0 = skip")
@@ -256,7 +258,7 @@ def spawn_ranks(n):
     import socket
     import subprocess
     have = torch.cuda.device_count()
-    if have < n:
+    if have < n and "gloo" not in sys.argv:
         raise SystemExit(f"bench.py --gpus {n}: only {have} GPU(s) visible on this node -- refusing to report an {n}-GPU line from fewer devices")
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -280,8 +282,10 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the path has no CPU fallback")
     if world != args.gpus:
         raise SystemExit(f"bench.py --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
-    if torch.cuda.device_count() < min(world, int(os.environ.get("LOCAL_WORLD_SIZE", world))):
+    if args.backend == "nccl" and torch.cuda.device_count() < min(world, int(os.environ.get("LOCAL_WORLD_SIZE", world))):
         raise SystemExit(f"bench.py: {world} ranks but only {torch.cuda.device_count()} GPU(s) visible")
+    if args.backend == "gloo":
+        local_rank = local_rank % max(1, torch.cuda.device_count())     # ranks share the visible GPU(s)
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or args.force_rccl:
@@ -290,7 +294,10 @@ def main():
         if world == 1:
             os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 400))
             os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if args.backend == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
     if args.config == 3:      # configs[2]: full-AMASS-sized library, 8192 envs (defaults only: explicit flags win)
         if "--envs" not in " ".join(sys.argv):
             args.envs = 8192

@@ -618,3 +618,28 @@ def test_force_sensors_and_self_obs_v3():
     assert (fz > 0.3 * weight).all() and (fz < 1.05 * weight).all(), (float(fz.min()), float(fz.max()), weight)
     np.testing.assert_allclose(f_world.cpu().numpy(), task._contact_forces[:, ids].cpu().numpy(), rtol=0.05, atol=0.02 * weight)
     assert torch.isfinite(s).all() and float(s[..., 3:].abs().max()) < 200.0     # torques about the ankle origin: N m scale
+
+
+def test_bench_multi_rank_logic_two_ranks_on_one_gpu():
+    """`python bench.py --gpus 2` end to end on a 1-GPU box: bench.py spawns two ranks itself (torch.distributed.run), here over gloo with
+    both ranks sharing cuda:0 (`--backend gloo`; RCCL refuses two ranks on one device) -- barriers, max-over-ranks timing, the whole-job
+    value, the PPO epochs with one gradient all-reduce per optimizer step next to the captured update, the rank table of the JSON line."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--envs", "512", "--steps", "20", "--warmup", "5",
+                        "--ppo-epochs", "2", "--no-cpu-baseline", "--no-pmc"], capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1, r.stdout[-2000:]            # rank 0 alone prints
+    d = json.loads(line[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["envs_per_gpu"] == 512
+    assert d["value"] > 0 and abs(d["value"] - 2 * 512 * 20 / (d["ms_per_step"] * 1e-3 * 20)) < 1e-6 * d["value"]
+    comm = d["ppo_comm"]
+    assert [x["rank"] for x in comm["ranks"]] == [0, 1] and all(x["world"] == 2 for x in comm["ranks"])
+    n_opt = d["ppo_config"]["optimizer_steps_per_epoch"]
+    assert comm["grad_allreduces_per_epoch"] == n_opt and all(x["collectives"] == 2 * n_opt for x in comm["ranks"])
+    assert d["ppo_config"]["collectives_per_epoch"] == n_opt and d["ppo_samples_per_s"] > 0
