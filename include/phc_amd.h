@@ -156,6 +156,8 @@ typedef struct {
     int32_t self_obs_v;               /* 1 (0 is read as 1): compute_humanoid_observations_smpl_max; 3: `_v3` (humanoid.py:2113-2169) = the same
                                          followed by the force-sensor readings [S*6] (num_self_obs grows by 6 S, humanoid.py:683) */
     int32_t num_force_sensors;        /* S of phc_sim_state_t.force_sensor (self_obs_v 3) */
+    int32_t amp_obs_v;                /* 1 (0 is read as 1): build_amp_observations_smpl; 2: `_v2` (humanoid_amp.py:1015-1059) = the same followed by the
+                                         key bodies' heading-local velocities [3 K] (num_amp_obs_per_step grows by 3 K, :303) */
 } phc_im_params_t;
 
 /* Task-owned per-env buffers (phc/env/tasks/base_task.py:99-105, humanoid_amp.py:109-116,

@@ -61,7 +61,7 @@ class ImParams(C.Structure):
                 ("num_self_obs", c_i32), ("num_task_obs", c_i32),
                 ("cycle_motion", c_i32), ("zero_out_far", c_i32), ("close_distance", c_f), ("far_distance", c_f),
                 ("dofs_per_joint", c_i32), ("num_ext_bodies", c_i32), ("ext_parent", c_p), ("ext_offset", c_p), ("obs_v", c_i32),
-                ("self_obs_v", c_i32), ("num_force_sensors", c_i32)]
+                ("self_obs_v", c_i32), ("num_force_sensors", c_i32), ("amp_obs_v", c_i32)]
 
 
 class ImBuffers(C.Structure):

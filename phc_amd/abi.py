@@ -112,8 +112,9 @@ def im_params_struct(dt, max_episode_length, reward_specs, power_reward, power_c
                      track_slot, reset_mask, num_reset_bodies, first_reset_body, termination_distances, num_key_bodies, key_body_ids,
                      num_amp_joints, amp_joint_slot, num_amp_obs_steps, num_amp_obs_per_step, num_self_obs, num_task_obs,
                      cycle_motion=False, zero_out_far=False, close_distance=0.25, far_distance=3.0,
-                     dofs_per_joint=3, ext_parent=None, ext_offset=None, obs_v=6, self_obs_v=1, num_force_sensors=0):
+                     dofs_per_joint=3, ext_parent=None, ext_offset=None, obs_v=6, self_obs_v=1, num_force_sensors=0, amp_obs_v=1):
     p = L.ImParams()
+    p.amp_obs_v = int(amp_obs_v)
     p.obs_v = int(obs_v)
     p.self_obs_v, p.num_force_sensors = int(self_obs_v), int(num_force_sensors)
     p.dofs_per_joint = int(dofs_per_joint)

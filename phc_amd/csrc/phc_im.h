@@ -37,7 +37,7 @@ PHC_HD void amp_obs_from_ref_lane(const phc_motion_lib_t& lib, const phc_im_para
     }
     if (j < prm.num_key_bodies) {
         BodyState kb = ref_body(lib, fr, prm.key_body_ids[j]);
-        amp_obs_key(prm, j, kb.pos, root.pos, hinv, a);
+        amp_obs_key(prm, j, kb.pos, kb.vel, root.pos, hinv, a);
     }
 }
 
@@ -56,7 +56,7 @@ PHC_HD void amp_obs_from_sim_lane(const phc_im_params_t& prm, const phc_sim_stat
     }
     if (j < prm.num_key_bodies) {
         BodyState kb = load_body(sim.rigid_body_state, env, nb, prm.key_body_ids[j]);
-        amp_obs_key(prm, j, kb.pos, root.pos, hinv, a);
+        amp_obs_key(prm, j, kb.pos, kb.vel, root.pos, hinv, a);
     }
 }
 

@@ -230,9 +230,11 @@ PHC_HD void amp_obs_joint(const phc_im_params_t& prm, int slot, V3 dof_pos, V3 d
     for (int k = 0; k < 6; ++k) a[off + slot * 6 + k] = tn[k];
     st3(a + off + prm.num_amp_joints * 6 + slot * 3, dof_vel);
 }
-PHC_HD void amp_obs_key(const phc_im_params_t& prm, int k, V3 key_pos, V3 root_pos, Q4 hinv, float* a) {
+// amp_obs_v 2 (build_amp_observations_smpl_v2, humanoid_amp.py:1015-1059): the key bodies' velocities, heading-local, follow their positions
+PHC_HD void amp_obs_key(const phc_im_params_t& prm, int k, V3 key_pos, V3 key_vel, V3 root_pos, Q4 hinv, float* a) {
     const int off = (prm.root_height_obs ? 1 : 0) + 12 + prm.num_amp_joints * (prm.dofs_per_joint == 1 ? 2 : 9);
     st3(a + off + k * 3, quat_rotate(hinv, key_pos - root_pos));
+    if (prm.amp_obs_v == 2) st3(a + off + prm.num_key_bodies * 3 + k * 3, quat_rotate(hinv, key_vel));
 }
 
 // ---- R1/R5 per-lane partials, reduced over the 32-lane group by the caller ----

@@ -90,11 +90,11 @@ class HumanoidIm:
             v = env.get(k, robot.get(k, off))
             if v != off:
                 raise NotImplementedError(f"config option {k}={v!r} is outside the hot path built so far")
-        if env.get("obs_v", 1) not in (6, 7) or env.get("self_obs_v", 1) not in (1, 3) or env.get("amp_obs_v", 1) != 1:
+        if env.get("obs_v", 1) not in (6, 7) or env.get("self_obs_v", 1) not in (1, 3) or env.get("amp_obs_v", 1) not in (1, 2):
             raise NotImplementedError("only obs_v=6 (the shipped env_im* configs) / obs_v=7 (the keypoint models), self_obs_v=1 / 3 (force "
-                                      "sensors), amp_obs_v=1 are built")
+                                      "sensors), amp_obs_v=1 / 2 (key-body velocities) are built")
         self.has_task = True
-        self.obs_v, self.self_obs_v, self.amp_obs_v = int(env.get("obs_v", 6)), int(env.get("self_obs_v", 1)), 1
+        self.obs_v, self.self_obs_v, self.amp_obs_v = int(env.get("obs_v", 6)), int(env.get("self_obs_v", 1)), int(env.get("amp_obs_v", 1))
         # S6: force sensors at the feet (humanoid.py:268,1031-1040), read by self_obs_v 3 only (:683,1449,1481)
         self.force_sensor_joints = list(env.get("force_sensor_joints", ["L_Ankle", "R_Ankle"]))
         if self._is_robot:  # load_robot_configs, humanoid.py:422-439
@@ -227,6 +227,8 @@ class HumanoidIm:
         self._num_self_obs = 1 + len(self._body_names) * (3 + 6 + 3 + 3) - 3
         if not self._root_height_obs:
             self._num_self_obs -= 1
+        if self.amp_obs_v == 2 and self._is_robot:
+            raise NotImplementedError("amp_obs_v=2 routes to build_amp_observations_smpl_v2 (humanoid_amp.py:716-717): SMPL family only")
         if self.self_obs_v == 3:   # humanoid.py:683
             if self._is_robot:
                 raise NotImplementedError("self_obs_v=3 (foot force sensors) is an SMPL-family option (humanoid.py:1449-1481)")
@@ -240,6 +242,8 @@ class HumanoidIm:
             self.dof_subset = torch.tensor([]).long()
         else:
             self._num_amp_obs_per_step = 13 + n_amp_joints * 9 + 3 * len(self.key_bodies) - (0 if self._amp_root_height_obs else 1)
+            if self.amp_obs_v == 2:   # + key-body velocities (humanoid_amp.py:303)
+                self._num_amp_obs_per_step += 3 * len(self.key_bodies)
             dof_sub = [np.arange(3 * (j - 1), 3 * j) for j in range(1, self.num_bodies) if amp_slot[j] >= 0]
             self.dof_subset = torch.from_numpy(np.concatenate(dof_sub)) if self._has_dof_subset else torch.tensor([]).long()
         # extended bodies of the full-body reward (humanoid_im.py:74-82)
@@ -417,7 +421,7 @@ class HumanoidIm:
             num_self_obs=self._num_self_obs, num_task_obs=self.get_task_obs_size(), obs_v=self.obs_v, cycle_motion=self.cycle_motion,
             zero_out_far=self.zero_out_far, close_distance=self.close_distance, far_distance=self.far_distance,
             dofs_per_joint=1 if self._is_robot else 3, ext_parent=self._ext_parent_i32, ext_offset=self._ext_offset_f32,
-            self_obs_v=self.self_obs_v, num_force_sensors=len(self.force_sensor_joints) if self.self_obs_v == 3 else 0)
+            self_obs_v=self.self_obs_v, num_force_sensors=len(self.force_sensor_joints) if self.self_obs_v == 3 else 0, amp_obs_v=self.amp_obs_v)
         self._flag_state = (flags.im_eval, flags.no_collision_check)
 
     def _buffers(self, amp_in, amp_out):

@@ -20,7 +20,7 @@ SPECS = po.DEFAULT_REWARD_SPECS
 
 
 def make_im_params(be, model, n_envs, use_mean=False, power_reward=True, power_coefficient=0.0005, track_bodies=None, reset_bodies=None,
-                   num_self_obs=358, **extra):
+                   num_self_obs=358, num_amp_obs_per_step=196, **extra):
     track_bodies = track_bodies or model.body_names
     reset_bodies = reset_bodies or ENV_IM["reset_bodies"]
     tabs = abi.task_index_tables(model, track_bodies, reset_bodies, ENV_IM["key_bodies"])
@@ -35,7 +35,7 @@ def make_im_params(be, model, n_envs, use_mean=False, power_reward=True, power_c
                                num_reset_bodies=len(reset_bodies), first_reset_body=model.body_names.index(reset_bodies[0]),
                                termination_distances=td,
                                num_key_bodies=len(ENV_IM["key_bodies"]), key_body_ids=key_ids, num_amp_joints=n_amp, amp_joint_slot=amp_slot,
-                               num_amp_obs_steps=10, num_amp_obs_per_step=196, num_self_obs=num_self_obs, num_task_obs=24 * len(track_bodies), **extra)
+                               num_amp_obs_steps=10, num_amp_obs_per_step=num_amp_obs_per_step, num_self_obs=num_self_obs, num_task_obs=24 * len(track_bodies), **extra)
     prm._keepalive = (track_slot, reset_mask, key_ids, amp_slot, td)  # the struct only holds raw addresses
     return prm, (track_slot, reset_mask, be.np(key_ids), amp_slot_np, td)
 
@@ -148,6 +148,33 @@ def test_self_obs_v3_force_sensors_vs_reference_golden(golden, backend):
     np.testing.assert_array_equal(obs[:, 358:370], g3["sensors"])                 # readings pass through untouched
     np.testing.assert_allclose(obs[:, 370:], g["task_obs"], atol=1e-5)            # the task block follows the longer self block
     np.testing.assert_allclose(be.np(b["rew"]), g["reward"] + g["power_reward"], atol=1e-5)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_amp_obs_v2_vs_reference_golden(golden, backend):
+    """R9 `_v2`: env.amp_obs_v=2 -> build_amp_observations_smpl_v2 (humanoid_amp.py:1015-1059): 196 + 12 floats per step (the key bodies'
+    heading-local velocities after their positions); the history shift works on the 208-float frames."""
+    be = get_backend(backend)
+    g, g2, gl = golden("task_fns"), golden("amp_obs_v2"), golden("motion_lib_eval")
+    model, mstruct, keepm = model_on(be)
+    lib, keep = motion_lib_on(be, gl)
+    N = g["body_pos"].shape[0]
+    prm, keepp = make_im_params(be, model, N, num_amp_obs_per_step=208, amp_obs_v=2)
+    arrs, sim = _sim_arrays(be, g, N)
+    rng = np.random.default_rng(2)
+    amp_in_np = rng.standard_normal((N, 10, 208)).astype(F)
+    amp_in, amp_out = be.arr(amp_in_np), be.zeros((N, 10, 208))
+    b = dict(progress=be.arr((g["progress"] - 1).astype(np.int64)), reset=be.zeros(N, np.int64), term=be.zeros(N, np.int64), rew=be.zeros(N),
+             raw=be.zeros((N, 5)), obs=be.zeros((N, 934)), mids=be.arr(g["env_motion"].astype(np.int64)),
+             st=be.arr(g["start_times"].astype(F)), so=be.zeros(N), goff=be.zeros((N, 3)))
+    buf = abi.im_buffers_struct(b["progress"], b["reset"], b["term"], b["rew"], b["raw"], b["obs"], amp_in, amp_out, b["mids"], b["st"],
+                                b["so"], b["goff"])
+    assert be.im_post_physics(mstruct, lib, prm, sim, buf) == 0
+    be.sync()
+    out = be.np(amp_out)
+    np.testing.assert_allclose(out[:, 0], g2["amp_obs_v2"], atol=1e-5)
+    np.testing.assert_array_equal(out[:, 1:], amp_in_np[:, :-1])
+    np.testing.assert_allclose(be.np(b["obs"])[:, :358], g["self_obs"], atol=1e-5)
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
