@@ -417,11 +417,14 @@ def main():
                        "envs_per_gpu": N, "num_bodies": task.num_bodies,
                        "obs": task.num_obs, "amp_obs": task.get_num_amp_obs(), "parallelism": f"env-sharded x{world}",
                        "self_collision": bool(task._sim_params.self_collision)},
-            "roofline": {"kernel": "phc_sim_step: k_sim_step16 / k_sim_step (A2 + %d ABA sub-steps + S7 publication)" % nsub, "bound": "hbm", "achieved": achieved,
+            "roofline": {"kernel": "phc_sim_step -> %s (A2 + %d ABA sub-steps + S7 publication)" % (
+                             (traffic_src["live"]["kernel"] if isinstance(traffic_src, dict) else "k_sim_step (one body per lane) / k_sim_step16 (two-slot), picked per launch"), nsub),
+                         "bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "note": "latency/ALU-bound tree sweep: SURVEY 8(d) canonical un-fused accounting (1484 B x 4 sub-steps + 1812 B "
-                                 "per env); the fused launch's compulsory traffic is 3296 B/env",
+                         "note": "SURVEY 8(d) canonical un-fused accounting (1484 B x 4 sub-steps + 1812 B per env; the fused launch's compulsory "
+                                 "traffic is 3296 B/env).  The kernel is NOT HBM-bound: at 4096 envs it sits on the VALU-issue roofline of its "
+                                 "instruction stream (SQ counters: 0.99 of every SIMD's cycles VALU-active, profiles/r02_pmc_valu.txt, r02_notes.md)",
                          "gflops": FLOPS_PER_ENV_SUBSTEP * nsub * N / (kern_ms * 1e-3) / 1e9},
         }
         if ppo is not None:
