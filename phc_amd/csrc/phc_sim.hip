@@ -114,6 +114,7 @@ __global__ __launch_bounds__(64, 2) void k_sim_step(phc_model_t model, phc_sim_p
 
     AbaLane L;
     L.level = -1;
+    PHC_PROF_DECL
     if (active) {
         aba_load_model(L, model, lane);
         if (JT == PHC_JT_REVOLUTE) aba_load_model_rev(L, model, lane);
@@ -130,6 +131,7 @@ __global__ __launch_bounds__(64, 2) void k_sim_step(phc_model_t model, phc_sim_p
     }
     const int max_level = model.max_level;
     for (int l = 0; l <= max_level; ++l) { aba_fk_level(L, l, lane, x); __syncthreads(); }
+    PHC_PROF(0)
     if (STEP) {
         const float dt = prm.sim_dt / (float)prm.substeps;
         const int nsub = num_sim_calls * prm.substeps;
@@ -144,9 +146,13 @@ __global__ __launch_bounds__(64, 2) void k_sim_step(phc_model_t model, phc_sim_p
                 __syncthreads();
                 if (active) aba_collect_self(L, lane, caps);
             }
+            PHC_PROF(1)
             if (active) aba_body_init<JT>(L, model, prm, dt, lane, s % prm.substeps == 0);
+            PHC_PROF(2)
             for (int l = max_level; l >= 0; --l) { aba_backward_level<JT>(L, l, lane, x); __syncthreads(); }
+            PHC_PROF(3)
             for (int l = 0; l <= max_level; ++l) { aba_forward_level<JT>(L, l, lane, x, prm, dt); __syncthreads(); }
+            PHC_PROF(7)
         }
     }
     // S7: the last forward sweep already produced the end-of-step kinematics
@@ -166,6 +172,8 @@ __global__ __launch_bounds__(64, 2) void k_sim_step(phc_model_t model, phc_sim_p
         aba_publish_body(L, sim, nb, env, lane, STEP);
     }
     if (STEP && active && sim.force_sensor != nullptr) aba_publish_sensors(L, model, prm, sim, prm.sim_dt / (float)prm.substeps, env, lane);   // S6
+    PHC_PROF(8)
+    if (STEP) { PHC_PROF_FLUSH }
 }
 
 // ------------------------------------------------------------------------------------------

@@ -12,8 +12,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 PROF = os.path.join(ROOT, "phc_amd", "_obj", "libphc_amd_prof.so")
-NAMES = ["load + initial FK", "body-body contact", "init B (deep bodies)", "backward B levels", "init A (shallow bodies)", "backward A levels",
-         "forward A levels", "forward B levels", "store + publish"]
+NAMES = ["load + initial FK", "body-body contact", "init B (deep bodies) / init (one body per lane)", "backward B levels / backward sweep",
+         "init A (shallow bodies)", "backward A levels", "forward A levels", "forward B levels / forward sweep", "store + publish"]
 
 
 def build():
@@ -41,7 +41,9 @@ def run():
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
     extra = sys.argv[3:]
     torch.manual_seed(0)
-    task, env = parse_task(compose([f"env.num_envs={n}", "env.motion_file=synthetic:1:0", "+solver.lane_mapping=2"] + extra))
+    mapping = next((a.split("=")[1] for a in extra if a.startswith("mapping=")), "2")
+    extra = [a for a in extra if not a.startswith("mapping=")]
+    task, env = parse_task(compose([f"env.num_envs={n}", "env.motion_file=synthetic:1:0", f"+solver.lane_mapping={mapping}"] + extra))
     env.reset()
     a = (torch.rand(n, task.num_actions, device=task.device) * 2 - 1) * 0.1
     for _ in range(20):
@@ -58,8 +60,8 @@ def run():
     tot = sum(buf[i] for i in range(9))
     print(f"{n} envs, {steps} steps, {waves} wavefront executions; s_memtime cycles per wavefront per launch (4 sub-steps):")
     for i, nm in enumerate(NAMES):
-        print(f"  {nm:26s} {buf[i] / waves:10.0f}  {100.0 * buf[i] / tot:5.1f} %")
-    print(f"  {'total':26s} {tot / waves:10.0f}")
+        print(f"  {nm:52s} {buf[i] / waves:10.0f}  {100.0 * buf[i] / tot:5.1f} %")
+    print(f"  {'total':52s} {tot / waves:10.0f}")
 
 
 if __name__ == "__main__":

@@ -1,5 +1,6 @@
 """Stepper launch time vs number of sub-steps: t = a + b * nsub separates the fixed part (state load, initial FK, store / publish, launch)
 from the per-sub-step cost.   python scripts/sim_substep_scan.py [num_envs] [lane_mapping]"""
+import os
 import sys
 
 import torch
@@ -18,8 +19,11 @@ def main():
     task, env = parse_task(compose([f"env.num_envs={n}", "env.motion_file=synthetic:1:0", f"+solver.lane_mapping={mapping}"] + sys.argv[3:]))
     env.reset()
     a = (torch.rand(n, task.num_actions, device=task.device) * 2 - 1) * 0.1
+    lift = float(os.environ.get("PHC_SCAN_LIFT", "0"))     # raise every humanoid: no body reaches the ground -> the contact-point loops are skipped
+    if lift:
+        task._root_states[:, 2] += lift
     root0, dof0 = task._root_states.clone(), task._dof_state.clone()
-    for calls in (0, 1, 2, 3, 4, 8):
+    for calls in (0, 2, 4):
         ts = []
         for it in range(30):
             task._root_states.copy_(root0); task._dof_state.copy_(dof0)
