@@ -407,19 +407,22 @@ PHC_HD void aba_publish_capsule(const AbaLane& L, const float* f, float* cap) {
 }
 // one candidate pair (bodies i < k): bounding spheres, then the capsule-capsule test, then the penalty force into both accumulators.
 // Needs both bodies' capsules in `caps` and kinematics (p w v at slot floats [10..19)) in the exchange slots.
-PHC_HD void aba_collide_pair(const phc_sim_params_t& prm, float dt, int i, int k, const Xch& x, float* caps) {
+// Returns true when the pair is FAR: its surfaces are more than PHC_SC_SKIP_MARGIN apart (see aba_collide_pairs).
+#define PHC_SC_SKIP_MARGIN 0.12f
+PHC_HD bool aba_collide_pair(const phc_sim_params_t& prm, float dt, int i, int k, const Xch& x, float* caps) {
     const float* ci = caps + PHC_CAP_STRIDE * i;
     const float* ck = caps + PHC_CAP_STRIDE * k;
     const V3 dm = v3(ci[0] - ck[0], ci[1] - ck[1], ci[2] - ck[2]);
     const float R = ci[3] + ck[3];
-    if (dot(dm, dm) > R * R) return;                         // broad phase
+    const float d2 = dot(dm, dm);
+    if (d2 > R * R) return d2 > (R + PHC_SC_SKIP_MARGIN) * (R + PHC_SC_SKIP_MARGIN);   // broad phase
     const V3 a1 = v3(ci[4], ci[5], ci[6]), b1 = v3(ci[8], ci[9], ci[10]), a2 = v3(ck[4], ck[5], ck[6]), b2 = v3(ck[8], ck[9], ck[10]);
     const float r1 = ci[7], m1 = ci[11], r2 = ck[7], m2 = ck[11];
     V3 c1, c2;
     seg_seg_closest(a1, b1, a2, b2, &c1, &c2);
     V3 n = c1 - c2;
     const float dist = norm(n), pen = r1 + r2 - dist;
-    if (pen <= 0.f) return;
+    if (pen <= 0.f) return pen < -PHC_SC_SKIP_MARGIN;
     n = dist > 1e-6f ? n * (1.0f / dist) : v3(0.f, 0.f, 1.f);
     const V3 cp = c2 + n * (r2 - 0.5f * pen);                // middle of the overlap
     constexpr int es = Xch::es;
@@ -432,7 +435,7 @@ PHC_HD void aba_collide_pair(const phc_sim_params_t& prm, float dt, int i, int k
     const float kk = prm.self_stiffness_scale * mu / (dt * dt);
     const float cc = 2.0f * prm.self_damping_ratio * sqrtf(kk * mu);
     const float fn = kk * pen - cc * dot(vrel, n);
-    if (fn <= 0.f) return;                                   // non-adhesive
+    if (fn <= 0.f) return false;                             // non-adhesive
     // force on body i (+) and body k (-), quantised once so that both bodies see exactly opposite values
     const int32_t fx = (int32_t)rintf(n.x * fn * PHC_SC_FSCALE), fy = (int32_t)rintf(n.y * fn * PHC_SC_FSCALE), fz = (int32_t)rintf(n.z * fn * PHC_SC_FSCALE);
     const V3 F = v3((float)fx, (float)fy, (float)fz) * (1.0f / PHC_SC_FSCALE);
@@ -443,6 +446,7 @@ PHC_HD void aba_collide_pair(const phc_sim_params_t& prm, float dt, int i, int k
     sc_atomic_add(ak + 0, -fx); sc_atomic_add(ak + 1, -fy); sc_atomic_add(ak + 2, -fz);
     sc_atomic_add(ai + 3, (int32_t)rintf(ni.x * PHC_SC_NSCALE)); sc_atomic_add(ai + 4, (int32_t)rintf(ni.y * PHC_SC_NSCALE)); sc_atomic_add(ai + 5, (int32_t)rintf(ni.z * PHC_SC_NSCALE));
     sc_atomic_add(ak + 3, -(int32_t)rintf(nk.x * PHC_SC_NSCALE)); sc_atomic_add(ak + 4, -(int32_t)rintf(nk.y * PHC_SC_NSCALE)); sc_atomic_add(ak + 5, -(int32_t)rintf(nk.z * PHC_SC_NSCALE));
+    return false;
 }
 // lane `l` of `nl` lanes of the env's group: its share of the candidate pairs, fetched ONCE per launch into registers (the list
 // sits in global memory; a dependent L2 round trip per pair and sub-step was the largest part of the first version's cost)
@@ -460,11 +464,24 @@ PHC_HD void aba_load_pairs(PairList<NP>& P, const phc_model_t& m, int l, int nl)
         P.pr[t] = q < np ? model_pair(m, q) : -1;
     }
 }
+// Temporal coherence over the sub-steps of ONE launch (round 2: body-body contact was 17 us of the two-slot launch): the first sub-step
+// tests every candidate pair and remembers in `near` (bit t = pair t of this lane) the ones whose surfaces are closer than
+// PHC_SC_SKIP_MARGIN = 0.12 m; the remaining sub-steps (3 x 1/120 s) only revisit those.  A pair closing faster than ~5 m/s from beyond the
+// margin is picked up one env step late at the latest (the penalty contact is soft by construction, k = mu / (4 dt^2)).  The host
+// emulation / fp64 oracle test every pair in every sub-step; they agree with this unless such a pair exists.
 template <int NP>
-PHC_HD void aba_collide_pairs(const PairList<NP>& P, const phc_sim_params_t& prm, float dt, const Xch& x, float* caps) {
+PHC_HD void aba_collide_pairs(const PairList<NP>& P, const phc_sim_params_t& prm, float dt, const Xch& x, float* caps, uint32_t& near, bool refresh) {
+    if (refresh) {
+        uint32_t nr = 0;
 #pragma unroll
-    for (int t = 0; t < NP; ++t)
-        if (P.pr[t] >= 0) aba_collide_pair(prm, dt, P.pr[t] & 0xff, P.pr[t] >> 8, x, caps);
+        for (int t = 0; t < NP; ++t)
+            if (P.pr[t] >= 0 && !aba_collide_pair(prm, dt, P.pr[t] & 0xff, P.pr[t] >> 8, x, caps)) nr |= 1u << t;
+        near = nr;
+    } else {
+#pragma unroll
+        for (int t = 0; t < NP; ++t)
+            if ((near >> t) & 1u) aba_collide_pair(prm, dt, P.pr[t] & 0xff, P.pr[t] >> 8, x, caps);
+    }
 }
 // net body-body contact force / moment of body j from its accumulators
 PHC_HD void aba_collect_self(AbaLane& L, int j, const float* caps) {

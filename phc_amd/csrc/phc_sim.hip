@@ -137,12 +137,13 @@ __global__ __launch_bounds__(64, 2) void k_sim_step(phc_model_t model, phc_sim_p
         const int nsub = num_sim_calls * prm.substeps;
         float* caps = cap_all + grp * GRP * PHC_CAP_STRIDE;
         PairList<PHC_SC_MAX_PER_LANE> pairs;
+        uint32_t near_pairs = 0;
         if (prm.self_collision) aba_load_pairs(pairs, model, lane, GRP);
         for (int s = 0; s < nsub; ++s) {
             if (prm.self_collision) {   // body-body contact from the kinematics the last sweep left in the exchange slots
                 if (active) aba_publish_capsule(L, model_body(model, lane), caps + PHC_CAP_STRIDE * lane);
                 __syncthreads();
-                if (env < sim.num_envs) aba_collide_pairs(pairs, prm, dt, x, caps);
+                if (env < sim.num_envs) aba_collide_pairs(pairs, prm, dt, x, caps, near_pairs, s == 0);
                 __syncthreads();
                 if (active) aba_collect_self(L, lane, caps);
             }
@@ -230,6 +231,7 @@ __global__ __launch_bounds__(64, 1) void k_sim_step16(phc_model_t model, phc_sim
     const float dt = prm.sim_dt / (float)prm.substeps;
     const int nsub = num_sim_calls * prm.substeps;
     PairList<(GRP == 32 ? PHC_SC_MAX_PER_LANE_WIDE : PHC_SC_MAX_PER_LANE)> pairs;
+    uint32_t near_pairs = 0;
     if (prm.self_collision) aba_load_pairs(pairs, model, lane, GRP);
     PHC_PROF(0)
     for (int s = 0; s < nsub; ++s) {
@@ -239,7 +241,7 @@ __global__ __launch_bounds__(64, 1) void k_sim_step16(phc_model_t model, phc_sim
             if (jA >= 0) aba_publish_capsule(LA, model_body(model, jA), caps + PHC_CAP_STRIDE * jA);
             if (jB >= 0) aba_publish_capsule(LB, model_body(model, jB), caps + PHC_CAP_STRIDE * jB);
             __syncthreads();
-            if (env_ok) aba_collide_pairs(pairs, prm, dt, x, caps);
+            if (env_ok) aba_collide_pairs(pairs, prm, dt, x, caps, near_pairs, s == 0);
             __syncthreads();
             if (jA >= 0) aba_collect_self(LA, jA, caps);
             if (jB >= 0) aba_collect_self(LB, jB, caps);

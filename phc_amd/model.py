@@ -466,6 +466,15 @@ class ArticulationModel:
             fl[i, 34] = (np.linalg.norm(self.contact_pos[idx], axis=-1) + self.contact_radius[idx]).max() * 1.0001 if len(idx) else 0.0
             fl[i, 36:43] = self.collision_capsule[i]
         cp = np.concatenate([self.contact_pos, self.contact_radius[:, None]], axis=1) if len(self.contact_body) else np.zeros((0, 4))
+        # within a body: lowest points (local z - radius) first.  The stepper walks a body's points in lockstep over the lanes of a
+        # wavefront and skips an iteration's force / inertia part when NO lane's point touches the ground: with the soles' points at the
+        # front of every foot's list, the iterations of the upper box corners are skipped together (a box came as z-alternating corners).
+        for i in range(NB):
+            idx = np.nonzero(self.contact_body == i)[0]
+            if len(idx) > 1:
+                assert (np.diff(idx) == 1).all()
+                order = np.argsort(cp[idx, 2] - cp[idx, 3], kind="stable")
+                cp[idx] = cp[idx][order]
         floats = np.concatenate([fl.reshape(-1), cp.reshape(-1)]).astype(np.float32)
         return ints, floats
 
