@@ -294,6 +294,10 @@ int32_t phc_running_norm(const float* x, const int64_t* row_index, int64_t rows,
  * the output gradient, AddmmBackward).  workspace: phc_colsum_workspace(rows, cols) bytes. */
 int64_t phc_colsum_workspace(int64_t rows, int32_t cols);
 int32_t phc_colsum_bf16(const void* x, int64_t rows, int32_t cols, float* out, float* workspace, void* stream);
+/* The same behind a ReLU whose output `y` was saved (round 2: layers whose ReLU rides in the GEMM epilogue): gm = gy where y > 0 else 0
+ * (torch's ThresholdBackward, phc/learning/network_builder.py:126-137 `activation: relu`) written as bf16 [rows, cols], and its column sums
+ * (the bias gradient) -- one pass instead of two.  Same workspace size. */
+int32_t phc_colsum_relu_bf16(const void* gy, const void* y, int64_t rows, int32_t cols, void* gm, float* out, float* workspace, void* stream);
 
 /* Discriminator loss pieces (phc/learning/amp_agent.py:732-808 `_disc_loss`).
  * phc_disc_bce: logits [n_agent + n_demo] (agent and replay rows first, demo rows last; bf16 or fp32):

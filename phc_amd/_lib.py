@@ -96,6 +96,7 @@ _SIGNATURES = {
     "phc_running_norm": ([c_p, c_p, c_i64, c_i32, c_p, c_p, c_f, c_f, c_p, c_i32, c_p, c_p, c_p, c_p, c_p], c_i32),
     "phc_colsum_workspace": ([c_i64, c_i32], c_i64),
     "phc_colsum_bf16": ([c_p, c_i64, c_i32, c_p, c_p, c_p], c_i32),
+    "phc_colsum_relu_bf16": ([c_p, c_p, c_i64, c_i32, c_p, c_p, c_p, c_p], c_i32),
     "phc_disc_bce": ([c_p, c_i32, c_i32, c_i32, c_f, c_p, c_p, c_p], c_i32),
     "phc_sumsq_workspace": ([], c_i64),
     "phc_weighted_sumsq": ([c_i32, c_p, c_p, c_p, c_i32, c_p, c_p, c_p], c_i32),

@@ -121,6 +121,38 @@ __global__ __launch_bounds__(256) void k_colsum_bf16(const __hip_bfloat16* __res
     __syncthreads();
     if (ry == 0 && c < cols) partial[(int64_t)blockIdx.y * cols + c] = (l[0][cx] + l[1][cx]) + (l[2][cx] + l[3][cx]);
 }
+// The same with the ReLU mask of a saved layer output applied on the way: gm = (y > 0) ? gy : 0 is written back, its column sums go to `partial`.
+__global__ __launch_bounds__(256) void k_colsum_relu_bf16(const __hip_bfloat16* __restrict__ gy, const __hip_bfloat16* __restrict__ y, int64_t rows, int cols,
+                                                          __hip_bfloat16* __restrict__ gm, float* __restrict__ partial) {
+    __shared__ float l[4][64];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
+    const int64_t r0 = (int64_t)blockIdx.y * CS_ROWS;
+    const int64_t r1 = r0 + CS_ROWS < rows ? r0 + CS_ROWS : rows;
+    float a = 0.f;
+    if (c < cols) {
+        int64_t r = r0 + ry;
+        for (; r + 28 < r1; r += 32) {   // 16 independent loads in flight
+            float g[8], o[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { g[k] = __bfloat162float(gy[(r + 4 * k) * cols + c]); o[k] = __bfloat162float(y[(r + 4 * k) * cols + c]); }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float m = o[k] > 0.f ? g[k] : 0.f;
+                gm[(r + 4 * k) * cols + c] = __float2bfloat16(m);
+                a += m;
+            }
+        }
+        for (; r < r1; r += 4) {
+            const float m = __bfloat162float(y[r * cols + c]) > 0.f ? __bfloat162float(gy[r * cols + c]) : 0.f;
+            gm[r * cols + c] = __float2bfloat16(m);
+            a += m;
+        }
+    }
+    l[ry][cx] = a;
+    __syncthreads();
+    if (ry == 0 && c < cols) partial[(int64_t)blockIdx.y * cols + c] = (l[0][cx] + l[1][cx]) + (l[2][cx] + l[3][cx]);
+}
 // block = 64 columns x 16 slices of the chunk list (up to 1024 chunks: 64 loads per thread, four in flight)
 __global__ __launch_bounds__(1024) void k_colsum_finish(const float* __restrict__ partial, int nchunks, int cols, float* __restrict__ out) {
     __shared__ float l[16][64];
@@ -513,6 +545,18 @@ int32_t phc_colsum_bf16(const void* x, int64_t rows, int32_t cols, float* out, f
     if (nchunks > 65535) return PHC_EUNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_colsum_bf16, dim3((cols + 63) / 64, (unsigned)nchunks), dim3(256), 0, st, reinterpret_cast<const __hip_bfloat16*>(x), rows, cols, workspace);
+    hipLaunchKernelGGL(k_colsum_finish, dim3((cols + 63) / 64), dim3(1024), 0, st, workspace, (int)nchunks, cols, out);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int32_t)e;
+}
+
+int32_t phc_colsum_relu_bf16(const void* gy, const void* y, int64_t rows, int32_t cols, void* gm, float* out, float* workspace, void* stream) {
+    if (!gy || !y || !gm || !out || !workspace || rows < 1 || cols < 1) return PHC_EINVAL;
+    const int64_t nchunks = (rows + CS_ROWS - 1) / CS_ROWS;
+    if (nchunks > 65535) return PHC_EUNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_colsum_relu_bf16, dim3((cols + 63) / 64, (unsigned)nchunks), dim3(256), 0, st, reinterpret_cast<const __hip_bfloat16*>(gy),
+                       reinterpret_cast<const __hip_bfloat16*>(y), rows, cols, reinterpret_cast<__hip_bfloat16*>(gm), workspace);
     hipLaunchKernelGGL(k_colsum_finish, dim3((cols + 63) / 64), dim3(1024), 0, st, workspace, (int)nchunks, cols, out);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int32_t)e;

@@ -14,7 +14,7 @@ import math
 import torch
 from torch import nn
 
-from .fast_ops import FastLinear, FastLinearDD
+from .fast_ops import FastLinear, FastLinearDD, FusedReLU
 
 DISC_LOGIT_INIT_SCALE = 1.0  # amp_network_builder.py:12
 
@@ -25,7 +25,12 @@ def build_mlp(input_size, units, activation, linear=nn.Linear):
     """network_builder.py:126-137 `_build_sequential_mlp`: Linear, act, Linear, act ... (indices 0,2,4,..)."""
     layers, n = [], input_size
     for u in units:
-        layers += [linear(n, u), _ACT[activation]()]
+        lin = linear(n, u)
+        if activation == "relu" and isinstance(lin, FastLinear):     # the ReLU rides in the GEMM epilogue of the device passes
+            lin.fuse_relu = True
+            layers += [lin, FusedReLU(lin)]
+        else:
+            layers += [lin, _ACT[activation]()]
         n = u
     return nn.Sequential(*layers)
 

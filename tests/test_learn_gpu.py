@@ -115,6 +115,39 @@ def test_fast_linear_matches_autocast_linear(B, K, N):
     assert torch.equal(fast(x), ref(x))
 
 
+@pytest.mark.parametrize("B,K,N", [(16384, 934, 1024), (4096, 1024, 512), (1000, 130, 7)])
+def test_fused_relu_layer_matches_linear_plus_relu(B, K, N):
+    """build_mlp's FastLinear + FusedReLU pair (ReLU in the GEMM epilogue, ReLU mask + bias gradient in one pass, phc_colsum_relu_bf16) ==
+    nn.Linear + nn.ReLU under bf16 autocast: identical forward values, identical masked gradients up to the bf16 GEMMs' accuracy; the
+    rollout-inference path (bf16 shadow parameters, no grad) fuses too; state-dict keys are those of Linear, ReLU."""
+    from phc_amd.learning.network import build_mlp
+    from phc_amd.learning.fast_ops import FastLinear, FusedReLU
+    torch.manual_seed(1)
+    ref = torch.nn.Sequential(torch.nn.Linear(K, N), torch.nn.ReLU()).cuda()
+    fast = build_mlp(K, [N], "relu", FastLinear).cuda()
+    assert isinstance(fast[0], FastLinear) and fast[0].fuse_relu and isinstance(fast[1], FusedReLU) and list(fast.state_dict()) == list(ref.state_dict())
+    fast.load_state_dict(ref.state_dict())
+    x = torch.randn(B, K, device="cuda")
+    gy = torch.randn(B, N, device="cuda") / B
+    outs = {}
+    for name, mod in (("ref", ref), ("fast", fast)):
+        xi = x.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = mod(xi)
+        (y.float() * gy).sum().backward()
+        outs[name] = (y.float(), mod[0].weight.grad.clone(), mod[0].bias.grad.clone(), xi.grad.clone())
+    assert torch.equal(outs["ref"][0], outs["fast"][0]) and float((outs["fast"][0] == 0).float().mean()) > 0.2
+    for k in (1, 2, 3):
+        scale = outs["ref"][k].abs().max().item()
+        assert (outs["fast"][k] - outs["ref"][k]).abs().max().item() < 2e-2 * scale, k
+    # bias gradient: exactly the column sums of the masked bf16 output gradient
+    gm = torch.where(outs["ref"][0] > 0, gy.to(torch.bfloat16).float(), torch.zeros_like(gy))
+    np.testing.assert_allclose(outs["fast"][2].cpu().numpy(), gm.sum(0).cpu().numpy(), rtol=2e-3, atol=1e-6)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        assert torch.equal(fast(x), ref(x))
+    assert torch.equal(fast(x), ref(x))          # fp32, no autocast: plain modules
+
+
 def test_adam_clip_step_equals_torch():
     """phc_adam_clip_step == clip_grad_norm_ + torch.optim.Adam.step on the flat parameter (three steps, clipping active and
     inactive, weight decay on), and the optimizer's state_dict stays loadable by a plain torch Adam."""
