@@ -10,6 +10,7 @@ discriminator.  The state-dict keys are the ones the reference's checkpoints use
 MI355X: weights are fp32 masters; the GEMMs run as bf16 MFMA under torch.autocast (hipBLASLt) -- the only
 dense contraction on the path."""
 import math
+import os
 
 import torch
 from torch import nn
@@ -26,7 +27,7 @@ def build_mlp(input_size, units, activation, linear=nn.Linear):
     layers, n = [], input_size
     for u in units:
         lin = linear(n, u)
-        if activation == "relu" and isinstance(lin, FastLinear):     # the ReLU rides in the GEMM epilogue of the device passes
+        if activation == "relu" and isinstance(lin, FastLinear) and not os.environ.get("PHC_NO_RELU_FUSION"):   # the ReLU rides in the GEMM epilogue of the device passes
             lin.fuse_relu = True
             layers += [lin, FusedReLU(lin)]
         else:
