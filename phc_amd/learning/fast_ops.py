@@ -181,43 +181,66 @@ class input_grad_only:
 class _LinearDDFn(torch.autograd.Function):
     """The same layer for the discriminator, whose gradient penalty differentiates the backward pass (create_graph=True): the
     backward is itself an autograd node (`_LinearDDBwdFn`) with an explicit second-order rule, so both the first- and the
-    second-order weight gradients -- four reductions over the 12 288-row batch per step -- run as split-K batched GEMMs."""
+    second-order weight gradients -- four reductions over the 12 288-row batch per step -- run as split-K batched GEMMs.
+    `relu=True` (round 2): the ReLU behind the layer rides along -- epilogue in the forward, its mask m = [y > 0] inside the backward
+    node (piecewise constant: the second-order rule only gains `d gy = m * (...)` and uses the masked gradient everywhere else)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, relu=False):
         wb, bb = _bf16_params(weight, bias)
-        ctx.save_for_backward(x, weight, bias)
-        return torch.addmm(bb, x.to(torch.bfloat16), wb.t())
+        xb = x.to(torch.bfloat16)
+        y = torch._addmm_activation(bb, xb, wb.t()) if relu else torch.addmm(bb, xb, wb.t())
+        ctx.relu = relu
+        if relu:
+            ctx.save_for_backward(x, weight, bias, y)
+        else:
+            ctx.save_for_backward(x, weight, bias)
+        return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, weight, bias = ctx.saved_tensors
+        if ctx.relu:
+            x, weight, bias, y = ctx.saved_tensors
+        else:
+            (x, weight, bias), y = ctx.saved_tensors, None
         only_x = _INPUT_GRAD_ONLY[0]
-        gx, gw, gb = _LinearDDBwdFn.apply(gy, x, weight, bias, ctx.needs_input_grad[0], only_x)
-        return gx if ctx.needs_input_grad[0] else None, None if only_x else gw, None if only_x else gb
+        gx, gw, gb = _LinearDDBwdFn.apply(gy, x, weight, bias, ctx.needs_input_grad[0], only_x, y)
+        out = (gx if ctx.needs_input_grad[0] else None, None if only_x else gw, None if only_x else gb)
+        return out + ((None,) if len(ctx.needs_input_grad) > 3 else ())
 
 
 class _LinearDDBwdFn(torch.autograd.Function):
-    """(gy, x, W) -> gx = gy W, gW = gy^T x, gb = 1^T gy; its own backward for cotangents (ggx, ggW, ggb):
-    d gy = ggx W^T + x ggW^T + ggb,  d x = gy ggW,  d W = gy^T ggx."""
+    """(gy, x, W[, y]) -> gz = gy (masked by y > 0 when the layer carries its ReLU), gx = gz W, gW = gz^T x, gb = 1^T gz; its own
+    backward for cotangents (ggx, ggW, ggb):  d gz = ggx W^T + x ggW^T + ggb,  d gy = mask * d gz,  d x = gz ggW,  d W = gz^T ggx."""
 
     @staticmethod
-    def forward(ctx, gy, x, weight, bias, need_gx, only_x):
+    def forward(ctx, gy, x, weight, bias, need_gx, only_x, y=None):
         gy = gy.contiguous()
         xb = x.to(torch.bfloat16)
         wb, _ = _bf16_params(weight, bias)
-        ctx.save_for_backward(gy, xb, wb)
-        ctx.x_dtype, ctx.need_gx, ctx.only_x = x.dtype, need_gx, only_x
+        gb = None
+        if y is not None:
+            if only_x or gy.dtype != torch.bfloat16:
+                gy = torch.ops.aten.threshold_backward(gy, y, 0.0)
+            else:
+                gy, gb = colsum_relu_bf16(gy, y)          # mask + bias gradient in one pass
+            ctx.save_for_backward(gy, xb, wb, y)
+        else:
+            ctx.save_for_backward(gy, xb, wb)
+        ctx.x_dtype, ctx.need_gx, ctx.only_x, ctx.masked = x.dtype, need_gx, only_x, y is not None
         ctx.set_materialize_grads(False)   # cotangents nobody produced arrive as None, not as zeros
         gx = (gy @ wb).to(x.dtype) if need_gx else gy.new_zeros(())
         if only_x:
             return gx, gy.new_zeros(()), gy.new_zeros(())
-        return gx, wgrad_split_k(gy, xb), colsum_bf16(gy)
+        return gx, wgrad_split_k(gy, xb), (gb if gb is not None else colsum_bf16(gy))
 
     @staticmethod
     @once_differentiable
     def backward(ctx, ggx, ggw, ggb):
-        gy, xb, wb = ctx.saved_tensors
+        if ctx.masked:
+            gy, xb, wb, y = ctx.saved_tensors
+        else:
+            (gy, xb, wb), y = ctx.saved_tensors, None
         d_gy = d_x = d_w = None
         if ctx.only_x:   # the weight / bias outputs were placeholders
             ggw = ggb = None
@@ -233,7 +256,9 @@ class _LinearDDBwdFn(torch.autograd.Function):
         if ggb is not None:
             t = ggb.to(torch.bfloat16).expand_as(gy)
             d_gy = t if d_gy is None else d_gy + t
-        return d_gy, d_x, d_w, None, None, None
+        if y is not None and d_gy is not None:
+            d_gy = torch.ops.aten.threshold_backward(d_gy.contiguous(), y, 0.0)
+        return d_gy, d_x, d_w, None, None, None, None
 
 
 def _device_training_pass(mod, x):
@@ -243,10 +268,14 @@ def _device_training_pass(mod, x):
 
 class FastLinearDD(nn.Linear):
     """nn.Linear for layers that are differentiated twice (the discriminator MLP): see _LinearDDFn."""
+    fuse_relu = False
+    _fused_now = False
 
     def forward(self, x):
+        self._fused_now = False
         if _device_training_pass(self, x):
-            return _LinearDDFn.apply(x, self.weight, self.bias)
+            self._fused_now = self.fuse_relu
+            return _LinearDDFn.apply(x, self.weight, self.bias, True) if self.fuse_relu else _LinearDDFn.apply(x, self.weight, self.bias)
         return nn.functional.linear(x, self.weight, self.bias)
 
 

@@ -27,7 +27,7 @@ def build_mlp(input_size, units, activation, linear=nn.Linear):
     layers, n = [], input_size
     for u in units:
         lin = linear(n, u)
-        if activation == "relu" and isinstance(lin, FastLinear) and not os.environ.get("PHC_NO_RELU_FUSION"):   # the ReLU rides in the GEMM epilogue of the device passes
+        if activation == "relu" and isinstance(lin, (FastLinear, FastLinearDD)) and not os.environ.get("PHC_NO_RELU_FUSION"):   # the ReLU rides in the GEMM epilogue of the device passes
             lin.fuse_relu = True
             layers += [lin, FusedReLU(lin)]
         else:

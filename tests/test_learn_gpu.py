@@ -259,14 +259,22 @@ def test_row_index_variants_equal_gathered_inputs():
         assert torch.equal(p, q)
 
 
-def test_twice_differentiable_linear_matches_autograd():
+@pytest.mark.parametrize("fused_relu", [False, True])
+def test_twice_differentiable_linear_matches_autograd(fused_relu):
     """FastLinearDD (discriminator MLP): loss + gradient penalty -- which differentiates the backward pass -- give the same parameter
-    gradients as nn.Linear under bf16 autocast, within bf16 GEMM accuracy of the fp64 result."""
+    gradients as nn.Linear under bf16 autocast, within bf16 GEMM accuracy of the fp64 result.  `fused_relu`: the pair FastLinearDD +
+    FusedReLU as network.build_mlp makes it (ReLU in the GEMM epilogue, its mask inside the twice-differentiable backward node)."""
     from phc_amd.learning.fast_ops import FastLinearDD
+    from phc_amd.learning.network import build_mlp
     torch.manual_seed(3)
     B, m, K = 6144, 2048, 1960
 
     def build(linear, dtype=torch.float32):
+        if fused_relu and linear is FastLinearDD:
+            net = build_mlp(K, [1024, 512], "relu", FastLinearDD)
+            assert net[0].fuse_relu and net[2].fuse_relu
+            net.append(torch.nn.Linear(512, 1))
+            return net.cuda().to(dtype)
         net = torch.nn.Sequential(linear(K, 1024), torch.nn.ReLU(), linear(1024, 512), torch.nn.ReLU(), torch.nn.Linear(512, 1)).cuda().to(dtype)
         return net
     ref = build(torch.nn.Linear)
