@@ -39,7 +39,7 @@ from torch import nn
 from .. import _lib as L
 from .network import A2CMCPNetwork, A2CNetwork, A2CPNNNetwork, ModelAMPContinuous, policy_kl
 from .replay_buffer import ReplayBuffer
-from .fast_ops import adam_clip_step, disc_bce, input_grad_only, policy_sample, ppo_loss, rows_with_grad, weighted_sumsq
+from .fast_ops import adam_clip_step, disc_bce, input_grad_only, param_grad_only, policy_sample, ppo_loss, rows_with_grad, weighted_sumsq
 from .running_mean_std import RunningMeanStd
 
 
@@ -532,8 +532,10 @@ class IMAmpAgent:
         coefs = [self._disc_weight_decay * k] * len(ws)
         coefs[-1] += self._disc_logit_reg * k   # the logit layer: regulariser + weight decay
         l2 = weighted_sumsq(ws, coefs)
-        with input_grad_only():
-            grad = torch.autograd.grad(logits[2 * m:], obs_demo, grad_outputs=self._ones_like_cached(m, logits), create_graph=True, retain_graph=True,
+        # d(sum of the demo logits) / d(demo rows): cotangent = [0; 0; 1] over the [agent; replay; demo] logits, and the layers are told
+        # that only the last row block carries anything (GEMMs over m instead of 3m rows, here and in the second-order pass)
+        with input_grad_only(row_start=2 * m):
+            grad = torch.autograd.grad(logits, obs_demo, grad_outputs=self._demo_row_mask(m, logits), create_graph=True, retain_graph=True,
                                        only_inputs=True)[0]
         pen = weighted_sumsq([grad], [self._disc_grad_penalty * k / m])
         total = bce + l2 + pen
@@ -544,10 +546,12 @@ class IMAmpAgent:
                     "disc_agent_acc": acc[0], "disc_demo_acc": acc[1]}
         return total, info
 
-    def _ones_like_cached(self, m, like):
+    def _demo_row_mask(self, m, like):
         key = (m, like.dtype, like.device)
         if getattr(self, "_ones_key", None) != key:
-            self._ones_key, self._ones = key, torch.ones((m, 1), dtype=like.dtype, device=like.device)
+            mask = torch.zeros((3 * m, 1), dtype=like.dtype, device=like.device)
+            mask[2 * m:] = 1
+            self._ones_key, self._ones = key, mask
         return self._ones
 
     def _fwd_bwd(self, d):
@@ -594,7 +598,8 @@ class IMAmpAgent:
             assert idx is None
             loss, info = self._ppo_loss_torch(res, d, disc_info)
         self.grads.zero()
-        loss.backward()
+        with param_grad_only():
+            loss.backward()
         info.update({k: (v.detach() if torch.is_tensor(v) else v) for k, v in disc_info.items()})
         return info
 

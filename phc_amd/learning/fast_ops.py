@@ -163,19 +163,59 @@ def _bf16_params(weight, bias):
     return weight.to(torch.bfloat16), bias.to(torch.bfloat16)
 
 
-_INPUT_GRAD_ONLY = [False]
+_INPUT_GRAD_ONLY = [False, 0]   # [active, first row of the cotangent's non-zero block]
 
 
 class input_grad_only:
     """Context for a `torch.autograd.grad(outputs, inputs=<activations>)` call (the gradient penalty): tells the twice-differentiable
     layers that no parameter gradient is asked for -- a custom Function cannot see which of its gradients the engine needs, and
-    computing the weight / bias gradients there cost 10 ms per update.  (Module-level flag: the backward runs on the autograd thread.)"""
+    computing the weight / bias gradients there cost 10 ms per update.  (Module-level flag: the backward runs on the autograd thread.)
+    `row_start` (round 2): the cotangent is zero in rows [0, row_start) -- the penalty differentiates the DEMO logits only, which are
+    the last third of the discriminator's [agent; replay; demo] batch -- and only rows [row_start, n) of the input gradient are read by
+    the caller: the layers then work on that row block alone, here and in the second-order pass (GEMMs over m instead of 3m rows); the
+    other rows of the full-size gradient tensors they hand to autograd are left UNWRITTEN."""
+
+    def __init__(self, row_start=0):
+        self.row_start = int(row_start)
 
     def __enter__(self):
-        _INPUT_GRAD_ONLY[0] = True
+        _INPUT_GRAD_ONLY[0], _INPUT_GRAD_ONLY[1] = True, self.row_start
 
     def __exit__(self, *a):
-        _INPUT_GRAD_ONLY[0] = False
+        _INPUT_GRAD_ONLY[0], _INPUT_GRAD_ONLY[1] = False, 0
+
+
+_PARAM_GRAD_ONLY = [False]
+
+
+class param_grad_only:
+    """Context for the `backward()` of the total loss: nobody reads the gradient w.r.t. the network INPUT (the discriminator's demo
+    rows are a leaf only for the penalty's `autograd.grad`), so the first twice-differentiable layer skips its input-gradient GEMM
+    (12288 x 1024 x 1960 per step)."""
+
+    def __enter__(self):
+        _PARAM_GRAD_ONLY[0] = True
+
+    def __exit__(self, *a):
+        _PARAM_GRAD_ONLY[0] = False
+
+
+_placeholders = {}
+
+
+def _placeholder(like):
+    """A constant zero-dim tensor for Function outputs nobody reads (a fresh alias per call: no fill launch)."""
+    key = (like.dtype, like.device)
+    if key not in _placeholders:
+        _placeholders[key] = torch.zeros((), dtype=like.dtype, device=like.device)
+    return _placeholders[key].detach()
+
+
+def _relu_mask(g, y, out=None):
+    """g where y > 0 else 0 (the ReLU's backward), optionally into `out`."""
+    if out is None:
+        return torch.ops.aten.threshold_backward(g, y, 0.0)
+    return torch.ops.aten.threshold_backward.grad_input(g, y, 0.0, grad_input=out)
 
 
 class _LinearDDFn(torch.autograd.Function):
@@ -191,6 +231,7 @@ class _LinearDDFn(torch.autograd.Function):
         xb = x.to(torch.bfloat16)
         y = torch._addmm_activation(bb, xb, wb.t()) if relu else torch.addmm(bb, xb, wb.t())
         ctx.relu = relu
+        ctx.x_is_net_input = type(x.grad_fn).__name__.startswith("_RowsWithGradFn")
         if relu:
             ctx.save_for_backward(x, weight, bias, y)
         else:
@@ -203,47 +244,71 @@ class _LinearDDFn(torch.autograd.Function):
             x, weight, bias, y = ctx.saved_tensors
         else:
             (x, weight, bias), y = ctx.saved_tensors, None
-        only_x = _INPUT_GRAD_ONLY[0]
-        gx, gw, gb = _LinearDDBwdFn.apply(gy, x, weight, bias, ctx.needs_input_grad[0], only_x, y)
-        out = (gx if ctx.needs_input_grad[0] else None, None if only_x else gw, None if only_x else gb)
+        only_x, r0 = _INPUT_GRAD_ONLY
+        need_gx = ctx.needs_input_grad[0] and not (_PARAM_GRAD_ONLY[0] and ctx.x_is_net_input)
+        gx, gw, gb = _LinearDDBwdFn.apply(gy, x, weight, bias, need_gx, only_x, y, r0 if only_x else 0)
+        out = (gx if need_gx else None, None if only_x else gw, None if only_x else gb)
         return out + ((None,) if len(ctx.needs_input_grad) > 3 else ())
 
 
 class _LinearDDBwdFn(torch.autograd.Function):
     """(gy, x, W[, y]) -> gz = gy (masked by y > 0 when the layer carries its ReLU), gx = gz W, gW = gz^T x, gb = 1^T gz; its own
-    backward for cotangents (ggx, ggW, ggb):  d gz = ggx W^T + x ggW^T + ggb,  d gy = mask * d gz,  d x = gz ggW,  d W = gz^T ggx."""
+    backward for cotangents (ggx, ggW, ggb):  d gz = ggx W^T + x ggW^T + ggb,  d gy = mask * d gz,  d x = gz ggW,  d W = gz^T ggx.
+    `only_x` (inside input_grad_only): gx alone, over the rows [r0, n) -- see input_grad_only."""
 
     @staticmethod
-    def forward(ctx, gy, x, weight, bias, need_gx, only_x, y=None):
+    def forward(ctx, gy, x, weight, bias, need_gx, only_x, y=None, r0=0):
         gy = gy.contiguous()
-        xb = x.to(torch.bfloat16)
         wb, _ = _bf16_params(weight, bias)
+        ctx.x_dtype, ctx.need_gx, ctx.only_x, ctx.masked, ctx.r0, ctx.rows = x.dtype, need_gx, only_x, y is not None, r0, gy.shape[0]
+        ctx.set_materialize_grads(False)   # cotangents nobody produced arrive as None, not as zeros
+        if only_x:
+            gz = gy[r0:]
+            if y is not None:
+                y = y[r0:]
+                gz = _relu_mask(gz, y)
+            ctx.save_for_backward(gz, wb, *([y] if y is not None else []))
+            if need_gx:
+                gx = torch.empty((gy.shape[0], wb.shape[1]), dtype=torch.bfloat16, device=gy.device)
+                torch.mm(gz, wb, out=gx[r0:])
+                gx = gx.to(x.dtype)
+            else:
+                gx = _placeholder(gy)
+            pw, pb = _placeholder(gy), _placeholder(gy)
+            ctx.mark_non_differentiable(pw, pb)
+            return gx, pw, pb
+        xb = x.to(torch.bfloat16)
         gb = None
         if y is not None:
-            if only_x or gy.dtype != torch.bfloat16:
-                gy = torch.ops.aten.threshold_backward(gy, y, 0.0)
+            if gy.dtype != torch.bfloat16:
+                gy = _relu_mask(gy, y)
             else:
                 gy, gb = colsum_relu_bf16(gy, y)          # mask + bias gradient in one pass
-            ctx.save_for_backward(gy, xb, wb, y)
+            ctx.save_for_backward(gy, wb, xb, y)
         else:
-            ctx.save_for_backward(gy, xb, wb)
-        ctx.x_dtype, ctx.need_gx, ctx.only_x, ctx.masked = x.dtype, need_gx, only_x, y is not None
-        ctx.set_materialize_grads(False)   # cotangents nobody produced arrive as None, not as zeros
-        gx = (gy @ wb).to(x.dtype) if need_gx else gy.new_zeros(())
-        if only_x:
-            return gx, gy.new_zeros(()), gy.new_zeros(())
+            ctx.save_for_backward(gy, wb, xb)
+        gx = (gy @ wb).to(x.dtype) if need_gx else _placeholder(gy)
         return gx, wgrad_split_k(gy, xb), (gb if gb is not None else colsum_bf16(gy))
 
     @staticmethod
     @once_differentiable
     def backward(ctx, ggx, ggw, ggb):
-        if ctx.masked:
-            gy, xb, wb, y = ctx.saved_tensors
-        else:
-            (gy, xb, wb), y = ctx.saved_tensors, None
+        saved = ctx.saved_tensors
+        gy, wb = saved[0], saved[1]
+        y = saved[-1] if ctx.masked else None
+        r0 = ctx.r0
         d_gy = d_x = d_w = None
-        if ctx.only_x:   # the weight / bias outputs were placeholders
-            ggw = ggb = None
+        if ctx.only_x:   # the weight / bias outputs were placeholders; gy, y are the row block [r0, n)
+            if ggx is not None and ctx.need_gx:
+                ggx = ggx[r0:].to(torch.bfloat16).contiguous()
+                d_w = wgrad_split_k(gy, ggx)
+                d_gy = torch.empty((ctx.rows, wb.shape[0]), dtype=torch.bfloat16, device=gy.device)   # rows [0, r0) stay unwritten
+                if y is not None:
+                    _relu_mask(ggx @ wb.t(), y, out=d_gy[r0:])
+                else:
+                    torch.mm(ggx, wb.t(), out=d_gy[r0:])
+            return d_gy, None, d_w, None, None, None, None, None
+        xb = saved[2]
         if ggx is not None and ctx.need_gx:
             ggx = ggx.to(torch.bfloat16).contiguous()
             d_gy = ggx @ wb.t()
@@ -257,8 +322,8 @@ class _LinearDDBwdFn(torch.autograd.Function):
             t = ggb.to(torch.bfloat16).expand_as(gy)
             d_gy = t if d_gy is None else d_gy + t
         if y is not None and d_gy is not None:
-            d_gy = torch.ops.aten.threshold_backward(d_gy.contiguous(), y, 0.0)
-        return d_gy, d_x, d_w, None, None, None, None
+            d_gy = _relu_mask(d_gy.contiguous(), y)
+        return d_gy, d_x, d_w, None, None, None, None, None
 
 
 def _device_training_pass(mod, x):
@@ -319,6 +384,84 @@ class _Linear1Fn(torch.autograd.Function):
                                          weight.grad.data_ptr() if direct else gwb.data_ptr(), ws.data_ptr(), _stream(xb.device)), "phc_linear1_backward")
         gx = gx.to(ctx.x_dtype) if gx is not None else None
         return (gx, None, None) if direct else (gx, gwb[:cols].view(1, cols), gwb[cols:])
+
+
+class _Linear1DDFn(torch.autograd.Function):
+    """The discriminator's logit layer (one output, differentiated twice by the gradient penalty) on the phc_linear1_* kernels:
+    hipBLASLt ran this 512 -> 1 layer as five skinny GEMMs per step (~175 us: 12288 x 512 x 1 and its transposes)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        wb, bb = _bf16_params(weight, bias)
+        ctx.save_for_backward(x, weight, bias)
+        return _linear1_forward(x.to(torch.bfloat16), wb, bb)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, bias = ctx.saved_tensors
+        only_x, r0 = _INPUT_GRAD_ONLY
+        gx, gw, gb = _Linear1DDBwdFn.apply(gy, x, weight, bias, only_x, r0 if only_x else 0)
+        return gx if ctx.needs_input_grad[0] else None, None if only_x else gw, None if only_x else gb
+
+
+class _Linear1DDBwdFn(torch.autograd.Function):
+    """(gy [n, 1], x [n, K], w [1, K]) -> gx = gy w, gw = gy^T x, gb = 1^T gy; second order (the penalty path only: cotangent ggx on
+    gx):  d w = gy^T ggx,  d gy = ggx w^T."""
+
+    @staticmethod
+    def forward(ctx, gy, x, weight, bias, only_x, r0=0):
+        lib = L.load()
+        gy = gy.to(torch.bfloat16).contiguous()
+        wb, _ = _bf16_params(weight, bias)
+        rows, cols = x.shape
+        ctx.only_x, ctx.r0, ctx.rows, ctx.x_dtype = only_x, r0, rows, x.dtype
+        ctx.set_materialize_grads(False)
+        if only_x:
+            gys = gy[r0:]
+            ctx.save_for_backward(gys, wb)
+            gx = torch.empty((rows, cols), dtype=torch.bfloat16, device=x.device)   # rows [0, r0) stay unwritten
+            torch.mul(gys, wb, out=gx[r0:])
+            pw, pb = _placeholder(gy), _placeholder(gy)
+            ctx.mark_non_differentiable(pw, pb)
+            return gx.to(x.dtype), pw, pb
+        ctx.save_for_backward(gy, wb)
+        xb = x.to(torch.bfloat16)
+        gx = torch.empty_like(xb)
+        gwb = torch.empty(cols + 1, dtype=torch.float32, device=x.device)
+        ws = _workspace("lin1", lib.phc_linear1_workspace(rows, cols), x.device, torch.float32)
+        L.check(lib.phc_linear1_backward(xb.data_ptr(), wb.data_ptr(), gy.data_ptr(), rows, cols, gx.data_ptr(), gwb.data_ptr(), ws.data_ptr(),
+                                         _stream(x.device)), "phc_linear1_backward")
+        return gx.to(x.dtype), gwb[:cols].view(1, cols), gwb[cols:]
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, ggx, ggw, ggb):
+        if ggw is not None or ggb is not None:
+            raise NotImplementedError("second-order rule through the logit layer's weight / bias gradient")
+        if ggx is None:
+            return (None,) * 6
+        lib = L.load()
+        gy, wb = ctx.saved_tensors       # (only_x: the row block [r0, n))
+        g = ggx[ctx.r0:].to(torch.bfloat16).contiguous()
+        m, cols = g.shape
+        gwb = torch.empty(cols + 1, dtype=torch.float32, device=g.device)
+        ws = _workspace("lin1", lib.phc_linear1_workspace(m, cols), g.device, torch.float32)
+        L.check(lib.phc_linear1_backward(g.data_ptr(), wb.data_ptr(), gy.data_ptr(), m, cols, None, gwb.data_ptr(), ws.data_ptr(), _stream(g.device)),
+                "phc_linear1_backward")
+        d_gy = None
+        if ctx.needs_input_grad[0]:
+            d_gy = torch.zeros((ctx.rows, 1), dtype=torch.bfloat16, device=g.device)
+            d_gy[ctx.r0:] = (g.float() * wb.float()).sum(-1, keepdim=True).to(torch.bfloat16)
+        return d_gy, None, gwb[:cols].view(1, cols), None, None, None
+
+
+class FastLinear1DD(nn.Linear):
+    """nn.Linear(K, 1) that is differentiated twice (the discriminator's `_disc_logits`): see _Linear1DDFn."""
+
+    def forward(self, x):
+        if self.out_features == 1 and _device_training_pass(self, x) and x.dtype == torch.bfloat16:
+            return _Linear1DDFn.apply(x, self.weight, self.bias)
+        return nn.functional.linear(x, self.weight, self.bias)
 
 
 class FastLinear(nn.Linear):
@@ -407,6 +550,22 @@ def ppo_loss(mu, value, logstd, actions, old_neglogp, adv, returns, old_values, 
     return _PPOLossFn.apply(mu, value, logstd, actions, old_neglogp, adv, returns, old_values if clip_value else None, old_mu, old_sigma, prm, unit_grad, row_index)
 
 
+class _TakeRowsFn(torch.autograd.Function):
+    """g[start:] whose backward leaves rows [0, start) of the full-size gradient unwritten (see input_grad_only(row_start))."""
+
+    @staticmethod
+    def forward(ctx, g, start):
+        ctx.start, ctx.rows = start, g.shape[0]
+        return g[start:]
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gg):
+        full = torch.empty((ctx.rows,) + tuple(gg.shape[1:]), dtype=gg.dtype, device=gg.device)
+        full[ctx.start:] = gg
+        return full, None
+
+
 class _RowsWithGradFn(torch.autograd.Function):
     """`buf` [n, A] already holds all rows (written in place by the normaliser); rows [start:] additionally ARE the leaf `rows_leaf`
     (same memory).  Forward is a view of `buf` -- no `torch.cat` of the discriminator's three input batches -- and backward hands the
@@ -415,10 +574,15 @@ class _RowsWithGradFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, buf, rows_leaf, start):
         ctx.start = start
+        ctx.set_materialize_grads(False)
         return buf.view_as(buf)
 
     @staticmethod
     def backward(ctx, g):
+        if g is None:     # (param_grad_only: the first layer formed no input gradient)
+            return None, None, None
+        if _INPUT_GRAD_ONLY[0] and _INPUT_GRAD_ONLY[1] == ctx.start and ctx.start > 0:
+            return None, _TakeRowsFn.apply(g, ctx.start), None
         return None, g[ctx.start:], None
 
 

@@ -15,7 +15,7 @@ import os
 import torch
 from torch import nn
 
-from .fast_ops import FastLinear, FastLinearDD, FusedReLU
+from .fast_ops import FastLinear, FastLinear1DD, FastLinearDD, FusedReLU
 
 DISC_LOGIT_INIT_SCALE = 1.0  # amp_network_builder.py:12
 
@@ -51,7 +51,7 @@ class A2CNetwork(nn.Module):
         self.mu = FastLinear(self.units[-1], actions_num)
         self.sigma = nn.Parameter(torch.full((actions_num,), float(space["sigma_init"]["val"]), dtype=torch.float32), requires_grad=False)
         self._disc_mlp = build_mlp(amp_input_shape[0], list(disc["units"]), disc["activation"], FastLinearDD)
-        self._disc_logits = nn.Linear(list(disc["units"])[-1], 1)
+        self._disc_logits = FastLinear1DD(list(disc["units"])[-1], 1)
         # initializer "default" leaves the weights at torch's Linear default; the builder then zeroes the bias of EVERY nn.Linear that
         # exists at that point -- actor_mlp, critic_mlp, value, mu (network_builder.py:277-284) -- and the AMP builder those of the
         # discriminator (amp_network_builder.py:230-249), logit layer U(-1,1).  PNN columns and the MCP composer are created after that

@@ -259,21 +259,26 @@ def test_row_index_variants_equal_gathered_inputs():
         assert torch.equal(p, q)
 
 
-@pytest.mark.parametrize("fused_relu", [False, True])
-def test_twice_differentiable_linear_matches_autograd(fused_relu):
+@pytest.mark.parametrize("mode", ["plain", "fused_relu", "agent_path"])
+def test_twice_differentiable_linear_matches_autograd(mode):
     """FastLinearDD (discriminator MLP): loss + gradient penalty -- which differentiates the backward pass -- give the same parameter
     gradients as nn.Linear under bf16 autocast, within bf16 GEMM accuracy of the fp64 result.  `fused_relu`: the pair FastLinearDD +
-    FusedReLU as network.build_mlp makes it (ReLU in the GEMM epilogue, its mask inside the twice-differentiable backward node)."""
-    from phc_amd.learning.fast_ops import FastLinearDD
+    FusedReLU as network.build_mlp makes it (ReLU in the GEMM epilogue, its mask inside the twice-differentiable backward node).
+    `agent_path`: additionally everything IMAmpAgent._fwd_bwd does around it -- the input is one buffer whose last row block is the
+    leaf (rows_with_grad), the logit layer is FastLinear1DD, the penalty's cotangent is a row mask over ALL logits inside
+    input_grad_only(row_start) (layers work on the demo rows alone and leave the other rows of their gradients unwritten), and the
+    loss backward runs inside param_grad_only()."""
+    from phc_amd.learning.fast_ops import FastLinear1DD, FastLinearDD, input_grad_only, param_grad_only, rows_with_grad
     from phc_amd.learning.network import build_mlp
     torch.manual_seed(3)
     B, m, K = 6144, 2048, 1960
+    fused_relu, agent_path = mode != "plain", mode == "agent_path"
 
     def build(linear, dtype=torch.float32):
         if fused_relu and linear is FastLinearDD:
             net = build_mlp(K, [1024, 512], "relu", FastLinearDD)
             assert net[0].fuse_relu and net[2].fuse_relu
-            net.append(torch.nn.Linear(512, 1))
+            net.append(FastLinear1DD(512, 1) if agent_path else torch.nn.Linear(512, 1))
             return net.cuda().to(dtype)
         net = torch.nn.Sequential(linear(K, 1024), torch.nn.ReLU(), linear(1024, 512), torch.nn.ReLU(), torch.nn.Linear(512, 1)).cuda().to(dtype)
         return net
@@ -285,26 +290,42 @@ def test_twice_differentiable_linear_matches_autograd(fused_relu):
     xa = (torch.randn(B - m, K, device="cuda") * 0.5).to(torch.bfloat16)
     xd = (torch.randn(m, K, device="cuda") * 0.5).to(torch.bfloat16)
 
-    def run(net, f64=False):
-        d = (xd.double() if f64 else xd.clone()).requires_grad_(True)
-        a = xa.double() if f64 else xa
-        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=not f64):
-            lg = net(torch.cat([a, d], 0))
-        lg = lg if f64 else lg.float()
-        la, ld = lg[:B - m], lg[B - m:]
+    def run(net, f64=False, agent=False):
         bce = torch.nn.BCEWithLogitsLoss()
+        if agent:
+            buf = torch.cat([xa, xd], 0)
+            d = buf[B - m:].requires_grad_(True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                raw = net(rows_with_grad(buf, d, B - m))
+            assert raw.dtype == torch.bfloat16
+            lg = raw.float()
+            mask = torch.zeros((B, 1), dtype=raw.dtype, device="cuda")
+            mask[B - m:] = 1
+            with input_grad_only(row_start=B - m):
+                g = torch.autograd.grad(raw, d, grad_outputs=mask, create_graph=True, retain_graph=True)[0].float()
+        else:
+            d = (xd.double() if f64 else xd.clone()).requires_grad_(True)
+            a = xa.double() if f64 else xa
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=not f64):
+                lg = net(torch.cat([a, d], 0))
+            lg = lg if f64 else lg.float()
+            with input_grad_only():
+                g = torch.autograd.grad(lg[B - m:], d, grad_outputs=torch.ones_like(lg[B - m:]), create_graph=True, retain_graph=True)[0]
+            g = g if f64 else g.float()
+        la, ld = lg[:B - m], lg[B - m:]
         loss = 0.5 * (bce(la, torch.zeros_like(la)) + bce(ld, torch.ones_like(ld)))
-        from phc_amd.learning.fast_ops import input_grad_only
-        with input_grad_only():
-            g = torch.autograd.grad(ld, d, grad_outputs=torch.ones_like(ld), create_graph=True, retain_graph=True)[0]
-        g = g if f64 else g.float()
         pen = g.square().sum(-1).mean()
-        (loss + 5.0 * pen).backward()
+        if agent:
+            with param_grad_only():
+                (loss + 5.0 * pen).backward()
+            assert d.grad is None      # the input gradient of the loss is not formed
+        else:
+            (loss + 5.0 * pen).backward()
         return float(loss), float(pen), [p.grad.double().clone() for p in net.parameters()]
     l64, p64, g64 = run(ref64, True)
     lr_, pr, gr = run(ref)
-    lf, pf, gf = run(fast)
-    assert abs(lf - lr_) < 1e-6 and abs(pf - pr) <= 2e-3 * abs(pr) + 1e-9, (lf, lr_, pf, pr)
+    lf, pf, gf = run(fast, agent=agent_path)
+    assert abs(lf - lr_) < (2e-4 if agent_path else 1e-6) and abs(pf - pr) <= 2e-3 * abs(pr) + 1e-9, (lf, lr_, pf, pr)   # (agent_path: bf16 logits from the one-output kernel)
     for k, (a, b, e) in enumerate(zip(gf, gr, g64)):
         scale = e.abs().max().item() + 1e-12
         ef, er = (a - e).abs().max().item() / scale, (b - e).abs().max().item() / scale
