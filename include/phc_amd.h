@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PHC_ABI_VERSION 19
+#define PHC_ABI_VERSION 20
 #define PHC_MAX_BODIES 64   /* bodies (incl. extended reference bodies) per articulation; also the slot count of the model tables */
 #define PHC_EINVAL (-1)
 #define PHC_EUNSUPPORTED (-2)
@@ -305,7 +305,8 @@ int32_t phc_colsum_relu_bf16(const void* gy, const void* y, int64_t rows, int32_
  *   grad [same shape / type] = d stats[0] / d logits.
  * phc_weighted_sumsq: out[0] = sum_i coefs[i] * |tensors[i]|^2 over count <= 4 device tensors of sizes[i] elements (all fp32 or all
  *   bf16): the logit regulariser + weight decay in one pass, or -- one bf16 tensor, coef = c / rows -- the gradient penalty
- *   c * mean_rows(sum_cols g^2).  workspace: phc_sumsq_workspace() bytes. */
+ *   c * mean_rows(sum_cols g^2).  out[1 + i] = |tensors[i]|^2 (ABI 20: `out` holds 1 + count floats; the last one of the weight call
+ *   is the reference's `disc_logit_loss`, amp_agent.py:757-758).  workspace: phc_sumsq_workspace() bytes. */
 int32_t phc_disc_bce(const void* logits, int32_t is_bf16, int32_t n_agent, int32_t n_demo, float scale, void* grad, float* stats,
                      void* stream);
 int64_t phc_sumsq_workspace(void);

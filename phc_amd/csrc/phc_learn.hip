@@ -481,9 +481,9 @@ __global__ __launch_bounds__(1024) void k_disc_bce(const T* __restrict__ logits,
 
 struct SumsqArgs { const void* ptr[4]; int64_t n[4]; float coef[4]; int count; int is_bf16; };
 #define SSM_BLOCKS 256
+// partial[t][block] = this block's share of |tensor t|^2 (unweighted)
 __global__ __launch_bounds__(256) void k_sumsq_multi(SumsqArgs a, double* __restrict__ partial) {
-    __shared__ double l[4];
-    double acc = 0.0;
+    __shared__ double l[4][4];
     for (int t = 0; t < a.count; ++t) {
         float s = 0.f;
         const int64_t n = a.n[t];
@@ -491,20 +491,28 @@ __global__ __launch_bounds__(256) void k_sumsq_multi(SumsqArgs a, double* __rest
             const float v = a.is_bf16 ? __bfloat162float(reinterpret_cast<const __hip_bfloat16*>(a.ptr[t])[i]) : reinterpret_cast<const float*>(a.ptr[t])[i];
             s += v * v;
         }
-        acc += (double)a.coef[t] * (double)s;
+        double acc = (double)s;
+        for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
+        if ((threadIdx.x & 63) == 0) l[t][threadIdx.x >> 6] = acc;
     }
-    for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
-    if ((threadIdx.x & 63) == 0) l[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) partial[blockIdx.x] = (l[0] + l[1]) + (l[2] + l[3]);
+    if (threadIdx.x < a.count) partial[threadIdx.x * SSM_BLOCKS + blockIdx.x] = (l[threadIdx.x][0] + l[threadIdx.x][1]) + (l[threadIdx.x][2] + l[threadIdx.x][3]);
 }
-__global__ __launch_bounds__(256) void k_sumsq_multi_finish(const double* __restrict__ partial, float* __restrict__ out) {
+// out[0] = sum_t coef[t] |tensor t|^2, out[1 + t] = |tensor t|^2
+__global__ __launch_bounds__(256) void k_sumsq_multi_finish(SumsqArgs a, const double* __restrict__ partial, float* __restrict__ out) {
     __shared__ double l[4];
-    double t = partial[threadIdx.x];   // SSM_BLOCKS == blockDim.x
-    for (int m = 32; m >= 1; m >>= 1) t += __shfl_xor(t, m, 64);
-    if ((threadIdx.x & 63) == 0) l[threadIdx.x >> 6] = t;
-    __syncthreads();
-    if (threadIdx.x == 0) out[0] = (float)((l[0] + l[1]) + (l[2] + l[3]));
+    double total = 0.0;
+    for (int t = 0; t < a.count; ++t) {
+        double v = partial[t * SSM_BLOCKS + threadIdx.x];   // SSM_BLOCKS == blockDim.x
+        for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) l[threadIdx.x >> 6] = v;
+        __syncthreads();
+        const double s = (l[0] + l[1]) + (l[2] + l[3]);
+        if (threadIdx.x == 0) out[1 + t] = (float)s;
+        total += (double)a.coef[t] * s;
+    }
+    if (threadIdx.x == 0) out[0] = (float)total;
 }
 
 extern "C" {
@@ -612,7 +620,7 @@ int32_t phc_disc_bce(const void* logits, int32_t is_bf16, int32_t n_agent, int32
     return e == hipSuccess ? 0 : (int32_t)e;
 }
 
-int64_t phc_sumsq_workspace(void) { return SSM_BLOCKS * (int64_t)sizeof(double); }
+int64_t phc_sumsq_workspace(void) { return 4 * SSM_BLOCKS * (int64_t)sizeof(double); }
 
 int32_t phc_weighted_sumsq(int32_t count, const void* const* tensors, const int64_t* sizes, const float* coefs, int32_t is_bf16, float* out,
                            double* workspace, void* stream) {
@@ -623,7 +631,7 @@ int32_t phc_weighted_sumsq(int32_t count, const void* const* tensors, const int6
     for (int t = 0; t < count; ++t) if (!a.ptr[t] || a.n[t] < 0) return PHC_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_sumsq_multi, dim3(SSM_BLOCKS), dim3(256), 0, st, a, workspace);
-    hipLaunchKernelGGL(k_sumsq_multi_finish, dim3(1), dim3(256), 0, st, workspace, out);
+    hipLaunchKernelGGL(k_sumsq_multi_finish, dim3(1), dim3(256), 0, st, a, workspace, out);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int32_t)e;
 }

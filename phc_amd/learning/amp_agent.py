@@ -146,9 +146,14 @@ class FlatGradBucket:
                 bucket._shadow_live[0] = False
         return _Scope()
 
-    def zero(self):
+    def zero(self, decay=None):
+        """`decay` [(parameter, c)]: start that parameter's gradient at c * parameter (an L2 term's gradient written in place instead of
+        being handed to autograd as a tensor to add)."""
         self.flat.zero_()
         self.gen += 1
+        for p, c in decay or ():
+            torch.mul(p.data, c, out=p.grad)
+            p._grad_gen = self.gen
 
     def all_reduce_mean(self, dist, force=False, timing=None):
         """The path's one collective.  `force`: issue it also in a one-rank group (exercises RCCL + the captured update on a 1-GPU box);
@@ -522,29 +527,43 @@ class IMAmpAgent:
         return {"disc_loss": disc_loss, "disc_grad_penalty": disc_grad_penalty.detach(), "disc_logit_loss": disc_logit_loss.detach(),
                 "disc_agent_acc": (disc_agent_logit < 0).float().mean().detach(), "disc_demo_acc": (disc_demo_logit > 0).float().mean().detach()}
 
+    # Every scalar the fused loss kernels produce lands in ONE fp32 vector (`_raw`), which a graphed step adds to its accumulator
+    # in one launch; the info dict is derived from it outside the step (all entries are linear in it).  Layout, nw = number of
+    # discriminator weight matrices:  [0:6] phc_ppo_loss (loss, a_loss, c_loss, b_loss, entropy, kl) | [6:9] phc_disc_bce (k * bce,
+    # agent acc, demo acc) | [9:10+nw] weight terms (k * (decay + logit reg), |W_i|^2 ...) | [10+nw:12+nw] penalty (k * pen, |grad|^2).
+    def _raw_buffer(self):
+        nw = len(self.model.a2c_network.get_disc_weights_raw())
+        if getattr(self, "_raw", None) is None or self._raw.numel() != 12 + nw:
+            self._raw = torch.zeros(12 + nw, dtype=torch.float32, device=self.device)
+        return self._raw, nw
+
+    def _info_from_raw(self, raw):
+        nw = raw.numel() - 12
+        k = self._disc_coef
+        return {"actor_loss": raw[1], "critic_loss": raw[2], "b_loss": raw[3], "entropy": raw[4], "kl": raw[5],
+                "disc_loss": (raw[6] + raw[9] + raw[10 + nw]) / k, "disc_grad_penalty": raw[10 + nw] / (self._disc_grad_penalty * k),
+                "disc_logit_loss": raw[9 + nw], "disc_agent_acc": raw[7], "disc_demo_acc": raw[8]}
+
     def _disc_loss_fused(self, logits, m, obs_demo):
         """`_disc_loss` on the device with the pieces as kernels (fast_ops.disc_bce / weighted_sumsq): every term already carries
-        `disc_coef` and enters the total loss with weight one.  `logits` [3m, 1]: agent, replay, demo rows."""
+        `disc_coef` and enters the total loss with weight one.  `logits` [3m, 1]: agent, replay, demo rows.
+        -> (the three loss terms, [(weight, c)] whose gradient c * weight is to be preloaded by FlatGradBucket.zero)."""
         net = self.model.a2c_network
         k = self._disc_coef
-        bce, acc = disc_bce(logits, 2 * m, k)
+        raw, nw = self._raw_buffer()
+        bce, _ = disc_bce(logits, 2 * m, k, out=raw[6:9])
         ws = [p for p in net.get_disc_weights_raw()]
         coefs = [self._disc_weight_decay * k] * len(ws)
         coefs[-1] += self._disc_logit_reg * k   # the logit layer: regulariser + weight decay
-        l2 = weighted_sumsq(ws, coefs)
+        preload = all(getattr(w, "_bucket", None) is self.grads for w in ws)
+        l2 = weighted_sumsq(ws, coefs, out=raw[9:10 + nw], preloaded=preload)
         # d(sum of the demo logits) / d(demo rows): cotangent = [0; 0; 1] over the [agent; replay; demo] logits, and the layers are told
         # that only the last row block carries anything (GEMMs over m instead of 3m rows, here and in the second-order pass)
         with input_grad_only(row_start=2 * m):
             grad = torch.autograd.grad(logits, obs_demo, grad_outputs=self._demo_row_mask(m, logits), create_graph=True, retain_graph=True,
                                        only_inputs=True)[0]
-        pen = weighted_sumsq([grad], [self._disc_grad_penalty * k / m])
-        total = bce + l2 + pen
-        with torch.no_grad():
-            logit_w = net.get_disc_logit_weights()
-            disc_logit_loss = torch.sum(torch.square(logit_w))
-            info = {"disc_loss": total / k, "disc_grad_penalty": pen / (self._disc_grad_penalty * k), "disc_logit_loss": disc_logit_loss,
-                    "disc_agent_acc": acc[0], "disc_demo_acc": acc[1]}
-        return total, info
+        pen = weighted_sumsq([grad], [self._disc_grad_penalty * k / m], out=raw[10 + nw:12 + nw])
+        return [bce, l2, pen], ([(w, 2.0 * c) for w, c in zip(ws, coefs)] if preload else None)
 
     def _demo_row_mask(self, m, like):
         key = (m, like.dtype, like.device)
@@ -554,8 +573,9 @@ class IMAmpAgent:
             self._ones_key, self._ones = key, mask
         return self._ones
 
-    def _fwd_bwd(self, d):
-        """Forward + losses + backward into the flat gradient bucket (amp_agent.py:554-655); no host sync."""
+    def _fwd_bwd(self, d, want_info=True):
+        """Forward + losses + backward into the flat gradient bucket (amp_agent.py:554-655); no host sync.  `want_info=False` (the
+        captured step): when all scalars are in `self._raw` the info dict is not built (it would cost launches)."""
         idx = amp_idx = None
         if "_dataset" in d:   # device: minibatch = (dataset, row index); the kernels below read the rows in place
             d, idx, amp_idx = d["_dataset"], d["_idx"], d["_amp_idx"]
@@ -582,26 +602,43 @@ class IMAmpAgent:
                    "amp_obs_demo": amp_obs_demo, "raw_disc_logits": False}
         with self._autocast():
             res = self.model.forward_heads(inp) if fused else self.model(inp)
+        decay = None
         if fused_disc:
-            disc_term, disc_info = self._disc_loss_fused(res["disc_logits"], amp_obs.shape[0], amp_obs_demo)
+            roots, decay = self._disc_loss_fused(res["disc_logits"], amp_obs.shape[0], amp_obs_demo)
+            disc_info = None
         else:
             disc_info = self._disc_loss(torch.cat([res["disc_agent_logit"], res["disc_agent_replay_logit"]], dim=0), res["disc_demo_logit"], amp_obs_demo)
-            disc_term = self._disc_coef * disc_info["disc_loss"]
+            roots = [self._disc_coef * disc_info["disc_loss"]]
         if fused:
             # actor / critic losses and their gradients w.r.t. the two heads: one HIP pass (phc_ppo_loss) instead of ~100 launches
             ppo, st = ppo_loss(res["mu"].contiguous(), res["value"].contiguous(), res["logstd"], d["actions"], d["old_logp_actions"], d["advantages"],
                                d["returns"], d["old_values"], d["mu"], d["sigma"], self.e_clip, self.critic_coef, self.entropy_coef,
-                               self.bounds_loss_coef, self.clip_value, unit_grad=True, row_index=idx)
-            loss = ppo + disc_term   # `ppo` (and the fused discriminator terms) enter with weight one (unit_grad)
-            info = {"actor_loss": st[0], "critic_loss": st[1], "b_loss": st[2], "entropy": st[3], "kl": st[4]}
+                               self.bounds_loss_coef, self.clip_value, unit_grad=True, row_index=idx, out=self._raw_buffer()[0][0:6])
+            # `ppo` and the fused discriminator terms enter the total with weight one (unit_grad): they are the roots of ONE backward
+            # pass with constant unit cotangents -- no sum node, no fill launches
+            roots = [ppo] + roots
+            info = None if fused_disc else {"actor_loss": st[0], "critic_loss": st[1], "b_loss": st[2], "entropy": st[3], "kl": st[4]}
+            self.grads.zero(decay)
+            with param_grad_only():
+                torch.autograd.backward(roots, grad_tensors=[self._unit_cotangent(r) for r in roots])
         else:
             assert idx is None
             loss, info = self._ppo_loss_torch(res, d, disc_info)
-        self.grads.zero()
-        with param_grad_only():
+            self.grads.zero()
             loss.backward()
+        if info is None:   # everything is in the raw vector
+            return self._info_from_raw(self._raw.clone()) if want_info else None   # (a copy: the next step overwrites `_raw`)
         info.update({k: (v.detach() if torch.is_tensor(v) else v) for k, v in disc_info.items()})
         return info
+
+    def _unit_cotangent(self, like):
+        key = (like.dtype, like.device)
+        c = getattr(self, "_unit_cot", None)
+        if c is None:
+            c = self._unit_cot = {}
+        if key not in c:
+            c[key] = torch.ones((), dtype=like.dtype, device=like.device)
+        return c[key]
 
     def _ppo_loss_torch(self, res, d, disc_info):
         """The actor / critic losses as torch expressions (amp_agent.py:598-640): the CPU path and the definition `phc_ppo_loss` is
@@ -689,7 +726,13 @@ class IMAmpAgent:
         return self._g_data
 
     def _graph_step_body(self):
-        info = self._fwd_bwd({"_dataset": self._g_data, "_idx": self._g_idx, "_amp_idx": self._g_idx[:self._amp_minibatch_size]})
+        info = self._fwd_bwd({"_dataset": self._g_data, "_idx": self._g_idx, "_amp_idx": self._g_idx[:self._amp_minibatch_size]}, want_info=False)
+        if info is None:     # raw vector of the fused kernels (see _raw_buffer): one launch
+            self._g_keys = None
+            if self._g_info.numel() != self._raw.numel():
+                self._g_info = torch.zeros_like(self._raw)
+            self._g_info += self._raw
+            return
         self._g_keys = list(info)
         self._g_info += torch.stack([info[k].float().reshape(()) for k in self._g_keys])
 
@@ -743,6 +786,8 @@ class IMAmpAgent:
                 self._clip_and_step()
                 n += 1
         mean = self._g_info / n
+        if self._g_keys is None:
+            return self._info_from_raw(mean)
         return {k: mean[j] for j, k in enumerate(self._g_keys)}
 
     def _probe_info_keys(self):

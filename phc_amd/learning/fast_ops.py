@@ -511,7 +511,7 @@ class _PPOLossFn(torch.autograd.Function):
     gradient is then 1 and the stored gradients are returned as they are (no extra pass over [B, D])."""
 
     @staticmethod
-    def forward(ctx, mu, value, logstd, actions, old_neglogp, adv, returns, old_values, old_mu, old_sigma, prm, unit_grad, row_index):
+    def forward(ctx, mu, value, logstd, actions, old_neglogp, adv, returns, old_values, old_mu, old_sigma, prm, unit_grad, row_index, out=None):
         lib = L.load()
         B, D = mu.shape
         assert value.numel() == B and mu.dtype == value.dtype and mu.dtype in (torch.bfloat16, torch.float32)
@@ -520,7 +520,8 @@ class _PPOLossFn(torch.autograd.Function):
         logstd, actions, old_neglogp, adv, returns, old_mu, old_sigma = map(f32, (logstd, actions, old_neglogp, adv, returns, old_mu, old_sigma))
         old_values = f32(old_values) if old_values is not None else None
         gmu, gval = torch.empty_like(mu), torch.empty_like(value)
-        buf = torch.empty(6, dtype=torch.float32, device=mu.device)
+        buf = torch.empty(6, dtype=torch.float32, device=mu.device) if out is None else out
+        assert buf.numel() == 6 and buf.dtype == torch.float32 and buf.is_contiguous()
         ws = _workspace("ppo", lib.phc_ppo_loss_workspace(), mu.device, torch.float64)
         p = L.PpoParams(float(prm["e_clip"]), float(prm["critic_coef"]), float(prm["entropy_coef"]), float(prm["bounds_loss_coef"]), int(prm["clip_value"]))
         L.check(lib.phc_ppo_loss(mu.data_ptr(), value.data_ptr(), int(mu.dtype == torch.bfloat16), logstd.data_ptr(), actions.data_ptr(),
@@ -529,6 +530,7 @@ class _PPOLossFn(torch.autograd.Function):
                                  ws.data_ptr(), _stream(mu.device)), "phc_ppo_loss")
         ctx.save_for_backward(gmu, gval)
         ctx.unit_grad = unit_grad
+        ctx.set_materialize_grads(False)
         loss, stats = buf.narrow(0, 0, 1).view(()), buf.narrow(0, 1, 5)   # disjoint views of the kernel's output
         ctx.mark_non_differentiable(stats)
         return loss, stats
@@ -539,15 +541,17 @@ class _PPOLossFn(torch.autograd.Function):
         gmu, gval = ctx.saved_tensors
         if not ctx.unit_grad:
             gmu, gval = gmu * g_loss.to(gmu.dtype), gval * g_loss.to(gval.dtype)
-        return (gmu, gval) + (None,) * 11
+        return (gmu, gval) + (None,) * 12
 
 
 def ppo_loss(mu, value, logstd, actions, old_neglogp, adv, returns, old_values, old_mu, old_sigma, e_clip, critic_coef, entropy_coef,
-             bounds_loss_coef, clip_value, unit_grad=False, row_index=None):
+             bounds_loss_coef, clip_value, unit_grad=False, row_index=None, out=None):
     """-> (loss, stats[5] = a_loss, c_loss, b_loss, entropy, kl); mu [B, D] / value [B, 1] are the (bf16 or fp32) network heads;
-    with `row_index` [B] the rollout tensors (actions ... old_sigma) are the whole dataset and row r of the minibatch is row_index[r]."""
+    with `row_index` [B] the rollout tensors (actions ... old_sigma) are the whole dataset and row r of the minibatch is row_index[r];
+    `out`: fp32 [6] that receives [loss, stats] (the results are views of it)."""
     prm = dict(e_clip=e_clip, critic_coef=critic_coef, entropy_coef=entropy_coef, bounds_loss_coef=bounds_loss_coef or 0.0, clip_value=bool(clip_value))
-    return _PPOLossFn.apply(mu, value, logstd, actions, old_neglogp, adv, returns, old_values if clip_value else None, old_mu, old_sigma, prm, unit_grad, row_index)
+    return _PPOLossFn.apply(mu, value, logstd, actions, old_neglogp, adv, returns, old_values if clip_value else None, old_mu, old_sigma, prm, unit_grad,
+                            row_index, out)
 
 
 class _TakeRowsFn(torch.autograd.Function):
@@ -595,12 +599,14 @@ class _DiscBCEFn(torch.autograd.Function):
     logits in one launch (`phc_disc_bce`).  Unit-weight convention as `_PPOLossFn`: the result is added to the total loss as it is."""
 
     @staticmethod
-    def forward(ctx, logits, n_agent, scale):
+    def forward(ctx, logits, n_agent, scale, out=None):
         lib = L.load()
         n = logits.shape[0]
         assert logits.is_contiguous() and logits.numel() == n and logits.dtype in (torch.bfloat16, torch.float32)
         grad = torch.empty_like(logits)
-        stats = torch.empty(3, dtype=torch.float32, device=logits.device)
+        stats = torch.empty(3, dtype=torch.float32, device=logits.device) if out is None else out
+        assert stats.numel() == 3 and stats.dtype == torch.float32 and stats.is_contiguous()
+        ctx.set_materialize_grads(False)
         L.check(lib.phc_disc_bce(logits.data_ptr(), int(logits.dtype == torch.bfloat16), n_agent, n - n_agent, float(scale), grad.data_ptr(), stats.data_ptr(),
                                  _stream(logits.device)), "phc_disc_bce")
         ctx.save_for_backward(grad)
@@ -612,49 +618,61 @@ class _DiscBCEFn(torch.autograd.Function):
     @once_differentiable
     def backward(ctx, g, _):
         (grad,) = ctx.saved_tensors
-        return grad, None, None
+        return grad, None, None, None
 
 
-def disc_bce(logits, n_agent, scale=1.0):
-    """-> (scale * 0.5 (bce(agent, 0) + bce(demo, 1)), [agent_acc, demo_acc]); logits [n, 1]: agent (+ replay) rows first, demo rows last."""
-    return _DiscBCEFn.apply(logits, n_agent, scale)
+def disc_bce(logits, n_agent, scale=1.0, out=None):
+    """-> (scale * 0.5 (bce(agent, 0) + bce(demo, 1)), [agent_acc, demo_acc]); logits [n, 1]: agent (+ replay) rows first, demo rows last;
+    `out`: fp32 [3] that receives [loss, accuracies] (the results are views of it)."""
+    return _DiscBCEFn.apply(logits, n_agent, scale, out)
 
 
-def _weighted_sumsq(tensors, coefs):
+def _weighted_sumsq(tensors, coefs, out=None):
+    """-> fp32 [1 + n]: [sum_i coefs[i] |t_i|^2, |t_0|^2, ...] (into `out` when given)"""
     lib = L.load()
     dev = tensors[0].device
     is_bf16 = tensors[0].dtype == torch.bfloat16
     for t in tensors:
         assert t.is_contiguous() and t.device == dev and t.dtype == tensors[0].dtype and t.dtype in (torch.bfloat16, torch.float32)
     n = len(tensors)
-    out = torch.empty(1, dtype=torch.float32, device=dev)
+    if out is None:
+        out = torch.empty(1 + n, dtype=torch.float32, device=dev)
+    assert out.numel() == 1 + n and out.dtype == torch.float32 and out.is_contiguous()
     ws = _workspace("sumsq", lib.phc_sumsq_workspace(), dev, torch.float64)
     ptrs = (C.c_void_p * n)(*[t.data_ptr() for t in tensors])
     sizes = (C.c_int64 * n)(*[t.numel() for t in tensors])
     cf = (C.c_float * n)(*[float(c) for c in coefs])
     L.check(lib.phc_weighted_sumsq(n, ptrs, sizes, cf, int(is_bf16), out.data_ptr(), ws.data_ptr(), _stream(dev)), "phc_weighted_sumsq")
-    return out.view(())
+    return out
 
 
 class _WeightedSumsqFn(torch.autograd.Function):
     """sum_i coefs[i] |t_i|^2 over up to four tensors in two launches (`phc_weighted_sumsq`); gradient 2 coefs[i] t_i.  Unit-weight
-    convention: the result enters the total loss as it is."""
+    convention: the result enters the total loss as it is.  `preloaded`: the caller has already put 2 coefs[i] t_i into the
+    gradient buffers (FlatGradBucket.zero(decay=...)), backward returns nothing."""
 
     @staticmethod
-    def forward(ctx, coefs, *tensors):
+    def forward(ctx, coefs, out, preloaded, *tensors):
         ctx.save_for_backward(*tensors)
-        ctx.coefs = [float(c) for c in coefs]
-        return _weighted_sumsq(tensors, coefs)
+        ctx.coefs, ctx.preloaded = [float(c) for c in coefs], preloaded
+        ctx.set_materialize_grads(False)
+        buf = _weighted_sumsq(tensors, coefs, out)
+        total, parts = buf.narrow(0, 0, 1).view(()), buf.narrow(0, 1, len(tensors))
+        ctx.mark_non_differentiable(parts)
+        return total, parts
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, g):
+    def backward(ctx, g, _):
         ts = ctx.saved_tensors
-        return (None,) + tuple(t * (2.0 * c) for t, c in zip(ts, ctx.coefs))   # (torch._foreach_mul: 49 us for these three tensors)
+        if ctx.preloaded:
+            return (None,) * (3 + len(ts))
+        return (None, None, None) + tuple(t * (2.0 * c) for t, c in zip(ts, ctx.coefs))   # (torch._foreach_mul: 49 us for these three tensors)
 
 
-def weighted_sumsq(tensors, coefs):
-    return _WeightedSumsqFn.apply(list(coefs), *tensors)
+def weighted_sumsq(tensors, coefs, out=None, preloaded=False, parts=False):
+    total, p = _WeightedSumsqFn.apply(list(coefs), out, preloaded, *tensors)
+    return (total, p) if parts else total
 
 
 def policy_sample(mu, value, logstd, value_norm, out_actions, out_mus, out_sigmas, out_neglogp, out_values, mask=None):
