@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PHC_ABI_VERSION 20
+#define PHC_ABI_VERSION 21
 #define PHC_MAX_BODIES 64   /* bodies (incl. extended reference bodies) per articulation; also the slot count of the model tables */
 #define PHC_EINVAL (-1)
 #define PHC_EUNSUPPORTED (-2)
@@ -47,6 +47,13 @@ typedef struct {
     int32_t split_level;      /* two-slot stepper mapping: bodies of tree levels < split_level share lanes with the deeper ones; */
     int32_t num_below_split;  /* -1 / 0 when the tree has no split with both halves <= 16 (NB <= 32) or <= 32 bodies (ArticulationModel.two_slot_split) */
     int32_t num_collision_pairs; /* body pairs that may collide (listed after the int tables); capacity 576 (NB <= 32) / 1152, see phc_sim_step */
+    /* Per-env body shapes (robot.has_shape_variation, humanoid.py:726-766,824-866): K compiled articulations with ONE topology (names,
+     * parents, joint types) but their own link offsets, masses, inertias, gains, collision geometry.  ints / floats then hold K blocks
+     * int_stride / float_stride elements apart, phc_sim_state_t.env_shape picks an env's block, and the scalar fields above are the
+     * maxima over the shapes.  num_shapes <= 1: one model for all envs. */
+    int32_t num_shapes;
+    int32_t int_stride;
+    int32_t float_stride;
 } phc_model_t;
 
 /* Flat reference-motion buffer.  Replaces MotionLibBase's gts/grs/lrs/gvs/gavs/dvs tensors
@@ -83,6 +90,7 @@ typedef struct {
                                          the sensor body's LOCAL frame (create_humanoid_force_sensors :1031-1040: identity pose on the
                                          body, use_world_frame False); nullable.  Written by phc_sim_step at the end of the step: the net
                                          ground-contact wrench on the body about its origin (PhysX's reading is closed: parity unpinned) */
+    const int32_t* env_shape;         /* [N] shape block of each env (phc_model_t.num_shapes > 1); nullable = block 0 */
 } phc_sim_state_t;
 
 /* Solver parameters.  Replaces gymapi.SimParams as filled by parse_sim_params
@@ -158,6 +166,18 @@ typedef struct {
     int32_t num_force_sensors;        /* S of phc_sim_state_t.force_sensor (self_obs_v 3) */
     int32_t amp_obs_v;                /* 1 (0 is read as 1): build_amp_observations_smpl; 2: `_v2` (humanoid_amp.py:1015-1059) = the same followed by the
                                          key bodies' heading-local velocities [3 K] (num_amp_obs_per_step grows by 3 K, :303) */
+    int32_t remove_base_rot;          /* robot.has_upright_start False: the observation functions strip the asset's base rotation (0.5,0.5,0.5,0.5)
+                                         from the root rotation before taking the heading (`remove_base_rot`, humanoid.py:1936-1939 and every
+                                         `if not upright:` of humanoid.py / humanoid_amp.py / humanoid_im.py) */
+    int32_t num_self_obs_extra;       /* per-env constant columns at the end of the self observation: body-shape parameters
+                                         (robot.has_shape_obs, humanoid.py:669-673,2043-2044) then limb weights (has_weight_obs, :676,2046-2047);
+                                         counted in num_self_obs */
+    int32_t num_amp_obs_extra;        /* the same at the end of every AMP step (has_shape_obs_disc / has_weight_obs_disc, humanoid_amp.py:1005-1008);
+                                         counted in num_amp_obs_per_step */
+    const float* self_obs_extra;      /* [N, num_self_obs_extra] row of the env */
+    const float* amp_obs_extra;       /* [N, num_amp_obs_extra] row of the env (observations from simulator state) or of the MOTION (observations
+                                         built from the reference clip: the clip carries its humanoid's shape, motion_lib_base.py:244,
+                                         humanoid_amp.py:253-284,575-603) -- the same row, clip i belongs to env i */
 } phc_im_params_t;
 
 /* Task-owned per-env buffers (phc/env/tasks/base_task.py:99-105, humanoid_amp.py:109-116,

@@ -13,13 +13,15 @@ using namespace phc;
 
 // Stepper: same phase sequence as k_sim_step, lanes looped inside each phase.
 template <int JT>
-static int emu_sim_step_t(const phc_model_t* model, const phc_sim_params_t* prm, const phc_sim_state_t* sim, const float* actions,
+static int emu_sim_step_t(const phc_model_t* model_all, const phc_sim_params_t* prm, const phc_sim_state_t* sim, const float* actions,
                           const float* pd_off, const float* pd_scale, const int32_t* freeze, int num_sim_calls, int do_step) {
-    const int nb = model->num_bodies, nd = model->num_dof;
+    const int nb = model_all->num_bodies, nd = model_all->num_dof;
     const int ndj = JT == PHC_JT_REVOLUTE ? 1 : 3;
 #pragma omp parallel for schedule(static)
     for (int64_t env = 0; env < sim->num_envs; ++env) {
         std::vector<float> xch(PHC_MAX_BODIES * PHC_XCH_STRIDE);
+        const phc_model_t model_env = model_for_env(*model_all, *sim, env);
+        const phc_model_t* model = &model_env;
         AbaLane L[PHC_MAX_BODIES];
         for (int j = 0; j < PHC_MAX_BODIES; ++j) L[j].level = -1;
         for (int j = 0; j < nb; ++j) {

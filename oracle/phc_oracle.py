@@ -455,11 +455,20 @@ def compute_imitation_observations_v6(root_pos, root_rot, body_pos, body_rot, bo
     return np.concatenate(obs, axis=-1).reshape(B, -1).astype(F)
 
 
+def remove_base_rot(quat):
+    """humanoid.py:1936-1939."""
+    base = np.array([[-0.5, -0.5, -0.5, 0.5]], dtype=quat.dtype)   # quat_conjugate((0.5, 0.5, 0.5, 0.5))
+    return quat_mul(quat, np.repeat(base, quat.shape[0], axis=0))
+
+
 def build_amp_observations_smpl(root_pos, root_rot, root_vel, root_ang_vel, dof_pos, dof_vel, key_body_pos,
-                                dof_subset, local_root_obs=True, root_height_obs=True):
-    """humanoid_amp.py:967-1011 with upright=True, has_dof_subset=True, no shape obs."""
+                                dof_subset, local_root_obs=True, root_height_obs=True, upright=True, shape_params=None, limb_weight_params=None):
+    """humanoid_amp.py:967-1011 with has_dof_subset=True; shape_params / limb_weight_params: the has_shape_obs_disc / has_limb_weight_obs
+    columns (:1005-1008)."""
     N = root_pos.shape[0]
     root_h = root_pos[:, 2:3]
+    if not upright:
+        root_rot = remove_base_rot(root_rot)
     hinv = calc_heading_quat_inv(root_rot)
     root_rot_obs = quat_mul(hinv, root_rot) if local_root_obs else root_rot
     root_rot_obs = quat_to_tan_norm(root_rot_obs)
@@ -473,6 +482,7 @@ def build_amp_observations_smpl(root_pos, root_rot, root_vel, root_ang_vel, dof_
     dp = dof_pos[:, dof_subset]
     dof_obs = quat_to_tan_norm(exp_map_to_quat(dp.reshape(-1, 3))).reshape(N, -1)  # humanoid.py:1756-1765
     parts = ([root_h] if root_height_obs else []) + [root_rot_obs, lrv, lrav, dof_obs, dv, lk]
+    parts += [p for p in (shape_params, limb_weight_params) if p is not None]
     return np.concatenate(parts, axis=-1).astype(F)
 
 

@@ -23,7 +23,8 @@ c_p = C.c_void_p
 
 class Model(C.Structure):
     _fields_ = [("num_bodies", c_i32), ("num_dof", c_i32), ("max_level", c_i32), ("num_contact_pts", c_i32),
-                ("ints", c_p), ("floats", c_p), ("split_level", c_i32), ("num_below_split", c_i32), ("num_collision_pairs", c_i32)]
+                ("ints", c_p), ("floats", c_p), ("split_level", c_i32), ("num_below_split", c_i32), ("num_collision_pairs", c_i32),
+                ("num_shapes", c_i32), ("int_stride", c_i32), ("float_stride", c_i32)]
 
 
 class MotionLib(C.Structure):
@@ -34,7 +35,7 @@ class MotionLib(C.Structure):
 
 class SimState(C.Structure):
     _fields_ = [("num_envs", c_i32), ("root_states", c_p), ("dof_state", c_p), ("rigid_body_state", c_p),
-                ("contact_force", c_p), ("dof_force", c_p), ("pd_target", c_p), ("force_sensor", c_p)]
+                ("contact_force", c_p), ("dof_force", c_p), ("pd_target", c_p), ("force_sensor", c_p), ("env_shape", c_p)]
 
 
 class SimParams(C.Structure):
@@ -61,7 +62,9 @@ class ImParams(C.Structure):
                 ("num_self_obs", c_i32), ("num_task_obs", c_i32),
                 ("cycle_motion", c_i32), ("zero_out_far", c_i32), ("close_distance", c_f), ("far_distance", c_f),
                 ("dofs_per_joint", c_i32), ("num_ext_bodies", c_i32), ("ext_parent", c_p), ("ext_offset", c_p), ("obs_v", c_i32),
-                ("self_obs_v", c_i32), ("num_force_sensors", c_i32), ("amp_obs_v", c_i32)]
+                ("self_obs_v", c_i32), ("num_force_sensors", c_i32), ("amp_obs_v", c_i32),
+                ("remove_base_rot", c_i32), ("num_self_obs_extra", c_i32), ("num_amp_obs_extra", c_i32),
+                ("self_obs_extra", c_p), ("amp_obs_extra", c_p)]
 
 
 class ImBuffers(C.Structure):
@@ -127,7 +130,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the .so does not export the symbol
         fn.argtypes = argtypes
         fn.restype = restype
-    if lib.phc_abi_version() != 20:
+    if lib.phc_abi_version() != 21:
         raise ImportError("libphc_amd.so ABI version mismatch")
     _lib = lib
     return lib

@@ -23,9 +23,16 @@ def ptr(x):
     return x.data_ptr()
 
 
-def model_struct(ints, floats, num_bodies, num_dof, max_level, num_contact_pts, split=(-1, 0)):
+def model_struct(ints, floats, num_bodies, num_dof, max_level, num_contact_pts, split=(-1, 0), num_shapes=1):
+    """`num_shapes` > 1: ints / floats are [K, ...] stacks of K packed models of one topology (model.py pack_shapes())."""
     m = L.Model()
-    m.num_collision_pairs = int(ints[4 + 13 * MAX_BODIES])   # count stored right after the 13 int tables (model.py pack())
+    m.num_shapes = int(num_shapes)
+    if num_shapes > 1:
+        assert ints.ndim == 2 and floats.ndim == 2 and ints.shape[0] == floats.shape[0] == num_shapes
+        m.int_stride, m.float_stride = int(ints.shape[1]), int(floats.shape[1])
+        m.num_collision_pairs = int(ints[:, 4 + 13 * MAX_BODIES].max())
+    else:
+        m.num_collision_pairs = int(ints.reshape(-1)[4 + 13 * MAX_BODIES])   # count stored right after the 13 int tables (model.py pack())
     m.split_level, m.num_below_split = int(split[0]), int(split[1])
     m.num_bodies, m.num_dof, m.max_level, m.num_contact_pts = num_bodies, num_dof, max_level, num_contact_pts
     m.ints, m.floats = ptr(ints), ptr(floats)
@@ -46,9 +53,10 @@ def motion_lib_struct(frames, frame_stride, num_bodies, motion_lengths, motion_d
     return s
 
 
-def sim_state_struct(num_envs, root_states, dof_state, rigid_body_state, contact_force, dof_force, pd_target, force_sensor=None):
+def sim_state_struct(num_envs, root_states, dof_state, rigid_body_state, contact_force, dof_force, pd_target, force_sensor=None, env_shape=None):
     s = L.SimState()
     s.force_sensor = ptr(force_sensor)
+    s.env_shape = ptr(env_shape)
     s.num_envs = int(num_envs)
     s.root_states, s.dof_state, s.rigid_body_state = ptr(root_states), ptr(dof_state), ptr(rigid_body_state)
     s.contact_force, s.dof_force, s.pd_target = ptr(contact_force), ptr(dof_force), ptr(pd_target)
@@ -112,8 +120,14 @@ def im_params_struct(dt, max_episode_length, reward_specs, power_reward, power_c
                      track_slot, reset_mask, num_reset_bodies, first_reset_body, termination_distances, num_key_bodies, key_body_ids,
                      num_amp_joints, amp_joint_slot, num_amp_obs_steps, num_amp_obs_per_step, num_self_obs, num_task_obs,
                      cycle_motion=False, zero_out_far=False, close_distance=0.25, far_distance=3.0,
-                     dofs_per_joint=3, ext_parent=None, ext_offset=None, obs_v=6, self_obs_v=1, num_force_sensors=0, amp_obs_v=1):
+                     dofs_per_joint=3, ext_parent=None, ext_offset=None, obs_v=6, self_obs_v=1, num_force_sensors=0, amp_obs_v=1,
+                     remove_base_rot=False, self_obs_extra=None, amp_obs_extra=None):
+    """`self_obs_extra` / `amp_obs_extra`: fp32 [N, E] per-env constant observation columns (shape parameters, limb weights) or None."""
     p = L.ImParams()
+    p.remove_base_rot = int(bool(remove_base_rot))
+    p.num_self_obs_extra = 0 if self_obs_extra is None else int(self_obs_extra.shape[1])
+    p.num_amp_obs_extra = 0 if amp_obs_extra is None else int(amp_obs_extra.shape[1])
+    p.self_obs_extra, p.amp_obs_extra = ptr(self_obs_extra), ptr(amp_obs_extra)
     p.amp_obs_v = int(amp_obs_v)
     p.obs_v = int(obs_v)
     p.self_obs_v, p.num_force_sensors = int(self_obs_v), int(num_force_sensors)

@@ -127,6 +127,15 @@ struct AbaLane {
     V3 fself, nself;
 };
 
+// per-env body shapes (phc_model_t.num_shapes > 1): the env's block of the int / float tables; the scalar header fields stay shared
+PHC_HD phc_model_t model_for_env(phc_model_t m, const phc_sim_state_t& s, int64_t env) {
+    if (m.num_shapes > 1 && s.env_shape != nullptr && env < s.num_envs) {
+        const int sh = s.env_shape[env];
+        m.ints += (int64_t)sh * m.int_stride;
+        m.floats += (int64_t)sh * m.float_stride;
+    }
+    return m;
+}
 PHC_HD const float* model_body(const phc_model_t& m, int j) { return m.floats + j * PHC_BODY_FLOATS; }
 PHC_HD int model_tab(const phc_model_t& m, int table, int j) { return m.ints[4 + table * PHC_MAX_BODIES + j]; }
 

@@ -25,7 +25,9 @@ PHC_HD void amp_obs_from_ref_lane(const phc_motion_lib_t& lib, const phc_im_para
                                   int64_t mid, float t, float* a) {
     FrameRef fr = frame_ref(lib, mid, t);
     BodyState root = ref_body(lib, fr, 0);
-    Q4 hinv = calc_heading_quat_inv(root.rot);
+    Q4 hinv = calc_heading_quat_inv(obs_root_rot(prm, root.rot));
+    if (j < nb && prm.num_amp_obs_extra > 0 && prm.amp_obs_extra)   // the clip's humanoid (motion id == env id)
+        obs_extra_lane(prm.amp_obs_extra + mid * prm.num_amp_obs_extra, prm.num_amp_obs_extra, j, nb, a + prm.num_amp_obs_per_step - prm.num_amp_obs_extra);
     if (j == 0) amp_obs_root(prm, root.pos, root.rot, root.vel, root.angvel, hinv, a);
     if (j >= 1 && j < nb) {
         int slot = prm.amp_joint_slot[j];
@@ -45,6 +47,8 @@ PHC_HD void amp_obs_from_ref_lane(const phc_motion_lib_t& lib, const phc_im_para
 // HumanoidAMP._compute_amp_observations (humanoid_amp.py:672-707)
 PHC_HD void amp_obs_from_sim_lane(const phc_im_params_t& prm, const phc_sim_state_t& sim, int nb, int nd, int64_t env, int j,
                                   const BodyState& root, Q4 hinv, const int* dof_start_tab, float* a) {
+    if (j < nb && prm.num_amp_obs_extra > 0 && prm.amp_obs_extra)
+        obs_extra_lane(prm.amp_obs_extra + env * prm.num_amp_obs_extra, prm.num_amp_obs_extra, j, nb, a + prm.num_amp_obs_per_step - prm.num_amp_obs_extra);
     if (j == 0) amp_obs_root(prm, root.pos, root.rot, root.vel, root.angvel, hinv, a);
     if (j >= 1 && j < nb) {
         int slot = prm.amp_joint_slot[j];
@@ -202,9 +206,10 @@ PHC_HD RewardPartial im_post_lane(const phc_model_t& model, const phc_motion_lib
         if (prm.dofs_per_joint != 1) rp.power += fabsf(f[1] * d[3]) + fabsf(f[2] * d[5]);
     }
     // observations for the next policy step (humanoid_im.py:694-726)
-    Q4 hinv = calc_heading_quat_inv(root.rot), h = calc_heading_quat(root.rot);
+    const Q4 hroot = obs_root_rot(prm, root.rot);
+    Q4 hinv = calc_heading_quat_inv(hroot), h = calc_heading_quat(hroot);
     float* obs = buf.obs_buf + env * (int64_t)(prm.num_self_obs + prm.num_task_obs);
-    self_obs_lane(prm, nb, j, body, root, hinv, obs, (sim.force_sensor && prm.self_obs_v == 3) ? sim.force_sensor + env * (int64_t)(prm.num_force_sensors * 6) : nullptr);
+    self_obs_lane(prm, nb, j, body, root, hinv, obs, (sim.force_sensor && prm.self_obs_v == 3) ? sim.force_sensor + env * (int64_t)(prm.num_force_sensors * 6) : nullptr, env);
     int slot = prm.track_slot[j];
     if (slot >= 0) {
         BodyState rt = r1;
@@ -325,10 +330,11 @@ PHC_HD void im_reset_lane(const phc_model_t& model, const phc_motion_lib_t& lib,
         const float t1 = motion_time(1, prm.dt, t, 0.f);
         const FrameRef fr1 = frame_ref(lib, mid, t1);
         BodyState r1 = ref_body(lib, fr1, j);
-        Q4 hinv = calc_heading_quat_inv(root.rot), h = calc_heading_quat(root.rot);
+        const Q4 hroot = obs_root_rot(prm, root.rot);
+    Q4 hinv = calc_heading_quat_inv(hroot), h = calc_heading_quat(hroot);
         float* obs = buf.obs_buf + env * (int64_t)(prm.num_self_obs + prm.num_task_obs);
         // (reset envs: the sensor tensor keeps its last reading until the next simulate call, as gym's does -- humanoid.py:1463)
-        self_obs_lane(prm, nb, j, rs, root, hinv, obs, (sim.force_sensor && prm.self_obs_v == 3) ? sim.force_sensor + env * (int64_t)(prm.num_force_sensors * 6) : nullptr);
+        self_obs_lane(prm, nb, j, rs, root, hinv, obs, (sim.force_sensor && prm.self_obs_v == 3) ? sim.force_sensor + env * (int64_t)(prm.num_force_sensors * 6) : nullptr, env);
         int slot = prm.track_slot[j];
         if (slot >= 0) {
             BodyState rt = r1;
@@ -383,9 +389,10 @@ PHC_HD void im_reset_from_state_lane(const phc_model_t& model, const phc_motion_
         const FrameRef fr1 = frame_ref(lib, mid, t1);
         BodyState r1 = ref_body(lib, fr1, j);
         r1.pos += goff;
-        Q4 hinv = calc_heading_quat_inv(root.rot), h = calc_heading_quat(root.rot);
+        const Q4 hroot = obs_root_rot(prm, root.rot);
+    Q4 hinv = calc_heading_quat_inv(hroot), h = calc_heading_quat(hroot);
         float* obs = buf.obs_buf + env * (int64_t)(prm.num_self_obs + prm.num_task_obs);
-        self_obs_lane(prm, nb, j, body, root, hinv, obs, (sim.force_sensor && prm.self_obs_v == 3) ? sim.force_sensor + env * (int64_t)(prm.num_force_sensors * 6) : nullptr);
+        self_obs_lane(prm, nb, j, body, root, hinv, obs, (sim.force_sensor && prm.self_obs_v == 3) ? sim.force_sensor + env * (int64_t)(prm.num_force_sensors * 6) : nullptr, env);
         int slot = prm.track_slot[j];
         if (slot >= 0) {
             BodyState rt = r1;

@@ -96,7 +96,7 @@ __device__ __forceinline__ bool stage_aligned(const phc_sim_state_t& sim) {
 // 68 B/lane of scratch) beats one (272 registers, no scratch: 195 us) and three (168 VGPRs, 412 B scratch: 280 us).
 // ------------------------------------------------------------------------------------------
 template <bool STEP, int JT, int GRP>
-__global__ __launch_bounds__(64, 2) void k_sim_step(phc_model_t model, phc_sim_params_t prm, phc_sim_state_t sim,
+__global__ __launch_bounds__(64, 2) void k_sim_step(phc_model_t model_all, phc_sim_params_t prm, phc_sim_state_t sim,
                                                 const float* __restrict__ actions, const float* __restrict__ pd_off,
                                                 const float* __restrict__ pd_scale, const int32_t* __restrict__ freeze,
                                                 int num_sim_calls, const int64_t* __restrict__ env_ids, int num_listed) {
@@ -107,6 +107,7 @@ __global__ __launch_bounds__(64, 2) void k_sim_step(phc_model_t model, phc_sim_p
     const int64_t slot = (int64_t)blockIdx.x * (64 / GRP) + grp;
     // env_ids (refresh of a teleported subset only): slot -> listed env
     const int64_t env = (!STEP && env_ids != nullptr) ? (slot < num_listed ? env_ids[slot] : sim.num_envs) : slot;
+    const phc_model_t model = model_for_env(model_all, sim, env);
     const int nb = model.num_bodies, nd = model.num_dof;
     const bool active = env < sim.num_envs && lane < nb;
     Xch x;
@@ -187,7 +188,7 @@ __global__ __launch_bounds__(64, 2) void k_sim_step(phc_model_t model, phc_sim_p
 // wavefront's 72 dependent level-steps, so halving the wavefront count at N = 4096 moves it onto the one-per-SIMD plateau.
 // ------------------------------------------------------------------------------------------
 template <int JT, int GRP>
-__global__ __launch_bounds__(64, 1) void k_sim_step16(phc_model_t model, phc_sim_params_t prm, phc_sim_state_t sim,
+__global__ __launch_bounds__(64, 1) void k_sim_step16(phc_model_t model_all, phc_sim_params_t prm, phc_sim_state_t sim,
                                                   const float* __restrict__ actions, const float* __restrict__ pd_off,
                                                   const float* __restrict__ pd_scale, const int32_t* __restrict__ freeze,
                                                   int num_sim_calls) {
@@ -196,6 +197,7 @@ __global__ __launch_bounds__(64, 1) void k_sim_step16(phc_model_t model, phc_sim
     const int lane = threadIdx.x & (GRP - 1);
     const int grp = threadIdx.x / GRP;
     const int64_t env = (int64_t)blockIdx.x * (64 / GRP) + grp;
+    const phc_model_t model = model_for_env(model_all, sim, env);
     const int nb = model.num_bodies, nd = model.num_dof;
     const int split = model.split_level, nA = model.num_below_split;
     const bool env_ok = env < sim.num_envs;

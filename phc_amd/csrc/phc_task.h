@@ -162,16 +162,29 @@ PHC_HD void store_body(float* rigid_body_state, int64_t env, int nb, int j, cons
     st3(p, s.pos); st4(p + 3, s.rot); st3(p + 7, s.vel); st3(p + 10, s.angvel);
 }
 
+// `if not upright: root_rot = remove_base_rot(root_rot)` (humanoid.py:1936-1939): quat_mul(q, conj(0.5, 0.5, 0.5, 0.5)); the heading and
+// the root-rotation observation are taken from the result
+PHC_HD Q4 obs_root_rot(const phc_im_params_t& prm, Q4 q) {
+    return prm.remove_base_rot ? quat_mul(q, q4(-0.5f, -0.5f, -0.5f, 0.5f)) : q;
+}
+// per-env constant columns (shape parameters, limb weights) appended to an observation: the `nl` lanes of the env share the copy
+PHC_HD void obs_extra_lane(const float* src, int n, int lane, int nl, float* dst) {
+    if (src == nullptr) return;
+    for (int k = lane; k < n; k += nl) dst[k] = src[k];
+}
+
 // ---- R6: compute_humanoid_observations_smpl_max (humanoid.py:1995-2050), lane j's slices ----
 // `sensors`: the env's S6 force-sensor readings [S*6] (self_obs_v 3: compute_humanoid_observations_smpl_max_v3, humanoid.py:2113-2169,
 // appends them after the angular-velocity block) or nullptr.
 PHC_HD void self_obs_lane(const phc_im_params_t& prm, int nb, int j, const BodyState& body, const BodyState& root,
-                          Q4 hinv, float* obs, const float* sensors = nullptr) {
+                          Q4 hinv, float* obs, const float* sensors = nullptr, int64_t env = -1) {
+    if (env >= 0 && j < nb && prm.num_self_obs_extra > 0 && prm.self_obs_extra)
+        obs_extra_lane(prm.self_obs_extra + env * prm.num_self_obs_extra, prm.num_self_obs_extra, j, nb, obs + prm.num_self_obs - prm.num_self_obs_extra);
     int off = 0;
     if (prm.root_height_obs) { if (j == 0) obs[0] = root.pos.z; off = 1; }
     if (j >= 1) st3(obs + off + (j - 1) * 3, quat_rotate(hinv, body.pos - root.pos));
     float tn[6];
-    if (j == 0 && !prm.local_root_obs) quat_to_tan_norm(root.rot, tn);  // :2026-2028
+    if (j == 0 && !prm.local_root_obs) quat_to_tan_norm(obs_root_rot(prm, root.rot), tn);  // :2026-2028
     else quat_to_tan_norm(quat_mul(hinv, body.rot), tn);
     float* pr = obs + off + (nb - 1) * 3 + j * 6;
     for (int k = 0; k < 6; ++k) pr[k] = tn[k];
@@ -213,6 +226,7 @@ PHC_HD void amp_obs_root(const phc_im_params_t& prm, V3 root_pos, Q4 root_rot, V
     int off = 0;
     if (prm.root_height_obs) { a[0] = root_pos.z; off = 1; }
     float tn[6];
+    root_rot = obs_root_rot(prm, root_rot);
     quat_to_tan_norm(prm.local_root_obs ? quat_mul(hinv, root_rot) : root_rot, tn);
     for (int k = 0; k < 6; ++k) a[off + k] = tn[k];
     st3(a + off + 6, quat_rotate(hinv, root_vel));

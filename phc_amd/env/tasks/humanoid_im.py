@@ -23,7 +23,7 @@ import torch
 
 from ... import _lib as L
 from ... import abi
-from ...model import load_model
+from ...model import load_model, pack_shapes
 from ...motion_lib import FixHeightMode, MotionLibReal, MotionLibSMPL
 from ... import robots
 from ...utils.flags import flags
@@ -85,7 +85,7 @@ class HumanoidIm:
             raise NotImplementedError(f"humanoid_type={self.humanoid_type!r}: built so far: smpl, h1, g1")
         self._is_robot = self.humanoid_type in ("h1", "g1")
         unsupported = dict(fut_tracks=False, zero_out_far_train=False, cycle_motion_xp=False, occl_training=False, res_action=False,
-                           kin_loss=False, z_readout=False, distill=False, has_shape_variation=False)
+                           kin_loss=False, z_readout=False, distill=False)
         for k, off in unsupported.items():
             v = env.get(k, robot.get(k, off))
             if v != off:
@@ -109,16 +109,15 @@ class HumanoidIm:
             self._dof_names = self._body_names[1:]
             self._full_track_bodies = self._body_names_orig.copy()
             self._eval_bodies = [b for b in self._body_names_orig if b not in ("L_Toe", "R_Toe", "L_Hand", "R_Hand")]
-        self._has_upright_start = robot.get("has_upright_start", True)
-        if not self._has_upright_start:
-            raise NotImplementedError("has_upright_start=False is not built")
+        self._has_upright_start = robot.get("has_upright_start", True)   # False: observations strip the asset's base rotation (humanoid.py:1936-1939)
         self._has_shape_obs = robot.get("has_shape_obs", False)
         self._has_shape_obs_disc = robot.get("has_shape_obs_disc", False)
         self._has_limb_weight_obs = robot.get("has_weight_obs", False)
         self._has_limb_weight_obs_disc = robot.get("has_weight_obs_disc", False)
-        if self._has_shape_obs or self._has_shape_obs_disc or self._has_limb_weight_obs or self._has_limb_weight_obs_disc:
-            raise NotImplementedError("shape / limb-weight observations are not built")
-        self.has_shape_variation = False
+        self.has_shape_variation = bool(robot.get("has_shape_variation", False))   # humanoid.py:275
+        if self._is_robot and (self.has_shape_variation or self._has_shape_obs or self._has_shape_obs_disc or self._has_limb_weight_obs
+                               or self._has_limb_weight_obs_disc):
+            raise NotImplementedError("body-shape variation / shape observations are SMPL-family options (humanoid.py:669-676,735)")
         self._has_dof_subset = robot.get("has_dof_subset", False)
         self._has_self_collision = robot.get("has_self_collision", False)
         self._freeze_toe = robot.get("freeze_toe", True)
@@ -197,21 +196,59 @@ class HumanoidIm:
             self.default_dof_pos = torch.tensor([self._robot_consts["default_dof_pos"]], dtype=torch.float32, device=self.device)
         robots.apply_collision_filter(self.model, self.humanoid_type)   # humanoid.py:1205-1226
         self.num_bodies, self.num_dof = self.model.num_bodies, self.model.num_dof
-        self.skeleton_trees = [SkeletonTree(self.model.body_names, self.model.parent, self.model.local_translation)] * self.num_envs
-        ints, floats = self.model.pack(self._kp_scale, self._kd_scale)
+        # ---- per-env body shapes (humanoid.py:726-766,824-866): env i wears gender_betas[i % K].  The reference writes one MJCF per env
+        # with smpl_sim's SMPL_Robot (needs the SMPL model files) and falls back to `smpl_{gender}_humanoid.xml` (:748) without it; here
+        # `robot.shape_assets` names one compiled model per row of `robot.shape_gender_betas` (default: the three gender assets, i.e. the
+        # reference's fallback) -- K compiled shapes, an int32 shape id per env, one launch for all of them ----
+        self.shape_models = [self.model]
+        self._env_shape = None
+        gender_betas = np.zeros((1, 17), dtype=np.float32)
+        if self.has_shape_variation and not flags.im_eval:     # (:743: evaluation runs on the mean shape)
+            gb = robot.get("shape_gender_betas", None)
+            if isinstance(gb, str):
+                import joblib
+                gb = joblib.load(gb)
+                gb = list(gb.values()) if isinstance(gb, dict) else gb
+            gender_betas = np.asarray(gb if gb is not None else [[g] + [0.0] * 16 for g in (0, 1, 2)], dtype=np.float32).reshape(-1, 17)
+            assets = robot.get("shape_assets", None) or [f"smpl_{int(row[0])}_humanoid" for row in gender_betas]
+            assert len(assets) == len(gender_betas), "one compiled model per row of shape_gender_betas"
+            loaded = {}
+            self.shape_models = []
+            for a in assets:
+                if a not in loaded:
+                    loaded[a] = load_model(a)
+                    robots.apply_collision_filter(loaded[a], self.humanoid_type)
+                self.shape_models.append(loaded[a])
+            self._env_shape = (torch.arange(self.num_envs, dtype=torch.int32) % len(self.shape_models)).to(self.device)
+        K = len(self.shape_models)
+        trees = [SkeletonTree(m.body_names, m.parent, m.local_translation) for m in self.shape_models]
+        self.skeleton_trees = [trees[i % K] for i in range(self.num_envs)]
+        if K > 1:
+            ints, floats = pack_shapes(self.shape_models, self._kp_scale, self._kd_scale)
+        else:
+            ints, floats = self.model.pack(self._kp_scale, self._kd_scale)
         self._model_ints = torch.from_numpy(ints).to(self.device)
         self._model_floats = torch.from_numpy(floats).to(self.device)
         self._model_struct = abi.model_struct(self._model_ints, self._model_floats, self.num_bodies, self.num_dof,
-                                              self.model.max_level, len(self.model.contact_body), split=self.model.two_slot_split())
-        self.humanoid_masses = [self.model.total_mass] * min(self.num_envs, 10)
+                                              self.model.max_level, max(len(m.contact_body) for m in self.shape_models),
+                                              split=self.model.two_slot_split(), num_shapes=K)
+        self.humanoid_masses = [self.shape_models[i % K].total_mass for i in range(min(self.num_envs, 10))]
         groups = robot.get("limb_weight_group", []) if self._is_robot else (
             ['L_Hip', 'L_Knee', 'L_Ankle', 'L_Toe'], ['R_Hip', 'R_Knee', 'R_Ankle', 'R_Toe'],
             ['Pelvis', 'Torso', 'Spine', 'Chest', 'Neck', 'Head'], ['L_Thorax', 'L_Shoulder', 'L_Elbow', 'L_Wrist', 'L_Hand'],
             ['R_Thorax', 'R_Shoulder', 'R_Elbow', 'R_Wrist', 'R_Hand'])
         self.limb_weight_group = [[self._body_names.index(g) for g in grp] for grp in groups]
-        lw = self.model.limb_lengths_and_weights(self.limb_weight_group)
-        self.humanoid_limb_and_weights = torch.from_numpy(lw).to(self.device).repeat(self.num_envs, 1)
-        self.humanoid_shapes = torch.zeros(self.num_envs, 17, device=self.device)
+        lw = torch.from_numpy(np.stack([m.limb_lengths_and_weights(self.limb_weight_group) for m in self.shape_models])).to(self.device)
+        shape_of_env = torch.arange(self.num_envs, device=self.device) % K
+        self.humanoid_limb_and_weights = lw[shape_of_env].contiguous()
+        self.humanoid_shapes = torch.from_numpy(gender_betas).to(self.device)[shape_of_env % len(gender_betas)].contiguous()   # [N, 17]
+        # constant per-env observation columns (humanoid.py:1469-1473,2043-2047; humanoid_amp.py:1005-1008).  The self observation takes
+        # humanoid_shapes[:, :-6] (gender + 10 betas: `_num_self_obs += 11`, :669-671); for the discriminator the reference counts the
+        # same 11 columns (humanoid_amp.py:310-311) but hands the function all 17 (:691) -- a shape mismatch as shipped; 11 are used here
+        se = ([self.humanoid_shapes[:, :-6]] if self._has_shape_obs else []) + ([self.humanoid_limb_and_weights] if self._has_limb_weight_obs else [])
+        ae = ([self.humanoid_shapes[:, :-6]] if self._has_shape_obs_disc else []) + ([self.humanoid_limb_and_weights] if self._has_limb_weight_obs_disc else [])
+        self._self_obs_extra = torch.cat(se, dim=-1).float().contiguous() if se else None
+        self._amp_obs_extra = torch.cat(ae, dim=-1).float().contiguous() if ae else None
 
         # ---- _setup_character_props (humanoid.py:636-706, humanoid_amp.py:290-329) ----
         self._dof_body_ids = np.arange(1, len(self._body_names))
@@ -225,6 +262,8 @@ class HumanoidIm:
             self._dof_size = len(self._dof_names) * 3
         self._num_actions = self._dof_size
         self._num_self_obs = 1 + len(self._body_names) * (3 + 6 + 3 + 3) - 3
+        if self._self_obs_extra is not None:   # humanoid.py:669-676
+            self._num_self_obs += self._self_obs_extra.shape[1]
         if not self._root_height_obs:
             self._num_self_obs -= 1
         if self.amp_obs_v == 2 and self._is_robot:
@@ -244,6 +283,8 @@ class HumanoidIm:
             self._num_amp_obs_per_step = 13 + n_amp_joints * 9 + 3 * len(self.key_bodies) - (0 if self._amp_root_height_obs else 1)
             if self.amp_obs_v == 2:   # + key-body velocities (humanoid_amp.py:303)
                 self._num_amp_obs_per_step += 3 * len(self.key_bodies)
+            if self._amp_obs_extra is not None:   # humanoid_amp.py:310-313
+                self._num_amp_obs_per_step += self._amp_obs_extra.shape[1]
             dof_sub = [np.arange(3 * (j - 1), 3 * j) for j in range(1, self.num_bodies) if amp_slot[j] >= 0]
             self.dof_subset = torch.from_numpy(np.concatenate(dof_sub)) if self._has_dof_subset else torch.tensor([]).long()
         # extended bodies of the full-body reward (humanoid_im.py:74-82)
@@ -313,7 +354,8 @@ class HumanoidIm:
         sensors_on = self.self_obs_v == 3 and not self._is_robot
         self.vec_sensor_tensor = torch.zeros((N, 6 * len(self.force_sensor_joints)), **f32) if sensors_on else None
         self._sim_struct = abi.sim_state_struct(N, self._root_states, self._dof_state, self._rigid_body_state, self._contact_forces,
-                                                self.dof_force_tensor, self._pd_target, force_sensor=self.vec_sensor_tensor)
+                                                self.dof_force_tensor, self._pd_target, force_sensor=self.vec_sensor_tensor,
+                                                env_shape=self._env_shape)
         physx = sim_cfg["physx"]
         plane = env.get("plane", {})
         solver = cfg.get("solver", {})  # phc_amd-specific knobs of the penalty contact model (not in the reference)
@@ -421,7 +463,8 @@ class HumanoidIm:
             num_self_obs=self._num_self_obs, num_task_obs=self.get_task_obs_size(), obs_v=self.obs_v, cycle_motion=self.cycle_motion,
             zero_out_far=self.zero_out_far, close_distance=self.close_distance, far_distance=self.far_distance,
             dofs_per_joint=1 if self._is_robot else 3, ext_parent=self._ext_parent_i32, ext_offset=self._ext_offset_f32,
-            self_obs_v=self.self_obs_v, num_force_sensors=len(self.force_sensor_joints) if self.self_obs_v == 3 else 0, amp_obs_v=self.amp_obs_v)
+            self_obs_v=self.self_obs_v, num_force_sensors=len(self.force_sensor_joints) if self.self_obs_v == 3 else 0, amp_obs_v=self.amp_obs_v,
+            remove_base_rot=not self._has_upright_start, self_obs_extra=self._self_obs_extra, amp_obs_extra=self._amp_obs_extra)
         self._flag_state = (flags.im_eval, flags.no_collision_check)
 
     def _buffers(self, amp_in, amp_out):

@@ -544,6 +544,23 @@ class ArticulationModel:
         return np.array(out, dtype=np.float32)
 
 
+def pack_shapes(models, kp_scale=1.0, kd_scale=1.0):
+    """K articulations of ONE topology (per-env body shapes, humanoid.py:726-766,824-866) -> (ints [K, ni], floats [K, nf]): their
+    packed tables side by side, zero-padded to a common length (contact-point and collision-pair counts may differ)."""
+    m0 = models[0]
+    for m in models[1:]:
+        if (m.body_names != m0.body_names or not np.array_equal(m.parent, m0.parent) or not np.array_equal(m.joint_type, m0.joint_type)
+                or not np.array_equal(m.dof_start, m0.dof_start) or m.num_dof != m0.num_dof):
+            raise ValueError("shape variants must share body names, parents and joint layout")
+    packed = [m.pack(kp_scale, kd_scale) for m in models]
+    ni, nf = max(p[0].size for p in packed), max(p[1].size for p in packed)
+    ints = np.zeros((len(models), ni), dtype=np.int32)
+    floats = np.zeros((len(models), nf), dtype=np.float32)
+    for k, (i, f) in enumerate(packed):
+        ints[k, :i.size], floats[k, :f.size] = i, f
+    return ints, floats
+
+
 def load_model(name_or_path):
     """Load a compiled JSON asset by name ("smpl_humanoid") or path, or compile an MJCF."""
     p = name_or_path

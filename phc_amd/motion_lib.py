@@ -207,9 +207,9 @@ _JOB_CTX = None   # (library, tree, max_len) of the load_motions call in flight:
 
 def _process_job(job):
     """One distinct clip (worker of the fork pool in load_motions; numpy only -- the forked children never touch the device)."""
-    u, start = job
-    lib, tree, max_len = _JOB_CTX
-    return lib._process_unique_clip(lib._motion_data_list[u], tree, max_len, start)
+    u, start, t = job
+    lib, trees, max_len = _JOB_CTX
+    return lib._process_unique_clip(lib._motion_data_list[u], trees[t], max_len, start)
 
 
 class MotionLibBase:
@@ -261,6 +261,15 @@ class MotionLibBase:
         num_to_load = len(skeleton_trees)
         tree = skeleton_trees[0]
         self.num_joints = len(tree.node_names)
+        # per-env body shapes (humanoid.py:824-866): env i's clip is run through env i's skeleton (motion_lib_smpl.py:153
+        # `skeleton_trees[f]`); the envs share a few tree OBJECTS, so the unit of work below is the distinct (clip, tree) pair
+        trees, tree_of = [], []
+        for t in skeleton_trees:
+            k = next((i for i, o in enumerate(trees) if o is t), None)
+            if k is None:
+                trees.append(t)
+                k = len(trees) - 1
+            tree_of.append(k)
         if random_sample:
             sample_idxes = torch.multinomial(self._sampling_prob, num_samples=num_to_load, replacement=True).to(self._device)
         else:
@@ -285,18 +294,20 @@ class MotionLibBase:
             rs = self._heading_rs
         # pass 1 -- every random draw, in the reference's order (per env: the crop of a not-yet-seen clip, then the heading), so that
         # the stream does not depend on how the work below is scheduled
-        uniq, crop, yaws = [], {}, []
-        for u in idx_np:
+        uniq, crop, yaws, seen = [], {}, [], set()
+        for e, u in enumerate(idx_np):
             u = int(u)
             if u not in crop:
                 crop[u] = self._draw_crop(self._motion_data_list[u], max_len, rs)
-                uniq.append(u)
+            if (u, tree_of[e]) not in seen:
+                seen.add((u, tree_of[e]))
+                uniq.append((u, tree_of[e]))
             yaws.append(self._draw_heading(rs))
         # pass 2 -- FK + velocities ONCE per distinct clip (fp64 on the host cores; a fork pool when there are many: cfg 3 samples
         # ~5 800 distinct clips of the 11 313 for 8 192 envs, 17 ms each)
         global _JOB_CTX
-        _JOB_CTX = (self, tree, max_len)
-        jobs = [(u, crop[u]) for u in uniq]
+        _JOB_CTX = (self, trees, max_len)
+        jobs = [(u, crop[u], t) for u, t in uniq]
         workers = int(self.m_cfg.get("num_workers", 0)) or min(32, max(1, (os.cpu_count() or 1) // 2))
         if len(jobs) >= 256 and workers > 1:
             import multiprocessing as mp
@@ -305,7 +316,7 @@ class MotionLibBase:
         else:
             done = [_process_job(j) for j in jobs]
         _JOB_CTX = None
-        slot = {u: k for k, u in enumerate(uniq)}
+        slot = {ut: k for k, ut in enumerate(uniq)}
         # pass 3 -- one packed fp32 record array per DISTINCT clip goes to the device once; the per-env copies (the reference keeps one
         # clip copy per env, motion_lib_base.py:300-307) are a device-side gather, and the per-env heading a device-side rotation
         dev = self._device
@@ -314,7 +325,7 @@ class MotionLibBase:
         u_nf = np.array([p.shape[0] for p in packed], dtype=np.int64)
         u_start = np.concatenate([[0], np.cumsum(u_nf)[:-1]])
         uniq_frames = torch.from_numpy(np.concatenate(packed, axis=0)).to(dev)
-        e_slot = np.array([slot[int(u)] for u in idx_np], dtype=np.int64)
+        e_slot = np.array([slot[(int(u), tree_of[e])] for e, u in enumerate(idx_np)], dtype=np.int64)
         nfs = [int(u_nf[k]) for k in e_slot]
         fpss = [done[k][1] for k in e_slot]
         src = torch.from_numpy(np.concatenate([np.arange(u_nf[k], dtype=np.int64) + u_start[k] for k in e_slot])).to(dev)

@@ -383,3 +383,58 @@ def test_sliding_friction_decelerates_at_mu_g(backend):
         v = o["root"][:, 7]
         expect = 2.0 - mu * 9.81 * 0.1
         assert np.all(np.abs(v - expect) < 0.25 * mu * 9.81 * 0.1 + 0.05), (mu, v, expect)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("self_collision,lane_mapping", [(0, 1), (1, 1), (0, 2)])
+def test_per_env_body_shapes_equal_single_shape_runs(backend, self_collision, lane_mapping):
+    """Per-env body shapes (robot.has_shape_variation, humanoid.py:726-766,824-866): ONE launch over K = 3 stacked models (the reference's
+    three gender assets: different link offsets, masses, contact-point counts) with an int32 shape id per env gives every env, bit for
+    bit, what a single-shape launch of its own model gives -- stepper and the FK-only refresh."""
+    from phc_amd.model import load_model, pack_shapes
+    from phc_amd.robots import apply_collision_filter
+    be = get_backend(backend)
+    if lane_mapping == 2 and backend == "hostemu":
+        pytest.skip("lane mappings are a device notion")
+    models = [load_model(f"smpl_{g}_humanoid") for g in range(3)]
+    for m in models:
+        apply_collision_filter(m, "smpl")
+    assert len({len(m.contact_body) for m in models}) > 1 and len({round(m.total_mass, 2) for m in models}) == 3
+    ints, floats = pack_shapes(models)
+    keep = (be.arr(ints), be.arr(floats))
+    m0 = models[0]
+    stacked = abi.model_struct(keep[0], keep[1], m0.num_bodies, m0.num_dof, m0.max_level, max(len(m.contact_body) for m in models),
+                               split=m0.two_slot_split(), num_shapes=3)
+    rng = np.random.default_rng(5)
+    n = 10
+    root, dof, target = random_states(m0, n, rng, height=0.85)
+    shape = (np.arange(n) % 3).astype(np.int32)
+    params = abi.sim_params_struct(self_collision=self_collision, lane_mapping=lane_mapping)
+
+    def run(mstruct, rows, env_shape):
+        k = len(rows)
+        a = dict(root=be.arr(root[rows]), dof=be.arr(dof[rows]), rbs=be.zeros((k, m0.num_bodies, 13)), cf=be.zeros((k, m0.num_bodies, 3)),
+                 df=be.zeros((k, m0.num_dof)), pd=be.arr(target[rows]))
+        es = None if env_shape is None else be.arr(env_shape)
+        sim = abi.sim_state_struct(k, a["root"], a["dof"], a["rbs"], a["cf"], a["df"], a["pd"], env_shape=es)
+        assert be.refresh_body_state(mstruct, sim) == 0
+        be.sync()
+        fk = be.np(a["rbs"]).copy()
+        assert be.sim_step(mstruct, params, sim, None, None, None, None, 2) == 0
+        be.sync()
+        return fk, {k_: be.np(v) for k_, v in a.items()}
+
+    fk_all, out_all = run(stacked, np.arange(n), shape)
+    for g, m in enumerate(models):
+        i, f = m.pack()
+        kg = (be.arr(i), be.arr(f))
+        single = abi.model_struct(kg[0], kg[1], m.num_bodies, m.num_dof, m.max_level, len(m.contact_body), split=m.two_slot_split())
+        rows = np.flatnonzero(shape == g)
+        fk_g, out_g = run(single, rows, None)
+        assert np.array_equal(fk_all[rows], fk_g)
+        for key in ("root", "dof", "rbs", "cf", "df"):
+            assert np.array_equal(out_all[key][rows], out_g[key]), (g, key)
+    # and the shapes really differ: env 0 (shape 0) and env 1 (shape 1) start from different states anyway, so compare FK of one state
+    root[:] = root[0]; dof[:] = dof[0]
+    fk_same, _ = run(stacked, np.arange(3), shape[:3])
+    assert np.abs(fk_same[0] - fk_same[1]).max() > 1e-3 and np.abs(fk_same[0] - fk_same[2]).max() > 1e-3

@@ -148,3 +148,16 @@ def test_model_compiler_on_the_reference_ant_fixture(golden):
     np.testing.assert_array_equal(np.array(m["parent"]), g["ant_parents"])
     np.testing.assert_allclose(np.array(m["local_translation"]), g["ant_local_translation"], atol=1e-7)
     assert len(m["dof_names"]) == 8 and abs(m["dof_upper"][0] - np.deg2rad(40)) < 1e-9
+
+
+def test_amp_observation_oracle_upright_and_shape_columns(golden):
+    """The numpy restatement of build_amp_observations_smpl, `upright=False` and shape / limb columns included, against the reference's
+    own outputs (oracle/gen_golden_shape_upright.py)."""
+    g, gs = golden("task_fns"), golden("obs_shape_upright")
+    kid, sub = g["key_body_ids"], g["dof_subset"]
+    for local_root in (True, False):
+        for upright in (True, False):
+            got = po.build_amp_observations_smpl(g["body_pos"][:, 0], g["body_rot"][:, 0], g["body_vel"][:, 0], g["body_ang_vel"][:, 0], g["dof_pos"],
+                                                 g["dof_vel"], g["body_pos"][:, kid], sub, local_root_obs=local_root, upright=upright,
+                                                 shape_params=gs["shape"], limb_weight_params=gs["limb"])
+            np.testing.assert_allclose(got, gs[f"amp_l{int(local_root)}u{int(upright)}"], atol=2e-6)

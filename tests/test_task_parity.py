@@ -151,6 +151,50 @@ def test_self_obs_v3_force_sensors_vs_reference_golden(golden, backend):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("local_root,upright", [(True, True), (True, False), (False, True), (False, False)])
+def test_upright_start_and_shape_columns_vs_reference_golden(golden, backend, local_root, upright):
+    """robot.has_upright_start False (`remove_base_rot` in front of the heading in every observation function, humanoid.py:1936-1939) and
+    the per-env constant columns of has_shape_obs / has_weight_obs (+ `_disc`): self observation = reference
+    compute_humanoid_observations_smpl_max(..., has_smpl_params, has_limb_weight_params), AMP step = build_amp_observations_smpl(...,
+    has_shape_obs_disc, has_limb_weight_obs), task observation v6 -- all from ONE post-physics launch, against the reference's outputs
+    (oracle/gen_golden_shape_upright.py)."""
+    be = get_backend(backend)
+    g, gs, gl = golden("task_fns"), golden("obs_shape_upright"), golden("motion_lib_eval")
+    model, mstruct, keepm = model_on(be)
+    lib, keep = motion_lib_on(be, gl)
+    N = g["body_pos"].shape[0]
+    extra = be.arr(np.concatenate([gs["shape"], gs["limb"]], axis=1).astype(F))
+    prm, keepp = make_im_params(be, model, N, num_self_obs=358 + 21, num_amp_obs_per_step=196 + 21, remove_base_rot=not upright,
+                                self_obs_extra=extra, amp_obs_extra=extra)
+    prm.local_root_obs = int(local_root)
+    arrs, sim = _sim_arrays(be, g, N)
+    amp_in, amp_out = be.zeros((N, 10, 217)), be.zeros((N, 10, 217))
+    b = dict(progress=be.arr((g["progress"] - 1).astype(np.int64)), reset=be.zeros(N, np.int64), term=be.zeros(N, np.int64), rew=be.zeros(N),
+             raw=be.zeros((N, 5)), obs=be.zeros((N, 379 + 576)), mids=be.arr(g["env_motion"].astype(np.int64)),
+             st=be.arr(g["start_times"].astype(F)), so=be.zeros(N), goff=be.zeros((N, 3)))
+    buf = abi.im_buffers_struct(b["progress"], b["reset"], b["term"], b["rew"], b["raw"], b["obs"], amp_in, amp_out, b["mids"], b["st"],
+                                b["so"], b["goff"])
+    assert be.im_post_physics(mstruct, lib, prm, sim, buf) == 0
+    be.sync()
+    tag = f"l{int(local_root)}u{int(upright)}"
+    obs = be.np(b["obs"])
+    np.testing.assert_allclose(obs[:, :379], gs[f"self_{tag}"], atol=1e-5)
+    np.testing.assert_array_equal(obs[:, 358:379], np.concatenate([gs["shape"], gs["limb"]], axis=1))
+    np.testing.assert_allclose(obs[:, 379:], gs[f"task_v6_u{int(upright)}"], atol=1e-5)
+    np.testing.assert_allclose(be.np(amp_out)[:, 0], gs[f"amp_{tag}"], atol=1e-5)
+    # keypoint task observation (obs_v 7) under the same flag
+    prm7, keep7 = make_im_params(be, model, N, obs_v=7, remove_base_rot=not upright)
+    prm7.num_task_obs = 9 * 24
+    b["obs7"] = be.zeros((N, 358 + 216))
+    b["progress"] = be.arr((g["progress"] - 1).astype(np.int64))
+    a7i, a7o = be.zeros((N, 10, 196)), be.zeros((N, 10, 196))
+    buf7 = abi.im_buffers_struct(b["progress"], b["reset"], b["term"], b["rew"], b["raw"], b["obs7"], a7i, a7o, b["mids"], b["st"], b["so"], b["goff"])
+    assert be.im_post_physics(mstruct, lib, prm7, sim, buf7) == 0
+    be.sync()
+    np.testing.assert_allclose(be.np(b["obs7"])[:, 358:], gs[f"task_v7_u{int(upright)}"], atol=1e-5)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
 def test_amp_obs_v2_vs_reference_golden(golden, backend):
     """R9 `_v2`: env.amp_obs_v=2 -> build_amp_observations_smpl_v2 (humanoid_amp.py:1015-1059): 196 + 12 floats per step (the key bodies'
     heading-local velocities after their positions); the history shift works on the 208-float frames."""
@@ -240,6 +284,22 @@ def test_amp_demo_and_reset_vs_oracle(golden, backend):
     want = po.build_amp_observations_smpl(ms["root_pos"], ms["root_rot"], ms["root_vel"], ms["root_ang_vel"], ms["dof_pos"], ms["dof_vel"],
                                           ms["rg_pos"][:, key_ids], dof_subset).reshape(n, 10, 196)
     np.testing.assert_allclose(be.np(out), want, atol=2e-5)
+    # the same with has_upright_start False and shape / limb columns: the clip's humanoid is the env of the same index
+    extra_np = rng.standard_normal((N, 21)).astype(F)
+    extra = be.arr(extra_np)
+    prm_s, keep_s = make_im_params(be, model, N, num_amp_obs_per_step=217, remove_base_rot=True, amp_obs_extra=extra)
+    out_s = be.zeros((n, 10, 217))
+    assert be.amp_obs_demo(mstruct, lib, prm_s, n, be.arr(ids), be.arr(t0), out_s) == 0
+    be.sync()
+    ex = np.repeat(extra_np[ids], 10, axis=0)
+    want_s = po.build_amp_observations_smpl(ms["root_pos"], ms["root_rot"], ms["root_vel"], ms["root_ang_vel"], ms["dof_pos"], ms["dof_vel"],
+                                            ms["rg_pos"][:, key_ids], dof_subset, upright=False, shape_params=ex[:, :11],
+                                            limb_weight_params=ex[:, 11:]).reshape(n, 10, 217)
+    # (upright clips read as a y-up asset: the stripped root frame's x axis can come close to vertical, where the heading atan2 amplifies
+    # fp32 rounding -- a handful of elements sit above the 2e-5 of the upright case)
+    d = np.abs(be.np(out_s) - want_s)
+    assert d.max() < 1e-3 and (d > 2e-5).mean() < 2e-3
+    np.testing.assert_array_equal(be.np(out_s)[..., 196:], ex.reshape(n, 10, 21))
 
     # ---- reset of a subset of envs ----
     nb, nd = 24, 69
