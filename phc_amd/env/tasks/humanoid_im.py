@@ -556,7 +556,9 @@ class HumanoidIm:
             if self._is_robot:
                 mf = make_robot_motion_dict(self.model, nclips, seed=seed, mean_seconds=mean_s, num_extend=self.num_extend_bodies, min_frames=min_frames)
             else:
-                mf = make_motion_dict(self.model.parent, nclips, seed=seed, body_names=self._body_names, mean_seconds=mean_s, min_frames=min_frames)
+                from ...utils.synthetic_motion import BASE_ROT
+                mf = make_motion_dict(self.model.parent, nclips, seed=seed, body_names=self._body_names, mean_seconds=mean_s, min_frames=min_frames,
+                                      base_rot=None if self._has_upright_start else BASE_ROT)
         from ...config import EasyDict
         motion_lib_cfg = EasyDict({"motion_file": mf, "device": self.device, "fix_height": FixHeightMode.full_fix,
                                    "min_length": self._min_motion_len, "max_length": -1, "im_eval": flags.im_eval,

@@ -32,10 +32,15 @@ def _quat_mul(a, b):
                      w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2], axis=-1)
 
 
-def make_clip(rng, parents, num_frames, body_names=None, fps=30):
+BASE_ROT = np.array([0.5, 0.5, 0.5, 0.5])   # root rotation of a y-up SMPL asset standing upright (robot.has_upright_start False, humanoid.py:1937)
+
+
+def make_clip(rng, parents, num_frames, body_names=None, fps=30, base_rot=None):
     """One smooth random clip.  Per-joint exp-map = low-pass filtered random walk
     (step N(0,0.05^2), sigma=3 frames), clipped to +-1 rad (knee y/z +-0.1);
-    root height 0.9+-0.05 m; root xy random walk ~1 m/s; random initial yaw."""
+    root height 0.9+-0.05 m; root xy random walk ~1 m/s; random initial yaw.
+    `base_rot` (xyzw): rest rotation of the root for assets that are not modelled upright (the root's world rotation is
+    yaw * tilt * base_rot)."""
     J = len(parents)
     T = int(num_frames)
     steps = rng.normal(0.0, 0.05, size=(T, J, 3))
@@ -52,6 +57,8 @@ def make_clip(rng, parents, num_frames, body_names=None, fps=30):
     q_local = _exp_map_to_quat(e)
     yaw_q = np.stack([np.zeros(T), np.zeros(T), np.sin(0.5 * yaw), np.cos(0.5 * yaw)], axis=-1)
     q_local[:, 0] = _quat_mul(yaw_q, q_local[:, 0])
+    if base_rot is not None:
+        q_local[:, 0] = _quat_mul(q_local[:, 0], np.broadcast_to(np.asarray(base_rot, dtype=np.float64), (T, 4)))
     q_global = np.zeros_like(q_local)
     for j in range(J):
         p = parents[j]
@@ -79,7 +86,7 @@ def make_clip(rng, parents, num_frames, body_names=None, fps=30):
 
 
 def make_motion_dict(parents, num_clips, seed=0, min_frames=30, max_frames=1800, mean_seconds=8.0,
-                     body_names=None, fps=30, lengths=None):
+                     body_names=None, fps=30, lengths=None, base_rot=None):
     """AMASS-shaped dict of ``num_clips`` clips.  Lengths are log-normal around
     ``mean_seconds`` clipped to [min_frames, max_frames] unless given."""
     rng = np.random.default_rng(seed)
@@ -89,7 +96,7 @@ def make_motion_dict(parents, num_clips, seed=0, min_frames=30, max_frames=1800,
             T = int(lengths[i])
         else:
             T = int(np.clip(rng.lognormal(np.log(mean_seconds), 0.5) * fps, min_frames, max_frames))
-        out[f"synthetic_{i:05d}"] = make_clip(rng, parents, T, body_names=body_names, fps=fps)
+        out[f"synthetic_{i:05d}"] = make_clip(rng, parents, T, body_names=body_names, fps=fps, base_rot=base_rot)
     return out
 
 

@@ -643,3 +643,73 @@ def test_bench_multi_rank_logic_two_ranks_on_one_gpu():
     n_opt = d["ppo_config"]["optimizer_steps_per_epoch"]
     assert comm["grad_allreduces_per_epoch"] == n_opt and all(x["collectives"] == 2 * n_opt for x in comm["ranks"])
     assert d["ppo_config"]["collectives_per_epoch"] == n_opt and d["ppo_samples_per_s"] > 0
+
+
+def test_shape_variation_env_end_to_end():
+    """robot.has_shape_variation (smpl_humanoid_shape.yaml) end to end: 3 compiled shapes (the reference's gender assets, its own fallback
+    when smpl_sim cannot write per-env MJCFs, humanoid.py:748), env i wears shape i % 3.  Checks: the reference clips are run through each
+    env's own skeleton (reset = reference state); the stepper keeps every env's OWN link lengths (rigid links: |knee - hip| is the shape's
+    offset norm) and carries its own weight; shape / limb columns sit at the end of the self observation and of every AMP step."""
+    task, env = make_task(48, motion="stand:4", **{"robot.has_shape_variation": True, "robot.has_shape_obs": True, "robot.has_shape_obs_disc": True,
+                                                   "robot.has_weight_obs": True})
+    N = 48
+    assert task._model_struct.num_shapes == 3 and len(task.shape_models) == 3
+    assert task.get_self_obs_size() == 358 + 11 + 10 and task._num_amp_obs_per_step == 196 + 11
+    shape = (torch.arange(N) % 3).numpy()
+    env.reset()
+    task._motion_start_times[:] = 0
+    names = task._body_names
+    pairs = [(names.index(a), names.index(b)) for a, b in (("L_Hip", "L_Knee"), ("R_Knee", "R_Ankle"), ("L_Shoulder", "L_Elbow"), ("Chest", "Neck"))]
+    want = np.array([[np.linalg.norm(task.shape_models[s].local_translation[b]) for a, b in pairs] for s in shape])
+    assert np.ptp(want[:3], axis=0).min() > 2e-3          # the three shapes do differ in every one of these links
+
+    def link_lengths():
+        p = task._rigid_body_pos.cpu().numpy()
+        return np.stack([np.linalg.norm(p[:, b] - p[:, a], axis=-1) for a, b in pairs], axis=1)
+    np.testing.assert_allclose(link_lengths(), want, atol=2e-5)              # reference state: FK of the clip through the env's skeleton
+    for it in range(40):
+        obs, rew, done, info = env.step(torch.zeros(N, 69, device=task.device))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(link_lengths(), want, atol=1e-4)              # the stepper used the env's own offsets for 40 steps
+    fz = task._contact_forces[..., 2].sum(-1).cpu().numpy()
+    weight = np.array([task.shape_models[s].total_mass for s in shape]) * 9.81
+    np.testing.assert_allclose(fz, weight, rtol=0.03)                        # standing: the ground carries each env's own weight
+    assert abs(weight[0] - weight[1]) > 50
+    hs = task.humanoid_shapes[:, :11]
+    assert torch.equal(obs[:, 358:369], hs) and torch.equal(obs[:, 369:379], task.humanoid_limb_and_weights)
+    amp = info["amp_obs"].view(N, 10, 207)
+    assert torch.equal(amp[:, :, 196:], hs[:, None].expand(N, 10, 11))
+    assert float(hs[:, 0].max()) == 2.0 and torch.isfinite(obs).all() and torch.isfinite(amp).all()
+    demo = env.fetch_amp_obs_demo(64)
+    assert demo.shape == (64, 2070) and torch.isfinite(demo).all()
+    # random actions + resets keep everything finite and the links rigid
+    for it in range(20):
+        obs, rew, done, info = env.step((torch.rand(N, 69, device=task.device) * 2 - 1) * 0.5)
+    np.testing.assert_allclose(link_lengths(), want, atol=2e-4)
+    assert torch.isfinite(obs).all() and torch.isfinite(rew).all()
+
+
+def test_non_upright_asset_env():
+    """robot.has_upright_start False (smplx_humanoid.yaml) end to end on the reference's y-up SMPL asset (mjcf/smpl_humanoid.xml): clips whose
+    root rests at (0.5, 0.5, 0.5, 0.5); the observations strip that base rotation, so a standing, forward-facing humanoid sees the same
+    heading-local picture as the upright asset does (root rotation observation ~ identity tan-norm), and PD offsets follow
+    humanoid.py:1398."""
+    task, env = make_task(32, motion="synthetic:3:1", **{"robot.has_upright_start": False, "model_asset": "smpl_yup_humanoid"})
+    assert task._im_params.remove_base_rot == 1
+    env.reset()
+    obs = task.obs_buf.clone()
+    root_rot = task._rigid_body_rot[:, 0]
+    base_c = torch.tensor([-0.5, -0.5, -0.5, 0.5], device=task.device).expand(32, 4)
+    stripped = torch.from_numpy(po.quat_mul(root_rot.cpu().numpy(), base_c.cpu().numpy())).to(task.device)
+    # heading-local root rotation observation (local_root_obs True): tan-norm of hinv * body_rot[0]; with the base rotation stripped from the
+    # heading the recomputation below must agree with the kernel's columns
+    hinv = po.calc_heading_quat_inv(stripped.cpu().numpy())
+    want = po.quat_to_tan_norm(po.quat_mul(hinv, root_rot.cpu().numpy()))
+    off = 1 + 23 * 3
+    np.testing.assert_allclose(obs[:, off:off + 6].cpu().numpy(), want, atol=1e-5)
+    # the stripped root is near upright (small tilt): its z axis points up
+    zc = po.my_quat_rotate(stripped.cpu().numpy(), np.tile(np.array([[0, 0, 1.0]], F), (32, 1)))[:, 2]
+    assert (zc > 0.9).all()
+    for it in range(10):
+        obs, rew, done, info = env.step((torch.rand(32, 69, device=task.device) * 2 - 1) * 0.3)
+    assert torch.isfinite(obs).all() and torch.isfinite(rew).all() and torch.isfinite(info["amp_obs"]).all()
