@@ -179,7 +179,10 @@ def _with_net(units, activation, net_name, cfg, extra_net):
 _BIG = [2048, 1536, 1024, 1024, 512, 512]
 GROUPS = {
     "env": {"env_im": _ENV_IM, "env_im_pnn": _ENV_IM_PNN, "env_im_getup_mcp": _ENV_IM_GETUP_MCP, "env_im_h1_phc": _ENV_IM_H1, "env_im_g1_phc": _ENV_IM_G1, "env_vr": _ENV_VR},
-    "robot": {"smpl_humanoid": _ROBOT_SMPL, "unitree_h1": _ROBOT_H1, "unitree_h1_nohead": _ROBOT_H1_NOHEAD, "unitree_g1": _ROBOT_G1},
+    "robot": {"smpl_humanoid": _ROBOT_SMPL,
+              # robot/smpl_humanoid_shape.yaml: per-env body shapes + shape parameters in the policy and discriminator observations
+              "smpl_humanoid_shape": dict(_ROBOT_SMPL, has_shape_obs=True, has_shape_obs_disc=True, has_shape_variation=True),
+              "unitree_h1": _ROBOT_H1, "unitree_h1_nohead": _ROBOT_H1_NOHEAD, "unitree_g1": _ROBOT_G1},
     "learning": {"im": _learning([1024, 512], "relu"), "im_big": _learning(_BIG, "silu", extra_cfg={"save_frequency": 1500}),
                  "im_pnn": _learning([1024, 512], "relu", "amp_pnn"),
                  "im_pnn_big": _learning(_BIG, "silu", "amp_pnn", {"amp_dropout": False, "save_frequency": 1500}),

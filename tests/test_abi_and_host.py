@@ -105,6 +105,12 @@ def test_model_asset_is_what_the_compiler_produces_from_the_reference_mjcf():
     b = load_model("smpl_humanoid")
     for x, y in zip(a.pack(), b.pack()):
         np.testing.assert_array_equal(x, y)
+    # the gender assets (per-env shapes: the reference's fallback, humanoid.py:748) and the y-up one (has_upright_start False)
+    for name, xml in (("smpl_0_humanoid", "smpl_0_humanoid.xml"), ("smpl_1_humanoid", "smpl_1_humanoid.xml"), ("smpl_2_humanoid", "smpl_2_humanoid.xml"),
+                      ("smpl_yup_humanoid", "smpl_humanoid.xml")):
+        a = ArticulationModel(compile_mjcf("/root/reference/phc/data/assets/mjcf/" + xml))
+        for x, y in zip(a.pack(), load_model(name).pack()):
+            np.testing.assert_array_equal(x, y)
     for name, xml in (("h1_humanoid", "unitree_h1/h1.xml"), ("g1_humanoid", "unitree_g1/g1.xml")):   # robots: mesh hulls from the shipped STLs
         a = ArticulationModel(compile_mjcf("/root/reference/phc/data/assets/robot/" + xml))
         for x, y in zip(a.pack(), load_model(name).pack()):
@@ -113,7 +119,7 @@ def test_model_asset_is_what_the_compiler_produces_from_the_reference_mjcf():
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/phc/data/cfg"), reason="reference checkout not present")
 @pytest.mark.parametrize("ov", [[], ["learning=im_big"], ["learning=im_pnn", "env=env_im_pnn"], ["learning=im_pnn_big"],
-                                ["learning=im_mcp", "env=env_im_getup_mcp"], ["env=env_vr"],
+                                ["learning=im_mcp", "env=env_im_getup_mcp"], ["env=env_vr"], ["robot=smpl_humanoid_shape"],
                                 ["robot=unitree_h1", "env=env_im_h1_phc", "sim=robot_sim", "control=robot_control"],
                                 ["robot=unitree_h1_nohead", "env=env_im_h1_phc", "sim=robot_sim", "control=robot_control"],
                                 ["robot=unitree_g1", "env=env_im_g1_phc", "sim=robot_sim", "control=robot_control", "learning=im_pnn_big"]])
