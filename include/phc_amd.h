@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PHC_ABI_VERSION 21
+#define PHC_ABI_VERSION 22
 #define PHC_MAX_BODIES 64   /* bodies (incl. extended reference bodies) per articulation; also the slot count of the model tables */
 #define PHC_EINVAL (-1)
 #define PHC_EUNSUPPORTED (-2)
@@ -160,7 +160,9 @@ typedef struct {
     const int32_t* ext_parent;        /* [E] body id of each extended body's parent */
     const float* ext_offset;          /* [E,3] position in the parent frame */
     int32_t obs_v;                    /* task-observation version: 6 (0 is read as 6; `compute_imitation_observations_v6`, humanoid_im.py:1300-1360: 24 floats per
-                                         tracked body) or 7 (`_v7`, :1362-1393, the keypoint models: position / velocity differences + reference positions, 9) */
+                                         tracked body), 7 (`_v7`, :1362-1393, the keypoint models: position / velocity differences + reference positions, 9),
+                                         or 1 / 2 / 3 / 8 / 9 (`compute_imitation_observations`, `_v2`, `_v3`, `_v8`, `_v9`, :1203-1306,1395-1515: 15 J,
+                                         15 J + 3 (J - 1), 9 J, 30 J, 18 J + 6 floats; 2 and 9 need the root as the first tracked body) */
     int32_t self_obs_v;               /* 1 (0 is read as 1): compute_humanoid_observations_smpl_max; 3: `_v3` (humanoid.py:2113-2169) = the same
                                          followed by the force-sensor readings [S*6] (num_self_obs grows by 6 S, humanoid.py:683) */
     int32_t num_force_sensors;        /* S of phc_sim_state_t.force_sensor (self_obs_v 3) */
@@ -174,6 +176,10 @@ typedef struct {
                                          counted in num_self_obs */
     int32_t num_amp_obs_extra;        /* the same at the end of every AMP step (has_shape_obs_disc / has_weight_obs_disc, humanoid_amp.py:1005-1008);
                                          counted in num_amp_obs_per_step */
+    int32_t zero_out_far_train;       /* env.zero_out_far_train (with zero_out_far): a reset / a clip restart moves the reference to a random spot of a
+                                         5 m disk around the humanoid and arms the cycle counter with zero_out_far_steps (humanoid_im.py:966-980,1133-1140) */
+    int32_t zero_out_far_steps;       /* env.zero_out_far_steps (90) */
+    int32_t cycle_motion_xp;          /* env.cycle_motion_xp: a clip restart shifts the reference by up to one metre in x and y (:1131-1132) */
     const float* self_obs_extra;      /* [N, num_self_obs_extra] row of the env */
     const float* amp_obs_extra;       /* [N, num_amp_obs_extra] row of the env (observations from simulator state) or of the MOTION (observations
                                          built from the reference clip: the clip carries its humanoid's shape, motion_lib_base.py:244,
@@ -212,6 +218,8 @@ typedef struct {
     int32_t* reset_count;             /* [3, PHC_RESET_SUBLISTS, PHC_RESET_COUNT_STRIDE], counter in element 0 */
     int32_t reset_slot;
     int32_t reset_sublist_cap;        /* >= 8 * ceil(ceil(N / 8) / PHC_RESET_SUBLISTS) */
+    const float* offset_rand;         /* [N,2] the caller's torch.rand draw for the random reference offsets of zero_out_far_train / cycle_motion_xp
+                                         (row of the env; refreshed by the caller before every launch that may use it); nullable unless one is set */
 } phc_im_buffers_t;
 
 int32_t phc_abi_version(void);

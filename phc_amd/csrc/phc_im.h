@@ -128,6 +128,13 @@ PHC_HD ImStepCtx im_post_prologue(const phc_motion_lib_t& lib, const phc_im_para
             const V3 rp = ref_root_pos_lerp(lib, fr);                               // get_root_pos_smpl motion_lib_base.py:522-547
             const float* rs = sim.root_states + env * 13;
             c.goff.x = rs[0] - rp.x; c.goff.y = rs[1] - rp.y;                       // :1146 (z keeps its value)
+            if (buf.offset_rand && prm.cycle_motion_xp) {                           // :1131-1132 (+ torch.rand(2): up to one metre)
+                c.goff.x += buf.offset_rand[env * 2]; c.goff.y += buf.offset_rand[env * 2 + 1];
+            } else if (buf.offset_rand && prm.zero_out_far && prm.zero_out_far_train) {   // :1133-1140
+                float ox, oy;
+                disk_offset(buf.offset_rand[env * 2], buf.offset_rand[env * 2 + 1], &ox, &oy);
+                c.goff.x += ox; c.goff.y += oy;
+            }
             c.t0 = motion_time(progress, prm.dt, c.start, c.start_off);             // :1148
         }
     }
@@ -213,13 +220,18 @@ PHC_HD RewardPartial im_post_lane(const phc_model_t& model, const phc_motion_lib
     int slot = prm.track_slot[j];
     if (slot >= 0) {
         BodyState rt = r1;
-        if (prm.zero_out_far) {
+        if (prm.zero_out_far && !(prm.obs_v >= 1 && prm.obs_v <= 3)) {   // (:783: versions 4 / 5 / 6 / 8 / 9, and 7 at :829)
             BodyState rroot = (j == 0) ? r1 : ref_body(lib, fr1, 0);
             if (j != 0) rroot.pos += c.goff;
             const float dist = zero_out_far_ref(prm, slot, body, root, rroot, &rt);
             if (j == 0 && buf.point_goal) buf.point_goal[env] = dist;  // :792
         }
-        task_obs_lane(prm, slot, body, root, rt, hinv, h, obs + prm.num_self_obs);
+        V3 jd = v3(0.f, 0.f, 0.f), jv, rjd = jd, rjv;
+        if (prm.obs_v == 2 && j >= 1) {   // humanoid_im.py:775-778: the joint of a tracked body, simulator vs reference at t + dt
+            ld_joint_state(sim, nd, env, model.ints[4 + 3 * PHC_MAX_BODIES + j], prm.dofs_per_joint, &jd, &jv);
+            ref_joint(lib, fr1, j, &rjd, &rjv);
+        }
+        task_obs_lane(prm, slot, body, root, rt, hinv, h, obs + prm.num_self_obs, &jd, &rjd);
     }
     // side-effect buffers of _compute_task_obs (humanoid_im.py:855-868)
     if (buf.ref_body_pos) st3(buf.ref_body_pos + (env * nb + j) * 3, r1.pos);
@@ -330,6 +342,10 @@ PHC_HD void im_reset_lane(const phc_model_t& model, const phc_motion_lib_t& lib,
         const float t1 = motion_time(1, prm.dt, t, 0.f);
         const FrameRef fr1 = frame_ref(lib, mid, t1);
         BodyState r1 = ref_body(lib, fr1, j);
+        V3 goff = v3(0.f, 0.f, 0.f);
+        if (buf.offset_rand && prm.zero_out_far && prm.zero_out_far_train)   // the far-away start (humanoid_im.py:966-980): set AFTER the state
+            disk_offset(buf.offset_rand[env * 2], buf.offset_rand[env * 2 + 1], &goff.x, &goff.y);   // was imposed, seen by the observations
+        r1.pos += goff;
         const Q4 hroot = obs_root_rot(prm, root.rot);
     Q4 hinv = calc_heading_quat_inv(hroot), h = calc_heading_quat(hroot);
         float* obs = buf.obs_buf + env * (int64_t)(prm.num_self_obs + prm.num_task_obs);
@@ -338,11 +354,15 @@ PHC_HD void im_reset_lane(const phc_model_t& model, const phc_motion_lib_t& lib,
         int slot = prm.track_slot[j];
         if (slot >= 0) {
             BodyState rt = r1;
-            if (prm.zero_out_far) {
-                const float dist = zero_out_far_ref(prm, slot, rs, root, (j == 0) ? r1 : ref_body(lib, fr1, 0), &rt);
+            if (prm.zero_out_far && !(prm.obs_v >= 1 && prm.obs_v <= 3)) {
+                BodyState rroot = (j == 0) ? r1 : ref_body(lib, fr1, 0);
+                if (j != 0) rroot.pos += goff;
+                const float dist = zero_out_far_ref(prm, slot, rs, root, rroot, &rt);
                 if (j == 0 && buf.point_goal) buf.point_goal[env] = dist;
             }
-            task_obs_lane(prm, slot, rs, root, rt, hinv, h, obs + prm.num_self_obs);
+            V3 jd = v3(0.f, 0.f, 0.f), jv, rjd = jd, rjv;
+            if (prm.obs_v == 2 && j >= 1) { ref_joint(lib, fr, j, &jd, &jv); ref_joint(lib, fr1, j, &rjd, &rjv); }   // (the imposed state is the reference at t)
+            task_obs_lane(prm, slot, rs, root, rt, hinv, h, obs + prm.num_self_obs, &jd, &rjd);
         }
         if (buf.ref_body_pos) st3(buf.ref_body_pos + (env * nb + j) * 3, r1.pos);
         if (buf.ref_body_rot) st4(buf.ref_body_rot + (env * nb + j) * 4, r1.rot);
@@ -356,10 +376,13 @@ PHC_HD void im_reset_lane(const phc_model_t& model, const phc_motion_lib_t& lib,
     if (j == 0) {
         buf.motion_start_times[env] = t;           // humanoid_amp.py:524
         buf.motion_start_times_offset[env] = 0.f;  // humanoid_im.py:956
-        st3(buf.global_offset + env * 3, v3(0.f, 0.f, 0.f));
+        V3 goff = v3(0.f, 0.f, 0.f);
+        const bool far_start = buf.offset_rand && prm.zero_out_far && prm.zero_out_far_train;
+        if (far_start) disk_offset(buf.offset_rand[env * 2], buf.offset_rand[env * 2 + 1], &goff.x, &goff.y);
+        st3(buf.global_offset + env * 3, goff);
         buf.progress_buf[env] = 0; buf.terminate_buf[env] = 0;  // humanoid.py:616-618
         if (clear_reset_flag) buf.reset_buf[env] = 0;
-        if (buf.cycle_counter) buf.cycle_counter[env] = 0;        // humanoid_im.py:960
+        if (buf.cycle_counter) buf.cycle_counter[env] = far_start ? prm.zero_out_far_steps : 0;        // humanoid_im.py:960,980
         if (buf.recovery_counter) buf.recovery_counter[env] = 0;  // humanoid_im_getup.py:155
     }
 }
@@ -396,13 +419,18 @@ PHC_HD void im_reset_from_state_lane(const phc_model_t& model, const phc_motion_
         int slot = prm.track_slot[j];
         if (slot >= 0) {
             BodyState rt = r1;
-            if (prm.zero_out_far) {
+            if (prm.zero_out_far && !(prm.obs_v >= 1 && prm.obs_v <= 3)) {
                 BodyState rroot = (j == 0) ? r1 : ref_body(lib, fr1, 0);
                 if (j != 0) rroot.pos += goff;
                 const float dist = zero_out_far_ref(prm, slot, body, root, rroot, &rt);
                 if (j == 0 && buf.point_goal) buf.point_goal[env] = dist;
             }
-            task_obs_lane(prm, slot, body, root, rt, hinv, h, obs + prm.num_self_obs);
+            V3 jd = v3(0.f, 0.f, 0.f), jv, rjd = jd, rjv;
+            if (prm.obs_v == 2 && j >= 1) {
+                ld_joint_state(sim, nd, env, model.ints[4 + 3 * PHC_MAX_BODIES + j], prm.dofs_per_joint, &jd, &jv);
+                ref_joint(lib, fr1, j, &rjd, &rjv);
+            }
+            task_obs_lane(prm, slot, body, root, rt, hinv, h, obs + prm.num_self_obs, &jd, &rjd);
         }
         if (buf.ref_body_pos) st3(buf.ref_body_pos + (env * nb + j) * 3, r1.pos);
         if (buf.ref_body_rot) st4(buf.ref_body_rot + (env * nb + j) * 4, r1.rot);

@@ -167,6 +167,14 @@ PHC_HD void store_body(float* rigid_body_state, int64_t env, int nb, int j, cons
 PHC_HD Q4 obs_root_rot(const phc_im_params_t& prm, Q4 q) {
     return prm.remove_base_rot ? quat_mul(q, q4(-0.5f, -0.5f, -0.5f, 0.5f)) : q;
 }
+// random reference offset of zero_out_far_train (humanoid_im.py:971-977,1135-1140): a point of the 5 m disk from two uniform draws
+PHC_HD void disk_offset(float u, float v, float* ox, float* oy) {
+    PHC_NO_CONTRACT
+    const float rd = sqrtf(u) * 5.0f;                  // torch.sqrt(torch.rand) * max_distance
+    const float ang = (v * 3.14159265358979323846f) * 2.0f;   // torch.rand * np.pi * 2
+    *ox = cosf(ang) * rd;
+    *oy = sinf(ang) * rd;
+}
 // per-env constant columns (shape parameters, limb weights) appended to an observation: the `nl` lanes of the env share the copy
 PHC_HD void obs_extra_lane(const float* src, int n, int lane, int nl, float* dst) {
     if (src == nullptr) return;
@@ -197,9 +205,44 @@ PHC_HD void self_obs_lane(const phc_im_params_t& prm, int nb, int j, const BodyS
 }
 
 // ---- R7: compute_imitation_observations_v6 (humanoid_im.py:1309-1358), time_steps = 1 ----
+// Other versions (env.obs_v), all at time_steps = 1 (fut_tracks off), J = tracked bodies, the tracked body in slot s:
+//   1 `compute_imitation_observations`   (:1203-1236)  [dpos 3J | drot 6J | dvel 3J | dangvel 3J]
+//   2 `_v2` (:1240-1278)  v1 + [ref_dof_pos - dof_pos of the joints of tracked bodies 1.. , 3 (J-1)]   (`dof` / `ref_dof`: this body's joint)
+//   3 `_v3` (:1281-1306)  [dpos 3J | drot 6J]
+//   8 `_v8` (:1396-1458)  v1 + [ref pos - root pos 3J | ref rot 6J | ref vel 3J | ref angvel 3J], all heading-local
+//   9 `_v9` (:1462-1515)  [dpos 3J | drot 6J | root dvel 3 | root dangvel 3 | ref pos - root pos 3J | ref rot 6J]
 PHC_HD void task_obs_lane(const phc_im_params_t& prm, int slot, const BodyState& body, const BodyState& root,
-                          const BodyState& ref, Q4 hinv, Q4 h, float* tobs) {
+                          const BodyState& ref, Q4 hinv, Q4 h, float* tobs, const V3* dof = nullptr, const V3* ref_dof = nullptr) {
     const int jt = prm.num_track_bodies;
+    if (prm.obs_v == 1 || prm.obs_v == 2 || prm.obs_v == 3 || prm.obs_v == 8 || prm.obs_v == 9) {
+        float tn[6];
+        st3(tobs + slot * 3, quat_rotate(hinv, ref.pos - body.pos));
+        quat_to_tan_norm(quat_mul(quat_mul(hinv, quat_mul(ref.rot, quat_conjugate(body.rot))), h), tn);
+        for (int k = 0; k < 6; ++k) tobs[jt * 3 + slot * 6 + k] = tn[k];
+        if (prm.obs_v == 3) return;
+        if (prm.obs_v == 9) {
+            if (slot == 0) {   // root velocity differences only (:1488-1494): the root is the first tracked body
+                st3(tobs + jt * 9, quat_rotate(hinv, ref.vel - body.vel));
+                st3(tobs + jt * 9 + 3, quat_rotate(hinv, ref.angvel - body.angvel));
+            }
+            st3(tobs + jt * 9 + 6 + slot * 3, quat_rotate(hinv, ref.pos - root.pos));
+            quat_to_tan_norm(quat_mul(hinv, ref.rot), tn);
+            for (int k = 0; k < 6; ++k) tobs[jt * 12 + 6 + slot * 6 + k] = tn[k];
+            return;
+        }
+        st3(tobs + jt * 9 + slot * 3, quat_rotate(hinv, ref.vel - body.vel));
+        st3(tobs + jt * 12 + slot * 3, quat_rotate(hinv, ref.angvel - body.angvel));
+        if (prm.obs_v == 2 && slot >= 1 && dof != nullptr && ref_dof != nullptr)
+            st3(tobs + jt * 15 + (slot - 1) * 3, *ref_dof - *dof);
+        if (prm.obs_v == 8) {
+            st3(tobs + jt * 15 + slot * 3, quat_rotate(hinv, ref.pos - root.pos));
+            quat_to_tan_norm(quat_mul(hinv, ref.rot), tn);
+            for (int k = 0; k < 6; ++k) tobs[jt * 18 + slot * 6 + k] = tn[k];
+            st3(tobs + jt * 24 + slot * 3, quat_rotate(hinv, ref.vel));
+            st3(tobs + jt * 27 + slot * 3, quat_rotate(hinv, ref.angvel));
+        }
+        return;
+    }
     if (prm.obs_v == 7) {
         // compute_imitation_observations_v7 (humanoid_im.py:1362-1393, the keypoint models): no rotation terms
         st3(tobs + slot * 3, quat_rotate(hinv, ref.pos - body.pos));

@@ -84,15 +84,15 @@ class HumanoidIm:
         if self.humanoid_type not in ("smpl", "h1", "g1"):
             raise NotImplementedError(f"humanoid_type={self.humanoid_type!r}: built so far: smpl, h1, g1")
         self._is_robot = self.humanoid_type in ("h1", "g1")
-        unsupported = dict(fut_tracks=False, zero_out_far_train=False, cycle_motion_xp=False, occl_training=False, res_action=False,
+        unsupported = dict(fut_tracks=False, occl_training=False, res_action=False,
                            kin_loss=False, z_readout=False, distill=False)
         for k, off in unsupported.items():
             v = env.get(k, robot.get(k, off))
             if v != off:
                 raise NotImplementedError(f"config option {k}={v!r} is outside the hot path built so far")
-        if env.get("obs_v", 1) not in (6, 7) or env.get("self_obs_v", 1) not in (1, 3) or env.get("amp_obs_v", 1) not in (1, 2):
-            raise NotImplementedError("only obs_v=6 (the shipped env_im* configs) / obs_v=7 (the keypoint models), self_obs_v=1 / 3 (force "
-                                      "sensors), amp_obs_v=1 / 2 (key-body velocities) are built")
+        if env.get("obs_v", 1) not in (1, 2, 3, 6, 7, 8, 9) or env.get("self_obs_v", 1) not in (1, 3) or env.get("amp_obs_v", 1) not in (1, 2):
+            raise NotImplementedError("built: obs_v 1 / 2 / 3 / 6 / 7 / 8 / 9 (4 and 5 -- past-step stacking, one-hot clip ids -- are not), self_obs_v 1 / 3 "
+                                      "(force sensors), amp_obs_v 1 / 2 (key-body velocities)")
         self.has_task = True
         self.obs_v, self.self_obs_v, self.amp_obs_v = int(env.get("obs_v", 6)), int(env.get("self_obs_v", 1)), int(env.get("amp_obs_v", 1))
         # S6: force sensors at the feet (humanoid.py:268,1031-1040), read by self_obs_v 3 only (:683,1449,1481)
@@ -130,14 +130,14 @@ class HumanoidIm:
         self._kd_scale = env.get("kd_scale", self._kp_scale)
         self.hard_negative = env.get("hard_negative", False)
         self.cycle_motion = env.get("cycle_motion", False)       # humanoid.py:316
-        self.cycle_motion_xp = False
+        self.cycle_motion_xp = env.get("cycle_motion_xp", False)  # humanoid.py:317 (a clip restart shifts the reference by up to a metre)
         self.power_reward = env.get("power_reward", False)
         self.power_coefficient = env.get("power_coefficient", 0.0005)
         self.kin_lr = env.get("kin_lr", 5e-4)
         self.fitting = env.get("fitting", False)
         self.z_readout = self.z_read = self.z_uniform = self.z_model = self.distill = self.kin_loss = False
         self.zero_out_far = env.get("zero_out_far", False)       # humanoid.py:325-330
-        self.zero_out_far_train = False
+        self.zero_out_far_train = env.get("zero_out_far_train", True)   # humanoid.py:315 (effective with zero_out_far only; the yamls set False)
         self.close_distance = env.get("close_distance", 0.25)
         self.far_distance = env.get("far_distance", 3)
         self._zero_out_far_steps = env.get("zero_out_far_steps", 90)
@@ -421,6 +421,9 @@ class HumanoidIm:
         self._reset_count = torch.zeros((3, abi.RESET_SUBLISTS, abi.RESET_COUNT_STRIDE), device=dev, dtype=torch.int32) if self._use_reset_list else None
         self._reset_slot, self._reset_list_pending = 0, False
         self._cycle_phase = torch.zeros(N, **f32) if self.cycle_motion else None
+        # draws behind the random reference offsets of zero_out_far_train (reset, clip restart) / cycle_motion_xp (clip restart)
+        self._far_start = bool(self.zero_out_far and self.zero_out_far_train)
+        self._offset_rand = torch.zeros((N, 2), **f32) if (self._far_start or (self.cycle_motion and self.cycle_motion_xp)) else None
         if not hasattr(self, "_recovery_counter"):
             self._recovery_counter = None                        # HumanoidImGetup owns one
         if self.zero_out_far and self._track_bodies[0] != self._body_names[0]:
@@ -464,7 +467,8 @@ class HumanoidIm:
             zero_out_far=self.zero_out_far, close_distance=self.close_distance, far_distance=self.far_distance,
             dofs_per_joint=1 if self._is_robot else 3, ext_parent=self._ext_parent_i32, ext_offset=self._ext_offset_f32,
             self_obs_v=self.self_obs_v, num_force_sensors=len(self.force_sensor_joints) if self.self_obs_v == 3 else 0, amp_obs_v=self.amp_obs_v,
-            remove_base_rot=not self._has_upright_start, self_obs_extra=self._self_obs_extra, amp_obs_extra=self._amp_obs_extra)
+            remove_base_rot=not self._has_upright_start, self_obs_extra=self._self_obs_extra, amp_obs_extra=self._amp_obs_extra,
+            zero_out_far_train=self._far_start, zero_out_far_steps=self._zero_out_far_steps, cycle_motion_xp=self.cycle_motion_xp)
         self._flag_state = (flags.im_eval, flags.no_collision_check)
 
     def _buffers(self, amp_in, amp_out):
@@ -473,7 +477,7 @@ class HumanoidIm:
                                      self._global_offset, self.ref_body_pos, self.ref_body_rot, self.ref_body_vel, self.ref_dof_pos,
                                      cycle_counter=self._cycle_counter, recovery_counter=self._recovery_counter,
                                      point_goal=self._point_goal, cycle_phase=self._cycle_phase, reset_list=self._reset_list,
-                                     reset_count=self._reset_count, reset_slot=self._reset_slot)
+                                     reset_count=self._reset_count, reset_slot=self._reset_slot, offset_rand=self._offset_rand)
 
     @property
     def _amp_obs_buf(self):
@@ -492,7 +496,12 @@ class HumanoidIm:
         return self._num_self_obs
 
     def get_task_obs_size(self):
-        return len(self._track_bodies) * (9 if self.obs_v == 7 else 24) if self._enable_task_obs else 0  # humanoid_im.py:505-509
+        if not self._enable_task_obs:
+            return 0
+        J = len(self._track_bodies)   # humanoid_im.py:486-520 with num_traj_samples = 1
+        if self.obs_v in (2, 9) and self._track_bodies[0] != self._body_names[0]:
+            raise NotImplementedError("obs_v 2 / 9 index the root as the first tracked body (humanoid_im.py:775-776,822)")
+        return {1: 15 * J, 2: 15 * J + 3 * (J - 1), 3: 9 * J, 6: 24 * J, 7: 9 * J, 8: 30 * J, 9: 18 * J + 6}[self.obs_v]
 
     def get_obs_size(self):
         return self.get_self_obs_size() + self.get_task_obs_size()
@@ -645,6 +654,8 @@ class HumanoidIm:
             # the draw behind `_sample_time` of the envs whose clip restarts this step (humanoid_im.py:1127); one value per
             # env is drawn (the reference draws only as many as restart, so the RNG streams differ in length, not in law)
             torch.rand(self.num_envs, out=self._cycle_phase)
+            if self._offset_rand is not None:
+                torch.rand(self._offset_rand.shape, out=self._offset_rand)
         if self._use_reset_list:
             if self._reset_list_pending:   # the previous step's list was never consumed (reset(env_ids) idiom): start this one empty
                 self._reset_count[self._reset_slot].zero_()
@@ -683,6 +694,8 @@ class HumanoidIm:
         env_ids = torch.as_tensor(env_ids, device=self.device).to(torch.long).contiguous()
         start_at_zero = (self._state_init == HumanoidIm.StateInit.Start) or flags.test  # humanoid_im.py:1003-1011
         phase = torch.rand(env_ids.shape, device=self.device) if self._state_init != HumanoidIm.StateInit.Start else None
+        if self._far_start:
+            torch.rand(self._offset_rand.shape, out=self._offset_rand)
         cur = self._amp_bufs[self._amp_cur]
         buf = self._buffers(cur, cur)
         L.check(self._lib.phc_im_reset(self._model_struct, self._motion_lib.struct, self._im_params, self._sim_struct, buf, n,
@@ -701,6 +714,8 @@ class HumanoidIm:
         cur = self._amp_bufs[self._amp_cur]
         self._reset_counter += 1
         use_list = self._use_reset_list and self._reset_list_pending
+        if self._far_start:
+            torch.rand(self._offset_rand.shape, out=self._offset_rand)
         buf = self._buffers(cur, cur)
         if not use_list:   # nothing appended since the last consumption (e.g. right after reset()): masked sweep over reset_buf
             buf.reset_list = None

@@ -195,6 +195,35 @@ def test_upright_start_and_shape_columns_vs_reference_golden(golden, backend, lo
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("obs_v,upright", [(1, True), (2, True), (3, True), (8, True), (9, True), (2, False), (8, False), (9, False)])
+def test_task_obs_versions_vs_reference_golden(golden, backend, obs_v, upright):
+    """env.obs_v = 1 / 2 / 3 / 8 / 9: the task block of the post-physics launch == the reference's compute_imitation_observations{,_v2,_v3,
+    _v8,_v9} (humanoid_im.py:1203-1306,1395-1515; oracle/gen_golden_task_obs_versions.py), self observation and reward untouched."""
+    be = get_backend(backend)
+    g, gv, gl = golden("task_fns"), golden("task_obs_versions"), golden("motion_lib_eval")
+    model, mstruct, keepm = model_on(be)
+    lib, keep = motion_lib_on(be, gl)
+    N = g["body_pos"].shape[0]
+    want = gv[f"v{obs_v}_u{int(upright)}"]
+    prm, keepp = make_im_params(be, model, N, obs_v=obs_v, remove_base_rot=not upright)
+    prm.num_task_obs = want.shape[1]
+    arrs, sim = _sim_arrays(be, g, N)
+    amp_in, amp_out = be.zeros((N, 10, 196)), be.zeros((N, 10, 196))
+    b = dict(progress=be.arr((g["progress"] - 1).astype(np.int64)), reset=be.zeros(N, np.int64), term=be.zeros(N, np.int64), rew=be.zeros(N),
+             raw=be.zeros((N, 5)), obs=be.zeros((N, 358 + want.shape[1])), mids=be.arr(g["env_motion"].astype(np.int64)),
+             st=be.arr(g["start_times"].astype(F)), so=be.zeros(N), goff=be.zeros((N, 3)))
+    buf = abi.im_buffers_struct(b["progress"], b["reset"], b["term"], b["rew"], b["raw"], b["obs"], amp_in, amp_out, b["mids"], b["st"],
+                                b["so"], b["goff"])
+    assert be.im_post_physics(mstruct, lib, prm, sim, buf) == 0
+    be.sync()
+    obs = be.np(b["obs"])
+    np.testing.assert_allclose(obs[:, 358:], want, atol=2e-5)
+    if upright:
+        np.testing.assert_allclose(obs[:, :358], g["self_obs"], atol=1e-5)
+    np.testing.assert_allclose(be.np(b["rew"]), g["reward"] + g["power_reward"], atol=1e-5)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
 def test_amp_obs_v2_vs_reference_golden(golden, backend):
     """R9 `_v2`: env.amp_obs_v=2 -> build_amp_observations_smpl_v2 (humanoid_amp.py:1015-1059): 196 + 12 floats per step (the key bodies'
     heading-local velocities after their positions); the history shift works on the 208-float frames."""
@@ -258,6 +287,28 @@ def test_post_physics_cycle_motion_zero_out_far_vs_reference_golden(golden, back
     np.testing.assert_allclose(o["pg"], g["point_goal_out"], atol=1e-5)
     np.testing.assert_allclose(o["obs"][:, 358:], g["task_obs"], atol=2e-5)
     assert g["pass_len"].sum() > 4 and g["zeros_subset"].sum() > 4 and g["far_subset"].sum() >= 1 and g["reward_far"].sum() > 4
+    # the random reference offsets of a clip restart: cycle_motion_xp adds torch.rand(2) (humanoid_im.py:1131-1132), zero_out_far_train a point
+    # of the 5 m disk (:1133-1140) to the offset the plain restart computes; envs that do not restart keep theirs
+    cycled = g["pass_len"].astype(bool)
+    uv = np.random.default_rng(8).random((N, 2)).astype(F)
+    for kw, add in ((dict(cycle_motion_xp=True), uv),
+                    (dict(zero_out_far_train=True), np.stack([np.cos(uv[:, 1] * F(np.pi) * F(2)) * np.sqrt(uv[:, 0]) * F(5),
+                                                              np.sin(uv[:, 1] * F(np.pi) * F(2)) * np.sqrt(uv[:, 0]) * F(5)], axis=1))):
+        prm2, keep2 = make_im_params(be, model, N, power_coefficient=0.00005, cycle_motion=True, zero_out_far=True, close_distance=0.25, far_distance=3.0, **kw)
+        arrs2, sim2 = _sim_arrays(be, gg, N)
+        b2 = dict(b, progress=be.arr((g["progress"] - 1).astype(np.int64)), st=be.arr(g["start_times"].astype(F)), so=be.arr(g["start_off"].astype(F)),
+                  goff=be.arr(g["global_offset"].astype(F)), cyc=be.arr(g["cycle_counter_in"].astype(np.int32)), obs=be.zeros((N, 934)),
+                  reset=be.zeros(N, np.int64), term=be.zeros(N, np.int64))
+        amp_out2, uv_d = be.zeros((N, 10, 196)), be.arr(uv)      # (the struct holds raw addresses: keep the arrays alive)
+        buf2 = abi.im_buffers_struct(b2["progress"], b2["reset"], b2["term"], b2["rew"], b2["raw"], b2["obs"], amp_in, amp_out2, b2["mids"],
+                                     b2["st"], b2["so"], b2["goff"], cycle_counter=b2["cyc"], point_goal=b2["pg"], cycle_phase=b2["ph"],
+                                     offset_rand=uv_d)
+        assert be.im_post_physics(mstruct, lib, prm2, sim2, buf2) == 0
+        be.sync()
+        want = g["global_offset_out"].astype(F).copy()
+        want[cycled, :2] += add[cycled]
+        np.testing.assert_allclose(be.np(b2["goff"]), want, atol=3e-6)
+        np.testing.assert_array_equal(be.np(b2["st"]), g["start_times_out"])
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
@@ -315,6 +366,7 @@ def test_amp_demo_and_reset_vs_oracle(golden, backend):
     phase = rng.random(3).astype(F)
     assert be.im_reset(mstruct, lib, prm, sim, buf, 3, be.arr(env_ids), be.arr(phase), 0) == 0
     be.sync()
+    keep_dev = (b, arrs, amp)      # (`sim` / `buf` hold raw addresses of these device arrays: they must outlive the launches below)
     b = {k: be.np(v) for k, v in b.items()}
     arrs = {k: be.np(v) for k, v in arrs.items()}
     amp = be.np(amp)
@@ -345,6 +397,40 @@ def test_amp_demo_and_reset_vs_oracle(golden, backend):
     want = po.build_amp_observations_smpl(msh["root_pos"], msh["root_rot"], msh["root_vel"], msh["root_ang_vel"], msh["dof_pos"],
                                           msh["dof_vel"], msh["rg_pos"][:, key_ids], dof_subset).reshape(3, 10, 196)
     np.testing.assert_allclose(amp[env_ids], want, atol=2e-5)
+
+    # ---- zero_out_far_train (humanoid_im.py:966-980): the reset leaves the humanoid on the clip but moves the REFERENCE to a random point of a
+    # 5 m disk (global offset), arms the cycle counter, and the observations of the reset envs see the shifted reference ----
+    prm_f, keep_f = make_im_params(be, model, N, zero_out_far=True, zero_out_far_train=True, zero_out_far_steps=90)
+    uv = rng.random((N, 2)).astype(F)
+    cyc, pg = be.zeros(N, np.int32), be.zeros(N)
+    bf = dict(progress=be.arr(np.full(N, 7, np.int64)), reset=be.arr(np.ones(N, np.int64)), term=be.arr(np.ones(N, np.int64)), rew=be.zeros(N),
+              raw=be.zeros((N, 5)), obs=be.zeros((N, 934)), mids=be.arr(np.arange(N, dtype=np.int64)), st=be.arr(np.full(N, -1, F)),
+              so=be.arr(np.full(N, 3, F)), goff=be.arr(np.ones((N, 3), F)))
+    ampf = be.zeros((N, 10, 196))
+    uv_d = be.arr(uv)      # (the struct holds raw addresses: keep the array alive)
+    buff = abi.im_buffers_struct(bf["progress"], bf["reset"], bf["term"], bf["rew"], bf["raw"], bf["obs"], ampf, ampf, bf["mids"], bf["st"], bf["so"],
+                                 bf["goff"], cycle_counter=cyc, point_goal=pg, offset_rand=uv_d)
+    ids_d, ph_d = be.arr(env_ids), be.arr(phase)
+    assert be.im_reset(mstruct, lib, prm_f, sim, buff, 3, ids_d, ph_d, 0) == 0
+    be.sync()
+    rd, ang = np.sqrt(uv[env_ids, 0]) * F(5), uv[env_ids, 1] * F(np.pi) * F(2)
+    want_off = np.stack([np.cos(ang) * rd, np.sin(ang) * rd, np.zeros(3, F)], axis=1).astype(F)
+    np.testing.assert_allclose(be.np(bf["goff"])[env_ids], want_off, atol=2e-6)
+    assert (be.np(cyc)[env_ids] == 90).all() and (be.np(cyc)[[0, 3, 5]] == 0).all()
+    obs_f = be.np(bf["obs"])
+    np.testing.assert_allclose(obs_f[env_ids, :358], so, atol=2e-5)                      # the state itself is the un-shifted reference
+    dist = np.linalg.norm(ms["rg_pos"][:, 0] - (ms1["rg_pos"][:, 0] + want_off), axis=-1)
+    np.testing.assert_allclose(be.np(pg)[env_ids], dist, atol=2e-5)                       # _point_goal (:792)
+    assert (dist > 0.25).any()
+    # task observation against the shifted reference with the zero_out_far gating of humanoid_im.py:783-797
+    rp, rr, rv, rw = ms1["rg_pos"] + want_off[:, None], ms1["rb_rot"].copy(), ms1["body_vel"].copy(), ms1["body_ang_vel"].copy()
+    z = dist > 0.25
+    rp[z, 1:], rr[z, 1:], rv[z], rw[z] = ms["rg_pos"][z, 1:], ms["rb_rot"][z, 1:], ms["body_vel"][z], ms["body_ang_vel"][z]
+    vz = dist > 3.0
+    rp[vz, 0] = (rp[vz, 0] - ms["rg_pos"][vz, 0]) / dist[vz, None] * F(3.0) + ms["rg_pos"][vz, 0]
+    to_f = po.compute_imitation_observations_v6(ms["rg_pos"][:, 0], ms["rb_rot"][:, 0], ms["rg_pos"], ms["rb_rot"], ms["body_vel"], ms["body_ang_vel"],
+                                                rp, rr, rv, rw)
+    np.testing.assert_allclose(obs_f[env_ids, 358:], to_f, atol=3e-5)
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
