@@ -480,17 +480,18 @@ PHC_HD void aba_load_pairs(PairList<NP>& P, const phc_model_t& m, int l, int nl)
 // emulation / fp64 oracle test every pair in every sub-step; they agree with this unless such a pair exists.
 template <int NP>
 PHC_HD void aba_collide_pairs(const PairList<NP>& P, const phc_sim_params_t& prm, float dt, const Xch& x, float* caps, uint32_t& near, bool refresh) {
-    if (refresh) {
-        uint32_t nr = 0;
+    // ONE unrolled loop for both modes (two copies of the 18 inlined pair tests cost the one-body-per-lane kernel 160 B / lane of
+    // scratch: 13 MB of extra write traffic per launch)
+    uint32_t nr = refresh ? 0u : near;
 #pragma unroll
-        for (int t = 0; t < NP; ++t)
-            if (P.pr[t] >= 0 && !aba_collide_pair(prm, dt, P.pr[t] & 0xff, P.pr[t] >> 8, x, caps)) nr |= 1u << t;
-        near = nr;
-    } else {
-#pragma unroll
-        for (int t = 0; t < NP; ++t)
-            if ((near >> t) & 1u) aba_collide_pair(prm, dt, P.pr[t] & 0xff, P.pr[t] >> 8, x, caps);
+    for (int t = 0; t < NP; ++t) {
+        const bool go = refresh ? (P.pr[t] >= 0) : (((near >> t) & 1u) != 0u);
+        if (go) {
+            const bool far = aba_collide_pair(prm, dt, P.pr[t] & 0xff, P.pr[t] >> 8, x, caps);
+            if (refresh && !far) nr |= 1u << t;
+        }
     }
+    near = nr;
 }
 // net body-body contact force / moment of body j from its accumulators
 PHC_HD void aba_collect_self(AbaLane& L, int j, const float* caps) {

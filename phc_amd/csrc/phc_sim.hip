@@ -95,7 +95,7 @@ __device__ __forceinline__ bool stage_aligned(const phc_sim_state_t& sim) {
 // >256 VGPRs: 214-252 us vs 158 us for this mapping.  __launch_bounds__(64, 2): two wavefronts per SIMD (<= 256 VGPRs,
 // 68 B/lane of scratch) beats one (272 registers, no scratch: 195 us) and three (168 VGPRs, 412 B scratch: 280 us).
 // ------------------------------------------------------------------------------------------
-template <bool STEP, int JT, int GRP>
+template <bool STEP, int JT, int GRP, bool SHAPES = false>
 __global__ __launch_bounds__(64, 2) void k_sim_step(phc_model_t model_all, phc_sim_params_t prm, phc_sim_state_t sim,
                                                 const float* __restrict__ actions, const float* __restrict__ pd_off,
                                                 const float* __restrict__ pd_scale, const int32_t* __restrict__ freeze,
@@ -107,7 +107,9 @@ __global__ __launch_bounds__(64, 2) void k_sim_step(phc_model_t model_all, phc_s
     const int64_t slot = (int64_t)blockIdx.x * (64 / GRP) + grp;
     // env_ids (refresh of a teleported subset only): slot -> listed env
     const int64_t env = (!STEP && env_ids != nullptr) ? (slot < num_listed ? env_ids[slot] : sim.num_envs) : slot;
-    const phc_model_t model = model_for_env(model_all, sim, env);
+    // SHAPES (per-env body shapes): the env's block of the model tables -- a per-lane pointer pair; the single-shape instantiation keeps the
+    // tables behind scalar registers (with the select compiled in unconditionally the kernel spilled 188 B / lane: 35 MB of scratch traffic)
+    const phc_model_t model = SHAPES ? model_for_env(model_all, sim, env) : model_all;
     const int nb = model.num_bodies, nd = model.num_dof;
     const bool active = env < sim.num_envs && lane < nb;
     Xch x;
@@ -187,7 +189,7 @@ __global__ __launch_bounds__(64, 2) void k_sim_step(phc_model_t model_all, phc_s
 // one wavefront per SIMD (<= 2048 envs) and 106 us with two or three (4096-6144 envs) -- it is bound by the latency of one
 // wavefront's 72 dependent level-steps, so halving the wavefront count at N = 4096 moves it onto the one-per-SIMD plateau.
 // ------------------------------------------------------------------------------------------
-template <int JT, int GRP>
+template <int JT, int GRP, bool SHAPES = false>
 __global__ __launch_bounds__(64, 1) void k_sim_step16(phc_model_t model_all, phc_sim_params_t prm, phc_sim_state_t sim,
                                                   const float* __restrict__ actions, const float* __restrict__ pd_off,
                                                   const float* __restrict__ pd_scale, const int32_t* __restrict__ freeze,
@@ -197,7 +199,9 @@ __global__ __launch_bounds__(64, 1) void k_sim_step16(phc_model_t model_all, phc
     const int lane = threadIdx.x & (GRP - 1);
     const int grp = threadIdx.x / GRP;
     const int64_t env = (int64_t)blockIdx.x * (64 / GRP) + grp;
-    const phc_model_t model = model_for_env(model_all, sim, env);
+    // SHAPES (per-env body shapes): the env's block of the model tables -- a per-lane pointer pair; the single-shape instantiation keeps the
+    // tables behind scalar registers (with the select compiled in unconditionally the kernel spilled 188 B / lane: 35 MB of scratch traffic)
+    const phc_model_t model = SHAPES ? model_for_env(model_all, sim, env) : model_all;
     const int nb = model.num_bodies, nd = model.num_dof;
     const int split = model.split_level, nA = model.num_below_split;
     const bool env_ok = env < sim.num_envs;
@@ -286,7 +290,7 @@ __global__ __launch_bounds__(64, 1) void k_sim_step16(phc_model_t model_all, phc
     PHC_PROF_FLUSH
 }
 
-template <bool STEP, int JT>
+template <bool STEP, int JT, bool SHAPES>
 static void sim_launch_jt(const phc_model_t* model, const phc_sim_params_t& prm, const phc_sim_state_t* sim, const float* actions,
                           const float* off, const float* scale, const int32_t* freeze, int num_sim_calls, hipStream_t stream,
                           const int64_t* env_ids, int num_listed, bool two_slot) {
@@ -294,18 +298,18 @@ static void sim_launch_jt(const phc_model_t* model, const phc_sim_params_t& prm,
     const bool wide = model->num_bodies > 32;   // more bodies than a 32-lane group holds: one env per wavefront (two in the two-slot mapping)
     if (STEP && two_slot) {
         if (wide)
-            hipLaunchKernelGGL((k_sim_step16<JT, 32>), dim3((groups + 1) / 2), dim3(64), 0, stream, *model, prm, *sim, actions, off, scale, freeze,
+            hipLaunchKernelGGL((k_sim_step16<JT, 32, SHAPES>), dim3((groups + 1) / 2), dim3(64), 0, stream, *model, prm, *sim, actions, off, scale, freeze,
                                num_sim_calls);
         else
-            hipLaunchKernelGGL((k_sim_step16<JT, 16>), dim3((groups + 3) / 4), dim3(64), 0, stream, *model, prm, *sim, actions, off, scale, freeze,
+            hipLaunchKernelGGL((k_sim_step16<JT, 16, SHAPES>), dim3((groups + 3) / 4), dim3(64), 0, stream, *model, prm, *sim, actions, off, scale, freeze,
                                num_sim_calls);
         return;
     }
     if (wide)
-        hipLaunchKernelGGL((k_sim_step<STEP, JT, 64>), dim3(groups), dim3(64), 0, stream, *model, prm, *sim, actions, off, scale, freeze,
+        hipLaunchKernelGGL((k_sim_step<STEP, JT, 64, SHAPES>), dim3(groups), dim3(64), 0, stream, *model, prm, *sim, actions, off, scale, freeze,
                            num_sim_calls, env_ids, num_listed);
     else
-        hipLaunchKernelGGL((k_sim_step<STEP, JT, 32>), dim3((groups + 1) / 2), dim3(64), 0, stream, *model, prm, *sim, actions, off, scale, freeze,
+        hipLaunchKernelGGL((k_sim_step<STEP, JT, 32, SHAPES>), dim3((groups + 1) / 2), dim3(64), 0, stream, *model, prm, *sim, actions, off, scale, freeze,
                            num_sim_calls, env_ids, num_listed);
 }
 
@@ -313,10 +317,12 @@ template <bool STEP>
 static void sim_launch(const phc_model_t* model, const phc_sim_params_t& prm, const phc_sim_state_t* sim, const float* actions,
                        const float* off, const float* scale, const int32_t* freeze, int num_sim_calls, hipStream_t stream,
                        const int64_t* env_ids = nullptr, int num_listed = 0, bool two_slot = false) {
-    if (model->num_dof == model->num_bodies - 1 && model->num_bodies > 2)  // one revolute joint per body (robots)
-        sim_launch_jt<STEP, PHC_JT_REVOLUTE>(model, prm, sim, actions, off, scale, freeze, num_sim_calls, stream, env_ids, num_listed, two_slot);
+    if (model->num_dof == model->num_bodies - 1 && model->num_bodies > 2)  // one revolute joint per body (robots; one shape)
+        sim_launch_jt<STEP, PHC_JT_REVOLUTE, false>(model, prm, sim, actions, off, scale, freeze, num_sim_calls, stream, env_ids, num_listed, two_slot);
+    else if (model->num_shapes > 1 && sim->env_shape != nullptr)   // per-env body shapes (SMPL family)
+        sim_launch_jt<STEP, PHC_JT_SPHERICAL, true>(model, prm, sim, actions, off, scale, freeze, num_sim_calls, stream, env_ids, num_listed, two_slot);
     else
-        sim_launch_jt<STEP, PHC_JT_SPHERICAL>(model, prm, sim, actions, off, scale, freeze, num_sim_calls, stream, env_ids, num_listed, two_slot);
+        sim_launch_jt<STEP, PHC_JT_SPHERICAL, false>(model, prm, sim, actions, off, scale, freeze, num_sim_calls, stream, env_ids, num_listed, two_slot);
 }
 
 static inline int32_t launch_status() {
@@ -330,6 +336,8 @@ static int32_t check_model(const phc_model_t* m) {
     if (!m || m->num_bodies < 1 || m->num_bodies > PHC_MAX_BODIES || !m->ints || !m->floats) return PHC_EINVAL;
     // all-spherical (SMPL family) or all-revolute (H1 / G1) articulations
     if (m->num_dof != 3 * (m->num_bodies - 1) && m->num_dof != m->num_bodies - 1) return PHC_EUNSUPPORTED;
+    if (m->num_shapes > 1 && m->num_dof != 3 * (m->num_bodies - 1)) return PHC_EUNSUPPORTED;   // per-env shapes: SMPL family only
+    if (m->num_shapes > 1 && (m->int_stride <= 0 || m->float_stride <= 0)) return PHC_EINVAL;
     return 0;
 }
 
