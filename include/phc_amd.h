@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PHC_ABI_VERSION 22
+#define PHC_ABI_VERSION 23
 #define PHC_MAX_BODIES 64   /* bodies (incl. extended reference bodies) per articulation; also the slot count of the model tables */
 #define PHC_EINVAL (-1)
 #define PHC_EUNSUPPORTED (-2)
@@ -311,11 +311,13 @@ int32_t phc_fk(const phc_model_t* model, int64_t num_frames, const float* local_
  *   run_mean / run_var / run_count (fp64, in place; NULL = no update, eval mode or frozen) <- parallel-variance update with the batch
  *   mean and unbiased variance (:56-67,100-104).  norm_* may alias run_* (output from the statistics BEFORE the update, as the
  *   reference computes it) or be a frozen copy (amp_agent.py:527-532 `running_mean_std_temp`).
+ * out_stride (ABI 23): elements between two output rows (0 = cols): the output may be the left columns of a wider buffer whose K is
+ *   padded to a GEMM-friendly multiple (934 -> 1024: the first-layer GEMMs of the update run 20-30 % faster, profiles/r02_notes.md).
  * workspace: phc_running_norm_workspace(rows, cols) bytes of device memory (only used when updating); its LAST 8 bytes (a ticket
  * counter of the finishing kernel) must be zero before the first call and are left at zero. */
 int64_t phc_running_norm_workspace(int64_t rows, int32_t cols);
 int32_t phc_running_norm(const float* x, const int64_t* row_index, int64_t rows, int32_t cols, const double* norm_mean, const double* norm_var, float epsilon,
-                         float clamp, void* out, int32_t out_bf16, double* run_mean, double* run_var, double* run_count,
+                         float clamp, void* out, int32_t out_bf16, int32_t out_stride, double* run_mean, double* run_var, double* run_count,
                          double* workspace, void* stream);
 
 /* Column sums of a bf16 matrix x [rows, cols] -> out fp32 [cols]: the bias gradient of a linear layer (autograd's `sum(0)` of

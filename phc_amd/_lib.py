@@ -97,7 +97,7 @@ _SIGNATURES = {
     "phc_gae": ([c_i32, c_i32, c_p, c_p, c_p, c_p, c_f, c_f, c_p, c_p], c_i32),
     "phc_fk": ([P(Model), c_i64, c_p, c_p, c_p, c_p, c_p], c_i32),
     "phc_running_norm_workspace": ([c_i64, c_i32], c_i64),
-    "phc_running_norm": ([c_p, c_p, c_i64, c_i32, c_p, c_p, c_f, c_f, c_p, c_i32, c_p, c_p, c_p, c_p, c_p], c_i32),
+    "phc_running_norm": ([c_p, c_p, c_i64, c_i32, c_p, c_p, c_f, c_f, c_p, c_i32, c_i32, c_p, c_p, c_p, c_p, c_p], c_i32),
     "phc_colsum_workspace": ([c_i64, c_i32], c_i64),
     "phc_colsum_bf16": ([c_p, c_i64, c_i32, c_p, c_p, c_p], c_i32),
     "phc_colsum_relu_bf16": ([c_p, c_p, c_i64, c_i32, c_p, c_p, c_p, c_p], c_i32),
@@ -131,7 +131,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the .so does not export the symbol
         fn.argtypes = argtypes
         fn.restype = restype
-    if lib.phc_abi_version() != 22:
+    if lib.phc_abi_version() != 23:
         raise ImportError("libphc_amd.so ABI version mismatch")
     _lib = lib
     return lib

@@ -24,7 +24,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 template <bool BF16>
 __global__ __launch_bounds__(RN_COLS) void k_running_norm(const float* __restrict__ x, const int64_t* __restrict__ idx, int64_t rows, int cols,
                                                           const double* __restrict__ mean, const double* __restrict__ var, float eps, float clampv,
-                                                          void* __restrict__ out, double* __restrict__ partial) {
+                                                          void* __restrict__ out, int out_stride, double* __restrict__ partial) {
     const int c = blockIdx.x * RN_COLS + threadIdx.x;
     if (c >= cols) return;
     const int64_t r0 = (int64_t)blockIdx.y * RN_ROWS;
@@ -38,8 +38,8 @@ __global__ __launch_bounds__(RN_COLS) void k_running_norm(const float* __restric
             const float t = (v - m) / s;
             float y = fminf(fmaxf(t, -clampv), clampv);
             if (t != t) y = t;   // torch.clamp propagates NaN; fminf / fmaxf do not
-            if (BF16) reinterpret_cast<__hip_bfloat16*>(out)[r * cols + c] = __float2bfloat16(y);
-            else reinterpret_cast<float*>(out)[r * cols + c] = y;
+            if (BF16) reinterpret_cast<__hip_bfloat16*>(out)[r * out_stride + c] = __float2bfloat16(y);
+            else reinterpret_cast<float*>(out)[r * out_stride + c] = y;
         }
     };
     int64_t r = r0;
@@ -523,9 +523,11 @@ int64_t phc_running_norm_workspace(int64_t rows, int32_t cols) {
 }
 
 int32_t phc_running_norm(const float* x, const int64_t* row_index, int64_t rows, int32_t cols, const double* norm_mean, const double* norm_var, float epsilon,
-                         float clamp, void* out, int32_t out_bf16, double* run_mean, double* run_var, double* run_count,
+                         float clamp, void* out, int32_t out_bf16, int32_t out_stride, double* run_mean, double* run_var, double* run_count,
                          double* workspace, void* stream) {
     if (!x || rows < 0 || cols < 1 || !norm_mean || !norm_var) return PHC_EINVAL;
+    if (out_stride == 0) out_stride = cols;
+    if (out_stride < cols) return PHC_EINVAL;
     const bool update = run_mean != nullptr;
     if (update && (!run_var || !run_count || !workspace)) return PHC_EINVAL;
     if (!update && !out) return PHC_EINVAL;
@@ -535,9 +537,9 @@ int32_t phc_running_norm(const float* x, const int64_t* row_index, int64_t rows,
     const dim3 grid((cols + RN_COLS - 1) / RN_COLS, (unsigned)nchunks);
     hipStream_t st = (hipStream_t)stream;
     if (out_bf16)
-        hipLaunchKernelGGL(k_running_norm<true>, grid, dim3(RN_COLS), 0, st, x, row_index, rows, cols, norm_mean, norm_var, epsilon, clamp, out, update ? workspace : nullptr);
+        hipLaunchKernelGGL(k_running_norm<true>, grid, dim3(RN_COLS), 0, st, x, row_index, rows, cols, norm_mean, norm_var, epsilon, clamp, out, out_stride, update ? workspace : nullptr);
     else
-        hipLaunchKernelGGL(k_running_norm<false>, grid, dim3(RN_COLS), 0, st, x, row_index, rows, cols, norm_mean, norm_var, epsilon, clamp, out, update ? workspace : nullptr);
+        hipLaunchKernelGGL(k_running_norm<false>, grid, dim3(RN_COLS), 0, st, x, row_index, rows, cols, norm_mean, norm_var, epsilon, clamp, out, out_stride, update ? workspace : nullptr);
     if (update)
         hipLaunchKernelGGL(k_running_norm_finish, dim3((cols + 63) / 64), dim3(1024), 0, st, workspace, (int)nchunks, rows, cols, run_mean, run_var, run_count,
                            reinterpret_cast<unsigned int*>(workspace + nchunks * 2 * (int64_t)cols));

@@ -31,6 +31,7 @@ MI355X-first differences (results-preserving):
 import copy
 import os
 import time
+import warnings
 
 import numpy as np
 import torch
@@ -94,6 +95,10 @@ class _marker:
             torch.cuda.nvtx.range_pop()
 
 
+# K-padded weights are strided views with strided gradients of the SAME layout: autograd's "gradient layout contract" note does not apply
+warnings.filterwarnings("ignore", message="grad and param do not obey the gradient layout contract")
+
+
 class FlatGradBucket:
     """All trainable parameters AND their gradients as views of two flat fp32 buffers.
 
@@ -106,17 +111,33 @@ class FlatGradBucket:
 
     def __init__(self, params):
         self.params = [p for p in params if p.requires_grad]
-        n = sum(p.numel() for p in self.params)
         dev = self.params[0].device
+        # K-padded weights (round 2): a first-layer weight [N, K] whose K is no GEMM-friendly multiple (obs 934, AMP obs 1960) is STORED with
+        # rows Kp = `_pad_cols` apart (network.build_mlp tags it); the module's parameter is the strided view [:, :K] -- shapes, state dicts
+        # and checkpoints are unchanged -- while the GEMMs read the padded bf16 copy against K-padded inputs (pad = 0: same numbers; the
+        # first-layer forward / weight-gradient GEMMs run 20-30 % faster, scripts/gemm_pad_probe.py).  The pad elements start at zero and only
+        # ever see zero gradients.
+        def alloc(p):
+            kp = int(getattr(p, "_pad_cols", 0))
+            return p.shape[0] * kp if (dev.type == "cuda" and p.dim() == 2 and kp > p.shape[1]) else p.numel()
+        self.segments = []
+        n = 0
+        for p in self.params:
+            self.segments.append((n, alloc(p)))
+            n += alloc(p)
         self.flat_param = torch.zeros(n, device=dev, dtype=torch.float32)
         self.flat = torch.zeros(n, device=dev, dtype=torch.float32)
-        o = 0
-        for p in self.params:
-            k = p.numel()
-            self.flat_param[o:o + k].copy_(p.data.reshape(-1))
-            p.data = self.flat_param[o:o + k].view_as(p)
-            p.grad = self.flat[o:o + k].view_as(p)
-            o += k
+        for p, (o, k) in zip(self.params, self.segments):
+            if k != p.numel():
+                kp = k // p.shape[0]
+                pv, gv = self.flat_param[o:o + k].view(p.shape[0], kp), self.flat[o:o + k].view(p.shape[0], kp)
+                pv[:, :p.shape[1]].copy_(p.data)
+                p._padded, p._grad_padded = pv, gv
+                p.data, p.grad = pv[:, :p.shape[1]], gv[:, :p.shape[1]]
+            else:
+                self.flat_param[o:o + k].copy_(p.data.reshape(-1))
+                p.data = self.flat_param[o:o + k].view_as(p)
+                p.grad = self.flat[o:o + k].view_as(p)
         self.flat_param.grad = self.flat
         self.gen = 0   # bumped by zero(): lets a layer's backward store the first gradient of a step directly (fast_ops._first_write)
         for p in self.params:
@@ -126,11 +147,9 @@ class FlatGradBucket:
         self.shadow, self._shadow_live = None, [False]
         if dev.type == "cuda":
             self.shadow = torch.zeros(n, device=dev, dtype=torch.bfloat16)
-            o = 0
-            for p in self.params:
-                k = p.numel()
-                p._bf16_shadow, p._shadow_live = self.shadow[o:o + k].view_as(p), self._shadow_live
-                o += k
+            for p, (o, k) in zip(self.params, self.segments):   # (a K-padded weight's bf16 copy is the PADDED matrix)
+                sh = self.shadow[o:o + k]
+                p._bf16_shadow, p._shadow_live = (sh.view(p.shape[0], k // p.shape[0]) if k != p.numel() else sh.view_as(p)), self._shadow_live
 
     def shadow_scope(self):
         """Context of the minibatch loop: inside it only the optimizer kernel changes the parameters, so their bf16 copies stay valid."""
@@ -145,6 +164,11 @@ class FlatGradBucket:
             def __exit__(self_, *a):
                 bucket._shadow_live[0] = False
         return _Scope()
+
+    def param_view(self, flat, i):
+        """Parameter i's slice of a flat per-element tensor (optimizer moments) in the parameter's own shape."""
+        p, (o, k) = self.params[i], self.segments[i]
+        return flat[o:o + k].view(p.shape[0], k // p.shape[0])[:, :p.shape[1]] if k != p.numel() else flat[o:o + k].view_as(p)
 
     def zero(self, decay=None):
         """`decay` [(parameter, c)]: start that parameter's gradient at c * parameter (an L2 term's gradient written in place instead of
@@ -243,6 +267,10 @@ class IMAmpAgent:
         self._amp_input_mean_std = RunningMeanStd((amp_dim,)).to(self.device) if self._normalize_amp_input else None
         self.running_mean_std_temp = None
         self.grads = FlatGradBucket(self.model.parameters())
+        # K-padded first layers: width of the padded input buffers the normalisers write (0: no padding; see FlatGradBucket)
+        padded_k = {p.shape[1]: p._padded.shape[1] for p in self.grads.params if getattr(p, "_padded", None) is not None}
+        self._obs_pad_cols = padded_k.get(obs_dim, 0)
+        self._amp_pad_cols = padded_k.get(amp_dim, 0)
         # opt-in (`learning.params.config.hip_graph=True`, bench.py sets it).  Known hazard (scripts/graph_repro2.py): if the caller keeps
         # an autograd-tracked copy of a parameter alive (`w0 = p.clone()` instead of `p.detach().clone()`), that parameter's
         # AccumulateGrad node lives on the stream it was created on; the captured backward then has to hand the gradient to a stream
@@ -295,9 +323,25 @@ class IMAmpAgent:
             return obs_batch if row_index is None else obs_batch[row_index]
         # bf16 runs: the normaliser writes the bf16 tensor the GEMMs read (the same values autocast's cast would produce)
         dt = torch.bfloat16 if self.bf16 else None
+        out = None
+        if obs_batch.is_cuda and self.bf16 and getattr(self, "_obs_pad_cols", 0) > obs_batch.shape[1]:
+            # K-padded first layers (FlatGradBucket): the normaliser writes the left columns of a persistent [rows, Kp] buffer (pad = 0)
+            rows = obs_batch.shape[0] if row_index is None else row_index.numel()
+            buf = self._pad_buf("obs", rows, self._obs_pad_cols)
+            out = buf[:, :obs_batch.shape[1]]
         if use_temp:  # statistics keep updating, the frozen copy provides the values (amp_agent.py:527-532)
-            return self.running_mean_std(obs_batch, norm_from=self.running_mean_std_temp, out_dtype=dt, row_index=row_index)
-        return self.running_mean_std(obs_batch, out_dtype=dt, row_index=row_index)
+            y = self.running_mean_std(obs_batch, norm_from=self.running_mean_std_temp, out_dtype=dt, row_index=row_index, out=out)
+        else:
+            y = self.running_mean_std(obs_batch, out_dtype=dt, row_index=row_index, out=out)
+        return y if out is None else buf
+
+    def _pad_buf(self, name, rows, cols):
+        """Persistent zero-initialised bf16 [rows, cols] buffers (one per use and row count: a captured graph keeps their address)."""
+        bufs = self.__dict__.setdefault("_pad_bufs", {})
+        key = (name, rows, cols)
+        if key not in bufs:
+            bufs[key] = torch.zeros((rows, cols), dtype=torch.bfloat16, device=self.device)
+        return bufs[key]
 
     def _preproc_amp_obs(self, amp_obs, row_index=None):
         if not self._normalize_amp_input:
@@ -556,7 +600,8 @@ class IMAmpAgent:
         coefs = [self._disc_weight_decay * k] * len(ws)
         coefs[-1] += self._disc_logit_reg * k   # the logit layer: regulariser + weight decay
         preload = all(getattr(w, "_bucket", None) is self.grads for w in ws)
-        l2 = weighted_sumsq(ws, coefs, out=raw[9:10 + nw], preloaded=preload)
+        # (a K-padded weight enters with its padded storage -- the pad is zero --, when its gradient is preloaded anyway)
+        l2 = weighted_sumsq([getattr(w, "_padded", w) if preload else w.contiguous() for w in ws], coefs, out=raw[9:10 + nw], preloaded=preload)
         # d(sum of the demo logits) / d(demo rows): cotangent = [0; 0; 1] over the [agent; replay; demo] logits, and the layers are told
         # that only the last row block carries anything (GEMMs over m instead of 3m rows, here and in the second-order pass)
         with input_grad_only(row_start=2 * m):
@@ -587,9 +632,13 @@ class IMAmpAgent:
             # of the discriminator); the demo block is also the leaf the gradient penalty differentiates to
             m = amp_idx.numel() if amp_idx is not None else d["amp_obs"].shape[0]
             dt = torch.bfloat16 if self.bf16 else torch.float32
-            cat = torch.empty((3 * m, d["amp_obs"].shape[1]), dtype=dt, device=obs.device)
+            A = d["amp_obs"].shape[1]
+            if self.bf16 and getattr(self, "_amp_pad_cols", 0) > A:   # K-padded discriminator input (pad columns stay zero)
+                cat = self._pad_buf("amp_cat", 3 * m, self._amp_pad_cols)
+            else:
+                cat = torch.empty((3 * m, A), dtype=dt, device=obs.device)
             for k, key in enumerate(("amp_obs", "amp_obs_replay", "amp_obs_demo")):
-                self._amp_input_mean_std(d[key], out_dtype=dt, row_index=amp_idx, out=cat[k * m:(k + 1) * m])
+                self._amp_input_mean_std(d[key], out_dtype=dt, row_index=amp_idx, out=cat[k * m:(k + 1) * m, :A])
             amp_obs = cat[:m]
             amp_obs_demo = cat[2 * m:].requires_grad_(True)
             inp = {"is_train": True, "obs": obs, "amp_obs_cat": rows_with_grad(cat, amp_obs_demo, 2 * m), "raw_disc_logits": True}
@@ -927,14 +976,12 @@ class IMAmpAgent:
         flat_state = sd["state"].get(0, {})
         all_params = list(self.model.parameters())
         index = {id(p): i for i, p in enumerate(all_params)}
-        state, o = {}, 0
-        for p in self.grads.params:
-            k = p.numel()
+        state = {}
+        for i, p in enumerate(self.grads.params):
             if flat_state:
                 state[index[id(p)]] = {"step": flat_state["step"].clone() if torch.is_tensor(flat_state["step"]) else flat_state["step"],
-                                       "exp_avg": flat_state["exp_avg"][o:o + k].view_as(p).clone(),
-                                       "exp_avg_sq": flat_state["exp_avg_sq"][o:o + k].view_as(p).clone()}
-            o += k
+                                       "exp_avg": self.grads.param_view(flat_state["exp_avg"], i).clone(),
+                                       "exp_avg_sq": self.grads.param_view(flat_state["exp_avg_sq"], i).clone()}
         group = dict(sd["param_groups"][0])
         group["params"] = list(range(len(all_params)))
         return {"state": state, "param_groups": [group]}
@@ -967,8 +1014,10 @@ class IMAmpAgent:
         dev = self.grads.flat_param.device
         step = state[mine[0]]["step"]
         flat = {"step": (step.clone().float() if torch.is_tensor(step) else torch.tensor(float(step))),
-                "exp_avg": torch.cat([state[i]["exp_avg"].reshape(-1).float() for i in mine]).to(dev),
-                "exp_avg_sq": torch.cat([state[i]["exp_avg_sq"].reshape(-1).float() for i in mine]).to(dev)}
+                "exp_avg": torch.zeros_like(self.grads.flat_param), "exp_avg_sq": torch.zeros_like(self.grads.flat_param)}
+        for k, i in enumerate(mine):   # (K-padded weights: the moments of the pad elements are zero)
+            for key in ("exp_avg", "exp_avg_sq"):
+                self.grads.param_view(flat[key], k).copy_(state[i][key].to(dev).float())
         group = {k: v for k, v in groups[0].items() if k != "params"}
         cur = self.optimizer.state_dict()["param_groups"][0]
         merged = dict(cur)

@@ -81,6 +81,28 @@ def colsum_relu_bf16(gy, y, out=None):
 SPLIT_K = 8
 
 
+# K-padded first-layer weights (FlatGradBucket): `weight` is the strided [N, K] view of a stored [N, Kp] matrix, its bf16 shadow is the
+# padded matrix, and the layer input may arrive K-padded (the normaliser wrote it into a [rows, Kp] buffer whose pad columns are zero).
+def _match_cols(wb, xb):
+    """Bring a (maybe padded) bf16 weight [N, K or Kp] and a (maybe padded) input [M, K or Kp] to the same K."""
+    if wb.shape[1] > xb.shape[1]:
+        wb = wb[:, :xb.shape[1]]
+    elif wb.shape[1] < xb.shape[1]:
+        xb = xb[:, :wb.shape[1]]
+    return wb, xb
+
+
+def _logical(g, weight):
+    """A weight gradient computed against a padded input, cut to the parameter's own shape."""
+    return g if g is None or g.shape[1] == weight.shape[1] else g[:, :weight.shape[1]]
+
+
+def _grad_out(weight, cols):
+    """The tensor a first-write weight gradient of `cols` columns goes to: the parameter's gradient, or its padded storage."""
+    gp = getattr(weight, "_grad_padded", None)
+    return gp if (gp is not None and gp.shape[1] == cols) else weight.grad
+
+
 def wgrad_split_k(gy, x, out=None):
     """gy^T x for gy [B, N], x [B, K] bf16 -> fp32 [N, K] (into `out` when given); the batch is cut into SPLIT_K chunks that run as
     one batched GEMM."""
@@ -111,6 +133,7 @@ class _LinearFn(torch.autograd.Function):
                 wb, bb = weight._bf16_shadow, bias._bf16_shadow
             else:
                 wb, bb = weight.to(torch.bfloat16), bias.to(torch.bfloat16)
+            wb, xb = _match_cols(wb, xb)
             y = torch._addmm_activation(bb, xb, wb.t()) if relu else torch.addmm(bb, xb, wb.t())
         if relu:
             ctx.save_for_backward(xb, wb, y)
@@ -145,9 +168,13 @@ class _LinearFn(torch.autograd.Function):
         gw = gb = None
         if ctx.needs_input_grad[1]:
             if _first_write(weight):
-                wgrad_split_k(gy, xb, out=weight.grad)
+                out = _grad_out(weight, xb.shape[1])
+                if out.shape[1] == xb.shape[1]:
+                    wgrad_split_k(gy, xb, out=out)
+                else:
+                    weight.grad.copy_(_logical(wgrad_split_k(gy, xb), weight))
             else:
-                gw = wgrad_split_k(gy, xb)
+                gw = _logical(wgrad_split_k(gy, xb), weight)
         if ctx.needs_input_grad[2] and not skip_bias:
             if _first_write(bias):
                 colsum_bf16(gy, out=bias.grad)
@@ -228,7 +255,7 @@ class _LinearDDFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, relu=False):
         wb, bb = _bf16_params(weight, bias)
-        xb = x.to(torch.bfloat16)
+        wb, xb = _match_cols(wb, x.to(torch.bfloat16))
         y = torch._addmm_activation(bb, xb, wb.t()) if relu else torch.addmm(bb, xb, wb.t())
         ctx.relu = relu
         ctx.x_is_net_input = type(x.grad_fn).__name__.startswith("_RowsWithGradFn")
@@ -260,6 +287,8 @@ class _LinearDDBwdFn(torch.autograd.Function):
     def forward(ctx, gy, x, weight, bias, need_gx, only_x, y=None, r0=0):
         gy = gy.contiguous()
         wb, _ = _bf16_params(weight, bias)
+        wb, _ = _match_cols(wb, x)          # (x may be K-padded; its gradient then is, too)
+        ctx.w_cols = weight.shape[1]
         ctx.x_dtype, ctx.need_gx, ctx.only_x, ctx.masked, ctx.r0, ctx.rows = x.dtype, need_gx, only_x, y is not None, r0, gy.shape[0]
         ctx.set_materialize_grads(False)   # cotangents nobody produced arrive as None, not as zeros
         if only_x:
@@ -277,7 +306,7 @@ class _LinearDDBwdFn(torch.autograd.Function):
             pw, pb = _placeholder(gy), _placeholder(gy)
             ctx.mark_non_differentiable(pw, pb)
             return gx, pw, pb
-        xb = x.to(torch.bfloat16)
+        _, xb = _match_cols(wb, x.to(torch.bfloat16))
         gb = None
         if y is not None:
             if gy.dtype != torch.bfloat16:
@@ -288,7 +317,7 @@ class _LinearDDBwdFn(torch.autograd.Function):
         else:
             ctx.save_for_backward(gy, wb, xb)
         gx = (gy @ wb).to(x.dtype) if need_gx else _placeholder(gy)
-        return gx, wgrad_split_k(gy, xb), (gb if gb is not None else colsum_bf16(gy))
+        return gx, _logical(wgrad_split_k(gy, xb), weight), (gb if gb is not None else colsum_bf16(gy))
 
     @staticmethod
     @once_differentiable
@@ -302,6 +331,7 @@ class _LinearDDBwdFn(torch.autograd.Function):
             if ggx is not None and ctx.need_gx:
                 ggx = ggx[r0:].to(torch.bfloat16).contiguous()
                 d_w = wgrad_split_k(gy, ggx)
+                d_w = d_w if d_w.shape[1] == ctx.w_cols else d_w[:, :ctx.w_cols]
                 d_gy = torch.empty((ctx.rows, wb.shape[0]), dtype=torch.bfloat16, device=gy.device)   # rows [0, r0) stay unwritten
                 if y is not None:
                     _relu_mask(ggx @ wb.t(), y, out=d_gy[r0:])
@@ -313,6 +343,7 @@ class _LinearDDBwdFn(torch.autograd.Function):
             ggx = ggx.to(torch.bfloat16).contiguous()
             d_gy = ggx @ wb.t()
             d_w = wgrad_split_k(gy, ggx)
+            d_w = d_w if d_w.shape[1] == ctx.w_cols else d_w[:, :ctx.w_cols]
         if ggw is not None:
             gwb = ggw.to(torch.bfloat16)
             t = xb @ gwb.t()
@@ -341,7 +372,7 @@ class FastLinearDD(nn.Linear):
         if _device_training_pass(self, x):
             self._fused_now = self.fuse_relu
             return _LinearDDFn.apply(x, self.weight, self.bias, True) if self.fuse_relu else _LinearDDFn.apply(x, self.weight, self.bias)
-        return nn.functional.linear(x, self.weight, self.bias)
+        return nn.functional.linear(x[..., :self.in_features] if x.shape[-1] > self.in_features else x, self.weight, self.bias)   # (x may be K-padded)
 
 
 def _linear1_forward(xb, wb, bb):
@@ -461,7 +492,7 @@ class FastLinear1DD(nn.Linear):
     def forward(self, x):
         if self.out_features == 1 and _device_training_pass(self, x) and x.dtype == torch.bfloat16:
             return _Linear1DDFn.apply(x, self.weight, self.bias)
-        return nn.functional.linear(x, self.weight, self.bias)
+        return nn.functional.linear(x[..., :self.in_features] if x.shape[-1] > self.in_features else x, self.weight, self.bias)   # (x may be K-padded)
 
 
 class FastLinear(nn.Linear):
@@ -483,11 +514,14 @@ class FastLinear(nn.Linear):
         live = getattr(self.weight, "_shadow_live", None)
         if live is not None and live[0] and x.is_cuda and x.dtype == torch.bfloat16 and not torch.is_grad_enabled() and self.bias is not None:
             # rollout inference inside FlatGradBucket.shadow_scope(): the bf16 parameter copies are current, no per-call casts
+            wb = self.weight._bf16_shadow
+            if x.dim() == 2:
+                wb, x = _match_cols(wb, x)
             if self.fuse_relu and x.dim() == 2:
                 self._fused_now = True
-                return torch._addmm_activation(self.bias._bf16_shadow, x, self.weight._bf16_shadow.t())
-            return nn.functional.linear(x, self.weight._bf16_shadow, self.bias._bf16_shadow)
-        return nn.functional.linear(x, self.weight, self.bias)
+                return torch._addmm_activation(self.bias._bf16_shadow, x, wb.t())
+            return nn.functional.linear(x, wb, self.bias._bf16_shadow)
+        return nn.functional.linear(x[..., :self.in_features] if x.shape[-1] > self.in_features else x, self.weight, self.bias)   # (x may be K-padded)
 
 
 class FusedReLU(nn.ReLU):

@@ -22,11 +22,21 @@ DISC_LOGIT_INIT_SCALE = 1.0  # amp_network_builder.py:12
 _ACT = {"relu": nn.ReLU, "silu": nn.SiLU, "tanh": nn.Tanh, "elu": nn.ELU, "gelu": nn.GELU, "None": nn.Identity}
 
 
+def pad_cols(k):
+    """GEMM-friendly K for a first-layer input width (obs 934 -> 1024, AMP obs 1960 -> 2048: hipBLASLt's forward / weight-gradient kernels run
+    20-30 % faster on multiples of 128 at these sizes, scripts/gemm_pad_probe.py); 0 = leave as is."""
+    if os.environ.get("PHC_NO_K_PAD") or k < 512 or k % 128 == 0:
+        return 0
+    return (k + 127) // 128 * 128
+
+
 def build_mlp(input_size, units, activation, linear=nn.Linear):
     """network_builder.py:126-137 `_build_sequential_mlp`: Linear, act, Linear, act ... (indices 0,2,4,..)."""
     layers, n = [], input_size
     for u in units:
         lin = linear(n, u)
+        if not layers and isinstance(lin, (FastLinear, FastLinearDD)):
+            lin.weight._pad_cols = pad_cols(n)   # first layer: store the weight K-padded on the device (FlatGradBucket)
         if activation == "relu" and isinstance(lin, (FastLinear, FastLinearDD)) and not os.environ.get("PHC_NO_RELU_FUSION"):   # the ReLU rides in the GEMM epilogue of the device passes
             lin.fuse_relu = True
             layers += [lin, FusedReLU(lin)]
@@ -187,7 +197,7 @@ class A2CMCPNetwork(A2CNetwork):
         super().__init__(params, actions_num, input_shape, amp_input_shape, value_size)
         self.num_primitive = task_obs_size_detail.get("num_prim", 4)
         assert actions_num == self.num_primitive, "the MCP task's action space is the primitive weights"
-        self.composer = build_mlp(input_shape[0], self.units + [self.num_primitive], self.activation)
+        self.composer = build_mlp(input_shape[0], self.units + [self.num_primitive], self.activation, FastLinear)
         if params.get("has_softmax", True):
             self.composer.append(nn.Softmax(dim=1))
         if not params.get("ending_act", True):

@@ -64,8 +64,8 @@ class RunningMeanStd(nn.Module):
             assert row_index.dtype == torch.int64 and row_index.is_contiguous() and row_index.device == input.device
             rows = row_index.numel()
         update = self.training and not self.forzen
-        if out is not None:
-            assert out.shape == (rows, cols) and out.dtype == out_dtype and out.is_contiguous() and out.device == input.device
+        if out is not None:   # (may be the left `cols` columns of a wider, K-padded buffer: rows `out.stride(0)` apart)
+            assert out.shape == (rows, cols) and out.dtype == out_dtype and out.stride(1) == 1 and out.device == input.device
         elif want_output:
             out = torch.empty((rows, cols), dtype=out_dtype, device=input.device)
         ws = None
@@ -77,7 +77,7 @@ class RunningMeanStd(nn.Module):
             ws = self._ws
         ptr = lambda t: None if t is None else t.data_ptr()
         L.check(lib.phc_running_norm(input.data_ptr(), ptr(row_index), rows, cols, src.running_mean.data_ptr(), src.running_var.data_ptr(), float(src.epsilon), 5.0,
-                                     ptr(out), int(out_dtype == torch.bfloat16), ptr(self.running_mean if update else None),
+                                     ptr(out), int(out_dtype == torch.bfloat16), 0 if out is None else int(out.stride(0)), ptr(self.running_mean if update else None),
                                      ptr(self.running_var if update else None), ptr(self.count if update else None), ptr(ws),
                                      torch.cuda.current_stream(input.device).cuda_stream), "phc_running_norm")
         return out

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     assert sorted(_lib.EXPORTED_SYMBOLS) == declared, "ctypes table and header disagree"
     for name in declared:
         assert hasattr(lib, name), f"libphc_amd.so does not export {name}"
-    assert lib.phc_abi_version() == 22
+    assert lib.phc_abi_version() == 23
 
 
 def test_struct_sizes_match_the_header():
@@ -190,7 +190,7 @@ def test_learner_entry_points_validate_arguments_before_launching():
     from phc_amd import _lib
     lib = _lib.load()
     EINVAL = -1
-    assert lib.phc_running_norm(None, None, 4, 3, None, None, 1e-5, 5.0, None, 0, None, None, None, None, None) == EINVAL
+    assert lib.phc_running_norm(None, None, 4, 3, None, None, 1e-5, 5.0, None, 0, 0, None, None, None, None, None) == EINVAL
     assert lib.phc_colsum_bf16(None, 4, 3, None, None, None) == EINVAL
     assert lib.phc_adam_clip_step(None, None, None, None, 10, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1, 50.0, None, None, None, None, None) == EINVAL
     prm = _lib.PpoParams(0.2, 5.0, 0.0, 10.0, 0)

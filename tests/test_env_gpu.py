@@ -713,3 +713,56 @@ def test_non_upright_asset_env():
     for it in range(10):
         obs, rew, done, info = env.step((torch.rand(32, 69, device=task.device) * 2 - 1) * 0.3)
     assert torch.isfinite(obs).all() and torch.isfinite(rew).all() and torch.isfinite(info["amp_obs"]).all()
+
+
+def test_k_padded_first_layers_keep_shapes_checkpoints_and_zero_pad():
+    """K-padded storage of the first-layer weights (FlatGradBucket; obs 934 -> 1024, AMP obs 1960 -> 2048 columns for the GEMMs): the
+    module parameters, the state dict and the per-parameter optimizer state keep the reference's shapes; the pad elements of the
+    parameter, of its gradient and of the Adam moments stay exactly zero through training; a checkpoint written by the padded agent
+    loads into an un-padded one (PHC_NO_K_PAD) and back, giving the same actions."""
+    import os
+    from phc_amd.learning.amp_agent import IMAmpAgent
+    over = {"learning.params.config.minibatch_size": 2048, "learning.params.config.amp_obs_demo_buffer_size": 4096,
+            "learning.params.config.amp_replay_buffer_size": 4096}
+    task, env = make_task(256, motion="synthetic:2:3", **over)
+    agent = IMAmpAgent(env, task.cfg)
+    net = agent.model.a2c_network
+    w_a, w_c, w_d = net.actor_mlp[0].weight, net.critic_mlp[0].weight, net._disc_mlp[0].weight
+    assert tuple(w_a.shape) == (1024, 934) and w_a._padded.shape == (1024, 1024) and w_a.stride() == (1024, 1)
+    assert tuple(w_d.shape) == (1024, 1960) and w_d._padded.shape == (1024, 2048) and agent._obs_pad_cols == 1024 and agent._amp_pad_cols == 2048
+    agent.init_train()
+    for _ in range(2):
+        info = agent.train_epoch()
+    assert np.isfinite([info["actor_loss"], info["disc_loss"]]).all()
+    for w in (w_a, w_c, w_d):
+        k = w.shape[1]
+        assert float(w._padded[:, k:].abs().max()) == 0.0 and float(w._grad_padded[:, k:].abs().max()) == 0.0
+        assert float(w._bf16_shadow[:, k:].abs().max()) == 0.0
+    ck = agent.get_full_state_weights()
+    sd = ck["model"]
+    assert tuple(sd["a2c_network.actor_mlp.0.weight"].shape) == (1024, 934) and tuple(sd["a2c_network._disc_mlp.0.weight"].shape) == (1024, 1960)
+    names = [n for n, _ in agent.model.named_parameters()]
+    i_a = names.index("a2c_network.actor_mlp.0.weight")
+    st = ck["optimizer"]["state"][i_a]
+    assert tuple(st["exp_avg"].shape) == (1024, 934) and float(st["exp_avg"].abs().max()) > 0
+    obs = torch.randn(64, task.num_obs, device=task.device)
+    agent.set_eval()
+    a0 = agent.get_action_values(obs)["mus"].float().clone()
+    # the same checkpoint in an agent without padding, and back
+    os.environ["PHC_NO_K_PAD"] = "1"
+    try:
+        task2, env2 = make_task(256, motion="synthetic:2:3", **over)
+        plain = IMAmpAgent(env2, task2.cfg)
+    finally:
+        del os.environ["PHC_NO_K_PAD"]
+    assert getattr(plain.model.a2c_network.actor_mlp[0].weight, "_padded", None) is None
+    plain.set_full_state_weights(ck)
+    plain.set_eval()
+    a1 = plain.get_action_values(obs)["mus"].float()
+    np.testing.assert_allclose(a1.cpu().numpy(), a0.cpu().numpy(), atol=2e-2, rtol=2e-2)     # (bf16 / fp32 inference paths)
+    assert torch.equal(plain.model.a2c_network.actor_mlp[0].weight, w_a.detach())
+    back = plain.get_full_state_weights()
+    agent.set_full_state_weights(back)
+    assert torch.equal(net.actor_mlp[0].weight, plain.model.a2c_network.actor_mlp[0].weight) and float(w_a._padded[:, 934:].abs().max()) == 0.0
+    st2 = agent.optimizer.state_dict()["state"][0]
+    np.testing.assert_array_equal(agent.grads.param_view(st2["exp_avg"], agent.grads.params.index(w_a)).cpu().numpy(), st["exp_avg"].cpu().numpy())
