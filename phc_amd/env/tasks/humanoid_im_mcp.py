@@ -60,6 +60,37 @@ def load_mcp_mlp(checkpoint, activation="relu", device="cpu", mlp_name="actor_ml
     return mlp.to(device).eval()
 
 
+class BypassMLP(torch.nn.Module):
+    """The distilled policy of `env.mlp_bypass` (phc/learning/mlp.py:4-58, built at humanoid_im_mcp.py:32 as MLP(num_obs, num_dof,
+    [2048, 1024, 512], "silu")): Linear + activation per hidden width, then a Linear head; parameters live under `model.*` as in the
+    reference's class, so its checkpoints load as they are."""
+
+    def __init__(self, input_dim, output_dim, units=(2048, 1024, 512), activation="silu"):
+        super().__init__()
+        act = {"none": None}.get(activation, _ACTIVATIONS.get(activation))
+        layers, n = [], input_dim
+        for u in units:
+            layers.append(torch.nn.Linear(n, u))
+            if act is not None:
+                layers.append(act())
+            n = u
+        layers.append(torch.nn.Linear(n, output_dim))
+        self.model = torch.nn.Sequential(*layers)
+
+    def forward(self, x):
+        return self.model(x)
+
+
+def load_bypass_mlp(path_or_state, num_obs, num_dof, device="cpu"):
+    """humanoid_im_mcp.py:31-38: `model_state_dict` entry of a training checkpoint, or a bare state dict."""
+    ck = torch.load(path_or_state, map_location=device, weights_only=False) if isinstance(path_or_state, str) else path_or_state
+    mlp = BypassMLP(num_obs, num_dof)
+    mlp.load_state_dict(ck["model_state_dict"] if "model_state_dict" in ck else ck)
+    for p in mlp.parameters():
+        p.requires_grad = False
+    return mlp.to(device).eval()
+
+
 class MCPMixin:
     """Shared by HumanoidImMCP and HumanoidImMCPGetup."""
 
@@ -70,12 +101,14 @@ class MCPMixin:
         self.has_pnn = env.get("has_pnn", False)
         self.has_lateral = env.get("has_lateral", False)
         self.z_activation = env.get("z_activation", "relu")
-        self.mlp_bypass = env.get("mlp_bypass", False)
-        if self.mlp_bypass:
-            raise NotImplementedError("mlp_bypass (distilled MLP in place of the primitives) is not built")
+        self.mlp_bypass = env.get("mlp_bypass", False)           # humanoid.py:338-341: a distilled MLP acts in place of the mixed primitives
+        self.mlp_model_path = env.get("mlp_model_path", "")
+        self.mlp_model = None
 
     def _mcp_load(self):
         self.pnn, self.actors = None, None
+        if self.mlp_bypass and self.mlp_model_path:
+            self.mlp_model = load_bypass_mlp(self.mlp_model_path, self.num_obs, self.num_dof, self.device)
         if not self.has_pnn:
             # one plain checkpoint per primitive, each rebuilt by load_mcp_mlp (network_loader.py:11-52); the observation statistics
             # are those of the first one
@@ -111,10 +144,14 @@ class MCPMixin:
         return d
 
     def compose_actions(self, weights):
-        if self.pnn is None and self.actors is None:
+        if self.pnn is None and self.actors is None and not self.mlp_bypass:
             raise RuntimeError("no primitives loaded: set env.models=[<pnn checkpoint>] or call load_primitives()")
         with torch.no_grad():
             obs = torch.clamp((self.obs_buf - self.running_mean) / torch.sqrt(self.running_var + 1e-05), min=-5.0, max=5.0)
+            if self.mlp_bypass:                                   # humanoid_im_mcp.py:83-84: the weights are ignored
+                if self.mlp_model is None:
+                    raise RuntimeError("env.mlp_bypass needs env.mlp_model_path (or load_bypass_mlp() installed as task.mlp_model)")
+                return self.mlp_model(obs)
             if self.discrete_mcp:
                 weights = torch.nn.functional.one_hot(torch.argmax(weights, dim=1), num_classes=self.num_prim).float()
             if self.pnn is not None:

@@ -11,6 +11,8 @@ CPU tests: the agent's torch path (which is also the definition the HIP kernels 
 `phc_disc_bce`, `phc_weighted_sumsq`, FastLinear / FastLinearDD, `phc_adam_clip_step` -- in fp32 (tight tolerance) and with bf16 GEMMs.
 
 Loading the reference's state dict with `strict=True` is the B4 check: the key sets are identical."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -326,3 +328,23 @@ def test_calc_gradients_equals_the_reference_agent_on_hip(golden, bf16):
     else:   # (statistics: fp64 column sums in another order than torch's)
         worst = _check_step(agent, g, info, rtol_loss=2e-4, grad_rtol=2e-3, grad_atol=1e-6, param_atol=2e-6, stats_rtol=1e-7)
     assert worst < (0.6 if bf16 else 2e-3)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/phc"), reason="reference checkout not present")
+def test_bypass_mlp_loads_the_reference_class_state_dict():
+    """env.mlp_bypass (humanoid_im_mcp.py:31-38,83-84): a state dict written by the reference's own `phc.learning.mlp.MLP` loads into
+    BypassMLP (bare or under `model_state_dict`) and gives the same actions."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle"))
+    import ref_shim
+    ref_shim.install()
+    RefMLP = ref_shim.ref_module("phc.learning.mlp").MLP
+    from phc_amd.env.tasks.humanoid_im_mcp import load_bypass_mlp
+    torch.manual_seed(4)
+    ref = RefMLP(input_dim=934, output_dim=69, units=[2048, 1024, 512], activation="silu")
+    x = torch.randn(5, 934)
+    want = ref(x)
+    for ck in (ref.state_dict(), {"model_state_dict": ref.state_dict(), "epoch": 3}):
+        mine = load_bypass_mlp(ck, 934, 69)
+        assert list(mine.state_dict()) == list(ref.state_dict())
+        assert torch.equal(mine(x), want) and not any(p.requires_grad for p in mine.parameters())
