@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PHC_ABI_VERSION 23
+#define PHC_ABI_VERSION 24
 #define PHC_MAX_BODIES 64   /* bodies (incl. extended reference bodies) per articulation; also the slot count of the model tables */
 #define PHC_EINVAL (-1)
 #define PHC_EUNSUPPORTED (-2)
@@ -328,6 +328,10 @@ int32_t phc_colsum_bf16(const void* x, int64_t rows, int32_t cols, float* out, f
  * (torch's ThresholdBackward, phc/learning/network_builder.py:126-137 `activation: relu`) written as bf16 [rows, cols], and its column sums
  * (the bias gradient) -- one pass instead of two.  Same workspace size. */
 int32_t phc_colsum_relu_bf16(const void* gy, const void* y, int64_t rows, int32_t cols, void* gm, float* out, float* workspace, void* stream);
+/* Weight gradient of a linear layer as a split-K batched GEMM (autograd's `grad_output.t() @ input`, AddmmBackward): `part` [slabs, n] bf16 are the
+ * slab products; out [n] fp32 receives their sum (accumulate 0) or has it added (accumulate != 0: a parameter's second and later gradient
+ * contributions of a step, torch's AccumulateGrad).  part and out 16-byte aligned. */
+int32_t phc_sum_slabs_bf16(const void* part, int32_t slabs, int64_t n, float* out, int32_t accumulate, void* stream);
 
 /* Discriminator loss pieces (phc/learning/amp_agent.py:732-808 `_disc_loss`).
  * phc_disc_bce: logits [n_agent + n_demo] (agent and replay rows first, demo rows last; bf16 or fp32):

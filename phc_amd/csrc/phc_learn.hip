@@ -479,6 +479,34 @@ __global__ __launch_bounds__(1024) void k_disc_bce(const T* __restrict__ logits,
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Sum of the split-K slabs of a weight gradient: part [slabs, n] bf16 (the batched GEMM's output) -> out fp32 [n], written or ADDED
+// (out += sum: a later contribution to a gradient that already holds one -- autograd's AccumulateGrad launch disappears).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_sum_slabs_bf16(const __hip_bfloat16* __restrict__ part, int slabs, int64_t n, float* __restrict__ out, int accumulate) {
+    const int64_t i8 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (i8 >= n) return;
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (i8 + 8 <= n && (n & 7) == 0) {
+        for (int s = 0; s < slabs; ++s) {
+            const uint4 q = *reinterpret_cast<const uint4*>(part + (int64_t)s * n + i8);
+            const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { a[2 * k] += __uint_as_float(w[k] << 16); a[2 * k + 1] += __uint_as_float(w[k] & 0xffff0000u); }
+        }
+        float4* o = reinterpret_cast<float4*>(out + i8);
+        float4 lo = make_float4(a[0], a[1], a[2], a[3]), hi = make_float4(a[4], a[5], a[6], a[7]);
+        if (accumulate) { const float4 p = o[0], r = o[1]; lo.x += p.x; lo.y += p.y; lo.z += p.z; lo.w += p.w; hi.x += r.x; hi.y += r.y; hi.z += r.z; hi.w += r.w; }
+        o[0] = lo; o[1] = hi;
+        return;
+    }
+    for (int k = 0; k < 8 && i8 + k < n; ++k) {
+        float v = 0.f;
+        for (int s = 0; s < slabs; ++s) v += __bfloat162float(part[(int64_t)s * n + i8 + k]);
+        out[i8 + k] = accumulate ? out[i8 + k] + v : v;
+    }
+}
+
 struct SumsqArgs { const void* ptr[4]; int64_t n[4]; float coef[4]; int count; int is_bf16; };
 #define SSM_BLOCKS 1024
 // partial[t][block] = this block's share of |tensor t|^2 (unweighted).  16-byte loads (8 bf16 / 4 fp32) over the aligned bulk, scalar tail;
@@ -595,6 +623,16 @@ int32_t phc_colsum_relu_bf16(const void* gy, const void* y, int64_t rows, int32_
     hipLaunchKernelGGL(k_colsum_relu_bf16, dim3((cols + 63) / 64, (unsigned)nchunks), dim3(256), 0, st, reinterpret_cast<const __hip_bfloat16*>(gy),
                        reinterpret_cast<const __hip_bfloat16*>(y), rows, cols, reinterpret_cast<__hip_bfloat16*>(gm), workspace);
     hipLaunchKernelGGL(k_colsum_finish, dim3((cols + 63) / 64), dim3(1024), 0, st, workspace, (int)nchunks, cols, out);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int32_t)e;
+}
+
+int32_t phc_sum_slabs_bf16(const void* part, int32_t slabs, int64_t n, float* out, int32_t accumulate, void* stream) {
+    if (!part || !out || slabs < 1 || n < 1) return PHC_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(part) & 15) || (reinterpret_cast<uintptr_t>(out) & 15)) return PHC_EINVAL;
+    const int64_t blocks = (n + 2047) / 2048;
+    hipLaunchKernelGGL(k_sum_slabs_bf16, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const __hip_bfloat16*>(part), slabs, n, out,
+                       accumulate);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int32_t)e;
 }

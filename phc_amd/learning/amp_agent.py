@@ -123,6 +123,7 @@ class FlatGradBucket:
         self.segments = []
         n = 0
         for p in self.params:
+            n = (n + 3) // 4 * 4          # segments start 16-byte aligned (vector loads / stores of the gradient kernels); the gaps stay zero
             self.segments.append((n, alloc(p)))
             n += alloc(p)
         self.flat_param = torch.zeros(n, device=dev, dtype=torch.float32)

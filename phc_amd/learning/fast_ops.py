@@ -103,19 +103,39 @@ def _grad_out(weight, cols):
     return gp if (gp is not None and gp.shape[1] == cols) else weight.grad
 
 
-def wgrad_split_k(gy, x, out=None):
-    """gy^T x for gy [B, N], x [B, K] bf16 -> fp32 [N, K] (into `out` when given); the batch is cut into SPLIT_K chunks that run as
-    one batched GEMM."""
+def wgrad_split_k(gy, x, out=None, accumulate=False):
+    """gy^T x for gy [B, N], x [B, K] bf16 -> fp32 [N, K] (into `out` when given, added to it with `accumulate`); the batch is cut into
+    SPLIT_K chunks that run as one batched GEMM, whose slabs `phc_sum_slabs_bf16` sums (and accumulates) in one pass."""
     B, N = gy.shape
     K = x.shape[1]
     if B % SPLIT_K == 0 and B >= 2048 and N >= 16:   # (a 1-row batched GEMM -- the value head -- stalls the host for 11 ms in hipBLASLt)
         part = torch.bmm(gy.view(SPLIT_K, B // SPLIT_K, N).transpose(1, 2), x.view(SPLIT_K, B // SPLIT_K, K))
         if out is not None:
+            if (part.dtype == torch.bfloat16 and part.is_contiguous() and out.dtype == torch.float32 and out.is_contiguous() and out.data_ptr() % 16 == 0
+                    and part.data_ptr() % 16 == 0):
+                L.check(L.load().phc_sum_slabs_bf16(part.data_ptr(), SPLIT_K, N * K, out.data_ptr(), int(accumulate), _stream(out.device)), "phc_sum_slabs_bf16")
+                return out
+            if accumulate:
+                return out.add_(part.sum(0, dtype=torch.float32))
             return torch.sum(part, 0, dtype=torch.float32, out=out)
         return part.sum(0, dtype=torch.float32)
     if out is not None:
-        return out.copy_(gy.t() @ x)
+        return out.add_(gy.t() @ x) if accumulate else out.copy_(gy.t() @ x)
     return (gy.t() @ x).float()
+
+
+def _wgrad_into(weight, gy, xb):
+    """The weight gradient gy^T xb of a bucket parameter, put where it belongs: STORED into the parameter's gradient when that holds nothing
+    of this step yet, ADDED to it otherwise (one kernel, no AccumulateGrad launch) -> None; parameters outside a FlatGradBucket get the tensor
+    back for autograd to accumulate."""
+    b = getattr(weight, "_bucket", None)
+    if b is None or weight.grad is None or gy.dtype != torch.bfloat16:
+        return _logical(wgrad_split_k(gy, xb), weight)
+    out = _grad_out(weight, xb.shape[1])
+    if out.shape[1] != xb.shape[1] or not out.is_contiguous():
+        return _logical(wgrad_split_k(gy, xb), weight)
+    wgrad_split_k(gy, xb, out=out, accumulate=not _first_write(weight))
+    return None
 
 
 class _LinearFn(torch.autograd.Function):
@@ -167,14 +187,7 @@ class _LinearFn(torch.autograd.Function):
         gx = (gy @ wb).to(ctx.x_dtype) if ctx.needs_input_grad[0] else None
         gw = gb = None
         if ctx.needs_input_grad[1]:
-            if _first_write(weight):
-                out = _grad_out(weight, xb.shape[1])
-                if out.shape[1] == xb.shape[1]:
-                    wgrad_split_k(gy, xb, out=out)
-                else:
-                    weight.grad.copy_(_logical(wgrad_split_k(gy, xb), weight))
-            else:
-                gw = _logical(wgrad_split_k(gy, xb), weight)
+            gw = _wgrad_into(weight, gy, xb)
         if ctx.needs_input_grad[2] and not skip_bias:
             if _first_write(bias):
                 colsum_bf16(gy, out=bias.grad)
@@ -274,7 +287,7 @@ class _LinearDDFn(torch.autograd.Function):
         only_x, r0 = _INPUT_GRAD_ONLY
         need_gx = ctx.needs_input_grad[0] and not (_PARAM_GRAD_ONLY[0] and ctx.x_is_net_input)
         gx, gw, gb = _LinearDDBwdFn.apply(gy, x, weight, bias, need_gx, only_x, y, r0 if only_x else 0)
-        out = (gx if need_gx else None, None if only_x else gw, None if only_x else gb)
+        out = (gx if need_gx else None, None if (only_x or gw.dim() != 2) else gw, None if only_x else gb)   # (0-dim gw: written in place)
         return out + ((None,) if len(ctx.needs_input_grad) > 3 else ())
 
 
@@ -288,7 +301,7 @@ class _LinearDDBwdFn(torch.autograd.Function):
         gy = gy.contiguous()
         wb, _ = _bf16_params(weight, bias)
         wb, _ = _match_cols(wb, x)          # (x may be K-padded; its gradient then is, too)
-        ctx.w_cols = weight.shape[1]
+        ctx.w_cols, ctx.weight = weight.shape[1], weight
         ctx.x_dtype, ctx.need_gx, ctx.only_x, ctx.masked, ctx.r0, ctx.rows = x.dtype, need_gx, only_x, y is not None, r0, gy.shape[0]
         ctx.set_materialize_grads(False)   # cotangents nobody produced arrive as None, not as zeros
         if only_x:
@@ -317,7 +330,11 @@ class _LinearDDBwdFn(torch.autograd.Function):
         else:
             ctx.save_for_backward(gy, wb, xb)
         gx = (gy @ wb).to(x.dtype) if need_gx else _placeholder(gy)
-        return gx, _logical(wgrad_split_k(gy, xb), weight), (gb if gb is not None else colsum_bf16(gy))
+        gw = _wgrad_into(weight, gy, xb)
+        if gw is None:        # stored / added in place
+            gw = _placeholder(gy)
+            ctx.mark_non_differentiable(gw)
+        return gx, gw, (gb if gb is not None else colsum_bf16(gy))
 
     @staticmethod
     @once_differentiable
@@ -330,8 +347,7 @@ class _LinearDDBwdFn(torch.autograd.Function):
         if ctx.only_x:   # the weight / bias outputs were placeholders; gy, y are the row block [r0, n)
             if ggx is not None and ctx.need_gx:
                 ggx = ggx[r0:].to(torch.bfloat16).contiguous()
-                d_w = wgrad_split_k(gy, ggx)
-                d_w = d_w if d_w.shape[1] == ctx.w_cols else d_w[:, :ctx.w_cols]
+                d_w = _wgrad_into(ctx.weight, gy, ggx)
                 d_gy = torch.empty((ctx.rows, wb.shape[0]), dtype=torch.bfloat16, device=gy.device)   # rows [0, r0) stay unwritten
                 if y is not None:
                     _relu_mask(ggx @ wb.t(), y, out=d_gy[r0:])
@@ -342,8 +358,7 @@ class _LinearDDBwdFn(torch.autograd.Function):
         if ggx is not None and ctx.need_gx:
             ggx = ggx.to(torch.bfloat16).contiguous()
             d_gy = ggx @ wb.t()
-            d_w = wgrad_split_k(gy, ggx)
-            d_w = d_w if d_w.shape[1] == ctx.w_cols else d_w[:, :ctx.w_cols]
+            d_w = _wgrad_into(ctx.weight, gy, ggx)
         if ggw is not None:
             gwb = ggw.to(torch.bfloat16)
             t = xb @ gwb.t()

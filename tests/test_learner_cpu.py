@@ -201,7 +201,8 @@ def test_flat_grad_bucket_is_one_buffer():
     lin = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.Linear(3, 2))
     b = FlatGradBucket(lin.parameters())
     lin(torch.randn(5, 4)).sum().backward()
-    assert b.flat.numel() == 4 * 3 + 3 + 3 * 2 + 2 and b.flat.abs().sum() > 0
+    # one buffer; every parameter's segment starts 16-byte aligned (12 | 3 + 1 pad | 6 + 2 pad | 2)
+    assert b.flat.numel() == 12 + 4 + 8 + 2 and [o for o, _ in b.segments] == [0, 12, 16, 24] and b.flat.abs().sum() > 0
     assert lin[0].weight.grad.data_ptr() == b.flat.data_ptr()
     b.zero()
     assert lin[1].bias.grad.abs().sum() == 0
