@@ -275,8 +275,9 @@ def test_released_checkpoint_layout_round_trip(golden, tmp_path):
     fresh.restore(path)
     assert fresh.epoch_num == 12 and fresh.frame == 34
     st = fresh.optimizer.state[fresh.grads.flat_param]
-    want = torch.cat([ref_opt_state[int(i)]["exp_avg"].reshape(-1) for i in g["opt/state_ids"]])
-    assert torch.equal(st["exp_avg"], want) and float(st["step"]) == 1.0
+    for k, i in enumerate(g["opt/state_ids"]):   # (per parameter: the flat state has 16-byte alignment gaps between segments)
+        assert torch.equal(fresh.grads.param_view(st["exp_avg"], k), ref_opt_state[int(i)]["exp_avg"])
+    assert float(st["step"]) == 1.0
     for n, p in fresh.model.state_dict().items():
         assert torch.equal(p, ck["model"][n]), n
     # second step from the restored state == continuing an agent that took the first step itself
