@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PHC_ABI_VERSION 24
+#define PHC_ABI_VERSION 25
 #define PHC_MAX_BODIES 64   /* bodies (incl. extended reference bodies) per articulation; also the slot count of the model tables */
 #define PHC_EINVAL (-1)
 #define PHC_EUNSUPPORTED (-2)
@@ -346,6 +346,14 @@ int32_t phc_disc_bce(const void* logits, int32_t is_bf16, int32_t n_agent, int32
 int64_t phc_sumsq_workspace(void);
 int32_t phc_weighted_sumsq(int32_t count, const void* const* tensors, const int64_t* sizes, const float* coefs, int32_t is_bf16, float* out,
                            double* workspace, void* stream);
+
+/* Rollout bookkeeping of one env step (phc/learning/amp_agent.py:321-341 inside play_steps; rl_games' current_rewards / current_lengths):
+ *   exp_rewards[i] = reward_scale * rewards[i];  exp_dones[i] = dones[i] != 0;  terminated_mask[i] = terminate[i] != 0 (the mask of the
+ *   next-value write, :327-329);  terminated_flags[i] += terminated_mask[i];  reward_raw_acc[k] += mean_i reward_raw[i, k];
+ *   current_rewards[i] = (current_rewards[i] + rewards[i]) * (1 - done);  current_lengths[i] = (current_lengths[i] + 1) * (1 - done). */
+int32_t phc_rollout_bookkeeping(const float* rewards, float reward_scale, const int64_t* dones, const int64_t* terminate, const float* reward_raw,
+                                int32_t num_reward_terms, int64_t num_envs, float* exp_rewards, uint8_t* exp_dones, float* terminated_flags,
+                                float* terminated_mask, float* reward_raw_acc, float* current_rewards, float* current_lengths, void* stream);
 
 /* Rollout policy step (phc/learning/amp_agent.py:309-341 with rl_games' ModelA2CContinuousLogStd in eval mode), per env r:
  *   actions = mu + exp(logstd) * noise, mus = mu, sigmas = exp(logstd), neglogp = neglogp(actions | mu, sigma)            (mu != NULL)

@@ -102,6 +102,7 @@ _SIGNATURES = {
     "phc_colsum_bf16": ([c_p, c_i64, c_i32, c_p, c_p, c_p], c_i32),
     "phc_colsum_relu_bf16": ([c_p, c_p, c_i64, c_i32, c_p, c_p, c_p, c_p], c_i32),
     "phc_sum_slabs_bf16": ([c_p, c_i32, c_i64, c_p, c_i32, c_p], c_i32),
+    "phc_rollout_bookkeeping": ([c_p, c_f, c_p, c_p, c_p, c_i32, c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p], c_i32),
     "phc_disc_bce": ([c_p, c_i32, c_i32, c_i32, c_f, c_p, c_p, c_p], c_i32),
     "phc_sumsq_workspace": ([], c_i64),
     "phc_weighted_sumsq": ([c_i32, c_p, c_p, c_p, c_i32, c_p, c_p, c_p], c_i32),
@@ -132,7 +133,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the .so does not export the symbol
         fn.argtypes = argtypes
         fn.restype = restype
-    if lib.phc_abi_version() != 24:
+    if lib.phc_abi_version() != 25:
         raise ImportError("libphc_amd.so ABI version mismatch")
     _lib = lib
     return lib

@@ -507,6 +507,44 @@ __global__ __launch_bounds__(256) void k_sum_slabs_bf16(const __hip_bfloat16* __
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Per-step bookkeeping of the rollout (amp_agent.py:321-341 of the reference's play_steps): row n of the experience buffer gets the
+// step's (scaled) rewards and done flags; the episode statistics advance; the per-term reward means accumulate.  One single-block launch
+// instead of a dozen elementwise torch kernels on 4096-element vectors (~5 us each in a captured graph).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_rollout_bookkeeping(const float* __restrict__ rewards, float reward_scale, const int64_t* __restrict__ dones,
+                                                              const int64_t* __restrict__ terminate, const float* __restrict__ reward_raw, int nraw,
+                                                              int64_t n, float* __restrict__ exp_rewards, uint8_t* __restrict__ exp_dones,
+                                                              float* __restrict__ terminated_flags, float* __restrict__ terminated_mask,
+                                                              float* __restrict__ reward_raw_acc, float* __restrict__ current_rewards,
+                                                              float* __restrict__ current_lengths) {
+    __shared__ double l[16][8];
+    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int64_t i = threadIdx.x; i < n; i += 1024) {
+        const float r = rewards[i];
+        const float nd = dones[i] != 0 ? 0.f : 1.f;
+        const float t = terminate[i] != 0 ? 1.f : 0.f;
+        exp_rewards[i] = r * reward_scale;
+        exp_dones[i] = dones[i] != 0 ? 1 : 0;
+        terminated_flags[i] += t;
+        terminated_mask[i] = t;
+        current_rewards[i] = (current_rewards[i] + r) * nd;
+        current_lengths[i] = (current_lengths[i] + 1.0f) * nd;
+        for (int k = 0; k < nraw; ++k) acc[k] += (double)reward_raw[i * nraw + k];
+    }
+    for (int k = 0; k < nraw; ++k) {
+        double v = acc[k];
+        for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+        if ((threadIdx.x & 63) == 0) l[threadIdx.x >> 6][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < nraw) {
+        double s = 0.0;
+        for (int w = 0; w < 16; ++w) s += l[w][threadIdx.x];
+        reward_raw_acc[threadIdx.x] += (float)(s / (double)n);
+    }
+}
+
 struct SumsqArgs { const void* ptr[4]; int64_t n[4]; float coef[4]; int count; int is_bf16; };
 #define SSM_BLOCKS 1024
 // partial[t][block] = this block's share of |tensor t|^2 (unweighted).  16-byte loads (8 bf16 / 4 fp32) over the aligned bulk, scalar tail;
@@ -633,6 +671,18 @@ int32_t phc_sum_slabs_bf16(const void* part, int32_t slabs, int64_t n, float* ou
     const int64_t blocks = (n + 2047) / 2048;
     hipLaunchKernelGGL(k_sum_slabs_bf16, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const __hip_bfloat16*>(part), slabs, n, out,
                        accumulate);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int32_t)e;
+}
+
+int32_t phc_rollout_bookkeeping(const float* rewards, float reward_scale, const int64_t* dones, const int64_t* terminate, const float* reward_raw,
+                                int32_t num_reward_terms, int64_t num_envs, float* exp_rewards, uint8_t* exp_dones, float* terminated_flags,
+                                float* terminated_mask, float* reward_raw_acc, float* current_rewards, float* current_lengths, void* stream) {
+    if (!rewards || !dones || !terminate || !reward_raw || !exp_rewards || !exp_dones || !terminated_flags || !terminated_mask || !reward_raw_acc ||
+        !current_rewards || !current_lengths || num_envs < 1 || num_reward_terms < 1 || num_reward_terms > 8)
+        return PHC_EINVAL;
+    hipLaunchKernelGGL(k_rollout_bookkeeping, dim3(1), dim3(1024), 0, (hipStream_t)stream, rewards, reward_scale, dones, terminate, reward_raw, num_reward_terms,
+                       num_envs, exp_rewards, exp_dones, terminated_flags, terminated_mask, reward_raw_acc, current_rewards, current_lengths);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int32_t)e;
 }

@@ -421,21 +421,33 @@ class IMAmpAgent:
 
         def seg_after(n, rewards, terminate, reward_raw):
             """(B) the step's outputs into row n, next-value critic (zeroed where the episode terminated), episode bookkeeping."""
-            e["rewards"][n].copy_(rewards if self.reward_scale == 1 else rewards * self.reward_scale)
             e["next_obses"][n].copy_(self.obs)
-            e["dones"][n].copy_(self.dones)
-            terminated = terminate.float()
-            terminated_flags.add_(terminated)
-            rr = reward_raw.mean(dim=0)
             if self._reward_raw_acc is None:
-                self._reward_raw_acc = torch.zeros_like(rr)
-            self._reward_raw_acc.add_(rr)
+                self._reward_raw_acc = torch.zeros(reward_raw.shape[1], dtype=torch.float32, device=self.device)
+            dev_ok = (rewards.is_cuda and rewards.dtype == torch.float32 and rewards.is_contiguous() and self.dones.dtype == torch.int64
+                      and terminate.dtype == torch.int64 and reward_raw.dtype == torch.float32 and reward_raw.is_contiguous() and reward_raw.shape[1] <= 8)
+            if dev_ok:   # rewards / dones / terminated flags / reward means / episode statistics in one launch (phc_rollout_bookkeeping)
+                if getattr(self, "_terminated_mask", None) is None:
+                    self._terminated_mask = torch.zeros(self.num_actors, dtype=torch.float32, device=self.device)
+                terminated = self._terminated_mask
+                L.check(L.load().phc_rollout_bookkeeping(
+                    rewards.data_ptr(), float(self.reward_scale), self.dones.data_ptr(), terminate.data_ptr(), reward_raw.data_ptr(), reward_raw.shape[1],
+                    self.num_actors, e["rewards"][n].data_ptr(), e["dones"][n].data_ptr(), terminated_flags.data_ptr(), terminated.data_ptr(),
+                    self._reward_raw_acc.data_ptr(), self.current_rewards.data_ptr(), self.current_lengths.data_ptr(),
+                    torch.cuda.current_stream().cuda_stream), "phc_rollout_bookkeeping")
+            else:
+                e["rewards"][n].copy_(rewards if self.reward_scale == 1 else rewards * self.reward_scale)
+                e["dones"][n].copy_(self.dones)
+                terminated = terminate.float()
+                terminated_flags.add_(terminated)
+                self._reward_raw_acc.add_(reward_raw.mean(dim=0))
             with self._autocast():
                 value = net.eval_critic(self._preproc_obs(self.obs))
             policy_sample(None, value.contiguous(), None, vnorm, None, None, None, None, e["next_values"][n], mask=terminated)
-            not_dones = 1.0 - self.dones.float()
-            self.current_rewards.add_(rewards).mul_(not_dones.unsqueeze(1))
-            self.current_lengths.add_(1).mul_(not_dones)
+            if not dev_ok:
+                not_dones = 1.0 - self.dones.float()
+                self.current_rewards.add_(rewards).mul_(not_dones.unsqueeze(1))
+                self.current_lengths.add_(1).mul_(not_dones)
 
         for n in range(self.horizon_length):
             if self.faithful_reset or not hasattr(task, "reset_done"):

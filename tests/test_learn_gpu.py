@@ -420,3 +420,30 @@ def test_discriminator_loss_kernels():
     ref = 5.0 * g.detach().float().square().sum(-1).mean()
     torch.testing.assert_close(pen, ref, rtol=1e-4, atol=1e-6)
     torch.testing.assert_close(g.grad.float(), (2 * 5.0 / m) * g.detach().float(), rtol=1e-2, atol=1e-9)
+
+
+def test_rollout_bookkeeping_kernel_matches_torch_ops():
+    """phc_rollout_bookkeeping == the torch statements of IMAmpAgent.play_steps it replaces (reference amp_agent.py:321-341)."""
+    from phc_amd import _lib
+    lib = _lib.load()
+    torch.manual_seed(9)
+    N, R = 4097, 5
+    rewards = torch.randn(N, 1, device="cuda")
+    dones = (torch.rand(N, device="cuda") < 0.2).long()
+    term = ((torch.rand(N, device="cuda") < 0.5) & (dones > 0)).long()
+    raw = torch.randn(N, R, device="cuda")
+    exp_r, exp_d = torch.zeros(N, 1, device="cuda"), torch.zeros(N, device="cuda", dtype=torch.uint8)
+    tf, tm = torch.rand(N, device="cuda"), torch.zeros(N, device="cuda")
+    acc = torch.rand(R, device="cuda")
+    cur_r, cur_l = torch.randn(N, 1, device="cuda"), torch.rand(N, device="cuda") * 50
+    want_tf = tf + term.float()
+    want_acc = acc + raw.mean(dim=0)
+    nd = 1.0 - dones.float()
+    want_r, want_l = (cur_r + rewards) * nd[:, None], (cur_l + 1) * nd
+    rc = lib.phc_rollout_bookkeeping(rewards.data_ptr(), 0.5, dones.data_ptr(), term.data_ptr(), raw.data_ptr(), R, N, exp_r.data_ptr(), exp_d.data_ptr(),
+                                     tf.data_ptr(), tm.data_ptr(), acc.data_ptr(), cur_r.data_ptr(), cur_l.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert torch.equal(exp_r, rewards * 0.5) and torch.equal(exp_d, dones.to(torch.uint8)) and torch.equal(tm, term.float()) and torch.equal(tf, want_tf)
+    assert torch.equal(cur_r, want_r) and torch.equal(cur_l, want_l)
+    assert torch.allclose(acc, want_acc, atol=1e-6)
