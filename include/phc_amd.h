@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PHC_ABI_VERSION 25
+#define PHC_ABI_VERSION 26
 #define PHC_MAX_BODIES 64   /* bodies (incl. extended reference bodies) per articulation; also the slot count of the model tables */
 #define PHC_EINVAL (-1)
 #define PHC_EUNSUPPORTED (-2)
@@ -164,7 +164,9 @@ typedef struct {
                                          or 1 / 2 / 3 / 8 / 9 (`compute_imitation_observations`, `_v2`, `_v3`, `_v8`, `_v9`, :1203-1306,1395-1515: 15 J,
                                          15 J + 3 (J - 1), 9 J, 30 J, 18 J + 6 floats; 2 and 9 need the root as the first tracked body) */
     int32_t self_obs_v;               /* 1 (0 is read as 1): compute_humanoid_observations_smpl_max; 3: `_v3` (humanoid.py:2113-2169) = the same
-                                         followed by the force-sensor readings [S*6] (num_self_obs grows by 6 S, humanoid.py:683) */
+                                         followed by the force-sensor readings [S*6] (num_self_obs grows by 6 S, humanoid.py:683); 2: `_v2`
+                                         (:2054-2108): the v1 block for each of the past_track_steps previous body states and the current one,
+                                         all relative to the CURRENT root position / heading (num_self_obs = (P + 1) x the v1 size, :513-514) */
     int32_t num_force_sensors;        /* S of phc_sim_state_t.force_sensor (self_obs_v 3) */
     int32_t amp_obs_v;                /* 1 (0 is read as 1): build_amp_observations_smpl; 2: `_v2` (humanoid_amp.py:1015-1059) = the same followed by the
                                          key bodies' heading-local velocities [3 K] (num_amp_obs_per_step grows by 3 K, :303) */
@@ -176,6 +178,7 @@ typedef struct {
                                          counted in num_self_obs */
     int32_t num_amp_obs_extra;        /* the same at the end of every AMP step (has_shape_obs_disc / has_weight_obs_disc, humanoid_amp.py:1005-1008);
                                          counted in num_amp_obs_per_step */
+    int32_t num_self_obs_hist;        /* P = env.past_track_steps (5) of self_obs_v 2; 0 otherwise */
     int32_t zero_out_far_train;       /* env.zero_out_far_train (with zero_out_far): a reset / a clip restart moves the reference to a random spot of a
                                          5 m disk around the humanoid and arms the cycle counter with zero_out_far_steps (humanoid_im.py:966-980,1133-1140) */
     int32_t zero_out_far_steps;       /* env.zero_out_far_steps (90) */
@@ -218,6 +221,8 @@ typedef struct {
     int32_t* reset_count;             /* [3, PHC_RESET_SUBLISTS, PHC_RESET_COUNT_STRIDE], counter in element 0 */
     int32_t reset_slot;
     int32_t reset_sublist_cap;        /* >= 8 * ceil(ceil(N / 8) / PHC_RESET_SUBLISTS) */
+    float* body_state_hist;           /* [N, P, NB, 13] self_obs_v 2: the P previous rigid-body states, oldest first (`_rigid_body_*_hist`,
+                                         humanoid.py:229-232,1621-1631); shifted by the post-physics launch, filled by the resets; nullable otherwise */
     const float* offset_rand;         /* [N,2] the caller's torch.rand draw for the random reference offsets of zero_out_far_train / cycle_motion_xp
                                          (row of the env; refreshed by the caller before every launch that may use it); nullable unless one is set */
 } phc_im_buffers_t;

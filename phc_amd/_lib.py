@@ -64,7 +64,7 @@ class ImParams(C.Structure):
                 ("dofs_per_joint", c_i32), ("num_ext_bodies", c_i32), ("ext_parent", c_p), ("ext_offset", c_p), ("obs_v", c_i32),
                 ("self_obs_v", c_i32), ("num_force_sensors", c_i32), ("amp_obs_v", c_i32),
                 ("remove_base_rot", c_i32), ("num_self_obs_extra", c_i32), ("num_amp_obs_extra", c_i32),
-                ("zero_out_far_train", c_i32), ("zero_out_far_steps", c_i32), ("cycle_motion_xp", c_i32),
+                ("num_self_obs_hist", c_i32), ("zero_out_far_train", c_i32), ("zero_out_far_steps", c_i32), ("cycle_motion_xp", c_i32),
                 ("self_obs_extra", c_p), ("amp_obs_extra", c_p)]
 
 
@@ -74,7 +74,7 @@ class ImBuffers(C.Structure):
                 ("motion_start_times", c_p), ("motion_start_times_offset", c_p), ("global_offset", c_p),
                 ("ref_body_pos", c_p), ("ref_body_rot", c_p), ("ref_body_vel", c_p), ("ref_dof_pos", c_p),
                 ("cycle_counter", c_p), ("recovery_counter", c_p), ("point_goal", c_p), ("cycle_phase", c_p),
-                ("reset_list", c_p), ("reset_count", c_p), ("reset_slot", c_i32), ("reset_sublist_cap", c_i32), ("offset_rand", c_p)]
+                ("reset_list", c_p), ("reset_count", c_p), ("reset_slot", c_i32), ("reset_sublist_cap", c_i32), ("body_state_hist", c_p), ("offset_rand", c_p)]
 
 
 class PpoParams(C.Structure):
@@ -133,7 +133,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the .so does not export the symbol
         fn.argtypes = argtypes
         fn.restype = restype
-    if lib.phc_abi_version() != 25:
+    if lib.phc_abi_version() != 26:
         raise ImportError("libphc_amd.so ABI version mismatch")
     _lib = lib
     return lib

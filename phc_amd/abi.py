@@ -122,10 +122,11 @@ def im_params_struct(dt, max_episode_length, reward_specs, power_reward, power_c
                      cycle_motion=False, zero_out_far=False, close_distance=0.25, far_distance=3.0,
                      dofs_per_joint=3, ext_parent=None, ext_offset=None, obs_v=6, self_obs_v=1, num_force_sensors=0, amp_obs_v=1,
                      remove_base_rot=False, self_obs_extra=None, amp_obs_extra=None, zero_out_far_train=False, zero_out_far_steps=90,
-                     cycle_motion_xp=False):
+                     cycle_motion_xp=False, num_self_obs_hist=0):
     """`self_obs_extra` / `amp_obs_extra`: fp32 [N, E] per-env constant observation columns (shape parameters, limb weights) or None."""
     p = L.ImParams()
     p.remove_base_rot = int(bool(remove_base_rot))
+    p.num_self_obs_hist = int(num_self_obs_hist)
     p.zero_out_far_train, p.zero_out_far_steps, p.cycle_motion_xp = int(bool(zero_out_far_train)), int(zero_out_far_steps), int(bool(cycle_motion_xp))
     p.num_self_obs_extra = 0 if self_obs_extra is None else int(self_obs_extra.shape[1])
     p.num_amp_obs_extra = 0 if amp_obs_extra is None else int(amp_obs_extra.shape[1])
@@ -172,9 +173,10 @@ def im_buffers_struct(progress_buf, reset_buf, terminate_buf, rew_buf, reward_ra
                       sampled_motion_ids, motion_start_times, motion_start_times_offset, global_offset,
                       ref_body_pos=None, ref_body_rot=None, ref_body_vel=None, ref_dof_pos=None,
                       cycle_counter=None, recovery_counter=None, point_goal=None, cycle_phase=None, reset_list=None, reset_count=None,
-                      reset_slot=0, offset_rand=None):
+                      reset_slot=0, offset_rand=None, body_state_hist=None):
     b = L.ImBuffers()
     b.offset_rand = ptr(offset_rand)
+    b.body_state_hist = ptr(body_state_hist)
     b.reset_list, b.reset_count, b.reset_slot = ptr(reset_list), ptr(reset_count), int(reset_slot)
     b.reset_sublist_cap = 0 if reset_list is None else int(reset_list.shape[0]) // RESET_SUBLISTS
     b.progress_buf, b.reset_buf, b.terminate_buf = ptr(progress_buf), ptr(reset_buf), ptr(terminate_buf)

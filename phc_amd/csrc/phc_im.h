@@ -216,7 +216,8 @@ PHC_HD RewardPartial im_post_lane(const phc_model_t& model, const phc_motion_lib
     const Q4 hroot = obs_root_rot(prm, root.rot);
     Q4 hinv = calc_heading_quat_inv(hroot), h = calc_heading_quat(hroot);
     float* obs = buf.obs_buf + env * (int64_t)(prm.num_self_obs + prm.num_task_obs);
-    self_obs_lane(prm, nb, j, body, root, hinv, obs, (sim.force_sensor && prm.self_obs_v == 3) ? sim.force_sensor + env * (int64_t)(prm.num_force_sensors * 6) : nullptr, env);
+    if (prm.self_obs_v == 2 && buf.body_state_hist) self_obs_v2_lane(prm, buf.body_state_hist, nb, env, j, body, root, hinv, obs, true, false);
+    else self_obs_lane(prm, nb, j, body, root, hinv, obs, (sim.force_sensor && prm.self_obs_v == 3) ? sim.force_sensor + env * (int64_t)(prm.num_force_sensors * 6) : nullptr, env);
     int slot = prm.track_slot[j];
     if (slot >= 0) {
         BodyState rt = r1;
@@ -350,7 +351,8 @@ PHC_HD void im_reset_lane(const phc_model_t& model, const phc_motion_lib_t& lib,
     Q4 hinv = calc_heading_quat_inv(hroot), h = calc_heading_quat(hroot);
         float* obs = buf.obs_buf + env * (int64_t)(prm.num_self_obs + prm.num_task_obs);
         // (reset envs: the sensor tensor keeps its last reading until the next simulate call, as gym's does -- humanoid.py:1463)
-        self_obs_lane(prm, nb, j, rs, root, hinv, obs, (sim.force_sensor && prm.self_obs_v == 3) ? sim.force_sensor + env * (int64_t)(prm.num_force_sensors * 6) : nullptr, env);
+        if (prm.self_obs_v == 2 && buf.body_state_hist) self_obs_v2_lane(prm, buf.body_state_hist, nb, env, j, rs, root, hinv, obs, false, true);   // humanoid.py:592-595
+        else self_obs_lane(prm, nb, j, rs, root, hinv, obs, (sim.force_sensor && prm.self_obs_v == 3) ? sim.force_sensor + env * (int64_t)(prm.num_force_sensors * 6) : nullptr, env);
         int slot = prm.track_slot[j];
         if (slot >= 0) {
             BodyState rt = r1;
@@ -415,7 +417,8 @@ PHC_HD void im_reset_from_state_lane(const phc_model_t& model, const phc_motion_
         const Q4 hroot = obs_root_rot(prm, root.rot);
     Q4 hinv = calc_heading_quat_inv(hroot), h = calc_heading_quat(hroot);
         float* obs = buf.obs_buf + env * (int64_t)(prm.num_self_obs + prm.num_task_obs);
-        self_obs_lane(prm, nb, j, body, root, hinv, obs, (sim.force_sensor && prm.self_obs_v == 3) ? sim.force_sensor + env * (int64_t)(prm.num_force_sensors * 6) : nullptr, env);
+        if (prm.self_obs_v == 2 && buf.body_state_hist) self_obs_v2_lane(prm, buf.body_state_hist, nb, env, j, body, root, hinv, obs, false, true);
+        else self_obs_lane(prm, nb, j, body, root, hinv, obs, (sim.force_sensor && prm.self_obs_v == 3) ? sim.force_sensor + env * (int64_t)(prm.num_force_sensors * 6) : nullptr, env);
         int slot = prm.track_slot[j];
         if (slot >= 0) {
             BodyState rt = r1;

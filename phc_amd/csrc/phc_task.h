@@ -185,14 +185,16 @@ PHC_HD void obs_extra_lane(const float* src, int n, int lane, int nl, float* dst
 // `sensors`: the env's S6 force-sensor readings [S*6] (self_obs_v 3: compute_humanoid_observations_smpl_max_v3, humanoid.py:2113-2169,
 // appends them after the angular-velocity block) or nullptr.
 PHC_HD void self_obs_lane(const phc_im_params_t& prm, int nb, int j, const BodyState& body, const BodyState& root,
-                          Q4 hinv, float* obs, const float* sensors = nullptr, int64_t env = -1) {
+                          Q4 hinv, float* obs, const float* sensors = nullptr, int64_t env = -1, bool hist_step = false) {
+    // `hist_step` (self_obs_v 2, humanoid.py:2054-2108): `body` is this body's state at one of the time steps, `root` / `hinv` stay the CURRENT
+    // root; the height column is the root's z at that time step (for j == 0 `body` IS the root then) and the raw root rotation is that step's
     if (env >= 0 && j < nb && prm.num_self_obs_extra > 0 && prm.self_obs_extra)
         obs_extra_lane(prm.self_obs_extra + env * prm.num_self_obs_extra, prm.num_self_obs_extra, j, nb, obs + prm.num_self_obs - prm.num_self_obs_extra);
     int off = 0;
-    if (prm.root_height_obs) { if (j == 0) obs[0] = root.pos.z; off = 1; }
+    if (prm.root_height_obs) { if (j == 0) obs[0] = body.pos.z; off = 1; }
     if (j >= 1) st3(obs + off + (j - 1) * 3, quat_rotate(hinv, body.pos - root.pos));
     float tn[6];
-    if (j == 0 && !prm.local_root_obs) quat_to_tan_norm(obs_root_rot(prm, root.rot), tn);  // :2026-2028
+    if (j == 0 && !prm.local_root_obs) quat_to_tan_norm(hist_step ? body.rot : obs_root_rot(prm, root.rot), tn);  // :2026-2028 / :2085-2087
     else quat_to_tan_norm(quat_mul(hinv, body.rot), tn);
     float* pr = obs + off + (nb - 1) * 3 + j * 6;
     for (int k = 0; k < 6; ++k) pr[k] = tn[k];
@@ -202,6 +204,26 @@ PHC_HD void self_obs_lane(const phc_im_params_t& prm, int nb, int j, const BodyS
         float* o = obs + off + (nb - 1) * 3 + nb * 12 + j * 6;
         for (int k = 0; k < 6; ++k) o[k] = sensors[j * 6 + k];
     }
+}
+
+// self_obs_v 2: the P history states of body j then the current one, each a v1 block of S1 = num_self_obs / (P + 1) floats (:2091-2107);
+// `shift`: afterwards the history advances by one step (`_update_tensor_history`, humanoid.py:1627-1631 -- called at the top of the NEXT
+// post_physics_step with the state this one saw); `fill`: every history slot := the current state (`_init_tensor_history`, :1621-1625)
+PHC_HD void self_obs_v2_lane(const phc_im_params_t& prm, float* hist_all, int nb, int64_t env, int j, const BodyState& body, const BodyState& root,
+                             Q4 hinv, float* obs, bool shift, bool fill) {
+    const int P = prm.num_self_obs_hist, S1 = prm.num_self_obs / (P + 1);
+    float* h = hist_all + ((env * P) * nb + j) * 13;       // slot k of body j: h + k * nb * 13
+    if (fill)
+        for (int k = 0; k < P; ++k) { float* p = h + (int64_t)k * nb * 13; st3(p, body.pos); st4(p + 3, body.rot); st3(p + 7, body.vel); st3(p + 10, body.angvel); }
+    for (int k = 0; k < P; ++k) {
+        const float* p = h + (int64_t)k * nb * 13;
+        BodyState s;
+        s.pos = ld3(p); s.rot = ld4(p + 3); s.vel = ld3(p + 7); s.angvel = ld3(p + 10);
+        self_obs_lane(prm, nb, j, s, root, hinv, obs + k * S1, nullptr, -1, true);
+        if (shift && k >= 1) { float* q = h + (int64_t)(k - 1) * nb * 13; st3(q, s.pos); st4(q + 3, s.rot); st3(q + 7, s.vel); st3(q + 10, s.angvel); }
+    }
+    self_obs_lane(prm, nb, j, body, root, hinv, obs + P * S1, nullptr, -1, true);
+    if (shift && P >= 1) { float* q = h + (int64_t)(P - 1) * nb * 13; st3(q, body.pos); st4(q + 3, body.rot); st3(q + 7, body.vel); st3(q + 10, body.angvel); }
 }
 
 // ---- R7: compute_imitation_observations_v6 (humanoid_im.py:1309-1358), time_steps = 1 ----

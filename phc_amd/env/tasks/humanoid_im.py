@@ -90,11 +90,14 @@ class HumanoidIm:
             v = env.get(k, robot.get(k, off))
             if v != off:
                 raise NotImplementedError(f"config option {k}={v!r} is outside the hot path built so far")
-        if env.get("obs_v", 1) not in (1, 2, 3, 6, 7, 8, 9) or env.get("self_obs_v", 1) not in (1, 3) or env.get("amp_obs_v", 1) not in (1, 2):
-            raise NotImplementedError("built: obs_v 1 / 2 / 3 / 6 / 7 / 8 / 9 (4 and 5 -- past-step stacking, one-hot clip ids -- are not), self_obs_v 1 / 3 "
+        if env.get("obs_v", 1) not in (1, 2, 3, 6, 7, 8, 9) or env.get("self_obs_v", 1) not in (1, 2, 3) or env.get("amp_obs_v", 1) not in (1, 2):
+            raise NotImplementedError("built: obs_v 1 / 2 / 3 / 6 / 7 / 8 / 9 (4 and 5 -- past-step stacking, one-hot clip ids -- are not), self_obs_v 1 / 2 / 3 "
                                       "(force sensors), amp_obs_v 1 / 2 (key-body velocities)")
         self.has_task = True
         self.obs_v, self.self_obs_v, self.amp_obs_v = int(env.get("obs_v", 6)), int(env.get("self_obs_v", 1)), int(env.get("amp_obs_v", 1))
+        self.past_track_steps = int(env.get("past_track_steps", 5))   # humanoid.py:331
+        if self.self_obs_v == 2 and (self._is_robot or robot.get("has_shape_obs", False) or robot.get("has_weight_obs", False)):
+            raise NotImplementedError("self_obs_v=2: SMPL family, without shape / limb-weight columns (the reference raises for them, humanoid.py:2101-2105)")
         # S6: force sensors at the feet (humanoid.py:268,1031-1040), read by self_obs_v 3 only (:683,1449,1481)
         self.force_sensor_joints = list(env.get("force_sensor_joints", ["L_Ankle", "R_Ankle"]))
         if self._is_robot:  # load_robot_configs, humanoid.py:422-439
@@ -432,7 +435,9 @@ class HumanoidIm:
         self._amp_bufs = [torch.zeros((N, S, A), **f32), torch.zeros((N, S, A), **f32)]
         self._amp_cur = 0
         self._amp_obs_demo_buf = None
-        self.self_obs_buf = self.obs_buf[:, :self._num_self_obs]
+        self.self_obs_buf = self.obs_buf[:, :self.get_self_obs_size()]
+        # self_obs_v 2: the past_track_steps previous rigid-body states per env (`_rigid_body_*_hist`, humanoid.py:229-232), kept by the kernels
+        self._body_state_hist = torch.zeros((N, self.past_track_steps, NB, 13), **f32) if self.self_obs_v == 2 else None
         self.reward_raw = torch.zeros((N, 5 if self.power_reward else 4), **f32)
         self.ref_body_pos = torch.zeros((N, NB, 3), **f32)
         self.ref_body_vel = torch.zeros((N, NB, 3), **f32)
@@ -463,10 +468,11 @@ class HumanoidIm:
             first_reset_body=self._body_names.index(self._reset_bodies[0]), termination_distances=self._termination_distances_full,
             num_key_bodies=len(self.key_bodies), key_body_ids=key_ids, num_amp_joints=self._n_amp_joints, amp_joint_slot=amp_slot,
             num_amp_obs_steps=self._num_amp_obs_steps, num_amp_obs_per_step=self._num_amp_obs_per_step,
-            num_self_obs=self._num_self_obs, num_task_obs=self.get_task_obs_size(), obs_v=self.obs_v, cycle_motion=self.cycle_motion,
+            num_self_obs=self.get_self_obs_size(), num_task_obs=self.get_task_obs_size(), obs_v=self.obs_v, cycle_motion=self.cycle_motion,
             zero_out_far=self.zero_out_far, close_distance=self.close_distance, far_distance=self.far_distance,
             dofs_per_joint=1 if self._is_robot else 3, ext_parent=self._ext_parent_i32, ext_offset=self._ext_offset_f32,
             self_obs_v=self.self_obs_v, num_force_sensors=len(self.force_sensor_joints) if self.self_obs_v == 3 else 0, amp_obs_v=self.amp_obs_v,
+            num_self_obs_hist=self.past_track_steps if self.self_obs_v == 2 else 0,
             remove_base_rot=not self._has_upright_start, self_obs_extra=self._self_obs_extra, amp_obs_extra=self._amp_obs_extra,
             zero_out_far_train=self._far_start, zero_out_far_steps=self._zero_out_far_steps, cycle_motion_xp=self.cycle_motion_xp)
         self._flag_state = (flags.im_eval, flags.no_collision_check)
@@ -477,7 +483,8 @@ class HumanoidIm:
                                      self._global_offset, self.ref_body_pos, self.ref_body_rot, self.ref_body_vel, self.ref_dof_pos,
                                      cycle_counter=self._cycle_counter, recovery_counter=self._recovery_counter,
                                      point_goal=self._point_goal, cycle_phase=self._cycle_phase, reset_list=self._reset_list,
-                                     reset_count=self._reset_count, reset_slot=self._reset_slot, offset_rand=self._offset_rand)
+                                     reset_count=self._reset_count, reset_slot=self._reset_slot, offset_rand=self._offset_rand,
+                                     body_state_hist=self._body_state_hist)
 
     @property
     def _amp_obs_buf(self):
@@ -493,6 +500,8 @@ class HumanoidIm:
 
     # ------------------------------------------------------------------ sizes (humanoid.py:504-526, humanoid_amp_task.py:47-55)
     def get_self_obs_size(self):
+        if self.self_obs_v == 2:   # humanoid.py:513-514: the block of every past state and of the current one
+            return self._num_self_obs * (self.past_track_steps + 1)
         return self._num_self_obs
 
     def get_task_obs_size(self):

@@ -766,3 +766,36 @@ def test_k_padded_first_layers_keep_shapes_checkpoints_and_zero_pad():
     assert torch.equal(net.actor_mlp[0].weight, plain.model.a2c_network.actor_mlp[0].weight) and float(w_a._padded[:, 934:].abs().max()) == 0.0
     st2 = agent.optimizer.state_dict()["state"][0]
     np.testing.assert_array_equal(agent.grads.param_view(st2["exp_avg"], agent.grads.params.index(w_a)).cpu().numpy(), st["exp_avg"].cpu().numpy())
+
+
+def test_self_obs_v2_env_keeps_a_body_state_history():
+    """env.self_obs_v = 2 end to end: observation = 6 x 358 self columns + task block; after a reset all six blocks agree (history = the reset
+    state); stepping makes the newest block the current state's v1 block and moves the previous one back by one slot each step."""
+    task, env = make_task(64, motion="synthetic:3:1", **{"env.self_obs_v": 2})
+    assert task.get_self_obs_size() == 6 * 358 and task.num_obs == 6 * 358 + 576
+    env.reset()
+    blocks = task.obs_buf[:, :6 * 358].view(64, 6, 358)
+    for k in range(5):
+        assert torch.equal(blocks[:, k], blocks[:, 5])
+    hist0 = task._body_state_hist.clone()
+    assert torch.equal(hist0[:, 0], task._rigid_body_state.view(64, 24, 13)) and torch.equal(hist0[:, 4], hist0[:, 0])
+    state0 = task._rigid_body_state.view(64, 24, 13).clone()
+    task.progress_buf[:] = 0
+    task._motion_start_times[:] = 0.2
+    obs, rew, done, info = env.step(torch.zeros(64, 69, device=task.device))
+    state1 = task._rigid_body_state.view(64, 24, 13).clone()
+    keep = done == 0
+    assert keep.sum() > 32
+    h = task._body_state_hist
+    assert torch.equal(h[keep][:, 4], state1[keep]) and torch.equal(h[keep][:, 3], state0[keep]) and torch.equal(h[keep][:, 0], state0[keep])
+    # the newest block is what self_obs_v 1 computes from the same state (same root / heading)
+    task1, env1 = make_task(64, motion="synthetic:3:1")
+    task1._rigid_body_state.copy_(task._rigid_body_state)
+    task1._root_states.copy_(task._root_states); task1._dof_state.copy_(task._dof_state)
+    task1.progress_buf.copy_(task.progress_buf - 1); task1._motion_start_times.copy_(task._motion_start_times)
+    task1._sampled_motion_ids.copy_(task._sampled_motion_ids)
+    task1.post_physics_step()
+    torch.cuda.synchronize()
+    got = obs[:, 5 * 358:6 * 358]
+    np.testing.assert_allclose(got.cpu().numpy(), task1.obs_buf[:, :358].cpu().numpy(), atol=1e-6)
+    assert torch.isfinite(obs).all()

@@ -224,6 +224,52 @@ def test_task_obs_versions_vs_reference_golden(golden, backend, obs_v, upright):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("upright", [True, False])
+def test_self_obs_v2_history_vs_reference_golden(golden, backend, upright):
+    """env.self_obs_v = 2: the policy observation carries the v1 block of the past_track_steps = 5 previous body states and of the current one,
+    all relative to the current root (compute_humanoid_observations_smpl_max_v2, humanoid.py:2054-2108; oracle/gen_golden_selfobs_v2.py); the
+    launch then advances the history (`_update_tensor_history`), and a reset fills it with the reset state (`_init_tensor_history`)."""
+    be = get_backend(backend)
+    g, g2, gl = golden("task_fns"), golden("self_obs_v2"), golden("motion_lib_eval")
+    model, mstruct, keepm = model_on(be)
+    lib, keep = motion_lib_on(be, gl)
+    N, P = g["body_pos"].shape[0], 5
+    prm, keepp = make_im_params(be, model, N, num_self_obs=358 * (P + 1), self_obs_v=2, num_self_obs_hist=P, remove_base_rot=not upright)
+    arrs, sim = _sim_arrays(be, g, N)
+    hist = be.arr(g2["hist"].astype(F))
+    amp_in, amp_out = be.zeros((N, 10, 196)), be.zeros((N, 10, 196))
+    W = 358 * (P + 1)
+    b = dict(progress=be.arr((g["progress"] - 1).astype(np.int64)), reset=be.zeros(N, np.int64), term=be.zeros(N, np.int64), rew=be.zeros(N),
+             raw=be.zeros((N, 5)), obs=be.zeros((N, W + 576)), mids=be.arr(g["env_motion"].astype(np.int64)),
+             st=be.arr(g["start_times"].astype(F)), so=be.zeros(N), goff=be.zeros((N, 3)))
+    buf = abi.im_buffers_struct(b["progress"], b["reset"], b["term"], b["rew"], b["raw"], b["obs"], amp_in, amp_out, b["mids"], b["st"],
+                                b["so"], b["goff"], body_state_hist=hist)
+    assert be.im_post_physics(mstruct, lib, prm, sim, buf) == 0
+    be.sync()
+    obs = be.np(b["obs"])
+    np.testing.assert_allclose(obs[:, :W], g2[f"l1u{int(upright)}"], atol=1e-5)
+    if upright:
+        np.testing.assert_allclose(obs[:, W:], g["task_obs"], atol=1e-5)
+    # the history advanced: old slots 1..4 moved to 0..3, slot 4 holds the state this launch saw
+    h = be.np(hist)
+    np.testing.assert_array_equal(h[:, :P - 1], g2["hist"][:, 1:])
+    cur = np.concatenate([g["body_pos"], g["body_rot"], g["body_vel"], g["body_ang_vel"]], axis=-1).astype(F)
+    np.testing.assert_array_equal(h[:, P - 1], cur)
+    # reset of three envs: their history becomes P copies of the imposed reference state, the observation P + 1 copies of its v1 block
+    env_ids = np.array([4, 1, 2], dtype=np.int64)
+    ids_d, ph_d = be.arr(env_ids), be.arr(np.array([0.3, 0.6, 0.1], F))
+    assert be.im_reset(mstruct, lib, prm, sim, buf, 3, ids_d, ph_d, 0) == 0
+    be.sync()
+    h, rbs, obs = be.np(hist), be.np(arrs["rbs"]), be.np(b["obs"])
+    for k in range(P):
+        np.testing.assert_array_equal(h[env_ids, k], rbs[env_ids])
+    blocks = obs[env_ids, :W].reshape(3, P + 1, 358)
+    for k in range(P):
+        np.testing.assert_array_equal(blocks[:, k], blocks[:, P])
+    assert np.abs(h[[0, 3, 5], P - 1] - cur[[0, 3, 5]]).max() == 0      # untouched envs
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
 def test_amp_obs_v2_vs_reference_golden(golden, backend):
     """R9 `_v2`: env.amp_obs_v=2 -> build_amp_observations_smpl_v2 (humanoid_amp.py:1015-1059): 196 + 12 floats per step (the key bodies'
     heading-local velocities after their positions); the history shift works on the 208-float frames."""
