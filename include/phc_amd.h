@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PHC_ABI_VERSION 26
+#define PHC_ABI_VERSION 27
 #define PHC_MAX_BODIES 64   /* bodies (incl. extended reference bodies) per articulation; also the slot count of the model tables */
 #define PHC_EINVAL (-1)
 #define PHC_EUNSUPPORTED (-2)
@@ -178,6 +178,8 @@ typedef struct {
                                          counted in num_self_obs */
     int32_t num_amp_obs_extra;        /* the same at the end of every AMP step (has_shape_obs_disc / has_weight_obs_disc, humanoid_amp.py:1005-1008);
                                          counted in num_amp_obs_per_step */
+    int32_t track_body_reward;        /* env.full_body_reward False: the imitation reward runs over the tracked bodies only (humanoid_im.py:925-936:
+                                         the `_track_bodies_id` subsets; means over len(trackBodies), no extended bodies) */
     int32_t num_self_obs_hist;        /* P = env.past_track_steps (5) of self_obs_v 2; 0 otherwise */
     int32_t zero_out_far_train;       /* env.zero_out_far_train (with zero_out_far): a reset / a clip restart moves the reference to a random spot of a
                                          5 m disk around the humanoid and arms the cycle counter with zero_out_far_steps (humanoid_im.py:966-980,1133-1140) */

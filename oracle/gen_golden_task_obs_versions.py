@@ -42,3 +42,15 @@ assert out["v1_u1"].shape[1] == 15 * J and out["v2_u1"].shape[1] == 15 * J + 3 *
 assert out["v8_u1"].shape[1] == 30 * J and out["v9_u1"].shape[1] == 18 * J + 6
 np.savez_compressed(os.path.join(ROOT, "tests", "golden", "task_obs_versions.npz"), **out)
 print("wrote task_obs_versions.npz", {k: v.shape for k, v in out.items()})
+
+# ---- env.full_body_reward False (humanoid_im.py:925-936): compute_imitation_reward on the tracked-body subsets ----
+TRACK = ["Pelvis", "L_Ankle", "R_Ankle", "Head", "L_Hand", "R_Hand"]
+names = ['Pelvis', 'L_Hip', 'L_Knee', 'L_Ankle', 'L_Toe', 'R_Hip', 'R_Knee', 'R_Ankle', 'R_Toe', 'Torso', 'Spine', 'Chest', 'Neck', 'Head', 'L_Thorax',
+         'L_Shoulder', 'L_Elbow', 'L_Wrist', 'L_Hand', 'R_Thorax', 'R_Shoulder', 'R_Elbow', 'R_Wrist', 'R_Hand']
+tid = torch.tensor([names.index(b) for b in TRACK])
+specs = {"k_pos": 100., "k_rot": 10., "k_vel": 0.1, "k_ang_vel": 0.1, "w_pos": 0.5, "w_rot": 0.3, "w_vel": 0.1, "w_ang_vel": 0.1}
+r0 = (t("ref_pos"), t("ref_rot"), t("ref_vel"), t("ref_ang_vel"))
+rew, raw = him.compute_imitation_reward(bp[:, 0], br[:, 0], bp[:, tid], br[:, tid], bv[:, tid], bav[:, tid], r0[0][:, tid], r0[1][:, tid], r0[2][:, tid],
+                                        r0[3][:, tid], specs)
+np.savez_compressed(os.path.join(ROOT, "tests", "golden", "reward_track_bodies.npz"), track_ids=tid.numpy(), reward=rew.numpy(), reward_raw=raw.numpy())
+print("wrote reward_track_bodies.npz", rew.shape, raw.shape)

@@ -174,7 +174,7 @@ PHC_HD RewardPartial im_post_lane(const phc_model_t& model, const phc_motion_lib
         // pose = parent pose composed with a fixed offset, reference from the extended record slots; only the position
         // and rotation terms include them (body_vel / body_ang_vel stay NB wide).
         const int e = j - nb;
-        if (e >= prm.num_ext_bodies) return rp;
+        if (e >= prm.num_ext_bodies || prm.track_body_reward) return rp;
         const BodyState par = load_body(sim.rigid_body_state, env, nb, prm.ext_parent[e]);
         BodyState cur;
         cur.pos = quat_rotate(par.rot, ld3(prm.ext_offset + 3 * e)) + par.pos;
@@ -204,6 +204,7 @@ PHC_HD RewardPartial im_post_lane(const phc_model_t& model, const phc_motion_lib
     } else if (j == 0) {
         rp.root_dist = norm(body.pos - r0.pos);  // humanoid_im.py:892
     }
+    if (prm.track_body_reward && prm.track_slot[j] < 0) rp.pos = rp.rot = rp.vel = rp.angvel = 0.f;   // full_body_reward False (:925-936)
     // R2 power partial: sum |tau * qdot| over this body's joint (humanoid_im.py:939-946)
     if (prm.power_reward && j >= 1) {
         int ds = model.ints[4 + 3 * PHC_MAX_BODIES + j];
@@ -254,7 +255,8 @@ PHC_HD RewardPartial im_post_lane(const phc_model_t& model, const phc_motion_lib
 PHC_HD void im_post_finalize(const phc_motion_lib_t& lib, const phc_im_params_t& prm, const phc_im_buffers_t& buf, int nb,
                              int64_t env, const ImStepCtx& c, int64_t progress, float s_pos, float s_rot, float s_vel, float s_angvel,
                              float s_power, float s_dist, float root_dist, float prev_point_goal, int any_fallen, int n_reset_bodies) {
-    const float J = (float)nb, JE = (float)(nb + prm.num_ext_bodies);  // position / rotation means include the extended bodies
+    float J = (float)nb, JE = (float)(nb + prm.num_ext_bodies);  // position / rotation means include the extended bodies
+    if (prm.track_body_reward) J = JE = (float)prm.num_track_bodies;
     float r_pos = expf(-prm.k_pos * (s_pos / JE));
     float r_rot = expf(-prm.k_rot * (s_rot / JE));
     float r_vel = expf(-prm.k_vel * (s_vel / J));

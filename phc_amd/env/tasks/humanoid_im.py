@@ -156,9 +156,7 @@ class HumanoidIm:
         self.collect_dataset = cfg.get("collect_dataset", False)
         self.temp_running_mean = env.get("temp_running_mean", True)
         self.partial_running_mean = env.get("partial_running_mean", False)
-        self._full_body_reward = env.get("full_body_reward", True)
-        if not self._full_body_reward:
-            raise NotImplementedError("full_body_reward=False is not built")
+        self._full_body_reward = env.get("full_body_reward", True)   # False: reward over the tracked bodies only (humanoid_im.py:925-936)
         self._min_motion_len = env.get("min_length", -1)
         self.reward_specs = dict(env.get("reward_specs", {"k_pos": 100, "k_rot": 10, "k_vel": 0.1, "k_ang_vel": 0.1,
                                                           "w_pos": 0.5, "w_rot": 0.3, "w_vel": 0.1, "w_ang_vel": 0.1}))
@@ -472,7 +470,7 @@ class HumanoidIm:
             zero_out_far=self.zero_out_far, close_distance=self.close_distance, far_distance=self.far_distance,
             dofs_per_joint=1 if self._is_robot else 3, ext_parent=self._ext_parent_i32, ext_offset=self._ext_offset_f32,
             self_obs_v=self.self_obs_v, num_force_sensors=len(self.force_sensor_joints) if self.self_obs_v == 3 else 0, amp_obs_v=self.amp_obs_v,
-            num_self_obs_hist=self.past_track_steps if self.self_obs_v == 2 else 0,
+            num_self_obs_hist=self.past_track_steps if self.self_obs_v == 2 else 0, track_body_reward=not self._full_body_reward,
             remove_base_rot=not self._has_upright_start, self_obs_extra=self._self_obs_extra, amp_obs_extra=self._amp_obs_extra,
             zero_out_far_train=self._far_start, zero_out_far_steps=self._zero_out_far_steps, cycle_motion_xp=self.cycle_motion_xp)
         self._flag_state = (flags.im_eval, flags.no_collision_check)

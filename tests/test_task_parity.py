@@ -270,6 +270,31 @@ def test_self_obs_v2_history_vs_reference_golden(golden, backend, upright):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
+def test_track_body_reward_vs_reference_golden(golden, backend):
+    """env.full_body_reward False: the imitation reward over the tracked bodies only == compute_imitation_reward on the `_track_bodies_id`
+    subsets (humanoid_im.py:925-936; oracle/gen_golden_task_obs_versions.py), here with the six-body VR-style track list."""
+    be = get_backend(backend)
+    g, gr, gl = golden("task_fns"), golden("reward_track_bodies"), golden("motion_lib_eval")
+    model, mstruct, keepm = model_on(be)
+    lib, keep = motion_lib_on(be, gl)
+    N = g["body_pos"].shape[0]
+    track = [model.body_names[i] for i in gr["track_ids"]]
+    prm, keepp = make_im_params(be, model, N, power_reward=False, track_bodies=track, track_body_reward=True)
+    arrs, sim = _sim_arrays(be, g, N)
+    amp_in, amp_out = be.zeros((N, 10, 196)), be.zeros((N, 10, 196))
+    b = dict(progress=be.arr((g["progress"] - 1).astype(np.int64)), reset=be.zeros(N, np.int64), term=be.zeros(N, np.int64), rew=be.zeros(N),
+             raw=be.zeros((N, 4)), obs=be.zeros((N, 358 + 24 * len(track))), mids=be.arr(g["env_motion"].astype(np.int64)),
+             st=be.arr(g["start_times"].astype(F)), so=be.zeros(N), goff=be.zeros((N, 3)))
+    buf = abi.im_buffers_struct(b["progress"], b["reset"], b["term"], b["rew"], b["raw"], b["obs"], amp_in, amp_out, b["mids"], b["st"],
+                                b["so"], b["goff"])
+    assert be.im_post_physics(mstruct, lib, prm, sim, buf) == 0
+    be.sync()
+    np.testing.assert_allclose(be.np(b["rew"]), gr["reward"], atol=1e-5)
+    np.testing.assert_allclose(be.np(b["raw"]), gr["reward_raw"], atol=1e-5)
+    assert np.abs(gr["reward"] - g["reward"]).max() > 1e-3      # differs from the full-body reward
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
 def test_amp_obs_v2_vs_reference_golden(golden, backend):
     """R9 `_v2`: env.amp_obs_v=2 -> build_amp_observations_smpl_v2 (humanoid_amp.py:1015-1059): 196 + 12 floats per step (the key bodies'
     heading-local velocities after their positions); the history shift works on the 208-float frames."""
