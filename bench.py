@@ -58,6 +58,8 @@ def parse():
                     "clip (the bench line), 3 = 8192 envs + AMASS-sized synthetic library (--motion-clips, default 11313), 5 = H1 4096 envs")
     ap.add_argument("--ppo-epochs", type=int, default=3, help="timed PPO epochs (rollout 32 steps + 36 optimizer steps); 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-workloads", action="store_true", help="skip the two extra env-step measurements (tracking actions, Unitree H1) "
+                    "that the default single-GPU run appends as `other_workloads`")
     ap.add_argument("--no-pmc", action="store_true", help="skip the live HBM-traffic measurement (two rocprofv3 --pmc passes of a 20-step "
                     "child run, FETCH_SIZE and WRITE_SIZE separately as MI355X_MICROARCH.md prescribes); `roofline.traffic` then falls "
                     "back to the newest committed profiles/*_pmc_traffic.json")
@@ -179,6 +181,25 @@ def cpu_reference():
             "stages_ms": {n: {k: v for k, v in st[n].items() if k.endswith("_ms")} for n in st}, "load_motions_ms_per_clip": d["load_motions"]["ms_per_clip"],
             "protocol": d.get("protocol", "5 warm-up + 50 timed iterations, median"), "measured_in": d.get("measured_in", "build container"),
             "source": "profiles/" + files[-1]}
+
+
+def other_workloads():
+    """The same env step on the other single-GPU workloads of BASELINE.json, measured NOW by child runs of this script (so that the driver's
+    line carries them too): configs[1] with tracking actions (no reset storm), configs[4] Unitree H1.  -> {name: {value, ms_per_step, ...}}."""
+    import subprocess
+    env = dict(os.environ, PHC_BENCH_CHILD="1")
+    out = {}
+    for name, tail in (("configs1_tracking_actions", ["--actions", "tracking"]), ("configs4_unitree_h1", ["--config", "5"])):
+        cmd = [sys.executable, os.path.abspath(__file__), "--steps", "300", "--warmup", "30", "--ppo-epochs", "0", "--no-cpu-baseline", "--no-pmc"] + tail
+        try:
+            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+            line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+            d = json.loads(line)
+            out[name] = {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "stepper_kernel_ms": d["roofline"]["kernel_ms"],
+                         "workload": d["config"]["workload"], "envs_per_gpu": d["config"]["envs_per_gpu"]}
+        except Exception as exc:   # noqa: BLE001
+            out[name] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
+    return out
 
 
 def live_pmc_traffic(argv_tail, kernel_prefixes):
@@ -436,6 +457,9 @@ def main():
                 out["cpu_reference"] = ref
         if cfg3 is not None:
             out["config3_motion_library"] = cfg3
+        if (world == 1 and not args.no_other_workloads and not os.environ.get("PHC_BENCH_CHILD") and args.config == 2 and args.robot == "smpl"
+                and args.actions == "random" and args.envs == 4096):
+            out["other_workloads"] = other_workloads()
         out["actions"] = args.actions
         if not os.environ.get("PHC_BENCH_CHILD"):
             out["device"] = device_state(dev)

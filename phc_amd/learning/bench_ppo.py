@@ -13,7 +13,10 @@ def time_ppo_epochs(task, env, cfg, epochs, dist=None, warmup=1):
     agent = IMAmpAgent(env, cfg, dist=dist)
     agent.init_train()
     if agent._graph_enabled():
-        warmup = max(warmup, 2)   # epoch 1 creates the optimizer state eagerly, epoch 2 captures the update graph
+        # epoch 1 captures the update graph, epoch 2 the rollout segments, epoch 3 is the first one with a non-empty replay buffer (its
+        # batch stops aliasing the agent batch: one-time buffer set-up, 92 vs 61 ms of update on a freshly started box -- scripts/ppo_epoch_trace.py);
+        # from epoch 4 on every epoch costs the same
+        warmup = max(warmup, 4)
     for _ in range(warmup):
         agent.train_epoch()
     if dist is not None:

@@ -744,6 +744,17 @@ def policy_sample(mu, value, logstd, value_norm, out_actions, out_mus, out_sigma
                                   ptr(out_sigmas), ptr(out_neglogp), ptr(out_values), _stream(head.device)), "phc_policy_sample")
 
 
+def adam_state(optimizer, flat_param):
+    """The optimizer's state of the flat parameter, created (zero moments, step 0) if it does not exist yet -- callers that capture the step
+    in a graph create it BEFORE the capture (tensors made inside a capture live in the graph's pool and their zero-fill would replay)."""
+    st = optimizer.state[flat_param]
+    if len(st) == 0:
+        st["step"] = torch.tensor(0.0, dtype=torch.float32)
+        st["exp_avg"] = torch.zeros_like(flat_param)
+        st["exp_avg_sq"] = torch.zeros_like(flat_param)
+    return st
+
+
 def adam_clip_step(optimizer, flat_param, flat_grad, max_norm, shadow=None, step_device=None, count_host=True):
     """`clip_grad_norm_(max_norm)` (None / <= 0: no clipping) + `optimizer.step()` for a torch.optim.Adam that holds the single flat
     parameter, on the device: its state (`step`, `exp_avg`, `exp_avg_sq`) stays the optimizer's, so checkpoints are unchanged.
@@ -754,11 +765,7 @@ def adam_clip_step(optimizer, flat_param, flat_grad, max_norm, shadow=None, step
     group = optimizer.param_groups[0]
     assert len(optimizer.param_groups) == 1 and len(group["params"]) == 1 and group["params"][0] is flat_param
     assert not group.get("amsgrad", False) and not group.get("maximize", False)
-    st = optimizer.state[flat_param]
-    if len(st) == 0:
-        st["step"] = torch.tensor(0.0, dtype=torch.float32)
-        st["exp_avg"] = torch.zeros_like(flat_param)
-        st["exp_avg_sq"] = torch.zeros_like(flat_param)
+    st = adam_state(optimizer, flat_param)
     if st["step"].is_cuda:   # state restored from a checkpoint written by a fused / capturable optimizer
         st["step"] = st["step"].detach().cpu()
     if count_host:
