@@ -799,3 +799,35 @@ def test_self_obs_v2_env_keeps_a_body_state_history():
     got = obs[:, 5 * 358:6 * 358]
     np.testing.assert_allclose(got.cpu().numpy(), task1.obs_buf[:, :358].cpu().numpy(), atol=1e-6)
     assert torch.isfinite(obs).all()
+
+
+@pytest.mark.parametrize("over", [
+    {"learning": "im_pnn", "env": "env_im_pnn"},                                                         # PNN columns (frozen + training)
+    {"robot": "smpl_humanoid_shape"},                                                                    # per-env shapes + shape columns in obs / AMP obs
+    {"env.self_obs_v": 2, "env.obs_v": 8},                                                               # history self obs + v8 task obs (wide inputs)
+])
+def test_captured_update_trains_the_other_network_and_observation_variants(over):
+    """The captured update (optimizer inside the graph on one rank, K-padded first layers, row-restricted gradient penalty) on the variants the
+    bench line does not exercise: three epochs, graph active, finite losses, parameters move, pad columns stay zero."""
+    from phc_amd.learning.amp_agent import IMAmpAgent
+    groups = [f"{k}={v}" for k, v in over.items() if "." not in k]
+    from phc_amd.config import compose
+    from phc_amd.env.tasks.vec_task import parse_task
+    torch.manual_seed(0)
+    cfg = compose(groups + ["env.num_envs=256", "env.motion_file=synthetic:2:3", "learning.params.config.minibatch_size=2048",
+                            "learning.params.config.amp_minibatch_size=1024", "learning.params.config.amp_obs_demo_buffer_size=4096",
+                            "learning.params.config.amp_replay_buffer_size=4096", "+learning.params.config.hip_graph=True"]
+                  + [f"{k}={v}" for k, v in over.items() if "." in k])
+    task, env = parse_task(cfg)
+    agent = IMAmpAgent(env, cfg)
+    agent.init_train()
+    p0 = agent.grads.flat_param.clone()
+    for _ in range(3):
+        info = agent.train_epoch()
+        assert np.isfinite([info["actor_loss"], info["critic_loss"], info["disc_loss"], info["kl"]]).all(), info
+    assert agent._graph is not None and not torch.equal(p0, agent.grads.flat_param)
+    st = agent.optimizer.state[agent.grads.flat_param]
+    assert int(st["step"]) == 3 * agent.mini_epochs_num * agent.num_minibatches
+    for p in agent.grads.params:
+        if getattr(p, "_padded", None) is not None:
+            assert float(p._padded[:, p.shape[1]:].abs().max()) == 0.0
