@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PHC_ABI_VERSION 27
+#define PHC_ABI_VERSION 28
 #define PHC_MAX_BODIES 64   /* bodies (incl. extended reference bodies) per articulation; also the slot count of the model tables */
 #define PHC_EINVAL (-1)
 #define PHC_EUNSUPPORTED (-2)
@@ -178,6 +178,10 @@ typedef struct {
                                          counted in num_self_obs */
     int32_t num_amp_obs_extra;        /* the same at the end of every AMP step (has_shape_obs_disc / has_weight_obs_disc, humanoid_amp.py:1005-1008);
                                          counted in num_amp_obs_per_step */
+    int32_t num_traj_samples;         /* env.fut_tracks: T = numTrajSamples reference frames in the task observation -- the next one and T - 1 more,
+                                         traj_sample_timestep apart (humanoid_im.py:39-47,741-747); obs_v 6 / 7 / 9 (time-major blocks); 0 / 1 = off;
+                                         num_task_obs counts all T blocks */
+    float traj_sample_timestep;       /* 1 / env.trajSampleTimestepInv (30) */
     int32_t track_body_reward;        /* env.full_body_reward False: the imitation reward runs over the tracked bodies only (humanoid_im.py:925-936:
                                          the `_track_bodies_id` subsets; means over len(trackBodies), no extended bodies) */
     int32_t num_self_obs_hist;        /* P = env.past_track_steps (5) of self_obs_v 2; 0 otherwise */

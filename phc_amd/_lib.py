@@ -64,7 +64,7 @@ class ImParams(C.Structure):
                 ("dofs_per_joint", c_i32), ("num_ext_bodies", c_i32), ("ext_parent", c_p), ("ext_offset", c_p), ("obs_v", c_i32),
                 ("self_obs_v", c_i32), ("num_force_sensors", c_i32), ("amp_obs_v", c_i32),
                 ("remove_base_rot", c_i32), ("num_self_obs_extra", c_i32), ("num_amp_obs_extra", c_i32),
-                ("track_body_reward", c_i32), ("num_self_obs_hist", c_i32), ("zero_out_far_train", c_i32), ("zero_out_far_steps", c_i32), ("cycle_motion_xp", c_i32),
+                ("num_traj_samples", c_i32), ("traj_sample_timestep", c_f), ("track_body_reward", c_i32), ("num_self_obs_hist", c_i32), ("zero_out_far_train", c_i32), ("zero_out_far_steps", c_i32), ("cycle_motion_xp", c_i32),
                 ("self_obs_extra", c_p), ("amp_obs_extra", c_p)]
 
 
@@ -133,7 +133,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the .so does not export the symbol
         fn.argtypes = argtypes
         fn.restype = restype
-    if lib.phc_abi_version() != 27:
+    if lib.phc_abi_version() != 28:
         raise ImportError("libphc_amd.so ABI version mismatch")
     _lib = lib
     return lib

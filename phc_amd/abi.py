@@ -122,12 +122,13 @@ def im_params_struct(dt, max_episode_length, reward_specs, power_reward, power_c
                      cycle_motion=False, zero_out_far=False, close_distance=0.25, far_distance=3.0,
                      dofs_per_joint=3, ext_parent=None, ext_offset=None, obs_v=6, self_obs_v=1, num_force_sensors=0, amp_obs_v=1,
                      remove_base_rot=False, self_obs_extra=None, amp_obs_extra=None, zero_out_far_train=False, zero_out_far_steps=90,
-                     cycle_motion_xp=False, num_self_obs_hist=0, track_body_reward=False):
+                     cycle_motion_xp=False, num_self_obs_hist=0, track_body_reward=False, num_traj_samples=1, traj_sample_timestep=1 / 30):
     """`self_obs_extra` / `amp_obs_extra`: fp32 [N, E] per-env constant observation columns (shape parameters, limb weights) or None."""
     p = L.ImParams()
     p.remove_base_rot = int(bool(remove_base_rot))
     p.num_self_obs_hist = int(num_self_obs_hist)
     p.track_body_reward = int(bool(track_body_reward))
+    p.num_traj_samples, p.traj_sample_timestep = int(num_traj_samples), float(np.float32(traj_sample_timestep))
     p.zero_out_far_train, p.zero_out_far_steps, p.cycle_motion_xp = int(bool(zero_out_far_train)), int(zero_out_far_steps), int(bool(cycle_motion_xp))
     p.num_self_obs_extra = 0 if self_obs_extra is None else int(self_obs_extra.shape[1])
     p.num_amp_obs_extra = 0 if amp_obs_extra is None else int(amp_obs_extra.shape[1])

@@ -161,6 +161,22 @@ PHC_HD float zero_out_far_ref(const phc_im_params_t& prm, int slot, const BodySt
     return distance;
 }
 
+// env.fut_tracks (humanoid_im.py:741-747): the blocks of the T - 1 further reference samples behind the standard one (obs_v 6 / 7 / 9 lay the
+// samples out time-major: one standard block each)
+PHC_HD void task_obs_future_lane(const phc_motion_lib_t& lib, const phc_im_params_t& prm, int64_t mid, int64_t progress1, float start, float start_off,
+                                 V3 goff, int slot, int j, const BodyState& body, const BodyState& root, Q4 hinv, Q4 h, float* tobs) {
+    const int T = prm.num_traj_samples;
+    if (T <= 1 || !(prm.obs_v == 6 || prm.obs_v == 7 || prm.obs_v == 9)) return;
+    const int block = prm.num_task_obs / T;
+    for (int k = 1; k < T; ++k) {
+        PHC_NO_CONTRACT
+        const float kts = (float)k * prm.traj_sample_timestep;
+        BodyState r = ref_body(lib, frame_ref(lib, mid, motion_time_future(progress1, prm.dt, kts, start, start_off)), j);
+        r.pos += goff;
+        task_obs_lane(prm, slot, body, root, r, hinv, h, tobs + k * block);
+    }
+}
+
 // post_physics_step for lane (env, j); `progress` is the already incremented progress_buf value
 // (humanoid.py:1637).  Writes obs / AMP slices, returns the partials the caller reduces over the env.
 PHC_HD RewardPartial im_post_lane(const phc_model_t& model, const phc_motion_lib_t& lib, const phc_im_params_t& prm,
@@ -234,6 +250,7 @@ PHC_HD RewardPartial im_post_lane(const phc_model_t& model, const phc_motion_lib
             ref_joint(lib, fr1, j, &rjd, &rjv);
         }
         task_obs_lane(prm, slot, body, root, rt, hinv, h, obs + prm.num_self_obs, &jd, &rjd);
+        task_obs_future_lane(lib, prm, mid, c.progress + 1, c.start, c.start_off, c.goff, slot, j, body, root, hinv, h, obs + prm.num_self_obs);
     }
     // side-effect buffers of _compute_task_obs (humanoid_im.py:855-868)
     if (buf.ref_body_pos) st3(buf.ref_body_pos + (env * nb + j) * 3, r1.pos);
@@ -367,6 +384,7 @@ PHC_HD void im_reset_lane(const phc_model_t& model, const phc_motion_lib_t& lib,
             V3 jd = v3(0.f, 0.f, 0.f), jv, rjd = jd, rjv;
             if (prm.obs_v == 2 && j >= 1) { ref_joint(lib, fr, j, &jd, &jv); ref_joint(lib, fr1, j, &rjd, &rjv); }   // (the imposed state is the reference at t)
             task_obs_lane(prm, slot, rs, root, rt, hinv, h, obs + prm.num_self_obs, &jd, &rjd);
+            task_obs_future_lane(lib, prm, mid, 1, t, 0.f, goff, slot, j, rs, root, hinv, h, obs + prm.num_self_obs);
         }
         if (buf.ref_body_pos) st3(buf.ref_body_pos + (env * nb + j) * 3, r1.pos);
         if (buf.ref_body_rot) st4(buf.ref_body_rot + (env * nb + j) * 4, r1.rot);
@@ -436,6 +454,8 @@ PHC_HD void im_reset_from_state_lane(const phc_model_t& model, const phc_motion_
                 ref_joint(lib, fr1, j, &rjd, &rjv);
             }
             task_obs_lane(prm, slot, body, root, rt, hinv, h, obs + prm.num_self_obs, &jd, &rjd);
+            task_obs_future_lane(lib, prm, mid, 1, buf.motion_start_times[env], buf.motion_start_times_offset[env], goff, slot, j, body, root, hinv, h,
+                                 obs + prm.num_self_obs);
         }
         if (buf.ref_body_pos) st3(buf.ref_body_pos + (env * nb + j) * 3, r1.pos);
         if (buf.ref_body_rot) st4(buf.ref_body_rot + (env * nb + j) * 4, r1.rot);

@@ -77,6 +77,14 @@ PHC_HD float motion_time(int64_t progress, float dt, float start, float start_of
     float b = a + start;
     return b + start_off;
 }
+// fut_tracks sample k (humanoid_im.py:744-745): (progress + 1) * dt + k * traj_sample_timestep + start + offset, left to right in fp32
+PHC_HD float motion_time_future(int64_t progress1, float dt, float k_ts, float start, float start_off) {
+    PHC_NO_CONTRACT
+    float a = (float)progress1 * dt;
+    float b = a + k_ts;
+    float c = b + start;
+    return c + start_off;
+}
 // humanoid_im.py:1126: -progress_buf * dt
 PHC_HD float neg_progress_time(int64_t progress, float dt) {
     PHC_NO_CONTRACT

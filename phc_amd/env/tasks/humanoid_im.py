@@ -84,7 +84,7 @@ class HumanoidIm:
         if self.humanoid_type not in ("smpl", "h1", "g1"):
             raise NotImplementedError(f"humanoid_type={self.humanoid_type!r}: built so far: smpl, h1, g1")
         self._is_robot = self.humanoid_type in ("h1", "g1")
-        unsupported = dict(fut_tracks=False, occl_training=False, res_action=False,
+        unsupported = dict(fut_tracks_dropout=False, occl_training=False, res_action=False,
                            kin_loss=False, z_readout=False, distill=False)
         for k, off in unsupported.items():
             v = env.get(k, robot.get(k, off))
@@ -96,6 +96,15 @@ class HumanoidIm:
         self.has_task = True
         self.obs_v, self.self_obs_v, self.amp_obs_v = int(env.get("obs_v", 6)), int(env.get("self_obs_v", 1)), int(env.get("amp_obs_v", 1))
         self.past_track_steps = int(env.get("past_track_steps", 5))   # humanoid.py:331
+        # future reference tracks in the task observation (humanoid_im.py:39-47): numTrajSamples frames, 1 / trajSampleTimestepInv apart
+        self._fut_tracks = bool(env.get("fut_tracks", False))
+        self._num_traj_samples = int(env["numTrajSamples"]) if self._fut_tracks else 1
+        self._traj_sample_timestep = 1 / env.get("trajSampleTimestepInv", 30)
+        if self._fut_tracks and self._num_traj_samples > 1:
+            if self.obs_v not in (6, 7, 9):
+                raise NotImplementedError("fut_tracks: built for the time-major task observations obs_v 6 / 7 / 9")
+            if env.get("zero_out_far", False):
+                raise NotImplementedError("fut_tracks with zero_out_far: the reference's far-mask indexes a single-sample block (humanoid_im.py:785-800)")
         if self.self_obs_v == 2 and (self._is_robot or robot.get("has_shape_obs", False) or robot.get("has_weight_obs", False)):
             raise NotImplementedError("self_obs_v=2: SMPL family, without shape / limb-weight columns (the reference raises for them, humanoid.py:2101-2105)")
         # S6: force sensors at the feet (humanoid.py:268,1031-1040), read by self_obs_v 3 only (:683,1449,1481)
@@ -471,6 +480,7 @@ class HumanoidIm:
             dofs_per_joint=1 if self._is_robot else 3, ext_parent=self._ext_parent_i32, ext_offset=self._ext_offset_f32,
             self_obs_v=self.self_obs_v, num_force_sensors=len(self.force_sensor_joints) if self.self_obs_v == 3 else 0, amp_obs_v=self.amp_obs_v,
             num_self_obs_hist=self.past_track_steps if self.self_obs_v == 2 else 0, track_body_reward=not self._full_body_reward,
+            num_traj_samples=self._num_traj_samples, traj_sample_timestep=self._traj_sample_timestep,
             remove_base_rot=not self._has_upright_start, self_obs_extra=self._self_obs_extra, amp_obs_extra=self._amp_obs_extra,
             zero_out_far_train=self._far_start, zero_out_far_steps=self._zero_out_far_steps, cycle_motion_xp=self.cycle_motion_xp)
         self._flag_state = (flags.im_eval, flags.no_collision_check)
@@ -508,7 +518,7 @@ class HumanoidIm:
         J = len(self._track_bodies)   # humanoid_im.py:486-520 with num_traj_samples = 1
         if self.obs_v in (2, 9) and self._track_bodies[0] != self._body_names[0]:
             raise NotImplementedError("obs_v 2 / 9 index the root as the first tracked body (humanoid_im.py:775-776,822)")
-        return {1: 15 * J, 2: 15 * J + 3 * (J - 1), 3: 9 * J, 6: 24 * J, 7: 9 * J, 8: 30 * J, 9: 18 * J + 6}[self.obs_v]
+        return {1: 15 * J, 2: 15 * J + 3 * (J - 1), 3: 9 * J, 6: 24 * J, 7: 9 * J, 8: 30 * J, 9: 18 * J + 6}[self.obs_v] * self._num_traj_samples
 
     def get_obs_size(self):
         return self.get_self_obs_size() + self.get_task_obs_size()
@@ -535,8 +545,8 @@ class HumanoidIm:
         """humanoid_im.py:522-537."""
         d = OrderedDict()
         d["target"] = self.get_task_obs_size()
-        d["fut_tracks"] = False
-        d["num_traj_samples"] = 1
+        d["fut_tracks"] = self._fut_tracks
+        d["num_traj_samples"] = self._num_traj_samples
         d["obs_v"] = self.obs_v
         d["track_bodies"] = self._track_bodies
         d["models_path"] = self.models_path

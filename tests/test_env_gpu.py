@@ -831,3 +831,39 @@ def test_captured_update_trains_the_other_network_and_observation_variants(over)
     for p in agent.grads.params:
         if getattr(p, "_padded", None) is not None:
             assert float(p._padded[:, p.shape[1]:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("obs_v", [6, 9])
+def test_fut_tracks_env_samples_future_reference_frames(obs_v):
+    """env.fut_tracks with numTrajSamples = 3 end to end (humanoid_im.py:39-47,741-747): the task block is three standard blocks; block 0 is the
+    plain env's block (reset and step paths), block k the plain env's block with the clip start moved k * (1 / trajSampleTimestepInv) s on."""
+    N = 64
+    over = {"env.obs_v": obs_v}
+    task, env = make_task(N, motion="synthetic:3:1", **over, **{"env.fut_tracks": True, "env.numTrajSamples": 3})
+    task1, env1 = make_task(N, motion="synthetic:3:1", **over)
+    blk = task1.get_task_obs_size()
+    so = task.get_self_obs_size()
+    assert task.get_task_obs_size() == 3 * blk and task.num_obs == so + 3 * blk
+    assert task.get_task_obs_size_detail()["num_traj_samples"] == 3
+    o, o1 = env.reset(), env1.reset()
+    o, o1 = (x["obs"] if isinstance(x, dict) else x for x in (o, o1))
+    assert torch.equal(task._sampled_motion_ids, task1._sampled_motion_ids) and torch.equal(task._motion_start_times, task1._motion_start_times)
+    assert torch.equal(o[:, :so + blk], o1) and torch.isfinite(o).all()
+    assert (o[:, so + blk:so + 2 * blk] - o[:, so:so + blk]).abs().max() > 1e-3       # a different reference frame
+    act = torch.zeros(N, task.get_action_size(), device=task.device)
+    for _ in range(2):
+        o, _, done, _ = env.step(act)
+        o1, _, done1, _ = env1.step(act)
+    assert torch.equal(done, done1) and torch.equal(o[:, :so + blk], o1)
+    keep = (done == 0).cpu().numpy()
+    assert keep.sum() > N // 2
+    # block k == the plain env's block with the clip start k sample intervals later, on the same simulator state
+    ts = task._traj_sample_timestep
+    assert ts == 1 / task.cfg["env"]["trajSampleTimestepInv"]
+    for k in (1, 2):
+        task1.progress_buf.copy_(task.progress_buf - 1)
+        task1._motion_start_times.copy_(task._motion_start_times + k * ts)
+        task1.post_physics_step()
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(o[:, so + k * blk:so + (k + 1) * blk].cpu().numpy()[keep], task1.obs_buf[:, so:].cpu().numpy()[keep], atol=2e-4)
+        task1._motion_start_times.copy_(task._motion_start_times)

@@ -224,6 +224,34 @@ def test_task_obs_versions_vs_reference_golden(golden, backend, obs_v, upright):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("obs_v,upright", [(6, True), (7, True), (9, True), (6, False), (9, False)])
+def test_task_obs_fut_tracks_vs_reference_golden(golden, backend, obs_v, upright):
+    """env.fut_tracks with numTrajSamples = 3: the task block holds one standard obs_v 6 / 7 / 9 block per future reference sample, time-major,
+    sampled at (progress + 1) * dt + k / 30 + start + offset (humanoid_im.py:741-747,1309-1358,1467-1520; oracle/gen_golden_fut_tracks.py)."""
+    be = get_backend(backend)
+    g, gv, gl = golden("task_fns"), golden("task_obs_fut_tracks"), golden("motion_lib_eval")
+    model, mstruct, keepm = model_on(be)
+    lib, keep = motion_lib_on(be, gl)
+    N = g["body_pos"].shape[0]
+    want = gv[f"v{obs_v}_u{int(upright)}"]
+    prm, keepp = make_im_params(be, model, N, obs_v=obs_v, remove_base_rot=not upright, num_traj_samples=3, traj_sample_timestep=1 / 30)
+    prm.num_task_obs = want.shape[1]
+    arrs, sim = _sim_arrays(be, g, N)
+    amp_in, amp_out = be.zeros((N, 10, 196)), be.zeros((N, 10, 196))
+    b = dict(progress=be.arr((g["progress"] - 1).astype(np.int64)), reset=be.zeros(N, np.int64), term=be.zeros(N, np.int64), rew=be.zeros(N),
+             raw=be.zeros((N, 5)), obs=be.zeros((N, 358 + want.shape[1])), mids=be.arr(g["env_motion"].astype(np.int64)),
+             st=be.arr(g["start_times"].astype(F)), so=be.arr(gv["start_off"].astype(F)), goff=be.zeros((N, 3)))
+    buf = abi.im_buffers_struct(b["progress"], b["reset"], b["term"], b["rew"], b["raw"], b["obs"], amp_in, amp_out, b["mids"], b["st"],
+                                b["so"], b["goff"])
+    assert be.im_post_physics(mstruct, lib, prm, sim, buf) == 0
+    be.sync()
+    obs = be.np(b["obs"])
+    np.testing.assert_allclose(obs[:, 358:], want, atol=3e-5)
+    if upright:
+        np.testing.assert_allclose(obs[:, :358], g["self_obs"], atol=1e-5)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
 @pytest.mark.parametrize("upright", [True, False])
 def test_self_obs_v2_history_vs_reference_golden(golden, backend, upright):
     """env.self_obs_v = 2: the policy observation carries the v1 block of the past_track_steps = 5 previous body states and of the current one,
