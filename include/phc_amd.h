@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PHC_ABI_VERSION 28
+#define PHC_ABI_VERSION 29
 #define PHC_MAX_BODIES 64   /* bodies (incl. extended reference bodies) per articulation; also the slot count of the model tables */
 #define PHC_EINVAL (-1)
 #define PHC_EUNSUPPORTED (-2)
@@ -91,6 +91,9 @@ typedef struct {
                                          body, use_world_frame False); nullable.  Written by phc_sim_step at the end of the step: the net
                                          ground-contact wrench on the body about its origin (PhysX's reading is closed: parity unpinned) */
     const int32_t* env_shape;         /* [N] shape block of each env (phc_model_t.num_shapes > 1); nullable = block 0 */
+    const float* pd_ref;              /* [N,D] env.res_action (humanoid_im.py:1094-1099): non-null = residual actions, pd_tar = pd_ref +
+                                         scale * action limited to the current joint position +- pi / 2; the caller passes the task's
+                                         ref_dof_pos (phc_im_buffers_t.ref_dof_pos, the reference pose of the next frame); nullable */
 } phc_sim_state_t;
 
 /* Solver parameters.  Replaces gymapi.SimParams as filled by parse_sim_params
@@ -231,6 +234,9 @@ typedef struct {
                                          humanoid.py:229-232,1621-1631); shifted by the post-physics launch, filled by the resets; nullable otherwise */
     const float* offset_rand;         /* [N,2] the caller's torch.rand draw for the random reference offsets of zero_out_far_train / cycle_motion_xp
                                          (row of the env; refreshed by the caller before every launch that may use it); nullable unless one is set */
+    const uint8_t* occl_mask;         /* [N, J] env.occl_training (humanoid_im.py:96-97,796-804,845-851,1081-1092,1180-1181): non-zero = the tracked body
+                                         (slot order) is occluded: its reference state in the task observation and its reference position in
+                                         the early-termination distance are the simulated ones; the caller keeps the mask; nullable */
 } phc_im_buffers_t;
 
 int32_t phc_abi_version(void);

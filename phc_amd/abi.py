@@ -53,8 +53,9 @@ def motion_lib_struct(frames, frame_stride, num_bodies, motion_lengths, motion_d
     return s
 
 
-def sim_state_struct(num_envs, root_states, dof_state, rigid_body_state, contact_force, dof_force, pd_target, force_sensor=None, env_shape=None):
+def sim_state_struct(num_envs, root_states, dof_state, rigid_body_state, contact_force, dof_force, pd_target, force_sensor=None, env_shape=None, pd_ref=None):
     s = L.SimState()
+    s.pd_ref = ptr(pd_ref)
     s.force_sensor = ptr(force_sensor)
     s.env_shape = ptr(env_shape)
     s.num_envs = int(num_envs)
@@ -175,8 +176,9 @@ def im_buffers_struct(progress_buf, reset_buf, terminate_buf, rew_buf, reward_ra
                       sampled_motion_ids, motion_start_times, motion_start_times_offset, global_offset,
                       ref_body_pos=None, ref_body_rot=None, ref_body_vel=None, ref_dof_pos=None,
                       cycle_counter=None, recovery_counter=None, point_goal=None, cycle_phase=None, reset_list=None, reset_count=None,
-                      reset_slot=0, offset_rand=None, body_state_hist=None):
+                      reset_slot=0, offset_rand=None, body_state_hist=None, occl_mask=None):
     b = L.ImBuffers()
+    b.occl_mask = ptr(occl_mask)
     b.offset_rand = ptr(offset_rand)
     b.body_state_hist = ptr(body_state_hist)
     b.reset_list, b.reset_count, b.reset_slot = ptr(reset_list), ptr(reset_count), int(reset_slot)

@@ -161,6 +161,17 @@ PHC_HD float zero_out_far_ref(const phc_im_params_t& prm, int slot, const BodySt
     return distance;
 }
 
+// env.occl_training (humanoid_im.py:796-804,845-851): the reference state of an occluded tracked body is replaced by the simulated one before the
+// task observation is formed -- all four fields for obs_v 4 / 5 / 6 / 8 / 9, the position (and the unused rotation) for obs_v 7
+PHC_HD bool occluded(const phc_im_buffers_t& buf, const phc_im_params_t& prm, int64_t env, int slot) {
+    return buf.occl_mask != nullptr && slot >= 0 && buf.occl_mask[env * prm.num_track_bodies + slot] != 0;
+}
+PHC_HD void occlude_ref(const phc_im_buffers_t& buf, const phc_im_params_t& prm, int64_t env, int slot, const BodyState& body, BodyState* rt) {
+    if (!occluded(buf, prm, env, slot) || (prm.obs_v >= 1 && prm.obs_v <= 3)) return;
+    if (prm.obs_v == 7) { rt->pos = body.pos; rt->rot = body.rot; }
+    else *rt = body;
+}
+
 // env.fut_tracks (humanoid_im.py:741-747): the blocks of the T - 1 further reference samples behind the standard one (obs_v 6 / 7 / 9 lay the
 // samples out time-major: one standard block each)
 PHC_HD void task_obs_future_lane(const phc_motion_lib_t& lib, const phc_im_params_t& prm, int64_t mid, int64_t progress1, float start, float start_off,
@@ -221,6 +232,7 @@ PHC_HD RewardPartial im_post_lane(const phc_model_t& model, const phc_motion_lib
         rp.root_dist = norm(body.pos - r0.pos);  // humanoid_im.py:892
     }
     if (prm.track_body_reward && prm.track_slot[j] < 0) rp.pos = rp.rot = rp.vel = rp.angvel = 0.f;   // full_body_reward False (:925-936)
+    if (occluded(buf, prm, env, prm.track_slot[j])) { rp.dist = 0.f; rp.fallen = 0; }   // _compute_reset: ref = body for occluded bodies (:1180-1181)
     // R2 power partial: sum |tau * qdot| over this body's joint (humanoid_im.py:939-946)
     if (prm.power_reward && j >= 1) {
         int ds = model.ints[4 + 3 * PHC_MAX_BODIES + j];
@@ -244,6 +256,7 @@ PHC_HD RewardPartial im_post_lane(const phc_model_t& model, const phc_motion_lib
             const float dist = zero_out_far_ref(prm, slot, body, root, rroot, &rt);
             if (j == 0 && buf.point_goal) buf.point_goal[env] = dist;  // :792
         }
+        occlude_ref(buf, prm, env, slot, body, &rt);
         V3 jd = v3(0.f, 0.f, 0.f), jv, rjd = jd, rjv;
         if (prm.obs_v == 2 && j >= 1) {   // humanoid_im.py:775-778: the joint of a tracked body, simulator vs reference at t + dt
             ld_joint_state(sim, nd, env, model.ints[4 + 3 * PHC_MAX_BODIES + j], prm.dofs_per_joint, &jd, &jv);
@@ -381,6 +394,7 @@ PHC_HD void im_reset_lane(const phc_model_t& model, const phc_motion_lib_t& lib,
                 const float dist = zero_out_far_ref(prm, slot, rs, root, rroot, &rt);
                 if (j == 0 && buf.point_goal) buf.point_goal[env] = dist;
             }
+            occlude_ref(buf, prm, env, slot, rs, &rt);
             V3 jd = v3(0.f, 0.f, 0.f), jv, rjd = jd, rjv;
             if (prm.obs_v == 2 && j >= 1) { ref_joint(lib, fr, j, &jd, &jv); ref_joint(lib, fr1, j, &rjd, &rjv); }   // (the imposed state is the reference at t)
             task_obs_lane(prm, slot, rs, root, rt, hinv, h, obs + prm.num_self_obs, &jd, &rjd);
@@ -448,6 +462,7 @@ PHC_HD void im_reset_from_state_lane(const phc_model_t& model, const phc_motion_
                 const float dist = zero_out_far_ref(prm, slot, body, root, rroot, &rt);
                 if (j == 0 && buf.point_goal) buf.point_goal[env] = dist;
             }
+            occlude_ref(buf, prm, env, slot, body, &rt);
             V3 jd = v3(0.f, 0.f, 0.f), jv, rjd = jd, rjv;
             if (prm.obs_v == 2 && j >= 1) {
                 ld_joint_state(sim, nd, env, model.ints[4 + 3 * PHC_MAX_BODIES + j], prm.dofs_per_joint, &jd, &jv);

@@ -31,6 +31,23 @@ extern "C" int32_t phc_debug_profile(unsigned long long* out16, int32_t reset) {
 #define PHC_PROF_FLUSH
 #endif
 
+// A2: pd_tar = offset + scale * action (humanoid.py:1711-1713); env.res_action (sim.pd_ref set): reference joint position + scale * action,
+// kept within pi / 2 of the current joint position (humanoid_im.py:1094-1099); frozen DoFs -> 0 (humanoid.py:1549-1554)
+__device__ __forceinline__ float pd_target_of(const phc_sim_state_t& sim, const float* __restrict__ actions, const float* __restrict__ pd_off,
+                                              const float* __restrict__ pd_scale, const int32_t* __restrict__ freeze, int64_t env, int nd, int d) {
+    const float sa = __fmul_rn(pd_scale[d], actions[env * nd + d]);
+    float t;
+    if (sim.pd_ref != nullptr) {
+        const float q = sim.dof_state[(env * nd + d) * 2];
+        const float half_pi = 1.57079637f;   // float32(np.pi / 2)
+        t = fmaxf(fminf(__fadd_rn(sim.pd_ref[env * nd + d], sa), __fadd_rn(q, half_pi)), __fsub_rn(q, half_pi));
+    } else {
+        t = __fadd_rn(pd_off[d], sa);
+    }
+    if (freeze != nullptr && freeze[d]) t = 0.f;
+    return t;
+}
+
 
 // ------------------------------------------------------------------------------------------
 // Staged epilogue (round 2).  The phase profile of the two-slot kernel (scripts/sim_phase_profile.py, profiles/r02_notes.md) put
@@ -122,12 +139,9 @@ __global__ __launch_bounds__(64, 2) void k_sim_step(phc_model_t model_all, phc_s
         aba_load_model(L, model, lane);
         if (JT == PHC_JT_REVOLUTE) aba_load_model_rev(L, model, lane);
         if (STEP && actions != nullptr && lane >= 1) {
-            // A2: pd_tar = offset + scale * action, frozen DoFs -> 0 (humanoid.py:1711-1713,1549-1554)
             for (int k = 0; k < (JT == PHC_JT_REVOLUTE ? 1 : 3); ++k) {
                 const int d = L.dof_start + k;
-                float t = __fadd_rn(pd_off[d], __fmul_rn(pd_scale[d], actions[env * nd + d]));
-                if (freeze != nullptr && freeze[d]) t = 0.f;
-                sim.pd_target[env * nd + d] = t;
+                sim.pd_target[env * nd + d] = pd_target_of(sim, actions, pd_off, pd_scale, freeze, env, nd, d);
             }
         }
         aba_load_state<JT>(L, sim, nd, env, lane);
@@ -218,11 +232,9 @@ __global__ __launch_bounds__(64, 1) void k_sim_step16(phc_model_t model_all, phc
         aba_load_model(L, model, j);
         if (JT == PHC_JT_REVOLUTE) aba_load_model_rev(L, model, j);
         if (actions != nullptr && j >= 1) {
-            for (int k = 0; k < ndj; ++k) {  // A2: pd_tar = offset + scale * action, frozen DoFs -> 0 (humanoid.py:1711-1713,1549-1554)
+            for (int k = 0; k < ndj; ++k) {
                 const int d = L.dof_start + k;
-                float t = __fadd_rn(pd_off[d], __fmul_rn(pd_scale[d], actions[env * nd + d]));
-                if (freeze != nullptr && freeze[d]) t = 0.f;
-                sim.pd_target[env * nd + d] = t;
+                sim.pd_target[env * nd + d] = pd_target_of(sim, actions, pd_off, pd_scale, freeze, env, nd, d);
             }
         }
         aba_load_state<JT>(L, sim, nd, env, j);

@@ -84,7 +84,7 @@ class HumanoidIm:
         if self.humanoid_type not in ("smpl", "h1", "g1"):
             raise NotImplementedError(f"humanoid_type={self.humanoid_type!r}: built so far: smpl, h1, g1")
         self._is_robot = self.humanoid_type in ("h1", "g1")
-        unsupported = dict(fut_tracks_dropout=False, occl_training=False, res_action=False,
+        unsupported = dict(fut_tracks_dropout=False,
                            kin_loss=False, z_readout=False, distill=False)
         for k, off in unsupported.items():
             v = env.get(k, robot.get(k, off))
@@ -450,6 +450,22 @@ class HumanoidIm:
         self.ref_body_vel = torch.zeros((N, NB, 3), **f32)
         self.ref_body_rot = torch.zeros((N, NB, 4), **f32)
         self.ref_dof_pos = torch.zeros((N, D), **f32)
+        # env.occl_training (humanoid.py:324-325, humanoid_im.py:96-97): per-env occlusion of tracked bodies, read by the task kernels
+        self._occl_training = bool(env.get("occl_training", False))
+        self._occl_training_prob = float(env.get("occl_training_prob", 0.1))
+        self._occl_mask = None
+        if self._occl_training:
+            if list(self._track_bodies) != list(self._body_names) or self._num_traj_samples > 1:
+                raise NotImplementedError("occl_training: the reference indexes the mask by body id and by env row (humanoid_im.py:800,1181): "
+                                          "full-body tracking, without fut_tracks")
+            J = len(self._track_bodies)
+            self.random_occlu_idx = torch.zeros((N, J), dtype=torch.bool, device=dev)
+            self.random_occlu_count = torch.zeros((N, J), **i64)
+            self._occl_mask = torch.zeros((N, J), dtype=torch.uint8, device=dev)
+        # env.res_action (humanoid.py:327, humanoid_im.py:1094-1099): actions are residuals on the reference pose of the next frame
+        self._res_action = bool(env.get("res_action", False))
+        if self._res_action:
+            self._sim_struct.pd_ref = abi.ptr(self.ref_dof_pos)
         self.ref_motion_cache = {}
         self._tab = [torch.from_numpy(t).to(dev) for t in (track_slot, reset_mask, key_ids, amp_slot)]
         self._n_amp_joints = n_amp_joints
@@ -492,7 +508,7 @@ class HumanoidIm:
                                      cycle_counter=self._cycle_counter, recovery_counter=self._recovery_counter,
                                      point_goal=self._point_goal, cycle_phase=self._cycle_phase, reset_list=self._reset_list,
                                      reset_count=self._reset_count, reset_slot=self._reset_slot, offset_rand=self._offset_rand,
-                                     body_state_hist=self._body_state_hist)
+                                     body_state_hist=self._body_state_hist, occl_mask=self._occl_mask)
 
     @property
     def _amp_obs_buf(self):
@@ -652,6 +668,20 @@ class HumanoidIm:
             self.actions = self.actions[None]
         if self.control_mode == "pd":
             self.actions = torch.clip(self.actions, -10, 10)   # humanoid.py:1568-1570
+        if self._occl_training:   # humanoid_im.py:1112-1113
+            self._update_occl_training()
+
+    def _update_occl_training(self):
+        """humanoid_im.py:1081-1092: occlusion spans of 30-59 steps start with probability occl_training_prob per tracked body and step (never the
+        root) -- and then the reference overwrites the mask: bodies 0..8 occluded, 9..23 visible (:1091-1092).  Both kept, in that order."""
+        start = torch.bernoulli(torch.full_like(self.random_occlu_count, self._occl_training_prob, dtype=torch.float32)).bool()
+        start[:, 0] = False
+        spans = torch.randint(30, 60, self.random_occlu_count.shape, device=self.device)
+        self.random_occlu_count = torch.clamp_min(torch.where(start, spans, self.random_occlu_count) - 1, 0)
+        self.random_occlu_idx = self.random_occlu_count > 0
+        self.random_occlu_idx[:] = True
+        self.random_occlu_idx[:, 9:24] = False
+        self._occl_mask.copy_(self.random_occlu_idx)
 
     def _physics_step(self):
         a = self.actions.contiguous()

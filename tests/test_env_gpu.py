@@ -867,3 +867,48 @@ def test_fut_tracks_env_samples_future_reference_frames(obs_v):
         torch.cuda.synchronize()
         np.testing.assert_allclose(o[:, so + k * blk:so + (k + 1) * blk].cpu().numpy()[keep], task1.obs_buf[:, so:].cpu().numpy()[keep], atol=2e-4)
         task1._motion_start_times.copy_(task._motion_start_times)
+
+
+def test_res_action_targets_are_residuals_on_the_reference_pose():
+    """env.res_action (humanoid_im.py:1094-1099): pd_tar = ref_dof_pos + scale * action, limited to the current joint position +- pi / 2, where
+    ref_dof_pos is the reference pose the last observation was computed against; bit-exact against the same torch expression."""
+    N = 64
+    task, env = make_task(N, motion="synthetic:3:1", **{"+env.res_action": True})
+    env.reset()
+    ref = task.ref_dof_pos.clone()
+    q = task._dof_state.view(N, -1, 2)[..., 0].clone()
+    assert ref.abs().max() > 0.05
+    torch.manual_seed(3)
+    a = 4 * torch.randn(N, task.get_action_size(), device=task.device)     # large enough for the +- pi / 2 window to bind
+    env.step(a)
+    want = torch.maximum(torch.minimum(ref + task._pd_action_scale * a, q + np.pi / 2), q - np.pi / 2)
+    assert torch.equal(task._pd_target, want)
+    bound = (want == q + np.pi / 2) | (want == q - np.pi / 2)
+    assert 0.02 < bound.float().mean() < 0.98
+    # the plain map on the same state for contrast
+    task0, env0 = make_task(N, motion="synthetic:3:1")
+    env0.reset()
+    env0.step(a)
+    assert torch.equal(task0._pd_target, task0._pd_action_offset + task0._pd_action_scale * a)
+
+
+def test_occl_training_env_masks_the_lower_body_reference():
+    """env.occl_training end to end: after the first step the mask the reference ends up with (bodies 0..8, humanoid_im.py:1091-1092) is in force:
+    the position / velocity differences of those bodies in the v6 task block are exactly zero, the other bodies' columns are the plain env's."""
+    N, J = 64, 24
+    task, env = make_task(N, motion="synthetic:3:1", **{"+env.occl_training": True})
+    task0, env0 = make_task(N, motion="synthetic:3:1")
+    so = task.get_self_obs_size()
+    o, o0 = env.reset(), env0.reset()
+    assert torch.equal(o, o0)                                     # the mask starts empty (:96)
+    act = torch.zeros(N, task.get_action_size(), device=task.device)
+    o, _, done, _ = env.step(act)
+    o0, _, done0, _ = env0.step(act)
+    assert task._occl_mask[:, :9].all() and not task._occl_mask[:, 9:].any()
+    keep = (done == 0) & (done0 == 0)
+    assert keep.sum() > N // 2
+    t, t0 = o[keep][:, so:], o0[keep][:, so:]
+    # v6 layout: dpos 3J | drot 6J | dvel 3J | dangvel 3J | local ref pos 3J | local ref rot 6J
+    assert (t[:, :27] == 0).all() and (t[:, 9 * J:9 * J + 27] == 0).all() and (t0[:, :27].abs().max() > 1e-4)
+    assert torch.equal(t[:, 27:3 * J], t0[:, 27:3 * J]) and torch.equal(t[:, 15 * J + 27:18 * J], t0[:, 15 * J + 27:18 * J])
+    assert torch.equal(task.rew_buf, task0.rew_buf)               # the reward sees the true reference

@@ -252,6 +252,39 @@ def test_task_obs_fut_tracks_vs_reference_golden(golden, backend, obs_v, upright
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("obs_v,mask,use_mean", [(6, "fixed", False), (6, "random", True), (7, "random", False), (8, "fixed", True), (8, "random", False)])
+def test_occlusion_mask_vs_reference_golden(golden, backend, obs_v, mask, use_mean):
+    """env.occl_training: occluded tracked bodies take the simulated state as their reference in the task observation (obs_v 6 / 8: all fields,
+    7: position) and in the early-termination distance (humanoid_im.py:796-804,845-851,1180-1181; oracle/gen_golden_occl.py); reward untouched."""
+    be = get_backend(backend)
+    g, go, gl = golden("task_fns"), golden("task_occl"), golden("motion_lib_eval")
+    model, mstruct, keepm = model_on(be)
+    lib, keep = motion_lib_on(be, gl)
+    N = g["body_pos"].shape[0]
+    want = go[f"v{obs_v}_{mask}"]
+    prm, keepp = make_im_params(be, model, N, obs_v=obs_v, use_mean=use_mean)
+    prm.num_task_obs = want.shape[1]
+    td = be.arr(np.full(64, go["term_dist"][int(use_mean)], dtype=F))
+    prm.termination_distances = abi.ptr(td)
+    arrs, sim = _sim_arrays(be, g, N)
+    amp_in, amp_out = be.zeros((N, 10, 196)), be.zeros((N, 10, 196))
+    occl = be.arr(go[f"mask_{mask}"].astype(np.uint8))
+    b = dict(progress=be.arr((g["progress"] - 1).astype(np.int64)), reset=be.zeros(N, np.int64), term=be.zeros(N, np.int64), rew=be.zeros(N),
+             raw=be.zeros((N, 5)), obs=be.zeros((N, 358 + want.shape[1])), mids=be.arr(g["env_motion"].astype(np.int64)),
+             st=be.arr(g["start_times"].astype(F)), so=be.zeros(N), goff=be.zeros((N, 3)))
+    buf = abi.im_buffers_struct(b["progress"], b["reset"], b["term"], b["rew"], b["raw"], b["obs"], amp_in, amp_out, b["mids"], b["st"],
+                                b["so"], b["goff"], occl_mask=occl)
+    assert be.im_post_physics(mstruct, lib, prm, sim, buf) == 0
+    be.sync()
+    obs = be.np(b["obs"])
+    np.testing.assert_allclose(obs[:, 358:], want, atol=2e-5)
+    np.testing.assert_allclose(obs[:, :358], g["self_obs"], atol=1e-5)
+    np.testing.assert_array_equal(be.np(b["term"]), go[f"terminate_{mask}_mean{int(use_mean)}"])
+    np.testing.assert_array_equal(be.np(b["reset"]), go[f"reset_{mask}_mean{int(use_mean)}"])
+    np.testing.assert_allclose(be.np(b["rew"]), g["reward"] + g["power_reward"], atol=1e-5)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
 @pytest.mark.parametrize("upright", [True, False])
 def test_self_obs_v2_history_vs_reference_golden(golden, backend, upright):
     """env.self_obs_v = 2: the policy observation carries the v1 block of the past_track_steps = 5 previous body states and of the current one,
