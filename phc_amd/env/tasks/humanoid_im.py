@@ -711,6 +711,7 @@ class HumanoidIm:
         L.check(self._lib.phc_im_post_physics(self._model_struct, self._motion_lib.struct, self._im_params, self._sim_struct, buf,
                                               _stream()), "phc_im_post_physics")
         self._amp_cur = 1 - self._amp_cur
+        self._obs_noise()
         self.extras["terminate"] = self._terminate_buf         # humanoid.py:1649-1650
         self.extras["reward_raw"] = self.reward_raw.detach()
         self.extras["amp_obs"] = self._amp_obs_buf.view(-1, self.get_num_amp_obs())  # humanoid_amp.py:208-209
@@ -747,6 +748,7 @@ class HumanoidIm:
         buf = self._buffers(cur, cur)
         L.check(self._lib.phc_im_reset(self._model_struct, self._motion_lib.struct, self._im_params, self._sim_struct, buf, n,
                                        env_ids.data_ptr(), abi.ptr(phase), int(bool(start_at_zero)), _stream()), "phc_im_reset")
+        self._obs_noise(env_ids)
         self._reset_ref_env_ids = env_ids
         self._reset_ref_motion_ids = self._sampled_motion_ids[env_ids]
         self._reset_ref_motion_times = self._motion_start_times[env_ids]
@@ -771,6 +773,19 @@ class HumanoidIm:
         if use_list:
             self._reset_slot = (self._reset_slot + 1) % 3   # the kernel zeroed that counter for the next post-physics launch
             self._reset_list_pending = False
+        self._obs_noise(reset_rows=True)
+
+    def _obs_noise(self, env_ids=None, reset_rows=False):
+        """env.add_obs_noise (humanoid_im.py:710-711): N(0, 0.1) on every freshly computed observation row, not in test mode.  Rows: all (the
+        step), `env_ids` (reset(env_ids)) or the rows whose reset flag is set (reset_done: a masked add, no device -> host sync)."""
+        if not self.add_obs_noise or flags.test:
+            return
+        if env_ids is not None:
+            self.obs_buf[env_ids] += torch.randn((len(env_ids), self.obs_buf.shape[1]), device=self.device) * 0.1
+        elif reset_rows:
+            self.obs_buf.addcmul_(torch.randn_like(self.obs_buf), (self.reset_buf != 0).to(self.obs_buf.dtype)[:, None], value=0.1)
+        else:
+            self.obs_buf.add_(torch.randn_like(self.obs_buf), alpha=0.1)
 
     # ------------------------------------------------------------------ AMP demo observations (humanoid_amp.py:215-284)
     def fetch_amp_obs_demo(self, num_samples):

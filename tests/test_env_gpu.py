@@ -917,3 +917,39 @@ def test_occl_training_env_masks_the_lower_body_reference():
     assert (t[:, :27] == 0).all() and (t[:, 9 * J:9 * J + 27] == 0).all() and (t0[:, :27].abs().max() > 1e-4)
     assert torch.equal(t[:, 27:3 * J], t0[:, 27:3 * J]) and torch.equal(t[:, 15 * J + 27:18 * J], t0[:, 15 * J + 27:18 * J])
     assert torch.equal(task.rew_buf, task0.rew_buf)               # the reward sees the true reference
+
+
+def test_add_obs_noise_perturbs_every_fresh_observation_row_once():
+    """env.add_obs_noise (humanoid_im.py:710-711): the observation is the clean one + N(0, 0.1) per element -- on the step's rows and on reset
+    rows alike -- and nothing is added in test mode."""
+    from phc_amd.utils.flags import flags
+    N = 256
+    task, env = make_task(N, motion="synthetic:3:1", **{"env.add_obs_noise": True})
+    task0, env0 = make_task(N, motion="synthetic:3:1")
+    torch.manual_seed(11)
+    o = env.reset()
+    torch.manual_seed(11)
+    o0 = env0.reset()
+    d = (o - o0).flatten()
+    assert abs(float(d.std()) - 0.1) < 0.003 and abs(float(d.mean())) < 0.002      # reset(env_ids) rows
+    act = torch.zeros(N, task.get_action_size(), device=task.device)
+    task.step(act); task0.step(act)
+    d = (task.obs_buf - task0.obs_buf).flatten()
+    assert abs(float(d.std()) - 0.1) < 0.003                                          # the step's rows
+    done = task.reset_buf != 0
+    assert torch.equal(task.reset_buf, task0.reset_buf) and 0 < int(done.sum()) < N
+    before = task.obs_buf.clone()
+    task.reset_done()
+    assert torch.equal(task.obs_buf[~done], before[~done])                           # only the reset rows change ...
+    task0.reset_done()
+    d = (task.obs_buf - task0.obs_buf)[done]                                         # ... (same hash-drawn start phases in both envs)
+    assert abs(float(d.std()) - 0.1) < 0.01
+    flags.test = True
+    try:
+        torch.manual_seed(5)
+        o = env.reset()
+        torch.manual_seed(5)
+        o0 = env0.reset()
+        assert torch.equal(o, o0)
+    finally:
+        flags.test = False
