@@ -780,12 +780,16 @@ class HumanoidIm:
         step), `env_ids` (reset(env_ids)) or the rows whose reset flag is set (reset_done: a masked add, no device -> host sync)."""
         if not self.add_obs_noise or flags.test:
             return
+        if getattr(self, "_obs_noise_rng", None) is None:   # own stream: switching the noise on leaves every other draw of the run as it was
+            self._obs_noise_rng = torch.Generator(device=self.device)
+            self._obs_noise_rng.manual_seed((int(torch.initial_seed()) + 0x6E6F6973) & 0x7FFFFFFFFFFFFFFF)
+        draw = lambda rows: torch.randn((rows, self.obs_buf.shape[1]), device=self.device, generator=self._obs_noise_rng)
         if env_ids is not None:
-            self.obs_buf[env_ids] += torch.randn((len(env_ids), self.obs_buf.shape[1]), device=self.device) * 0.1
+            self.obs_buf[env_ids] += draw(len(env_ids)) * 0.1
         elif reset_rows:
-            self.obs_buf.addcmul_(torch.randn_like(self.obs_buf), (self.reset_buf != 0).to(self.obs_buf.dtype)[:, None], value=0.1)
+            self.obs_buf.addcmul_(draw(self.num_envs), (self.reset_buf != 0).to(self.obs_buf.dtype)[:, None], value=0.1)
         else:
-            self.obs_buf.add_(torch.randn_like(self.obs_buf), alpha=0.1)
+            self.obs_buf.add_(draw(self.num_envs), alpha=0.1)
 
     # ------------------------------------------------------------------ AMP demo observations (humanoid_amp.py:215-284)
     def fetch_amp_obs_demo(self, num_samples):
