@@ -84,8 +84,9 @@ class HumanoidIm:
         if self.humanoid_type not in ("smpl", "h1", "g1"):
             raise NotImplementedError(f"humanoid_type={self.humanoid_type!r}: built so far: smpl, h1, g1")
         self._is_robot = self.humanoid_type in ("h1", "g1")
-        unsupported = dict(fut_tracks_dropout=False,
-                           kin_loss=False, z_readout=False, distill=False)
+        # options of the reference this path does not build: refuse them rather than run without them
+        unsupported = dict(fut_tracks_dropout=False, kin_loss=False, z_readout=False, distill=False, enableHistObs=False, remove_disc_rot=False,
+                           divide_group=False, group_obs=False, add_action_noise=False, is_discrete=False)
         for k, off in unsupported.items():
             v = env.get(k, robot.get(k, off))
             if v != off:
@@ -160,6 +161,7 @@ class HumanoidIm:
         self.auto_pmcp_soft = env.get("auto_pmcp_soft", False)
         self.strict_eval = env.get("strict_eval", False)
         self.add_obs_noise = env.get("add_obs_noise", False)
+        self._add_amp_input_noise = bool(env.get("add_amp_input_noise", False))   # humanoid_amp.py:135
         self.start_idx = env.get("start_idx", 0)
         self.seq_motions = env.get("seq_motions", False)
         self.collect_dataset = cfg.get("collect_dataset", False)
@@ -801,6 +803,8 @@ class HumanoidIm:
         motion_ids = self._motion_lib.sample_motions(num_samples)
         motion_times0 = self._motion_lib.sample_time_interval(motion_ids)
         self.build_amp_obs_demo(motion_ids, motion_times0, out=self._amp_obs_demo_buf)
+        if self._add_amp_input_noise:   # humanoid_amp.py:281-282
+            self._amp_obs_demo_buf.add_(torch.randn_like(self._amp_obs_demo_buf), alpha=0.01)
         return self._amp_obs_demo_buf.view(-1, self.get_num_amp_obs())
 
     def build_amp_obs_demo(self, motion_ids, motion_times0, out=None):
