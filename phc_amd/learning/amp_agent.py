@@ -223,6 +223,9 @@ class IMAmpAgent:
         self.bf16 = bf16 and str(self.device).startswith("cuda")
         self.num_actors = vec_env.num_envs
         self.horizon_length = c["horizon_length"]
+        # rl_games' A2CBase.preprocess_actions (a dependency of the reference, not vendored; common_agent.py:47 reads the switch): the env gets
+        # the sampled action clamped to the action space [-1, 1]; the experience buffer keeps the unclamped sample
+        self.clip_actions = bool(c.get("clip_actions", True))
         self.batch_size = self.horizon_length * self.num_actors
         self.minibatch_size = min(c["minibatch_size"], self.batch_size)
         assert self.batch_size % self.minibatch_size == 0
@@ -350,6 +353,13 @@ class IMAmpAgent:
         return self._amp_input_mean_std(amp_obs, out_dtype=torch.bfloat16 if self.bf16 else None, row_index=row_index)
 
     # ------------------------------------------------------------------ rollout (amp_agent.py:309-397)
+    def preprocess_actions(self, actions, out=None):
+        """What the env is stepped with (rl_games a2c_common.preprocess_actions; players: im_amp.py:68-74): clamp to [-1, 1] and rescale to the
+        action space -- the identity here, VecTask's space is Box(-1, 1)."""
+        if not self.clip_actions:
+            return actions
+        return torch.clamp(actions, -1.0, 1.0, out=out)
+
     def get_action_values(self, obs):
         processed = self._preproc_obs(obs)
         with torch.no_grad(), self._autocast():
@@ -399,6 +409,7 @@ class IMAmpAgent:
             self._terminated_flags = torch.zeros(self.num_actors, device=self.device)
             self._reward_raw_acc = None
             self._roll_graphs = {}
+            self._env_actions = torch.empty_like(self.exp["actions"][0])
         terminated_flags = self._terminated_flags.zero_()
         if self._reward_raw_acc is not None:
             self._reward_raw_acc.zero_()
@@ -418,6 +429,8 @@ class IMAmpAgent:
                 value = net.eval_critic(processed)
             policy_sample(mu.contiguous(), value.contiguous(), (logstd[0] if logstd.dim() == 2 else logstd).float().contiguous(), vnorm,
                           e["actions"][n], e["mus"][n], e["sigmas"][n], e["neglogpacs"][n], e["values"][n])
+            if self.clip_actions:
+                self.preprocess_actions(e["actions"][n], out=self._env_actions)
 
         def seg_after(n, rewards, terminate, reward_raw):
             """(B) the step's outputs into row n, next-value critic (zeroed where the episode terminated), episode bookkeeping."""
@@ -463,13 +476,14 @@ class IMAmpAgent:
                     self._replay(("policy", n, self.obs.data_ptr()), lambda: seg_policy(n))
                 else:
                     seg_policy(n)
-                res = {"actions": e["actions"][n]}
+                res = {"actions": self._env_actions if self.clip_actions else e["actions"][n]}
             else:
                 if self.obs.data_ptr() != e["obses"][n].data_ptr():
                     e["obses"][n].copy_(self.obs)
                 res = self.get_action_values(self.obs)
                 for k in ("values", "neglogpacs", "actions", "mus", "sigmas"):
                     e[k][n].copy_(res[k])
+                res = {"actions": self.preprocess_actions(res["actions"])}
             self.obs, rewards, self.dones, infos = self.vec_env.step(res["actions"])
             rewards = rewards.unsqueeze(1) if rewards.dim() == 1 else rewards
             e["amp_obs"][n].copy_(infos["amp_obs"])   # (eager: the task's AMP buffer is a ping-pong pair, its address alternates)

@@ -69,7 +69,7 @@ def evaluate(agent, output_dir=None, log=print):
                 curr = 0
                 while True:
                     res = agent.get_action_values(obs)
-                    obs, r, done, info = env.step(res["mus"])  # deterministic policy (is_determenistic=True)
+                    obs, r, done, info = env.step(agent.preprocess_actions(res["mus"]))  # deterministic policy (is_determenistic=True)
                     # a termination after the clip's last frame is not a failure (im_amp.py:248)
                     term = torch.logical_and(torch.as_tensor(curr <= num_steps - 1, device=task.device), info["terminate"].bool())
                     terminate_state |= term

@@ -80,7 +80,7 @@ def play(agent, task, env, steps=300):
     lens, rews = [], []
     with torch.no_grad():
         for _ in range(steps):
-            obs, r, done, info = env.step(agent.get_action_values(obs)["mus"])
+            obs, r, done, info = env.step(agent.preprocess_actions(agent.get_action_values(obs)["mus"]))
             rew_sum += r
             ep_len += 1
             ids = done.nonzero(as_tuple=False).flatten()

@@ -55,7 +55,7 @@ def main():
     with torch.no_grad():
         for t in range(n_steps):
             res = agent.get_action_values(obs)
-            obs, r, done, info = env.step(res["mus"])
+            obs, r, done, info = env.step(agent.preprocess_actions(res["mus"]))
             alive &= ~info["terminate"].bool()
             survived += alive.float()
             rr = info["reward_raw"][alive].mean(0) if alive.any() else torch.zeros(info["reward_raw"].shape[1], device=task.device)

@@ -396,3 +396,26 @@ def test_checkpoint_optimizer_state_is_per_parameter_and_loads_plain_adam_checkp
     # players do not touch the optimizer
     fresh.restore(path, load_optimizer=False)
     assert len(fresh.optimizer.state) == 0 and torch.equal(fresh.grads.flat_param, agent.grads.flat_param)
+
+
+@pytest.mark.parametrize("clip", [True, False])
+def test_env_is_stepped_with_clamped_actions_and_the_buffer_keeps_the_samples(clip):
+    """rl_games' A2CBase.env_step -> preprocess_actions (clip_actions, default True; common_agent.py:47): the env sees clamp(action, -1, 1) (the
+    action space is Box(-1, 1): the rescale is the identity) while the experience buffer -- and so the PPO ratio -- keeps the raw sample."""
+    torch.manual_seed(0)
+    env = FakeVecEnv(32)
+    cfg = small_cfg()
+    cfg["learning"]["params"]["config"]["clip_actions"] = clip
+    agent = IMAmpAgent(env, cfg, bf16=False)
+    agent.init_train()
+    with torch.no_grad():
+        agent.model.a2c_network.mu.bias.add_(1.5)    # push the policy mean outside the action space
+    seen = []
+    step = env.step
+    env.step = lambda a: (seen.append(a.clone()), step(a))[1]
+    agent.play_steps()
+    raw = agent.exp["actions"]
+    assert len(seen) == 8 and float(raw.abs().max()) > 1.2
+    for n, a in enumerate(seen):
+        assert torch.equal(a, raw[n].clamp(-1, 1) if clip else raw[n])
+    assert torch.equal(agent.preprocess_actions(torch.tensor([-3.0, 0.25, 2.0])), torch.tensor([-1.0, 0.25, 1.0]) if clip else torch.tensor([-3.0, 0.25, 2.0]))
