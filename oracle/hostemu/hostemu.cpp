@@ -55,7 +55,9 @@ static int emu_sim_step_t(const phc_model_t* model_all, const phc_sim_params_t* 
                 }
                 for (int j = 0; j < nb; ++j) aba_body_init<JT>(L[j], *model, *prm, dt, j, s % prm->substeps == 0);
                 for (int l = ml; l >= 0; --l) for (int j = 0; j < nb; ++j) aba_backward_level<JT>(L[j], l, j, x);
-                for (int l = 0; l <= ml; ++l) for (int j = 0; j < nb; ++j) aba_forward_level<JT>(L[j], l, j, x, *prm, dt);
+                for (int l = 0; l <= ml; ++l) for (int j = 0; j < nb; ++j) aba_accel_level<JT>(L[j], l, j, x);
+                for (int j = 0; j < nb; ++j) aba_integrate_joint<JT>(L[j], *prm, dt);
+                for (int l = 0; l <= ml; ++l) for (int j = 0; j < nb; ++j) aba_fk_level(L[j], l, j, x);
             }
         }
         for (int j = 0; j < nb; ++j) {

@@ -114,6 +114,11 @@ struct AbaLane {
     // --- articulated quantities kept between the sweeps ---
     Inertia6 IA; Force6 pA;
     Sym3 Di; V3 u;    // D^-1 and tau_w - p_omega
+    // world-frame joint-drive terms, rotated ONCE per sub-step in aba_body_init (the backward level-step is issued once per tree level):
+    Sym3 Dw;          // R diag(dimp + arm) R^T (spherical)
+    float diso;       // >= 0: the three entries of dimp + arm are equal (Dw = diso * 1, no rotation needed; true of every SMPL joint) -- else -1
+    V3 tau_w;         // R tau_local
+    V3 aw;            // R axis (revolute)
     V3 tau_local;     // explicit joint torque (child frame), for dof_force publication
     V3 dimp;          // implicit PD diagonal dt kd + dt^2 kp (WITHOUT the armature), child frame
     V3 arm;           // armature
@@ -335,6 +340,8 @@ PHC_HD void aba_body_init(AbaLane& L, const phc_model_t& m, const phc_sim_params
             }
             L.tau_local = L.axis * tau;
             L.dimp = v3(d, 0.f, 0.f);
+            L.aw = mat_mul(R, L.axis);
+            L.tau_w = L.aw * tau;
         }
         return;
     }
@@ -351,6 +358,10 @@ PHC_HD void aba_body_init(AbaLane& L, const phc_model_t& m, const phc_sim_params
         V3 d = v3(dt * kd.x + dt * dt * kp.x, dt * kd.y + dt * dt * kp.y, dt * kd.z + dt * dt * kp.z);
         L.tau_local = tau;
         L.dimp = d;
+        const V3 dd = d + L.arm;
+        if (dd.x == dd.y && dd.y == dd.z) { L.diso = dd.x; }
+        else { L.diso = -1.f; L.Dw = rot_diag(R, dd); }
+        L.tau_w = mat_mul(R, tau);
     }
 }
 
@@ -543,38 +554,56 @@ PHC_HD void aba_backward_level(AbaLane& L, int level, int j, const Xch& x) {
     for (int k = 0; k < 3; ++k)
         if (k < L.nchild) accumulate_child(L.IA, L.pA, xslot(x, L.child[k]), Xch::es);
     if (level == 0) return;
-    M3 R = quat_to_mat(L.Q);
     if (JT == PHC_JT_REVOLUTE) {
         // one free axis a (world): D = a^T A a + d is a scalar and D^-1 acts as the rank-1 matrix a a^T / D; with it the
         // spherical-joint expressions below hold unchanged (U D^-1 U^T removes exactly the a-component)
-        const V3 a = mat_mul(R, L.axis);
+        const V3 a = L.aw;
         const float ids = 1.0f / (dot(a, sym_mul(L.IA.A, a)) + L.dimp.x + L.arm.x);
         L.Di.xx = a.x * a.x * ids; L.Di.xy = a.x * a.y * ids; L.Di.xz = a.x * a.z * ids;
         L.Di.yy = a.y * a.y * ids; L.Di.yz = a.y * a.z * ids; L.Di.zz = a.z * a.z * ids;
-    } else {
-        Sym3 D = rot_diag(R, L.dimp + L.arm);
+    } else if (L.diso < 0.f) {
+        Sym3 D = L.Dw;
         D.xx += L.IA.A.xx; D.xy += L.IA.A.xy; D.xz += L.IA.A.xz; D.yy += L.IA.A.yy; D.yz += L.IA.A.yz; D.zz += L.IA.A.zz;
         L.Di = sym_inv(D);
     }
-    L.u = mat_mul(R, L.tau_local) - L.pA.n;
-    // G = Di A (3x3), H = Di B (3x3)
+    L.u = L.tau_w - L.pA.n;
     const Sym3& A = L.IA.A;
     const float* B = L.IA.B;
     V3 a0 = v3(A.xx, A.xy, A.xz), a1 = v3(A.xy, A.yy, A.yz), a2 = v3(A.xz, A.yz, A.zz);  // columns (=rows) of A
-    V3 g0 = sym_mul(L.Di, a0), g1 = sym_mul(L.Di, a1), g2 = sym_mul(L.Di, a2);         // columns of G
     V3 bc0 = v3(B[0], B[3], B[6]), bc1 = v3(B[1], B[4], B[7]), bc2 = v3(B[2], B[5], B[8]);  // columns of B
-    V3 h0 = sym_mul(L.Di, bc0), h1 = sym_mul(L.Di, bc1), h2 = sym_mul(L.Di, bc2);      // columns of H
     Inertia6 Ia;
-    // A_a = A - A G  (symmetric)
-    Ia.A.xx = A.xx - dot(a0, g0); Ia.A.xy = A.xy - dot(a0, g1); Ia.A.xz = A.xz - dot(a0, g2);
-    Ia.A.yy = A.yy - dot(a1, g1); Ia.A.yz = A.yz - dot(a1, g2); Ia.A.zz = A.zz - dot(a2, g2);
-    // B_a = B - A H : (A H)_{ij} = row_i(A) . h_j
-    Ia.B[0] = B[0] - dot(a0, h0); Ia.B[1] = B[1] - dot(a0, h1); Ia.B[2] = B[2] - dot(a0, h2);
-    Ia.B[3] = B[3] - dot(a1, h0); Ia.B[4] = B[4] - dot(a1, h1); Ia.B[5] = B[5] - dot(a1, h2);
-    Ia.B[6] = B[6] - dot(a2, h0); Ia.B[7] = B[7] - dot(a2, h1); Ia.B[8] = B[8] - dot(a2, h2);
-    // C_a = C - B^T H : (B^T H)_{ij} = col_i(B) . h_j
-    Ia.C.xx = L.IA.C.xx - dot(bc0, h0); Ia.C.xy = L.IA.C.xy - dot(bc0, h1); Ia.C.xz = L.IA.C.xz - dot(bc0, h2);
-    Ia.C.yy = L.IA.C.yy - dot(bc1, h1); Ia.C.yz = L.IA.C.yz - dot(bc1, h2); Ia.C.zz = L.IA.C.zz - dot(bc2, h2);
+    if (JT != PHC_JT_REVOLUTE && L.diso >= 0.f) {
+        // D = A + d 1 with a scalar d: A = D - d 1, so A P = 1 - d P (P = D^-1) and
+        //   A_a = A - A P A = d (A P) (symmetric) ;  B_a = B - A P B = d P B ;  C_a = C - B^T P B
+        // -- 39 multiply-adds fewer per level-step than the general expressions below
+        const float d = L.diso;
+        Sym3 D = A;
+        D.xx += d; D.yy += d; D.zz += d;
+        L.Di = sym_inv(D);
+        V3 p0 = v3(L.Di.xx, L.Di.xy, L.Di.xz), p1 = v3(L.Di.xy, L.Di.yy, L.Di.yz), p2 = v3(L.Di.xz, L.Di.yz, L.Di.zz);
+        Ia.A.xx = d * dot(a0, p0); Ia.A.xy = d * dot(a0, p1); Ia.A.xz = d * dot(a0, p2);
+        Ia.A.yy = d * dot(a1, p1); Ia.A.yz = d * dot(a1, p2); Ia.A.zz = d * dot(a2, p2);
+        V3 h0 = sym_mul(L.Di, bc0), h1 = sym_mul(L.Di, bc1), h2 = sym_mul(L.Di, bc2);      // columns of H = P B
+        Ia.B[0] = d * h0.x; Ia.B[1] = d * h1.x; Ia.B[2] = d * h2.x;
+        Ia.B[3] = d * h0.y; Ia.B[4] = d * h1.y; Ia.B[5] = d * h2.y;
+        Ia.B[6] = d * h0.z; Ia.B[7] = d * h1.z; Ia.B[8] = d * h2.z;
+        Ia.C.xx = L.IA.C.xx - dot(bc0, h0); Ia.C.xy = L.IA.C.xy - dot(bc0, h1); Ia.C.xz = L.IA.C.xz - dot(bc0, h2);
+        Ia.C.yy = L.IA.C.yy - dot(bc1, h1); Ia.C.yz = L.IA.C.yz - dot(bc1, h2); Ia.C.zz = L.IA.C.zz - dot(bc2, h2);
+    } else {
+        // G = Di A (3x3), H = Di B (3x3)
+        V3 g0 = sym_mul(L.Di, a0), g1 = sym_mul(L.Di, a1), g2 = sym_mul(L.Di, a2);         // columns of G
+        V3 h0 = sym_mul(L.Di, bc0), h1 = sym_mul(L.Di, bc1), h2 = sym_mul(L.Di, bc2);      // columns of H
+        // A_a = A - A G  (symmetric)
+        Ia.A.xx = A.xx - dot(a0, g0); Ia.A.xy = A.xy - dot(a0, g1); Ia.A.xz = A.xz - dot(a0, g2);
+        Ia.A.yy = A.yy - dot(a1, g1); Ia.A.yz = A.yz - dot(a1, g2); Ia.A.zz = A.zz - dot(a2, g2);
+        // B_a = B - A H : (A H)_{ij} = row_i(A) . h_j
+        Ia.B[0] = B[0] - dot(a0, h0); Ia.B[1] = B[1] - dot(a0, h1); Ia.B[2] = B[2] - dot(a0, h2);
+        Ia.B[3] = B[3] - dot(a1, h0); Ia.B[4] = B[4] - dot(a1, h1); Ia.B[5] = B[5] - dot(a1, h2);
+        Ia.B[6] = B[6] - dot(a2, h0); Ia.B[7] = B[7] - dot(a2, h1); Ia.B[8] = B[8] - dot(a2, h2);
+        // C_a = C - B^T H : (B^T H)_{ij} = col_i(B) . h_j
+        Ia.C.xx = L.IA.C.xx - dot(bc0, h0); Ia.C.xy = L.IA.C.xy - dot(bc0, h1); Ia.C.xz = L.IA.C.xz - dot(bc0, h2);
+        Ia.C.yy = L.IA.C.yy - dot(bc1, h1); Ia.C.yz = L.IA.C.yz - dot(bc1, h2); Ia.C.zz = L.IA.C.zz - dot(bc2, h2);
+    }
     // p_a = p^A + I^a c + U Di u,  U = [A; B^T]
     V3 du = sym_mul(L.Di, L.u);
     Force6 pa;
@@ -583,14 +612,14 @@ PHC_HD void aba_backward_level(AbaLane& L, int level, int j, const Xch& x) {
     shift_to_parent(Ia, pa, L.rw, xslot(x, j), Xch::es);
 }
 
-// ---- forward sweep, one tree level (root -> leaves): accelerations, semi-implicit Euler on this body's joint, and
-// the NEW kinematics (from the parent's new kinematics) in the same pass -- the separate integration step and the next
-// sub-step's kinematics sweep are folded in, so a sub-step is two sweeps.  Slot: alpha(3) a(3) | Q(4) p(3) w(3) v(3).
+// ---- forward sweep, part 1: spatial accelerations, one tree level (root -> leaves).  Slot [0..6): alpha(3) a(3) of the body.
+// Only what depends on the parent's acceleration is in the level-step (a level-step is issued once per tree level whatever the
+// number of lanes at that level: every instruction here costs max_level + 1 issues per sub-step).  The body's own result stays
+// in registers for part 2: the root's alpha -> L.u, a -> L.ca; a joint's world-frame angular acceleration beta -> L.u.
 template <int JT>
-PHC_HD void aba_forward_level(AbaLane& L, int level, int j, const Xch& x, const phc_sim_params_t& prm, float dt) {
+PHC_HD void aba_accel_level(AbaLane& L, int level, int j, const Xch& x) {
     if (L.level != level) return;
     constexpr int es = Xch::es;
-    const float damp = 1.0f / (1.0f + dt * prm.angular_damping);
     V3 alpha, a;
     if (level == 0) {
         // free root: [A B; B^T C] [alpha; a] = -[n; f]  by block elimination on C
@@ -608,12 +637,7 @@ PHC_HD void aba_forward_level(AbaLane& L, int level, int j, const Xch& x, const 
         V3 rhs = v3(-L.pA.n.x + dot(w0, L.pA.f), -L.pA.n.y + dot(w1, L.pA.f), -L.pA.n.z + dot(w2, L.pA.f));
         alpha = sym_mul(sym_inv(S), rhs);
         a = -sym_mul(Ci, L.pA.f + Bt_mul(B, alpha));
-        // integrate the root, new kinematics
-        L.v0 = L.v0 + a * dt;
-        L.w0 = (L.w0 + alpha * dt) * damp;
-        L.p0 = L.p0 + L.v0 * dt;
-        L.q = quat_normalize(quat_mul16(quat_from_rotvec(L.w0 * dt), L.q));
-        L.Q = L.q; L.p = L.p0; L.w = L.w0; L.v = L.v0;
+        L.u = alpha; L.ca = a;
     } else {
         const float* ps = xslot(x, L.parent);
         V3 alp = v3(ps[0 * es], ps[1 * es], ps[2 * es]), ap = v3(ps[3 * es], ps[4 * es], ps[5 * es]);
@@ -622,31 +646,46 @@ PHC_HD void aba_forward_level(AbaLane& L, int level, int j, const Xch& x, const 
         V3 beta = sym_mul(L.Di, L.u - sym_mul(L.IA.A, al1) - B_mul(L.IA.B, a1));  // world-frame joint angular acceleration
         alpha = al1 + beta;
         a = a1;
-        M3 R = quat_to_mat(L.Q);
-        V3 qdd = mat_tmul(R, beta);  // child-frame joint acceleration
-        if (JT == PHC_JT_REVOLUTE) {
-            const float thdd = dot(L.axis, qdd);
-            // torque actually applied over the step (explicit part minus the implicit augmentation), S5 -- kept in tau_local.x
-            L.tau_local = v3(dot(L.axis, L.tau_local) - L.dimp.x * thdd, 0.f, 0.f);
-            L.thd = (L.thd + thdd * dt) * damp;
-            L.thd = fminf(fmaxf(L.thd, -prm.max_angular_velocity), prm.max_angular_velocity);
-            L.th += L.thd * dt;
-            L.wj = L.axis * L.thd;
-            L.q = rev_joint_quat(L);
-        } else {
-            // torque actually applied over the step (explicit part minus the implicit augmentation), S5
-            L.tau_local = v3(L.tau_local.x - L.dimp.x * qdd.x, L.tau_local.y - L.dimp.y * qdd.y, L.tau_local.z - L.dimp.z * qdd.z);
-            L.wj = (L.wj + qdd * dt) * damp;
-            float wn = norm(L.wj);
-            if (wn > prm.max_angular_velocity) L.wj = L.wj * (prm.max_angular_velocity / wn);
-            L.q = quat_normalize(quat_mul16(L.q, quat_from_rotvec(L.wj * dt)));
-        }
-        aba_kinematics_from_parent(L, q4(ps[6 * es], ps[7 * es], ps[8 * es], ps[9 * es]), v3(ps[10 * es], ps[11 * es], ps[12 * es]),
-                                   v3(ps[13 * es], ps[14 * es], ps[15 * es]), v3(ps[16 * es], ps[17 * es], ps[18 * es]));
+        L.u = beta;
     }
     float* s = xslot(x, j);
     s[0 * es] = alpha.x; s[1 * es] = alpha.y; s[2 * es] = alpha.z; s[3 * es] = a.x; s[4 * es] = a.y; s[5 * es] = a.z;
-    aba_write_kin(L, s, es, 6);
+}
+
+// ---- forward sweep, part 2 (no communication, every body at once): semi-implicit Euler on the body's own joint -- on the floating
+// base for the root -- from the accelerations part 1 left in L.u / L.ca.  The new kinematics then follow from one aba_fk_level
+// sweep (part 3), which is also the next sub-step's kinematics sweep: a sub-step is three sweeps, two of them short.
+template <int JT>
+PHC_HD void aba_integrate_joint(AbaLane& L, const phc_sim_params_t& prm, float dt) {
+    if (L.level < 0) return;
+    const float damp = 1.0f / (1.0f + dt * prm.angular_damping);
+    if (L.level == 0) {
+        const V3 alpha = L.u, a = L.ca;
+        L.v0 = L.v0 + a * dt;
+        L.w0 = (L.w0 + alpha * dt) * damp;
+        L.p0 = L.p0 + L.v0 * dt;
+        L.q = quat_normalize(quat_mul16(quat_from_rotvec(L.w0 * dt), L.q));
+        return;
+    }
+    M3 R = quat_to_mat(L.Q);
+    V3 qdd = mat_tmul(R, L.u);  // child-frame joint acceleration
+    if (JT == PHC_JT_REVOLUTE) {
+        const float thdd = dot(L.axis, qdd);
+        // torque actually applied over the step (explicit part minus the implicit augmentation), S5 -- kept in tau_local.x
+        L.tau_local = v3(dot(L.axis, L.tau_local) - L.dimp.x * thdd, 0.f, 0.f);
+        L.thd = (L.thd + thdd * dt) * damp;
+        L.thd = fminf(fmaxf(L.thd, -prm.max_angular_velocity), prm.max_angular_velocity);
+        L.th += L.thd * dt;
+        L.wj = L.axis * L.thd;
+        L.q = rev_joint_quat(L);
+    } else {
+        // torque actually applied over the step (explicit part minus the implicit augmentation), S5
+        L.tau_local = v3(L.tau_local.x - L.dimp.x * qdd.x, L.tau_local.y - L.dimp.y * qdd.y, L.tau_local.z - L.dimp.z * qdd.z);
+        L.wj = (L.wj + qdd * dt) * damp;
+        float wn = norm(L.wj);
+        if (wn > prm.max_angular_velocity) L.wj = L.wj * (prm.max_angular_velocity / wn);
+        L.q = quat_normalize(quat_mul16(L.q, quat_from_rotvec(L.wj * dt)));
+    }
 }
 
 // ---- state store: S1/S2 (+S5 dof force), and S3/S4 publication from the last kinematics sweep ----

@@ -169,7 +169,9 @@ __global__ __launch_bounds__(64, 2) void k_sim_step(phc_model_t model_all, phc_s
             PHC_PROF(2)
             for (int l = max_level; l >= 0; --l) { aba_backward_level<JT>(L, l, lane, x); __syncthreads(); }
             PHC_PROF(3)
-            for (int l = 0; l <= max_level; ++l) { aba_forward_level<JT>(L, l, lane, x, prm, dt); __syncthreads(); }
+            for (int l = 0; l <= max_level; ++l) { aba_accel_level<JT>(L, l, lane, x); __syncthreads(); }
+            aba_integrate_joint<JT>(L, prm, dt);
+            for (int l = 0; l <= max_level; ++l) { aba_fk_level(L, l, lane, x); __syncthreads(); }
             PHC_PROF(7)
         }
     }
@@ -275,9 +277,13 @@ __global__ __launch_bounds__(64, 1) void k_sim_step16(phc_model_t model_all, phc
         PHC_PROF(4)
         for (int l = split - 1; l >= 0; --l) { aba_backward_level<JT>(LA, l, jA, x); __syncthreads(); }
         PHC_PROF(5)
-        for (int l = 0; l < split; ++l) { aba_forward_level<JT>(LA, l, jA, x, prm, dt); __syncthreads(); }
+        for (int l = 0; l < split; ++l) { aba_accel_level<JT>(LA, l, jA, x); __syncthreads(); }
+        for (int l = split; l <= max_level; ++l) { aba_accel_level<JT>(LB, l, jB, x); __syncthreads(); }
         PHC_PROF(6)
-        for (int l = split; l <= max_level; ++l) { aba_forward_level<JT>(LB, l, jB, x, prm, dt); __syncthreads(); }
+        aba_integrate_joint<JT>(LA, prm, dt);
+        aba_integrate_joint<JT>(LB, prm, dt);
+        for (int l = 0; l < split; ++l) { aba_fk_level(LA, l, jA, x); __syncthreads(); }
+        for (int l = split; l <= max_level; ++l) { aba_fk_level(LB, l, jB, x); __syncthreads(); }
         PHC_PROF(7)
     }
     constexpr int E = 64 / GRP;                       // envs per wavefront

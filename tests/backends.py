@@ -118,9 +118,12 @@ def get_backend(name):
 BACKENDS = ["hostemu", pytest.param("hip", marks=pytest.mark.gpu)]
 
 
-def model_on(be, name="smpl_humanoid", kp_scale=1.0, kd_scale=1.0, zero_armature=False):
+def model_on(be, name="smpl_humanoid", kp_scale=1.0, kd_scale=1.0, zero_armature=False, anisotropic=False):
     from phc_amd.model import load_model
     m = load_model(name)
+    if anisotropic:   # different gains / armature on the three axes of every joint (the SMPL asset's are equal: the stepper's scalar-D path)
+        w = np.tile(np.array([1.0, 0.6, 1.5]), m.num_dof // 3)
+        m.dof_kp, m.dof_kd, m.dof_armature = m.dof_kp * w, m.dof_kd * w[::-1], m.dof_armature * w
     from phc_amd.robots import apply_collision_filter
     apply_collision_filter(m, name.split("_")[0] if name in ("h1_humanoid", "g1_humanoid") else "smpl")
     if name in ("h1_humanoid", "g1_humanoid"):

@@ -41,11 +41,12 @@ def run_step(be, model, mstruct, root, dof, target, params, num_sim_calls=2):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
-@pytest.mark.parametrize("num_sim_calls,height", [(1, 0.95), (2, 0.95), (2, 0.80), (1, 3.0)])
-def test_aba_matches_dense_oracle(backend, num_sim_calls, height):
-    """Featherstone recursion (fp32, one lane per body) == dense M^-1 solve (fp64), incl. implicit PD + contact."""
+@pytest.mark.parametrize("num_sim_calls,height,anisotropic", [(1, 0.95, False), (2, 0.95, False), (2, 0.80, False), (1, 3.0, False), (2, 0.95, True), (2, 0.80, True)])
+def test_aba_matches_dense_oracle(backend, num_sim_calls, height, anisotropic):
+    """Featherstone recursion (fp32, one lane per body) == dense M^-1 solve (fp64), incl. implicit PD + contact.  `anisotropic`: per-axis joint
+    gains / armature, the general joint-space inertia D = A + R diag(d) R^T (the SMPL asset's equal gains take the scalar-d expressions)."""
     be = get_backend(backend)
-    model, mstruct, keep = model_on(be)
+    model, mstruct, keep = model_on(be, anisotropic=anisotropic)
     rng = np.random.default_rng(11)
     n = 6
     root, dof, target = random_states(model, n, rng, height=height)
