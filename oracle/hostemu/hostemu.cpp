@@ -23,7 +23,7 @@ static int emu_sim_step_t(const phc_model_t* model_all, const phc_sim_params_t* 
         const phc_model_t model_env = model_for_env(*model_all, *sim, env);
         const phc_model_t* model = &model_env;
         AbaLane L[PHC_MAX_BODIES];
-        for (int j = 0; j < PHC_MAX_BODIES; ++j) L[j].level = -1;
+        for (int j = 0; j < PHC_MAX_BODIES; ++j) L[j].level = L[j].slevel = -1;
         for (int j = 0; j < nb; ++j) {
             aba_load_model(L[j], *model, j);
             if (JT == PHC_JT_REVOLUTE) aba_load_model_rev(L[j], *model, j);
@@ -46,6 +46,8 @@ static int emu_sim_step_t(const phc_model_t* model_all, const phc_sim_params_t* 
             const float dt = prm->sim_dt / (float)prm->substeps;
             const int nsub = num_sim_calls * prm->substeps;
             std::vector<float> caps(PHC_MAX_BODIES * PHC_CAP_STRIDE);
+            const int sd = model_solver_depth(*model, true);
+            const bool rerooted = model_tab(*model, 11, 3) != 0;
             for (int s = 0; s < nsub; ++s) {
                 if (prm->self_collision) {
                     for (int j = 0; j < nb; ++j) aba_publish_capsule(L[j], model_body(*model, j), caps.data() + PHC_CAP_STRIDE * j);
@@ -53,9 +55,14 @@ static int emu_sim_step_t(const phc_model_t* model_all, const phc_sim_params_t* 
                         aba_collide_pair(*prm, dt, model_pair(*model, q) & 0xff, model_pair(*model, q) >> 8, x, caps.data());
                     for (int j = 0; j < nb; ++j) aba_collect_self(L[j], j, caps.data());
                 }
-                for (int j = 0; j < nb; ++j) aba_body_init<JT>(L[j], *model, *prm, dt, j, s % prm->substeps == 0);
-                for (int l = ml; l >= 0; --l) for (int j = 0; j < nb; ++j) aba_backward_level<JT>(L[j], l, j, x);
-                for (int l = 0; l <= ml; ++l) for (int j = 0; j < nb; ++j) aba_accel_level<JT>(L[j], l, j, x);
+                for (int j = 0; j < nb; ++j) { aba_velocity_products(L[j], *model, j, x, true); aba_body_init<JT>(L[j], *model, *prm, dt, j, s % prm->substeps == 0, true); }
+                if (JT == PHC_JT_SPHERICAL && rerooted) {
+                    for (int j = 0; j < nb; ++j) aba_publish_drive(L[j], j, x);
+                    for (int j = 0; j < nb; ++j) aba_fetch_drive(L[j], j, x);
+                }
+                for (int l = sd; l >= 0; --l) for (int j = 0; j < nb; ++j) aba_backward_level<JT>(L[j], l, j, x);
+                for (int l = 0; l <= sd; ++l) for (int j = 0; j < nb; ++j) aba_accel_level<JT>(L[j], l, j, x);
+                if (JT == PHC_JT_SPHERICAL && rerooted) for (int j = 0; j < nb; ++j) aba_accel_finish(L[j], *model, j, x);
                 for (int j = 0; j < nb; ++j) aba_integrate_joint<JT>(L[j], *prm, dt);
                 for (int l = 0; l <= ml; ++l) for (int j = 0; j < nb; ++j) aba_fk_level(L[j], l, j, x);
             }

@@ -10,6 +10,7 @@ import numpy as np
 from . import _lib as L
 
 MAX_BODIES = 64  # PHC_MAX_BODIES
+NUM_INT_TABLES = 20  # PHC_NTAB
 
 
 def ptr(x):
@@ -30,9 +31,9 @@ def model_struct(ints, floats, num_bodies, num_dof, max_level, num_contact_pts, 
     if num_shapes > 1:
         assert ints.ndim == 2 and floats.ndim == 2 and ints.shape[0] == floats.shape[0] == num_shapes
         m.int_stride, m.float_stride = int(ints.shape[1]), int(floats.shape[1])
-        m.num_collision_pairs = int(ints[:, 4 + 13 * MAX_BODIES].max())
+        m.num_collision_pairs = int(ints[:, 4 + NUM_INT_TABLES * MAX_BODIES].max())
     else:
-        m.num_collision_pairs = int(ints.reshape(-1)[4 + 13 * MAX_BODIES])   # count stored right after the 13 int tables (model.py pack())
+        m.num_collision_pairs = int(ints.reshape(-1)[4 + NUM_INT_TABLES * MAX_BODIES])   # count stored right after the int tables (model.py pack())
     m.split_level, m.num_below_split = int(split[0]), int(split[1])
     m.num_bodies, m.num_dof, m.max_level, m.num_contact_pts = num_bodies, num_dof, max_level, num_contact_pts
     m.ints, m.floats = ptr(ints), ptr(floats)

@@ -29,13 +29,13 @@
 namespace phc {
 
 #define PHC_XCH_STRIDE 28      // floats per exchange slot
-#define PHC_BODY_FLOATS 44     // floats per body in phc_model_t.floats (model.py pack())
+#define PHC_BODY_FLOATS 56     // floats per body in phc_model_t.floats (model.py pack())
 #define PHC_CAP_STRIDE 20       // 32-bit words per body in the per-env world-capsule exchange area (self-collision)
 #define PHC_SC_FSCALE 1024.0f    // fixed-point scales of the body-body force / moment accumulators (1/1024 N, 1/4096 N m)
 #define PHC_SC_NSCALE 4096.0f
 #define PHC_JT_SPHERICAL 1     // joint types as model.py numbers them
 #define PHC_JT_REVOLUTE 2
-#define PHC_NTAB 13            // int tables per model (parent level jtype dof_start child0-2 nchild cp_start cp_count order misc collide-mask)
+#define PHC_NTAB 20            // int tables per model (parent level jtype dof_start child0-2 nchild cp_start cp_count order misc collide-mask | solver tree: parent level child0-2 nchild jsrc/bsrc)
 
 struct Sym3 { float xx, xy, xz, yy, yz, zz; };
 
@@ -102,15 +102,21 @@ PHC_HD V3 Bt_mul(const float* B, V3 v) {
 struct AbaLane {
     // --- constants (model); everything only body_init needs (mass, inertia, gains, contact points) is re-read
     //     from the L2-resident model there instead of being pinned in registers across the sweeps ---
-    int parent, level, dof_start, nchild, child[3];
+    int parent, level, dof_start;   // kinematic tree (rooted at body 0, the simulator's root): state, kinematics sweep, integration
+    // solver tree (model.py solver_tree(): the same articulation rooted at the body that minimises the depth -- the backward and the
+    // acceleration sweeps walk THIS tree; identical to the kinematic tree unless the model re-roots):
+    int sparent, slevel, nchild, child[3];   // (children: of the solver tree)
+    int jsrc;         // body whose joint links this body to its solver parent (itself; its solver parent for a REVERSED body; -1 base)
+    int bsrc;         // bodies whose own joint is solved by a reversed body: that body (their kinematic parent), else -1
     V3 r_local;       // offset from parent origin, parent frame
     // --- state ---
     Q4 q;             // joint rotation child-in-parent (root: world rotation)
     V3 wj;            // joint velocity, child frame (root: unused)
-    V3 p0, v0, w0;    // root only: position, linear velocity of the origin, angular velocity (world)
+                      // (the root's position / velocities ARE its world kinematics p, v, w below: no separate copy in registers)
     V3 target;        // PD target, exp-map
     // --- kinematics (world) ---
-    Q4 Q; V3 p, w, v, rw, cw, ca;
+    Q4 Q; V3 p, w, v;
+    V3 rw, cw, ca;    // solver: reference point minus the solver parent's (world); velocity-product accelerations of the solver joint
     // --- articulated quantities kept between the sweeps ---
     Inertia6 IA; Force6 pA;
     Sym3 Di; V3 u;    // D^-1 and tau_w - p_omega
@@ -144,11 +150,35 @@ PHC_HD phc_model_t model_for_env(phc_model_t m, const phc_sim_state_t& s, int64_
 PHC_HD const float* model_body(const phc_model_t& m, int j) { return m.floats + j * PHC_BODY_FLOATS; }
 PHC_HD int model_tab(const phc_model_t& m, int table, int j) { return m.ints[4 + table * PHC_MAX_BODIES + j]; }
 
-PHC_HD void aba_load_model(AbaLane& L, const phc_model_t& m, int j) {
+// depth of the solver tree (misc table: [split level, bodies below it, solver depth, solver base])
+PHC_HD int model_solver_depth(const phc_model_t& m, bool reroot) { return reroot ? model_tab(m, 11, 2) : m.max_level; }
+// a body's solver reference point (body frame), m * (com - it), inertia about it: floats [44..56) -- or the origin's when not re-rooted
+struct SolverRef { V3 off, mc; Sym3 Io; };
+PHC_HD SolverRef model_solver_ref(const float* f, bool reroot) {
+    SolverRef r;
+    const int o = reroot ? 47 : 4;
+    r.off = reroot ? v3(f[44], f[45], f[46]) : v3(0.f, 0.f, 0.f);
+    r.mc = v3(f[o], f[o + 1], f[o + 2]);
+    r.Io.xx = f[o + 3]; r.Io.xy = f[o + 4]; r.Io.xz = f[o + 5]; r.Io.yy = f[o + 6]; r.Io.yz = f[o + 7]; r.Io.zz = f[o + 8];
+    return r;
+}
+
+PHC_HD void aba_load_model(AbaLane& L, const phc_model_t& m, int j, bool reroot = true) {
     L.parent = model_tab(m, 0, j); L.level = model_tab(m, 1, j);
     L.dof_start = model_tab(m, 3, j);
-    L.child[0] = model_tab(m, 4, j); L.child[1] = model_tab(m, 5, j); L.child[2] = model_tab(m, 6, j);
-    L.nchild = model_tab(m, 7, j);
+    if (reroot) {
+        L.sparent = model_tab(m, 13, j); L.slevel = model_tab(m, 14, j);
+        L.child[0] = model_tab(m, 15, j); L.child[1] = model_tab(m, 16, j); L.child[2] = model_tab(m, 17, j);
+        L.nchild = model_tab(m, 18, j);
+        const int js = model_tab(m, 19, j);
+        L.jsrc = (js & 0xff) - 1; L.bsrc = ((js >> 8) & 0xff) - 1;
+    } else {   // solve on the kinematic tree (the two-slot kernel: its slots are split by kinematic level)
+        L.sparent = L.parent; L.slevel = L.level;
+        L.child[0] = model_tab(m, 4, j); L.child[1] = model_tab(m, 5, j); L.child[2] = model_tab(m, 6, j);
+        L.nchild = model_tab(m, 7, j);
+        L.jsrc = j > 0 ? j : -1; L.bsrc = -1;
+    }
+    L.rw = L.cw = L.ca = v3(0.f, 0.f, 0.f);
     const float* f = model_body(m, j);
     L.r_local = v3(f[0], f[1], f[2]);
     L.arm = v3(f[19], f[20], f[21]);
@@ -157,7 +187,7 @@ PHC_HD void aba_load_model(AbaLane& L, const phc_model_t& m, int j) {
 // revolute extras (template JT == PHC_JT_REVOLUTE paths only)
 // convenience overload: constants read from the model at every call
 template <int JT>
-PHC_HD void aba_body_init(AbaLane& L, const phc_model_t& m, const phc_sim_params_t& prm, float dt, int j, bool new_sim_call);
+PHC_HD void aba_body_init(AbaLane& L, const phc_model_t& m, const phc_sim_params_t& prm, float dt, int j, bool new_sim_call, bool reroot = true);
 
 PHC_HD void aba_load_model_rev(AbaLane& L, const phc_model_t& m, int j) {
     const float* f = model_body(m, j);
@@ -173,8 +203,8 @@ template <int JT>
 PHC_HD void aba_load_state(AbaLane& L, const phc_sim_state_t& s, int nd, int64_t env, int j) {
     if (j == 0) {
         const float* r = s.root_states + env * 13;
-        L.p0 = v3(r[0], r[1], r[2]); L.q = quat_normalize(q4(r[3], r[4], r[5], r[6]));
-        L.v0 = v3(r[7], r[8], r[9]); L.w0 = v3(r[10], r[11], r[12]);
+        L.p = v3(r[0], r[1], r[2]); L.q = quat_normalize(q4(r[3], r[4], r[5], r[6]));
+        L.v = v3(r[7], r[8], r[9]); L.w = v3(r[10], r[11], r[12]);
         L.wj = v3(0.f, 0.f, 0.f); L.target = v3(0.f, 0.f, 0.f);
         if (JT == PHC_JT_REVOLUTE) { L.th = L.thd = 0.f; }
     } else if (JT == PHC_JT_REVOLUTE) {
@@ -183,14 +213,12 @@ PHC_HD void aba_load_state(AbaLane& L, const phc_sim_state_t& s, int nd, int64_t
         L.q = rev_joint_quat(L);
         L.wj = L.axis * L.thd;
         L.target = v3(s.pd_target[env * nd + L.dof_start], 0.f, 0.f);
-        L.p0 = L.v0 = L.w0 = v3(0.f, 0.f, 0.f);
     } else {
         const float* d = s.dof_state + (env * nd + L.dof_start) * 2;
         L.q = quat_from_rotvec(v3(d[0], d[2], d[4]));
         L.wj = v3(d[1], d[3], d[5]);
         const float* t = s.pd_target + env * nd + L.dof_start;
         L.target = v3(t[0], t[1], t[2]);
-        L.p0 = L.v0 = L.w0 = v3(0.f, 0.f, 0.f);
     }
 }
 
@@ -205,13 +233,31 @@ PHC_HD float* xslot(const Xch& x, int body) { return x.base + body * Xch::bs; }
 
 // new kinematics of body (level > 0) from its parent's: shared by the initial sweep and the merged forward sweep
 PHC_HD void aba_kinematics_from_parent(AbaLane& L, Q4 Qp, V3 pp, V3 wp, V3 vp) {
-    L.rw = quat_rotate(Qp, L.r_local);
-    L.p = pp + L.rw;
+    const V3 r = quat_rotate(Qp, L.r_local);
+    L.p = pp + r;
     L.Q = quat_normalize(quat_mul16(Qp, L.q));
     V3 wJw = quat_rotate(L.Q, L.wj);
     L.w = wp + wJw;
-    L.v = vp + cross(wp, L.rw);
-    L.cw = cross(wp, wJw);
+    L.v = vp + cross(wp, r);
+}
+// velocity-product accelerations of the body's joint, c_w = w_p x w_J and c_a = w_p x (w_p x r), from the parent's angular velocity as the
+// last kinematics sweep left it in the parent's slot.  Every body at once, before aba_body_init: nothing inside the kinematics
+// level-step needs them, and an instruction there is issued once per tree level.  (Root: zero, set by aba_fk_level.)
+// With a re-rooted solver tree the "parent" is the SOLVER parent and positions are the bodies' solver reference points (the anchor of
+// the joint towards the solver parent: a material point of both bodies, so the rigid-body relations keep their form).
+PHC_HD void aba_velocity_products(AbaLane& L, const phc_model_t& m, int j, const Xch& x, bool reroot) {
+    if (L.slevel <= 0) { L.rw = L.cw = L.ca = v3(0.f, 0.f, 0.f); return; }
+    constexpr int es = Xch::es;
+    const float* ps = xslot(x, L.sparent);
+    const V3 pp = v3(ps[10 * es], ps[11 * es], ps[12 * es]), wp = v3(ps[13 * es], ps[14 * es], ps[15 * es]);
+    L.rw = L.p - pp;
+    if (reroot) {   // reference points instead of origins (zero offsets for every body that is not reversed)
+        const float* f = model_body(m, j);
+        const float* fp = model_body(m, L.sparent);
+        L.rw = L.rw + quat_rotate(L.Q, v3(f[44], f[45], f[46]))
+                    - quat_rotate(q4(ps[6 * es], ps[7 * es], ps[8 * es], ps[9 * es]), v3(fp[44], fp[45], fp[46]));
+    }
+    L.cw = cross(wp, L.w - wp);
     L.ca = cross(wp, cross(wp, L.rw));
 }
 PHC_HD void aba_write_kin(const AbaLane& L, float* s, int es, int o) {
@@ -226,8 +272,7 @@ PHC_HD void aba_fk_level(AbaLane& L, int level, int j, const Xch& x) {
     if (L.level != level) return;
     constexpr int es = Xch::es;
     if (level == 0) {
-        L.Q = L.q; L.p = L.p0; L.w = L.w0; L.v = L.v0;
-        L.rw = L.cw = L.ca = v3(0.f, 0.f, 0.f);
+        L.Q = L.q;   // (p, w, v: the root's state itself)
     } else {
         const float* ps = xslot(x, L.parent);
         aba_kinematics_from_parent(L, q4(ps[6 * es], ps[7 * es], ps[8 * es], ps[9 * es]), v3(ps[10 * es], ps[11 * es], ps[12 * es]),
@@ -242,14 +287,15 @@ PHC_HD void aba_fk_level(AbaLane& L, int level, int j, const Xch& x) {
 // `cp_start / cp_total`: the body's slice of the contact-point table.
 template <int JT>
 PHC_HD void aba_body_init(AbaLane& L, const phc_model_t& m, const phc_sim_params_t& prm, float dt, int j, bool new_sim_call,
-                          const float* f, int cp_start, int cp_total) {
+                          const float* f, int cp_start, int cp_total, bool reroot) {
     const float mass = f[3];
-    Sym3 Io_b;
-    Io_b.xx = f[7]; Io_b.xy = f[8]; Io_b.xz = f[9]; Io_b.yy = f[10]; Io_b.yz = f[11]; Io_b.zz = f[12];
+    // every spatial quantity of the body is taken about its solver reference point o = p + R off (the origin unless the body is reversed)
+    const SolverRef sr = model_solver_ref(f, reroot);
     M3 R = quat_to_mat(L.Q);
-    Sym3 Io = rot_sym(R, Io_b);
-    V3 mc = mat_mul(R, v3(f[4], f[5], f[6]));
-    // rigid-body inertia about the origin: [[Io, [mc]x], [[mc]x^T, m 1]]
+    Sym3 Io = rot_sym(R, sr.Io);
+    V3 mc = mat_mul(R, sr.mc);
+    const V3 so = mat_mul(R, sr.off);
+    // rigid-body inertia about the reference point: [[Io, [mc]x], [[mc]x^T, m 1]]
     L.IA.A = Io;
     L.IA.B[0] = 0.f;   L.IA.B[1] = -mc.z; L.IA.B[2] = mc.y;
     L.IA.B[3] = mc.z;  L.IA.B[4] = 0.f;   L.IA.B[5] = -mc.x;
@@ -272,6 +318,7 @@ PHC_HD void aba_body_init(AbaLane& L, const phc_model_t& m, const phc_sim_params
         if (depth <= 0.f) continue;
         arm.z -= rad;  // actual contact location relative to the body origin
         V3 uc = L.v + cross(L.w, arm);
+        arm = arm - so;  // ... relative to the reference point, which the moments and the implicit terms refer to
         float fn0 = prm.contact_stiffness * depth - cn * uc.z;
         if (fn0 <= 0.f) continue;  // separating: non-adhesive
         float ut = sqrtf(uc.x * uc.x + uc.y * uc.y);
@@ -299,7 +346,7 @@ PHC_HD void aba_body_init(AbaLane& L, const phc_model_t& m, const phc_sim_params
     }
     // body-body contact forces of this sub-step (explicit; zero unless sim_params.self_collision)
     L.fcontact += L.fself;
-    L.pA.n -= L.nself;
+    L.pA.n -= L.nself - cross(so, L.fself);   // (nself: about the origin)
     L.pA.f -= L.fself;
     if (JT == PHC_JT_REVOLUTE) {
         if (L.level > 0) {
@@ -358,7 +405,7 @@ PHC_HD void aba_body_init(AbaLane& L, const phc_model_t& m, const phc_sim_params
         V3 d = v3(dt * kd.x + dt * dt * kp.x, dt * kd.y + dt * dt * kp.y, dt * kd.z + dt * dt * kp.z);
         L.tau_local = tau;
         L.dimp = d;
-        const V3 dd = d + L.arm;
+        const V3 dd = d + v3(f[19], f[20], f[21]);   // + armature (read here: not pinned in registers across the sweeps)
         if (dd.x == dd.y && dd.y == dd.z) { L.diso = dd.x; }
         else { L.diso = -1.f; L.Dw = rot_diag(R, dd); }
         L.tau_w = mat_mul(R, tau);
@@ -366,8 +413,8 @@ PHC_HD void aba_body_init(AbaLane& L, const phc_model_t& m, const phc_sim_params
 }
 
 template <int JT>
-PHC_HD void aba_body_init(AbaLane& L, const phc_model_t& m, const phc_sim_params_t& prm, float dt, int j, bool new_sim_call) {
-    aba_body_init<JT>(L, m, prm, dt, j, new_sim_call, model_body(m, j), model_tab(m, 8, j), model_tab(m, 9, j));
+PHC_HD void aba_body_init(AbaLane& L, const phc_model_t& m, const phc_sim_params_t& prm, float dt, int j, bool new_sim_call, bool reroot) {
+    aba_body_init<JT>(L, m, prm, dt, j, new_sim_call, model_body(m, j), model_tab(m, 8, j), model_tab(m, 9, j), reroot);
 }
 
 // ---- body-body contact (SURVEY f-1; the reference runs with robot.has_self_collision: True, humanoid.py:1205-1226) ----
@@ -550,7 +597,7 @@ PHC_HD void accumulate_child(Inertia6& I, Force6& p, const float* s, int es) {
 // they are the root, reduce over their own joint and publish T^T I^a T, T^T p^a for their parent.
 template <int JT>
 PHC_HD void aba_backward_level(AbaLane& L, int level, int j, const Xch& x) {
-    if (L.level != level) return;
+    if (L.slevel != level) return;
     for (int k = 0; k < 3; ++k)
         if (k < L.nchild) accumulate_child(L.IA, L.pA, xslot(x, L.child[k]), Xch::es);
     if (level == 0) return;
@@ -618,7 +665,7 @@ PHC_HD void aba_backward_level(AbaLane& L, int level, int j, const Xch& x) {
 // in registers for part 2: the root's alpha -> L.u, a -> L.ca; a joint's world-frame angular acceleration beta -> L.u.
 template <int JT>
 PHC_HD void aba_accel_level(AbaLane& L, int level, int j, const Xch& x) {
-    if (L.level != level) return;
+    if (L.slevel != level) return;
     constexpr int es = Xch::es;
     V3 alpha, a;
     if (level == 0) {
@@ -639,7 +686,7 @@ PHC_HD void aba_accel_level(AbaLane& L, int level, int j, const Xch& x) {
         a = -sym_mul(Ci, L.pA.f + Bt_mul(B, alpha));
         L.u = alpha; L.ca = a;
     } else {
-        const float* ps = xslot(x, L.parent);
+        const float* ps = xslot(x, L.sparent);
         V3 alp = v3(ps[0 * es], ps[1 * es], ps[2 * es]), ap = v3(ps[3 * es], ps[4 * es], ps[5 * es]);
         V3 al1 = alp + L.cw;
         V3 a1 = ap + cross(alp, L.rw) + L.ca;
@@ -650,6 +697,48 @@ PHC_HD void aba_accel_level(AbaLane& L, int level, int j, const Xch& x) {
     }
     float* s = xslot(x, j);
     s[0 * es] = alpha.x; s[1 * es] = alpha.y; s[2 * es] = alpha.z; s[3 * es] = a.x; s[4 * es] = a.y; s[5 * es] = a.z;
+    s[19 * es] = L.u.x; s[20 * es] = L.u.y; s[21 * es] = L.u.z;   // (re-rooted trees: aba_accel_finish hands it to the joint's owner)
+}
+
+// ---- re-rooted solver tree only (model.py solver_tree()), every body at once ----
+// Before the backward sweep: a reversed body's solver joint is its solver parent's joint.  Every body publishes the world-frame drive
+// terms of its OWN joint (slot [19..28): tau_w, D_w); a reversed body then takes its solver parent's -- the torque with the opposite
+// sign, the joint-space matrix as it is (same physical joint, seen from its other side).
+PHC_HD void aba_publish_drive(const AbaLane& L, int j, const Xch& x) {
+    constexpr int es = Xch::es;
+    float* s = xslot(x, j);
+    s[19 * es] = L.tau_w.x; s[20 * es] = L.tau_w.y; s[21 * es] = L.tau_w.z;
+    const bool iso = L.diso >= 0.f;
+    s[22 * es] = iso ? L.diso : L.Dw.xx; s[23 * es] = iso ? 0.f : L.Dw.xy; s[24 * es] = iso ? 0.f : L.Dw.xz;
+    s[25 * es] = iso ? L.diso : L.Dw.yy; s[26 * es] = iso ? 0.f : L.Dw.yz; s[27 * es] = iso ? L.diso : L.Dw.zz;
+}
+PHC_HD void aba_fetch_drive(AbaLane& L, int j, const Xch& x) {
+    if (L.jsrc < 0 || L.jsrc == j) return;
+    constexpr int es = Xch::es;
+    const float* s = xslot(x, L.jsrc);
+    L.tau_w = v3(-s[19 * es], -s[20 * es], -s[21 * es]);
+    L.Dw.xx = s[22 * es]; L.Dw.xy = s[23 * es]; L.Dw.xz = s[24 * es]; L.Dw.yy = s[25 * es]; L.Dw.yz = s[26 * es]; L.Dw.zz = s[27 * es];
+    const bool iso = L.Dw.xy == 0.f && L.Dw.xz == 0.f && L.Dw.yz == 0.f && L.Dw.xx == L.Dw.yy && L.Dw.yy == L.Dw.zz;
+    L.diso = iso ? L.Dw.xx : -1.f;
+}
+// After the acceleration sweep: what aba_integrate_joint reads from L.u / L.ca.  A joint solved by a reversed body gets that body's
+// relative acceleration with the opposite sign (beta_c = alpha_c - alpha_p - w_p x w_c = -(alpha_p - alpha_c - w_c x w_p)); the
+// simulator's root, when it is not the solver base, gets its own alpha and the acceleration of its ORIGIN from that of its reference point.
+PHC_HD void aba_accel_finish(AbaLane& L, const phc_model_t& m, int j, const Xch& x) {
+    if (L.level < 0) return;
+    constexpr int es = Xch::es;
+    if (L.bsrc >= 0) {
+        const float* s = xslot(x, L.bsrc);
+        L.u = v3(-s[19 * es], -s[20 * es], -s[21 * es]);
+    }
+    if (L.level == 0 && L.slevel > 0) {
+        const float* s = xslot(x, j);
+        const float* f = model_body(m, j);
+        const V3 alpha = v3(s[0 * es], s[1 * es], s[2 * es]), a = v3(s[3 * es], s[4 * es], s[5 * es]);
+        const V3 d = -quat_rotate(L.Q, v3(f[44], f[45], f[46]));   // origin minus reference point
+        L.u = alpha;
+        L.ca = a + cross(alpha, d) + cross(L.w, cross(L.w, d));
+    }
 }
 
 // ---- forward sweep, part 2 (no communication, every body at once): semi-implicit Euler on the body's own joint -- on the floating
@@ -661,10 +750,10 @@ PHC_HD void aba_integrate_joint(AbaLane& L, const phc_sim_params_t& prm, float d
     const float damp = 1.0f / (1.0f + dt * prm.angular_damping);
     if (L.level == 0) {
         const V3 alpha = L.u, a = L.ca;
-        L.v0 = L.v0 + a * dt;
-        L.w0 = (L.w0 + alpha * dt) * damp;
-        L.p0 = L.p0 + L.v0 * dt;
-        L.q = quat_normalize(quat_mul16(quat_from_rotvec(L.w0 * dt), L.q));
+        L.v = L.v + a * dt;
+        L.w = (L.w + alpha * dt) * damp;
+        L.p = L.p + L.v * dt;
+        L.q = quat_normalize(quat_mul16(quat_from_rotvec(L.w * dt), L.q));
         return;
     }
     M3 R = quat_to_mat(L.Q);
@@ -693,8 +782,8 @@ template <int JT>
 PHC_HD void aba_store_state(const AbaLane& L, const phc_sim_state_t& s, int nd, int64_t env, int j) {
     if (j == 0) {
         float* r = s.root_states + env * 13;
-        r[0] = L.p0.x; r[1] = L.p0.y; r[2] = L.p0.z; r[3] = L.q.x; r[4] = L.q.y; r[5] = L.q.z; r[6] = L.q.w;
-        r[7] = L.v0.x; r[8] = L.v0.y; r[9] = L.v0.z; r[10] = L.w0.x; r[11] = L.w0.y; r[12] = L.w0.z;
+        r[0] = L.p.x; r[1] = L.p.y; r[2] = L.p.z; r[3] = L.q.x; r[4] = L.q.y; r[5] = L.q.z; r[6] = L.q.w;
+        r[7] = L.v.x; r[8] = L.v.y; r[9] = L.v.z; r[10] = L.w.x; r[11] = L.w.y; r[12] = L.w.z;
     } else if (JT == PHC_JT_REVOLUTE) {
         float* d = s.dof_state + (env * nd + L.dof_start) * 2;
         d[0] = L.th; d[1] = L.thd;

@@ -133,7 +133,7 @@ __global__ __launch_bounds__(64, 2) void k_sim_step(phc_model_t model_all, phc_s
     x.base = xch_all + grp * GRP * PHC_XCH_STRIDE;
 
     AbaLane L;
-    L.level = -1;
+    L.level = L.slevel = -1;
     PHC_PROF_DECL
     if (active) {
         aba_load_model(L, model, lane);
@@ -156,6 +156,9 @@ __global__ __launch_bounds__(64, 2) void k_sim_step(phc_model_t model_all, phc_s
         PairList<PHC_SC_MAX_PER_LANE> pairs;
         uint32_t near_pairs = 0;
         if (prm.self_collision) aba_load_pairs(pairs, model, lane, GRP);
+        // the backward / acceleration sweeps walk the solver tree (model.py solver_tree(): re-rooted where that makes it shallower)
+        const int solver_depth = model_solver_depth(model, true);
+        const bool rerooted = model_tab(model, 11, 3) != 0;
         for (int s = 0; s < nsub; ++s) {
             if (prm.self_collision) {   // body-body contact from the kinematics the last sweep left in the exchange slots
                 if (active) aba_publish_capsule(L, model_body(model, lane), caps + PHC_CAP_STRIDE * lane);
@@ -165,11 +168,18 @@ __global__ __launch_bounds__(64, 2) void k_sim_step(phc_model_t model_all, phc_s
                 if (active) aba_collect_self(L, lane, caps);
             }
             PHC_PROF(1)
-            if (active) aba_body_init<JT>(L, model, prm, dt, lane, s % prm.substeps == 0);
+            if (active) { aba_velocity_products(L, model, lane, x, true); aba_body_init<JT>(L, model, prm, dt, lane, s % prm.substeps == 0, true); }
+            if (JT == PHC_JT_SPHERICAL && rerooted) {   // reversed bodies take the drive terms of their solver parent's joint
+                if (active) aba_publish_drive(L, lane, x);
+                __syncthreads();
+                if (active) aba_fetch_drive(L, lane, x);
+                __syncthreads();
+            }
             PHC_PROF(2)
-            for (int l = max_level; l >= 0; --l) { aba_backward_level<JT>(L, l, lane, x); __syncthreads(); }
+            for (int l = solver_depth; l >= 0; --l) { aba_backward_level<JT>(L, l, lane, x); __syncthreads(); }
             PHC_PROF(3)
-            for (int l = 0; l <= max_level; ++l) { aba_accel_level<JT>(L, l, lane, x); __syncthreads(); }
+            for (int l = 0; l <= solver_depth; ++l) { aba_accel_level<JT>(L, l, lane, x); __syncthreads(); }
+            if (JT == PHC_JT_SPHERICAL && rerooted) aba_accel_finish(L, model, lane, x);
             aba_integrate_joint<JT>(L, prm, dt);
             for (int l = 0; l <= max_level; ++l) { aba_fk_level(L, l, lane, x); __syncthreads(); }
             PHC_PROF(7)
@@ -228,10 +238,10 @@ __global__ __launch_bounds__(64, 1) void k_sim_step16(phc_model_t model_all, phc
     constexpr int ndj = JT == PHC_JT_REVOLUTE ? 1 : 3;
 
     AbaLane LA, LB;
-    LA.level = LB.level = -1;
+    LA.level = LB.level = LA.slevel = LB.slevel = -1;
     PHC_PROF_DECL
     auto load = [&](AbaLane& L, int j) {
-        aba_load_model(L, model, j);
+        aba_load_model(L, model, j, false);   // two-slot: the slots are split by kinematic level, so the solve stays on the kinematic tree
         if (JT == PHC_JT_REVOLUTE) aba_load_model_rev(L, model, j);
         if (actions != nullptr && j >= 1) {
             for (int k = 0; k < ndj; ++k) {
@@ -269,11 +279,11 @@ __global__ __launch_bounds__(64, 1) void k_sim_step16(phc_model_t model_all, phc
         PHC_PROF(1)
         // slot A's articulated quantities are initialised only when the sweep reaches its levels: while the deep (slot B) levels
         // run, slot A holds kinematic state only (27 fewer live registers)
-        if (jB >= 0) aba_body_init<JT>(LB, model, prm, dt, jB, fresh);
+        if (jB >= 0) { aba_velocity_products(LB, model, jB, x, false); aba_body_init<JT>(LB, model, prm, dt, jB, fresh, false); }
         PHC_PROF(2)
         for (int l = max_level; l >= split; --l) { aba_backward_level<JT>(LB, l, jB, x); __syncthreads(); }
         PHC_PROF(3)
-        if (jA >= 0) aba_body_init<JT>(LA, model, prm, dt, jA, fresh);
+        if (jA >= 0) { aba_velocity_products(LA, model, jA, x, false); aba_body_init<JT>(LA, model, prm, dt, jA, fresh, false); }
         PHC_PROF(4)
         for (int l = split - 1; l >= 0; --l) { aba_backward_level<JT>(LA, l, jA, x); __syncthreads(); }
         PHC_PROF(5)

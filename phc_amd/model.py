@@ -363,6 +363,61 @@ class ArticulationModel:
             ch[self.parent[i]].append(i)
         return ch
 
+    def solver_tree(self):
+        """The tree the stepper's backward / acceleration sweeps walk.  A free-floating articulation can be solved from ANY body as the
+        floating base; a level-step of the sweeps is issued once per tree level whatever the number of bodies at that level, so the base
+        that minimises the depth is the cheapest: the SMPL humanoid is 8 deep from the pelvis (pelvis ... hand) and 6 from `Spine`
+        (arms and legs balance).  State, kinematics, integration and every published tensor stay pelvis-rooted; only the solve re-roots.
+
+        Bodies on the path old root -> base are REVERSED: their solver parent is their child on the path, the joint that connects them
+        to it is that child's joint, and their spatial quantities are taken about that joint's anchor (`s_off`, body frame) instead of
+        their own origin, so that the joint keeps the motion subspace [1; 0].  All-spherical articulations only (robots keep the root).
+
+        -> dict(base, sparent, slevel, schildren, s_off [NB,3], jsrc (body whose joint links b to its solver parent; -1 base),
+                bsrc (path bodies: the reversed body that solves their joint; else -1))"""
+        nb = self.num_bodies
+        ident = dict(base=0, sparent=self.parent.copy(), slevel=self.level.copy(), schildren=self.children(), s_off=np.zeros((nb, 3)),
+                     jsrc=np.array([-1] + list(range(1, nb))), bsrc=np.full(nb, -1))
+        if not self.all_spherical or nb < 3 or not getattr(self, "reroot", True):
+            return ident
+        adj = self.children()
+        for i in range(1, nb):
+            adj[i] = adj[i] + [int(self.parent[i])]
+
+        def levels_from(base):
+            lv, par, order = np.full(nb, -1), np.full(nb, -1), [base]
+            lv[base] = 0
+            for b in order:
+                for c in adj[b]:
+                    if lv[c] < 0:
+                        lv[c], par[c] = lv[b] + 1, b
+                        order.append(c)
+            return lv, par
+        best, best_depth = 0, self.max_level
+        for b in range(nb):
+            lv, par = levels_from(b)
+            kids = np.bincount(par[par >= 0], minlength=nb)
+            if lv.max() < best_depth and kids.max() <= 3:
+                best, best_depth = b, int(lv.max())
+        if best == 0:
+            return ident
+        lv, par = levels_from(best)
+        sch = [[] for _ in range(nb)]
+        for i in range(nb):
+            if par[i] >= 0:
+                sch[par[i]].append(i)
+        s_off, jsrc, bsrc = np.zeros((nb, 3)), np.arange(nb), np.full(nb, -1)
+        jsrc[best] = -1
+        c = best
+        while c != 0:                       # walk the path base -> old root: p is reversed, its solver joint is c's
+            p = int(self.parent[c])
+            assert par[p] == c
+            s_off[p] = self.local_translation[c]
+            jsrc[p] = c
+            bsrc[c] = p
+            c = p
+        return dict(base=best, sparent=par, slevel=lv, schildren=sch, s_off=s_off, jsrc=jsrc, bsrc=bsrc)
+
     def collision_allow_masks(self):
         """Bit j of entry i: bodies i and j may collide -- not the same body, not joined by a joint (PhysX articulations never
         collide parent and child), no common Isaac Gym filter bit (humanoid.py:1205-1226: shapes collide iff (fa & fb) == 0),
@@ -397,11 +452,12 @@ class ArticulationModel:
                 cp_start, cp_count, order (bodies sorted by level), misc [split level, bodies below it],
                 self-collision partner mask
         floats: per body (MAX_BODIES slots x BODY_FLOATS): r_local[3], mass, m*com[3], Io(xx,xy,xz,yy,yz,zz)[6],
-                kp[3], kd[3], armature[3], effort[3], axis[3] (revolute), rest rotation xyzw[4], limit lo/hi [2], contact bound radius, pad, collision capsule a[3] b[3] radius, pad ;
+                kp[3], kd[3], armature[3], effort[3], axis[3] (revolute), rest rotation xyzw[4], limit lo/hi [2], contact bound radius, pad, collision capsule a[3] b[3] radius, pad,
+                solver reference point s_off[3], m*(com - s_off)[3], inertia about it [6] ;
                 then contact points NCP x 4 (pos[3], radius)
         """
         NB, MB = self.num_bodies, self.MAX_BODIES
-        NT = 13
+        NT = 20
         ints = np.zeros(4 + NT * MB, dtype=np.int32)
         ints[0:4] = [NB, self.num_dof, self.max_level, len(self.contact_body)]
         tab = ints[4:].reshape(NT, MB)
@@ -426,6 +482,20 @@ class ArticulationModel:
         # levels < split, slot B = the rest, both <= 16 (32) bodies, so that at every tree level all active bodies sit in the same slot.  tab[11] = [split, nA].
         tab[11, 0:2] = self.two_slot_split()
         tab[12, :NB] = np.array([v & 0xffffffff for v in self.collision_allow_masks()], dtype=np.uint32).view(np.int32)   # partner bit masks (bodies 0-31; informative)
+        # solver tree (solver_tree()): tables 13..19 = parent, level, child0-2, nchild, jsrc | bsrc << 8 (+1 each, 0 = none); misc[2:4] = its depth, its base
+        st = self.solver_tree()
+        tab[13, :] = -1
+        tab[14, :] = -1
+        tab[15:18, :] = -1
+        for i in range(NB):
+            assert len(st["schildren"][i]) <= 3
+            tab[13, i] = st["sparent"][i]
+            tab[14, i] = st["slevel"][i]
+            for k, c in enumerate(st["schildren"][i]):
+                tab[15 + k, i] = c
+            tab[18, i] = len(st["schildren"][i])
+            tab[19, i] = (int(st["jsrc"][i]) + 1) | ((int(st["bsrc"][i]) + 1) << 8)
+        tab[11, 2:4] = [int(st["slevel"].max()), st["base"]]
         # self-collision candidate pairs (i < k, may collide), appended after the tables: [count, i | k << 8, ...]; lane l of a
         # group evaluates pairs l, l + L, l + 2L, ... so the list is ordered to spread each body's pairs over many lanes
         masks = self.collision_allow_masks()
@@ -465,6 +535,14 @@ class ArticulationModel:
             # contact broad phase: no point of the body can touch z = 0 while the body origin is higher than this
             fl[i, 34] = (np.linalg.norm(self.contact_pos[idx], axis=-1) + self.contact_radius[idx]).max() * 1.0001 if len(idx) else 0.0
             fl[i, 36:43] = self.collision_capsule[i]
+            # solver reference point (solver_tree()): offset, m * com and inertia about it (= the origin's for every body that is not reversed)
+            so = st["s_off"][i]
+            cr = self.com[i] - so
+            Icom = I - self.mass[i] * (self.com[i] @ self.com[i] * np.eye(3) - np.outer(self.com[i], self.com[i]))
+            Ir = Icom + self.mass[i] * (cr @ cr * np.eye(3) - np.outer(cr, cr))
+            fl[i, 44:47] = so
+            fl[i, 47:50] = self.mass[i] * cr
+            fl[i, 50:56] = [Ir[0, 0], Ir[0, 1], Ir[0, 2], Ir[1, 1], Ir[1, 2], Ir[2, 2]]
         cp = np.concatenate([self.contact_pos, self.contact_radius[:, None]], axis=1) if len(self.contact_body) else np.zeros((0, 4))
         # within a body: lowest points (local z - radius) first.  The stepper walks a body's points in lockstep over the lanes of a
         # wavefront and skips an iteration's force / inertia part when NO lane's point touches the ground: with the soles' points at the
@@ -478,7 +556,7 @@ class ArticulationModel:
         floats = np.concatenate([fl.reshape(-1), cp.reshape(-1)]).astype(np.float32)
         return ints, floats
 
-    BODY_FLOATS = 44
+    BODY_FLOATS = 56
 
     # ---- action scaling (A1) ---------------------------------------------------------------
     def dof_limits(self):
