@@ -235,7 +235,7 @@ PHC_HD float* xslot(const Xch& x, int body) { return x.base + body * Xch::bs; }
 PHC_HD void aba_kinematics_from_parent(AbaLane& L, Q4 Qp, V3 pp, V3 wp, V3 vp) {
     const V3 r = quat_rotate(Qp, L.r_local);
     L.p = pp + r;
-    L.Q = quat_normalize(quat_mul16(Qp, L.q));
+    L.Q = quat_mul16(Qp, L.q);   // (unit: the root's and every joint's quaternion are normalised where they are integrated / loaded)
     V3 wJw = quat_rotate(L.Q, L.wj);
     L.w = wp + wJw;
     L.v = vp + cross(wp, r);

@@ -398,9 +398,11 @@ int32_t phc_sim_step(const phc_model_t* model, const phc_sim_params_t* params, c
     const bool can_split = model->split_level > 0 && model->num_below_split <= half && model->num_bodies - model->num_below_split <= half &&
                            !(params->self_collision && model->num_collision_pairs > cap_two);
     // wide articulations (G1, N = 4096, scripts/gpu_g1.sh): 434 us one body per lane vs 515 us two-slot -> never picked automatically
-    const bool two_slot = can_split && (params->lane_mapping == 2 || (params->lane_mapping == 0 && !wide && model->max_level >= 7 &&
-                                                                      !params->self_collision &&
-                                                                      (int64_t)sim->num_envs <= 4 * (int64_t)num_simds));
+    // Since the round-2 rework of the sweeps (solver tree re-rooted at the body of least depth, forward sweep split, joint-drive rotations hoisted --
+    // one body per lane only: the two-slot kernel's slots are split by KINEMATIC level, so it solves on the kinematic tree) one body per lane
+    // wins everywhere measured: SMPL @4096 80.8 vs 100.1 us with body-body contact, 69.1 vs 83.4 us without.  Two-slot only on request.
+    const bool two_slot = can_split && params->lane_mapping == 2;
+    (void)num_simds;
     sim_launch<true>(model, *params, sim, actions, pd_action_offset, pd_action_scale, freeze_mask, num_sim_calls, (hipStream_t)stream, nullptr, 0,
                      two_slot);
     return launch_status();
