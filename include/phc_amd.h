@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PHC_ABI_VERSION 29
+#define PHC_ABI_VERSION 30
 #define PHC_MAX_BODIES 64   /* bodies (incl. extended reference bodies) per articulation; also the slot count of the model tables */
 #define PHC_EINVAL (-1)
 #define PHC_EUNSUPPORTED (-2)
@@ -237,6 +237,12 @@ typedef struct {
     const uint8_t* occl_mask;         /* [N, J] env.occl_training (humanoid_im.py:96-97,796-804,845-851,1081-1092,1180-1181): non-zero = the tracked body
                                          (slot order) is occluded: its reference state in the task observation and its reference position in
                                          the early-termination distance are the simulated ones; the caller keeps the mask; nullable */
+    int64_t amp_env_stride;           /* floats between two envs' AMP history windows; 0 = S * P (plain [N,S,P] buffers).  Larger: every env owns a strip of
+                                         more than S frames and amp_obs_in / amp_obs_out point at window positions inside env 0's strip.  When
+                                         amp_obs_out + P == amp_obs_in (the new window starts one frame before the old one) phc_im_post_physics
+                                         writes the new frame only -- the history shift of humanoid_amp.py:662-670 (14 KB of traffic per env and
+                                         step) is then implicit; the caller moves the window back to the end of the strip every (strip - S) steps
+                                         with one ordinary shifting call (HumanoidIm: strips of 2 S frames) */
 } phc_im_buffers_t;
 
 int32_t phc_abi_version(void);

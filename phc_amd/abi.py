@@ -177,8 +177,9 @@ def im_buffers_struct(progress_buf, reset_buf, terminate_buf, rew_buf, reward_ra
                       sampled_motion_ids, motion_start_times, motion_start_times_offset, global_offset,
                       ref_body_pos=None, ref_body_rot=None, ref_body_vel=None, ref_dof_pos=None,
                       cycle_counter=None, recovery_counter=None, point_goal=None, cycle_phase=None, reset_list=None, reset_count=None,
-                      reset_slot=0, offset_rand=None, body_state_hist=None, occl_mask=None):
+                      reset_slot=0, offset_rand=None, body_state_hist=None, occl_mask=None, amp_env_stride=0):
     b = L.ImBuffers()
+    b.amp_env_stride = int(amp_env_stride)
     b.occl_mask = ptr(occl_mask)
     b.offset_rand = ptr(offset_rand)
     b.body_state_hist = ptr(body_state_hist)
@@ -186,7 +187,9 @@ def im_buffers_struct(progress_buf, reset_buf, terminate_buf, rew_buf, reward_ra
     b.reset_sublist_cap = 0 if reset_list is None else int(reset_list.shape[0]) // RESET_SUBLISTS
     b.progress_buf, b.reset_buf, b.terminate_buf = ptr(progress_buf), ptr(reset_buf), ptr(terminate_buf)
     b.rew_buf, b.reward_raw, b.obs_buf = ptr(rew_buf), ptr(reward_raw), ptr(obs_buf)
-    b.amp_obs_in, b.amp_obs_out = ptr(amp_obs_in), ptr(amp_obs_out)
+    # (windows inside longer per-env strips come as non-contiguous views: their first element is what the kernels need)
+    first = lambda t: t.ctypes.data if isinstance(t, np.ndarray) else t.data_ptr()
+    b.amp_obs_in, b.amp_obs_out = (ptr(t) if amp_env_stride == 0 else first(t) for t in (amp_obs_in, amp_obs_out))
     b.sampled_motion_ids = ptr(sampled_motion_ids)
     b.motion_start_times, b.motion_start_times_offset = ptr(motion_start_times), ptr(motion_start_times_offset)
     b.global_offset = ptr(global_offset)

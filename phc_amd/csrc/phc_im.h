@@ -66,10 +66,17 @@ PHC_HD void amp_obs_from_sim_lane(const phc_im_params_t& prm, const phc_sim_stat
 
 // History shift of HumanoidAMP._update_hist_amp_obs (humanoid_amp.py:662-670), ping-pong:
 // out[env][1..S) = in[env][0..S-1).  Cooperative over the `nl` lanes of the env, float4 wide.
+// Floats between two envs' history windows: S * A, or phc_im_buffers_t.amp_env_stride when the windows live in longer per-env strips.
+PHC_HD int64_t amp_env_stride(const phc_im_params_t& prm, const phc_im_buffers_t& buf) {
+    return buf.amp_env_stride > 0 ? buf.amp_env_stride : (int64_t)prm.num_amp_obs_steps * prm.num_amp_obs_per_step;
+}
 PHC_HD void amp_shift_lane(const phc_im_params_t& prm, const phc_im_buffers_t& buf, int64_t env, int lane, int nl) {
     const int A = prm.num_amp_obs_per_step, S = prm.num_amp_obs_steps;
-    const float* src = buf.amp_obs_in + env * (int64_t)(S * A);
-    float* dst = buf.amp_obs_out + env * (int64_t)(S * A) + A;
+    // the caller's new window starts one frame BEFORE the old one in the same strip: the old frames already sit where the shift would put
+    // them (phc_im_buffers_t.amp_env_stride: the strip is 2 S frames long, the window walks down it and is moved back up every S steps)
+    if (buf.amp_obs_out + A == buf.amp_obs_in) return;
+    const float* src = buf.amp_obs_in + env * amp_env_stride(prm, buf);
+    float* dst = buf.amp_obs_out + env * amp_env_stride(prm, buf) + A;
     const int n = (S - 1) * A;
     if ((A & 3) == 0) {
         const float4* s4 = reinterpret_cast<const float4*>(src);
@@ -275,7 +282,7 @@ PHC_HD RewardPartial im_post_lane(const phc_model_t& model, const phc_motion_lib
         st_joint(buf.ref_dof_pos + env * nd + model.ints[4 + 3 * PHC_MAX_BODIES + j], prm.dofs_per_joint, dp);
     }
     // AMP observation of this step -> slot 0 of the new history (humanoid_amp.py:204-209)
-    float* amp = buf.amp_obs_out + env * (int64_t)(prm.num_amp_obs_steps * prm.num_amp_obs_per_step);
+    float* amp = buf.amp_obs_out + env * amp_env_stride(prm, buf);
     amp_obs_from_sim_lane(prm, sim, nb, nd, env, j, root, hinv, model.ints + 4 + 3 * PHC_MAX_BODIES, amp);
     return rp;
 }
@@ -481,7 +488,7 @@ PHC_HD void im_reset_from_state_lane(const phc_model_t& model, const phc_motion_
             st_joint(buf.ref_dof_pos + env * nd + model.ints[4 + 3 * PHC_MAX_BODIES + j], prm.dofs_per_joint, dp);
         }
         // _compute_amp_observations(env_ids) -> slot 0; _init_amp_obs_default copies it into every history slot
-        float* amp = buf.amp_obs_out + env * (int64_t)(S * A);
+        float* amp = buf.amp_obs_out + env * amp_env_stride(prm, buf);
         const int nfill = fill_history ? S : 1;
         for (int k = 0; k < nfill; ++k)
             amp_obs_from_sim_lane(prm, sim, nb, nd, env, j, root, hinv, model.ints + 4 + 3 * PHC_MAX_BODIES, amp + k * A);
@@ -497,7 +504,7 @@ PHC_HD void im_reset_from_state_lane(const phc_model_t& model, const phc_motion_
 PHC_HD void im_reset_amp_lane(const phc_motion_lib_t& lib, const phc_im_params_t& prm, const phc_im_buffers_t& buf, int nb,
                               int64_t env, int j, float t, int k) {
     const int A = prm.num_amp_obs_per_step, S = prm.num_amp_obs_steps;
-    float* amp = buf.amp_obs_out + env * (int64_t)(S * A);
+    float* amp = buf.amp_obs_out + env * amp_env_stride(prm, buf);
     amp_obs_from_ref_lane(lib, prm, nb, j, buf.sampled_motion_ids[env], history_time(t, prm.dt, k), amp + k * A);
 }
 

@@ -441,8 +441,12 @@ class HumanoidIm:
         if self.zero_out_far and self._track_bodies[0] != self._body_names[0]:
             raise NotImplementedError("zero_out_far needs the root as the first track body (humanoid_im.py:785)")
         S, A = self._num_amp_obs_steps, self._num_amp_obs_per_step
-        self._amp_bufs = [torch.zeros((N, S, A), **f32), torch.zeros((N, S, A), **f32)]
-        self._amp_cur = 0
+        # AMP history (humanoid_amp.py:125-131): every env owns a strip of 2 S frames; the history is the window of S frames starting at
+        # row `_amp_head` (newest first, like `_amp_obs_buf` of the reference).  A step writes its frame in the row BEFORE the window and
+        # moves the head down: the old frames are where the reference's shift would put them, without the 14 KB per env of copy traffic;
+        # once the head reaches the top the window is moved back to the bottom half by one ordinary shifting launch (every S steps).
+        self._amp_strip = torch.zeros((N, 2 * S, A), **f32)
+        self._amp_head = S
         self._amp_obs_demo_buf = None
         self.self_obs_buf = self.obs_buf[:, :self.get_self_obs_size()]
         # self_obs_v 2: the past_track_steps previous rigid-body states per env (`_rigid_body_*_hist`, humanoid.py:229-232), kept by the kernels
@@ -510,11 +514,14 @@ class HumanoidIm:
                                      cycle_counter=self._cycle_counter, recovery_counter=self._recovery_counter,
                                      point_goal=self._point_goal, cycle_phase=self._cycle_phase, reset_list=self._reset_list,
                                      reset_count=self._reset_count, reset_slot=self._reset_slot, offset_rand=self._offset_rand,
-                                     body_state_hist=self._body_state_hist, occl_mask=self._occl_mask)
+                                     body_state_hist=self._body_state_hist, occl_mask=self._occl_mask, amp_env_stride=self._amp_strip.stride(0))
 
     @property
     def _amp_obs_buf(self):
-        return self._amp_bufs[self._amp_cur]
+        return self._amp_window(self._amp_head)
+
+    def _amp_window(self, head):
+        return self._amp_strip[:, head:head + self._num_amp_obs_steps]
 
     @property
     def _curr_amp_obs_buf(self):
@@ -697,8 +704,8 @@ class HumanoidIm:
     def post_physics_step(self):
         if (flags.im_eval, flags.no_collision_check) != self._flag_state:
             self._rebuild_im_params()
-        amp_in = self._amp_bufs[self._amp_cur]
-        amp_out = self._amp_bufs[1 - self._amp_cur]
+        new_head = self._amp_head - 1 if self._amp_head > 0 else self._num_amp_obs_steps
+        amp_in, amp_out = self._amp_window(self._amp_head), self._amp_window(new_head)
         if self.cycle_motion:
             # the draw behind `_sample_time` of the envs whose clip restarts this step (humanoid_im.py:1127); one value per
             # env is drawn (the reference draws only as many as restart, so the RNG streams differ in length, not in law)
@@ -712,7 +719,7 @@ class HumanoidIm:
         buf = self._buffers(amp_in, amp_out)
         L.check(self._lib.phc_im_post_physics(self._model_struct, self._motion_lib.struct, self._im_params, self._sim_struct, buf,
                                               _stream()), "phc_im_post_physics")
-        self._amp_cur = 1 - self._amp_cur
+        self._amp_head = new_head
         self._obs_noise()
         self.extras["terminate"] = self._terminate_buf         # humanoid.py:1649-1650
         self.extras["reward_raw"] = self.reward_raw.detach()
@@ -746,7 +753,7 @@ class HumanoidIm:
         phase = torch.rand(env_ids.shape, device=self.device) if self._state_init != HumanoidIm.StateInit.Start else None
         if self._far_start:
             torch.rand(self._offset_rand.shape, out=self._offset_rand)
-        cur = self._amp_bufs[self._amp_cur]
+        cur = self._amp_obs_buf
         buf = self._buffers(cur, cur)
         L.check(self._lib.phc_im_reset(self._model_struct, self._motion_lib.struct, self._im_params, self._sim_struct, buf, n,
                                        env_ids.data_ptr(), abi.ptr(phase), int(bool(start_at_zero)), _stream()), "phc_im_reset")
@@ -762,7 +769,7 @@ class HumanoidIm:
         zeroed afterwards: nothing reads reset_buf before the next post-physics launch rewrites every entry of it.  The envs come
         from the list the post-physics kernel built on the device (dense wavefronts; a masked sweep over all envs is the fallback)."""
         start_at_zero = (self._state_init == HumanoidIm.StateInit.Start) or flags.test
-        cur = self._amp_bufs[self._amp_cur]
+        cur = self._amp_obs_buf
         self._reset_counter += 1
         use_list = self._use_reset_list and self._reset_list_pending
         if self._far_start:

@@ -486,7 +486,7 @@ class IMAmpAgent:
                 res = {"actions": self.preprocess_actions(res["actions"])}
             self.obs, rewards, self.dones, infos = self.vec_env.step(res["actions"])
             rewards = rewards.unsqueeze(1) if rewards.dim() == 1 else rewards
-            e["amp_obs"][n].copy_(infos["amp_obs"])   # (eager: the task's AMP buffer is a ping-pong pair, its address alternates)
+            e["amp_obs"][n].copy_(infos["amp_obs"])   # (eager: the window of the task's AMP strip moves every step)
             if fused:
                 if self._reward_raw_acc is None:       # first rollout: creates the accumulator eagerly
                     seg_after(n, rewards, infos["terminate"], infos["reward_raw"])

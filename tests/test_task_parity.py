@@ -224,6 +224,47 @@ def test_task_obs_versions_vs_reference_golden(golden, backend, obs_v, upright):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("head", [10, 4, 0])
+def test_amp_history_window_in_a_strip_equals_the_shifted_buffers(golden, backend, head):
+    """phc_im_buffers_t.amp_env_stride: the AMP history as a window of S frames in a per-env strip of 2 S.  Writing the new frame in the row
+    before the window (heads 10, 4) or moving the window back to the lower half with the ordinary shift (head 0) leaves the same history,
+    newest first, as the reference's shift into a second buffer (humanoid_amp.py:662-670) -- and touches nothing outside the new window."""
+    be = get_backend(backend)
+    g, gl = golden("task_fns"), golden("motion_lib_eval")
+    model, mstruct, keepm = model_on(be)
+    lib, keep = motion_lib_on(be, gl)
+    N, S, A = g["body_pos"].shape[0], 10, 196
+    prm, keepp = make_im_params(be, model, N)
+    arrs, sim = _sim_arrays(be, g, N)
+    rng = np.random.default_rng(2)
+    hist = rng.standard_normal((N, S, A)).astype(F)
+
+    def run(amp_in, amp_out, **kw):
+        b = dict(progress=be.arr((g["progress"] - 1).astype(np.int64)), reset=be.zeros(N, np.int64), term=be.zeros(N, np.int64), rew=be.zeros(N),
+                 raw=be.zeros((N, 5)), obs=be.zeros((N, 934)), mids=be.arr(g["env_motion"].astype(np.int64)), st=be.arr(g["start_times"].astype(F)),
+                 so=be.zeros(N), goff=be.zeros((N, 3)))
+        buf = abi.im_buffers_struct(b["progress"], b["reset"], b["term"], b["rew"], b["raw"], b["obs"], amp_in, amp_out, b["mids"], b["st"], b["so"],
+                                    b["goff"], **kw)
+        assert be.im_post_physics(mstruct, lib, prm, sim, buf) == 0
+        be.sync()
+        return b
+    plain_in, plain_out = be.arr(hist), be.zeros((N, S, A))
+    run(plain_in, plain_out)
+    want = be.np(plain_out)
+    np.testing.assert_array_equal(want[:, 1:], hist[:, :-1])
+    strip_np = rng.standard_normal((N, 2 * S, A)).astype(F)
+    strip_np[:, head:head + S] = hist
+    strip = be.arr(strip_np)
+    new_head = head - 1 if head > 0 else S
+    run(strip[:, head:head + S], strip[:, new_head:new_head + S], amp_env_stride=2 * S * A)
+    got = be.np(strip)
+    np.testing.assert_array_equal(got[:, new_head:new_head + S], want)
+    untouched = np.ones(2 * S, bool)
+    untouched[new_head:new_head + S] = False
+    np.testing.assert_array_equal(got[:, untouched], strip_np[:, untouched])
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
 @pytest.mark.parametrize("obs_v,upright", [(6, True), (7, True), (9, True), (6, False), (9, False)])
 def test_task_obs_fut_tracks_vs_reference_golden(golden, backend, obs_v, upright):
     """env.fut_tracks with numTrajSamples = 3: the task block holds one standard obs_v 6 / 7 / 9 block per future reference sample, time-major,
