@@ -444,8 +444,8 @@ def main():
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
                          "note": "SURVEY 8(d) canonical un-fused accounting (1484 B x 4 sub-steps + 1812 B per env; the fused launch's compulsory "
-                                 "traffic is 3296 B/env).  The kernel is NOT HBM-bound: at 4096 envs it sits on the VALU-issue roofline of its "
-                                 "instruction stream (SQ counters: 0.99 of every SIMD's cycles VALU-active, profiles/r02_pmc_valu.txt, r02_notes.md)",
+                                 "traffic is 3296 B/env).  The kernel is NOT HBM-bound: at 4096 envs it is bound by the VALU issue of its "
+                                 "instruction stream (SQ counters: 16.7 k VALU instructions per wavefront, 0.82 of every SIMD's cycles VALU-active, profiles/r02_pmc_valu.txt, r02_notes.md)",
                          "gflops": FLOPS_PER_ENV_SUBSTEP * nsub * N / (kern_ms * 1e-3) / 1e9},
         }
         if ppo is not None:

@@ -2,8 +2,9 @@
 
 gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE counts 128-B fabric requests at 64 B -> read bytes = 2 x FETCH_SIZE;
 WRITE_SIZE is taken as is.  Both factors are CALIBRATED here on a kernel of this very path whose byte count is known:
-k_im_post_physics reads 14 124 B/env (body 1248 + dof 552 + dof_force 276 + 4 reference frames x 1248 + AMP history 7056) and
-writes 12 872 B/env (obs 3736 + AMP history 7840 + ref_* side buffers 1236 + flags 60); the table prints measured/expected."""
+k_im_post_physics reads 7 774 B/env (body 1248 + dof 552 + dof_force 276 + 4 reference frames x 1248 + AMP history shift 7056 on one step
+in ten -- the window-in-a-strip layout of round 2; 14 124 with plain shifted buffers) and writes 6 522 B/env (obs 3736 + new AMP frame 784 +
+shift 7056 / 10 + ref_* side buffers 1236 + flags 60; 12 872 before); the table prints measured/expected."""
 import collections
 import csv
 import json
@@ -35,8 +36,8 @@ def main(fetch_csv, write_csv, n_envs=4096):
     post = pick("k_im_post_physics")
     if post in out:
         o = out[post]
-        print(f"# calibration on k_im_post_physics: read {o['read_bytes'] / n_envs:.0f} B/env measured vs 14124 expected "
-              f"({o['read_bytes'] / n_envs / 14124:.2f}x), write {o['write_bytes'] / n_envs:.0f} vs 12872 ({o['write_bytes'] / n_envs / 12872:.2f}x)")
+        print(f"# calibration on k_im_post_physics: read {o['read_bytes'] / n_envs:.0f} B/env measured vs 7774 expected "
+              f"({o['read_bytes'] / n_envs / 7774:.2f}x), write {o['write_bytes'] / n_envs:.0f} vs 6522 ({o['write_bytes'] / n_envs / 6522:.2f}x)")
     print("JSON " + json.dumps(out))
 
 

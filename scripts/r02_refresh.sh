@@ -2,7 +2,7 @@
 # Round-2 measurement refresh on the GPU box: gpu tests, the default bench line, kernel-trace summaries (env step, PPO epoch), PMC traffic.
 O=gpurun_out/${1:-r2r}
 mkdir -p $O
-python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; tail -3 $O/pytest_gpu.log
+if [ -z "$SKIP_PYTEST" ]; then python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; tail -3 $O/pytest_gpu.log; fi
 python bench.py > $O/bench_default.json 2> $O/bench_default.err; tail -c 600 $O/bench_default.err
 python bench.py --actions tracking --no-cpu-baseline --no-pmc --ppo-epochs 0 > $O/bench_tracking.json 2>> $O/bench_default.err
 python bench.py --config 5 --ppo-epochs 0 --no-cpu-baseline --no-pmc > $O/bench_h1.json 2>> $O/bench_default.err
