@@ -181,10 +181,15 @@ PHC_HD void occlude_ref(const phc_im_buffers_t& buf, const phc_im_params_t& prm,
 
 // env.fut_tracks (humanoid_im.py:741-747): the blocks of the T - 1 further reference samples behind the standard one (obs_v 6 / 7 / 9 lay the
 // samples out time-major: one standard block each)
+// Called at the very END of the lane functions with everything re-derived from memory (`body` / `root`: the simulated -- or, in a reset,
+// the imposed -- state): inlined where the first block is formed, its registers stacked on top of the callers' live reference frames and
+// cost the post-physics and reset kernels a wavefront of occupancy each (189 / 149 VGPRs vs 160 / 118) for a path no shipped config takes.
 PHC_HD void task_obs_future_lane(const phc_motion_lib_t& lib, const phc_im_params_t& prm, int64_t mid, int64_t progress1, float start, float start_off,
-                                 V3 goff, int slot, int j, const BodyState& body, const BodyState& root, Q4 hinv, Q4 h, float* tobs) {
+                                 V3 goff, int slot, int j, const BodyState& body, const BodyState& root, float* tobs) {
     const int T = prm.num_traj_samples;
-    if (T <= 1 || !(prm.obs_v == 6 || prm.obs_v == 7 || prm.obs_v == 9)) return;
+    if (T <= 1 || slot < 0 || !(prm.obs_v == 6 || prm.obs_v == 7 || prm.obs_v == 9)) return;
+    const Q4 hroot = obs_root_rot(prm, root.rot);
+    const Q4 hinv = calc_heading_quat_inv(hroot), h = calc_heading_quat(hroot);
     const int block = prm.num_task_obs / T;
     for (int k = 1; k < T; ++k) {
         PHC_NO_CONTRACT
@@ -270,7 +275,6 @@ PHC_HD RewardPartial im_post_lane(const phc_model_t& model, const phc_motion_lib
             ref_joint(lib, fr1, j, &rjd, &rjv);
         }
         task_obs_lane(prm, slot, body, root, rt, hinv, h, obs + prm.num_self_obs, &jd, &rjd);
-        task_obs_future_lane(lib, prm, mid, c.progress + 1, c.start, c.start_off, c.goff, slot, j, body, root, hinv, h, obs + prm.num_self_obs);
     }
     // side-effect buffers of _compute_task_obs (humanoid_im.py:855-868)
     if (buf.ref_body_pos) st3(buf.ref_body_pos + (env * nb + j) * 3, r1.pos);
@@ -284,6 +288,9 @@ PHC_HD RewardPartial im_post_lane(const phc_model_t& model, const phc_motion_lib
     // AMP observation of this step -> slot 0 of the new history (humanoid_amp.py:204-209)
     float* amp = buf.amp_obs_out + env * amp_env_stride(prm, buf);
     amp_obs_from_sim_lane(prm, sim, nb, nd, env, j, root, hinv, model.ints + 4 + 3 * PHC_MAX_BODIES, amp);
+    if (prm.num_traj_samples > 1)   // env.fut_tracks: the further reference samples' blocks (see task_obs_future_lane)
+        task_obs_future_lane(lib, prm, mid, c.progress + 1, c.start, c.start_off, c.goff, prm.track_slot[j], j, load_body(sim.rigid_body_state, env, nb, j),
+                             load_body(sim.rigid_body_state, env, nb, 0), buf.obs_buf + env * (int64_t)(prm.num_self_obs + prm.num_task_obs) + prm.num_self_obs);
     return rp;
 }
 
@@ -405,7 +412,6 @@ PHC_HD void im_reset_lane(const phc_model_t& model, const phc_motion_lib_t& lib,
             V3 jd = v3(0.f, 0.f, 0.f), jv, rjd = jd, rjv;
             if (prm.obs_v == 2 && j >= 1) { ref_joint(lib, fr, j, &jd, &jv); ref_joint(lib, fr1, j, &rjd, &rjv); }   // (the imposed state is the reference at t)
             task_obs_lane(prm, slot, rs, root, rt, hinv, h, obs + prm.num_self_obs, &jd, &rjd);
-            task_obs_future_lane(lib, prm, mid, 1, t, 0.f, goff, slot, j, rs, root, hinv, h, obs + prm.num_self_obs);
         }
         if (buf.ref_body_pos) st3(buf.ref_body_pos + (env * nb + j) * 3, r1.pos);
         if (buf.ref_body_rot) st4(buf.ref_body_rot + (env * nb + j) * 4, r1.rot);
@@ -414,6 +420,13 @@ PHC_HD void im_reset_lane(const phc_model_t& model, const phc_motion_lib_t& lib,
             V3 dp, dv;
             ref_joint(lib, fr1, j, &dp, &dv);
             st_joint(buf.ref_dof_pos + env * nd + model.ints[4 + 3 * PHC_MAX_BODIES + j], prm.dofs_per_joint, dp);
+        }
+        if (prm.num_traj_samples > 1) {   // env.fut_tracks (see task_obs_future_lane): the imposed state is the reference at t
+            const FrameRef frt = frame_ref(lib, mid, t);
+            V3 go = v3(0.f, 0.f, 0.f);
+            if (buf.offset_rand && prm.zero_out_far && prm.zero_out_far_train) disk_offset(buf.offset_rand[env * 2], buf.offset_rand[env * 2 + 1], &go.x, &go.y);
+            task_obs_future_lane(lib, prm, mid, 1, t, 0.f, go, prm.track_slot[j], j, ref_body(lib, frt, j), ref_body(lib, frt, 0),
+                                 buf.obs_buf + env * (int64_t)(prm.num_self_obs + prm.num_task_obs) + prm.num_self_obs);
         }
     }
     if (j == 0) {
@@ -476,8 +489,6 @@ PHC_HD void im_reset_from_state_lane(const phc_model_t& model, const phc_motion_
                 ref_joint(lib, fr1, j, &rjd, &rjv);
             }
             task_obs_lane(prm, slot, body, root, rt, hinv, h, obs + prm.num_self_obs, &jd, &rjd);
-            task_obs_future_lane(lib, prm, mid, 1, buf.motion_start_times[env], buf.motion_start_times_offset[env], goff, slot, j, body, root, hinv, h,
-                                 obs + prm.num_self_obs);
         }
         if (buf.ref_body_pos) st3(buf.ref_body_pos + (env * nb + j) * 3, r1.pos);
         if (buf.ref_body_rot) st4(buf.ref_body_rot + (env * nb + j) * 4, r1.rot);
@@ -492,6 +503,10 @@ PHC_HD void im_reset_from_state_lane(const phc_model_t& model, const phc_motion_
         const int nfill = fill_history ? S : 1;
         for (int k = 0; k < nfill; ++k)
             amp_obs_from_sim_lane(prm, sim, nb, nd, env, j, root, hinv, model.ints + 4 + 3 * PHC_MAX_BODIES, amp + k * A);
+        if (prm.num_traj_samples > 1)   // env.fut_tracks (see task_obs_future_lane)
+            task_obs_future_lane(lib, prm, mid, 1, buf.motion_start_times[env], buf.motion_start_times_offset[env], ld3(buf.global_offset + env * 3),
+                                 prm.track_slot[j], j, load_body(sim.rigid_body_state, env, nb, j), load_body(sim.rigid_body_state, env, nb, 0),
+                                 buf.obs_buf + env * (int64_t)(prm.num_self_obs + prm.num_task_obs) + prm.num_self_obs);
     }
     if (j == 0) {
         buf.progress_buf[env] = 0; buf.terminate_buf[env] = 0; buf.reset_buf[env] = 0;  // humanoid.py:616-618

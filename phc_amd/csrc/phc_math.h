@@ -15,8 +15,10 @@
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define PHC_HD __host__ __device__ __forceinline__
+#define PHC_NOINLINE_HD __host__ __device__ __attribute__((noinline))   // rarely taken paths: kept out of the callers' register budget
 #else
 #define PHC_HD inline
+#define PHC_NOINLINE_HD inline
 struct float4 { float x, y, z, w; };  // host build only (oracle/hostemu)
 #endif
 
