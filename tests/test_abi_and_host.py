@@ -219,3 +219,46 @@ def test_bench_refuses_to_report_more_gpus_than_it_has():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True, text=True,
                        timeout=300, env=env)
     assert r.returncode != 0 and '"n_gpus"' not in r.stdout
+
+
+def test_solver_tree_reroots_the_smpl_humanoid_at_the_shallowest_base():
+    """model.py solver_tree(): the tree the stepper's backward / acceleration sweeps walk.  SMPL: base Spine, depth 6 (8 from the pelvis), at most
+    three solver children per body, the two bodies on the path pelvis -> base reversed (solver parent = their child on the path, reference
+    point = that child's joint anchor, solver joint = that child's joint); robots keep their root.  The packed inertia about the reference
+    point obeys the parallel-axis theorem against the inertia about the origin."""
+    from phc_amd.model import load_model
+    m = load_model("smpl_humanoid")
+    st = m.solver_tree()
+    names = m.body_names
+    assert names[st["base"]] == "Spine" and int(st["slevel"].max()) == 6 and m.max_level == 8
+    assert st["sparent"][st["base"]] == -1 and st["slevel"][st["base"]] == 0
+    assert max(len(c) for c in st["schildren"]) <= 3
+    for b in range(m.num_bodies):                      # a tree over the same joints: every solver edge is a kinematic edge
+        p = st["sparent"][b]
+        if p >= 0:
+            assert st["slevel"][b] == st["slevel"][p] + 1 and b in st["schildren"][p]
+            assert m.parent[b] == p or m.parent[p] == b
+    rev = [b for b in range(m.num_bodies) if st["sparent"][b] >= 0 and m.parent[st["sparent"][b]] == b]
+    assert [names[b] for b in rev] == ["Pelvis", "Torso"]
+    for b in rev:
+        c = st["sparent"][b]
+        np.testing.assert_array_equal(st["s_off"][b], m.local_translation[c])   # the joint anchor = the child's origin
+        assert st["jsrc"][b] == c and st["bsrc"][c] == b
+    assert all(st["jsrc"][b] == b and not st["s_off"][b].any() for b in range(m.num_bodies) if b not in rev and b != st["base"])
+    ints, fl = m.pack()
+    MB, BF = m.MAX_BODIES, m.BODY_FLOATS
+    tab = ints[4:4 + 20 * MB].reshape(20, MB)
+    assert tuple(tab[11, 2:4]) == (6, st["base"]) and (tab[13, :m.num_bodies] == st["sparent"]).all()
+    f = fl[:MB * BF].reshape(MB, BF).astype(np.float64)
+    for b in range(m.num_bodies):
+        so, mass, com = st["s_off"][b], m.mass[b], m.com[b]
+        np.testing.assert_allclose(f[b, 44:47], so, atol=1e-7)
+        np.testing.assert_allclose(f[b, 47:50], mass * (com - so), atol=1e-6)
+        sym = lambda v: np.array([[v[0], v[1], v[2]], [v[1], v[3], v[4]], [v[2], v[4], v[5]]])
+        Io, Ir = sym(f[b, 7:13]), sym(f[b, 50:56])
+        d0, d1 = com, com - so
+        shift = lambda d: mass * (d @ d * np.eye(3) - np.outer(d, d))
+        np.testing.assert_allclose(Ir - shift(d1), Io - shift(d0), atol=2e-6)                # same inertia about the centre of mass
+    for robot in ("h1_humanoid", "g1_humanoid"):
+        r = load_model(robot)
+        assert r.solver_tree()["base"] == 0
