@@ -118,9 +118,10 @@ def get_backend(name):
 BACKENDS = ["hostemu", pytest.param("hip", marks=pytest.mark.gpu)]
 
 
-def model_on(be, name="smpl_humanoid", kp_scale=1.0, kd_scale=1.0, zero_armature=False, anisotropic=False):
+def model_on(be, name="smpl_humanoid", kp_scale=1.0, kd_scale=1.0, zero_armature=False, anisotropic=False, reroot=True):
     from phc_amd.model import load_model
     m = load_model(name)
+    m.reroot = reroot   # False: the solver tree is the kinematic tree (model.py solver_tree())
     if anisotropic:   # different gains / armature on the three axes of every joint (the SMPL asset's are equal: the stepper's scalar-D path)
         w = np.tile(np.array([1.0, 0.6, 1.5]), m.num_dof // 3)
         m.dof_kp, m.dof_kd, m.dof_armature = m.dof_kp * w, m.dof_kd * w[::-1], m.dof_armature * w

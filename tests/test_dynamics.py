@@ -74,6 +74,31 @@ def test_aba_matches_dense_oracle(backend, num_sim_calls, height, anisotropic):
         assert n_contacts == 0
 
 
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("self_collision", [0, 1])
+def test_rerooted_solve_equals_the_pelvis_rooted_solve(backend, self_collision):
+    """The solver tree re-rooted at Spine (7 level-steps per sweep) and the kinematic tree (9) solve the same equations: after two simulate
+    calls from random states -- ground contact, PD drives, body-body contact -- every simulator tensor agrees to fp32 rounding."""
+    be = get_backend(backend)
+    rng = np.random.default_rng(23)
+    outs = []
+    for reroot in (True, False):
+        model, mstruct, keep = model_on(be, reroot=reroot)
+        if not outs:
+            root, dof, target = random_states(model, 8, rng, height=0.85)
+        params = abi.sim_params_struct(self_collision=self_collision, lane_mapping=1)
+        outs.append(run_step(be, model, mstruct, root, dof, target, params, 2))
+    assert int(model_on(be, reroot=True)[0].solver_tree()["base"]) != 0 and int(model.solver_tree()["base"]) == 0
+    a, b = outs
+    np.testing.assert_allclose(a["root"], b["root"], atol=2e-4, rtol=1e-4)
+    np.testing.assert_allclose(a["dof"][..., 1], b["dof"][..., 1], atol=4e-3, rtol=1e-3)
+    np.testing.assert_allclose(a["rbs"][..., 0:3], b["rbs"][..., 0:3], atol=2e-4)
+    np.testing.assert_allclose(a["rbs"][..., 7:13], b["rbs"][..., 7:13], atol=4e-3, rtol=1e-3)
+    np.testing.assert_allclose(a["df"], b["df"], atol=0.2, rtol=3e-3)
+    np.testing.assert_allclose(a["cf"], b["cf"], atol=0.6, rtol=6e-3)
+    assert np.abs(a["cf"]).sum() > 0
+
+
 def _free_params(**kw):
     d = dict(gravity_z=0.0, contact_stiffness=0.0, contact_damping=0.0, friction=0.0, friction_viscous=0.0, angular_damping=0.0)
     d.update(kw)
