@@ -85,7 +85,7 @@ class HumanoidIm:
             raise NotImplementedError(f"humanoid_type={self.humanoid_type!r}: built so far: smpl, h1, g1")
         self._is_robot = self.humanoid_type in ("h1", "g1")
         # options of the reference this path does not build: refuse them rather than run without them
-        unsupported = dict(fut_tracks_dropout=False, kin_loss=False, z_readout=False, distill=False, enableHistObs=False, remove_disc_rot=False,
+        unsupported = dict(kin_loss=False, z_readout=False, distill=False, enableHistObs=False, remove_disc_rot=False,
                            divide_group=False, group_obs=False, add_action_noise=False, is_discrete=False)
         for k, off in unsupported.items():
             v = env.get(k, robot.get(k, off))
@@ -101,9 +101,12 @@ class HumanoidIm:
         self._fut_tracks = bool(env.get("fut_tracks", False))
         self._num_traj_samples = int(env["numTrajSamples"]) if self._fut_tracks else 1
         self._traj_sample_timestep = 1 / env.get("trajSampleTimestepInv", 30)
+        self._fut_tracks_dropout = bool(env.get("fut_tracks_dropout", False)) and self._num_traj_samples > 1   # humanoid_im.py:40,824-830
         if self._fut_tracks and self._num_traj_samples > 1:
             if self.obs_v not in (6, 7, 9):
                 raise NotImplementedError("fut_tracks: built for the time-major task observations obs_v 6 / 7 / 9")
+            if env.get("fut_tracks_dropout", False) and self.obs_v == 7:
+                raise NotImplementedError("fut_tracks_dropout: the reference drops samples in the obs_v 4 / 5 / 6 / 8 / 9 branch only (humanoid_im.py:824-830)")
             if env.get("zero_out_far", False):
                 raise NotImplementedError("fut_tracks with zero_out_far: the reference's far-mask indexes a single-sample block (humanoid_im.py:785-800)")
         if self.self_obs_v == 2 and (self._is_robot or robot.get("has_shape_obs", False) or robot.get("has_weight_obs", False)):
@@ -785,6 +788,26 @@ class HumanoidIm:
         self._obs_noise(reset_rows=True)
 
     def _obs_noise(self, env_ids=None, reset_rows=False):
+        self._fut_dropout(env_ids, reset_rows)
+        self._add_obs_noise(env_ids, reset_rows)
+
+    def _fut_dropout(self, env_ids=None, reset_rows=False):
+        """env.fut_tracks_dropout (humanoid_im.py:824-830): every reference sample of a freshly computed task observation is zeroed with
+        probability 0.1, not in test mode; before the observation noise, as in the reference.  Rows as in `_add_obs_noise`."""
+        if not self._fut_tracks_dropout or flags.test:
+            return
+        so, T = self.get_self_obs_size(), self._num_traj_samples
+        rows = self.num_envs if env_ids is None else len(env_ids)
+        keep = (torch.rand((rows, T), device=self.device) >= 0.1).to(self.obs_buf.dtype)
+        if env_ids is not None:
+            blocks = self.obs_buf[env_ids, so:].view(rows, T, -1) * keep[:, :, None]
+            self.obs_buf[env_ids, so:] = blocks.view(rows, -1)
+            return
+        if reset_rows:   # only the rows whose reset flag is set are fresh
+            keep = torch.where((self.reset_buf != 0)[:, None], keep, torch.ones_like(keep))
+        self.obs_buf[:, so:].view(rows, T, -1).mul_(keep[:, :, None])
+
+    def _add_obs_noise(self, env_ids=None, reset_rows=False):
         """env.add_obs_noise (humanoid_im.py:710-711): N(0, 0.1) on every freshly computed observation row, not in test mode.  Rows: all (the
         step), `env_ids` (reset(env_ids)) or the rows whose reset flag is set (reset_done: a masked add, no device -> host sync)."""
         if not self.add_obs_noise or flags.test:

@@ -953,3 +953,26 @@ def test_add_obs_noise_perturbs_every_fresh_observation_row_once():
         assert torch.equal(o, o0)
     finally:
         flags.test = False
+
+
+def test_fut_tracks_dropout_zeroes_a_tenth_of_the_reference_samples():
+    """env.fut_tracks_dropout (humanoid_im.py:824-830): each of the numTrajSamples blocks of a fresh task observation is zeroed with probability
+    0.1 -- on the step's rows and on reset rows -- and never in test mode."""
+    from phc_amd.utils.flags import flags
+    N, T = 2048, 3
+    task, env = make_task(N, motion="synthetic:3:1", **{"env.fut_tracks": True, "env.numTrajSamples": T, "+env.fut_tracks_dropout": True})
+    so = task.get_self_obs_size()
+
+    def zero_share():
+        blocks = task.obs_buf[:, so:].view(N, T, -1)
+        return float((blocks.abs().amax(dim=-1) == 0).float().mean())
+    env.reset()
+    assert abs(zero_share() - 0.1) < 0.02                 # reset(env_ids) rows
+    task.step(torch.zeros(N, task.get_action_size(), device=task.device))
+    assert abs(zero_share() - 0.1) < 0.02                 # the step's rows
+    flags.test = True
+    try:
+        env.reset()
+        assert zero_share() == 0.0
+    finally:
+        flags.test = False
