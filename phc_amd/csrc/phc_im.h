@@ -518,7 +518,7 @@ PHC_HD void im_reset_from_state_lane(const phc_model_t& model, const phc_motion_
 // every (env, k) pair its own 32-lane group.
 PHC_HD void im_reset_amp_lane(const phc_motion_lib_t& lib, const phc_im_params_t& prm, const phc_im_buffers_t& buf, int nb,
                               int64_t env, int j, float t, int k) {
-    const int A = prm.num_amp_obs_per_step, S = prm.num_amp_obs_steps;
+    const int A = prm.num_amp_obs_per_step;
     float* amp = buf.amp_obs_out + env * amp_env_stride(prm, buf);
     amp_obs_from_ref_lane(lib, prm, nb, j, buf.sampled_motion_ids[env], history_time(t, prm.dt, k), amp + k * A);
 }
