@@ -414,14 +414,14 @@ def main():
         if world == 1 and not args.no_pmc and not os.environ.get("PHC_BENCH_CHILD"):
             tail = ["--envs", str(args.envs), "--robot", args.robot, "--lane-mapping", str(args.lane_mapping), "--actions", args.actions,
                     "--motion-clips", str(args.motion_clips), "--self-collision", str(args.self_collision)]
-            traffic, detail = live_pmc_traffic(tail, ("k_sim_quad", "k_sim_step16", "k_sim_step<true"))
+            traffic, detail = live_pmc_traffic(tail, ("k_sim_step<true",))
             traffic_src = {"live": detail} if traffic is not None else None
             if traffic is None:
                 print(f"[bench] live PMC traffic unavailable ({detail}); falling back to the committed profile", file=sys.stderr)
         pmc = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json"))
         if traffic is None and pmc and N == 4096 and args.robot == "smpl":
             tab = json.load(open(os.path.join(ROOT, "profiles", pmc[-1])))
-            rec = next((v for k, v in tab.items() if k.startswith("k_sim_step16")), None) or next((v for k, v in tab.items() if k.startswith("k_sim_step<true")), None)
+            rec = next((v for k, v in tab.items() if k.startswith("k_sim_step<true")), None)
             if rec:
                 traffic, traffic_src = rec["traffic_bytes"], "profiles/" + pmc[-1]
         achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
@@ -439,7 +439,7 @@ def main():
                        "obs": task.num_obs, "amp_obs": task.get_num_amp_obs(), "parallelism": f"env-sharded x{world}",
                        "self_collision": bool(task._sim_params.self_collision)},
             "roofline": {"kernel": "phc_sim_step -> %s (A2 + %d ABA sub-steps + S7 publication)" % (
-                             (traffic_src["live"]["kernel"] if isinstance(traffic_src, dict) else "k_sim_step (one body per lane) / k_sim_step16 (two-slot), picked per launch"), nsub),
+                             (traffic_src["live"]["kernel"] if isinstance(traffic_src, dict) else "k_sim_step (one body per lane)"), nsub),
                          "bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_per_launch,

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PHC_ABI_VERSION 30
+#define PHC_ABI_VERSION 31
 #define PHC_MAX_BODIES 64   /* bodies (incl. extended reference bodies) per articulation; also the slot count of the model tables */
 #define PHC_EINVAL (-1)
 #define PHC_EUNSUPPORTED (-2)
@@ -44,8 +44,6 @@ typedef struct {
     int32_t num_contact_pts;
     const int32_t* ints;      /* packed tables, see model.py pack() */
     const float* floats;
-    int32_t split_level;      /* two-slot stepper mapping: bodies of tree levels < split_level share lanes with the deeper ones; */
-    int32_t num_below_split;  /* -1 / 0 when the tree has no split with both halves <= 16 (NB <= 32) or <= 32 bodies (ArticulationModel.two_slot_split) */
     int32_t num_collision_pairs; /* body pairs that may collide (listed after the int tables); capacity 576 (NB <= 32) / 1152, see phc_sim_step */
     /* Per-env body shapes (robot.has_shape_variation, humanoid.py:726-766,824-866): K compiled articulations with ONE topology (names,
      * parents, joint types) but their own link offsets, masses, inertias, gains, collision geometry.  ints / floats then hold K blocks
@@ -122,8 +120,8 @@ typedef struct {
                                          (mu = reduced mass) and damping ratio self_damping_ratio */
     float self_stiffness_scale;       /* <= 1 (explicit stability bound is 4); default 0.25 */
     float self_damping_ratio;         /* default 0.5 */
-    int32_t lane_mapping;             /* stepper thread mapping: 2 = two bodies per lane (16 lanes per env, 4 envs per wavefront; NB > 32: 32 lanes, 2 envs);
-                                         1 = one body per lane (32 lanes per env, 2 envs per wavefront; NB > 32: 64 lanes, 1 env); 0 = pick by env count */
+    int32_t lane_mapping;             /* stepper thread mapping: 0 / 1 = one body per lane (32 lanes per env, 2 envs per wavefront; NB > 32: 64 lanes,
+                                         1 env); other values PHC_EUNSUPPORTED (2 was the two-bodies-per-lane kernel of rounds 1-2, removed in ABI 31) */
     int32_t num_force_sensors;        /* S <= 4: force sensors (env.force_sensor_joints, default L_Ankle / R_Ankle, humanoid.py:268) */
     int32_t force_sensor_body[4];     /* body id of each sensor */
 } phc_sim_params_t;

@@ -64,7 +64,11 @@ static int emu_sim_step_t(const phc_model_t* model_all, const phc_sim_params_t* 
                 for (int l = 0; l <= sd; ++l) for (int j = 0; j < nb; ++j) aba_accel_level<JT>(L[j], l, j, x);
                 if (JT == PHC_JT_SPHERICAL && rerooted) for (int j = 0; j < nb; ++j) aba_accel_finish(L[j], *model, j, x);
                 for (int j = 0; j < nb; ++j) aba_integrate_joint<JT>(L[j], *prm, dt);
-                for (int l = 0; l <= ml; ++l) for (int j = 0; j < nb; ++j) aba_fk_level(L[j], l, j, x);
+                for (int j = 0; j < nb; ++j) aba_fk_jump_begin(L[j], j, x);
+                for (int k = 0, ks = model_jump_steps(*model); k < ks; ++k) {   // all bodies read the previous step's slots, then all write
+                    for (int j = 0; j < nb; ++j) aba_fk_jump_step(L[j], k, x);
+                    for (int j = 0; j < nb; ++j) aba_write_kin(L[j], xslot(x, j), Xch::es, 6);
+                }
             }
         }
         for (int j = 0; j < nb; ++j) {

@@ -56,7 +56,7 @@ def np_model(name="smpl_humanoid", kp_scale=1.0, kd_scale=1.0):
     from phc_amd.robots import apply_collision_filter
     apply_collision_filter(m, name.split("_")[0] if name in ("h1_humanoid", "g1_humanoid") else "smpl")
     ints, floats = m.pack(kp_scale, kd_scale)
-    return m, abi.model_struct(ints, floats, m.num_bodies, m.num_dof, m.max_level, len(m.contact_body), split=m.two_slot_split()), (ints, floats)
+    return m, abi.model_struct(ints, floats, m.num_bodies, m.num_dof, m.max_level, len(m.contact_body)), (ints, floats)
 
 
 def np_motion_lib(lib):

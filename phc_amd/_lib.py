@@ -23,7 +23,7 @@ c_p = C.c_void_p
 
 class Model(C.Structure):
     _fields_ = [("num_bodies", c_i32), ("num_dof", c_i32), ("max_level", c_i32), ("num_contact_pts", c_i32),
-                ("ints", c_p), ("floats", c_p), ("split_level", c_i32), ("num_below_split", c_i32), ("num_collision_pairs", c_i32),
+                ("ints", c_p), ("floats", c_p), ("num_collision_pairs", c_i32),
                 ("num_shapes", c_i32), ("int_stride", c_i32), ("float_stride", c_i32)]
 
 
@@ -133,7 +133,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the .so does not export the symbol
         fn.argtypes = argtypes
         fn.restype = restype
-    if lib.phc_abi_version() != 30:
+    if lib.phc_abi_version() != 31:
         raise ImportError("libphc_amd.so ABI version mismatch")
     _lib = lib
     return lib

@@ -10,7 +10,7 @@ import numpy as np
 from . import _lib as L
 
 MAX_BODIES = 64  # PHC_MAX_BODIES
-NUM_INT_TABLES = 20  # PHC_NTAB
+NUM_INT_TABLES = 21  # PHC_NTAB
 
 
 def ptr(x):
@@ -24,7 +24,7 @@ def ptr(x):
     return x.data_ptr()
 
 
-def model_struct(ints, floats, num_bodies, num_dof, max_level, num_contact_pts, split=(-1, 0), num_shapes=1):
+def model_struct(ints, floats, num_bodies, num_dof, max_level, num_contact_pts, num_shapes=1):
     """`num_shapes` > 1: ints / floats are [K, ...] stacks of K packed models of one topology (model.py pack_shapes())."""
     m = L.Model()
     m.num_shapes = int(num_shapes)
@@ -34,7 +34,6 @@ def model_struct(ints, floats, num_bodies, num_dof, max_level, num_contact_pts, 
         m.num_collision_pairs = int(ints[:, 4 + NUM_INT_TABLES * MAX_BODIES].max())
     else:
         m.num_collision_pairs = int(ints.reshape(-1)[4 + NUM_INT_TABLES * MAX_BODIES])   # count stored right after the int tables (model.py pack())
-    m.split_level, m.num_below_split = int(split[0]), int(split[1])
     m.num_bodies, m.num_dof, m.max_level, m.num_contact_pts = num_bodies, num_dof, max_level, num_contact_pts
     m.ints, m.floats = ptr(ints), ptr(floats)
     return m

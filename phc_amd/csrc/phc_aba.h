@@ -35,7 +35,7 @@ namespace phc {
 #define PHC_SC_NSCALE 4096.0f
 #define PHC_JT_SPHERICAL 1     // joint types as model.py numbers them
 #define PHC_JT_REVOLUTE 2
-#define PHC_NTAB 20            // int tables per model (parent level jtype dof_start child0-2 nchild cp_start cp_count order misc collide-mask | solver tree: parent level child0-2 nchild jsrc/bsrc)
+#define PHC_NTAB 21            // int tables per model (parent level jtype dof_start child0-2 nchild cp_start cp_count order misc collide-mask | solver tree: parent level child0-2 nchild jsrc/bsrc | pointer-jumping anchors)
 
 struct Sym3 { float xx, xy, xz, yy, yz, zz; };
 
@@ -106,6 +106,7 @@ struct AbaLane {
     // solver tree (model.py solver_tree(): the same articulation rooted at the body that minimises the depth -- the backward and the
     // acceleration sweeps walk THIS tree; identical to the kinematic tree unless the model re-roots):
     int sparent, slevel, nchild, child[3];   // (children: of the solver tree)
+    int anchors;      // kinematics by pointer jumping: the body's anchor in steps 0..3, 8 bits each (0xff: already in the world frame)
     int jsrc;         // body whose joint links this body to its solver parent (itself; its solver parent for a REVERSED body; -1 base)
     int bsrc;         // bodies whose own joint is solved by a reversed body: that body (their kinematic parent), else -1
     V3 r_local;       // offset from parent origin, parent frame
@@ -166,6 +167,7 @@ PHC_HD SolverRef model_solver_ref(const float* f, bool reroot) {
 PHC_HD void aba_load_model(AbaLane& L, const phc_model_t& m, int j, bool reroot = true) {
     L.parent = model_tab(m, 0, j); L.level = model_tab(m, 1, j);
     L.dof_start = model_tab(m, 3, j);
+    L.anchors = model_tab(m, 20, j);
     if (reroot) {
         L.sparent = model_tab(m, 13, j); L.slevel = model_tab(m, 14, j);
         L.child[0] = model_tab(m, 15, j); L.child[1] = model_tab(m, 16, j); L.child[2] = model_tab(m, 17, j);
@@ -279,6 +281,37 @@ PHC_HD void aba_fk_level(AbaLane& L, int level, int j, const Xch& x) {
                                    v3(ps[13 * es], ps[14 * es], ps[15 * es]), v3(ps[16 * es], ps[17 * es], ps[18 * es]));
     }
     aba_write_kin(L, xslot(x, j), es, 6);
+}
+
+// ---- kinematics sweep by POINTER JUMPING (the sweep of every sub-step; the launch's first one stays level by level) ----
+// Level by level the sweep is max_level + 1 dependent level-steps of ~70 instructions (9 for SMPL).  Here every body starts from its
+// transform relative to its parent -- pose (q, r_local), relative angular velocity q w_J, relative velocity of its origin 0 -- and in
+// step k composes it with its anchor's (anchor = parent at first); the anchor's anchor becomes the new anchor, so the distance covered
+// doubles per step and ceil(log2(depth + 1)) steps (4 for SMPL) with every lane busy leave the world kinematics in L.Q / p / w / v and
+// in slot [6..19), exactly where aba_fk_level leaves them.  Composition of B (relative to frame a) after A (frame a relative to X):
+//   Q = Qa Qb,  p = pa + Qa pb,  w = wa + Qa wb,  v = va + wa x (Qa pb) + Qa vb.
+PHC_HD int model_jump_steps(const phc_model_t& m) { return model_tab(m, 11, 4); }
+PHC_HD void aba_fk_jump_begin(AbaLane& L, int j, const Xch& x) {
+    if (L.level < 0) return;
+    if (L.level == 0) { L.Q = L.q; }   // (p, w, v: the root's state itself, already world)
+    else { L.Q = L.q; L.p = L.r_local; L.w = quat_rotate(L.q, L.wj); L.v = v3(0.f, 0.f, 0.f); }
+    aba_write_kin(L, xslot(x, j), Xch::es, 6);
+}
+// one step: read the anchor's transform as the previous step left it and compose (the caller writes the result back after a barrier)
+PHC_HD void aba_fk_jump_step(AbaLane& L, int k, const Xch& x) {
+    if (L.level < 0) return;
+    const int a = (L.anchors >> (8 * k)) & 0xff;
+    if (a == 0xff) return;
+    constexpr int es = Xch::es;
+    const float* s = xslot(x, a);
+    const Q4 Qa = q4(s[6 * es], s[7 * es], s[8 * es], s[9 * es]);
+    const V3 pa = v3(s[10 * es], s[11 * es], s[12 * es]), wa = v3(s[13 * es], s[14 * es], s[15 * es]), va = v3(s[16 * es], s[17 * es], s[18 * es]);
+    const M3 Ra = quat_to_mat(Qa);
+    const V3 r = mat_mul(Ra, L.p);
+    L.v = va + cross(wa, r) + mat_mul(Ra, L.v);
+    L.w = wa + mat_mul(Ra, L.w);
+    L.p = pa + r;
+    L.Q = quat_mul16(Qa, L.Q);
 }
 
 // ---- per-body initialisation of I^A, p^A and of the joint drive (no communication) ----

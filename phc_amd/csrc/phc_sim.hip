@@ -13,7 +13,7 @@
 
 using namespace phc;
 
-// Phase profile of the two-slot stepper (scripts/sim_phase_profile.py builds a SEPARATE library with -DPHC_SIM_PROFILE; the product
+// Phase profile of the stepper (scripts/sim_phase_profile.py builds a SEPARATE library with -DPHC_SIM_PROFILE; the product
 // library never contains this): per-wavefront s_memtime deltas accumulated per phase, summed over wavefronts into a device array.
 #ifdef PHC_SIM_PROFILE
 __device__ unsigned long long g_phc_prof[16];
@@ -50,9 +50,7 @@ __device__ __forceinline__ float pd_target_of(const phc_sim_state_t& sim, const 
 
 
 // ------------------------------------------------------------------------------------------
-// Staged epilogue (round 2).  The phase profile of the two-slot kernel (scripts/sim_phase_profile.py, profiles/r02_notes.md) put
-// 20 % of a wavefront's cycles into "store + publish": ~50 scattered 4-byte global stores per lane, issued by all 1024 wavefronts
-// at the same instant.  The output slices of the E consecutive envs of ONE wavefront are contiguous and 16-byte aligned in every
+// Staged epilogue.  A lane would otherwise issue ~50 scattered 4-byte global stores, all wavefronts at the same instant.  The output slices of the E consecutive envs of ONE wavefront are contiguous and 16-byte aligned in every
 // simulator tensor (E * 13, E * NB * 13, E * ND * 2, ... floats), so the lanes first write their values into the (now idle) LDS
 // exchange area in exactly that layout and the wavefront then streams each slice out with coalesced dwordx4 / dwordx2 stores.
 // ------------------------------------------------------------------------------------------
@@ -158,6 +156,7 @@ __global__ __launch_bounds__(64, 2) void k_sim_step(phc_model_t model_all, phc_s
         if (prm.self_collision) aba_load_pairs(pairs, model, lane, GRP);
         // the backward / acceleration sweeps walk the solver tree (model.py solver_tree(): re-rooted where that makes it shallower)
         const int solver_depth = model_solver_depth(model, true);
+        const int jump_steps = model_jump_steps(model);
         const bool rerooted = model_tab(model, 11, 3) != 0;
         for (int s = 0; s < nsub; ++s) {
             if (prm.self_collision) {   // body-body contact from the kinematics the last sweep left in the exchange slots
@@ -181,7 +180,14 @@ __global__ __launch_bounds__(64, 2) void k_sim_step(phc_model_t model_all, phc_s
             for (int l = 0; l <= solver_depth; ++l) { aba_accel_level<JT>(L, l, lane, x); __syncthreads(); }
             if (JT == PHC_JT_SPHERICAL && rerooted) aba_accel_finish(L, model, lane, x);
             aba_integrate_joint<JT>(L, prm, dt);
-            for (int l = 0; l <= max_level; ++l) { aba_fk_level(L, l, lane, x); __syncthreads(); }
+            aba_fk_jump_begin(L, lane, x);   // kinematics by pointer jumping: jump_steps composition steps instead of max_level + 1 level-steps
+            __syncthreads();
+            for (int k = 0; k < jump_steps; ++k) {
+                aba_fk_jump_step(L, k, x);
+                __syncthreads();
+                if (active) aba_write_kin(L, xslot(x, lane), Xch::es, 6);
+                __syncthreads();
+            }
             PHC_PROF(7)
         }
     }
@@ -206,133 +212,12 @@ __global__ __launch_bounds__(64, 2) void k_sim_step(phc_model_t model_all, phc_s
     if (STEP) { PHC_PROF_FLUSH }
 }
 
-// ------------------------------------------------------------------------------------------
-// Two-slot variant of the step kernel: GRP = 16 lanes per env, FOUR envs per wavefront (GRP = 32, two envs, for articulations
-// of more than 32 bodies), each lane carries two bodies -- slot A a
-// body of the shallow tree levels (< split), slot B one of the deep levels.  At any tree level all active bodies sit in one
-// slot, so a level-step executes exactly one copy of the level code (wave-uniform branch), as in the 32-lane kernel, but the
-// launch has half the wavefronts.  Measured on MI355X (scripts/gpu_sweep_small.sh): the 32-lane kernel takes 76-85 us with
-// one wavefront per SIMD (<= 2048 envs) and 106 us with two or three (4096-6144 envs) -- it is bound by the latency of one
-// wavefront's 72 dependent level-steps, so halving the wavefront count at N = 4096 moves it onto the one-per-SIMD plateau.
-// ------------------------------------------------------------------------------------------
-template <int JT, int GRP, bool SHAPES = false>
-__global__ __launch_bounds__(64, 1) void k_sim_step16(phc_model_t model_all, phc_sim_params_t prm, phc_sim_state_t sim,
-                                                  const float* __restrict__ actions, const float* __restrict__ pd_off,
-                                                  const float* __restrict__ pd_scale, const int32_t* __restrict__ freeze,
-                                                  int num_sim_calls) {
-    __shared__ float xch_all[128 * PHC_XCH_STRIDE];   // two exchange slots (bodies) per lane
-    __shared__ float cap_all[128 * PHC_CAP_STRIDE];
-    const int lane = threadIdx.x & (GRP - 1);
-    const int grp = threadIdx.x / GRP;
-    const int64_t env = (int64_t)blockIdx.x * (64 / GRP) + grp;
-    // SHAPES (per-env body shapes): the env's block of the model tables -- a per-lane pointer pair; the single-shape instantiation keeps the
-    // tables behind scalar registers (with the select compiled in unconditionally the kernel spilled 188 B / lane: 35 MB of scratch traffic)
-    const phc_model_t model = SHAPES ? model_for_env(model_all, sim, env) : model_all;
-    const int nb = model.num_bodies, nd = model.num_dof;
-    const int split = model.split_level, nA = model.num_below_split;
-    const bool env_ok = env < sim.num_envs;
-    const int jA = (env_ok && lane < nA) ? model_tab(model, 10, lane) : -1;
-    const int jB = (env_ok && lane < nb - nA) ? model_tab(model, 10, nA + lane) : -1;
-    Xch x;
-    x.base = xch_all + grp * 2 * GRP * PHC_XCH_STRIDE;
-    constexpr int ndj = JT == PHC_JT_REVOLUTE ? 1 : 3;
-
-    AbaLane LA, LB;
-    LA.level = LB.level = LA.slevel = LB.slevel = -1;
-    PHC_PROF_DECL
-    auto load = [&](AbaLane& L, int j) {
-        aba_load_model(L, model, j, false);   // two-slot: the slots are split by kinematic level, so the solve stays on the kinematic tree
-        if (JT == PHC_JT_REVOLUTE) aba_load_model_rev(L, model, j);
-        if (actions != nullptr && j >= 1) {
-            for (int k = 0; k < ndj; ++k) {
-                const int d = L.dof_start + k;
-                sim.pd_target[env * nd + d] = pd_target_of(sim, actions, pd_off, pd_scale, freeze, env, nd, d);
-            }
-        }
-        aba_load_state<JT>(L, sim, nd, env, j);
-    };
-    if (jA >= 0) load(LA, jA);
-    if (jB >= 0) load(LB, jB);
-    const int max_level = model.max_level;
-    for (int l = 0; l <= max_level; ++l) {
-        if (l < split) aba_fk_level(LA, l, jA, x); else aba_fk_level(LB, l, jB, x);
-        __syncthreads();
-    }
-    const float dt = prm.sim_dt / (float)prm.substeps;
-    const int nsub = num_sim_calls * prm.substeps;
-    PairList<(GRP == 32 ? PHC_SC_MAX_PER_LANE_WIDE : PHC_SC_MAX_PER_LANE)> pairs;
-    uint32_t near_pairs = 0;
-    if (prm.self_collision) aba_load_pairs(pairs, model, lane, GRP);
-    PHC_PROF(0)
-    for (int s = 0; s < nsub; ++s) {
-        const bool fresh = s % prm.substeps == 0;
-        if (prm.self_collision) {   // body-body contact from the kinematics the last sweep left in the exchange slots
-            float* caps = cap_all + grp * 2 * GRP * PHC_CAP_STRIDE;
-            if (jA >= 0) aba_publish_capsule(LA, model_body(model, jA), caps + PHC_CAP_STRIDE * jA);
-            if (jB >= 0) aba_publish_capsule(LB, model_body(model, jB), caps + PHC_CAP_STRIDE * jB);
-            __syncthreads();
-            if (env_ok) aba_collide_pairs(pairs, prm, dt, x, caps, near_pairs, s == 0);
-            __syncthreads();
-            if (jA >= 0) aba_collect_self(LA, jA, caps);
-            if (jB >= 0) aba_collect_self(LB, jB, caps);
-        }
-        PHC_PROF(1)
-        // slot A's articulated quantities are initialised only when the sweep reaches its levels: while the deep (slot B) levels
-        // run, slot A holds kinematic state only (27 fewer live registers)
-        if (jB >= 0) { aba_velocity_products(LB, model, jB, x, false); aba_body_init<JT>(LB, model, prm, dt, jB, fresh, false); }
-        PHC_PROF(2)
-        for (int l = max_level; l >= split; --l) { aba_backward_level<JT>(LB, l, jB, x); __syncthreads(); }
-        PHC_PROF(3)
-        if (jA >= 0) { aba_velocity_products(LA, model, jA, x, false); aba_body_init<JT>(LA, model, prm, dt, jA, fresh, false); }
-        PHC_PROF(4)
-        for (int l = split - 1; l >= 0; --l) { aba_backward_level<JT>(LA, l, jA, x); __syncthreads(); }
-        PHC_PROF(5)
-        for (int l = 0; l < split; ++l) { aba_accel_level<JT>(LA, l, jA, x); __syncthreads(); }
-        for (int l = split; l <= max_level; ++l) { aba_accel_level<JT>(LB, l, jB, x); __syncthreads(); }
-        PHC_PROF(6)
-        aba_integrate_joint<JT>(LA, prm, dt);
-        aba_integrate_joint<JT>(LB, prm, dt);
-        for (int l = 0; l < split; ++l) { aba_fk_level(LA, l, jA, x); __syncthreads(); }
-        for (int l = split; l <= max_level; ++l) { aba_fk_level(LB, l, jB, x); __syncthreads(); }
-        PHC_PROF(7)
-    }
-    constexpr int E = 64 / GRP;                       // envs per wavefront
-    const int64_t env0 = (int64_t)blockIdx.x * E;
-    const StageLayout so = stage_layout(E, nb, nd, sim.dof_force != nullptr, sim.contact_force != nullptr);
-    if (env0 + E <= sim.num_envs && stage_aligned(sim) && so.total <= 128 * PHC_XCH_STRIDE) {   // wave-uniform
-        float* stage = xch_all;                           // the exchange slots are dead after the last forward level-step
-        const phc_sim_state_t st = stage_state(sim, stage, so);
-        if (jA >= 0) { aba_store_state<JT>(LA, st, nd, grp, jA); aba_publish_body(LA, st, nb, grp, jA, true); }
-        if (jB >= 0) { aba_store_state<JT>(LB, st, nd, grp, jB); aba_publish_body(LB, st, nb, grp, jB, true); }
-        __syncthreads();
-        stage_flush<E>(sim, stage, so, env0, nb, nd);
-    } else {
-        if (jA >= 0) { aba_store_state<JT>(LA, sim, nd, env, jA); aba_publish_body(LA, sim, nb, env, jA, true); }
-        if (jB >= 0) { aba_store_state<JT>(LB, sim, nd, env, jB); aba_publish_body(LB, sim, nb, env, jB, true); }
-    }
-    if (sim.force_sensor != nullptr) {   // S6 (wave-uniform branch; the sensor bodies' lanes only)
-        if (jA >= 0) aba_publish_sensors(LA, model, prm, sim, dt, env, jA);
-        if (jB >= 0) aba_publish_sensors(LB, model, prm, sim, dt, env, jB);
-    }
-    PHC_PROF(8)
-    PHC_PROF_FLUSH
-}
-
 template <bool STEP, int JT, bool SHAPES>
 static void sim_launch_jt(const phc_model_t* model, const phc_sim_params_t& prm, const phc_sim_state_t* sim, const float* actions,
                           const float* off, const float* scale, const int32_t* freeze, int num_sim_calls, hipStream_t stream,
-                          const int64_t* env_ids, int num_listed, bool two_slot) {
+                          const int64_t* env_ids, int num_listed) {
     const int64_t groups = env_ids ? num_listed : sim->num_envs;
-    const bool wide = model->num_bodies > 32;   // more bodies than a 32-lane group holds: one env per wavefront (two in the two-slot mapping)
-    if (STEP && two_slot) {
-        if (wide)
-            hipLaunchKernelGGL((k_sim_step16<JT, 32, SHAPES>), dim3((groups + 1) / 2), dim3(64), 0, stream, *model, prm, *sim, actions, off, scale, freeze,
-                               num_sim_calls);
-        else
-            hipLaunchKernelGGL((k_sim_step16<JT, 16, SHAPES>), dim3((groups + 3) / 4), dim3(64), 0, stream, *model, prm, *sim, actions, off, scale, freeze,
-                               num_sim_calls);
-        return;
-    }
+    const bool wide = model->num_bodies > 32;   // more bodies than a 32-lane group holds: one env per wavefront
     if (wide)
         hipLaunchKernelGGL((k_sim_step<STEP, JT, 64, SHAPES>), dim3(groups), dim3(64), 0, stream, *model, prm, *sim, actions, off, scale, freeze,
                            num_sim_calls, env_ids, num_listed);
@@ -344,13 +229,13 @@ static void sim_launch_jt(const phc_model_t* model, const phc_sim_params_t& prm,
 template <bool STEP>
 static void sim_launch(const phc_model_t* model, const phc_sim_params_t& prm, const phc_sim_state_t* sim, const float* actions,
                        const float* off, const float* scale, const int32_t* freeze, int num_sim_calls, hipStream_t stream,
-                       const int64_t* env_ids = nullptr, int num_listed = 0, bool two_slot = false) {
+                       const int64_t* env_ids = nullptr, int num_listed = 0) {
     if (model->num_dof == model->num_bodies - 1 && model->num_bodies > 2)  // one revolute joint per body (robots; one shape)
-        sim_launch_jt<STEP, PHC_JT_REVOLUTE, false>(model, prm, sim, actions, off, scale, freeze, num_sim_calls, stream, env_ids, num_listed, two_slot);
+        sim_launch_jt<STEP, PHC_JT_REVOLUTE, false>(model, prm, sim, actions, off, scale, freeze, num_sim_calls, stream, env_ids, num_listed);
     else if (model->num_shapes > 1 && sim->env_shape != nullptr)   // per-env body shapes (SMPL family)
-        sim_launch_jt<STEP, PHC_JT_SPHERICAL, true>(model, prm, sim, actions, off, scale, freeze, num_sim_calls, stream, env_ids, num_listed, two_slot);
+        sim_launch_jt<STEP, PHC_JT_SPHERICAL, true>(model, prm, sim, actions, off, scale, freeze, num_sim_calls, stream, env_ids, num_listed);
     else
-        sim_launch_jt<STEP, PHC_JT_SPHERICAL, false>(model, prm, sim, actions, off, scale, freeze, num_sim_calls, stream, env_ids, num_listed, two_slot);
+        sim_launch_jt<STEP, PHC_JT_SPHERICAL, false>(model, prm, sim, actions, off, scale, freeze, num_sim_calls, stream, env_ids, num_listed);
 }
 
 static inline int32_t launch_status() {
@@ -377,34 +262,10 @@ int32_t phc_sim_step(const phc_model_t* model, const phc_sim_params_t* params, c
     if (!params || !sim || sim->num_envs < 0 || params->substeps < 1 || num_sim_calls < 0) return PHC_EINVAL;
     if (actions && (!pd_action_offset || !pd_action_scale)) return PHC_EINVAL;
     if (sim->num_envs == 0) return 0;
-    const int wide = model->num_bodies > 32;
-    // pair capacity of the two mappings (pairs are dealt round-robin to the lanes of an env's group)
-    const int cap_one = PHC_SC_MAX_PER_LANE * (wide ? 64 : 32), cap_two = wide ? PHC_SC_MAX_PER_LANE_WIDE * 32 : PHC_SC_MAX_PER_LANE * 16;
-    if (params->self_collision && model->num_collision_pairs > cap_one) return PHC_EUNSUPPORTED;
-    // lane_mapping 1 / 2 force a kernel; 0 picks.  Measured on MI355X at N = 4096 (scripts/sim_substep_scan.py, round 2, same box, 4 sub-steps):
-    //   SMPL, body-body contact ON  (the shipped configuration): one body per lane 97.0 us (2 wavefronts / SIMD, VALU-issue bound at
-    //         4.1 cycles per VALU instruction), two-slot 100.9 us (1 wavefront / SIMD, latency bound at 6.7) -> one body per lane;
-    //   SMPL, body-body contact OFF: two-slot 84 us vs 92 us (round 1) -> two-slot while its N/4 wavefronts fit the chip in one round
-    //         (N <= 4 x #SIMDs = 4096; profiles/r01_env_count_sweep.json);
-    //   H1 (depth 5, 12.8 contact points per body, 8 sub-steps): 104 vs 126 us -> one body per lane (the two-slot kernel runs the
-    //         per-body initialisation twice per sub-step, which only pays off when the level sweeps dominate).
-    static int num_simds = 0;
-    if (num_simds == 0) {
-        int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        num_simds = 4 * (cus > 0 ? cus : 256);
-    }
-    const int half = wide ? 32 : 16;   // lanes per env of the two-slot mapping
-    const bool can_split = model->split_level > 0 && model->num_below_split <= half && model->num_bodies - model->num_below_split <= half &&
-                           !(params->self_collision && model->num_collision_pairs > cap_two);
-    // wide articulations (G1, N = 4096, scripts/gpu_g1.sh): 434 us one body per lane vs 515 us two-slot -> never picked automatically
-    // Since the round-2 rework of the sweeps (solver tree re-rooted at the body of least depth, forward sweep split, joint-drive rotations hoisted --
-    // one body per lane only: the two-slot kernel's slots are split by KINEMATIC level, so it solves on the kinematic tree) one body per lane
-    // wins everywhere measured: SMPL @4096 80.8 vs 100.1 us with body-body contact, 69.1 vs 83.4 us without.  Two-slot only on request.
-    const bool two_slot = can_split && params->lane_mapping == 2;
-    (void)num_simds;
-    sim_launch<true>(model, *params, sim, actions, pd_action_offset, pd_action_scale, freeze_mask, num_sim_calls, (hipStream_t)stream, nullptr, 0,
-                     two_slot);
+    // pairs are dealt round-robin to the lanes of an env's group: PHC_SC_MAX_PER_LANE each
+    if (params->self_collision && model->num_collision_pairs > PHC_SC_MAX_PER_LANE * (model->num_bodies > 32 ? 64 : 32)) return PHC_EUNSUPPORTED;
+    if (params->lane_mapping != 0 && params->lane_mapping != 1) return PHC_EUNSUPPORTED;   // (2 was the two-bodies-per-lane kernel of rounds 1-2: removed)
+    sim_launch<true>(model, *params, sim, actions, pd_action_offset, pd_action_scale, freeze_mask, num_sim_calls, (hipStream_t)stream);
     return launch_status();
 }
 

@@ -246,7 +246,7 @@ class HumanoidIm:
         self._model_floats = torch.from_numpy(floats).to(self.device)
         self._model_struct = abi.model_struct(self._model_ints, self._model_floats, self.num_bodies, self.num_dof,
                                               self.model.max_level, max(len(m.contact_body) for m in self.shape_models),
-                                              split=self.model.two_slot_split(), num_shapes=K)
+                                              num_shapes=K)
         self.humanoid_masses = [self.shape_models[i % K].total_mass for i in range(min(self.num_envs, 10))]
         groups = robot.get("limb_weight_group", []) if self._is_robot else (
             ['L_Hip', 'L_Knee', 'L_Ankle', 'L_Toe'], ['R_Hip', 'R_Knee', 'R_Ankle', 'R_Toe'],

@@ -431,25 +431,13 @@ class ArticulationModel:
                     m[i] |= 1 << j
         return m
 
-    def two_slot_split(self):
-        """(split level, bodies below it) for the stepper's two-slot mapping: slot A = bodies of levels < split, slot B = the rest,
-        both <= 16 bodies (<= 32 for articulations of more than 32 bodies), as balanced as possible; (-1, 0) when the tree admits
-        no such split (the one-body-per-lane kernel is used)."""
-        best = (-1, 0)
-        half = 16 if self.num_bodies <= 32 else 32
-        for split in range(1, self.max_level + 1):
-            nA = int((self.level < split).sum())
-            if nA <= half and self.num_bodies - nA <= half and (best[0] < 0 or abs(2 * nA - self.num_bodies) < abs(2 * best[1] - self.num_bodies)):
-                best = (split, nA)
-        return best
-
     # ---- packed buffers --------------------------------------------------------------------
     def pack(self, kp_scale=1.0, kd_scale=1.0):
         """-> (ints int32[...], floats float32[...]) laid out as csrc/phc_model.h expects.
 
         ints  : [0]=NB [1]=ND [2]=max_level [3]=NCP then per body (MAX_BODIES slots each):
                 parent, level, joint_type, dof_start, child0, child1, child2, nchild,
-                cp_start, cp_count, order (bodies sorted by level), misc [split level, bodies below it],
+                cp_start, cp_count, order (bodies sorted by level), misc [-, -, solver depth, solver base, jump steps],
                 self-collision partner mask
         floats: per body (MAX_BODIES slots x BODY_FLOATS): r_local[3], mass, m*com[3], Io(xx,xy,xz,yy,yz,zz)[6],
                 kp[3], kd[3], armature[3], effort[3], axis[3] (revolute), rest rotation xyzw[4], limit lo/hi [2], contact bound radius, pad, collision capsule a[3] b[3] radius, pad,
@@ -457,7 +445,7 @@ class ArticulationModel:
                 then contact points NCP x 4 (pos[3], radius)
         """
         NB, MB = self.num_bodies, self.MAX_BODIES
-        NT = 20
+        NT = 21
         ints = np.zeros(4 + NT * MB, dtype=np.int32)
         ints[0:4] = [NB, self.num_dof, self.max_level, len(self.contact_body)]
         tab = ints[4:].reshape(NT, MB)
@@ -478,9 +466,7 @@ class ArticulationModel:
             tab[8, i] = idx[0] if len(idx) else 0
             tab[9, i] = len(idx)
         tab[10, :NB] = np.argsort(self.level, kind="stable")  # bodies sorted by tree level
-        # two-slot mapping of the stepper (16 lanes per env, 4 envs per wavefront; 32 and 2 above 32 bodies): slot A = bodies of
-        # levels < split, slot B = the rest, both <= 16 (32) bodies, so that at every tree level all active bodies sit in the same slot.  tab[11] = [split, nA].
-        tab[11, 0:2] = self.two_slot_split()
+        # misc table 11: [0, 0 (reserved), solver depth, solver base, pointer-jumping steps]
         tab[12, :NB] = np.array([v & 0xffffffff for v in self.collision_allow_masks()], dtype=np.uint32).view(np.int32)   # partner bit masks (bodies 0-31; informative)
         # solver tree (solver_tree()): tables 13..19 = parent, level, child0-2, nchild, jsrc | bsrc << 8 (+1 each, 0 = none); misc[2:4] = its depth, its base
         st = self.solver_tree()
@@ -496,6 +482,19 @@ class ArticulationModel:
             tab[18, i] = len(st["schildren"][i])
             tab[19, i] = (int(st["jsrc"][i]) + 1) | ((int(st["bsrc"][i]) + 1) << 8)
         tab[11, 2:4] = [int(st["slevel"].max()), st["base"]]
+        # kinematics by pointer jumping (phc_aba.h aba_fk_jump_*): table 20 = the body's anchor in steps 0..3 (8 bits each, 0xff = already in the
+        # world frame): step k composes the body's transform with its anchor's, the anchor's anchor becomes the new anchor; misc[4] = steps
+        anc = [int(p) for p in self.parent[:NB]]
+        steps, words = 0, [0xffffffff] * NB
+        while any(a >= 0 for a in anc):
+            assert steps < 4, "kinematic tree deeper than 15"
+            for i in range(NB):
+                words[i] = (words[i] & ~(0xff << (8 * steps))) | ((anc[i] & 0xff) << (8 * steps))
+            anc = [anc[a] if a >= 0 else -1 for a in anc]
+            steps += 1
+        tab[20, :] = -1
+        tab[20, :NB] = np.array(words, dtype=np.uint32).view(np.int32)
+        tab[11, 4] = steps
         # self-collision candidate pairs (i < k, may collide), appended after the tables: [count, i | k << 8, ...]; lane l of a
         # group evaluates pairs l, l + L, l + 2L, ... so the list is ordered to spread each body's pairs over many lanes
         masks = self.collision_allow_masks()

@@ -27,7 +27,7 @@ def main(fetch_csv, write_csv, n_envs=4096):
         c = [k for k in f if k.startswith(prefix)]
         return max(c, key=lambda k: len(f[k])) if c else None
 
-    for k in filter(None, (pick("k_sim_step16"), pick("k_sim_step<true"), pick("k_im_post_physics"), pick("k_im_reset"))):
+    for k in filter(None, (pick("k_sim_step<true"), pick("k_im_post_physics"), pick("k_im_reset"))):
         # steady state: drop the first dispatches (full reset of all envs) by taking the median
         fv, wv = sorted(f[k])[len(f[k]) // 2], sorted(w[k])[len(w[k]) // 2]
         rd, wr = 2 * fv * 1024, wv * 1024

@@ -134,7 +134,7 @@ def model_on(be, name="smpl_humanoid", kp_scale=1.0, kd_scale=1.0, zero_armature
         m.dof_armature[:] = 0
     ints, floats = m.pack(kp_scale, kd_scale)
     ints_d, floats_d = be.arr(ints), be.arr(floats)
-    return m, abi.model_struct(ints_d, floats_d, m.num_bodies, m.num_dof, m.max_level, len(m.contact_body), split=m.two_slot_split()), (ints_d, floats_d)
+    return m, abi.model_struct(ints_d, floats_d, m.num_bodies, m.num_dof, m.max_level, len(m.contact_body)), (ints_d, floats_d)
 
 
 def motion_lib_on(be, lib):

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     assert sorted(_lib.EXPORTED_SYMBOLS) == declared, "ctypes table and header disagree"
     for name in declared:
         assert hasattr(lib, name), f"libphc_amd.so does not export {name}"
-    assert lib.phc_abi_version() == 30
+    assert lib.phc_abi_version() == 31
 
 
 def test_struct_sizes_match_the_header():
@@ -247,7 +247,7 @@ def test_solver_tree_reroots_the_smpl_humanoid_at_the_shallowest_base():
     assert all(st["jsrc"][b] == b and not st["s_off"][b].any() for b in range(m.num_bodies) if b not in rev and b != st["base"])
     ints, fl = m.pack()
     MB, BF = m.MAX_BODIES, m.BODY_FLOATS
-    tab = ints[4:4 + 20 * MB].reshape(20, MB)
+    tab = ints[4:4 + 21 * MB].reshape(21, MB)
     assert tuple(tab[11, 2:4]) == (6, st["base"]) and (tab[13, :m.num_bodies] == st["sparent"]).all()
     f = fl[:MB * BF].reshape(MB, BF).astype(np.float64)
     for b in range(m.num_bodies):

@@ -286,29 +286,6 @@ def test_robot_settles_on_its_feet(backend, rb, control_mode):
     assert (np.abs(cf[:, feet, 2]).sum(-1) > 0.9 * np.abs(cf[:, :, 2]).sum(-1)).all(), "only the ankle links touch the ground"
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("name,nd", [("smpl_humanoid", 69), ("h1_humanoid", 19), ("g1_humanoid", 37)])
-def test_two_slot_mapping_equals_one_body_per_lane(name, nd):
-    """k_sim_step16 (16 lanes per env, two bodies per lane, 4 envs per wavefront) runs the same per-lane functions in the same
-    order as k_sim_step (one body per lane), also for env counts that do not fill the last wavefront.  The stepper TU is built with
-    -ffast-math, so the two instantiations may contract / reassociate differently: equality to a few ulp, not bit-identity."""
-    be = get_backend("hip")
-    model, mstruct, keep = model_on(be, name)
-    rng = np.random.default_rng(5)
-    for n in (1, 7, 64):
-        root, dof, target = random_states(model, n, rng, height=0.9, pose=0.5 if nd == 69 else 0.3)
-        outs = []
-        for mapping in (1, 2):
-            kw = dict(sim_dt=1 / 200, control_freq_inv=4, control_mode=2, limit_stiffness=2000.0, limit_damping=20.0) if nd != 69 else {}
-            params = abi.sim_params_struct(lane_mapping=mapping, **kw)
-            outs.append(run_step(be, model, mstruct, root, dof, target, params, 2))
-        for k in ("root", "dof", "rbs", "cf", "df"):
-            # contact forces are stiffness x penetration (1e-6 m of rounding noise in the pose is 0.1 N on H1's feet): relative 5e-3
-            np.testing.assert_allclose(outs[0][k], outs[1][k], rtol=5e-3 if k == "cf" else 1e-4, atol={"cf": 5e-2, "df": 5e-3}.get(k, 3e-4),
-                                       err_msg=f"{name} n={n} {k}")
-        assert np.isfinite(outs[0]["rbs"]).all()
-
-
 # ---------------------------------------------------------------------------------------------------------------
 # body-body contact (SURVEY f-1)
 # ---------------------------------------------------------------------------------------------------------------
@@ -412,16 +389,14 @@ def test_sliding_friction_decelerates_at_mu_g(backend):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
-@pytest.mark.parametrize("self_collision,lane_mapping", [(0, 1), (1, 1), (0, 2)])
-def test_per_env_body_shapes_equal_single_shape_runs(backend, self_collision, lane_mapping):
+@pytest.mark.parametrize("self_collision", [0, 1])
+def test_per_env_body_shapes_equal_single_shape_runs(backend, self_collision):
     """Per-env body shapes (robot.has_shape_variation, humanoid.py:726-766,824-866): ONE launch over K = 3 stacked models (the reference's
     three gender assets: different link offsets, masses, contact-point counts) with an int32 shape id per env gives every env, bit for
     bit, what a single-shape launch of its own model gives -- stepper and the FK-only refresh."""
     from phc_amd.model import load_model, pack_shapes
     from phc_amd.robots import apply_collision_filter
     be = get_backend(backend)
-    if lane_mapping == 2 and backend == "hostemu":
-        pytest.skip("lane mappings are a device notion")
     models = [load_model(f"smpl_{g}_humanoid") for g in range(3)]
     for m in models:
         apply_collision_filter(m, "smpl")
@@ -430,12 +405,12 @@ def test_per_env_body_shapes_equal_single_shape_runs(backend, self_collision, la
     keep = (be.arr(ints), be.arr(floats))
     m0 = models[0]
     stacked = abi.model_struct(keep[0], keep[1], m0.num_bodies, m0.num_dof, m0.max_level, max(len(m.contact_body) for m in models),
-                               split=m0.two_slot_split(), num_shapes=3)
+                               num_shapes=3)
     rng = np.random.default_rng(5)
     n = 10
     root, dof, target = random_states(m0, n, rng, height=0.85)
     shape = (np.arange(n) % 3).astype(np.int32)
-    params = abi.sim_params_struct(self_collision=self_collision, lane_mapping=lane_mapping)
+    params = abi.sim_params_struct(self_collision=self_collision)
 
     def run(mstruct, rows, env_shape):
         k = len(rows)
@@ -454,7 +429,7 @@ def test_per_env_body_shapes_equal_single_shape_runs(backend, self_collision, la
     for g, m in enumerate(models):
         i, f = m.pack()
         kg = (be.arr(i), be.arr(f))
-        single = abi.model_struct(kg[0], kg[1], m.num_bodies, m.num_dof, m.max_level, len(m.contact_body), split=m.two_slot_split())
+        single = abi.model_struct(kg[0], kg[1], m.num_bodies, m.num_dof, m.max_level, len(m.contact_body))
         rows = np.flatnonzero(shape == g)
         fk_g, out_g = run(single, rows, None)
         assert np.array_equal(fk_all[rows], fk_g)

@@ -494,37 +494,35 @@ def test_h1_env_end_to_end():
 
 
 def test_g1_env_end_to_end():
-    """Unitree G1 (env_im_g1_phc): 38 bodies -> one env per wavefront in the task kernels and the stepper (two per wavefront in its
-    two-bodies-per-lane mapping); obs 568 + 912, AMP obs 99 x 10, one extended body; body state == FK of the joint state."""
+    """Unitree G1 (env_im_g1_phc): 38 bodies -> one env per wavefront in the task kernels and the stepper; obs 568 + 912, AMP obs 99 x 10, one extended body; body state == FK of the joint state."""
     import dyn_oracle as do
     over = {"robot": "unitree_g1", "env": "env_im_g1_phc", "sim": "robot_sim", "control": "robot_control"}
-    for mapping in (1, 2):
-        task, env = make_task(192, motion="synthetic:3:2:2.0", **dict(over, **{"+solver.lane_mapping": mapping}))
-        assert task.humanoid_type == "g1" and task.num_bodies == 38 and task.num_dof == 37 and task.num_actions == 37
-        assert task.num_obs == 568 + 912 and task.get_num_amp_obs() == 990 and task.num_extend_bodies == 1
-        obs = env.reset()
-        assert obs.shape == (192, 1480) and torch.isfinite(obs).all()
-        res = task._motion_lib.get_motion_state(task._sampled_motion_ids, task._motion_start_times)
-        np.testing.assert_allclose(task._dof_pos.cpu().numpy(), res["dof_pos"].cpu().numpy(), atol=1e-6)
-        np.testing.assert_allclose(task._rigid_body_pos.cpu().numpy(), res["rg_pos"].cpu().numpy(), atol=1e-5)
-        rew_sum = torch.zeros(192, device=task.device)
-        for k in range(30):
-            task.reset_done()
-            act = task.ref_dof_pos - task.default_dof_pos + torch.randn(192, 37, device=task.device) * 0.05
-            obs, rew, done, info = env.step(act)
-            rew_sum += rew
-        torch.cuda.synchronize()
-        assert torch.isfinite(obs).all() and torch.isfinite(rew_sum).all() and info["amp_obs"].shape == (192, 990)
-        assert (task.progress_buf.max() > 5) and rew_sum.mean() > 0.2 * 30 * 0.5, float(rew_sum.mean())
-        root, dof = task._root_states.cpu().numpy(), task._dof_state.view(192, 37, 2).cpu().numpy()
-        bp, br = task._rigid_body_pos.cpu().numpy(), task._rigid_body_rot.cpu().numpy()
-        for e in (0, 100, 191):
-            st = do.State(root[e], dof[e], task.model)
-            Q, R, p = do.kinematics(task.model, st)
-            np.testing.assert_allclose(bp[e], p, atol=2e-5)
-            np.testing.assert_allclose(np.abs((br[e] * np.array(Q)).sum(-1)), 1.0, atol=1e-5)
-        demo = task.fetch_amp_obs_demo(64)
-        assert demo.shape == (64, 990) and torch.isfinite(demo).all()
+    task, env = make_task(192, motion="synthetic:3:2:2.0", **over)
+    assert task.humanoid_type == "g1" and task.num_bodies == 38 and task.num_dof == 37 and task.num_actions == 37
+    assert task.num_obs == 568 + 912 and task.get_num_amp_obs() == 990 and task.num_extend_bodies == 1
+    obs = env.reset()
+    assert obs.shape == (192, 1480) and torch.isfinite(obs).all()
+    res = task._motion_lib.get_motion_state(task._sampled_motion_ids, task._motion_start_times)
+    np.testing.assert_allclose(task._dof_pos.cpu().numpy(), res["dof_pos"].cpu().numpy(), atol=1e-6)
+    np.testing.assert_allclose(task._rigid_body_pos.cpu().numpy(), res["rg_pos"].cpu().numpy(), atol=1e-5)
+    rew_sum = torch.zeros(192, device=task.device)
+    for k in range(30):
+        task.reset_done()
+        act = task.ref_dof_pos - task.default_dof_pos + torch.randn(192, 37, device=task.device) * 0.05
+        obs, rew, done, info = env.step(act)
+        rew_sum += rew
+    torch.cuda.synchronize()
+    assert torch.isfinite(obs).all() and torch.isfinite(rew_sum).all() and info["amp_obs"].shape == (192, 990)
+    assert (task.progress_buf.max() > 5) and rew_sum.mean() > 0.2 * 30 * 0.5, float(rew_sum.mean())
+    root, dof = task._root_states.cpu().numpy(), task._dof_state.view(192, 37, 2).cpu().numpy()
+    bp, br = task._rigid_body_pos.cpu().numpy(), task._rigid_body_rot.cpu().numpy()
+    for e in (0, 100, 191):
+        st = do.State(root[e], dof[e], task.model)
+        Q, R, p = do.kinematics(task.model, st)
+        np.testing.assert_allclose(bp[e], p, atol=2e-5)
+        np.testing.assert_allclose(np.abs((br[e] * np.array(Q)).sum(-1)), 1.0, atol=1e-5)
+    demo = task.fetch_amp_obs_demo(64)
+    assert demo.shape == (64, 990) and torch.isfinite(demo).all()
 
 
 def test_h1_ppo_epoch():
