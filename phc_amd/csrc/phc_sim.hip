@@ -22,13 +22,34 @@ extern "C" int32_t phc_debug_profile(unsigned long long* out16, int32_t reset) {
     if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_phc_prof), z, sizeof(z)) != hipSuccess) return -1; }
     return 0;
 }
+// phase ablation (scripts/probes/sim_ablation.py): bit b set = phase b of the list there is skipped (timing only; the results are then meaningless)
+__device__ int g_phc_skip;
+extern "C" int32_t phc_debug_set_skip(int32_t mask) { return hipMemcpyToSymbol(HIP_SYMBOL(g_phc_skip), &mask, sizeof(mask)) == hipSuccess ? 0 : -1; }
+// single-wave timeline (scripts/probes/sim_timeline.py): workgroup g_phc_tl_block stamps s_memtime at PHC_TL(id) points of sub-step 1
+__device__ unsigned long long g_phc_tl[512];
+__device__ int g_phc_tl_block = -1;
+extern "C" int32_t phc_debug_timeline(unsigned long long* out512, int32_t block) {
+    if (out512 && hipMemcpyFromSymbol(out512, HIP_SYMBOL(g_phc_tl), sizeof(g_phc_tl)) != hipSuccess) return -1;
+    unsigned long long z[512] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_phc_tl), z, sizeof(z)) != hipSuccess) return -1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_phc_tl_block), &block, sizeof(block)) == hipSuccess ? 0 : -1;
+}
+#define PHC_TL_DECL int tl_n = 0; const bool tl_on = (int)blockIdx.x == g_phc_tl_block;
+#define PHC_TL(id) if (tl_on && tl_sub == 1 && tl_n < 255) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_readcyclecounter(); \
+        if (threadIdx.x == 0) { g_phc_tl[2 * tl_n] = (unsigned long long)(id); g_phc_tl[2 * tl_n + 1] = t_; } ++tl_n; __builtin_amdgcn_sched_barrier(0); }
+#define PHC_SKIP_DECL const int skip_mask = g_phc_skip;
+#define PHC_SKIP(b) ((skip_mask >> (b)) & 1)
 #define PHC_PROF_DECL unsigned long long prof_acc[10] = {0}; unsigned long long prof_t = __builtin_readcyclecounter();
-#define PHC_PROF(i) { const unsigned long long t_ = __builtin_readcyclecounter(); prof_acc[i] += t_ - prof_t; prof_t = t_; }
-#define PHC_PROF_FLUSH if (threadIdx.x == 0) { for (int i_ = 0; i_ < 10; ++i_) atomicAdd(&g_phc_prof[i_], prof_acc[i_]); atomicAdd(&g_phc_prof[15], 1ull); }
+#define PHC_PROF(i) if (!PHC_SKIP(15)) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0); const unsigned long long t_ = __builtin_readcyclecounter(); prof_acc[i] += t_ - prof_t; prof_t = t_; __builtin_amdgcn_sched_barrier(0); }
+#define PHC_PROF_FLUSH if (threadIdx.x == 0 && !PHC_SKIP(15)) { for (int i_ = 0; i_ < 10; ++i_) atomicAdd(&g_phc_prof[i_], prof_acc[i_]); atomicAdd(&g_phc_prof[15], 1ull); }
 #else
 #define PHC_PROF_DECL
 #define PHC_PROF(i)
 #define PHC_PROF_FLUSH
+#define PHC_SKIP_DECL
+#define PHC_SKIP(b) false
+#define PHC_TL_DECL
+#define PHC_TL(id)
 #endif
 
 // A2: pd_tar = offset + scale * action (humanoid.py:1711-1713); env.res_action (sim.pd_ref set): reference joint position + scale * action,
@@ -127,25 +148,28 @@ __global__ __launch_bounds__(64, 2) void k_sim_step(phc_model_t model_all, phc_s
     const phc_model_t model = SHAPES ? model_for_env(model_all, sim, env) : model_all;
     const int nb = model.num_bodies, nd = model.num_dof;
     const bool active = env < sim.num_envs && lane < nb;
+    const int body = lane;   // one lane per body, in the model's body order
     Xch x;
     x.base = xch_all + grp * GRP * PHC_XCH_STRIDE;
 
     AbaLane L;
     L.level = L.slevel = -1;
+    PHC_SKIP_DECL
     PHC_PROF_DECL
+    PHC_TL_DECL
     if (active) {
-        aba_load_model(L, model, lane);
-        if (JT == PHC_JT_REVOLUTE) aba_load_model_rev(L, model, lane);
-        if (STEP && actions != nullptr && lane >= 1) {
+        aba_load_model(L, model, body);
+        if (JT == PHC_JT_REVOLUTE) aba_load_model_rev(L, model, body);
+        if (STEP && actions != nullptr && body >= 1) {
             for (int k = 0; k < (JT == PHC_JT_REVOLUTE ? 1 : 3); ++k) {
                 const int d = L.dof_start + k;
                 sim.pd_target[env * nd + d] = pd_target_of(sim, actions, pd_off, pd_scale, freeze, env, nd, d);
             }
         }
-        aba_load_state<JT>(L, sim, nd, env, lane);
+        aba_load_state<JT>(L, sim, nd, env, body);
     }
     const int max_level = model.max_level;
-    for (int l = 0; l <= max_level; ++l) { aba_fk_level(L, l, lane, x); __syncthreads(); }
+    if (!PHC_SKIP(8)) for (int l = 0; l <= max_level; ++l) { aba_fk_level(L, l, body, x); __syncthreads(); }
     PHC_PROF(0)
     if (STEP) {
         const float dt = prm.sim_dt / (float)prm.substeps;
@@ -159,55 +183,70 @@ __global__ __launch_bounds__(64, 2) void k_sim_step(phc_model_t model_all, phc_s
         const int jump_steps = model_jump_steps(model);
         const bool rerooted = model_tab(model, 11, 3) != 0;
         for (int s = 0; s < nsub; ++s) {
-            if (prm.self_collision) {   // body-body contact from the kinematics the last sweep left in the exchange slots
-                if (active) aba_publish_capsule(L, model_body(model, lane), caps + PHC_CAP_STRIDE * lane);
+            const int tl_sub = s; (void)tl_sub;
+            PHC_TL(1)
+            if (prm.self_collision && !PHC_SKIP(0)) {   // body-body contact from the kinematics the last sweep left in the exchange slots
+                if (active) aba_publish_capsule(L, model_body(model, body), caps + PHC_CAP_STRIDE * body);
                 __syncthreads();
                 if (env < sim.num_envs) aba_collide_pairs(pairs, prm, dt, x, caps, near_pairs, s == 0);
                 __syncthreads();
-                if (active) aba_collect_self(L, lane, caps);
+                if (active) aba_collect_self(L, body, caps);
             }
             PHC_PROF(1)
-            if (active) { aba_velocity_products(L, model, lane, x, true); aba_body_init<JT>(L, model, prm, dt, lane, s % prm.substeps == 0, true); }
-            if (JT == PHC_JT_SPHERICAL && rerooted) {   // reversed bodies take the drive terms of their solver parent's joint
-                if (active) aba_publish_drive(L, lane, x);
+            PHC_TL(2)
+            if (active && !PHC_SKIP(1)) { aba_velocity_products(L, model, body, x, true); PHC_TL(3) aba_body_init<JT>(L, model, prm, dt, body, s % prm.substeps == 0, true); }
+            PHC_PROF(2)
+            PHC_TL(4)
+            if (JT == PHC_JT_SPHERICAL && rerooted && !PHC_SKIP(2)) {   // reversed bodies take the drive terms of their solver parent's joint
+                if (active) aba_publish_drive(L, body, x);
                 __syncthreads();
-                if (active) aba_fetch_drive(L, lane, x);
+                if (active) aba_fetch_drive(L, body, x);
                 __syncthreads();
             }
-            PHC_PROF(2)
-            for (int l = solver_depth; l >= 0; --l) { aba_backward_level<JT>(L, l, lane, x); __syncthreads(); }
             PHC_PROF(3)
-            for (int l = 0; l <= solver_depth; ++l) { aba_accel_level<JT>(L, l, lane, x); __syncthreads(); }
-            if (JT == PHC_JT_SPHERICAL && rerooted) aba_accel_finish(L, model, lane, x);
-            aba_integrate_joint<JT>(L, prm, dt);
-            aba_fk_jump_begin(L, lane, x);   // kinematics by pointer jumping: jump_steps composition steps instead of max_level + 1 level-steps
+            PHC_TL(5)
+            if (!PHC_SKIP(3)) for (int l = solver_depth; l >= 0; --l) { aba_backward_level<JT>(L, l, body, x); __syncthreads(); PHC_TL(120 + l) }
+            PHC_PROF(4)
+            if (!PHC_SKIP(4)) {
+                for (int l = 0; l <= solver_depth; ++l) { aba_accel_level<JT>(L, l, body, x); __syncthreads(); PHC_TL(140 + l) }
+                if (JT == PHC_JT_SPHERICAL && rerooted) aba_accel_finish(L, model, body, x);
+            }
+            PHC_PROF(5)
+            PHC_TL(6)
+            if (!PHC_SKIP(5)) aba_integrate_joint<JT>(L, prm, dt);
+            PHC_PROF(6)
+            PHC_TL(7)
+            if (!PHC_SKIP(6)) aba_fk_jump_begin(L, body, x);   // kinematics by pointer jumping: jump_steps composition steps instead of max_level + 1 level-steps
             __syncthreads();
-            for (int k = 0; k < jump_steps; ++k) {
+            for (int k = 0; k < (PHC_SKIP(6) ? 0 : jump_steps); ++k) {
                 aba_fk_jump_step(L, k, x);
                 __syncthreads();
-                if (active) aba_write_kin(L, xslot(x, lane), Xch::es, 6);
+                if (active) aba_write_kin(L, xslot(x, body), Xch::es, 6);
                 __syncthreads();
+                PHC_TL(160 + k)
             }
             PHC_PROF(7)
+            PHC_TL(8)
         }
     }
     // S7: the last forward sweep already produced the end-of-step kinematics
     constexpr int E = 64 / GRP;
     const int64_t env0 = (int64_t)blockIdx.x * E;
     const StageLayout so = stage_layout(E, nb, nd, sim.dof_force != nullptr, sim.contact_force != nullptr);
-    if (STEP && E >= 2 && env0 + E <= sim.num_envs && stage_aligned(sim) && so.total <= 64 * PHC_XCH_STRIDE) {   // staged epilogue, see above
+    if (PHC_SKIP(7)) {
+    } else if (STEP && E >= 2 && env0 + E <= sim.num_envs && stage_aligned(sim) && so.total <= 64 * PHC_XCH_STRIDE) {   // staged epilogue, see above
         const phc_sim_state_t st = stage_state(sim, xch_all, so);
         if (active) {
-            aba_store_state<JT>(L, st, nd, grp, lane);
-            aba_publish_body(L, st, nb, grp, lane, true);
+            aba_store_state<JT>(L, st, nd, grp, body);
+            aba_publish_body(L, st, nb, grp, body, true);
         }
         __syncthreads();
         stage_flush<E>(sim, xch_all, so, env0, nb, nd);
     } else if (active) {
-        if (STEP) aba_store_state<JT>(L, sim, nd, env, lane);
-        aba_publish_body(L, sim, nb, env, lane, STEP);
+        if (STEP) aba_store_state<JT>(L, sim, nd, env, body);
+        aba_publish_body(L, sim, nb, env, body, STEP);
     }
-    if (STEP && active && sim.force_sensor != nullptr) aba_publish_sensors(L, model, prm, sim, prm.sim_dt / (float)prm.substeps, env, lane);   // S6
+    if (STEP && active && sim.force_sensor != nullptr) aba_publish_sensors(L, model, prm, sim, prm.sim_dt / (float)prm.substeps, env, body);   // S6
     PHC_PROF(8)
     if (STEP) { PHC_PROF_FLUSH }
 }

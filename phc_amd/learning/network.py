@@ -113,6 +113,10 @@ class PNN(nn.Module):
             self.actors.append(mlp)
         if self.has_lateral:
             assert len(units) == 2, "lateral connections: the reference supports two hidden layers (pnn.py:98)"
+            # the lateral term enters BEFORE the second hidden layer's activation (pnn.py:103: relu(W a1 + b + lateral)): that layer must
+            # not apply its ReLU in the GEMM epilogue (the FusedReLU behind it then does the activation itself)
+            for mlp in self.actors:
+                mlp[2].fuse_relu = False
             self.u = nn.ModuleList()
             for i in range(num_cols - 1):
                 self.u.append(nn.ModuleList())

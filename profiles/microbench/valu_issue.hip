@@ -19,12 +19,14 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 #define REP64(x) REP8(REP8(x))
 
 enum Kind { FMA_DEP, FMA_IND, PKFMA_DEP, PKFMA_IND, PKMUL_IND, PKADD_IND, MUL_IND, ADD_DPP_IND, FMAC_DPP_IND, MOV_DPP_IND, RCP_IND, SIN_IND, SQRT_IND, CNDMASK_IND,
-            LDS_RT, BPERMUTE_DEP, LDS_RD128, BARRIER, FMA_2CH, FMA_4CH, PKFMA_2CH, NKINDS };
+            LDS_RT, BPERMUTE_DEP, LDS_RD128, BARRIER, FMA_2CH, FMA_4CH, PKFMA_2CH, CNDMASK_SGPR, FMA_SGPR, MUL_SGPR, CMP_VCC, CMP_SGPR, FMAAK, MOV_IND, FMA_CND_MIX, NKINDS };
 static const char* kind_name[NKINDS] = {"v_fma_f32 dependent chain", "v_fma_f32 8 independent chains", "v_pk_fma_f32 dependent chain", "v_pk_fma_f32 8 independent chains",
     "v_pk_mul_f32 8 independent", "v_pk_add_f32 8 independent", "v_mul_f32 (VOP2) 8 independent", "v_add_f32 dpp row_shr:1 8 independent", "v_fmac_f32 dpp row_shr:1 8 independent",
     "v_mov_b32 dpp row_shr:1 8 independent", "v_rcp_f32 8 independent", "v_sin_f32 8 independent", "v_sqrt_f32 8 independent", "v_cndmask_b32 8 independent",
     "ds_write_b32 -> ds_read_b32 round trip (dependent)", "ds_bpermute_b32 dependent chain", "ds_read_b128 8 in flight", "s_barrier (1-wave workgroup)",
-    "v_fma_f32 2 interleaved chains", "v_fma_f32 4 interleaved chains", "v_pk_fma_f32 2 interleaved chains"};
+    "v_fma_f32 2 interleaved chains", "v_fma_f32 4 interleaved chains", "v_pk_fma_f32 2 interleaved chains",
+    "v_cndmask_b32_e64 (SGPR-pair mask) 8 independent", "v_fma_f32 with one SGPR source, 8 independent", "v_mul_f32 with an SGPR source, 8 independent",
+    "v_cmp_lt_f32_e32 (writes vcc)", "v_cmp_lt_f32_e64 (writes an SGPR pair)", "v_fmaak_f32 (literal), 8 independent", "v_mov_b32 8 independent", "v_fma_f32 / v_cndmask_b32 (vcc) alternating"};
 
 template <int K>
 __global__ __launch_bounds__(64) void k_bench(float* out, unsigned long long* cyc, int reps, float seed) {
@@ -38,6 +40,7 @@ __global__ __launch_bounds__(64) void k_bench(float* out, unsigned long long* cy
     lds[threadIdx.x] = a0;
     for (int i = 0; i < 8; ++i) lds[64 * i + threadIdx.x] = a0 + i;
     __syncthreads();
+    asm volatile("s_mov_b32 s20, 0x3f7fbe77\n s_mov_b32 s21, 0x55555555\n s_mov_b32 vcc_lo, 0x55555555\n s_mov_b32 vcc_hi, 0x55555555" ::: "s20", "s21", "vcc");
     const unsigned long long t0 = __builtin_readcyclecounter();
     for (int r = 0; r < reps; ++r) {
         if (K == FMA_DEP) { asm volatile(REP64("v_fma_f32 %0, %0, %1, %2\n") : "+v"(a0) : "v"(b), "v"(c)); }
@@ -74,6 +77,21 @@ __global__ __launch_bounds__(64) void k_bench(float* out, unsigned long long* cy
             a0 += q0.x + q1.x + q2.x + q3.x + q4.x + q5.x + q6.x + q7.x;
         }
         if (K == BARRIER) { asm volatile(REP8("s_barrier\n") ::: "memory"); }
+        if (K == CNDMASK_SGPR) { SIND8("v_cndmask_b32_e64", ", s[20:21]"); }
+        if (K == FMA_SGPR) { asm volatile(REP8("v_fma_f32 %0, %0, s20, %8\n v_fma_f32 %1, %1, s20, %8\n v_fma_f32 %2, %2, s20, %8\n v_fma_f32 %3, %3, s20, %8\n v_fma_f32 %4, %4, s20, %8\n v_fma_f32 %5, %5, s20, %8\n v_fma_f32 %6, %6, s20, %8\n v_fma_f32 %7, %7, s20, %8\n")
+            : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c) : "s20"); }
+        if (K == MUL_SGPR) { asm volatile(REP8("v_mul_f32_e32 %0, s20, %0\n v_mul_f32_e32 %1, s20, %1\n v_mul_f32_e32 %2, s20, %2\n v_mul_f32_e32 %3, s20, %3\n v_mul_f32_e32 %4, s20, %4\n v_mul_f32_e32 %5, s20, %5\n v_mul_f32_e32 %6, s20, %6\n v_mul_f32_e32 %7, s20, %7\n")
+            : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) :: "s20"); }
+        if (K == CMP_VCC) { asm volatile(REP8("v_cmp_lt_f32_e32 vcc, %0, %1\n v_cmp_lt_f32_e32 vcc, %1, %2\n v_cmp_lt_f32_e32 vcc, %2, %3\n v_cmp_lt_f32_e32 vcc, %3, %4\n v_cmp_lt_f32_e32 vcc, %4, %5\n v_cmp_lt_f32_e32 vcc, %5, %6\n v_cmp_lt_f32_e32 vcc, %6, %7\n v_cmp_lt_f32_e32 vcc, %7, %0\n")
+            :: "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(a5), "v"(a6), "v"(a7) : "vcc"); }
+        if (K == CMP_SGPR) { asm volatile(REP8("v_cmp_lt_f32_e64 s[20:21], %0, %1\n v_cmp_lt_f32_e64 s[22:23], %1, %2\n v_cmp_lt_f32_e64 s[24:25], %2, %3\n v_cmp_lt_f32_e64 s[26:27], %3, %4\n v_cmp_lt_f32_e64 s[20:21], %4, %5\n v_cmp_lt_f32_e64 s[22:23], %5, %6\n v_cmp_lt_f32_e64 s[24:25], %6, %7\n v_cmp_lt_f32_e64 s[26:27], %7, %0\n")
+            :: "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(a5), "v"(a6), "v"(a7) : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27"); }
+        if (K == FMAAK) { asm volatile(REP8("v_fmaak_f32 %0, %0, %8, 0x3a83126f\n v_fmaak_f32 %1, %1, %8, 0x3a83126f\n v_fmaak_f32 %2, %2, %8, 0x3a83126f\n v_fmaak_f32 %3, %3, %8, 0x3a83126f\n v_fmaak_f32 %4, %4, %8, 0x3a83126f\n v_fmaak_f32 %5, %5, %8, 0x3a83126f\n v_fmaak_f32 %6, %6, %8, 0x3a83126f\n v_fmaak_f32 %7, %7, %8, 0x3a83126f\n")
+            : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b)); }
+        if (K == MOV_IND) { asm volatile(REP8("v_mov_b32_e32 %0, %1\n v_mov_b32_e32 %1, %2\n v_mov_b32_e32 %2, %3\n v_mov_b32_e32 %3, %4\n v_mov_b32_e32 %4, %5\n v_mov_b32_e32 %5, %6\n v_mov_b32_e32 %6, %7\n v_mov_b32_e32 %7, %0\n")
+            : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)); }
+        if (K == FMA_CND_MIX) { asm volatile(REP8("v_fma_f32 %0, %0, %8, %9\n v_cndmask_b32_e32 %1, %1, %8, vcc\n v_fma_f32 %2, %2, %8, %9\n v_cndmask_b32_e32 %3, %3, %8, vcc\n v_fma_f32 %4, %4, %8, %9\n v_cndmask_b32_e32 %5, %5, %8, vcc\n v_fma_f32 %6, %6, %8, %9\n v_cndmask_b32_e32 %7, %7, %8, vcc\n")
+            : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c)); }
     }
     const unsigned long long t1 = __builtin_readcyclecounter();
     if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
@@ -81,7 +99,7 @@ __global__ __launch_bounds__(64) void k_bench(float* out, unsigned long long* cy
 }
 
 static int instr_per_rep(int k) {
-    switch (k) { case LDS_RT: return 8; case BPERMUTE_DEP: return 8; case LDS_RD128: return 8; case BARRIER: return 8; default: return 64; }
+    switch (k) { case LDS_RT: return 8; case BPERMUTE_DEP: return 8; case LDS_RD128: return 8; case BARRIER: return 8; case FMA_2CH: case PKFMA_2CH: return 128; case FMA_4CH: return 256; default: return 64; }
 }
 
 template <int K>
@@ -118,7 +136,7 @@ static void run(int blocks, int reps, float* out, unsigned long long* cyc, FILE*
 template <int K>
 static void sweep(float* out, unsigned long long* cyc, FILE* js, bool& first) {
     const int reps = (K == LDS_RT || K == BPERMUTE_DEP || K == LDS_RD128 || K == BARRIER) ? 500 : 400;
-    for (int blocks : {1, 1024, 2048, 4096, 8192}) run<K>(blocks, reps, out, cyc, js, first);
+    for (int blocks : {1, 256, 1024, 2048, 4096, 8192}) run<K>(blocks, reps, out, cyc, js, first);
 }
 
 template <int K>

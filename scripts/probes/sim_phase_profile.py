@@ -1,4 +1,4 @@
-"""Where do the cycles of the two-slot stepper go?  Builds an instrumented copy of the library (-DPHC_SIM_PROFILE: s_memtime deltas per
+"""Where do the cycles of the stepper go?  Builds an instrumented copy of the library (-DPHC_SIM_PROFILE: s_memtime deltas per
 phase, accumulated per wavefront) next to the product one, runs the bench's env step with it and prints the phase table.
 
     python scripts/sim_phase_profile.py build      # here (hipcc cross-compiles): phc_amd/_obj/libphc_amd_prof.so
@@ -9,11 +9,12 @@ import os
 import subprocess
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 PROF = os.path.join(ROOT, "phc_amd", "_obj", "libphc_amd_prof.so")
-NAMES = ["load + initial FK", "body-body contact", "init B (deep bodies) / init (one body per lane)", "backward B levels / backward sweep",
-         "init A (shallow bodies)", "backward A levels", "forward A levels", "forward B levels / forward sweep", "store + publish"]
+NAMES = ["load + initial FK", "body-body contact (capsules, pairs, collect)", "velocity products + per-body init (ground contact, drive)",
+         "drive exchange of the re-rooted tree", "backward sweep", "acceleration sweep", "joint integration", "kinematics by pointer jumping",
+         "store + publish"]
 
 
 def build():
@@ -41,9 +42,7 @@ def run():
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
     extra = sys.argv[3:]
     torch.manual_seed(0)
-    mapping = next((a.split("=")[1] for a in extra if a.startswith("mapping=")), "2")
-    extra = [a for a in extra if not a.startswith("mapping=")]
-    task, env = parse_task(compose([f"env.num_envs={n}", "env.motion_file=synthetic:1:0", f"+solver.lane_mapping={mapping}"] + extra))
+    task, env = parse_task(compose([f"env.num_envs={n}", "env.motion_file=synthetic:1:0"] + extra))
     env.reset()
     a = (torch.rand(n, task.num_actions, device=task.device) * 2 - 1) * 0.1
     for _ in range(20):

@@ -115,6 +115,46 @@ def test_fast_linear_matches_autocast_linear(B, K, N):
     assert torch.equal(fast(x), ref(x))
 
 
+def test_pnn_lateral_path_on_the_bf16_device_passes():
+    """pnn.py:103: the lateral term enters BEFORE the second hidden layer's activation, relu(W a1 + b + lateral).  On the device passes that
+    layer's ReLU normally rides in the GEMM epilogue (FastLinear.fuse_relu) -- it must not for a lateral column: the bf16 autocast
+    training forward / backward and the no-grad inference forward equal a plain nn.Linear / nn.ReLU restatement of the reference's forward."""
+    from phc_amd.learning.network import PNN
+    torch.manual_seed(3)
+    K, A, B = 160, 12, 512
+    pnn = PNN(K, [64, 32], "relu", A, 3, has_lateral=True).cuda()
+    x = torch.randn(B, K, device="cuda")
+
+    def plain(xi):   # the reference's forward on plain ops with the same parameters (pnn.py:85-126)
+        first, outs = [], []
+        for k in range(3):
+            col = pnn.actors[k]
+            a1 = torch.relu(torch.nn.functional.linear(xi, col[0].weight, col[0].bias))
+            lat = sum(torch.nn.functional.linear(first[j], pnn.u[k - 1][j][0].weight) for j in range(len(first))) if first else 0
+            a2 = torch.relu(torch.nn.functional.linear(a1, col[2].weight, col[2].bias) + lat)
+            outs.append(torch.nn.functional.linear(a2, col[4].weight, col[4].bias))
+            first.append(a1)
+        return outs
+    res = {}
+    for name in ("plain", "pnn"):
+        pnn.zero_grad()
+        xi = x.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            outs = plain(xi) if name == "plain" else pnn(xi, idx=-1)[1]
+        y = torch.stack([o.float() for o in outs], 1)
+        y.square().mean().backward()
+        res[name] = (y.detach(), xi.grad.clone(), pnn.actors[2][2].weight.grad.clone(), pnn.u[1][0][0].weight.grad.clone())
+    assert float((res["plain"][0] - res["pnn"][0]).abs().max()) <= 2e-2 * float(res["plain"][0].abs().max())
+    # the un-fixed path (ReLU before the lateral term) differs from the reference by O(1) of the output scale on the lateral columns
+    for k in (1, 2, 3):
+        scale = float(res["plain"][k].abs().max())
+        assert float((res["plain"][k] - res["pnn"][k]).abs().max()) < 3e-2 * scale, k
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        y_inf = torch.stack([o.float() for o in pnn(x, idx=-1)[1]], 1)
+    assert float((y_inf - res["plain"][0]).abs().max()) <= 2e-2 * float(res["plain"][0].abs().max())
+    assert not any(col[2].fuse_relu for col in pnn.actors) and all(col[0].fuse_relu for col in pnn.actors)
+
+
 @pytest.mark.parametrize("B,K,N", [(16384, 934, 1024), (4096, 1024, 512), (1000, 130, 7)])
 def test_fused_relu_layer_matches_linear_plus_relu(B, K, N):
     """build_mlp's FastLinear + FusedReLU pair (ReLU in the GEMM epilogue, ReLU mask + bias gradient in one pass, phc_colsum_relu_bf16) ==
