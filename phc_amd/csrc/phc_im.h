@@ -33,8 +33,14 @@ PHC_HD void amp_obs_from_ref_lane(const phc_motion_lib_t& lib, const phc_im_para
         int slot = prm.amp_joint_slot[j];
         if (slot >= 0) {
             V3 dp, dv;
-            ref_joint(lib, fr, j, &dp, &dv);
-            amp_obs_joint(prm, slot, dp, dv, a);
+            if (prm.dofs_per_joint == 1) {
+                ref_joint(lib, fr, j, &dp, &dv);
+                amp_obs_joint(prm, slot, dp, dv, a);
+            } else {
+                Q4 lr;
+                ref_joint_rot(lib, fr, j, &lr, &dv);
+                amp_obs_joint_rot(prm, slot, lr, dv, a);
+            }
         }
     }
     if (j < prm.num_key_bodies) {

@@ -84,6 +84,21 @@ static inline uint64_t splitmix64(uint64_t z) {
     return z ^ (z >> 31);
 }
 
+#ifdef PHC_SIM_PROFILE   // one lane group's timeline through the reset kernel (scripts/probes/reset_timeline.py; the product library has none of this)
+__device__ unsigned long long g_phc_rtl[64];
+__device__ int g_phc_rtl_group = -1;   // r * 16 + k of the group that stamps
+extern "C" int32_t phc_debug_reset_timeline(unsigned long long* out64, int32_t group) {
+    if (out64 && hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_phc_rtl), sizeof(g_phc_rtl)) != hipSuccess) return -1;
+    unsigned long long z[64] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_phc_rtl), z, sizeof(z)) != hipSuccess) return -1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_phc_rtl_group), &group, sizeof(group)) == hipSuccess ? 0 : -1;
+}
+#define PHC_RTL(i) if (rtl_on) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0); const unsigned long long t_ = __builtin_readcyclecounter(); \
+        if (lane == 0) g_phc_rtl[i] = t_; __builtin_amdgcn_sched_barrier(0); }
+#else
+#define PHC_RTL(i)
+#endif
+
 // Measured alternative (round 2, profiles/r02_notes.md): ONE workgroup per listed env with its S history-frame groups side by side
 // (blockDim = G * S), so that the S lookups of an env -- S + 1 consecutive clip frames -- share a CU's L1: 46.6 us vs 34 us for this
 // geometry (the ten groups of an env then hit one clip region, i.e. the same HBM channels, at the same instant).  Not kept.
@@ -95,6 +110,10 @@ __global__ __launch_bounds__(256) void k_im_reset(phc_model_t model, phc_motion_
     const int lane = threadIdx.x & (G - 1);
     const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;   // listed env (grid.x), AMP history frame k (grid.y)
     const int k = (int)blockIdx.y;
+#ifdef PHC_SIM_PROFILE
+    const bool rtl_on = (int)(r * 16 + k) == g_phc_rtl_group;
+#endif
+    PHC_RTL(0)
     int64_t env;
     if (RNG && buf.reset_list) {
         // reset_done() on the device-built list of finished envs: dense wavefronts, blocks beyond the count leave at once
@@ -113,12 +132,16 @@ __global__ __launch_bounds__(256) void k_im_reset(phc_model_t model, phc_motion_
         env = env_ids ? env_ids[r] : r;
         if (!env_ids && buf.reset_buf[env] == 0) return;
     }
+    PHC_RTL(1)
     const int64_t mid = buf.sampled_motion_ids[env];
     // _sample_ref_state (humanoid_im.py:1000-1023): StateInit.Random -> sample_time_interval; Start / flags.test -> 0
     // (start_at_zero with a null phase array is only legal in the RNG-free instantiation's list mode)
     const float t = start_at_zero ? 0.f : sample_time_interval(lib, mid, RNG ? hash_u01(rng_key, (uint32_t)env) : phase[r]);
+    PHC_RTL(2)
     if (k == 0) im_reset_lane(model, lib, prm, sim, buf, env, lane, t, env_ids != nullptr);
+    PHC_RTL(3)
     im_reset_amp_lane(lib, prm, buf, model.num_bodies, env, lane, t, k);
+    PHC_RTL(4)
 }
 
 // build_amp_obs_demo: n samples x S history steps.  One lane group per (sample, step).

@@ -41,6 +41,60 @@ PHC_HD V3 cross(V3 a, V3 b) { return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x *
 PHC_HD float norm2(V3 a) { return dot(a, a); }
 PHC_HD float norm(V3 a) { return sqrtf(dot(a, a)); }
 
+// ---- elementary functions of the reference-library restatements below ----
+// The reference evaluates these as torch CPU / CUDA ops (libm accuracy).  On the device the libm expansions are most of the task kernels'
+// instruction stream (round 3 count: sinf ~50 executed / 120 static instructions with its huge-argument path, IEEE division 12, IEEE sqrt 18), and
+// the kernels are bound by the length of one wavefront's stream (profiles/r03_stepper/README.md).  Device versions with <= 2 ulp error for the
+// bounded arguments of this path (angles of a few turns at most, normalised quaternions); parity with the reference is pinned at 1e-5 absolute by
+// tests/test_task_parity.py, five orders above their error.  INDEX arithmetic (frame_ref, sample_time_interval: bit-exact contract) does not
+// use them.  Host build (oracle/hostemu): plain libm.
+#if defined(__HIP_DEVICE_COMPILE__)
+PHC_HD float t_rcp(float b) {   // 1 / b, one Newton step on v_rcp_f32
+    float r = __builtin_amdgcn_rcpf(b);
+    return __builtin_fmaf(__builtin_fmaf(-b, r, 1.0f), r, r);
+}
+PHC_HD float t_div(float a, float b) {
+    const float r = t_rcp(b);
+    const float q = a * r;
+    return __builtin_fmaf(__builtin_fmaf(-b, q, a), r, q);
+}
+PHC_HD float t_sqrt(float x) {   // v_rsq_f32 + one Heron step; sqrt(0) = 0, sqrt(negative) = NaN like the reference
+    const float y = __builtin_amdgcn_rsqf(x);
+    float s = x * y;
+    s = __builtin_fmaf(__builtin_fmaf(-s, s, x) * 0.5f, y, s);
+    return x == 0.0f ? 0.0f : s;
+}
+// sin and cos of one argument: Cody-Waite reduction to [-pi/4, pi/4] (three-part pi/2, exact products for |x| < ~1e4), Cephes sinf / cosf kernels
+PHC_HD void t_sincos(float x, float* sn, float* cs) {
+    const float k = rintf(x * 0.636619772f);
+    float r = __builtin_fmaf(-k, 1.57073974609375f, x);
+    r = __builtin_fmaf(-k, 5.657970905303955078125e-05f, r);
+    r = __builtin_fmaf(-k, 9.920936294705029468e-10f, r);
+    const float z = r * r;
+    const float ps = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f) * z, r, r);
+    const float pc = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f) * z, z,
+                                    __builtin_fmaf(-0.5f, z, 1.0f));
+    const int n = (int)k;
+    const float s0 = (n & 1) ? pc : ps, c0 = (n & 1) ? ps : pc;
+    *sn = (n & 2) ? -s0 : s0;
+    *cs = ((n + 1) & 2) ? -c0 : c0;
+}
+PHC_HD float t_sin(float x) { float s, c; t_sincos(x, &s, &c); return s; }
+// atan2(sin x, cos x): x brought into (-pi, pi] by subtracting the nearest multiple of 2 pi (identity for |x| < pi)
+PHC_HD float t_normalize_angle(float x) {
+    const float k = rintf(x * 0.159154937f);
+    return __builtin_fmaf(k, 1.7484555e-7f, __builtin_fmaf(-k, 6.28318548f, x));
+}
+#else
+PHC_HD float t_rcp(float b) { return 1.0f / b; }
+PHC_HD float t_div(float a, float b) { return a / b; }
+PHC_HD float t_sqrt(float x) { return sqrtf(x); }
+PHC_HD void t_sincos(float x, float* sn, float* cs) { *sn = sinf(x); *cs = cosf(x); }
+PHC_HD float t_sin(float x) { return sinf(x); }
+PHC_HD float t_normalize_angle(float x) { return atan2f(sinf(x), cosf(x)); }
+#endif
+PHC_HD float t_norm(V3 a) { return t_sqrt(dot(a, a)); }
+
 // isaacgym_torch_utils.py:25-45 -- the 8-multiplication form
 PHC_HD Q4 quat_mul(Q4 a, Q4 b) {
     float ww = (a.z + a.x) * (b.x + b.y);
@@ -70,15 +124,15 @@ PHC_HD V3 quat_rotate(Q4 q, V3 v) {
 }
 
 // isaacgym_torch_utils.py:110-111
-PHC_HD float normalize_angle(float x) { return atan2f(sinf(x), cosf(x)); }
+PHC_HD float normalize_angle(float x) { return t_normalize_angle(x); }
 
 // isaacgym_torch_utils.py:250-271 -- (angle, axis); min_theta 1e-5, default axis z
 PHC_HD float quat_to_angle_axis(Q4 q, V3* axis) {
     const float min_theta = 1e-5f;
-    float sin_theta = sqrtf(1.0f - q.w * q.w);
+    float sin_theta = t_sqrt(1.0f - q.w * q.w);
     float angle = normalize_angle(2.0f * acosf(q.w));
     bool mask = fabsf(sin_theta) > min_theta;  // NaN (|w|>1) -> false, as torch.abs(nan) > x
-    if (axis) *axis = mask ? v3(q.x / sin_theta, q.y / sin_theta, q.z / sin_theta) : v3(0.f, 0.f, 1.f);
+    if (axis) { const float is = t_rcp(sin_theta); *axis = mask ? v3(q.x * is, q.y * is, q.z * is) : v3(0.f, 0.f, 1.f); }
     return mask ? angle : 0.0f;
 }
 
@@ -99,18 +153,22 @@ PHC_HD void quat_to_tan_norm(Q4 q, float* out6) {
 // isaacgym_torch_utils.py:49-50,97-106 -- normalises the axis, then the quaternion
 PHC_HD Q4 quat_from_angle_axis(float angle, V3 axis) {
     float theta = angle / 2.0f;
-    float an = fmaxf(norm(axis), 1e-9f);
-    float s = sinf(theta);
-    Q4 q = q4(axis.x / an * s, axis.y / an * s, axis.z / an * s, cosf(theta));
-    float qn = fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-9f);
-    return q4(q.x / qn, q.y / qn, q.z / qn, q.w / qn);
+    float an = fmaxf(t_norm(axis), 1e-9f);
+    float s, c;
+    t_sincos(theta, &s, &c);
+    const float ia = t_rcp(an);
+    Q4 q = q4(axis.x * ia * s, axis.y * ia * s, axis.z * ia * s, c);
+    float qn = fmaxf(t_sqrt(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-9f);
+    const float iq = t_rcp(qn);
+    return q4(q.x * iq, q.y * iq, q.z * iq, q.w * iq);
 }
 
 // isaacgym_torch_utils.py:342-365
 PHC_HD Q4 exp_map_to_quat(V3 e) {
     const float min_theta = 1e-5f;
-    float angle = norm(e);
-    V3 axis = v3(e.x / angle, e.y / angle, e.z / angle);
+    float angle = t_norm(e);
+    const float ian = t_rcp(angle);     // (angle 0: inf * 0 = NaN axis, replaced by the mask below -- as the reference's 0 / 0)
+    V3 axis = v3(e.x * ian, e.y * ian, e.z * ian);
     angle = normalize_angle(angle);
     bool mask = fabsf(angle) > min_theta;
     if (!mask) { angle = 0.f; axis = v3(0.f, 0.f, 1.f); }
@@ -123,9 +181,10 @@ PHC_HD Q4 slerp(Q4 q0, Q4 q1, float t) {
     if (c < 0.f) { q1 = q4(-q1.x, -q1.y, -q1.z, -q1.w); }
     c = fabsf(c);
     float half_theta = acosf(c);
-    float s = sqrtf(1.0f - c * c);
-    float ra = sinf((1.0f - t) * half_theta) / s;
-    float rb = sinf(t * half_theta) / s;
+    float s = t_sqrt(1.0f - c * c);
+    const float is = t_rcp(s);
+    float ra = t_sin((1.0f - t) * half_theta) * is;
+    float rb = t_sin(t * half_theta) * is;
     Q4 r = q4(ra * q0.x + rb * q1.x, ra * q0.y + rb * q1.y, ra * q0.z + rb * q1.z, ra * q0.w + rb * q1.w);
     if (fabsf(s) < 0.001f) r = q4(0.5f * q0.x + 0.5f * q1.x, 0.5f * q0.y + 0.5f * q1.y, 0.5f * q0.z + 0.5f * q1.z, 0.5f * q0.w + 0.5f * q1.w);
     if (fabsf(c) >= 1.f) r = q0;

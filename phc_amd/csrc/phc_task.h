@@ -148,6 +148,31 @@ PHC_HD void ref_joint(const phc_motion_lib_t& lib, const FrameRef& fr, int j, V3
     *dof_pos = quat_to_exp_map(lr);
     *dof_vel = lerp3(ld3(a + fr_dvel(lib) + 3 * (j - 1)), ld3(b + fr_dvel(lib) + 3 * (j - 1)), fr.blend);
 }
+// Spherical joint of body j >= 1 for the AMP observation of a REFERENCE frame (humanoid_amp.py:575-603,253-284): the reference goes
+// local rotation -> slerp -> quat_to_exp_map (dof_pos, motion_lib_base.py:483-484) -> exp_map_to_quat -> tan_norm (dof_to_obs_smpl,
+// humanoid.py:1756-1765).  Composed in closed form here: with q = (v, w), a = normalize_angle(2 acos w), s = sqrt(1 - w^2), the exp-map is
+// (v / s) a, so exp_map_to_quat sees the angle |a| |v| / s about sign(a) v / |v| -- for a unit q that is +-q, for the not-quite-unit
+// rotations a motion file holds the factor |v| / s is what the reference computes, and it is kept (it moves small joint angles by up to
+// 1e-4 on the synthetic clips).  Both 1e-5 thresholds of the chain are kept.  One acos, one sin / cos pair, two square roots instead of
+// acos + 2 atan2 + 3 sin / cos pairs + ~14 divisions (round 3: this chain was half of the reset kernel's instruction stream).
+PHC_HD Q4 exp_map_round_trip(Q4 q) {
+    const float sin_half = t_sqrt(1.0f - q.w * q.w);
+    const bool mask1 = fabsf(sin_half) > 1e-5f;                   // quat_to_angle_axis (NaN for |w| > 1 -> false, as torch.abs(nan) > x)
+    const float angle = normalize_angle(2.0f * acosf(q.w));
+    const float vn = t_sqrt(q.x * q.x + q.y * q.y + q.z * q.z);
+    const float ang2 = normalize_angle(fabsf(angle) * vn * t_rcp(sin_half));   // exp_map_to_quat: |exp-map|, then normalize_angle
+    const bool mask2 = fabsf(ang2) > 1e-5f;
+    const float k = (angle < 0.f ? -1.0f : 1.0f) * t_rcp(vn);
+    float sn, cs;
+    t_sincos(0.5f * ang2, &sn, &cs);
+    return (mask1 && mask2) ? q4(q.x * k * sn, q.y * k * sn, q.z * k * sn, cs) : q4(0.f, 0.f, 0.f, 1.f);
+}
+PHC_HD void ref_joint_rot(const phc_motion_lib_t& lib, const FrameRef& fr, int j, Q4* rot, V3* dof_vel) {
+    const float* a = lib.frames + fr.f0 * (int64_t)lib.frame_stride;
+    const float* b = lib.frames + fr.f1 * (int64_t)lib.frame_stride;
+    *rot = exp_map_round_trip(slerp(ld4(a + fr_lrot(lib) + 4 * j), ld4(b + fr_lrot(lib) + 4 * j), fr.blend));
+    *dof_vel = lerp3(ld3(a + fr_dvel(lib) + 3 * (j - 1)), ld3(b + fr_dvel(lib) + 3 * (j - 1)), fr.blend);
+}
 // joint coordinates in the simulator tensors: 3 (exp-map) or 1 (angle) consecutive DoFs starting at ds
 PHC_HD void ld_joint_state(const phc_sim_state_t& sim, int nd, int64_t env, int ds, int dpj, V3* pos, V3* vel) {
     const float* d = sim.dof_state + (env * nd + ds) * 2;
@@ -314,6 +339,13 @@ PHC_HD void amp_obs_joint(const phc_im_params_t& prm, int slot, V3 dof_pos, V3 d
     }
     float tn[6];
     quat_to_tan_norm(exp_map_to_quat(dof_pos), tn);  // dof_to_obs_smpl humanoid.py:1756-1765
+    for (int k = 0; k < 6; ++k) a[off + slot * 6 + k] = tn[k];
+    st3(a + off + prm.num_amp_joints * 6 + slot * 3, dof_vel);
+}
+PHC_HD void amp_obs_joint_rot(const phc_im_params_t& prm, int slot, Q4 rot, V3 dof_vel, float* a) {   // spherical joints, see ref_joint_rot
+    const int off = (prm.root_height_obs ? 1 : 0) + 12;
+    float tn[6];
+    quat_to_tan_norm(rot, tn);
     for (int k = 0; k < 6; ++k) a[off + slot * 6 + k] = tn[k];
     st3(a + off + prm.num_amp_joints * 6 + slot * 3, dof_vel);
 }
