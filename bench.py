@@ -388,8 +388,12 @@ def main():
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    per_rank = [elapsed]
     if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        gathered = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(gathered, t)                      # every rank's own time: weak scaling readable per rank
+        per_rank = [float(x.item()) for x in gathered]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))  # torch's current stream == the launch stream
@@ -444,8 +448,10 @@ def main():
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
                          "note": "SURVEY 8(d) canonical un-fused accounting (1484 B x 4 sub-steps + 1812 B per env; the fused launch's compulsory "
-                                 "traffic is 3296 B/env).  The kernel is NOT HBM-bound: at 4096 envs it is bound by the VALU issue of its "
-                                 "instruction stream (SQ counters: 16.7 k VALU instructions per wavefront, 0.82 of every SIMD's cycles VALU-active, profiles/r02_pmc_valu.txt, r02_notes.md)",
+                                 "traffic is 3296 B/env).  The kernel is NOT HBM-bound: at 4096 envs all 2048 wavefronts run concurrently and the launch "
+                                 "lasts as long as ONE wavefront's serial stream (15.9 k VALU instructions at a per-wavefront issue interval of ~4.4 "
+                                 "cycles + LDS / scalar / waits); the SIMDs' fp32 pipes are ~41 % busy (profiles/r03_stepper/README.md, "
+                                 "profiles/microbench/valu_issue_mi355x.txt, profiles/r03_pmc_valu.txt)",
                          "gflops": FLOPS_PER_ENV_SUBSTEP * nsub * N / (kern_ms * 1e-3) / 1e9},
         }
         if ppo is not None:
@@ -460,6 +466,7 @@ def main():
         if (world == 1 and not args.no_other_workloads and not os.environ.get("PHC_BENCH_CHILD") and args.config == 2 and args.robot == "smpl"
                 and args.actions == "random" and args.envs == 4096):
             out["other_workloads"] = other_workloads()
+        out["per_rank"] = [{"rank": r, "elapsed_s": e, "env_steps_per_s": N * args.steps / e} for r, e in enumerate(per_rank)]
         out["actions"] = args.actions
         if not os.environ.get("PHC_BENCH_CHILD"):
             out["device"] = device_state(dev)

@@ -85,18 +85,32 @@ class HumanoidIm:
             raise NotImplementedError(f"humanoid_type={self.humanoid_type!r}: built so far: smpl, h1, g1")
         self._is_robot = self.humanoid_type in ("h1", "g1")
         # options of the reference this path does not build: refuse them rather than run without them
-        unsupported = dict(kin_loss=False, z_readout=False, distill=False, enableHistObs=False, remove_disc_rot=False,
-                           divide_group=False, group_obs=False, add_action_noise=False, is_discrete=False)
+        #   enableHistObs: the AMP history window appended to the self observation (humanoid_amp.py:98-101,327,549-555);
+        #   divide_group: several humanoids in ONE collision group, i.e. inter-env contact (humanoid.py:261-266,1051-1052): the stepper's envs are independent
+        unsupported = dict(kin_loss=False, z_readout=False, distill=False, enableHistObs=False, divide_group=False, is_discrete=False)
         for k, off in unsupported.items():
             v = env.get(k, robot.get(k, off))
             if v != off:
                 raise NotImplementedError(f"config option {k}={v!r} is outside the hot path built so far")
-        if env.get("obs_v", 1) not in (1, 2, 3, 6, 7, 8, 9) or env.get("self_obs_v", 1) not in (1, 2, 3) or env.get("amp_obs_v", 1) not in (1, 2):
-            raise NotImplementedError("built: obs_v 1 / 2 / 3 / 6 / 7 / 8 / 9 (4 and 5 -- past-step stacking, one-hot clip ids -- are not), self_obs_v 1 / 2 / 3 "
-                                      "(force sensors), amp_obs_v 1 / 2 (key-body velocities)")
+        # (env.group_obs / disable_group_obs: read by load_common_humanoid_configs (humanoid.py:262-263) and used nowhere else in the reference)
+        self._group_obs, self._disable_group_obs = env.get("group_obs", False), env.get("disable_group_obs", False)
+        if env.get("obs_v", 1) not in (1, 2, 3, 4, 5, 6, 7, 8, 9) or env.get("self_obs_v", 1) not in (1, 2, 3) or env.get("amp_obs_v", 1) not in (1, 2):
+            raise NotImplementedError("built: obs_v 1 - 9, self_obs_v 1 / 2 / 3 (force sensors), amp_obs_v 1 / 2 (key-body velocities)")
         self.has_task = True
         self.obs_v, self.self_obs_v, self.amp_obs_v = int(env.get("obs_v", 6)), int(env.get("self_obs_v", 1)), int(env.get("amp_obs_v", 1))
         self.past_track_steps = int(env.get("past_track_steps", 5))   # humanoid.py:331
+        if self.obs_v == 4 and self.past_track_steps != 1:
+            # obs_v 4 = the v6 observation of the last `past_track_steps` steps: `_compute_observations` (humanoid_im.py:713-722) stacks the WHOLE row
+            # (self + task, width n) into rows of width n * past_track_steps, while the sizes count only the task block that many times
+            # (:496-501; the self-observation factor is commented out, :479-484): for past_track_steps > 1 the reference's own assignment fails with
+            # a shape error.  With past_track_steps = 1 the stacking is the identity and the observation is the v6 one.
+            raise NotImplementedError("obs_v=4 with past_track_steps > 1: the reference's row stacking (humanoid_im.py:713-722) does not fit its own "
+                                      "observation size (:496-501,479-484); past_track_steps=1 (== obs_v 6) is what it can run")
+        if self.obs_v in (4, 5) and env.get("fut_tracks", False):
+            raise NotImplementedError("fut_tracks: built for the time-major task observations obs_v 6 / 7 / 9")
+        self._add_action_noise = bool(env.get("add_action_noise", False))     # humanoid.py:337,1533-1535: applied only while collect_dataset is on
+        self._action_noise_std = float(env.get("action_noise_std", 0.05))
+        self._remove_disc_rot = bool(env.get("remove_disc_rot", False))       # humanoid.py:309,405-406: no joint rotations / rates in the AMP observation
         # future reference tracks in the task observation (humanoid_im.py:39-47): numTrajSamples frames, 1 / trajSampleTimestepInv apart
         self._fut_tracks = bool(env.get("fut_tracks", False))
         self._num_traj_samples = int(env["numTrajSamples"]) if self._fut_tracks else 1
@@ -289,8 +303,12 @@ class HumanoidIm:
             self._num_self_obs += 6 * len(self.force_sensor_joints)
         self._track_bodies = env.get("trackBodies", self._full_track_bodies)
         self._reset_bodies = env.get("reset_bodies", self._track_bodies)
+        if self._remove_disc_rot and (self._is_robot or not self._has_dof_subset):
+            raise NotImplementedError("remove_disc_rot empties dof_subset, which only the SMPL family with robot.has_dof_subset reads (humanoid.py:405-413, "
+                                      "humanoid_amp.py:996-998)")
         track_slot, reset_mask, key_ids, amp_slot, n_amp_joints = abi.task_index_tables(
-            self.model, self._track_bodies, self._reset_bodies, self.key_bodies, has_dof_subset=self._has_dof_subset and not self._is_robot)
+            self.model, self._track_bodies, self._reset_bodies, self.key_bodies, has_dof_subset=self._has_dof_subset and not self._is_robot,
+            **({"amp_remove_names": tuple(self._body_names_orig)} if self._remove_disc_rot else {}))
         if self._is_robot:  # humanoid_amp.py:315-322: [root_h, root_rot 6, root_vel 3, root_ang_vel 3, dof_pos, dof_vel, key_body_pos]
             self._num_amp_obs_per_step = 13 + self._dof_obs_size + len(self._dof_names) + 3 * len(self.key_bodies) - (0 if self._amp_root_height_obs else 1)
             self.dof_subset = torch.tensor([]).long()
@@ -301,7 +319,7 @@ class HumanoidIm:
             if self._amp_obs_extra is not None:   # humanoid_amp.py:310-313
                 self._num_amp_obs_per_step += self._amp_obs_extra.shape[1]
             dof_sub = [np.arange(3 * (j - 1), 3 * j) for j in range(1, self.num_bodies) if amp_slot[j] >= 0]
-            self.dof_subset = torch.from_numpy(np.concatenate(dof_sub)) if self._has_dof_subset else torch.tensor([]).long()
+            self.dof_subset = torch.from_numpy(np.concatenate(dof_sub)) if self._has_dof_subset and dof_sub else torch.tensor([]).long()
         # extended bodies of the full-body reward (humanoid_im.py:74-82)
         ext = list(robot.get("extend_config", [])) if self._is_robot else []
         self.num_extend_bodies = len(ext)
@@ -500,7 +518,7 @@ class HumanoidIm:
             first_reset_body=self._body_names.index(self._reset_bodies[0]), termination_distances=self._termination_distances_full,
             num_key_bodies=len(self.key_bodies), key_body_ids=key_ids, num_amp_joints=self._n_amp_joints, amp_joint_slot=amp_slot,
             num_amp_obs_steps=self._num_amp_obs_steps, num_amp_obs_per_step=self._num_amp_obs_per_step,
-            num_self_obs=self.get_self_obs_size(), num_task_obs=self.get_task_obs_size(), obs_v=self.obs_v, cycle_motion=self.cycle_motion,
+            num_self_obs=self.get_self_obs_size(), num_task_obs=self.get_task_obs_size(), obs_v=6 if self.obs_v in (4, 5) else self.obs_v, cycle_motion=self.cycle_motion,
             zero_out_far=self.zero_out_far, close_distance=self.close_distance, far_distance=self.far_distance,
             dofs_per_joint=1 if self._is_robot else 3, ext_parent=self._ext_parent_i32, ext_offset=self._ext_offset_f32,
             self_obs_v=self.self_obs_v, num_force_sensors=len(self.force_sensor_joints) if self.self_obs_v == 3 else 0, amp_obs_v=self.amp_obs_v,
@@ -546,7 +564,9 @@ class HumanoidIm:
         J = len(self._track_bodies)   # humanoid_im.py:486-520 with num_traj_samples = 1
         if self.obs_v in (2, 9) and self._track_bodies[0] != self._body_names[0]:
             raise NotImplementedError("obs_v 2 / 9 index the root as the first tracked body (humanoid_im.py:775-776,822)")
-        return {1: 15 * J, 2: 15 * J + 3 * (J - 1), 3: 9 * J, 6: 24 * J, 7: 9 * J, 8: 30 * J, 9: 18 * J + 6}[self.obs_v] * self._num_traj_samples
+        if self.obs_v == 5:   # v6 + the one-hot id of the env's clip, "+ 30  # Hard coded." (humanoid_im.py:503-504,812-815)
+            return 24 * J + 30
+        return {1: 15 * J, 2: 15 * J + 3 * (J - 1), 3: 9 * J, 4: 24 * J, 6: 24 * J, 7: 9 * J, 8: 30 * J, 9: 18 * J + 6}[self.obs_v] * self._num_traj_samples
 
     def get_obs_size(self):
         return self.get_self_obs_size() + self.get_task_obs_size()
@@ -678,6 +698,10 @@ class HumanoidIm:
         self.actions = actions.to(self.device)
         if self.actions.dim() == 1:
             self.actions = self.actions[None]
+        if self.collect_dataset:   # humanoid.py:1530-1535
+            self.clean_actions = self.actions.clone()
+            if self._add_action_noise:
+                self.actions = self.actions + torch.normal(mean=0.0, std=self._action_noise_std, size=self.actions.shape, device=self.device)
         if self.control_mode == "pd":
             self.actions = torch.clip(self.actions, -10, 10)   # humanoid.py:1568-1570
         if self._occl_training:   # humanoid_im.py:1112-1113
@@ -787,7 +811,20 @@ class HumanoidIm:
             self._reset_list_pending = False
         self._obs_noise(reset_rows=True)
 
+    def _one_hot_obs(self):
+        """obs_v 5 (humanoid_im.py:812-815, motion_lib_base.py:214): the one-hot id of the env's clip among the library's unique motions behind the
+        v6 block; the size is hard-coded to 30 columns (:503-504), i.e. the option runs on libraries of exactly 30 clips.  The kernels write the
+        v6 columns only; these are refreshed here (the ids change when motions are re-sampled)."""
+        if self.obs_v != 5:
+            return
+        U = self._motion_lib._num_unique_motions
+        if U != 30:
+            raise ValueError(f"obs_v=5: the observation reserves 30 one-hot columns (humanoid_im.py:504), the motion library has {U} clips")
+        off = self.get_self_obs_size() + 24 * len(self._track_bodies)
+        self.obs_buf[:, off:off + U] = torch.nn.functional.one_hot(self._motion_lib._curr_motion_ids.to(self.device), num_classes=U).to(self.obs_buf.dtype)
+
     def _obs_noise(self, env_ids=None, reset_rows=False):
+        self._one_hot_obs()
         self._fut_dropout(env_ids, reset_rows)
         self._add_obs_noise(env_ids, reset_rows)
 

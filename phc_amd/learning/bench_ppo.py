@@ -43,10 +43,16 @@ def time_ppo_epochs(task, env, cfg, epochs, dist=None, warmup=1):
         ws = [None] * world
         dist.all_gather_object(ws, {"rank": dist.get_rank(), "world": dist.get_world_size(), "backend": dist.get_backend(),
                                     "device": torch.cuda.current_device(), "collectives": agent.num_collectives - c0})
+        # the replicas stay in lock-step: every rank's parameter vector (fp64 sum and sum of squares) after the timed epochs
+        flat = torch.cat([p.detach().double().flatten() for p in agent.model.parameters()])
+        sig = torch.stack([flat.sum(), flat.square().sum()])
+        sigs = [torch.zeros_like(sig) for _ in range(world)]
+        dist.all_gather(sigs, sig)
+        identical = all(bool(torch.equal(sigs[0], x)) for x in sigs)
         ar = sorted(a.elapsed_time(b) for a, b in agent.allreduce_timing)
         nbytes = int(agent.grads.flat.numel() * 4)
         med = ar[len(ar) // 2] if ar else None
-        comm = {"ppo_comm": {"backend": dist.get_backend(), "ranks": ws, "grad_allreduces_per_epoch": (agent.num_collectives - c0) / epochs,
+        comm = {"ppo_comm": {"backend": dist.get_backend(), "ranks": ws, "replicas_identical": identical, "grad_allreduces_per_epoch": (agent.num_collectives - c0) / epochs,
                              "allreduce_bytes": nbytes, "allreduce_ms_median": med, "allreduce_ms_mean": (sum(ar) / len(ar)) if ar else None,
                              "allreduce_ms_max": ar[-1] if ar else None,
                              # ring all-reduce moves 2 (G-1)/G x bytes per rank
