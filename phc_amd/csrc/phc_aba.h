@@ -344,7 +344,25 @@ PHC_HD void aba_body_init(AbaLane& L, const phc_model_t& m, const phc_sim_params
     const float* cp = m.floats + PHC_MAX_BODIES * PHC_BODY_FLOATS + cp_start * 4;
     // broad phase: f[34] bounds |contact point| + radius, so above that height nothing of this body reaches the plane
     const int cp_count = (L.p.z < f[34]) ? cp_total : 0;
+    // touching points first (round 3): the heights of up to 32 of the body's points above the plane are formed branch-free with their table
+    // loads in flight together (the z row of R only: 4 instructions per point); the loop below then visits the SET BITS -- one iteration per
+    // touching point of the busiest lane, each with its point's record already requested -- instead of one dependent table load and one
+    // depth test per point (the 8-corner feet made every sub-step walk 8 iterations)
+    uint32_t touching = 0u;
+    const int cp_fast = cp_count < 32 ? cp_count : 32;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 8
+#endif
+    for (int k = 0; k < cp_fast; ++k) {
+        const float az = R.m[6] * cp[4 * k] + R.m[7] * cp[4 * k + 1] + R.m[8] * cp[4 * k + 2];
+        if (cp[4 * k + 3] - (L.p.z + az) > 0.f) touching |= 1u << k;
+    }
     for (int k = 0; k < cp_count; ++k) {
+        if (k < 32) {   // jump to the next touching point
+            const uint32_t rest = touching >> k;
+            if (rest == 0u) { if (cp_count <= 32) break; k = 31; continue; }
+            k += __builtin_ctz(rest);
+        }
         V3 arm = mat_mul(R, v3(cp[4 * k], cp[4 * k + 1], cp[4 * k + 2]));
         float rad = cp[4 * k + 3];
         float depth = rad - (L.p.z + arm.z);
@@ -509,13 +527,20 @@ PHC_HD void aba_publish_capsule(const AbaLane& L, const float* f, float* cap) {
 // Needs both bodies' capsules in `caps` and kinematics (p w v at slot floats [10..19)) in the exchange slots.
 // Returns true when the pair is FAR: its surfaces are more than PHC_SC_SKIP_MARGIN apart (see aba_collide_pairs).
 #define PHC_SC_SKIP_MARGIN 0.12f
-PHC_HD bool aba_collide_pair(const phc_sim_params_t& prm, float dt, int i, int k, const Xch& x, float* caps) {
+// broad phase of one pair: bounding spheres.  -> 0: the spheres overlap (run the narrow phase), 1: apart but within PHC_SC_SKIP_MARGIN, 2: far
+PHC_HD int aba_pair_broad(int i, int k, const float* caps) {
     const float* ci = caps + PHC_CAP_STRIDE * i;
     const float* ck = caps + PHC_CAP_STRIDE * k;
     const V3 dm = v3(ci[0] - ck[0], ci[1] - ck[1], ci[2] - ck[2]);
     const float R = ci[3] + ck[3];
     const float d2 = dot(dm, dm);
-    if (d2 > R * R) return d2 > (R + PHC_SC_SKIP_MARGIN) * (R + PHC_SC_SKIP_MARGIN);   // broad phase
+    if (d2 <= R * R) return 0;
+    return d2 > (R + PHC_SC_SKIP_MARGIN) * (R + PHC_SC_SKIP_MARGIN) ? 2 : 1;
+}
+// narrow phase: the capsule-capsule test, then the penalty force into both accumulators.  Returns true when the surfaces are more than the margin apart.
+PHC_HD bool aba_pair_narrow(const phc_sim_params_t& prm, float dt, int i, int k, const Xch& x, float* caps) {
+    const float* ci = caps + PHC_CAP_STRIDE * i;
+    const float* ck = caps + PHC_CAP_STRIDE * k;
     const V3 a1 = v3(ci[4], ci[5], ci[6]), b1 = v3(ci[8], ci[9], ci[10]), a2 = v3(ck[4], ck[5], ck[6]), b2 = v3(ck[8], ck[9], ck[10]);
     const float r1 = ci[7], m1 = ci[11], r2 = ck[7], m2 = ck[11];
     V3 c1, c2;
@@ -548,41 +573,54 @@ PHC_HD bool aba_collide_pair(const phc_sim_params_t& prm, float dt, int i, int k
     sc_atomic_add(ak + 3, -(int32_t)rintf(nk.x * PHC_SC_NSCALE)); sc_atomic_add(ak + 4, -(int32_t)rintf(nk.y * PHC_SC_NSCALE)); sc_atomic_add(ak + 5, -(int32_t)rintf(nk.z * PHC_SC_NSCALE));
     return false;
 }
-// lane `l` of `nl` lanes of the env's group: its share of the candidate pairs, fetched ONCE per launch into registers (the list
-// sits in global memory; a dependent L2 round trip per pair and sub-step was the largest part of the first version's cost)
-// pairs per lane: 18 x 16 lanes hold the 245 pairs of the SMPL humanoid; a wide group (32 lanes x 2 bodies) takes 24 (G1: 589)
+// one candidate pair (bodies i < k), both phases (the host emulation walks the pairs with this).  Returns true when the pair is FAR.
+PHC_HD bool aba_collide_pair(const phc_sim_params_t& prm, float dt, int i, int k, const Xch& x, float* caps) {
+    const int b = aba_pair_broad(i, k, caps);
+    return b == 0 ? aba_pair_narrow(prm, dt, i, k, x, caps) : b == 2;
+}
+// lane `l` of `nl` lanes of the env's group: its share of the candidate pairs, dealt round-robin, kept in LDS as [pair slot t][thread]
+// (round 3; 18 x 32 lanes hold the 245 pairs of the SMPL humanoid, 18 x 64 the 589 of G1)
 #define PHC_SC_MAX_PER_LANE 18
-#define PHC_SC_MAX_PER_LANE_WIDE 24
 template <int NP>
-struct PairList { int pr[NP]; };
-template <int NP>
-PHC_HD void aba_load_pairs(PairList<NP>& P, const phc_model_t& m, int l, int nl) {
+PHC_HD void aba_load_pairs(int* pr /*[NP][stride]*/, int stride, const phc_model_t& m, int l, int nl) {
     const int np = model_num_pairs(m);
+#if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
+#endif
     for (int t = 0; t < NP; ++t) {
         const int q = t * nl + l;
-        P.pr[t] = q < np ? model_pair(m, q) : -1;
+        pr[t * stride] = q < np ? model_pair(m, q) : -1;
     }
 }
-// Temporal coherence over the sub-steps of ONE launch (round 2: body-body contact was 17 us of the two-slot launch): the first sub-step
-// tests every candidate pair and remembers in `near` (bit t = pair t of this lane) the ones whose surfaces are closer than
-// PHC_SC_SKIP_MARGIN = 0.12 m; the remaining sub-steps (3 x 1/120 s) only revisit those.  A pair closing faster than ~5 m/s from beyond the
-// margin is picked up one env step late at the latest (the penalty contact is soft by construction, k = mu / (4 dt^2)).  The host
-// emulation / fp64 oracle test every pair in every sub-step; they agree with this unless such a pair exists.
+// Temporal coherence over the sub-steps of ONE launch (round 2): the first sub-step tests every candidate pair and remembers in `near`
+// (bit t = pair t of this lane) the ones whose surfaces are closer than PHC_SC_SKIP_MARGIN = 0.12 m; the remaining sub-steps (3 x 1/120 s)
+// only revisit those.  A pair closing faster than ~5 m/s from beyond the margin is picked up one env step late at the latest (the penalty
+// contact is soft by construction, k = mu / (4 dt^2)).  The host emulation / fp64 oracle test every pair in every sub-step; they agree with
+// this unless such a pair exists.
+// A loop over the SET BITS of the lane's candidate mask (round 3): the first version walked all NP pair slots with a branch around each --
+// a wavefront then executes slot t whenever ANY of its 64 lanes has a pair there, i.e. nearly all of them although a lane has 0-2 near pairs
+// (one wavefront's timeline: 5.5 k of a sub-step's 38 k cycles, profiles/r03_stepper).  Compacted, the wavefront runs as many iterations as
+// its busiest lane has candidates.  The pair list lives in LDS so that the loop can index it.
 template <int NP>
-PHC_HD void aba_collide_pairs(const PairList<NP>& P, const phc_sim_params_t& prm, float dt, const Xch& x, float* caps, uint32_t& near, bool refresh) {
-    // ONE unrolled loop for both modes (two copies of the 18 inlined pair tests cost the one-body-per-lane kernel 160 B / lane of
-    // scratch: 13 MB of extra write traffic per launch)
-    uint32_t nr = refresh ? 0u : near;
+PHC_HD void aba_collide_pairs(const int* pr, int stride, const phc_sim_params_t& prm, float dt, const Xch& x, float* caps, uint32_t& near, bool refresh) {
+    uint32_t cand = near, nr = 0u;
+    if (refresh) {   // every valid slot of the lane
+        cand = 0u;
+#if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
-    for (int t = 0; t < NP; ++t) {
-        const bool go = refresh ? (P.pr[t] >= 0) : (((near >> t) & 1u) != 0u);
-        if (go) {
-            const bool far = aba_collide_pair(prm, dt, P.pr[t] & 0xff, P.pr[t] >> 8, x, caps);
-            if (refresh && !far) nr |= 1u << t;
-        }
+#endif
+        for (int t = 0; t < NP; ++t) cand |= (pr[t * stride] >= 0 ? 1u : 0u) << t;
     }
-    near = nr;
+    while (cand != 0u) {
+        const int t = __builtin_ctz(cand);
+        cand &= cand - 1u;
+        const int pq = pr[t * stride];
+        const int i = pq & 0xff, k = pq >> 8;
+        const int b = aba_pair_broad(i, k, caps);
+        const bool far = b == 0 ? aba_pair_narrow(prm, dt, i, k, x, caps) : b == 2;
+        if (!far) nr |= 1u << t;
+    }
+    if (refresh) near = nr;   // (the later sub-steps keep the first sub-step's set)
 }
 // net body-body contact force / moment of body j from its accumulators
 PHC_HD void aba_collect_self(AbaLane& L, int j, const float* caps) {

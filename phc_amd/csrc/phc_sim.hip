@@ -138,6 +138,7 @@ __global__ __launch_bounds__(64, 2) void k_sim_step(phc_model_t model_all, phc_s
                                                 int num_sim_calls, const int64_t* __restrict__ env_ids, int num_listed) {
     __shared__ float xch_all[64 * PHC_XCH_STRIDE];   // one exchange slot per lane == body
     __shared__ float cap_all[64 * PHC_CAP_STRIDE];
+    __shared__ int pair_all[PHC_SC_MAX_PER_LANE * 64];   // candidate pairs of body-body contact: [pair slot][thread]
     const int lane = threadIdx.x & (GRP - 1);
     const int grp = threadIdx.x / GRP;
     const int64_t slot = (int64_t)blockIdx.x * (64 / GRP) + grp;
@@ -175,9 +176,8 @@ __global__ __launch_bounds__(64, 2) void k_sim_step(phc_model_t model_all, phc_s
         const float dt = prm.sim_dt / (float)prm.substeps;
         const int nsub = num_sim_calls * prm.substeps;
         float* caps = cap_all + grp * GRP * PHC_CAP_STRIDE;
-        PairList<PHC_SC_MAX_PER_LANE> pairs;
         uint32_t near_pairs = 0;
-        if (prm.self_collision) aba_load_pairs(pairs, model, lane, GRP);
+        if (prm.self_collision) aba_load_pairs<PHC_SC_MAX_PER_LANE>(pair_all + threadIdx.x, 64, model, lane, GRP);
         // the backward / acceleration sweeps walk the solver tree (model.py solver_tree(): re-rooted where that makes it shallower)
         const int solver_depth = model_solver_depth(model, true);
         const int jump_steps = model_jump_steps(model);
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(64, 2) void k_sim_step(phc_model_t model_all, phc_s
             if (prm.self_collision && !PHC_SKIP(0)) {   // body-body contact from the kinematics the last sweep left in the exchange slots
                 if (active) aba_publish_capsule(L, model_body(model, body), caps + PHC_CAP_STRIDE * body);
                 __syncthreads();
-                if (env < sim.num_envs) aba_collide_pairs(pairs, prm, dt, x, caps, near_pairs, s == 0);
+                if (env < sim.num_envs) aba_collide_pairs<PHC_SC_MAX_PER_LANE>(pair_all + threadIdx.x, 64, prm, dt, x, caps, near_pairs, s == 0);
                 __syncthreads();
                 if (active) aba_collect_self(L, body, caps);
             }

@@ -18,6 +18,8 @@ There is no CPU fallback: constructing the task without a HIP device raises.
 from collections import OrderedDict
 from enum import Enum
 
+import os
+
 import numpy as np
 import torch
 
@@ -529,6 +531,21 @@ class HumanoidIm:
         self._flag_state = (flags.im_eval, flags.no_collision_check)
 
     def _buffers(self, amp_in, amp_out):
+        """The phc_im_buffers_t of a launch.  Building the struct costs ~20 us of host time (thirty data_ptr() calls and ctypes stores) and a rollout
+        step needs two; the combinations that occur (AMP window position x reset-list slot) are few, every other pointer is fixed for the
+        task's lifetime: cached (the rollout is host-bound, profiles/r02_notes.md)."""
+        key = (amp_in.data_ptr(), amp_out.data_ptr(), self._reset_slot, None if self._occl_mask is None else self._occl_mask.data_ptr(),
+               None if self._offset_rand is None else self._offset_rand.data_ptr(), self._sampled_motion_ids.data_ptr(), self.obs_buf.data_ptr())
+        cache = self.__dict__.setdefault("_buffers_cache", {})
+        b = cache.get(key)
+        if b is None:
+            if len(cache) > 256:
+                cache.clear()
+            b = cache[key] = self._buffers_uncached(amp_in, amp_out)
+        b.reset_list = abi.ptr(self._reset_list)     # (callers clear it for the masked sweep: restored on every use)
+        return b
+
+    def _buffers_uncached(self, amp_in, amp_out):
         return abi.im_buffers_struct(self.progress_buf, self.reset_buf, self._terminate_buf, self.rew_buf, self.reward_raw, self.obs_buf,
                                      amp_in, amp_out, self._sampled_motion_ids, self._motion_start_times, self._motion_start_times_offset,
                                      self._global_offset, self.ref_body_pos, self.ref_body_rot, self.ref_body_vel, self.ref_dof_pos,
@@ -616,6 +633,12 @@ class HumanoidIm:
             # "stand[:seconds]" -- the rest pose standing still (a physically feasible clip for end-to-end sanity runs)
             from ...utils.synthetic_motion import make_stand_clip
             mf = {"stand_00000": make_stand_clip(self.model, float(mf.split(":")[1]) if ":" in mf else 10.0)}
+        if isinstance(mf, str) and mf.split(":")[0] in ("squat", "stepinplace", "walk") and not self._is_robot:
+            # "squat | stepinplace | walk[:seconds]" -- locomotion-class sanity clips (leg IK on prescribed pelvis / foot trajectories: feet leave the
+            # ground and come back without sliding, the walk translates the centre of mass at 0.7 m/s)
+            from ...utils.synthetic_motion import make_gait_clip
+            kind = mf.split(":")[0]
+            mf = {f"{kind}_00000": make_gait_clip(self.model, kind, float(mf.split(":")[1]) if ":" in mf else 10.0)}
         if isinstance(mf, str) and mf.startswith("armswing") and not self._is_robot:
             # "armswing[:seconds]" -- standing with swinging arms (the second feasible sanity clip)
             from ...utils.synthetic_motion import make_armswing_clip
@@ -637,7 +660,8 @@ class HumanoidIm:
         motion_lib_cfg = EasyDict({"motion_file": mf, "device": self.device, "fix_height": FixHeightMode.full_fix,
                                    "min_length": self._min_motion_len, "max_length": -1, "im_eval": flags.im_eval,
                                    "multi_thread": False, "smpl_type": self.humanoid_type, "randomrize_heading": True, "step_dt": self.dt,
-                                   "heading_rng": self.cfg["env"].get("heading_rng", "persistent")})
+                                   "heading_rng": self.cfg["env"].get("heading_rng", "persistent"),
+                                   "rank": int(self.cfg.get("rank", os.environ.get("RANK", 0)))})   # per-rank heading / crop stream (run_hydra.py:121 seeds per rank)
         if self._is_robot:  # humanoid_im.py:342-359
             motion_lib_cfg["robot"] = self.cfg["robot"]
             motion_lib_cfg["robot_model"] = self.model

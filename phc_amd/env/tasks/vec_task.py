@@ -70,15 +70,21 @@ class VecTaskPython(VecTask):
     def get_state(self):
         return torch.clamp(self.task.states_buf, -self.clip_obs, self.clip_obs).to(self.rl_device)
 
+    def _clipped_obs(self):
+        # clip_observations = inf (parse_task.py:61, the default): the task's own buffer, no [N, obs] copy per step and a STABLE address (the
+        # learner's captured rollout segments are keyed by it; a fresh clamp output made the graph cache depend on the allocator)
+        if not np.isfinite(self.clip_obs):
+            return self.task.obs_buf.to(self.rl_device)
+        return torch.clamp(self.task.obs_buf, -self.clip_obs, self.clip_obs).to(self.rl_device)
+
     def step(self, actions):
         self.task.step(actions)
-        return (torch.clamp(self.task.obs_buf, -self.clip_obs, self.clip_obs).to(self.rl_device), self.task.rew_buf.to(self.rl_device),
-                self.task.reset_buf.to(self.rl_device), self.task.extras)
+        return (self._clipped_obs(), self.task.rew_buf.to(self.rl_device), self.task.reset_buf.to(self.rl_device), self.task.extras)
 
     def reset(self):
         actions = 0.01 * (1 - 2 * torch.rand([self.task.num_envs, self.task.num_actions], dtype=torch.float32, device=self.rl_device))
         self.task.step(actions)
-        return torch.clamp(self.task.obs_buf, -self.clip_obs, self.clip_obs).to(self.rl_device)
+        return self._clipped_obs()
 
 
 class VecTaskPythonWrapper(VecTaskPython):

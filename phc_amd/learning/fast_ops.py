@@ -14,6 +14,8 @@ Anywhere else (CPU, fp32, frozen columns) the layers are exactly nn.Linear and t
 tested against (tests/test_learn_gpu.py)."""
 import ctypes as C
 
+import os
+
 import torch
 from torch import nn
 from torch.autograd.function import once_differentiable
@@ -90,6 +92,22 @@ def _match_cols(wb, xb):
     elif wb.shape[1] < xb.shape[1]:
         xb = xb[:, :wb.shape[1]]
     return wb, xb
+
+
+def _pad_like(gx, x):
+    """An input gradient computed against the UNPADDED weight (outside FlatGradBucket.shadow_scope() the bf16 copy of a K-padded first layer
+    has K columns) brought to the K-padded input's width: the pad columns of the input are constants (zero), their gradient is zero."""
+    if gx is None or gx.dim() != 2 or x.dim() != 2 or gx.shape[1] >= x.shape[1]:
+        return gx
+    return torch.nn.functional.pad(gx, (0, x.shape[1] - gx.shape[1]))
+
+
+def _zero_rows(t, r0):
+    """PHC_DEBUG_ZERO_FILL=1: rows [0, r0) of a gradient tensor that `input_grad_only(row_start)` leaves unwritten are zeroed, so that anomaly
+    detection / NaN checks over whole tensors do not trip over uninitialised memory (off by default: a memset per layer and step)."""
+    if r0 > 0 and os.environ.get("PHC_DEBUG_ZERO_FILL"):
+        t[:r0].zero_()
+    return t
 
 
 def _logical(g, weight):
@@ -311,9 +329,9 @@ class _LinearDDBwdFn(torch.autograd.Function):
                 gz = _relu_mask(gz, y)
             ctx.save_for_backward(gz, wb, *([y] if y is not None else []))
             if need_gx:
-                gx = torch.empty((gy.shape[0], wb.shape[1]), dtype=torch.bfloat16, device=gy.device)
+                gx = _zero_rows(torch.empty((gy.shape[0], wb.shape[1]), dtype=torch.bfloat16, device=gy.device), r0)
                 torch.mm(gz, wb, out=gx[r0:])
-                gx = gx.to(x.dtype)
+                gx = _pad_like(gx.to(x.dtype), x)
             else:
                 gx = _placeholder(gy)
             pw, pb = _placeholder(gy), _placeholder(gy)
@@ -329,7 +347,7 @@ class _LinearDDBwdFn(torch.autograd.Function):
             ctx.save_for_backward(gy, wb, xb, y)
         else:
             ctx.save_for_backward(gy, wb, xb)
-        gx = (gy @ wb).to(x.dtype) if need_gx else _placeholder(gy)
+        gx = _pad_like((gy @ wb).to(x.dtype), x) if need_gx else _placeholder(gy)
         gw = _wgrad_into(weight, gy, xb)
         if gw is None:        # stored / added in place
             gw = _placeholder(gy)
@@ -348,7 +366,7 @@ class _LinearDDBwdFn(torch.autograd.Function):
             if ggx is not None and ctx.need_gx:
                 ggx = ggx[r0:].to(torch.bfloat16).contiguous()
                 d_w = _wgrad_into(ctx.weight, gy, ggx)
-                d_gy = torch.empty((ctx.rows, wb.shape[0]), dtype=torch.bfloat16, device=gy.device)   # rows [0, r0) stay unwritten
+                d_gy = _zero_rows(torch.empty((ctx.rows, wb.shape[0]), dtype=torch.bfloat16, device=gy.device), r0)   # rows [0, r0) stay unwritten (PHC_DEBUG_ZERO_FILL)
                 if y is not None:
                     _relu_mask(ggx @ wb.t(), y, out=d_gy[r0:])
                 else:
@@ -465,7 +483,7 @@ class _Linear1DDBwdFn(torch.autograd.Function):
         if only_x:
             gys = gy[r0:]
             ctx.save_for_backward(gys, wb)
-            gx = torch.empty((rows, cols), dtype=torch.bfloat16, device=x.device)   # rows [0, r0) stay unwritten
+            gx = _zero_rows(torch.empty((rows, cols), dtype=torch.bfloat16, device=x.device), r0)   # rows [0, r0) stay unwritten (PHC_DEBUG_ZERO_FILL)
             torch.mul(gys, wb, out=gx[r0:])
             pw, pb = _placeholder(gy), _placeholder(gy)
             ctx.mark_non_differentiable(pw, pb)
@@ -614,7 +632,7 @@ class _TakeRowsFn(torch.autograd.Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, gg):
-        full = torch.empty((ctx.rows,) + tuple(gg.shape[1:]), dtype=gg.dtype, device=gg.device)
+        full = _zero_rows(torch.empty((ctx.rows,) + tuple(gg.shape[1:]), dtype=gg.dtype, device=gg.device), ctx.rows - gg.shape[0])
         full[ctx.start:] = gg
         return full, None
 

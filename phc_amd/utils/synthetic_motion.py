@@ -192,3 +192,142 @@ def make_armswing_clip(model, seconds=10.0, fps=30, swing=0.6, freq=0.4):
     aa = q_local[..., :3] / s_[..., None] * (ang * np.sign(w + 1e-30))[..., None]
     return {"pose_quat_global": q_global, "pose_quat": q_local, "root_trans_offset": trans, "trans_orig": trans.copy(),
             "pose_aa": aa.reshape(T, J * 3), "beta": np.zeros(10), "gender": "neutral", "fps": fps}
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Locomotion-class sanity clips (round 3): squat, step in place, walk.  Built by inverse kinematics of the legs on prescribed pelvis and
+# ankle trajectories, so that a stance foot stays where it was put (no sliding), a swing foot leaves the ground and comes back, and -- for
+# the walk -- the centre of mass travels.  Kinematic, not dynamically optimised: what a retargeted mocap clip is to the tracker.
+def _quat_rotate(q, v):
+    qv, w = q[..., :3], q[..., 3:4]
+    t = 2.0 * np.cross(qv, v)
+    return v + w * t + np.cross(qv, t)
+
+
+def _fk(model, q_local, root_pos):
+    """-> (q_global [T,J,4], origin [T,J,3]) of local rotations q_local [T,J,4] (xyzw) with the root at root_pos [T,3]."""
+    T, J = q_local.shape[:2]
+    qg, org = np.zeros_like(q_local), np.zeros((T, J, 3))
+    for j in range(J):
+        p = model.parent[j]
+        if p < 0:
+            qg[:, j], org[:, j] = q_local[:, j], root_pos
+        else:
+            qg[:, j] = _quat_mul(qg[:, p], q_local[:, j])
+            org[:, j] = org[:, p] + _quat_rotate(qg[:, p], np.broadcast_to(model.local_translation[j], (T, 3)))
+    return qg / np.linalg.norm(qg, axis=-1, keepdims=True), org
+
+
+def _lowest_point(model, qg, org):
+    """Height of the lowest contact point of the whole body per frame."""
+    pts = org[:, model.contact_body] + _quat_rotate(qg[:, model.contact_body], np.broadcast_to(model.contact_pos, (len(org),) + model.contact_pos.shape))
+    return (pts[..., 2] - model.contact_radius).min(axis=1)
+
+
+def _leg_ik(model, side, pelvis, ankle_target, lateral_tilt):
+    """Hip / knee / ankle exp-maps (about y: flexion; about x: the lateral tilt, undone at the ankle) of one leg such that the ankle joint sits
+    at `ankle_target` [T,3] (world, sagittal x / z solved, y given by the tilt) for the pelvis origin at `pelvis` [T,3], pelvis upright.
+    Newton iterations on the leg's own forward kinematics (the asset's link offsets are not exactly vertical)."""
+    names = list(model.body_names)
+    hip, knee, ankle = (names.index(f"{side}_{n}") for n in ("Hip", "Knee", "Ankle"))
+    T = len(pelvis)
+
+    def ankle_pos(a, b):   # hip flexion a (thigh forward), knee flexion b: rotations about y by -a and +b, after the tilt about x
+        e_h = np.stack([lateral_tilt, -a, np.zeros(T)], -1)
+        q_h = _exp_map_to_quat(e_h)
+        q_k = _quat_mul(q_h, _exp_map_to_quat(np.stack([np.zeros(T), b, np.zeros(T)], -1)))
+        p_h = pelvis + model.local_translation[hip]
+        p_k = p_h + _quat_rotate(q_h, np.broadcast_to(model.local_translation[knee], (T, 3)))
+        return p_k + _quat_rotate(q_k, np.broadcast_to(model.local_translation[ankle], (T, 3)))
+    a, b = np.full(T, 0.3), np.full(T, 0.6)
+    for _ in range(25):
+        r = (ankle_pos(a, b) - ankle_target)[:, [0, 2]]
+        h = 1e-5
+        ja = ((ankle_pos(a + h, b) - ankle_target)[:, [0, 2]] - r) / h
+        jb = ((ankle_pos(a, b + h) - ankle_target)[:, [0, 2]] - r) / h
+        det = ja[:, 0] * jb[:, 1] - ja[:, 1] * jb[:, 0]
+        det = np.where(np.abs(det) < 1e-9, 1e-9, det)
+        da = (r[:, 0] * jb[:, 1] - r[:, 1] * jb[:, 0]) / det
+        db = (ja[:, 0] * r[:, 1] - ja[:, 1] * r[:, 0]) / det
+        a, b = a - np.clip(da, -0.3, 0.3), np.clip(b - np.clip(db, -0.3, 0.3), 0.02, 2.4)
+    assert np.abs((ankle_pos(a, b) - ankle_target)[:, [0, 2]]).max() < 2e-3, "leg IK did not converge (target out of reach?)"
+    e = {hip: np.stack([lateral_tilt, -a, np.zeros(T)], -1), knee: np.stack([np.zeros(T), b, np.zeros(T)], -1),
+         ankle: np.stack([-lateral_tilt, a - b, np.zeros(T)], -1)}   # the foot stays flat: the ankle undoes thigh + shank pitch and the tilt
+    return e
+
+
+def make_gait_clip(model, kind, seconds=10.0, fps=30):
+    """`squat`, `stepinplace` or `walk` for the SMPL humanoid (facing +x, z up).  The first second ramps out of the rest pose (the reset
+    imposes a clip frame; the evaluation starts every clip at t = 0)."""
+    assert kind in ("squat", "stepinplace", "walk")
+    T, J = int(round(seconds * fps)) + 1, model.num_bodies
+    names = list(model.body_names)
+    t = np.arange(T) / fps
+    ramp = np.clip(t / 1.0, 0.0, 1.0) ** 2 * (3 - 2 * np.clip(t / 1.0, 0.0, 1.0))
+    # rest pose: pelvis height with the soles on the ground, ankle joints' rest positions relative to the pelvis
+    q0 = np.zeros((1, J, 4)); q0[..., 3] = 1.0
+    qg0, org0 = _fk(model, q0, np.zeros((1, 3)))
+    h0 = float(-_lowest_point(model, qg0, org0)[0]) + 0.002
+    ank = {s: org0[0, names.index(f"{s}_Ankle")] for s in "LR"}
+    pelvis = np.zeros((T, 3))
+    drop = 0.03 if kind != "walk" else 0.05
+    pelvis[:, 2] = h0 - drop                          # knees slightly bent throughout (a straight leg has no IK margin; the reset imposes the clip's frame)
+    foot = {s: np.tile(ank[s] + np.array([0.0, 0.0, h0]), (T, 1)) for s in "LR"}
+    tilt = np.zeros(T)
+    e = np.zeros((T, J, 3))
+    if kind == "squat":
+        period = 2.5
+        pelvis[:, 2] -= 0.20 * ramp * 0.5 * (1 - np.cos(2 * np.pi * np.clip(t - 1.0, 0, None) / period))
+        lean = (h0 - drop - pelvis[:, 2]) / 0.20
+        e[:, names.index("Torso"), 1] = 0.20 * lean
+        e[:, names.index("Spine"), 1] = 0.15 * lean
+        for s, sg in (("L", 1.0), ("R", -1.0)):
+            e[:, names.index(f"{s}_Shoulder"), 0] = -sg * 0.9 * ramp
+            e[:, names.index(f"{s}_Shoulder"), 1] = -0.5 * lean
+    else:
+        period = 1.2 if kind == "stepinplace" else 1.0       # one gait cycle = two steps
+        speed = 0.0 if kind == "stepinplace" else 0.7
+        lift = 0.10 if kind == "stepinplace" else 0.07
+        ph = np.clip(t - 1.0, 0, None) / period               # gait phase in cycles, 0 during the ramp
+        go = (t >= 1.0).astype(float)
+        def pelvis_x(tt):   # the speed ramps up over the first second of the gait
+            tau = np.clip(tt - 1.0, 0, None)
+            tr = np.clip(tau, 0, 1)
+            return speed * np.where(tau < 1, tr ** 3 - 0.5 * tr ** 4, 0.5 + (tau - 1))
+        pelvis[:, 0] = pelvis_x(t)
+        sway = 0.045 if kind == "stepinplace" else 0.025
+        for s, off in (("L", 0.0), ("R", 0.5)):               # the left foot swings in the first half of a cycle, the right one in the second
+            c = ph + off
+            k = np.floor(c)
+            u = c - k                                         # phase within this foot's own cycle: swing for u < 0.4, stance after
+            sw = np.clip(u / 0.4, 0, 1)
+            first = 0.0 if off == 0.0 else 1.0                # the cycle in which this foot leaves its rest position
+            swing = (u < 0.4) & (go > 0) & (k >= first)
+            smooth = sw * sw * (3 - 2 * sw)
+            # a foot is planted where the pelvis will be at the middle of the stance that follows; before its first swing it rests at x = 0
+            plant = lambda kk: np.where(kk >= first, pelvis_x(1.0 + period * (kk + 0.7 - off)), 0.0)
+            x = np.where(go > 0, np.where(swing, plant(k - 1) + (plant(k) - plant(k - 1)) * smooth, plant(k)), 0.0) + ank[s][0]
+            foot[s][:, 0] = x
+            foot[s][:, 2] = ank[s][2] + h0 + np.where(swing, lift * np.sin(np.pi * sw) ** 2, 0.0)
+        # lateral sway towards the stance foot (left foot swings first -> weight on the right, y < 0)
+        pelvis[:, 1] = -sway * np.sin(2 * np.pi * (ph + 0.05)) * go * np.clip((t - 1.0) / 0.6, 0, 1)
+        tilt = -pelvis[:, 1] / max(h0 - 0.1, 0.5)
+        for s, sg in (("L", 1.0), ("R", -1.0)):
+            sh = names.index(f"{s}_Shoulder")
+            e[:, sh, 0] = -sg * 1.0 * ramp
+            e[:, sh, 1] = sg * 0.25 * np.sin(2 * np.pi * ph) * go * (1.0 if kind == "walk" else 0.4)
+            e[:, names.index(f"{s}_Elbow"), 2] = sg * 0.3 * ramp
+    for s in "LR":
+        target = foot[s].copy()
+        for j, v in _leg_ik(model, s, pelvis, target, tilt).items():
+            e[:, j] = v
+    q_local = _exp_map_to_quat(e)
+    qg, org = _fk(model, q_local, pelvis)
+    trans = pelvis.copy()
+    trans[:, 2] += 0.002 - _lowest_point(model, qg, org)       # the lowest sole corner on the ground in every frame
+    w = np.clip(q_local[..., 3], -1, 1)
+    ang = 2 * np.arccos(np.abs(w))
+    s_ = np.sqrt(np.maximum(1 - w * w, 1e-16))
+    aa = q_local[..., :3] / s_[..., None] * (ang * np.sign(w + 1e-30))[..., None]
+    return {"pose_quat_global": qg, "pose_quat": q_local, "root_trans_offset": trans, "trans_orig": trans.copy(),
+            "pose_aa": aa.reshape(T, J * 3), "beta": np.zeros(10), "gender": "neutral", "fps": fps}

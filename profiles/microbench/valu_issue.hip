@@ -19,14 +19,16 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 #define REP64(x) REP8(REP8(x))
 
 enum Kind { FMA_DEP, FMA_IND, PKFMA_DEP, PKFMA_IND, PKMUL_IND, PKADD_IND, MUL_IND, ADD_DPP_IND, FMAC_DPP_IND, MOV_DPP_IND, RCP_IND, SIN_IND, SQRT_IND, CNDMASK_IND,
-            LDS_RT, BPERMUTE_DEP, LDS_RD128, BARRIER, FMA_2CH, FMA_4CH, PKFMA_2CH, CNDMASK_SGPR, FMA_SGPR, MUL_SGPR, CMP_VCC, CMP_SGPR, FMAAK, MOV_IND, FMA_CND_MIX, NKINDS };
+            LDS_RT, BPERMUTE_DEP, LDS_RD128, BARRIER, FMA_2CH, FMA_4CH, PKFMA_2CH, CNDMASK_SGPR, FMA_SGPR, MUL_SGPR, CMP_VCC, CMP_SGPR, FMAAK, MOV_IND, FMA_CND_MIX, FMA_BANK3, FMA_BANK2, FMAC_IND, FMAC_BANK, SUB_IND, NKINDS };
 static const char* kind_name[NKINDS] = {"v_fma_f32 dependent chain", "v_fma_f32 8 independent chains", "v_pk_fma_f32 dependent chain", "v_pk_fma_f32 8 independent chains",
     "v_pk_mul_f32 8 independent", "v_pk_add_f32 8 independent", "v_mul_f32 (VOP2) 8 independent", "v_add_f32 dpp row_shr:1 8 independent", "v_fmac_f32 dpp row_shr:1 8 independent",
     "v_mov_b32 dpp row_shr:1 8 independent", "v_rcp_f32 8 independent", "v_sin_f32 8 independent", "v_sqrt_f32 8 independent", "v_cndmask_b32 8 independent",
     "ds_write_b32 -> ds_read_b32 round trip (dependent)", "ds_bpermute_b32 dependent chain", "ds_read_b128 8 in flight", "s_barrier (1-wave workgroup)",
     "v_fma_f32 2 interleaved chains", "v_fma_f32 4 interleaved chains", "v_pk_fma_f32 2 interleaved chains",
     "v_cndmask_b32_e64 (SGPR-pair mask) 8 independent", "v_fma_f32 with one SGPR source, 8 independent", "v_mul_f32 with an SGPR source, 8 independent",
-    "v_cmp_lt_f32_e32 (writes vcc)", "v_cmp_lt_f32_e64 (writes an SGPR pair)", "v_fmaak_f32 (literal), 8 independent", "v_mov_b32 8 independent", "v_fma_f32 / v_cndmask_b32 (vcc) alternating"};
+    "v_cmp_lt_f32_e32 (writes vcc)", "v_cmp_lt_f32_e64 (writes an SGPR pair)", "v_fmaak_f32 (literal), 8 independent", "v_mov_b32 8 independent", "v_fma_f32 / v_cndmask_b32 (vcc) alternating",
+    "v_fma_f32, three sources in ONE VGPR bank (v8 v12 v16)", "v_fma_f32, two sources in one bank", "v_fmac_f32_e32 8 independent (distinct banks)",
+    "v_fmac_f32_e32, both sources and dst in one bank", "v_sub_f32_e32 8 independent"};
 
 template <int K>
 __global__ __launch_bounds__(64) void k_bench(float* out, unsigned long long* cyc, int reps, float seed) {
@@ -77,6 +79,15 @@ __global__ __launch_bounds__(64) void k_bench(float* out, unsigned long long* cy
             a0 += q0.x + q1.x + q2.x + q3.x + q4.x + q5.x + q6.x + q7.x;
         }
         if (K == BARRIER) { asm volatile(REP8("s_barrier\n") ::: "memory"); }
+        if (K == FMA_BANK3) { asm volatile(REP8("v_fma_f32 v20, v8, v12, v16\n v_fma_f32 v21, v8, v12, v16\n v_fma_f32 v22, v8, v12, v16\n v_fma_f32 v23, v8, v12, v16\n v_fma_f32 v24, v8, v12, v16\n v_fma_f32 v25, v8, v12, v16\n v_fma_f32 v26, v8, v12, v16\n v_fma_f32 v27, v8, v12, v16\n")
+            ::: "v8", "v12", "v16", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27"); }
+        if (K == FMA_BANK2) { asm volatile(REP8("v_fma_f32 v20, v8, v12, v17\n v_fma_f32 v21, v8, v12, v17\n v_fma_f32 v22, v8, v12, v17\n v_fma_f32 v23, v8, v12, v17\n v_fma_f32 v24, v8, v12, v17\n v_fma_f32 v25, v8, v12, v17\n v_fma_f32 v26, v8, v12, v17\n v_fma_f32 v27, v8, v12, v17\n")
+            ::: "v8", "v12", "v17", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27"); }
+        if (K == FMAC_IND) { asm volatile(REP8("v_fmac_f32_e32 v20, v9, v14\n v_fmac_f32_e32 v21, v10, v15\n v_fmac_f32_e32 v22, v11, v12\n v_fmac_f32_e32 v23, v8, v13\n v_fmac_f32_e32 v24, v9, v14\n v_fmac_f32_e32 v25, v10, v15\n v_fmac_f32_e32 v26, v11, v12\n v_fmac_f32_e32 v27, v8, v13\n")
+            ::: "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27"); }
+        if (K == FMAC_BANK) { asm volatile(REP8("v_fmac_f32_e32 v20, v8, v12\n v_fmac_f32_e32 v24, v8, v12\n v_fmac_f32_e32 v28, v8, v12\n v_fmac_f32_e32 v32, v8, v12\n v_fmac_f32_e32 v36, v8, v12\n v_fmac_f32_e32 v40, v8, v12\n v_fmac_f32_e32 v44, v8, v12\n v_fmac_f32_e32 v48, v8, v12\n")
+            ::: "v8", "v12", "v20", "v24", "v28", "v32", "v36", "v40", "v44", "v48"); }
+        if (K == SUB_IND) { SIND8("v_sub_f32_e32", ""); }
         if (K == CNDMASK_SGPR) { SIND8("v_cndmask_b32_e64", ", s[20:21]"); }
         if (K == FMA_SGPR) { asm volatile(REP8("v_fma_f32 %0, %0, s20, %8\n v_fma_f32 %1, %1, s20, %8\n v_fma_f32 %2, %2, s20, %8\n v_fma_f32 %3, %3, s20, %8\n v_fma_f32 %4, %4, s20, %8\n v_fma_f32 %5, %5, s20, %8\n v_fma_f32 %6, %6, s20, %8\n v_fma_f32 %7, %7, s20, %8\n")
             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c) : "s20"); }
