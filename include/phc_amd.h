@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PHC_ABI_VERSION 31
+#define PHC_ABI_VERSION 32
 #define PHC_MAX_BODIES 64   /* bodies (incl. extended reference bodies) per articulation; also the slot count of the model tables */
 #define PHC_EINVAL (-1)
 #define PHC_EUNSUPPORTED (-2)
@@ -241,6 +241,9 @@ typedef struct {
                                          writes the new frame only -- the history shift of humanoid_amp.py:662-670 (14 KB of traffic per env and
                                          step) is then implicit; the caller moves the window back to the end of the strip every (strip - S) steps
                                          with one ordinary shifting call (HumanoidIm: strips of 2 S frames) */
+    uint64_t* reset_rng_counter;      /* [1] device-side call counter of phc_im_reset_done (nullable).  Non-null: the start-time draws of a call are keyed by
+                                         (seed, *reset_rng_counter) -- the counter argument is ignored -- and phc_im_post_physics advances it by one -- a launch captured in
+                                         a hipGraph then draws fresh phases on every replay (the host-side counter argument is frozen at capture) */
 } phc_im_buffers_t;
 
 int32_t phc_abi_version(void);

@@ -74,7 +74,7 @@ class ImBuffers(C.Structure):
                 ("motion_start_times", c_p), ("motion_start_times_offset", c_p), ("global_offset", c_p),
                 ("ref_body_pos", c_p), ("ref_body_rot", c_p), ("ref_body_vel", c_p), ("ref_dof_pos", c_p),
                 ("cycle_counter", c_p), ("recovery_counter", c_p), ("point_goal", c_p), ("cycle_phase", c_p),
-                ("reset_list", c_p), ("reset_count", c_p), ("reset_slot", c_i32), ("reset_sublist_cap", c_i32), ("body_state_hist", c_p), ("offset_rand", c_p), ("occl_mask", c_p), ("amp_env_stride", C.c_int64)]
+                ("reset_list", c_p), ("reset_count", c_p), ("reset_slot", c_i32), ("reset_sublist_cap", c_i32), ("body_state_hist", c_p), ("offset_rand", c_p), ("occl_mask", c_p), ("amp_env_stride", C.c_int64), ("reset_rng_counter", c_p)]
 
 
 class PpoParams(C.Structure):
@@ -133,7 +133,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the .so does not export the symbol
         fn.argtypes = argtypes
         fn.restype = restype
-    if lib.phc_abi_version() != 31:
+    if lib.phc_abi_version() != 32:
         raise ImportError("libphc_amd.so ABI version mismatch")
     _lib = lib
     return lib

@@ -176,9 +176,10 @@ def im_buffers_struct(progress_buf, reset_buf, terminate_buf, rew_buf, reward_ra
                       sampled_motion_ids, motion_start_times, motion_start_times_offset, global_offset,
                       ref_body_pos=None, ref_body_rot=None, ref_body_vel=None, ref_dof_pos=None,
                       cycle_counter=None, recovery_counter=None, point_goal=None, cycle_phase=None, reset_list=None, reset_count=None,
-                      reset_slot=0, offset_rand=None, body_state_hist=None, occl_mask=None, amp_env_stride=0):
+                      reset_slot=0, offset_rand=None, body_state_hist=None, occl_mask=None, amp_env_stride=0, reset_rng_counter=None):
     b = L.ImBuffers()
     b.amp_env_stride = int(amp_env_stride)
+    b.reset_rng_counter = ptr(reset_rng_counter)
     b.occl_mask = ptr(occl_mask)
     b.offset_rand = ptr(offset_rand)
     b.body_state_hist = ptr(body_state_hist)

@@ -42,6 +42,7 @@ __global__ __launch_bounds__(256) void k_im_post_physics(phc_model_t model, phc_
     const int lane = threadIdx.x & (G - 1);
     const int64_t env = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
     if (env >= sim.num_envs) return;  // whole lane group exits together
+    if (blockIdx.x == 0 && threadIdx.x == 0 && buf.reset_rng_counter) *buf.reset_rng_counter += 1;   // (one writer; no reset launch runs concurrently)
     const int64_t progress = buf.progress_buf[env] + 1;  // humanoid.py:1637
     const ImStepCtx c = im_post_prologue(lib, prm, sim, buf, env, progress);
     const float prev_goal = (prm.zero_out_far && buf.point_goal) ? buf.point_goal[env] : 0.f;  // read before lane 0 overwrites it
@@ -77,7 +78,7 @@ __device__ __forceinline__ float hash_u01(uint64_t key, uint32_t env) {
     x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 12; x *= 0x297A2D39u; x ^= x >> 15;
     return (float)(x >> 8) * (1.0f / 16777216.0f);
 }
-static inline uint64_t splitmix64(uint64_t z) {
+__host__ __device__ static inline uint64_t splitmix64(uint64_t z) {
     z += 0x9E3779B97F4A7C15ull;
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
@@ -136,7 +137,9 @@ __global__ __launch_bounds__(256) void k_im_reset(phc_model_t model, phc_motion_
     const int64_t mid = buf.sampled_motion_ids[env];
     // _sample_ref_state (humanoid_im.py:1000-1023): StateInit.Random -> sample_time_interval; Start / flags.test -> 0
     // (start_at_zero with a null phase array is only legal in the RNG-free instantiation's list mode)
-    const float t = start_at_zero ? 0.f : sample_time_interval(lib, mid, RNG ? hash_u01(rng_key, (uint32_t)env) : phase[r]);
+    // (device-side call counter, phc_im_buffers_t.reset_rng_counter: folded into the key so that a captured launch draws anew on every replay)
+    const uint64_t key = (RNG && buf.reset_rng_counter) ? splitmix64(rng_key ^ (*buf.reset_rng_counter * 0x9E6C63D0876A9A47ull)) : rng_key;
+    const float t = start_at_zero ? 0.f : sample_time_interval(lib, mid, RNG ? hash_u01(key, (uint32_t)env) : phase[r]);
     PHC_RTL(2)
     if (k == 0) im_reset_lane(model, lib, prm, sim, buf, env, lane, t, env_ids != nullptr);
     PHC_RTL(3)
@@ -352,7 +355,8 @@ int32_t phc_im_reset_done(const phc_model_t* model, const phc_motion_lib_t* lib,
     if (sim->num_envs == 0) return 0;
     if (buf->reset_list && (!buf->reset_count || buf->reset_sublist_cap * PHC_RESET_SUBLISTS < sim->num_envs)) return PHC_EINVAL;
     const int n = buf->reset_list ? buf->reset_sublist_cap * PHC_RESET_SUBLISTS : sim->num_envs;   // groups to launch
-    const uint64_t key = splitmix64(splitmix64(seed) ^ (counter * 0xD1342543DE82EF95ull));
+    // (with a device-side call counter the host one stays out of the key: a captured launch and an eager one then draw the same numbers)
+    const uint64_t key = splitmix64(splitmix64(seed) ^ ((buf->reset_rng_counter ? 0ull : counter) * 0xD1342543DE82EF95ull));
     const int g = group_lanes(model->num_bodies, prm->num_ext_bodies);
     const dim3 grid(env_blocks(n, g), prm->num_amp_obs_steps);
 #define PHC_RESET(DPJ, G) hipLaunchKernelGGL((k_im_reset<DPJ, true, G>), grid, dim3(256), 0, (hipStream_t)stream, *model, *lib, *prm, *sim, *buf, n, nullptr, nullptr, start_at_zero, key)

@@ -455,6 +455,7 @@ class HumanoidIm:
         self._reset_list = torch.zeros(abi.RESET_SUBLISTS * abi.reset_sublist_cap(N), device=dev, dtype=torch.int32) if self._use_reset_list else None
         self._reset_count = torch.zeros((3, abi.RESET_SUBLISTS, abi.RESET_COUNT_STRIDE), device=dev, dtype=torch.int32) if self._use_reset_list else None
         self._reset_slot, self._reset_list_pending = 0, False
+        self._reset_rng_dev = torch.zeros(1, device=dev, dtype=torch.int64)   # phc_im_buffers_t.reset_rng_counter (advanced by the post-physics launch)
         self._cycle_phase = torch.zeros(N, **f32) if self.cycle_motion else None
         # draws behind the random reference offsets of zero_out_far_train (reset, clip restart) / cycle_motion_xp (clip restart)
         self._far_start = bool(self.zero_out_far and self.zero_out_far_train)
@@ -552,7 +553,8 @@ class HumanoidIm:
                                      cycle_counter=self._cycle_counter, recovery_counter=self._recovery_counter,
                                      point_goal=self._point_goal, cycle_phase=self._cycle_phase, reset_list=self._reset_list,
                                      reset_count=self._reset_count, reset_slot=self._reset_slot, offset_rand=self._offset_rand,
-                                     body_state_hist=self._body_state_hist, occl_mask=self._occl_mask, amp_env_stride=self._amp_strip.stride(0))
+                                     body_state_hist=self._body_state_hist, occl_mask=self._occl_mask, amp_env_stride=self._amp_strip.stride(0),
+                                     reset_rng_counter=self._reset_rng_dev)
 
     @property
     def _amp_obs_buf(self):
@@ -763,24 +765,64 @@ class HumanoidIm:
             torch.rand(self.num_envs, out=self._cycle_phase)
             if self._offset_rand is not None:
                 torch.rand(self._offset_rand.shape, out=self._offset_rand)
-        if self._use_reset_list:
-            if self._reset_list_pending:   # the previous step's list was never consumed (reset(env_ids) idiom): start this one empty
-                self._reset_count[self._reset_slot].zero_()
-            self._reset_list_pending = True
+        if self._use_reset_list and self._reset_list_pending:   # the previous step's list was never consumed (reset(env_ids) idiom): start this one empty
+            self._reset_count[self._reset_slot].zero_()
         buf = self._buffers(amp_in, amp_out)
         L.check(self._lib.phc_im_post_physics(self._model_struct, self._motion_lib.struct, self._im_params, self._sim_struct, buf,
                                               _stream()), "phc_im_post_physics")
-        self._amp_head = new_head
         self._obs_noise()
-        self.extras["terminate"] = self._terminate_buf         # humanoid.py:1649-1650
-        self.extras["reward_raw"] = self.reward_raw.detach()
-        self.extras["amp_obs"] = self._amp_obs_buf.view(-1, self.get_num_amp_obs())  # humanoid_amp.py:208-209
+        self._post_physics_host(new_head)
         if flags.im_eval:  # humanoid_im.py:674-680
             t = self.progress_buf * self.dt + self._motion_start_times + self._motion_start_times_offset
             res = self._motion_lib.get_motion_state(self._sampled_motion_ids, t, self._global_offset)
             self.extras["mpjpe"] = (self._rigid_body_pos - res["rg_pos"]).norm(dim=-1).mean(dim=-1)
             self.extras["body_pos"] = self._rigid_body_pos.cpu().numpy()
             self.extras["body_pos_gt"] = res["rg_pos"].cpu().numpy()
+
+    def _post_physics_host(self, new_head):
+        """The HOST side of a post-physics step (no launch): the AMP window moved, a reset list is pending, the info dict.  A replayed hipGraph of a
+        whole rollout step (IMAmpAgent.play_steps) runs the launches; the learner calls this to keep the task's host state in step."""
+        if self._use_reset_list:
+            self._reset_list_pending = True
+        self._amp_head = new_head
+        self.extras["terminate"] = self._terminate_buf         # humanoid.py:1649-1650
+        self.extras["reward_raw"] = self.reward_raw.detach()
+        self.extras["amp_obs"] = self._amp_obs_buf.view(-1, self.get_num_amp_obs())  # humanoid_amp.py:208-209
+
+    def _reset_done_host(self, use_list):
+        """The host side of reset_done() (see _post_physics_host)."""
+        self._reset_counter += 1
+        if use_list:
+            self._reset_slot = (self._reset_slot + 1) % 3   # the kernel zeroed that counter for the next post-physics launch
+            self._reset_list_pending = False
+
+    def whole_step_capturable(self):
+        """True when reset_done() + step() consist of launches and host bookkeeping only (no host-side random draws or syncs between them), so that
+        the learner may capture them, with its own policy / critic segments, into ONE hipGraph per rollout step."""
+        return bool(self._use_reset_list and not (self.cycle_motion or self._far_start or self._occl_training or self.add_obs_noise or self._fut_tracks_dropout
+                                                  or self.collect_dataset or self.obs_v == 5 or flags.im_eval or flags.test)
+                    and type(self).step is HumanoidIm.step and type(self).reset_done is HumanoidIm.reset_done
+                    and type(self).post_physics_step is HumanoidIm.post_physics_step and type(self).pre_physics_step is HumanoidIm.pre_physics_step)
+
+    def rollout_step_key(self):
+        """What a captured rollout step depends on besides the step index: the reset-list slot and whether a list is pending (the AMP window position
+        is normalised by align_amp_window())."""
+        return (self._reset_slot, self._reset_list_pending, self._amp_head)
+
+    def align_amp_window(self):
+        """Move the AMP history window to the top of its strip (head = S), as after every S-th step: a rollout that starts from there visits the same
+        window positions at the same step indices in every epoch."""
+        S = self._num_amp_obs_steps
+        if self._amp_head != S:
+            self._amp_strip[:, S:2 * S] = self._amp_strip[:, self._amp_head:self._amp_head + S].clone()
+            self._amp_head = S
+            self.extras["amp_obs"] = self._amp_obs_buf.view(-1, self.get_num_amp_obs())
+
+    def replay_step_host(self):
+        """Host bookkeeping of one reset_done() + step() whose launches a graph replay has just issued."""
+        self._reset_done_host(self._use_reset_list and self._reset_list_pending)
+        new_head = self._amp_head - 1 if self._amp_head > 0 else self._num_amp_obs_steps
+        self._post_physics_host(new_head)
 
     # ------------------------------------------------------------------ reset (humanoid.py:537-621)
     def reset(self, env_ids=None):
@@ -821,7 +863,6 @@ class HumanoidIm:
         from the list the post-physics kernel built on the device (dense wavefronts; a masked sweep over all envs is the fallback)."""
         start_at_zero = (self._state_init == HumanoidIm.StateInit.Start) or flags.test
         cur = self._amp_obs_buf
-        self._reset_counter += 1
         use_list = self._use_reset_list and self._reset_list_pending
         if self._far_start:
             torch.rand(self._offset_rand.shape, out=self._offset_rand)
@@ -829,10 +870,8 @@ class HumanoidIm:
         if not use_list:   # nothing appended since the last consumption (e.g. right after reset()): masked sweep over reset_buf
             buf.reset_list = None
         L.check(self._lib.phc_im_reset_done(self._model_struct, self._motion_lib.struct, self._im_params, self._sim_struct, buf,
-                                            self._reset_seed, self._reset_counter, int(bool(start_at_zero)), _stream()), "phc_im_reset_done")
-        if use_list:
-            self._reset_slot = (self._reset_slot + 1) % 3   # the kernel zeroed that counter for the next post-physics launch
-            self._reset_list_pending = False
+                                            self._reset_seed, self._reset_counter + 1, int(bool(start_at_zero)), _stream()), "phc_im_reset_done")
+        self._reset_done_host(use_list)
         self._obs_noise(reset_rows=True)
 
     def _one_hot_obs(self):

@@ -396,7 +396,9 @@ class IMAmpAgent:
             in_group = self.dist is not None and self.dist.is_initialized()
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode="thread_local" if in_group else "global"):
+            if getattr(self, "_roll_pool", None) is None:   # the rollout graphs replay one after the other and leave their results in the
+                self._roll_pool = torch.cuda.graph_pool_handle()   # persistent experience buffers: their temporaries can share one pool
+            with torch.cuda.graph(g, pool=self._roll_pool, capture_error_mode="thread_local" if in_group else "global"):
                 fn()
             self._roll_graphs[key] = g
         g.replay()
@@ -462,7 +464,33 @@ class IMAmpAgent:
                 self.current_rewards.add_(rewards).mul_(not_dones.unsqueeze(1))
                 self.current_lengths.add_(1).mul_(not_dones)
 
-        for n in range(self.horizon_length):
+        # ONE hipGraph per rollout step (round 3): reset of the finished envs, observation row, actor / critic / sampling, stepper, post-physics, AMP
+        # window copy, next-value critic and bookkeeping -- ~40 launches -- replayed with a single host call; the task's host-side state (AMP
+        # window position, reset-list slot, info dict) is advanced by task.replay_step_host().  Keyed by the step index and that state; the
+        # start-time draws of the captured reset launch stay fresh through the device-side call counter (phc_im_buffers_t.reset_rng_counter).
+        whole = (graphed and self._reward_raw_acc is not None and getattr(task, "whole_step_capturable", lambda: False)()
+                 and not os.environ.get("PHC_NO_STEP_GRAPH"))
+        if whole:
+            task.align_amp_window()
+
+            def whole_step(n):
+                task.reset_done()
+                self.obs = task.obs_buf
+                seg_policy(n)
+                self.obs, rewards, self.dones, infos = self.vec_env.step(self._env_actions if self.clip_actions else e["actions"][n])
+                rewards = rewards.unsqueeze(1) if rewards.dim() == 1 else rewards
+                e["amp_obs"][n].copy_(infos["amp_obs"])
+                seg_after(n, rewards, infos["terminate"], infos["reward_raw"])
+
+            for n in range(self.horizon_length):
+                key = ("step", n) + task.rollout_step_key()
+                if key in self._roll_graphs:
+                    self._roll_graphs[key].replay()
+                    task.replay_step_host()
+                else:
+                    self._replay(key, lambda: whole_step(n))   # capture (runs the task's own host bookkeeping), then the first replay: no bookkeeping
+            self.obs, self.dones = task.obs_buf, task.reset_buf
+        for n in range(self.horizon_length if not whole else 0):
             if self.faithful_reset or not hasattr(task, "reset_done"):
                 self.obs = self.env_reset(done_indices)
             else:

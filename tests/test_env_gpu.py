@@ -1042,3 +1042,46 @@ def test_obs_v4_v5_remove_disc_rot_and_action_noise_switches():
     assert torch.equal(inert.actions, plain.actions) and torch.equal(noisy.clean_actions, a256)
     d = (noisy.actions - a256).flatten()
     assert abs(float(d.std()) - 0.05) < 0.003 and abs(float(d.mean())) < 0.002
+
+
+def test_whole_rollout_step_in_one_graph_equals_eager_launches():
+    """reset_done() + step() captured into ONE hipGraph per (step index, reset-list slot, AMP window position) and replayed with
+    `replay_step_host()` keeping the task's host state in step -- bit-identical simulator state, observations, AMP windows, reset flags and start
+    times to the eager launches over 45 steps (several passes through the 11 window positions and 3 slots, resets included), and the start-time
+    draws of a replayed reset launch are fresh (device-side call counter), not those of the captured one."""
+    torch.manual_seed(3)
+    a = (torch.rand(512, 69, device="cuda") * 2 - 1) * 0.1
+    tasks = []
+    for mode in ("eager", "graph"):
+        task, env = make_task(512, motion="synthetic:3:1", seed=7)
+        torch.manual_seed(11)
+        env.reset()
+        tasks.append((task, env))
+    (te, ee), (tg, eg) = tasks
+    assert tg.whole_step_capturable()
+    tg.align_amp_window(); te.align_amp_window()
+    graphs, pool, starts = {}, torch.cuda.graph_pool_handle(), []
+    for k in range(45):
+        te.reset_done(); ee.step(a)
+        key = tg.rollout_step_key()
+        if key in graphs:
+            graphs[key].replay()
+            tg.replay_step_host()
+        else:
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool):
+                tg.reset_done(); eg.step(a)
+            g.replay()
+            graphs[key] = g
+        torch.cuda.synchronize()
+        for name in ("_root_states", "_dof_state", "obs_buf", "reset_buf", "progress_buf", "_motion_start_times", "rew_buf", "_terminate_buf"):
+            assert torch.equal(getattr(te, name), getattr(tg, name)), (k, name)
+        assert torch.equal(te.extras["amp_obs"], tg.extras["amp_obs"]), k
+        assert te._amp_head == tg._amp_head and te._reset_slot == tg._reset_slot
+        starts.append(tg._motion_start_times.clone())
+    assert len(graphs) < 45 and sum(1 for _ in graphs) >= 11          # replays happened
+    assert int(tg._reset_rng_dev.item()) == 45
+    fresh = torch.stack(starts)                                        # [45, N]: envs that reset several times drew different start times
+    resets = (fresh[1:] != fresh[:-1]).sum(0)
+    assert int((resets >= 2).sum()) > 50 and int(torch.unique(fresh).numel()) > 100
