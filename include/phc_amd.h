@@ -207,7 +207,7 @@ typedef struct {
     float* obs_buf;                   /* [N, num_self_obs+num_task_obs] */
     float* amp_obs_in;                /* [N,S,A] history before this step */
     float* amp_obs_out;               /* [N,S,A] history after this step (ping-pong; may equal amp_obs_in only for reset) */
-    const int64_t* sampled_motion_ids;/* [N] */
+    const int64_t* sampled_motion_ids;/* [N]; NULL = the identity (env i follows clip i: humanoid_im.py:121) -- saves a dependent load per lookup chain */
     float* motion_start_times;        /* [N] */
     float* motion_start_times_offset; /* [N] */
     float* global_offset;             /* [N,3] */

@@ -6,6 +6,10 @@
 
 namespace phc {
 
+// the env's clip: sampled_motion_ids[env], or the env's own index when the caller passes no table (one clip per env, humanoid_im.py:121
+// `_sampled_motion_ids = arange(num_envs)`: the table load is then one dependent memory round trip the lookup chain does not need)
+PHC_HD int64_t motion_id_of(const phc_im_buffers_t& buf, int64_t env) { return buf.sampled_motion_ids ? buf.sampled_motion_ids[env] : env; }
+
 // fetch-and-increment (device: one atomic per finished env; host emulation: OpenMP atomic capture)
 PHC_HD int phc_atomic_inc(int32_t* p) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -117,7 +121,7 @@ struct ImStepCtx {
 PHC_HD ImStepCtx im_post_prologue(const phc_motion_lib_t& lib, const phc_im_params_t& prm, const phc_sim_state_t& sim,
                                   const phc_im_buffers_t& buf, int64_t env, int64_t progress) {
     ImStepCtx c;
-    const int64_t mid = buf.sampled_motion_ids[env];
+    const int64_t mid = motion_id_of(buf, env);
     c.start = buf.motion_start_times[env];
     c.start_off = buf.motion_start_times_offset[env];
     c.goff_rew = ld3(buf.global_offset + env * 3);
@@ -213,7 +217,7 @@ PHC_HD RewardPartial im_post_lane(const phc_model_t& model, const phc_motion_lib
     const int nb = model.num_bodies, nd = model.num_dof;
     RewardPartial rp;
     rp.pos = rp.rot = rp.vel = rp.angvel = rp.power = rp.dist = rp.root_dist = 0.f; rp.fallen = 0;
-    const int64_t mid = buf.sampled_motion_ids[env];
+    const int64_t mid = motion_id_of(buf, env);
     if (j >= nb) {
         // R3: extended bodies of the full-body reward (humanoid_im.py:916-923) -- lane NB+e carries extended body e: current
         // pose = parent pose composed with a fixed offset, reference from the extended record slots; only the position
@@ -370,7 +374,7 @@ PHC_HD void im_post_finalize(const phc_motion_lib_t& lib, const phc_im_params_t&
 PHC_HD void im_reset_lane(const phc_model_t& model, const phc_motion_lib_t& lib, const phc_im_params_t& prm,
                           const phc_sim_state_t& sim, const phc_im_buffers_t& buf, int64_t env, int j, float t, bool clear_reset_flag) {
     const int nb = model.num_bodies, nd = model.num_dof;
-    const int64_t mid = buf.sampled_motion_ids[env];
+    const int64_t mid = motion_id_of(buf, env);
     if (j < nb) {
         const FrameRef fr = frame_ref(lib, mid, t);
         BodyState rs = ref_body(lib, fr, j);     // global offset was just zeroed (humanoid_im.py:956-957)
@@ -457,7 +461,7 @@ PHC_HD void im_reset_lane(const phc_model_t& model, const phc_motion_lib_t& lib,
 PHC_HD void im_reset_from_state_lane(const phc_model_t& model, const phc_motion_lib_t& lib, const phc_im_params_t& prm,
                                      const phc_sim_state_t& sim, const phc_im_buffers_t& buf, int64_t env, int j, int fill_history) {
     const int nb = model.num_bodies, nd = model.num_dof;
-    const int64_t mid = buf.sampled_motion_ids[env];
+    const int64_t mid = motion_id_of(buf, env);
     const int S = prm.num_amp_obs_steps, A = prm.num_amp_obs_per_step;
     if (j < nb) {
         BodyState body = load_body(sim.rigid_body_state, env, nb, j);
@@ -526,7 +530,7 @@ PHC_HD void im_reset_amp_lane(const phc_motion_lib_t& lib, const phc_im_params_t
                               int64_t env, int j, float t, int k) {
     const int A = prm.num_amp_obs_per_step;
     float* amp = buf.amp_obs_out + env * amp_env_stride(prm, buf);
-    amp_obs_from_ref_lane(lib, prm, nb, j, buf.sampled_motion_ids[env], history_time(t, prm.dt, k), amp + k * A);
+    amp_obs_from_ref_lane(lib, prm, nb, j, motion_id_of(buf, env), history_time(t, prm.dt, k), amp + k * A);
 }
 
 }  // namespace phc

@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void k_im_reset(phc_model_t model, phc_motion_
         if (!env_ids && buf.reset_buf[env] == 0) return;
     }
     PHC_RTL(1)
-    const int64_t mid = buf.sampled_motion_ids[env];
+    const int64_t mid = motion_id_of(buf, env);
     // _sample_ref_state (humanoid_im.py:1000-1023): StateInit.Random -> sample_time_interval; Start / flags.test -> 0
     // (start_at_zero with a null phase array is only legal in the RNG-free instantiation's list mode)
     // (device-side call counter, phc_im_buffers_t.reset_rng_counter: folded into the key so that a captured launch draws anew on every replay)

@@ -536,7 +536,8 @@ class HumanoidIm:
         step needs two; the combinations that occur (AMP window position x reset-list slot) are few, every other pointer is fixed for the
         task's lifetime: cached (the rollout is host-bound, profiles/r02_notes.md)."""
         key = (amp_in.data_ptr(), amp_out.data_ptr(), self._reset_slot, None if self._occl_mask is None else self._occl_mask.data_ptr(),
-               None if self._offset_rand is None else self._offset_rand.data_ptr(), self._sampled_motion_ids.data_ptr(), self.obs_buf.data_ptr())
+               None if self._offset_rand is None else self._offset_rand.data_ptr(), self._sampled_motion_ids.data_ptr(), self._motion_ids_are_identity(),
+               self.obs_buf.data_ptr())
         cache = self.__dict__.setdefault("_buffers_cache", {})
         b = cache.get(key)
         if b is None:
@@ -546,9 +547,19 @@ class HumanoidIm:
         b.reset_list = abi.ptr(self._reset_list)     # (callers clear it for the masked sweep: restored on every use)
         return b
 
+    def _motion_ids_are_identity(self):
+        """`_sampled_motion_ids` is arange(num_envs) unless somebody assigned it (humanoid_im.py:121 sets it once; tests and tools may): checked once per
+        tensor object and in-place version, the kernels then skip the table (phc_im_buffers_t.sampled_motion_ids NULL)."""
+        t = self._sampled_motion_ids
+        c = self.__dict__.get("_ids_identity_cache")
+        if c is None or c[0] is not t or c[1] != t._version:
+            c = self.__dict__["_ids_identity_cache"] = (t, t._version, bool(torch.equal(t, torch.arange(self.num_envs, device=t.device, dtype=t.dtype))))
+        return c[2]
+
     def _buffers_uncached(self, amp_in, amp_out):
         return abi.im_buffers_struct(self.progress_buf, self.reset_buf, self._terminate_buf, self.rew_buf, self.reward_raw, self.obs_buf,
-                                     amp_in, amp_out, self._sampled_motion_ids, self._motion_start_times, self._motion_start_times_offset,
+                                     amp_in, amp_out, None if self._motion_ids_are_identity() else self._sampled_motion_ids, self._motion_start_times,
+                                     self._motion_start_times_offset,
                                      self._global_offset, self.ref_body_pos, self.ref_body_rot, self.ref_body_vel, self.ref_dof_pos,
                                      cycle_counter=self._cycle_counter, recovery_counter=self._recovery_counter,
                                      point_goal=self._point_goal, cycle_phase=self._cycle_phase, reset_list=self._reset_list,

@@ -143,7 +143,10 @@ def _check_step(agent, g, info, rtol_loss, grad_rtol, grad_atol, param_atol, ski
     for k in ("actor_loss", "critic_loss", "b_loss", "entropy", "kl", "disc_loss", "disc_grad_penalty", "disc_logit_loss"):
         if k in skip:
             continue
-        np.testing.assert_allclose(float(info[k]), float(g["res/" + k]), rtol=rtol_loss, atol=rtol_loss * 1e-2, err_msg=k)
+        atol = rtol_loss * 1e-2
+        if k == "actor_loss":   # a mean of signed terms of size |advantage| that nearly cancels: the error scales with the terms, not with the mean
+            atol = max(atol, rtol_loss * 0.1 * float(np.abs(g["in/advantages"]).mean()))
+        np.testing.assert_allclose(float(info[k]), float(g["res/" + k]), rtol=rtol_loss, atol=atol, err_msg=k)
     for k in ("disc_agent_acc", "disc_demo_acc"):
         assert abs(float(info[k]) - float(g["res/" + k])) <= (0.0 if rtol_loss < 1e-3 else 2.0 / _dims(g)[4]), k
     names = [str(n) for n in g["param_names"]]
@@ -164,9 +167,17 @@ def _check_step(agent, g, info, rtol_loss, grad_rtol, grad_atol, param_atol, ski
         np.testing.assert_allclose(got, ref, rtol=grad_rtol, atol=grad_atol + grad_rtol * scale, err_msg="grad " + n)
     after = _sub(g, "model_after/")
     before = _sub(g, "model/")
+    lr = float(agent.last_lr)
     for n, p in agent.model.state_dict().items():
         ref = after[n].numpy()
-        np.testing.assert_allclose(p.detach().float().cpu().numpy(), ref, rtol=0, atol=param_atol, err_msg="param " + n)
+        atol = np.full(ref.shape, param_atol, np.float64)
+        if "grad/" + n in g:
+            # Adam's first step is -lr g / (|g| + eps) = -lr sign(g): an element whose reference gradient lies inside the gradient tolerance
+            # may step the other way (seen: 1 of 18432 weights of the wide fixture)
+            gr = g["grad/" + n]
+            atol = np.where(np.abs(gr) <= grad_atol + grad_rtol * max(np.abs(gr).max(), 1e-12), param_atol + 2.0 * lr, param_atol)
+        err = np.abs(p.detach().float().cpu().numpy().astype(np.float64) - ref)
+        assert (err <= atol).all(), f"param {n}: {int((err > atol).sum())} of {err.size} elements off, worst {err.max():.3e}"
     moved = max(float((after[n] - before[n]).abs().max()) for n in names)
     assert moved > 1e-5            # lr 2e-5: Adam's first step moves every weight by ~lr
     for nm, mod in (("running_mean_std", agent.running_mean_std), ("amp_input_mean_std", agent._amp_input_mean_std)):
