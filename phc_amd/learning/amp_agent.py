@@ -115,7 +115,7 @@ class FlatGradBucket:
         # K-padded weights (round 2): a first-layer weight [N, K] whose K is no GEMM-friendly multiple (obs 934, AMP obs 1960) is STORED with
         # rows Kp = `_pad_cols` apart (network.build_mlp tags it); the module's parameter is the strided view [:, :K] -- shapes, state dicts
         # and checkpoints are unchanged -- while the GEMMs read the padded bf16 copy against K-padded inputs (pad = 0: same numbers; the
-        # first-layer forward / weight-gradient GEMMs run 20-30 % faster, scripts/gemm_pad_probe.py).  The pad elements start at zero and only
+        # first-layer forward / weight-gradient GEMMs run 20-30 % faster, scripts/probes/gemm_pad_probe.py).  The pad elements start at zero and only
         # ever see zero gradients.
         def alloc(p):
             kp = int(getattr(p, "_pad_cols", 0))
@@ -275,7 +275,7 @@ class IMAmpAgent:
         padded_k = {p.shape[1]: p._padded.shape[1] for p in self.grads.params if getattr(p, "_padded", None) is not None}
         self._obs_pad_cols = padded_k.get(obs_dim, 0)
         self._amp_pad_cols = padded_k.get(amp_dim, 0)
-        # opt-in (`learning.params.config.hip_graph=True`, bench.py sets it).  Known hazard (scripts/graph_repro2.py): if the caller keeps
+        # opt-in (`learning.params.config.hip_graph=True`, bench.py sets it).  Known hazard (scripts/probes/graph_repro2.py): if the caller keeps
         # an autograd-tracked copy of a parameter alive (`w0 = p.clone()` instead of `p.detach().clone()`), that parameter's
         # AccumulateGrad node lives on the stream it was created on; the captured backward then has to hand the gradient to a stream
         # that is not capturing and `hipStreamEndCapture` segfaults on ROCm 7.2 instead of raising.

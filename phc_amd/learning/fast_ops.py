@@ -3,7 +3,7 @@
 * `FastLinear` -- `nn.Linear` (same parameters, same state-dict keys) whose TRAINING pass under bf16 autocast on the device is one
   autograd node built for this problem shape (16 384-row batches, 10^2..10^3 features): bf16 addmm forward; weight gradient dY^T X
   as a batched GEMM over 8 row chunks + fp32 sum (the library's pick for a 16 384-long reduction is a 240-workgroup kernel without
-  split-K: 105-115 us vs 44-68 us, scripts/gemm_probe2.py); bias gradient by `phc_colsum_bf16`; one-output layers (the value head)
+  split-K: 105-115 us vs 44-68 us, scripts/probes/gemm_probe2.py); bias gradient by `phc_colsum_bf16`; one-output layers (the value head)
   by `phc_linear1_*`.  Used for actor, critic, PNN columns.
 * `FastLinearDD` -- the same, differentiable twice, for the discriminator MLP whose gradient penalty differentiates the backward pass.
 * `ppo_loss`, `disc_bce`, `weighted_sumsq` -- the loss terms with their gradients as kernels (unit-weight convention, see `_PPOLossFn`).

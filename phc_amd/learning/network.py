@@ -24,7 +24,7 @@ _ACT = {"relu": nn.ReLU, "silu": nn.SiLU, "tanh": nn.Tanh, "elu": nn.ELU, "gelu"
 
 def pad_cols(k):
     """GEMM-friendly K for a first-layer input width (obs 934 -> 1024, AMP obs 1960 -> 2048: hipBLASLt's forward / weight-gradient kernels run
-    20-30 % faster on multiples of 128 at these sizes, scripts/gemm_pad_probe.py); 0 = leave as is."""
+    20-30 % faster on multiples of 128 at these sizes, scripts/probes/gemm_pad_probe.py); 0 = leave as is."""
     if os.environ.get("PHC_NO_K_PAD") or k < 512 or k % 128 == 0:
         return 0
     return (k + 127) // 128 * 128
@@ -270,7 +270,7 @@ class ModelAMPContinuous(nn.Module):
             a, r, d = input_dict["amp_obs"], input_dict["amp_obs_replay"], input_dict["amp_obs_demo"]
             x = torch.cat([a, r, d], dim=0)
         # one discriminator pass over [agent; replay; demo] (the reference runs three, amp_models.py:40-48); a separate demo pass would
-        # shrink the gradient penalty's double backward to a third of the rows but adds nine launches: no gain measured (scripts/gpu_ab.sh)
+        # shrink the gradient penalty's double backward to a third of the rows but adds nine launches: no gain measured (scripts/probes/gpu_ab.sh)
         logits_raw = self.a2c_network.eval_disc(x)
         if input_dict.get("raw_disc_logits", False):   # the fused discriminator loss takes the [3m, 1] logits as the GEMM wrote them
             la = lr_ = ld = None

@@ -3,7 +3,7 @@ import os, subprocess, sys
 STAGES = ["A_preproc", "B_forward", "C_disc_loss", "D_backward", "E_full", "F_train_epoch", "G_as_test", "H_deep_stack"]
 if len(sys.argv) > 1 and sys.argv[1] in STAGES:
     import torch
-    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
     from phc_amd.config import compose
     from phc_amd.env.tasks.vec_task import parse_task
     from phc_amd.learning.amp_agent import IMAmpAgent

@@ -3,7 +3,7 @@ import os, subprocess, sys
 PIECES = ["linear", "fastlinear", "norm", "ppo", "disc", "adam", "stack"]
 if len(sys.argv) > 2:
     import torch
-    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
     piece, B = sys.argv[1], int(sys.argv[2])
     from phc_amd.learning.fast_ops import FastLinear, adam_clip_step, ppo_loss
     from phc_amd.learning.running_mean_std import RunningMeanStd

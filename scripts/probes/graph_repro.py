@@ -3,13 +3,13 @@ import os, subprocess, sys
 VARS = ["seed0_first", "seed0_oracle", "seed0_scipy", "seed0_pytestimport"]
 if len(sys.argv) > 1:
     import torch
-    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
     from phc_amd.config import compose
     from phc_amd.env.tasks.vec_task import parse_task
     from phc_amd.learning.amp_agent import IMAmpAgent
     v = sys.argv[1]
     if v.endswith("oracle"):
-        sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "oracle"))
         import phc_oracle  # noqa: F401
     if v.endswith("scipy"):
         import scipy.ndimage, scipy.sparse.linalg, scipy.special  # noqa: F401,E401

@@ -2,7 +2,7 @@ import os, subprocess, sys
 VARS = ["inline_copy", "inline_detach"]
 if len(sys.argv) > 1:
     v = sys.argv[1]
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     sys.path[:0] = [root, os.path.join(root, "tests"), os.path.join(root, "oracle")]
     if v == "plain_env":
         os.environ["PHC_FORCE_GRAPH"] = "1"

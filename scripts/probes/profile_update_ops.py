@@ -1,7 +1,7 @@
 """Which torch op launches which kernel in ONE optimizer step (dev tool): eager `_fwd_bwd` of one minibatch under torch.profiler, ops in launch
-order with their kernels.  python scripts/profile_update_ops.py"""
+order with their kernels.  python scripts/probes/profile_update_ops.py"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from torch.profiler import profile, ProfilerActivity
 from phc_amd.config import compose

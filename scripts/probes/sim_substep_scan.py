@@ -1,5 +1,5 @@
 """Stepper launch time vs number of sub-steps: t = a + b * nsub separates the fixed part (state load, initial FK, store / publish, launch)
-from the per-sub-step cost.   python scripts/sim_substep_scan.py [num_envs] [lane_mapping]"""
+from the per-sub-step cost.   python scripts/probes/sim_substep_scan.py [num_envs] [lane_mapping]"""
 import os
 import sys
 
