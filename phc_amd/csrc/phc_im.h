@@ -371,15 +371,21 @@ PHC_HD void im_post_finalize(const phc_motion_lib_t& lib, const phc_im_params_t&
 
 // Reset of one env, lane j: HumanoidIm._reset_envs (humanoid.py:585-621; humanoid_amp.py:378-398,508-528,
 // 559-637; humanoid_im.py:955-1023).  `t` = sampled start time.
+// `parts`: bit 0 = the state, the self observation and the per-env scalars; bit 1 = the task observation and the ref_* side buffers.  The two
+// halves share nothing but the reference frame at t (the imposed state IS that frame), so the kernel gives each its own lane group: the reset
+// launch lasts as long as its longest dependent chain (profiles/r03_task/reset_group_timeline.txt).
 PHC_HD void im_reset_lane(const phc_model_t& model, const phc_motion_lib_t& lib, const phc_im_params_t& prm,
-                          const phc_sim_state_t& sim, const phc_im_buffers_t& buf, int64_t env, int j, float t, bool clear_reset_flag) {
+                          const phc_sim_state_t& sim, const phc_im_buffers_t& buf, int64_t env, int j, float t, bool clear_reset_flag,
+                          int parts = 3) {
     const int nb = model.num_bodies, nd = model.num_dof;
     const int64_t mid = motion_id_of(buf, env);
+    const bool p_state = (parts & 1) != 0, p_task = (parts & 2) != 0;
     if (j < nb) {
         const FrameRef fr = frame_ref(lib, mid, t);
         BodyState rs = ref_body(lib, fr, j);     // global offset was just zeroed (humanoid_im.py:956-957)
         BodyState root = (j == 0) ? rs : ref_body(lib, fr, 0);
         // _set_env_state (humanoid_amp.py:605-637)
+        if (p_state) {
         store_body(sim.rigid_body_state, env, nb, j, rs);
         if (sim.contact_force) st3(sim.contact_force + (env * nb + j) * 3, v3(0.f, 0.f, 0.f));  // humanoid.py:619
         if (j == 0) {
@@ -395,7 +401,17 @@ PHC_HD void im_reset_lane(const phc_model_t& model, const phc_motion_lib_t& lib,
             st_joint(sim.pd_target + env * nd + ds, prm.dofs_per_joint, dp);  // set_dof_position_target_tensor_indexed(dof_pos) humanoid.py:605
             if (sim.dof_force) st_joint(sim.dof_force + env * nd + ds, prm.dofs_per_joint, v3(0.f, 0.f, 0.f));
         }
+        }
         // observations of the reset envs (humanoid.py:595 -> humanoid_im.py:694-726), progress_buf == 0
+        const Q4 hroot = obs_root_rot(prm, root.rot);
+        Q4 hinv = calc_heading_quat_inv(hroot), h = calc_heading_quat(hroot);
+        float* obs = buf.obs_buf + env * (int64_t)(prm.num_self_obs + prm.num_task_obs);
+        if (p_state) {
+        // (reset envs: the sensor tensor keeps its last reading until the next simulate call, as gym's does -- humanoid.py:1463)
+        if (prm.self_obs_v == 2 && buf.body_state_hist) self_obs_v2_lane(prm, buf.body_state_hist, nb, env, j, rs, root, hinv, obs, false, true);   // humanoid.py:592-595
+        else self_obs_lane(prm, nb, j, rs, root, hinv, obs, (sim.force_sensor && prm.self_obs_v == 3) ? sim.force_sensor + env * (int64_t)(prm.num_force_sensors * 6) : nullptr, env);
+        }
+        if (p_task) {
         const float t1 = motion_time(1, prm.dt, t, 0.f);
         const FrameRef fr1 = frame_ref(lib, mid, t1);
         BodyState r1 = ref_body(lib, fr1, j);
@@ -403,12 +419,6 @@ PHC_HD void im_reset_lane(const phc_model_t& model, const phc_motion_lib_t& lib,
         if (buf.offset_rand && prm.zero_out_far && prm.zero_out_far_train)   // the far-away start (humanoid_im.py:966-980): set AFTER the state
             disk_offset(buf.offset_rand[env * 2], buf.offset_rand[env * 2 + 1], &goff.x, &goff.y);   // was imposed, seen by the observations
         r1.pos += goff;
-        const Q4 hroot = obs_root_rot(prm, root.rot);
-    Q4 hinv = calc_heading_quat_inv(hroot), h = calc_heading_quat(hroot);
-        float* obs = buf.obs_buf + env * (int64_t)(prm.num_self_obs + prm.num_task_obs);
-        // (reset envs: the sensor tensor keeps its last reading until the next simulate call, as gym's does -- humanoid.py:1463)
-        if (prm.self_obs_v == 2 && buf.body_state_hist) self_obs_v2_lane(prm, buf.body_state_hist, nb, env, j, rs, root, hinv, obs, false, true);   // humanoid.py:592-595
-        else self_obs_lane(prm, nb, j, rs, root, hinv, obs, (sim.force_sensor && prm.self_obs_v == 3) ? sim.force_sensor + env * (int64_t)(prm.num_force_sensors * 6) : nullptr, env);
         int slot = prm.track_slot[j];
         if (slot >= 0) {
             BodyState rt = r1;
@@ -438,8 +448,9 @@ PHC_HD void im_reset_lane(const phc_model_t& model, const phc_motion_lib_t& lib,
             task_obs_future_lane(lib, prm, mid, 1, t, 0.f, go, prm.track_slot[j], j, ref_body(lib, frt, j), ref_body(lib, frt, 0),
                                  buf.obs_buf + env * (int64_t)(prm.num_self_obs + prm.num_task_obs) + prm.num_self_obs);
         }
+        }
     }
-    if (j == 0) {
+    if (j == 0 && p_state) {
         buf.motion_start_times[env] = t;           // humanoid_amp.py:524
         buf.motion_start_times_offset[env] = 0.f;  // humanoid_im.py:956
         V3 goff = v3(0.f, 0.f, 0.f);

@@ -109,7 +109,9 @@ __global__ __launch_bounds__(256) void k_im_reset(phc_model_t model, phc_motion_
                                                  const float* __restrict__ phase, int start_at_zero, uint64_t rng_key) {
     pin_family<DPJ>(lib, prm);
     const int lane = threadIdx.x & (G - 1);
-    const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;   // listed env (grid.x), AMP history frame k (grid.y)
+    // listed env (grid.x); grid.y: 0 = state + self observation, 1 = task observation, 2 + k = AMP history frame k -- the heaviest groups
+    // are dispatched first and no group carries more than one lookup chain
+    const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
     const int k = (int)blockIdx.y;
 #ifdef PHC_SIM_PROFILE
     const bool rtl_on = (int)(r * 16 + k) == g_phc_rtl_group;
@@ -141,9 +143,9 @@ __global__ __launch_bounds__(256) void k_im_reset(phc_model_t model, phc_motion_
     const uint64_t key = (RNG && buf.reset_rng_counter) ? splitmix64(rng_key ^ (*buf.reset_rng_counter * 0x9E6C63D0876A9A47ull)) : rng_key;
     const float t = start_at_zero ? 0.f : sample_time_interval(lib, mid, RNG ? hash_u01(key, (uint32_t)env) : phase[r]);
     PHC_RTL(2)
-    if (k == 0) im_reset_lane(model, lib, prm, sim, buf, env, lane, t, env_ids != nullptr);
+    if (k < 2) im_reset_lane(model, lib, prm, sim, buf, env, lane, t, env_ids != nullptr, 1 << k);
     PHC_RTL(3)
-    im_reset_amp_lane(lib, prm, buf, model.num_bodies, env, lane, t, k);
+    if (k >= 2) im_reset_amp_lane(lib, prm, buf, model.num_bodies, env, lane, t, k - 2);
     PHC_RTL(4)
 }
 
@@ -339,7 +341,7 @@ int32_t phc_im_reset(const phc_model_t* model, const phc_motion_lib_t* lib, cons
     if (!sim || !buf || num_reset < 0 || (!start_at_zero && !phase)) return PHC_EINVAL;
     if (num_reset == 0) return 0;
     const int g = group_lanes(model->num_bodies, prm->num_ext_bodies);
-    const dim3 grid(env_blocks(num_reset, g), prm->num_amp_obs_steps);
+    const dim3 grid(env_blocks(num_reset, g), prm->num_amp_obs_steps + 2);
 #define PHC_RESET(DPJ, G) hipLaunchKernelGGL((k_im_reset<DPJ, false, G>), grid, dim3(256), 0, (hipStream_t)stream, *model, *lib, *prm, *sim, *buf, num_reset, env_ids, phase, start_at_zero, 0ull)
     if (prm->dofs_per_joint == 1) { if (g == 64) PHC_RESET(1, 64); else PHC_RESET(1, 32); }
     else { if (g == 64) PHC_RESET(3, 64); else PHC_RESET(3, 32); }
@@ -358,7 +360,7 @@ int32_t phc_im_reset_done(const phc_model_t* model, const phc_motion_lib_t* lib,
     // (with a device-side call counter the host one stays out of the key: a captured launch and an eager one then draw the same numbers)
     const uint64_t key = splitmix64(splitmix64(seed) ^ ((buf->reset_rng_counter ? 0ull : counter) * 0xD1342543DE82EF95ull));
     const int g = group_lanes(model->num_bodies, prm->num_ext_bodies);
-    const dim3 grid(env_blocks(n, g), prm->num_amp_obs_steps);
+    const dim3 grid(env_blocks(n, g), prm->num_amp_obs_steps + 2);
 #define PHC_RESET(DPJ, G) hipLaunchKernelGGL((k_im_reset<DPJ, true, G>), grid, dim3(256), 0, (hipStream_t)stream, *model, *lib, *prm, *sim, *buf, n, nullptr, nullptr, start_at_zero, key)
     if (prm->dofs_per_joint == 1) { if (g == 64) PHC_RESET(1, 64); else PHC_RESET(1, 32); }
     else { if (g == 64) PHC_RESET(3, 64); else PHC_RESET(3, 32); }

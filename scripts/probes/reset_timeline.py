@@ -25,8 +25,8 @@ def main():
         task.reset_done(); env.step(a)
     torch.cuda.synchronize()
     print(f"{n} envs, {int((task.reset_buf != 0).sum())} envs reset this step")
-    names = ["list entry -> env", "motion id -> start time", "state + observations (k = 0 only)", "AMP history frame"]
-    for r, k in ((3, 0), (200, 0), (3, 5), (200, 9)):
+    names = ["list entry -> env", "motion id -> start time", "state + self obs (y = 0) / task obs (y = 1)", "AMP history frame (y >= 2)"]
+    for r, k in ((3, 0), (200, 0), (3, 1), (200, 1), (3, 2), (3, 7), (200, 11)):
         buf = (C.c_ulonglong * 64)()
         raw.phc_debug_reset_timeline(buf, r * 16 + k)
         task.reset_done(); env.step(a)
@@ -34,9 +34,9 @@ def main():
         raw.phc_debug_reset_timeline(buf, -1)
         t = [int(buf[i]) for i in range(5)]
         if not all(t):
-            print(f"group r={r} k={k}: not an active group this step {t}")
+            print(f"group r={r} y={k}: not an active group this step {t}")
             continue
-        print(f"group r={r} k={k}: total {t[4] - t[0]} cycles: " + ", ".join(f"{nm} {b - a}" for nm, a, b in zip(names, t[:-1], t[1:])))
+        print(f"group r={r} y={k}: total {t[4] - t[0]} cycles: " + ", ".join(f"{nm} {b - a}" for nm, a, b in zip(names, t[:-1], t[1:])))
 
 
 if __name__ == "__main__":
