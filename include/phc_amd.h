@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PHC_ABI_VERSION 33
+#define PHC_ABI_VERSION 32
 #define PHC_MAX_BODIES 64   /* bodies (incl. extended reference bodies) per articulation; also the slot count of the model tables */
 #define PHC_EINVAL (-1)
 #define PHC_EUNSUPPORTED (-2)
@@ -345,9 +345,7 @@ int32_t phc_running_norm(const float* x, const int64_t* row_index, int64_t rows,
                          double* workspace, void* stream);
 
 /* Column sums of a bf16 matrix x [rows, cols] -> out fp32 [cols]: the bias gradient of a linear layer (autograd's `sum(0)` of
- * the output gradient, AddmmBackward).  workspace: phc_colsum_workspace(rows, cols) bytes; its FIRST 1024 bytes are ticket counters of the
- * "last block sums" scheme (ABI 33: one launch instead of two) and must be ZERO before the first call -- every launch leaves them at zero, so one
- * zero-initialised buffer of the largest size serves all calls on a stream.  At most 16384 columns. */
+ * the output gradient, AddmmBackward).  workspace: phc_colsum_workspace(rows, cols) bytes. */
 int64_t phc_colsum_workspace(int64_t rows, int32_t cols);
 int32_t phc_colsum_bf16(const void* x, int64_t rows, int32_t cols, float* out, float* workspace, void* stream);
 /* The same behind a ReLU whose output `y` was saved (round 2: layers whose ReLU rides in the GEMM epilogue): gm = gy where y > 0 else 0
@@ -366,8 +364,7 @@ int32_t phc_sum_slabs_bf16(const void* part, int32_t slabs, int64_t n, float* ou
  * phc_weighted_sumsq: out[0] = sum_i coefs[i] * |tensors[i]|^2 over count <= 4 device tensors of sizes[i] elements (all fp32 or all
  *   bf16): the logit regulariser + weight decay in one pass, or -- one bf16 tensor, coef = c / rows -- the gradient penalty
  *   c * mean_rows(sum_cols g^2).  out[1 + i] = |tensors[i]|^2 (ABI 20: `out` holds 1 + count floats; the last one of the weight call
- *   is the reference's `disc_logit_loss`, amp_agent.py:757-758).  workspace: phc_sumsq_workspace() bytes, the last 8 a ticket counter: ZERO before the
- *   first call, left at zero (ABI 33). */
+ *   is the reference's `disc_logit_loss`, amp_agent.py:757-758).  workspace: phc_sumsq_workspace() bytes. */
 int32_t phc_disc_bce(const void* logits, int32_t is_bf16, int32_t n_agent, int32_t n_demo, float scale, void* grad, float* stats,
                      void* stream);
 int64_t phc_sumsq_workspace(void);
@@ -418,7 +415,7 @@ int32_t phc_adam_clip_step(float* param, float* grad, float* exp_avg, float* exp
  * in the same type; stats[6] = loss, mean a_loss, mean c_loss, mean b_loss, entropy, mean kl(policy || old policy).
  * old_values is only read when clip_value.  row_index (optional, [B] int64): minibatch row r takes actions / old_* / advantages /
  * returns from row row_index[r] of the rollout tensors (mu, value and the gradients stay minibatch-ordered).
- * workspace: phc_ppo_loss_workspace() bytes, the last 8 a ticket counter: ZERO before the first call, left at zero (ABI 33). */
+ * workspace: phc_ppo_loss_workspace() bytes. */
 typedef struct {
     float e_clip, critic_coef, entropy_coef, bounds_loss_coef;
     int32_t clip_value;

@@ -133,7 +133,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the .so does not export the symbol
         fn.argtypes = argtypes
         fn.restype = restype
-    if lib.phc_abi_version() != 33:
+    if lib.phc_abi_version() != 32:
         raise ImportError("libphc_amd.so ABI version mismatch")
     _lib = lib
     return lib

@@ -15,24 +15,6 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-// ---- "the block that finishes last does the final sum" (round 3: the separate finishing launches of the column sums, the PPO loss and the
-// weighted square sums cost 5-8 us each plus a launch gap, 13 times per optimizer step).  A ticket counter in the workspace (ZERO before the
-// first launch, left at zero by every launch) tells a block that all others have published their partial sums; it then reduces them in a FIXED
-// order -- the result does not depend on which block came last.  Partials are re-read past the L1 (agent-scope loads).
-template <typename T> __device__ __forceinline__ T ld_dev(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ bool last_block_of(unsigned int* ticket, unsigned int nblocks) {
-    __shared__ unsigned int s_ticket;
-    __threadfence();            // this thread's partial sums are visible device-wide ...
-    __syncthreads();            // ... for every thread of the block, before the block takes its ticket
-    if (threadIdx.x == 0) s_ticket = atomicAdd(ticket, 1u);
-    __syncthreads();
-    if (s_ticket != nblocks - 1u) return false;
-    if (threadIdx.x == 0) atomicExch(ticket, 0u);
-    __threadfence();
-    return true;
-}
-#define PHC_TICKET_BYTES 1024   // ticket area at the START of the column-sum workspace: one counter per 64-column block
-
 #define RN_COLS 256   // columns per block == threads per block (thread <-> column: loads coalesce across the block)
 #define RN_ROWS 32    // rows per block (4096 x 1960 -> 1024 blocks: four per CU; 128 rows left one wavefront per SIMD, latency-bound)
 #define RN_UNROLL 8   // independent loads in flight per thread
@@ -117,26 +99,7 @@ __global__ __launch_bounds__(1024) void k_running_norm_finish(const double* __re
 // 256-row chunk, then one sum over the chunks.
 // ------------------------------------------------------------------------------------------
 #define CS_ROWS 256
-// the last chunk-block of a 64-column group: out[c] = sum over the chunks, in chunk order (4 row lanes x 4 loads in flight)
-__device__ __forceinline__ void colsum_tail(const float* partial, int nchunks, int cols, float* __restrict__ out, float (*l)[64]) {
-    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cx;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    if (c < cols) {
-        int k = ry;
-        for (; k + 12 < nchunks; k += 16) {
-            a0 += ld_dev(partial + (int64_t)k * cols + c); a1 += ld_dev(partial + (int64_t)(k + 4) * cols + c);
-            a2 += ld_dev(partial + (int64_t)(k + 8) * cols + c); a3 += ld_dev(partial + (int64_t)(k + 12) * cols + c);
-        }
-        for (; k < nchunks; k += 4) a0 += ld_dev(partial + (int64_t)k * cols + c);
-    }
-    __syncthreads();
-    l[ry][cx] = (a0 + a1) + (a2 + a3);
-    __syncthreads();
-    if (ry == 0 && c < cols) out[c] = (l[0][cx] + l[1][cx]) + (l[2][cx] + l[3][cx]);
-}
-__global__ __launch_bounds__(256) void k_colsum_bf16(const __hip_bfloat16* __restrict__ x, int64_t rows, int cols, float* __restrict__ partial,
-                                                     unsigned int* __restrict__ tickets, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void k_colsum_bf16(const __hip_bfloat16* __restrict__ x, int64_t rows, int cols, float* __restrict__ partial) {
     __shared__ float l[4][64];
     const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cx;
@@ -157,12 +120,10 @@ __global__ __launch_bounds__(256) void k_colsum_bf16(const __hip_bfloat16* __res
     l[ry][cx] = a;
     __syncthreads();
     if (ry == 0 && c < cols) partial[(int64_t)blockIdx.y * cols + c] = (l[0][cx] + l[1][cx]) + (l[2][cx] + l[3][cx]);
-    if (last_block_of(tickets + blockIdx.x, gridDim.y)) colsum_tail(partial, (int)gridDim.y, cols, out, l);
 }
 // The same with the ReLU mask of a saved layer output applied on the way: gm = (y > 0) ? gy : 0 is written back, its column sums go to `partial`.
 __global__ __launch_bounds__(256) void k_colsum_relu_bf16(const __hip_bfloat16* __restrict__ gy, const __hip_bfloat16* __restrict__ y, int64_t rows, int cols,
-                                                          __hip_bfloat16* __restrict__ gm, float* __restrict__ partial,
-                                                          unsigned int* __restrict__ tickets, float* __restrict__ out) {
+                                                          __hip_bfloat16* __restrict__ gm, float* __restrict__ partial) {
     __shared__ float l[4][64];
     const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cx;
@@ -191,9 +152,7 @@ __global__ __launch_bounds__(256) void k_colsum_relu_bf16(const __hip_bfloat16* 
     l[ry][cx] = a;
     __syncthreads();
     if (ry == 0 && c < cols) partial[(int64_t)blockIdx.y * cols + c] = (l[0][cx] + l[1][cx]) + (l[2][cx] + l[3][cx]);
-    if (last_block_of(tickets + blockIdx.x, gridDim.y)) colsum_tail(partial, (int)gridDim.y, cols, out, l);
 }
-// (the value head's weight gradient, k_linear1_bwd, keeps this separate finishing launch: its partials are 513 columns wide per block)
 // block = 64 columns x 16 slices of the chunk list (up to 1024 chunks: 64 loads per thread, four in flight)
 __global__ __launch_bounds__(1024) void k_colsum_finish(const float* __restrict__ partial, int nchunks, int cols, float* __restrict__ out) {
     __shared__ float l[16][64];
@@ -356,37 +315,12 @@ template <> __device__ __forceinline__ void st_f<__hip_bfloat16>(__hip_bfloat16*
 
 
 #define PPO_NSUM 4   // a_loss, c_loss, b_loss, kl
-// stats[0..5] = loss, mean a_loss, mean c_loss, mean b_loss, entropy, mean kl.  The block that finishes last; 256 threads: wavefront k
-// reduces sum k over the blocks (block order), wavefront 0 also the entropy.
-__device__ __forceinline__ void ppo_loss_finish(const double* partial, int nblocks, int64_t B, int D, const float* __restrict__ logstd,
-                                                const phc_ppo_params_t& prm, float* __restrict__ stats) {
-    __shared__ double l[PPO_NSUM];
-    __shared__ float lent;
-    const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    double t = 0.0;
-    for (int b = lane; b < nblocks; b += 64) t += ld_dev(partial + (int64_t)b * PPO_NSUM + k);
-    for (int m = 32; m >= 1; m >>= 1) t += __shfl_xor(t, m, 64);
-    if (lane == 0) l[k] = t / (double)B;
-    if (k == 0) {
-        float e = 0.f;
-        for (int d = lane; d < D; d += 64) e += 0.5f + 0.5f * 1.8378770664093453f + logstd[d];
-        e = wave_sum(e);
-        if (lane == 0) lent = e;
-    }
-    __syncthreads();
-    if (threadIdx.x != 0) return;
-    const float ent = lent;
-    stats[1] = (float)l[0]; stats[2] = (float)l[1]; stats[3] = (float)l[2]; stats[4] = ent; stats[5] = (float)l[3];
-    stats[0] = (float)l[0] + prm.critic_coef * (float)l[1] - prm.entropy_coef * ent + prm.bounds_loss_coef * (float)l[2];
-}
-
 template <typename T>
 __global__ __launch_bounds__(256) void k_ppo_loss(const T* __restrict__ mu, const T* __restrict__ value, const float* __restrict__ logstd,
                                                   const float* __restrict__ actions, const float* __restrict__ old_neglogp,
                                                   const float* __restrict__ adv, const float* __restrict__ ret, const float* __restrict__ old_value,
                                                   const float* __restrict__ old_mu, const float* __restrict__ old_sigma,
-                                                  const int64_t* __restrict__ idx, int64_t B, int D, phc_ppo_params_t prm, T* __restrict__ grad_mu, T* __restrict__ grad_value, double* __restrict__ partial,
-                                                  unsigned int* __restrict__ ticket, float* __restrict__ stats) {
+                                                  const int64_t* __restrict__ idx, int64_t B, int D, phc_ppo_params_t prm, T* __restrict__ grad_mu, T* __restrict__ grad_value, double* __restrict__ partial) {
     __shared__ double lsum[4][PPO_NSUM];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const float invB = 1.0f / (float)B;
@@ -448,7 +382,30 @@ __global__ __launch_bounds__(256) void k_ppo_loss(const T* __restrict__ mu, cons
     __syncthreads();
     if (threadIdx.x < PPO_NSUM)
         partial[(int64_t)blockIdx.x * PPO_NSUM + threadIdx.x] = (lsum[0][threadIdx.x] + lsum[1][threadIdx.x]) + (lsum[2][threadIdx.x] + lsum[3][threadIdx.x]);
-    if (last_block_of(ticket, gridDim.x)) ppo_loss_finish(partial, (int)gridDim.x, B, D, logstd, prm, stats);
+}
+
+// stats[0..5] = loss, mean a_loss, mean c_loss, mean b_loss, entropy, mean kl.  256 threads: wavefront k reduces sum k; wavefront 0
+// also the entropy.
+__global__ __launch_bounds__(256) void k_ppo_loss_finish(const double* __restrict__ partial, int nblocks, int64_t B, int D,
+                                                         const float* __restrict__ logstd, phc_ppo_params_t prm, float* __restrict__ stats) {
+    __shared__ double l[PPO_NSUM];
+    __shared__ float lent;
+    const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double t = 0.0;
+    for (int b = lane; b < nblocks; b += 64) t += partial[(int64_t)b * PPO_NSUM + k];
+    for (int m = 32; m >= 1; m >>= 1) t += __shfl_xor(t, m, 64);
+    if (lane == 0) l[k] = t / (double)B;
+    if (k == 0) {
+        float e = 0.f;
+        for (int d = lane; d < D; d += 64) e += 0.5f + 0.5f * 1.8378770664093453f + logstd[d];
+        e = wave_sum(e);
+        if (lane == 0) lent = e;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    const float ent = lent;
+    stats[1] = (float)l[0]; stats[2] = (float)l[1]; stats[3] = (float)l[2]; stats[4] = ent; stats[5] = (float)l[3];
+    stats[0] = (float)l[0] + prm.critic_coef * (float)l[1] - prm.entropy_coef * ent + prm.bounds_loss_coef * (float)l[2];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -592,24 +549,7 @@ struct SumsqArgs { const void* ptr[4]; int64_t n[4]; float coef[4]; int count; i
 #define SSM_BLOCKS 1024
 // partial[t][block] = this block's share of |tensor t|^2 (unweighted).  16-byte loads (8 bf16 / 4 fp32) over the aligned bulk, scalar tail;
 // 1024 blocks (round 2: 256 blocks of scalar loads read the 16 MB penalty gradient at 0.47 TB/s)
-// out[0] = sum_t coef[t] |tensor t|^2, out[1 + t] = |tensor t|^2: the block that finishes last sums the partials in block order
-__device__ __forceinline__ void sumsq_multi_finish(const SumsqArgs& a, const double* partial, float* __restrict__ out) {
-    __shared__ double l[4];
-    double total = 0.0;
-    for (int t = 0; t < a.count; ++t) {
-        double v = 0.0;
-        for (int k = threadIdx.x; k < SSM_BLOCKS; k += 256) v += ld_dev(partial + t * SSM_BLOCKS + k);
-        for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-        __syncthreads();
-        if ((threadIdx.x & 63) == 0) l[threadIdx.x >> 6] = v;
-        __syncthreads();
-        const double s = (l[0] + l[1]) + (l[2] + l[3]);
-        if (threadIdx.x == 0) out[1 + t] = (float)s;
-        total += (double)a.coef[t] * s;
-    }
-    if (threadIdx.x == 0) out[0] = (float)total;
-}
-__global__ __launch_bounds__(256) void k_sumsq_multi(SumsqArgs a, double* __restrict__ partial, unsigned int* __restrict__ ticket, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void k_sumsq_multi(SumsqArgs a, double* __restrict__ partial) {
     __shared__ double l[4][4];
     const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x, nthreads = (int64_t)SSM_BLOCKS * 256;
     for (int t = 0; t < a.count; ++t) {
@@ -649,8 +589,25 @@ __global__ __launch_bounds__(256) void k_sumsq_multi(SumsqArgs a, double* __rest
     }
     __syncthreads();
     if (threadIdx.x < a.count) partial[threadIdx.x * SSM_BLOCKS + blockIdx.x] = (l[threadIdx.x][0] + l[threadIdx.x][1]) + (l[threadIdx.x][2] + l[threadIdx.x][3]);
-    if (last_block_of(ticket, gridDim.x)) sumsq_multi_finish(a, partial, out);
 }
+// out[0] = sum_t coef[t] |tensor t|^2, out[1 + t] = |tensor t|^2
+__global__ __launch_bounds__(256) void k_sumsq_multi_finish(SumsqArgs a, const double* __restrict__ partial, float* __restrict__ out) {
+    __shared__ double l[4];
+    double total = 0.0;
+    for (int t = 0; t < a.count; ++t) {
+        double v = 0.0;
+        for (int k = threadIdx.x; k < SSM_BLOCKS; k += 256) v += partial[t * SSM_BLOCKS + k];
+        for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) l[threadIdx.x >> 6] = v;
+        __syncthreads();
+        const double s = (l[0] + l[1]) + (l[2] + l[3]);
+        if (threadIdx.x == 0) out[1 + t] = (float)s;
+        total += (double)a.coef[t] * s;
+    }
+    if (threadIdx.x == 0) out[0] = (float)total;
+}
+
 extern "C" {
 
 // partial sums + 8 bytes holding the finish kernel's ticket counter, which must be ZERO before the first call (it is left at zero)
@@ -683,17 +640,15 @@ int32_t phc_running_norm(const float* x, const int64_t* row_index, int64_t rows,
     return e == hipSuccess ? 0 : (int32_t)e;
 }
 
-// ticket area (ZERO before the first call; left at zero) + per-chunk partial sums
-int64_t phc_colsum_workspace(int64_t rows, int32_t cols) { return PHC_TICKET_BYTES + ((rows + CS_ROWS - 1) / CS_ROWS) * (int64_t)cols * (int64_t)sizeof(float); }
+int64_t phc_colsum_workspace(int64_t rows, int32_t cols) { return ((rows + CS_ROWS - 1) / CS_ROWS) * (int64_t)cols * (int64_t)sizeof(float); }
 
 int32_t phc_colsum_bf16(const void* x, int64_t rows, int32_t cols, float* out, float* workspace, void* stream) {
     if (!x || !out || !workspace || rows < 1 || cols < 1) return PHC_EINVAL;
     const int64_t nchunks = (rows + CS_ROWS - 1) / CS_ROWS;
     if (nchunks > 65535) return PHC_EUNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    if ((cols + 63) / 64 > PHC_TICKET_BYTES / 4) return PHC_EUNSUPPORTED;
-    hipLaunchKernelGGL(k_colsum_bf16, dim3((cols + 63) / 64, (unsigned)nchunks), dim3(256), 0, st, reinterpret_cast<const __hip_bfloat16*>(x), rows, cols,
-                       workspace + PHC_TICKET_BYTES / 4, reinterpret_cast<unsigned int*>(workspace), out);
+    hipLaunchKernelGGL(k_colsum_bf16, dim3((cols + 63) / 64, (unsigned)nchunks), dim3(256), 0, st, reinterpret_cast<const __hip_bfloat16*>(x), rows, cols, workspace);
+    hipLaunchKernelGGL(k_colsum_finish, dim3((cols + 63) / 64), dim3(1024), 0, st, workspace, (int)nchunks, cols, out);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int32_t)e;
 }
@@ -701,11 +656,11 @@ int32_t phc_colsum_bf16(const void* x, int64_t rows, int32_t cols, float* out, f
 int32_t phc_colsum_relu_bf16(const void* gy, const void* y, int64_t rows, int32_t cols, void* gm, float* out, float* workspace, void* stream) {
     if (!gy || !y || !gm || !out || !workspace || rows < 1 || cols < 1) return PHC_EINVAL;
     const int64_t nchunks = (rows + CS_ROWS - 1) / CS_ROWS;
-    if (nchunks > 65535 || (cols + 63) / 64 > PHC_TICKET_BYTES / 4) return PHC_EUNSUPPORTED;
+    if (nchunks > 65535) return PHC_EUNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_colsum_relu_bf16, dim3((cols + 63) / 64, (unsigned)nchunks), dim3(256), 0, st, reinterpret_cast<const __hip_bfloat16*>(gy),
-                       reinterpret_cast<const __hip_bfloat16*>(y), rows, cols, reinterpret_cast<__hip_bfloat16*>(gm), workspace + PHC_TICKET_BYTES / 4,
-                       reinterpret_cast<unsigned int*>(workspace), out);
+                       reinterpret_cast<const __hip_bfloat16*>(y), rows, cols, reinterpret_cast<__hip_bfloat16*>(gm), workspace);
+    hipLaunchKernelGGL(k_colsum_finish, dim3((cols + 63) / 64), dim3(1024), 0, st, workspace, (int)nchunks, cols, out);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int32_t)e;
 }
@@ -782,8 +737,7 @@ int32_t phc_disc_bce(const void* logits, int32_t is_bf16, int32_t n_agent, int32
     return e == hipSuccess ? 0 : (int32_t)e;
 }
 
-// partial sums + 8 bytes holding the ticket counter (ZERO before the first call; left at zero)
-int64_t phc_sumsq_workspace(void) { return 4 * SSM_BLOCKS * (int64_t)sizeof(double) + 8; }
+int64_t phc_sumsq_workspace(void) { return 4 * SSM_BLOCKS * (int64_t)sizeof(double); }
 
 int32_t phc_weighted_sumsq(int32_t count, const void* const* tensors, const int64_t* sizes, const float* coefs, int32_t is_bf16, float* out,
                            double* workspace, void* stream) {
@@ -793,7 +747,8 @@ int32_t phc_weighted_sumsq(int32_t count, const void* const* tensors, const int6
     for (int t = 0; t < 4; ++t) { a.ptr[t] = t < count ? tensors[t] : nullptr; a.n[t] = t < count ? sizes[t] : 0; a.coef[t] = t < count ? coefs[t] : 0.f; }
     for (int t = 0; t < count; ++t) if (!a.ptr[t] || a.n[t] < 0) return PHC_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_sumsq_multi, dim3(SSM_BLOCKS), dim3(256), 0, st, a, workspace, reinterpret_cast<unsigned int*>(workspace + 4 * SSM_BLOCKS), out);
+    hipLaunchKernelGGL(k_sumsq_multi, dim3(SSM_BLOCKS), dim3(256), 0, st, a, workspace);
+    hipLaunchKernelGGL(k_sumsq_multi_finish, dim3(1), dim3(256), 0, st, a, workspace, out);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int32_t)e;
 }
@@ -817,8 +772,7 @@ int32_t phc_adam_clip_step(float* param, float* grad, float* exp_avg, float* exp
 }
 
 #define PPO_BLOCKS 1024
-// partial sums + 8 bytes holding the ticket counter (ZERO before the first call; left at zero)
-int64_t phc_ppo_loss_workspace(void) { return PPO_BLOCKS * PPO_NSUM * (int64_t)sizeof(double) + 8; }
+int64_t phc_ppo_loss_workspace(void) { return PPO_BLOCKS * PPO_NSUM * (int64_t)sizeof(double); }
 
 int32_t phc_ppo_loss(const void* mu, const void* value, int32_t is_bf16, const float* logstd, const float* actions, const float* old_neglogp,
                      const float* advantages, const float* returns, const float* old_values, const float* old_mu, const float* old_sigma,
@@ -833,11 +787,11 @@ int32_t phc_ppo_loss(const void* mu, const void* value, int32_t is_bf16, const f
     if (is_bf16)
         hipLaunchKernelGGL(k_ppo_loss<__hip_bfloat16>, dim3(nblocks), dim3(256), 0, st, (const __hip_bfloat16*)mu, (const __hip_bfloat16*)value, logstd, actions,
                            old_neglogp, advantages, returns, old_values, old_mu, old_sigma, row_index, batch, num_actions, *prm, (__hip_bfloat16*)grad_mu,
-                           (__hip_bfloat16*)grad_value, workspace, reinterpret_cast<unsigned int*>(workspace + PPO_BLOCKS * PPO_NSUM), stats);
+                           (__hip_bfloat16*)grad_value, workspace);
     else
         hipLaunchKernelGGL(k_ppo_loss<float>, dim3(nblocks), dim3(256), 0, st, (const float*)mu, (const float*)value, logstd, actions, old_neglogp,
-                           advantages, returns, old_values, old_mu, old_sigma, row_index, batch, num_actions, *prm, (float*)grad_mu, (float*)grad_value, workspace,
-                           reinterpret_cast<unsigned int*>(workspace + PPO_BLOCKS * PPO_NSUM), stats);
+                           advantages, returns, old_values, old_mu, old_sigma, row_index, batch, num_actions, *prm, (float*)grad_mu, (float*)grad_value, workspace);
+    hipLaunchKernelGGL(k_ppo_loss_finish, dim3(1), dim3(256), 0, st, workspace, nblocks, batch, num_actions, logstd, *prm, stats);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int32_t)e;
 }

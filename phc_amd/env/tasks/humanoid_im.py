@@ -87,9 +87,8 @@ class HumanoidIm:
             raise NotImplementedError(f"humanoid_type={self.humanoid_type!r}: built so far: smpl, h1, g1")
         self._is_robot = self.humanoid_type in ("h1", "g1")
         # options of the reference this path does not build: refuse them rather than run without them
-        #   enableHistObs: the AMP history window appended to the self observation (humanoid_amp.py:98-101,327,549-555);
         #   divide_group: several humanoids in ONE collision group, i.e. inter-env contact (humanoid.py:261-266,1051-1052): the stepper's envs are independent
-        unsupported = dict(kin_loss=False, z_readout=False, distill=False, enableHistObs=False, divide_group=False, is_discrete=False)
+        unsupported = dict(kin_loss=False, z_readout=False, distill=False, divide_group=False, is_discrete=False)
         for k, off in unsupported.items():
             v = env.get(k, robot.get(k, off))
             if v != off:
@@ -113,6 +112,7 @@ class HumanoidIm:
         self._add_action_noise = bool(env.get("add_action_noise", False))     # humanoid.py:337,1533-1535: applied only while collect_dataset is on
         self._action_noise_std = float(env.get("action_noise_std", 0.05))
         self._remove_disc_rot = bool(env.get("remove_disc_rot", False))       # humanoid.py:309,405-406: no joint rotations / rates in the AMP observation
+        self._enable_hist_obs = bool(env.get("enableHistObs", False))         # humanoid_amp.py:98-101,327-328,546-557: the AMP history behind the self observation
         # future reference tracks in the task observation (humanoid_im.py:39-47): numTrajSamples frames, 1 / trajSampleTimestepInv apart
         self._fut_tracks = bool(env.get("fut_tracks", False))
         self._num_traj_samples = int(env["numTrajSamples"]) if self._fut_tracks else 1
@@ -322,6 +322,20 @@ class HumanoidIm:
                 self._num_amp_obs_per_step += self._amp_obs_extra.shape[1]
             dof_sub = [np.arange(3 * (j - 1), 3 * j) for j in range(1, self.num_bodies) if amp_slot[j] >= 0]
             self.dof_subset = torch.from_numpy(np.concatenate(dof_sub)) if self._has_dof_subset and dof_sub else torch.tensor([]).long()
+        # env.enableHistObs (humanoid_amp.py:327-328,546-557): HumanoidAMP._compute_humanoid_obs appends `_amp_obs_buf` -- flattened, newest frame first, AS
+        # IT STANDS when the observation is formed: post_physics_step (:193-204) and _reset_envs (:378-385) both form the observation BEFORE they
+        # update / re-initialise the history, so the policy sees the history of the previous step (and, after a reset, the finished episode's).  Here
+        # the columns ride behind the constant per-env columns of the self observation (`self_obs_extra`) and are refreshed from the AMP window in
+        # front of every launch that writes observations (_refresh_hist_obs).
+        self._hist_obs_cols = 0
+        if self._enable_hist_obs:
+            if self.self_obs_v == 2:
+                raise NotImplementedError("enableHistObs with self_obs_v=2: get_self_obs_size (humanoid.py:513-514) multiplies the widened block by the "
+                                          "number of past states, which the observation function does not produce")
+            self._hist_obs_cols = int(env.get("numAMPObsSteps", 10)) * self._num_amp_obs_per_step
+            hist = torch.zeros((self.num_envs, self._hist_obs_cols), dtype=torch.float32, device=self.device)
+            self._self_obs_extra = hist if self._self_obs_extra is None else torch.cat([self._self_obs_extra, hist], dim=-1).contiguous()
+            self._num_self_obs += self._hist_obs_cols
         # extended bodies of the full-body reward (humanoid_im.py:74-82)
         ext = list(robot.get("extend_config", [])) if self._is_robot else []
         self.num_extend_bodies = len(ext)
@@ -778,6 +792,7 @@ class HumanoidIm:
                 torch.rand(self._offset_rand.shape, out=self._offset_rand)
         if self._use_reset_list and self._reset_list_pending:   # the previous step's list was never consumed (reset(env_ids) idiom): start this one empty
             self._reset_count[self._reset_slot].zero_()
+        self._refresh_hist_obs()
         buf = self._buffers(amp_in, amp_out)
         L.check(self._lib.phc_im_post_physics(self._model_struct, self._motion_lib.struct, self._im_params, self._sim_struct, buf,
                                               _stream()), "phc_im_post_physics")
@@ -811,7 +826,7 @@ class HumanoidIm:
         """True when reset_done() + step() consist of launches and host bookkeeping only (no host-side random draws or syncs between them), so that
         the learner may capture them, with its own policy / critic segments, into ONE hipGraph per rollout step."""
         return bool(self._use_reset_list and not (self.cycle_motion or self._far_start or self._occl_training or self.add_obs_noise or self._fut_tracks_dropout
-                                                  or self.collect_dataset or self.obs_v == 5 or flags.im_eval or flags.test)
+                                                  or self.collect_dataset or self.obs_v == 5 or self._hist_obs_cols or flags.im_eval or flags.test)
                     and type(self).step is HumanoidIm.step and type(self).reset_done is HumanoidIm.reset_done
                     and type(self).post_physics_step is HumanoidIm.post_physics_step and type(self).pre_physics_step is HumanoidIm.pre_physics_step)
 
@@ -858,6 +873,7 @@ class HumanoidIm:
         if self._far_start:
             torch.rand(self._offset_rand.shape, out=self._offset_rand)
         cur = self._amp_obs_buf
+        self._refresh_hist_obs()
         buf = self._buffers(cur, cur)
         L.check(self._lib.phc_im_reset(self._model_struct, self._motion_lib.struct, self._im_params, self._sim_struct, buf, n,
                                        env_ids.data_ptr(), abi.ptr(phase), int(bool(start_at_zero)), _stream()), "phc_im_reset")
@@ -877,6 +893,7 @@ class HumanoidIm:
         use_list = self._use_reset_list and self._reset_list_pending
         if self._far_start:
             torch.rand(self._offset_rand.shape, out=self._offset_rand)
+        self._refresh_hist_obs()
         buf = self._buffers(cur, cur)
         if not use_list:   # nothing appended since the last consumption (e.g. right after reset()): masked sweep over reset_buf
             buf.reset_list = None
@@ -884,6 +901,12 @@ class HumanoidIm:
                                             self._reset_seed, self._reset_counter + 1, int(bool(start_at_zero)), _stream()), "phc_im_reset_done")
         self._reset_done_host(use_list)
         self._obs_noise(reset_rows=True)
+
+    def _refresh_hist_obs(self):
+        """env.enableHistObs: the current AMP history (the one the launch about to be issued has not touched yet) into the trailing columns of
+        the self observation's per-env extra block."""
+        if self._hist_obs_cols:
+            self._self_obs_extra[:, -self._hist_obs_cols:].copy_(self._amp_obs_buf.reshape(self.num_envs, self._hist_obs_cols))
 
     def _one_hot_obs(self):
         """obs_v 5 (humanoid_im.py:812-815, motion_lib_base.py:214): the one-hot id of the env's clip among the library's unique motions behind the

@@ -110,6 +110,7 @@ class HumanoidImGetup(HumanoidIm):
             L.check(self._lib.phc_refresh_body_state_indexed(self._model_struct, self._sim_struct, n, ids.data_ptr(), _stream()),
                     "phc_refresh_body_state_indexed")
         cur = self._amp_obs_buf
+        self._refresh_hist_obs()
         L.check(self._lib.phc_im_reset_from_state(self._model_struct, self._motion_lib.struct, self._im_params, self._sim_struct,
                                                   self._buffers(cur, cur), n, ids.data_ptr(), int(fill_history), _stream()),
                 "phc_im_reset_from_state")

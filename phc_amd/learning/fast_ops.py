@@ -32,9 +32,7 @@ def _workspace(key, nbytes, device, dtype):
     if t is None or t.numel() < n:
         if t is not None:
             _ws_retired.append(t)
-        # zero-initialised: the column-sum / PPO-loss / square-sum workspaces hold ticket counters that must start at zero (the kernels leave
-        # them at zero)
-        t = torch.zeros(max(n, 1), dtype=dtype, device=device)
+        t = torch.empty(max(n, 1), dtype=dtype, device=device)
         _ws[(key, device)] = t
     return t
 

@@ -981,6 +981,41 @@ def test_fut_tracks_dropout_zeroes_a_tenth_of_the_reference_samples():
         flags.test = False
 
 
+def test_enable_hist_obs_appends_the_amp_history_as_it_stood_before_the_step():
+    """env.enableHistObs (humanoid_amp.py:98-101,327-328,546-557): `_compute_humanoid_obs` appends `_amp_obs_buf` (flattened, newest first) behind the
+    self observation.  post_physics_step (:193-204) forms the observation BEFORE `_update_hist_amp_obs`, and `_reset_envs` (:378-385) before
+    `_init_amp_obs`: the block is the history of the PREVIOUS step -- for a freshly reset env the finished episode's.  Checked against a task
+    without the switch stepped in lockstep."""
+    torch.manual_seed(0)
+    a = (torch.rand(64, 69, device="cuda") * 2 - 1) * 0.3
+    hist, env = make_task(64, motion="synthetic:3:1", **{"+env.enableHistObs": True})
+    plain, penv = make_task(64, motion="synthetic:3:1")
+    H = 1960
+    assert hist.get_self_obs_size() == 358 + H and hist.num_obs == 934 + H and not hist.whole_step_capturable()
+    torch.manual_seed(5); env.reset()
+    torch.manual_seed(5); penv.reset()
+    assert torch.equal(hist._root_states, plain._root_states)
+    seen_reset = False
+    for step in range(12):
+        before = plain._amp_obs_buf.reshape(64, H).clone()
+        obs, rew, done, _ = env.step(a)
+        pobs, prew, pdone, _ = penv.step(a)
+        assert torch.equal(done, pdone) and torch.equal(rew, prew)
+        assert torch.equal(obs[:, :358], pobs[:, :358]) and torch.equal(obs[:, 358 + H:], pobs[:, 358:])      # the kernel's own columns, task block moved back
+        assert torch.equal(obs[:, 358:358 + H], before)                                                     # the history the step started with
+        assert not torch.equal(before, plain._amp_obs_buf.reshape(64, H))
+        if bool(done.any()):
+            seen_reset = True
+            after_step = plain._amp_obs_buf.reshape(64, H).clone()
+            torch.manual_seed(100 + step); hist.reset_done()
+            torch.manual_seed(100 + step); plain.reset_done()
+            rows = done.bool()
+            assert torch.equal(hist.obs_buf[rows][:, 358:358 + H], after_step[rows])      # the finished episode's history, not the re-initialised one
+            assert torch.equal(hist.obs_buf[rows][:, :358], plain.obs_buf[rows][:, :358])
+            assert torch.equal(hist._amp_obs_buf, plain._amp_obs_buf)
+    assert seen_reset
+
+
 def test_obs_v4_v5_remove_disc_rot_and_action_noise_switches():
     """The remaining env switches of VERDICT r2 #9, each against what the reference's code does with it:
       * obs_v 4 (humanoid_im.py:496-501,713-722): with past_track_steps = 1 -- the only value its row stacking fits -- the observation IS the v6 one;
