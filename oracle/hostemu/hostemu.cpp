@@ -132,16 +132,19 @@ int emu_im_post_physics(const phc_model_t* model, const phc_motion_lib_t* lib, c
         const int64_t progress = buf->progress_buf[env] + 1;
         const ImStepCtx c = im_post_prologue(*lib, *prm, *sim, *buf, env, progress);
         const float prev_goal = (prm->zero_out_far && buf->point_goal) ? buf->point_goal[env] : 0.f;
-        for (int lane = 0; lane < PHC_MAX_BODIES; ++lane) amp_shift_lane(*prm, *buf, env, lane, PHC_MAX_BODIES);
         float s[6] = {0, 0, 0, 0, 0, 0};
         float root_dist = 0.f;
         int fallen = 0;
+        const FrameTab tab = frame_tab(*lib, motion_id_of(*buf, env));
+        const BodyState root = load_body(sim->rigid_body_state, env, model->num_bodies, 0);
         for (int lane = 0; lane < PHC_MAX_BODIES; ++lane) {
-            RewardPartial rp = im_post_lane(*model, *lib, *prm, *sim, *buf, env, lane, c);
+            const BodyState body = load_body(sim->rigid_body_state, env, model->num_bodies, lane < model->num_bodies ? lane : 0);
+            RewardPartial rp = im_post_lane(*model, *lib, *prm, *sim, *buf, env, lane, c, tab, body, root);
             s[0] += rp.pos; s[1] += rp.rot; s[2] += rp.vel; s[3] += rp.angvel; s[4] += rp.power; s[5] += rp.dist;
             if (lane == 0) root_dist = rp.root_dist;
             fallen |= rp.fallen;
         }
+        for (int lane = 0; lane < PHC_MAX_BODIES; ++lane) amp_shift_lane(*prm, *buf, env, lane, PHC_MAX_BODIES);   // (after the new frame, as the kernel)
         im_post_finalize(*lib, *prm, *buf, model->num_bodies, env, c, progress, s[0], s[1], s[2], s[3], s[4], s[5], root_dist, prev_goal,
                          fallen, prm->num_reset_bodies > 0 ? prm->num_reset_bodies : 1);
     }

@@ -202,7 +202,7 @@ PHC_HD Q4 rev_joint_quat(const AbaLane& L) { return quat_mul16(L.qrest, quat_fro
 // State load: S1 root_states [N,13], S2 dof_state [N,D,2] (spherical: exp-map triple + joint velocity; revolute: angle +
 // rate), S8 pd_target [N,D]
 template <int JT>
-PHC_HD void aba_load_state(AbaLane& L, const phc_sim_state_t& s, int nd, int64_t env, int j) {
+PHC_HD void aba_load_state(AbaLane& L, const phc_sim_state_t& s, int nd, int64_t env, int j, bool load_target = true) {
     if (j == 0) {
         const float* r = s.root_states + env * 13;
         L.p = v3(r[0], r[1], r[2]); L.q = quat_normalize(q4(r[3], r[4], r[5], r[6]));
@@ -214,13 +214,13 @@ PHC_HD void aba_load_state(AbaLane& L, const phc_sim_state_t& s, int nd, int64_t
         L.th = d[0]; L.thd = d[1];
         L.q = rev_joint_quat(L);
         L.wj = L.axis * L.thd;
-        L.target = v3(s.pd_target[env * nd + L.dof_start], 0.f, 0.f);
+        L.target = load_target ? v3(s.pd_target[env * nd + L.dof_start], 0.f, 0.f) : v3(0.f, 0.f, 0.f);
     } else {
         const float* d = s.dof_state + (env * nd + L.dof_start) * 2;
         L.q = quat_from_rotvec(v3(d[0], d[2], d[4]));
         L.wj = v3(d[1], d[3], d[5]);
         const float* t = s.pd_target + env * nd + L.dof_start;
-        L.target = v3(t[0], t[1], t[2]);
+        L.target = load_target ? v3(t[0], t[1], t[2]) : v3(0.f, 0.f, 0.f);
     }
 }
 

@@ -6,6 +6,21 @@
 
 namespace phc {
 
+#if defined(PHC_SIM_PROFILE) && defined(__HIPCC__)
+// one env's timeline through the post-physics kernel (scripts/probes/post_timeline.py; -DPHC_SIM_PROFILE library only).  Every stamp drains the
+// memory counters first: the deltas are the SERIALISED cost of each section.
+static __device__ unsigned long long g_phc_ptl[32];
+static __device__ long long g_phc_ptl_env = -1;
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PHC_PTL(i, ENV, LANE) if ((long long)(ENV) == g_phc_ptl_env) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0); \
+        const unsigned long long t_ = __builtin_readcyclecounter(); if ((LANE) == 0) g_phc_ptl[i] = t_; __builtin_amdgcn_sched_barrier(0); }
+#else
+#define PHC_PTL(i, ENV, LANE)
+#endif
+#else
+#define PHC_PTL(i, ENV, LANE)
+#endif
+
 // the env's clip: sampled_motion_ids[env], or the env's own index when the caller passes no table (one clip per env, humanoid_im.py:121
 // `_sampled_motion_ids = arange(num_envs)`: the table load is then one dependent memory round trip the lookup chain does not need)
 PHC_HD int64_t motion_id_of(const phc_im_buffers_t& buf, int64_t env) { return buf.sampled_motion_ids ? buf.sampled_motion_ids[env] : env; }
@@ -213,7 +228,8 @@ PHC_HD void task_obs_future_lane(const phc_motion_lib_t& lib, const phc_im_param
 // post_physics_step for lane (env, j); `progress` is the already incremented progress_buf value
 // (humanoid.py:1637).  Writes obs / AMP slices, returns the partials the caller reduces over the env.
 PHC_HD RewardPartial im_post_lane(const phc_model_t& model, const phc_motion_lib_t& lib, const phc_im_params_t& prm,
-                                  const phc_sim_state_t& sim, const phc_im_buffers_t& buf, int64_t env, int j, const ImStepCtx& c) {
+                                  const phc_sim_state_t& sim, const phc_im_buffers_t& buf, int64_t env, int j, const ImStepCtx& c,
+                                  const FrameTab& tab, const BodyState& body, const BodyState& root) {
     const int nb = model.num_bodies, nd = model.num_dof;
     RewardPartial rp;
     rp.pos = rp.rot = rp.vel = rp.angvel = rp.power = rp.dist = rp.root_dist = 0.f; rp.fallen = 0;
@@ -237,10 +253,30 @@ PHC_HD RewardPartial im_post_lane(const phc_model_t& model, const phc_motion_lib
         rp.rot = ang * ang;
         return rp;
     }
-    const FrameRef fr0 = frame_ref(lib, mid, c.t0), fr1 = frame_ref(lib, mid, c.t1);
-    BodyState body = load_body(sim.rigid_body_state, env, nb, j);
-    BodyState root = load_body(sim.rigid_body_state, env, nb, 0);
-    BodyState r0 = ref_body(lib, fr0, j), r1 = ref_body(lib, fr1, j);
+    const FrameRef fr0 = frame_ref(tab, c.t0), fr1 = frame_ref(tab, c.t1);
+    PHC_PTL(3, env, j)
+    // Order of work (round 3, profiles/r03_task/post_physics_timeline.txt): the two frame-record pairs are REQUESTED first, then everything that
+    // needs the simulator state only -- self observation, AMP frame -- is computed and stored while they are on their way, then the blends,
+    // the reward partials and the task observation.
+    const BodyRaw q0 = ref_body_raw(lib, fr0, j), q1 = ref_body_raw(lib, fr1, j);
+    JointPosRaw qj;
+    const bool want_dof = buf.ref_dof_pos != nullptr && j >= 1;
+    if (want_dof) qj = ref_joint_pos_raw(lib, fr1, j);
+    PHC_PTL(4, env, j)
+    // observations for the next policy step (humanoid_im.py:694-726)
+    const Q4 hroot = obs_root_rot(prm, root.rot);
+    Q4 hinv = calc_heading_quat_inv(hroot), h = calc_heading_quat(hroot);
+    float* obs = buf.obs_buf + env * (int64_t)(prm.num_self_obs + prm.num_task_obs);
+    if (prm.self_obs_v == 2 && buf.body_state_hist) self_obs_v2_lane(prm, buf.body_state_hist, nb, env, j, body, root, hinv, obs, true, false);
+    else self_obs_lane(prm, nb, j, body, root, hinv, obs, (sim.force_sensor && prm.self_obs_v == 3) ? sim.force_sensor + env * (int64_t)(prm.num_force_sensors * 6) : nullptr, env);
+    PHC_PTL(6, env, j)
+    // AMP observation of this step -> slot 0 of the new history (humanoid_amp.py:204-209)
+    {
+        float* amp = buf.amp_obs_out + env * amp_env_stride(prm, buf);
+        amp_obs_from_sim_lane(prm, sim, nb, nd, env, j, root, hinv, model.ints + 4 + 3 * PHC_MAX_BODIES, amp);
+    }
+    PHC_PTL(9, env, j)
+    BodyState r0 = ref_body_blend(q0, fr0.blend), r1 = ref_body_blend(q1, fr1.blend);
     r0.pos += c.goff; r1.pos += c.goff;  // motion_lib_base.py:476
     // R1 / R5 partials
     rp = reward_partial(prm, env, nb, j, body, r0);
@@ -263,12 +299,7 @@ PHC_HD RewardPartial im_post_lane(const phc_model_t& model, const phc_motion_lib
         rp.power = fabsf(f[0] * d[1]);
         if (prm.dofs_per_joint != 1) rp.power += fabsf(f[1] * d[3]) + fabsf(f[2] * d[5]);
     }
-    // observations for the next policy step (humanoid_im.py:694-726)
-    const Q4 hroot = obs_root_rot(prm, root.rot);
-    Q4 hinv = calc_heading_quat_inv(hroot), h = calc_heading_quat(hroot);
-    float* obs = buf.obs_buf + env * (int64_t)(prm.num_self_obs + prm.num_task_obs);
-    if (prm.self_obs_v == 2 && buf.body_state_hist) self_obs_v2_lane(prm, buf.body_state_hist, nb, env, j, body, root, hinv, obs, true, false);
-    else self_obs_lane(prm, nb, j, body, root, hinv, obs, (sim.force_sensor && prm.self_obs_v == 3) ? sim.force_sensor + env * (int64_t)(prm.num_force_sensors * 6) : nullptr, env);
+    PHC_PTL(5, env, j)
     int slot = prm.track_slot[j];
     if (slot >= 0) {
         BodyState rt = r1;
@@ -286,18 +317,14 @@ PHC_HD RewardPartial im_post_lane(const phc_model_t& model, const phc_motion_lib
         }
         task_obs_lane(prm, slot, body, root, rt, hinv, h, obs + prm.num_self_obs, &jd, &rjd);
     }
+    PHC_PTL(7, env, j)
     // side-effect buffers of _compute_task_obs (humanoid_im.py:855-868)
     if (buf.ref_body_pos) st3(buf.ref_body_pos + (env * nb + j) * 3, r1.pos);
     if (buf.ref_body_rot) st4(buf.ref_body_rot + (env * nb + j) * 4, r1.rot);
     if (buf.ref_body_vel) st3(buf.ref_body_vel + (env * nb + j) * 3, r1.vel);
-    if (buf.ref_dof_pos && j >= 1) {
-        V3 dp, dv;
-        ref_joint(lib, fr1, j, &dp, &dv);
-        st_joint(buf.ref_dof_pos + env * nd + model.ints[4 + 3 * PHC_MAX_BODIES + j], prm.dofs_per_joint, dp);
-    }
-    // AMP observation of this step -> slot 0 of the new history (humanoid_amp.py:204-209)
-    float* amp = buf.amp_obs_out + env * amp_env_stride(prm, buf);
-    amp_obs_from_sim_lane(prm, sim, nb, nd, env, j, root, hinv, model.ints + 4 + 3 * PHC_MAX_BODIES, amp);
+    if (want_dof)
+        st_joint(buf.ref_dof_pos + env * nd + model.ints[4 + 3 * PHC_MAX_BODIES + j], prm.dofs_per_joint, ref_joint_pos_blend(lib, qj, fr1.blend));
+    PHC_PTL(8, env, j)
     if (prm.num_traj_samples > 1)   // env.fut_tracks: the further reference samples' blocks (see task_obs_future_lane)
         task_obs_future_lane(lib, prm, mid, c.progress + 1, c.start, c.start_off, c.goff, prm.track_slot[j], j, load_body(sim.rigid_body_state, env, nb, j),
                              load_body(sim.rigid_body_state, env, nb, 0), buf.obs_buf + env * (int64_t)(prm.num_self_obs + prm.num_task_obs) + prm.num_self_obs);

@@ -11,16 +11,26 @@
 
 using namespace phc;
 
+// Sum / or over the G lanes of an env's group, result in every lane.  Inside a row of 16 lanes the butterfly runs on DPP operands (quad_perm xor 1,
+// xor 2, row_half_mirror, row_mirror: folded into the add, ~4 cycles each); only the steps across rows are ds_bpermute round trips (~64 cycles
+// each, round 3: seven sums x five dependent permutes were 1.8 k cycles of the post-physics wavefront's 38 k).
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
 template <int G>
 __device__ __forceinline__ float group_sum(float v) {
+    v += __int_as_float(dpp_i<0xB1>(__float_as_int(v)));    // quad_perm:[1,0,3,2]
+    v += __int_as_float(dpp_i<0x4E>(__float_as_int(v)));    // quad_perm:[2,3,0,1]
+    v += __int_as_float(dpp_i<0x141>(__float_as_int(v)));   // row_half_mirror
+    v += __int_as_float(dpp_i<0x140>(__float_as_int(v)));   // row_mirror
 #pragma unroll
-    for (int m = G / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, G);
+    for (int m = 16; m < G; m <<= 1) v += __shfl_xor(v, m, G);
     return v;
 }
 template <int G>
 __device__ __forceinline__ int group_or(int v) {
+    v |= dpp_i<0xB1>(v); v |= dpp_i<0x4E>(v); v |= dpp_i<0x141>(v); v |= dpp_i<0x140>(v);
 #pragma unroll
-    for (int m = G / 2; m >= 1; m >>= 1) v |= __shfl_xor(v, m, G);
+    for (int m = 16; m < G; m <<= 1) v |= __shfl_xor(v, m, G);
     return v;
 }
 
@@ -42,19 +52,39 @@ __global__ __launch_bounds__(256) void k_im_post_physics(phc_model_t model, phc_
     const int lane = threadIdx.x & (G - 1);
     const int64_t env = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
     if (env >= sim.num_envs) return;  // whole lane group exits together
+    PHC_PTL(0, env, lane)
     if (blockIdx.x == 0 && threadIdx.x == 0 && buf.reset_rng_counter) *buf.reset_rng_counter += 1;   // (one writer; no reset launch runs concurrently)
+    // Everything the launch reads that does not depend on something else it reads is REQUESTED here, before the first wait: the clip's table
+    // entries, the body's and the root's state, the per-env scalars of the prologue (a wavefront waits for a load at its first use; this
+    // kernel's wavefronts spend three quarters of their life waiting, profiles/r03_task/post_physics_timeline.txt)
     const int64_t progress = buf.progress_buf[env] + 1;  // humanoid.py:1637
+    const FrameTab tab = frame_tab(lib, motion_id_of(buf, env));
+    const int jb = lane < model.num_bodies ? lane : 0;
+    const BodyState body = load_body(sim.rigid_body_state, env, model.num_bodies, jb);
+    const BodyState root = load_body(sim.rigid_body_state, env, model.num_bodies, 0);
     const ImStepCtx c = im_post_prologue(lib, prm, sim, buf, env, progress);
     const float prev_goal = (prm.zero_out_far && buf.point_goal) ? buf.point_goal[env] : 0.f;  // read before lane 0 overwrites it
-    amp_shift_lane(prm, buf, env, lane, G);
-    RewardPartial rp = im_post_lane(model, lib, prm, sim, buf, env, lane, c);
+    PHC_PTL(1, env, lane)
+    RewardPartial rp = im_post_lane(model, lib, prm, sim, buf, env, lane, c, tab, body, root);
+    PHC_PTL(2, env, lane)
+    amp_shift_lane(prm, buf, env, lane, G);   // (every S-th step; reads the old window, writes rows 1.. of the new one: after the frame in row 0)
     float s_pos = group_sum<G>(rp.pos), s_rot = group_sum<G>(rp.rot), s_vel = group_sum<G>(rp.vel), s_ang = group_sum<G>(rp.angvel);
     float s_pow = group_sum<G>(rp.power), s_dist = group_sum<G>(rp.dist);
     int fallen = group_or<G>(rp.fallen);
+    PHC_PTL(10, env, lane)
     if (lane == 0)
         im_post_finalize(lib, prm, buf, model.num_bodies, env, c, progress, s_pos, s_rot, s_vel, s_ang, s_pow, s_dist, rp.root_dist,
                          prev_goal, fallen, n_reset_bodies);
+    PHC_PTL(11, env, lane)
 }
+#ifdef PHC_SIM_PROFILE
+extern "C" int32_t phc_debug_post_timeline(unsigned long long* out32, long long env) {
+    if (out32 && hipMemcpyFromSymbol(out32, HIP_SYMBOL(phc::g_phc_ptl), sizeof(unsigned long long) * 32) != hipSuccess) return -1;
+    unsigned long long z[32] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(phc::g_phc_ptl), z, sizeof(z)) != hipSuccess) return -1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(phc::g_phc_ptl_env), &env, sizeof(env)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 // HumanoidImGetup fall / recovery resets: one lane group per listed env (state kept, see im_reset_from_state_lane).
 template <int G>

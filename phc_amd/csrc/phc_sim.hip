@@ -161,13 +161,19 @@ __global__ __launch_bounds__(64, 2) void k_sim_step(phc_model_t model_all, phc_s
     if (active) {
         aba_load_model(L, model, body);
         if (JT == PHC_JT_REVOLUTE) aba_load_model_rev(L, model, body);
-        if (STEP && actions != nullptr && body >= 1) {
+        // (the state is requested BEFORE the new PD targets are stored: no load of this prologue has to wait behind a store, and the targets go
+        //  into the lane's registers directly instead of through memory)
+        const bool new_targets = STEP && actions != nullptr && body >= 1;
+        aba_load_state<JT>(L, sim, nd, env, body, !new_targets);
+        if (new_targets) {
+            float tg[3] = {0.f, 0.f, 0.f};
             for (int k = 0; k < (JT == PHC_JT_REVOLUTE ? 1 : 3); ++k) {
                 const int d = L.dof_start + k;
-                sim.pd_target[env * nd + d] = pd_target_of(sim, actions, pd_off, pd_scale, freeze, env, nd, d);
+                tg[k] = pd_target_of(sim, actions, pd_off, pd_scale, freeze, env, nd, d);
+                sim.pd_target[env * nd + d] = tg[k];
             }
+            L.target = v3(tg[0], tg[1], tg[2]);
         }
-        aba_load_state<JT>(L, sim, nd, env, body);
     }
     const int max_level = model.max_level;
     if (!PHC_SKIP(8)) for (int l = 0; l <= max_level; ++l) { aba_fk_level(L, l, body, x); __syncthreads(); }

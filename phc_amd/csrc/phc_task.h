@@ -36,13 +36,22 @@ struct FrameRef { int64_t f0, f1; float blend; int64_t idx0, idx1; };
 
 // M8 _calc_frame_blend (motion_lib_base.py:549-559) + the length_starts offset (:447-448).
 // Index arithmetic is the bit-exact part of the contract: no fma contraction in here.
-PHC_HD FrameRef frame_ref(const phc_motion_lib_t& lib, int64_t mid, float time) {
-    PHC_NO_CONTRACT
-    float len = lib.motion_lengths[mid];
-    float dt = lib.motion_dt[mid];
+// (the clip's table entries are loaded separately from the arithmetic, so that a kernel can request them at its very top)
+struct FrameTab { float len, dt; int nf; int64_t start; };
+PHC_HD FrameTab frame_tab(const phc_motion_lib_t& lib, int64_t mid) {
+    FrameTab t;
+    t.len = lib.motion_lengths[mid];
+    t.dt = lib.motion_dt[mid];
     // frame counts are far below 2^24, so 32-bit integers and their float conversions give the same values as torch's int64
     // arithmetic (the 64-bit conversions cost ~10 instructions each on the device)
-    const int nf = (int)lib.motion_num_frames[mid];
+    t.nf = (int)lib.motion_num_frames[mid];
+    t.start = lib.length_starts[mid];
+    return t;
+}
+PHC_HD FrameRef frame_ref(const FrameTab& tab, float time) {
+    PHC_NO_CONTRACT
+    const float len = tab.len, dt = tab.dt;
+    const int nf = tab.nf;
     float phase = time / len;
     phase = fminf(fmaxf(phase, 0.0f), 1.0f);  // torch.clip
     if (time < 0.f) time = 0.f;
@@ -56,11 +65,11 @@ PHC_HD FrameRef frame_ref(const phc_motion_lib_t& lib, int64_t mid, float time) 
     float sub = (float)i0 * dt;
     float bl = (time - sub) / dt;
     r.blend = fminf(fmaxf(bl, 0.0f), 1.0f);
-    int64_t start = lib.length_starts[mid];
-    r.f0 = r.idx0 + start;
-    r.f1 = r.idx1 + start;
+    r.f0 = r.idx0 + tab.start;
+    r.f1 = r.idx1 + tab.start;
     return r;
 }
+PHC_HD FrameRef frame_ref(const phc_motion_lib_t& lib, int64_t mid, float time) { return frame_ref(frame_tab(lib, mid), time); }
 
 // M7 sample_time_interval (motion_lib_base.py:414-423)
 PHC_HD float sample_time_interval(const phc_motion_lib_t& lib, int64_t mid, float phase) {
@@ -119,6 +128,27 @@ PHC_HD BodyState ref_body(const phc_motion_lib_t& lib, const FrameRef& fr, int j
     s.rot = slerp(ld4(a + fr_rot(lib) + 4 * j), ld4(b + fr_rot(lib) + 4 * j), fr.blend);
     return s;
 }
+// The same in two halves: the LOADS of body j's two frame records, and the blend.  A caller that has independent work puts it between the two, so that
+// the records' memory latency is covered (a wavefront issues in order: a load's value is waited for at its first use, not at the load).
+struct BodyRaw { V3 pa, pb, va, vb, wa, wb; Q4 ra, rb; };
+PHC_HD BodyRaw ref_body_raw(const phc_motion_lib_t& lib, const FrameRef& fr, int j) {
+    const float* a = lib.frames + fr.f0 * (int64_t)lib.frame_stride;
+    const float* b = lib.frames + fr.f1 * (int64_t)lib.frame_stride;
+    BodyRaw q;
+    q.pa = ld3(a + fr_pos(lib) + 3 * j); q.pb = ld3(b + fr_pos(lib) + 3 * j);
+    q.va = ld3(a + fr_vel(lib) + 3 * j); q.vb = ld3(b + fr_vel(lib) + 3 * j);
+    q.wa = ld3(a + fr_angvel(lib) + 3 * j); q.wb = ld3(b + fr_angvel(lib) + 3 * j);
+    q.ra = ld4(a + fr_rot(lib) + 4 * j); q.rb = ld4(b + fr_rot(lib) + 4 * j);
+    return q;
+}
+PHC_HD BodyState ref_body_blend(const BodyRaw& q, float blend) {
+    BodyState s;
+    s.pos = lerp3(q.pa, q.pb, blend);
+    s.vel = lerp3(q.va, q.vb, blend);
+    s.angvel = lerp3(q.wa, q.wb, blend);
+    s.rot = slerp(q.ra, q.rb, blend);
+    return s;
+}
 // extended reference body e (record slot NB+e): position and rotation only (rg_pos_t / rg_rot_t, motion_lib_real.py:300-312)
 PHC_HD void ref_body_ext(const phc_motion_lib_t& lib, const FrameRef& fr, int e, V3* pos, Q4* rot) {
     const int j = lib.num_bodies + e;
@@ -147,6 +177,20 @@ PHC_HD void ref_joint(const phc_motion_lib_t& lib, const FrameRef& fr, int j, V3
     Q4 lr = slerp(ld4(a + fr_lrot(lib) + 4 * j), ld4(b + fr_lrot(lib) + 4 * j), fr.blend);
     *dof_pos = quat_to_exp_map(lr);
     *dof_vel = lerp3(ld3(a + fr_dvel(lib) + 3 * (j - 1)), ld3(b + fr_dvel(lib) + 3 * (j - 1)), fr.blend);
+}
+// dof_pos alone, in the same two halves as ref_body_raw / ref_body_blend
+struct JointPosRaw { Q4 la, lb; };   // spherical: the two local rotations; revolute: the two angles in la.x / lb.x
+PHC_HD JointPosRaw ref_joint_pos_raw(const phc_motion_lib_t& lib, const FrameRef& fr, int j) {
+    const float* a = lib.frames + fr.f0 * (int64_t)lib.frame_stride;
+    const float* b = lib.frames + fr.f1 * (int64_t)lib.frame_stride;
+    JointPosRaw q;
+    if (lib.dofs_per_joint == 1) { q.la = q4(a[fr_lrot(lib) + j - 1], 0.f, 0.f, 1.f); q.lb = q4(b[fr_lrot(lib) + j - 1], 0.f, 0.f, 1.f); }
+    else { q.la = ld4(a + fr_lrot(lib) + 4 * j); q.lb = ld4(b + fr_lrot(lib) + 4 * j); }
+    return q;
+}
+PHC_HD V3 ref_joint_pos_blend(const phc_motion_lib_t& lib, const JointPosRaw& q, float blend) {
+    if (lib.dofs_per_joint == 1) return v3((1.0f - blend) * q.la.x + blend * q.lb.x, 0.f, 0.f);
+    return quat_to_exp_map(slerp(q.la, q.lb, blend));
 }
 // Spherical joint of body j >= 1 for the AMP observation of a REFERENCE frame (humanoid_amp.py:575-603,253-284): the reference goes
 // local rotation -> slerp -> quat_to_exp_map (dof_pos, motion_lib_base.py:483-484) -> exp_map_to_quat -> tan_norm (dof_to_obs_smpl,
