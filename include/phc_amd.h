@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PHC_ABI_VERSION 32
+#define PHC_ABI_VERSION 33
 #define PHC_MAX_BODIES 64   /* bodies (incl. extended reference bodies) per articulation; also the slot count of the model tables */
 #define PHC_EINVAL (-1)
 #define PHC_EUNSUPPORTED (-2)
@@ -194,6 +194,14 @@ typedef struct {
     const float* amp_obs_extra;       /* [N, num_amp_obs_extra] row of the env (observations from simulator state) or of the MOTION (observations
                                          built from the reference clip: the clip carries its humanoid's shape, motion_lib_base.py:244,
                                          humanoid_amp.py:253-284,575-603) -- the same row, clip i belongs to env i */
+    const float* amp_ref_table;       /* [F, num_amp_obs_per_step - num_amp_obs_extra] (nullable; ABI 33): the AMP observation of every frame of the motion
+                                         library (build_amp_observations of the frame itself), written by phc_amp_ref_table.  With it a reset fills an
+                                         env's AMP history from S consecutive ROWS instead of S lookups + observation builds: start times are multiples
+                                         of 1/30 s (sample_time_interval) and the history steps back by dt, so on 30 fps clips stepped at dt = k/30 every
+                                         history time falls on a frame up to fp32 rounding of the blend factor: exactly 0 for ~5 lookups in 6 (the row IS
+                                         the full build then, bit for bit), below 1e-4 for most others (first-order blend with the next row, error
+                                         ~1e-6); lookups with any other blend factor (a few % land just below the next frame) are built in full.
+                                         NULL: every history frame is looked up and built (robots at 50 Hz). */
 } phc_im_params_t;
 
 /* Task-owned per-env buffers (phc/env/tasks/base_task.py:99-105, humanoid_amp.py:109-116,
@@ -283,6 +291,13 @@ int32_t phc_refresh_body_state_indexed(const phc_model_t* model, const phc_sim_s
  * imitation + power reward, reset / terminate, self obs, task obs v6, AMP obs + history shift. */
 int32_t phc_im_post_physics(const phc_model_t* model, const phc_motion_lib_t* lib, const phc_im_params_t* prm,
                             const phc_sim_state_t* sim, const phc_im_buffers_t* buf, void* stream);
+
+/* phc_im_params_t.amp_ref_table: row f = AMP observation (without the per-env extra columns) of the lookup (f0 = f, f1 = next_frame[f], blend 0), i.e.
+ * of a time that falls on frame f of its clip; next_frame[f] = f + 1, or f at the last frame of a clip (the pair matters even at blend 0: the
+ * reference's slerp returns the MEAN of two nearly equal rotations whatever the blend factor, isaacgym torch_utils slerp).
+ * Rebuild after every (re)load of the motion library and whenever prm's AMP options change. */
+int32_t phc_amp_ref_table(const phc_model_t* model, const phc_motion_lib_t* lib, const phc_im_params_t* prm, int64_t num_frames,
+                          const int64_t* next_frame /*[num_frames]*/, float* table /*[num_frames, A - extra]*/, void* stream);
 
 /* Humanoid.reset(env_ids) -> _reset_envs (humanoid.py:585-621, humanoid_amp.py:378-398,508-528,559-637,
  * humanoid_im.py:955-1023): per listed env sample a start time from `phase`, impose the reference

@@ -65,7 +65,7 @@ class ImParams(C.Structure):
                 ("self_obs_v", c_i32), ("num_force_sensors", c_i32), ("amp_obs_v", c_i32),
                 ("remove_base_rot", c_i32), ("num_self_obs_extra", c_i32), ("num_amp_obs_extra", c_i32),
                 ("num_traj_samples", c_i32), ("traj_sample_timestep", c_f), ("track_body_reward", c_i32), ("num_self_obs_hist", c_i32), ("zero_out_far_train", c_i32), ("zero_out_far_steps", c_i32), ("cycle_motion_xp", c_i32),
-                ("self_obs_extra", c_p), ("amp_obs_extra", c_p)]
+                ("self_obs_extra", c_p), ("amp_obs_extra", c_p), ("amp_ref_table", c_p)]
 
 
 class ImBuffers(C.Structure):
@@ -89,6 +89,7 @@ _SIGNATURES = {
     "phc_sim_step": ([P(Model), P(SimParams), P(SimState), c_p, c_p, c_p, c_p, c_i32, c_p], c_i32),
     "phc_refresh_body_state": ([P(Model), P(SimState), c_p], c_i32),
     "phc_im_post_physics": ([P(Model), P(MotionLib), P(ImParams), P(SimState), P(ImBuffers), c_p], c_i32),
+    "phc_amp_ref_table": ([P(Model), P(MotionLib), P(ImParams), c_i64, c_p, c_p, c_p], c_i32),
     "phc_im_reset": ([P(Model), P(MotionLib), P(ImParams), P(SimState), P(ImBuffers), c_i32, c_p, c_p, c_i32, c_p], c_i32),
     "phc_im_reset_done": ([P(Model), P(MotionLib), P(ImParams), P(SimState), P(ImBuffers), C.c_uint64, C.c_uint64, c_i32, c_p], c_i32),
     "phc_im_reset_from_state": ([P(Model), P(MotionLib), P(ImParams), P(SimState), P(ImBuffers), c_i32, c_p, c_i32, c_p], c_i32),
@@ -133,7 +134,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the .so does not export the symbol
         fn.argtypes = argtypes
         fn.restype = restype
-    if lib.phc_abi_version() != 32:
+    if lib.phc_abi_version() != 33:
         raise ImportError("libphc_amd.so ABI version mismatch")
     _lib = lib
     return lib

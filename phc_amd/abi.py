@@ -123,7 +123,7 @@ def im_params_struct(dt, max_episode_length, reward_specs, power_reward, power_c
                      cycle_motion=False, zero_out_far=False, close_distance=0.25, far_distance=3.0,
                      dofs_per_joint=3, ext_parent=None, ext_offset=None, obs_v=6, self_obs_v=1, num_force_sensors=0, amp_obs_v=1,
                      remove_base_rot=False, self_obs_extra=None, amp_obs_extra=None, zero_out_far_train=False, zero_out_far_steps=90,
-                     cycle_motion_xp=False, num_self_obs_hist=0, track_body_reward=False, num_traj_samples=1, traj_sample_timestep=1 / 30):
+                     cycle_motion_xp=False, num_self_obs_hist=0, track_body_reward=False, num_traj_samples=1, traj_sample_timestep=1 / 30, amp_ref_table=None):
     """`self_obs_extra` / `amp_obs_extra`: fp32 [N, E] per-env constant observation columns (shape parameters, limb weights) or None."""
     p = L.ImParams()
     p.remove_base_rot = int(bool(remove_base_rot))
@@ -134,6 +134,7 @@ def im_params_struct(dt, max_episode_length, reward_specs, power_reward, power_c
     p.num_self_obs_extra = 0 if self_obs_extra is None else int(self_obs_extra.shape[1])
     p.num_amp_obs_extra = 0 if amp_obs_extra is None else int(amp_obs_extra.shape[1])
     p.self_obs_extra, p.amp_obs_extra = ptr(self_obs_extra), ptr(amp_obs_extra)
+    p.amp_ref_table = ptr(amp_ref_table)
     p.amp_obs_v = int(amp_obs_v)
     p.obs_v = int(obs_v)
     p.self_obs_v, p.num_force_sensors = int(self_obs_v), int(num_force_sensors)

@@ -40,13 +40,17 @@ PHC_HD int phc_atomic_inc(int32_t* p) {
 // AMP observation of one time step computed from the *reference motion* (no offset):
 // HumanoidAMP._init_amp_obs_ref / build_amp_obs_demo (humanoid_amp.py:575-603,253-284).
 // Lane j writes its slices of a[0..A).
+// (the part that depends on the frame pair only -- also what phc_amp_ref_table tabulates per frame, with f0 = f1 = f and blend 0)
+PHC_HD void amp_obs_from_frames_lane(const phc_motion_lib_t& lib, const phc_im_params_t& prm, int nb, int j, const FrameRef& fr, float* a);
 PHC_HD void amp_obs_from_ref_lane(const phc_motion_lib_t& lib, const phc_im_params_t& prm, int nb, int j,
                                   int64_t mid, float t, float* a) {
-    FrameRef fr = frame_ref(lib, mid, t);
-    BodyState root = ref_body(lib, fr, 0);
-    Q4 hinv = calc_heading_quat_inv(obs_root_rot(prm, root.rot));
     if (j < nb && prm.num_amp_obs_extra > 0 && prm.amp_obs_extra)   // the clip's humanoid (motion id == env id)
         obs_extra_lane(prm.amp_obs_extra + mid * prm.num_amp_obs_extra, prm.num_amp_obs_extra, j, nb, a + prm.num_amp_obs_per_step - prm.num_amp_obs_extra);
+    amp_obs_from_frames_lane(lib, prm, nb, j, frame_ref(lib, mid, t), a);
+}
+PHC_HD void amp_obs_from_frames_lane(const phc_motion_lib_t& lib, const phc_im_params_t& prm, int nb, int j, const FrameRef& fr, float* a) {
+    BodyState root = ref_body(lib, fr, 0);
+    Q4 hinv = calc_heading_quat_inv(obs_root_rot(prm, root.rot));
     if (j == 0) amp_obs_root(prm, root.pos, root.rot, root.vel, root.angvel, hinv, a);
     if (j >= 1 && j < nb) {
         int slot = prm.amp_joint_slot[j];
@@ -569,6 +573,35 @@ PHC_HD void im_reset_amp_lane(const phc_motion_lib_t& lib, const phc_im_params_t
     const int A = prm.num_amp_obs_per_step;
     float* amp = buf.amp_obs_out + env * amp_env_stride(prm, buf);
     amp_obs_from_ref_lane(lib, prm, nb, j, motion_id_of(buf, env), history_time(t, prm.dt, k), amp + k * A);
+}
+// The same from the per-frame table (phc_im_params_t.amp_ref_table, row f = the build for the pair (f, f + 1) at blend 0): the history times of a reset
+// fall on frames of the clip up to the rounding of the blend factor b -- exactly 0 for ~5 lookups in 6: the row is then the full build bit for bit --
+// so for b <= PHC_AMP_TABLE_BLEND_TOL frame k's observation is (1 - b) T[f0] + b T[f1] (first-order; error ~1e-6); any other lookup (a few % land
+// just BELOW the next frame, b ~ 1: the reference's slerp then still averages the previous pair, which row f1 does not hold) is built in full.
+// `nl` lanes.  All loads of a chunk are requested before its stores.
+#define PHC_AMP_TABLE_BLEND_TOL 1e-4f
+PHC_HD void amp_obs_from_table_lane(const phc_motion_lib_t& lib, const phc_im_params_t& prm, int nb, int j, int nl, int64_t mid, float t, float* a) {
+    const int A = prm.num_amp_obs_per_step, E = prm.num_amp_obs_extra, W = A - E;
+    const FrameRef fr = frame_ref(lib, mid, t);
+    const float b = fr.blend;
+    if (j < nb && E > 0 && prm.amp_obs_extra) obs_extra_lane(prm.amp_obs_extra + mid * E, E, j, nb, a + W);
+    if (!(b <= PHC_AMP_TABLE_BLEND_TOL)) {
+        amp_obs_from_frames_lane(lib, prm, nb, j, fr, a);
+        return;
+    }
+    const float* r0 = prm.amp_ref_table + fr.f0 * (int64_t)W;
+    const float* r1 = prm.amp_ref_table + fr.f1 * (int64_t)W;
+    const float s0 = 1.0f - b;
+    for (int c0 = j; c0 < W; c0 += 8 * nl) {
+        float u[8], v[8];
+        for (int i = 0; i < 8; ++i) { const int c = c0 + i * nl; if (c < W) { u[i] = r0[c]; v[i] = r1[c]; } }
+        for (int i = 0; i < 8; ++i) { const int c = c0 + i * nl; if (c < W) a[c] = s0 * u[i] + b * v[i]; }
+    }
+}
+PHC_HD void im_reset_amp_table_lane(const phc_motion_lib_t& lib, const phc_im_params_t& prm, const phc_im_buffers_t& buf, int nb,
+                                    int64_t env, int j, int nl, float t, int k) {
+    amp_obs_from_table_lane(lib, prm, nb, j, nl, motion_id_of(buf, env), history_time(t, prm.dt, k),
+                            buf.amp_obs_out + env * amp_env_stride(prm, buf) + k * prm.num_amp_obs_per_step);
 }
 
 }  // namespace phc

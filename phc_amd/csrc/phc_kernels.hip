@@ -86,6 +86,19 @@ extern "C" int32_t phc_debug_post_timeline(unsigned long long* out32, long long 
 }
 #endif
 
+// phc_amp_ref_table: one lane group per frame of the library.
+template <int DPJ, int G>
+__global__ __launch_bounds__(256) void k_amp_ref_table(phc_model_t model, phc_motion_lib_t lib, phc_im_params_t prm, int64_t num_frames,
+                                                       const int64_t* __restrict__ next_frame, float* __restrict__ table) {
+    pin_family<DPJ>(lib, prm);
+    const int lane = threadIdx.x & (G - 1);
+    const int64_t f = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+    if (f >= num_frames) return;
+    FrameRef fr;
+    fr.f0 = f; fr.f1 = next_frame[f]; fr.idx0 = fr.idx1 = 0; fr.blend = 0.f;
+    amp_obs_from_frames_lane(lib, prm, model.num_bodies, lane, fr, table + f * (int64_t)(prm.num_amp_obs_per_step - prm.num_amp_obs_extra));
+}
+
 // HumanoidImGetup fall / recovery resets: one lane group per listed env (state kept, see im_reset_from_state_lane).
 template <int G>
 __global__ __launch_bounds__(256) void k_im_reset_from_state(phc_model_t model, phc_motion_lib_t lib, phc_im_params_t prm, phc_sim_state_t sim,
@@ -175,7 +188,10 @@ __global__ __launch_bounds__(256) void k_im_reset(phc_model_t model, phc_motion_
     PHC_RTL(2)
     if (k < 2) im_reset_lane(model, lib, prm, sim, buf, env, lane, t, env_ids != nullptr, 1 << k);
     PHC_RTL(3)
-    if (k >= 2) im_reset_amp_lane(lib, prm, buf, model.num_bodies, env, lane, t, k - 2);
+    if (k >= 2) {
+        if (prm.amp_ref_table != nullptr) im_reset_amp_table_lane(lib, prm, buf, model.num_bodies, env, lane, G, t, k - 2);
+        else im_reset_amp_lane(lib, prm, buf, model.num_bodies, env, lane, t, k - 2);
+    }
     PHC_RTL(4)
 }
 
@@ -189,7 +205,9 @@ __global__ __launch_bounds__(256) void k_amp_obs_demo(phc_model_t model, phc_mot
     const int k = (int)blockIdx.y;
     const int S = prm.num_amp_obs_steps, A = prm.num_amp_obs_per_step;
     if (i >= n) return;
-    amp_obs_from_ref_lane(lib, prm, model.num_bodies, lane, motion_ids[i], history_time(times0[i], prm.dt, k), out + (i * S + k) * A);
+    // (demo start times are multiples of 1/30 s too -- sample_time_interval, humanoid_amp.py:262 -- : the per-frame table serves them as it serves resets)
+    if (prm.amp_ref_table != nullptr) amp_obs_from_table_lane(lib, prm, model.num_bodies, lane, G, motion_ids[i], history_time(times0[i], prm.dt, k), out + (i * S + k) * A);
+    else amp_obs_from_ref_lane(lib, prm, model.num_bodies, lane, motion_ids[i], history_time(times0[i], prm.dt, k), out + (i * S + k) * A);
 }
 
 // M9 standalone: get_motion_state for n (id, time) pairs.  One lane group per lookup.
@@ -360,6 +378,22 @@ int32_t phc_im_post_physics(const phc_model_t* model, const phc_motion_lib_t* li
     if (prm->dofs_per_joint == 1) { if (g == 64) PHC_POST(1, 64); else PHC_POST(1, 32); }
     else { if (g == 64) PHC_POST(3, 64); else PHC_POST(3, 32); }
 #undef PHC_POST
+    return launch_status();
+}
+
+int32_t phc_amp_ref_table(const phc_model_t* model, const phc_motion_lib_t* lib, const phc_im_params_t* prm, int64_t num_frames,
+                          const int64_t* next_frame, float* table, void* stream) {
+    int32_t rc = check_im(model, lib, prm);
+    if (rc) return rc;
+    if (!table || !next_frame || num_frames < 0 || num_frames > lib->num_frames_total) return PHC_EINVAL;
+    if (num_frames == 0) return 0;
+    const int g = group_lanes(model->num_bodies, prm->num_ext_bodies);
+    const int64_t blocks = (num_frames * g + 255) / 256;
+    if (blocks > 0x7fffffffLL) return PHC_EUNSUPPORTED;
+#define PHC_TAB(DPJ, G) hipLaunchKernelGGL((k_amp_ref_table<DPJ, G>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *model, *lib, *prm, num_frames, next_frame, table)
+    if (prm->dofs_per_joint == 1) { if (g == 64) PHC_TAB(1, 64); else PHC_TAB(1, 32); }
+    else { if (g == 64) PHC_TAB(3, 64); else PHC_TAB(3, 32); }
+#undef PHC_TAB
     return launch_status();
 }
 

@@ -874,6 +874,7 @@ class HumanoidIm:
             torch.rand(self._offset_rand.shape, out=self._offset_rand)
         cur = self._amp_obs_buf
         self._refresh_hist_obs()
+        self._ensure_amp_ref_table()
         buf = self._buffers(cur, cur)
         L.check(self._lib.phc_im_reset(self._model_struct, self._motion_lib.struct, self._im_params, self._sim_struct, buf, n,
                                        env_ids.data_ptr(), abi.ptr(phase), int(bool(start_at_zero)), _stream()), "phc_im_reset")
@@ -894,6 +895,7 @@ class HumanoidIm:
         if self._far_start:
             torch.rand(self._offset_rand.shape, out=self._offset_rand)
         self._refresh_hist_obs()
+        self._ensure_amp_ref_table()
         buf = self._buffers(cur, cur)
         if not use_list:   # nothing appended since the last consumption (e.g. right after reset()): masked sweep over reset_buf
             buf.reset_list = None
@@ -907,6 +909,34 @@ class HumanoidIm:
         the self observation's per-env extra block."""
         if self._hist_obs_cols:
             self._self_obs_extra[:, -self._hist_obs_cols:].copy_(self._amp_obs_buf.reshape(self.num_envs, self._hist_obs_cols))
+
+    def _ensure_amp_ref_table(self):
+        """phc_im_params_t.amp_ref_table: the AMP observation of every frame of the motion library, so that a reset fills an env's AMP history from S
+        consecutive rows instead of S lookups + observation builds (the history frames of a reset were ~3/4 of the reset launch's instructions).
+        Only where the history times fall on frames: clips at 30 fps, env dt a multiple of 1/30 s (start times are multiples of 1/30 s,
+        motion_lib_base.py:414-423); the kernel still checks every blend factor and builds off-frame lookups in full.  Rebuilt when the library's
+        frames change (re-sampled motions), re-attached when the parameter struct was rebuilt."""
+        lib = self._motion_lib
+        frames = lib.frames
+        key = (id(lib), getattr(lib, "frames_epoch", 0), frames.data_ptr(), tuple(frames.shape), frames._version)
+        c = self.__dict__.get("_amp_ref_cache")
+        if c is None or c[0] != key:
+            table = None
+            steps = self.dt * 30.0
+            width = self._num_amp_obs_per_step - (0 if self._amp_obs_extra is None else self._amp_obs_extra.shape[1])
+            ok = (self.cfg["env"].get("amp_ref_table", True) and not os.environ.get("PHC_NO_AMP_REF_TABLE") and abs(steps - round(steps)) < 1e-6 and round(steps) >= 1
+                  and bool(torch.all(torch.abs(lib._motion_dt - 1.0 / 30.0) < 1e-7)) and frames.shape[0] * width * 4 <= 16 * 2 ** 30)
+            if ok:
+                table = torch.empty((frames.shape[0], width), dtype=torch.float32, device=self.device)
+                nxt = torch.arange(1, frames.shape[0] + 1, dtype=torch.long, device=self.device)
+                last = (lib.length_starts + lib._motion_num_frames.to(torch.long) - 1).to(torch.long)
+                nxt[last] = last                       # the last frame of a clip pairs with itself (idx1 = min(idx0 + 1, nf - 1))
+                self._im_params.amp_ref_table = None
+                L.check(self._lib.phc_amp_ref_table(self._model_struct, lib.struct, self._im_params, frames.shape[0], nxt.data_ptr(), table.data_ptr(),
+                                                    _stream()), "phc_amp_ref_table")
+                torch.cuda.current_stream(self.device).synchronize()   # (`nxt` is released right after)
+            c = self._amp_ref_cache = (key, table)
+        self._im_params.amp_ref_table = abi.ptr(c[1])
 
     def _one_hot_obs(self):
         """obs_v 5 (humanoid_im.py:812-815, motion_lib_base.py:214): the one-hot id of the env's clip among the library's unique motions behind the
@@ -977,6 +1007,7 @@ class HumanoidIm:
             out = torch.empty((n, self._num_amp_obs_steps, self._num_amp_obs_per_step), device=self.device, dtype=torch.float32)
         ids = motion_ids.to(torch.long).contiguous()
         t0 = motion_times0.to(torch.float32).contiguous()
+        self._ensure_amp_ref_table()
         L.check(self._lib.phc_amp_obs_demo(self._model_struct, self._motion_lib.struct, self._im_params, n, ids.data_ptr(),
                                            t0.data_ptr(), out.data_ptr(), _stream()), "phc_amp_obs_demo")
         return out

@@ -356,6 +356,7 @@ class MotionLibBase:
         self._struct = abi.motion_lib_struct(self.frames, self.frames.shape[1], self.num_bodies, self._motion_lengths, self._motion_dt,
                                              self._motion_num_frames, self.length_starts, num_ext_bodies=self.num_ext_bodies,
                                              dofs_per_joint=self.dofs_per_joint)
+        self.frames_epoch = getattr(self, "frames_epoch", 0) + 1   # (consumers that derive tables from `frames` key them on this)
         return per
 
     # ---- per-family hooks (SMPL here; MotionLibReal overrides) ----

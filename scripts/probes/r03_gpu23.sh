@@ -1,0 +1,15 @@
+#!/bin/bash
+# round 3: AMP history of a reset from a per-frame table (phc_amp_ref_table): diagnostic, env suite, A/B by env switch
+O=gpurun_out/r03_23; mkdir -p $O
+python scripts/probes/amp_table_diag.py > $O/diag.txt 2>&1; grep -E "max diff|blend distance|per history" $O/diag.txt
+timeout 1200 python -m pytest tests/test_env_gpu.py tests/test_h1.py -m gpu -x -q > $O/pytest.log 2>&1; tail -5 $O/pytest.log
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+for rep in 1 2; do
+for v in off on; do
+  if [ $v = off ]; then export PHC_NO_AMP_REF_TABLE=1; else unset PHC_NO_AMP_REF_TABLE; fi
+  rm -rf /tmp/prof_$v
+  rocprofv3 --kernel-trace --stats -d /tmp/prof_$v -o b -- python bench.py --steps 300 --warmup 30 --ppo-epochs 0 --no-cpu-baseline --no-pmc --no-other-workloads > $O/bench_${v}_$rep.json 2> $O/bench_${v}_$rep.err
+  python profiles/summarize_rocpd.py $(find /tmp/prof_$v -name '*.db' | head -1) > $O/stats_${v}_$rep.txt
+  echo "$v $rep: $(python -c "import json; d=json.load(open('$O/bench_${v}_$rep.json')); print(round(d['value']/1e6,2), 'M', round(d['ms_per_step']*1e3,1), 'us/step')")"; grep -E "k_im_reset<3, true|k_im_post|k_sim_step<true|k_amp_ref" $O/stats_${v}_$rep.txt | cut -c1-120
+done
+done

@@ -981,6 +981,56 @@ def test_fut_tracks_dropout_zeroes_a_tenth_of_the_reference_samples():
         flags.test = False
 
 
+def test_reset_amp_history_from_the_per_frame_table_equals_the_lookups():
+    """phc_im_params_t.amp_ref_table (ABI 33): a reset fills the AMP history from rows of the per-frame table instead of S lookups + observation builds.
+    Start times are multiples of 1/30 s and the history steps back by dt = 1/30 s on 30 fps clips, so every history time is a frame up to the rounding
+    of the blend factor: exactly 0 for ~5 lookups in 6 -- row f is built from the pair (f, f + 1) at blend 0, the very lookup, so those are bit-equal --
+    and <= 1e-4 for most others (first-order blend of two rows; tolerance 5e-6 here, the full build itself is pinned to the reference at 1e-5); lookups
+    that land just below the next frame are built in full.  Both reset idioms, resets at t = 0 (negative history times clamp to frame 0) included;
+    the table is rebuilt when the motions are re-sampled; a 50 Hz robot gets no table."""
+    from phc_amd.utils.flags import flags
+    ta, ea = make_task(256, motion="synthetic:5:1")
+    tb, eb = make_task(256, motion="synthetic:5:1", **{"+env.amp_ref_table": False})
+    torch.manual_seed(3); ea.reset()
+    torch.manual_seed(3); eb.reset()
+    assert ta._amp_ref_cache[1] is not None and ta._amp_ref_cache[1].shape == (ta._motion_lib.frames.shape[0], 196) and tb._amp_ref_cache[1] is None
+    assert torch.isfinite(ta._amp_ref_cache[1]).all()
+    close = lambda x, y: np.testing.assert_allclose(x.cpu().numpy(), y.cpu().numpy(), rtol=0, atol=5e-6)
+    close(ta._amp_obs_buf, tb._amp_obs_buf)
+    assert float((ta._amp_obs_buf == tb._amp_obs_buf).float().mean()) > 0.7      # (the lookups with blend factor 0: bit-equal)
+    assert torch.equal(ta.obs_buf, tb.obs_buf) and torch.equal(ta._root_states, tb._root_states)
+    a = (torch.rand(256, 69, device=ta.device) * 2 - 1) * 0.5
+    n_reset = 0
+    for step in range(30):
+        ea.step(a); eb.step(a)
+        if step % 2:
+            torch.manual_seed(70 + step); ta.reset_done()
+            torch.manual_seed(70 + step); tb.reset_done()
+        else:
+            ids = ta.reset_buf.nonzero().flatten()
+            n_reset += len(ids)
+            torch.manual_seed(70 + step); ea.reset(ids)
+            torch.manual_seed(70 + step); eb.reset(ids)
+        close(ta._amp_obs_buf, tb._amp_obs_buf)
+        assert torch.equal(ta.obs_buf, tb.obs_buf) and torch.equal(ta.progress_buf, tb.progress_buf)
+    assert n_reset > 20
+    flags.test = True          # episodes start at t = 0: history times below zero
+    try:
+        ea.reset(); eb.reset()
+        close(ta._amp_obs_buf, tb._amp_obs_buf)
+        assert float(ta._motion_start_times.abs().max()) == 0.0
+    finally:
+        flags.test = False
+    old = ta._amp_ref_cache[1]
+    torch.manual_seed(9); ta.resample_motions()
+    torch.manual_seed(9); tb.resample_motions()
+    assert ta._amp_ref_cache[1] is not old
+    close(ta._amp_obs_buf, tb._amp_obs_buf)
+    th, eh = make_task(64, motion="synthetic:3:2:2.0", **H1_OVER)
+    eh.reset()
+    assert th._amp_ref_cache[1] is None and abs(th.dt - 0.02) < 1e-9
+
+
 def test_enable_hist_obs_appends_the_amp_history_as_it_stood_before_the_step():
     """env.enableHistObs (humanoid_amp.py:98-101,327-328,546-557): `_compute_humanoid_obs` appends `_amp_obs_buf` (flattened, newest first) behind the
     self observation.  post_physics_step (:193-204) forms the observation BEFORE `_update_hist_amp_obs`, and `_reset_envs` (:378-385) before
