@@ -402,18 +402,17 @@ PHC_HD void im_post_finalize(const phc_motion_lib_t& lib, const phc_im_params_t&
 
 // Reset of one env, lane j: HumanoidIm._reset_envs (humanoid.py:585-621; humanoid_amp.py:378-398,508-528,
 // 559-637; humanoid_im.py:955-1023).  `t` = sampled start time.
-// `parts`: bit 0 = the state and the per-env scalars; bit 1 = the task observation; bit 2 = the self observation; bit 3 = the ref_* side buffers.  The
-// parts share nothing but the reference frame at t (the imposed state IS that frame), so the kernel gives each its own lane group: the reset
-// launch lasts as long as its longest dependent chain (profiles/r03_task/reset_group_timeline*.txt).
+// `parts`: bit 0 = the state, the self observation and the per-env scalars; bit 1 = the task observation and the ref_* side buffers.  The two
+// halves share nothing but the reference frame at t (the imposed state IS that frame), so the kernel gives each its own lane group: the reset
+// launch lasts as long as its longest dependent chain (profiles/r03_task/reset_group_timeline.txt).
 PHC_HD void im_reset_lane(const phc_model_t& model, const phc_motion_lib_t& lib, const phc_im_params_t& prm,
                           const phc_sim_state_t& sim, const phc_im_buffers_t& buf, int64_t env, int j, float t, bool clear_reset_flag,
-                          int parts = 15, const FrameTab* tabp = nullptr) {
+                          int parts = 3) {
     const int nb = model.num_bodies, nd = model.num_dof;
     const int64_t mid = motion_id_of(buf, env);
-    const FrameTab tab = tabp ? *tabp : frame_tab(lib, mid);   // (the kernel requests the clip's table entries before it knows the start time)
-    const bool p_state = (parts & 1) != 0, p_task = (parts & 2) != 0, p_self = (parts & 4) != 0, p_side = (parts & 8) != 0;
+    const bool p_state = (parts & 1) != 0, p_task = (parts & 2) != 0;
     if (j < nb) {
-        const FrameRef fr = frame_ref(tab, t);
+        const FrameRef fr = frame_ref(lib, mid, t);
         BodyState rs = ref_body(lib, fr, j);     // global offset was just zeroed (humanoid_im.py:956-957)
         BodyState root = (j == 0) ? rs : ref_body(lib, fr, 0);
         // _set_env_state (humanoid_amp.py:605-637)
@@ -438,21 +437,21 @@ PHC_HD void im_reset_lane(const phc_model_t& model, const phc_motion_lib_t& lib,
         const Q4 hroot = obs_root_rot(prm, root.rot);
         Q4 hinv = calc_heading_quat_inv(hroot), h = calc_heading_quat(hroot);
         float* obs = buf.obs_buf + env * (int64_t)(prm.num_self_obs + prm.num_task_obs);
-        if (p_self) {
+        if (p_state) {
         // (reset envs: the sensor tensor keeps its last reading until the next simulate call, as gym's does -- humanoid.py:1463)
         if (prm.self_obs_v == 2 && buf.body_state_hist) self_obs_v2_lane(prm, buf.body_state_hist, nb, env, j, rs, root, hinv, obs, false, true);   // humanoid.py:592-595
         else self_obs_lane(prm, nb, j, rs, root, hinv, obs, (sim.force_sensor && prm.self_obs_v == 3) ? sim.force_sensor + env * (int64_t)(prm.num_force_sensors * 6) : nullptr, env);
         }
-        if (p_task || p_side) {
+        if (p_task) {
         const float t1 = motion_time(1, prm.dt, t, 0.f);
-        const FrameRef fr1 = frame_ref(tab, t1);
+        const FrameRef fr1 = frame_ref(lib, mid, t1);
         BodyState r1 = ref_body(lib, fr1, j);
         V3 goff = v3(0.f, 0.f, 0.f);
         if (buf.offset_rand && prm.zero_out_far && prm.zero_out_far_train)   // the far-away start (humanoid_im.py:966-980): set AFTER the state
             disk_offset(buf.offset_rand[env * 2], buf.offset_rand[env * 2 + 1], &goff.x, &goff.y);   // was imposed, seen by the observations
         r1.pos += goff;
         int slot = prm.track_slot[j];
-        if (p_task && slot >= 0) {
+        if (slot >= 0) {
             BodyState rt = r1;
             if (prm.zero_out_far && !(prm.obs_v >= 1 && prm.obs_v <= 3)) {
                 BodyState rroot = (j == 0) ? r1 : ref_body(lib, fr1, 0);
@@ -465,7 +464,6 @@ PHC_HD void im_reset_lane(const phc_model_t& model, const phc_motion_lib_t& lib,
             if (prm.obs_v == 2 && j >= 1) { ref_joint(lib, fr, j, &jd, &jv); ref_joint(lib, fr1, j, &rjd, &rjv); }   // (the imposed state is the reference at t)
             task_obs_lane(prm, slot, rs, root, rt, hinv, h, obs + prm.num_self_obs, &jd, &rjd);
         }
-        if (p_side) {
         if (buf.ref_body_pos) st3(buf.ref_body_pos + (env * nb + j) * 3, r1.pos);
         if (buf.ref_body_rot) st4(buf.ref_body_rot + (env * nb + j) * 4, r1.rot);
         if (buf.ref_body_vel) st3(buf.ref_body_vel + (env * nb + j) * 3, r1.vel);
@@ -474,8 +472,7 @@ PHC_HD void im_reset_lane(const phc_model_t& model, const phc_motion_lib_t& lib,
             ref_joint(lib, fr1, j, &dp, &dv);
             st_joint(buf.ref_dof_pos + env * nd + model.ints[4 + 3 * PHC_MAX_BODIES + j], prm.dofs_per_joint, dp);
         }
-        }
-        if (p_task && prm.num_traj_samples > 1) {   // env.fut_tracks (see task_obs_future_lane): the imposed state is the reference at t
+        if (prm.num_traj_samples > 1) {   // env.fut_tracks (see task_obs_future_lane): the imposed state is the reference at t
             const FrameRef frt = frame_ref(lib, mid, t);
             V3 go = v3(0.f, 0.f, 0.f);
             if (buf.offset_rand && prm.zero_out_far && prm.zero_out_far_train) disk_offset(buf.offset_rand[env * 2], buf.offset_rand[env * 2 + 1], &go.x, &go.y);
@@ -583,10 +580,9 @@ PHC_HD void im_reset_amp_lane(const phc_motion_lib_t& lib, const phc_im_params_t
 // just BELOW the next frame, b ~ 1: the reference's slerp then still averages the previous pair, which row f1 does not hold) is built in full.
 // `nl` lanes.  All loads of a chunk are requested before its stores.
 #define PHC_AMP_TABLE_BLEND_TOL 1e-4f
-PHC_HD void amp_obs_from_table_lane(const phc_motion_lib_t& lib, const phc_im_params_t& prm, int nb, int j, int nl, int64_t mid, float t, float* a,
-                                    const FrameTab* tabp = nullptr) {
+PHC_HD void amp_obs_from_table_lane(const phc_motion_lib_t& lib, const phc_im_params_t& prm, int nb, int j, int nl, int64_t mid, float t, float* a) {
     const int A = prm.num_amp_obs_per_step, E = prm.num_amp_obs_extra, W = A - E;
-    const FrameRef fr = tabp ? frame_ref(*tabp, t) : frame_ref(lib, mid, t);
+    const FrameRef fr = frame_ref(lib, mid, t);
     const float b = fr.blend;
     if (j < nb && E > 0 && prm.amp_obs_extra) obs_extra_lane(prm.amp_obs_extra + mid * E, E, j, nb, a + W);
     if (!(b <= PHC_AMP_TABLE_BLEND_TOL)) {
@@ -603,9 +599,9 @@ PHC_HD void amp_obs_from_table_lane(const phc_motion_lib_t& lib, const phc_im_pa
     }
 }
 PHC_HD void im_reset_amp_table_lane(const phc_motion_lib_t& lib, const phc_im_params_t& prm, const phc_im_buffers_t& buf, int nb,
-                                    int64_t env, int j, int nl, float t, int k, const FrameTab* tabp = nullptr) {
+                                    int64_t env, int j, int nl, float t, int k) {
     amp_obs_from_table_lane(lib, prm, nb, j, nl, motion_id_of(buf, env), history_time(t, prm.dt, k),
-                            buf.amp_obs_out + env * amp_env_stride(prm, buf) + k * prm.num_amp_obs_per_step, tabp);
+                            buf.amp_obs_out + env * amp_env_stride(prm, buf) + k * prm.num_amp_obs_per_step);
 }
 
 }  // namespace phc

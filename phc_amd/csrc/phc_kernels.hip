@@ -146,15 +146,14 @@ extern "C" int32_t phc_debug_reset_timeline(unsigned long long* out64, int32_t g
 // Measured alternative (round 2, profiles/r02_notes.md): ONE workgroup per listed env with its S history-frame groups side by side
 // (blockDim = G * S), so that the S lookups of an env -- S + 1 consecutive clip frames -- share a CU's L1: 46.6 us vs 34 us for this
 // geometry (the ten groups of an env then hit one clip region, i.e. the same HBM channels, at the same instant).  Not kept.
-#define PHC_RESET_ROLES 4   // lane-group roles of a reset env in front of its AMP history frames (grid.y)
 template <int DPJ, bool RNG, int G>
 __global__ __launch_bounds__(256) void k_im_reset(phc_model_t model, phc_motion_lib_t lib, phc_im_params_t prm, phc_sim_state_t sim,
                                                  phc_im_buffers_t buf, int num_reset, const int64_t* __restrict__ env_ids,
                                                  const float* __restrict__ phase, int start_at_zero, uint64_t rng_key) {
     pin_family<DPJ>(lib, prm);
     const int lane = threadIdx.x & (G - 1);
-    // listed env (grid.x); grid.y: 0 = task observation, 1 = state, 2 = self observation, 3 = ref_* side buffers, PHC_RESET_ROLES + k = AMP history
-    // frame k -- the heaviest groups are dispatched first and no group carries more than one lookup chain
+    // listed env (grid.x); grid.y: 0 = state + self observation, 1 = task observation, 2 + k = AMP history frame k -- the heaviest groups
+    // are dispatched first and no group carries more than one lookup chain
     const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
     const int k = (int)blockIdx.y;
 #ifdef PHC_SIM_PROFILE
@@ -181,18 +180,17 @@ __global__ __launch_bounds__(256) void k_im_reset(phc_model_t model, phc_motion_
     }
     PHC_RTL(1)
     const int64_t mid = motion_id_of(buf, env);
-    const FrameTab tab = frame_tab(lib, mid);   // (requested together: the start time needs the clip's length, the lookups the other three entries)
     // _sample_ref_state (humanoid_im.py:1000-1023): StateInit.Random -> sample_time_interval; Start / flags.test -> 0
     // (start_at_zero with a null phase array is only legal in the RNG-free instantiation's list mode)
     // (device-side call counter, phc_im_buffers_t.reset_rng_counter: folded into the key so that a captured launch draws anew on every replay)
     const uint64_t key = (RNG && buf.reset_rng_counter) ? splitmix64(rng_key ^ (*buf.reset_rng_counter * 0x9E6C63D0876A9A47ull)) : rng_key;
-    const float t = start_at_zero ? 0.f : sample_time_interval(tab.len, RNG ? hash_u01(key, (uint32_t)env) : phase[r]);
+    const float t = start_at_zero ? 0.f : sample_time_interval(lib, mid, RNG ? hash_u01(key, (uint32_t)env) : phase[r]);
     PHC_RTL(2)
-    if (k < PHC_RESET_ROLES) im_reset_lane(model, lib, prm, sim, buf, env, lane, t, env_ids != nullptr, k == 0 ? 2 : (k == 1 ? 1 : (k == 2 ? 4 : 8)), &tab);
+    if (k < 2) im_reset_lane(model, lib, prm, sim, buf, env, lane, t, env_ids != nullptr, 1 << k);
     PHC_RTL(3)
-    if (k >= PHC_RESET_ROLES) {
-        if (prm.amp_ref_table != nullptr) im_reset_amp_table_lane(lib, prm, buf, model.num_bodies, env, lane, G, t, k - PHC_RESET_ROLES, &tab);
-        else im_reset_amp_lane(lib, prm, buf, model.num_bodies, env, lane, t, k - PHC_RESET_ROLES);
+    if (k >= 2) {
+        if (prm.amp_ref_table != nullptr) im_reset_amp_table_lane(lib, prm, buf, model.num_bodies, env, lane, G, t, k - 2);
+        else im_reset_amp_lane(lib, prm, buf, model.num_bodies, env, lane, t, k - 2);
     }
     PHC_RTL(4)
 }
@@ -407,7 +405,7 @@ int32_t phc_im_reset(const phc_model_t* model, const phc_motion_lib_t* lib, cons
     if (!sim || !buf || num_reset < 0 || (!start_at_zero && !phase)) return PHC_EINVAL;
     if (num_reset == 0) return 0;
     const int g = group_lanes(model->num_bodies, prm->num_ext_bodies);
-    const dim3 grid(env_blocks(num_reset, g), prm->num_amp_obs_steps + PHC_RESET_ROLES);
+    const dim3 grid(env_blocks(num_reset, g), prm->num_amp_obs_steps + 2);
 #define PHC_RESET(DPJ, G) hipLaunchKernelGGL((k_im_reset<DPJ, false, G>), grid, dim3(256), 0, (hipStream_t)stream, *model, *lib, *prm, *sim, *buf, num_reset, env_ids, phase, start_at_zero, 0ull)
     if (prm->dofs_per_joint == 1) { if (g == 64) PHC_RESET(1, 64); else PHC_RESET(1, 32); }
     else { if (g == 64) PHC_RESET(3, 64); else PHC_RESET(3, 32); }
@@ -426,7 +424,7 @@ int32_t phc_im_reset_done(const phc_model_t* model, const phc_motion_lib_t* lib,
     // (with a device-side call counter the host one stays out of the key: a captured launch and an eager one then draw the same numbers)
     const uint64_t key = splitmix64(splitmix64(seed) ^ ((buf->reset_rng_counter ? 0ull : counter) * 0xD1342543DE82EF95ull));
     const int g = group_lanes(model->num_bodies, prm->num_ext_bodies);
-    const dim3 grid(env_blocks(n, g), prm->num_amp_obs_steps + PHC_RESET_ROLES);
+    const dim3 grid(env_blocks(n, g), prm->num_amp_obs_steps + 2);
 #define PHC_RESET(DPJ, G) hipLaunchKernelGGL((k_im_reset<DPJ, true, G>), grid, dim3(256), 0, (hipStream_t)stream, *model, *lib, *prm, *sim, *buf, n, nullptr, nullptr, start_at_zero, key)
     if (prm->dofs_per_joint == 1) { if (g == 64) PHC_RESET(1, 64); else PHC_RESET(1, 32); }
     else { if (g == 64) PHC_RESET(3, 64); else PHC_RESET(3, 32); }

@@ -72,13 +72,12 @@ PHC_HD FrameRef frame_ref(const FrameTab& tab, float time) {
 PHC_HD FrameRef frame_ref(const phc_motion_lib_t& lib, int64_t mid, float time) { return frame_ref(frame_tab(lib, mid), time); }
 
 // M7 sample_time_interval (motion_lib_base.py:414-423)
-PHC_HD float sample_time_interval(float motion_length, float phase) {
+PHC_HD float sample_time_interval(const phc_motion_lib_t& lib, int64_t mid, float phase) {
     PHC_NO_CONTRACT
     const float curr_fps = (float)(1.0 / 30.0);
-    float t = (phase * motion_length) / curr_fps;
+    float t = (phase * lib.motion_lengths[mid]) / curr_fps;
     return (float)((int)t) * curr_fps;   // .long(): t < 2^24 frames
 }
-PHC_HD float sample_time_interval(const phc_motion_lib_t& lib, int64_t mid, float phase) { return sample_time_interval(lib.motion_lengths[mid], phase); }
 
 // env time (humanoid_im.py:879,752,1118): progress * dt + start + offset, each op rounded to fp32
 PHC_HD float motion_time(int64_t progress, float dt, float start, float start_off) {
