@@ -3,6 +3,7 @@
 O=gpurun_out/${1:-r3r}
 mkdir -p $O
 if [ -z "$SKIP_PYTEST" ]; then timeout 1500 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; tail -3 $O/pytest_gpu.log; fi
+python __graft_entry__.py --smoke > $O/smoke.log 2>&1; tail -1 $O/smoke.log
 python bench.py > $O/bench_default.json 2> $O/bench_default.err; tail -c 400 $O/bench_default.err
 python bench.py --actions tracking --no-cpu-baseline --no-pmc --ppo-epochs 0 > $O/bench_tracking.json 2>> $O/bench_default.err
 python bench.py --config 5 --ppo-epochs 0 --no-cpu-baseline --no-pmc > $O/bench_h1.json 2>> $O/bench_default.err
