@@ -167,7 +167,10 @@ int emu_im_reset(const phc_model_t* model, const phc_motion_lib_t* lib, const ph
         const int64_t mid = buf->sampled_motion_ids[env];
         const float t = start_at_zero ? 0.f : sample_time_interval(*lib, mid, phase[r]);
         for (int k = 0; k < prm->num_amp_obs_steps; ++k)
-            for (int lane = 0; lane < PHC_MAX_BODIES; ++lane) im_reset_amp_lane(*lib, *prm, *buf, model->num_bodies, env, lane, t, k);
+            for (int lane = 0; lane < PHC_MAX_BODIES; ++lane) {
+                if (prm->amp_ref_table) im_reset_amp_table_lane(*lib, *prm, *buf, model->num_bodies, env, lane, PHC_MAX_BODIES, t, k);
+                else im_reset_amp_lane(*lib, *prm, *buf, model->num_bodies, env, lane, t, k);
+            }
         for (int lane = PHC_MAX_BODIES - 1; lane >= 0; --lane) im_reset_lane(*model, *lib, *prm, *sim, *buf, env, lane, t, true);
     }
     return 0;
@@ -179,8 +182,23 @@ int emu_amp_obs_demo(const phc_model_t* model, const phc_motion_lib_t* lib, cons
     for (int64_t g = 0; g < (int64_t)n * S; ++g) {
         const int64_t i = g / S;
         const int k = (int)(g - i * S);
-        for (int lane = 0; lane < PHC_MAX_BODIES; ++lane)
-            amp_obs_from_ref_lane(*lib, *prm, model->num_bodies, lane, ids[i], history_time(times0[i], prm->dt, k), out + g * A);
+        for (int lane = 0; lane < PHC_MAX_BODIES; ++lane) {
+            if (prm->amp_ref_table) amp_obs_from_table_lane(*lib, *prm, model->num_bodies, lane, PHC_MAX_BODIES, ids[i], history_time(times0[i], prm->dt, k), out + g * A);
+            else amp_obs_from_ref_lane(*lib, *prm, model->num_bodies, lane, ids[i], history_time(times0[i], prm->dt, k), out + g * A);
+        }
+    }
+    return 0;
+}
+
+// phc_amp_ref_table: row f = the AMP observation of the lookup (f, next_frame[f], blend 0)
+int emu_amp_ref_table(const phc_model_t* model, const phc_motion_lib_t* lib, const phc_im_params_t* prm, int64_t num_frames,
+                      const int64_t* next_frame, float* table) {
+    const int W = prm->num_amp_obs_per_step - prm->num_amp_obs_extra;
+#pragma omp parallel for schedule(static)
+    for (int64_t f = 0; f < num_frames; ++f) {
+        FrameRef fr;
+        fr.f0 = f; fr.f1 = next_frame[f]; fr.idx0 = fr.idx1 = 0; fr.blend = 0.f;
+        for (int lane = 0; lane < PHC_MAX_BODIES; ++lane) amp_obs_from_frames_lane(*lib, *prm, model->num_bodies, lane, fr, table + f * (int64_t)W);
     }
     return 0;
 }

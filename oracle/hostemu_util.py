@@ -42,6 +42,7 @@ def emu():
         lib.emu_im_reset.argtypes = [PS(L.Model), PS(L.MotionLib), PS(L.ImParams), PS(L.SimState), PS(L.ImBuffers), i32, vp, vp, i32]
         lib.emu_im_reset_from_state.argtypes = [PS(L.Model), PS(L.MotionLib), PS(L.ImParams), PS(L.SimState), PS(L.ImBuffers), i32, vp, i32]
         lib.emu_amp_obs_demo.argtypes = [PS(L.Model), PS(L.MotionLib), PS(L.ImParams), i32, vp, vp, vp]
+        lib.emu_amp_ref_table.argtypes = [PS(L.Model), PS(L.MotionLib), PS(L.ImParams), C.c_int64, vp, vp]
         lib.emu_sim_step.argtypes = [PS(L.Model), PS(L.SimParams), PS(L.SimState), vp, vp, vp, vp, i32, i32]
         _emu = lib
     return _emu

@@ -258,7 +258,7 @@ PHC_HD RewardPartial im_post_lane(const phc_model_t& model, const phc_motion_lib
         return rp;
     }
     const FrameRef fr0 = frame_ref(tab, c.t0), fr1 = frame_ref(tab, c.t1);
-    PHC_PTL(3, env, j)
+    PHC_PTL(2, env, j)
     // Order of work (round 3, profiles/r03_task/post_physics_timeline.txt): the two frame-record pairs are REQUESTED first, then everything that
     // needs the simulator state only -- self observation, AMP frame -- is computed and stored while they are on their way, then the blends,
     // the reward partials and the task observation.
@@ -266,20 +266,20 @@ PHC_HD RewardPartial im_post_lane(const phc_model_t& model, const phc_motion_lib
     JointPosRaw qj;
     const bool want_dof = buf.ref_dof_pos != nullptr && j >= 1;
     if (want_dof) qj = ref_joint_pos_raw(lib, fr1, j);
-    PHC_PTL(4, env, j)
+    PHC_PTL(3, env, j)
     // observations for the next policy step (humanoid_im.py:694-726)
     const Q4 hroot = obs_root_rot(prm, root.rot);
     Q4 hinv = calc_heading_quat_inv(hroot), h = calc_heading_quat(hroot);
     float* obs = buf.obs_buf + env * (int64_t)(prm.num_self_obs + prm.num_task_obs);
     if (prm.self_obs_v == 2 && buf.body_state_hist) self_obs_v2_lane(prm, buf.body_state_hist, nb, env, j, body, root, hinv, obs, true, false);
     else self_obs_lane(prm, nb, j, body, root, hinv, obs, (sim.force_sensor && prm.self_obs_v == 3) ? sim.force_sensor + env * (int64_t)(prm.num_force_sensors * 6) : nullptr, env);
-    PHC_PTL(6, env, j)
+    PHC_PTL(4, env, j)
     // AMP observation of this step -> slot 0 of the new history (humanoid_amp.py:204-209)
     {
         float* amp = buf.amp_obs_out + env * amp_env_stride(prm, buf);
         amp_obs_from_sim_lane(prm, sim, nb, nd, env, j, root, hinv, model.ints + 4 + 3 * PHC_MAX_BODIES, amp);
     }
-    PHC_PTL(9, env, j)
+    PHC_PTL(5, env, j)
     BodyState r0 = ref_body_blend(q0, fr0.blend), r1 = ref_body_blend(q1, fr1.blend);
     r0.pos += c.goff; r1.pos += c.goff;  // motion_lib_base.py:476
     // R1 / R5 partials
@@ -303,7 +303,7 @@ PHC_HD RewardPartial im_post_lane(const phc_model_t& model, const phc_motion_lib
         rp.power = fabsf(f[0] * d[1]);
         if (prm.dofs_per_joint != 1) rp.power += fabsf(f[1] * d[3]) + fabsf(f[2] * d[5]);
     }
-    PHC_PTL(5, env, j)
+    PHC_PTL(6, env, j)
     int slot = prm.track_slot[j];
     if (slot >= 0) {
         BodyState rt = r1;

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void k_im_post_physics(phc_model_t model, phc_
     const float prev_goal = (prm.zero_out_far && buf.point_goal) ? buf.point_goal[env] : 0.f;  // read before lane 0 overwrites it
     PHC_PTL(1, env, lane)
     RewardPartial rp = im_post_lane(model, lib, prm, sim, buf, env, lane, c, tab, body, root);
-    PHC_PTL(2, env, lane)
+    PHC_PTL(9, env, lane)
     amp_shift_lane(prm, buf, env, lane, G);   // (every S-th step; reads the old window, writes rows 1.. of the new one: after the frame in row 0)
     float s_pos = group_sum<G>(rp.pos), s_rot = group_sum<G>(rp.rot), s_vel = group_sum<G>(rp.vel), s_ang = group_sum<G>(rp.angvel);
     float s_pow = group_sum<G>(rp.power), s_dist = group_sum<G>(rp.dist);

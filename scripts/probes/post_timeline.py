@@ -25,8 +25,9 @@ def main():
     for _ in range(10):
         task.reset_done(); env.step(a)
     torch.cuda.synchronize()
-    names = {1: "progress + per-env context (prologue)", 2: "AMP window shift (1 step in 10)", 3: "frame indices of both lookups", 4: "body / root state + both reference states (loads, blends)",
-             5: "reward partials + power", 6: "self observation", 7: "task observation", 8: "ref_* side buffers", 9: "AMP observation frame", 10: "32-lane sums", 11: "finalize (lane 0)"}
+    names = {1: "requests at the top + per-env context (prologue)", 2: "frame indices of both lookups", 3: "frame-record requests (drained here by the stamp)",
+             4: "self observation", 5: "AMP observation frame", 6: "blends + reward partials + power", 7: "task observation", 8: "ref_* side buffers",
+             9: "(end of the lane function)", 10: "AMP window shift (1 step in 10) + 32-lane sums", 11: "finalize (lane 0)"}
     for e in (5, 1000, n - 3):
         buf = (C.c_ulonglong * 32)()
         raw.phc_debug_post_timeline(None, e)

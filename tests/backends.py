@@ -47,6 +47,9 @@ class HostEmu:
     def amp_obs_demo(self, model, lib, prm, n, ids, t0, out):
         return emu().emu_amp_obs_demo(P(model), P(lib), P(prm), n, abi.ptr(ids), abi.ptr(t0), abi.ptr(out))
 
+    def amp_ref_table(self, model, lib, prm, num_frames, next_frame, table):
+        return emu().emu_amp_ref_table(P(model), P(lib), P(prm), num_frames, abi.ptr(next_frame), abi.ptr(table))
+
     def sim_step(self, model, params, sim, actions, off, scale, freeze, num_sim_calls):
         return emu().emu_sim_step(P(model), P(params), P(sim), abi.ptr(actions), abi.ptr(off), abi.ptr(scale), abi.ptr(freeze), num_sim_calls, 1)
 
@@ -98,6 +101,9 @@ class Hip:
 
     def amp_obs_demo(self, model, lib, prm, n, ids, t0, out):
         return self.lib.phc_amp_obs_demo(model, lib, prm, n, abi.ptr(ids), abi.ptr(t0), abi.ptr(out), self._s())
+
+    def amp_ref_table(self, model, lib, prm, num_frames, next_frame, table):
+        return self.lib.phc_amp_ref_table(model, lib, prm, num_frames, abi.ptr(next_frame), abi.ptr(table), self._s())
 
     def sim_step(self, model, params, sim, actions, off, scale, freeze, num_sim_calls):
         return self.lib.phc_sim_step(model, params, sim, abi.ptr(actions), abi.ptr(off), abi.ptr(scale), abi.ptr(freeze), num_sim_calls, self._s())

@@ -485,6 +485,60 @@ def test_post_physics_cycle_motion_zero_out_far_vs_reference_golden(golden, back
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
+def test_amp_ref_table_rows_equal_the_full_builds_at_frame_times(golden, backend):
+    """phc_amp_ref_table / phc_im_params_t.amp_ref_table (ABI 33): row f = the AMP observation of the lookup (f, f + 1, blend 0).  At start times on the
+    1/30 s grid (sample_time_interval) and history steps of dt = 1/30 s every lookup falls on a frame up to the rounding of its blend factor: exactly 0 for
+    most (bit-equal to the full build), <= 1e-4 for the rest that use the table (first-order blend of two rows), full build otherwise.  Against the full
+    build of the same backend and against the numpy oracle driven the reference's way (humanoid_amp.py:253-284)."""
+    be = get_backend(backend)
+    gl = golden("motion_lib_eval")
+    model, mstruct, keepm = model_on(be)
+    lib, keep = motion_lib_on(be, gl)
+    N = 6
+    prm, keepp = make_im_params(be, model, N)
+    track_slot, reset_mask, key_ids, amp_slot, td = keepp
+    dof_subset = np.concatenate([np.arange(3 * (j - 1), 3 * j) for j in range(1, 24) if amp_slot[j] >= 0])
+    nf, starts = gl["motion_num_frames"].astype(np.int64), gl["length_starts"].astype(np.int64)
+    assert np.allclose(gl["motion_dt"], 1 / 30)
+    Ftot = int(starts[-1] + nf[-1])
+    nxt = np.arange(1, Ftot + 1, dtype=np.int64)
+    nxt[starts + nf - 1] = starts + nf - 1
+    table = be.zeros((Ftot, 196))
+    assert be.amp_ref_table(mstruct, lib, prm, Ftot, be.arr(nxt), table) == 0
+    be.sync()
+    assert np.isfinite(be.np(table)).all()
+    prm_t, keept = make_im_params(be, model, N, amp_ref_table=table)
+    rng = np.random.default_rng(5)
+    n = 64
+    ids = rng.integers(0, N, n).astype(np.int64)
+    t0 = np.zeros(n, dtype=F)
+    assert be.sample_time_interval(lib, n, be.arr(ids), be.arr(rng.random(n).astype(F)), (t0d := be.zeros(n))) == 0   # multiples of 1/30 s
+    be.sync()
+    t0 = be.np(t0d).copy()
+    t0[:4] = 0.0                                        # history times below zero clamp to frame 0
+    out_full, out_tab = be.zeros((n, 10, 196)), be.zeros((n, 10, 196))
+    assert be.amp_obs_demo(mstruct, lib, prm, n, be.arr(ids), be.arr(t0), out_full) == 0
+    assert be.amp_obs_demo(mstruct, lib, prm_t, n, be.arr(ids), be.arr(t0), out_tab) == 0
+    be.sync()
+    a, b = be.np(out_tab), be.np(out_full)
+    np.testing.assert_allclose(a, b, rtol=0, atol=5e-6)
+    assert (a == b).all(axis=-1).mean() > 0.6           # rows of the lookups with blend factor exactly 0 (and of the off-grid ones built in full)
+    dt = F(2 * (1 / 60))
+    times = (t0[:, None] + (-dt) * np.arange(10, dtype=F)[None]).astype(F)
+    ms = po.get_motion_state(gl, np.repeat(ids, 10), times.reshape(-1))
+    want = po.build_amp_observations_smpl(ms["root_pos"], ms["root_rot"], ms["root_vel"], ms["root_ang_vel"], ms["dof_pos"], ms["dof_vel"],
+                                          ms["rg_pos"][:, key_ids], dof_subset).reshape(n, 10, 196)
+    np.testing.assert_allclose(a, want, atol=2e-5)
+    # start times OFF the frame grid: every lookup is built in full -- same numbers as without the table
+    t1 = (rng.random(n).astype(F) * gl["motion_lengths"][ids]).astype(F)
+    o1, o2 = be.zeros((n, 10, 196)), be.zeros((n, 10, 196))
+    assert be.amp_obs_demo(mstruct, lib, prm, n, be.arr(ids), be.arr(t1), o1) == 0 and be.amp_obs_demo(mstruct, lib, prm_t, n, be.arr(ids), be.arr(t1), o2) == 0
+    be.sync()
+    d = np.abs(be.np(o1) - be.np(o2))
+    assert d.max() <= 5e-6 and (d == 0).mean() > 0.95
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
 def test_amp_demo_and_reset_vs_oracle(golden, backend):
     """build_amp_obs_demo and the reset composition, against the numpy oracle driven the reference's way."""
     be = get_backend(backend)
