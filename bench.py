@@ -299,6 +299,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # Exactly ONE line on stdout, the JSON the driver parses: everything else that writes to descriptor 1 -- RCCL prints a version banner there when
+    # its first communicator comes up, after Python has flushed its own buffer -- is sent to stderr; the line goes to the saved descriptor.
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the path has no CPU fallback")
     if world != args.gpus:
@@ -475,7 +480,7 @@ def main():
         if not os.environ.get("PHC_BENCH_CHILD"):
             out["device"] = device_state(dev)
         out["envs_within_5_steps_of_a_reset"] = resets
-        print(json.dumps(out))
+        print(json.dumps(out), file=real_stdout, flush=True)
     if dist is not None:
         dist.destroy_process_group()
 
