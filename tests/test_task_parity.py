@@ -485,6 +485,40 @@ def test_post_physics_cycle_motion_zero_out_far_vs_reference_golden(golden, back
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
+def test_enable_hist_obs_vs_reference_method(golden, backend):
+    """env.enableHistObs against the reference's own `HumanoidAMP._compute_humanoid_obs` (humanoid_amp.py:546-557; fixture from
+    oracle/gen_golden_hist_obs.py, run on a `__new__`-made task): the AMP history buffer, flattened newest frame first, BEHIND the self observation -- for
+    all envs and for an env subset.  The kernels place it through the per-env extra columns of the self observation (`self_obs_extra`), as
+    HumanoidIm._refresh_hist_obs fills them; here the same post-physics launch on the fixture's body states."""
+    be = get_backend(backend)
+    g, gt = golden("hist_obs"), golden("task_fns")
+    N = g["obs_all"].shape[0]
+    H = g["amp_obs_buf"].shape[1] * g["amp_obs_buf"].shape[2]
+    assert g["obs_all"].shape[1] == 358 + H
+    np.testing.assert_array_equal(g["obs_all"][:, 358:], g["amp_obs_buf"].reshape(N, H))             # what the reference appends, and where
+    np.testing.assert_array_equal(g["obs_subset"], g["obs_all"][g["env_ids"]])
+    np.testing.assert_array_equal(g["obs_all"][:, :358], g["obs_without_hist"])
+    # the kernels' composition: one post-physics launch on the fixture's body states with the history as the extra columns of the self observation
+    sub = {k: (gt[k][:N] if getattr(gt[k], "ndim", 0) >= 1 and gt[k].shape[0] == gt["body_pos"].shape[0] else gt[k]) for k in gt}
+    model, mstruct, keepm = model_on(be)
+    lib, keep = motion_lib_on(be, golden("motion_lib_eval"))
+    extra = be.arr(g["amp_obs_buf"].reshape(N, H).astype(F))
+    prm, keepp = make_im_params(be, model, N, num_self_obs=358 + H, self_obs_extra=extra)
+    arrs, sim = _sim_arrays(be, sub, N)
+    amp_in, amp_out = be.zeros((N, 10, 196)), be.zeros((N, 10, 196))
+    b = dict(progress=be.arr((sub["progress"] - 1).astype(np.int64)), reset=be.zeros(N, np.int64), term=be.zeros(N, np.int64), rew=be.zeros(N),
+             raw=be.zeros((N, 5)), obs=be.zeros((N, 358 + H + 576)), mids=be.arr(sub["env_motion"].astype(np.int64)),
+             st=be.arr(sub["start_times"].astype(F)), so=be.zeros(N), goff=be.zeros((N, 3)))
+    buf = abi.im_buffers_struct(b["progress"], b["reset"], b["term"], b["rew"], b["raw"], b["obs"], amp_in, amp_out, b["mids"], b["st"], b["so"], b["goff"])
+    assert be.im_post_physics(mstruct, lib, prm, sim, buf) == 0
+    be.sync()
+    obs = be.np(b["obs"])
+    np.testing.assert_allclose(obs[:, :358 + H], g["obs_all"], atol=1e-5)                          # == the reference method's output
+    np.testing.assert_array_equal(obs[:, 358:358 + H], g["amp_obs_buf"].reshape(N, H))
+    np.testing.assert_allclose(obs[:, 358 + H:], sub["task_obs"], atol=1e-5)                       # the task block behind it
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
 def test_amp_ref_table_rows_equal_the_full_builds_at_frame_times(golden, backend):
     """phc_amp_ref_table / phc_im_params_t.amp_ref_table (ABI 33): row f = the AMP observation of the lookup (f, f + 1, blend 0).  At start times on the
     1/30 s grid (sample_time_interval) and history steps of dt = 1/30 s every lookup falls on a frame up to the rounding of its blend factor: exactly 0 for
