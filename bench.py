@@ -56,7 +56,7 @@ def parse():
                     "exists to exercise the multi-rank logic of this script with several ranks SHARING one GPU (tests on 1-GPU boxes)")
     ap.add_argument("--config", type=int, default=2, choices=[2, 3, 5], help="BASELINE.json configs preset (1-based): 2 = SMPL 4096 envs single "
                     "clip (the bench line), 3 = 8192 envs + AMASS-sized synthetic library (--motion-clips, default 11313), 5 = H1 4096 envs")
-    ap.add_argument("--ppo-epochs", type=int, default=3, help="timed PPO epochs (rollout 32 steps + 36 optimizer steps); 0 = skip")
+    ap.add_argument("--ppo-epochs", type=int, default=3, help="timed PPO epochs (rollout 32 steps + 48 optimizer steps: 6 mini-epochs x 8 minibatches); 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-workloads", action="store_true", help="skip the two extra env-step measurements (tracking actions, Unitree H1) "
                     "that the default single-GPU run appends as `other_workloads`")
@@ -67,7 +67,9 @@ def parse():
                     "(Unitree H1, 19 revolute DoFs, 200 Hz x 4 pd-torque control); g1: Unitree G1 (38 bodies, the 64-lane kernels) -- parity-test "
                     "configurations, timed for reference only")
     ap.add_argument("--lane-mapping", type=int, default=0, help="stepper thread mapping (phc_sim_params_t.lane_mapping): 0 auto, 1 one body "
-                    "per lane (32 lanes/env), 2 two bodies per lane (16 lanes/env)")
+                    "per lane (32 lanes/env, or 64 above 32 bodies) -- the only mapping the stepper has")
+    ap.add_argument("--burn-in", type=int, default=64, help="untimed env steps in FRONT of the W warm-up steps (reported as `protocol_burn_in_steps`): "
+                    "right after env.reset() every env falls, and is reset, in the same few steps; 0 = the bare driver protocol (W warm-up steps only)")
     ap.add_argument("--self-collision", type=int, default=-1, help="-1: as the robot yaml says (has_self_collision: True); 0/1 force")
     ap.add_argument("--motion-clips", type=int, default=1, help="synthetic clips in the motion library (configs[1]: 1; configs[2]/[3] shape: thousands)")
     ap.add_argument("--actions", choices=["random", "tracking"], default="random",
@@ -383,7 +385,7 @@ def main():
     # The SURVEY protocol is a STEADY state (fixed random actions, ~98 % of the envs within 5 steps of a reset, resets spread over the steps).  Right
     # after env.reset() all envs are in lockstep -- they fall, and are reset, in the same few steps -- so a short run (the driver's K = 20, W = 5)
     # would time that transient instead.  Untimed burn-in in front of the W warm-up steps; reported in the line.
-    BURN_IN = 64
+    BURN_IN = max(0, args.burn_in)
     for _ in range(BURN_IN):
         env_step()
     for _ in range(args.warmup):

@@ -164,7 +164,7 @@ int emu_im_reset(const phc_model_t* model, const phc_motion_lib_t* lib, const ph
     for (int r = 0; r < num_reset; ++r) {
         const int64_t env = env_ids ? env_ids[r] : r;
         if (!env_ids && buf->reset_buf[env] == 0) continue;
-        const int64_t mid = buf->sampled_motion_ids[env];
+        const int64_t mid = motion_id_of(*buf, env);   // (NULL table = identity, as on the device: ABI 33)
         const float t = start_at_zero ? 0.f : sample_time_interval(*lib, mid, phase[r]);
         for (int k = 0; k < prm->num_amp_obs_steps; ++k)
             for (int lane = 0; lane < PHC_MAX_BODIES; ++lane) {

@@ -519,3 +519,71 @@ def discount_values(mb_fdones, mb_values, mb_rewards, mb_next_values, gamma=0.99
         lastgaelam = delta + gamma * tau * not_done * lastgaelam
         mb_advs[t] = lastgaelam
     return mb_advs
+
+
+# --------------------------------------------------------------------------
+# Robot path (Unitree H1 / G1): MotionLibReal lookup, extended bodies, robot AMP observation, explicit `pd` torque
+# --------------------------------------------------------------------------
+def get_motion_state_robot(lib, motion_ids, motion_times, offset=None):
+    """motion_lib_real.py:236-361 (`"dof_pos" in self.__dict__` branch): joint angles and rates blend linearly, the
+    (NB + E)-wide `gts_t / grs_t` carry the extended bodies.  ``lib``: flat frame tensors gts grs gvs gavs dvs dof_pos
+    gts_t grs_t (fp32) + the per-motion arrays of get_motion_state."""
+    motion_len = lib["motion_lengths"][motion_ids]
+    num_frames = lib["motion_num_frames"][motion_ids]
+    dt = lib["motion_dt"][motion_ids]
+    idx0, idx1, blend = calc_frame_blend(motion_times, motion_len, num_frames, dt)
+    f0l = idx0 + lib["length_starts"][motion_ids]
+    f1l = idx1 + lib["length_starts"][motion_ids]
+    b1 = blend[:, None]
+    b2 = b1[:, :, None]
+    one = F(1.0)
+    off = F(0) if offset is None else offset[:, None, :].astype(F)
+    rg_pos = (one - b2) * lib["gts"][f0l] + b2 * lib["gts"][f1l] + off
+    rg_pos_t = (one - b2) * lib["gts_t"][f0l] + b2 * lib["gts_t"][f1l] + off
+    body_vel = (one - b2) * lib["gvs"][f0l] + b2 * lib["gvs"][f1l]
+    body_ang_vel = (one - b2) * lib["gavs"][f0l] + b2 * lib["gavs"][f1l]
+    dof_vel = (one - b1) * lib["dvs"][f0l] + b1 * lib["dvs"][f1l]
+    dof_pos = (one - b1) * lib["dof_pos"][f0l] + b1 * lib["dof_pos"][f1l]
+    rb_rot = slerp(lib["grs"][f0l], lib["grs"][f1l], b2)
+    rg_rot_t = slerp(lib["grs_t"][f0l], lib["grs_t"][f1l], b2)
+    return {"root_pos": rg_pos[:, 0].copy(), "root_rot": rb_rot[:, 0].copy(), "dof_pos": dof_pos.astype(F), "dof_vel": dof_vel.astype(F),
+            "root_vel": body_vel[:, 0].copy(), "root_ang_vel": body_ang_vel[:, 0].copy(),
+            "rg_pos": rg_pos, "rb_rot": rb_rot, "body_vel": body_vel, "body_ang_vel": body_ang_vel,
+            "rg_pos_t": rg_pos_t, "rg_rot_t": rg_rot_t, "f0l": f0l, "f1l": f1l, "blend": blend}
+
+
+def extend_bodies(body_pos, body_rot, ext_parent, ext_pos):
+    """humanoid_im.py:917-919: the extended bodies (hands / head) ride on their parent link; appended behind the NB simulated bodies."""
+    ext_parent = np.asarray(ext_parent, np.int64)
+    N, E = body_pos.shape[0], len(ext_parent)
+    pr = body_rot[:, ext_parent].reshape(-1, 4)
+    ep = np.broadcast_to(np.asarray(ext_pos, F)[None], (N, E, 3)).reshape(-1, 3)
+    cur = my_quat_rotate(pr, ep).reshape(N, E, 3) + body_pos[:, ext_parent]
+    return np.concatenate([body_pos, cur], 1).astype(F), np.concatenate([body_rot, body_rot[:, ext_parent]], 1).astype(F)
+
+
+def build_amp_observations_robot(root_pos, root_rot, root_vel, root_ang_vel, dof_pos, dof_vel, key_body_pos,
+                                 local_root_obs=True, root_height_obs=True, upright=True):
+    """humanoid_amp.py:1063-1104 without shape / limb-weight columns: the joint angles themselves are the dof observation (:1091)."""
+    N = root_pos.shape[0]
+    root_h = root_pos[:, 2:3]
+    if not upright:
+        root_rot = remove_base_rot(root_rot)
+    hinv = calc_heading_quat_inv(root_rot)
+    root_rot_obs = quat_to_tan_norm(quat_mul(hinv, root_rot) if local_root_obs else root_rot)
+    lrv = my_quat_rotate(hinv, root_vel)
+    lrav = my_quat_rotate(hinv, root_ang_vel)
+    K = key_body_pos.shape[1]
+    lk = key_body_pos - root_pos[:, None]
+    hinv_e = np.repeat(hinv[:, None], K, axis=1).reshape(-1, 4)
+    lk = my_quat_rotate(hinv_e, lk.reshape(-1, 3)).reshape(N, K * 3)
+    parts = ([root_h] if root_height_obs else []) + [root_rot_obs, lrv, lrav, dof_pos, dof_vel, lk]
+    return np.concatenate(parts, axis=-1).astype(F)
+
+
+def compute_torques_pd(actions, dof_pos, dof_vel, p_gains, d_gains, default_dof_pos, torque_limits, action_scale=1.0):
+    """humanoid.py:1575-1599, control_type "P": clip(p (a s + q0 - q) - d qd, +-limit) in fp32, torch's operation order."""
+    a = actions.astype(F) * F(action_scale)
+    t = p_gains.astype(F) * (a + default_dof_pos.astype(F) - dof_pos.astype(F)) - d_gains.astype(F) * dof_vel.astype(F)
+    lim = np.broadcast_to(np.asarray(torque_limits, F), t.shape)
+    return np.clip(t, -lim, lim).astype(F)

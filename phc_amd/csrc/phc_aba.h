@@ -10,9 +10,8 @@
 //   * the sweeps (articulated inertia leaves->root; accelerations root->leaves) run level-synchronously: at tree level l only
 //     the lanes whose body sits at level l work; parent/child hand-off goes through a 28-float LDS slot per body.  A sub-step is
 //     TWO sweeps: the accelerations sweep also integrates each joint and produces the next kinematics on its way down.
-//     Two thread mappings share these lane functions: one body per lane (32 lanes / env) and two bodies per lane (16 lanes /
-//     env, a shallow-level and a deep-level body; phc_sim.hip).  Joint families are template instantiations (spherical: SMPL;
-//     revolute with rest rotations: H1).
+//     One body per lane (32 lanes / env; 64 above 32 bodies; phc_sim.hip).  Joint families are template instantiations (spherical: SMPL;
+//     revolute with rest rotations: H1 / G1).
 //   * everything stiff is integrated LINEARLY IMPLICITLY by augmenting the articulated inertia:
 //       - PD drive (kp,kd) + armature:  D += R diag(armature + dt*kd + dt^2*kp) R^T,
 //         tau_explicit = clamp(kp*err, +-effort) - (kd + dt*kp)*w_joint   (Isaac Gym "isaac_pd" drive, S8)

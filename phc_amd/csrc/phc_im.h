@@ -576,8 +576,12 @@ PHC_HD void im_reset_amp_lane(const phc_motion_lib_t& lib, const phc_im_params_t
 }
 // The same from the per-frame table (phc_im_params_t.amp_ref_table, row f = the build for the pair (f, f + 1) at blend 0): the history times of a reset
 // fall on frames of the clip up to the rounding of the blend factor b -- exactly 0 for ~5 lookups in 6: the row is then the full build bit for bit --
-// so for b <= PHC_AMP_TABLE_BLEND_TOL frame k's observation is (1 - b) T[f0] + b T[f1] (first-order; error ~1e-6); any other lookup (a few % land
-// just BELOW the next frame, b ~ 1: the reference's slerp then still averages the previous pair, which row f1 does not hold) is built in full.
+// so for b <= PHC_AMP_TABLE_BLEND_TOL frame k's observation is (1 - b) T[f0] + b T[f1]; any other lookup (a few % land just BELOW the next frame,
+// b ~ 1: the reference's slerp then still averages the previous pair, which row f1 does not hold) is built in full.
+// Error of the first-order form: T[f1] is the build for the pair (f1, f1 + 1), not the pair (f0, f1) at blend 1, so the deviation from the full
+// build is bounded by b * |T[f1] - build(f0, f1, 1)| + O(b^2) <= 1e-4 x (how far a column moves between consecutive frames): <= 1e-4 even for a
+// velocity column that changes by a full unit per frame, i.e. inside the north-star bar by construction; measured maximum 1.2e-6 (blend factors
+// above ~4e-5 need t / dt > 300, tests/test_env_gpu.py::test_reset_amp_history_from_the_per_frame_table_equals_the_lookups compares at 2e-5).
 // `nl` lanes.  All loads of a chunk are requested before its stores.
 #define PHC_AMP_TABLE_BLEND_TOL 1e-4f
 PHC_HD void amp_obs_from_table_lane(const phc_motion_lib_t& lib, const phc_im_params_t& prm, int nb, int j, int nl, int64_t mid, float t, float* a) {

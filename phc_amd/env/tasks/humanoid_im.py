@@ -17,6 +17,7 @@ There is no CPU fallback: constructing the task without a HIP device raises.
 """
 from collections import OrderedDict
 from enum import Enum
+import itertools
 
 import os
 
@@ -30,6 +31,8 @@ from ...motion_lib import FixHeightMode, MotionLibReal, MotionLibSMPL
 from ... import robots
 from ...utils.flags import flags
 from ...utils.synthetic_motion import make_motion_dict, make_robot_motion_dict
+
+_GENERATION = itertools.count(1)   # serial numbers behind HumanoidIm.launch_generation()
 
 SMPL_MUJOCO_NAMES = ['Pelvis', 'L_Hip', 'L_Knee', 'L_Ankle', 'L_Toe', 'R_Hip', 'R_Knee', 'R_Ankle', 'R_Toe', 'Torso', 'Spine',
                      'Chest', 'Neck', 'Head', 'L_Thorax', 'L_Shoulder', 'L_Elbow', 'L_Wrist', 'L_Hand', 'R_Thorax', 'R_Shoulder',
@@ -544,29 +547,43 @@ class HumanoidIm:
             remove_base_rot=not self._has_upright_start, self_obs_extra=self._self_obs_extra, amp_obs_extra=self._amp_obs_extra,
             zero_out_far_train=self._far_start, zero_out_far_steps=self._zero_out_far_steps, cycle_motion_xp=self.cycle_motion_xp)
         self._flag_state = (flags.im_eval, flags.no_collision_check)
+        self._im_params_gen = next(_GENERATION)   # (launch_generation(): a captured launch holds this struct BY VALUE)
 
     def _buffers(self, amp_in, amp_out):
         """The phc_im_buffers_t of a launch.  Building the struct costs ~20 us of host time (thirty data_ptr() calls and ctypes stores) and a rollout
-        step needs two; the combinations that occur (AMP window position x reset-list slot) are few, every other pointer is fixed for the
-        task's lifetime: cached (the rollout is host-bound, profiles/r02_notes.md)."""
-        key = (amp_in.data_ptr(), amp_out.data_ptr(), self._reset_slot, None if self._occl_mask is None else self._occl_mask.data_ptr(),
-               None if self._offset_rand is None else self._offset_rand.data_ptr(), self._sampled_motion_ids.data_ptr(), self._motion_ids_are_identity(),
-               self.obs_buf.data_ptr())
+        step needs two; the combinations that occur (AMP window position x reset-list slot) are few: cached (the rollout is host-bound,
+        profiles/r02_notes.md).  A cached struct holds ~25 raw pointers: the entry keeps the TENSOR OBJECTS they were taken from and is only
+        served while every one of the task's attributes still is that very object (a subclass, test or tool that rebinds a buffer gets a
+        fresh struct instead of launches through a stale pointer)."""
+        key = (amp_in.data_ptr(), amp_out.data_ptr(), self._reset_slot, self._motion_ids_are_identity())
         cache = self.__dict__.setdefault("_buffers_cache", {})
-        b = cache.get(key)
-        if b is None:
+        tensors = self._buffer_tensors()
+        hit = cache.get(key)
+        if hit is None or len(hit[1]) != len(tensors) or any(a is not b for a, b in zip(hit[1], tensors)):
             if len(cache) > 256:
                 cache.clear()
-            b = cache[key] = self._buffers_uncached(amp_in, amp_out)
+            hit = cache[key] = (self._buffers_uncached(amp_in, amp_out), tensors)
+        b = hit[0]
         b.reset_list = abi.ptr(self._reset_list)     # (callers clear it for the masked sweep: restored on every use)
         return b
 
+    def _buffer_tensors(self):
+        """Every tensor whose address `_buffers_uncached` stores (the AMP windows are views of `_amp_strip`)."""
+        return (self.progress_buf, self.reset_buf, self._terminate_buf, self.rew_buf, self.reward_raw, self.obs_buf, self._sampled_motion_ids,
+                self._motion_start_times, self._motion_start_times_offset, self._global_offset, self.ref_body_pos, self.ref_body_rot,
+                self.ref_body_vel, self.ref_dof_pos, self._cycle_counter, self._recovery_counter, self._point_goal, self._cycle_phase,
+                self._reset_list, self._reset_count, self._offset_rand, self._body_state_hist, self._occl_mask, self._amp_strip, self._reset_rng_dev)
+
     def _motion_ids_are_identity(self):
         """`_sampled_motion_ids` is arange(num_envs) unless somebody assigned it (humanoid_im.py:121 sets it once; tests and tools may): checked once per
-        tensor object and in-place version, the kernels then skip the table (phc_im_buffers_t.sampled_motion_ids NULL)."""
+        tensor object and in-place version, the kernels then skip the table (phc_im_buffers_t.sampled_motion_ids NULL).  The check is a host
+        sync: `launch_generation()` refreshes it OUTSIDE any stream capture, and a capture that would still find it dirty fails loudly here
+        instead of inside hipStreamEndCapture."""
         t = self._sampled_motion_ids
         c = self.__dict__.get("_ids_identity_cache")
         if c is None or c[0] is not t or c[1] != t._version:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("_sampled_motion_ids changed since launch_generation(): the identity check (a host sync) cannot run inside a stream capture")
             c = self.__dict__["_ids_identity_cache"] = (t, t._version, bool(torch.equal(t, torch.arange(self.num_envs, device=t.device, dtype=t.dtype))))
         return c[2]
 
@@ -822,6 +839,16 @@ class HumanoidIm:
             self._reset_slot = (self._reset_slot + 1) % 3   # the kernel zeroed that counter for the next post-physics launch
             self._reset_list_pending = False
 
+    def get_env_rng_state(self):
+        """The counters behind the device-side start-time draws of `reset_done()` (phc_im_buffers_t.reset_rng_counter, advanced by every
+        post-physics launch, and the host call counter): saved with a checkpoint (IMAmpAgent.get_full_state_weights, key `env_state`) so that a
+        resumed run continues the draw sequence instead of repeating it from the top."""
+        return {"reset_rng_counter": int(self._reset_rng_dev.item()), "reset_counter": int(self._reset_counter)}
+
+    def set_env_rng_state(self, state):
+        self._reset_rng_dev.fill_(int(state.get("reset_rng_counter", 0)))
+        self._reset_counter = int(state.get("reset_counter", 0))
+
     def whole_step_capturable(self):
         """True when reset_done() + step() consist of launches and host bookkeeping only (no host-side random draws or syncs between them), so that
         the learner may capture them, with its own policy / critic segments, into ONE hipGraph per rollout step."""
@@ -832,8 +859,25 @@ class HumanoidIm:
 
     def rollout_step_key(self):
         """What a captured rollout step depends on besides the step index: the reset-list slot and whether a list is pending (the AMP window position
-        is normalised by align_amp_window())."""
+        is normalised by align_amp_window()).  Everything else a captured env launch bakes in is covered by `launch_generation()`."""
         return (self._reset_slot, self._reset_list_pending, self._amp_head)
+
+    def launch_generation(self):
+        """A token that changes whenever anything changes that the env launches take BY VALUE or by raw pointer besides the per-step buffers:
+        the motion library (`phc_motion_lib_t`: frames, motion_lengths, length_starts -- re-allocated by every `load_motions`, i.e. by
+        `resample_motions()`, and swapped by `im_eval.evaluate`), the parameter struct (`phc_im_params_t`, rebuilt when the evaluation flags
+        flip) with its AMP reference table (re-built per library), and the clip-id table mode.  A learner that replays captured env launches
+        (IMAmpAgent.play_steps) compares it BEFORE every rollout and drops its graphs when it moved (a replay after
+        `resample_motions()` / `evaluate()` read freed library memory).  Called outside stream capture: it also performs the host-side refreshes a
+        replay skips (parameter rebuild, AMP table, identity check of the clip-id table -- a host sync)."""
+        if (flags.im_eval, flags.no_collision_check) != self._flag_state:
+            self._rebuild_im_params()
+        self._ensure_amp_ref_table()
+        lib = self._motion_lib
+        if "_serial" not in lib.__dict__:
+            lib._serial = next(_GENERATION)
+        return (lib._serial, getattr(lib, "frames_epoch", 0), self.__dict__.get("_amp_ref_gen", 0), self._im_params_gen, self._motion_ids_are_identity(),
+                self._sampled_motion_ids.data_ptr())
 
     def align_amp_window(self):
         """Move the AMP history window to the top of its strip (head = S), as after every S-th step: a rollout that starts from there visits the same
@@ -918,16 +962,24 @@ class HumanoidIm:
         frames change (re-sampled motions), re-attached when the parameter struct was rebuilt."""
         lib = self._motion_lib
         frames = lib.frames
-        key = (id(lib), getattr(lib, "frames_epoch", 0), frames.data_ptr(), tuple(frames.shape), frames._version)
-        c = self.__dict__.get("_amp_ref_cache")
+        key = (getattr(lib, "frames_epoch", 0), frames.data_ptr(), tuple(frames.shape), frames._version)
+        c = lib.__dict__.get("_amp_ref_cache")    # kept ON the library object: the train library keeps its table across an evaluation sweep
         if c is None or c[0] != key:
             table = None
             steps = self.dt * 30.0
             width = self._num_amp_obs_per_step - (0 if self._amp_obs_extra is None else self._amp_obs_extra.shape[1])
+            cap_gib = float(self.cfg["env"].get("amp_ref_table_max_gib", 16.0))
+            nbytes = frames.shape[0] * width * 4
+            # not in evaluation / test mode: the sweep re-loads the library for every batch of clips (a table build + stream sync each) and
+            # resets every env once per batch -- the full builds are cheaper there
             ok = (self.cfg["env"].get("amp_ref_table", True) and not os.environ.get("PHC_NO_AMP_REF_TABLE") and abs(steps - round(steps)) < 1e-6 and round(steps) >= 1
-                  and bool(torch.all(torch.abs(lib._motion_dt - 1.0 / 30.0) < 1e-7)) and frames.shape[0] * width * 4 <= 16 * 2 ** 30)
+                  and not (flags.im_eval or flags.test or lib.m_cfg.get("im_eval", False))
+                  and bool(torch.all(torch.abs(lib._motion_dt - 1.0 / 30.0) < 1e-7)) and nbytes <= cap_gib * 2 ** 30)
             if ok:
                 table = torch.empty((frames.shape[0], width), dtype=torch.float32, device=self.device)
+                if nbytes >= 2 ** 30 and int(self.cfg.get("rank", 0)) == 0:
+                    print(f"[phc_amd] AMP reference table: {frames.shape[0]} frames x {width} floats = {nbytes / 2 ** 30:.2f} GiB "
+                          f"(env.amp_ref_table_max_gib={cap_gib:g}, env.amp_ref_table=False turns it off)", flush=True)
                 nxt = torch.arange(1, frames.shape[0] + 1, dtype=torch.long, device=self.device)
                 last = (lib.length_starts + lib._motion_num_frames.to(torch.long) - 1).to(torch.long)
                 nxt[last] = last                       # the last frame of a clip pairs with itself (idx1 = min(idx0 + 1, nf - 1))
@@ -935,7 +987,8 @@ class HumanoidIm:
                 L.check(self._lib.phc_amp_ref_table(self._model_struct, lib.struct, self._im_params, frames.shape[0], nxt.data_ptr(), table.data_ptr(),
                                                     _stream()), "phc_amp_ref_table")
                 torch.cuda.current_stream(self.device).synchronize()   # (`nxt` is released right after)
-            c = self._amp_ref_cache = (key, table)
+            c = lib._amp_ref_cache = (key, table, next(_GENERATION))
+        self._amp_ref_gen = c[2]
         self._im_params.amp_ref_table = abi.ptr(c[1])
 
     def _one_hot_obs(self):

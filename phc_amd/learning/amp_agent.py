@@ -415,6 +415,15 @@ class IMAmpAgent:
         terminated_flags = self._terminated_flags.zero_()
         if self._reward_raw_acc is not None:
             self._reward_raw_acc.zero_()
+        # captured env launches hold the motion library, the parameter struct and the AMP reference table by value / raw pointer: when the task
+        # says any of them moved (resample_motions(), evaluate() swapping libraries, flipped evaluation flags), every captured graph is dropped and
+        # re-captured against the new objects (tests/test_env_gpu.py::test_rollout_graphs_follow_resample_motions_and_evaluate)
+        gen = task.launch_generation() if hasattr(task, "launch_generation") else None
+        if gen != getattr(self, "_roll_generation", None):
+            if self._roll_graphs:
+                torch.cuda.synchronize()
+                self._roll_graphs.clear()
+            self._roll_generation = gen
         done_indices = []
         net = self.model.a2c_network
         fused = e["obses"].is_cuda
@@ -1122,6 +1131,8 @@ class IMAmpAgent:
             s["reward_mean_std"] = self.value_mean_std.state_dict()
         if self._amp_input_mean_std is not None:
             s["amp_input_mean_std"] = self._amp_input_mean_std.state_dict()
+        if hasattr(self.task, "get_env_rng_state"):   # (an extra key: the reference's loaders read the keys above by name)
+            s["env_state"] = self.task.get_env_rng_state()
         return s
 
     def set_full_state_weights(self, w, load_optimizer=True):
@@ -1135,6 +1146,8 @@ class IMAmpAgent:
                 mod.load_state_dict(w[key])
         if self.grads.shadow is not None:
             self.grads.shadow.copy_(self.grads.flat_param)
+        if "env_state" in w and hasattr(self.task, "set_env_rng_state"):
+            self.task.set_env_rng_state(w["env_state"])
 
     def save(self, path):
         torch.save(self.get_full_state_weights(), path)

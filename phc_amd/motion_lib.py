@@ -202,14 +202,80 @@ def process_clip_real(parents, local_translation, local_rotation_wxyz, ext_paren
                 gts_t=wpos, grs_t=wrot, gvs_t=vel(wpos), gavs_t=_angular_velocity(wrot, dt), dof_pos=dof_pos, dvs=dvs, lrs=pq)
 
 
-_JOB_CTX = None   # (library, tree, max_len) of the load_motions call in flight: forked workers inherit it (nothing big is pickled)
+# ---- clip workers (load_motions pass 2) ------------------------------------------------------------------------------------------------
+# FK + finite-difference velocities of one clip crop are numpy fp64 on the host cores; a library draw for thousands of envs (BASELINE
+# configs[2]: ~5 800 distinct clips for 8 192 envs, 17 ms each) spreads them over a process pool.  The pool's workers come from a FORKSERVER
+# (round 4; it was `fork`): load_motions runs -- and `resample_motions()` re-runs it in the middle of training -- in a process that holds a HIP
+# context, torch's thread pools and, with several ranks, RCCL's proxy / watchdog threads; forking THAT process copies locked mutexes and a device
+# context into the children (the classic multi-GPU hang).  The fork server is a fresh interpreter started before any of this matters for it: it
+# never touches the device, workers forked from it inherit nothing of the caller.  What a worker needs is therefore PICKLED: per worker once
+# the constants of the clip family (`_clip_consts`: skeleton arrays / robot model arrays -- no motion data), per job the cropped clip arrays.
+_WORKER_CONSTS = None
 
 
-def _process_job(job):
-    """One distinct clip (worker of the fork pool in load_motions; numpy only -- the forked children never touch the device)."""
-    u, start, t = job
-    lib, trees, max_len = _JOB_CTX
-    return lib._process_unique_clip(lib._motion_data_list[u], trees[t], max_len, start)
+def _set_worker_consts(consts):
+    global _WORKER_CONSTS
+    _WORKER_CONSTS = consts
+
+
+def _run_clip_job(payload, consts=None):
+    """One distinct (clip crop, skeleton) pair -> (packed fp32 frame records [T, stride], fps, T).  Pure numpy."""
+    c = _WORKER_CONSTS if consts is None else consts
+    if c["kind"] == "smpl":
+        t, g, trans, fps = payload
+        parents, local_translation = c["trees"][t]
+        proc = process_clip(parents, local_translation, g, trans, fps)
+        f = {k: proc[k].astype(np.float32) for k in ("gts", "grs", "gvs", "gavs", "lrs", "dvs")}
+        return abi.pack_frames(f["gts"], f["grs"], f["gvs"], f["gavs"], f["lrs"], f["dvs"]), fps, g.shape[0]
+    t, pose_aa, trans, fps = payload
+    if c["fix_height"]:
+        # motion_lib_real.py:61-72: shift the clip so that the lowest point of the robot in its FIRST frame touches z = 0.  The reference takes the
+        # minimum over all mesh vertices; here the links' convex-hull support points (the points the stepper uses for ground contact) stand in
+        # for the meshes, which are not shipped with the package.
+        wpos, wmat, _, _ = robot_fk(c["parent"], c["local_translation"], c["local_rotation"], c["ext_parent"], c["ext_pos"], c["ext_rot"], pose_aa[:1], trans[:1])
+        z = wpos[0][c["contact_body"], 2] + np.einsum("kj,kj->k", wmat[0][c["contact_body"]][:, 2, :], c["contact_pos"]) - c["contact_radius"]
+        trans = trans.copy()
+        trans[:, 2] -= float(z.min())
+    proc = process_clip_real(c["parent"], c["local_translation"], c["local_rotation"], c["ext_parent"], c["ext_pos"], c["ext_rot"], pose_aa, trans, fps)
+    nb = c["num_bodies"]
+    f = {k: proc[k].astype(np.float32) for k in ("gts", "grs", "gvs", "gavs", "dof_pos", "dvs", "gts_t", "grs_t")}
+    packed = abi.pack_frames(f["gts"], f["grs"], f["gvs"], f["gavs"], None, f["dvs"], gts_ext=f["gts_t"][:, nb:], grs_ext=f["grs_t"][:, nb:], dof_pos=f["dof_pos"])
+    return packed, int(fps), trans.shape[0]   # fk_batch returns fps = int(1 / dt) (torch_humanoid_batch.py:219)
+
+
+_POOL = {}
+
+
+def _clip_pool(workers):
+    """The process pool behind load_motions, created on first use and kept for the life of the process (a `resample_motions()` every few hundred
+    epochs re-uses it).  Context: forkserver (see above); `PHC_MOTION_POOL_CONTEXT=spawn` selects spawn."""
+    import multiprocessing as mp
+    key = (os.getpid(), workers)
+    if key not in _POOL:
+        for k in list(_POOL):            # (a pool inherited through somebody else's fork belongs to the parent)
+            if k[0] == os.getpid():
+                _POOL.pop(k).terminate()
+            else:
+                _POOL.pop(k)
+        ctx = mp.get_context(os.environ.get("PHC_MOTION_POOL_CONTEXT", "forkserver"))
+        if ctx.get_start_method() == "forkserver":
+            ctx.set_forkserver_preload(["phc_amd.motion_lib"])   # numpy / torch / this module are imported once, in the server
+        _POOL[key] = ctx.Pool(workers)
+        import atexit
+        atexit.register(_close_pools)
+    return _POOL[key]
+
+
+def _close_pools():
+    for k in list(_POOL):
+        pool = _POOL.pop(k)
+        if k[0] == os.getpid():
+            pool.terminate()
+
+
+def _run_clip_chunk(args):
+    consts, payloads = args
+    return [_run_clip_job(p, consts) for p in payloads]
 
 
 class MotionLibBase:
@@ -305,23 +371,22 @@ class MotionLibBase:
             yaws.append(self._draw_heading(rs))
         # pass 2 -- FK + velocities ONCE per distinct clip (fp64 on the host cores; a fork pool when there are many: cfg 3 samples
         # ~5 800 distinct clips of the 11 313 for 8 192 envs, 17 ms each)
-        global _JOB_CTX
-        _JOB_CTX = (self, trees, max_len)
-        jobs = [(u, crop[u], t) for u, t in uniq]
+        consts = self._clip_consts(trees)
+        jobs = [self._clip_payload(self._motion_data_list[u], t, max_len, crop[u]) for u, t in uniq]
         workers = int(self.m_cfg.get("num_workers", 0)) or min(32, max(1, (os.cpu_count() or 1) // 2))
-        if len(jobs) >= 256 and workers > 1:
-            import multiprocessing as mp
-            with mp.get_context("fork").Pool(workers) as pool:
-                done = pool.map(_process_job, jobs, chunksize=max(1, len(jobs) // (workers * 8)))
+        if len(jobs) >= int(self.m_cfg.get("pool_min_jobs", 256)) and workers > 1:
+            # chunks of jobs, each carrying the (small) constants: no per-worker state to set up or to go stale between calls
+            per = max(1, -(-len(jobs) // (workers * 8)))
+            chunks = [(consts, jobs[i:i + per]) for i in range(0, len(jobs), per)]
+            done = [r for part in _clip_pool(workers).map(_run_clip_chunk, chunks, chunksize=1) for r in part]
         else:
-            done = [_process_job(j) for j in jobs]
-        _JOB_CTX = None
+            done = [_run_clip_job(j, consts) for j in jobs]
         slot = {ut: k for k, ut in enumerate(uniq)}
         # pass 3 -- one packed fp32 record array per DISTINCT clip goes to the device once; the per-env copies (the reference keeps one
         # clip copy per env, motion_lib_base.py:300-307) are a device-side gather, and the per-env heading a device-side rotation
         dev = self._device
         self.num_bodies = self.num_joints
-        packed = [self._pack_one(proc) for proc, _, _ in done]
+        packed = [rec for rec, _, _ in done]
         u_nf = np.array([p.shape[0] for p in packed], dtype=np.int64)
         u_start = np.concatenate([[0], np.cumsum(u_nf)[:-1]])
         uniq_frames = torch.from_numpy(np.concatenate(packed, axis=0)).to(dev)
@@ -373,15 +438,23 @@ class MotionLibBase:
         randomize = (not flags.im_eval) and (not flags.test) and self.m_cfg.get("randomrize_heading", True)
         return float(np.pi * (2 * rs.random_sample() - 1.0)) if randomize else None
 
-    def _process_unique_clip(self, clip, tree, max_len, start):
-        """motion_lib_smpl.py:101-180 up to (not including) the per-env heading."""
+    def _clip_consts(self, trees):
+        """Per-family constants of the clip workers (picklable, numpy only; no motion data)."""
+        return {"kind": "smpl", "trees": [(np.asarray(t.parent_indices), np.asarray(t.local_translation)) for t in trees]}
+
+    def _clip_payload(self, clip, tree_index, max_len, start):
+        """One job of the clip workers: the crop of the clip's arrays (motion_lib_smpl.py:101-180 up to, not including, the per-env heading)."""
         trans = clip["root_trans_offset"]
         trans = trans.numpy() if isinstance(trans, torch.Tensor) else np.asarray(trans)
         g = np.asarray(clip["pose_quat_global"])
         if start is not None:
             g, trans = g[start:start + max_len], trans[start:start + max_len]
-        proc = process_clip(np.asarray(tree.parent_indices), np.asarray(tree.local_translation), g, trans, clip.get("fps", 30))
-        return proc, clip.get("fps", 30), g.shape[0]
+        return tree_index, np.ascontiguousarray(g), np.ascontiguousarray(trans), clip.get("fps", 30)
+
+    def _process_unique_clip(self, clip, tree, max_len, start):
+        """(kept for tools) FK + velocities of one clip on skeleton `tree`: (proc dict, fps, frames)."""
+        _, g, trans, fps = self._clip_payload(clip, 0, max_len, start)
+        return process_clip(np.asarray(tree.parent_indices), np.asarray(tree.local_translation), g, trans, fps), fps, g.shape[0]
 
     def _clip_pose_aa(self, clip, nf, start=None):
         if "pose_aa" in clip:
@@ -610,18 +683,29 @@ class MotionLibReal(MotionLibBase):
     def _draw_heading(self, rs):
         return None
 
-    def _process_unique_clip(self, clip, tree, max_len, start):
+    def _clip_consts(self, trees):
+        m = self.robot_model
+        return {"kind": "robot", "parent": np.asarray(m.parent), "local_translation": np.asarray(m.local_translation),
+                "local_rotation": np.asarray(m.local_rotation), "ext_parent": self.ext_parent, "ext_pos": self.ext_pos, "ext_rot": self.ext_rot,
+                "contact_body": np.asarray(m.contact_body), "contact_pos": np.asarray(m.contact_pos), "contact_radius": np.asarray(m.contact_radius),
+                "fix_height": self.fix_height != FixHeightMode.no_fix, "num_bodies": int(self.num_joints)}
+
+    def _clip_payload(self, clip, tree_index, max_len, start):
         trans = clip["root_trans_offset"]
         trans = (trans.numpy() if isinstance(trans, torch.Tensor) else np.asarray(trans)).astype(np.float64)
         pose_aa = clip["pose_aa"]
         pose_aa = (pose_aa.numpy() if isinstance(pose_aa, torch.Tensor) else np.asarray(pose_aa)).astype(np.float64)
         if start is not None:
             trans, pose_aa = trans[start:start + max_len], pose_aa[start:start + max_len]
+        return tree_index, np.ascontiguousarray(pose_aa), np.ascontiguousarray(trans), clip.get("fps", 30)
+
+    def _process_unique_clip(self, clip, tree, max_len, start):
+        """(kept for tools) (proc dict, fps, frames) of one clip."""
+        _, pose_aa, trans, fps = self._clip_payload(clip, 0, max_len, start)
         trans, _ = self.fix_trans_height(pose_aa, trans)
         m = self.robot_model
-        fps = clip.get("fps", 30)
         proc = process_clip_real(m.parent, m.local_translation, m.local_rotation, self.ext_parent, self.ext_pos, self.ext_rot, pose_aa, trans, fps)
-        return proc, int(fps), trans.shape[0]   # fk_batch returns fps = int(1 / dt) (torch_humanoid_batch.py:219)
+        return proc, int(fps), trans.shape[0]
 
     def _clip_pose_aa(self, clip, nf, start=None):
         return np.zeros((nf, self.num_joints * 3), dtype=np.float32)   # motion_lib_real.py:171-173: no "beta" -> zeros

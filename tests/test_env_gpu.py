@@ -993,8 +993,8 @@ def test_reset_amp_history_from_the_per_frame_table_equals_the_lookups():
     tb, eb = make_task(256, motion="synthetic:5:1", **{"+env.amp_ref_table": False})
     torch.manual_seed(3); ea.reset()
     torch.manual_seed(3); eb.reset()
-    assert ta._amp_ref_cache[1] is not None and ta._amp_ref_cache[1].shape == (ta._motion_lib.frames.shape[0], 196) and tb._amp_ref_cache[1] is None
-    assert torch.isfinite(ta._amp_ref_cache[1]).all()
+    assert ta._motion_lib._amp_ref_cache[1] is not None and ta._motion_lib._amp_ref_cache[1].shape == (ta._motion_lib.frames.shape[0], 196) and tb._motion_lib._amp_ref_cache[1] is None
+    assert torch.isfinite(ta._motion_lib._amp_ref_cache[1]).all()
     close = lambda x, y: np.testing.assert_allclose(x.cpu().numpy(), y.cpu().numpy(), rtol=0, atol=5e-6)
     close(ta._amp_obs_buf, tb._amp_obs_buf)
     assert float((ta._amp_obs_buf == tb._amp_obs_buf).float().mean()) > 0.7      # (the lookups with blend factor 0: bit-equal)
@@ -1021,14 +1021,14 @@ def test_reset_amp_history_from_the_per_frame_table_equals_the_lookups():
         assert float(ta._motion_start_times.abs().max()) == 0.0
     finally:
         flags.test = False
-    old = ta._amp_ref_cache[1]
+    old = ta._motion_lib._amp_ref_cache[1]
     torch.manual_seed(9); ta.resample_motions()
     torch.manual_seed(9); tb.resample_motions()
-    assert ta._amp_ref_cache[1] is not old
+    assert ta._motion_lib._amp_ref_cache[1] is not old
     close(ta._amp_obs_buf, tb._amp_obs_buf)
     th, eh = make_task(64, motion="synthetic:3:2:2.0", **H1_OVER)
     eh.reset()
-    assert th._amp_ref_cache[1] is None and abs(th.dt - 0.02) < 1e-9
+    assert th._motion_lib._amp_ref_cache[1] is None and abs(th.dt - 0.02) < 1e-9
 
 
 def test_enable_hist_obs_appends_the_amp_history_as_it_stood_before_the_step():
@@ -1170,3 +1170,57 @@ def test_whole_rollout_step_in_one_graph_equals_eager_launches():
     fresh = torch.stack(starts)                                        # [45, N]: envs that reset several times drew different start times
     resets = (fresh[1:] != fresh[:-1]).sum(0)
     assert int((resets >= 2).sum()) > 50 and int(torch.unique(fresh).numel()) > 100
+
+
+def _check_task_tracks_its_current_library(task, tag):
+    """After a rollout: the reference side buffers (written by the last post-physics launch) and the AMP history of the envs the last reset launch
+    touched must come from the task's CURRENT motion library -- a captured launch replayed against a library that has since been re-loaded or
+    swapped reads freed memory instead."""
+    torch.cuda.synchronize()
+    t = (task.progress_buf + 1).float() * task.dt + task._motion_start_times + task._motion_start_times_offset
+    res = task._motion_lib.get_motion_state(task._sampled_motion_ids, t, task._global_offset)
+    np.testing.assert_allclose(task.ref_body_pos.cpu().numpy(), res["rg_pos"].cpu().numpy(), atol=2e-5, err_msg=f"{tag}: reference bodies of the last step")
+    e = (task.progress_buf == 1).nonzero(as_tuple=False).squeeze(-1)
+    assert len(e) > 0, tag
+    demo = task.build_amp_obs_demo(task._sampled_motion_ids[e], task._motion_start_times[e])   # row k: the clip at start - k dt
+    np.testing.assert_allclose(task._amp_obs_buf[e][:, 1:].cpu().numpy(), demo[:, :-1].cpu().numpy(), atol=2e-5, err_msg=f"{tag}: AMP history of freshly reset envs")
+
+
+def test_rollout_graphs_follow_resample_motions_and_evaluate():
+    """the whole-rollout-step hipGraphs bake `phc_motion_lib_t`, `phc_im_params_t` (with the AMP reference table) and the buffer
+    struct into the captured env kernels.  `resample_motions()` re-allocates the library, `evaluate()` swaps it (and the table) and flips the
+    evaluation flags: `launch_generation()` moves, the learner drops its graphs and captures new ones -- and the replayed launches keep tracking the
+    task's current library, exactly like eager launches do."""
+    from phc_amd.learning.amp_agent import IMAmpAgent
+    over = {"learning.params.config.minibatch_size": 2048, "learning.params.config.amp_obs_demo_buffer_size": 4096,
+            "learning.params.config.amp_replay_buffer_size": 4096}
+    runs = {}
+    for mode in ("graph", "eager"):
+        task, env = make_task(256, motion="synthetic:6:1:1.5", seed=5, **dict(over, **({"+learning.params.config.hip_graph": True} if mode == "graph" else {})))
+        agent = IMAmpAgent(env, task.cfg)
+        agent.init_train()
+        for _ in range(3):
+            agent.train_epoch()                      # rollout graphs are captured from the third epoch on
+        if mode == "graph":
+            assert any(k[0] == "step" for k in agent._roll_graphs), "whole-step graphs in use"
+        _check_task_tracks_its_current_library(task, f"{mode}: before")
+        gens = [task.launch_generation()]
+        frames0 = task._motion_lib.frames
+        task.resample_motions()                      # new frames / lengths / starts tensors, new AMP table
+        assert task._motion_lib.frames is not frames0
+        gens.append(task.launch_generation())
+        for _ in range(2):
+            agent.train_epoch()
+        _check_task_tracks_its_current_library(task, f"{mode}: after resample_motions()")
+        lib_train = task._motion_lib
+        info, failed = agent.eval()                  # eval library in, flags flipped, params rebuilt, table rebuilt -- and everything back
+        assert task._motion_lib is lib_train
+        gens.append(task.launch_generation())
+        for _ in range(2):
+            agent.train_epoch()
+        _check_task_tracks_its_current_library(task, f"{mode}: after evaluate()")
+        assert len(set(gens)) == 3, gens
+        if mode == "graph":
+            assert agent._roll_generation == gens[-1] and any(k[0] == "step" for k in agent._roll_graphs)
+        runs[mode] = np.isfinite(info["eval/mpjpe_all"])
+    assert all(runs.values())

@@ -8,6 +8,7 @@ import pytest
 import phc_oracle as po
 
 TOL = dict(rtol=0, atol=1e-4)  # north_star: <=1e-4 on FK / quaternion floats
+F = np.float32
 
 
 def test_quat_kat(golden):
@@ -161,3 +162,47 @@ def test_amp_observation_oracle_upright_and_shape_columns(golden):
                                                  g["dof_vel"], g["body_pos"][:, kid], sub, local_root_obs=local_root, upright=upright,
                                                  shape_params=gs["shape"], limb_weight_params=gs["limb"])
             np.testing.assert_allclose(got, gs[f"amp_l{int(local_root)}u{int(upright)}"], atol=2e-6)
+
+
+@pytest.mark.parametrize("rb", ["h1", "g1"])
+def test_robot_oracle_functions_vs_reference_goldens(golden, rb):
+    """The numpy restatements of the robot path (MotionLibReal lookup, extended bodies, reward over NB + E bodies, self / task observation
+    on robot shapes, robot AMP observation) against the goldens of oracle/gen_golden_h1.py -- outputs of the reference's own
+    `MotionLibReal.get_motion_state` and jit functions.  These restatements are what the -m gpu tests at BASELINE configs[4]'s own size
+    (4096 envs) compare the HIP path with."""
+    g, t = golden(f"motion_lib_{rb}"), golden(f"task_fns_{rb}")
+    lib = {k: g[k] for k in ("gts", "grs", "gvs", "gavs", "dvs", "dof_pos", "gts_t", "grs_t", "motion_lengths", "motion_dt", "motion_num_frames",
+                             "length_starts")}
+    r = po.get_motion_state_robot(lib, g["ms_ids"], g["ms_times"].astype(F), g["ms_offset"].astype(F))
+    for k in ("rg_pos", "rb_rot", "body_vel", "body_ang_vel", "dof_pos", "dof_vel", "rg_pos_t", "rg_rot_t", "root_pos", "root_rot"):
+        np.testing.assert_allclose(r[k], g["ms_" + k], atol=2e-6, err_msg=k)
+    NB = t["body_pos"].shape[1]
+    dt = F(4 * (1 / 200))
+    mt = (t["progress"].astype(F) * dt + t["start_times"]).astype(F)
+    r0 = po.get_motion_state_robot(lib, t["env_motion"], mt, np.zeros((len(mt), 3), F))
+    r1 = po.get_motion_state_robot(lib, t["env_motion"], ((t["progress"] + 1).astype(F) * dt + t["start_times"]).astype(F), np.zeros((len(mt), 3), F))
+    bpe, bre = po.extend_bodies(t["body_pos"], t["body_rot"], t["ext_parent"], t["ext_pos"])
+    rew, raw = po.compute_imitation_reward(bpe, bre, t["body_vel"], t["body_ang_vel"], np.concatenate([r0["rg_pos"], r0["rg_pos_t"][:, NB:]], 1),
+                                           np.concatenate([r0["rb_rot"], r0["rg_rot_t"][:, NB:]], 1), r0["body_vel"], r0["body_ang_vel"])
+    np.testing.assert_allclose(raw, t["reward_raw"], atol=2e-6)
+    np.testing.assert_allclose(rew, t["reward"], atol=2e-6)
+    np.testing.assert_allclose(po.power_reward(t["dof_force"], t["dof_vel"], t["progress"]), t["power_reward"], rtol=1e-6, atol=1e-6)
+    reset, term = po.compute_humanoid_im_reset(t["progress"], t["body_pos"], r0["rg_pos"], mt >= lib["motion_lengths"][t["env_motion"]],
+                                               np.full((len(mt), NB), 0.25, F))
+    np.testing.assert_array_equal(reset, t["reset"])
+    np.testing.assert_array_equal(term, t["terminate"])
+    np.testing.assert_allclose(po.compute_humanoid_observations_smpl_max(t["body_pos"], t["body_rot"], t["body_vel"], t["body_ang_vel"]), t["self_obs"], atol=3e-6)
+    to = po.compute_imitation_observations_v6(t["body_pos"][:, 0], t["body_rot"][:, 0], t["body_pos"], t["body_rot"], t["body_vel"], t["body_ang_vel"],
+                                              r1["rg_pos"], r1["rb_rot"], r1["body_vel"], r1["body_ang_vel"])
+    np.testing.assert_allclose(to, t["task_obs"], atol=5e-6)
+    amp = po.build_amp_observations_robot(t["body_pos"][:, 0], t["body_rot"][:, 0], t["body_vel"][:, 0], t["body_ang_vel"][:, 0], t["dof_pos"], t["dof_vel"],
+                                          t["body_pos"][:, t["key_body_ids"]])
+    np.testing.assert_allclose(amp, t["amp_obs"], atol=2e-6)
+
+
+@pytest.mark.parametrize("tag", ["h1_pdv1", "h1_pdv2", "g1_pdv1"])
+def test_pd_torque_oracle_vs_reference_compute_torques(golden, tag):
+    """`compute_torques_pd` == the reference's own `Humanoid._compute_torques` (oracle/gen_golden_torques.py), bit for bit."""
+    g = {k.split("/", 1)[1]: v for k, v in golden("pd_torques").items() if k.startswith(tag + "/")}
+    tq = po.compute_torques_pd(g["actions"], g["dof_pos"], g["dof_vel"], g["p_gains"], g["d_gains"], g["default_dof_pos"][0], g["torque_limits"])
+    np.testing.assert_array_equal(tq, g["torques"])
