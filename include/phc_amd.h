@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PHC_ABI_VERSION 33
+#define PHC_ABI_VERSION 34
 #define PHC_MAX_BODIES 64   /* bodies (incl. extended reference bodies) per articulation; also the slot count of the model tables */
 #define PHC_EINVAL (-1)
 #define PHC_EUNSUPPORTED (-2)
@@ -124,6 +124,22 @@ typedef struct {
                                          1 env); other values PHC_EUNSUPPORTED (2 was the two-bodies-per-lane kernel of rounds 1-2, removed in ABI 31) */
     int32_t num_force_sensors;        /* S <= 4: force sensors (env.force_sensor_joints, default L_Ankle / R_Ankle, humanoid.py:268) */
     int32_t force_sensor_body[4];     /* body id of each sensor */
+    /* ---- ABI 34: ground-contact model (solver.contact) ----
+     * 0 = penalty spring-damper with regularised Coulomb friction (contact_stiffness / contact_damping / friction_viscous above).
+     * 1 = rigid ("tgs"): what parse_sim_params asks PhysX for (phc/run_hydra.py:88-91 solver_type 1 = TGS, num_position_iterations 4,
+     *     phc/data/cfg/sim/default_sim.yaml contact_offset / bounce_threshold_velocity / max_depenetration_velocity) restated for the
+     *     articulated-body recursion: a velocity-level unilateral constraint per contact point, u_n(t + dt) >= v_target, enforced through
+     *     the impedance contact_impedance (N s/m; its compliance 1 / c is the constraint's CFM), v_target = min(depth / dt,
+     *     max_depenetration_velocity) for a penetrating point, -gap / dt for a speculative one inside contact_offset, and
+     *     -restitution * u_n(t) when the approach speed exceeds bounce_threshold_velocity; Coulomb cone |F_t| <= mu F_n evaluated on the
+     *     END-of-step normal force and slip velocity; active set and cone are found by contact_iterations fixed-point passes, each an exact
+     *     O(n) articulated-body solve of the whole tree with the contact impedances of the previous pass. */
+    int32_t contact_model;
+    int32_t contact_iterations;       /* passes per sub-step in model 1 (PhysX num_position_iterations: 4); >= 2 */
+    float contact_impedance;          /* model 1: N s/m per contact point (default 1e5: dt * c = 833 kg of apparent mass per point) */
+    float max_depenetration_velocity; /* m/s (default_sim.yaml: 10) */
+    float bounce_threshold_velocity;  /* m/s (default_sim.yaml: 0.2) */
+    float restitution;                /* plane / shape restitution (env_im.yaml plane.restitution: 0) */
 } phc_sim_params_t;
 
 /* Imitation-task parameters (phc/env/tasks/humanoid_im.py:37-123, env_im.yaml). */

@@ -18,6 +18,11 @@ Only tests and bench.py's cpu_baseline leg import this file.
 import numpy as np
 
 
+def cross3(a, b):
+    """a x b for 3-vectors (numpy's general `cross` spends 30 us per call on axis bookkeeping; the oracle calls it ~300 times per evaluation)."""
+    return np.array([a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]])
+
+
 def skew(a):
     return np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]], dtype=np.float64)
 
@@ -115,7 +120,10 @@ class State:
 
 DEFAULT_PARAMS = dict(gravity_z=-9.81, contact_stiffness=1.0e5, contact_damping=1.0e3, friction=1.0, friction_viscous=2.0e3,
                       angular_damping=0.01, max_angular_velocity=100.0, control_mode=0, limit_stiffness=0.0, limit_damping=0.0,
-                      self_collision=0, self_stiffness_scale=0.25, self_damping_ratio=0.5)
+                      self_collision=0, self_stiffness_scale=0.25, self_damping_ratio=0.5,
+                      # ground-contact model (include/phc_amd.h, ABI 34): 0 penalty, 1 rigid ("tgs")
+                      contact_model=0, contact_iterations=4, contact_impedance=1.0e5, max_depenetration_velocity=10.0,
+                      bounce_threshold_velocity=0.2, restitution=0.0, contact_offset=0.02)
 
 
 def kinematics(model, st):
@@ -146,7 +154,7 @@ def body_velocities(model, st, R, p):
             w[i], v[i] = st.w0, st.v0
         else:
             w[i] = w[par] + R[i] @ (st.S(i - 1) @ st.qd[i - 1])
-            v[i] = v[par] + np.cross(w[par], p[i] - p[par])
+            v[i] = v[par] + cross3(w[par], p[i] - p[par])
     return w, v
 
 
@@ -196,7 +204,7 @@ def self_collision_wrenches(model, R, p, w, v, prm, dt):
                 continue
             n = n / dist if dist > 1e-6 else np.array([0.0, 0.0, 1.0])
             cp = c2 + n * (cap[k, 6] - 0.5 * pen)
-            vrel = (v[i] + np.cross(w[i], cp - p[i])) - (v[k] + np.cross(w[k], cp - p[k]))
+            vrel = (v[i] + cross3(w[i], cp - p[i])) - (v[k] + cross3(w[k], cp - p[k]))
             mu = model.mass[i] * model.mass[k] / (model.mass[i] + model.mass[k])
             kk = prm["self_stiffness_scale"] * mu / (dt * dt)
             cc = 2.0 * prm["self_damping_ratio"] * np.sqrt(kk * mu)
@@ -204,7 +212,7 @@ def self_collision_wrenches(model, R, p, w, v, prm, dt):
             if fn <= 0:
                 continue
             F[i] += n * fn
-            N[i] += np.cross(cp - p[i], n * fn)
+            N[i] += cross3(cp - p[i], n * fn)
     return F, N
 
 
@@ -220,8 +228,9 @@ def explicit_torque(model, st, target, kp_scale=1.0, kd_scale=1.0):
     return np.clip(tau, -model.dof_effort, model.dof_effort), np.where(sat, np.sign(tau) * model.dof_effort, sp), sat
 
 
-def accelerations(model, st, target, params, dt, kp_scale=1.0, kd_scale=1.0, return_parts=False, tau_hold=None):
-    """Generalized accelerations nu_dot = [alpha0, a0, qdd_1..] of one implicit sub-step."""
+def accelerations(model, st, target, params, dt, kp_scale=1.0, kd_scale=1.0, return_parts=False, tau_hold=None, nud_prev=None, cstate=None):
+    """Generalized accelerations nu_dot = [alpha0, a0, qdd_1..] of one implicit sub-step.  `nud_prev` (rigid contact model): the solution of
+    the previous pass of this sub-step -- active set and friction cone are evaluated on the end-of-step velocities it predicts."""
     prm = dict(DEFAULT_PARAMS, **(params or {}))
     nb = model.num_bodies
     offs = np.concatenate([[6], 6 + np.cumsum(st.nd)]).astype(int)
@@ -249,13 +258,16 @@ def accelerations(model, st, target, params, dt, kp_scale=1.0, kd_scale=1.0, ret
     for i in range(1, nb):
         par = model.parent[i]
         r = p[i] - p[par]
-        ab_w[i] = ab_w[par] + np.cross(w[par], R[i] @ (st.S(i - 1) @ st.qd[i - 1]))
-        ab_v[i] = ab_v[par] + np.cross(ab_w[par], r) + np.cross(w[par], np.cross(w[par], r))
+        ab_w[i] = ab_w[par] + cross3(w[par], R[i] @ (st.S(i - 1) @ st.qd[i - 1]))
+        ab_v[i] = ab_v[par] + cross3(ab_w[par], r) + cross3(w[par], cross3(w[par], r))
     M = np.zeros((nv, nv))
     rhs = np.zeros(nv)
     g = np.array([0.0, 0.0, prm["gravity_z"]])
     cn = prm["contact_stiffness"] * dt + prm["contact_damping"]
     fcontact = np.zeros((nb, 3))
+    # rigid model: contact points (global index) that pushed in the previous pass / were released for the rest of the sub-step
+    cstate = cstate if cstate is not None else {"active": set(), "removed": set()}
+    act_now = set()
     for i in range(nb):
         Io = R[i] @ model.inertia_origin[i] @ R[i].T
         mc = R[i] @ (model.mass[i] * model.com[i])
@@ -265,18 +277,45 @@ def accelerations(model, st, target, params, dt, kp_scale=1.0, kd_scale=1.0, ret
         Mi[3:, :3] = -skew(mc)
         Mi[3:, 3:] = model.mass[i] * np.eye(3)
         J = np.concatenate([Jw[i], Jv[i]], axis=0)
-        bias = np.concatenate([np.cross(w[i], Io @ w[i]), np.cross(w[i], np.cross(w[i], mc))])
-        ext = np.concatenate([np.cross(mc, g), model.mass[i] * g])
+        bias = np.concatenate([cross3(w[i], Io @ w[i]), cross3(w[i], cross3(w[i], mc))])
+        ext = np.concatenate([cross3(mc, g), model.mass[i] * g])
         M += J.T @ Mi @ J
         rhs -= J.T @ (Mi @ np.concatenate([ab_w[i], ab_v[i]]) + bias - ext)
         for k in np.nonzero(model.contact_body == i)[0]:
             arm = R[i] @ model.contact_pos[k]
             rad = model.contact_radius[k]
             depth = rad - (p[i][2] + arm[2])
+            if prm["contact_model"] == 1:
+                # rigid: unilateral velocity constraint u_n(t + dt) >= v_target through the impedance c; active set and cone from the previous pass
+                if depth <= -prm["contact_offset"]:
+                    continue
+                c = prm["contact_impedance"]
+                arm = arm - np.array([0, 0, rad])
+                uc = v[i] + cross3(w[i], arm)
+                apb = ab_v[i] + cross3(ab_w[i], arm) + cross3(w[i], cross3(w[i], arm))
+                Jpt = Jv[i] - skew(arm) @ Jw[i]
+                un = uc if nud_prev is None else uc + dt * (Jpt @ nud_prev + apb)
+                vt = min(depth / dt, prm["max_depenetration_velocity"]) if depth > 0 else depth / dt
+                if prm["restitution"] > 0 and -uc[2] > prm["bounce_threshold_velocity"]:
+                    vt = max(vt, -prm["restitution"] * uc[2])
+                lam = c * (vt - un[2])
+                if lam <= 0:   # idle -- or released: it pushed in the last pass and would have to pull (phc_aba.h aba_ground_contact_rigid)
+                    if k in cstate["active"]:
+                        cstate["removed"].add(k)
+                    continue
+                if k in cstate["removed"]:
+                    continue
+                act_now.add(k)
+                ct = rigid_ct(prm, lam, uc, un)
+                Cm = np.diag([ct, ct, c])
+                F0 = np.array([-ct * uc[0], -ct * uc[1], c * (vt - uc[2])])
+                M += dt * Jpt.T @ Cm @ Jpt
+                rhs += Jpt.T @ (F0 - dt * Cm @ apb)
+                continue
             if depth <= 0:
                 continue
             arm = arm - np.array([0, 0, rad])
-            uc = v[i] + np.cross(w[i], arm)
+            uc = v[i] + cross3(w[i], arm)
             fn0 = prm["contact_stiffness"] * depth - cn * uc[2]
             if fn0 <= 0:
                 continue
@@ -284,8 +323,8 @@ def accelerations(model, st, target, params, dt, kp_scale=1.0, kd_scale=1.0, ret
             ct = min(prm["friction_viscous"], prm["friction"] * fn0 / (ut + 1e-6))
             Cm = np.diag([ct, ct, cn])
             F0 = np.array([-ct * uc[0], -ct * uc[1], fn0])
-            fcontact[i] += F0 - dt * Cm @ np.cross(w[i], np.cross(w[i], arm))
-            apb = ab_v[i] + np.cross(ab_w[i], arm) + np.cross(w[i], np.cross(w[i], arm))
+            fcontact[i] += F0 - dt * Cm @ cross3(w[i], cross3(w[i], arm))
+            apb = ab_v[i] + cross3(ab_w[i], arm) + cross3(w[i], cross3(w[i], arm))
             Jpt = Jv[i] - skew(arm) @ Jw[i]
             M += dt * Jpt.T @ Cm @ Jpt
             rhs += Jpt.T @ (F0 - dt * Cm @ apb)
@@ -333,15 +372,55 @@ def accelerations(model, st, target, params, dt, kp_scale=1.0, kd_scale=1.0, ret
         rhs[col(i)] += tau
         tau_all[i], dimp_all[i] = tau, d
     nud = np.linalg.solve(M, rhs)
+    cstate["active"] = act_now
     if return_parts:
-        return nud, dict(M=M, rhs=rhs, R=R, p=p, w=w, v=v, Q=Q, tau=tau_all, dimp=dimp_all, fcontact=fcontact, offs=offs)
+        return nud, dict(M=M, rhs=rhs, R=R, p=p, w=w, v=v, Q=Q, tau=tau_all, dimp=dimp_all, fcontact=fcontact, offs=offs, Jw=Jw, Jv=Jv, ab_w=ab_w, ab_v=ab_v)
     return nud
+
+
+def rigid_ct(prm, lam, uc, un):
+    """Tangential impedance of a pushing point of the rigid model (phc_aba.h rigid_point_ct): c_t = min(c, mu lambda / max(|u_t|, |u+_t|))."""
+    return min(prm["contact_impedance"], prm["friction"] * lam / (max(np.hypot(uc[0], uc[1]), np.hypot(un[0], un[1])) + 1e-9))
+
+
+def rigid_contact_forces(model, parts, prm, dt, nud, active):
+    """Rigid contact model: the contact law evaluated on the end-of-step velocities the FINAL solve predicts -- net ground force per body (S4)."""
+    nb = model.num_bodies
+    R, p, w, v = parts["R"], parts["p"], parts["w"], parts["v"]
+    F = np.zeros((nb, 3))
+    c = prm["contact_impedance"]
+    for k, i in enumerate(model.contact_body):
+        arm = R[i] @ model.contact_pos[k]
+        rad = model.contact_radius[k]
+        depth = rad - (p[i][2] + arm[2])
+        if depth <= -prm["contact_offset"]:
+            continue
+        arm = arm - np.array([0, 0, rad])
+        uc = v[i] + cross3(w[i], arm)
+        apb = parts["ab_v"][i] + cross3(parts["ab_w"][i], arm) + cross3(w[i], cross3(w[i], arm))
+        Jpt = parts["Jv"][i] - skew(arm) @ parts["Jw"][i]
+        un = uc + dt * (Jpt @ nud + apb)
+        vt = min(depth / dt, prm["max_depenetration_velocity"]) if depth > 0 else depth / dt
+        if prm["restitution"] > 0 and -uc[2] > prm["bounce_threshold_velocity"]:
+            vt = max(vt, -prm["restitution"] * uc[2])
+        lam = c * (vt - un[2])
+        if lam <= 0 or k not in active:   # only the points the final solve let push
+            continue
+        ct = rigid_ct(prm, lam, uc, un)
+        F[i] += np.array([-ct * un[0], -ct * un[1], lam])
+    return F
 
 
 def substep(model, st, target, params, dt, kp_scale=1.0, kd_scale=1.0, tau_hold=None):
     """One linearly-implicit sub-step; returns the applied joint torques (S5)."""
     prm = dict(DEFAULT_PARAMS, **(params or {}))
     nud, parts = accelerations(model, st, target, prm, dt, kp_scale, kd_scale, return_parts=True, tau_hold=tau_hold)
+    if prm["contact_model"] == 1:
+        cstate = {"active": set(), "removed": set()}
+        nud, parts = accelerations(model, st, target, prm, dt, kp_scale, kd_scale, return_parts=True, tau_hold=tau_hold, cstate=cstate)
+        for _ in range(1, max(1, int(prm["contact_iterations"]))):   # passes on active set and friction cone
+            nud, parts = accelerations(model, st, target, prm, dt, kp_scale, kd_scale, return_parts=True, tau_hold=tau_hold, nud_prev=nud, cstate=cstate)
+        parts["fcontact"] = rigid_contact_forces(model, parts, prm, dt, nud, cstate["active"]) + parts["fcontact"]
     damp = 1.0 / (1.0 + dt * prm["angular_damping"])
     st.w0 = (st.w0 + dt * nud[0:3]) * damp
     st.v0 = st.v0 + dt * nud[3:6]
@@ -397,7 +476,61 @@ def energy(model, st, gravity_z=-9.81):
     for i in range(model.num_bodies):
         Io = R[i] @ model.inertia_origin[i] @ R[i].T
         mc = R[i] @ (model.mass[i] * model.com[i])
-        E += 0.5 * w[i] @ Io @ w[i] + 0.5 * model.mass[i] * v[i] @ v[i] + v[i] @ np.cross(w[i], mc)
+        E += 0.5 * w[i] @ Io @ w[i] + 0.5 * model.mass[i] * v[i] @ v[i] + v[i] @ cross3(w[i], mc)
         com_z = p[i][2] + (R[i] @ model.com[i])[2]
         E -= model.mass[i] * gravity_z * com_z
     return E
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# The CONTINUOUS model (round 4): what the stepper's linearly-implicit scheme discretises.  `accelerations(..., dt=0)` is exactly the
+# right-hand side of the ODE  M(q) nu_dot + h(q, nu) = tau_PD(q, nu) + J^T F_contact(q, nu):  every dt-weighted term of the implicit
+# scheme vanishes -- the joint-space matrix is the armature alone, the drive is tau = clamp(kp err, +-effort) - kd qd, a touching point
+# pushes with the penalty force F_n = max(0, k depth - d v_n), F_t = -min(c_max, mu F_n / |u_t|) u_t.  `ode_step` integrates it EXPLICITLY
+# (symplectic Euler, fp64) at a step far below the stepper's; tests/test_dynamics.py::test_stepper_converges_to_the_continuous_model checks
+# that the stepper approaches this solution at FIRST ORDER as its dt -> 0.  That pins the MODELLING of the implicit scheme (which terms
+# enter D, the sign and the dt-weights of every implicit correction, the saturation rule), not just its arithmetic -- `sim_step` above
+# shares the scheme with the kernel.  (Body-body contact has no continuous limit by construction -- its stiffness is tied to dt -- and
+# the rate clamps are excluded: the scenarios stay below them.)
+def ode_step(model, st, target, params, h):
+    prm = dict(DEFAULT_PARAMS, **(params or {}))
+    assert not prm["self_collision"] and prm["control_mode"] == 0
+    nud, parts = accelerations(model, st, target, prm, 0.0, return_parts=True)
+    c = prm["angular_damping"]
+    offs = parts["offs"]
+    st.w0 = st.w0 + h * (nud[0:3] - c * st.w0)
+    st.v0 = st.v0 + h * nud[3:6]
+    st.p0 = st.p0 + h * st.v0
+    q = quat_mul(quat_from_rotvec(st.w0 * h), st.q0)
+    st.q0 = q / np.linalg.norm(q)
+    for i in range(1, model.num_bodies):
+        qdd = nud[offs[i - 1]:offs[i]]
+        wj = st.qd[i - 1] + h * (qdd - c * st.qd[i - 1])
+        st.qd[i - 1] = wj
+        if st.nd[i - 1] == 3:
+            q = quat_mul(st.q[i - 1], quat_from_rotvec(wj * h))
+            st.q[i - 1] = q / np.linalg.norm(q)
+        else:
+            st.theta[i - 1] += wj[0] * h
+            st.q[i - 1] = st._rev_quat(i - 1)
+
+
+def ode_solve(model, root_states, dof_state, pd_target, T, h, params=None):
+    """Integrate the continuous model over [0, T] with explicit steps of (about) h.  Returns (root_states, dof_state, rigid_body_state)."""
+    st = State(root_states, dof_state, model)
+    n = max(1, int(round(T / h)))
+    for _ in range(n):
+        ode_step(model, st, pd_target, params, T / n)
+    Q, R, p = kinematics(model, st)
+    w, v = body_velocities(model, st, R, p)
+    return st.root_states(), st.dof_state(), np.concatenate([p, np.array(Q), v, w], axis=-1)
+
+
+def ode_body_positions(model, root_states, dof_state, pd_target, T, h, params=None, levels=2):
+    """Body positions of the continuous model at time T by RICHARDSON extrapolation of the explicit first-order integrator: x(h / 2) * 2 - x(h)
+    cancels the O(h) term.  Returns (extrapolated positions [NB, 3], estimate of their error = the difference between the extrapolations from
+    (h, h / 2) and (h / 2, h / 4) when `levels` == 3, else the last correction's size)."""
+    xs = [ode_solve(model, root_states, dof_state, pd_target, T, h / 2 ** k, params)[2][:, 0:3] for k in range(levels)]
+    ex = [2.0 * xs[k + 1] - xs[k] for k in range(levels - 1)]
+    err = np.abs(ex[-1] - ex[-2]).max() if levels >= 3 else np.abs(ex[-1] - xs[-1]).max()
+    return ex[-1], err

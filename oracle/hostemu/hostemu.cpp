@@ -55,13 +55,22 @@ static int emu_sim_step_t(const phc_model_t* model_all, const phc_sim_params_t* 
                         aba_collide_pair(*prm, dt, model_pair(*model, q) & 0xff, model_pair(*model, q) >> 8, x, caps.data());
                     for (int j = 0; j < nb; ++j) aba_collect_self(L[j], j, caps.data());
                 }
-                for (int j = 0; j < nb; ++j) { aba_velocity_products(L[j], *model, j, x, true); aba_body_init<JT>(L[j], *model, *prm, dt, j, s % prm->substeps == 0, true); }
-                if (JT == PHC_JT_SPHERICAL && rerooted) {
-                    for (int j = 0; j < nb; ++j) aba_publish_drive(L[j], j, x);
-                    for (int j = 0; j < nb; ++j) aba_fetch_drive(L[j], j, x);
+                for (int j = 0; j < nb; ++j) aba_velocity_products(L[j], *model, j, x, true);
+                const bool rigid = prm->contact_model == 1;
+                const int passes = rigid ? (prm->contact_iterations < 1 ? 1 : prm->contact_iterations) : 1;
+                for (int pass = 0; pass < passes; ++pass) {
+                    for (int j = 0; j < nb; ++j) {
+                        if (rigid) aba_body_init<JT, true>(L[j], *model, *prm, dt, j, s % prm->substeps == 0, true, pass);
+                        else aba_body_init<JT, false>(L[j], *model, *prm, dt, j, s % prm->substeps == 0, true, 0);
+                    }
+                    if (JT == PHC_JT_SPHERICAL && rerooted && pass == 0) {
+                        for (int j = 0; j < nb; ++j) aba_publish_drive(L[j], j, x);
+                        for (int j = 0; j < nb; ++j) aba_fetch_drive(L[j], j, x);
+                    }
+                    for (int l = sd; l >= 0; --l) for (int j = 0; j < nb; ++j) aba_backward_level<JT>(L[j], l, j, x);
+                    for (int l = 0; l <= sd; ++l) for (int j = 0; j < nb; ++j) aba_accel_level<JT>(L[j], l, j, x);
                 }
-                for (int l = sd; l >= 0; --l) for (int j = 0; j < nb; ++j) aba_backward_level<JT>(L[j], l, j, x);
-                for (int l = 0; l <= sd; ++l) for (int j = 0; j < nb; ++j) aba_accel_level<JT>(L[j], l, j, x);
+                if (rigid && s == nsub - 1) for (int j = 0; j < nb; ++j) aba_publish_contact_rigid(L[j], *model, *prm, *sim, dt, env, j, true);
                 if (JT == PHC_JT_SPHERICAL && rerooted) for (int j = 0; j < nb; ++j) aba_accel_finish(L[j], *model, j, x);
                 for (int j = 0; j < nb; ++j) aba_integrate_joint<JT>(L[j], *prm, dt);
                 for (int j = 0; j < nb; ++j) aba_fk_jump_begin(L[j], j, x);
@@ -74,7 +83,7 @@ static int emu_sim_step_t(const phc_model_t* model_all, const phc_sim_params_t* 
         for (int j = 0; j < nb; ++j) {
             if (do_step) aba_store_state<JT>(L[j], *sim, nd, env, j);
             aba_publish_body(L[j], *sim, nb, env, j, do_step != 0);
-            if (do_step) aba_publish_sensors(L[j], *model, *prm, *sim, prm->sim_dt / (float)prm->substeps, env, j);
+            if (do_step && prm->contact_model != 1) aba_publish_sensors(L[j], *model, *prm, *sim, prm->sim_dt / (float)prm->substeps, env, j);
         }
     }
     return 0;

@@ -44,7 +44,9 @@ class SimParams(C.Structure):
                 ("angular_damping", c_f), ("max_angular_velocity", c_f), ("contact_offset", c_f),
                 ("control_mode", c_i32), ("limit_stiffness", c_f), ("limit_damping", c_f),
                 ("self_collision", c_i32), ("self_stiffness_scale", c_f), ("self_damping_ratio", c_f), ("lane_mapping", c_i32),
-                ("num_force_sensors", c_i32), ("force_sensor_body", c_i32 * 4)]
+                ("num_force_sensors", c_i32), ("force_sensor_body", c_i32 * 4),
+                ("contact_model", c_i32), ("contact_iterations", c_i32), ("contact_impedance", c_f), ("max_depenetration_velocity", c_f),
+                ("bounce_threshold_velocity", c_f), ("restitution", c_f)]
 
 
 class ImParams(C.Structure):
@@ -134,7 +136,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the .so does not export the symbol
         fn.argtypes = argtypes
         fn.restype = restype
-    if lib.phc_abi_version() != 33:
+    if lib.phc_abi_version() != 34:
         raise ImportError("libphc_amd.so ABI version mismatch")
     _lib = lib
     return lib

@@ -67,8 +67,12 @@ def sim_state_struct(num_envs, root_states, dof_state, rigid_body_state, contact
 def sim_params_struct(sim_dt=1 / 60, substeps=2, control_freq_inv=2, gravity_z=-9.81, contact_stiffness=1.0e5,
                       contact_damping=1.0e3, friction=1.0, friction_viscous=2.0e3, angular_damping=0.01,
                       max_angular_velocity=100.0, contact_offset=0.02, control_mode=0, limit_stiffness=0.0, limit_damping=0.0, lane_mapping=0,
-                      self_collision=0, self_stiffness_scale=0.25, self_damping_ratio=0.5, force_sensor_bodies=()):
+                      self_collision=0, self_stiffness_scale=0.25, self_damping_ratio=0.5, force_sensor_bodies=(), contact_model=0,
+                      contact_iterations=4, contact_impedance=1.0e5, max_depenetration_velocity=10.0, bounce_threshold_velocity=0.2, restitution=0.0):
     p = L.SimParams()
+    p.contact_model = {"penalty": 0, "tgs": 1, "rigid": 1}.get(contact_model, contact_model)
+    p.contact_iterations, p.contact_impedance = int(contact_iterations), float(contact_impedance)
+    p.max_depenetration_velocity, p.bounce_threshold_velocity, p.restitution = float(max_depenetration_velocity), float(bounce_threshold_velocity), float(restitution)
     assert len(force_sensor_bodies) <= 4, "at most 4 force sensors"
     p.num_force_sensors = len(force_sensor_bodies)
     for i, b in enumerate(force_sensor_bodies):

@@ -136,6 +136,10 @@ struct AbaLane {
     float tau_hold;   // explicit `pd` torque of the current simulate call (control_mode 1)
     // --- body-body contact (self-collision): net explicit force / moment about the origin on this body, set by aba_self_collision ---
     V3 fself, nself;
+    // --- rigid ground contact (contact_model 1): the body's world angular acceleration and the classical acceleration of its solver reference
+    //     point as the LAST solve of this sub-step left them (aba_accel_level) -- the next pass evaluates active set and friction cone on them ---
+    V3 acc_w, acc_v;
+    uint32_t c_active, c_removed;   // per contact point of the body (bit k, k < 32): pushed in the previous pass / released for the rest of the sub-step
 };
 
 // per-env body shapes (phc_model_t.num_shapes > 1): the env's block of the int / float tables; the scalar header fields stay shared
@@ -187,8 +191,8 @@ PHC_HD void aba_load_model(AbaLane& L, const phc_model_t& m, int j, bool reroot 
 }
 // revolute extras (template JT == PHC_JT_REVOLUTE paths only)
 // convenience overload: constants read from the model at every call
-template <int JT>
-PHC_HD void aba_body_init(AbaLane& L, const phc_model_t& m, const phc_sim_params_t& prm, float dt, int j, bool new_sim_call, bool reroot = true);
+template <int JT, bool RIGID = false>
+PHC_HD void aba_body_init(AbaLane& L, const phc_model_t& m, const phc_sim_params_t& prm, float dt, int j, bool new_sim_call, bool reroot = true, int pass = 0);
 
 PHC_HD void aba_load_model_rev(AbaLane& L, const phc_model_t& m, int j) {
     const float* f = model_body(m, j);
@@ -313,13 +317,116 @@ PHC_HD void aba_fk_jump_step(AbaLane& L, int k, const Xch& x) {
     L.Q = quat_mul16(Qa, L.Q);
 }
 
+// one contact point's contribution to the body's articulated quantities: explicit force F0 at `arm` (relative to the solver reference point) and the
+// implicit impedance C = diag(c1, c1, c3) / dt of the point:  I^A += J^T (dt C) J,  p^A -= J^T F0  (J = [-[arm]x  1])
+PHC_HD void aba_add_point_contact(AbaLane& L, V3 arm, V3 F0, float c1, float c3) {
+    L.pA.n -= cross(arm, F0);
+    L.pA.f -= F0;
+    const float ax = arm.x, ay = arm.y, az = arm.z;
+    // A += [a]x C [a]x^T
+    L.IA.A.xx += az * az * c1 + ay * ay * c3;
+    L.IA.A.yy += az * az * c1 + ax * ax * c3;
+    L.IA.A.zz += (ax * ax + ay * ay) * c1;
+    L.IA.A.xy -= ax * ay * c3;
+    L.IA.A.xz -= ax * az * c1;
+    L.IA.A.yz -= ay * az * c1;
+    // B += [a]x C   ([a]x = [[0,-az,ay],[az,0,-ax],[-ay,ax,0]], columns scaled by (c1,c1,c3))
+    L.IA.B[1] += -az * c1; L.IA.B[2] += ay * c3;
+    L.IA.B[3] += az * c1;  L.IA.B[5] += -ax * c3;
+    L.IA.B[6] += -ay * c1; L.IA.B[7] += ax * c1;
+    // C += C
+    L.IA.C.xx += c1; L.IA.C.yy += c1; L.IA.C.zz += c3;
+}
+
+// ---- rigid ground contact (phc_sim_params_t.contact_model 1; include/phc_amd.h) ----
+// Per contact point a unilateral VELOCITY constraint on the end-of-step normal velocity, u_n(t + dt) >= v_target, carried by the impedance c =
+// contact_impedance:  F_n = c (v_target - u_n(t + dt)) >= 0  -- the same linearly-implicit form as the penalty contact (I^A += dt J^T C J), so the
+// articulated-body recursion solves ALL contacts of the tree and the joint drives together, exactly, in O(n).  What a single linear solve cannot
+// know is the active set (a point only pushes) and where each point sits in its friction cone: they are found by `contact_iterations` passes;
+// pass k evaluates them on the velocities the solve of pass k - 1 predicts,
+//   u+ = u + dt (a_ref + alpha x r + w x (w x r)),   lambda = c (v_target - u+_n)     (pass 0: u+ = u)
+//   a point pushes in pass k iff lambda > 0 -- and it has not been RELEASED: a point that pushed in pass k - 1 and came out with lambda <= 0
+//   (the solve needed it to pull) is released for the rest of the sub-step.  Every point therefore changes state at most twice (idle -> pushing ->
+//   released): the passes cannot cycle, which plain active-set switching does on statically indeterminate supports (measured: period-2 cycles
+//   on a sliding, lying humanoid); a point released wrongly is picked up again by the next sub-step.
+//   tangential impedance c_t = min(c, mu lambda / max(|u_t|, |u+_t|)),  F_t = -c_t u_t(t + dt):  a point at rest whose holding force c |u+_t|
+//   stays inside the cone keeps the full impedance (it sticks); a slipping point feels mu lambda against its slip (to first order in the change
+//   of slip speed over the sub-step) and is caught by the cap when the slip dies -- the friction force can never reverse a slip.
+// v_target: depth / dt capped at max_depenetration_velocity for a penetrating point; -gap / dt (the point may close its gap, no more) for a
+// speculative point within contact_offset above the plane; -restitution u_n above the bounce threshold.
+PHC_HD float rigid_point_velocity_target(const phc_sim_params_t& prm, float dt, float depth, float un_now) {
+    float vt = depth > 0.f ? fminf(depth / dt, prm.max_depenetration_velocity) : depth / dt;
+    if (prm.restitution > 0.f && -un_now > prm.bounce_threshold_velocity) vt = fmaxf(vt, -prm.restitution * un_now);
+    return vt;
+}
+// one candidate point: geometry and velocities.  false: out of range
+struct RigidPoint { V3 arm, uc, un, cc; float depth, lam; };
+PHC_HD bool rigid_point(const AbaLane& L, const phc_sim_params_t& prm, float dt, const M3& R, V3 so, const float* cpk, bool predicted, RigidPoint* o) {
+    V3 arm = mat_mul(R, v3(cpk[0], cpk[1], cpk[2]));
+    const float rad = cpk[3];
+    o->depth = rad - (L.p.z + arm.z);
+    if (o->depth <= -prm.contact_offset) return false;
+    arm.z -= rad;
+    o->uc = L.v + cross(L.w, arm);
+    o->arm = arm - so;
+    o->cc = cross(L.w, cross(L.w, o->arm));
+    o->un = predicted ? o->uc + (L.acc_v + cross(L.acc_w, o->arm) + o->cc) * dt : o->uc;
+    o->lam = prm.contact_impedance * (rigid_point_velocity_target(prm, dt, o->depth, o->uc.z) - o->un.z);
+    return true;
+}
+// tangential impedance of a pushing point (see above)
+PHC_HD float rigid_point_ct(const phc_sim_params_t& prm, const RigidPoint& q) {
+    const float us = sqrtf(q.uc.x * q.uc.x + q.uc.y * q.uc.y), up = sqrtf(q.un.x * q.un.x + q.un.y * q.un.y);
+    return fminf(prm.contact_impedance, prm.friction * q.lam / (fmaxf(us, up) + 1e-9f));
+}
+PHC_HD void aba_ground_contact_rigid(AbaLane& L, const phc_sim_params_t& prm, float dt, const M3& R, V3 so, const float* f, const float* cp,
+                                     int cp_total, int pass) {
+    const float c = prm.contact_impedance;
+    if (pass == 0) L.c_active = L.c_removed = 0u;
+    uint32_t act = 0u;
+    const int cp_count = (L.p.z < f[34] + prm.contact_offset) ? cp_total : 0;
+    for (int k = 0; k < cp_count; ++k) {
+        RigidPoint q;
+        if (!rigid_point(L, prm, dt, R, so, cp + 4 * k, pass > 0, &q)) continue;   // out of range
+        const uint32_t bit = k < 32 ? 1u << k : 0u;
+        if (q.lam <= 0.f) { L.c_removed |= L.c_active & bit; continue; }           // idle -- or released: it pushed in the last pass and would have to pull
+        if (L.c_removed & bit) continue;
+        act |= bit;
+        const float vt = rigid_point_velocity_target(prm, dt, q.depth, q.uc.z);
+        const float ct = rigid_point_ct(prm, q);
+        const V3 F0 = v3(-ct * q.uc.x - dt * ct * q.cc.x, -ct * q.uc.y - dt * ct * q.cc.y, c * (vt - q.uc.z) - dt * c * q.cc.z);
+        aba_add_point_contact(L, q.arm, F0, dt * ct, dt * c);
+    }
+    L.c_active = act;
+}
+// The contact law evaluated on the END-of-sub-step velocities the final solve predicts: the net ground
+// force on the body (S4) and, about the body origin, its moment (S6).  `R`: the body's rotation, `so`: origin -> solver reference point (world).
+PHC_HD void aba_ground_force_rigid(const AbaLane& L, const phc_sim_params_t& prm, float dt, const M3& R, V3 so, const float* f, const float* cp,
+                                   int cp_total, V3* Fout, V3* Nout) {
+    V3 F = v3(0.f, 0.f, 0.f), N = v3(0.f, 0.f, 0.f);
+    const int cp_count = (L.p.z < f[34] + prm.contact_offset) ? cp_total : 0;
+    for (int k = 0; k < cp_count; ++k) {
+        RigidPoint q;
+        if (!rigid_point(L, prm, dt, R, so, cp + 4 * k, true, &q) || q.lam <= 0.f) continue;
+        if (k < 32 && !((L.c_active >> k) & 1u)) continue;   // only the points the final solve let push
+        const float ct = rigid_point_ct(prm, q);
+        const V3 Fk = v3(-ct * q.un.x, -ct * q.un.y, q.lam);
+        F += Fk;
+        N += cross(q.arm + so, Fk);
+    }
+    *Fout = F; *Nout = N;
+}
+
 // ---- per-body initialisation of I^A, p^A and of the joint drive (no communication) ----
 // `new_sim_call`: first sub-step of a gym.simulate call -- the explicit `pd` torque is recomputed there (humanoid.py:1608-1616).
 // `f`: the body's PHC_BODY_FLOATS constants -- straight from the model (L2) or a register copy the caller made once per launch;
 // `cp_start / cp_total`: the body's slice of the contact-point table.
-template <int JT>
+// `RIGID` / `pass`: contact_model 1 (include/phc_amd.h) -- the sub-step is solved contact_iterations times; pass 0 decides active set and friction
+// cone on the current velocities, pass k > 0 on the end-of-step velocities the previous solve predicts (L.acc_w / L.acc_v); the joint drive is
+// formed in pass 0 only (it does not depend on the contact forces).
+template <int JT, bool RIGID>
 PHC_HD void aba_body_init(AbaLane& L, const phc_model_t& m, const phc_sim_params_t& prm, float dt, int j, bool new_sim_call,
-                          const float* f, int cp_start, int cp_total, bool reroot) {
+                          const float* f, int cp_start, int cp_total, bool reroot, int pass) {
     const float mass = f[3];
     // every spatial quantity of the body is taken about its solver reference point o = p + R off (the origin unless the body is reversed)
     const SolverRef sr = model_solver_ref(f, reroot);
@@ -339,8 +446,11 @@ PHC_HD void aba_body_init(AbaLane& L, const phc_model_t& m, const phc_sim_params
     L.pA.f = cross(L.w, cross(L.w, mc)) - g * mass;
     // ground contact: plane z = 0, normal +z
     L.fcontact = v3(0.f, 0.f, 0.f);
-    const float cn = prm.contact_stiffness * dt + prm.contact_damping;
     const float* cp = m.floats + PHC_MAX_BODIES * PHC_BODY_FLOATS + cp_start * 4;
+    if (RIGID) {
+        aba_ground_contact_rigid(L, prm, dt, R, so, f, cp, cp_total, pass);
+    } else {
+    const float cn = prm.contact_stiffness * dt + prm.contact_damping;
     // broad phase: f[34] bounds |contact point| + radius, so above that height nothing of this body reaches the plane
     const int cp_count = (L.p.z < f[34]) ? cp_total : 0;
     // touching points first (round 3): the heights of up to 32 of the body's points above the plane are formed branch-free with their table
@@ -376,28 +486,14 @@ PHC_HD void aba_body_init(AbaLane& L, const phc_model_t& m, const phc_sim_params
         V3 cc = cross(L.w, cross(L.w, arm));
         V3 F0 = v3(-ct * uc.x - dt * ct * cc.x, -ct * uc.y - dt * ct * cc.y, fn0 - dt * cn * cc.z);
         L.fcontact += F0;
-        L.pA.n -= cross(arm, F0);
-        L.pA.f -= F0;
-        float c1 = dt * ct, c3 = dt * cn;
-        float ax = arm.x, ay = arm.y, az = arm.z;
-        // A += [a]x C [a]x^T
-        L.IA.A.xx += az * az * c1 + ay * ay * c3;
-        L.IA.A.yy += az * az * c1 + ax * ax * c3;
-        L.IA.A.zz += (ax * ax + ay * ay) * c1;
-        L.IA.A.xy -= ax * ay * c3;
-        L.IA.A.xz -= ax * az * c1;
-        L.IA.A.yz -= ay * az * c1;
-        // B += [a]x C   ([a]x = [[0,-az,ay],[az,0,-ax],[-ay,ax,0]], columns scaled by (c1,c1,c3))
-        L.IA.B[1] += -az * c1; L.IA.B[2] += ay * c3;
-        L.IA.B[3] += az * c1;  L.IA.B[5] += -ax * c3;
-        L.IA.B[6] += -ay * c1; L.IA.B[7] += ax * c1;
-        // C += C
-        L.IA.C.xx += c1; L.IA.C.yy += c1; L.IA.C.zz += c3;
+        aba_add_point_contact(L, arm, F0, dt * ct, dt * cn);
+    }
     }
     // body-body contact forces of this sub-step (explicit; zero unless sim_params.self_collision)
     L.fcontact += L.fself;
     L.pA.n -= L.nself - cross(so, L.fself);   // (nself: about the origin)
     L.pA.f -= L.fself;
+    if (RIGID && pass > 0) return;   // the drive terms of pass 0 stand (L.tau_w / Dw / diso / aw / dimp / tau_local)
     if (JT == PHC_JT_REVOLUTE) {
         if (L.level > 0) {
             // joint drive (revolute).  control_mode 0 = Isaac Gym's implicit position drive (`isaac_pd`), linearly implicit as
@@ -462,9 +558,27 @@ PHC_HD void aba_body_init(AbaLane& L, const phc_model_t& m, const phc_sim_params
     }
 }
 
-template <int JT>
-PHC_HD void aba_body_init(AbaLane& L, const phc_model_t& m, const phc_sim_params_t& prm, float dt, int j, bool new_sim_call, bool reroot) {
-    aba_body_init<JT>(L, m, prm, dt, j, new_sim_call, model_body(m, j), model_tab(m, 8, j), model_tab(m, 9, j), reroot);
+template <int JT, bool RIGID>
+PHC_HD void aba_body_init(AbaLane& L, const phc_model_t& m, const phc_sim_params_t& prm, float dt, int j, bool new_sim_call, bool reroot, int pass) {
+    aba_body_init<JT, RIGID>(L, m, prm, dt, j, new_sim_call, model_body(m, j), model_tab(m, 8, j), model_tab(m, 9, j), reroot, pass);
+}
+// rigid contact model: S4 net ground force of the body from the final solve of the sub-step (+ the body-body forces, as the penalty model
+// publishes), and S6: the force sensors read the same wrench (about the body origin, in the body frame)
+PHC_HD void aba_publish_contact_rigid(AbaLane& L, const phc_model_t& m, const phc_sim_params_t& prm, const phc_sim_state_t& s, float dt,
+                                      int64_t env, int j, bool reroot) {
+    const float* f = model_body(m, j);
+    const M3 R = quat_to_mat(L.Q);
+    const V3 so = mat_mul(R, model_solver_ref(f, reroot).off);
+    V3 F, N;
+    aba_ground_force_rigid(L, prm, dt, R, so, f, m.floats + PHC_MAX_BODIES * PHC_BODY_FLOATS + model_tab(m, 8, j) * 4, model_tab(m, 9, j), &F, &N);
+    L.fcontact = F + L.fself;
+    if (s.force_sensor != nullptr)
+        for (int k = 0; k < prm.num_force_sensors; ++k)
+            if (prm.force_sensor_body[k] == j) {
+                const V3 Fl = mat_tmul(R, F), Nl = mat_tmul(R, N);
+                float* o = s.force_sensor + (env * prm.num_force_sensors + k) * 6;
+                o[0] = Fl.x; o[1] = Fl.y; o[2] = Fl.z; o[3] = Nl.x; o[4] = Nl.y; o[5] = Nl.z;
+            }
 }
 
 // ---- body-body contact (SURVEY f-1; the reference runs with robot.has_self_collision: True, humanoid.py:1205-1226) ----
@@ -755,6 +869,7 @@ PHC_HD void aba_accel_level(AbaLane& L, int level, int j, const Xch& x) {
         alpha = sym_mul(sym_inv(S), rhs);
         a = -sym_mul(Ci, L.pA.f + Bt_mul(B, alpha));
         L.u = alpha; L.ca = a;
+        L.acc_w = alpha; L.acc_v = a;
     } else {
         const float* ps = xslot(x, L.sparent);
         V3 alp = v3(ps[0 * es], ps[1 * es], ps[2 * es]), ap = v3(ps[3 * es], ps[4 * es], ps[5 * es]);
@@ -764,6 +879,7 @@ PHC_HD void aba_accel_level(AbaLane& L, int level, int j, const Xch& x) {
         alpha = al1 + beta;
         a = a1;
         L.u = beta;
+        L.acc_w = alpha; L.acc_v = a;
     }
     float* s = xslot(x, j);
     s[0 * es] = alpha.x; s[1 * es] = alpha.y; s[2 * es] = alpha.z; s[3 * es] = a.x; s[4 * es] = a.y; s[5 * es] = a.z;

@@ -131,7 +131,7 @@ __device__ __forceinline__ bool stage_aligned(const phc_sim_state_t& sim) {
 // >256 VGPRs: 214-252 us vs 158 us for this mapping.  __launch_bounds__(64, 2): two wavefronts per SIMD (<= 256 VGPRs,
 // 68 B/lane of scratch) beats one (272 registers, no scratch: 195 us) and three (168 VGPRs, 412 B scratch: 280 us).
 // ------------------------------------------------------------------------------------------
-template <bool STEP, int JT, int GRP, bool SHAPES = false>
+template <bool STEP, int JT, int GRP, bool SHAPES = false, bool RIGID = false>
 __global__ __launch_bounds__(64, 2) void k_sim_step(phc_model_t model_all, phc_sim_params_t prm, phc_sim_state_t sim,
                                                 const float* __restrict__ actions, const float* __restrict__ pd_off,
                                                 const float* __restrict__ pd_scale, const int32_t* __restrict__ freeze,
@@ -200,10 +200,16 @@ __global__ __launch_bounds__(64, 2) void k_sim_step(phc_model_t model_all, phc_s
             }
             PHC_PROF(1)
             PHC_TL(2)
-            if (active && !PHC_SKIP(1)) { aba_velocity_products(L, model, body, x, true); PHC_TL(3) aba_body_init<JT>(L, model, prm, dt, body, s % prm.substeps == 0, true); }
+            if (active && !PHC_SKIP(1)) aba_velocity_products(L, model, body, x, true);
+            // contact_model 1 (rigid): the sub-step's solve is repeated contact_iterations times, each pass with the active set and friction cone the
+            // previous one implies (phc_aba.h aba_ground_contact_rigid); the penalty model is the single pass it always was
+            const int passes = RIGID ? (prm.contact_iterations < 1 ? 1 : prm.contact_iterations) : 1;
+            for (int pass = 0; pass < passes; ++pass) {
+            PHC_TL(3)
+            if (active && !PHC_SKIP(1)) aba_body_init<JT, RIGID>(L, model, prm, dt, body, s % prm.substeps == 0, true, pass);
             PHC_PROF(2)
             PHC_TL(4)
-            if (JT == PHC_JT_SPHERICAL && rerooted && !PHC_SKIP(2)) {   // reversed bodies take the drive terms of their solver parent's joint
+            if (JT == PHC_JT_SPHERICAL && rerooted && pass == 0 && !PHC_SKIP(2)) {   // reversed bodies take the drive terms of their solver parent's joint
                 if (active) aba_publish_drive(L, body, x);
                 __syncthreads();
                 if (active) aba_fetch_drive(L, body, x);
@@ -215,8 +221,10 @@ __global__ __launch_bounds__(64, 2) void k_sim_step(phc_model_t model_all, phc_s
             PHC_PROF(4)
             if (!PHC_SKIP(4)) {
                 for (int l = 0; l <= solver_depth; ++l) { aba_accel_level<JT>(L, l, body, x); __syncthreads(); PHC_TL(140 + l) }
-                if (JT == PHC_JT_SPHERICAL && rerooted) aba_accel_finish(L, model, body, x);
             }
+            }
+            if (RIGID && active && s == nsub - 1) aba_publish_contact_rigid(L, model, prm, sim, dt, env, body, true);   // S4 / S6 from the final solve
+            if (JT == PHC_JT_SPHERICAL && rerooted && !PHC_SKIP(4)) aba_accel_finish(L, model, body, x);
             PHC_PROF(5)
             PHC_TL(6)
             if (!PHC_SKIP(5)) aba_integrate_joint<JT>(L, prm, dt);
@@ -252,23 +260,32 @@ __global__ __launch_bounds__(64, 2) void k_sim_step(phc_model_t model_all, phc_s
         if (STEP) aba_store_state<JT>(L, sim, nd, env, body);
         aba_publish_body(L, sim, nb, env, body, STEP);
     }
-    if (STEP && active && sim.force_sensor != nullptr) aba_publish_sensors(L, model, prm, sim, prm.sim_dt / (float)prm.substeps, env, body);   // S6
+    if (STEP && !RIGID && active && sim.force_sensor != nullptr) aba_publish_sensors(L, model, prm, sim, prm.sim_dt / (float)prm.substeps, env, body);   // S6
     PHC_PROF(8)
     if (STEP) { PHC_PROF_FLUSH }
 }
 
-template <bool STEP, int JT, bool SHAPES>
-static void sim_launch_jt(const phc_model_t* model, const phc_sim_params_t& prm, const phc_sim_state_t* sim, const float* actions,
+template <bool STEP, int JT, bool SHAPES, bool RIGID>
+static void sim_launch_cm(const phc_model_t* model, const phc_sim_params_t& prm, const phc_sim_state_t* sim, const float* actions,
                           const float* off, const float* scale, const int32_t* freeze, int num_sim_calls, hipStream_t stream,
                           const int64_t* env_ids, int num_listed) {
     const int64_t groups = env_ids ? num_listed : sim->num_envs;
     const bool wide = model->num_bodies > 32;   // more bodies than a 32-lane group holds: one env per wavefront
     if (wide)
-        hipLaunchKernelGGL((k_sim_step<STEP, JT, 64, SHAPES>), dim3(groups), dim3(64), 0, stream, *model, prm, *sim, actions, off, scale, freeze,
+        hipLaunchKernelGGL((k_sim_step<STEP, JT, 64, SHAPES, RIGID>), dim3(groups), dim3(64), 0, stream, *model, prm, *sim, actions, off, scale, freeze,
                            num_sim_calls, env_ids, num_listed);
     else
-        hipLaunchKernelGGL((k_sim_step<STEP, JT, 32, SHAPES>), dim3((groups + 1) / 2), dim3(64), 0, stream, *model, prm, *sim, actions, off, scale, freeze,
+        hipLaunchKernelGGL((k_sim_step<STEP, JT, 32, SHAPES, RIGID>), dim3((groups + 1) / 2), dim3(64), 0, stream, *model, prm, *sim, actions, off, scale, freeze,
                            num_sim_calls, env_ids, num_listed);
+}
+template <bool STEP, int JT, bool SHAPES>
+static void sim_launch_jt(const phc_model_t* model, const phc_sim_params_t& prm, const phc_sim_state_t* sim, const float* actions,
+                          const float* off, const float* scale, const int32_t* freeze, int num_sim_calls, hipStream_t stream,
+                          const int64_t* env_ids, int num_listed) {
+    if (STEP && prm.contact_model == 1)   // rigid ground contact: its own instantiation, the penalty kernel is untouched by it
+        sim_launch_cm<STEP, JT, SHAPES, STEP>(model, prm, sim, actions, off, scale, freeze, num_sim_calls, stream, env_ids, num_listed);
+    else
+        sim_launch_cm<STEP, JT, SHAPES, false>(model, prm, sim, actions, off, scale, freeze, num_sim_calls, stream, env_ids, num_listed);
 }
 
 template <bool STEP>
@@ -309,7 +326,9 @@ int32_t phc_sim_step(const phc_model_t* model, const phc_sim_params_t* params, c
     if (sim->num_envs == 0) return 0;
     // pairs are dealt round-robin to the lanes of an env's group: PHC_SC_MAX_PER_LANE each
     if (params->self_collision && model->num_collision_pairs > PHC_SC_MAX_PER_LANE * (model->num_bodies > 32 ? 64 : 32)) return PHC_EUNSUPPORTED;
-    if (params->lane_mapping != 0 && params->lane_mapping != 1) return PHC_EUNSUPPORTED;   // (2 was the two-bodies-per-lane kernel of rounds 1-2: removed)
+    if (params->lane_mapping != 0 && params->lane_mapping != 1) return PHC_EUNSUPPORTED;
+    if (params->contact_model != 0 && params->contact_model != 1) return PHC_EUNSUPPORTED;
+    if (params->contact_model == 1 && (params->contact_iterations < 1 || !(params->contact_impedance > 0.f))) return PHC_EINVAL;   // (2 was the two-bodies-per-lane kernel of rounds 1-2: removed)
     sim_launch<true>(model, *params, sim, actions, pd_action_offset, pd_action_scale, freeze_mask, num_sim_calls, (hipStream_t)stream);
     return launch_status();
 }

@@ -425,7 +425,14 @@ class HumanoidIm:
             # body-body contact between non-adjacent links (robot.has_self_collision, on in the shipped robot yamls)
             self_collision=int(bool(solver.get("self_collision", self._has_self_collision))),
             self_stiffness_scale=float(solver.get("self_stiffness_scale", 0.25)), self_damping_ratio=float(solver.get("self_damping_ratio", 0.5)),
-            force_sensor_bodies=[self._body_names.index(b) for b in self.force_sensor_joints] if sensors_on else ())
+            force_sensor_bodies=[self._body_names.index(b) for b in self.force_sensor_joints] if sensors_on else (),
+            # ground-contact model: `+solver.contact=tgs` (alias rigid) = the velocity-level rigid contact with what parse_sim_params hands PhysX
+            # (run_hydra.py:88-91, sim/default_sim.yaml: num_position_iterations, max_depenetration_velocity, bounce_threshold_velocity; plane
+            # restitution of the env yaml); default `penalty` (include/phc_amd.h, ABI 34)
+            contact_model=str(solver.get("contact", "penalty")), contact_iterations=int(solver.get("contact_iterations", physx.get("num_position_iterations", 4))),
+            contact_impedance=float(solver.get("contact_impedance", 1.0e5)),
+            max_depenetration_velocity=float(physx.get("max_depenetration_velocity", 10.0)),
+            bounce_threshold_velocity=float(physx.get("bounce_threshold_velocity", 0.2)), restitution=float(plane.get("restitution", 0.0)))
 
         # ---- action scaling (A1) + freeze masks (humanoid.py:1331-1409,1549-1554) ----
         self.dof_limits_lower, self.dof_limits_upper = (torch.from_numpy(x).to(dev) for x in self.model.dof_limits())

@@ -41,6 +41,7 @@ class StepChecker:
         self.st_before = t._motion_start_times.cpu().numpy().copy()
         self.so_before = t._motion_start_times_offset.cpu().numpy().copy()
         self.cycle_before = t._cycle_counter.cpu().numpy().copy()
+        self.goff_before = t._global_offset.cpu().numpy().copy()
 
     def dynamics(self, actions, envs, pos_atol=1e-3, root_atol=2e-3):
         """The stepper's result on `envs` against the fp64 dense oracle stepped from the pre-step state (same model, same PD targets)."""
@@ -54,7 +55,10 @@ class StepChecker:
         sp = t._sim_params
         params = dict(self_collision=int(sp.self_collision), control_mode=int(sp.control_mode), limit_stiffness=float(sp.limit_stiffness),
                       limit_damping=float(sp.limit_damping), contact_stiffness=float(sp.contact_stiffness), contact_damping=float(sp.contact_damping),
-                      friction=float(sp.friction), friction_viscous=float(sp.friction_viscous))
+                      friction=float(sp.friction), friction_viscous=float(sp.friction_viscous), contact_model=int(sp.contact_model),
+                      contact_iterations=int(sp.contact_iterations), contact_impedance=float(sp.contact_impedance),
+                      max_depenetration_velocity=float(sp.max_depenetration_velocity), bounce_threshold_velocity=float(sp.bounce_threshold_velocity),
+                      restitution=float(sp.restitution), contact_offset=float(sp.contact_offset))
         for e in envs:
             r, d, rbs, tau, fc = do.sim_step(t.model, self.root0[e], self.dof0[e], tgt[e], params=params, sim_dt=t.sim_dt, substeps=int(sp.substeps),
                                              num_sim_calls=t.control_freq_inv)
@@ -91,6 +95,9 @@ class StepChecker:
         t0 = (prog.astype(F) * dt + st + so).astype(F)
         t1 = ((prog + 1).astype(F) * dt + st + so).astype(F)
         r0, r1 = lookup(lib, mids, t0, goff), lookup(lib, mids, t1, goff)
+        # the reward is computed BEFORE `_compute_reset` restarts a clip that ran out (humanoid.py:1634-1650: reward, reset, observations): for those
+        # envs its reference is the OLD clock (past the end: clamped to the last frame) under the old offset
+        rr = r0 if not wrapped.any() else lookup(lib, mids, (prog.astype(F) * dt + self.st_before + self.so_before).astype(F), self.goff_before)
         bp, br = t._rigid_body_pos.cpu().numpy(), t._rigid_body_rot.cpu().numpy()
         bv, bav = t._rigid_body_vel.cpu().numpy(), t._rigid_body_ang_vel.cpu().numpy()
         assert np.isfinite(bp).all() and np.isfinite(bv).all()
@@ -98,10 +105,10 @@ class StepChecker:
         if robot:
             ep, eo = t.extend_body_parent_ids.cpu().numpy(), t.extend_body_pos_in_parent[0].cpu().numpy()
             bpe, bre = po.extend_bodies(bp, br, ep, eo)
-            rw, raw = po.compute_imitation_reward(bpe, bre, bv, bav, np.concatenate([r0["rg_pos"], r0["rg_pos_t"][:, nb:]], 1),
-                                                  np.concatenate([r0["rb_rot"], r0["rg_rot_t"][:, nb:]], 1), r0["body_vel"], r0["body_ang_vel"], t.reward_specs)
+            rw, raw = po.compute_imitation_reward(bpe, bre, bv, bav, np.concatenate([rr["rg_pos"], rr["rg_pos_t"][:, nb:]], 1),
+                                                  np.concatenate([rr["rb_rot"], rr["rg_rot_t"][:, nb:]], 1), rr["body_vel"], rr["body_ang_vel"], t.reward_specs)
         else:
-            rw, raw = po.compute_imitation_reward(bp, br, bv, bav, r0["rg_pos"], r0["rb_rot"], r0["body_vel"], r0["body_ang_vel"], t.reward_specs)
+            rw, raw = po.compute_imitation_reward(bp, br, bv, bav, rr["rg_pos"], rr["rb_rot"], rr["body_vel"], rr["body_ang_vel"], t.reward_specs)
         pr = po.power_reward(t.dof_force_tensor.cpu().numpy(), t._dof_vel.cpu().numpy(), prog, coef=t.power_coefficient)
         np.testing.assert_allclose(info["reward_raw"].cpu().numpy()[:, :4], raw, atol=atol)
         np.testing.assert_allclose(rew.cpu().numpy(), rw + pr, atol=atol, rtol=1e-4)

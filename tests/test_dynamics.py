@@ -439,3 +439,160 @@ def test_per_env_body_shapes_equal_single_shape_runs(backend, self_collision):
     root[:] = root[0]; dof[:] = dof[0]
     fk_same, _ = run(stacked, np.arange(3), shape[:3])
     assert np.abs(fk_same[0] - fk_same[1]).max() > 1e-3 and np.abs(fk_same[0] - fk_same[2]).max() > 1e-3
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("scene", ["standing_pd", "falling_contact"])
+def test_stepper_converges_to_the_continuous_model(backend, scene):
+    """pin the MODELLING of the stepper, not only its arithmetic.  `dyn_oracle.ode_solve` integrates the continuous PD +
+    penalty-contact ODE explicitly in fp64 at dt = 1/7680 .. 1/30720 s with Richardson extrapolation (no implicit term of the scheme exists in it); the stepper, run over the same 0.025 s
+    with sub-steps of 1/120, 1/240, 1/480 and 1/960 s, must approach that solution at first order: the error roughly halves with dt, and at
+    the shipped dt = 1/120 s it is small in absolute terms.  Scenes: a humanoid standing on the ground whose PD targets pull it into a bent
+    pose (stiff drives + sustained contact + friction), and one dropped from 2 cm with joint velocities (contact onset)."""
+    be = get_backend(backend)
+    model, mstruct, keep = model_on(be)
+    nd = model.num_dof
+    rng = np.random.default_rng(3)
+    root = np.zeros((1, 13), F)
+    root[0, 6] = 1.0
+    dof = np.zeros((1, nd, 2), F)
+    names = model.body_names
+    tgt = np.zeros((1, nd), F)
+    st0 = do.State(root[0].astype(np.float64), dof[0].astype(np.float64), model)
+    Q, R, p = do.kinematics(model, st0)
+    low = min(p[i][2] + (R[i] @ model.contact_pos[k])[2] - model.contact_radius[k] for k, i in enumerate(model.contact_body))
+    if scene == "standing_pd":
+        root[0, 2] = -low - 0.004                        # resting a few mm into the ground (near its static equilibrium)
+        for jn, ax, ang in (("L_Knee", 1, 0.5), ("R_Knee", 1, 0.5), ("L_Hip", 1, -0.3), ("R_Hip", 1, -0.3), ("L_Shoulder", 0, 0.6), ("Torso", 1, 0.2)):
+            tgt[0, 3 * (names.index(jn) - 1) + ax] = ang
+    else:
+        root[0, 2] = -low + 0.02
+        dof[0, :, 1] = rng.normal(0, 1.0, nd)
+        root[0, 7:10] = (0.3, -0.2, 0.0)
+        tgt[0] = rng.normal(0, 0.2, nd)
+    T = 0.025
+    # explicit integration bounds the stiffness it can take: 8 foot corners x friction_viscous on a ~1 kg foot is a 16 000 1/s mode at the
+    # shipped 2000 N s/m (stable only below h = 1/8000 s); both sides of this test run at 500 N s/m, everything else as shipped
+    soft = dict(friction_viscous=500.0)
+    key = (scene,)
+    if key not in _ODE_CACHE:      # (shared by the two backends of one session: ~7 s of fp64 numpy)
+        _ODE_CACHE[key] = do.ode_body_positions(model, root[0], dof[0], tgt[0], T, 1 / 7680, params=soft, levels=3)
+    pos_ref, ref_err = _ODE_CACHE[key]
+    errs = []
+    for sub in (1, 2, 4, 8):                             # dt = 1/120 .. 1/960 s; 3 * sub sub-steps cover T
+        params = abi.sim_params_struct(sim_dt=sub / (120.0 * sub), substeps=sub, **soft)
+        out = run_step(be, model, mstruct, root, dof, tgt, params, num_sim_calls=3)
+        errs.append(np.abs(out["rbs"][0][:, 0:3] - pos_ref).max())
+    errs = np.array(errs)
+    assert ref_err < 0.2 * errs[-1], (ref_err, errs)     # the reference itself is converged well below the finest stepper run
+    assert errs[0] < 1e-2, errs                          # the shipped sub-step: millimetres
+    ratios = errs[:-1] / errs[1:]
+    assert (ratios > 1.5).all() and (ratios < 2.7).all(), (errs, ratios)   # first order: halving dt halves the error
+
+
+_ODE_CACHE = {}
+
+
+# ------------------------------------------------------------------------------------------------------------------ rigid ("tgs") ground contact
+RIGID = dict(contact_model=1, contact_iterations=4)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("num_sim_calls,height,self_collision", [(1, 0.90, 0), (2, 0.925, 0), (2, 0.93, 1)])
+def test_rigid_contact_matches_dense_oracle(backend, num_sim_calls, height, self_collision):
+    """contact_model 1 (include/phc_amd.h; solver.contact=tgs): the O(n) recursion with per-point contact impedances and 4 active-set / friction-cone
+    passes per sub-step == the fp64 dense solve of the same equations (oracle/dyn_oracle.py accelerations(nud_prev=...)): state, joint torques and
+    the published net ground force.  The impedance (dt c = 833 kg per point) is 55 x the penalty model's: the fp32 recursion has to carry it."""
+    be = get_backend(backend)
+    model, mstruct, keep = model_on(be)
+    rng = np.random.default_rng(17)
+    n = 6
+    root, dof, target = random_states(model, n, rng, height=height, vel=0.5, pose=0.15)
+    params = abi.sim_params_struct(self_collision=self_collision, **RIGID)
+    out = run_step(be, model, mstruct, root, dof, target, params, num_sim_calls)
+    n_contacts = 0
+    for e in range(n):
+        r, d, rbs, tau, fc = do.sim_step(model, root[e], dof[e], target[e], params=dict(self_collision=self_collision, **RIGID), sim_dt=1 / 60, substeps=2,
+                                         num_sim_calls=num_sim_calls)
+        n_contacts += int((np.abs(fc).sum(-1) > 0).sum())
+        np.testing.assert_allclose(out["root"][e], r, atol=5e-4, rtol=2e-4, err_msg=f"root env {e}")
+        np.testing.assert_allclose(out["rbs"][e][:, 0:3], rbs[:, 0:3], atol=5e-4, err_msg="body pos")
+        np.testing.assert_allclose(out["rbs"][e][:, 7:13], rbs[:, 7:13], atol=1e-2, rtol=2e-3, err_msg="body vel")
+        np.testing.assert_allclose(out["dof"][e, :, 1], d[:, 1], atol=1e-2, rtol=2e-3, err_msg=f"dof vel env {e}")
+        np.testing.assert_allclose(out["cf"][e], fc, atol=3.0, rtol=2e-2, err_msg="net ground force per body")
+    assert n_contacts > 0
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_rigid_contact_is_rigid_unilateral_and_carries_the_weight(backend):
+    """Physical checks of contact_model 1 on a standing humanoid (PD holds the rest pose): started 3 cm above the ground it lands and comes to rest
+    WITHOUT sinking in (lowest contact point within +-0.3 mm of the plane; the penalty model rests ~1 mm inside), the published ground forces sum
+    to the body weight, no body is ever pulled down (F_z >= 0: the constraint is unilateral), it does not bounce (restitution 0), and a
+    speculative contact (contact_offset) stops the approach AT the plane instead of after a penetration."""
+    be = get_backend(backend)
+    model, mstruct, keep = model_on(be)
+    nd = model.num_dof
+    root = np.zeros((1, 13), F)
+    root[0, 6] = 1.0
+    st0 = do.State(root[0].astype(np.float64), np.zeros((nd, 2)), model)
+    Q, R, p = do.kinematics(model, st0)
+    low0 = min(p[i][2] + (R[i] @ model.contact_pos[k])[2] - model.contact_radius[k] for k, i in enumerate(model.contact_body))
+    root[0, 2] = -low0 + 0.03
+    weight = model.mass.sum() * 9.81
+
+    def lowest(rbs):
+        q = rbs[:, 3:7].astype(np.float64)
+        z = []
+        for k, i in enumerate(model.contact_body):
+            Rm = do.quat_to_mat(q[i])
+            z.append(rbs[i, 2] + (Rm @ model.contact_pos[k])[2] - model.contact_radius[k])
+        return min(z)
+    for mdl, tol in ((1, 3e-4), (0, 3e-3)):
+        params = abi.sim_params_struct(contact_model=mdl, contact_iterations=4)
+        out = dict(root=root.copy(), dof=np.zeros((1, nd, 2), F))
+        tgt = np.zeros((1, nd), F)
+        lows, fzs, vz = [], [], []
+        for step in range(45):      # 1.5 s
+            out = run_step(be, model, mstruct, out["root"], out["dof"], tgt, params, 2)
+            lows.append(lowest(out["rbs"][0])); fzs.append(out["cf"][0][:, 2].copy()); vz.append(out["root"][0, 9])
+        lows, fzs, vz = np.array(lows), np.array(fzs), np.array(vz)
+        assert (fzs >= -1e-3).all(), "a ground contact never pulls"
+        assert lows.min() > -tol * (1 if mdl else 3), (mdl, lows.min())         # never deeper than this
+        assert abs(lows[-10:].mean()) < tol and np.abs(vz[-10:]).max() < 0.02, (mdl, lows[-10:], vz[-10:])
+        np.testing.assert_allclose(fzs[-10:].sum(-1).mean(), weight, rtol=0.03)
+        if mdl == 1:
+            touch = int(np.argmax(fzs.sum(-1) > 0))
+            assert (vz[touch + 2:touch + 12] < 0.05).all(), "no bounce"
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_rigid_contact_sliding_friction_decelerates_at_mu_g(backend):
+    """The Coulomb cone of contact_model 1 on END-of-step force and slip: a lying humanoid sliding at 2 m/s decelerates at mu g, then sticks."""
+    be = get_backend(backend)
+    model, mstruct, keep = model_on(be)
+    for mu in (1.0, 0.5):
+        n = 2
+        root = np.zeros((n, 13), F)
+        root[:, 2] = 0.12
+        root[:, 3:7] = np.array([0.0, -np.sqrt(0.5), 0.0, np.sqrt(0.5)], F)
+        dof = np.zeros((n, 69, 2), F)
+        target = np.zeros((n, 69), F)
+        params = abi.sim_params_struct(friction=mu, **RIGID)
+        out = dict(root=root, dof=dof)
+        for _ in range(10):
+            out = run_step(be, model, mstruct, out["root"], out["dof"], target, params, 2)
+        r = out["root"].copy()
+        assert (r[:, 2] < 0.2).all() and np.abs(r[:, 7:10]).max() < 0.5, r
+        r[:, 7] = 2.0
+        r[:, 8:13] = 0
+        d = out["dof"].copy()
+        d[:, :, 1] = 0
+        o = dict(root=r, dof=d)
+        for _ in range(3):
+            o = run_step(be, model, mstruct, o["root"], o["dof"], target, params, 2)
+        v = o["root"][:, 7]
+        expect = 2.0 - mu * 9.81 * 0.1
+        assert np.all(np.abs(v - expect) < 0.25 * mu * 9.81 * 0.1 + 0.05), (mu, v, expect)
+        for _ in range(12):
+            o = run_step(be, model, mstruct, o["root"], o["dof"], target, params, 2)
+        assert np.abs(o["root"][:, 7]).max() < 0.03, "sticks once the slip is gone"

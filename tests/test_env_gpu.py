@@ -1224,3 +1224,33 @@ def test_rollout_graphs_follow_resample_motions_and_evaluate():
             assert agent._roll_generation == gens[-1] and any(k[0] == "step" for k in agent._roll_graphs)
         runs[mode] = np.isfinite(info["eval/mpjpe_all"])
     assert all(runs.values())
+
+
+def test_tgs_contact_option_env_steps_match_the_dense_oracle_and_the_humanoid_stands():
+    """`+solver.contact=tgs` (phc_sim_params_t.contact_model 1, ABI 34): the task installs the rigid ground-contact model with the PhysX parameters of
+    sim/default_sim.yaml (4 passes, max_depenetration_velocity 10, bounce threshold 0.2); whole env steps agree with the fp64 dense oracle of the
+    same model, every post-physics output with the numpy oracle, and a humanoid under zero actions keeps standing ON the plane (the penalty model
+    rests ~1 mm inside it)."""
+    from step_oracle import StepChecker
+    task, env = make_task(256, motion="synthetic:2:1", **{"+solver.contact": "tgs"})
+    sp = task._sim_params
+    assert sp.contact_model == 1 and sp.contact_iterations == 4 and abs(sp.max_depenetration_velocity - 10.0) < 1e-6 and abs(sp.bounce_threshold_velocity - 0.2) < 1e-6
+    env.reset()
+    chk = StepChecker(task)
+    for it in range(4):
+        chk.before()
+        actions = (torch.rand(256, 69, device=task.device) * 2 - 1) * 0.2
+        obs, rew, done, info = env.step(actions)
+        chk.dynamics(actions, [0, 1, 100, 255], pos_atol=2e-3, root_atol=4e-3)
+        chk.after(obs, rew, done, info)
+        task.reset_done()
+    stand, env2 = make_task(64, motion="stand:4", **{"+solver.contact": "tgs"})
+    env2.reset()
+    zero = (torch.zeros(64, 69, device=stand.device) - stand._pd_action_offset) / stand._pd_action_scale   # PD target = the rest pose
+    for _ in range(60):
+        obs, rew, done, info = env2.step(zero)
+    torch.cuda.synchronize()
+    assert int(stand.progress_buf.min()) >= 60 and float(stand._rigid_body_pos[:, 0, 2].min()) > 0.85, "still standing after 2 s"
+    fz = stand._contact_forces[..., 2].sum(-1)
+    weight = float(stand.model.mass.sum()) * 9.81
+    assert float((fz / weight - 1).abs().max()) < 0.15, (fz / weight)
