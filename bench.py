@@ -57,6 +57,8 @@ def parse():
     ap.add_argument("--config", type=int, default=2, choices=[2, 3, 5], help="BASELINE.json configs preset (1-based): 2 = SMPL 4096 envs single "
                     "clip (the bench line), 3 = 8192 envs + AMASS-sized synthetic library (--motion-clips, default 11313), 5 = H1 4096 envs")
     ap.add_argument("--ppo-epochs", type=int, default=3, help="timed PPO epochs (rollout 32 steps + 48 optimizer steps: 6 mini-epochs x 8 minibatches); 0 = skip")
+    ap.add_argument("--learning", default="im", help="learner config of the PPO part (phc/data/cfg/learning/*.yaml): im (the bench line: 1024-512 ReLU), "
+                    "im_big / im_pnn_big (the reference's flagship 2048-1536-1024-1024-512-512 SiLU networks; im_pnn* also selects env=env_im_pnn)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-workloads", action="store_true", help="skip the two extra env-step measurements (tracking actions, Unitree H1) "
                     "that the default single-GPU run appends as `other_workloads`")
@@ -185,6 +187,46 @@ def cpu_reference():
             "source": "profiles/" + files[-1]}
 
 
+def config0_line(dev):
+    """BASELINE.json configs[0] -- "poselib FK + imitation-reward on 64 envs, CPU PyTorch, single AMASS clip (plumbing, no GPU)" -- next to the same
+    work on the MI355X: `phc_fk` over 64 poses of one clip + the post-physics launch (reference lookup x2, imitation reward, reset test,
+    observations, AMP frame) of a 64-env task, timed with HIP events over 200 repetitions; the reference side is its own poselib
+    `SkeletonState.from_rotation_and_root_translation` + `compute_imitation_reward` timed by oracle/time_reference.py in the build container."""
+    from phc_amd.config import compose
+    from phc_amd.env.tasks.vec_task import parse_task
+    from phc_amd import _lib as L
+    files = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_reference_cpu_stages.json"))
+    ref = json.load(open(os.path.join(ROOT, "profiles", files[-1]))).get("config0") if files else None
+    task, env = parse_task(compose(["env.num_envs=64", "env.motion_file=synthetic:1:0", f"device_id={dev.index or 0}", f"rl_device={dev}"]), device_id=dev.index or 0)
+    env.reset()
+    lib = task._motion_lib
+    lr = lib.lrs[:64].contiguous()
+    rt = lib.gts[:64, 0].contiguous()
+    grot, gpos = torch.empty(64, task.num_bodies, 4, device=dev), torch.empty(64, task.num_bodies, 3, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    def once():
+        L.check(task._lib.phc_fk(task._model_struct, 64, lr.data_ptr(), rt.data_ptr(), grot.data_ptr(), gpos.data_ptr(), stream), "phc_fk")
+        task.post_physics_step()
+    for _ in range(20):
+        once()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    torch.cuda.synchronize()
+    ev[0].record()
+    for _ in range(200):
+        once()
+    ev[1].record()
+    torch.cuda.synchronize()
+    ms = ev[0].elapsed_time(ev[1]) / 200
+    out = {"what": "BASELINE configs[0] shape: FK of 64 poses of one clip + imitation reward (+ the rest of post-physics) on 64 envs",
+           "mi355x_ms": ms, "mi355x_env_evaluations_per_s": 64 / (ms * 1e-3), "mi355x_method": "HIP events around 200 x (phc_fk + phc_im_post_physics), 64 envs "
+           "(launch-latency bound at this size: two launches)"}
+    if ref is not None:
+        out.update(reference_cpu_ms=ref["fk_plus_reward_ms"], reference_cpu_poselib_fk_ms=ref["poselib_fk_ms"], reference_cpu_env_evaluations_per_s=ref["env_evaluations_per_s"],
+                   reference_source="profiles/" + files[-1] + " (build container, host stated there)")
+    return out
+
+
 def other_workloads():
     """The same env step on the other single-GPU workloads of BASELINE.json, measured NOW by child runs of this script (so that the driver's
     line carries them too): configs[1] with tracking actions (no reset storm), configs[4] Unitree H1.  -> {name: {value, ms_per_step, ...}}."""
@@ -201,6 +243,14 @@ def other_workloads():
                          "workload": d["config"]["workload"], "envs_per_gpu": d["config"]["envs_per_gpu"]}
         except Exception as exc:   # noqa: BLE001
             out[name] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
+    # the PPO half on the reference's flagship learner config (phc/data/cfg/learning/im_pnn_big.yaml: 2048-1536-1024-1024-512-512, SiLU, PNN actor)
+    cmd = [sys.executable, os.path.abspath(__file__), "--steps", "20", "--warmup", "5", "--ppo-epochs", "3", "--learning", "im_pnn_big", "--no-cpu-baseline", "--no-pmc"]
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420)
+        d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        out["ppo_learning_im_pnn_big"] = {k: d[k] for k in ("ppo_samples_per_s", "ppo_epoch_ms", "ppo_play_ms", "ppo_update_ms", "ppo_roofline", "ppo_config") if k in d}
+    except Exception as exc:   # noqa: BLE001
+        out["ppo_learning_im_pnn_big"] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
     return out
 
 
@@ -343,7 +393,8 @@ def main():
     graph_over = ["+learning.params.config.hip_graph=True"] if not args.no_update_graph else []
     if args.force_rccl:
         graph_over.append("+learning.params.config.force_collectives=True")
-    cfg = compose(robot_over + graph_over + [f"env.num_envs={args.envs}", f"env.motion_file=synthetic:{args.motion_clips}:0", f"device_id={local_rank}",
+    learn_over = ([f"learning={args.learning}"] + (["env=env_im_pnn"] if "pnn" in args.learning and args.robot == "smpl" else [])) if args.learning != "im" else []
+    cfg = compose(learn_over + robot_over + graph_over + [f"env.num_envs={args.envs}", f"env.motion_file=synthetic:{args.motion_clips}:0", f"device_id={local_rank}",
                                 f"rl_device=cuda:{local_rank}", f"+solver.lane_mapping={args.lane_mapping}"] + ([f"+solver.self_collision={args.self_collision}"] if args.self_collision >= 0 else []))
     t_build = time.perf_counter()
     task, env = parse_task(cfg, device_id=local_rank)
@@ -420,6 +471,7 @@ def main():
         try:
             from phc_amd.learning.bench_ppo import time_ppo_epochs
             ppo = time_ppo_epochs(task, env, cfg, args.ppo_epochs, dist)
+            ppo["ppo_config"]["learning"] = args.learning
         except ImportError:
             ppo = None
 
@@ -478,6 +530,11 @@ def main():
             ref = cpu_reference()
             if ref is not None:
                 out["cpu_reference"] = ref
+            if not os.environ.get("PHC_BENCH_CHILD"):
+                try:
+                    out["config0"] = config0_line(dev)
+                except Exception as e:   # never lose the line over the plumbing comparison
+                    out["config0"] = {"error": repr(e)}
         if cfg3 is not None:
             out["config3_motion_library"] = cfg3
         if (world == 1 and not args.no_other_workloads and not os.environ.get("PHC_BENCH_CHILD") and args.config == 2 and args.robot == "smpl"

@@ -10,6 +10,9 @@ Stages (5 warm-up + 50 timed iterations, median), at N = 64 and N = 4096 on the 
   (2) 2 x get_motion_state                                   (motion_lib_base.py:437-520)
   (3) compute_imitation_reward + compute_humanoid_im_reset   (humanoid_im.py:1524-1554, 1581-1608)
   (4) compute_humanoid_observations_smpl_max + compute_imitation_observations_v6 + build_amp_observations_smpl
+  (c0) BASELINE.json configs[0] as written -- "poselib FK + imitation-reward on 64 envs, CPU PyTorch, single AMASS clip": one
+       `SkeletonState.from_rotation_and_root_translation(...).global_translation / .global_rotation` (poselib FK, skeleton3d.py:390-426) over
+       64 poses of ONE clip + one `compute_imitation_reward` on the 64 resulting body states (round 4)
 There is no reference CPU number for the dynamics (Isaac Gym is a closed GPU binary).
 """
 import json
@@ -121,9 +124,35 @@ def main():
         a, b, c = median_ms(s2), median_ms(s3), median_ms(s4)
         out["stages"][str(N)] = {"get_motion_state_x2_ms": a, "reward_reset_ms": b, "observations_ms": c, "sum_ms": a + b + c,
                                  "env_steps_per_s_reward_obs_only": N / ((a + b + c) * 1e-3)}
+    # ---- BASELINE configs[0]: poselib FK + imitation reward, 64 envs, single clip ----
+    from poselib.poselib.skeleton.skeleton3d import SkeletonState
+    clip0 = list(clips.values())[0]
+    T0 = len(clip0["root_trans_offset"])
+    fr = torch.arange(64) % T0
+    pq = torch.from_numpy(np.asarray(clip0["pose_quat_global"], np.float32))[fr]          # [64, 24, 4] global rotations of 64 frames
+    rt = clip0["root_trans_offset"][fr].float()
+    state0 = SkeletonState.from_rotation_and_root_translation(tree, pq, rt, is_local=False)
+    local_rot = state0.local_rotation.clone()
+    ids0 = torch.zeros(64, dtype=torch.long)
+    t64 = fr.float() / 30
+    ref64 = lib.get_motion_state(ids0, t64, offset=torch.zeros(64, 3))
+
+    def c0_fk():
+        s_ = SkeletonState.from_rotation_and_root_translation(tree, local_rot, rt, is_local=True)
+        return s_.global_translation, s_.global_rotation
+
+    def c0_reward():
+        gp, gr = c0_fk()
+        him.compute_imitation_reward(gp[:, 0], gr[:, 0], gp, gr, ref64["body_vel"], ref64["body_ang_vel"], ref64["rg_pos"], ref64["rb_rot"],
+                                     ref64["body_vel"], ref64["body_ang_vel"], specs)
+    fk_ms, both_ms = median_ms(c0_fk), median_ms(c0_reward)
+    out["config0"] = {"what": "BASELINE configs[0]: poselib FK (SkeletonState.from_rotation_and_root_translation -> global_translation / global_rotation) "
+                              "of 64 poses of one clip + compute_imitation_reward on them, CPU PyTorch fp32", "envs": 64, "poselib_fk_ms": fk_ms,
+                      "fk_plus_reward_ms": both_ms, "env_evaluations_per_s": 64 / (both_ms * 1e-3)}
+    out["date"] = time.strftime("%Y-%m-%d")
     out["protocol"] = "BASELINE.md section 2: 5 warm-up + 50 timed iterations, median; torch.set_num_threads(all usable cores); fp32"
     out["measured_in"] = "build container (the reference is a Python checkout under /root/reference and cannot travel to the GPU box)"
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
     dst = os.path.join(ROOT, "profiles", f"{tag}_reference_cpu_stages.json")
     json.dump(out, open(dst, "w"), indent=1)
     print(json.dumps(out, indent=1))

@@ -131,8 +131,12 @@ __device__ __forceinline__ bool stage_aligned(const phc_sim_state_t& sim) {
 // >256 VGPRs: 214-252 us vs 158 us for this mapping.  __launch_bounds__(64, 2): two wavefronts per SIMD (<= 256 VGPRs,
 // 68 B/lane of scratch) beats one (272 registers, no scratch: 195 us) and three (168 VGPRs, 412 B scratch: 280 us).
 // ------------------------------------------------------------------------------------------
-template <bool STEP, int JT, int GRP, bool SHAPES = false, bool RIGID = false>
-__global__ __launch_bounds__(64, 2) void k_sim_step(phc_model_t model_all, phc_sim_params_t prm, phc_sim_state_t sim,
+// OCC: wavefronts per SIMD the register allocation aims at.  2 (<= 256 VGPRs, no scratch) is the fastest launch while all wavefronts are resident at
+// once (up to 4096 envs of <= 32 bodies: 2048 wavefronts = 2 per SIMD).  Above that a launch runs in occupancy ROUNDS; OCC = 3 (168 VGPRs,
+// 116 B / lane of scratch) trades a slower wavefront for 3072 resident ones -- BASELINE configs[2] (8192 envs) then needs 1.33 rounds
+// instead of 2 (profiles/r04_stepper_occupancy.txt).
+template <bool STEP, int JT, int GRP, bool SHAPES = false, bool RIGID = false, int OCC = 2>
+__global__ __launch_bounds__(64, OCC) void k_sim_step(phc_model_t model_all, phc_sim_params_t prm, phc_sim_state_t sim,
                                                 const float* __restrict__ actions, const float* __restrict__ pd_off,
                                                 const float* __restrict__ pd_scale, const int32_t* __restrict__ freeze,
                                                 int num_sim_calls, const int64_t* __restrict__ env_ids, int num_listed) {
@@ -271,7 +275,13 @@ static void sim_launch_cm(const phc_model_t* model, const phc_sim_params_t& prm,
                           const int64_t* env_ids, int num_listed) {
     const int64_t groups = env_ids ? num_listed : sim->num_envs;
     const bool wide = model->num_bodies > 32;   // more bodies than a 32-lane group holds: one env per wavefront
-    if (wide)
+    // more wavefronts than fit at two per SIMD (256 CUs x 4 SIMDs): the 3-per-SIMD register allocation (lane_mapping 0 = auto, 1 / 3 force)
+    const int64_t waves = wide ? groups : (groups + 1) / 2;
+    const bool occ3 = STEP && !RIGID && !SHAPES && JT == PHC_JT_SPHERICAL && !wide && (prm.lane_mapping == 3 || (prm.lane_mapping == 0 && waves > 2 * 1024 + 256));
+    if (occ3)
+        hipLaunchKernelGGL((k_sim_step<STEP, JT, 32, SHAPES, RIGID, (STEP && !RIGID && !SHAPES && JT == PHC_JT_SPHERICAL) ? 3 : 2>), dim3((groups + 1) / 2), dim3(64), 0, stream,
+                           *model, prm, *sim, actions, off, scale, freeze, num_sim_calls, env_ids, num_listed);
+    else if (wide)
         hipLaunchKernelGGL((k_sim_step<STEP, JT, 64, SHAPES, RIGID>), dim3(groups), dim3(64), 0, stream, *model, prm, *sim, actions, off, scale, freeze,
                            num_sim_calls, env_ids, num_listed);
     else
@@ -326,7 +336,7 @@ int32_t phc_sim_step(const phc_model_t* model, const phc_sim_params_t* params, c
     if (sim->num_envs == 0) return 0;
     // pairs are dealt round-robin to the lanes of an env's group: PHC_SC_MAX_PER_LANE each
     if (params->self_collision && model->num_collision_pairs > PHC_SC_MAX_PER_LANE * (model->num_bodies > 32 ? 64 : 32)) return PHC_EUNSUPPORTED;
-    if (params->lane_mapping != 0 && params->lane_mapping != 1) return PHC_EUNSUPPORTED;
+    if (params->lane_mapping != 0 && params->lane_mapping != 1 && params->lane_mapping != 3) return PHC_EUNSUPPORTED;
     if (params->contact_model != 0 && params->contact_model != 1) return PHC_EUNSUPPORTED;
     if (params->contact_model == 1 && (params->contact_iterations < 1 || !(params->contact_impedance > 0.f))) return PHC_EINVAL;   // (2 was the two-bodies-per-lane kernel of rounds 1-2: removed)
     sim_launch<true>(model, *params, sim, actions, pd_action_offset, pd_action_scale, freeze_mask, num_sim_calls, (hipStream_t)stream);

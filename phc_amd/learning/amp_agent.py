@@ -275,11 +275,13 @@ class IMAmpAgent:
         padded_k = {p.shape[1]: p._padded.shape[1] for p in self.grads.params if getattr(p, "_padded", None) is not None}
         self._obs_pad_cols = padded_k.get(obs_dim, 0)
         self._amp_pad_cols = padded_k.get(amp_dim, 0)
-        # opt-in (`learning.params.config.hip_graph=True`, bench.py sets it).  Known hazard (scripts/probes/graph_repro2.py): if the caller keeps
-        # an autograd-tracked copy of a parameter alive (`w0 = p.clone()` instead of `p.detach().clone()`), that parameter's
-        # AccumulateGrad node lives on the stream it was created on; the captured backward then has to hand the gradient to a stream
-        # that is not capturing and `hipStreamEndCapture` segfaults on ROCm 7.2 instead of raising.
-        self._use_graph = bool(c.get("hip_graph", False))
+        # ON by default on the device since round 4 (`+learning.params.config.hip_graph=False` turns it off): a user of `python -m phc_amd.run` gets the
+        # update the bench line quotes.  Known hazard (scripts/probes/graph_repro2.py): if the caller keeps an autograd-tracked copy of a
+        # parameter alive (`w0 = p.clone()` instead of `p.detach().clone()`), that parameter's AccumulateGrad node lives on the stream it was
+        # created on; the captured backward then has to hand the gradient to a stream that is not capturing and `hipStreamEndCapture` segfaults on
+        # ROCm 7.2 instead of raising -- `_stale_grad_accumulators()` detects exactly that before capturing and the update falls back to eager
+        # launches, as it does when a capture raises or the minibatch is small (< 2048 rows: not launch-bound).
+        self._use_graph = bool(c.get("hip_graph", True))
         self._graph = self._g_data = self._g_idx = self._g_info = None
         self._graph_failed = False
         # one flat fp32 parameter; on the device clip + step are two HIP launches over it (fast_ops.adam_clip_step) and this object

@@ -1196,7 +1196,7 @@ def test_rollout_graphs_follow_resample_motions_and_evaluate():
             "learning.params.config.amp_replay_buffer_size": 4096}
     runs = {}
     for mode in ("graph", "eager"):
-        task, env = make_task(256, motion="synthetic:6:1:1.5", seed=5, **dict(over, **({"+learning.params.config.hip_graph": True} if mode == "graph" else {})))
+        task, env = make_task(256, motion="synthetic:6:1:1.5", seed=5, **dict(over, **{"+learning.params.config.hip_graph": mode == "graph"}))
         agent = IMAmpAgent(env, task.cfg)
         agent.init_train()
         for _ in range(3):
