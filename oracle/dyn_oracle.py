@@ -185,25 +185,24 @@ def seg_seg_closest(p1, q1, p2, q2):
 
 
 def self_collision_wrenches(model, R, p, w, v, prm, dt):
-    """Explicit capsule-capsule penalty forces between bodies that may collide: (F[NB,3], N[NB,3] about each body origin)."""
+    """Explicit capsule-capsule penalty forces between the collision SHAPES that may collide (model.collision_pairs(): a body may carry more
+    than one capsule since round 4): (F[NB,3], N[NB,3] about each body origin)."""
     nb = model.num_bodies
     F, N = np.zeros((nb, 3)), np.zeros((nb, 3))
-    masks = model.collision_allow_masks()
-    cap = model.collision_capsule
-    A = np.array([p[i] + R[i] @ cap[i, 0:3] for i in range(nb)])
-    B = np.array([p[i] + R[i] @ cap[i, 3:6] for i in range(nb)])
-    for i in range(nb):
-        for k in range(nb):
-            if not (int(masks[i]) >> k) & 1:
-                continue
-            c1, c2 = seg_seg_closest(A[i], B[i], A[k], B[k])
+    own, cap = model.shape_owner(), model.shape_capsules()
+    A = np.array([p[o] + R[o] @ c[0:3] for o, c in zip(own, cap)])
+    B = np.array([p[o] + R[o] @ c[3:6] for o, c in zip(own, cap)])
+    for s1, s2 in model.collision_pairs():
+        for a, b in ((s1, s2), (s2, s1)):      # both directions: each owner receives its own force
+            i, k = int(own[a]), int(own[b])
+            c1, c2 = seg_seg_closest(A[a], B[a], A[b], B[b])
             n = c1 - c2
             dist = np.linalg.norm(n)
-            pen = cap[i, 6] + cap[k, 6] - dist
+            pen = cap[a, 6] + cap[b, 6] - dist
             if pen <= 0:
                 continue
             n = n / dist if dist > 1e-6 else np.array([0.0, 0.0, 1.0])
-            cp = c2 + n * (cap[k, 6] - 0.5 * pen)
+            cp = c2 + n * (cap[b, 6] - 0.5 * pen)
             vrel = (v[i] + cross3(w[i], cp - p[i])) - (v[k] + cross3(w[k], cp - p[k]))
             mu = model.mass[i] * model.mass[k] / (model.mass[i] + model.mass[k])
             kk = prm["self_stiffness_scale"] * mu / (dt * dt)

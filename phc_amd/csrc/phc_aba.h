@@ -615,8 +615,13 @@ PHC_HD void seg_seg_closest(V3 p1, V3 q1, V3 p2, V3 q2, V3* c1, V3* c2) {
 // env's group, so every lane tests different pairs (no redundant work, no per-body imbalance).  A contact adds +-F and the moments
 // to the two bodies' accumulators with INTEGER (fixed-point) LDS atomics: integer addition is associative, so the sums do not
 // depend on the order lanes arrive in -- bit-reproducible and exactly antisymmetric.
-// Per-body record in the exchange area (PHC_CAP_STRIDE words): [0..4) bounding sphere (centre, radius) | [4..8) a, radius |
-// [8..12) b, mass | [12..18) int32 accumulators F(3) N(3).
+// Per-SHAPE record in the exchange area (PHC_CAP_STRIDE words): [0..4) bounding sphere (centre, radius) | [4..8) a, radius |
+// [8..12) b, owner's mass | [12..18) int32 accumulators F(3) N(3) of BODY s (shape s < NB is body s's primary capsule) | [18] owner body.
+// Round 4: a body may carry more than one collision capsule (the second half of a flat box -- SMPL toes / hands --, further geoms of a multi-geom
+// link -- G1 torso / forearm); the extra capsules are shapes NB .. NB + NX - 1, published by the idle lanes behind the bodies (model.py pack():
+// NX in the misc table, records a[3] b[3] radius owner after the contact points), and the candidate list pairs SHAPES.
+PHC_HD int model_num_extra_shapes(const phc_model_t& m) { return model_tab(m, 11, 5); }
+PHC_HD const float* model_extra_shape(const phc_model_t& m, int e) { return m.floats + PHC_MAX_BODIES * PHC_BODY_FLOATS + m.ints[3] * 4 + e * 8; }
 PHC_HD int model_num_pairs(const phc_model_t& m) { return m.ints[4 + PHC_NTAB * PHC_MAX_BODIES]; }
 PHC_HD int model_pair(const phc_model_t& m, int q) { return m.ints[4 + PHC_NTAB * PHC_MAX_BODIES + 1 + q]; }
 PHC_HD void sc_atomic_add(int32_t* p, int32_t v) {
@@ -626,15 +631,29 @@ PHC_HD void sc_atomic_add(int32_t* p, int32_t v) {
     *p += v;   // the host emulation walks the pairs sequentially
 #endif
 }
-PHC_HD void aba_publish_capsule(const AbaLane& L, const float* f, float* cap) {
-    const M3 R = quat_to_mat(L.Q);
-    const V3 a = L.p + mat_mul(R, v3(f[36], f[37], f[38])), b = L.p + mat_mul(R, v3(f[39], f[40], f[41]));
+PHC_HD void cap_write(float* cap, V3 a, V3 b, float radius, float mass, int owner) {
     const V3 mid = (a + b) * 0.5f;
-    cap[0] = mid.x; cap[1] = mid.y; cap[2] = mid.z; cap[3] = 0.5f * norm(b - a) + f[42];
-    cap[4] = a.x; cap[5] = a.y; cap[6] = a.z; cap[7] = f[42];
-    cap[8] = b.x; cap[9] = b.y; cap[10] = b.z; cap[11] = f[3];
+    cap[0] = mid.x; cap[1] = mid.y; cap[2] = mid.z; cap[3] = 0.5f * norm(b - a) + radius;
+    cap[4] = a.x; cap[5] = a.y; cap[6] = a.z; cap[7] = radius;
+    cap[8] = b.x; cap[9] = b.y; cap[10] = b.z; cap[11] = mass;
     int32_t* acc = reinterpret_cast<int32_t*>(cap + 12);
     for (int k = 0; k < 6; ++k) acc[k] = 0;
+    acc[6] = owner;
+}
+PHC_HD void aba_publish_capsule(const AbaLane& L, const float* f, float* cap, int j) {
+    const M3 R = quat_to_mat(L.Q);
+    cap_write(cap, L.p + mat_mul(R, v3(f[36], f[37], f[38])), L.p + mat_mul(R, v3(f[39], f[40], f[41])), f[42], f[3], j);
+}
+// extra shape e (lane NB + e of the env's group): its owner's pose comes from the owner's exchange slot (kinematics of the last sweep)
+PHC_HD void aba_publish_extra_capsule(const phc_model_t& m, int e, const Xch& x, float* caps) {
+    const float* r = model_extra_shape(m, e);
+    const int owner = (int)r[7];
+    constexpr int es = Xch::es;
+    const float* s = xslot(x, owner);
+    const M3 R = quat_to_mat(q4(s[6 * es], s[7 * es], s[8 * es], s[9 * es]));
+    const V3 p = v3(s[10 * es], s[11 * es], s[12 * es]);
+    cap_write(caps + PHC_CAP_STRIDE * (m.num_bodies + e), p + mat_mul(R, v3(r[0], r[1], r[2])), p + mat_mul(R, v3(r[3], r[4], r[5])), r[6],
+              model_body(m, owner)[3], owner);
 }
 // one candidate pair (bodies i < k): bounding spheres, then the capsule-capsule test, then the penalty force into both accumulators.
 // Needs both bodies' capsules in `caps` and kinematics (p w v at slot floats [10..19)) in the exchange slots.
@@ -664,8 +683,9 @@ PHC_HD bool aba_pair_narrow(const phc_sim_params_t& prm, float dt, int i, int k,
     n = dist > 1e-6f ? n * (1.0f / dist) : v3(0.f, 0.f, 1.f);
     const V3 cp = c2 + n * (r2 - 0.5f * pen);                // middle of the overlap
     constexpr int es = Xch::es;
-    const float* si = xslot(x, i);
-    const float* sk = xslot(x, k);
+    const int oi = reinterpret_cast<const int32_t*>(ci)[18], ok = reinterpret_cast<const int32_t*>(ck)[18];   // owner bodies of the two shapes
+    const float* si = xslot(x, oi);
+    const float* sk = xslot(x, ok);
     const V3 pi = v3(si[10 * es], si[11 * es], si[12 * es]), wi = v3(si[13 * es], si[14 * es], si[15 * es]), vi = v3(si[16 * es], si[17 * es], si[18 * es]);
     const V3 pk = v3(sk[10 * es], sk[11 * es], sk[12 * es]), wk = v3(sk[13 * es], sk[14 * es], sk[15 * es]), vk = v3(sk[16 * es], sk[17 * es], sk[18 * es]);
     const V3 vrel = (vi + cross(wi, cp - pi)) - (vk + cross(wk, cp - pk));
@@ -678,8 +698,8 @@ PHC_HD bool aba_pair_narrow(const phc_sim_params_t& prm, float dt, int i, int k,
     const int32_t fx = (int32_t)rintf(n.x * fn * PHC_SC_FSCALE), fy = (int32_t)rintf(n.y * fn * PHC_SC_FSCALE), fz = (int32_t)rintf(n.z * fn * PHC_SC_FSCALE);
     const V3 F = v3((float)fx, (float)fy, (float)fz) * (1.0f / PHC_SC_FSCALE);
     const V3 ni = cross(cp - pi, F), nk = cross(cp - pk, F);
-    int32_t* ai = reinterpret_cast<int32_t*>(caps + PHC_CAP_STRIDE * i + 12);
-    int32_t* ak = reinterpret_cast<int32_t*>(caps + PHC_CAP_STRIDE * k + 12);
+    int32_t* ai = reinterpret_cast<int32_t*>(caps + PHC_CAP_STRIDE * oi + 12);
+    int32_t* ak = reinterpret_cast<int32_t*>(caps + PHC_CAP_STRIDE * ok + 12);
     sc_atomic_add(ai + 0, fx); sc_atomic_add(ai + 1, fy); sc_atomic_add(ai + 2, fz);
     sc_atomic_add(ak + 0, -fx); sc_atomic_add(ak + 1, -fy); sc_atomic_add(ak + 2, -fz);
     sc_atomic_add(ai + 3, (int32_t)rintf(ni.x * PHC_SC_NSCALE)); sc_atomic_add(ai + 4, (int32_t)rintf(ni.y * PHC_SC_NSCALE)); sc_atomic_add(ai + 5, (int32_t)rintf(ni.z * PHC_SC_NSCALE));

@@ -196,7 +196,8 @@ __global__ __launch_bounds__(64, OCC) void k_sim_step(phc_model_t model_all, phc
             const int tl_sub = s; (void)tl_sub;
             PHC_TL(1)
             if (prm.self_collision && !PHC_SKIP(0)) {   // body-body contact from the kinematics the last sweep left in the exchange slots
-                if (active) aba_publish_capsule(L, model_body(model, body), caps + PHC_CAP_STRIDE * body);
+                if (active) aba_publish_capsule(L, model_body(model, body), caps + PHC_CAP_STRIDE * body, body);
+                else if (env < sim.num_envs && lane < nb + model_num_extra_shapes(model)) aba_publish_extra_capsule(model, lane - nb, x, caps);   // idle lanes: the extra shapes
                 __syncthreads();
                 if (env < sim.num_envs) aba_collide_pairs<PHC_SC_MAX_PER_LANE>(pair_all + threadIdx.x, 64, prm, dt, x, caps, near_pairs, s == 0);
                 __syncthreads();

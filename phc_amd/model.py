@@ -129,33 +129,41 @@ class _Attr:
         self.attrib = attrib
 
 
-def _geom_capsule(g, defaults, pts):
-    """Collision capsule (a[3], b[3], radius) standing in for a body's geom in body-body contact: spheres and capsules are
-    exact, a box becomes the capsule along its longest axis with the mean of the two other half extents as radius, a mesh the
-    capsule spanned by its two farthest hull support points with the median distance of the others to that axis."""
+def _geom_capsules(g, defaults, pts):
+    """Collision capsules [(a[3], b[3], radius)] standing in for a geom in body-body contact: spheres and capsules are exact; a box becomes
+    the capsule along its longest axis with the mean of the two other half extents as radius -- or, when it is FLAT (the larger of those two
+    half extents exceeds 1.5 x the smaller: the SMPL toes and hands), TWO capsules of the smaller half extent side by side (round 4); a mesh
+    the capsule spanned by its two farthest hull support points with the median distance of the others to that axis."""
     gtype = g.attrib.get("type", defaults.get("type", "sphere"))
     size = _floats(g.attrib.get("size"), [0.0])
     if gtype == "sphere":
         c = _floats(g.attrib.get("pos"), [0, 0, 0])
-        return np.concatenate([c, c, [size[0]]])
+        return [np.concatenate([c, c, [size[0]]])]
     if gtype in ("capsule", "cylinder"):
         (p0, r), (p1, _) = pts[0], pts[1]
-        return np.concatenate([p0, p1, [r]])
+        return [np.concatenate([p0, p1, [r]])]
     if gtype == "box":
         pos = _floats(g.attrib.get("pos"), [0, 0, 0])
         R = _quat_wxyz_to_mat(_floats(g.attrib.get("quat"), [1, 0, 0, 0]))
         h = size[:3]
         k = int(np.argmax(h))
+        others = [a for a in range(3) if a != k]
+        u, v = (others[0], others[1]) if h[others[0]] >= h[others[1]] else (others[1], others[0])
+        if h[u] > 1.5 * h[v]:
+            r = float(h[v])
+            half = max(h[k] - r, 0.0)
+            off = R[:, u] * (h[u] - r)
+            return [np.concatenate([pos + sgn * off - R[:, k] * half, pos + sgn * off + R[:, k] * half, [r]]) for sgn in (-1.0, 1.0)]
         r = float(np.mean(np.delete(h, k)))
         half = max(h[k] - r, 0.0)
-        return np.concatenate([pos - R[:, k] * half, pos + R[:, k] * half, [r]])
+        return [np.concatenate([pos - R[:, k] * half, pos + R[:, k] * half, [r]])]
     P = np.array([p for p, _ in pts])
     d = np.linalg.norm(P[:, None] - P[None], axis=-1)
     i, j = np.unravel_index(np.argmax(d), d.shape)
     ax = (P[j] - P[i]) / max(d[i, j], 1e-9)
     off = P - P[i]
     rad = float(np.median(np.linalg.norm(off - np.outer(off @ ax, ax), axis=-1)))
-    return np.concatenate([P[i] + ax * rad, P[j] - ax * rad, [rad]]) if d[i, j] > 2 * rad else np.concatenate([0.5 * (P[i] + P[j])] * 2 + [[0.5 * d[i, j]]])
+    return [np.concatenate([P[i] + ax * rad, P[j] - ax * rad, [rad]]) if d[i, j] > 2 * rad else np.concatenate([0.5 * (P[i] + P[j])] * 2 + [[0.5 * d[i, j]]])]
 
 
 def compile_mjcf(path):
@@ -205,6 +213,8 @@ def compile_mjcf(path):
     dof_axis, dof_kp, dof_kd, dof_arm, dof_lo, dof_hi, dof_effort, dof_names = [], [], [], [], [], [], [], []
     cpts = []
     capsules = []
+    extra_caps = []            # (body, shape ordinal, capsule[7]) of every collision capsule beyond a body's first
+    shape_ordinal = {}         # body -> collision geoms seen so far
 
     def add(node, parent):
         idx = len(names)
@@ -229,6 +239,7 @@ def compile_mjcf(path):
             mc = m_tot * c
             parts = [(m_tot, c, Ic)]
         capsules.append(np.zeros(7))
+        shape_ordinal[idx] = 0
         first_geom = True
         for g in node.findall("geom"):
             if "class" in g.attrib:   # effective attributes: class defaults, then the geom's own
@@ -238,9 +249,15 @@ def compile_mjcf(path):
             if g.attrib.get("type") == "mesh" and g.attrib.get("mesh") not in meshes:
                 continue
             gm, gc, gI, pts = _geom_props(g, geom_defaults, meshes)
-            if first_geom:
-                capsules[idx] = _geom_capsule(g, geom_defaults, pts)
-                first_geom = False
+            # collision shapes of the body, in geom order (Isaac Gym enumerates an actor's rigid shapes in this order: the per-shape filter
+            # table of humanoid.py:1205-1226 is indexed by it): the first capsule is the body's primary one, the others are EXTRA capsules
+            for ci, cap7 in enumerate(_geom_capsules(g, geom_defaults, pts)):
+                if first_geom and ci == 0:
+                    capsules[idx] = cap7
+                else:
+                    extra_caps.append((idx, shape_ordinal[idx], cap7))
+            first_geom = False
+            shape_ordinal[idx] += 1
             for p, r in pts:
                 cpts.append((idx, np.asarray(p, dtype=np.float64), float(r)))
             if inert is None:
@@ -284,6 +301,7 @@ def compile_mjcf(path):
     for i in range(1, nb):
         level[i] = level[parents[i]] + 1
     cpts.sort(key=lambda t: t[0])
+    extra_caps.sort(key=lambda t: t[0])
     model = {
         "source": os.path.basename(path),
         "body_names": names,
@@ -305,6 +323,9 @@ def compile_mjcf(path):
         "contact_pos": [c[1].tolist() for c in cpts],
         "contact_radius": [c[2] for c in cpts],
         "collision_capsule": np.array(capsules).tolist(),
+        # [body, shape ordinal within the body (geom order), a[3], b[3], radius] of every collision capsule beyond a body's first
+        "extra_capsules": [[int(b), int(o)] + np.asarray(c7, dtype=np.float64).tolist() for b, o, c7 in extra_caps],
+        "shapes_per_body": [int(shape_ordinal[i]) for i in range(nb)],
     }
     return model
 
@@ -343,6 +364,14 @@ class ArticulationModel:
         self.contact_pos = np.array(d["contact_pos"], dtype=np.float64).reshape(-1, 3)
         self.contact_radius = np.array(d["contact_radius"], dtype=np.float64)
         self.collision_capsule = np.array(d.get("collision_capsule", np.zeros((self.num_bodies, 7))), dtype=np.float64).reshape(-1, 7)
+        # collision SHAPES (round 4): shape s < NB is body s's primary capsule; shapes NB.. are the extra capsules (second half of a flat box,
+        # further geoms of a multi-geom link), each owned by a body.  `shape_filter` = Isaac Gym's per-shape filter word (humanoid.py:1205-1226).
+        ex = np.array(d.get("extra_capsules", []), dtype=np.float64).reshape(-1, 9)
+        self.extra_owner = ex[:, 0].astype(np.int32)
+        self.extra_ordinal = ex[:, 1].astype(np.int32)
+        self.extra_capsule = ex[:, 2:9].copy()
+        self.shapes_per_body = np.array(d.get("shapes_per_body", [1 if c[6] > 0 else 0 for c in self.collision_capsule]), dtype=np.int32)
+        self.shape_filter = np.zeros(self.num_bodies + len(self.extra_owner), dtype=np.int64)
         self.collision_filter = np.zeros(self.num_bodies, dtype=np.int64)   # Isaac Gym shape filter bits (robots.py installs them)
         self.max_level = int(self.level.max())
         self.all_spherical = bool(np.all(self.joint_type[1:] == JOINT_SPHERICAL))
@@ -418,18 +447,64 @@ class ArticulationModel:
             c = p
         return dict(base=best, sparent=par, slevel=lv, schildren=sch, s_off=s_off, jsrc=jsrc, bsrc=bsrc)
 
+    @property
+    def num_shapes_collision(self):
+        return self.num_bodies + len(self.extra_owner)
+
+    def shape_owner(self):
+        return np.concatenate([np.arange(self.num_bodies, dtype=np.int32), self.extra_owner])
+
+    def shape_capsules(self):
+        return np.concatenate([self.collision_capsule, self.extra_capsule.reshape(-1, 7)], axis=0)
+
+    def set_body_filters(self, body_filters):
+        """One Isaac Gym filter word per BODY (every shape of the body takes it)."""
+        f = np.asarray(body_filters, dtype=np.int64)
+        self.collision_filter[:] = f
+        self.shape_filter = f[self.shape_owner()].copy()
+
+    def set_shape_filters(self, shape_filters):
+        """One filter word per SHAPE in the reference's order (bodies in order, a body's shapes in geom order; humanoid.py:1205-1226).  A body's
+        capsules beyond its geoms (the second half of a split box) share their geom's word."""
+        f = np.asarray(shape_filters, dtype=np.int64)
+        assert len(f) == int(self.shapes_per_body.sum()), (len(f), int(self.shapes_per_body.sum()))
+        start = np.concatenate([[0], np.cumsum(self.shapes_per_body)[:-1]])
+        self.shape_filter = np.zeros(self.num_shapes_collision, dtype=np.int64)
+        for b in range(self.num_bodies):
+            n = int(self.shapes_per_body[b])
+            if n:
+                self.shape_filter[b] = f[start[b]]
+                self.collision_filter[b] = int(np.bitwise_or.reduce(f[start[b]:start[b] + n]))
+        for e, (b, o) in enumerate(zip(self.extra_owner, self.extra_ordinal)):
+            self.shape_filter[self.num_bodies + e] = f[start[b] + min(int(o), int(self.shapes_per_body[b]) - 1)]
+
     def collision_allow_masks(self):
         """Bit j of entry i: bodies i and j may collide -- not the same body, not joined by a joint (PhysX articulations never
-        collide parent and child), no common Isaac Gym filter bit (humanoid.py:1205-1226: shapes collide iff (fa & fb) == 0),
-        and both carry a collision capsule."""
+        collide parent and child), no common Isaac Gym filter bit on their PRIMARY shapes (humanoid.py:1205-1226: shapes collide iff
+        (fa & fb) == 0), and both carry a collision capsule.  (Informative: the kernels walk `collision_pairs()`.)"""
         nb = self.num_bodies
         has = self.collision_capsule[:, 6] > 0
+        sf = self.shape_filter if len(self.shape_filter) >= nb and self.shape_filter.any() else self.collision_filter
         m = [0] * nb   # Python ints: bit 63 does not fit a signed 64-bit numpy scalar
         for i in range(nb):
             for j in range(nb):
-                if i != j and has[i] and has[j] and self.parent[i] != j and self.parent[j] != i and (self.collision_filter[i] & self.collision_filter[j]) == 0:
+                if i != j and has[i] and has[j] and self.parent[i] != j and self.parent[j] != i and (int(sf[i]) & int(sf[j])) == 0:
                     m[i] |= 1 << j
         return m
+
+    def collision_pairs(self):
+        """Candidate pairs of collision SHAPES (s1 < s2): different owner bodies that are not joined by a joint, no common filter bit, both with
+        a radius.  With one capsule per body this is the body-pair list of rounds 1-3."""
+        own, cap = self.shape_owner(), self.shape_capsules()
+        sf = self.shape_filter if self.shape_filter.any() else self.collision_filter[own]
+        ns = len(own)
+        out = []
+        for a in range(ns):
+            for b in range(a + 1, ns):
+                i, j = int(own[a]), int(own[b])
+                if i != j and cap[a, 6] > 0 and cap[b, 6] > 0 and self.parent[i] != j and self.parent[j] != i and (int(sf[a]) & int(sf[b])) == 0:
+                    out.append((a, b))
+        return out
 
     # ---- packed buffers --------------------------------------------------------------------
     def pack(self, kp_scale=1.0, kd_scale=1.0):
@@ -497,15 +572,17 @@ class ArticulationModel:
         tab[11, 4] = steps
         # self-collision candidate pairs (i < k, may collide), appended after the tables: [count, i | k << 8, ...]; lane l of a
         # group evaluates pairs l, l + L, l + 2L, ... so the list is ordered to spread each body's pairs over many lanes
-        masks = self.collision_allow_masks()
-        pairs = [(i, k) for i in range(NB) for k in range(i + 1, NB) if (int(masks[i]) >> k) & 1]
+        pairs = self.collision_pairs()
         # lanes work through the list in lock step (pair t * L + l in round t): sorted by the gap between the bounding spheres in
         # the rest pose, a round holds pairs that are either all near (everyone runs the capsule test) or all far (nobody does)
         org = np.zeros((NB, 3))
         for j in range(1, NB):
             org[j] = org[self.parent[j]] + self.local_translation[j]
-        cap = self.collision_capsule
-        mid = org + 0.5 * (cap[:, 0:3] + cap[:, 3:6])
+        own, cap = self.shape_owner(), self.shape_capsules()
+        NX = len(self.extra_owner)
+        assert NB + NX <= (32 if NB <= 32 else MB), "the collision shapes of an env must fit the lanes of its group"
+        tab[11, 5] = NX
+        mid = org[own] + 0.5 * (cap[:, 0:3] + cap[:, 3:6])
         rad = 0.5 * np.linalg.norm(cap[:, 3:6] - cap[:, 0:3], axis=-1) + cap[:, 6]
         pairs.sort(key=lambda ik: np.linalg.norm(mid[ik[0]] - mid[ik[1]]) - rad[ik[0]] - rad[ik[1]])
         ints = np.concatenate([ints, np.array([len(pairs)] + [i | (k << 8) for i, k in pairs], dtype=np.int32)])
@@ -552,7 +629,9 @@ class ArticulationModel:
                 assert (np.diff(idx) == 1).all()
                 order = np.argsort(cp[idx, 2] - cp[idx, 3], kind="stable")
                 cp[idx] = cp[idx][order]
-        floats = np.concatenate([fl.reshape(-1), cp.reshape(-1)]).astype(np.float32)
+        # extra collision capsules after the contact points: a[3], b[3], radius, owner body (as a float) each
+        xc = np.concatenate([self.extra_capsule.reshape(-1, 7), self.extra_owner.reshape(-1, 1).astype(np.float64)], axis=1) if NX else np.zeros((0, 8))
+        floats = np.concatenate([fl.reshape(-1), cp.reshape(-1), xc.reshape(-1)]).astype(np.float32)
         return ints, floats
 
     BODY_FLOATS = 56

@@ -67,5 +67,10 @@ COLLISION_FILTERS["g1"] = _per_body_filters(_G1_SHAPE_FILTERS, _G1_SHAPES_PER_BO
 
 
 def apply_collision_filter(model, humanoid_type):
-    model.collision_filter[:] = np.asarray(COLLISION_FILTERS[humanoid_type], dtype=np.int64)
+    """Isaac Gym's collision filter words (humanoid.py:1205-1226).  G1's table is per collision SHAPE (40 shapes: torso_link carries three,
+    elbow_roll_link two): since round 4 the model carries every shape, each with its own word."""
+    if humanoid_type == "g1" and int(model.shapes_per_body.sum()) == len(_G1_SHAPE_FILTERS) and list(model.shapes_per_body) == _G1_SHAPES_PER_BODY:
+        model.set_shape_filters(_G1_SHAPE_FILTERS)
+    else:
+        model.set_body_filters(COLLISION_FILTERS[humanoid_type])
     return model

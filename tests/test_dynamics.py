@@ -596,3 +596,78 @@ def test_rigid_contact_sliding_friction_decelerates_at_mu_g(backend):
         for _ in range(12):
             o = run_step(be, model, mstruct, o["root"], o["dof"], target, params, 2)
         assert np.abs(o["root"][:, 7]).max() < 0.03, "sticks once the slip is gone"
+
+
+# ------------------------------------------------------------------------------------------------------------------ several capsules per body (f-1)
+def _penetrating_shape_pairs(model, root, dof):
+    st = do.State(root, dof, model)
+    Q, R, p = do.kinematics(model, st)
+    own, cap = model.shape_owner(), model.shape_capsules()
+    A = [p[o] + R[o] @ c[0:3] for o, c in zip(own, cap)]
+    B = [p[o] + R[o] @ c[3:6] for o, c in zip(own, cap)]
+    out = []
+    for a, b in model.collision_pairs():
+        c1, c2 = do.seg_seg_closest(A[a], B[a], A[b], B[b])
+        if cap[a, 6] + cap[b, 6] - np.linalg.norm(c1 - c2) > 1e-3:
+            out.append((a, b))
+    return out
+
+
+def test_collision_shapes_of_the_compiled_models():
+    """f-1: more than one collision primitive per body.  SMPL: the flat toe boxes (and the hands of the assets whose hand box
+    is flat) are two capsules side by side; G1: torso_link carries three shapes and each elbow_roll_link two, with the reference's PER-SHAPE
+    filter words (humanoid.py:1205-1226: 40 entries for G1); H1 has one geom per link."""
+    from phc_amd.model import load_model
+    from phc_amd.robots import _G1_SHAPE_FILTERS, apply_collision_filter
+    smpl = apply_collision_filter(load_model("smpl_humanoid"), "smpl")
+    assert [smpl.body_names[b] for b in smpl.extra_owner] == ["L_Toe", "R_Toe"] and smpl.num_shapes_collision == 26
+    toe = smpl.body_names.index("L_Toe")
+    a, b = smpl.collision_capsule[toe], smpl.extra_capsule[0]
+    assert abs(a[6] - b[6]) < 1e-12 and a[6] < 0.03 and np.linalg.norm(a[0:3] - b[0:3]) > 0.04      # two thin capsules, one box width apart
+    assert len(smpl.collision_pairs()) > 245 and all(smpl.shape_owner()[i] != smpl.shape_owner()[k] for i, k in smpl.collision_pairs())
+    g1 = apply_collision_filter(load_model("g1_humanoid"), "g1")
+    names = [g1.body_names[b] for b in g1.extra_owner]
+    assert names == ["torso_link", "torso_link", "left_elbow_roll_link", "right_elbow_roll_link"] and int(g1.shapes_per_body.sum()) == 40
+    # shape order = bodies in order, a body's shapes in geom order: primary shapes take the first word of their body, extras the following ones
+    start = np.concatenate([[0], np.cumsum(g1.shapes_per_body)[:-1]])
+    for bdy in range(g1.num_bodies):
+        if g1.shapes_per_body[bdy]:
+            assert g1.shape_filter[bdy] == _G1_SHAPE_FILTERS[start[bdy]]
+    for e, (bdy, o) in enumerate(zip(g1.extra_owner, g1.extra_ordinal)):
+        assert g1.shape_filter[g1.num_bodies + e] == _G1_SHAPE_FILTERS[start[bdy] + o]
+    h1 = load_model("h1_humanoid")
+    assert len(h1.extra_owner) == 0
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("name", ["smpl_humanoid", "g1_humanoid"])
+def test_extra_collision_shapes_collide_and_match_the_dense_oracle(backend, name):
+    """A pose in which an EXTRA capsule (shape index >= NB: second half of a toe box; G1's head / logo / palm shapes) is what touches: the kernel's
+    forces -- accumulated on the shapes' owner bodies -- equal the fp64 dense oracle's, and differ from a model stripped of its extra shapes."""
+    be = get_backend(backend)
+    model, mstruct, keep = model_on(be, name)
+    rng = np.random.default_rng(4)
+    robot = name != "smpl_humanoid"
+    found = None
+    for _ in range(400):
+        root, dof, target = random_states(model, 1, rng, height=1.5, vel=0.0, pose=1.0 if not robot else 1.3)
+        pairs = _penetrating_shape_pairs(model, root[0], dof[0])
+        if any(b >= model.num_bodies or a >= model.num_bodies for a, b in pairs):
+            found = (root, dof, target, pairs)
+            break
+    assert found is not None, "no random pose brought an extra shape into contact"
+    root, dof, target, pairs = found
+    kw = dict(sim_dt=1 / 200, control_freq_inv=4, control_mode=2) if robot else {}
+    out = run_step(be, model, mstruct, root, dof, target, abi.sim_params_struct(self_collision=1, **kw), 1)
+    r, d, rbs, tau, fc = do.sim_step(model, root[0], dof[0], target[0], params=dict(self_collision=1, control_mode=2 if robot else 0),
+                                     sim_dt=1 / 200 if robot else 1 / 60, substeps=2, num_sim_calls=1)
+    np.testing.assert_allclose(out["rbs"][0][:, 0:3], rbs[:, 0:3], atol=5e-4)
+    np.testing.assert_allclose(out["cf"][0], fc, atol=1.0, rtol=1e-2)
+    # the same pose on a model without the extra shapes gives different body-body forces: the extra shapes really took part
+    import copy
+    bare = copy.deepcopy(model)
+    bare.extra_owner, bare.extra_ordinal, bare.extra_capsule = bare.extra_owner[:0], bare.extra_ordinal[:0], bare.extra_capsule[:0]
+    bare.shape_filter = bare.shape_filter[:bare.num_bodies]
+    r2, d2, rbs2, tau2, fc2 = do.sim_step(bare, root[0], dof[0], target[0], params=dict(self_collision=1, control_mode=2 if robot else 0),
+                                          sim_dt=1 / 200 if robot else 1 / 60, substeps=2, num_sim_calls=1)
+    assert np.abs(fc2 - fc).max() > 1.0
