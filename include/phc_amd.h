@@ -121,9 +121,9 @@ typedef struct {
     float self_stiffness_scale;       /* <= 1 (explicit stability bound is 4); default 0.25 */
     float self_damping_ratio;         /* default 0.5 */
     int32_t lane_mapping;             /* stepper thread mapping: one body per lane (32 lanes per env, 2 envs per wavefront; NB > 32: 64 lanes, 1 env).
-                                         0 = auto register allocation: two wavefronts per SIMD, three when the launch has more wavefronts than fit at
-                                         two (SMPL-family penalty kernel: 8192 envs run 1.33 occupancy rounds instead of 2); 1 / 3 force two / three;
-                                         other values PHC_EUNSUPPORTED (2 was the two-bodies-per-lane kernel of rounds 1-2, removed in ABI 31) */
+                                         0 / 1 = the product kernel (two wavefronts per SIMD); 3 = the same kernel compiled for three wavefronts per
+                                         SIMD (SMPL-family penalty kernel only; measured slower at every env count, profiles/r04_stepper_occupancy.txt --
+                                         an experiment knob); other values PHC_EUNSUPPORTED (2 was the two-bodies-per-lane kernel, removed in ABI 31) */
     int32_t num_force_sensors;        /* S <= 4: force sensors (env.force_sensor_joints, default L_Ankle / R_Ankle, humanoid.py:268) */
     int32_t force_sensor_body[4];     /* body id of each sensor */
     /* ---- ABI 34: ground-contact model (solver.contact) ----

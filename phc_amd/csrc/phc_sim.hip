@@ -131,10 +131,10 @@ __device__ __forceinline__ bool stage_aligned(const phc_sim_state_t& sim) {
 // >256 VGPRs: 214-252 us vs 158 us for this mapping.  __launch_bounds__(64, 2): two wavefronts per SIMD (<= 256 VGPRs,
 // 68 B/lane of scratch) beats one (272 registers, no scratch: 195 us) and three (168 VGPRs, 412 B scratch: 280 us).
 // ------------------------------------------------------------------------------------------
-// OCC: wavefronts per SIMD the register allocation aims at.  2 (<= 256 VGPRs, no scratch) is the fastest launch while all wavefronts are resident at
-// once (up to 4096 envs of <= 32 bodies: 2048 wavefronts = 2 per SIMD).  Above that a launch runs in occupancy ROUNDS; OCC = 3 (168 VGPRs,
-// 116 B / lane of scratch) trades a slower wavefront for 3072 resident ones -- BASELINE configs[2] (8192 envs) then needs 1.33 rounds
-// instead of 2 (profiles/r04_stepper_occupancy.txt).
+// OCC: wavefronts per SIMD the register allocation aims at.  2 (<= 256 VGPRs, no scratch) is what every launch uses.  OCC = 3 (168 VGPRs, 116 B / lane
+// of scratch) keeps 3072 wavefronts resident instead of 2048 -- and was measured SLOWER at every size (round 4, profiles/r04_stepper_occupancy.txt:
+// 96.6 vs 78.0 us at 4096 envs, 168.9 vs 145.3 at 8192, 241.0 vs 211.9 at 12288): the spilled wavefront's longer stream costs more than the
+// third resident wavefront hides.  Kept behind lane_mapping = 3 so that the measurement can be repeated; never chosen automatically.
 template <bool STEP, int JT, int GRP, bool SHAPES = false, bool RIGID = false, int OCC = 2>
 __global__ __launch_bounds__(64, OCC) void k_sim_step(phc_model_t model_all, phc_sim_params_t prm, phc_sim_state_t sim,
                                                 const float* __restrict__ actions, const float* __restrict__ pd_off,
@@ -276,9 +276,7 @@ static void sim_launch_cm(const phc_model_t* model, const phc_sim_params_t& prm,
                           const int64_t* env_ids, int num_listed) {
     const int64_t groups = env_ids ? num_listed : sim->num_envs;
     const bool wide = model->num_bodies > 32;   // more bodies than a 32-lane group holds: one env per wavefront
-    // more wavefronts than fit at two per SIMD (256 CUs x 4 SIMDs): the 3-per-SIMD register allocation (lane_mapping 0 = auto, 1 / 3 force)
-    const int64_t waves = wide ? groups : (groups + 1) / 2;
-    const bool occ3 = STEP && !RIGID && !SHAPES && JT == PHC_JT_SPHERICAL && !wide && (prm.lane_mapping == 3 || (prm.lane_mapping == 0 && waves > 2 * 1024 + 256));
+    const bool occ3 = STEP && !RIGID && !SHAPES && JT == PHC_JT_SPHERICAL && !wide && prm.lane_mapping == 3;   // (experiment knob, see k_sim_step)
     if (occ3)
         hipLaunchKernelGGL((k_sim_step<STEP, JT, 32, SHAPES, RIGID, (STEP && !RIGID && !SHAPES && JT == PHC_JT_SPHERICAL) ? 3 : 2>), dim3((groups + 1) / 2), dim3(64), 0, stream,
                            *model, prm, *sim, actions, off, scale, freeze, num_sim_calls, env_ids, num_listed);
