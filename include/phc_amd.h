@@ -122,7 +122,7 @@ typedef struct {
     float self_damping_ratio;         /* default 0.5 */
     int32_t lane_mapping;             /* stepper thread mapping: one body per lane (32 lanes per env, 2 envs per wavefront; NB > 32: 64 lanes, 1 env).
                                          0 / 1 = the product kernel (two wavefronts per SIMD); 3 = the same kernel compiled for three wavefronts per
-                                         SIMD (SMPL-family penalty kernel only; measured slower at every env count, profiles/r04_stepper_occupancy.txt --
+                                         SIMD (SMPL-family penalty kernel only; measured slower at every env count, profiles/r04_stepper/occupancy_2_vs_3_waves_per_simd.txt --
                                          an experiment knob); other values PHC_EUNSUPPORTED (2 was the two-bodies-per-lane kernel, removed in ABI 31) */
     int32_t num_force_sensors;        /* S <= 4: force sensors (env.force_sensor_joints, default L_Ankle / R_Ankle, humanoid.py:268) */
     int32_t force_sensor_body[4];     /* body id of each sensor */

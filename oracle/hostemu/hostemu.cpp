@@ -50,8 +50,12 @@ static int emu_sim_step_t(const phc_model_t* model_all, const phc_sim_params_t* 
             const bool rerooted = model_tab(*model, 11, 3) != 0;
             for (int s = 0; s < nsub; ++s) {
                 if (prm->self_collision) {
-                    for (int j = 0; j < nb; ++j) aba_publish_capsule(L[j], model_body(*model, j), caps.data() + PHC_CAP_STRIDE * j, j);
-                    for (int e = 0, nx = model_num_extra_shapes(*model); e < nx; ++e) aba_publish_extra_capsule(*model, e, x, caps.data());
+                    for (int j = 0; j < nb; ++j) aba_publish_shape(L[j], j, x, caps.data());
+                    for (int e = 0, nx = model_num_extra_shapes(*model); e < nx; ++e) {
+                        AbaLane X;
+                        aba_load_extra_shape(X, *model, e);
+                        aba_publish_shape(X, nb + e, x, caps.data());
+                    }
                     for (int q = 0, np = model_num_pairs(*model); q < np; ++q)
                         aba_collide_pair(*prm, dt, model_pair(*model, q) & 0xff, model_pair(*model, q) >> 8, x, caps.data());
                     for (int j = 0; j < nb; ++j) aba_collect_self(L[j], j, caps.data());

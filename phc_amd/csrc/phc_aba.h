@@ -136,6 +136,9 @@ struct AbaLane {
     float tau_hold;   // explicit `pd` torque of the current simulate call (control_mode 1)
     // --- body-body contact (self-collision): net explicit force / moment about the origin on this body, set by aba_self_collision ---
     V3 fself, nself;
+    // the collision capsule this LANE publishes (a body lane: its body's primary capsule; an idle lane behind the bodies: an extra shape of
+    // body cap_owner), in the owner's frame -- loaded once per launch
+    V3 cap_a, cap_b; float cap_r, cap_m; int cap_owner;
     // --- rigid ground contact (contact_model 1): the body's world angular acceleration and the classical acceleration of its solver reference
     //     point as the LAST solve of this sub-step left them (aba_accel_level) -- the next pass evaluates active set and friction cone on them ---
     V3 acc_w, acc_v;
@@ -188,6 +191,7 @@ PHC_HD void aba_load_model(AbaLane& L, const phc_model_t& m, int j, bool reroot 
     L.r_local = v3(f[0], f[1], f[2]);
     L.arm = v3(f[19], f[20], f[21]);
     L.fself = L.nself = v3(0.f, 0.f, 0.f);
+    L.cap_a = v3(f[36], f[37], f[38]); L.cap_b = v3(f[39], f[40], f[41]); L.cap_r = f[42]; L.cap_m = f[3]; L.cap_owner = j;
 }
 // revolute extras (template JT == PHC_JT_REVOLUTE paths only)
 // convenience overload: constants read from the model at every call
@@ -640,20 +644,20 @@ PHC_HD void cap_write(float* cap, V3 a, V3 b, float radius, float mass, int owne
     for (int k = 0; k < 6; ++k) acc[k] = 0;
     acc[6] = owner;
 }
-PHC_HD void aba_publish_capsule(const AbaLane& L, const float* f, float* cap, int j) {
-    const M3 R = quat_to_mat(L.Q);
-    cap_write(cap, L.p + mat_mul(R, v3(f[36], f[37], f[38])), L.p + mat_mul(R, v3(f[39], f[40], f[41])), f[42], f[3], j);
-}
-// extra shape e (lane NB + e of the env's group): its owner's pose comes from the owner's exchange slot (kinematics of the last sweep)
-PHC_HD void aba_publish_extra_capsule(const phc_model_t& m, int e, const Xch& x, float* caps) {
+// extra shape e: the lane behind the bodies that publishes it loads its record once per launch
+PHC_HD void aba_load_extra_shape(AbaLane& L, const phc_model_t& m, int e) {
     const float* r = model_extra_shape(m, e);
-    const int owner = (int)r[7];
+    L.cap_a = v3(r[0], r[1], r[2]); L.cap_b = v3(r[3], r[4], r[5]); L.cap_r = r[6]; L.cap_owner = (int)r[7];
+    L.cap_m = model_body(m, L.cap_owner)[3];
+}
+// shape s (body lanes: s = body; extra lanes: s = NB + e): world capsule from the OWNER's pose as the last kinematics sweep left it in the owner's
+// exchange slot -- one code path for body lanes and extra-shape lanes
+PHC_HD void aba_publish_shape(const AbaLane& L, int s, const Xch& x, float* caps) {
     constexpr int es = Xch::es;
-    const float* s = xslot(x, owner);
-    const M3 R = quat_to_mat(q4(s[6 * es], s[7 * es], s[8 * es], s[9 * es]));
-    const V3 p = v3(s[10 * es], s[11 * es], s[12 * es]);
-    cap_write(caps + PHC_CAP_STRIDE * (m.num_bodies + e), p + mat_mul(R, v3(r[0], r[1], r[2])), p + mat_mul(R, v3(r[3], r[4], r[5])), r[6],
-              model_body(m, owner)[3], owner);
+    const float* k = xslot(x, L.cap_owner);
+    const M3 R = quat_to_mat(q4(k[6 * es], k[7 * es], k[8 * es], k[9 * es]));
+    const V3 p = v3(k[10 * es], k[11 * es], k[12 * es]);
+    cap_write(caps + PHC_CAP_STRIDE * s, p + mat_mul(R, L.cap_a), p + mat_mul(R, L.cap_b), L.cap_r, L.cap_m, L.cap_owner);
 }
 // one candidate pair (bodies i < k): bounding spheres, then the capsule-capsule test, then the penalty force into both accumulators.
 // Needs both bodies' capsules in `caps` and kinematics (p w v at slot floats [10..19)) in the exchange slots.

@@ -132,7 +132,7 @@ __device__ __forceinline__ bool stage_aligned(const phc_sim_state_t& sim) {
 // 68 B/lane of scratch) beats one (272 registers, no scratch: 195 us) and three (168 VGPRs, 412 B scratch: 280 us).
 // ------------------------------------------------------------------------------------------
 // OCC: wavefronts per SIMD the register allocation aims at.  2 (<= 256 VGPRs, no scratch) is what every launch uses.  OCC = 3 (168 VGPRs, 116 B / lane
-// of scratch) keeps 3072 wavefronts resident instead of 2048 -- and was measured SLOWER at every size (round 4, profiles/r04_stepper_occupancy.txt:
+// of scratch) keeps 3072 wavefronts resident instead of 2048 -- and was measured SLOWER at every size (round 4, profiles/r04_stepper/occupancy_2_vs_3_waves_per_simd.txt:
 // 96.6 vs 78.0 us at 4096 envs, 168.9 vs 145.3 at 8192, 241.0 vs 211.9 at 12288): the spilled wavefront's longer stream costs more than the
 // third resident wavefront hides.  Kept behind lane_mapping = 3 so that the measurement can be repeated; never chosen automatically.
 template <bool STEP, int JT, int GRP, bool SHAPES = false, bool RIGID = false, int OCC = 2>
@@ -179,6 +179,9 @@ __global__ __launch_bounds__(64, OCC) void k_sim_step(phc_model_t model_all, phc
             L.target = v3(tg[0], tg[1], tg[2]);
         }
     }
+    // the idle lanes behind the bodies publish the extra collision shapes (phc_aba.h): their capsule records are loaded once, here
+    const bool shape_lane = active || (STEP && prm.self_collision && env < sim.num_envs && lane < nb + model_num_extra_shapes(model));
+    if (shape_lane && !active) aba_load_extra_shape(L, model, lane - nb);
     const int max_level = model.max_level;
     if (!PHC_SKIP(8)) for (int l = 0; l <= max_level; ++l) { aba_fk_level(L, l, body, x); __syncthreads(); }
     PHC_PROF(0)
@@ -196,8 +199,7 @@ __global__ __launch_bounds__(64, OCC) void k_sim_step(phc_model_t model_all, phc
             const int tl_sub = s; (void)tl_sub;
             PHC_TL(1)
             if (prm.self_collision && !PHC_SKIP(0)) {   // body-body contact from the kinematics the last sweep left in the exchange slots
-                if (active) aba_publish_capsule(L, model_body(model, body), caps + PHC_CAP_STRIDE * body, body);
-                else if (env < sim.num_envs && lane < nb + model_num_extra_shapes(model)) aba_publish_extra_capsule(model, lane - nb, x, caps);   // idle lanes: the extra shapes
+                if (shape_lane) aba_publish_shape(L, lane, x, caps);   // body lanes: the primary capsules; the idle lanes behind them: the extra shapes
                 __syncthreads();
                 if (env < sim.num_envs) aba_collide_pairs<PHC_SC_MAX_PER_LANE>(pair_all + threadIdx.x, 64, prm, dt, x, caps, near_pairs, s == 0);
                 __syncthreads();

@@ -28,6 +28,8 @@ def main():
     for _ in range(10):
         task.reset_done(); env.step(a)
     torch.cuda.synchronize()
+    if os.environ.get("PHC_TL_LIFT"):      # lift every humanoid off the ground: the same sub-step without a single ground contact
+        task._root_states[:, 2] += float(os.environ["PHC_TL_LIFT"])
     buf = (C.c_ulonglong * 512)()
     raw.phc_debug_timeline(buf, block)
     task.reset_done(); env.step(a)
