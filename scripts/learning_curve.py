@@ -20,10 +20,12 @@ def main():
     num_envs = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
     out = sys.argv[3] if len(sys.argv) > 3 else "gpurun_out/learning_curve.json"
     extra = sys.argv[4:]
+    bf16 = "--fp32-gemm" not in extra          # A/B of the GEMM precision (the reference trains in fp32, im.yaml:51; the product runs bf16 MFMA GEMMs)
+    extra = [e for e in extra if e != "--fp32-gemm"]
     torch.manual_seed(0)
     cfg = compose([f"env.num_envs={num_envs}", "env.motion_file=synthetic:1:0"] + extra)   # extra may override env.motion_file
     task, env = parse_task(cfg)
-    agent = IMAmpAgent(env, cfg)
+    agent = IMAmpAgent(env, cfg, bf16=bf16)
     agent.init_train()
     rows, t0 = [], time.time()
     for ep in range(epochs):
@@ -64,7 +66,7 @@ def main():
     acc = {"deterministic_rollout_steps": n_steps, "mean_steps_survived": float(survived.mean()), "fraction_surviving_whole_clip": float(alive.float().mean()),
            "mean_reward_raw_terms [pos, rot, vel, ang_vel, power]": (raw_sum / n_steps).tolist(), **eval_info}
     print("acceptance:", json.dumps(acc))
-    json.dump({"config": {"num_envs": num_envs, "epochs": epochs, "extra": extra}, "acceptance": acc, "rows": rows}, open(out, "w"))
+    json.dump({"config": {"num_envs": num_envs, "epochs": epochs, "extra": extra, "gemm_dtype": "bf16" if bf16 else "f32"}, "acceptance": acc, "rows": [r for r in rows if r["epoch"] == 1 or r["epoch"] % 10 == 0]}, open(out, "w"))
 
 
 if __name__ == "__main__":
