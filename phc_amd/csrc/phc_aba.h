@@ -470,28 +470,43 @@ PHC_HD void aba_body_init(AbaLane& L, const phc_model_t& m, const phc_sim_params
         const float az = R.m[6] * cp[4 * k] + R.m[7] * cp[4 * k + 1] + R.m[8] * cp[4 * k + 2];
         if (cp[4 * k + 3] - (L.p.z + az) > 0.f) touching |= 1u << k;
     }
-    for (int k = 0; k < cp_count; ++k) {
-        if (k < 32) {   // jump to the next touching point
-            const uint32_t rest = touching >> k;
-            if (rest == 0u) { if (cp_count <= 32) break; k = 31; continue; }
-            k += __builtin_ctz(rest);
-        }
-        V3 arm = mat_mul(R, v3(cp[4 * k], cp[4 * k + 1], cp[4 * k + 2]));
-        float rad = cp[4 * k + 3];
-        float depth = rad - (L.p.z + arm.z);
-        if (depth <= 0.f) continue;
+    // one iteration per touching point of the busiest lane; the NEXT touching point's record is requested before the current one is worked on
+    // (round 4: the table sits in L2 -- ~200 cycles per dependent load -- and the set-bit order is only known at run time)
+    struct Cp4 { float x, y, z, r; };
+    auto cp_load = [&](int k) { Cp4 c; c.x = cp[4 * k]; c.y = cp[4 * k + 1]; c.z = cp[4 * k + 2]; c.r = cp[4 * k + 3]; return c; };
+    auto cp_point = [&](const Cp4& c) {
+        V3 arm = mat_mul(R, v3(c.x, c.y, c.z));
+        const float rad = c.r;
+        const float depth = rad - (L.p.z + arm.z);
+        if (depth <= 0.f) return;
         arm.z -= rad;  // actual contact location relative to the body origin
-        V3 uc = L.v + cross(L.w, arm);
+        const V3 uc = L.v + cross(L.w, arm);
         arm = arm - so;  // ... relative to the reference point, which the moments and the implicit terms refer to
-        float fn0 = prm.contact_stiffness * depth - cn * uc.z;
-        if (fn0 <= 0.f) continue;  // separating: non-adhesive
-        float ut = sqrtf(uc.x * uc.x + uc.y * uc.y);
-        float ct = fminf(prm.friction_viscous, prm.friction * fn0 / (ut + 1e-6f));
-        V3 cc = cross(L.w, cross(L.w, arm));
-        V3 F0 = v3(-ct * uc.x - dt * ct * cc.x, -ct * uc.y - dt * ct * cc.y, fn0 - dt * cn * cc.z);
+        const float fn0 = prm.contact_stiffness * depth - cn * uc.z;
+        if (fn0 <= 0.f) return;  // separating: non-adhesive
+        const float ut = sqrtf(uc.x * uc.x + uc.y * uc.y);
+        const float ct = fminf(prm.friction_viscous, prm.friction * fn0 / (ut + 1e-6f));
+        const V3 cc = cross(L.w, cross(L.w, arm));
+        const V3 F0 = v3(-ct * uc.x - dt * ct * cc.x, -ct * uc.y - dt * ct * cc.y, fn0 - dt * cn * cc.z);
         L.fcontact += F0;
         aba_add_point_contact(L, arm, F0, dt * ct, dt * cn);
+    };
+    if (touching != 0u) {
+        uint32_t rest = touching;
+        int k = __builtin_ctz(rest);
+        rest &= rest - 1u;
+        Cp4 cur = cp_load(k);
+        while (true) {
+            const bool more = rest != 0u;
+            const int kn = more ? __builtin_ctz(rest) : k;
+            rest &= rest - 1u;
+            const Cp4 nxt = cp_load(kn);     // (in flight while the current point is worked on)
+            cp_point(cur);
+            if (!more) break;
+            k = kn; cur = nxt;
+        }
     }
+    for (int k = 32; k < cp_count; ++k) cp_point(cp_load(k));   // (bodies with more than 32 points: the rest one by one)
     }
     // body-body contact forces of this sub-step (explicit; zero unless sim_params.self_collision)
     L.fcontact += L.fself;

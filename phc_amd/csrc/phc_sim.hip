@@ -214,6 +214,7 @@ __global__ __launch_bounds__(64, OCC) void k_sim_step(phc_model_t model_all, phc
             for (int pass = 0; pass < passes; ++pass) {
             PHC_TL(3)
             if (active && !PHC_SKIP(1)) aba_body_init<JT, RIGID>(L, model, prm, dt, body, s % prm.substeps == 0, true, pass);
+            if (active && PHC_SKIP(9)) aba_body_init<JT, RIGID>(L, model, prm, dt, body, s % prm.substeps == 0, true, pass);   // (profiling builds: the phase a second time, loads warm -- its pure instruction cost)
             PHC_PROF(2)
             PHC_TL(4)
             if (JT == PHC_JT_SPHERICAL && rerooted && pass == 0 && !PHC_SKIP(2)) {   // reversed bodies take the drive terms of their solver parent's joint

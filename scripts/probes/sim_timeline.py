@@ -22,7 +22,7 @@ def main():
     torch.manual_seed(0)
     task, env = parse_task(compose([f"env.num_envs={n}", "env.motion_file=synthetic:1:0"] + sys.argv[3:]))
     raw = C.CDLL(PROF)
-    raw.phc_debug_set_skip(1 << 15)
+    raw.phc_debug_set_skip((1 << 15) | int(os.environ.get("PHC_TL_SKIP", "0"), 0))
     env.reset()
     a = (torch.rand(n, task.num_actions, device=task.device) * 2 - 1) * 0.1
     for _ in range(10):
