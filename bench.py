@@ -197,7 +197,9 @@ def config0_line(dev):
     from phc_amd import _lib as L
     files = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_reference_cpu_stages.json"))
     ref = json.load(open(os.path.join(ROOT, "profiles", files[-1]))).get("config0") if files else None
-    task, env = parse_task(compose(["env.num_envs=64", "env.motion_file=synthetic:1:0", f"device_id={dev.index or 0}", f"rl_device={dev}"]), device_id=dev.index or 0)
+    dev = torch.device(dev)
+    di = dev.index if dev.index is not None else torch.cuda.current_device()
+    task, env = parse_task(compose(["env.num_envs=64", "env.motion_file=synthetic:1:0", f"device_id={di}", f"rl_device=cuda:{di}"]), device_id=di)
     env.reset()
     lib = task._motion_lib
     lr = lib.lrs[:64].contiguous()

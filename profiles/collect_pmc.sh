@@ -4,6 +4,6 @@
 # Run on the GPU box from the repo root:  bash profiles/collect_pmc.sh > profiles/rNN_pmc_traffic.txt
 cd /tmp && export TMPDIR=/tmp; cd "${GRAFT_REPO_ROOT:-$OLDPWD}"
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -o pmc -- python bench.py --steps 20 --warmup 5 --ppo-epochs 0 --no-cpu-baseline --no-pmc > /dev/null 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -o pmc -- python bench.py --steps 20 --warmup 5 --ppo-epochs 0 --no-cpu-baseline --no-pmc --no-other-workloads > /dev/null 2>&1
 done
 python profiles/pmc_summary.py /tmp/pmc_FETCH_SIZE/pmc_counter_collection.csv /tmp/pmc_WRITE_SIZE/pmc_counter_collection.csv
