@@ -38,10 +38,13 @@ static int emu_sim_step_t(const phc_model_t* model_all, const phc_sim_params_t* 
             }
             aba_load_state<JT>(L[j], *sim, nd, env, j);
         }
-        const int ml = model->max_level;
         Xch x;
         x.base = xch.data();
-        for (int l = 0; l <= ml; ++l) for (int j = 0; j < nb; ++j) aba_fk_level(L[j], l, j, x);
+        for (int j = 0; j < nb; ++j) aba_fk_jump_begin(L[j], j, x);   // initial kinematics by pointer jumping, as the kernel does
+        for (int k = 0, ks = model_jump_steps(*model); k < ks; ++k) {
+            for (int j = 0; j < nb; ++j) aba_fk_jump_step(L[j], k, x);
+            for (int j = 0; j < nb; ++j) aba_write_kin(L[j], xslot(x, j), Xch::es, 6);
+        }
         if (do_step) {
             const float dt = prm->sim_dt / (float)prm->substeps;
             const int nsub = num_sim_calls * prm->substeps;

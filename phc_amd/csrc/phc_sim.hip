@@ -17,6 +17,10 @@ using namespace phc;
 // library never contains this): per-wavefront s_memtime deltas accumulated per phase, summed over wavefronts into a device array.
 #ifdef PHC_SIM_PROFILE
 __device__ unsigned long long g_phc_prof[16];
+__device__ unsigned long long g_phc_prof_wg[8192][10];   // the same per workgroup (= wavefront), of the LAST launch: the launch lasts as long as its slowest wavefront
+extern "C" int32_t phc_debug_profile_wg(unsigned long long* out, int32_t nwg) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phc_prof_wg), sizeof(unsigned long long) * 10 * (nwg < 8192 ? nwg : 8192)) == hipSuccess ? 0 : -1;
+}
 extern "C" int32_t phc_debug_profile(unsigned long long* out16, int32_t reset) {
     if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_phc_prof), sizeof(g_phc_prof)) != hipSuccess) return -1;
     if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_phc_prof), z, sizeof(z)) != hipSuccess) return -1; }
@@ -41,7 +45,7 @@ extern "C" int32_t phc_debug_timeline(unsigned long long* out512, int32_t block)
 #define PHC_SKIP(b) ((skip_mask >> (b)) & 1)
 #define PHC_PROF_DECL unsigned long long prof_acc[10] = {0}; unsigned long long prof_t = __builtin_readcyclecounter();
 #define PHC_PROF(i) if (!PHC_SKIP(15)) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0); const unsigned long long t_ = __builtin_readcyclecounter(); prof_acc[i] += t_ - prof_t; prof_t = t_; __builtin_amdgcn_sched_barrier(0); }
-#define PHC_PROF_FLUSH if (threadIdx.x == 0 && !PHC_SKIP(15)) { for (int i_ = 0; i_ < 10; ++i_) atomicAdd(&g_phc_prof[i_], prof_acc[i_]); atomicAdd(&g_phc_prof[15], 1ull); }
+#define PHC_PROF_FLUSH if (threadIdx.x == 0 && !PHC_SKIP(15)) { for (int i_ = 0; i_ < 10; ++i_) { atomicAdd(&g_phc_prof[i_], prof_acc[i_]); if (blockIdx.x < 8192) g_phc_prof_wg[blockIdx.x][i_] = prof_acc[i_]; } atomicAdd(&g_phc_prof[15], 1ull); }
 #else
 #define PHC_PROF_DECL
 #define PHC_PROF(i)
@@ -182,8 +186,18 @@ __global__ __launch_bounds__(64, OCC) void k_sim_step(phc_model_t model_all, phc
     // the idle lanes behind the bodies publish the extra collision shapes (phc_aba.h): their capsule records are loaded once, here
     const bool shape_lane = active || (STEP && prm.self_collision && env < sim.num_envs && lane < nb + model_num_extra_shapes(model));
     if (shape_lane && !active) aba_load_extra_shape(L, model, lane - nb);
-    const int max_level = model.max_level;
-    if (!PHC_SKIP(8)) for (int l = 0; l <= max_level; ++l) { aba_fk_level(L, l, body, x); __syncthreads(); }
+    // initial kinematics by pointer jumping too (round 4: 4 composition steps instead of max_level + 1 = 9 level-steps for the SMPL tree)
+    if (!PHC_SKIP(8)) {
+        const int jsteps = model_jump_steps(model);
+        aba_fk_jump_begin(L, body, x);
+        __syncthreads();
+        for (int k = 0; k < jsteps; ++k) {
+            aba_fk_jump_step(L, k, x);
+            __syncthreads();
+            if (active) aba_write_kin(L, xslot(x, body), Xch::es, 6);
+            __syncthreads();
+        }
+    }
     PHC_PROF(0)
     if (STEP) {
         const float dt = prm.sim_dt / (float)prm.substeps;
