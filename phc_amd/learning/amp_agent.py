@@ -29,6 +29,7 @@ MI355X-first differences (results-preserving):
     are tested against.
 """
 import copy
+import contextlib
 import os
 import time
 import warnings
@@ -171,10 +172,24 @@ class FlatGradBucket:
         p, (o, k) = self.params[i], self.segments[i]
         return flat[o:o + k].view(p.shape[0], k // p.shape[0])[:, :p.shape[1]] if k != p.numel() else flat[o:o + k].view_as(p)
 
-    def zero(self, decay=None):
+    def spans_of(self, params):
+        """([(lo, hi)] of the flat gradient that holds `params`, [(lo, hi)] of everything else): `params` must be consecutive in the bucket."""
+        ids = {id(p) for p in params}
+        idx = [i for i, p in enumerate(self.params) if id(p) in ids]
+        if not idx or idx != list(range(idx[0], idx[-1] + 1)):
+            raise ValueError("parameters are not one consecutive run of the gradient bucket")
+        lo, hi, n = self.segments[idx[0]][0], self.segments[idx[-1]][0] + self.segments[idx[-1]][1], self.flat.numel()
+        return [(lo, hi)], [(a, b) for a, b in ((0, lo), (hi, n)) if b > a]
+
+    def zero(self, decay=None, spans=None):
         """`decay` [(parameter, c)]: start that parameter's gradient at c * parameter (an L2 term's gradient written in place instead of
-        being handed to autograd as a tensor to add)."""
-        self.flat.zero_()
+        being handed to autograd as a tensor to add).  `spans`: only these ranges of the flat gradient (a pass that owns a part of the
+        parameters: the other pass zeroes its own, possibly at the same time on another stream)."""
+        if spans is None:
+            self.flat.zero_()
+        else:
+            for lo, hi in spans:
+                self.flat[lo:hi].zero_()
         self.gen += 1
         for p, c in decay or ():
             torch.mul(p.data, c, out=p.grad)
@@ -282,6 +297,12 @@ class IMAmpAgent:
         # ROCm 7.2 instead of raising -- `_stale_grad_accumulators()` detects exactly that before capturing and the update falls back to eager
         # launches, as it does when a capture raises or the minibatch is small (< 2048 rows: not launch-bound).
         self._use_graph = bool(c.get("hip_graph", True))
+        # The discriminator's share of an optimizer step (three input normalisers, forward, loss terms, the gradient penalty's double backward,
+        # backward) shares nothing with actor + critic but the optimizer launches at the end: two chains of ~256-workgroup GEMMs and 5 us
+        # finishing launches.  On the device the discriminator pass runs on its own HIP stream (_fwd_bwd); captured, it is its OWN linear
+        # hipGraph replayed on that stream next to the policy graph (_graph_update).
+        self._use_branches = bool(c.get("branch_streams", True)) and not os.environ.get("PHC_NO_BRANCH_STREAMS")
+        self._branches = None
         self._graph = self._g_data = self._g_idx = self._g_info = None
         self._graph_failed = False
         # one flat fp32 parameter; on the device clip + step are two HIP launches over it (fast_ops.adam_clip_step) and this object
@@ -658,14 +679,10 @@ class IMAmpAgent:
         """`_disc_loss` on the device with the pieces as kernels (fast_ops.disc_bce / weighted_sumsq): every term already carries
         `disc_coef` and enters the total loss with weight one.  `logits` [3m, 1]: agent, replay, demo rows.
         -> (the three loss terms, [(weight, c)] whose gradient c * weight is to be preloaded by FlatGradBucket.zero)."""
-        net = self.model.a2c_network
         k = self._disc_coef
         raw, nw = self._raw_buffer()
         bce, _ = disc_bce(logits, 2 * m, k, out=raw[6:9])
-        ws = [p for p in net.get_disc_weights_raw()]
-        coefs = [self._disc_weight_decay * k] * len(ws)
-        coefs[-1] += self._disc_logit_reg * k   # the logit layer: regulariser + weight decay
-        preload = all(getattr(w, "_bucket", None) is self.grads for w in ws)
+        ws, coefs, preload = self._disc_decay_terms()
         # (a K-padded weight enters with its padded storage -- the pad is zero --, when its gradient is preloaded anyway)
         l2 = weighted_sumsq([getattr(w, "_padded", w) if preload else w.contiguous() for w in ws], coefs, out=raw[9:10 + nw], preloaded=preload)
         # d(sum of the demo logits) / d(demo rows): cotangent = [0; 0; 1] over the [agent; replay; demo] logits, and the layers are told
@@ -675,6 +692,15 @@ class IMAmpAgent:
                                        only_inputs=True)[0]
         pen = weighted_sumsq([grad], [self._disc_grad_penalty * k / m], out=raw[10 + nw:12 + nw])
         return [bce, l2, pen], ([(w, 2.0 * c) for w, c in zip(ws, coefs)] if preload else None)
+
+    def _disc_decay_terms(self):
+        """(discriminator weights, coefficient of each one's sum of squares in the total loss, whether their gradients 2 c w can be preloaded
+        into the flat bucket)."""
+        k = self._disc_coef
+        ws = [p for p in self.model.a2c_network.get_disc_weights_raw()]
+        coefs = [self._disc_weight_decay * k] * len(ws)
+        coefs[-1] += self._disc_logit_reg * k   # the logit layer: regulariser + weight decay
+        return ws, coefs, all(getattr(w, "_bucket", None) is self.grads for w in ws)
 
     def _demo_row_mask(self, m, like):
         key = (m, like.dtype, like.device)
@@ -690,6 +716,16 @@ class IMAmpAgent:
         idx = amp_idx = None
         if "_dataset" in d:   # device: minibatch = (dataset, row index); the kernels below read the rows in place
             d, idx, amp_idx = d["_dataset"], d["_idx"], d["_amp_idx"]
+        br = self._branch_streams(d["obs"].device) if (d["obs"].is_cuda and self._disc_grad_penalty > 0 and self._normalize_amp_input) else None
+        if br:
+            # the discriminator pass on its stream next to the policy pass: see __init__
+            main = torch.cuda.current_stream(d["obs"].device)
+            br.wait_stream(main)
+            with torch.cuda.stream(br):
+                self._disc_pass(d, amp_idx)
+            self._policy_pass(d, idx)
+            main.wait_stream(br)
+            return self._info_from_raw(self._raw.clone()) if want_info else None   # (a copy: the next step overwrites `_raw`)
         obs = self._preproc_obs(d["obs"], use_temp=self.temp_running_mean, row_index=idx)
         fused = obs.is_cuda
         fused_disc = fused and self._disc_grad_penalty > 0 and self._normalize_amp_input
@@ -745,6 +781,56 @@ class IMAmpAgent:
             return self._info_from_raw(self._raw.clone()) if want_info else None   # (a copy: the next step overwrites `_raw`)
         info.update({k: (v.detach() if torch.is_tensor(v) else v) for k, v in disc_info.items()})
         return info
+
+    def _branch_streams(self, device):
+        """The discriminator's stream of the optimizer step, or None (CPU, switched off)."""
+        if not self._use_branches or torch.device(device).type != "cuda":
+            return None
+        if self._branches is None:
+            from .fast_ops import register_lane
+            self._branches = torch.cuda.Stream(device)
+            register_lane(self._branches, "disc")      # (its kernels get their own reduction scratch buffers)
+            net = self.model.a2c_network
+            disc_params = [p for mod in (net._disc_mlp, net._disc_logits) for p in mod.parameters()]
+            self._disc_spans, self._policy_spans = self.grads.spans_of([p for p in disc_params if getattr(p, "_bucket", None) is self.grads])
+        return self._branches
+
+    def _disc_pass(self, d, amp_idx):
+        """The discriminator's share of an optimizer step on the CURRENT stream: its slice of the gradient bucket zeroed (weight-decay gradients
+        preloaded), the three AMP batches normalised into one [agent; replay; demo] buffer, forward, loss terms, backward."""
+        ws, coefs, preload = self._disc_decay_terms()
+        self.grads.zero([(w, 2.0 * c) for w, c in zip(ws, coefs)] if preload else None, spans=self._disc_spans)
+        m = amp_idx.numel() if amp_idx is not None else d["amp_obs"].shape[0]
+        dt = torch.bfloat16 if self.bf16 else torch.float32
+        A = d["amp_obs"].shape[1]
+        if self.bf16 and getattr(self, "_amp_pad_cols", 0) > A:   # K-padded discriminator input (pad columns stay zero)
+            cat = self._pad_buf("amp_cat", 3 * m, self._amp_pad_cols)
+        else:
+            cat = torch.empty((3 * m, A), dtype=dt, device=d["amp_obs"].device)
+        for k, key in enumerate(("amp_obs", "amp_obs_replay", "amp_obs_demo")):
+            self._amp_input_mean_std(d[key], out_dtype=dt, row_index=amp_idx, out=cat[k * m:(k + 1) * m, :A])
+        amp_obs_demo = cat[2 * m:].requires_grad_(True)
+        with self._autocast():
+            logits = self.model.a2c_network.eval_disc(rows_with_grad(cat, amp_obs_demo, 2 * m))
+        roots, _ = self._disc_loss_fused(logits, m, amp_obs_demo)
+        with param_grad_only():
+            torch.autograd.backward(roots, grad_tensors=[self._unit_cotangent(r) for r in roots])
+
+    def _policy_pass(self, d, idx):
+        """Actor + critic share of an optimizer step on the current stream: their slices of the gradient bucket zeroed, the observation
+        normalised, both forward passes, the fused loss kernel, backward.  (The critic on a third stream was measured too: a graph with a
+        fork inside leaves the runtime's packet-replay path -- profiles/r04_ppo/README.md.)"""
+        net = self.model.a2c_network
+        self.grads.zero(spans=self._policy_spans)
+        obs = self._preproc_obs(d["obs"], use_temp=self.temp_running_mean, row_index=idx)
+        with self._autocast():
+            value = net.eval_critic(obs)
+            mu, logstd = net.eval_actor(obs)
+        ppo, _ = ppo_loss(mu.contiguous(), value.contiguous(), logstd[0] if logstd.dim() == 2 else logstd, d["actions"], d["old_logp_actions"],
+                          d["advantages"], d["returns"], d["old_values"], d["mu"], d["sigma"], self.e_clip, self.critic_coef, self.entropy_coef,
+                          self.bounds_loss_coef, self.clip_value, unit_grad=True, row_index=idx, out=self._raw_buffer()[0][0:6])
+        with param_grad_only():
+            torch.autograd.backward([ppo], grad_tensors=[self._unit_cotangent(ppo)])
 
     def _unit_cotangent(self, like):
         key = (like.dtype, like.device)
@@ -853,6 +939,15 @@ class IMAmpAgent:
         self._g_keys = list(info)
         self._g_info += torch.stack([info[k].float().reshape(()) for k in self._g_keys])
 
+    def _graph_tail(self, fuse_opt):
+        """Behind the two passes of a branched step: the step's scalars into the epoch's accumulator, clip + Adam (one rank)."""
+        self._g_keys = None
+        if self._g_info.numel() != self._raw.numel():
+            self._g_info = torch.zeros_like(self._raw)
+        self._g_info += self._raw
+        if fuse_opt:
+            self._clip_and_step(step_device=self._g_step)
+
     def _graph_opt_key(self):
         """What a graph with the optimizer step inside has baked in: a change (checkpoint with another lr, ...) forces a re-capture."""
         g = self.optimizer.param_groups[0]
@@ -901,10 +996,27 @@ class IMAmpAgent:
                     torch.cuda.synchronize()
                 if fuse_opt and getattr(self, "_g_step", None) is None:
                     self._g_step = torch.zeros((), dtype=torch.int64, device=self.device)
-                with torch.cuda.graph(g, capture_error_mode="thread_local" if in_group else "global"):
-                    self._graph_step_body()
-                    if fuse_opt:
-                        self._clip_and_step(step_device=self._g_step)
+                mode = "thread_local" if in_group else "global"
+                br = self._branch_streams(self.device) if (self._disc_grad_penalty > 0 and self._normalize_amp_input) else None
+                if br:
+                    # three LINEAR graphs per step: the policy pass, the discriminator pass captured ON its stream, and the tail (scalars,
+                    # clip + Adam).  One graph with the passes as branches was measured first: a graph with a fork is enqueued node by node by
+                    # the host (286 vs 40 us per replay in scripts/probes/graph_branch_concurrency.py) in topological order, and the device
+                    # ran the chains mostly one after the other (profiles/r04_ppo/README.md)
+                    gd, gt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                    data, m = self._g_data, self._amp_minibatch_size
+                    with torch.cuda.graph(g, capture_error_mode=mode):
+                        self._policy_pass(data, self._g_idx)
+                    with torch.cuda.graph(gd, stream=br, capture_error_mode=mode):
+                        self._disc_pass(data, self._g_idx[:m])
+                    with torch.cuda.graph(gt, capture_error_mode=mode):
+                        self._graph_tail(fuse_opt)
+                    g = (g, gd, gt)
+                else:
+                    with torch.cuda.graph(g, capture_error_mode=mode):
+                        self._graph_step_body()
+                        if fuse_opt:
+                            self._clip_and_step(step_device=self._g_step)
             finally:
                 for m, bufs in norms:
                     for b, k in zip(m.buffers(), bufs):
@@ -921,7 +1033,17 @@ class IMAmpAgent:
                 self._g_idx.copy_(self._idx_buf[s:e])
                 if e >= self.batch_size:
                     self._idx_buf[:] = torch.randperm(self.batch_size, device=self._idx_buf.device)
-                self._graph.replay()
+                if isinstance(self._graph, tuple):
+                    gp, gd, gt = self._graph
+                    main, sd = torch.cuda.current_stream(self.device), self._branches
+                    sd.wait_stream(main)
+                    with torch.cuda.stream(sd):
+                        gd.replay()
+                    gp.replay()
+                    main.wait_stream(sd)
+                    gt.replay()
+                else:
+                    self._graph.replay()
                 if not fuse_opt:
                     self._grad_all_reduce()
                     self._clip_and_step()

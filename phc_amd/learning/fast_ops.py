@@ -26,13 +26,27 @@ _ws = {}
 _ws_retired = []   # outgrown workspaces are kept alive: a captured hipGraph may still hold their address
 
 
+_lanes = {}        # raw stream handle -> lane name (register_lane): kernels on a branch stream get their OWN scratch buffers
+
+
+def register_lane(stream, name):
+    """The optimizer step forks independent networks onto side streams (IMAmpAgent._fwd_bwd): launches issued while `stream` is current
+    -- the forward under `torch.cuda.stream(stream)`, the backward because autograd runs a node on its forward's stream -- take their
+    workspaces under `name`, so that two branches never share a reduction scratch buffer."""
+    _lanes[stream.cuda_stream] = name
+
+
 def _workspace(key, nbytes, device, dtype):
     n = (nbytes + dtype.itemsize - 1) // dtype.itemsize
+    if _lanes and torch.device(device).type == "cuda":
+        lane = _lanes.get(torch.cuda.current_stream(device).cuda_stream)
+        if lane is not None:
+            key = (key, lane)
     t = _ws.get((key, device))
     if t is None or t.numel() < n:
         if t is not None:
             _ws_retired.append(t)
-        t = torch.empty(max(n, 1), dtype=dtype, device=device)
+        t = torch.empty(max(n, 1), dtype=dtype, device=device)   # (long-lived: which stream's pool it comes from does not matter)
         _ws[(key, device)] = t
     return t
 
