@@ -267,7 +267,7 @@ def test_ppo_train_epoch_on_device():
 
 
 def test_update_graph_equals_eager_launches():
-    """The captured optimizer step (hipGraph, replayed per minibatch with the row-index buffer and the device-side Adam step
+    """The captured optimizer step (hipGraphs, replayed per minibatch with the row-index buffer and the device-side Adam step
     count) trains like the eager launch sequence: same parameters and normaliser statistics after three epochs.  Runs in a child
     process (tests/graph_equivalence_main.py): a failed stream capture takes the process down on this ROCm stack."""
     import json
@@ -283,6 +283,10 @@ def test_update_graph_equals_eager_launches():
     assert out["param_maxdiff"] < 2e-4 and out["param_maxdiff"] < 0.05 * out["param_update_size"], out
     for k, (a, b) in out["info"].items():
         assert abs(a - b) <= 2e-3 * max(1.0, abs(b)), (k, a, b)
+    # round 4: the discriminator pass is its own graph on a second stream (three linear graphs per step); the eager steps fork the same way;
+    # `branch_streams=False` is the one-graph, one-stream update of round 3 -- same kernels on the same operands
+    assert out["three_graphs"] == [True, False] and out["two_streams"] == [True, True, False]
+    assert out["count_equal_one_stream"] and out["param_maxdiff_one_stream"] < 2e-4 and out["param_maxdiff_one_stream"] < 0.05 * out["param_update_size"], out
 
 
 @pytest.mark.parametrize("mode", ["eager", "graph"])
