@@ -788,11 +788,15 @@ class IMAmpAgent:
             return None
         if self._branches is None:
             from .fast_ops import register_lane
-            self._branches = torch.cuda.Stream(device)
-            register_lane(self._branches, "disc")      # (its kernels get their own reduction scratch buffers)
             net = self.model.a2c_network
             disc_params = [p for mod in (net._disc_mlp, net._disc_logits) for p in mod.parameters()]
-            self._disc_spans, self._policy_spans = self.grads.spans_of([p for p in disc_params if getattr(p, "_bucket", None) is self.grads])
+            try:
+                self._disc_spans, self._policy_spans = self.grads.spans_of([p for p in disc_params if getattr(p, "_bucket", None) is self.grads])
+            except ValueError:      # (a network whose discriminator parameters are not one run of the bucket: one stream, as before round 4)
+                self._use_branches = False
+                return None
+            self._branches = torch.cuda.Stream(device)
+            register_lane(self._branches, "disc")      # (its kernels get their own reduction scratch buffers)
         return self._branches
 
     def _disc_pass(self, d, amp_idx):
