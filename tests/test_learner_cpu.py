@@ -208,6 +208,25 @@ def test_flat_grad_bucket_is_one_buffer():
     assert lin[1].bias.grad.abs().sum() == 0
 
 
+def test_flat_grad_bucket_spans_and_partial_zero():
+    """Round 4: the two passes of an optimizer step (policy, discriminator) each zero THEIR part of the flat gradient (`spans_of`, `zero(spans=)`)."""
+    net = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.Linear(3, 2), torch.nn.Linear(2, 5))
+    b = FlatGradBucket(net.parameters())
+    own, rest = b.spans_of(list(net[1].parameters()))
+    assert own == [(16, 26)] and rest == [(0, 16), (26, b.flat.numel())]          # (weight 6 + 2 pad, bias 2 | before | after)
+    own_last, rest_last = b.spans_of(list(net[2].parameters()))
+    assert own_last == [(28, b.flat.numel())] and rest_last == [(0, 28)]
+    with pytest.raises(ValueError):
+        b.spans_of([net[0].weight, net[2].weight])                                 # not one consecutive run
+    b.flat.fill_(1.0)
+    g0 = b.gen
+    b.zero(decay=[(net[1].weight, 2.0)], spans=own)
+    assert b.gen == g0 + 1 and torch.equal(net[1].weight.grad, 2.0 * net[1].weight.data) and net[1].bias.grad.abs().sum() == 0
+    assert (net[0].weight.grad == 1).all() and (net[2].bias.grad == 1).all()       # the other pass's gradients are not touched
+    b.zero(spans=rest)
+    assert net[0].weight.grad.abs().sum() == 0 and net[2].bias.grad.abs().sum() == 0 and torch.equal(net[1].weight.grad, 2.0 * net[1].weight.data)
+
+
 def test_pnn_network_and_forward_pmcp():
     """P3: PNN actor columns (key names, freezing, column selection) and the forward_pmcp column copy."""
     from phc_amd.learning.network import A2CPNNNetwork, forward_pmcp
