@@ -1,6 +1,8 @@
 """Offline selection of the library GEMM solutions of the PPO path (PyTorch TunableOp over hipBLASLt / rocBLAS) on the GPU box:
 runs eager train_epochs of the bench-sized learner with tuning on, so that every GEMM shape of the rollout and of the optimizer step is timed against
-the library's candidate solutions once, and writes the winners to phc_amd/learning/tuned_gemms_gfx950.csv (committed; IMAmpAgent loads it, tuning off).
+the library's candidate solutions once, and writes the winners to a TunableOp results file.  Measured in round 4 (profiles/r04_ppo/README.md): the
+library's default heuristic already picks the fastest candidate for most of the 25 shapes and the update does not get faster with the file loaded, so
+no loader ships -- this script stays as the probe that produced that result.
 
     python scripts/tune_gemms.py [--learning im] [--out gpurun_out/tuned/tuned_gemms_gfx950.csv] [--iters 10] [--ms 10]
 """
@@ -33,8 +35,7 @@ def main():
     from phc_amd.env.tasks.vec_task import parse_task
     from phc_amd.learning.amp_agent import IMAmpAgent
     torch.manual_seed(0)
-    cfg = compose([f"env.num_envs={a.num_envs}", "env.motion_file=synthetic:1:0", f"learning={a.learning}", "+learning.params.config.hip_graph=False",
-                   "+learning.params.config.tuned_gemms=False"])
+    cfg = compose([f"env.num_envs={a.num_envs}", "env.motion_file=synthetic:1:0", f"learning={a.learning}", "+learning.params.config.hip_graph=False"])
     task, env = parse_task(cfg)
     agent = IMAmpAgent(env, cfg)
     agent.init_train()
