@@ -29,7 +29,6 @@ MI355X-first differences (results-preserving):
     are tested against.
 """
 import copy
-import contextlib
 import os
 import time
 import warnings
