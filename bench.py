@@ -73,6 +73,8 @@ def parse():
     ap.add_argument("--burn-in", type=int, default=64, help="untimed env steps in FRONT of the W warm-up steps (reported as `protocol_burn_in_steps`): "
                     "right after env.reset() every env falls, and is reset, in the same few steps; 0 = the bare driver protocol (W warm-up steps only)")
     ap.add_argument("--self-collision", type=int, default=-1, help="-1: as the robot yaml says (has_self_collision: True); 0/1 force")
+    ap.add_argument("--solver", action="append", default=[], metavar="KEY=VALUE", help="stepper switch passed on as `+solver.KEY=VALUE` (repeatable), "
+                    "e.g. --solver inertia_lag=1 --solver force_average=1 --solver contact=tgs")
     ap.add_argument("--motion-clips", type=int, default=1, help="synthetic clips in the motion library (configs[1]: 1; configs[2]/[3] shape: thousands)")
     ap.add_argument("--actions", choices=["random", "tracking"], default="random",
                     help="random: fixed a ~ U(-1,1)*0.1 tensor (SURVEY 8d protocol; zero-pose targets -> episodes end after a few steps); "
@@ -397,7 +399,8 @@ def main():
         graph_over.append("+learning.params.config.force_collectives=True")
     learn_over = ([f"learning={args.learning}"] + (["env=env_im_pnn"] if "pnn" in args.learning and args.robot == "smpl" else [])) if args.learning != "im" else []
     cfg = compose(learn_over + robot_over + graph_over + [f"env.num_envs={args.envs}", f"env.motion_file=synthetic:{args.motion_clips}:0", f"device_id={local_rank}",
-                                f"rl_device=cuda:{local_rank}", f"+solver.lane_mapping={args.lane_mapping}"] + ([f"+solver.self_collision={args.self_collision}"] if args.self_collision >= 0 else []))
+                                f"rl_device=cuda:{local_rank}", f"+solver.lane_mapping={args.lane_mapping}"] + ([f"+solver.self_collision={args.self_collision}"] if args.self_collision >= 0 else [])
+                  + [f"+solver.{kv}" for kv in args.solver])
     t_build = time.perf_counter()
     task, env = parse_task(cfg, device_id=local_rank)
     t_build = time.perf_counter() - t_build
@@ -487,7 +490,7 @@ def main():
         traffic, traffic_src = None, None  # HBM bytes per launch of the stepper from the PMC counters
         if world == 1 and not args.no_pmc and not os.environ.get("PHC_BENCH_CHILD"):
             tail = ["--envs", str(args.envs), "--robot", args.robot, "--lane-mapping", str(args.lane_mapping), "--actions", args.actions,
-                    "--motion-clips", str(args.motion_clips), "--self-collision", str(args.self_collision)]
+                    "--motion-clips", str(args.motion_clips), "--self-collision", str(args.self_collision)] + [x for kv in args.solver for x in ("--solver", kv)]
             traffic, detail = live_pmc_traffic(tail, ("k_sim_step<true",))
             traffic_src = {"live": detail} if traffic is not None else None
             if traffic is None:
@@ -544,6 +547,8 @@ def main():
             out["other_workloads"] = other_workloads()
         out["per_rank"] = [{"rank": r, "elapsed_s": e, "env_steps_per_s": N * args.steps / e} for r, e in enumerate(per_rank)]
         out["actions"] = args.actions
+        if args.solver:
+            out["solver_overrides"] = list(args.solver)
         if not os.environ.get("PHC_BENCH_CHILD"):
             out["device"] = device_state(dev)
         out["envs_within_5_steps_of_a_reset"] = resets

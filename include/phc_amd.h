@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PHC_ABI_VERSION 34
+#define PHC_ABI_VERSION 35
 #define PHC_MAX_BODIES 64   /* bodies (incl. extended reference bodies) per articulation; also the slot count of the model tables */
 #define PHC_EINVAL (-1)
 #define PHC_EUNSUPPORTED (-2)
@@ -137,11 +137,22 @@ typedef struct {
      *     END-of-step normal force and slip velocity; active set and cone are found by contact_iterations fixed-point passes, each an exact
      *     O(n) articulated-body solve of the whole tree with the contact impedances of the previous pass. */
     int32_t contact_model;
-    int32_t contact_iterations;       /* passes per sub-step in model 1 (PhysX num_position_iterations: 4); >= 2 */
+    int32_t contact_iterations;       /* passes per sub-step in model 1 (PhysX num_position_iterations: 4); >= 2 (a single pass never re-evaluates the active set
+                                         or the friction cone on predicted velocities: PHC_EINVAL) */
     float contact_impedance;          /* model 1: N s/m per contact point (default 1e5: dt * c = 833 kg of apparent mass per point) */
     float max_depenetration_velocity; /* m/s (default_sim.yaml: 10) */
     float bounce_threshold_velocity;  /* m/s (default_sim.yaml: 0.2) */
     float restitution;                /* plane / shape restitution (env_im.yaml plane.restitution: 0) */
+    /* ---- ABI 35 ---- */
+    int32_t inertia_lag;              /* 1 (solver.inertia_lag; contact_model 0 only): the articulated inertias I^A and the joint-space inverses are formed in the FIRST
+                                         sub-step of every simulate() call and kept over its other sub-steps, which only redo the bias-force recursion
+                                         (forces, drives and velocity products at the current state; a third of the backward sweep's arithmetic).  The kept
+                                         I^A is O(dt) old, the velocities it produces differ by O(dt^2) per sub-step: the scheme stays first-order consistent
+                                         (tests/test_dynamics.py: dt-convergence with the switch on).  A ground-contact point that starts to touch in a
+                                         lagged sub-step joins at the next fresh one (its impedance is not in the kept I^A).  0 = every sub-step fresh. */
+    int32_t force_average;            /* 1 (solver.force_average): contact_force (S4) and dof_force (S5) are the MEANS over all sub-steps of the env step
+                                         (what a power / contact reward integrates over the control interval); 0 = the last sub-step's values -- what Isaac
+                                         Gym's tensors hold after simulate() with substeps > 1, as far as its documentation says (humanoid.py:185,193-194) */
 } phc_sim_params_t;
 
 /* Imitation-task parameters (phc/env/tasks/humanoid_im.py:37-123, env_im.yaml). */

@@ -49,6 +49,7 @@ static int emu_sim_step_t(const phc_model_t* model_all, const phc_sim_params_t* 
             const float dt = prm->sim_dt / (float)prm->substeps;
             const int nsub = num_sim_calls * prm->substeps;
             std::vector<float> caps(PHC_MAX_BODIES * PHC_CAP_STRIDE);
+            float favg[PHC_MAX_BODIES * 6];
             const int sd = model_solver_depth(*model, true);
             const bool rerooted = model_tab(*model, 11, 3) != 0;
             for (int s = 0; s < nsub; ++s) {
@@ -66,21 +67,23 @@ static int emu_sim_step_t(const phc_model_t* model_all, const phc_sim_params_t* 
                 for (int j = 0; j < nb; ++j) aba_velocity_products(L[j], *model, j, x, true);
                 const bool rigid = prm->contact_model == 1;
                 const int passes = rigid ? (prm->contact_iterations < 1 ? 1 : prm->contact_iterations) : 1;
+                const bool lag = !rigid && prm->inertia_lag != 0 && (s % prm->substeps) != 0;
                 for (int pass = 0; pass < passes; ++pass) {
                     for (int j = 0; j < nb; ++j) {
                         if (rigid) aba_body_init<JT, true>(L[j], *model, *prm, dt, j, s % prm->substeps == 0, true, pass);
-                        else aba_body_init<JT, false>(L[j], *model, *prm, dt, j, s % prm->substeps == 0, true, 0);
+                        else aba_body_init<JT, false>(L[j], *model, *prm, dt, j, s % prm->substeps == 0, true, 0, lag);
                     }
                     if (JT == PHC_JT_SPHERICAL && rerooted && pass == 0) {
                         for (int j = 0; j < nb; ++j) aba_publish_drive(L[j], j, x);
                         for (int j = 0; j < nb; ++j) aba_fetch_drive(L[j], j, x);
                     }
-                    for (int l = sd; l >= 0; --l) for (int j = 0; j < nb; ++j) aba_backward_level<JT>(L[j], l, j, x);
+                    for (int l = sd; l >= 0; --l) for (int j = 0; j < nb; ++j) aba_backward_level<JT>(L[j], l, j, x, lag);
                     for (int l = 0; l <= sd; ++l) for (int j = 0; j < nb; ++j) aba_accel_level<JT>(L[j], l, j, x);
                 }
-                if (rigid && s == nsub - 1) for (int j = 0; j < nb; ++j) aba_publish_contact_rigid(L[j], *model, *prm, *sim, dt, env, j, true);
+                if (rigid && (s == nsub - 1 || prm->force_average)) for (int j = 0; j < nb; ++j) aba_publish_contact_rigid(L[j], *model, *prm, *sim, dt, env, j, true);
                 if (JT == PHC_JT_SPHERICAL && rerooted) for (int j = 0; j < nb; ++j) aba_accel_finish(L[j], *model, j, x);
                 for (int j = 0; j < nb; ++j) aba_integrate_joint<JT>(L[j], *prm, dt);
+                if (prm->force_average) for (int j = 0; j < nb; ++j) aba_force_accumulate(L[j], s, nsub, favg + 6 * j);
                 for (int j = 0; j < nb; ++j) aba_fk_jump_begin(L[j], j, x);
                 for (int k = 0, ks = model_jump_steps(*model); k < ks; ++k) {   // all bodies read the previous step's slots, then all write
                     for (int j = 0; j < nb; ++j) aba_fk_jump_step(L[j], k, x);

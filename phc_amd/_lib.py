@@ -46,7 +46,7 @@ class SimParams(C.Structure):
                 ("self_collision", c_i32), ("self_stiffness_scale", c_f), ("self_damping_ratio", c_f), ("lane_mapping", c_i32),
                 ("num_force_sensors", c_i32), ("force_sensor_body", c_i32 * 4),
                 ("contact_model", c_i32), ("contact_iterations", c_i32), ("contact_impedance", c_f), ("max_depenetration_velocity", c_f),
-                ("bounce_threshold_velocity", c_f), ("restitution", c_f)]
+                ("bounce_threshold_velocity", c_f), ("restitution", c_f), ("inertia_lag", c_i32), ("force_average", c_i32)]
 
 
 class ImParams(C.Structure):
@@ -136,7 +136,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the .so does not export the symbol
         fn.argtypes = argtypes
         fn.restype = restype
-    if lib.phc_abi_version() != 34:
+    if lib.phc_abi_version() != 35:
         raise ImportError("libphc_amd.so ABI version mismatch")
     _lib = lib
     return lib

@@ -68,9 +68,17 @@ def sim_params_struct(sim_dt=1 / 60, substeps=2, control_freq_inv=2, gravity_z=-
                       contact_damping=1.0e3, friction=1.0, friction_viscous=2.0e3, angular_damping=0.01,
                       max_angular_velocity=100.0, contact_offset=0.02, control_mode=0, limit_stiffness=0.0, limit_damping=0.0, lane_mapping=0,
                       self_collision=0, self_stiffness_scale=0.25, self_damping_ratio=0.5, force_sensor_bodies=(), contact_model=0,
-                      contact_iterations=4, contact_impedance=1.0e5, max_depenetration_velocity=10.0, bounce_threshold_velocity=0.2, restitution=0.0):
+                      contact_iterations=4, contact_impedance=1.0e5, max_depenetration_velocity=10.0, bounce_threshold_velocity=0.2, restitution=0.0,
+                      inertia_lag=0, force_average=0):
     p = L.SimParams()
+    if isinstance(contact_model, str) and contact_model not in ("penalty", "tgs", "rigid"):
+        raise ValueError(f"solver.contact must be 'penalty' or 'tgs' (alias 'rigid'), not {contact_model!r}")
     p.contact_model = {"penalty": 0, "tgs": 1, "rigid": 1}.get(contact_model, contact_model)
+    p.inertia_lag, p.force_average = int(bool(inertia_lag)), int(bool(force_average))
+    if p.contact_model == 1 and p.inertia_lag:
+        raise ValueError("solver.inertia_lag needs the penalty contact model (the rigid model re-solves every sub-step with fresh impedances)")
+    if p.contact_model == 1 and int(contact_iterations) < 2:
+        raise ValueError("solver.contact_iterations must be >= 2 for the rigid contact model")
     p.contact_iterations, p.contact_impedance = int(contact_iterations), float(contact_impedance)
     p.max_depenetration_velocity, p.bounce_threshold_velocity, p.restitution = float(max_depenetration_velocity), float(bounce_threshold_velocity), float(restitution)
     assert len(force_sensor_bodies) <= 4, "at most 4 force sensors"

@@ -36,6 +36,16 @@ namespace phc {
 #define PHC_JT_REVOLUTE 2
 #define PHC_NTAB 21            // int tables per model (parent level jtype dof_start child0-2 nchild cp_start cp_count order misc collide-mask | solver tree: parent level child0-2 nchild jsrc/bsrc | pointer-jumping anchors)
 
+// set of ground-contact points of one body (bit k = point k of the body's slice of the table): 64 bits -- Unitree G1 has bodies with 40 points
+#if defined(PHC_CP_MASK32)
+typedef uint32_t CpMask;
+#define PHC_CP_CTZ(x) __builtin_ctz(x)
+#else
+typedef uint64_t CpMask;
+#define PHC_CP_CTZ(x) __builtin_ctzll(x)
+#endif
+#define PHC_CP_BITS ((int)(8 * sizeof(CpMask)))
+
 struct Sym3 { float xx, xy, xz, yy, yz, zz; };
 
 PHC_HD V3 sym_mul(const Sym3& s, V3 v) {
@@ -143,6 +153,9 @@ struct AbaLane {
     //     point as the LAST solve of this sub-step left them (aba_accel_level) -- the next pass evaluates active set and friction cone on them ---
     V3 acc_w, acc_v;
     uint32_t c_active, c_removed;   // per contact point of the body (bit k, k < 32): pushed in the previous pass / released for the rest of the sub-step
+    // --- lagged articulated inertia (phc_sim_params_t.inertia_lag): the ground-contact points that carried force in the last FRESH sub-step --
+    //     the only ones whose impedance the kept I^A contains, hence the only ones a lagged sub-step lets push
+    CpMask c_touch;
 };
 
 // per-env body shapes (phc_model_t.num_shapes > 1): the env's block of the int / float tables; the scalar header fields stay shared
@@ -196,7 +209,7 @@ PHC_HD void aba_load_model(AbaLane& L, const phc_model_t& m, int j, bool reroot 
 // revolute extras (template JT == PHC_JT_REVOLUTE paths only)
 // convenience overload: constants read from the model at every call
 template <int JT, bool RIGID = false>
-PHC_HD void aba_body_init(AbaLane& L, const phc_model_t& m, const phc_sim_params_t& prm, float dt, int j, bool new_sim_call, bool reroot = true, int pass = 0);
+PHC_HD void aba_body_init(AbaLane& L, const phc_model_t& m, const phc_sim_params_t& prm, float dt, int j, bool new_sim_call, bool reroot = true, int pass = 0, bool lag = false);
 
 PHC_HD void aba_load_model_rev(AbaLane& L, const phc_model_t& m, int j) {
     const float* f = model_body(m, j);
@@ -428,9 +441,12 @@ PHC_HD void aba_ground_force_rigid(const AbaLane& L, const phc_sim_params_t& prm
 // `RIGID` / `pass`: contact_model 1 (include/phc_amd.h) -- the sub-step is solved contact_iterations times; pass 0 decides active set and friction
 // cone on the current velocities, pass k > 0 on the end-of-step velocities the previous solve predicts (L.acc_w / L.acc_v); the joint drive is
 // formed in pass 0 only (it does not depend on the contact forces).
+// `lag` (phc_sim_params_t.inertia_lag, penalty contact only): a sub-step that keeps the articulated inertias I^A and the joint-space inverses D^-1 of the
+// previous sub-step (aba_backward_level's bias-only form).  Only p^A and the joint drive are formed here then: bias force and gravity at the current
+// state, the explicit part F0 of the contact law for the points whose impedance the kept I^A holds (L.c_touch), body-body forces, drive torque.
 template <int JT, bool RIGID>
 PHC_HD void aba_body_init(AbaLane& L, const phc_model_t& m, const phc_sim_params_t& prm, float dt, int j, bool new_sim_call,
-                          const float* f, int cp_start, int cp_total, bool reroot, int pass) {
+                          const float* f, int cp_start, int cp_total, bool reroot, int pass, bool lag = false) {
     const float mass = f[3];
     // every spatial quantity of the body is taken about its solver reference point o = p + R off (the origin unless the body is reversed)
     const SolverRef sr = model_solver_ref(f, reroot);
@@ -439,11 +455,13 @@ PHC_HD void aba_body_init(AbaLane& L, const phc_model_t& m, const phc_sim_params
     V3 mc = mat_mul(R, sr.mc);
     const V3 so = mat_mul(R, sr.off);
     // rigid-body inertia about the reference point: [[Io, [mc]x], [[mc]x^T, m 1]]
-    L.IA.A = Io;
-    L.IA.B[0] = 0.f;   L.IA.B[1] = -mc.z; L.IA.B[2] = mc.y;
-    L.IA.B[3] = mc.z;  L.IA.B[4] = 0.f;   L.IA.B[5] = -mc.x;
-    L.IA.B[6] = -mc.y; L.IA.B[7] = mc.x;  L.IA.B[8] = 0.f;
-    L.IA.C.xx = L.IA.C.yy = L.IA.C.zz = mass; L.IA.C.xy = L.IA.C.xz = L.IA.C.yz = 0.f;
+    if (!lag) {
+        L.IA.A = Io;
+        L.IA.B[0] = 0.f;   L.IA.B[1] = -mc.z; L.IA.B[2] = mc.y;
+        L.IA.B[3] = mc.z;  L.IA.B[4] = 0.f;   L.IA.B[5] = -mc.x;
+        L.IA.B[6] = -mc.y; L.IA.B[7] = mc.x;  L.IA.B[8] = 0.f;
+        L.IA.C.xx = L.IA.C.yy = L.IA.C.zz = mass; L.IA.C.xy = L.IA.C.xz = L.IA.C.yz = 0.f;
+    }
     // bias force + gravity (external forces enter p^A with a minus sign)
     V3 g = v3(0.f, 0.f, prm.gravity_z);
     L.pA.n = cross(L.w, sym_mul(Io, L.w)) - cross(mc, g);
@@ -461,52 +479,59 @@ PHC_HD void aba_body_init(AbaLane& L, const phc_model_t& m, const phc_sim_params
     // loads in flight together (the z row of R only: 4 instructions per point); the loop below then visits the SET BITS -- one iteration per
     // touching point of the busiest lane, each with its point's record already requested -- instead of one dependent table load and one
     // depth test per point (the 8-corner feet made every sub-step walk 8 iterations)
-    uint32_t touching = 0u;
-    const int cp_fast = cp_count < 32 ? cp_count : 32;
+    CpMask touching = 0;
+    const int cp_fast = cp_count < PHC_CP_BITS ? cp_count : PHC_CP_BITS;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll 8
 #endif
     for (int k = 0; k < cp_fast; ++k) {
         const float az = R.m[6] * cp[4 * k] + R.m[7] * cp[4 * k + 1] + R.m[8] * cp[4 * k + 2];
-        if (cp[4 * k + 3] - (L.p.z + az) > 0.f) touching |= 1u << k;
+        if (cp[4 * k + 3] - (L.p.z + az) > 0.f) touching |= (CpMask)1 << k;
     }
+    if (lag) touching &= L.c_touch;   // (a point that arrives between two fresh sub-steps joins at the next one: its impedance is not in the kept I^A)
     // one iteration per touching point of the busiest lane; the NEXT touching point's record is requested before the current one is worked on
     // (round 4: the table sits in L2 -- ~200 cycles per dependent load -- and the set-bit order is only known at run time)
     struct Cp4 { float x, y, z, r; };
     auto cp_load = [&](int k) { Cp4 c; c.x = cp[4 * k]; c.y = cp[4 * k + 1]; c.z = cp[4 * k + 2]; c.r = cp[4 * k + 3]; return c; };
-    auto cp_point = [&](const Cp4& c) {
+    auto cp_point = [&](const Cp4& c) -> bool {
         V3 arm = mat_mul(R, v3(c.x, c.y, c.z));
         const float rad = c.r;
         const float depth = rad - (L.p.z + arm.z);
-        if (depth <= 0.f) return;
+        if (depth <= 0.f) return false;
         arm.z -= rad;  // actual contact location relative to the body origin
         const V3 uc = L.v + cross(L.w, arm);
         arm = arm - so;  // ... relative to the reference point, which the moments and the implicit terms refer to
         const float fn0 = prm.contact_stiffness * depth - cn * uc.z;
-        if (fn0 <= 0.f) return;  // separating: non-adhesive
+        if (fn0 <= 0.f) return false;  // separating: non-adhesive
         const float ut = sqrtf(uc.x * uc.x + uc.y * uc.y);
         const float ct = fminf(prm.friction_viscous, prm.friction * fn0 / (ut + 1e-6f));
         const V3 cc = cross(L.w, cross(L.w, arm));
         const V3 F0 = v3(-ct * uc.x - dt * ct * cc.x, -ct * uc.y - dt * ct * cc.y, fn0 - dt * cn * cc.z);
         L.fcontact += F0;
-        aba_add_point_contact(L, arm, F0, dt * ct, dt * cn);
+        if (lag) { L.pA.n -= cross(arm, F0); L.pA.f -= F0; }
+        else aba_add_point_contact(L, arm, F0, dt * ct, dt * cn);
+        return true;
     };
-    if (touching != 0u) {
-        uint32_t rest = touching;
-        int k = __builtin_ctz(rest);
-        rest &= rest - 1u;
+    CpMask pushed = 0;
+    if (touching != 0) {
+        CpMask rest = touching;
+        int k = PHC_CP_CTZ(rest);
+        rest &= rest - 1;
         Cp4 cur = cp_load(k);
         while (true) {
-            const bool more = rest != 0u;
-            const int kn = more ? __builtin_ctz(rest) : k;
-            rest &= rest - 1u;
+            const bool more = rest != 0;
+            const int kn = more ? PHC_CP_CTZ(rest) : k;
+            rest &= rest - 1;
             const Cp4 nxt = cp_load(kn);     // (in flight while the current point is worked on)
-            cp_point(cur);
+            if (cp_point(cur)) pushed |= (CpMask)1 << k;
             if (!more) break;
             k = kn; cur = nxt;
         }
     }
-    for (int k = 32; k < cp_count; ++k) cp_point(cp_load(k));   // (bodies with more than 32 points: the rest one by one)
+    if (!lag) {
+        for (int k = PHC_CP_BITS; k < cp_count; ++k) cp_point(cp_load(k));   // (bodies with more points than the mask has bits: the rest one by one; a lagged sub-step leaves them out)
+        L.c_touch = pushed;
+    }
     }
     // body-body contact forces of this sub-step (explicit; zero unless sim_params.self_collision)
     L.fcontact += L.fself;
@@ -572,14 +597,14 @@ PHC_HD void aba_body_init(AbaLane& L, const phc_model_t& m, const phc_sim_params
         L.dimp = d;
         const V3 dd = d + v3(f[19], f[20], f[21]);   // + armature (read here: not pinned in registers across the sweeps)
         if (dd.x == dd.y && dd.y == dd.z) { L.diso = dd.x; }
-        else { L.diso = -1.f; L.Dw = rot_diag(R, dd); }
+        else { L.diso = -1.f; if (!lag) L.Dw = rot_diag(R, dd); }
         L.tau_w = mat_mul(R, tau);
     }
 }
 
 template <int JT, bool RIGID>
-PHC_HD void aba_body_init(AbaLane& L, const phc_model_t& m, const phc_sim_params_t& prm, float dt, int j, bool new_sim_call, bool reroot, int pass) {
-    aba_body_init<JT, RIGID>(L, m, prm, dt, j, new_sim_call, model_body(m, j), model_tab(m, 8, j), model_tab(m, 9, j), reroot, pass);
+PHC_HD void aba_body_init(AbaLane& L, const phc_model_t& m, const phc_sim_params_t& prm, float dt, int j, bool new_sim_call, bool reroot, int pass, bool lag) {
+    aba_body_init<JT, RIGID>(L, m, prm, dt, j, new_sim_call, model_body(m, j), model_tab(m, 8, j), model_tab(m, 9, j), reroot, pass, lag);
 }
 // rigid contact model: S4 net ground force of the body from the final solve of the sub-step (+ the body-body forces, as the penalty model
 // publishes), and S6: the force sensors read the same wrench (about the body origin, in the body frame)
@@ -818,9 +843,32 @@ PHC_HD void accumulate_child(Inertia6& I, Force6& p, const float* s, int es) {
 // ---- backward sweep: articulated inertia, one tree level (leaves -> root) ----
 // Lanes at `level` first absorb their children's contributions (written at level+1), then, unless
 // they are the root, reduce over their own joint and publish T^T I^a T, T^T p^a for their parent.
+// `lag` (phc_sim_params_t.inertia_lag): the BIAS-ONLY level-step of a sub-step that keeps I^A and D^-1 of the previous one.  With U = [A; B^T] the first
+// three columns of I^A and I^a = I^A - U D^-1 U^T,
+//     p^a = p^A + I^a c + U D^-1 u = p^A + I^A c + U D^-1 (u - U^T c),      U^T c = A c_w + B c_a = (I^A c)_top,
+// i.e. two 3x3 products with c, one with D^-1 and two with its result: ~75 multiply-adds and a 6-float hand-over instead of the ~350 and 27 floats of
+// the full step -- no 3x3 inverse, no projected inertia, no congruence.
 template <int JT>
-PHC_HD void aba_backward_level(AbaLane& L, int level, int j, const Xch& x) {
+PHC_HD void aba_backward_level(AbaLane& L, int level, int j, const Xch& x, bool lag = false) {
     if (L.slevel != level) return;
+    if (lag) {
+        constexpr int es = Xch::es;
+        for (int k = 0; k < 3; ++k)
+            if (k < L.nchild) {
+                const float* s = xslot(x, L.child[k]);
+                L.pA.n.x += s[21 * es]; L.pA.n.y += s[22 * es]; L.pA.n.z += s[23 * es]; L.pA.f.x += s[24 * es]; L.pA.f.y += s[25 * es]; L.pA.f.z += s[26 * es];
+            }
+        if (level == 0) return;
+        L.u = L.tau_w - L.pA.n;
+        const V3 t = sym_mul(L.IA.A, L.cw) + B_mul(L.IA.B, L.ca);
+        const V3 sb = Bt_mul(L.IA.B, L.cw) + sym_mul(L.IA.C, L.ca);
+        const V3 z = sym_mul(L.Di, L.u - t);
+        const V3 f = L.pA.f + sb + Bt_mul(L.IA.B, z);
+        const V3 n = L.pA.n + t + sym_mul(L.IA.A, z) + cross(L.rw, f);
+        float* o = xslot(x, j);
+        o[21 * es] = n.x; o[22 * es] = n.y; o[23 * es] = n.z; o[24 * es] = f.x; o[25 * es] = f.y; o[26 * es] = f.z;
+        return;
+    }
     for (int k = 0; k < 3; ++k)
         if (k < L.nchild) accumulate_child(L.IA, L.pA, xslot(x, L.child[k]), Xch::es);
     if (level == 0) return;
@@ -1000,6 +1048,17 @@ PHC_HD void aba_integrate_joint(AbaLane& L, const phc_sim_params_t& prm, float d
         if (wn > prm.max_angular_velocity) L.wj = L.wj * (prm.max_angular_velocity / wn);
         L.q = quat_normalize(quat_mul16(L.q, quat_from_rotvec(L.wj * dt)));
     }
+}
+
+// S4 / S5 over the whole control step (phc_sim_params_t.force_average): sub-step s of n adds its net contact force (L.fcontact: ground + body-body)
+// and the joint torque it applied (L.tau_local after aba_integrate_joint) to the accumulators; the last one leaves the means where
+// aba_store_state / aba_publish_body read them.
+PHC_HD void aba_force_accumulate(AbaLane& L, int s, int n, float* acc /*6 floats of this lane: LDS on the device -- not lane registers, the kernel sits at its VGPR limit*/) {
+    if (L.level < 0) return;
+    V3 f = L.fcontact, t = L.tau_local;
+    if (s > 0) { f += v3(acc[0], acc[1], acc[2]); t += v3(acc[3], acc[4], acc[5]); }
+    if (s == n - 1) { const float w = 1.0f / (float)n; L.fcontact = f * w; L.tau_local = t * w; return; }
+    acc[0] = f.x; acc[1] = f.y; acc[2] = f.z; acc[3] = t.x; acc[4] = t.y; acc[5] = t.z;
 }
 
 // ---- state store: S1/S2 (+S5 dof force), and S3/S4 publication from the last kinematics sweep ----

@@ -18,8 +18,12 @@ using namespace phc;
 #ifdef PHC_SIM_PROFILE
 __device__ unsigned long long g_phc_prof[16];
 __device__ unsigned long long g_phc_prof_wg[8192][10];   // the same per workgroup (= wavefront), of the LAST launch: the launch lasts as long as its slowest wavefront
+__device__ unsigned long long g_phc_prof_where[8192][2];   // round 5: [start cycle of the wavefront, XCC_ID << 32 | HW_ID]: WHERE and WHEN the slow wavefronts ran
 extern "C" int32_t phc_debug_profile_wg(unsigned long long* out, int32_t nwg) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phc_prof_wg), sizeof(unsigned long long) * 10 * (nwg < 8192 ? nwg : 8192)) == hipSuccess ? 0 : -1;
+}
+extern "C" int32_t phc_debug_profile_where(unsigned long long* out, int32_t nwg) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phc_prof_where), sizeof(unsigned long long) * 2 * (nwg < 8192 ? nwg : 8192)) == hipSuccess ? 0 : -1;
 }
 extern "C" int32_t phc_debug_profile(unsigned long long* out16, int32_t reset) {
     if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_phc_prof), sizeof(g_phc_prof)) != hipSuccess) return -1;
@@ -43,9 +47,11 @@ extern "C" int32_t phc_debug_timeline(unsigned long long* out512, int32_t block)
         if (threadIdx.x == 0) { g_phc_tl[2 * tl_n] = (unsigned long long)(id); g_phc_tl[2 * tl_n + 1] = t_; } ++tl_n; __builtin_amdgcn_sched_barrier(0); }
 #define PHC_SKIP_DECL const int skip_mask = g_phc_skip;
 #define PHC_SKIP(b) ((skip_mask >> (b)) & 1)
-#define PHC_PROF_DECL unsigned long long prof_acc[10] = {0}; unsigned long long prof_t = __builtin_readcyclecounter();
+#define PHC_PROF_DECL unsigned long long prof_acc[10] = {0}; unsigned long long prof_t = __builtin_readcyclecounter(); const unsigned long long prof_t0 = prof_t; \
+        const unsigned long long prof_hw = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4);
 #define PHC_PROF(i) if (!PHC_SKIP(15)) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0); const unsigned long long t_ = __builtin_readcyclecounter(); prof_acc[i] += t_ - prof_t; prof_t = t_; __builtin_amdgcn_sched_barrier(0); }
-#define PHC_PROF_FLUSH if (threadIdx.x == 0 && !PHC_SKIP(15)) { for (int i_ = 0; i_ < 10; ++i_) { atomicAdd(&g_phc_prof[i_], prof_acc[i_]); if (blockIdx.x < 8192) g_phc_prof_wg[blockIdx.x][i_] = prof_acc[i_]; } atomicAdd(&g_phc_prof[15], 1ull); }
+#define PHC_PROF_FLUSH if (threadIdx.x == 0 && !PHC_SKIP(15)) { for (int i_ = 0; i_ < 10; ++i_) { atomicAdd(&g_phc_prof[i_], prof_acc[i_]); if (blockIdx.x < 8192) g_phc_prof_wg[blockIdx.x][i_] = prof_acc[i_]; } atomicAdd(&g_phc_prof[15], 1ull); \
+        if (blockIdx.x < 8192) { g_phc_prof_where[blockIdx.x][0] = prof_t0; g_phc_prof_where[blockIdx.x][1] = prof_hw; } }
 #else
 #define PHC_PROF_DECL
 #define PHC_PROF(i)
@@ -139,7 +145,10 @@ __device__ __forceinline__ bool stage_aligned(const phc_sim_state_t& sim) {
 // of scratch) keeps 3072 wavefronts resident instead of 2048 -- and was measured SLOWER at every size (round 4, profiles/r04_stepper/occupancy_2_vs_3_waves_per_simd.txt:
 // 96.6 vs 78.0 us at 4096 envs, 168.9 vs 145.3 at 8192, 241.0 vs 211.9 at 12288): the spilled wavefront's longer stream costs more than the
 // third resident wavefront hides.  Kept behind lane_mapping = 3 so that the measurement can be repeated; never chosen automatically.
-template <bool STEP, int JT, int GRP, bool SHAPES = false, bool RIGID = false, int OCC = 2>
+// LAG: the instantiation whose sub-steps behind the first one of a simulate() call keep its articulated inertias (phc_sim_params_t.inertia_lag); a
+// template parameter, not a run-time branch: with the switch compiled into the one kernel it took 256 VGPRs + 12 spilled SGPRs instead of 224 and the
+// every-sub-step-fresh launch went from 77 to 82 us (round 5, same box).
+template <bool STEP, int JT, int GRP, bool SHAPES = false, bool RIGID = false, int OCC = 2, bool LAG = false>
 __global__ __launch_bounds__(64, OCC) void k_sim_step(phc_model_t model_all, phc_sim_params_t prm, phc_sim_state_t sim,
                                                 const float* __restrict__ actions, const float* __restrict__ pd_off,
                                                 const float* __restrict__ pd_scale, const int32_t* __restrict__ freeze,
@@ -147,6 +156,7 @@ __global__ __launch_bounds__(64, OCC) void k_sim_step(phc_model_t model_all, phc
     __shared__ float xch_all[64 * PHC_XCH_STRIDE];   // one exchange slot per lane == body
     __shared__ float cap_all[64 * PHC_CAP_STRIDE];
     __shared__ int pair_all[PHC_SC_MAX_PER_LANE * 64];   // candidate pairs of body-body contact: [pair slot][thread]
+    __shared__ float favg_all[STEP ? 64 * 6 : 1];        // force_average: per-lane sums of S4 / S5 over the sub-steps
     const int lane = threadIdx.x & (GRP - 1);
     const int grp = threadIdx.x / GRP;
     const int64_t slot = (int64_t)blockIdx.x * (64 / GRP) + grp;
@@ -225,10 +235,13 @@ __global__ __launch_bounds__(64, OCC) void k_sim_step(phc_model_t model_all, phc
             // contact_model 1 (rigid): the sub-step's solve is repeated contact_iterations times, each pass with the active set and friction cone the
             // previous one implies (phc_aba.h aba_ground_contact_rigid); the penalty model is the single pass it always was
             const int passes = RIGID ? (prm.contact_iterations < 1 ? 1 : prm.contact_iterations) : 1;
+            // inertia_lag (round 5; penalty contact): the sub-steps behind the first one of a simulate() call keep its articulated inertias and joint-space
+            // inverses and only redo the bias-force recursion (aba_body_init / aba_backward_level, `lag`)
+            const bool lag = LAG && !RIGID && (s % prm.substeps) != 0;
             for (int pass = 0; pass < passes; ++pass) {
             PHC_TL(3)
-            if (active && !PHC_SKIP(1)) aba_body_init<JT, RIGID>(L, model, prm, dt, body, s % prm.substeps == 0, true, pass);
-            if (active && PHC_SKIP(9)) aba_body_init<JT, RIGID>(L, model, prm, dt, body, s % prm.substeps == 0, true, pass);   // (profiling builds: the phase a second time, loads warm -- its pure instruction cost)
+            if (active && !PHC_SKIP(1)) aba_body_init<JT, RIGID>(L, model, prm, dt, body, s % prm.substeps == 0, true, pass, lag);
+            if (active && PHC_SKIP(9)) aba_body_init<JT, RIGID>(L, model, prm, dt, body, s % prm.substeps == 0, true, pass, lag);   // (profiling builds: the phase a second time, loads warm -- its pure instruction cost)
             PHC_PROF(2)
             PHC_TL(4)
             if (JT == PHC_JT_SPHERICAL && rerooted && pass == 0 && !PHC_SKIP(2)) {   // reversed bodies take the drive terms of their solver parent's joint
@@ -239,17 +252,18 @@ __global__ __launch_bounds__(64, OCC) void k_sim_step(phc_model_t model_all, phc
             }
             PHC_PROF(3)
             PHC_TL(5)
-            if (!PHC_SKIP(3)) for (int l = solver_depth; l >= 0; --l) { aba_backward_level<JT>(L, l, body, x); __syncthreads(); PHC_TL(120 + l) }
+            if (!PHC_SKIP(3)) for (int l = solver_depth; l >= 0; --l) { aba_backward_level<JT>(L, l, body, x, lag); __syncthreads(); PHC_TL(120 + l) }
             PHC_PROF(4)
             if (!PHC_SKIP(4)) {
                 for (int l = 0; l <= solver_depth; ++l) { aba_accel_level<JT>(L, l, body, x); __syncthreads(); PHC_TL(140 + l) }
             }
             }
-            if (RIGID && active && s == nsub - 1) aba_publish_contact_rigid(L, model, prm, sim, dt, env, body, true);   // S4 / S6 from the final solve
+            if (RIGID && active && (s == nsub - 1 || prm.force_average)) aba_publish_contact_rigid(L, model, prm, sim, dt, env, body, true);   // S4 / S6 from the final solve
             if (JT == PHC_JT_SPHERICAL && rerooted && !PHC_SKIP(4)) aba_accel_finish(L, model, body, x);
             PHC_PROF(5)
             PHC_TL(6)
             if (!PHC_SKIP(5)) aba_integrate_joint<JT>(L, prm, dt);
+            if (prm.force_average) aba_force_accumulate(L, s, nsub, favg_all + threadIdx.x * 6);   // S4 / S5 as means over the sub-steps of the env step instead of the last one's values
             PHC_PROF(6)
             PHC_TL(7)
             if (!PHC_SKIP(6)) aba_fk_jump_begin(L, body, x);   // kinematics by pointer jumping: jump_steps composition steps instead of max_level + 1 level-steps
@@ -294,9 +308,16 @@ static void sim_launch_cm(const phc_model_t* model, const phc_sim_params_t& prm,
     const int64_t groups = env_ids ? num_listed : sim->num_envs;
     const bool wide = model->num_bodies > 32;   // more bodies than a 32-lane group holds: one env per wavefront
     const bool occ3 = STEP && !RIGID && !SHAPES && JT == PHC_JT_SPHERICAL && !wide && prm.lane_mapping == 3;   // (experiment knob, see k_sim_step)
+    const bool lag = STEP && !RIGID && !SHAPES && prm.inertia_lag != 0;
     if (occ3)
         hipLaunchKernelGGL((k_sim_step<STEP, JT, 32, SHAPES, RIGID, (STEP && !RIGID && !SHAPES && JT == PHC_JT_SPHERICAL) ? 3 : 2>), dim3((groups + 1) / 2), dim3(64), 0, stream,
                            *model, prm, *sim, actions, off, scale, freeze, num_sim_calls, env_ids, num_listed);
+    else if (lag && wide)
+        hipLaunchKernelGGL((k_sim_step<STEP, JT, 64, SHAPES, RIGID, 2, STEP && !RIGID && !SHAPES>), dim3(groups), dim3(64), 0, stream, *model, prm, *sim, actions, off, scale, freeze,
+                           num_sim_calls, env_ids, num_listed);
+    else if (lag)
+        hipLaunchKernelGGL((k_sim_step<STEP, JT, 32, SHAPES, RIGID, 2, STEP && !RIGID && !SHAPES>), dim3((groups + 1) / 2), dim3(64), 0, stream, *model, prm, *sim, actions, off, scale, freeze,
+                           num_sim_calls, env_ids, num_listed);
     else if (wide)
         hipLaunchKernelGGL((k_sim_step<STEP, JT, 64, SHAPES, RIGID>), dim3(groups), dim3(64), 0, stream, *model, prm, *sim, actions, off, scale, freeze,
                            num_sim_calls, env_ids, num_listed);
@@ -352,9 +373,11 @@ int32_t phc_sim_step(const phc_model_t* model, const phc_sim_params_t* params, c
     if (sim->num_envs == 0) return 0;
     // pairs are dealt round-robin to the lanes of an env's group: PHC_SC_MAX_PER_LANE each
     if (params->self_collision && model->num_collision_pairs > PHC_SC_MAX_PER_LANE * (model->num_bodies > 32 ? 64 : 32)) return PHC_EUNSUPPORTED;
-    if (params->lane_mapping != 0 && params->lane_mapping != 1 && params->lane_mapping != 3) return PHC_EUNSUPPORTED;
+    if (params->lane_mapping != 0 && params->lane_mapping != 1 && params->lane_mapping != 3) return PHC_EUNSUPPORTED;   // (2 was the two-bodies-per-lane kernel of rounds 1-2: removed)
     if (params->contact_model != 0 && params->contact_model != 1) return PHC_EUNSUPPORTED;
-    if (params->contact_model == 1 && (params->contact_iterations < 1 || !(params->contact_impedance > 0.f))) return PHC_EINVAL;   // (2 was the two-bodies-per-lane kernel of rounds 1-2: removed)
+    if (params->contact_model == 1 && (params->contact_iterations < 2 || !(params->contact_impedance > 0.f))) return PHC_EINVAL;
+    if (params->contact_model == 1 && params->inertia_lag) return PHC_EUNSUPPORTED;   // (the rigid model re-solves every sub-step contact_iterations times with fresh impedances)
+    if (params->inertia_lag && model->num_shapes > 1 && sim->env_shape != nullptr) return PHC_EUNSUPPORTED;   // (per-env body shapes: the lagged instantiation is not built for them)
     sim_launch<true>(model, *params, sim, actions, pd_action_offset, pd_action_scale, freeze_mask, num_sim_calls, (hipStream_t)stream);
     return launch_status();
 }

@@ -432,7 +432,13 @@ class HumanoidIm:
             contact_model=str(solver.get("contact", "penalty")), contact_iterations=int(solver.get("contact_iterations", physx.get("num_position_iterations", 4))),
             contact_impedance=float(solver.get("contact_impedance", 1.0e5)),
             max_depenetration_velocity=float(physx.get("max_depenetration_velocity", 10.0)),
-            bounce_threshold_velocity=float(physx.get("bounce_threshold_velocity", 0.2)), restitution=float(plane.get("restitution", 0.0)))
+            bounce_threshold_velocity=float(physx.get("bounce_threshold_velocity", 0.2)), restitution=float(plane.get("restitution", 0.0)),
+            # round 5 (ABI 35): `+solver.inertia_lag=1` keeps the articulated inertias of a simulate() call's first sub-step over its other sub-steps;
+            # `+solver.force_average=1` publishes contact_force / dof_force as means over the env step's sub-steps instead of the last one's values
+            inertia_lag=int(bool(solver.get("inertia_lag", 0))), force_average=int(bool(solver.get("force_average", 0))))
+        if self._sim_params.contact_model == 1 and max((int(c) for c in np.bincount(self.model.contact_body, minlength=1)), default=0) > 32:
+            # (the rigid model's per-point active / released sets are 32-bit masks: a point beyond bit 31 could never be released)
+            raise ValueError("solver.contact=tgs supports at most 32 ground-contact points per body; this model has more (use the penalty model)")
 
         # ---- action scaling (A1) + freeze masks (humanoid.py:1331-1409,1549-1554) ----
         self.dof_limits_lower, self.dof_limits_upper = (torch.from_numpy(x).to(dev) for x in self.model.dof_limits())

@@ -251,6 +251,10 @@ def test_robot_settles_on_its_feet(backend, rb, control_mode):
     """0.4 s of holding the reference's default pose (humanoid.py:1121,1181) after a 5 cm drop: the feet carry the weight, no
     chatter, joints quiet (an un-balanced humanoid tips over later -- that is physics, not tested).  Modes: implicit
     position drive and `pd` with the continuous damper (the held-damper variant, mode 1, chatters on the unloaded foot)."""
+    robot_settles_on_its_feet(backend, rb, control_mode)
+
+
+def robot_settles_on_its_feet(backend, rb, control_mode, **extra):
     be = get_backend(backend)
     from phc_amd.robots import ROBOTS
     model, mstruct, keep = model_on(be, f"{rb}_humanoid")
@@ -267,7 +271,7 @@ def test_robot_settles_on_its_feet(backend, rb, control_mode):
     h0 = 1.0 if rb == "h1" else 0.05 - low   # H1: the height the test has always used (a ~5 cm drop as well)
     root[:, 2] = h0
     target = dof[:, :, 0].copy()
-    params = abi.sim_params_struct(sim_dt=1 / 200, substeps=2, control_freq_inv=4, control_mode=control_mode, limit_stiffness=2000.0, limit_damping=20.0)
+    params = abi.sim_params_struct(sim_dt=1 / 200, substeps=2, control_freq_inv=4, control_mode=control_mode, limit_stiffness=2000.0, limit_damping=20.0, **extra)
     a = dict(root=be.arr(root), dof=be.arr(dof), rbs=be.zeros((n, nb, 13)), cf=be.zeros((n, nb, 3)), df=be.zeros((n, nd)), pd=be.arr(target))
     sim = abi.sim_state_struct(n, a["root"], a["dof"], a["rbs"], a["cf"], a["df"], a["pd"])
     fz = []
