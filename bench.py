@@ -38,6 +38,7 @@ HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8
 ABA_BYTES_PER_ENV_SUBSTEP = 1484
 PUBLISH_BYTES_PER_ENV_STEP = 1812
 FLOPS_PER_ENV_SUBSTEP = 40e3   # SURVEY.md 8(d) "algorithmic flops (secondary)"
+FP32_VECTOR_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 (vector)
 
 
 def parse():
@@ -171,22 +172,51 @@ def cpu_baseline(num_envs=4096, budget_s=12.0, max_steps=4000):
                       f"(oracle/hostemu), {dt:.1f} s wall on {best} OpenMP threads (best of {cands}; host reports {os.cpu_count()} cpus)"}
 
 
+_REF_CACHE = {}
+
+
+def reference_timings():
+    """The reference's own CPU stage timings (oracle/time_reference.py).  LIVE on this host when a copy of the reference is importable -- /root/reference in the
+    build container, or the git-ignored travel copy oracle/_ref that oracle/make_ref.py made and that rides along with the gpurun snapshot (the checker
+    being timed as a baseline; nothing of it is in the timed region of the path) -- else the newest committed profiles/*_reference_cpu_stages.json, with
+    `measured_in` saying which.  -> (dict, source string) or (None, None)."""
+    if "v" in _REF_CACHE:
+        return _REF_CACHE["v"]
+    import subprocess
+    res = (None, None)
+    have = os.path.isdir("/root/reference/phc") or os.path.isdir(os.path.join(ROOT, "oracle", "_ref", "phc"))
+    if have and not os.environ.get("PHC_BENCH_NO_LIVE_REFERENCE"):
+        try:
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "time_reference.py"), "--stdout"], capture_output=True, text=True, timeout=420,
+                               env=dict(os.environ, CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES=""))
+            line = next(l for l in r.stdout.splitlines() if l.startswith("REFERENCE_JSON"))
+            res = (json.loads(line[len("REFERENCE_JSON"):]), "live: oracle/time_reference.py --stdout on this host")
+        except Exception as exc:   # noqa: BLE001
+            print(f"[bench] live reference timing failed ({type(exc).__name__}: {exc}); falling back to the committed file", file=sys.stderr)
+    if res[0] is None:
+        files = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_reference_cpu_stages.json"))
+        if files:
+            d = json.load(open(os.path.join(ROOT, "profiles", files[-1])))
+            d["measured_in"] = "NOT this host -- committed file from " + d.get("measured_in", "the build container")
+            res = (d, "profiles/" + files[-1])
+    _REF_CACHE["v"] = res
+    return res
+
+
 def cpu_reference():
     """The REFERENCE'S OWN CPU path (stages C1-C3: motion lookup x2, imitation reward + reset, self / task / AMP
-    observations; C0 load_motions) as measured by oracle/time_reference.py.  The reference is a Python checkout that exists in the build
-    container only, so these numbers are measured there (host stated inside) and shipped as a committed file -- not re-measured on the
-    GPU box.  There is no reference CPU number for C4 (dynamics: closed Isaac Gym binary); `cpu_baseline` (kind "port") covers it."""
-    files = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_reference_cpu_stages.json"))
-    if not files:
+    observations; C0 load_motions) as measured by oracle/time_reference.py -- on THIS host's cores when the reference (or its travel copy) is present,
+    see reference_timings().  There is no reference CPU number for C4 (dynamics: closed Isaac Gym binary); `cpu_baseline` (kind "port") covers it."""
+    d, src = reference_timings()
+    if d is None:
         return None
-    d = json.load(open(os.path.join(ROOT, "profiles", files[-1])))
     st = d["stages"]
     return {"kind": "reference", "what": "phc MotionLibSMPL.get_motion_state x2 + compute_imitation_reward + compute_humanoid_im_reset + "
             "compute_humanoid_observations_smpl_max + compute_imitation_observations_v6 + build_amp_observations_smpl (no dynamics: C4 has no CPU code)",
             "value": st["4096"]["env_steps_per_s_reward_obs_only"], "unit": "env-steps/s", "cores": d["host"]["threads"], "host": d["host"]["model"],
             "stages_ms": {n: {k: v for k, v in st[n].items() if k.endswith("_ms")} for n in st}, "load_motions_ms_per_clip": d["load_motions"]["ms_per_clip"],
             "protocol": d.get("protocol", "5 warm-up + 50 timed iterations, median"), "measured_in": d.get("measured_in", "build container"),
-            "source": "profiles/" + files[-1]}
+            "sample": "50 timed iterations per stage at 64 and 4096 envs (about 10 s of CPU work)", "source": src}
 
 
 def config0_line(dev):
@@ -197,8 +227,8 @@ def config0_line(dev):
     from phc_amd.config import compose
     from phc_amd.env.tasks.vec_task import parse_task
     from phc_amd import _lib as L
-    files = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_reference_cpu_stages.json"))
-    ref = json.load(open(os.path.join(ROOT, "profiles", files[-1]))).get("config0") if files else None
+    d_ref, ref_src = reference_timings()
+    ref = d_ref.get("config0") if d_ref else None
     dev = torch.device(dev)
     di = dev.index if dev.index is not None else torch.cuda.current_device()
     task, env = parse_task(compose(["env.num_envs=64", "env.motion_file=synthetic:1:0", f"device_id={di}", f"rl_device=cuda:{di}"]), device_id=di)
@@ -227,7 +257,7 @@ def config0_line(dev):
            "(launch-latency bound at this size: two launches)"}
     if ref is not None:
         out.update(reference_cpu_ms=ref["fk_plus_reward_ms"], reference_cpu_poselib_fk_ms=ref["poselib_fk_ms"], reference_cpu_env_evaluations_per_s=ref["env_evaluations_per_s"],
-                   reference_source="profiles/" + files[-1] + " (build container, host stated there)")
+                   reference_source=ref_src, reference_measured_in=d_ref.get("measured_in"), reference_cores=d_ref["host"]["threads"])
     return out
 
 
@@ -237,7 +267,8 @@ def other_workloads():
     import subprocess
     env = dict(os.environ, PHC_BENCH_CHILD="1")
     out = {}
-    for name, tail in (("configs1_tracking_actions", ["--actions", "tracking"]), ("configs4_unitree_h1", ["--config", "5"])):
+    for name, tail in (("configs1_tracking_actions", ["--actions", "tracking"]), ("configs4_unitree_h1", ["--config", "5"]),
+                       ("configs1_inertia_lag", ["--solver", "inertia_lag=1"])):   # (round 5: the stepper's `+solver.inertia_lag=1` scheme)
         cmd = [sys.executable, os.path.abspath(__file__), "--steps", "300", "--warmup", "30", "--ppo-epochs", "0", "--no-cpu-baseline", "--no-pmc"] + tail
         try:
             r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
@@ -258,42 +289,47 @@ def other_workloads():
     return out
 
 
-def live_pmc_traffic(argv_tail, kernel_prefixes):
-    """HBM bytes per launch of the dominant kernel from the PMC counters, measured NOW: two child runs of this script under
-    `rocprofv3 --pmc <counter> --kernel-trace` (FETCH_SIZE and WRITE_SIZE in separate passes: TCC slot limit), corrected as
-    MI355X_MICROARCH.md prescribes for gfx950 (read bytes = 2 x FETCH_SIZE KiB; WRITE_SIZE as is; calibration on k_im_post_physics in
-    profiles/pmc_summary.py).  Returns (bytes, detail) or (None, reason)."""
+def live_pmc(argv_tail, counter_groups):
+    """PMC counters per kernel measured NOW: one child run of this script per counter group under `rocprofv3 --pmc <group> --kernel-trace` (never
+    together with another trace domain; FETCH_SIZE and WRITE_SIZE in separate passes: TCC slot limit -- MI355X_MICROARCH.md).
+    -> ({kernel: {counter: (median per dispatch, dispatches)}}, None) or (None, reason)."""
     import csv
     import shutil
     import subprocess
     import tempfile
     if shutil.which("rocprofv3") is None:
         return None, "rocprofv3 not on PATH"
-    vals = {}
+    per = {}
     env = dict(os.environ, PHC_BENCH_CHILD="1", TMPDIR="/tmp")
-    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+    for group in counter_groups:
         d = tempfile.mkdtemp(prefix="phc_pmc_", dir="/tmp")
-        cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "pmc", "--", sys.executable,
+        cmd = ["rocprofv3", "--pmc", *group.split(), "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "pmc", "--", sys.executable,
                os.path.abspath(__file__), "--steps", "20", "--warmup", "5", "--ppo-epochs", "0", "--no-cpu-baseline", "--no-pmc"] + argv_tail
         try:
             r = subprocess.run(cmd, env=env, cwd="/tmp", capture_output=True, text=True, timeout=240)
         except Exception as exc:   # noqa: BLE001
-            return None, f"{counter} pass failed: {type(exc).__name__}"
+            return None, f"{group} pass failed: {type(exc).__name__}"
         path = next((os.path.join(dp, f) for dp, _, fs in os.walk(d) for f in fs if f.endswith("counter_collection.csv")), None)
         if r.returncode != 0 or path is None:
-            return None, f"{counter} pass rc={r.returncode}"
-        per = {}
+            return None, f"{group} pass rc={r.returncode}"
+        vals = {}
         for row in csv.DictReader(open(path)):
-            if row["Counter_Name"] == counter:
-                per.setdefault(row["Kernel_Name"].split("(")[0].replace("void ", ""), []).append(float(row["Counter_Value"]))
-        k = next((k for pre in kernel_prefixes for k in per if k.startswith(pre)), None)
-        if k is None:
-            return None, f"no stepper dispatch in the {counter} pass"
-        v = sorted(per[k])
-        vals[counter] = (k, v[len(v) // 2], len(v))
+            vals.setdefault((row["Kernel_Name"].split("(")[0].replace("void ", ""), row["Counter_Name"]), []).append(float(row["Counter_Value"]))
+        for (k, c), v in vals.items():
+            v = sorted(v)
+            per.setdefault(k, {})[c] = (v[len(v) // 2], len(v))   # median: the first dispatches (everything reset at once) are not the steady state
         shutil.rmtree(d, ignore_errors=True)
-    rd, wr = 2.0 * vals["FETCH_SIZE"][1] * 1024.0, vals["WRITE_SIZE"][1] * 1024.0
-    return rd + wr, {"kernel": vals["FETCH_SIZE"][0], "read_bytes": rd, "write_bytes": wr, "dispatches": vals["FETCH_SIZE"][2],
+    return per, None
+
+
+def pmc_traffic_of(per, prefix):
+    """HBM bytes per launch of the kernel whose name starts with `prefix`, corrected as MI355X_MICROARCH.md prescribes for gfx950 (read bytes =
+    2 x FETCH_SIZE KiB, WRITE_SIZE KiB as is; calibrated on k_im_post_physics in profiles/pmc_summary.py) -> (bytes, detail) or (None, reason)."""
+    k = next((k for k in per if k.startswith(prefix) and "FETCH_SIZE" in per[k] and "WRITE_SIZE" in per[k]), None)
+    if k is None:
+        return None, f"no {prefix} dispatch in the FETCH_SIZE / WRITE_SIZE passes"
+    rd, wr = 2.0 * per[k]["FETCH_SIZE"][0] * 1024.0, per[k]["WRITE_SIZE"][0] * 1024.0
+    return rd + wr, {"kernel": k, "read_bytes": rd, "write_bytes": wr, "dispatches": per[k]["FETCH_SIZE"][1],
                      "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, --kernel-trace), median per dispatch; gfx950: read = 2 x FETCH_SIZE"}
 
 
@@ -422,7 +458,7 @@ def main():
 
     inv_scale = 1.0 / task._pd_action_scale
 
-    def env_step(ev=None):
+    def env_step(ev=None, ev_post=None):
         task.reset_done()                 # envs that finished on the previous step (device-side mask, no host sync)
         if args.actions == "random":
             a = actions
@@ -436,7 +472,11 @@ def main():
         task._physics_step()
         if ev is not None:
             ev[1].record()
+        if ev_post is not None:
+            ev_post[0].record()
         task.post_physics_step()
+        if ev_post is not None:
+            ev_post[1].record()
 
     # The SURVEY protocol is a STEADY state (fixed random actions, ~98 % of the envs within 5 steps of a reset, resets spread over the steps).  Right
     # after env.reset() all envs are in lockstep -- they fall, and are reset, in the same few steps -- so a short run (the driver's K = 20, W = 5)
@@ -450,12 +490,13 @@ def main():
     # average launch duration does not need all of them)
     EVENT_STRIDE = 4
     events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if k % EVENT_STRIDE == 0 else None for k in range(args.steps)]
+    events_post = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if k % EVENT_STRIDE == 2 else None for k in range(args.steps)]   # (the post-physics launch, on other steps)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        env_step(events[k])
+        env_step(events[k], events_post[k])
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -469,6 +510,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kern_ms = float(np.mean([ev[0].elapsed_time(ev[1]) for ev in events if ev is not None]))  # torch's current stream == the launch stream
+    post_ms = float(np.mean([ev[0].elapsed_time(ev[1]) for ev in events_post if ev is not None])) if any(e is not None for e in events_post) else None
     resets = float((task.progress_buf < 5).float().mean().item())
 
     ppo = None
@@ -488,13 +530,26 @@ def main():
         assert args.robot != "smpl" or (aba_bytes, pub_bytes) == (ABA_BYTES_PER_ENV_SUBSTEP, PUBLISH_BYTES_PER_ENV_STEP)
         bytes_per_launch = (aba_bytes * nsub + pub_bytes) * N
         traffic, traffic_src = None, None  # HBM bytes per launch of the stepper from the PMC counters
+        per, post_traffic, post_src, sq = None, None, None, None
         if world == 1 and not args.no_pmc and not os.environ.get("PHC_BENCH_CHILD"):
             tail = ["--envs", str(args.envs), "--robot", args.robot, "--lane-mapping", str(args.lane_mapping), "--actions", args.actions,
                     "--motion-clips", str(args.motion_clips), "--self-collision", str(args.self_collision)] + [x for kv in args.solver for x in ("--solver", kv)]
-            traffic, detail = live_pmc_traffic(tail, ("k_sim_step<true",))
-            traffic_src = {"live": detail} if traffic is not None else None
-            if traffic is None:
-                print(f"[bench] live PMC traffic unavailable ({detail}); falling back to the committed profile", file=sys.stderr)
+            # four child passes: HBM read / write traffic (all kernels), then the SQ counters behind the VALU roofline of the stepper
+            per, why = live_pmc(tail, ["FETCH_SIZE", "WRITE_SIZE", "SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU"])
+            if per is None:
+                print(f"[bench] live PMC counters unavailable ({why}); falling back to the committed profile", file=sys.stderr)
+            else:
+                traffic, detail = pmc_traffic_of(per, "k_sim_step<true")
+                traffic_src = {"live": detail} if traffic is not None else None
+                post_traffic, post_src = pmc_traffic_of(per, "k_im_post_physics")
+                k = next((k for k in per if k.startswith("k_sim_step<true") and "SQ_INSTS_VALU" in per[k]), None)
+                if k is not None:
+                    c = {n: v[0] for n, v in per[k].items()}
+                    sq = {"valu_instructions_per_wavefront": c["SQ_INSTS_VALU"] / max(c.get("SQ_WAVES", 0.0), 1.0),
+                          "valu_active_share_of_wavefront_cycles": c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"] if c.get("SQ_WAVE_CYCLES") else None,
+                          "active_lane_share": c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"]) if c.get("SQ_THREAD_CYCLES_VALU") and c.get("SQ_ACTIVE_INST_VALU") else None,
+                          "method": "rocprofv3 --pmc (SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU | SQ_THREAD_CYCLES_VALU, separate passes, --kernel-trace), "
+                                    "median per dispatch of " + k}
         pmc = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json"))
         if traffic is None and pmc and N == 4096 and args.robot == "smpl":
             tab = json.load(open(os.path.join(ROOT, "profiles", pmc[-1])))
@@ -502,6 +557,8 @@ def main():
             if rec:
                 traffic, traffic_src = rec["traffic_bytes"], "profiles/" + pmc[-1]
         achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
+        tflops = FLOPS_PER_ENV_SUBSTEP * nsub * N / (kern_ms * 1e-3) / 1e12
+        kname = traffic_src["live"]["kernel"] if isinstance(traffic_src, dict) else "k_sim_step (one body per lane)"
         out = {
             "metric": "env-steps/sec at 4096 humanoid envs per GPU (VecEnv.step incl. resets)",
             "value": N * world * args.steps / elapsed, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -515,19 +572,33 @@ def main():
                        "envs_per_gpu": N, "num_bodies": task.num_bodies,
                        "obs": task.num_obs, "amp_obs": task.get_num_amp_obs(), "parallelism": f"env-sharded x{world}",
                        "self_collision": bool(task._sim_params.self_collision)},
-            "roofline": {"kernel": "phc_sim_step -> %s (A2 + %d ABA sub-steps + S7 publication)" % (
-                             (traffic_src["live"]["kernel"] if isinstance(traffic_src, dict) else "k_sim_step (one body per lane)"), nsub),
-                         "bound": "hbm", "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+            # The dominant kernel is the stepper, and what bounds it is the fp32 VECTOR pipe seen through one wavefront's serial instruction stream -- not HBM
+            # (PMC traffic = 1.2 x the fused launch's compulsory bytes).  `roofline` therefore prices it against the fp32 vector peak; the HBM accounting of
+            # SURVEY 8(d) (the north star's "fraction of HBM roofline") is kept in full under `roofline.hbm`.
+            "roofline": {"kernel": "phc_sim_step -> %s (A2 + %d ABA sub-steps + S7 publication)" % (kname, nsub),
+                         "bound": "valu", "achieved": tflops, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / FP32_VECTOR_PEAK_TFLOPS,
+                         "algorithmic_flops_per_launch": FLOPS_PER_ENV_SUBSTEP * nsub * N,
+                         "traffic": traffic, "traffic_source": traffic_src,
                          "kernel_ms": kern_ms, "kernel_ms_method": "HIP events around the launch of every %d-th of the %d timed steps, launch stream" % (EVENT_STRIDE, args.steps),
-                         "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "note": "SURVEY 8(d) canonical un-fused accounting (1484 B x 4 sub-steps + 1812 B per env; the fused launch's compulsory "
-                                 "traffic is 3296 B/env).  The kernel is NOT HBM-bound: at 4096 envs all 2048 wavefronts run concurrently and the launch "
-                                 "lasts as long as ONE wavefront's serial stream (15.9 k VALU instructions at a per-wavefront issue interval of ~4.4 "
-                                 "cycles + LDS / scalar / waits); the SIMDs' fp32 pipes are ~41 % busy (profiles/r03_stepper/README.md, "
-                                 "profiles/microbench/valu_issue_mi355x.txt, profiles/r03_pmc_valu.txt)",
-                         "gflops": FLOPS_PER_ENV_SUBSTEP * nsub * N / (kern_ms * 1e-3) / 1e9},
+                         "sq_counters": sq,
+                         "hbm": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                                 "algorithmic_bytes_per_launch": bytes_per_launch, "compulsory_bytes_per_launch_fused": (aba_bytes + pub_bytes) * N,
+                                 "note": "SURVEY 8(d) canonical un-fused accounting: %d B x %d sub-steps + %d B per env; the fused launch reads the state once and "
+                                         "writes it once (compulsory %d B/env)" % (aba_bytes, nsub, pub_bytes, aba_bytes + pub_bytes)},
+                         "note": "SURVEY 8(d): 40 kflop per env and sub-step against the fp32 vector peak (MI355X_MICROARCH.md: 157.3 TFLOP/s).  At 4096 envs all 2048 "
+                                 "wavefronts are resident at once (two per SIMD) and the launch lasts as long as ONE wavefront's serial stream: ~15.5 k VALU "
+                                 "instructions at a per-wavefront issue interval of ~4.4 cycles + LDS / scalar / waits; one lane per body leaves `active_lane_share` "
+                                 "of the lanes working during the level-synchronous tree sweeps (profiles/r03_stepper/README.md, profiles/microbench/valu_issue_mi355x.txt)"},
         }
+        if post_ms is not None:
+            # the HBM-bound kernel of the env step: bytes per env as DESIGN.md section 4 counts them (7 774 read + 6 522 written for the SMPL task)
+            post_bytes = 14296 * N if (args.robot == "smpl" and task.num_obs == 934) else None
+            out["roofline_post_physics"] = {"kernel": "phc_im_post_physics -> k_im_post_physics (reference lookups x2, reward, reset test, observations, AMP frame)",
+                                            "bound": "hbm", "achieved": (post_bytes / (post_ms * 1e-3) / 1e9) if post_bytes else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                            "frac": (post_bytes / (post_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if post_bytes else None, "traffic": post_traffic,
+                                            "traffic_source": {"live": post_src} if post_traffic is not None else None, "kernel_ms": post_ms,
+                                            "kernel_ms_method": "HIP events around phc_im_post_physics on every %d-th timed step (steps the stepper events skip)" % EVENT_STRIDE,
+                                            "algorithmic_bytes_per_launch": post_bytes}
         if ppo is not None:
             out.update(ppo)
         if world == 1 and not args.no_cpu_baseline and args.robot == "smpl":

@@ -25,7 +25,15 @@ import sys
 import types
 from unittest.mock import MagicMock
 
-REFERENCE_ROOT = os.environ.get("PHC_REFERENCE_ROOT", "/root/reference")
+# /root/reference in the build container; on the GPU box the travel copy `oracle/_ref` that oracle/make_ref.py made (git-ignored, rides along with the
+# gpurun snapshot like a built .so): only the files oracle/time_reference.py and tests/test_reference_direct_gpu.py import
+_TRAVEL_COPY = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref")
+REFERENCE_ROOT = os.environ.get("PHC_REFERENCE_ROOT") or ("/root/reference" if os.path.isdir("/root/reference/phc") else _TRAVEL_COPY)
+
+
+def available():
+    """Is some copy of the reference importable here?"""
+    return os.path.isdir(os.path.join(REFERENCE_ROOT, "phc"))
 
 _MOCK_TOPLEVEL = (
     "isaacgym", "smpl_sim", "smplx", "open3d", "imageio", "aiohttp", "cv2", "gym",
@@ -90,7 +98,7 @@ def install():
     if _installed:
         return
     if not os.path.isdir(REFERENCE_ROOT):
-        raise RuntimeError(f"reference not found at {REFERENCE_ROOT}; the shim only works in the build container")
+        raise RuntimeError(f"reference not found at {REFERENCE_ROOT}; the shim needs /root/reference (build container) or the travel copy oracle/_ref (oracle/make_ref.py)")
     import numpy as np
     import torch
 

@@ -1,9 +1,11 @@
 """TEST INFRASTRUCTURE ONLY -- time the *reference's own* CPU reward / FK / observation path (SURVEY.md 8d "CPU baseline
 beside it"): the unmodified reference functions imported through ``oracle/ref_shim.py``, on the host cores of the machine
-this runs on.  /root/reference does not exist on the GPU box, so this runs in the build container only:
+this runs on.  /root/reference does not exist on the GPU box; since round 5 a git-ignored travel copy of exactly the imported reference files
+(`oracle/_ref`, made by oracle/make_ref.py in the build container) rides along with the gpurun snapshot, so bench.py's `cpu_reference` / `config0`
+legs run this script LIVE on the GPU box's host cores (`--stdout`); without either copy bench.py falls back to the newest committed file:
 
-    python oracle/time_reference.py [rNN]      # -> profiles/rNN_reference_cpu_stages.json (default r02); bench.py ships the newest
-                                               #    of these files as the `cpu_reference` object of its JSON line
+    python oracle/time_reference.py [rNN]      # -> profiles/rNN_reference_cpu_stages.json (default r05)
+    python oracle/time_reference.py --stdout   # one line `REFERENCE_JSON{...}` on stdout (bench.py)
 
 Stages (5 warm-up + 50 timed iterations, median), at N = 64 and N = 4096 on the synthetic AMASS-shaped clips:
   (1) MotionLibSMPL.load_motions (poselib FK + finite differences; start-up cost, timed once for 64 clips)
@@ -52,6 +54,13 @@ def median_ms(fn, warm=5, it=50):
 
 def main():
     threads = len(os.sched_getaffinity(0))
+    try:   # container CPU quota (cgroup v2), which sched_getaffinity does not show: 256 torch threads on a 16-core quota would time the scheduler
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            threads = max(1, min(threads, int(float(q) / float(per) + 0.5)))
+    except Exception:
+        pass
+    threads = int(os.environ.get("PHC_REFERENCE_THREADS", threads))
     torch.set_num_threads(threads)
     him = ref_shim.ref_module("phc.env.tasks.humanoid_im")
     hum = ref_shim.ref_module("phc.env.tasks.humanoid")
@@ -151,8 +160,15 @@ def main():
                       "fk_plus_reward_ms": both_ms, "env_evaluations_per_s": 64 / (both_ms * 1e-3)}
     out["date"] = time.strftime("%Y-%m-%d")
     out["protocol"] = "BASELINE.md section 2: 5 warm-up + 50 timed iterations, median; torch.set_num_threads(all usable cores); fp32"
-    out["measured_in"] = "build container (the reference is a Python checkout under /root/reference and cannot travel to the GPU box)"
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+    import socket
+    travel = os.path.realpath(ref_shim.REFERENCE_ROOT) == os.path.realpath(os.path.join(HERE, "_ref"))
+    out["measured_in"] = (f"this host ({socket.gethostname()}): the reference's modules from " +
+                          ("the travel copy oracle/_ref (oracle/make_ref.py)" if travel else ref_shim.REFERENCE_ROOT + " (build container)"))
+    out["has_gpu"] = bool(torch.cuda.is_available())
+    if "--stdout" in sys.argv:      # bench.py's live `cpu_reference` leg: one JSON line, nothing written
+        print("REFERENCE_JSON" + json.dumps(out))
+        return
+    tag = next((a for a in sys.argv[1:] if not a.startswith("--")), "r05")
     dst = os.path.join(ROOT, "profiles", f"{tag}_reference_cpu_stages.json")
     json.dump(out, open(dst, "w"), indent=1)
     print(json.dumps(out, indent=1))
