@@ -453,7 +453,7 @@ def main():
         cfg3 = {"library_clips": int(lib_._num_unique_motions), "distinct_clips_sampled": int(torch.unique(lib_._curr_motion_ids).numel()),
                 "task_build_s_incl_synthetic_library_and_first_load": t_build, "resample_motions_s": time.perf_counter() - t0,
                 "motion_frames": int(lib_.frames.shape[0]), "motion_bytes_on_device": int(lib_.frames.numel() * 4),
-                "host_workers": int(lib_.m_cfg.get("num_workers", 0)) or min(32, max(1, (os.cpu_count() or 1) // 2))}
+                "host_workers": int(lib_.m_cfg.get("num_workers", 0)) or __import__("phc_amd.motion_lib", fromlist=["x"]).default_pool_workers()}
     actions = (torch.rand(N, task.num_actions, device=dev) * 2 - 1) * 0.1  # fixed a ~ U(-1,1)*0.1
 
     inv_scale = 1.0 / task._pd_action_scale

@@ -700,6 +700,12 @@ class HumanoidIm:
             # "armswing[:seconds]" -- standing with swinging arms (the second feasible sanity clip)
             from ...utils.synthetic_motion import make_armswing_clip
             mf = {"armswing_00000": make_armswing_clip(self.model, float(mf.split(":")[1]) if ":" in mf else 10.0)}
+        if isinstance(mf, str) and mf.startswith("locomotion") and not self._is_robot:
+            # "locomotion[:num_clips[:seed[:seconds]]]" -- a multi-clip set of feasible stand / arm-swing / step-in-place / walk (/ squat) clips (round 5)
+            from ...utils.synthetic_motion import make_locomotion_library
+            parts = mf.split(":")
+            mf = make_locomotion_library(self.model, int(parts[1]) if len(parts) > 1 else 64, int(parts[2]) if len(parts) > 2 else 0,
+                                         float(parts[3]) if len(parts) > 3 else 8.0)
         if isinstance(mf, str) and mf.startswith("synthetic"):
             # "synthetic[:num_clips[:seed[:mean_seconds]]]" -- AMASS-shaped smooth random clips
             parts = mf.split(":")
@@ -975,7 +981,10 @@ class HumanoidIm:
         frames change (re-sampled motions), re-attached when the parameter struct was rebuilt."""
         lib = self._motion_lib
         frames = lib.frames
-        key = (getattr(lib, "frames_epoch", 0), frames.data_ptr(), tuple(frames.shape), frames._version)
+        # (ADVICE r4) the table is built from THIS task's model and parameter struct and the decision below reads the evaluation flags: all of them are part
+        # of the key, so a library shared by two tasks, parameters rebuilt after a flag flip, or flags toggled without a reload never get a stale table
+        key = (getattr(lib, "frames_epoch", 0), frames.data_ptr(), tuple(frames.shape), frames._version, id(self), self._im_params_gen,
+               bool(flags.im_eval), bool(flags.test))
         c = lib.__dict__.get("_amp_ref_cache")    # kept ON the library object: the train library keeps its table across an evaluation sweep
         if c is None or c[0] != key:
             table = None

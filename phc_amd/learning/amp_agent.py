@@ -30,6 +30,7 @@ MI355X-first differences (results-preserving):
 """
 import copy
 import os
+import sys
 import time
 import warnings
 
@@ -97,6 +98,21 @@ class _marker:
 
 # K-padded weights are strided views with strided gradients of the SAME layout: autograd's "gradient layout contract" note does not apply
 warnings.filterwarnings("ignore", message="grad and param do not obey the gradient layout contract")
+
+
+VERIFIED_GRAPH_STACKS = (("2.10", "7."),)   # (torch.__version__ prefix, torch.version.hip prefix)
+_graph_default_warned = [False]
+
+
+def graph_default_on():
+    """Is the captured (hipGraph) update the default on this software stack?  See IMAmpAgent.__init__."""
+    hip = getattr(torch.version, "hip", None) or ""
+    ok = any(torch.__version__.startswith(a) and hip.startswith(b) for a, b in VERIFIED_GRAPH_STACKS)
+    if not ok and torch.cuda.is_available() and not _graph_default_warned[0]:
+        _graph_default_warned[0] = True
+        print(f"[phc_amd] torch {torch.__version__} / HIP {hip or None} is not a stack the captured update has been verified on: hipGraphs are OFF by default "
+              f"(eager launches); +learning.params.config.hip_graph=True turns them on", file=sys.stderr)
+    return ok
 
 
 class FlatGradBucket:
@@ -295,7 +311,11 @@ class IMAmpAgent:
         # created on; the captured backward then has to hand the gradient to a stream that is not capturing and `hipStreamEndCapture` segfaults on
         # ROCm 7.2 instead of raising -- `_stale_grad_accumulators()` detects exactly that before capturing and the update falls back to eager
         # launches, as it does when a capture raises or the minibatch is small (< 2048 rows: not launch-bound).
-        self._use_graph = bool(c.get("hip_graph", True))
+        # the known failure mode of a bad capture on this stack is a crash, not an exception, so the DEFAULT is on only for the (torch, HIP)
+        # pairs the -m gpu suite has run the captured update on (VERIFIED_GRAPH_STACKS: tests/test_env_gpu.py::test_update_graph_equals_eager_launches,
+        # ::test_captured_update_trains_the_other_network_and_observation_variants incl. PNN / im_big / im_pnn_big); an explicit
+        # `learning.params.config.hip_graph=True|False` always wins, `PHC_NO_GRAPH=1` / `PHC_NO_BRANCH_STREAMS=1` switch off at run time
+        self._use_graph = bool(c["hip_graph"]) if "hip_graph" in c else graph_default_on()
         # The discriminator's share of an optimizer step (three input normalisers, forward, loss terms, the gradient penalty's double backward,
         # backward) shares nothing with actor + critic but the optimizer launches at the end: two chains of ~256-workgroup GEMMs and 5 us
         # finishing launches.  On the device the discriminator pass runs on its own HIP stream (_fwd_bwd); captured, it is its OWN linear

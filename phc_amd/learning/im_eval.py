@@ -137,6 +137,8 @@ def evaluate(agent, output_dir=None, log=print):
         mean_of = lambda k, sel: float(per_clip[k][sel & (have[k] > 0.5)].mean()) if (sel & (have[k] > 0.5)).any() else float("nan")
         m_all = {k: mean_of(k, np.ones(U, dtype=bool)) for k in METRICS}
         m_succ = {k: mean_of(k, ~term) for k in METRICS} if ((~term) & (have["mpjpe_g"] > 0.5)).any() else m_all   # "No success!!!" (im_amp.py:330-332)
+        # per-clip table of the last sweep (scripts / the player's report: which clips fail, how closely each one is tracked)
+        agent.last_eval_per_clip = {"keys": [str(k) for k in keys], "failed": term.copy(), **{k: np.where(have[k] > 0.5, per_clip[k], np.nan) for k in METRICS}}
         eval_info = {"eval/success_rate": float(1 - term.mean()), "eval/mpjpe_all": m_all["mpjpe_g"], "eval/mpjpe_succ": m_succ["mpjpe_g"],
                      "eval/accel_dist": m_succ["accel_dist"], "eval/vel_dist": m_succ["vel_dist"], "eval/mpjpel_all": m_all["mpjpe_l"],
                      "eval/mpjpel_succ": m_succ["mpjpe_l"], "eval/mpjpe_pa": m_succ["mpjpe_pa"]}

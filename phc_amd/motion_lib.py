@@ -244,33 +244,82 @@ def _run_clip_job(payload, consts=None):
 
 
 _POOL = {}
+_POOL_STATE = {"atexit": False, "timer": None, "lock": None, "busy": 0}
+
+
+def default_pool_workers():
+    """Clip workers per process: half the usable cores, shared between the ranks of this node (8 ranks of an 8-GPU launch must not start 8 x 32
+    workers), at most 32."""
+    cpus = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")) or 1))
+    return max(1, min(32, cpus // (2 * local_world)))
 
 
 def _clip_pool(workers):
-    """The process pool behind load_motions, created on first use and kept for the life of the process (a `resample_motions()` every few hundred
-    epochs re-uses it).  Context: forkserver (see above); `PHC_MOTION_POOL_CONTEXT=spawn` selects spawn."""
+    """The process pool behind load_motions: created on first use, re-used by calls that follow closely (load + the first `resample_motions()`,
+    evaluation libraries), and shut down after `PHC_MOTION_POOL_IDLE_S` (default 60) seconds without work -- a `resample_motions()` comes every few
+    hundred epochs; up to 32 idle torch-importing processes per rank for the whole training in between were pure cost.  The next
+    call simply starts a new pool (the forkserver itself stays: a worker start is a fork of the preloaded server, ~10 ms each).
+    Context: forkserver (see above); `PHC_MOTION_POOL_CONTEXT=spawn` selects spawn."""
     import multiprocessing as mp
-    key = (os.getpid(), workers)
-    if key not in _POOL:
-        for k in list(_POOL):            # (a pool inherited through somebody else's fork belongs to the parent)
+    import threading
+    if _POOL_STATE["lock"] is None:
+        _POOL_STATE["lock"] = threading.Lock()
+    with _POOL_STATE["lock"]:
+        _POOL_STATE["busy"] += 1          # (the idle timer's shutdown leaves a pool alone while a call is using it; _arm_idle_shutdown() ends the use)
+        if _POOL_STATE["timer"] is not None:
+            _POOL_STATE["timer"].cancel()
+        key = (os.getpid(), workers)
+        if key not in _POOL:
+            for k in list(_POOL):            # (a pool inherited through somebody else's fork belongs to the parent)
+                if k[0] == os.getpid():
+                    _POOL.pop(k).terminate()
+                else:
+                    _POOL.pop(k)
+            ctx = mp.get_context(os.environ.get("PHC_MOTION_POOL_CONTEXT", "forkserver"))
+            if ctx.get_start_method() == "forkserver":
+                # numpy / torch / this module are imported once, in the server.  (Ignored by multiprocessing if the host application has started a
+                # forkserver already: the workers then import them themselves -- slower to start, same results.)
+                ctx.set_forkserver_preload(["phc_amd.motion_lib"])
+            _POOL[key] = ctx.Pool(workers)
+            if not _POOL_STATE["atexit"]:
+                import atexit
+                atexit.register(_close_pools)
+                _POOL_STATE["atexit"] = True
+        return _POOL[key]
+
+
+def _arm_idle_shutdown():
+    """End of a pooled call: (re)start the idle timer."""
+    import threading
+    idle = float(os.environ.get("PHC_MOTION_POOL_IDLE_S", "60"))
+    with _POOL_STATE["lock"]:
+        _POOL_STATE["busy"] = max(0, _POOL_STATE["busy"] - 1)
+        t = _POOL_STATE["timer"]
+        if t is not None:
+            t.cancel()
+        if idle <= 0:
+            return
+        t = threading.Timer(idle, _close_pools, kwargs={"only_if_idle": True})
+        t.daemon = True
+        t.start()
+        _POOL_STATE["timer"] = t
+
+
+def _close_pools(only_if_idle=False):
+    lock = _POOL_STATE["lock"]
+    if lock is not None:
+        lock.acquire()
+    try:
+        if only_if_idle and _POOL_STATE["busy"] > 0:
+            return
+        for k in list(_POOL):
+            pool = _POOL.pop(k)
             if k[0] == os.getpid():
-                _POOL.pop(k).terminate()
-            else:
-                _POOL.pop(k)
-        ctx = mp.get_context(os.environ.get("PHC_MOTION_POOL_CONTEXT", "forkserver"))
-        if ctx.get_start_method() == "forkserver":
-            ctx.set_forkserver_preload(["phc_amd.motion_lib"])   # numpy / torch / this module are imported once, in the server
-        _POOL[key] = ctx.Pool(workers)
-        import atexit
-        atexit.register(_close_pools)
-    return _POOL[key]
-
-
-def _close_pools():
-    for k in list(_POOL):
-        pool = _POOL.pop(k)
-        if k[0] == os.getpid():
-            pool.terminate()
+                pool.terminate()
+    finally:
+        if lock is not None:
+            lock.release()
 
 
 def _run_clip_chunk(args):
@@ -373,12 +422,15 @@ class MotionLibBase:
         # ~5 800 distinct clips of the 11 313 for 8 192 envs, 17 ms each)
         consts = self._clip_consts(trees)
         jobs = [self._clip_payload(self._motion_data_list[u], t, max_len, crop[u]) for u, t in uniq]
-        workers = int(self.m_cfg.get("num_workers", 0)) or min(32, max(1, (os.cpu_count() or 1) // 2))
+        workers = int(self.m_cfg.get("num_workers", 0)) or default_pool_workers()
         if len(jobs) >= int(self.m_cfg.get("pool_min_jobs", 256)) and workers > 1:
             # chunks of jobs, each carrying the (small) constants: no per-worker state to set up or to go stale between calls
             per = max(1, -(-len(jobs) // (workers * 8)))
             chunks = [(consts, jobs[i:i + per]) for i in range(0, len(jobs), per)]
-            done = [r for part in _clip_pool(workers).map(_run_clip_chunk, chunks, chunksize=1) for r in part]
+            try:
+                done = [r for part in _clip_pool(workers).map(_run_clip_chunk, chunks, chunksize=1) for r in part]
+            finally:
+                _arm_idle_shutdown()
         else:
             done = [_run_clip_job(j, consts) for j in jobs]
         slot = {ut: k for k, ut in enumerate(uniq)}

@@ -256,9 +256,11 @@ def _leg_ik(model, side, pelvis, ankle_target, lateral_tilt):
     return e
 
 
-def make_gait_clip(model, kind, seconds=10.0, fps=30):
+def make_gait_clip(model, kind, seconds=10.0, fps=30, speed=None, period=None, lift=None, sway=None, arm=None, heading=0.0, depth=None):
     """`squat`, `stepinplace` or `walk` for the SMPL humanoid (facing +x, z up).  The first second ramps out of the rest pose (the reset
-    imposes a clip frame; the evaluation starts every clip at t = 0)."""
+    imposes a clip frame; the evaluation starts every clip at t = 0).  Round 5: the gait's parameters can be given -- walking `speed` (m/s), cycle
+    `period` (s, two steps), foot `lift` (m), lateral `sway` (m), `arm` swing factor, squat `depth` (m) -- and the whole clip turned by `heading`
+    (rad about +z): the members of `make_locomotion_library`."""
     assert kind in ("squat", "stepinplace", "walk")
     T, J = int(round(seconds * fps)) + 1, model.num_bodies
     names = list(model.body_names)
@@ -276,8 +278,9 @@ def make_gait_clip(model, kind, seconds=10.0, fps=30):
     tilt = np.zeros(T)
     e = np.zeros((T, J, 3))
     if kind == "squat":
-        period = 2.5
-        pelvis[:, 2] -= 0.20 * ramp * 0.5 * (1 - np.cos(2 * np.pi * np.clip(t - 1.0, 0, None) / period))
+        period = 2.5 if period is None else float(period)
+        depth = 0.20 if depth is None else float(depth)
+        pelvis[:, 2] -= depth * ramp * 0.5 * (1 - np.cos(2 * np.pi * np.clip(t - 1.0, 0, None) / period))
         lean = (h0 - drop - pelvis[:, 2]) / 0.20
         e[:, names.index("Torso"), 1] = 0.20 * lean
         e[:, names.index("Spine"), 1] = 0.15 * lean
@@ -285,9 +288,9 @@ def make_gait_clip(model, kind, seconds=10.0, fps=30):
             e[:, names.index(f"{s}_Shoulder"), 0] = -sg * 0.9 * ramp
             e[:, names.index(f"{s}_Shoulder"), 1] = -0.5 * lean
     else:
-        period = 1.2 if kind == "stepinplace" else 1.0       # one gait cycle = two steps
-        speed = 0.0 if kind == "stepinplace" else 0.7
-        lift = 0.10 if kind == "stepinplace" else 0.07
+        period = (1.2 if kind == "stepinplace" else 1.0) if period is None else float(period)       # one gait cycle = two steps
+        speed = 0.0 if kind == "stepinplace" else (0.7 if speed is None else float(speed))
+        lift = (0.10 if kind == "stepinplace" else 0.07) if lift is None else float(lift)
         ph = np.clip(t - 1.0, 0, None) / period               # gait phase in cycles, 0 during the ramp
         go = (t >= 1.0).astype(float)
         def pelvis_x(tt):   # the speed ramps up over the first second of the gait
@@ -295,7 +298,7 @@ def make_gait_clip(model, kind, seconds=10.0, fps=30):
             tr = np.clip(tau, 0, 1)
             return speed * np.where(tau < 1, tr ** 3 - 0.5 * tr ** 4, 0.5 + (tau - 1))
         pelvis[:, 0] = pelvis_x(t)
-        sway = 0.045 if kind == "stepinplace" else 0.025
+        sway = (0.045 if kind == "stepinplace" else 0.025) if sway is None else float(sway)
         for s, off in (("L", 0.0), ("R", 0.5)):               # the left foot swings in the first half of a cycle, the right one in the second
             c = ph + off
             k = np.floor(c)
@@ -315,13 +318,18 @@ def make_gait_clip(model, kind, seconds=10.0, fps=30):
         for s, sg in (("L", 1.0), ("R", -1.0)):
             sh = names.index(f"{s}_Shoulder")
             e[:, sh, 0] = -sg * 1.0 * ramp
-            e[:, sh, 1] = sg * 0.25 * np.sin(2 * np.pi * ph) * go * (1.0 if kind == "walk" else 0.4)
+            e[:, sh, 1] = sg * 0.25 * np.sin(2 * np.pi * ph) * go * ((1.0 if kind == "walk" else 0.4) if arm is None else float(arm))
             e[:, names.index(f"{s}_Elbow"), 2] = sg * 0.3 * ramp
     for s in "LR":
         target = foot[s].copy()
         for j, v in _leg_ik(model, s, pelvis, target, tilt).items():
             e[:, j] = v
     q_local = _exp_map_to_quat(e)
+    if heading != 0.0:      # the whole clip turned about +z: root rotation and root path
+        yq = np.array([0.0, 0.0, np.sin(0.5 * heading), np.cos(0.5 * heading)])
+        q_local[:, 0] = _quat_mul(np.broadcast_to(yq, (T, 4)), q_local[:, 0])
+        c, s_h = np.cos(heading), np.sin(heading)
+        pelvis = np.stack([c * pelvis[:, 0] - s_h * pelvis[:, 1], s_h * pelvis[:, 0] + c * pelvis[:, 1], pelvis[:, 2]], -1)
     qg, org = _fk(model, q_local, pelvis)
     trans = pelvis.copy()
     trans[:, 2] += 0.002 - _lowest_point(model, qg, org)       # the lowest sole corner on the ground in every frame
@@ -331,3 +339,36 @@ def make_gait_clip(model, kind, seconds=10.0, fps=30):
     aa = q_local[..., :3] / s_[..., None] * (ang * np.sign(w + 1e-30))[..., None]
     return {"pose_quat_global": qg, "pose_quat": q_local, "root_trans_offset": trans, "trans_orig": trans.copy(),
             "pose_aa": aa.reshape(T, J * 3), "beta": np.zeros(10), "gender": "neutral", "fps": fps}
+
+
+def make_locomotion_library(model, num_clips=64, seed=0, seconds=8.0, fps=30, with_squats=True):
+    """A small multi-clip motion set of physically feasible clips for policy-level acceptance runs (round 5): standing, standing with swinging arms,
+    stepping in place and walking at 0.3 .. 0.9 m/s with different cadences, foot lifts, arm swings and headings -- the members are `make_stand_clip`,
+    `make_armswing_clip` and parametrised `make_gait_clip`s, drawn with a seeded generator.  Keys sort by kind.  `with_squats`: two squat clips (the
+    class no policy of rounds 3-4 learned) ride along at the end."""
+    rng = np.random.default_rng(seed)
+    out = {}
+    n_stand, n_arm = max(1, num_clips // 32), max(2, num_clips // 10)
+    n_squat = 2 if (with_squats and num_clips >= 16) else 0
+    n_step = max(2, num_clips // 5)
+    n_walk = max(1, num_clips - n_stand - n_arm - n_squat - n_step)
+    for i in range(n_stand):
+        out[f"loco_a_stand_{i:03d}"] = make_stand_clip(model, seconds + 2.0 * i, fps)
+    for i in range(n_arm):
+        out[f"loco_b_armswing_{i:03d}"] = make_armswing_clip(model, seconds, fps, swing=float(rng.uniform(0.3, 0.8)), freq=float(rng.uniform(0.3, 0.6)))
+    for i in range(n_step):
+        out[f"loco_c_stepinplace_{i:03d}"] = make_gait_clip(model, "stepinplace", seconds, fps, period=float(rng.uniform(1.0, 1.5)), lift=float(rng.uniform(0.06, 0.12)),
+                                                          sway=float(rng.uniform(0.035, 0.05)), arm=float(rng.uniform(0.2, 0.8)), heading=float(rng.uniform(-np.pi, np.pi)))
+    for i in range(n_walk):
+        while True:   # (stride = speed x period must stay within the legs' reach at the clip's pelvis height: re-draw the few that do not)
+            per = float(rng.uniform(0.9, 1.2))
+            sp = float(rng.uniform(0.3, min(0.9, 0.74 / per)))
+            try:
+                out[f"loco_d_walk_{i:03d}"] = make_gait_clip(model, "walk", seconds, fps, speed=sp, period=per, lift=float(rng.uniform(0.05, 0.09)),
+                                                            sway=float(rng.uniform(0.02, 0.03)), arm=float(rng.uniform(0.5, 1.2)), heading=float(rng.uniform(-np.pi, np.pi)))
+                break
+            except AssertionError:
+                continue
+    for i in range(n_squat):
+        out[f"loco_e_squat_{i:03d}"] = make_gait_clip(model, "squat", seconds, fps, period=float(rng.uniform(2.2, 3.0)), depth=float(rng.uniform(0.12, 0.2)))
+    return out

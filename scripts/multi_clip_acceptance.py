@@ -1,0 +1,120 @@
+"""Round 5: multi-clip policy-level acceptance -- the closest offline analogue of the reference's acceptance numbers (README.MD:107-118).
+
+A 64-clip library of feasible locomotion clips (`env.motion_file=locomotion:64:0`: stand, arm swing, step in place, walk at 0.3-0.8 m/s in all headings, two
+squats), 8192 envs, the PNN learner (`learning=im_pnn env=env_im_pnn`):
+  stage 1  primitive 0 trained on the whole set; every `--eval-every` epochs the evaluation sweep (`IMAmpAgent.eval` = im_amp.py:136-242: every clip from
+           t = 0, deterministic policy, 0.5 m mean-distance termination) re-weights the clip sampling (soft auto-PMCP, im_amp.py:126-132);
+  copy     `forward_pmcp` (scripts/pmcp/forward_pmcp.py:44-51): column 0 -> column 1, column 0 frozen (`training_prim=1`);
+  stage 2  primitive 1 trained with HARD negative mining on the clips primitive 0 still fails (`auto_pmcp`), as PHC's progressive schedule does;
+  report   the sweep with each primitive: success rate, G-MPJPE per clip and per clip class; a clip counts as covered when one primitive tracks it (what
+           the composer of the next PHC stage selects between).
+
+    python scripts/multi_clip_acceptance.py [--stage1-s 480] [--stage2-s 240] [--envs 8192] [--clips 64] [--out gpurun_out/multi_clip.json]
+"""
+import argparse
+import json
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, ".")
+from phc_amd.config import compose  # noqa: E402
+from phc_amd.env.tasks.vec_task import parse_task  # noqa: E402
+from phc_amd.learning.amp_agent import IMAmpAgent  # noqa: E402
+from phc_amd.learning.network import forward_pmcp  # noqa: E402
+
+
+def sweep(agent, tag, log):
+    info, failed = agent.eval(output_dir=None, log=None)
+    pc = agent.last_eval_per_clip
+    kinds = sorted({k.split("_")[2] for k in pc["keys"]})
+    by = {}
+    for kd in kinds:
+        m = np.array([k.split("_")[2] == kd for k in pc["keys"]])
+        by[kd] = {"clips": int(m.sum()), "success_rate": float(1 - pc["failed"][m].mean()), "mpjpe_g_mm": float(np.nanmean(pc["mpjpe_g"][m]))}
+    log(f"[{tag}] success {info['eval/success_rate']:.3f}  G-MPJPE all {info['eval/mpjpe_all']:.1f} mm  succ {info['eval/mpjpe_succ']:.1f} mm  by class " +
+        "  ".join(f"{k}: {v['success_rate']:.2f}/{v['mpjpe_g_mm']:.0f}mm" for k, v in by.items()))
+    return {"summary": info, "by_class": by, "per_clip": {k: {"failed": bool(f), "mpjpe_g_mm": float(g), "mpjpe_pa_mm": float(p)}
+                                                          for k, f, g, p in zip(pc["keys"], pc["failed"], pc["mpjpe_g"], pc["mpjpe_pa"])}}
+
+
+def train_for(agent, task, seconds, eval_every, log, rows, stage):
+    t0, n = time.time(), 0
+    while time.time() - t0 < seconds:
+        info = agent.train_epoch()
+        n += 1
+        if n % 50 == 0:
+            dones = float(agent.exp["dones"].float().sum())
+            rows.append({"stage": stage, "epoch": agent.epoch_num, "t": time.time() - t0, "task_reward": info["mean_task_reward"],
+                         "mean_episode_length": agent.batch_size / max(dones, 1.0), "total_fps": info["total_fps"]})
+        if n % 250 == 0:
+            r = rows[-1]
+            log(f"  stage {stage} epoch {agent.epoch_num:5d}  task_r {r['task_reward']:.4f}  ep_len {r['mean_episode_length']:6.1f}  fps {r['total_fps']:.0f}  ({r['t']:.0f} s)")
+        if eval_every and n % eval_every == 0:
+            e, failed = agent.eval(output_dir=None, log=None)      # also re-weights the sampler (auto-PMCP)
+            log(f"  stage {stage} epoch {agent.epoch_num:5d}  sweep: success {e['eval/success_rate']:.3f}  G-MPJPE {e['eval/mpjpe_all']:.1f} mm  failed {len(failed)}")
+            rows.append({"stage": stage, "epoch": agent.epoch_num, "t": time.time() - t0, "sweep_success_rate": e["eval/success_rate"], "sweep_mpjpe_all": e["eval/mpjpe_all"],
+                         "failed": len(failed)})
+    return n
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--stage1-s", type=float, default=480.0)
+    ap.add_argument("--stage2-s", type=float, default=240.0)
+    ap.add_argument("--envs", type=int, default=8192)
+    ap.add_argument("--clips", type=int, default=64)
+    ap.add_argument("--eval-every", type=int, default=500)
+    ap.add_argument("--out", default="gpurun_out/multi_clip.json")
+    ap.add_argument("extra", nargs="*")
+    a = ap.parse_args()
+    log = lambda s: print(s, flush=True)
+    torch.manual_seed(0)
+    over = ["learning=im_pnn", "env=env_im_pnn", f"env.num_envs={a.envs}", f"env.motion_file=locomotion:{a.clips}:0", "env.num_prim=2", "env.training_prim=0",
+            "env.auto_pmcp=False", "env.auto_pmcp_soft=True"] + a.extra
+    cfg = compose(over)
+    task, env = parse_task(cfg)
+    lib = task._motion_lib
+    log(f"library: {lib._num_unique_motions} clips, {a.envs} envs, overrides {over}")
+    rows, t_all = [], time.time()
+    agent = IMAmpAgent(env, cfg)
+    agent.init_train()
+    n1 = train_for(agent, task, a.stage1_s, a.eval_every, log, rows, 1)
+    res = {"config": {"overrides": over, "stage1_s": a.stage1_s, "stage2_s": a.stage2_s}, "stage1_epochs": n1, "samples_stage1": n1 * agent.batch_size}
+    res["primitive0_after_stage1"] = sweep(agent, "primitive 0 after stage 1", log)
+    fail0 = np.array([v["failed"] for v in res["primitive0_after_stage1"]["per_clip"].values()])
+    # ---- forward_pmcp: column 0 -> column 1; train column 1 on the failures with hard negative mining ----
+    ck = forward_pmcp(agent.get_full_state_weights(), 0)
+    task.cfg["env"]["training_prim"] = 1
+    task.auto_pmcp, task.auto_pmcp_soft = True, False
+    agent2 = IMAmpAgent(env, cfg)
+    agent2.set_full_state_weights(ck, load_optimizer=False)
+    agent2.epoch_num = agent.epoch_num
+    w0 = {k: v.clone() for k, v in agent2.model.state_dict().items() if ".pnn.actors.0." in k}
+    res["primitive1_equals_primitive0_after_the_copy"] = bool(all(torch.equal(agent2.model.state_dict()[k.replace("actors.0.", "actors.1.")], v) for k, v in w0.items()))
+    del agent
+    if fail0.any() and a.stage2_s > 0:
+        agent2.init_train()
+        agent2.eval(output_dir=None, log=None)          # hard re-weighting: only the clips primitive 0 fails are sampled from now on
+        task.resample_motions()                         # (takes effect now, not at the next multiple of shape_resampling_interval)
+        agent2.obs = agent2.env_reset()
+        n2 = train_for(agent2, task, a.stage2_s, a.eval_every, log, rows, 2)
+        res.update(stage2_epochs=n2, samples_stage2=n2 * agent2.batch_size)
+        res["primitive1_after_stage2"] = sweep(agent2, "primitive 1 after stage 2", log)
+        res["primitive0_frozen_unchanged"] = bool(all(torch.equal(agent2.model.state_dict()[k], v) for k, v in w0.items()))
+        p1 = res["primitive1_after_stage2"]["per_clip"]
+        covered = {k: (not v["failed"]) or (not p1[k]["failed"]) for k, v in res["primitive0_after_stage1"]["per_clip"].items()}
+        res["covered_by_some_primitive"] = {"rate": float(np.mean(list(covered.values()))), "uncovered": [k for k, c in covered.items() if not c]}
+        log(f"covered by primitive 0 or 1: {res['covered_by_some_primitive']['rate']:.3f}; uncovered {res['covered_by_some_primitive']['uncovered']}")
+    else:
+        log("primitive 0 tracks every clip: no second stage needed")
+    res["wall_s"] = time.time() - t_all
+    res["curve"] = rows
+    json.dump(res, open(a.out, "w"), indent=1)
+    log(f"wrote {a.out}  ({res['wall_s']:.0f} s)")
+
+
+if __name__ == "__main__":
+    main()

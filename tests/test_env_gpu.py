@@ -810,6 +810,8 @@ def test_self_obs_v2_env_keeps_a_body_state_history():
 
 @pytest.mark.parametrize("over", [
     {"learning": "im_pnn", "env": "env_im_pnn"},                                                         # PNN columns (frozen + training)
+    {"learning": "im_big"},                                                                              # the six-layer SiLU networks (2048-1536-1024-1024-512-512)
+    {"learning": "im_pnn_big", "env": "env_im_pnn"},                                                     # ... with the PNN actor: the reference's flagship learner
     {"robot": "smpl_humanoid_shape"},                                                                    # per-env shapes + shape columns in obs / AMP obs
     {"env.self_obs_v": 2, "env.obs_v": 8},                                                               # history self obs + v8 task obs (wide inputs)
 ])
@@ -833,6 +835,8 @@ def test_captured_update_trains_the_other_network_and_observation_variants(over)
         info = agent.train_epoch()
         assert np.isfinite([info["actor_loss"], info["critic_loss"], info["disc_loss"], info["kl"]]).all(), info
     assert agent._graph is not None and not torch.equal(p0, agent.grads.flat_param)
+    #  the default form: THREE linear graphs per step -- policy pass, discriminator pass captured on its own stream, tail -- not one graph
+    assert isinstance(agent._graph, tuple) and len(agent._graph) == 3 and agent._branches is not None
     st = agent.optimizer.state[agent.grads.flat_param]
     assert int(st["step"]) == 3 * agent.mini_epochs_num * agent.num_minibatches
     for p in agent.grads.params:
