@@ -396,6 +396,20 @@ int32_t phc_colsum_bf16(const void* x, int64_t rows, int32_t cols, float* out, f
  * (torch's ThresholdBackward, phc/learning/network_builder.py:126-137 `activation: relu`) written as bf16 [rows, cols], and its column sums
  * (the bias gradient) -- one pass instead of two.  Same workspace size. */
 int32_t phc_colsum_relu_bf16(const void* gy, const void* y, int64_t rows, int32_t cols, void* gm, float* out, float* workspace, void* stream);
+/* ABI 35: `out` == NULL in phc_colsum_bf16 / phc_colsum_relu_bf16 / `gw_gb` == NULL in phc_linear1_backward runs the FIRST stage only -- the per-chunk partial
+ * sums stay in `workspace`, [phc_colsum_chunks(rows)] (resp. [phc_linear1_chunks(rows)], `cols + 1` wide) rows -- and phc_colsum_finish_batch later finishes
+ * up to any number of such sums in one launch per PHC_COLSUM_MAX_JOBS of them: the bias gradients of a backward pass (autograd's AccumulateGrad of
+ * `AddmmBackward`'s `sum(0)`, read by nobody before clip_grad_norm_ + Adam, phc/learning/amp_agent.py:669-676) cost one dependent ~5 us launch at the end
+ * of the pass instead of one per layer.  `accumulate` != 0 adds to `out` instead of storing. */
+#define PHC_COLSUM_MAX_JOBS 16
+typedef struct {
+    const float* partial;             /* [nchunks, cols] fp32: a first stage's workspace (must stay untouched until the batch has run) */
+    float* out;                       /* [cols] fp32 */
+    int32_t nchunks, cols, accumulate;
+} phc_colsum_job_t;
+int32_t phc_colsum_chunks(int64_t rows);
+int32_t phc_linear1_chunks(int64_t rows);
+int32_t phc_colsum_finish_batch(int32_t count, const phc_colsum_job_t* jobs /* host array */, void* stream);
 /* Weight gradient of a linear layer as a split-K batched GEMM (autograd's `grad_output.t() @ input`, AddmmBackward): `part` [slabs, n] bf16 are the
  * slab products; out [n] fp32 receives their sum (accumulate 0) or has it added (accumulate != 0: a parameter's second and later gradient
  * contributions of a step, torch's AccumulateGrad).  part and out 16-byte aligned. */

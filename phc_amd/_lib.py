@@ -49,6 +49,10 @@ class SimParams(C.Structure):
                 ("bounce_threshold_velocity", c_f), ("restitution", c_f), ("inertia_lag", c_i32), ("force_average", c_i32)]
 
 
+class ColsumJob(C.Structure):
+    _fields_ = [("partial", c_p), ("out", c_p), ("nchunks", c_i32), ("cols", c_i32), ("accumulate", c_i32)]
+
+
 class ImParams(C.Structure):
     _fields_ = [("dt", c_f), ("max_episode_length", c_i32),
                 ("k_pos", c_f), ("k_rot", c_f), ("k_vel", c_f), ("k_ang_vel", c_f),
@@ -105,6 +109,9 @@ _SIGNATURES = {
     "phc_colsum_bf16": ([c_p, c_i64, c_i32, c_p, c_p, c_p], c_i32),
     "phc_colsum_relu_bf16": ([c_p, c_p, c_i64, c_i32, c_p, c_p, c_p, c_p], c_i32),
     "phc_sum_slabs_bf16": ([c_p, c_i32, c_i64, c_p, c_i32, c_p], c_i32),
+    "phc_colsum_chunks": ([c_i64], c_i32),
+    "phc_linear1_chunks": ([c_i64], c_i32),
+    "phc_colsum_finish_batch": ([c_i32, P(ColsumJob), c_p], c_i32),
     "phc_rollout_bookkeeping": ([c_p, c_f, c_p, c_p, c_p, c_i32, c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p], c_i32),
     "phc_disc_bce": ([c_p, c_i32, c_i32, c_i32, c_f, c_p, c_p, c_p], c_i32),
     "phc_sumsq_workspace": ([], c_i64),

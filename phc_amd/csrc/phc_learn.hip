@@ -67,11 +67,24 @@ __global__ __launch_bounds__(1024) void k_running_norm_finish(const double* __re
     const int cx = threadIdx.x & 63, sy = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cx;
     double s = 0.0, q = 0.0;
-    if (c < cols)
-        for (int k = sy; k < nchunks; k += 16) {
+    if (c < cols) {
+        // eight independent loads in flight per thread (round 5: one load pair at a time made the 512-chunk finish of the 16 384-row observation batch a
+        // 35 us chain of 32 dependent L2 round trips -- at the head of the policy pass, in front of its first GEMM)
+        int k = sy;
+        double s1 = 0.0, q1 = 0.0, s2 = 0.0, q2 = 0.0, s3 = 0.0, q3 = 0.0;
+        for (; k + 48 < nchunks; k += 64) {
+            const double a0 = partial[((int64_t)k * 2 + 0) * cols + c], b0 = partial[((int64_t)k * 2 + 1) * cols + c];
+            const double a1 = partial[((int64_t)(k + 16) * 2 + 0) * cols + c], b1 = partial[((int64_t)(k + 16) * 2 + 1) * cols + c];
+            const double a2 = partial[((int64_t)(k + 32) * 2 + 0) * cols + c], b2 = partial[((int64_t)(k + 32) * 2 + 1) * cols + c];
+            const double a3 = partial[((int64_t)(k + 48) * 2 + 0) * cols + c], b3 = partial[((int64_t)(k + 48) * 2 + 1) * cols + c];
+            s += a0; q += b0; s1 += a1; q1 += b1; s2 += a2; q2 += b2; s3 += a3; q3 += b3;
+        }
+        for (; k < nchunks; k += 16) {
             s += partial[((int64_t)k * 2 + 0) * cols + c];
             q += partial[((int64_t)k * 2 + 1) * cols + c];
         }
+        s = (s + s1) + (s2 + s3); q = (q + q1) + (q2 + q3);
+    }
     ls[sy][cx] = s; lq[sy][cx] = q;
     const double count = *run_count;
     const double n = (double)rows;
@@ -154,8 +167,7 @@ __global__ __launch_bounds__(256) void k_colsum_relu_bf16(const __hip_bfloat16* 
     if (ry == 0 && c < cols) partial[(int64_t)blockIdx.y * cols + c] = (l[0][cx] + l[1][cx]) + (l[2][cx] + l[3][cx]);
 }
 // block = 64 columns x 16 slices of the chunk list (up to 1024 chunks: 64 loads per thread, four in flight)
-__global__ __launch_bounds__(1024) void k_colsum_finish(const float* __restrict__ partial, int nchunks, int cols, float* __restrict__ out) {
-    __shared__ float l[16][64];
+__device__ __forceinline__ void colsum_finish_block(const float* __restrict__ partial, int nchunks, int cols, float* __restrict__ out, int accumulate, float (*l)[64]) {
     const int cx = threadIdx.x & 63, sy = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cx;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
@@ -173,8 +185,21 @@ __global__ __launch_bounds__(1024) void k_colsum_finish(const float* __restrict_
         float t = 0.f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) t += l[i][cx];
-        out[c] = t;
+        out[c] = accumulate ? out[c] + t : t;
     }
+}
+__global__ __launch_bounds__(1024) void k_colsum_finish(const float* __restrict__ partial, int nchunks, int cols, float* __restrict__ out) {
+    __shared__ float l[16][64];
+    colsum_finish_block(partial, nchunks, cols, out, 0, l);
+}
+// Round 5: the second stage of SEVERAL column sums in one launch (grid.y = job).  The bias gradients of a backward pass are read by nobody before
+// clip + Adam, so the layers only run their first stage and the pass ends with one of these instead of a ~5 us dependent launch per layer.
+struct ColsumJobs { phc_colsum_job_t job[PHC_COLSUM_MAX_JOBS]; };
+__global__ __launch_bounds__(1024) void k_colsum_finish_batch(ColsumJobs jobs) {
+    __shared__ float l[16][64];
+    const phc_colsum_job_t j = jobs.job[blockIdx.y];
+    if ((int)blockIdx.x * 64 >= j.cols) return;
+    colsum_finish_block(j.partial, j.nchunks, j.cols, j.out, j.accumulate, l);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -488,7 +513,19 @@ __global__ __launch_bounds__(256) void k_sum_slabs_bf16(const __hip_bfloat16* __
     if (i8 >= n) return;
     float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (i8 + 8 <= n && (n & 7) == 0) {
-        for (int s = 0; s < slabs; ++s) {
+        int s = 0;
+        for (; s + 8 <= slabs; s += 8) {     // (SPLIT_K = 8: all eight slab loads in flight -- one at a time made this a chain of dependent L2 / HBM round trips)
+            uint4 q[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) q[t] = *reinterpret_cast<const uint4*>(part + (int64_t)(s + t) * n + i8);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const uint32_t w[4] = {q[t].x, q[t].y, q[t].z, q[t].w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { a[2 * k] += __uint_as_float(w[k] << 16); a[2 * k + 1] += __uint_as_float(w[k] & 0xffff0000u); }
+            }
+        }
+        for (; s < slabs; ++s) {
             const uint4 q = *reinterpret_cast<const uint4*>(part + (int64_t)s * n + i8);
             const uint32_t w[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
@@ -643,24 +680,43 @@ int32_t phc_running_norm(const float* x, const int64_t* row_index, int64_t rows,
 int64_t phc_colsum_workspace(int64_t rows, int32_t cols) { return ((rows + CS_ROWS - 1) / CS_ROWS) * (int64_t)cols * (int64_t)sizeof(float); }
 
 int32_t phc_colsum_bf16(const void* x, int64_t rows, int32_t cols, float* out, float* workspace, void* stream) {
-    if (!x || !out || !workspace || rows < 1 || cols < 1) return PHC_EINVAL;
+    if (!x || !workspace || rows < 1 || cols < 1) return PHC_EINVAL;
     const int64_t nchunks = (rows + CS_ROWS - 1) / CS_ROWS;
     if (nchunks > 65535) return PHC_EUNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_colsum_bf16, dim3((cols + 63) / 64, (unsigned)nchunks), dim3(256), 0, st, reinterpret_cast<const __hip_bfloat16*>(x), rows, cols, workspace);
-    hipLaunchKernelGGL(k_colsum_finish, dim3((cols + 63) / 64), dim3(1024), 0, st, workspace, (int)nchunks, cols, out);
+    if (out) hipLaunchKernelGGL(k_colsum_finish, dim3((cols + 63) / 64), dim3(1024), 0, st, workspace, (int)nchunks, cols, out);   // (NULL: phc_colsum_finish_batch later)
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int32_t)e;
 }
 
 int32_t phc_colsum_relu_bf16(const void* gy, const void* y, int64_t rows, int32_t cols, void* gm, float* out, float* workspace, void* stream) {
-    if (!gy || !y || !gm || !out || !workspace || rows < 1 || cols < 1) return PHC_EINVAL;
+    if (!gy || !y || !gm || !workspace || rows < 1 || cols < 1) return PHC_EINVAL;
     const int64_t nchunks = (rows + CS_ROWS - 1) / CS_ROWS;
     if (nchunks > 65535) return PHC_EUNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_colsum_relu_bf16, dim3((cols + 63) / 64, (unsigned)nchunks), dim3(256), 0, st, reinterpret_cast<const __hip_bfloat16*>(gy),
                        reinterpret_cast<const __hip_bfloat16*>(y), rows, cols, reinterpret_cast<__hip_bfloat16*>(gm), workspace);
-    hipLaunchKernelGGL(k_colsum_finish, dim3((cols + 63) / 64), dim3(1024), 0, st, workspace, (int)nchunks, cols, out);
+    if (out) hipLaunchKernelGGL(k_colsum_finish, dim3((cols + 63) / 64), dim3(1024), 0, st, workspace, (int)nchunks, cols, out);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int32_t)e;
+}
+
+int32_t phc_colsum_chunks(int64_t rows) { return (int32_t)((rows + CS_ROWS - 1) / CS_ROWS); }
+int32_t phc_linear1_chunks(int64_t rows) { return (int32_t)((rows + L1_ROWS - 1) / L1_ROWS); }
+
+int32_t phc_colsum_finish_batch(int32_t count, const phc_colsum_job_t* jobs, void* stream) {
+    if (count < 0 || (count > 0 && !jobs)) return PHC_EINVAL;
+    for (int32_t i = 0; i < count; ++i)
+        if (!jobs[i].partial || !jobs[i].out || jobs[i].nchunks < 1 || jobs[i].cols < 1) return PHC_EINVAL;
+    for (int32_t i0 = 0; i0 < count; i0 += PHC_COLSUM_MAX_JOBS) {
+        ColsumJobs a;
+        const int n = count - i0 < PHC_COLSUM_MAX_JOBS ? count - i0 : PHC_COLSUM_MAX_JOBS;
+        int maxcols = 1;
+        for (int i = 0; i < n; ++i) { a.job[i] = jobs[i0 + i]; if (a.job[i].cols > maxcols) maxcols = a.job[i].cols; }
+        for (int i = n; i < PHC_COLSUM_MAX_JOBS; ++i) a.job[i] = a.job[0];
+        hipLaunchKernelGGL(k_colsum_finish_batch, dim3((maxcols + 63) / 64, (unsigned)n), dim3(1024), 0, (hipStream_t)stream, a);
+    }
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int32_t)e;
 }
@@ -699,12 +755,12 @@ int32_t phc_linear1_forward(const void* x, const void* w, const void* b, int64_t
 
 int32_t phc_linear1_backward(const void* x, const void* w, const void* gy, int64_t rows, int32_t cols, void* gx, float* gw_gb, float* workspace,
                              void* stream) {
-    if (!x || !w || !gy || !gw_gb || !workspace || rows < 1 || cols < 1) return PHC_EINVAL;
+    if (!x || !w || !gy || !workspace || rows < 1 || cols < 1) return PHC_EINVAL;
     const int64_t nchunks = (rows + L1_ROWS - 1) / L1_ROWS;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_linear1_bwd, dim3((unsigned)nchunks), dim3(256), 0, st, (const __hip_bfloat16*)x, (const __hip_bfloat16*)w, (const __hip_bfloat16*)gy,
                        rows, cols, (__hip_bfloat16*)gx, workspace);
-    hipLaunchKernelGGL(k_colsum_finish, dim3((cols + 1 + 63) / 64), dim3(1024), 0, st, workspace, (int)nchunks, cols + 1, gw_gb);
+    if (gw_gb) hipLaunchKernelGGL(k_colsum_finish, dim3((cols + 1 + 63) / 64), dim3(1024), 0, st, workspace, (int)nchunks, cols + 1, gw_gb);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int32_t)e;
 }

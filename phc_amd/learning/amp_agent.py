@@ -41,7 +41,7 @@ from torch import nn
 from .. import _lib as L
 from .network import A2CMCPNetwork, A2CNetwork, A2CPNNNetwork, ModelAMPContinuous, policy_kl
 from .replay_buffer import ReplayBuffer
-from .fast_ops import adam_clip_step, disc_bce, input_grad_only, param_grad_only, policy_sample, ppo_loss, rows_with_grad, weighted_sumsq
+from .fast_ops import adam_clip_step, deferred_colsums, disc_bce, input_grad_only, param_grad_only, policy_sample, ppo_loss, rows_with_grad, weighted_sumsq
 from .running_mean_std import RunningMeanStd
 
 
@@ -789,7 +789,7 @@ class IMAmpAgent:
             roots = [ppo] + roots
             info = None if fused_disc else {"actor_loss": st[0], "critic_loss": st[1], "b_loss": st[2], "entropy": st[3], "kl": st[4]}
             self.grads.zero(decay)
-            with param_grad_only():
+            with param_grad_only(), deferred_colsums():
                 torch.autograd.backward(roots, grad_tensors=[self._unit_cotangent(r) for r in roots])
         else:
             assert idx is None
@@ -836,7 +836,7 @@ class IMAmpAgent:
         with self._autocast():
             logits = self.model.a2c_network.eval_disc(rows_with_grad(cat, amp_obs_demo, 2 * m))
         roots, _ = self._disc_loss_fused(logits, m, amp_obs_demo)
-        with param_grad_only():
+        with param_grad_only(), deferred_colsums():   # (bias gradients: first stages in the layers, ONE finishing launch here)
             torch.autograd.backward(roots, grad_tensors=[self._unit_cotangent(r) for r in roots])
 
     def _policy_pass(self, d, idx):
@@ -852,7 +852,7 @@ class IMAmpAgent:
         ppo, _ = ppo_loss(mu.contiguous(), value.contiguous(), logstd[0] if logstd.dim() == 2 else logstd, d["actions"], d["old_logp_actions"],
                           d["advantages"], d["returns"], d["old_values"], d["mu"], d["sigma"], self.e_clip, self.critic_coef, self.entropy_coef,
                           self.bounds_loss_coef, self.clip_value, unit_grad=True, row_index=idx, out=self._raw_buffer()[0][0:6])
-        with param_grad_only():
+        with param_grad_only(), deferred_colsums():
             torch.autograd.backward([ppo], grad_tensors=[self._unit_cotangent(ppo)])
 
     def _unit_cotangent(self, like):

@@ -68,6 +68,55 @@ def _first_write(p):
     return True
 
 
+# ---- deferred second stage of the column sums (round 5) ---------------------------------------------------------------------------------
+# Inside `deferred_colsums()` a column sum that goes straight into a bucket gradient (`out` given) only runs its first stage; the per-chunk
+# partials wait in a workspace of their own (keyed by the destination) and ONE `phc_colsum_finish_batch` launch at the end of the pass finishes
+# all of them -- the agent's passes end with it (IMAmpAgent._policy_pass / _disc_pass / _fwd_bwd).  Nobody reads a bias gradient before clip + Adam.
+# Module-level state, like `_INPUT_GRAD_ONLY`: the backward runs on the autograd engine's thread; the pending list is per lane (stream).
+_DEFER = [0]
+_pending = {}
+
+
+def _lane_of(device):
+    return _lanes.get(torch.cuda.current_stream(device).cuda_stream) if _lanes else None
+
+
+class deferred_colsums:
+    def __enter__(self):
+        _DEFER[0] += 1
+        return self
+
+    def __exit__(self, et, ev, tb):
+        _DEFER[0] -= 1
+        if et is None:
+            flush_colsums()
+        else:
+            _pending.clear()
+
+
+def _defer(out):
+    return _DEFER[0] > 0 and out is not None and out.is_cuda and not os.environ.get("PHC_NO_DEFER_COLSUM")
+
+
+def _pend(ws, out, nchunks, cols, accumulate=0):
+    _pending.setdefault((out.device, _lane_of(out.device)), []).append((ws, out, int(nchunks), int(cols), int(accumulate)))
+
+
+def flush_colsums(device=None):
+    """Finish every pending column sum of the current lane (stream) in one launch per 16 of them."""
+    if not _pending:
+        return
+    for key in list(_pending):
+        dev, lane = key
+        if (device is not None and torch.device(device) != dev) or lane != _lane_of(dev):
+            continue
+        jobs = _pending.pop(key)
+        arr = (L.ColsumJob * len(jobs))()
+        for i, (ws, out, nch, cols, acc) in enumerate(jobs):
+            arr[i].partial, arr[i].out, arr[i].nchunks, arr[i].cols, arr[i].accumulate = ws.data_ptr(), out.data_ptr(), nch, cols, acc
+        L.check(L.load().phc_colsum_finish_batch(len(jobs), arr, _stream(dev)), "phc_colsum_finish_batch")
+
+
 def colsum_bf16(x, out=None):
     """x bf16 [rows, cols] (contiguous, device) -> fp32 [cols] (written into `out` when given)"""
     lib = L.load()
@@ -76,6 +125,11 @@ def colsum_bf16(x, out=None):
         out = torch.empty(cols, dtype=torch.float32, device=x.device)
     else:
         assert out.numel() == cols and out.dtype == torch.float32 and out.is_contiguous()
+        if _defer(out):
+            ws = _workspace(("colsum", out.data_ptr()), lib.phc_colsum_workspace(rows, cols), x.device, torch.float32)
+            L.check(lib.phc_colsum_bf16(x.data_ptr(), rows, cols, None, ws.data_ptr(), _stream(x.device)), "phc_colsum_bf16")
+            _pend(ws, out, lib.phc_colsum_chunks(rows), cols)
+            return out
     ws = _workspace("colsum", lib.phc_colsum_workspace(rows, cols), x.device, torch.float32)
     L.check(lib.phc_colsum_bf16(x.data_ptr(), rows, cols, out.data_ptr(), ws.data_ptr(), _stream(x.device)), "phc_colsum_bf16")
     return out
@@ -86,6 +140,12 @@ def colsum_relu_bf16(gy, y, out=None):
     lib = L.load()
     rows, cols = gy.shape
     gm = torch.empty_like(gy)
+    if _defer(out):
+        assert out.numel() == cols and out.dtype == torch.float32 and out.is_contiguous()
+        ws = _workspace(("colsum", out.data_ptr()), lib.phc_colsum_workspace(rows, cols), gy.device, torch.float32)
+        L.check(lib.phc_colsum_relu_bf16(gy.data_ptr(), y.data_ptr(), rows, cols, gm.data_ptr(), None, ws.data_ptr(), _stream(gy.device)), "phc_colsum_relu_bf16")
+        _pend(ws, out, lib.phc_colsum_chunks(rows), cols)
+        return gm, out
     if out is None:
         out = torch.empty(cols, dtype=torch.float32, device=gy.device)
     ws = _workspace("colsum", lib.phc_colsum_workspace(rows, cols), gy.device, torch.float32)
@@ -319,7 +379,7 @@ class _LinearDDFn(torch.autograd.Function):
         only_x, r0 = _INPUT_GRAD_ONLY
         need_gx = ctx.needs_input_grad[0] and not (_PARAM_GRAD_ONLY[0] and ctx.x_is_net_input)
         gx, gw, gb = _LinearDDBwdFn.apply(gy, x, weight, bias, need_gx, only_x, y, r0 if only_x else 0)
-        out = (gx if need_gx else None, None if (only_x or gw.dim() != 2) else gw, None if only_x else gb)   # (0-dim gw: written in place)
+        out = (gx if need_gx else None, None if (only_x or gw.dim() != 2) else gw, None if (only_x or gb.dim() != 1) else gb)   # (0-dim gw / gb: written in place)
         return out + ((None,) if len(ctx.needs_input_grad) > 3 else ())
 
 
@@ -353,11 +413,15 @@ class _LinearDDBwdFn(torch.autograd.Function):
             return gx, pw, pb
         _, xb = _match_cols(wb, x.to(torch.bfloat16))
         gb = None
+        # the bias receives ONE contribution per step (the penalty path asks for no parameter gradient, the second-order rule has no bias term): when it is
+        # the first write into a bucket gradient the column sums are stored there directly -- no tensor for autograd to add (one launch per layer, round 5)
+        direct_b = (gy.dtype == torch.bfloat16 and bias.grad is not None and bias.grad.is_contiguous() and not os.environ.get("PHC_NO_DIRECT_DD_BIAS")
+                    and _first_write(bias))
         if y is not None:
             if gy.dtype != torch.bfloat16:
                 gy = _relu_mask(gy, y)
             else:
-                gy, gb = colsum_relu_bf16(gy, y)          # mask + bias gradient in one pass
+                gy, gb = colsum_relu_bf16(gy, y, out=bias.grad if direct_b else None)          # mask + bias gradient in one pass
             ctx.save_for_backward(gy, wb, xb, y)
         else:
             ctx.save_for_backward(gy, wb, xb)
@@ -366,7 +430,12 @@ class _LinearDDBwdFn(torch.autograd.Function):
         if gw is None:        # stored / added in place
             gw = _placeholder(gy)
             ctx.mark_non_differentiable(gw)
-        return gx, gw, (gb if gb is not None else colsum_bf16(gy))
+        if gb is None:
+            gb = colsum_bf16(gy, out=bias.grad if direct_b else None)
+        if direct_b:
+            gb = _placeholder(gy)
+            ctx.mark_non_differentiable(gb)
+        return gx, gw, gb
 
     @staticmethod
     @once_differentiable
@@ -457,6 +526,13 @@ class _Linear1Fn(torch.autograd.Function):
         if direct:
             weight._grad_gen = bias._grad_gen = b.gen
         gwb = None if direct else torch.empty(cols + 1, dtype=torch.float32, device=xb.device)
+        if direct and _defer(weight.grad):   # first stage only: the [cols + 1] result is finished with the pass's other column sums
+            ws = _workspace(("lin1", weight.grad.data_ptr()), lib.phc_linear1_workspace(rows, cols), xb.device, torch.float32)
+            L.check(lib.phc_linear1_backward(xb.data_ptr(), wb.data_ptr(), gy.data_ptr(), rows, cols, None if gx is None else gx.data_ptr(), None, ws.data_ptr(),
+                                             _stream(xb.device)), "phc_linear1_backward")
+            _pend(ws, weight.grad, lib.phc_linear1_chunks(rows), cols + 1)
+            gx = gx.to(ctx.x_dtype) if gx is not None else None
+            return gx, None, None
         ws = _workspace("lin1", lib.phc_linear1_workspace(rows, cols), xb.device, torch.float32)
         L.check(lib.phc_linear1_backward(xb.data_ptr(), wb.data_ptr(), gy.data_ptr(), rows, cols, None if gx is None else gx.data_ptr(),
                                          weight.grad.data_ptr() if direct else gwb.data_ptr(), ws.data_ptr(), _stream(xb.device)), "phc_linear1_backward")

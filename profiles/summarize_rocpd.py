@@ -10,8 +10,14 @@ import sys
 def main(path):
     db = sqlite3.connect(path)
     cur = db.cursor()
-    rows = cur.execute("select name, count(*), sum(duration), avg(duration), min(duration), max(duration), max(vgpr_count), max(sgpr_count), "
+    cols = [r[1] for r in cur.execute("pragma table_info(kernels)").fetchall()]
+    # an earlier table showed 112 in the `vgpr` column for the stepper, whose code object holds 224 VGPRs (`-Rpass-analysis=kernel-resource-usage`,
+    # the number DESIGN.md quotes).  rocpd keeps architectural and accumulation registers in separate columns where it has both: the table prints their sum
+    # and, on its first line, the columns this trace's `kernels` view has -- read the column against the compiler's number, not instead of it.
+    vg = "max(vgpr_count" + (" + accum_vgpr_count" if "accum_vgpr_count" in cols else "") + ")"
+    rows = cur.execute(f"select name, count(*), sum(duration), avg(duration), min(duration), max(duration), {vg}, max(sgpr_count), "
                        "max(lds_size), max(scratch_size), max(grid_x), max(workgroup_x) from kernels group by name order by sum(duration) desc").fetchall()
+    print(f"# kernels view columns: {' '.join(cols)}")
     total = sum(r[2] for r in rows)
     print(f"# source: {path}")
     print(f"# {'kernel':58s} {'calls':>6s} {'total_ms':>9s} {'avg_us':>8s} {'min_us':>8s} {'max_us':>8s} {'pct':>6s} {'vgpr':>5s} {'sgpr':>5s} {'lds':>6s} {'scr':>4s} {'grid':>8s} {'wg':>4s}")

@@ -48,10 +48,12 @@ def train_for(agent, task, seconds, eval_every, log, rows, stage):
         if n % 50 == 0:
             dones = float(agent.exp["dones"].float().sum())
             rows.append({"stage": stage, "epoch": agent.epoch_num, "t": time.time() - t0, "task_reward": info["mean_task_reward"],
-                         "mean_episode_length": agent.batch_size / max(dones, 1.0), "total_fps": info["total_fps"]})
+                         "mean_episode_length": agent.batch_size / max(dones, 1.0), "total_fps": info["total_fps"], "kl": float(info["kl"]),
+                         "disc_reward": float(info["mean_disc_reward"]), "mu_abs_max": float(agent.exp["mus"].abs().max()), "mu_abs_mean": float(agent.exp["mus"].abs().mean())})
         if n % 250 == 0:
             r = rows[-1]
-            log(f"  stage {stage} epoch {agent.epoch_num:5d}  task_r {r['task_reward']:.4f}  ep_len {r['mean_episode_length']:6.1f}  fps {r['total_fps']:.0f}  ({r['t']:.0f} s)")
+            log(f"  stage {stage} epoch {agent.epoch_num:5d}  task_r {r['task_reward']:.4f}  ep_len {r['mean_episode_length']:6.1f}  kl {r['kl']:.4f}  |mu| mean {r['mu_abs_mean']:.3f} max {r['mu_abs_max']:.2f}  "
+                f"disc_r {r['disc_reward']:.3f}  fps {r['total_fps']:.0f}  ({r['t']:.0f} s)")
         if eval_every and n % eval_every == 0:
             e, failed = agent.eval(output_dir=None, log=None)      # also re-weights the sampler (auto-PMCP)
             log(f"  stage {stage} epoch {agent.epoch_num:5d}  sweep: success {e['eval/success_rate']:.3f}  G-MPJPE {e['eval/mpjpe_all']:.1f} mm  failed {len(failed)}")

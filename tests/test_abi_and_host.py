@@ -38,7 +38,8 @@ def test_struct_sizes_match_the_header():
     """Compile a tiny C program against include/phc_amd.h and compare sizeof() with the ctypes mirrors."""
     from phc_amd import _lib
     names = {"phc_model_t": _lib.Model, "phc_motion_lib_t": _lib.MotionLib, "phc_sim_state_t": _lib.SimState,
-             "phc_sim_params_t": _lib.SimParams, "phc_im_params_t": _lib.ImParams, "phc_im_buffers_t": _lib.ImBuffers, "phc_ppo_params_t": _lib.PpoParams}
+             "phc_sim_params_t": _lib.SimParams, "phc_im_params_t": _lib.ImParams, "phc_im_buffers_t": _lib.ImBuffers, "phc_ppo_params_t": _lib.PpoParams,
+             "phc_colsum_job_t": _lib.ColsumJob}
     src = '#include <stdio.h>\n#include "phc_amd.h"\nint main(){' + "".join(f'printf("{n} %zu\\n", sizeof({n}));' for n in names) + "return 0;}"
     with tempfile.TemporaryDirectory() as d:
         c = os.path.join(d, "s.c")

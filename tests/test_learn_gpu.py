@@ -80,6 +80,42 @@ def test_colsum_kernel(rows, cols):
     np.testing.assert_allclose(got.cpu().numpy(), ref.cpu().numpy(), rtol=1e-5, atol=1e-4)
 
 
+def test_deferred_column_sums_finish_in_one_batch_launch():
+    """Round 5: inside `deferred_colsums()` the column sums that go straight into a destination only run their first stage; one
+    `phc_colsum_finish_batch` launch at the end finishes all of them (20 jobs here: two launches of <= 16) -- same values as the immediate path,
+    incl. the masked variant, the value head's [cols + 1] result and an accumulating job."""
+    import ctypes as C
+    from phc_amd import _lib as L
+    from phc_amd.learning import fast_ops as fo
+    torch.manual_seed(0)
+    shapes = [(16384, 1024), (16384, 512), (4096, 69), (1000, 513)] * 5
+    xs = [(torch.randn(r, c, device="cuda") * 0.1).to(torch.bfloat16) for r, c in shapes]
+    ys = [torch.randn(r, c, device="cuda").to(torch.bfloat16) for r, c in shapes]
+    want = [fo.colsum_relu_bf16(x, y) if i % 2 else (None, fo.colsum_bf16(x)) for i, (x, y) in enumerate(zip(xs, ys))]
+    outs = [torch.full((c,), 7.0, device="cuda") for _, c in shapes]
+    with fo.deferred_colsums():
+        got = [fo.colsum_relu_bf16(x, y, out=o) if i % 2 else (None, fo.colsum_bf16(x, out=o)) for i, (x, y, o) in enumerate(zip(xs, ys, outs))]
+        assert sum(len(v) for v in fo._pending.values()) == len(shapes)
+    assert not fo._pending
+    torch.cuda.synchronize()
+    for i, ((gm_w, w), (gm_g, g), o) in enumerate(zip(want, got, outs)):
+        assert g is o
+        torch.testing.assert_close(o, w, rtol=0, atol=0)
+        if gm_w is not None:
+            assert torch.equal(gm_w, gm_g)
+    # an accumulating job through the C ABI itself
+    lib = L.load()
+    x = xs[0]
+    ws = torch.empty(lib.phc_colsum_workspace(*x.shape) // 4, device="cuda")
+    L.check(lib.phc_colsum_bf16(x.data_ptr(), x.shape[0], x.shape[1], None, ws.data_ptr(), torch.cuda.current_stream().cuda_stream), "first stage")
+    acc = torch.full((x.shape[1],), 2.0, device="cuda")
+    job = (L.ColsumJob * 1)()
+    job[0].partial, job[0].out, job[0].nchunks, job[0].cols, job[0].accumulate = ws.data_ptr(), acc.data_ptr(), lib.phc_colsum_chunks(x.shape[0]), x.shape[1], 1
+    L.check(lib.phc_colsum_finish_batch(1, job, torch.cuda.current_stream().cuda_stream), "batch")
+    torch.testing.assert_close(acc, want[0][1] + 2.0, rtol=1e-6, atol=1e-6)
+    assert lib.phc_colsum_finish_batch(1, None, None) != 0      # PHC_EINVAL
+
+
 @pytest.mark.parametrize("B,K,N", [(16384, 934, 1024), (16384, 512, 69), (1000, 130, 7)])
 def test_fast_linear_matches_autocast_linear(B, K, N):
     """FastLinear's training pass == nn.Linear under bf16 autocast: same forward values; weight / bias / input gradients equal to the
@@ -372,11 +408,12 @@ def test_twice_differentiable_linear_matches_autograd(mode):
         assert ef < 0.1 and ef <= 1.5 * er + 2e-3, (k, ef, er)   # er: what stock autograd's bf16 path achieves (~5 % on the small bias gradients)
 
 
-def test_one_output_linear_kernels():
-    """FastLinear with out_features == 1 (the value head): phc_linear1_forward / _backward == nn.Linear under bf16 autocast."""
+@pytest.mark.parametrize("B,K", [(5000, 512), (16384, 512), (4099, 1024), (777, 130)])
+def test_one_output_linear_kernels(B, K):
+    """FastLinear with out_features == 1 (the value head): phc_linear1_forward / _backward == nn.Linear under bf16 autocast (ragged last blocks: B = 5000,
+    4099, 777)."""
     from phc_amd.learning.fast_ops import FastLinear
     torch.manual_seed(5)
-    B, K = 5000, 512
     ref, fast = torch.nn.Linear(K, 1).cuda(), FastLinear(K, 1).cuda()
     fast.load_state_dict(ref.state_dict())
     x = torch.randn(B, K, device="cuda").to(torch.bfloat16)

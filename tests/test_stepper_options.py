@@ -153,3 +153,4 @@ def test_force_average_is_the_mean_over_the_sub_steps(backend, lag):
     np.testing.assert_allclose(avg["cf"], np.mean(cfs, 0), atol=1.0, rtol=2e-2)
     np.testing.assert_allclose(avg["df"], np.mean(dfs, 0), atol=0.3, rtol=2e-2)
     assert np.abs(avg["cf"] - last["cf"]).max() > 1.0   # (and the two publications do differ)
+
