@@ -110,8 +110,10 @@ def main():
         covered = {k: (not v["failed"]) or (not p1[k]["failed"]) for k, v in res["primitive0_after_stage1"]["per_clip"].items()}
         res["covered_by_some_primitive"] = {"rate": float(np.mean(list(covered.values()))), "uncovered": [k for k, c in covered.items() if not c]}
         log(f"covered by primitive 0 or 1: {res['covered_by_some_primitive']['rate']:.3f}; uncovered {res['covered_by_some_primitive']['uncovered']}")
-    else:
+    elif not fail0.any():
         log("primitive 0 tracks every clip: no second stage needed")
+    else:
+        log(f"primitive 0 fails {int(fail0.sum())} clips; second stage not requested (--stage2-s 0)")
     res["wall_s"] = time.time() - t_all
     res["curve"] = rows
     json.dump(res, open(a.out, "w"), indent=1)
