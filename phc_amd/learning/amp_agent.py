@@ -261,6 +261,13 @@ class IMAmpAgent:
         assert self.batch_size % self.minibatch_size == 0
         self.num_minibatches = self.batch_size // self.minibatch_size
         self.mini_epochs_num = c["mini_epochs"]
+        # round 5 (profiles/r05_multi_clip/README.md): with the shipped lr / fixed sigma the multi-clip runs of this repository learn at 24 optimizer steps per rollout (2048 envs as
+        # shipped, 4096 envs with mini_epochs=3) and drift into a policy that fails every clip at 48 (4096 envs as shipped) and 96 (8192 envs); the reference's 3072 envs give 36
+        steps = self.mini_epochs_num * self.num_minibatches
+        if steps > 36 and self.rank == 0 and str(self.device).startswith("cuda") and not os.environ.get("PHC_QUIET"):
+            print(f"[phc_amd] {steps} optimizer steps per rollout (mini_epochs {self.mini_epochs_num} x {self.num_minibatches} minibatches of {self.minibatch_size}): the shipped yaml is tuned for "
+                  f"3072 envs = 36; multi-clip runs here plateau above that -- consider learning.params.config.mini_epochs={max(1, 24 // self.num_minibatches)} or a larger minibatch_size "
+                  f"(profiles/r05_multi_clip/README.md)", file=sys.stderr)
         self.gamma, self.tau = c["gamma"], c["tau"]
         self.e_clip, self.critic_coef, self.entropy_coef = c["e_clip"], c["critic_coef"], c["entropy_coef"]
         self.bounds_loss_coef = c.get("bounds_loss_coef", None)

@@ -1262,3 +1262,28 @@ def test_tgs_contact_option_env_steps_match_the_dense_oracle_and_the_humanoid_st
     fz = stand._contact_forces[..., 2].sum(-1)
     weight = float(stand.model.mass.sum()) * 9.81
     assert float((fz / weight - 1).abs().max()) < 0.15, (fz / weight)
+
+
+def test_multi_clip_acceptance_pipeline_mechanics(tmp_path):
+    """Round 5 (f-2 + f-3 together): scripts/multi_clip_acceptance.py end to end in a child process with tiny budgets -- the 16-clip locomotion library, the PNN learner,
+    sweeps with soft auto-PMCP re-weighting, the `forward_pmcp` column copy, a hard-mined second stage with column 0 frozen, per-clip report.  Mechanics only (the learning
+    result of the real run is under profiles/r05_multi_clip/): the copy is exact, the frozen column does not move, every clip has its row."""
+    import json
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = str(tmp_path / "mc.json")
+    r = subprocess.run([sys.executable, os.path.join(here, "..", "scripts", "multi_clip_acceptance.py"), "--stage1-s", "6", "--stage2-s", "5", "--envs", "512", "--clips", "16",
+                        "--eval-every", "12", "--out", out, "learning.params.config.minibatch_size=4096", "learning.params.config.amp_minibatch_size=1024"],
+                       capture_output=True, text=True, timeout=600, cwd=os.path.join(here, ".."))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    d = json.load(open(out))
+    assert d["primitive1_equals_primitive0_after_the_copy"] is True
+    p0 = d["primitive0_after_stage1"]
+    assert len(p0["per_clip"]) == 16 and set(p0["by_class"]) == {"stand", "armswing", "stepinplace", "walk", "squat"}
+    assert all(np.isfinite(v["mpjpe_g_mm"]) for v in p0["per_clip"].values())
+    if "primitive1_after_stage2" in d:      # (always, unless 11 s of training tracked everything)
+        assert d["primitive0_frozen_unchanged"] is True and d["stage2_epochs"] > 0
+        assert set(d["covered_by_some_primitive"]) == {"rate", "uncovered"}
+    assert any("sweep_success_rate" in row for row in d["curve"])
