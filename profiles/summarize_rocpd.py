@@ -11,13 +11,14 @@ def main(path):
     db = sqlite3.connect(path)
     cur = db.cursor()
     cols = [r[1] for r in cur.execute("pragma table_info(kernels)").fetchall()]
-    # an earlier table showed 112 in the `vgpr` column for the stepper, whose code object holds 224 VGPRs (`-Rpass-analysis=kernel-resource-usage`,
-    # the number DESIGN.md quotes).  rocpd keeps architectural and accumulation registers in separate columns where it has both: the table prints their sum
-    # and, on its first line, the columns this trace's `kernels` view has -- read the column against the compiler's number, not instead of it.
-    vg = "max(vgpr_count" + (" + accum_vgpr_count" if "accum_vgpr_count" in cols else "") + ")"
+    # an earlier table showed 112 in the `vgpr` column for the stepper, whose code object allocates 224 VGPRs (221 used: `-Rpass-analysis=kernel-resource-usage`,
+    # the number DESIGN.md quotes).  rocpd derives `vgpr_count` from the kernel descriptor's granulated field with a 4-register granule; wave64 kernels on gfx9 / gfx950 allocate
+    # in granules of 8, so the view reports HALF the allocation (check: 112 -> 224 for k_sim_step; 256 -> 512 = the whole unified file for the hipBLASLt MFMA kernels, whose
+    # `accum_vgpr_count` column is 0 in this view).  The table prints 2 x (vgpr_count + accum_vgpr_count).
+    vg = "2 * max(vgpr_count" + (" + accum_vgpr_count" if "accum_vgpr_count" in cols else "") + ")"
     rows = cur.execute(f"select name, count(*), sum(duration), avg(duration), min(duration), max(duration), {vg}, max(sgpr_count), "
                        "max(lds_size), max(scratch_size), max(grid_x), max(workgroup_x) from kernels group by name order by sum(duration) desc").fetchall()
-    print(f"# kernels view columns: {' '.join(cols)}")
+    print("# vgpr = 2 x rocpd's vgpr_count (+ accum_vgpr_count): wave64 allocation granule 8, see profiles/summarize_rocpd.py")
     total = sum(r[2] for r in rows)
     print(f"# source: {path}")
     print(f"# {'kernel':58s} {'calls':>6s} {'total_ms':>9s} {'avg_us':>8s} {'min_us':>8s} {'max_us':>8s} {'pct':>6s} {'vgpr':>5s} {'sgpr':>5s} {'lds':>6s} {'scr':>4s} {'grid':>8s} {'wg':>4s}")
