@@ -1264,6 +1264,43 @@ def test_tgs_contact_option_env_steps_match_the_dense_oracle_and_the_humanoid_st
     assert float((fz / weight - 1).abs().max()) < 0.15, (fz / weight)
 
 
+def test_stepper_switches_through_the_task_config():
+    """Round 5: `+solver.inertia_lag=1` and `+solver.force_average=1` reach the kernel through the hydra-style overrides.  With the lagged scheme every
+    post-physics output still equals the numpy oracle recomputed from the task's own tensors (the checker does not depend on the stepper's scheme; the scheme
+    itself is gated in tests/test_stepper_options.py) and a humanoid under zero actions keeps standing.  With force_average the state trajectory is bit-identical and the published forces differ."""
+    from step_oracle import StepChecker
+    task, env = make_task(256, motion="synthetic:2:1", **{"+solver.inertia_lag": 1})
+    assert task._sim_params.inertia_lag == 1 and task._sim_params.force_average == 0
+    env.reset()
+    chk = StepChecker(task)
+    for it in range(4):
+        chk.before()
+        actions = (torch.rand(256, 69, device=task.device) * 2 - 1) * 0.2
+        obs, rew, done, info = env.step(actions)
+        chk.after(obs, rew, done, info)
+        task.reset_done()
+    stand, env2 = make_task(64, motion="stand:4", **{"+solver.inertia_lag": 1})
+    env2.reset()
+    zero = (torch.zeros(64, 69, device=stand.device) - stand._pd_action_offset) / stand._pd_action_scale
+    for _ in range(60):
+        env2.step(zero)
+    torch.cuda.synchronize()
+    assert int(stand.progress_buf.min()) >= 60 and float(stand._rigid_body_pos[:, 0, 2].min()) > 0.85, "still standing after 2 s"
+    # force_average: same states, other published forces
+    outs = {}
+    for avg in (0, 1):
+        t, e = make_task(64, motion="synthetic:2:1", seed=3, **{"+solver.force_average": avg})
+        assert t._sim_params.force_average == avg
+        e.reset()
+        torch.manual_seed(11)
+        for _ in range(3):
+            e.step((torch.rand(64, 69, device=t.device) * 2 - 1) * 0.2)
+        torch.cuda.synchronize()
+        outs[avg] = (t._rigid_body_state.clone(), t._contact_forces.clone(), t.dof_force_tensor.clone())
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert not torch.equal(outs[0][2], outs[1][2]) and float((outs[0][1] - outs[1][1]).abs().max()) > 0.0
+
+
 def test_multi_clip_acceptance_pipeline_mechanics(tmp_path):
     """Round 5 (f-2 + f-3 together): scripts/multi_clip_acceptance.py end to end in a child process with tiny budgets -- the 16-clip locomotion library, the PNN learner,
     sweeps with soft auto-PMCP re-weighting, the `forward_pmcp` column copy, a hard-mined second stage with column 0 frozen, per-clip report.  Mechanics only (the learning
