@@ -299,27 +299,30 @@ def live_pmc(argv_tail, counter_groups):
     import tempfile
     if shutil.which("rocprofv3") is None:
         return None, "rocprofv3 not on PATH"
-    per = {}
+    per, failed = {}, []
     env = dict(os.environ, PHC_BENCH_CHILD="1", TMPDIR="/tmp")
-    for group in counter_groups:
+    for group in counter_groups:     # a group that fails (counter not offered on a box, time-out) does not take the others with it
         d = tempfile.mkdtemp(prefix="phc_pmc_", dir="/tmp")
         cmd = ["rocprofv3", "--pmc", *group.split(), "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "pmc", "--", sys.executable,
                os.path.abspath(__file__), "--steps", "20", "--warmup", "5", "--ppo-epochs", "0", "--no-cpu-baseline", "--no-pmc"] + argv_tail
         try:
             r = subprocess.run(cmd, env=env, cwd="/tmp", capture_output=True, text=True, timeout=240)
+            path = next((os.path.join(dp, f) for dp, _, fs in os.walk(d) for f in fs if f.endswith("counter_collection.csv")), None)
+            if r.returncode != 0 or path is None:
+                raise RuntimeError(f"rc={r.returncode}")
+            vals = {}
+            for row in csv.DictReader(open(path)):
+                vals.setdefault((row["Kernel_Name"].split("(")[0].replace("void ", ""), row["Counter_Name"]), []).append(float(row["Counter_Value"]))
+            for (k, c), v in vals.items():
+                v = sorted(v)
+                per.setdefault(k, {})[c] = (v[len(v) // 2], len(v))   # median: the first dispatches (everything reset at once) are not the steady state
         except Exception as exc:   # noqa: BLE001
-            return None, f"{group} pass failed: {type(exc).__name__}"
-        path = next((os.path.join(dp, f) for dp, _, fs in os.walk(d) for f in fs if f.endswith("counter_collection.csv")), None)
-        if r.returncode != 0 or path is None:
-            return None, f"{group} pass rc={r.returncode}"
-        vals = {}
-        for row in csv.DictReader(open(path)):
-            vals.setdefault((row["Kernel_Name"].split("(")[0].replace("void ", ""), row["Counter_Name"]), []).append(float(row["Counter_Value"]))
-        for (k, c), v in vals.items():
-            v = sorted(v)
-            per.setdefault(k, {})[c] = (v[len(v) // 2], len(v))   # median: the first dispatches (everything reset at once) are not the steady state
-        shutil.rmtree(d, ignore_errors=True)
-    return per, None
+            failed.append(f"{group}: {type(exc).__name__} {exc}"[:120])
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    if failed:
+        print(f"[bench] PMC passes that failed: {failed}", file=sys.stderr)
+    return (per, None) if per else (None, "; ".join(failed) or "no counters")
 
 
 def pmc_traffic_of(per, prefix):
@@ -542,7 +545,7 @@ def main():
                 traffic, detail = pmc_traffic_of(per, "k_sim_step<true")
                 traffic_src = {"live": detail} if traffic is not None else None
                 post_traffic, post_src = pmc_traffic_of(per, "k_im_post_physics")
-                k = next((k for k in per if k.startswith("k_sim_step<true") and "SQ_INSTS_VALU" in per[k]), None)
+                k = next((k for k in per if k.startswith("k_sim_step<true") and "SQ_INSTS_VALU" in per[k] and "SQ_ACTIVE_INST_VALU" in per[k]), None)
                 if k is not None:
                     c = {n: v[0] for n, v in per[k].items()}
                     sq = {"valu_instructions_per_wavefront": c["SQ_INSTS_VALU"] / max(c.get("SQ_WAVES", 0.0), 1.0),

@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--clips", type=int, default=64)
     ap.add_argument("--eval-every", type=int, default=500)
     ap.add_argument("--out", default="gpurun_out/multi_clip.json")
+    ap.add_argument("--fp32-gemm", action="store_true", help="fp32 GEMMs instead of bf16 (the reference trains in fp32, im.yaml:51; ~4 x slower update)")
     ap.add_argument("extra", nargs="*")
     a = ap.parse_args()
     log = lambda s: print(s, flush=True)
@@ -81,17 +82,17 @@ def main():
     lib = task._motion_lib
     log(f"library: {lib._num_unique_motions} clips, {a.envs} envs, overrides {over}")
     rows, t_all = [], time.time()
-    agent = IMAmpAgent(env, cfg)
+    agent = IMAmpAgent(env, cfg, bf16=not a.fp32_gemm)
     agent.init_train()
     n1 = train_for(agent, task, a.stage1_s, a.eval_every, log, rows, 1)
-    res = {"config": {"overrides": over, "stage1_s": a.stage1_s, "stage2_s": a.stage2_s}, "stage1_epochs": n1, "samples_stage1": n1 * agent.batch_size}
+    res = {"config": {"overrides": over, "stage1_s": a.stage1_s, "stage2_s": a.stage2_s, "gemm_dtype": "f32" if a.fp32_gemm else "bf16"}, "stage1_epochs": n1, "samples_stage1": n1 * agent.batch_size}
     res["primitive0_after_stage1"] = sweep(agent, "primitive 0 after stage 1", log)
     fail0 = np.array([v["failed"] for v in res["primitive0_after_stage1"]["per_clip"].values()])
     # ---- forward_pmcp: column 0 -> column 1; train column 1 on the failures with hard negative mining ----
     ck = forward_pmcp(agent.get_full_state_weights(), 0)
     task.cfg["env"]["training_prim"] = 1
     task.auto_pmcp, task.auto_pmcp_soft = True, False
-    agent2 = IMAmpAgent(env, cfg)
+    agent2 = IMAmpAgent(env, cfg, bf16=not a.fp32_gemm)
     agent2.set_full_state_weights(ck, load_optimizer=False)
     agent2.epoch_num = agent.epoch_num
     w0 = {k: v.clone() for k, v in agent2.model.state_dict().items() if ".pnn.actors.0." in k}
