@@ -1180,6 +1180,42 @@ class IMAmpAgent:
                     step_fps=self.batch_size / (t1 - t0), total_fps=self.batch_size / (t2 - t0))  # common_agent.py:134-138
         return info
 
+    def assemble_train_info(self, info):
+        """The scalars the reference hands its SummaryWriter / wandb every epoch, under the reference's tags (`CommonAgent._assemble_train_info`,
+        common_agent.py:603-626; `AMPAgent._assemble_train_info`, amp_agent.py:900-933): performance, learning rate, losses, discriminator statistics, reward
+        terms; plus the evaluation sweep's `eval/*` entries when the epoch ran one (im_amp.py:334-346).  (`loss/clip_frac`, `disc/agent_logit`, `disc/demo_logit` and
+        `disc/reward_std` are not formed on the fused device path and are left out.)"""
+        raw = list(info.get("reward_raw", [])) + [0.0] * 5
+        out = {"performance/update_time": info["update_time"], "performance/play_time": info["play_time"], "performance/total_fps": info["total_fps"],
+               "learning_rate/last_lr": self.last_lr, "learning_rate/lr_mul": 1.0, "learning_rate/e_clip": self.e_clip,
+               "loss/actor_loss": info["actor_loss"], "loss/critic_loss": info["critic_loss"], "loss/bounds_loss": info["b_loss"], "loss/entropy": info["entropy"],
+               "loss/kl": info["kl"], "disc/loss": info["disc_loss"], "disc/agent_acc": info["disc_agent_acc"], "disc/demo_acc": info["disc_demo_acc"],
+               "disc/grad_penalty": info["disc_grad_penalty"], "disc/logit_loss": info["disc_logit_loss"], "disc/reward_mean": info["mean_disc_reward"],
+               "rewards/mb_rewards": info["mean_task_reward"], "rewards/body_pos": raw[0], "rewards/body_rot": raw[1], "rewards/lin_vel": raw[2], "rewards/ang_vel": raw[3],
+               "rewards/power": raw[4]}
+        out.update({k: v for k, v in info.items() if k.startswith("eval/")})
+        return {k: float(v) for k, v in out.items()}
+
+    def _log_train_info(self, scalars, output_dir):
+        """`CommonAgent._log_train_info` (common_agent.py:627-635): `writer.add_scalar(tag, value, epoch)` for every entry.  tensorboardX / wandb are not part of
+        this image; the same (tag, value, step) stream goes to `<output_dir>/summaries/scalars.jsonl`, one line per epoch, and -- where a `torch.utils.tensorboard`
+        SummaryWriter can be made -- into event files next to it."""
+        import json
+        d = os.path.join(output_dir, "summaries")
+        if getattr(self, "_summary_file", None) is None:
+            os.makedirs(d, exist_ok=True)
+            self._summary_file = open(os.path.join(d, "scalars.jsonl"), "a")
+            try:
+                from torch.utils.tensorboard import SummaryWriter
+                self._summary_writer = SummaryWriter(d)
+            except Exception:   # noqa: BLE001  (no tensorboard package: the jsonl stream is the record)
+                self._summary_writer = None
+        self._summary_file.write(json.dumps({"step": self.epoch_num, "frame": self.frame, **scalars}) + "\n")
+        self._summary_file.flush()
+        if self._summary_writer is not None:
+            for k, v in scalars.items():
+                self._summary_writer.add_scalar(k, v, self.epoch_num)
+
     def train(self, max_epochs, log=print, output_dir=None):
         """Training loop with the reference's checkpoint / evaluation cadence (common_agent.py:142-165): with `output_dir`,
         `Humanoid.pth` every min(50, save_best_after) epochs; every `save_frequency` epochs (save_intermediate) also
@@ -1206,6 +1242,8 @@ class IMAmpAgent:
                     if hasattr(self.task, "_motion_lib") and hasattr(self.task, "_termination_distances"):
                         eval_info, _ = self.eval(output_dir=output_dir, log=log)
                         info.update(eval_info)
+            if output_dir is not None and self.rank == 0:
+                self._log_train_info(self.assemble_train_info(info), output_dir)
         return info
 
     def eval(self, output_dir=None, log=print):

@@ -326,7 +326,15 @@ def test_train_checkpoint_cadence_and_termination_history_restore(tmp_path):
     cfg.learning.params.config.save_intermediate = True
     agent = IMAmpAgent(FakeVecEnv(32), cfg, bf16=False)
     agent.train(4, log=None, output_dir=str(tmp_path))
-    assert sorted(os.listdir(tmp_path)) == ["Humanoid.pth", "Humanoid_00000002.pth", "Humanoid_00000004.pth"]   # Humanoid.pth written at epoch 3
+    assert sorted(os.listdir(tmp_path)) == ["Humanoid.pth", "Humanoid_00000002.pth", "Humanoid_00000004.pth", "summaries"]   # Humanoid.pth written at epoch 3
+    # the reference's per-epoch scalars (common_agent.py:603-635, amp_agent.py:900-933: writer.add_scalar(tag, value, epoch)) as a jsonl stream, its tags
+    import json
+    rows = [json.loads(l) for l in open(tmp_path / "summaries" / "scalars.jsonl")]
+    assert [r["step"] for r in rows] == [1, 2, 3, 4] and rows[-1]["frame"] == agent.frame
+    for tag in ("performance/update_time", "performance/play_time", "learning_rate/last_lr", "learning_rate/e_clip", "loss/actor_loss", "loss/critic_loss", "loss/bounds_loss",
+                "loss/entropy", "loss/kl", "disc/loss", "disc/agent_acc", "disc/demo_acc", "disc/grad_penalty", "disc/logit_loss", "disc/reward_mean", "rewards/mb_rewards",
+                "rewards/body_pos", "rewards/body_rot", "rewards/lin_vel", "rewards/ang_vel", "rewards/power"):
+        assert all(tag in r and np.isfinite(r[tag]) for r in rows), tag
 
     class Lib:
         def __init__(self):
