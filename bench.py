@@ -177,14 +177,14 @@ _REF_CACHE = {}
 
 def reference_timings():
     """The reference's own CPU stage timings (oracle/time_reference.py).  LIVE on this host when a copy of the reference is importable -- /root/reference in the
-    build container, or the git-ignored travel copy oracle/_ref that oracle/make_ref.py made and that rides along with the gpurun snapshot (the checker
+    build container, or the git-ignored travel archive oracle/_ref/reference_modules.zip that oracle/make_ref.py packed and that rides along with the gpurun snapshot (the checker
     being timed as a baseline; nothing of it is in the timed region of the path) -- else the newest committed profiles/*_reference_cpu_stages.json, with
     `measured_in` saying which.  -> (dict, source string) or (None, None)."""
     if "v" in _REF_CACHE:
         return _REF_CACHE["v"]
     import subprocess
     res = (None, None)
-    have = os.path.isdir("/root/reference/phc") or os.path.isdir(os.path.join(ROOT, "oracle", "_ref", "phc"))
+    have = os.path.isdir("/root/reference/phc") or os.path.isfile(os.path.join(ROOT, "oracle", "_ref", "reference_modules.zip"))
     if have and not os.environ.get("PHC_BENCH_NO_LIVE_REFERENCE"):
         try:
             r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "time_reference.py"), "--stdout"], capture_output=True, text=True, timeout=420,
@@ -205,7 +205,7 @@ def reference_timings():
 
 def cpu_reference():
     """The REFERENCE'S OWN CPU path (stages C1-C3: motion lookup x2, imitation reward + reset, self / task / AMP
-    observations; C0 load_motions) as measured by oracle/time_reference.py -- on THIS host's cores when the reference (or its travel copy) is present,
+    observations; C0 load_motions) as measured by oracle/time_reference.py -- on THIS host's cores when the reference (or its travel archive) is present,
     see reference_timings().  There is no reference CPU number for C4 (dynamics: closed Isaac Gym binary); `cpu_baseline` (kind "port") covers it."""
     d, src = reference_timings()
     if d is None:

@@ -1,12 +1,13 @@
-"""TEST INFRASTRUCTURE ONLY -- a travel copy of the reference modules the GPU-box legs need.
+"""TEST INFRASTRUCTURE ONLY -- a travel archive of the reference modules the GPU-box legs need.
 
 The reference is a Python checkout under /root/reference that exists in the build container only; the GPU box gets a snapshot of /root/repo.  This script
-copies EXACTLY the reference files that `oracle/time_reference.py` and `tests/test_reference_direct_gpu.py` import (found by importing them through
-`oracle/ref_shim.py` in a child interpreter and reading `sys.modules`), plus the one MJCF they parse, into `oracle/_ref/` -- which is listed in `.gitignore`
-(it never enters the history; like a built `.so` it only rides along with `gpurun` snapshots).  `__graft_entry__.build()` runs it whenever
-/root/reference is present.  `ref_shim.REFERENCE_ROOT` falls back to `oracle/_ref` where /root/reference does not exist.
+packs EXACTLY the reference files that `oracle/time_reference.py` and `tests/test_reference_direct_gpu.py` import (found by importing them through
+`oracle/ref_shim.py` in a child interpreter and reading `sys.modules`), plus the one MJCF they parse, into ONE archive `oracle/_ref/reference_modules.zip` --
+a built artefact like `oracle/_build/libphc_hostemu.so`: `oracle/_ref/` is listed in `.gitignore` (it never enters the history and holds no source tree;
+it only rides along with `gpurun` snapshots).  Python imports straight from the archive (zipimport).  `__graft_entry__.build()` runs this whenever
+/root/reference is present.  `ref_shim.REFERENCE_ROOT` falls back to the archive where /root/reference does not exist.
 
-    python oracle/make_ref.py            # -> oracle/_ref/{phc,poselib}/... + MANIFEST.txt
+    python oracle/make_ref.py            # -> oracle/_ref/reference_modules.zip + MANIFEST.txt
 """
 import json
 import os
@@ -46,23 +47,35 @@ def main():
         sys.stderr.write(out.stdout[-2000:] + out.stderr[-2000:])
         raise SystemExit("make_ref: importing the reference failed")
     files = json.loads(line[len("MANIFEST"):]) + DATA
+    import zipfile
     if os.path.isdir(DST):
         shutil.rmtree(DST)
-    n = 0
-    for rel in files:
-        dst = os.path.join(DST, rel)
-        os.makedirs(os.path.dirname(dst), exist_ok=True)
-        shutil.copy2(os.path.join(SRC, rel), dst)
-        n += os.path.getsize(dst)
+    os.makedirs(DST)
+    members = set(files)
+    for rel in files:     # package markers along the way (the reference's own, where it has them)
         d = os.path.dirname(rel)
-        while d:     # package markers along the way (the reference's own, where it has them)
-            init = os.path.join(d, "__init__.py")
-            if os.path.exists(os.path.join(SRC, init)) and not os.path.exists(os.path.join(DST, init)):
-                shutil.copy2(os.path.join(SRC, init), os.path.join(DST, init))
+        while d:
+            if os.path.exists(os.path.join(SRC, d, "__init__.py")):
+                members.add(os.path.join(d, "__init__.py"))
             d = os.path.dirname(d)
+    n = 0
+    with zipfile.ZipFile(os.path.join(DST, "reference_modules.zip"), "w", zipfile.ZIP_DEFLATED) as z:
+        for rel in sorted(members):
+            z.write(os.path.join(SRC, rel), rel)
+            n += os.path.getsize(os.path.join(SRC, rel))
+        # directories the reference imports as implicit namespace packages (no __init__.py of their own, e.g. phc/env/util): zipimport needs a marker
+        dirs = set()
+        for rel in members:
+            d = os.path.dirname(rel)
+            while d:
+                dirs.add(d)
+                d = os.path.dirname(d)
+        for d in sorted(dirs):
+            if os.path.join(d, "__init__.py") not in members and any(m.endswith(".py") and os.path.dirname(m) == d for m in members):
+                z.writestr(os.path.join(d, "__init__.py"), "")
     with open(os.path.join(DST, "MANIFEST.txt"), "w") as f:
-        f.write("# travel copy of reference files for the GPU-box legs (oracle/make_ref.py); git-ignored, never committed\n" + "\n".join(files) + "\n")
-    print(f"make_ref: {len(files)} files, {n / 1024:.0f} KiB -> {DST}")
+        f.write("# members of reference_modules.zip (oracle/make_ref.py): the reference files the GPU-box legs import; git-ignored, never committed\n" + "\n".join(sorted(members)) + "\n")
+    print(f"make_ref: {len(members)} files, {n / 1024:.0f} KiB -> {os.path.join(DST, 'reference_modules.zip')} ({os.path.getsize(os.path.join(DST, 'reference_modules.zip')) / 1024:.0f} KiB)")
     return 0
 
 

@@ -25,15 +25,32 @@ import sys
 import types
 from unittest.mock import MagicMock
 
-# /root/reference in the build container; on the GPU box the travel copy `oracle/_ref` that oracle/make_ref.py made (git-ignored, rides along with the
-# gpurun snapshot like a built .so): only the files oracle/time_reference.py and tests/test_reference_direct_gpu.py import
-_TRAVEL_COPY = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref")
+# /root/reference in the build container; on the GPU box the travel archive `oracle/_ref/reference_modules.zip` that oracle/make_ref.py packed (git-ignored,
+# rides along with the gpurun snapshot like a built .so): only the files oracle/time_reference.py and tests/test_reference_direct_gpu.py import.  Python
+# imports straight from the archive (zipimport: "<zip>" and "<zip>/phc" are valid sys.path entries).
+_TRAVEL_COPY = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref", "reference_modules.zip")
 REFERENCE_ROOT = os.environ.get("PHC_REFERENCE_ROOT") or ("/root/reference" if os.path.isdir("/root/reference/phc") else _TRAVEL_COPY)
+
+
+def is_archive():
+    return REFERENCE_ROOT.endswith(".zip")
 
 
 def available():
     """Is some copy of the reference importable here?"""
-    return os.path.isdir(os.path.join(REFERENCE_ROOT, "phc"))
+    return os.path.isfile(REFERENCE_ROOT) if is_archive() else os.path.isdir(os.path.join(REFERENCE_ROOT, "phc"))
+
+
+def data_path(rel):
+    """A real file path for a data file of the reference (an MJCF): the file itself, or its member of the travel archive extracted to a temp dir."""
+    if not is_archive():
+        return os.path.join(REFERENCE_ROOT, rel)
+    import tempfile
+    import zipfile
+    d = tempfile.mkdtemp(prefix="phc_ref_")
+    with zipfile.ZipFile(REFERENCE_ROOT) as z:
+        return z.extract(rel, d)
+
 
 _MOCK_TOPLEVEL = (
     "isaacgym", "smpl_sim", "smplx", "open3d", "imageio", "aiohttp", "cv2", "gym",
@@ -97,8 +114,8 @@ def install():
     global _installed
     if _installed:
         return
-    if not os.path.isdir(REFERENCE_ROOT):
-        raise RuntimeError(f"reference not found at {REFERENCE_ROOT}; the shim needs /root/reference (build container) or the travel copy oracle/_ref (oracle/make_ref.py)")
+    if not available():
+        raise RuntimeError(f"reference not found at {REFERENCE_ROOT}; the shim needs /root/reference (build container) or the travel archive oracle/_ref/reference_modules.zip (oracle/make_ref.py)")
     import numpy as np
     import torch
 

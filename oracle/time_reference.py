@@ -1,7 +1,7 @@
 """TEST INFRASTRUCTURE ONLY -- time the *reference's own* CPU reward / FK / observation path (SURVEY.md 8d "CPU baseline
 beside it"): the unmodified reference functions imported through ``oracle/ref_shim.py``, on the host cores of the machine
-this runs on.  /root/reference does not exist on the GPU box; since round 5 a git-ignored travel copy of exactly the imported reference files
-(`oracle/_ref`, made by oracle/make_ref.py in the build container) rides along with the gpurun snapshot, so bench.py's `cpu_reference` / `config0`
+this runs on.  /root/reference does not exist on the GPU box; since round 5 a git-ignored travel archive of exactly the imported reference files
+(`oracle/_ref/reference_modules.zip`, packed by oracle/make_ref.py in the build container; zipimport) rides along with the gpurun snapshot, so bench.py's `cpu_reference` / `config0`
 legs run this script LIVE on the GPU box's host cores (`--stdout`); without either copy bench.py falls back to the newest committed file:
 
     python oracle/time_reference.py [rNN]      # -> profiles/rNN_reference_cpu_stages.json (default r05)
@@ -37,7 +37,7 @@ import torch  # noqa: E402
 
 from phc_amd.utils.synthetic_motion import make_motion_dict  # noqa: E402
 
-MJCF = os.path.join(ref_shim.REFERENCE_ROOT, "phc/data/assets/mjcf/smpl_0_humanoid.xml")
+MJCF = ref_shim.data_path("phc/data/assets/mjcf/smpl_0_humanoid.xml")
 KEY_BODIES = ["R_Ankle", "L_Ankle", "R_Wrist", "L_Wrist"]
 
 
@@ -161,9 +161,8 @@ def main():
     out["date"] = time.strftime("%Y-%m-%d")
     out["protocol"] = "BASELINE.md section 2: 5 warm-up + 50 timed iterations, median; torch.set_num_threads(all usable cores); fp32"
     import socket
-    travel = os.path.realpath(ref_shim.REFERENCE_ROOT) == os.path.realpath(os.path.join(HERE, "_ref"))
     out["measured_in"] = (f"this host ({socket.gethostname()}): the reference's modules from " +
-                          ("the travel copy oracle/_ref (oracle/make_ref.py)" if travel else ref_shim.REFERENCE_ROOT + " (build container)"))
+                          ("the travel archive oracle/_ref/reference_modules.zip (oracle/make_ref.py)" if ref_shim.is_archive() else ref_shim.REFERENCE_ROOT + " (build container)"))
     out["has_gpu"] = bool(torch.cuda.is_available())
     if "--stdout" in sys.argv:      # bench.py's live `cpu_reference` leg: one JSON line, nothing written
         print("REFERENCE_JSON" + json.dumps(out))

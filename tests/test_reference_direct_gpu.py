@@ -1,7 +1,7 @@
 """BASELINE configs[1] at its own size (4096 envs) against the REFERENCE'S OWN FUNCTIONS, imported -- not through the numpy restatement.
 
-Round 5: `oracle/make_ref.py` leaves a git-ignored travel copy of exactly the reference files these legs import in `oracle/_ref`
-(it rides along with the gpurun snapshot like a built .so); `oracle/ref_shim.py` imports /root/reference in the build container and that copy on the GPU
+Round 5: `oracle/make_ref.py` packs exactly the reference files these legs import into the git-ignored archive `oracle/_ref/reference_modules.zip`
+(it rides along with the gpurun snapshot like a built .so); `oracle/ref_shim.py` imports /root/reference in the build container and that archive (zipimport) on the GPU
 box.  Every output of `phc_im_post_physics` for one env step of the HIP task is recomputed here by the reference: `MotionLibSMPL.get_motion_state`
 (motion_lib_base.py:437-520, on a `__new__`-made library that holds the task's own clip tensors), `compute_imitation_reward`, `compute_humanoid_im_reset`
 (humanoid_im.py:1524-1608), `compute_humanoid_observations_smpl_max` (humanoid.py:1995-2052), `compute_imitation_observations_v6` (humanoid_im.py:1309-1360),
@@ -13,7 +13,7 @@ import torch
 
 import ref_shim
 
-pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not ref_shim.available(), reason="no copy of the reference here (oracle/make_ref.py makes the travel copy)")]
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not ref_shim.available(), reason="no copy of the reference here (oracle/make_ref.py packs the travel archive)")]
 
 N = 4096
 
