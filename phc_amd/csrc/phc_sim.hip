@@ -145,6 +145,8 @@ __device__ __forceinline__ bool stage_aligned(const phc_sim_state_t& sim) {
 // of scratch) keeps 3072 wavefronts resident instead of 2048 -- and was measured SLOWER at every size (round 4, profiles/r04_stepper/occupancy_2_vs_3_waves_per_simd.txt:
 // 96.6 vs 78.0 us at 4096 envs, 168.9 vs 145.3 at 8192, 241.0 vs 211.9 at 12288): the spilled wavefront's longer stream costs more than the
 // third resident wavefront hides.  Kept behind lane_mapping = 3 so that the measurement can be repeated; never chosen automatically.
+// (Round 5: the per-lane force accumulators of `force_average` took the workgroup's LDS from 16.9 to 18.4 KB; eight workgroups per CU = two per SIMD still fit
+// the 160 KB, a third per SIMD would not -- the compiler says so when it builds this instantiation; the knob now measures the 168-VGPR code at occupancy 2.)
 // LAG: the instantiation whose sub-steps behind the first one of a simulate() call keep its articulated inertias (phc_sim_params_t.inertia_lag); a
 // template parameter, not a run-time branch: with the switch compiled into the one kernel it took 256 VGPRs + 12 spilled SGPRs instead of 224 and the
 // every-sub-step-fresh launch went from 77 to 82 us (round 5, same box).
