@@ -436,6 +436,8 @@ class HumanoidIm:
             # round 5 (ABI 35): `+solver.inertia_lag=1` keeps the articulated inertias of a simulate() call's first sub-step over its other sub-steps;
             # `+solver.force_average=1` publishes contact_force / dof_force as means over the env step's sub-steps instead of the last one's values
             inertia_lag=int(bool(solver.get("inertia_lag", 0))), force_average=int(bool(solver.get("force_average", 0))))
+        if self._sim_params.inertia_lag and self._env_shape is not None:
+            raise ValueError("solver.inertia_lag is not built for per-env body shapes (robot.has_shape_variation): the lagged stepper instantiation exists for one shared model")
         if self._sim_params.contact_model == 1 and max((int(c) for c in np.bincount(self.model.contact_body, minlength=1)), default=0) > 32:
             # (the rigid model's per-point active / released sets are 32-bit masks: a point beyond bit 31 could never be released)
             raise ValueError("solver.contact=tgs supports at most 32 ground-contact points per body; this model has more (use the penalty model)")
