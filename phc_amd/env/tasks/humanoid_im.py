@@ -692,6 +692,13 @@ class HumanoidIm:
             # "stand[:seconds]" -- the rest pose standing still (a physically feasible clip for end-to-end sanity runs)
             from ...utils.synthetic_motion import make_stand_clip
             mf = {"stand_00000": make_stand_clip(self.model, float(mf.split(":")[1]) if ":" in mf else 10.0)}
+        if isinstance(mf, str) and mf.split(":")[0] in ("stand", "armswing") and self._is_robot:
+            # robots: "stand[:seconds]" / "armswing[:seconds]" -- the default joint pose standing still / with swinging shoulder-pitch joints (round 5)
+            from ...utils.synthetic_motion import make_robot_stand_clip
+            from ...robots import ROBOTS
+            kind = mf.split(":")[0]
+            mf = {f"{kind}_00000": make_robot_stand_clip(self.model, ROBOTS[self.humanoid_type]["default_dof_pos"], float(mf.split(":")[1]) if ":" in mf else 10.0,
+                                                        num_extend=self.num_extend_bodies, arm_swing=0.5 if kind == "armswing" else 0.0)}
         if isinstance(mf, str) and mf.split(":")[0] in ("squat", "stepinplace", "walk") and not self._is_robot:
             # "squat | stepinplace | walk[:seconds]" -- locomotion-class sanity clips (leg IK on prescribed pelvis / foot trajectories: feet leave the
             # ground and come back without sliding, the walk translates the centre of mass at 0.7 m/s)

@@ -472,6 +472,10 @@ class IMAmpAgent:
             if self._roll_graphs:
                 torch.cuda.synchronize()
                 self._roll_graphs.clear()
+                # ... and their memory pool with them (round 5): with every graph of the pool destroyed its use count is zero, and capturing into the
+                # same pool id again trips `use_count > 0` in HIPCachingAllocator unless empty_cache() could free the whole pool -- it cannot while any
+                # tensor allocated during a capture is still referenced (robots: a Unitree H1 run crashed at epoch 101, its first resample_motions())
+                self._roll_pool = None
             self._roll_generation = gen
         done_indices = []
         net = self.model.a2c_network

@@ -129,6 +129,28 @@ def make_robot_clip(rng, model, num_frames, num_extend=3, fps=30, root_height=1.
     return {"pose_aa": pose_aa.astype(np.float32), "root_trans_offset": trans.astype(np.float64), "dof": dof.astype(np.float32), "fps": fps}
 
 
+def make_robot_stand_clip(model, default_dof_pos, seconds=10.0, fps=30, num_extend=3, arm_swing=0.0, freq=0.4):
+    """A physically feasible clip for a revolute-joint robot (round 5: policy-level acceptance of BASELINE configs[4]): the reference's default joint pose
+    (`humanoid.py:1121,1181`, robots.py) standing still -- with `arm_swing` > 0 the shoulder-pitch joints swing in antiphase by that many radians at `freq` Hz,
+    ramped in over the first second.  Same schema as `make_robot_clip`; the motion library's height fix puts the soles on the ground."""
+    T, nd = int(round(seconds * fps)) + 1, model.num_dof
+    dof = np.tile(np.asarray(default_dof_pos, np.float64)[None], (T, 1))
+    if arm_swing > 0:
+        t = np.arange(T) / fps
+        ramp = np.clip(t / 1.0, 0.0, 1.0)
+        for i, name in enumerate(model.body_names):
+            if "shoulder_pitch" in name:
+                sgn = 1.0 if name.startswith("left") else -1.0
+                dof[:, model.dof_start[i]] += sgn * arm_swing * np.sin(2 * np.pi * freq * t) * ramp
+    pose_aa = np.zeros((T, model.num_bodies + num_extend, 3))
+    for i in range(1, model.num_bodies):
+        s_ = model.dof_start[i]
+        pose_aa[:, i] = model.dof_axis[s_][None] * dof[:, s_:s_ + 1]
+    trans = np.zeros((T, 3))
+    trans[:, 2] = 1.0
+    return {"pose_aa": pose_aa.astype(np.float32), "root_trans_offset": trans.astype(np.float64), "dof": dof.astype(np.float32), "fps": fps}
+
+
 def make_robot_motion_dict(model, num_clips, seed=0, mean_seconds=8.0, fps=30, lengths=None, num_extend=3, min_frames=30):
     """`make_motion_dict` for a revolute-joint robot (H1)."""
     rng = np.random.default_rng(seed)

@@ -1234,6 +1234,28 @@ def test_rollout_graphs_follow_resample_motions_and_evaluate():
     assert all(runs.values())
 
 
+def test_rollout_graphs_survive_a_resample_on_a_robot():
+    """Round 5: a Unitree H1 learning run crashed at epoch 101 (`use_count > 0` INTERNAL ASSERT in HIPCachingAllocator, from `torch.cuda.graph(..., pool=...)`): the H1 task
+    resamples its motions every 100 epochs, the learner dropped every rollout graph -- and then captured into the dead graphs' pool id.  With the interval cut to 4 epochs
+    the same sequence runs here in seconds: graphs from epoch 3, a resample at epochs 5 and 9, fresh graphs in a fresh pool each time."""
+    from phc_amd.learning.amp_agent import IMAmpAgent
+    over = {"robot": "unitree_h1", "env": "env_im_h1_phc", "sim": "robot_sim", "control": "robot_control", "env.shape_resampling_interval": 4,
+            "learning.params.config.minibatch_size": 2048, "learning.params.config.amp_obs_demo_buffer_size": 4096,
+            "learning.params.config.amp_replay_buffer_size": 4096, "+learning.params.config.hip_graph": True}
+    task, env = make_task(256, motion="stand:4", seed=2, **over)
+    agent = IMAmpAgent(env, task.cfg)
+    agent.init_train()
+    gens, pools = set(), set()
+    for _ in range(10):
+        agent.train_epoch()                          # pre_epoch(): resample_motions() when epoch_num % 4 == 1
+        gens.add(task.launch_generation())
+        if getattr(agent, "_roll_pool", None) is not None:
+            pools.add(tuple(agent._roll_pool))
+    assert len(gens) >= 3, gens
+    assert any(k[0] == "step" for k in agent._roll_graphs) and len(pools) >= 2, pools
+    assert torch.isfinite(task.obs_buf).all()
+
+
 def test_tgs_contact_option_env_steps_match_the_dense_oracle_and_the_humanoid_stands():
     """`+solver.contact=tgs` (phc_sim_params_t.contact_model 1, ABI 34): the task installs the rigid ground-contact model with the PhysX parameters of
     sim/default_sim.yaml (4 passes, max_depenetration_velocity 10, bounce threshold 0.2); whole env steps agree with the fp64 dense oracle of the

@@ -84,3 +84,27 @@ def test_fit_recovers_a_robot_clip_and_loads_into_the_motion_library():
             raise
         return
     assert lib._motion_num_frames.tolist() == [T, T]
+
+
+@pytest.mark.parametrize("name", ["unitree_h1", "unitree_g1"])
+def test_robot_stand_and_armswing_clips(name):
+    """`env.motion_file=stand | armswing` on a robot (round 5, profiles/r05_robots/): the default joint pose held still; with `arm_swing` only the two shoulder-pitch
+    joints move, in antiphase, ramped in from rest; `pose_aa` is the per-joint axis times the joint angle (what the motion library's FK consumes)."""
+    from phc_amd.utils.synthetic_motion import make_robot_stand_clip
+    rc, model = _robot(name)
+    q0 = np.asarray(robots.ROBOTS[rc["humanoid_type"]]["default_dof_pos"])
+    ne = len(rc["extend_config"])
+    still = make_robot_stand_clip(model, q0, seconds=2.0, num_extend=ne)
+    T = 61
+    assert still["dof"].shape == (T, model.num_dof) and still["pose_aa"].shape == (T, model.num_bodies + ne, 3) and still["fps"] == 30
+    np.testing.assert_allclose(still["dof"], np.tile(q0[None], (T, 1)), atol=1e-7)
+    swing = make_robot_stand_clip(model, q0, seconds=2.0, num_extend=ne, arm_swing=0.5)
+    moved = np.flatnonzero(np.abs(swing["dof"] - still["dof"]).max(0) > 0)
+    names = [n for i, n in enumerate(model.body_names) if i > 0 and model.dof_start[i] in moved]
+    assert len(moved) == 2 and all("shoulder_pitch" in n for n in names), names
+    d = swing["dof"][:, moved] - still["dof"][:, moved]
+    np.testing.assert_allclose(d[:, 0], -d[:, 1], atol=1e-7)
+    assert d[0].max() == 0 and 0.3 < np.abs(d).max() <= 0.5
+    for i in range(1, model.num_bodies):
+        s = model.dof_start[i]
+        np.testing.assert_allclose(swing["pose_aa"][:, i], model.dof_axis[s][None] * swing["dof"][:, s:s + 1], atol=1e-6)
