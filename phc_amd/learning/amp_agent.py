@@ -261,12 +261,13 @@ class IMAmpAgent:
         assert self.batch_size % self.minibatch_size == 0
         self.num_minibatches = self.batch_size // self.minibatch_size
         self.mini_epochs_num = c["mini_epochs"]
-        # round 5 (profiles/r05_multi_clip/README.md): with the shipped lr / fixed sigma the multi-clip runs of this repository learn at 24 optimizer steps per rollout (2048 envs as
-        # shipped, 4096 envs with mini_epochs=3) and drift into a policy that fails every clip at 48 (4096 envs as shipped) and 96 (8192 envs); the reference's 3072 envs give 36
+        # round 5 (profiles/r05_multi_clip/README.md): with the shipped lr / fixed sigma the multi-clip runs of this repository learn the 64-clip library at 24 optimizer steps per rollout
+        # (2048 envs as shipped; 4096 envs with mini_epochs=3; 8192 envs with mini_epochs=3 and minibatch 32768) and NOT at 36 (3072 envs as shipped, the reference's own configuration: static
+        # clips only), 48 (4096 envs as shipped) or 96 (8192 envs); halving the learning rate at 36 steps does not help.  Single clips are not affected.
         steps = self.mini_epochs_num * self.num_minibatches
-        if steps > 36 and self.rank == 0 and str(self.device).startswith("cuda") and not os.environ.get("PHC_QUIET"):
-            print(f"[phc_amd] {steps} optimizer steps per rollout (mini_epochs {self.mini_epochs_num} x {self.num_minibatches} minibatches of {self.minibatch_size}): the shipped yaml is tuned for "
-                  f"3072 envs = 36; multi-clip runs here plateau above that -- consider learning.params.config.mini_epochs={max(1, 24 // self.num_minibatches)} or a larger minibatch_size "
+        if steps > 24 and self.rank == 0 and str(self.device).startswith("cuda") and not os.environ.get("PHC_QUIET"):
+            print(f"[phc_amd] {steps} optimizer steps per rollout (mini_epochs {self.mini_epochs_num} x {self.num_minibatches} minibatches of {self.minibatch_size}): multi-clip libraries were "
+                  f"learned here at 24 and not at 36 / 48 / 96 -- consider learning.params.config.mini_epochs={max(1, 24 // self.num_minibatches)} or a larger minibatch_size "
                   f"(profiles/r05_multi_clip/README.md)", file=sys.stderr)
         self.gamma, self.tau = c["gamma"], c["tau"]
         self.e_clip, self.critic_coef, self.entropy_coef = c["e_clip"], c["critic_coef"], c["entropy_coef"]
