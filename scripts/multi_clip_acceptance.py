@@ -1,7 +1,7 @@
 """Round 5: multi-clip policy-level acceptance -- the closest offline analogue of the reference's acceptance numbers (README.MD:107-118).
 
 A 64-clip library of feasible locomotion clips (`env.motion_file=locomotion:64:0`: stand, arm swing, step in place, walk at 0.3-0.8 m/s in all headings, two
-squats), 8192 envs, the PNN learner (`learning=im_pnn env=env_im_pnn`):
+squats), 2048 envs by default (24 optimizer steps per rollout with the shipped yaml: what learns here, profiles/r05_multi_clip/README.md), the PNN learner (`learning=im_pnn env=env_im_pnn`):
   stage 1  primitive 0 trained on the whole set; every `--eval-every` epochs the evaluation sweep (`IMAmpAgent.eval` = im_amp.py:136-242: every clip from
            t = 0, deterministic policy, 0.5 m mean-distance termination) re-weights the clip sampling (soft auto-PMCP, im_amp.py:126-132);
   copy     `forward_pmcp` (scripts/pmcp/forward_pmcp.py:44-51): column 0 -> column 1, column 0 frozen (`training_prim=1`);
@@ -9,7 +9,7 @@ squats), 8192 envs, the PNN learner (`learning=im_pnn env=env_im_pnn`):
   report   the sweep with each primitive: success rate, G-MPJPE per clip and per clip class; a clip counts as covered when one primitive tracks it (what
            the composer of the next PHC stage selects between).
 
-    python scripts/multi_clip_acceptance.py [--stage1-s 480] [--stage2-s 240] [--envs 8192] [--clips 64] [--out gpurun_out/multi_clip.json]
+    python scripts/multi_clip_acceptance.py [--stage1-s 480] [--stage2-s 240] [--envs 2048] [--clips 64] [--out gpurun_out/multi_clip.json]
 """
 import argparse
 import json
@@ -66,7 +66,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--stage1-s", type=float, default=480.0)
     ap.add_argument("--stage2-s", type=float, default=240.0)
-    ap.add_argument("--envs", type=int, default=8192)
+    ap.add_argument("--envs", type=int, default=2048)
     ap.add_argument("--clips", type=int, default=64)
     ap.add_argument("--eval-every", type=int, default=500)
     ap.add_argument("--out", default="gpurun_out/multi_clip.json")
