@@ -460,7 +460,7 @@ class IMAmpAgent:
         if getattr(self, "_terminated_flags", None) is None:
             self._terminated_flags = torch.zeros(self.num_actors, device=self.device)
             self._reward_raw_acc = None
-            self._roll_graphs = {}
+            self._roll_graphs, self._roll_pool = {}, None
             self._env_actions = torch.empty_like(self.exp["actions"][0])
         terminated_flags = self._terminated_flags.zero_()
         if self._reward_raw_acc is not None:
