@@ -263,7 +263,7 @@ class IMAmpAgent:
         self.mini_epochs_num = c["mini_epochs"]
         # round 5 (profiles/r05_multi_clip/README.md): with the shipped lr / fixed sigma the multi-clip runs of this repository learn the 64-clip library at 24 optimizer steps per rollout
         # (2048 envs as shipped; 4096 envs with mini_epochs=3; 8192 envs with mini_epochs=3 and minibatch 32768) and NOT at 36 (3072 envs as shipped, the reference's own configuration: static
-        # clips only), 48 (4096 envs as shipped) or 96 (8192 envs); halving the learning rate at 36 steps does not help.  Single clips are not affected.
+        # clips only), 48 (4096 envs as shipped) or 96 (8192 envs); halving the learning rate at 36 steps did not help within the same budget.  Single clips are not affected.
         steps = self.mini_epochs_num * self.num_minibatches
         if steps > 24 and self.rank == 0 and str(self.device).startswith("cuda") and not os.environ.get("PHC_QUIET"):
             print(f"[phc_amd] {steps} optimizer steps per rollout (mini_epochs {self.mini_epochs_num} x {self.num_minibatches} minibatches of {self.minibatch_size}): multi-clip libraries were "
