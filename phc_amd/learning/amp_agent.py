@@ -262,7 +262,7 @@ class IMAmpAgent:
         self.num_minibatches = self.batch_size // self.minibatch_size
         self.mini_epochs_num = c["mini_epochs"]
         # round 5 (profiles/r05_multi_clip/README.md): with the shipped lr / fixed sigma the multi-clip runs of this repository learn the 64-clip library at 24 optimizer steps per rollout
-        # (2048 envs as shipped; 4096 envs with mini_epochs=3; 8192 envs with mini_epochs=3 and minibatch 32768) and NOT at 36 (3072 envs as shipped, the reference's own configuration: static
+        # (2048 envs as shipped; 3072 envs with mini_epochs=4; 4096 envs with mini_epochs=3; 8192 envs with mini_epochs=3 and minibatch 32768) and NOT at 36 (3072 envs as shipped, the reference's own configuration: static
         # clips only), 48 (4096 envs as shipped) or 96 (8192 envs); halving the learning rate at 36 steps did not help within the same budget.  Single clips are not affected.
         steps = self.mini_epochs_num * self.num_minibatches
         if steps > 24 and self.rank == 0 and str(self.device).startswith("cuda") and not os.environ.get("PHC_QUIET"):
