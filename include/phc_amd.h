@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PHC_ABI_VERSION 35
+#define PHC_ABI_VERSION 36
 #define PHC_MAX_BODIES 64   /* bodies (incl. extended reference bodies) per articulation; also the slot count of the model tables */
 #define PHC_EINVAL (-1)
 #define PHC_EUNSUPPORTED (-2)
@@ -417,7 +417,9 @@ int32_t phc_sum_slabs_bf16(const void* part, int32_t slabs, int64_t n, float* ou
 
 /* Discriminator loss pieces (phc/learning/amp_agent.py:732-808 `_disc_loss`).
  * phc_disc_bce: logits [n_agent + n_demo] (agent and replay rows first, demo rows last; bf16 or fp32):
- *   stats[0] = scale * 0.5 (BCEWithLogits(agent, 0) + BCEWithLogits(demo, 1)), stats[1] = mean(agent < 0), stats[2] = mean(demo > 0);
+ *   stats[0] = scale * 0.5 (BCEWithLogits(agent, 0) + BCEWithLogits(demo, 1)), stats[1] = mean(agent < 0), stats[2] = mean(demo > 0),
+ *   stats[3] = mean(agent logits), stats[4] = mean(demo logits) (ABI 36: `stats` holds 5 floats; the reference's `disc/agent_logit`, `disc/demo_logit`
+ *   scalars, amp_agent.py:911-912);
  *   grad [same shape / type] = d stats[0] / d logits.
  * phc_weighted_sumsq: out[0] = sum_i coefs[i] * |tensors[i]|^2 over count <= 4 device tensors of sizes[i] elements (all fp32 or all
  *   bf16): the logit regulariser + weight decay in one pass, or -- one bf16 tensor, coef = c / rows -- the gradient penalty
@@ -470,7 +472,8 @@ int32_t phc_adam_clip_step(float* param, float* grad, float* exp_avg, float* exp
  *   loss = mean(max(-adv r, -adv clamp(r, 1 -+ e_clip))) + critic_coef mean(c_loss) - entropy_coef entropy + bounds_loss_coef mean(b_loss),
  *   r = exp(old_neglogp - neglogp(actions | mu, exp(logstd)))
  * mu [B, D] and value [B] are the network heads (bf16 when is_bf16, else fp32); grad_mu / grad_value receive d loss / d mu, d loss / d value
- * in the same type; stats[6] = loss, mean a_loss, mean c_loss, mean b_loss, entropy, mean kl(policy || old policy).
+ * in the same type; stats[7] = loss, mean a_loss, mean c_loss, mean b_loss, entropy, mean kl(policy || old policy), mean(|r - 1| > e_clip)
+ * (ABI 36: the clip fraction, `actor_clipped` of common_agent.py:570-571 -> `loss/clip_frac`).
  * old_values is only read when clip_value.  row_index (optional, [B] int64): minibatch row r takes actions / old_* / advantages /
  * returns from row row_index[r] of the rollout tensors (mu, value and the gradients stay minibatch-ordered).
  * workspace: phc_ppo_loss_workspace() bytes. */

@@ -10,9 +10,14 @@ Everything PHC itself owns on the learner path is NOT restated: with these stand
 and `oracle/gen_golden_learner.py` calls their method bodies (losses, GAE, discriminator reward, `calc_gradients`, the
 checkpoint loaders) to produce `tests/golden/learner_*.npz`.
 
-The agent base classes (`a2c_continuous.A2CAgent`, `a2c_common.A2CBase`, players) are EMPTY real classes: the reference's
+The agent base classes (`a2c_continuous.A2CAgent`, `a2c_common.A2CBase`, players) carry no constructor: the reference's
 constructors are never run (they need a simulator); instances are made with `__new__` and given exactly the attributes the
-called method reads."""
+called method reads.  For the whole-epoch fixture (oracle/gen_golden_epoch.py: the reference's `play_steps`, `prepare_dataset`,
+`train_epoch`, `AMPDataset`, `ReplayBuffer`, `_store_replay_amp_obs` bodies run unmodified) the base class restates the handful of
+rl-games methods those bodies call -- `init_tensors` + `ExperienceBuffer.update_data / get_transformed_list` (rl_games/common/experience.py),
+`env_step`, `preprocess_actions`, `obs_to_tensors`, `train_actor_critic`, `update_lr` (a2c_common.py / a2c_continuous.py), `PPODataset`
+(common/datasets.py), `DefaultRewardsShaper` (common/tr_helpers.py), `AverageMeter` (algos_torch/torch_ext.py), `IdentityScheduler`
+(common/schedulers.py) -- all PARITY UNPINNED like the rest of this file."""
 import sys
 import types
 
@@ -155,6 +160,40 @@ def register():
 
     class A2CBase(_Empty):
         # rl_games/common/a2c_common.py: A2CBase.set_eval / set_train (the reference's AMPAgent.set_train calls super())
+        # ... and, for oracle/gen_golden_epoch.py (the reference's play_steps / prepare_dataset / train_epoch run on a `__new__`-made agent), the
+        # few base-class methods those bodies call: obs_to_tensors, preprocess_actions, env_step, train_actor_critic, update_lr
+        def obs_to_tensors(self, obs):
+            return obs if isinstance(obs, dict) else {"obs": obs}
+
+        def preprocess_actions(self, actions):
+            if self.clip_actions:
+                return _rescale_actions(self.actions_low, self.actions_high, torch.clamp(actions, -1.0, 1.0))
+            return actions
+
+        def env_step(self, actions):
+            actions = self.preprocess_actions(actions)
+            obs, rewards, dones, infos = self.vec_env.step(actions)
+            if self.value_size == 1:
+                rewards = rewards.unsqueeze(1)
+            return self.obs_to_tensors(obs), rewards.to(self.ppo_device), dones.to(self.ppo_device), infos
+
+        def train_actor_critic(self, input_dict):   # rl_games/algos_torch/a2c_continuous.py
+            self.calc_gradients(input_dict)
+            return self.train_result
+
+        def update_lr(self, lr):
+            for g in self.optimizer.param_groups:
+                g["lr"] = lr
+
+        def init_tensors(self):   # A2CBase.init_tensors + ContinuousA2CBase.init_tensors
+            n = self.num_agents * self.num_actors
+            self.experience_buffer = ExperienceBuffer(self.horizon_length, n, self.obs_shape, self.actions_num, self.value_size, self.ppo_device)
+            self.current_rewards = torch.zeros((n, self.value_size), dtype=torch.float32, device=self.ppo_device)
+            self.current_lengths = torch.zeros(n, dtype=torch.float32, device=self.ppo_device)
+            self.dones = torch.ones((n,), dtype=torch.uint8, device=self.ppo_device)
+            self.update_list = ["actions", "neglogpacs", "values", "mus", "sigmas"]
+            self.tensor_list = self.update_list + ["obses", "states", "dones"]
+
         def set_eval(self):
             self.model.eval()
             if self.normalize_input:
@@ -178,8 +217,23 @@ def register():
     class DiscreteA2CAgent(A2CBase):
         pass
 
-    class PPODataset(_Empty):
-        pass
+    class PPODataset:
+        """rl_games/common/datasets.py: the minibatch view of one rollout (the reference's AMPDataset overrides _get_item / the shuffling)."""
+
+        def __init__(self, batch_size, minibatch_size, is_discrete, is_rnn, device, seq_len):
+            self.is_rnn, self.seq_len, self.batch_size, self.minibatch_size, self.device = is_rnn, seq_len, batch_size, minibatch_size, device
+            self.length = self.batch_size // self.minibatch_size
+            self.is_discrete, self.is_continuous = is_discrete, not is_discrete
+            self.special_names = ["rnn_states"]
+
+        def update_values_dict(self, values_dict):
+            self.values_dict = values_dict
+
+        def __len__(self):
+            return self.length
+
+        def __getitem__(self, idx):
+            return self._get_item_rnn(idx) if self.is_rnn else self._get_item(idx)
 
     class BasePlayer(_Empty):
         pass
@@ -193,6 +247,75 @@ def register():
     _module("rl_games.common.datasets", PPODataset=PPODataset)
     _module("rl_games.common.player", BasePlayer=BasePlayer)
     _module("rl_games.algos_torch.players", PpoPlayerContinuous=PpoPlayerContinuous, rescale_actions=_rescale_actions)
+
+
+class ExperienceBuffer:
+    """rl_games/common/experience.py, the part a continuous-action, single-agent, non-recurrent rollout uses: [T, N, ...] tensors by name."""
+
+    def __init__(self, horizon_length, num_actors, obs_shape, actions_num, value_size, device):
+        self.obs_base_shape = (horizon_length, num_actors)
+        z = lambda *s, dtype=torch.float32: torch.zeros(self.obs_base_shape + s, dtype=dtype, device=device)
+        self.tensor_dict = {"obses": z(*obs_shape), "rewards": z(value_size), "values": z(value_size), "neglogpacs": z(),
+                            "dones": z(dtype=torch.uint8), "actions": z(actions_num), "mus": z(actions_num), "sigmas": z(actions_num)}
+
+    def update_data(self, name, index, val):
+        self.tensor_dict[name][index, :] = val
+
+    def get_transformed_list(self, transform_op, tensor_list):
+        res = {}
+        for k in tensor_list:
+            v = self.tensor_dict.get(k)
+            if v is None:
+                continue
+            res[k] = transform_op(v)
+        return res
+
+
+class DefaultRewardsShaper:
+    """rl_games/common/tr_helpers.py."""
+
+    def __init__(self, scale_value=1, shift_value=0, min_val=-np.inf, max_val=np.inf, is_torch=True):
+        self.scale_value, self.shift_value, self.min_val, self.max_val, self.is_torch = scale_value, shift_value, min_val, max_val, is_torch
+
+    def __call__(self, reward):
+        reward = reward + self.shift_value
+        reward = reward * self.scale_value
+        if self.is_torch:
+            import torch
+            reward = torch.clamp(reward, self.min_val, self.max_val)
+        else:
+            reward = np.clip(reward, self.min_val, self.max_val)
+        return reward
+
+
+class AverageMeter(nn.Module):
+    """rl_games/algos_torch/torch_ext.py: running mean of the last `max_size` episode scores."""
+
+    def __init__(self, in_shape, max_size):
+        super().__init__()
+        self.max_size, self.current_size = max_size, 0
+        self.register_buffer("mean", torch.zeros(in_shape, dtype=torch.float32))
+
+    def update(self, values):
+        size = values.size()[0]
+        if size == 0:
+            return
+        new_mean = torch.mean(values.float(), dim=0)
+        size = np.clip(size, 0, self.max_size)
+        old_size = min(self.max_size - size, self.current_size)
+        size_sum = old_size + size
+        self.current_size = size_sum
+        self.mean = (self.mean * old_size + new_mean * size) / size_sum
+
+    def get_mean(self):
+        return self.mean.squeeze(0).cpu().numpy()
+
+
+class IdentityScheduler:
+    """rl_games/common/schedulers.py (`lr_schedule: constant`, im.yaml:60)."""
+
+    def update(self, current_lr, entropy_coef, epoch, frames, kl_dist, **kwargs):
+        return current_lr, entropy_coef
 
 
 def _swap_and_flatten01(arr):

@@ -143,7 +143,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the .so does not export the symbol
         fn.argtypes = argtypes
         fn.restype = restype
-    if lib.phc_abi_version() != 35:
+    if lib.phc_abi_version() != 36:
         raise ImportError("libphc_amd.so ABI version mismatch")
     _lib = lib
     return lib

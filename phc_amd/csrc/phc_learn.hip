@@ -339,7 +339,7 @@ template <> __device__ __forceinline__ void st_f<float>(float* p, int64_t i, flo
 template <> __device__ __forceinline__ void st_f<__hip_bfloat16>(__hip_bfloat16* p, int64_t i, float v) { p[i] = __float2bfloat16(v); }
 
 
-#define PPO_NSUM 4   // a_loss, c_loss, b_loss, kl
+#define PPO_NSUM 5   // a_loss, c_loss, b_loss, kl, clipped (|ratio - 1| > e_clip: common_agent.py:570-571)
 template <typename T>
 __global__ __launch_bounds__(256) void k_ppo_loss(const T* __restrict__ mu, const T* __restrict__ value, const float* __restrict__ logstd,
                                                   const float* __restrict__ actions, const float* __restrict__ old_neglogp,
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(256) void k_ppo_loss(const T* __restrict__ mu, cons
     for (int d = lane; d < D; d += 64) sum_logstd += logstd[d];
     sum_logstd = wave_sum(sum_logstd);
     const float nlp_const = 0.5f * 1.8378770664093453f * (float)D + sum_logstd;   // log(2 pi)
-    double acc[PPO_NSUM] = {0.0, 0.0, 0.0, 0.0};
+    double acc[PPO_NSUM] = {0.0, 0.0, 0.0, 0.0, 0.0};
     for (int64_t r = (int64_t)blockIdx.x * 4 + w; r < B; r += (int64_t)gridDim.x * 4) {
         float s_nlp = 0.f, s_b = 0.f, s_kl = 0.f;
         const int64_t q = idx ? idx[r] : r;   // row of the rollout tensors (actions, old_*, adv, ret); mu / value are minibatch-ordered
@@ -394,6 +394,7 @@ __global__ __launch_bounds__(256) void k_ppo_loss(const T* __restrict__ mu, cons
         if (lane == 0) {
             st_f(grad_value, r, prm.critic_coef * dC * invB);
             acc[0] += (double)a_loss; acc[1] += (double)c_loss; acc[2] += (double)s_b; acc[3] += (double)s_kl;
+            acc[4] += fabsf(ratio - 1.0f) > prm.e_clip ? 1.0 : 0.0;
         }
         const float cb = prm.bounds_loss_coef * invB;
         for (int d = lane; d < D; d += 64) {
@@ -409,9 +410,9 @@ __global__ __launch_bounds__(256) void k_ppo_loss(const T* __restrict__ mu, cons
         partial[(int64_t)blockIdx.x * PPO_NSUM + threadIdx.x] = (lsum[0][threadIdx.x] + lsum[1][threadIdx.x]) + (lsum[2][threadIdx.x] + lsum[3][threadIdx.x]);
 }
 
-// stats[0..5] = loss, mean a_loss, mean c_loss, mean b_loss, entropy, mean kl.  256 threads: wavefront k reduces sum k; wavefront 0
-// also the entropy.
-__global__ __launch_bounds__(256) void k_ppo_loss_finish(const double* __restrict__ partial, int nblocks, int64_t B, int D,
+// stats[0..6] = loss, mean a_loss, mean c_loss, mean b_loss, entropy, mean kl, clip fraction.  320 threads: wavefront k reduces sum k;
+// wavefront 0 also the entropy.
+__global__ __launch_bounds__(64 * PPO_NSUM) void k_ppo_loss_finish(const double* __restrict__ partial, int nblocks, int64_t B, int D,
                                                          const float* __restrict__ logstd, phc_ppo_params_t prm, float* __restrict__ stats) {
     __shared__ double l[PPO_NSUM];
     __shared__ float lent;
@@ -429,7 +430,7 @@ __global__ __launch_bounds__(256) void k_ppo_loss_finish(const double* __restric
     __syncthreads();
     if (threadIdx.x != 0) return;
     const float ent = lent;
-    stats[1] = (float)l[0]; stats[2] = (float)l[1]; stats[3] = (float)l[2]; stats[4] = ent; stats[5] = (float)l[3];
+    stats[1] = (float)l[0]; stats[2] = (float)l[1]; stats[3] = (float)l[2]; stats[4] = ent; stats[5] = (float)l[3]; stats[6] = (float)l[4];
     stats[0] = (float)l[0] + prm.critic_coef * (float)l[1] - prm.entropy_coef * ent + prm.bounds_loss_coef * (float)l[2];
 }
 
@@ -477,21 +478,21 @@ __global__ __launch_bounds__(256) void k_policy_sample(const T* __restrict__ mu,
 template <typename T>
 __global__ __launch_bounds__(1024) void k_disc_bce(const T* __restrict__ logits, int n_agent, int n_demo, float scale, T* __restrict__ grad,
                                                    float* __restrict__ stats) {
-    __shared__ float l[4][16];
-    float la = 0.f, ld = 0.f, ca = 0.f, cd = 0.f;
+    __shared__ float l[6][16];
+    float la = 0.f, ld = 0.f, ca = 0.f, cd = 0.f, xa = 0.f, xd = 0.f;
     const int n = n_agent + n_demo;
     for (int i = threadIdx.x; i < n; i += 1024) {
         const float x = ld_f(logits, i);
         const float sp = fmaxf(x, 0.f) + log1pf(expf(-fabsf(x)));   // softplus(x) = BCEWithLogits(x, 0); BCEWithLogits(x, 1) = softplus(x) - x
         const float sg = 1.0f / (1.0f + expf(-x));
-        if (i < n_agent) { la += sp; ca += x < 0.f ? 1.f : 0.f; st_f(grad, i, scale * 0.5f * sg / (float)n_agent); }
-        else { ld += sp - x; cd += x > 0.f ? 1.f : 0.f; st_f(grad, i, scale * 0.5f * (sg - 1.0f) / (float)n_demo); }
+        if (i < n_agent) { la += sp; ca += x < 0.f ? 1.f : 0.f; xa += x; st_f(grad, i, scale * 0.5f * sg / (float)n_agent); }
+        else { ld += sp - x; cd += x > 0.f ? 1.f : 0.f; xd += x; st_f(grad, i, scale * 0.5f * (sg - 1.0f) / (float)n_demo); }
     }
-    la = wave_sum(la); ld = wave_sum(ld); ca = wave_sum(ca); cd = wave_sum(cd);
+    la = wave_sum(la); ld = wave_sum(ld); ca = wave_sum(ca); cd = wave_sum(cd); xa = wave_sum(xa); xd = wave_sum(xd);
     const int w = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) { l[0][w] = la; l[1][w] = ld; l[2][w] = ca; l[3][w] = cd; }
+    if ((threadIdx.x & 63) == 0) { l[0][w] = la; l[1][w] = ld; l[2][w] = ca; l[3][w] = cd; l[4][w] = xa; l[5][w] = xd; }
     __syncthreads();
-    if (threadIdx.x < 4) {
+    if (threadIdx.x < 6) {
         float t = 0.f;
         for (int k = 0; k < 16; ++k) t += l[threadIdx.x][k];
         l[threadIdx.x][0] = t;
@@ -501,6 +502,8 @@ __global__ __launch_bounds__(1024) void k_disc_bce(const T* __restrict__ logits,
         stats[0] = scale * 0.5f * (l[0][0] / (float)n_agent + l[1][0] / (float)n_demo);
         stats[1] = l[2][0] / (float)n_agent;
         stats[2] = l[3][0] / (float)n_demo;
+        stats[3] = l[4][0] / (float)n_agent;      // mean logits: the reference's `disc/agent_logit`, `disc/demo_logit` scalars (amp_agent.py:911-912)
+        stats[4] = l[5][0] / (float)n_demo;
     }
 }
 
@@ -847,7 +850,7 @@ int32_t phc_ppo_loss(const void* mu, const void* value, int32_t is_bf16, const f
     else
         hipLaunchKernelGGL(k_ppo_loss<float>, dim3(nblocks), dim3(256), 0, st, (const float*)mu, (const float*)value, logstd, actions, old_neglogp,
                            advantages, returns, old_values, old_mu, old_sigma, row_index, batch, num_actions, *prm, (float*)grad_mu, (float*)grad_value, workspace);
-    hipLaunchKernelGGL(k_ppo_loss_finish, dim3(1), dim3(256), 0, st, workspace, nblocks, batch, num_actions, logstd, *prm, stats);
+    hipLaunchKernelGGL(k_ppo_loss_finish, dim3(1), dim3(64 * PPO_NSUM), 0, st, workspace, nblocks, batch, num_actions, logstd, *prm, stats);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int32_t)e;
 }

@@ -916,9 +916,10 @@ class HumanoidIm:
             self._amp_head = S
             self.extras["amp_obs"] = self._amp_obs_buf.view(-1, self.get_num_amp_obs())
 
-    def replay_step_host(self):
-        """Host bookkeeping of one reset_done() + step() whose launches a graph replay has just issued."""
-        self._reset_done_host(self._use_reset_list and self._reset_list_pending)
+    def replay_step_host(self, reset=True):
+        """Host bookkeeping of one reset_done() (`reset`) + step() whose launches a graph replay has just issued."""
+        if reset:
+            self._reset_done_host(self._use_reset_list and self._reset_list_pending)
         new_head = self._amp_head - 1 if self._amp_head > 0 else self._num_amp_obs_steps
         self._post_physics_host(new_head)
 

@@ -246,6 +246,7 @@ class IMAmpAgent:
         # `force_collectives`: run the gradient all-reduce also in a one-rank process group (tests: RCCL next to the captured update on one GPU)
         self._force_collectives = bool(c.get("force_collectives", False))
         self.allreduce_timing = None   # bench.py sets a list: (start, end) events of every gradient all-reduce
+        self._trace = [] if c.get("trace_minibatches", False) else None
         self.num_collectives = 0       # gradient all-reduces issued so far
         self.config = c
         self.device = self.task.device if hasattr(self.task, "device") else "cpu"
@@ -537,7 +538,8 @@ class IMAmpAgent:
             task.align_amp_window()
 
             def whole_step(n):
-                task.reset_done()
+                if n > 0:   # (step 0 resets nothing: see the eager loop below)
+                    task.reset_done()
                 self.obs = task.obs_buf
                 seg_policy(n)
                 self.obs, rewards, self.dones, infos = self.vec_env.step(self._env_actions if self.clip_actions else e["actions"][n])
@@ -549,7 +551,7 @@ class IMAmpAgent:
                 key = ("step", n) + task.rollout_step_key()
                 if key in self._roll_graphs:
                     self._roll_graphs[key].replay()
-                    task.replay_step_host()
+                    task.replay_step_host(reset=n > 0)
                 else:
                     self._replay(key, lambda: whole_step(n))   # capture (runs the task's own host bookkeeping), then the first replay: no bookkeeping
             self.obs, self.dones = task.obs_buf, task.reset_buf
@@ -557,7 +559,12 @@ class IMAmpAgent:
             if self.faithful_reset or not hasattr(task, "reset_done"):
                 self.obs = self.env_reset(done_indices)
             else:
-                task.reset_done()
+                # The reference starts every rollout with `done_indices = []` (amp_agent.py:313): the envs that finished on the LAST step of the previous
+                # rollout are not reset at step 0 -- they run one more step, are flagged again by that step's `_compute_reset` (their clip is still over /
+                # they are still down) and are reset at step 1.  Kept: one in `horizon_length` episode ends carries that extra transition in the reference's
+                # data too (tests/test_learner_epoch.py pins it).
+                if n > 0:
+                    task.reset_done()
                 if np.isfinite(self.vec_env.clip_obs):   # clamp straight into the experience buffer row
                     self.obs = torch.clamp(task.obs_buf, -self.vec_env.clip_obs, self.vec_env.clip_obs, out=e["obses"][n])
                 else:
@@ -603,7 +610,7 @@ class IMAmpAgent:
                 not_dones = 1.0 - self.dones.float()
                 self.current_rewards = self.current_rewards * not_dones.unsqueeze(1)
                 self.current_lengths = self.current_lengths * not_dones
-            if self.faithful_reset:
+            if self.faithful_reset or not hasattr(task, "reset_done"):   # (a task without the device-side reset gets the reference's index list)
                 done_indices = self.dones.nonzero(as_tuple=False)[:, 0]
         reward_raw = self._reward_raw_acc
         mb_fdones = e["dones"].float()
@@ -687,24 +694,29 @@ class IMAmpAgent:
             w = torch.cat(net.get_disc_weights(), dim=-1)
             disc_loss = disc_loss + self._disc_weight_decay * torch.sum(torch.square(w))
         return {"disc_loss": disc_loss, "disc_grad_penalty": disc_grad_penalty.detach(), "disc_logit_loss": disc_logit_loss.detach(),
-                "disc_agent_acc": (disc_agent_logit < 0).float().mean().detach(), "disc_demo_acc": (disc_demo_logit > 0).float().mean().detach()}
+                "disc_agent_acc": (disc_agent_logit < 0).float().mean().detach(), "disc_demo_acc": (disc_demo_logit > 0).float().mean().detach(),
+                # (the reference keeps the logit tensors and logs their mean over the epoch, amp_agent.py:786-787,911-912: equal-sized minibatches, same number)
+                "disc_agent_logit": disc_agent_logit.detach().float().mean(), "disc_demo_logit": disc_demo_logit.detach().float().mean()}
 
     # Every scalar the fused loss kernels produce lands in ONE fp32 vector (`_raw`), which a graphed step adds to its accumulator
     # in one launch; the info dict is derived from it outside the step (all entries are linear in it).  Layout, nw = number of
-    # discriminator weight matrices:  [0:6] phc_ppo_loss (loss, a_loss, c_loss, b_loss, entropy, kl) | [6:9] phc_disc_bce (k * bce,
-    # agent acc, demo acc) | [9:10+nw] weight terms (k * (decay + logit reg), |W_i|^2 ...) | [10+nw:12+nw] penalty (k * pen, |grad|^2).
+    # discriminator weight matrices:  [0:7] phc_ppo_loss (loss, a_loss, c_loss, b_loss, entropy, kl, clip fraction) | [7:12] phc_disc_bce (k * bce,
+    # agent acc, demo acc, mean agent logit, mean demo logit) | [12:13+nw] weight terms (k * (decay + logit reg), |W_i|^2 ...) |
+    # [13+nw:15+nw] penalty (k * pen, |grad|^2).
+    _RAW_FIXED = 15
+
     def _raw_buffer(self):
         nw = len(self.model.a2c_network.get_disc_weights_raw())
-        if getattr(self, "_raw", None) is None or self._raw.numel() != 12 + nw:
-            self._raw = torch.zeros(12 + nw, dtype=torch.float32, device=self.device)
+        if getattr(self, "_raw", None) is None or self._raw.numel() != self._RAW_FIXED + nw:
+            self._raw = torch.zeros(self._RAW_FIXED + nw, dtype=torch.float32, device=self.device)
         return self._raw, nw
 
     def _info_from_raw(self, raw):
-        nw = raw.numel() - 12
+        nw = raw.numel() - self._RAW_FIXED
         k = self._disc_coef
-        return {"actor_loss": raw[1], "critic_loss": raw[2], "b_loss": raw[3], "entropy": raw[4], "kl": raw[5],
-                "disc_loss": (raw[6] + raw[9] + raw[10 + nw]) / k, "disc_grad_penalty": raw[10 + nw] / (self._disc_grad_penalty * k),
-                "disc_logit_loss": raw[9 + nw], "disc_agent_acc": raw[7], "disc_demo_acc": raw[8]}
+        return {"actor_loss": raw[1], "critic_loss": raw[2], "b_loss": raw[3], "entropy": raw[4], "kl": raw[5], "actor_clip_frac": raw[6],
+                "disc_loss": (raw[7] + raw[12] + raw[13 + nw]) / k, "disc_grad_penalty": raw[13 + nw] / (self._disc_grad_penalty * k),
+                "disc_logit_loss": raw[12 + nw], "disc_agent_acc": raw[8], "disc_demo_acc": raw[9], "disc_agent_logit": raw[10], "disc_demo_logit": raw[11]}
 
     def _disc_loss_fused(self, logits, m, obs_demo):
         """`_disc_loss` on the device with the pieces as kernels (fast_ops.disc_bce / weighted_sumsq): every term already carries
@@ -712,16 +724,16 @@ class IMAmpAgent:
         -> (the three loss terms, [(weight, c)] whose gradient c * weight is to be preloaded by FlatGradBucket.zero)."""
         k = self._disc_coef
         raw, nw = self._raw_buffer()
-        bce, _ = disc_bce(logits, 2 * m, k, out=raw[6:9])
+        bce, _ = disc_bce(logits, 2 * m, k, out=raw[7:12])
         ws, coefs, preload = self._disc_decay_terms()
         # (a K-padded weight enters with its padded storage -- the pad is zero --, when its gradient is preloaded anyway)
-        l2 = weighted_sumsq([getattr(w, "_padded", w) if preload else w.contiguous() for w in ws], coefs, out=raw[9:10 + nw], preloaded=preload)
+        l2 = weighted_sumsq([getattr(w, "_padded", w) if preload else w.contiguous() for w in ws], coefs, out=raw[12:13 + nw], preloaded=preload)
         # d(sum of the demo logits) / d(demo rows): cotangent = [0; 0; 1] over the [agent; replay; demo] logits, and the layers are told
         # that only the last row block carries anything (GEMMs over m instead of 3m rows, here and in the second-order pass)
         with input_grad_only(row_start=2 * m):
             grad = torch.autograd.grad(logits, obs_demo, grad_outputs=self._demo_row_mask(m, logits), create_graph=True, retain_graph=True,
                                        only_inputs=True)[0]
-        pen = weighted_sumsq([grad], [self._disc_grad_penalty * k / m], out=raw[10 + nw:12 + nw])
+        pen = weighted_sumsq([grad], [self._disc_grad_penalty * k / m], out=raw[13 + nw:15 + nw])
         return [bce, l2, pen], ([(w, 2.0 * c) for w, c in zip(ws, coefs)] if preload else None)
 
     def _disc_decay_terms(self):
@@ -795,11 +807,11 @@ class IMAmpAgent:
             # actor / critic losses and their gradients w.r.t. the two heads: one HIP pass (phc_ppo_loss) instead of ~100 launches
             ppo, st = ppo_loss(res["mu"].contiguous(), res["value"].contiguous(), res["logstd"], d["actions"], d["old_logp_actions"], d["advantages"],
                                d["returns"], d["old_values"], d["mu"], d["sigma"], self.e_clip, self.critic_coef, self.entropy_coef,
-                               self.bounds_loss_coef, self.clip_value, unit_grad=True, row_index=idx, out=self._raw_buffer()[0][0:6])
+                               self.bounds_loss_coef, self.clip_value, unit_grad=True, row_index=idx, out=self._raw_buffer()[0][0:7])
             # `ppo` and the fused discriminator terms enter the total with weight one (unit_grad): they are the roots of ONE backward
             # pass with constant unit cotangents -- no sum node, no fill launches
             roots = [ppo] + roots
-            info = None if fused_disc else {"actor_loss": st[0], "critic_loss": st[1], "b_loss": st[2], "entropy": st[3], "kl": st[4]}
+            info = None if fused_disc else {"actor_loss": st[0], "critic_loss": st[1], "b_loss": st[2], "entropy": st[3], "kl": st[4], "actor_clip_frac": st[5]}
             self.grads.zero(decay)
             with param_grad_only(), deferred_colsums():
                 torch.autograd.backward(roots, grad_tensors=[self._unit_cotangent(r) for r in roots])
@@ -863,7 +875,7 @@ class IMAmpAgent:
             mu, logstd = net.eval_actor(obs)
         ppo, _ = ppo_loss(mu.contiguous(), value.contiguous(), logstd[0] if logstd.dim() == 2 else logstd, d["actions"], d["old_logp_actions"],
                           d["advantages"], d["returns"], d["old_values"], d["mu"], d["sigma"], self.e_clip, self.critic_coef, self.entropy_coef,
-                          self.bounds_loss_coef, self.clip_value, unit_grad=True, row_index=idx, out=self._raw_buffer()[0][0:6])
+                          self.bounds_loss_coef, self.clip_value, unit_grad=True, row_index=idx, out=self._raw_buffer()[0][0:7])
         with param_grad_only(), deferred_colsums():
             torch.autograd.backward([ppo], grad_tensors=[self._unit_cotangent(ppo)])
 
@@ -894,7 +906,9 @@ class IMAmpAgent:
         loss = a_loss + self.critic_coef * c_loss - self.entropy_coef * entropy + bl * b_loss + self._disc_coef * disc_info["disc_loss"]
         with torch.no_grad():
             kl = policy_kl(res["mus"].detach(), res["sigmas"].detach(), d["mu"], d["sigma"])
-        return loss, {"actor_loss": a_loss.detach(), "critic_loss": c_loss.detach(), "b_loss": b_loss.detach(), "entropy": entropy.detach(), "kl": kl}
+            clip_frac = (torch.abs(ratio - 1.0) > self.e_clip).float().mean()     # common_agent.py:570-571,327
+        return loss, {"actor_loss": a_loss.detach(), "critic_loss": c_loss.detach(), "b_loss": b_loss.detach(), "entropy": entropy.detach(), "kl": kl,
+                      "actor_clip_frac": clip_frac}
 
     def _clip_and_step(self, step_device=None):
         """`step_device`: inside a captured graph -- the kernels count the optimizer step on the device, the host-side `step` is advanced by
@@ -934,7 +948,7 @@ class IMAmpAgent:
     # ONE step -- minibatch given by a row-index buffer into persistent dataset tensors -- and replay it 48 times per epoch; the
     # gradient all-reduce (multi-GPU) and the two optimizer launches follow each replay eagerly, so the graph holds no collective.
     def _graph_enabled(self):
-        return (self.grads.flat.is_cuda and self._use_graph and not self._graph_failed and self.minibatch_size >= 2048
+        return (self.grads.flat.is_cuda and self._use_graph and not self._graph_failed and self.minibatch_size >= int(self.config.get("hip_graph_min_rows", 2048))
                 and not os.environ.get("PHC_NO_GRAPH"))
 
     def _stale_grad_accumulators(self):
@@ -1082,6 +1096,9 @@ class IMAmpAgent:
                 if not fuse_opt:
                     self._grad_all_reduce()
                     self._clip_and_step()
+                if self._trace is not None and self._g_keys is None:
+                    inf = self._info_from_raw(self._raw.clone())
+                    self._trace.append(torch.stack([inf[k] for k in self._probe_info_keys()]))
                 n += 1
         if fuse_opt:
             st["step"] += n
@@ -1091,8 +1108,8 @@ class IMAmpAgent:
         return {k: mean[j] for j, k in enumerate(self._g_keys)}
 
     def _probe_info_keys(self):
-        return ["actor_loss", "critic_loss", "b_loss", "entropy", "kl", "disc_loss", "disc_grad_penalty", "disc_logit_loss", "disc_agent_acc",
-                "disc_demo_acc"]
+        return ["actor_loss", "critic_loss", "b_loss", "entropy", "kl", "actor_clip_frac", "disc_loss", "disc_grad_penalty", "disc_logit_loss", "disc_agent_acc",
+                "disc_demo_acc", "disc_agent_logit", "disc_demo_logit"]
 
     # ------------------------------------------------------------------ epoch (amp_agent.py:413-532)
     def _init_amp_demo_buf(self):
@@ -1174,29 +1191,40 @@ class IMAmpAgent:
                 for _ in range(self.mini_epochs_num):
                     for i in range(self.num_minibatches):
                         infos.append(self.calc_gradients(self._get_item(i)))
+                        if self._trace is not None:
+                            self._trace.append(torch.stack([infos[-1][k].float().reshape(()) for k in self._probe_info_keys()]))
         self._store_replay_amp_obs(batch["amp_obs"])
         self.post_epoch(self.epoch_num)
         sync()
         t2 = time.time()
         self.frame += self.batch_size * self.world
         info = {k: v.item() for k, v in ginfo.items()} if ginfo is not None else {k: torch.stack([i[k] for i in infos]).mean().item() for k in infos[0]}
-        info.update(play_time=t1 - t0, update_time=t2 - t1, total_time=t2 - t0, mean_task_reward=batch["rewards"].mean().item(),
-                    mean_disc_reward=batch["disc_rewards"].mean().item(), reward_raw=batch["reward_raw"].tolist(),
+        # (one host transfer for the rollout's reward statistics: amp_agent.py:900-925 logs mean / std of the discriminator reward, the mean combined reward and the mean return)
+        dr_std, dr_mean = torch.std_mean(batch["disc_rewards"])
+        rs = torch.stack([batch["rewards"].mean(), dr_mean, dr_std, batch["mb_rewards"].mean(), batch["returns"].mean()]).tolist()
+        info.update(play_time=t1 - t0, update_time=t2 - t1, total_time=t2 - t0, mean_task_reward=rs[0], mean_disc_reward=rs[1], disc_reward_std=rs[2],
+                    mean_mb_reward=rs[3], mean_return=rs[4], reward_raw=batch["reward_raw"].tolist(),
                     step_fps=self.batch_size / (t1 - t0), total_fps=self.batch_size / (t2 - t0))  # common_agent.py:134-138
+        if self._trace is not None:   # `+learning.params.config.trace_minibatches=True`: every optimizer step's scalars, in order (a diagnostic)
+            tr = torch.stack(self._trace).cpu() if self._trace else torch.zeros(0)
+            keys = self._probe_info_keys()
+            info["minibatch_trace"] = {k: tr[:, j].tolist() for j, k in enumerate(keys)} if tr.numel() else {}
+            self._trace = []
         return info
 
     def assemble_train_info(self, info):
         """The scalars the reference hands its SummaryWriter / wandb every epoch, under the reference's tags (`CommonAgent._assemble_train_info`,
         common_agent.py:603-626; `AMPAgent._assemble_train_info`, amp_agent.py:900-933): performance, learning rate, losses, discriminator statistics, reward
-        terms; plus the evaluation sweep's `eval/*` entries when the epoch ran one (im_amp.py:334-346).  (`loss/clip_frac`, `disc/agent_logit`, `disc/demo_logit` and
-        `disc/reward_std` are not formed on the fused device path and are left out.)"""
+        terms; plus the evaluation sweep's `eval/*` entries when the epoch ran one (im_amp.py:334-346).  Pinned to the reference's method by tests/test_learner_epoch.py."""
         raw = list(info.get("reward_raw", [])) + [0.0] * 5
         out = {"performance/update_time": info["update_time"], "performance/play_time": info["play_time"], "performance/total_fps": info["total_fps"],
                "learning_rate/last_lr": self.last_lr, "learning_rate/lr_mul": 1.0, "learning_rate/e_clip": self.e_clip,
                "loss/actor_loss": info["actor_loss"], "loss/critic_loss": info["critic_loss"], "loss/bounds_loss": info["b_loss"], "loss/entropy": info["entropy"],
-               "loss/kl": info["kl"], "disc/loss": info["disc_loss"], "disc/agent_acc": info["disc_agent_acc"], "disc/demo_acc": info["disc_demo_acc"],
+               "loss/kl": info["kl"], "loss/clip_frac": info["actor_clip_frac"], "disc/loss": info["disc_loss"], "disc/agent_acc": info["disc_agent_acc"],
+               "disc/demo_acc": info["disc_demo_acc"], "disc/agent_logit": info["disc_agent_logit"], "disc/demo_logit": info["disc_demo_logit"],
                "disc/grad_penalty": info["disc_grad_penalty"], "disc/logit_loss": info["disc_logit_loss"], "disc/reward_mean": info["mean_disc_reward"],
-               "rewards/mb_rewards": info["mean_task_reward"], "rewards/body_pos": raw[0], "rewards/body_rot": raw[1], "rewards/lin_vel": raw[2], "rewards/ang_vel": raw[3],
+               "disc/reward_std": info["disc_reward_std"], "rewards/returns": info["mean_return"],
+               "rewards/mb_rewards": info["mean_mb_reward"], "rewards/body_pos": raw[0], "rewards/body_rot": raw[1], "rewards/lin_vel": raw[2], "rewards/ang_vel": raw[3],
                "rewards/power": raw[4]}
         out.update({k: v for k, v in info.items() if k.startswith("eval/")})
         return {k: float(v) for k, v in out.items()}

@@ -677,8 +677,8 @@ class _PPOLossFn(torch.autograd.Function):
         logstd, actions, old_neglogp, adv, returns, old_mu, old_sigma = map(f32, (logstd, actions, old_neglogp, adv, returns, old_mu, old_sigma))
         old_values = f32(old_values) if old_values is not None else None
         gmu, gval = torch.empty_like(mu), torch.empty_like(value)
-        buf = torch.empty(6, dtype=torch.float32, device=mu.device) if out is None else out
-        assert buf.numel() == 6 and buf.dtype == torch.float32 and buf.is_contiguous()
+        buf = torch.empty(7, dtype=torch.float32, device=mu.device) if out is None else out
+        assert buf.numel() == 7 and buf.dtype == torch.float32 and buf.is_contiguous()
         ws = _workspace("ppo", lib.phc_ppo_loss_workspace(), mu.device, torch.float64)
         p = L.PpoParams(float(prm["e_clip"]), float(prm["critic_coef"]), float(prm["entropy_coef"]), float(prm["bounds_loss_coef"]), int(prm["clip_value"]))
         L.check(lib.phc_ppo_loss(mu.data_ptr(), value.data_ptr(), int(mu.dtype == torch.bfloat16), logstd.data_ptr(), actions.data_ptr(),
@@ -688,7 +688,7 @@ class _PPOLossFn(torch.autograd.Function):
         ctx.save_for_backward(gmu, gval)
         ctx.unit_grad = unit_grad
         ctx.set_materialize_grads(False)
-        loss, stats = buf.narrow(0, 0, 1).view(()), buf.narrow(0, 1, 5)   # disjoint views of the kernel's output
+        loss, stats = buf.narrow(0, 0, 1).view(()), buf.narrow(0, 1, 6)   # disjoint views of the kernel's output
         ctx.mark_non_differentiable(stats)
         return loss, stats
 
@@ -703,9 +703,9 @@ class _PPOLossFn(torch.autograd.Function):
 
 def ppo_loss(mu, value, logstd, actions, old_neglogp, adv, returns, old_values, old_mu, old_sigma, e_clip, critic_coef, entropy_coef,
              bounds_loss_coef, clip_value, unit_grad=False, row_index=None, out=None):
-    """-> (loss, stats[5] = a_loss, c_loss, b_loss, entropy, kl); mu [B, D] / value [B, 1] are the (bf16 or fp32) network heads;
+    """-> (loss, stats[6] = a_loss, c_loss, b_loss, entropy, kl, clip fraction); mu [B, D] / value [B, 1] are the (bf16 or fp32) network heads;
     with `row_index` [B] the rollout tensors (actions ... old_sigma) are the whole dataset and row r of the minibatch is row_index[r];
-    `out`: fp32 [6] that receives [loss, stats] (the results are views of it)."""
+    `out`: fp32 [7] that receives [loss, stats] (the results are views of it)."""
     prm = dict(e_clip=e_clip, critic_coef=critic_coef, entropy_coef=entropy_coef, bounds_loss_coef=bounds_loss_coef or 0.0, clip_value=bool(clip_value))
     return _PPOLossFn.apply(mu, value, logstd, actions, old_neglogp, adv, returns, old_values if clip_value else None, old_mu, old_sigma, prm, unit_grad,
                             row_index, out)
@@ -761,13 +761,13 @@ class _DiscBCEFn(torch.autograd.Function):
         n = logits.shape[0]
         assert logits.is_contiguous() and logits.numel() == n and logits.dtype in (torch.bfloat16, torch.float32)
         grad = torch.empty_like(logits)
-        stats = torch.empty(3, dtype=torch.float32, device=logits.device) if out is None else out
-        assert stats.numel() == 3 and stats.dtype == torch.float32 and stats.is_contiguous()
+        stats = torch.empty(5, dtype=torch.float32, device=logits.device) if out is None else out
+        assert stats.numel() == 5 and stats.dtype == torch.float32 and stats.is_contiguous()
         ctx.set_materialize_grads(False)
         L.check(lib.phc_disc_bce(logits.data_ptr(), int(logits.dtype == torch.bfloat16), n_agent, n - n_agent, float(scale), grad.data_ptr(), stats.data_ptr(),
                                  _stream(logits.device)), "phc_disc_bce")
         ctx.save_for_backward(grad)
-        acc = stats.narrow(0, 1, 2)
+        acc = stats.narrow(0, 1, 4)
         ctx.mark_non_differentiable(acc)
         return stats.narrow(0, 0, 1).view(()), acc
 
@@ -779,8 +779,8 @@ class _DiscBCEFn(torch.autograd.Function):
 
 
 def disc_bce(logits, n_agent, scale=1.0, out=None):
-    """-> (scale * 0.5 (bce(agent, 0) + bce(demo, 1)), [agent_acc, demo_acc]); logits [n, 1]: agent (+ replay) rows first, demo rows last;
-    `out`: fp32 [3] that receives [loss, accuracies] (the results are views of it)."""
+    """-> (scale * 0.5 (bce(agent, 0) + bce(demo, 1)), [agent_acc, demo_acc, mean agent logit, mean demo logit]); logits [n, 1]: agent (+ replay) rows
+    first, demo rows last; `out`: fp32 [5] that receives [loss, the four statistics] (the results are views of it)."""
     return _DiscBCEFn.apply(logits, n_agent, scale, out)
 
 

@@ -296,7 +296,9 @@ def test_fused_ppo_loss_equals_torch_losses(dtype, clip_value, D):
     (loss * 1.0).backward()
     tol = dict(rtol=2e-4, atol=2e-5)
     torch.testing.assert_close(loss, ref.detach(), **tol)
-    torch.testing.assert_close(st, torch.stack([a_loss, c_loss, b_loss, ent, kl]).detach(), **tol)
+    clip_frac = ((ratio - 1.0).abs() > e_clip).float().mean()       # `actor_clipped` (common_agent.py:570-571)
+    torch.testing.assert_close(st[:5], torch.stack([a_loss, c_loss, b_loss, ent, kl]).detach(), **tol)
+    assert abs(float(st[5]) - float(clip_frac)) <= 3.0 / B and float(clip_frac) > 0.05      # (a count: a row whose ratio sits on the threshold may fall on either side)
     gtol = dict(rtol=2e-2, atol=2e-6) if dtype == torch.bfloat16 else dict(rtol=2e-4, atol=2e-7)
     torch.testing.assert_close(mu_f.grad.float(), mu_t.grad.float(), **gtol)
     torch.testing.assert_close(val_f.grad.float(), val_t.grad.float(), **gtol)
@@ -480,7 +482,8 @@ def test_discriminator_loss_kernels():
         loss, acc = disc_bce(xk, 2 * m, 2.5)
         loss.backward()
         torch.testing.assert_close(loss, ref.detach(), rtol=1e-5, atol=1e-6)
-        torch.testing.assert_close(acc, torch.stack([(xf[:2 * m] < 0).float().mean(), (xf[2 * m:] > 0).float().mean()]).detach())
+        torch.testing.assert_close(acc, torch.stack([(xf[:2 * m] < 0).float().mean(), (xf[2 * m:] > 0).float().mean(), xf[:2 * m].mean(), xf[2 * m:].mean()]).detach(),
+                                   rtol=1e-4, atol=1e-5)
         torch.testing.assert_close(xk.grad.float(), xr.grad.float(), rtol=1e-2 if dtype == torch.bfloat16 else 1e-5, atol=1e-9)
     ws = [torch.randn(1024, 1960, device=dev, requires_grad=True), torch.randn(512, 1024, device=dev, requires_grad=True),
           torch.randn(1, 512, device=dev, requires_grad=True)]
