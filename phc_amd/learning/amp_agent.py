@@ -247,6 +247,7 @@ class IMAmpAgent:
         self._force_collectives = bool(c.get("force_collectives", False))
         self.allreduce_timing = None   # bench.py sets a list: (start, end) events of every gradient all-reduce
         self._trace = [] if c.get("trace_minibatches", False) else None
+        self._step_in_epoch = 0
         self.num_collectives = 0       # gradient all-reduces issued so far
         self.config = c
         self.device = self.task.device if hasattr(self.task, "device") else "cpu"
@@ -934,8 +935,49 @@ class IMAmpAgent:
         d = self._amp_rows(d)
         info = self._fwd_bwd(d)
         self._grad_all_reduce()
+        restore = self._debug_freeze(self._step_in_epoch) if self._debug_groups() else None
         self._clip_and_step()
+        if restore is not None:
+            restore()
+        self._step_in_epoch += 1
         return info
+
+    # ---- diagnostic knobs: `+learning.params.config.debug_actor_steps=K` (`debug_critic_steps`, `debug_disc_steps`) lets that network take only the
+    # FIRST K optimizer steps of every epoch -- what `mini_epochs` does for all three at once, separately.  On the other steps the group's gradient is zeroed before
+    # the clip and its parameters + Adam moments are put back after the step (the optimizer kernel works on the whole flat parameter).  Eager launches only.
+    def _debug_groups(self):
+        if getattr(self, "_dbg", None) is None:
+            c, self._dbg = self.config, {}
+            names = {id(p): n for n, p in self.model.named_parameters()}
+            for grp, key in (("actor", "debug_actor_steps"), ("critic", "debug_critic_steps"), ("disc", "debug_disc_steps")):
+                if c.get(key) is None:
+                    continue
+                of = lambda n: "disc" if "_disc" in n else ("critic" if ("critic" in n or ".value." in n) else "actor")
+                spans = [(o, o + k) for p, (o, k) in zip(self.grads.params, self.grads.segments) if of(names[id(p)]) == grp]
+                self._dbg[grp] = (int(c[key]), spans)
+        return self._dbg
+
+    def _debug_freeze(self, step_in_epoch):
+        """-> restore() for the groups that sit this step out (None when every group steps)."""
+        off = [spans for k, spans in self._debug_groups().values() if step_in_epoch >= k]
+        if not off:
+            return None
+        from .fast_ops import adam_state
+        st = adam_state(self.optimizer, self.grads.flat_param) if self.grads.flat.is_cuda else self.optimizer.state.get(self.grads.flat_param, {})
+        bufs = [self.grads.flat_param] + [st[k] for k in ("exp_avg", "exp_avg_sq") if k in st]
+        saved = []
+        for spans in off:
+            for lo, hi in spans:
+                self.grads.flat[lo:hi].zero_()
+                saved.append((lo, hi, [b[lo:hi].clone() for b in bufs]))
+
+        def restore():
+            for lo, hi, vals in saved:
+                for b, v in zip(bufs, vals):
+                    b[lo:hi].copy_(v)
+            if self.grads.shadow is not None:
+                self.grads.shadow.copy_(self.grads.flat_param)
+        return restore
 
     def _grad_all_reduce(self):
         if self.multi_gpu or (self._force_collectives and self.dist is not None):
@@ -948,7 +990,7 @@ class IMAmpAgent:
     # ONE step -- minibatch given by a row-index buffer into persistent dataset tensors -- and replay it 48 times per epoch; the
     # gradient all-reduce (multi-GPU) and the two optimizer launches follow each replay eagerly, so the graph holds no collective.
     def _graph_enabled(self):
-        return (self.grads.flat.is_cuda and self._use_graph and not self._graph_failed and self.minibatch_size >= int(self.config.get("hip_graph_min_rows", 2048))
+        return (self.grads.flat.is_cuda and self._use_graph and not self._graph_failed and not self._debug_groups() and self.minibatch_size >= int(self.config.get("hip_graph_min_rows", 2048))
                 and not os.environ.get("PHC_NO_GRAPH"))
 
     def _stale_grad_accumulators(self):
@@ -1177,6 +1219,7 @@ class IMAmpAgent:
         self.set_train()
         self.prepare_dataset(batch)
         infos, ginfo = [], None
+        self._step_in_epoch = 0
         with self.grads.shadow_scope(), _marker("phc:update"):
             if self._graph_enabled():
                 try:
