@@ -151,10 +151,10 @@ def _near(got, want, rtol, atol, msg):
     np.testing.assert_allclose(got, np.asarray(want), rtol=rtol, atol=atol, err_msg=msg)
 
 
-def run_epochs(g, device="cpu", faithful_reset=False, with_reset_done=True, extra=(), tol=None):
+def run_epochs(g, device="cpu", faithful_reset=False, with_reset_done=True, extra=(), tol=None, graphs=False):
     """-> worst relative parameter error over the epochs (for the caller's report)."""
     d = _dims(g)
-    t = dict(exp=2e-5, scal_r=2e-4, scal_a=2e-6, stat=1e-6, param_tail=1e-3)
+    t = dict(exp=2e-5, scal_r=2e-4, scal_a=2e-6, stat=1e-6, stat_a=1e-9, param_tail=1e-3)
     t.update(tol or {})
     env = ScriptedVecEnv(g, device, with_reset_done)
     draws = _Draws(g, env)
@@ -202,7 +202,7 @@ def run_epochs(g, device="cpu", faithful_reset=False, with_reset_done=True, extr
                 want = g[f"{tag}/dataset/{k}"]
                 _near(seen["dataset"][k].reshape(want.shape), want, 20 * t["exp"], 20 * t["exp"], f"{tag} dataset/{k}")
             for k, v in _sub(g, f"{tag}/reward_mean_std_after_prepare/").items():
-                _near(seen["vms"][k], v.numpy(), t["stat"], 1e-9, f"{tag} value normaliser after prepare_dataset: {k}")
+                _near(seen["vms"][k], v.numpy(), t["stat"], t["stat_a"], f"{tag} value normaliser after prepare_dataset: {k}")
             # ---- P8 x 8: every optimizer step's scalars, in order (a wrong minibatch slice or shuffle would show here)
             keys = [str(k) for k in g["step_keys"]]
             ours = {"actor_loss": "actor_loss", "critic_loss": "critic_loss", "b_loss": "b_loss", "entropy": "entropy", "kl": "kl", "actor_clip_frac": "actor_clip_frac",
@@ -232,7 +232,7 @@ def run_epochs(g, device="cpu", faithful_reset=False, with_reset_done=True, extr
             for nm, mod in (("running_mean_std", agent.running_mean_std), ("running_mean_std_temp", agent.running_mean_std_temp), ("reward_mean_std", agent.value_mean_std),
                             ("amp_input_mean_std", agent._amp_input_mean_std)):
                 for k, v in _sub(g, f"{tag}/{nm}/").items():
-                    _near(getattr(mod, k), v.numpy(), t["stat"], 1e-9, f"{tag} {nm}.{k}")
+                    _near(getattr(mod, k), v.numpy(), t["stat"], t["stat_a"], f"{tag} {nm}.{k}")
             for nm, buf in (("replay", agent._amp_replay_buffer), ("demo", agent._amp_obs_demo_buffer)):
                 assert np.array_equal(buf._data_buf["amp_obs"].cpu().numpy(), g[f"{tag}/{nm}/data"]), f"{tag} {nm} buffer contents"
                 assert [buf._head, buf._total_count, buf._sample_head] == list(g[f"{tag}/{nm}/head_count_samplehead"]), f"{tag} {nm} buffer counters"
@@ -247,7 +247,8 @@ def run_epochs(g, device="cpu", faithful_reset=False, with_reset_done=True, extr
         np.testing.assert_allclose(got_actions, g["actions_seen"], rtol=t["exp"], atol=t["exp"])
         assert np.abs(got_actions).max() <= 1.0
         assert env.k == d["EPOCHS"] * d["T"] and env.demo_k == env.s["demo"].shape[0]
-        assert draws.noise_used >= d["EPOCHS"] * d["T"] and draws.all_consumed(), "the agent drew fewer permutations / masks than the reference"
+        # (replayed rollout segments read the noise buffer without a host-side draw: epoch 1 eager + epoch 2 capture make the calls)
+        assert draws.noise_used >= (2 if graphs else d["EPOCHS"]) * d["T"] and draws.all_consumed(), "the agent drew fewer permutations / masks than the reference"
         if faithful_reset or not with_reset_done:
             assert env.reset_counts == list(g["reset_counts"])
         opt = agent.get_full_state_weights()["optimizer"]
@@ -274,6 +275,6 @@ def test_three_epochs_equal_the_reference_agent_on_hip(golden, graph):
     phc_adam_clip_step through the C ABI, fp32 GEMMs; `graph`: the rollout's policy / bookkeeping segments (from epoch 2) and the optimizer step replayed from hipGraphs."""
     g = golden("learner_epoch")
     extra = ["+learning.params.config.hip_graph=True", "+learning.params.config.hip_graph_min_rows=1"] if graph else ["+learning.params.config.hip_graph=False"]
-    worst = run_epochs(g, "cuda", extra=extra, tol=dict(exp=2e-4, scal_r=2e-3, scal_a=2e-5, stat=1e-6, param_tail=2e-2, count_slack=1.0 / 32))
+    worst = run_epochs(g, "cuda", extra=extra, graphs=graph, tol=dict(exp=2e-4, scal_r=2e-3, scal_a=2e-5, stat=2e-6, stat_a=1e-7, param_tail=2e-2, count_slack=1.0 / 32))   # (statistics: batch moments summed in another order)
     torch.cuda.synchronize()
     print(f"hip graph={graph}: worst parameter difference after three epochs = {worst:.3f} Adam steps")
