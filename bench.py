@@ -278,6 +278,12 @@ def other_workloads():
                          "workload": d["config"]["workload"], "envs_per_gpu": d["config"]["envs_per_gpu"]}
         except Exception as exc:   # noqa: BLE001
             out[name] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
+    # the regime a trained policy produces: the 64-clip locomotion library tracked by a policy trained on the spot (<= 90 s), < 2 % of the envs reset per step
+    try:
+        r = subprocess.run([sys.executable, "-m", "phc_amd.learning.bench_policy", "--train-s", "90", "--steps", "300"], env=env, capture_output=True, text=True, timeout=400, cwd=ROOT)
+        out["trained_policy"] = json.loads(next(l for l in r.stdout.splitlines() if l.startswith("POLICY_JSON"))[len("POLICY_JSON"):])
+    except Exception as exc:   # noqa: BLE001
+        out["trained_policy"] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
     # the PPO half on the reference's flagship learner config (phc/data/cfg/learning/im_pnn_big.yaml: 2048-1536-1024-1024-512-512, SiLU, PNN actor)
     cmd = [sys.executable, os.path.abspath(__file__), "--steps", "20", "--warmup", "5", "--ppo-epochs", "3", "--learning", "im_pnn_big", "--no-cpu-baseline", "--no-pmc"]
     try:
@@ -462,6 +468,9 @@ def main():
     inv_scale = 1.0 / task._pd_action_scale
 
     def env_step(ev=None, ev_post=None):
+        """One step THROUGH THE B1 BOUNDARY the metric names (`VecTaskPython.step`, phc/env/tasks/vec_task.py:145-162 -> phc_amd/env/tasks/vec_task.py): the rollout
+        idiom's reset of the envs that finished on the previous step, then `env.step(actions)` -> (obs, reward, done, info).  The HIP events around the stepper /
+        post-physics launches are recorded inside `task.step` (HumanoidIm._launch_events) on the steps that carry them."""
         task.reset_done()                 # envs that finished on the previous step (device-side mask, no host sync)
         if args.actions == "random":
             a = actions
@@ -469,17 +478,9 @@ def main():
             a = task.ref_dof_pos - task.default_dof_pos
         else:
             a = (task.ref_dof_pos - task._pd_action_offset) * inv_scale
-        task.pre_physics_step(a)
-        if ev is not None:
-            ev[0].record()
-        task._physics_step()
-        if ev is not None:
-            ev[1].record()
-        if ev_post is not None:
-            ev_post[0].record()
-        task.post_physics_step()
-        if ev_post is not None:
-            ev_post[1].record()
+        if ev is not None or ev_post is not None:
+            task._launch_events = (ev, ev_post)
+        return env.step(a)
 
     # The SURVEY protocol is a STEADY state (fixed random actions, ~98 % of the envs within 5 steps of a reset, resets spread over the steps).  Right
     # after env.reset() all envs are in lockstep -- they fall, and are reset, in the same few steps -- so a short run (the driver's K = 20, W = 5)
@@ -572,6 +573,7 @@ def main():
                                     "30 Hz control = 2 x simulate @60 Hz x 2 sub-steps") if args.robot == "smpl" else
                                    (("BASELINE configs[4]: Unitree H1 19-DoF" if args.robot == "h1" else "env_im_g1_phc: Unitree G1 37-DoF, 38 bodies") +
                                     ", envs per GPU as given, synthetic retargeted-shape clips, 50 Hz control = 4 x simulate @200 Hz x 2 sub-steps, pd torque mode"),
+                       "timed_call": "task.reset_done() + VecTaskPythonWrapper.step(actions) -> (obs, reward, done, info): the B1 boundary (phc/env/tasks/vec_task.py:145-162)",
                        "envs_per_gpu": N, "num_bodies": task.num_bodies,
                        "obs": task.num_obs, "amp_obs": task.get_num_amp_obs(), "parallelism": f"env-sharded x{world}",
                        "self_collision": bool(task._sim_params.self_collision)},

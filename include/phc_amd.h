@@ -52,6 +52,9 @@ typedef struct {
     int32_t num_shapes;
     int32_t int_stride;
     int32_t float_stride;
+    int32_t max_body_contact_pts; /* ABI 36: the largest number of ground-contact points any one body carries (int table 9; the maximum over the shapes).  The per-point
+                                   * masks of the solver are finite: phc_sim_step returns PHC_EUNSUPPORTED for contact_model 1 above 32 (c_active / c_removed) and for
+                                   * inertia_lag above 64 (c_touch: the tail points of a lagged sub-step would lose their force while their impedance stays in I^A) */
 } phc_model_t;
 
 /* Flat reference-motion buffer.  Replaces MotionLibBase's gts/grs/lrs/gvs/gavs/dvs tensors

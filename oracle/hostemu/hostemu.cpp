@@ -225,6 +225,13 @@ int emu_amp_ref_table(const phc_model_t* model, const phc_motion_lib_t* lib, con
 
 int emu_sim_step(const phc_model_t* model, const phc_sim_params_t* prm, const phc_sim_state_t* sim, const float* actions,
                  const float* pd_off, const float* pd_scale, const int32_t* freeze, int num_sim_calls, int do_step) {
+    if (do_step) {   // the option checks of phc_sim_step (phc_sim.hip), mirrored: same refusals on both backends
+        if (prm->contact_model == 1 && prm->inertia_lag) return PHC_EUNSUPPORTED;
+        if (prm->inertia_lag && model->num_shapes > 1 && sim->env_shape != nullptr) return PHC_EUNSUPPORTED;
+        if (prm->inertia_lag && prm->lane_mapping == 3) return PHC_EUNSUPPORTED;
+        if (prm->contact_model == 1 && model->max_body_contact_pts > 32) return PHC_EUNSUPPORTED;
+        if (prm->inertia_lag && model->max_body_contact_pts > PHC_CP_BITS) return PHC_EUNSUPPORTED;
+    }
     if (model->num_dof == model->num_bodies - 1 && model->num_bodies > 2)
         return emu_sim_step_t<PHC_JT_REVOLUTE>(model, prm, sim, actions, pd_off, pd_scale, freeze, num_sim_calls, do_step);
     return emu_sim_step_t<PHC_JT_SPHERICAL>(model, prm, sim, actions, pd_off, pd_scale, freeze, num_sim_calls, do_step);

@@ -45,11 +45,21 @@ def data_path(rel):
     """A real file path for a data file of the reference (an MJCF): the file itself, or its member of the travel archive extracted to a temp dir."""
     if not is_archive():
         return os.path.join(REFERENCE_ROOT, rel)
+    import atexit
+    import shutil
     import tempfile
     import zipfile
-    d = tempfile.mkdtemp(prefix="phc_ref_")
+    if _EXTRACT_DIR[0] is None:   # ONE scratch directory per process, removed at exit (ADVICE r5: a fresh mkdtemp per call was never cleaned up)
+        _EXTRACT_DIR[0] = tempfile.mkdtemp(prefix="phc_ref_")
+        atexit.register(shutil.rmtree, _EXTRACT_DIR[0], ignore_errors=True)
+    out = os.path.join(_EXTRACT_DIR[0], rel)
+    if os.path.isfile(out):
+        return out
     with zipfile.ZipFile(REFERENCE_ROOT) as z:
-        return z.extract(rel, d)
+        return z.extract(rel, _EXTRACT_DIR[0])
+
+
+_EXTRACT_DIR = [None]
 
 
 _MOCK_TOPLEVEL = (

@@ -24,7 +24,7 @@ c_p = C.c_void_p
 class Model(C.Structure):
     _fields_ = [("num_bodies", c_i32), ("num_dof", c_i32), ("max_level", c_i32), ("num_contact_pts", c_i32),
                 ("ints", c_p), ("floats", c_p), ("num_collision_pairs", c_i32),
-                ("num_shapes", c_i32), ("int_stride", c_i32), ("float_stride", c_i32)]
+                ("num_shapes", c_i32), ("int_stride", c_i32), ("float_stride", c_i32), ("max_body_contact_pts", c_i32)]
 
 
 class MotionLib(C.Structure):

@@ -35,6 +35,8 @@ def model_struct(ints, floats, num_bodies, num_dof, max_level, num_contact_pts, 
     else:
         m.num_collision_pairs = int(ints.reshape(-1)[4 + NUM_INT_TABLES * MAX_BODIES])   # count stored right after the int tables (model.py pack())
     m.num_bodies, m.num_dof, m.max_level, m.num_contact_pts = num_bodies, num_dof, max_level, num_contact_pts
+    per_body = ints.reshape(max(1, int(num_shapes)), -1)[:, 4 + 9 * MAX_BODIES:4 + 10 * MAX_BODIES]   # int table 9: contact points per body
+    m.max_body_contact_pts = int(per_body.max())
     m.ints, m.floats = ptr(ints), ptr(floats)
     return m
 

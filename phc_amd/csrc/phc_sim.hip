@@ -380,6 +380,9 @@ int32_t phc_sim_step(const phc_model_t* model, const phc_sim_params_t* params, c
     if (params->contact_model == 1 && (params->contact_iterations < 2 || !(params->contact_impedance > 0.f))) return PHC_EINVAL;
     if (params->contact_model == 1 && params->inertia_lag) return PHC_EUNSUPPORTED;   // (the rigid model re-solves every sub-step contact_iterations times with fresh impedances)
     if (params->inertia_lag && model->num_shapes > 1 && sim->env_shape != nullptr) return PHC_EUNSUPPORTED;   // (per-env body shapes: the lagged instantiation is not built for them)
+    if (params->inertia_lag && params->lane_mapping == 3) return PHC_EUNSUPPORTED;   // (the three-wavefront experiment build has no lagged instantiation: it would silently run fresh)
+    if (params->contact_model == 1 && model->max_body_contact_pts > 32) return PHC_EUNSUPPORTED;   // c_active / c_removed are 32-bit masks: a point beyond them could never be released
+    if (params->inertia_lag && model->max_body_contact_pts > PHC_CP_BITS) return PHC_EUNSUPPORTED;  // c_touch: tail points would alternate between full and no force
     sim_launch<true>(model, *params, sim, actions, pd_action_offset, pd_action_scale, freeze_mask, num_sim_calls, (hipStream_t)stream);
     return launch_status();
 }

@@ -482,6 +482,7 @@ class HumanoidIm:
         self._point_goal = torch.zeros(N, **f32)                 # humanoid_im.py:95
         self._reset_seed = int(torch.initial_seed()) & 0x7FFFFFFFFFFFFFFF
         self._reset_counter = 0
+        self._launch_events = None   # see step()
         # device-built list of the envs that finished in the last step (phc_im_buffers_t.reset_list): reset_done() works on it
         self._use_reset_list = getattr(self, "_use_reset_list", True)
         self._reset_list = torch.zeros(abi.RESET_SUBLISTS * abi.reset_sublist_cap(N), device=dev, dtype=torch.int32) if self._use_reset_list else None
@@ -785,8 +786,18 @@ class HumanoidIm:
     # ------------------------------------------------------------------ step (base_task.py:216-234)
     def step(self, actions):
         self.pre_physics_step(actions)
-        self._physics_step()
-        self.post_physics_step()
+        ev = self._launch_events    # bench.py: (stepper pair, post-physics pair) of HIP events for THIS step, or None (consumed)
+        if ev is None:
+            self._physics_step()
+            self.post_physics_step()
+            return
+        self._launch_events = None
+        for pair, fn in zip(ev, (self._physics_step, self.post_physics_step)):
+            if pair is not None:
+                pair[0].record()
+            fn()
+            if pair is not None:
+                pair[1].record()
 
     def pre_physics_step(self, actions):
         # humanoid.py:1522-1572: the action -> PD-target map itself runs inside phc_sim_step

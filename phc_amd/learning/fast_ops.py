@@ -63,6 +63,10 @@ def _first_write(p):
     if b is None or p.grad is None:
         return False
     if getattr(p, "_grad_gen", -1) == b.gen:
+        # a SECOND contribution to this gradient inside one pass (a module applied twice): the first one may still be a pending column-sum
+        # job whose finishing launch STORES -- finish it now, so that the store lands before this contribution is added
+        if _pending and p.grad.data_ptr() in _pending_dst:
+            flush_colsums(p.grad.device)
         return False
     p._grad_gen = b.gen
     return True
@@ -75,6 +79,7 @@ def _first_write(p):
 # Module-level state, like `_INPUT_GRAD_ONLY`: the backward runs on the autograd engine's thread; the pending list is per lane (stream).
 _DEFER = [0]
 _pending = {}
+_pending_dst = set()    # data pointers of the gradients (and gradient blocks) a pending job will write
 
 
 def _lane_of(device):
@@ -92,6 +97,7 @@ class deferred_colsums:
             flush_colsums()
         else:
             _pending.clear()
+            _pending_dst.clear()
 
 
 def _defer(out):
@@ -99,6 +105,9 @@ def _defer(out):
 
 
 def _pend(ws, out, nchunks, cols, accumulate=0):
+    if out.data_ptr() in _pending_dst:   # (two stores into one destination in one batch would race: finish the first)
+        flush_colsums(out.device)
+    _pending_dst.add(out.data_ptr())
     _pending.setdefault((out.device, _lane_of(out.device)), []).append((ws, out, int(nchunks), int(cols), int(accumulate)))
 
 
@@ -111,6 +120,8 @@ def flush_colsums(device=None):
         if (device is not None and torch.device(device) != dev) or lane != _lane_of(dev):
             continue
         jobs = _pending.pop(key)
+        for j in jobs:
+            _pending_dst.discard(j[1].data_ptr())
         arr = (L.ColsumJob * len(jobs))()
         for i, (ws, out, nch, cols, acc) in enumerate(jobs):
             arr[i].partial, arr[i].out, arr[i].nchunks, arr[i].cols, arr[i].accumulate = ws.data_ptr(), out.data_ptr(), nch, cols, acc
@@ -525,6 +536,8 @@ class _Linear1Fn(torch.autograd.Function):
                   and getattr(weight, "_grad_gen", -1) != b.gen and getattr(bias, "_grad_gen", -1) != b.gen)
         if direct:
             weight._grad_gen = bias._grad_gen = b.gen
+        elif _pending and weight.grad is not None and weight.grad.data_ptr() in _pending_dst:
+            flush_colsums(weight.grad.device)   # (a second application of the layer in one pass: the first one's pending STORE lands before this one is added)
         gwb = None if direct else torch.empty(cols + 1, dtype=torch.float32, device=xb.device)
         if direct and _defer(weight.grad):   # first stage only: the [cols + 1] result is finished with the pass's other column sums
             ws = _workspace(("lin1", weight.grad.data_ptr()), lib.phc_linear1_workspace(rows, cols), xb.device, torch.float32)

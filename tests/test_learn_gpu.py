@@ -116,6 +116,47 @@ def test_deferred_column_sums_finish_in_one_batch_launch():
     assert lib.phc_colsum_finish_batch(1, None, None) != 0      # PHC_EINVAL
 
 
+def test_a_layer_applied_twice_inside_deferred_colsums_keeps_both_bias_contributions():
+    """inside `deferred_colsums()` a bucket parameter's FIRST bias gradient is a pending job whose finishing launch STORES at the end of the pass; a second
+    application of the same module in that pass adds its contribution right away -- the store must land first.  One FastLinear + ReLU, one plain FastLinear and one
+    one-output layer (the value head's kernels), each applied to two different inputs in ONE backward pass: gradients == two separate passes summed."""
+    from phc_amd.learning.amp_agent import FlatGradBucket
+    from phc_amd.learning import fast_ops as fo
+    from phc_amd.learning.network import build_mlp
+    torch.manual_seed(3)
+    B, K, H = 4096, 96, 64
+    trunk = build_mlp(K, [H], "relu", fo.FastLinear).cuda()
+    mid, head = fo.FastLinear(H, H).cuda(), fo.FastLinear(H, 1).cuda()
+    params = [p for m in (trunk, mid, head) for p in m.parameters()]
+    bucket = FlatGradBucket(params)
+    xa, xb = torch.randn(B, K, device="cuda"), torch.randn(B, K, device="cuda") * 0.5 + 0.3
+
+    def loss_of(x):
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            return (head(mid(trunk(x))).float() ** 2).mean()
+
+    singles = []
+    with bucket.shadow_scope():
+        for x in (xa, xb):
+            bucket.zero()
+            with fo.deferred_colsums():
+                loss_of(x).backward()
+            singles.append(bucket.flat.clone())
+        bucket.zero()
+        with fo.deferred_colsums():
+            (loss_of(xa) + loss_of(xb)).backward()      # every module twice in one pass
+        assert not fo._pending and not fo._pending_dst
+    both = bucket.flat.clone()
+    torch.cuda.synchronize()
+    want = singles[0] + singles[1]
+    for p, (o, k) in zip(bucket.params, bucket.segments):
+        scale = float(want[o:o + k].abs().max())
+        assert scale > 0 and float((both[o:o + k] - want[o:o + k]).abs().max()) <= 2e-2 * scale, (tuple(p.shape), scale)
+    for m in (trunk[0], mid, head):      # the bias gradients in particular (the store that used to come last)
+        o, k = bucket.segments[[id(q) for q in bucket.params].index(id(m.bias))]
+        torch.testing.assert_close(both[o:o + k], want[o:o + k], rtol=2e-2, atol=2e-2 * float(want[o:o + k].abs().max()))
+
+
 @pytest.mark.parametrize("B,K,N", [(16384, 934, 1024), (16384, 512, 69), (1000, 130, 7)])
 def test_fast_linear_matches_autocast_linear(B, K, N):
     """FastLinear's training pass == nn.Linear under bf16 autocast: same forward values; weight / bias / input gradients equal to the

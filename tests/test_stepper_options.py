@@ -154,3 +154,37 @@ def test_force_average_is_the_mean_over_the_sub_steps(backend, lag):
     np.testing.assert_allclose(avg["df"], np.mean(dfs, 0), atol=0.3, rtol=2e-2)
     assert np.abs(avg["cf"] - last["cf"]).max() > 1.0   # (and the two publications do differ)
 
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_option_combinations_the_solver_masks_cannot_serve_are_refused(backend):
+    """no silent fall-backs at the C ABI -- `inertia_lag` with the three-wavefront experiment mapping (no lagged instantiation), the rigid contact model on a
+    body with more than 32 contact points (32-bit active / removed masks) and `inertia_lag` above 64 points per body (the touch mask) return PHC_EUNSUPPORTED on both
+    backends; the shipped models (SMPL 8, H1 8, G1 40 points on their busiest body) stay inside."""
+    be = get_backend(backend)
+    model, mstruct, keep = model_on(be)
+    root, dof, target = random_states(model, 2, np.random.default_rng(0), height=0.95)
+    UNSUPPORTED = -2   # PHC_EUNSUPPORTED (include/phc_amd.h)
+    args = lambda p, ms=mstruct: (ms, p) + _sim_args(be, model, root, dof, target)
+    assert 0 < mstruct.max_body_contact_pts <= 32
+    assert be.sim_step(*args(abi.sim_params_struct(inertia_lag=1))) == 0
+    assert be.sim_step(*args(abi.sim_params_struct(inertia_lag=1, lane_mapping=3))) == UNSUPPORTED
+    many = type(mstruct).from_buffer_copy(mstruct)
+    many.max_body_contact_pts = 40
+    assert be.sim_step(*args(abi.sim_params_struct(contact_model=1, contact_iterations=4), many)) == UNSUPPORTED
+    assert be.sim_step(*args(abi.sim_params_struct(inertia_lag=1), many)) == 0
+    many.max_body_contact_pts = 65
+    assert be.sim_step(*args(abi.sim_params_struct(inertia_lag=1), many)) == UNSUPPORTED
+    assert be.sim_step(*args(abi.sim_params_struct(), many)) == 0
+    be.sync()
+
+
+def _sim_args(be, model, root, dof, target):
+    n, nb, nd = root.shape[0], model.num_bodies, model.num_dof
+    a = dict(root=be.arr(root), dof=be.arr(dof), rbs=be.zeros((n, nb, 13)), cf=be.zeros((n, nb, 3)), df=be.zeros((n, nd)), pd=be.arr(target))
+    sim = abi.sim_state_struct(n, a["root"], a["dof"], a["rbs"], a["cf"], a["df"], a["pd"])
+    _KEEP.append(a)
+    return sim, None, None, None, None, 1
+
+
+_KEEP = []
