@@ -284,6 +284,12 @@ def other_workloads():
         out["trained_policy"] = json.loads(next(l for l in r.stdout.splitlines() if l.startswith("POLICY_JSON"))[len("POLICY_JSON"):])
     except Exception as exc:   # noqa: BLE001
         out["trained_policy"] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
+    # the path's collective on ONE rank at the two bucket sizes (its per-step floor; over xGMI: unmeasured)
+    try:
+        r = subprocess.run([sys.executable, "-m", "phc_amd.learning.bench_collective"], env=env, capture_output=True, text=True, timeout=180, cwd=ROOT)
+        out["collective_us"] = json.loads(next(l for l in r.stdout.splitlines() if l.startswith("COLLECTIVE_JSON"))[len("COLLECTIVE_JSON"):])
+    except Exception as exc:   # noqa: BLE001
+        out["collective_us"] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
     # the PPO half on the reference's flagship learner config (phc/data/cfg/learning/im_pnn_big.yaml: 2048-1536-1024-1024-512-512, SiLU, PNN actor)
     cmd = [sys.executable, os.path.abspath(__file__), "--steps", "20", "--warmup", "5", "--ppo-epochs", "3", "--learning", "im_pnn_big", "--no-cpu-baseline", "--no-pmc"]
     try:

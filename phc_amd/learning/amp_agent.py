@@ -210,20 +210,25 @@ class FlatGradBucket:
             torch.mul(p.data, c, out=p.grad)
             p._grad_gen = self.gen
 
-    def all_reduce_mean(self, dist, force=False, timing=None):
+    def all_reduce_mean(self, dist, force=False, timing=None, spans=None):
         """The path's one collective.  `force`: issue it also in a one-rank group (exercises RCCL + the captured update on a 1-GPU box);
-        `timing`: a list that receives (start, end) event pairs on the launch stream (bench.py: per-all-reduce time)."""
+        `timing`: a list that receives (start, end) event pairs on the launch stream (bench.py: per-all-reduce time); `spans` [(lo, hi)]: only these ranges of
+        the flat gradient, one all-reduce each (`split_allreduce`: the discriminator's part on its stream while the policy pass still runs).  -> number issued."""
         if dist is not None and dist.is_initialized() and (dist.get_world_size() > 1 or force):
             ev = None
             if timing is not None and self.flat.is_cuda and len(timing) < 4096:
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 ev[0].record()
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-            if dist.get_world_size() > 1:
-                self.flat.div_(dist.get_world_size())
+            views = [self.flat] if spans is None else [self.flat[lo:hi] for lo, hi in spans]
+            for v in views:
+                dist.all_reduce(v, op=dist.ReduceOp.SUM)
+                if dist.get_world_size() > 1:
+                    v.div_(dist.get_world_size())
             if ev is not None:
                 ev[1].record()
                 timing.append(ev)
+            return len(views)
+        return 0
 
     def clip_grad_norm_(self, max_norm):
         """torch.nn.utils.clip_grad_norm_ on the flat view: same total norm, same clip coefficient (clamped to 1)."""
@@ -331,6 +336,10 @@ class IMAmpAgent:
         # finishing launches.  On the device the discriminator pass runs on its own HIP stream (_fwd_bwd); captured, it is its OWN linear
         # hipGraph replayed on that stream next to the policy graph (_graph_update).
         self._use_branches = bool(c.get("branch_streams", True)) and not os.environ.get("PHC_NO_BRANCH_STREAMS")
+        # VERDICT r5 item 6b (UNMEASURED on multi-GPU hardware -- no node was ever available to this project; exercised by two-rank gloo and one-rank RCCL tests): the
+        # gradient bucket cut at the policy / discriminator boundary, the discriminator's all-reduce issued on its stream as soon as its pass is done.  Off by default:
+        # the shipped path is ONE all-reduce per optimizer step (north star); for `im` the discriminator holds 2.5 M of the 5.8 M gradient elements.
+        self._split_allreduce = bool(c.get("split_allreduce", False))
         self._branches = None
         self._graph = self._g_data = self._g_idx = self._g_info = None
         self._graph_failed = False
@@ -765,9 +774,15 @@ class IMAmpAgent:
             # the discriminator pass on its stream next to the policy pass: see __init__
             main = torch.cuda.current_stream(d["obs"].device)
             br.wait_stream(main)
+            split = self._split_active() and want_info      # (want_info=False: a captured step's warm-up pass -- gradients only, no collective)
             with torch.cuda.stream(br):
                 self._disc_pass(d, amp_idx)
+                if split:
+                    self._grad_all_reduce("disc")
             self._policy_pass(d, idx)
+            if split:
+                self._grad_all_reduce("policy")
+            self._reduced_in_pass = split
             main.wait_stream(br)
             return self._info_from_raw(self._raw.clone()) if want_info else None   # (a copy: the next step overwrites `_raw`)
         obs = self._preproc_obs(d["obs"], use_temp=self.temp_running_mean, row_index=idx)
@@ -933,8 +948,10 @@ class IMAmpAgent:
         all-reduce, replacing `optimizer.synchronize()` (:667-668) -- then clip + Adam on the flat parameter."""
         self.set_train()
         d = self._amp_rows(d)
+        self._reduced_in_pass = False
         info = self._fwd_bwd(d)
-        self._grad_all_reduce()
+        if not self._reduced_in_pass:
+            self._grad_all_reduce()
         restore = self._debug_freeze(self._step_in_epoch) if self._debug_groups() else None
         self._clip_and_step()
         if restore is not None:
@@ -979,10 +996,16 @@ class IMAmpAgent:
                 self.grads.shadow.copy_(self.grads.flat_param)
         return restore
 
-    def _grad_all_reduce(self):
+    def _grad_all_reduce(self, part=None):
+        """`part` None: the whole flat gradient (one collective per optimizer step, the default).  "disc" / "policy" (`split_allreduce`): that pass's range of the
+        bucket, issued on the CURRENT stream right behind the pass -- the discriminator's all-reduce then runs while the (longer) policy chain is still computing."""
         if self.multi_gpu or (self._force_collectives and self.dist is not None):
-            self.grads.all_reduce_mean(self.dist, force=self._force_collectives, timing=self.allreduce_timing)
-            self.num_collectives += 1
+            spans = None if part is None else (self._disc_spans if part == "disc" else self._policy_spans)
+            self.num_collectives += self.grads.all_reduce_mean(self.dist, force=self._force_collectives, timing=self.allreduce_timing, spans=spans)
+
+    def _split_active(self):
+        """Two all-reduces per optimizer step instead of one (`+learning.params.config.split_allreduce=True`; needs the two-stream step)."""
+        return (self._split_allreduce and (self.multi_gpu or (self._force_collectives and self.dist is not None)) and self._branches is not None)
 
     # ------------------------------------------------------------------ the optimizer step as a hipGraph
     # With the loss, normaliser and optimizer kernels fused, a step is ~140 launches of 2 ms total device time and the host needs
@@ -1127,16 +1150,23 @@ class IMAmpAgent:
                 if isinstance(self._graph, tuple):
                     gp, gd, gt = self._graph
                     main, sd = torch.cuda.current_stream(self.device), self._branches
+                    split = (not fuse_opt) and self._split_active()
                     sd.wait_stream(main)
                     with torch.cuda.stream(sd):
                         gd.replay()
+                        if split:
+                            self._grad_all_reduce("disc")
                     gp.replay()
+                    if split:
+                        self._grad_all_reduce("policy")
                     main.wait_stream(sd)
                     gt.replay()
                 else:
+                    split = False
                     self._graph.replay()
                 if not fuse_opt:
-                    self._grad_all_reduce()
+                    if not split:
+                        self._grad_all_reduce()
                     self._clip_and_step()
                 if self._trace is not None and self._g_keys is None:
                     inf = self._info_from_raw(self._raw.clone())

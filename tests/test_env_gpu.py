@@ -307,6 +307,26 @@ def test_two_rank_update_on_one_gpu(mode):
     assert out["collectives"] == out["expected_collectives"]
 
 
+@pytest.mark.parametrize("backend", ["gloo", "nccl"])
+@pytest.mark.parametrize("mode", ["eager", "graph"])
+def test_split_gradient_allreduce_keeps_replicas_identical(mode, backend):
+    """`+learning.params.config.split_allreduce=True` (round 6): the bucket cut at the policy / discriminator boundary, the discriminator's all-reduce issued on its
+    stream right behind its pass -- two gloo ranks sharing cuda:0 (different seeds and clips) and a one-rank RCCL communicator: two collectives per optimizer step,
+    replicas bit-identical, finite parameters."""
+    import json
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    extra = ["nccl", "world=1"] if backend == "nccl" else []
+    r = subprocess.run([sys.executable, os.path.join(here, "two_rank_gpu_main.py"), "split"] + extra + (["graph"] if mode == "graph" else []),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert all(c == 0 for c in out["exitcodes"]) and out["same_params"] and out["same_stats"] and out["finite"] and out["graph"] == (mode == "graph"), out
+    assert out["collectives"] == out["expected_collectives"] > 0, out
+
+
 @pytest.mark.parametrize("world", [1, 2])
 @pytest.mark.parametrize("mode", ["eager", "graph"])
 def test_rccl_gradient_allreduce_next_to_the_update(mode, world):

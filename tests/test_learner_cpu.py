@@ -176,8 +176,19 @@ def _ddp_worker(rank, world, port, q):
     stats = torch.cat([agent.running_mean_std.running_mean, agent.running_mean_std.running_var])
     sg = [torch.zeros_like(stats) for _ in range(world)]
     dist.all_gather(sg, stats)
+    # the optional split collective (amp_agent.py `split_allreduce`): the same bucket reduced in two ranges == reduced in one piece
+    b = agent.grads
+    net = agent.model.a2c_network
+    own, rest = b.spans_of([p for mod in (net._disc_mlp, net._disc_logits) for p in mod.parameters()])
+    g0 = torch.randn(b.flat.numel(), generator=torch.Generator().manual_seed(7 + rank))
+    b.flat.copy_(g0)
+    n_one = b.all_reduce_mean(dist)
+    whole = b.flat.clone()
+    b.flat.copy_(g0)
+    n_two = b.all_reduce_mean(dist, spans=own) + b.all_reduce_mean(dist, spans=rest)
+    split_ok = bool(torch.equal(whole, b.flat)) and n_one == 1 and n_two == len(own) + len(rest) == 2
     if rank == 0:
-        q.put((bool(torch.equal(gather[0], gather[1])), bool(torch.allclose(sg[0], sg[1])), float(flat.abs().sum())))
+        q.put((bool(torch.equal(gather[0], gather[1])) and split_ok, bool(torch.allclose(sg[0], sg[1])), float(flat.abs().sum())))
     dist.destroy_process_group()
 
 

@@ -11,7 +11,7 @@ import torch.multiprocessing as mp
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def worker(rank, world, port, graph, q, backend="gloo"):
+def worker(rank, world, port, graph, q, backend="gloo", split=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     dev = rank if backend == "nccl" else 0          # RCCL: one GPU per rank; gloo: both ranks share cuda:0
@@ -27,7 +27,7 @@ def worker(rank, world, port, graph, q, backend="gloo"):
     cfg = compose(["env.num_envs=128", f"env.motion_file=synthetic:2:{rank}", "learning.params.config.minibatch_size=2048",
                    "learning.params.config.amp_minibatch_size=1024", "learning.params.config.amp_obs_demo_buffer_size=4096",
                    "learning.params.config.amp_replay_buffer_size=4096", f"+learning.params.config.hip_graph={graph}",
-                   f"+learning.params.config.force_collectives={world == 1}", f"device_id={dev}", f"rl_device=cuda:{dev}"])
+                   f"+learning.params.config.force_collectives={world == 1}", f"+learning.params.config.split_allreduce={split}", f"device_id={dev}", f"rl_device=cuda:{dev}"])
     task, env = parse_task(cfg, device_id=dev)
     agent = IMAmpAgent(env, cfg, dist=dist)
     agent.init_train()
@@ -44,20 +44,21 @@ def worker(rank, world, port, graph, q, backend="gloo"):
     if rank == 0:
         q.put({"same_params": all(bool(torch.equal(gather[0], g)) for g in gather), "same_stats": all(bool(torch.allclose(sg[0], s)) for s in sg),
                "graph": agent._graph is not None, "finite": bool(torch.isfinite(flat).all()), "actor_loss": info["actor_loss"],
-               "collectives": agent.num_collectives, "expected_collectives": 3 * agent.mini_epochs_num * agent.num_minibatches,
+               "collectives": agent.num_collectives, "expected_collectives": (2 if split else 1) * 3 * agent.mini_epochs_num * agent.num_minibatches,
                "backend": dist.get_backend(), "world": dist.get_world_size()})
     dist.destroy_process_group()
 
 
 if __name__ == "__main__":
-    # usage: two_rank_gpu_main.py [graph] [nccl] [world=N]
+    # usage: two_rank_gpu_main.py [graph] [nccl] [split] [world=N]
     graph = "graph" in sys.argv[1:]
+    split = "split" in sys.argv[1:]
     backend = "nccl" if "nccl" in sys.argv[1:] else "gloo"
     world = next((int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("world=")), 2)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29600 + (os.getpid() % 300)
-    procs = [ctx.Process(target=worker, args=(r, world, port, graph, q, backend)) for r in range(world)]
+    procs = [ctx.Process(target=worker, args=(r, world, port, graph, q, backend, split)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
