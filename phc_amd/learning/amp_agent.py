@@ -253,6 +253,8 @@ class IMAmpAgent:
         self.allreduce_timing = None   # bench.py sets a list: (start, end) events of every gradient all-reduce
         self._trace = [] if c.get("trace_minibatches", False) else None
         self._step_in_epoch = 0
+        # diagnostic (round 6): True = rounds 1-5's behaviour, the envs that finished on the last step of a rollout are reset at step 0 of the next one
+        self._reset_at_rollout_start = bool(c.get("debug_reset_at_rollout_start", False))
         self.num_collectives = 0       # gradient all-reduces issued so far
         self.config = c
         self.device = self.task.device if hasattr(self.task, "device") else "cpu"
@@ -548,7 +550,7 @@ class IMAmpAgent:
             task.align_amp_window()
 
             def whole_step(n):
-                if n > 0:   # (step 0 resets nothing: see the eager loop below)
+                if n > 0 or self._reset_at_rollout_start:   # (step 0 resets nothing: see the eager loop below)
                     task.reset_done()
                 self.obs = task.obs_buf
                 seg_policy(n)
@@ -561,7 +563,7 @@ class IMAmpAgent:
                 key = ("step", n) + task.rollout_step_key()
                 if key in self._roll_graphs:
                     self._roll_graphs[key].replay()
-                    task.replay_step_host(reset=n > 0)
+                    task.replay_step_host(reset=n > 0 or self._reset_at_rollout_start)
                 else:
                     self._replay(key, lambda: whole_step(n))   # capture (runs the task's own host bookkeeping), then the first replay: no bookkeeping
             self.obs, self.dones = task.obs_buf, task.reset_buf
@@ -573,7 +575,7 @@ class IMAmpAgent:
                 # rollout are not reset at step 0 -- they run one more step, are flagged again by that step's `_compute_reset` (their clip is still over /
                 # they are still down) and are reset at step 1.  Kept: one in `horizon_length` episode ends carries that extra transition in the reference's
                 # data too (tests/test_learner_epoch.py pins it).
-                if n > 0:
+                if n > 0 or self._reset_at_rollout_start:
                     task.reset_done()
                 if np.isfinite(self.vec_env.clip_obs):   # clamp straight into the experience buffer row
                     self.obs = torch.clamp(task.obs_buf, -self.vec_env.clip_obs, self.vec_env.clip_obs, out=e["obses"][n])

@@ -18,6 +18,8 @@ for tag in $TAGS; do
     all24)    X="$C.mini_epochs=4" ;;
     tgs)      X="+solver.contact=tgs" ;;
     eager)    X="+$C.hip_graph=False" ;;
+    oldreset) X="+$C.debug_reset_at_rollout_start=True" ;;
+    oldreset24) X="+$C.debug_reset_at_rollout_start=True $C.mini_epochs=4" ;;
     *)        X="$tag" ;;
   esac
   PHC_QUIET=1 timeout $((SECS + 240)) python scripts/multi_clip_acceptance.py --envs 3072 --stage1-s $SECS --stage2-s 0 --eval-every 500 --out $O/$tag.json $X > $O/$tag.log 2>&1
