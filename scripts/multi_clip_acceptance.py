@@ -74,11 +74,12 @@ def main():
     ap.add_argument("--clips", type=int, default=64)
     ap.add_argument("--eval-every", type=int, default=500)
     ap.add_argument("--out", default="gpurun_out/multi_clip.json")
+    ap.add_argument("--seed", type=int, default=0, help="torch seed (env start times, policy noise, minibatch order, network initialisation)")
     ap.add_argument("--fp32-gemm", action="store_true", help="fp32 GEMMs instead of bf16 (the reference trains in fp32, im.yaml:51; ~4 x slower update)")
     ap.add_argument("extra", nargs="*")
     a = ap.parse_args()
     log = lambda s: print(s, flush=True)
-    torch.manual_seed(0)
+    torch.manual_seed(a.seed)
     over = ["learning=im_pnn", "env=env_im_pnn", f"env.num_envs={a.envs}", f"env.motion_file=locomotion:{a.clips}:0", "env.num_prim=2", "env.training_prim=0",
             "env.auto_pmcp=False", "env.auto_pmcp_soft=True"] + a.extra
     cfg = compose(over)
