@@ -268,7 +268,7 @@ def other_workloads():
     env = dict(os.environ, PHC_BENCH_CHILD="1")
     out = {}
     for name, tail in (("configs1_tracking_actions", ["--actions", "tracking"]), ("configs4_unitree_h1", ["--config", "5"]),
-                       ("configs1_inertia_lag", ["--solver", "inertia_lag=1"])):   # (round 5: the stepper's `+solver.inertia_lag=1` scheme)
+                       ("configs1_fresh_inertias", ["--solver", "inertia_lag=0"])):   # (round 6: the lagged scheme is the default; this is the every-sub-step-fresh one)
         cmd = [sys.executable, os.path.abspath(__file__), "--steps", "300", "--warmup", "30", "--ppo-epochs", "0", "--no-cpu-baseline", "--no-pmc"] + tail
         try:
             r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)

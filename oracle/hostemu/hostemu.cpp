@@ -227,7 +227,6 @@ int emu_sim_step(const phc_model_t* model, const phc_sim_params_t* prm, const ph
                  const float* pd_off, const float* pd_scale, const int32_t* freeze, int num_sim_calls, int do_step) {
     if (do_step) {   // the option checks of phc_sim_step (phc_sim.hip), mirrored: same refusals on both backends
         if (prm->contact_model == 1 && prm->inertia_lag) return PHC_EUNSUPPORTED;
-        if (prm->inertia_lag && model->num_shapes > 1 && sim->env_shape != nullptr) return PHC_EUNSUPPORTED;
         if (prm->inertia_lag && prm->lane_mapping == 3) return PHC_EUNSUPPORTED;
         if (prm->contact_model == 1 && model->max_body_contact_pts > 32) return PHC_EUNSUPPORTED;
         if (prm->inertia_lag && model->max_body_contact_pts > PHC_CP_BITS) return PHC_EUNSUPPORTED;

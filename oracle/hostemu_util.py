@@ -70,3 +70,56 @@ def np_motion_lib(lib):
                 ls=np.ascontiguousarray(lib["length_starts"], dtype=np.int64))
     s = abi.motion_lib_struct(frames, frames.shape[1], nb, keep["ml"], keep["mdt"], keep["mnf"], keep["ls"])
     return s, keep
+
+
+# ---- the stepper at DOUBLE precision (oracle/hostemu/hostemu64.cpp): the exact-arithmetic statement of the kernel's recursion, incl. the lagged scheme -------------------
+SRC64 = os.path.join(HERE, "hostemu", "hostemu64.cpp")
+OUT64 = os.path.join(HERE, "_build", "libphc_hostemu64.so")
+
+
+def build64():
+    deps = [SRC, SRC64] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(os.path.dirname(HERE), "include", "phc_amd.h")]
+    if os.path.exists(OUT64) and all(os.path.getmtime(d) <= os.path.getmtime(OUT64) for d in deps):
+        return OUT64
+    os.makedirs(os.path.dirname(OUT64), exist_ok=True)
+    subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fopenmp", "-ffp-contract=off", SRC64, "-o", OUT64], check=True)
+    return OUT64
+
+
+def _clone64(cls):
+    """The ctypes mirror of a struct of include/phc_amd.h as the `-Dfloat=double` build lays it out."""
+    return type(cls.__name__ + "64", (C.Structure,), {"_fields_": [(n, C.c_double if t is C.c_float else t) for n, t in cls._fields_]})
+
+
+Model64, SimParams64, SimState64 = _clone64(L.Model), _clone64(L.SimParams), _clone64(L.SimState)
+_emu64 = None
+
+
+def emu64():
+    global _emu64
+    if _emu64 is None:
+        lib = C.CDLL(build64())
+        lib.emu_sim_step.argtypes = [C.POINTER(Model64), C.POINTER(SimParams64), C.POINTER(SimState64), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
+        _emu64 = lib
+    return _emu64
+
+
+def _to64(s, cls64):
+    d = cls64()
+    for n, _ in s._fields_:
+        setattr(d, n, getattr(s, n))
+    return d
+
+
+def sim_step_f64(model, params, root_states, dof_state, pd_target, num_sim_calls=2, kp_scale=1.0, kd_scale=1.0):
+    """`phc_sim_step` for n envs through the double-precision build: `model` an ArticulationModel, `params` the fp32 `phc_sim_params_t` (abi.sim_params_struct),
+    states as float arrays [n, 13] / [n, D, 2] / [n, D].  -> dict(root, dof, rbs, cf, df) of float64 arrays."""
+    ints, floats = model.pack(kp_scale, kd_scale, float_dtype=np.float64)
+    ms = _to64(abi.model_struct(ints, floats, model.num_bodies, model.num_dof, model.max_level, len(model.contact_body)), Model64)
+    n, nb, nd = np.asarray(root_states).shape[0], model.num_bodies, model.num_dof
+    a = dict(root=np.array(root_states, dtype=np.float64, order="C"), dof=np.array(dof_state, dtype=np.float64, order="C"), rbs=np.zeros((n, nb, 13)),
+             cf=np.zeros((n, nb, 3)), df=np.zeros((n, nd)), pd=np.array(pd_target, dtype=np.float64, order="C"))
+    sim = _to64(abi.sim_state_struct(n, a["root"], a["dof"], a["rbs"], a["cf"], a["df"], a["pd"]), SimState64)
+    rc = emu64().emu_sim_step(C.byref(ms), C.byref(_to64(params, SimParams64)), C.byref(sim), None, None, None, None, int(num_sim_calls), 1)
+    assert rc == 0, rc
+    return a

@@ -727,7 +727,7 @@ PHC_HD bool aba_pair_narrow(const phc_sim_params_t& prm, float dt, int i, int k,
     n = dist > 1e-6f ? n * (1.0f / dist) : v3(0.f, 0.f, 1.f);
     const V3 cp = c2 + n * (r2 - 0.5f * pen);                // middle of the overlap
     constexpr int es = Xch::es;
-    const int oi = reinterpret_cast<const int32_t*>(ci)[18], ok = reinterpret_cast<const int32_t*>(ck)[18];   // owner bodies of the two shapes
+    const int oi = reinterpret_cast<const int32_t*>(ci + 12)[6], ok = reinterpret_cast<const int32_t*>(ck + 12)[6];   // owner bodies of the two shapes (cap_write: acc[6])
     const float* si = xslot(x, oi);
     const float* sk = xslot(x, ok);
     const V3 pi = v3(si[10 * es], si[11 * es], si[12 * es]), wi = v3(si[13 * es], si[14 * es], si[15 * es]), vi = v3(si[16 * es], si[17 * es], si[18 * es]);

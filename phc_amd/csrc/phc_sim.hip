@@ -310,15 +310,15 @@ static void sim_launch_cm(const phc_model_t* model, const phc_sim_params_t& prm,
     const int64_t groups = env_ids ? num_listed : sim->num_envs;
     const bool wide = model->num_bodies > 32;   // more bodies than a 32-lane group holds: one env per wavefront
     const bool occ3 = STEP && !RIGID && !SHAPES && JT == PHC_JT_SPHERICAL && !wide && prm.lane_mapping == 3;   // (experiment knob, see k_sim_step)
-    const bool lag = STEP && !RIGID && !SHAPES && prm.inertia_lag != 0;
+    const bool lag = STEP && !RIGID && prm.inertia_lag != 0;
     if (occ3)
         hipLaunchKernelGGL((k_sim_step<STEP, JT, 32, SHAPES, RIGID, (STEP && !RIGID && !SHAPES && JT == PHC_JT_SPHERICAL) ? 3 : 2>), dim3((groups + 1) / 2), dim3(64), 0, stream,
                            *model, prm, *sim, actions, off, scale, freeze, num_sim_calls, env_ids, num_listed);
     else if (lag && wide)
-        hipLaunchKernelGGL((k_sim_step<STEP, JT, 64, SHAPES, RIGID, 2, STEP && !RIGID && !SHAPES>), dim3(groups), dim3(64), 0, stream, *model, prm, *sim, actions, off, scale, freeze,
+        hipLaunchKernelGGL((k_sim_step<STEP, JT, 64, SHAPES, RIGID, 2, STEP && !RIGID>), dim3(groups), dim3(64), 0, stream, *model, prm, *sim, actions, off, scale, freeze,
                            num_sim_calls, env_ids, num_listed);
     else if (lag)
-        hipLaunchKernelGGL((k_sim_step<STEP, JT, 32, SHAPES, RIGID, 2, STEP && !RIGID && !SHAPES>), dim3((groups + 1) / 2), dim3(64), 0, stream, *model, prm, *sim, actions, off, scale, freeze,
+        hipLaunchKernelGGL((k_sim_step<STEP, JT, 32, SHAPES, RIGID, 2, STEP && !RIGID>), dim3((groups + 1) / 2), dim3(64), 0, stream, *model, prm, *sim, actions, off, scale, freeze,
                            num_sim_calls, env_ids, num_listed);
     else if (wide)
         hipLaunchKernelGGL((k_sim_step<STEP, JT, 64, SHAPES, RIGID>), dim3(groups), dim3(64), 0, stream, *model, prm, *sim, actions, off, scale, freeze,
@@ -379,7 +379,6 @@ int32_t phc_sim_step(const phc_model_t* model, const phc_sim_params_t* params, c
     if (params->contact_model != 0 && params->contact_model != 1) return PHC_EUNSUPPORTED;
     if (params->contact_model == 1 && (params->contact_iterations < 2 || !(params->contact_impedance > 0.f))) return PHC_EINVAL;
     if (params->contact_model == 1 && params->inertia_lag) return PHC_EUNSUPPORTED;   // (the rigid model re-solves every sub-step contact_iterations times with fresh impedances)
-    if (params->inertia_lag && model->num_shapes > 1 && sim->env_shape != nullptr) return PHC_EUNSUPPORTED;   // (per-env body shapes: the lagged instantiation is not built for them)
     if (params->inertia_lag && params->lane_mapping == 3) return PHC_EUNSUPPORTED;   // (the three-wavefront experiment build has no lagged instantiation: it would silently run fresh)
     if (params->contact_model == 1 && model->max_body_contact_pts > 32) return PHC_EUNSUPPORTED;   // c_active / c_removed are 32-bit masks: a point beyond them could never be released
     if (params->inertia_lag && model->max_body_contact_pts > PHC_CP_BITS) return PHC_EUNSUPPORTED;  // c_touch: tail points would alternate between full and no force

@@ -433,11 +433,12 @@ class HumanoidIm:
             contact_impedance=float(solver.get("contact_impedance", 1.0e5)),
             max_depenetration_velocity=float(physx.get("max_depenetration_velocity", 10.0)),
             bounce_threshold_velocity=float(physx.get("bounce_threshold_velocity", 0.2)), restitution=float(plane.get("restitution", 0.0)),
-            # round 5 (ABI 35): `+solver.inertia_lag=1` keeps the articulated inertias of a simulate() call's first sub-step over its other sub-steps;
+            # `solver.inertia_lag` (ABI 35): the sub-steps behind the first one of a simulate() call keep its articulated inertias and only redo the bias-force recursion.
+            # Round 6: the DEFAULT for the penalty contact model (stepper -5 %; H1 -10 %, G1 -11 %) -- pinned like the fresh scheme since
+            # tests/test_stepper_options.py::test_stepper_equals_the_double_precision_recursion; `+solver.inertia_lag=0` = every sub-step fresh.  The rigid model
+            # (`+solver.contact=tgs`) re-solves every sub-step with fresh impedances and runs fresh.
             # `+solver.force_average=1` publishes contact_force / dof_force as means over the env step's sub-steps instead of the last one's values
-            inertia_lag=int(bool(solver.get("inertia_lag", 0))), force_average=int(bool(solver.get("force_average", 0))))
-        if self._sim_params.inertia_lag and self._env_shape is not None:
-            raise ValueError("solver.inertia_lag is not built for per-env body shapes (robot.has_shape_variation): the lagged stepper instantiation exists for one shared model")
+            inertia_lag=int(bool(solver.get("inertia_lag", str(solver.get("contact", "penalty")) == "penalty"))), force_average=int(bool(solver.get("force_average", 0))))
         if self._sim_params.contact_model == 1 and max((int(c) for c in np.bincount(self.model.contact_body, minlength=1)), default=0) > 32:
             # (the rigid model's per-point active / released sets are 32-bit masks: a point beyond bit 31 could never be released)
             raise ValueError("solver.contact=tgs supports at most 32 ground-contact points per body; this model has more (use the penalty model)")

@@ -507,7 +507,7 @@ class ArticulationModel:
         return out
 
     # ---- packed buffers --------------------------------------------------------------------
-    def pack(self, kp_scale=1.0, kd_scale=1.0):
+    def pack(self, kp_scale=1.0, kd_scale=1.0, float_dtype=np.float32):
         """-> (ints int32[...], floats float32[...]) laid out as csrc/phc_model.h expects.
 
         ints  : [0]=NB [1]=ND [2]=max_level [3]=NCP then per body (MAX_BODIES slots each):
@@ -631,7 +631,7 @@ class ArticulationModel:
                 cp[idx] = cp[idx][order]
         # extra collision capsules after the contact points: a[3], b[3], radius, owner body (as a float) each
         xc = np.concatenate([self.extra_capsule.reshape(-1, 7), self.extra_owner.reshape(-1, 1).astype(np.float64)], axis=1) if NX else np.zeros((0, 8))
-        floats = np.concatenate([fl.reshape(-1), cp.reshape(-1), xc.reshape(-1)]).astype(np.float32)
+        floats = np.concatenate([fl.reshape(-1), cp.reshape(-1), xc.reshape(-1)]).astype(float_dtype)
         return ints, floats
 
     BODY_FLOATS = 56

@@ -40,6 +40,69 @@ def run_step(be, model, mstruct, root, dof, target, params, num_sim_calls=2):
     return {k: be.np(v) for k, v in a.items()}
 
 
+def check_step_against(model, out, r, d, rbs, tau, fc, tag="", scale=1.0):
+    """One env's simulator tensors after a step against a reference (root [13], dof [D, 2], rbs [NB, 13], dof force [D], contact force [NB, 3]) at the tolerances the
+    fp32 stepper is held to against the fp64 dense oracle (`scale` < 1 tightens all of them)."""
+    np.testing.assert_allclose(out["root"], r, atol=3e-4 * scale, rtol=1e-4 * scale, err_msg=f"root {tag}")
+    np.testing.assert_allclose(out["dof"][:, 1], d[:, 1], atol=3e-3 * scale, rtol=1e-3 * scale, err_msg=f"dof vel {tag}")
+    if model.all_spherical:   # exp-map coordinates may differ by the 2*pi branch: compare as rotations
+        for j in range(model.num_bodies - 1):
+            qa = do.quat_from_rotvec(np.asarray(out["dof"][3 * j:3 * j + 3, 0], dtype=np.float64))
+            qb = do.quat_from_rotvec(np.asarray(d[3 * j:3 * j + 3, 0], dtype=np.float64))
+            assert abs(abs(qa @ qb) - 1) < 1e-6 * scale + 1e-12, tag
+    else:
+        np.testing.assert_allclose(out["dof"][:, 0], d[:, 0], atol=3e-4 * scale, err_msg=f"dof pos {tag}")
+    np.testing.assert_allclose(out["rbs"][:, 0:3], rbs[:, 0:3], atol=3e-4 * scale, err_msg=f"body pos {tag}")
+    np.testing.assert_allclose(np.abs((out["rbs"][:, 3:7] * rbs[:, 3:7]).sum(-1)), 1, atol=1e-5 * scale + 1e-12)
+    np.testing.assert_allclose(out["rbs"][:, 7:13], rbs[:, 7:13], atol=3e-3 * scale, rtol=1e-3 * scale, err_msg=f"body vel {tag}")
+    np.testing.assert_allclose(out["df"], tau, atol=0.15 * scale, rtol=2e-3 * scale, err_msg=f"dof force {tag}")
+    np.testing.assert_allclose(out["cf"], fc, atol=0.5 * scale, rtol=5e-3 * scale, err_msg=f"contact force {tag}")
+
+
+def f32_params(prm):
+    """The dense oracle's parameter dict holding exactly the numbers the C struct holds (fp32-rounded gravity, damping, dt ...): what the double-precision build of the
+    lane code computes with, so that the two can be compared to rounding of fp64."""
+    keys = ("gravity_z", "contact_stiffness", "contact_damping", "friction", "friction_viscous", "angular_damping", "max_angular_velocity", "limit_stiffness",
+            "limit_damping", "self_stiffness_scale", "self_damping_ratio")
+    d = {k: float(getattr(prm, k)) for k in keys}
+    d.update(control_mode=int(prm.control_mode), self_collision=int(prm.self_collision))
+    return d, float(prm.sim_dt), int(prm.substeps)
+
+
+@pytest.mark.parametrize("robot,control_mode", [("smpl_humanoid", 0), ("h1_humanoid", 0), ("h1_humanoid", 1), ("g1_humanoid", 2)])
+@pytest.mark.parametrize("height,anisotropic,reroot", [(0.95, False, True), (0.80, False, True), (0.80, True, True), (0.80, False, False), (3.0, False, True)])
+def test_double_precision_build_of_the_recursion_is_the_dense_scheme(robot, control_mode, height, anisotropic, reroot):
+    """oracle/hostemu/hostemu64.cpp -- the kernel's own per-lane recursion (re-rooted solver tree, linearly-implicit drives, penalty contact) compiled with every float a
+    double -- against the dense fp64 oracle, BOTH computing with the fp32-rounded parameters of the C struct: equal to 1e-9 (observed ~1e-14).  The recursion and the dense
+    M^-1 solve are the same scheme exactly; what separates the fp32 kernel from the oracle elsewhere in this file is rounding alone.  This build is also the
+    exact-arithmetic reference of the LAGGED scheme (tests/test_stepper_options.py), which has no dense form."""
+    import hostemu_util as hu
+    if robot != "smpl_humanoid" and (anisotropic or not reroot):
+        pytest.skip("SMPL-only variants")
+    model, _, _ = model_on(get_backend("hostemu"), name=robot, anisotropic=anisotropic, reroot=reroot)
+    rng = np.random.default_rng(31)
+    n = 3
+    if model.all_spherical:
+        root, dof, target = random_states(model, n, rng, height=height)
+    else:
+        root, dof, target = random_states(model, n, rng, height=height + (0.1 if robot == "h1_humanoid" else -0.15), vel=0.5, pose=0.15)
+        lo, hi = model.dof_limits()
+        dof[:, :, 0] = np.clip(dof[:, :, 0], lo + 0.05, hi - 0.05)
+        target = np.clip(target, lo, hi).astype(F)
+    prm = abi.sim_params_struct(control_mode=control_mode) if not model.all_spherical else abi.sim_params_struct()
+    if not model.all_spherical:
+        prm.sim_dt = 1.0 / 200.0
+    out = hu.sim_step_f64(model, prm, root, dof, target, 2)
+    dp, sim_dt, substeps = f32_params(prm)
+    worst = 0.0
+    for e in range(n):
+        r, d, rbs, tau, fc = do.sim_step(model, root[e], dof[e], target[e], params=dp, sim_dt=sim_dt, substeps=substeps, num_sim_calls=2)
+        check_step_against(model, {k: v[e] for k, v in out.items()}, r, d, rbs, tau, fc, f"env {e}", scale=1e-5)
+        worst = max(worst, float(np.abs(out["rbs"][e] - rbs).max()))
+    print(f"{robot} mode {control_mode} height {height}: fp64 recursion vs dense oracle, worst body-state difference {worst:.2e}")
+    assert worst < 1e-9
+
+
 @pytest.mark.parametrize("backend", BACKENDS)
 @pytest.mark.parametrize("num_sim_calls,height,anisotropic", [(1, 0.95, False), (2, 0.95, False), (2, 0.80, False), (1, 3.0, False), (2, 0.95, True), (2, 0.80, True)])
 def test_aba_matches_dense_oracle(backend, num_sim_calls, height, anisotropic):
@@ -56,18 +119,7 @@ def test_aba_matches_dense_oracle(backend, num_sim_calls, height, anisotropic):
     for e in range(n):
         r, d, rbs, tau, fc = do.sim_step(model, root[e], dof[e], target[e], sim_dt=1 / 60, substeps=2, num_sim_calls=num_sim_calls)
         n_contacts += int((np.abs(fc).sum(-1) > 0).sum())
-        np.testing.assert_allclose(out["root"][e], r, atol=3e-4, rtol=1e-4, err_msg=f"root env {e}")
-        np.testing.assert_allclose(out["dof"][e, :, 1], d[:, 1], atol=3e-3, rtol=1e-3, err_msg=f"dof vel env {e}")
-        # exp-map coordinates may differ by the 2*pi branch: compare as rotations
-        for j in range(model.num_bodies - 1):
-            qa = do.quat_from_rotvec(out["dof"][e, 3 * j:3 * j + 3, 0].astype(np.float64))
-            qb = do.quat_from_rotvec(d[3 * j:3 * j + 3, 0])
-            assert abs(abs(qa @ qb) - 1) < 1e-6
-        np.testing.assert_allclose(out["rbs"][e][:, 0:3], rbs[:, 0:3], atol=3e-4, err_msg="body pos")
-        np.testing.assert_allclose(np.abs((out["rbs"][e][:, 3:7] * rbs[:, 3:7]).sum(-1)), 1, atol=1e-5)
-        np.testing.assert_allclose(out["rbs"][e][:, 7:13], rbs[:, 7:13], atol=3e-3, rtol=1e-3, err_msg="body vel")
-        np.testing.assert_allclose(out["df"][e], tau, atol=0.15, rtol=2e-3, err_msg="dof force")
-        np.testing.assert_allclose(out["cf"][e], fc, atol=0.5, rtol=5e-3, err_msg="contact force")
+        check_step_against(model, {k: v[e] for k, v in out.items()}, r, d, rbs, tau, fc, f"env {e}")
     if height < 0.9:
         assert n_contacts > 0, "the low-height case must exercise ground contact"
     if height > 2:
@@ -393,8 +445,8 @@ def test_sliding_friction_decelerates_at_mu_g(backend):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
-@pytest.mark.parametrize("self_collision", [0, 1])
-def test_per_env_body_shapes_equal_single_shape_runs(backend, self_collision):
+@pytest.mark.parametrize("self_collision,inertia_lag", [(0, 0), (1, 0), (1, 1)])
+def test_per_env_body_shapes_equal_single_shape_runs(backend, self_collision, inertia_lag):
     """Per-env body shapes (robot.has_shape_variation, humanoid.py:726-766,824-866): ONE launch over K = 3 stacked models (the reference's
     three gender assets: different link offsets, masses, contact-point counts) with an int32 shape id per env gives every env, bit for
     bit, what a single-shape launch of its own model gives -- stepper and the FK-only refresh."""
@@ -414,7 +466,7 @@ def test_per_env_body_shapes_equal_single_shape_runs(backend, self_collision):
     n = 10
     root, dof, target = random_states(m0, n, rng, height=0.85)
     shape = (np.arange(n) % 3).astype(np.int32)
-    params = abi.sim_params_struct(self_collision=self_collision)
+    params = abi.sim_params_struct(self_collision=self_collision, inertia_lag=inertia_lag)   # (round 6: the lagged instantiation exists for per-env shapes too)
 
     def run(mstruct, rows, env_shape):
         k = len(rows)

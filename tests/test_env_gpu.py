@@ -1307,12 +1307,14 @@ def test_tgs_contact_option_env_steps_match_the_dense_oracle_and_the_humanoid_st
 
 
 def test_stepper_switches_through_the_task_config():
-    """Round 5: `+solver.inertia_lag=1` and `+solver.force_average=1` reach the kernel through the hydra-style overrides.  With the lagged scheme every
+    """Round 5 / 6: `solver.inertia_lag` (default on for penalty contact since round 6) and `+solver.force_average=1` reach the kernel through the hydra-style overrides.  With the lagged scheme every
     post-physics output still equals the numpy oracle recomputed from the task's own tensors (the checker does not depend on the stepper's scheme; the scheme
     itself is gated in tests/test_stepper_options.py) and a humanoid under zero actions keeps standing.  With force_average the state trajectory is bit-identical and the published forces differ."""
     from step_oracle import StepChecker
-    task, env = make_task(256, motion="synthetic:2:1", **{"+solver.inertia_lag": 1})
-    assert task._sim_params.inertia_lag == 1 and task._sim_params.force_average == 0
+    task, env = make_task(256, motion="synthetic:2:1")
+    assert task._sim_params.inertia_lag == 1 and task._sim_params.force_average == 0          # round 6: the lagged scheme is the default of the penalty contact model ...
+    assert make_task(8, motion="synthetic:2:1", **{"+solver.inertia_lag": 0})[0]._sim_params.inertia_lag == 0     # ... `+solver.inertia_lag=0` = every sub-step fresh ...
+    assert make_task(8, motion="synthetic:2:1", **{"+solver.contact": "tgs"})[0]._sim_params.inertia_lag == 0      # ... and the rigid model always runs fresh
     env.reset()
     chk = StepChecker(task)
     for it in range(4):
@@ -1321,7 +1323,7 @@ def test_stepper_switches_through_the_task_config():
         obs, rew, done, info = env.step(actions)
         chk.after(obs, rew, done, info)
         task.reset_done()
-    stand, env2 = make_task(64, motion="stand:4", **{"+solver.inertia_lag": 1})
+    stand, env2 = make_task(64, motion="stand:4")
     env2.reset()
     zero = (torch.zeros(64, 69, device=stand.device) - stand._pd_action_offset) / stand._pd_action_scale
     for _ in range(60):
