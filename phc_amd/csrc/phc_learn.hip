@@ -340,24 +340,32 @@ template <> __device__ __forceinline__ void st_f<__hip_bfloat16>(__hip_bfloat16*
 
 
 #define PPO_NSUM 5   // a_loss, c_loss, b_loss, kl, clipped (|ratio - 1| > e_clip: common_agent.py:570-571)
+// Round 6: one HALF-wavefront (32 lanes) per row instead of a whole one -- 69 action dimensions are three passes of 32 lanes or two of 64 with 59 idle lanes in
+// the second; two rows per wavefront halve the number of dependent row iterations (gather index -> row loads -> three reductions -> exp -> second pass) a
+// wavefront walks through (27 -> 16 us at 16384 x 69).
+__device__ __forceinline__ float half_sum(float v) {
+#pragma unroll
+    for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
 template <typename T>
 __global__ __launch_bounds__(256) void k_ppo_loss(const T* __restrict__ mu, const T* __restrict__ value, const float* __restrict__ logstd,
                                                   const float* __restrict__ actions, const float* __restrict__ old_neglogp,
                                                   const float* __restrict__ adv, const float* __restrict__ ret, const float* __restrict__ old_value,
                                                   const float* __restrict__ old_mu, const float* __restrict__ old_sigma,
                                                   const int64_t* __restrict__ idx, int64_t B, int D, phc_ppo_params_t prm, T* __restrict__ grad_mu, T* __restrict__ grad_value, double* __restrict__ partial) {
-    __shared__ double lsum[4][PPO_NSUM];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __shared__ double lsum[8][PPO_NSUM];
+    const int lane = threadIdx.x & 31, w = threadIdx.x >> 5;   // lane of the half-wavefront, half-wavefront of the block
     const float invB = 1.0f / (float)B;
     float sum_logstd = 0.f;
-    for (int d = lane; d < D; d += 64) sum_logstd += logstd[d];
-    sum_logstd = wave_sum(sum_logstd);
+    for (int d = lane; d < D; d += 32) sum_logstd += logstd[d];
+    sum_logstd = half_sum(sum_logstd);
     const float nlp_const = 0.5f * 1.8378770664093453f * (float)D + sum_logstd;   // log(2 pi)
     double acc[PPO_NSUM] = {0.0, 0.0, 0.0, 0.0, 0.0};
-    for (int64_t r = (int64_t)blockIdx.x * 4 + w; r < B; r += (int64_t)gridDim.x * 4) {
+    for (int64_t r = (int64_t)blockIdx.x * 8 + w; r < B; r += (int64_t)gridDim.x * 8) {
         float s_nlp = 0.f, s_b = 0.f, s_kl = 0.f;
         const int64_t q = idx ? idx[r] : r;   // row of the rollout tensors (actions, old_*, adv, ret); mu / value are minibatch-ordered
-        for (int d = lane; d < D; d += 64) {
+        for (int d = lane; d < D; d += 32) {
             const float m = ld_f(mu, r * D + d), a = actions[q * D + d], sg = expf(logstd[d]);
             const float z = (a - m) / sg;
             s_nlp += z * z;
@@ -366,7 +374,7 @@ __global__ __launch_bounds__(256) void k_ppo_loss(const T* __restrict__ mu, cons
             const float m1 = old_mu[q * D + d], s1 = old_sigma[q * D + d];
             s_kl += logf(s1 / sg + 1e-5f) + (sg * sg + (m1 - m) * (m1 - m)) / (2.0f * (s1 * s1 + 1e-5f)) - 0.5f;
         }
-        s_nlp = wave_sum(s_nlp); s_b = wave_sum(s_b); s_kl = wave_sum(s_kl);
+        s_nlp = half_sum(s_nlp); s_b = half_sum(s_b); s_kl = half_sum(s_kl);
         const float neglogp = 0.5f * s_nlp + nlp_const;
         const float ratio = expf(old_neglogp[q] - neglogp);
         const float A = adv[q];
@@ -397,7 +405,7 @@ __global__ __launch_bounds__(256) void k_ppo_loss(const T* __restrict__ mu, cons
             acc[4] += fabsf(ratio - 1.0f) > prm.e_clip ? 1.0 : 0.0;
         }
         const float cb = prm.bounds_loss_coef * invB;
-        for (int d = lane; d < D; d += 64) {
+        for (int d = lane; d < D; d += 32) {
             const float m = ld_f(mu, r * D + d), a = actions[q * D + d], sg = expf(logstd[d]);
             const float g = c_mu * (a - m) / (sg * sg) + cb * (2.0f * fmaxf(m - 1.0f, 0.f) + 2.0f * fminf(m + 1.0f, 0.f));
             st_f(grad_mu, r * D + d, g);
@@ -406,8 +414,10 @@ __global__ __launch_bounds__(256) void k_ppo_loss(const T* __restrict__ mu, cons
     if (lane == 0)
         for (int k = 0; k < PPO_NSUM; ++k) lsum[w][k] = acc[k];
     __syncthreads();
-    if (threadIdx.x < PPO_NSUM)
-        partial[(int64_t)blockIdx.x * PPO_NSUM + threadIdx.x] = (lsum[0][threadIdx.x] + lsum[1][threadIdx.x]) + (lsum[2][threadIdx.x] + lsum[3][threadIdx.x]);
+    if (threadIdx.x < PPO_NSUM) {
+        const int k = threadIdx.x;
+        partial[(int64_t)blockIdx.x * PPO_NSUM + k] = ((lsum[0][k] + lsum[1][k]) + (lsum[2][k] + lsum[3][k])) + ((lsum[4][k] + lsum[5][k]) + (lsum[6][k] + lsum[7][k]));
+    }
 }
 
 // stats[0..6] = loss, mean a_loss, mean c_loss, mean b_loss, entropy, mean kl, clip fraction.  320 threads: wavefront k reduces sum k;
@@ -842,7 +852,7 @@ int32_t phc_ppo_loss(const void* mu, const void* value, int32_t is_bf16, const f
         return PHC_EINVAL;
     if (prm->clip_value && !old_values) return PHC_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    const int nblocks = (int)((batch + 3) / 4 < PPO_BLOCKS ? (batch + 3) / 4 : PPO_BLOCKS);
+    const int nblocks = (int)((batch + 7) / 8 < PPO_BLOCKS ? (batch + 7) / 8 : PPO_BLOCKS);   // eight rows (half-wavefronts) per block and pass
     if (is_bf16)
         hipLaunchKernelGGL(k_ppo_loss<__hip_bfloat16>, dim3(nblocks), dim3(256), 0, st, (const __hip_bfloat16*)mu, (const __hip_bfloat16*)value, logstd, actions,
                            old_neglogp, advantages, returns, old_values, old_mu, old_sigma, row_index, batch, num_actions, *prm, (__hip_bfloat16*)grad_mu,
