@@ -22,7 +22,9 @@ def main():
     extra = sys.argv[4:]
     bf16 = "--fp32-gemm" not in extra          # A/B of the GEMM precision (the reference trains in fp32, im.yaml:51; the product runs bf16 MFMA GEMMs)
     extra = [e for e in extra if e != "--fp32-gemm"]
-    torch.manual_seed(0)
+    seed = next((int(e.split("=")[1]) for e in extra if e.startswith("--seed=")), 0)      # (round 6: outcomes of early training depend on the seed, profiles/r06_multi_clip/)
+    extra = [e for e in extra if not e.startswith("--seed=")]
+    torch.manual_seed(seed)
     cfg = compose([f"env.num_envs={num_envs}", "env.motion_file=synthetic:1:0"] + extra)   # extra may override env.motion_file
     task, env = parse_task(cfg)
     agent = IMAmpAgent(env, cfg, bf16=bf16)
