@@ -146,58 +146,53 @@ extern "C" int32_t phc_debug_reset_timeline(unsigned long long* out64, int32_t g
 // Measured alternative (round 2, profiles/r02_notes.md): ONE workgroup per listed env with its S history-frame groups side by side
 // (blockDim = G * S), so that the S lookups of an env -- S + 1 consecutive clip frames -- share a CU's L1: 46.6 us vs 34 us for this
 // geometry (the ten groups of an env then hit one clip region, i.e. the same HBM channels, at the same instant).  Not kept.
-// one listed env, one role k (grid.y): 0 = state + self observation, 1 = task observation, 2 + k = AMP history frame k
-// workgroups along x of the list-mode reset launch: 128 x 8 lane groups (32-lane envs) = 1024 listed envs per pass -- one pass still serves the ~800 resets per step of
-// the random-action protocol at 4096 envs; more finished envs take further passes of the same groups
-#define PHC_RESET_GRID_X 128
-template <int DPJ, bool RNG, int G>
-__device__ __forceinline__ void im_reset_group(const phc_model_t& model, const phc_motion_lib_t& lib, const phc_im_params_t& prm, const phc_sim_state_t& sim,
-                                               const phc_im_buffers_t& buf, int64_t env, int64_t r, int k, int lane, const int64_t* __restrict__ env_ids,
-                                               const float* __restrict__ phase, int start_at_zero, uint64_t rng_key) {
-    const int64_t mid = motion_id_of(buf, env);
-    // _sample_ref_state (humanoid_im.py:1000-1023): StateInit.Random -> sample_time_interval; Start / flags.test -> 0
-    // (start_at_zero with a null phase array is only legal in the RNG-free instantiation's list mode)
-    // (device-side call counter, phc_im_buffers_t.reset_rng_counter: folded into the key so that a captured launch draws anew on every replay)
-    const uint64_t key = (RNG && buf.reset_rng_counter) ? splitmix64(rng_key ^ (*buf.reset_rng_counter * 0x9E6C63D0876A9A47ull)) : rng_key;
-    const float t = start_at_zero ? 0.f : sample_time_interval(lib, mid, RNG ? hash_u01(key, (uint32_t)env) : phase[r]);
-    if (k < 2) im_reset_lane(model, lib, prm, sim, buf, env, lane, t, env_ids != nullptr, 1 << k);
-    if (k >= 2) {
-        if (prm.amp_ref_table != nullptr) im_reset_amp_table_lane(lib, prm, buf, model.num_bodies, env, lane, G, t, k - 2);
-        else im_reset_amp_lane(lib, prm, buf, model.num_bodies, env, lane, t, k - 2);
-    }
-}
-
 template <int DPJ, bool RNG, int G>
 __global__ __launch_bounds__(256) void k_im_reset(phc_model_t model, phc_motion_lib_t lib, phc_im_params_t prm, phc_sim_state_t sim,
                                                  phc_im_buffers_t buf, int num_reset, const int64_t* __restrict__ env_ids,
                                                  const float* __restrict__ phase, int start_at_zero, uint64_t rng_key) {
     pin_family<DPJ>(lib, prm);
     const int lane = threadIdx.x & (G - 1);
-    // listed env (grid.x); grid.y: the role -- the heaviest groups are dispatched first and no group carries more than one lookup chain
+    // listed env (grid.x); grid.y: 0 = state + self observation, 1 = task observation, 2 + k = AMP history frame k -- the heaviest groups
+    // are dispatched first and no group carries more than one lookup chain
     const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
     const int k = (int)blockIdx.y;
+#ifdef PHC_SIM_PROFILE
+    const bool rtl_on = (int)(r * 16 + k) == g_phc_rtl_group;
+#endif
+    PHC_RTL(0)
+    int64_t env;
     if (RNG && buf.reset_list) {
-        // reset_done() on the device-built list of finished envs: dense wavefronts.  Round 6: the grid no longer covers the worst case (every env listed: 512 x 12
-        // workgroups at 4096 envs, ~92 % of which read a count and left -- and ~99 % once a policy tracks its clips) but PHC_RESET_GRID_X x 12 workgroups that STRIDE over
-        // the list; a group keeps its sub-list (the stride is a multiple of 16) and stops at that sub-list's count.
-        const int cap = buf.reset_sublist_cap;
-        const int stride = (int)(gridDim.x * blockDim.x) / G;
-        if (r < PHC_RESET_SUBLISTS && k == 0 && lane == 0)   // next step's counters
-            buf.reset_count[(((buf.reset_slot + 1) % 3) * PHC_RESET_SUBLISTS + (int)r) * PHC_RESET_COUNT_STRIDE] = 0;
-        // group r works on entries r / 16, (r + stride) / 16, ... of sub-list r % 16: concurrently running wavefronts draw from all sub-lists (a sub-list holds
+        // reset_done() on the device-built list of finished envs: dense wavefronts, blocks beyond the count leave at once
+        const int cap = buf.reset_sublist_cap, r32 = (int)r;
+        // group r works on entry r / 16 of sub-list r % 16: concurrently running wavefronts draw from all sub-lists (a sub-list holds
         // envs of every 16th workgroup, whose clips sit at a fixed stride in HBM -- walking one sub-list at a time camps on channels)
-        for (int r32 = (int)r; ; r32 += stride) {
-            const int sub = r32 & (PHC_RESET_SUBLISTS - 1), i = r32 >> 4;
-            if (i >= cap || i >= buf.reset_count[(buf.reset_slot * PHC_RESET_SUBLISTS + sub) * PHC_RESET_COUNT_STRIDE]) return;
-            im_reset_group<DPJ, RNG, G>(model, lib, prm, sim, buf, buf.reset_list[sub * cap + i], r32, k, lane, env_ids, phase, start_at_zero, rng_key);
-        }
+        const int sub = r32 & (PHC_RESET_SUBLISTS - 1), i = r32 >> 4;
+        if (r32 < PHC_RESET_SUBLISTS && k == 0 && lane == 0)   // next step's counters
+            buf.reset_count[(((buf.reset_slot + 1) % 3) * PHC_RESET_SUBLISTS + r32) * PHC_RESET_COUNT_STRIDE] = 0;
+        if (i >= cap || i >= buf.reset_count[(buf.reset_slot * PHC_RESET_SUBLISTS + sub) * PHC_RESET_COUNT_STRIDE]) return;
+        env = buf.reset_list[sub * cap + i];
+    } else {
+        if (r >= num_reset) return;
+        // env_ids == NULL: masked mode over all envs (reset every env whose reset_buf is set) -- no host sync needed.
+        // The flag is NOT cleared here (other groups of the same env still read it).
+        env = env_ids ? env_ids[r] : r;
+        if (!env_ids && buf.reset_buf[env] == 0) return;
     }
-    if (r >= num_reset) return;
-    // env_ids == NULL: masked mode over all envs (reset every env whose reset_buf is set) -- no host sync needed.
-    // The flag is NOT cleared here (other groups of the same env still read it).
-    const int64_t env = env_ids ? env_ids[r] : r;
-    if (!env_ids && buf.reset_buf[env] == 0) return;
-    im_reset_group<DPJ, RNG, G>(model, lib, prm, sim, buf, env, r, k, lane, env_ids, phase, start_at_zero, rng_key);
+    PHC_RTL(1)
+    const int64_t mid = motion_id_of(buf, env);
+    // _sample_ref_state (humanoid_im.py:1000-1023): StateInit.Random -> sample_time_interval; Start / flags.test -> 0
+    // (start_at_zero with a null phase array is only legal in the RNG-free instantiation's list mode)
+    // (device-side call counter, phc_im_buffers_t.reset_rng_counter: folded into the key so that a captured launch draws anew on every replay)
+    const uint64_t key = (RNG && buf.reset_rng_counter) ? splitmix64(rng_key ^ (*buf.reset_rng_counter * 0x9E6C63D0876A9A47ull)) : rng_key;
+    const float t = start_at_zero ? 0.f : sample_time_interval(lib, mid, RNG ? hash_u01(key, (uint32_t)env) : phase[r]);
+    PHC_RTL(2)
+    if (k < 2) im_reset_lane(model, lib, prm, sim, buf, env, lane, t, env_ids != nullptr, 1 << k);
+    PHC_RTL(3)
+    if (k >= 2) {
+        if (prm.amp_ref_table != nullptr) im_reset_amp_table_lane(lib, prm, buf, model.num_bodies, env, lane, G, t, k - 2);
+        else im_reset_amp_lane(lib, prm, buf, model.num_bodies, env, lane, t, k - 2);
+    }
+    PHC_RTL(4)
 }
 
 // build_amp_obs_demo: n samples x S history steps.  One lane group per (sample, step).
@@ -429,9 +424,7 @@ int32_t phc_im_reset_done(const phc_model_t* model, const phc_motion_lib_t* lib,
     // (with a device-side call counter the host one stays out of the key: a captured launch and an eager one then draw the same numbers)
     const uint64_t key = splitmix64(splitmix64(seed) ^ ((buf->reset_rng_counter ? 0ull : counter) * 0xD1342543DE82EF95ull));
     const int g = group_lanes(model->num_bodies, prm->num_ext_bodies);
-    int gx = env_blocks(n, g);
-    if (buf->reset_list && gx > PHC_RESET_GRID_X) gx = PHC_RESET_GRID_X;   // list mode strides over the list (k_im_reset); a smaller grid covers it in one pass
-    const dim3 grid(gx, prm->num_amp_obs_steps + 2);
+    const dim3 grid(env_blocks(n, g), prm->num_amp_obs_steps + 2);
 #define PHC_RESET(DPJ, G) hipLaunchKernelGGL((k_im_reset<DPJ, true, G>), grid, dim3(256), 0, (hipStream_t)stream, *model, *lib, *prm, *sim, *buf, n, nullptr, nullptr, start_at_zero, key)
     if (prm->dofs_per_joint == 1) { if (g == 64) PHC_RESET(1, 64); else PHC_RESET(1, 32); }
     else { if (g == 64) PHC_RESET(3, 64); else PHC_RESET(3, 32); }

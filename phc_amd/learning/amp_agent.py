@@ -380,9 +380,7 @@ class IMAmpAgent:
         return torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.bf16)
 
     # ------------------------------------------------------------------ observation pre-processing (amp_agent.py:535-552)
-    def _preproc_obs(self, obs_batch, use_temp=False, row_index=None, update=True):
-        """`update=False` (with `use_temp`): only the frozen copy's output -- the fold of the batch into the live statistics is issued elsewhere
-        (`_fold_obs_stats`: the two-stream optimizer step puts it on the discriminator's stream, off the policy chain's head)."""
+    def _preproc_obs(self, obs_batch, use_temp=False, row_index=None):
         if not self.normalize_input:
             return obs_batch if row_index is None else obs_batch[row_index]
         # bf16 runs: the normaliser writes the bf16 tensor the GEMMs read (the same values autocast's cast would produce)
@@ -393,25 +391,11 @@ class IMAmpAgent:
             rows = obs_batch.shape[0] if row_index is None else row_index.numel()
             buf = self._pad_buf("obs", rows, self._obs_pad_cols)
             out = buf[:, :obs_batch.shape[1]]
-        if use_temp and not update:
-            y = self.running_mean_std_temp(obs_batch, out_dtype=dt, row_index=row_index, out=out)     # (frozen: no statistics move)
-        elif use_temp:  # statistics keep updating, the frozen copy provides the values (amp_agent.py:527-532)
+        if use_temp:  # statistics keep updating, the frozen copy provides the values (amp_agent.py:527-532)
             y = self.running_mean_std(obs_batch, norm_from=self.running_mean_std_temp, out_dtype=dt, row_index=row_index, out=out)
         else:
             y = self.running_mean_std(obs_batch, out_dtype=dt, row_index=row_index, out=out)
         return y if out is None else buf
-
-    def _fold_obs_stats(self, obs_batch, row_index=None):
-        """The statistics half of `_preproc_obs(..., use_temp=True)`: the minibatch folded into the live observation normaliser, no output."""
-        if self.normalize_input:
-            self.running_mean_std(obs_batch, want_output=False, row_index=row_index)
-
-    def _split_obs_norm(self, obs):
-        """Round 6: in the two-stream step the policy chain is the longer one and starts with the observation normaliser (moments over 16384 x 934 + their finishing
-        launch, ~40 us before the first GEMM can start).  Its OUTPUT comes from the frozen copy (`temp_running_mean`), so the moments are not needed by anything in
-        the step: the policy stream only normalises, the discriminator's stream folds the statistics.  Same numbers, same final statistics."""
-        return (self.normalize_input and self.temp_running_mean and obs.is_cuda and self.running_mean_std_temp is not None and bool(self.config.get("split_obs_norm", True))
-                and not self.running_mean_std.forzen and not os.environ.get("PHC_NO_SPLIT_OBS_NORM"))
 
     def _pad_buf(self, name, rows, cols):
         """Persistent zero-initialised bf16 [rows, cols] buffers (one per use and row count: a captured graph keeps their address)."""
@@ -788,12 +772,11 @@ class IMAmpAgent:
             main = torch.cuda.current_stream(d["obs"].device)
             br.wait_stream(main)
             split = self._split_active() and want_info      # (want_info=False: a captured step's warm-up pass -- gradients only, no collective)
-            fold = self._split_obs_norm(d["obs"])
             with torch.cuda.stream(br):
-                self._disc_pass(d, amp_idx, obs_rows=idx if fold else None, fold_obs=fold)
+                self._disc_pass(d, amp_idx)
                 if split:
                     self._grad_all_reduce("disc")
-            self._policy_pass(d, idx, fold_obs=not fold)
+            self._policy_pass(d, idx)
             if split:
                 self._grad_all_reduce("policy")
             self._reduced_in_pass = split
@@ -872,7 +855,7 @@ class IMAmpAgent:
             register_lane(self._branches, "disc")      # (its kernels get their own reduction scratch buffers)
         return self._branches
 
-    def _disc_pass(self, d, amp_idx, obs_rows=None, fold_obs=False):
+    def _disc_pass(self, d, amp_idx):
         """The discriminator's share of an optimizer step on the CURRENT stream: its slice of the gradient bucket zeroed (weight-decay gradients
         preloaded), the three AMP batches normalised into one [agent; replay; demo] buffer, forward, loss terms, backward."""
         ws, coefs, preload = self._disc_decay_terms()
@@ -892,16 +875,14 @@ class IMAmpAgent:
         roots, _ = self._disc_loss_fused(logits, m, amp_obs_demo)
         with param_grad_only(), deferred_colsums():   # (bias gradients: first stages in the layers, ONE finishing launch here)
             torch.autograd.backward(roots, grad_tensors=[self._unit_cotangent(r) for r in roots])
-        if fold_obs:   # the observation normaliser's statistics (see _split_obs_norm): behind the discriminator's own work, this chain is the shorter one
-            self._fold_obs_stats(d["obs"], obs_rows)
 
-    def _policy_pass(self, d, idx, fold_obs=True):
+    def _policy_pass(self, d, idx):
         """Actor + critic share of an optimizer step on the current stream: their slices of the gradient bucket zeroed, the observation
         normalised, both forward passes, the fused loss kernel, backward.  (The critic on a third stream was measured too: a graph with a
         fork inside leaves the runtime's packet-replay path -- profiles/r04_ppo/README.md.)"""
         net = self.model.a2c_network
         self.grads.zero(spans=self._policy_spans)
-        obs = self._preproc_obs(d["obs"], use_temp=self.temp_running_mean, row_index=idx, update=fold_obs)
+        obs = self._preproc_obs(d["obs"], use_temp=self.temp_running_mean, row_index=idx)
         with self._autocast():
             value = net.eval_critic(obs)
             mu, logstd = net.eval_actor(obs)
@@ -1135,11 +1116,10 @@ class IMAmpAgent:
                     # ran the chains mostly one after the other (profiles/r04_ppo/README.md)
                     gd, gt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
                     data, m = self._g_data, self._amp_minibatch_size
-                    fold = self._split_obs_norm(data["obs"])
                     with torch.cuda.graph(g, capture_error_mode=mode):
-                        self._policy_pass(data, self._g_idx, fold_obs=not fold)
+                        self._policy_pass(data, self._g_idx)
                     with torch.cuda.graph(gd, stream=br, capture_error_mode=mode):
-                        self._disc_pass(data, self._g_idx[:m], obs_rows=self._g_idx if fold else None, fold_obs=fold)
+                        self._disc_pass(data, self._g_idx[:m])
                     with torch.cuda.graph(gt, capture_error_mode=mode):
                         self._graph_tail(fuse_opt)
                     g = (g, gd, gt)
