@@ -52,11 +52,28 @@ def test_step_matches_oracle(n, motion, iters):
             tgt = (task._pd_action_offset + task._pd_action_scale * actions).cpu().numpy()
             tgt[:, task._freeze_mask.cpu().numpy() != 0] = 0
             fresh = np.flatnonzero(prog_before == 0)
-            for e in sorted({0, 1, 63, n // 2 + 5, n - 64, n - 1, *fresh[:2].tolist()}):
-                r, d, rbs, tau, fc = do.sim_step(task.model, root0[e], dof0[e], tgt[e], params=dict(self_collision=int(task._sim_params.self_collision)),
-                                                 sim_dt=task.sim_dt, substeps=2, num_sim_calls=task.control_freq_inv)
-                np.testing.assert_allclose(task._rigid_body_pos[e].cpu().numpy(), rbs[:, 0:3], atol=1e-3, err_msg=f"env {e}")
-                np.testing.assert_allclose(task._root_states[e].cpu().numpy(), r, atol=2e-3, rtol=1e-3, err_msg=f"env {e}")
+            envs = sorted({0, 1, 63, n // 2 + 5, n - 64, n - 1, *fresh[:2].tolist()})
+            assert task._sim_params.inertia_lag == 1      # (round 6 default: the reference of the lagged scheme is the fp64 build of the recursion, tests/step_oracle.py)
+            import hostemu_util as hu
+            ref = hu.sim_step_f64(task.model, task._sim_params, root0[envs], dof0[envs], tgt[envs], task.control_freq_inv)
+            for k, e in enumerate(envs):
+                np.testing.assert_allclose(task._rigid_body_pos[e].cpu().numpy(), ref["rbs"][k][:, 0:3], atol=1e-3, err_msg=f"env {e}")
+                np.testing.assert_allclose(task._root_states[e].cpu().numpy(), ref["root"][k], atol=2e-3, rtol=1e-3, err_msg=f"env {e}")
+            if it == 0:   # ... and the every-sub-step-fresh scheme at this size against the dense oracle, through the C ABI on a copy of the pre-step state
+                from phc_amd import abi
+                a = {k_: torch.from_numpy(np.ascontiguousarray(v)).to(task.device) for k_, v in dict(root=root0[envs], dof=dof0[envs], pd=tgt[envs].astype(F)).items()}
+                z = lambda *sh: torch.zeros(*sh, device=task.device)
+                ne, nb_, nd_ = len(envs), task.num_bodies, task.num_dof
+                rbs_d, cf_d, df_d = z(ne, nb_, 13), z(ne, nb_, 3), z(ne, nd_)
+                sim = abi.sim_state_struct(ne, a["root"], a["dof"], rbs_d, cf_d, df_d, a["pd"])
+                prm = abi.sim_params_struct(self_collision=int(task._sim_params.self_collision), inertia_lag=0)
+                assert task._lib.phc_sim_step(task._model_struct, prm, sim, None, None, None, None, task.control_freq_inv, torch.cuda.current_stream().cuda_stream) == 0
+                torch.cuda.synchronize()
+                for k, e in enumerate(envs):
+                    r, d, rbs, tau, fc = do.sim_step(task.model, root0[e], dof0[e], tgt[e], params=dict(self_collision=int(task._sim_params.self_collision)),
+                                                     sim_dt=task.sim_dt, substeps=2, num_sim_calls=task.control_freq_inv)
+                    np.testing.assert_allclose(rbs_d[k, :, 0:3].cpu().numpy(), rbs[:, 0:3], atol=1e-3, err_msg=f"env {e} (fresh scheme vs dense oracle)")
+                    np.testing.assert_allclose(a["root"][k].cpu().numpy(), r, atol=2e-3, rtol=1e-3, err_msg=f"env {e} (fresh scheme vs dense oracle)")
         torch.cuda.synchronize()
         lib = lib_dict(task)
         prog = task.progress_buf.cpu().numpy()
