@@ -119,7 +119,7 @@ def cpu_baseline(num_envs=4096, budget_s=12.0, max_steps=4000):
     amp = [np.zeros((N, 10, 196), F), np.zeros((N, 10, 196), F)]
     b = dict(progress=np.zeros(N, np.int64), reset=np.ones(N, np.int64), term=np.zeros(N, np.int64), rew=np.zeros(N, F), raw=np.zeros((N, 5), F),
              obs=np.zeros((N, 934), F), mids=np.arange(N, dtype=np.int64), st=np.zeros(N, F), so=np.zeros(N, F), goff=np.zeros((N, 3), F))
-    params = abi.sim_params_struct(self_collision=1)   # as the GPU run: robot.has_self_collision is True in smpl_humanoid.yaml
+    params = abi.sim_params_struct(self_collision=1, inertia_lag=1)   # as the GPU run: robot.has_self_collision is True in smpl_humanoid.yaml, lagged inertias (the task's default)
     rng = np.random.default_rng(0)
     actions = ((rng.random((N, nd)) * 2 - 1) * 0.1).astype(F)
     off, scale = model.pd_action_offset_scale()
