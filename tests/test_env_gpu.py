@@ -689,6 +689,27 @@ def test_bench_multi_rank_logic_ranks_sharing_one_gpu(world):
     assert d["ppo_config"]["collectives_per_epoch"] == n_opt and d["ppo_samples_per_s"] > 0
 
 
+def test_trained_policy_and_collective_workloads_of_the_bench_line():
+    """Round 6: the two new child workloads of `bench.py` at a small size -- `bench_policy.run` (train a policy for a few seconds on the 64-clip library, then time the env step with
+    its actions; the policy's inference replayed from ONE captured graph so that the loop is GPU-bound) and `bench_collective.run` (a one-rank RCCL all-reduce at the two bucket sizes),
+    the second in a child process (it owns a process group)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from phc_amd.learning import bench_policy
+    out = bench_policy.run(envs=256, train_s=4.0, steps=24, target_episode_len=1e9)
+    assert out["policy_inference_as_one_graph"] and out["envs_per_gpu"] == 256 and out["policy_train_epochs"] >= 2
+    assert 0.0 <= out["resets_per_step_share"] <= 1.0 and out["env_step_us"] > 0
+    assert out["env_step_us"] >= out["stepper_launch_us"] and out["stepper_launch_us"] > out["reset_launch_us"] > 0 and out["post_physics_launch_us"] > 0
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, "-m", "phc_amd.learning.bench_collective"], capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    c = json.loads(next(l for l in r.stdout.splitlines() if l.startswith("COLLECTIVE_JSON"))[len("COLLECTIVE_JSON"):])
+    assert c["world_size"] == 1 and set(c["allreduce"]) == {"23.2MB", "149.0MB"} and all(v["median_us"] > 0 for v in c["allreduce"].values())
+
+
 def test_shape_variation_env_end_to_end():
     """robot.has_shape_variation (smpl_humanoid_shape.yaml) end to end: 3 compiled shapes (the reference's gender assets, its own fallback
     when smpl_sim cannot write per-env MJCFs, humanoid.py:748), env i wears shape i % 3.  Checks: the reference clips are run through each
