@@ -151,7 +151,7 @@ def _near(got, want, rtol, atol, msg):
     np.testing.assert_allclose(got, np.asarray(want), rtol=rtol, atol=atol, err_msg=msg)
 
 
-def run_epochs(g, device="cpu", faithful_reset=False, with_reset_done=True, extra=(), tol=None, graphs=False):
+def run_epochs(g, device="cpu", faithful_reset=False, with_reset_done=True, extra=(), tol=None, graphs=False, bf16=False):
     """-> worst relative parameter error over the epochs (for the caller's report)."""
     d = _dims(g)
     t = dict(exp=2e-5, scal_r=2e-4, scal_a=2e-6, stat=1e-6, stat_a=1e-9, param_tail=1e-3)
@@ -160,7 +160,8 @@ def run_epochs(g, device="cpu", faithful_reset=False, with_reset_done=True, extr
     draws = _Draws(g, env)
     with draws:
         torch.manual_seed(0)
-        agent = IMAmpAgent(env, _cfg(d, g, extra), faithful_reset=faithful_reset, bf16=False)
+        agent = IMAmpAgent(env, _cfg(d, g, extra), faithful_reset=faithful_reset, bf16=bf16)
+        assert agent.bf16 == bf16
         agent.model.load_state_dict(_sub(g, "model/"), strict=True)
         if agent.grads.shadow is not None:
             agent.grads.shadow.copy_(agent.grads.flat_param)
@@ -186,13 +187,17 @@ def run_epochs(g, device="cpu", faithful_reset=False, with_reset_done=True, extr
             agent.prepare_dataset = orig_prepare
             tag = f"ep{e}"
             # ---- P4: the rollout
-            for k in ("obses", "next_obses", "amp_obs", "rewards", "actions", "mus", "sigmas", "neglogpacs", "values", "next_values"):
-                _near(agent.exp[k], g[f"{tag}/exp/{k}"], t["exp"], t["exp"] * (10 if k == "neglogpacs" else 1), f"{tag} exp/{k}")
+            for k in ("obses", "next_obses", "amp_obs", "rewards", "sigmas"):        # what the env handed over + the fixed sigma: no network arithmetic in them
+                _near(agent.exp[k], g[f"{tag}/exp/{k}"], t["exp"], t["exp"], f"{tag} exp/{k}")
+            for k in ("actions", "mus", "values", "next_values"):
+                _near(agent.exp[k], g[f"{tag}/exp/{k}"], t.get("net", t["exp"]), t.get("net", t["exp"]), f"{tag} exp/{k}")
+            _near(agent.exp["neglogpacs"], g[f"{tag}/exp/neglogpacs"], t.get("net", t["exp"]), t.get("nlp", 10 * t["exp"]), f"{tag} exp/neglogpacs")
             assert np.array_equal(agent.exp["dones"].cpu().numpy(), g[f"{tag}/exp/dones"]), f"{tag} exp/dones"
             _near(agent.current_rewards, g[f"{tag}/current_rewards"], 1e-5, 1e-5, f"{tag} current_rewards")
             assert np.array_equal(agent.current_lengths.cpu().numpy(), g[f"{tag}/current_lengths"]), f"{tag} current_lengths"
             for k in ("returns", "disc_rewards", "mb_rewards", "reward_raw"):
-                _near(seen["batch"][k], g[f"{tag}/batch/{k}"], 10 * t["exp"], 10 * t["exp"], f"{tag} batch/{k}")
+                bt = t["exp"] if k == "reward_raw" else t.get("net", t["exp"])
+                _near(seen["batch"][k], g[f"{tag}/batch/{k}"], 10 * bt, 10 * bt, f"{tag} batch/{k}")
             assert np.array_equal(seen["batch"]["terminated_flags"].cpu().numpy(), g[f"{tag}/batch/terminated_flags"])
             # ---- P9: what the two ring buffers handed out (bit-exact: index arithmetic on stored rows)
             for k in ("amp_obs_demo", "amp_obs_replay"):
@@ -200,9 +205,10 @@ def run_epochs(g, device="cpu", faithful_reset=False, with_reset_done=True, extr
             # ---- P7: the dataset
             for k in ("old_values", "advantages", "returns", "old_logp_actions"):
                 want = g[f"{tag}/dataset/{k}"]
-                _near(seen["dataset"][k].reshape(want.shape), want, 20 * t["exp"], 20 * t["exp"], f"{tag} dataset/{k}")
+                dt_ = t.get("nlp", 20 * t["exp"]) if k == "old_logp_actions" else 20 * t.get("net", t["exp"])
+                _near(seen["dataset"][k].reshape(want.shape), want, 20 * t.get("net", t["exp"]), dt_, f"{tag} dataset/{k}")
             for k, v in _sub(g, f"{tag}/reward_mean_std_after_prepare/").items():
-                _near(seen["vms"][k], v.numpy(), t["stat"], t["stat_a"], f"{tag} value normaliser after prepare_dataset: {k}")
+                _near(seen["vms"][k], v.numpy(), t.get("vstat", t["stat"]), t.get("vstat", t["stat_a"]), f"{tag} value normaliser after prepare_dataset: {k}")
             # ---- P8 x 8: every optimizer step's scalars, in order (a wrong minibatch slice or shuffle would show here)
             keys = [str(k) for k in g["step_keys"]]
             ours = {"actor_loss": "actor_loss", "critic_loss": "critic_loss", "b_loss": "b_loss", "entropy": "entropy", "kl": "kl", "actor_clip_frac": "actor_clip_frac",
@@ -212,6 +218,8 @@ def run_epochs(g, device="cpu", faithful_reset=False, with_reset_done=True, extr
             want = g[f"{tag}/steps"]
             assert want.shape == (steps_per_epoch, len(keys)) and len(trace["kl"]) == steps_per_epoch
             for j, k in enumerate(keys):
+                if k in t.get("skip_scalars", ()):
+                    continue
                 got = np.asarray(trace[ours[k]])
                 if k in ("actor_clip_frac", "disc_agent_acc", "disc_demo_acc"):     # counts over 64 / 32 rows: at most one row on the other side of its threshold
                     assert np.abs(got - want[:, j]).max() <= t.get("count_slack", 0.0) + 1e-7, f"{tag} step {k}: {got} vs {want[:, j]}"
@@ -224,6 +232,12 @@ def run_epochs(g, device="cpu", faithful_reset=False, with_reset_done=True, extr
             assert list(dict(agent.model.named_parameters())) == names
             for n, p in sd.items():
                 err = (p.detach().float().cpu() - after[n]).abs()
+                if bf16:   # bf16 GEMMs: every gradient element carries a few per cent of rounding noise; the UPDATE has to agree in the mean, element for element it cannot
+                    moved = (after[n] - _sub(g, "model/")[n]).abs().mean()
+                    assert float(err.max()) <= 2.0 * lr * steps_per_epoch * e + 1e-7 and float(err.mean()) <= t["param_mean"] * float(moved) + 1e-9, \
+                        f"{tag} param {n}: mean error {float(err.mean()):.3e} vs mean update {float(moved):.3e}"
+                    worst_param = max(worst_param, float(err.mean()) / max(float(moved), 1e-12))
+                    continue
                 # Adam moves every element by ~lr per step whatever the gradient's size: an element whose gradient is within rounding of zero may step the other way
                 assert float(err.max()) <= 2.0 * lr * steps_per_epoch * e + 1e-7, f"{tag} param {n}: worst {float(err.max()):.3e}"
                 frac_off = float((err > 0.05 * lr).float().mean())
@@ -232,7 +246,8 @@ def run_epochs(g, device="cpu", faithful_reset=False, with_reset_done=True, extr
             for nm, mod in (("running_mean_std", agent.running_mean_std), ("running_mean_std_temp", agent.running_mean_std_temp), ("reward_mean_std", agent.value_mean_std),
                             ("amp_input_mean_std", agent._amp_input_mean_std)):
                 for k, v in _sub(g, f"{tag}/{nm}/").items():
-                    _near(getattr(mod, k), v.numpy(), t["stat"], t["stat_a"], f"{tag} {nm}.{k}")
+                    st_ = (t.get("vstat", t["stat"]), t.get("vstat", t["stat_a"])) if nm == "reward_mean_std" else (t["stat"], t["stat_a"])
+                    _near(getattr(mod, k), v.numpy(), st_[0], st_[1], f"{tag} {nm}.{k}")
             for nm, buf in (("replay", agent._amp_replay_buffer), ("demo", agent._amp_obs_demo_buffer)):
                 assert np.array_equal(buf._data_buf["amp_obs"].cpu().numpy(), g[f"{tag}/{nm}/data"]), f"{tag} {nm} buffer contents"
                 assert [buf._head, buf._total_count, buf._sample_head] == list(g[f"{tag}/{nm}/head_count_samplehead"]), f"{tag} {nm} buffer counters"
@@ -240,11 +255,13 @@ def run_epochs(g, device="cpu", faithful_reset=False, with_reset_done=True, extr
             tags = agent.assemble_train_info(info)
             for k, v in zip((str(x) for x in g[f"{tag}/tags"]), g[f"{tag}/tag_values"]):
                 assert k in tags, f"tag {k} of the reference is not logged"
+                if k.split("/")[1] in t.get("skip_scalars", ()):
+                    continue
                 slack = t.get("count_slack", 0.0) if k in ("loss/clip_frac", "disc/agent_acc", "disc/demo_acc") else 0.0
                 assert abs(tags[k] - v) <= t["scal_a"] + slack + t["scal_r"] * max(abs(v), 0.05), f"{tag} {k}: {tags[k]} vs {v}"
         # ---- the whole run
         got_actions = torch.stack(env.actions_seen).cpu().numpy()
-        np.testing.assert_allclose(got_actions, g["actions_seen"], rtol=t["exp"], atol=t["exp"])
+        np.testing.assert_allclose(got_actions, g["actions_seen"], rtol=t.get("net", t["exp"]), atol=t.get("net", t["exp"]))
         assert np.abs(got_actions).max() <= 1.0
         assert env.k == d["EPOCHS"] * d["T"] and env.demo_k == env.s["demo"].shape[0]
         # (replayed rollout segments read the noise buffer without a host-side draw: epoch 1 eager + epoch 2 capture make the calls)
@@ -255,6 +272,8 @@ def run_epochs(g, device="cpu", faithful_reset=False, with_reset_done=True, extr
         assert sorted(opt["state"]) == list(g["opt/state_ids"])
         for i in g["opt/state_ids"]:
             assert float(opt["state"][int(i)]["step"]) == float(g[f"opt/{i}/step"]) == d["EPOCHS"] * steps_per_epoch
+            if bf16:
+                continue
             m_ref = g[f"opt/{i}/exp_avg"]
             _near(opt["state"][int(i)]["exp_avg"], m_ref, 50 * t["scal_r"], 50 * t["scal_r"] * np.abs(m_ref).max() + 1e-9, f"Adam exp_avg {i}")
     return worst_param
@@ -278,3 +297,17 @@ def test_three_epochs_equal_the_reference_agent_on_hip(golden, graph):
     worst = run_epochs(g, "cuda", extra=extra, graphs=graph, tol=dict(exp=2e-4, scal_r=2e-3, scal_a=2e-5, stat=2e-6, stat_a=1e-7, param_tail=2e-2, count_slack=1.0 / 32))   # (statistics: batch moments summed in another order)
     torch.cuda.synchronize()
     print(f"hip graph={graph}: worst parameter difference after three epochs = {worst:.3f} Adam steps")
+
+
+@pytest.mark.gpu
+def test_three_epochs_of_the_reference_agent_on_hip_with_bf16_gemms(golden):
+    """The BENCHMARKED path -- bf16 MFMA GEMMs under autocast, captured graphs -- through the same three epochs: everything that involves no network arithmetic stays exact (what the env handed over, done
+    flags, both ring buffers' contents and counters, the observation / AMP normalisers, which permutations and masks were drawn), network outputs agree within bf16 accuracy against sigma = 0.055 (mu / values
+    3e-2, neglogp 2.0 of ~10, the value normaliser 5e-2), every optimizer step's critic / bound / discriminator scalars within 15 %, and the parameter UPDATE of each epoch agrees with the reference's in the
+    mean (mean |error| <= 0.5 x mean |update|).  The actor loss and the KL of a 64-row minibatch are not compared in bf16 (a mean of signed terms that nearly cancels: tests/test_learner_parity.py)."""
+    g = golden("learner_epoch")
+    worst = run_epochs(g, "cuda", extra=["+learning.params.config.hip_graph=True", "+learning.params.config.hip_graph_min_rows=1"], graphs=True, bf16=True,
+                       tol=dict(exp=2e-4, net=3e-2, nlp=2.0, scal_r=0.15, scal_a=2e-3, stat=2e-6, stat_a=1e-7, vstat=5e-2, param_mean=0.5, count_slack=6.0 / 32,
+                                skip_scalars=("actor_loss", "kl")))
+    torch.cuda.synchronize()
+    print(f"bf16 GEMMs: worst mean parameter error / mean update over the three epochs = {worst:.3f}")
