@@ -304,10 +304,10 @@ def test_three_epochs_of_the_reference_agent_on_hip_with_bf16_gemms(golden):
     """The BENCHMARKED path -- bf16 MFMA GEMMs under autocast, captured graphs -- through the same three epochs: everything that involves no network arithmetic stays exact (what the env handed over, done
     flags, both ring buffers' contents and counters, the observation / AMP normalisers, which permutations and masks were drawn), network outputs agree within bf16 accuracy against sigma = 0.055 (mu / values
     3e-2, neglogp 2.0 of ~10, the value normaliser 5e-2), every optimizer step's critic / bound / discriminator scalars within 15 %, and the parameter UPDATE of each epoch agrees with the reference's in the
-    mean (mean |error| <= 0.5 x mean |update|).  The actor loss and the KL of a 64-row minibatch are not compared in bf16 (a mean of signed terms that nearly cancels: tests/test_learner_parity.py)."""
+    mean (mean |error| <= 0.35 x mean |update|; measured 0.195).  The actor loss and the KL of a 64-row minibatch are not compared in bf16 (a mean of signed terms that nearly cancels: tests/test_learner_parity.py)."""
     g = golden("learner_epoch")
     worst = run_epochs(g, "cuda", extra=["+learning.params.config.hip_graph=True", "+learning.params.config.hip_graph_min_rows=1"], graphs=True, bf16=True,
-                       tol=dict(exp=2e-4, net=3e-2, nlp=2.0, scal_r=0.15, scal_a=2e-3, stat=2e-6, stat_a=1e-7, vstat=5e-2, param_mean=0.5, count_slack=6.0 / 32,
+                       tol=dict(exp=2e-4, net=3e-2, nlp=2.0, scal_r=0.15, scal_a=2e-3, stat=2e-6, stat_a=1e-7, vstat=5e-2, param_mean=0.35, count_slack=6.0 / 32,
                                 skip_scalars=("actor_loss", "kl")))
     torch.cuda.synchronize()
     print(f"bf16 GEMMs: worst mean parameter error / mean update over the three epochs = {worst:.3f}")
