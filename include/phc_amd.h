@@ -152,7 +152,9 @@ typedef struct {
                                          (forces, drives and velocity products at the current state; a third of the backward sweep's arithmetic).  The kept
                                          I^A is O(dt) old, the velocities it produces differ by O(dt^2) per sub-step: the scheme stays first-order consistent
                                          (tests/test_dynamics.py: dt-convergence with the switch on).  A ground-contact point that starts to touch in a
-                                         lagged sub-step joins at the next fresh one (its impedance is not in the kept I^A).  0 = every sub-step fresh. */
+                                         lagged sub-step joins at the next fresh one (its impedance is not in the kept I^A).  0 = every sub-step fresh.
+                                         The host side (HumanoidIm) sets 1 by default for contact_model 0 since round 6: pinned against the double-precision build
+                                         of this recursion (oracle/hostemu/hostemu64.cpp; tests/test_stepper_options.py). */
     int32_t force_average;            /* 1 (solver.force_average): contact_force (S4) and dof_force (S5) are the MEANS over all sub-steps of the env step
                                          (what a power / contact reward integrates over the control interval); 0 = the last sub-step's values -- what Isaac
                                          Gym's tensors hold after simulate() with substeps > 1, as far as its documentation says (humanoid.py:185,193-194) */
