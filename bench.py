@@ -76,6 +76,8 @@ def parse():
     ap.add_argument("--self-collision", type=int, default=-1, help="-1: as the robot yaml says (has_self_collision: True); 0/1 force")
     ap.add_argument("--solver", action="append", default=[], metavar="KEY=VALUE", help="stepper switch passed on as `+solver.KEY=VALUE` (repeatable), "
                     "e.g. --solver inertia_lag=1 --solver force_average=1 --solver contact=tgs")
+    ap.add_argument("--learner", action="append", default=[], metavar="KEY=VALUE", help="learner switch passed on as `+learning.params.config.KEY=VALUE` (repeatable), "
+                    "e.g. --learner actor_precision=split_bf16")
     ap.add_argument("--motion-clips", type=int, default=1, help="synthetic clips in the motion library (configs[1]: 1; configs[2]/[3] shape: thousands)")
     ap.add_argument("--actions", choices=["random", "tracking"], default="random",
                     help="random: fixed a ~ U(-1,1)*0.1 tensor (SURVEY 8d protocol; zero-pose targets -> episodes end after a few steps); "
@@ -451,7 +453,7 @@ def main():
     learn_over = ([f"learning={args.learning}"] + (["env=env_im_pnn"] if "pnn" in args.learning and args.robot == "smpl" else [])) if args.learning != "im" else []
     cfg = compose(learn_over + robot_over + graph_over + [f"env.num_envs={args.envs}", f"env.motion_file=synthetic:{args.motion_clips}:0", f"device_id={local_rank}",
                                 f"rl_device=cuda:{local_rank}", f"+solver.lane_mapping={args.lane_mapping}"] + ([f"+solver.self_collision={args.self_collision}"] if args.self_collision >= 0 else [])
-                  + [f"+solver.{kv}" for kv in args.solver])
+                  + [f"+solver.{kv}" for kv in args.solver] + [f"+learning.params.config.{kv}" for kv in args.learner])
     t_build = time.perf_counter()
     task, env = parse_task(cfg, device_id=local_rank)
     t_build = time.perf_counter() - t_build

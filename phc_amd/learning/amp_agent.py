@@ -312,6 +312,19 @@ class IMAmpAgent:
         self.value_mean_std = RunningMeanStd((1,)).to(self.device) if self.normalize_value else None
         self._amp_input_mean_std = RunningMeanStd((amp_dim,)).to(self.device) if self._normalize_amp_input else None
         self.running_mean_std_temp = None
+        # `actor_precision=split_bf16` (round 6): the actor's layers work on fp32 activations with three bf16 GEMMs per product (fast_ops._SplitLinearFn)
+        # -- an option between the bf16 path (actor-gradient parity 8e-2 on the small fixtures) and fp32 GEMMs for everything (4.8 x the update)
+        self._actor_split = str(c.get("actor_precision", "bf16")) == "split_bf16" and self.bf16
+        if str(c.get("actor_precision", "bf16")) not in ("bf16", "split_bf16"):
+            raise ValueError(f"learning.params.config.actor_precision must be bf16 or split_bf16, not {c.get('actor_precision')!r}")
+        if self._actor_split:
+            if net_name != "amp" or not self.normalize_input or not self.temp_running_mean:
+                raise NotImplementedError("actor_precision=split_bf16 is built for the plain `amp` network with normalize_input and temp_running_mean")
+            from .fast_ops import FastLinear
+            for m in list(net.actor_mlp.modules()) + [net.mu]:
+                if isinstance(m, FastLinear):
+                    m.split_precision = True
+                    m.weight._pad_cols = 0      # (the split layers read the fp32 master weights: no K-padded bf16 copy)
         self.grads = FlatGradBucket(self.model.parameters())
         # K-padded first layers: width of the padded input buffers the normalisers write (0: no padding; see FlatGradBucket)
         padded_k = {p.shape[1]: p._padded.shape[1] for p in self.grads.params if getattr(p, "_padded", None) is not None}
@@ -397,6 +410,17 @@ class IMAmpAgent:
             y = self.running_mean_std(obs_batch, out_dtype=dt, row_index=row_index, out=out)
         return y if out is None else buf
 
+    def _actor_obs(self, obs_batch, use_temp=False, row_index=None):
+        """The ACTOR's input in split-precision mode: the normalised observation in fp32, from the same statistics the bf16 tensor of `_preproc_obs` comes from, WITHOUT
+        folding the batch into them again (the bf16 call of the same step does that once)."""
+        src = self.running_mean_std_temp if use_temp else self.running_mean_std
+        was_training = src.training
+        src.eval()
+        try:
+            return src(obs_batch, out_dtype=torch.float32, row_index=row_index)
+        finally:
+            src.train(was_training)
+
     def _pad_buf(self, name, rows, cols):
         """Persistent zero-initialised bf16 [rows, cols] buffers (one per use and row count: a captured graph keeps their address)."""
         bufs = self.__dict__.setdefault("_pad_bufs", {})
@@ -421,7 +445,7 @@ class IMAmpAgent:
     def get_action_values(self, obs):
         processed = self._preproc_obs(obs)
         with torch.no_grad(), self._autocast():
-            res = self.model({"is_train": False, "prev_actions": None, "obs": processed})
+            res = self.model({"is_train": False, "prev_actions": None, "obs": processed, "obs_actor": self._actor_obs(obs) if self._actor_split else None})
         if self.normalize_value:
             res["values"] = self.value_mean_std(res["values"], True)
         return res
@@ -498,8 +522,10 @@ class IMAmpAgent:
                 e["obses"][n].copy_(self.obs)
             processed = self._preproc_obs(self.obs)
             with self._autocast():
-                mu, logstd = net.eval_actor(processed)
+                mu, logstd = net.eval_actor(self._actor_obs(self.obs) if self._actor_split else processed)
                 value = net.eval_critic(processed)
+            if self._actor_split:
+                value = value.float()       # (one dtype flag for both heads in phc_policy_sample)
             policy_sample(mu.contiguous(), value.contiguous(), (logstd[0] if logstd.dim() == 2 else logstd).float().contiguous(), vnorm,
                           e["actions"][n], e["mus"][n], e["sigmas"][n], e["neglogpacs"][n], e["values"][n])
             if self.clip_actions:
@@ -807,8 +833,12 @@ class IMAmpAgent:
             amp_obs_demo.requires_grad_(True)
             inp = {"is_train": True, "prev_actions": d["actions"], "obs": obs, "amp_obs": amp_obs, "amp_obs_replay": amp_obs_replay,
                    "amp_obs_demo": amp_obs_demo, "raw_disc_logits": False}
+        if self._actor_split and fused:
+            inp["obs_actor"] = self._actor_obs(d["obs"], use_temp=self.temp_running_mean, row_index=idx)
         with self._autocast():
             res = self.model.forward_heads(inp) if fused else self.model(inp)
+        if self._actor_split and fused:
+            res["value"] = res["value"].float()
         decay = None
         if fused_disc:
             roots, decay = self._disc_loss_fused(res["disc_logits"], amp_obs.shape[0], amp_obs_demo)
@@ -885,7 +915,9 @@ class IMAmpAgent:
         obs = self._preproc_obs(d["obs"], use_temp=self.temp_running_mean, row_index=idx)
         with self._autocast():
             value = net.eval_critic(obs)
-            mu, logstd = net.eval_actor(obs)
+            mu, logstd = net.eval_actor(self._actor_obs(d["obs"], use_temp=self.temp_running_mean, row_index=idx) if self._actor_split else obs)
+        if self._actor_split:
+            value = value.float()           # (phc_ppo_loss takes both heads in one type)
         ppo, _ = ppo_loss(mu.contiguous(), value.contiguous(), logstd[0] if logstd.dim() == 2 else logstd, d["actions"], d["old_logp_actions"],
                           d["advantages"], d["returns"], d["old_values"], d["mu"], d["sigma"], self.e_clip, self.critic_coef, self.entropy_coef,
                           self.bounds_loss_coef, self.clip_value, unit_grad=True, row_index=idx, out=self._raw_buffer()[0][0:7])

@@ -631,12 +631,66 @@ class FastLinear1DD(nn.Linear):
         return nn.functional.linear(x[..., :self.in_features] if x.shape[-1] > self.in_features else x, self.weight, self.bias)   # (x may be K-padded)
 
 
+# ---- split-bf16 layers (round 6, `+learning.params.config.actor_precision=split_bf16`) --------------------------------------------------------------------------
+# A precision option between bf16 GEMMs and the 4.8 x slower fp32 ones for the ACTOR: every operand is cut into a bf16 head and a bf16 tail (x = xh + xl with
+# xl = bf16(x - xh): 16 mantissa bits together), a product takes three MFMA GEMMs with fp32 results -- ah bh + ah bl + al bh, the tail x tail term (2^-18) is dropped -- and the
+# activations stay fp32 between the layers (`torch.mm(..., out_dtype=torch.float32)`, aten::mm.dtype).  Plain torch ops: a correctness-first path, ~3 x the actor's GEMM time.
+def _split16(t):
+    h = t.to(torch.bfloat16)
+    return h, (t - h.float()).to(torch.bfloat16)
+
+
+def _mm3(ah, al, bh, bl, bias=None):
+    """(ah + al) @ (bh + bl) in fp32 without the tail x tail term; `bias` [N] fp32 rides in the first product."""
+    y = torch.mm(ah, bh, out_dtype=torch.float32) if bias is None else torch.addmm(bias, ah, bh, out_dtype=torch.float32)
+    y = torch.addmm(y, ah, bl, out_dtype=torch.float32)
+    return torch.addmm(y, al, bh, out_dtype=torch.float32)
+
+
+class _SplitLinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu):
+        with torch.autocast("cuda", enabled=False):
+            xh, xl = _split16(x)
+            wh, wl = _split16(weight.detach())
+            y = _mm3(xh, xl, wh.t(), wl.t(), bias.detach().float())
+            if relu:
+                y = torch.relu_(y)
+        ctx.save_for_backward(xh, xl, wh, wl, *( (y,) if relu else ()))
+        ctx.relu = relu
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        xh, xl, wh, wl = ctx.saved_tensors[:4]
+        with torch.autocast("cuda", enabled=False):
+            gy = gy.float()
+            if ctx.relu:
+                gy = gy * (ctx.saved_tensors[4] > 0)
+            gh, gl = _split16(gy)
+            gx = _mm3(gh, gl, wh, wl) if ctx.needs_input_grad[0] else None
+            gw = _mm3(gh.t(), gl.t(), xh, xl) if ctx.needs_input_grad[1] else None
+            gb = gy.sum(0) if ctx.needs_input_grad[2] else None
+        return gx, gw, gb, None
+
+
 class FastLinear(nn.Linear):
     fuse_relu = False      # set by network.build_mlp when a ReLU follows: the device passes apply it in the GEMM epilogue
     _fused_now = False     # did the last forward() apply it?  (read by the FusedReLU module that follows in the nn.Sequential)
+    split_precision = False   # IMAmpAgent sets it on the actor's layers for `actor_precision=split_bf16`: fp32 activations in, fp32 out, three bf16 GEMMs per product
 
     def forward(self, x):
         self._fused_now = False
+        if self.split_precision and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32:
+            self._fused_now = self.fuse_relu
+            if torch.is_grad_enabled() and self.weight.requires_grad:
+                return _SplitLinearFn.apply(x[:, :self.in_features] if x.shape[1] > self.in_features else x, self.weight, self.bias, self.fuse_relu)
+            with torch.autocast("cuda", enabled=False):
+                xh, xl = _split16(x[:, :self.in_features] if x.shape[1] > self.in_features else x)
+                wh, wl = _split16(self.weight.detach())
+                y = _mm3(xh, xl, wh.t(), wl.t(), self.bias.detach().float())
+                return torch.relu_(y) if self.fuse_relu else y
         if self.out_features == 1 and x.is_cuda and x.dim() == 2 and x.dtype == torch.bfloat16 and x.is_contiguous() and self.bias is not None:
             if _device_training_pass(self, x):
                 return _Linear1Fn.apply(x, self.weight, self.bias)

@@ -241,7 +241,8 @@ class ModelAMPContinuous(nn.Module):
     def forward(self, input_dict):
         is_train = input_dict.get("is_train", True)
         obs = input_dict["obs"]
-        mu, logstd = self.a2c_network.eval_actor(obs)
+        obs_actor = input_dict.get("obs_actor")     # (split-precision actor: its fp32 input, IMAmpAgent._actor_obs)
+        mu, logstd = self.a2c_network.eval_actor(obs if obs_actor is None else obs_actor)
         value = self.a2c_network.eval_critic(obs)
         mu, logstd, value = mu.float(), logstd.float(), value.float()
         sigma = torch.exp(logstd)
@@ -262,7 +263,8 @@ class ModelAMPContinuous(nn.Module):
         """Training pass that stops at the network heads -- `mu` [B, D] and `value` [B, 1] as the GEMMs produce them (bf16 under
         autocast), `logstd` [D] and the three discriminator logit blocks -- for the fused loss (fast_ops.ppo_loss)."""
         obs = input_dict["obs"]
-        mu, logstd = self.a2c_network.eval_actor(obs)
+        obs_actor = input_dict.get("obs_actor")
+        mu, logstd = self.a2c_network.eval_actor(obs if obs_actor is None else obs_actor)
         value = self.a2c_network.eval_critic(obs)
         if "amp_obs_cat" in input_dict:   # [agent; replay; demo] already assembled in one buffer (fast_ops.rows_with_grad)
             x = input_dict["amp_obs_cat"]
