@@ -389,7 +389,7 @@ def test_split_bf16_actor_brings_the_actor_gradients_to_the_reference(golden, fi
         err = float(np.abs(params[n].grad.detach().float().cpu().numpy() - ref).max() / scale)
         worst = max(worst, err)
     print(f"{fixture}: worst actor-gradient element error / parameter's gradient scale with the split-bf16 actor = {worst:.2e}")
-    assert worst < 5e-2      # VERDICT r5 item 7's target; measured far below
+    assert worst < 5e-3      # (VERDICT r5 item 7 asked for <= 5e-2; measured 1.5e-3 / 2.9e-5 / 1.0e-4)
     # the other networks: the bf16 tolerances of test_calc_gradients_equals_the_reference_agent_on_hip
     _check_step(agent, g, info, rtol_loss=8e-2, grad_rtol=0.6, grad_atol=1e-4, param_atol=4.1e-5, stats_rtol=1e-7, skip=("actor_loss", "kl", "actor_mlp", "a2c_network.mu"))
 
