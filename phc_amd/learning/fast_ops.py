@@ -633,44 +633,61 @@ class FastLinear1DD(nn.Linear):
 
 # ---- split-bf16 layers (round 6, `+learning.params.config.actor_precision=split_bf16`) --------------------------------------------------------------------------
 # A precision option between bf16 GEMMs and the 4.8 x slower fp32 ones for the ACTOR: every operand is cut into a bf16 head and a bf16 tail (x = xh + xl with
-# xl = bf16(x - xh): 16 mantissa bits together), a product takes three MFMA GEMMs with fp32 results -- ah bh + ah bl + al bh, the tail x tail term (2^-18) is dropped -- and the
-# activations stay fp32 between the layers (`torch.mm(..., out_dtype=torch.float32)`, aten::mm.dtype).  Plain torch ops: a correctness-first path, ~3 x the actor's GEMM time.
+# xl = bf16(x - xh): 16 mantissa bits together), a product is (ah + al)(bh + bl) ~ ah bh + ah bl + al bh (the tail x tail term, 2^-18, is dropped) and the activations stay
+# fp32 between the layers.  The three partial products of one product are ONE MFMA GEMM with a three times longer reduction -- [ah, ah, al] against [bh; bl; bh] -- with an
+# fp32 result (`torch.mm(..., out_dtype=torch.float32)`, aten::mm.dtype): 3 x the flops of the bf16 layer at a GEMM shape the library likes better, instead of nine launches
+# and two fp32 accumulate passes.  Plain torch ops around it (split, concatenation, mask): a correctness-first path.
 def _split16(t):
     h = t.to(torch.bfloat16)
     return h, (t - h.float()).to(torch.bfloat16)
 
 
-def _mm3(ah, al, bh, bl, bias=None):
-    """(ah + al) @ (bh + bl) in fp32 without the tail x tail term; `bias` [N] fp32 rides in the first product."""
-    y = torch.mm(ah, bh, out_dtype=torch.float32) if bias is None else torch.addmm(bias, ah, bh, out_dtype=torch.float32)
-    y = torch.addmm(y, ah, bl, out_dtype=torch.float32)
-    return torch.addmm(y, al, bh, out_dtype=torch.float32)
+def _cat3(h, l, dim, second_tail):
+    """[h, h, l] (second_tail False) or [h, l, h] (True) along `dim`: the left / right operand of a split product."""
+    return torch.cat([h, l, h] if second_tail else [h, h, l], dim=dim)
+
+
+def _split_weight(weight):
+    wh, wl = _split16(weight.detach())
+    return _cat3(wh, wl, 1, True), _cat3(wh, wl, 0, True)     # [N, 3K] for the forward product, [3N, K] for the input gradient
+
+
+def _split_forward(x, wc, bias, relu):
+    xh, xl = _split16(x)
+    xc = _cat3(xh, xl, 1, False)                               # [B, 3K]
+    y = torch.addmm(bias, xc, wc.t(), out_dtype=torch.float32)
+    return (torch.relu_(y) if relu else y), xh, xl
 
 
 class _SplitLinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, relu):
         with torch.autocast("cuda", enabled=False):
-            xh, xl = _split16(x)
-            wh, wl = _split16(weight.detach())
-            y = _mm3(xh, xl, wh.t(), wl.t(), bias.detach().float())
-            if relu:
-                y = torch.relu_(y)
-        ctx.save_for_backward(xh, xl, wh, wl, *( (y,) if relu else ()))
+            wc, wr = _split_weight(weight)
+            y, xh, xl = _split_forward(x, wc, bias.detach().float(), relu)
+        ctx.save_for_backward(xh, xl, wr, *((y,) if relu else ()))
         ctx.relu = relu
         return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, gy):
-        xh, xl, wh, wl = ctx.saved_tensors[:4]
+        xh, xl, wr = ctx.saved_tensors[:3]
         with torch.autocast("cuda", enabled=False):
             gy = gy.float()
             if ctx.relu:
-                gy = gy * (ctx.saved_tensors[4] > 0)
+                gy = gy * (ctx.saved_tensors[3] > 0)
             gh, gl = _split16(gy)
-            gx = _mm3(gh, gl, wh, wl) if ctx.needs_input_grad[0] else None
-            gw = _mm3(gh.t(), gl.t(), xh, xl) if ctx.needs_input_grad[1] else None
+            gx = torch.mm(_cat3(gh, gl, 1, False), wr, out_dtype=torch.float32) if ctx.needs_input_grad[0] else None     # [B, 3N] x [3N, K]
+            gw = None
+            if ctx.needs_input_grad[1]:
+                # dW = gh^T xh + gh^T xl + gl^T xh = [gh; gh; gl]^T [xh; xl; xh]: one reduction over 3 B rows, cut into SPLIT_K slabs like the bf16 layers' (wgrad_split_k)
+                gr, xr = _cat3(gh, gl, 0, False), _cat3(xh, xl, 0, True)
+                rows = gr.shape[0]
+                if rows % SPLIT_K == 0 and rows >= 2048 and gr.shape[1] >= 16:
+                    gw = torch.bmm(gr.view(SPLIT_K, rows // SPLIT_K, -1).transpose(1, 2), xr.view(SPLIT_K, rows // SPLIT_K, -1), out_dtype=torch.float32).sum(0)
+                else:
+                    gw = torch.mm(gr.t(), xr, out_dtype=torch.float32)
             gb = gy.sum(0) if ctx.needs_input_grad[2] else None
         return gx, gw, gb, None
 
@@ -687,10 +704,8 @@ class FastLinear(nn.Linear):
             if torch.is_grad_enabled() and self.weight.requires_grad:
                 return _SplitLinearFn.apply(x[:, :self.in_features] if x.shape[1] > self.in_features else x, self.weight, self.bias, self.fuse_relu)
             with torch.autocast("cuda", enabled=False):
-                xh, xl = _split16(x[:, :self.in_features] if x.shape[1] > self.in_features else x)
-                wh, wl = _split16(self.weight.detach())
-                y = _mm3(xh, xl, wh.t(), wl.t(), self.bias.detach().float())
-                return torch.relu_(y) if self.fuse_relu else y
+                wc, _ = _split_weight(self.weight)
+                return _split_forward(x[:, :self.in_features] if x.shape[1] > self.in_features else x, wc, self.bias.detach().float(), self.fuse_relu)[0]
         if self.out_features == 1 and x.is_cuda and x.dim() == 2 and x.dtype == torch.bfloat16 and x.is_contiguous() and self.bias is not None:
             if _device_training_pass(self, x):
                 return _Linear1Fn.apply(x, self.weight, self.bias)
