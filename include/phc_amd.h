@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PHC_ABI_VERSION 36
+#define PHC_ABI_VERSION 37
 #define PHC_MAX_BODIES 64   /* bodies (incl. extended reference bodies) per articulation; also the slot count of the model tables */
 #define PHC_EINVAL (-1)
 #define PHC_EUNSUPPORTED (-2)
@@ -419,6 +419,15 @@ int32_t phc_colsum_finish_batch(int32_t count, const phc_colsum_job_t* jobs /* h
  * slab products; out [n] fp32 receives their sum (accumulate 0) or has it added (accumulate != 0: a parameter's second and later gradient
  * contributions of a step, torch's AccumulateGrad).  part and out 16-byte aligned. */
 int32_t phc_sum_slabs_bf16(const void* part, int32_t slabs, int64_t n, float* out, int32_t accumulate, void* stream);
+/* ABI 37.  Operand of a split-precision linear layer (`+learning.params.config.actor_precision=split_bf16`; no reference counterpart: the reference's layers are fp32
+ * `torch.nn.Linear`s, phc/learning/network_builder.py, and this is the precision option between bf16 and fp32 GEMMs).  x fp32 [rows, cols], rows `ld_in` floats apart,
+ * optionally gated (gate fp32, rows `ld_gate` apart: x where gate > 0, else 0 -- the ReLU mask of a backward pass; NULL = no gate), is cut into bf16 head h = bf16(x) and
+ * tail l = bf16(x - h) and written as the three chunks ONE bf16 GEMM with a three times longer reduction reads:
+ *   out[row * row_stride + c * chunk_stride + col] (bf16), c = 0, 1, 2 = (h, h, l) for order 0, (h, l, h) for order 1,
+ * with zeros in columns cols .. cols_pad - 1 and rows rows .. rows_pad - 1.  (x h)(w h) + (x l)(w h) + (x h)(w l) = an order-1 operand against an order-0 one.
+ * cols_pad, row_stride, chunk_stride multiples of 4; out 8-byte aligned. */
+int32_t phc_split3_bf16(const float* x, int64_t ld_in, const float* gate, int64_t ld_gate, int64_t rows, int32_t cols, int64_t rows_pad, int32_t cols_pad, void* out,
+                        int64_t row_stride, int64_t chunk_stride, int32_t order, void* stream);
 
 /* Discriminator loss pieces (phc/learning/amp_agent.py:732-808 `_disc_loss`).
  * phc_disc_bce: logits [n_agent + n_demo] (agent and replay rows first, demo rows last; bf16 or fp32):

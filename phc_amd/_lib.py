@@ -109,6 +109,7 @@ _SIGNATURES = {
     "phc_colsum_bf16": ([c_p, c_i64, c_i32, c_p, c_p, c_p], c_i32),
     "phc_colsum_relu_bf16": ([c_p, c_p, c_i64, c_i32, c_p, c_p, c_p, c_p], c_i32),
     "phc_sum_slabs_bf16": ([c_p, c_i32, c_i64, c_p, c_i32, c_p], c_i32),
+    "phc_split3_bf16": ([c_p, c_i64, c_p, c_i64, c_i64, c_i32, c_i64, c_i32, c_p, c_i64, c_i64, c_i32, c_p], c_i32),
     "phc_colsum_chunks": ([c_i64], c_i32),
     "phc_linear1_chunks": ([c_i64], c_i32),
     "phc_colsum_finish_batch": ([c_i32, P(ColsumJob), c_p], c_i32),
@@ -143,7 +144,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the .so does not export the symbol
         fn.argtypes = argtypes
         fn.restype = restype
-    if lib.phc_abi_version() != 36:
+    if lib.phc_abi_version() != 37:
         raise ImportError("libphc_amd.so ABI version mismatch")
     _lib = lib
     return lib

@@ -744,6 +744,59 @@ int32_t phc_sum_slabs_bf16(const void* part, int32_t slabs, int64_t n, float* ou
     return e == hipSuccess ? 0 : (int32_t)e;
 }
 
+// ------------------------------------------------------------------------------------------
+// Split-precision operand of a linear layer (`actor_precision=split_bf16`): x fp32 [rows, cols] (rows `ld_in` apart), optionally gated by another fp32 tensor
+// (the ReLU mask of a backward pass: x where gate > 0, else 0), is cut into a bf16 head h = bf16(x) and a bf16 tail l = bf16(x - h) and stored as the three
+// chunks one long-reduction GEMM reads: out[row * row_stride + c * chunk_stride + col], c = 0..2 holding (h, h, l) (order 0) or (h, l, h) (order 1); columns
+// cols..cols_pad-1 and rows rows..rows_pad-1 are written as zeros (the GEMM's reduction length is a multiple of 32 elements).  4 columns per lane.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_split3_bf16(const float* __restrict__ x, int64_t ld_in, const float* __restrict__ gate, int64_t ld_gate, int64_t rows, int cols,
+                                                     int64_t rows_pad, int cols_pad, __hip_bfloat16* __restrict__ out, int64_t row_stride, int64_t chunk_stride, int order) {
+    const int q = cols_pad >> 2;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t row = t / q;
+    if (row >= rows_pad) return;
+    const int c0 = (int)(t - row * q) << 2;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (row < rows) {
+        const float* xr = x + row * ld_in;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (c0 + k < cols) v[k] = xr[c0 + k];
+        if (gate) {
+            const float* gr = gate + row * ld_gate;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (c0 + k < cols && !(gr[c0 + k] > 0.f)) v[k] = 0.f;
+        }
+    }
+    uint16_t h[4], l[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const __hip_bfloat16 hb = __float2bfloat16(v[k]);
+        const __hip_bfloat16 lb = __float2bfloat16(v[k] - __bfloat162float(hb));
+        h[k] = *reinterpret_cast<const uint16_t*>(&hb);
+        l[k] = *reinterpret_cast<const uint16_t*>(&lb);
+    }
+    const uint2 hq = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
+    const uint2 lq = make_uint2((uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16));
+    __hip_bfloat16* o = out + row * row_stride + c0;
+    *reinterpret_cast<uint2*>(o) = hq;
+    *reinterpret_cast<uint2*>(o + chunk_stride) = order ? lq : hq;
+    *reinterpret_cast<uint2*>(o + 2 * chunk_stride) = order ? hq : lq;
+}
+
+int32_t phc_split3_bf16(const float* x, int64_t ld_in, const float* gate, int64_t ld_gate, int64_t rows, int32_t cols, int64_t rows_pad, int32_t cols_pad, void* out,
+                        int64_t row_stride, int64_t chunk_stride, int32_t order, void* stream) {
+    if (!x || !out || rows < 1 || cols < 1 || rows_pad < rows || cols_pad < cols || (cols_pad & 3) || (row_stride & 3) || (chunk_stride & 3)) return PHC_EINVAL;
+    if (reinterpret_cast<uintptr_t>(out) & 7) return PHC_EINVAL;
+    const int64_t threads = rows_pad * (cols_pad >> 2);
+    hipLaunchKernelGGL(k_split3_bf16, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ld_in, gate, ld_gate, rows, cols, rows_pad, cols_pad,
+                       reinterpret_cast<__hip_bfloat16*>(out), row_stride, chunk_stride, order);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int32_t)e;
+}
+
 int32_t phc_rollout_bookkeeping(const float* rewards, float reward_scale, const int64_t* dones, const int64_t* terminate, const float* reward_raw,
                                 int32_t num_reward_terms, int64_t num_envs, float* exp_rewards, uint8_t* exp_dones, float* terminated_flags,
                                 float* terminated_mask, float* reward_raw_acc, float* current_rewards, float* current_lengths, void* stream) {

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     assert sorted(_lib.EXPORTED_SYMBOLS) == declared, "ctypes table and header disagree"
     for name in declared:
         assert hasattr(lib, name), f"libphc_amd.so does not export {name}"
-    assert lib.phc_abi_version() == 36
+    assert lib.phc_abi_version() == 37
 
 
 def test_struct_sizes_match_the_header():

@@ -568,3 +568,52 @@ def test_rollout_bookkeeping_kernel_matches_torch_ops():
     assert torch.equal(exp_r, rewards * 0.5) and torch.equal(exp_d, dones.to(torch.uint8)) and torch.equal(tm, term.float()) and torch.equal(tf, want_tf)
     assert torch.equal(cur_r, want_r) and torch.equal(cur_l, want_l)
     assert torch.allclose(acc, want_acc, atol=1e-6)
+
+
+@pytest.mark.parametrize("rows,cols,gated", [(257, 934, False), (64, 69, True), (1024, 512, True), (69, 512, False)])
+def test_split3_kernel_writes_head_tail_chunks_of_the_operand(rows, cols, gated):
+    """phc_split3_bf16 (ABI 37): head = bf16(x), tail = bf16(x - head), the three chunks in both orders and both layouts, zero padding, the ReLU gate."""
+    from phc_amd.learning import fast_ops as F
+    g = torch.Generator(device="cuda").manual_seed(rows * 1000 + cols)
+    x = torch.randn(rows, cols + 5, device="cuda", generator=g)[:, :cols] * 3.0        # (a strided view: rows cols + 5 apart)
+    gate = torch.randn(rows, cols, device="cuda", generator=g) if gated else None
+    xm = x if gate is None else x * (gate > 0)
+    h = xm.to(torch.bfloat16)
+    l = (xm - h.float()).to(torch.bfloat16)
+    assert float(((h.float() + l.float()) - xm).abs().max()) <= float(xm.abs().max()) * 2.0 ** -16
+    Rp, Cp = rows + 27, F._pad32(cols)
+    for order, chunks in ((0, (h, h, l)), (1, (h, l, h))):
+        for chunk_major in (False, True):
+            out = F._split3(x, order, gate=gate, rows_pad=Rp, cols_pad=Cp, chunk_major=chunk_major)
+            if not chunk_major:
+                out = out.permute(1, 0, 2)
+            assert out.shape == (3, Rp, Cp)
+            for c in range(3):
+                assert torch.equal(out[c, :rows, :cols], chunks[c])
+            assert not bool(out[:, rows:, :].any()) and not bool(out[:, :, cols:].any())
+
+
+@pytest.mark.parametrize("B,K,N,relu", [(16384, 934, 1024, True), (4096, 512, 69, False), (300, 100, 40, True)])
+def test_split_precision_layer_matches_the_fp64_layer(B, K, N, relu):
+    """FastLinear.split_precision: output, input gradient, weight and bias gradients against the same layer in double (error 2^-16-ish, not bf16's 2^-8)."""
+    from phc_amd.learning.fast_ops import FastLinear
+    torch.manual_seed(B + K)
+    lin = FastLinear(K, N).cuda()
+    lin.split_precision, lin.fuse_relu = True, relu
+    x = torch.randn(B, K, device="cuda", requires_grad=True)
+    gy = torch.randn(B, N, device="cuda") / B
+    y = lin(x)
+    assert y.dtype == torch.float32 and y.shape == (B, N)
+    y.backward(gy)
+    xd = x.detach().double().requires_grad_(True)
+    wd, bd = lin.weight.detach().double().requires_grad_(True), lin.bias.detach().double().requires_grad_(True)
+    yd = torch.nn.functional.linear(xd, wd, bd)
+    if relu:
+        yd = torch.relu(yd)
+    yd.backward(gy.double())
+    rel = lambda a, b: float((a.double() - b).abs().max() / b.abs().max())
+    errs = {"y": rel(y.detach(), yd.detach()), "gx": rel(x.grad, xd.grad), "gw": rel(lin.weight.grad, wd.grad), "gb": rel(lin.bias.grad, bd.grad)}
+    print(f"split-precision layer {B}x{K}->{N}: max error / max value {errs}")
+    assert max(errs.values()) < 2e-4, errs          # (bf16 operands: ~4e-3; ReLU mask flips at |y| < 1e-5 are inside this)
+    with torch.no_grad():
+        assert torch.equal(lin(x.detach()), y.detach())      # the no-grad path (rollout inference) is the same product
