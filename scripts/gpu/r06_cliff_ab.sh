@@ -20,6 +20,8 @@ for tag in $TAGS; do
     eager)    X="+$C.hip_graph=False" ;;
     oldreset) X="+$C.debug_reset_at_rollout_start=True" ;;
     oldreset24) X="+$C.debug_reset_at_rollout_start=True $C.mini_epochs=4" ;;
+    nopower)  X="env.power_reward=False" ;;
+    halfpower) X="+env.power_coefficient=0.00025" ;;
     *)        X="$tag" ;;
   esac
   for seed in $SEEDS; do

@@ -53,11 +53,13 @@ def train_for(agent, task, seconds, eval_every, log, rows, stage):
                          # round 6: the diagnostics the 24-vs-36-step question needs (clip fraction, critic / discriminator state)
                          "clip_frac": float(info["actor_clip_frac"]), "actor_loss": float(info["actor_loss"]), "critic_loss": float(info["critic_loss"]),
                          "disc_agent_logit": float(info["disc_agent_logit"]), "disc_demo_logit": float(info["disc_demo_logit"]), "disc_reward_std": float(info["disc_reward_std"]),
-                         "disc_agent_acc": float(info["disc_agent_acc"]), "disc_demo_acc": float(info["disc_demo_acc"]), "mean_return": float(info["mean_return"])})
+                         "disc_agent_acc": float(info["disc_agent_acc"]), "disc_demo_acc": float(info["disc_demo_acc"]), "mean_return": float(info["mean_return"]),
+                         # the task reward's terms, mean per step of this rollout: body position, rotation, velocity, angular velocity [, power] (humanoid_im.py:934-946)
+                         "reward_raw": [float(v) for v in info.get("reward_raw", [])]})
         if n % 250 == 0:
             r = rows[-1]
             log(f"  stage {stage} epoch {agent.epoch_num:5d}  task_r {r['task_reward']:.4f}  ep_len {r['mean_episode_length']:6.1f}  kl {r['kl']:.4f}  clip {r['clip_frac']:.3f}  |mu| mean {r['mu_abs_mean']:.3f} max {r['mu_abs_max']:.2f}  "
-                f"disc_r {r['disc_reward']:.3f} logits {r['disc_agent_logit']:+.2f}/{r['disc_demo_logit']:+.2f}  c_loss {r['critic_loss']:.4f}  fps {r['total_fps']:.0f}  ({r['t']:.0f} s)")
+                f"disc_r {r['disc_reward']:.3f} logits {r['disc_agent_logit']:+.2f}/{r['disc_demo_logit']:+.2f}  c_loss {r['critic_loss']:.4f}  raw {' '.join(f'{v:+.3f}' for v in r['reward_raw'])}  fps {r['total_fps']:.0f}  ({r['t']:.0f} s)")
         if eval_every and n % eval_every == 0:
             e, failed = agent.eval(output_dir=None, log=None)      # also re-weights the sampler (auto-PMCP)
             log(f"  stage {stage} epoch {agent.epoch_num:5d}  sweep: success {e['eval/success_rate']:.3f}  G-MPJPE {e['eval/mpjpe_all']:.1f} mm  failed {len(failed)}")

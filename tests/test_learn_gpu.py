@@ -609,11 +609,11 @@ def test_split_precision_layer_matches_the_fp64_layer(B, K, N, relu):
     wd, bd = lin.weight.detach().double().requires_grad_(True), lin.bias.detach().double().requires_grad_(True)
     yd = torch.nn.functional.linear(xd, wd, bd)
     if relu:
-        yd = torch.relu(yd)
+        yd = yd * (y.detach() > 0)       # the layer's own mask: an output within 1e-5 of zero may land on the other side, and ONE flipped term moves an input gradient by percents
     yd.backward(gy.double())
     rel = lambda a, b: float((a.double() - b).abs().max() / b.abs().max())
     errs = {"y": rel(y.detach(), yd.detach()), "gx": rel(x.grad, xd.grad), "gw": rel(lin.weight.grad, wd.grad), "gb": rel(lin.bias.grad, bd.grad)}
     print(f"split-precision layer {B}x{K}->{N}: max error / max value {errs}")
-    assert max(errs.values()) < 2e-4, errs          # (bf16 operands: ~4e-3; ReLU mask flips at |y| < 1e-5 are inside this)
+    assert max(errs.values()) < 2e-4, errs          # (bf16 operands: ~4e-3)
     with torch.no_grad():
         assert torch.equal(lin(x.detach()), y.detach())      # the no-grad path (rollout inference) is the same product
