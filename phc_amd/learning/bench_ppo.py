@@ -108,7 +108,7 @@ def time_ppo_epochs(task, env, cfg, epochs, dist=None, warmup=1):
     return {**comm, **roof, "ppo_samples_per_s": agent.batch_size * world * epochs / el, "ppo_epoch_ms": el / epochs * 1e3,
             "ppo_play_ms": 1e3 * sum(i["play_time"] for i in infos) / epochs, "ppo_update_ms": 1e3 * sum(i["update_time"] for i in infos) / epochs,
             "ppo_config": {"learning": str(cfg.get("learning_name", "")) or None, "horizon": agent.horizon_length, "batch_per_gpu": agent.batch_size, "minibatch": agent.minibatch_size,
-                           "optimizer_steps_per_epoch": n_opt, "gemm_dtype": "bf16" if agent.bf16 else "f32",
+                           "optimizer_steps_per_epoch": n_opt, "gemm_dtype": "bf16" if agent.bf16 else "f32", "actor_precision": "split_bf16" if getattr(agent, "_actor_split", False) else ("bf16" if agent.bf16 else "f32"),
                            "grad_allreduce_bytes": int(agent.grads.flat.numel() * 4), "collectives_per_epoch": int((agent.num_collectives - c0) / epochs),
                            "update_graph": agent._graph is not None,
                            "update_streams": 2 if agent._branches is not None else 1}}
