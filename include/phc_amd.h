@@ -425,9 +425,12 @@ int32_t phc_sum_slabs_bf16(const void* part, int32_t slabs, int64_t n, float* ou
  * tail l = bf16(x - h) and written as the three chunks ONE bf16 GEMM with a three times longer reduction reads:
  *   out[row * row_stride + c * chunk_stride + col] (bf16), c = 0, 1, 2 = (h, h, l) for order 0, (h, l, h) for order 1,
  * with zeros in columns cols .. cols_pad - 1 and rows rows .. rows_pad - 1.  (x h)(w h) + (x l)(w h) + (x h)(w l) = an order-1 operand against an order-0 one.
+ * extra_mode 1 writes the constant 1 into column `cols` of the valid rows, extra_mode 2 writes extra[row] (fp32 [rows]) there (cols_pad > cols then): an activation
+ * operand with the ones column against a weight operand carrying the bias in that column makes the bias part of the product, and row `cols` of the weight-gradient
+ * product (gradient operand^T x activation operand) is the bias gradient.  extra_mode 0: `extra` unused.
  * cols_pad, row_stride, chunk_stride multiples of 4; out 8-byte aligned. */
-int32_t phc_split3_bf16(const float* x, int64_t ld_in, const float* gate, int64_t ld_gate, int64_t rows, int32_t cols, int64_t rows_pad, int32_t cols_pad, void* out,
-                        int64_t row_stride, int64_t chunk_stride, int32_t order, void* stream);
+int32_t phc_split3_bf16(const float* x, int64_t ld_in, const float* gate, int64_t ld_gate, int64_t rows, int32_t cols, int64_t rows_pad, int32_t cols_pad,
+                        const float* extra, int32_t extra_mode, void* out, int64_t row_stride, int64_t chunk_stride, int32_t order, void* stream);
 
 /* Discriminator loss pieces (phc/learning/amp_agent.py:732-808 `_disc_loss`).
  * phc_disc_bce: logits [n_agent + n_demo] (agent and replay rows first, demo rows last; bf16 or fp32):

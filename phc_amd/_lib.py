@@ -109,7 +109,7 @@ _SIGNATURES = {
     "phc_colsum_bf16": ([c_p, c_i64, c_i32, c_p, c_p, c_p], c_i32),
     "phc_colsum_relu_bf16": ([c_p, c_p, c_i64, c_i32, c_p, c_p, c_p, c_p], c_i32),
     "phc_sum_slabs_bf16": ([c_p, c_i32, c_i64, c_p, c_i32, c_p], c_i32),
-    "phc_split3_bf16": ([c_p, c_i64, c_p, c_i64, c_i64, c_i32, c_i64, c_i32, c_p, c_i64, c_i64, c_i32, c_p], c_i32),
+    "phc_split3_bf16": ([c_p, c_i64, c_p, c_i64, c_i64, c_i32, c_i64, c_i32, c_p, c_i32, c_p, c_i64, c_i64, c_i32, c_p], c_i32),
     "phc_colsum_chunks": ([c_i64], c_i32),
     "phc_linear1_chunks": ([c_i64], c_i32),
     "phc_colsum_finish_batch": ([c_i32, P(ColsumJob), c_p], c_i32),

@@ -748,10 +748,13 @@ int32_t phc_sum_slabs_bf16(const void* part, int32_t slabs, int64_t n, float* ou
 // Split-precision operand of a linear layer (`actor_precision=split_bf16`): x fp32 [rows, cols] (rows `ld_in` apart), optionally gated by another fp32 tensor
 // (the ReLU mask of a backward pass: x where gate > 0, else 0), is cut into a bf16 head h = bf16(x) and a bf16 tail l = bf16(x - h) and stored as the three
 // chunks one long-reduction GEMM reads: out[row * row_stride + c * chunk_stride + col], c = 0..2 holding (h, h, l) (order 0) or (h, l, h) (order 1); columns
-// cols..cols_pad-1 and rows rows..rows_pad-1 are written as zeros (the GEMM's reduction length is a multiple of 32 elements).  4 columns per lane.
+// cols..cols_pad-1 and rows rows..rows_pad-1 are written as zeros (the GEMM's reduction length is a multiple of 32 elements) -- except column `cols` of the valid
+// rows with extra_mode 1 (the constant 1) or 2 (extra[row]): an activation operand with the ones column against a weight operand whose column `cols` is the bias
+// makes the bias part of the product, and the ones column's row of the weight-gradient product IS the bias gradient.  4 columns per lane.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_split3_bf16(const float* __restrict__ x, int64_t ld_in, const float* __restrict__ gate, int64_t ld_gate, int64_t rows, int cols,
-                                                     int64_t rows_pad, int cols_pad, __hip_bfloat16* __restrict__ out, int64_t row_stride, int64_t chunk_stride, int order) {
+                                                     int64_t rows_pad, int cols_pad, const float* __restrict__ extra, int extra_mode, __hip_bfloat16* __restrict__ out,
+                                                     int64_t row_stride, int64_t chunk_stride, int order) {
     const int q = cols_pad >> 2;
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t row = t / q;
@@ -769,6 +772,7 @@ __global__ __launch_bounds__(256) void k_split3_bf16(const float* __restrict__ x
             for (int k = 0; k < 4; ++k)
                 if (c0 + k < cols && !(gr[c0 + k] > 0.f)) v[k] = 0.f;
         }
+        if (extra_mode && cols >= c0 && cols < c0 + 4) v[cols - c0] = extra_mode == 1 ? 1.f : extra[row];
     }
     uint16_t h[4], l[4];
 #pragma unroll
@@ -786,13 +790,14 @@ __global__ __launch_bounds__(256) void k_split3_bf16(const float* __restrict__ x
     *reinterpret_cast<uint2*>(o + 2 * chunk_stride) = order ? hq : lq;
 }
 
-int32_t phc_split3_bf16(const float* x, int64_t ld_in, const float* gate, int64_t ld_gate, int64_t rows, int32_t cols, int64_t rows_pad, int32_t cols_pad, void* out,
-                        int64_t row_stride, int64_t chunk_stride, int32_t order, void* stream) {
+int32_t phc_split3_bf16(const float* x, int64_t ld_in, const float* gate, int64_t ld_gate, int64_t rows, int32_t cols, int64_t rows_pad, int32_t cols_pad,
+                        const float* extra, int32_t extra_mode, void* out, int64_t row_stride, int64_t chunk_stride, int32_t order, void* stream) {
     if (!x || !out || rows < 1 || cols < 1 || rows_pad < rows || cols_pad < cols || (cols_pad & 3) || (row_stride & 3) || (chunk_stride & 3)) return PHC_EINVAL;
+    if (extra_mode < 0 || extra_mode > 2 || (extra_mode && cols_pad <= cols) || (extra_mode == 2 && !extra)) return PHC_EINVAL;
     if (reinterpret_cast<uintptr_t>(out) & 7) return PHC_EINVAL;
     const int64_t threads = rows_pad * (cols_pad >> 2);
     hipLaunchKernelGGL(k_split3_bf16, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ld_in, gate, ld_gate, rows, cols, rows_pad, cols_pad,
-                       reinterpret_cast<__hip_bfloat16*>(out), row_stride, chunk_stride, order);
+                       extra, extra_mode, reinterpret_cast<__hip_bfloat16*>(out), row_stride, chunk_stride, order);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int32_t)e;
 }

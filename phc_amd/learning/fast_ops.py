@@ -636,33 +636,35 @@ class FastLinear1DD(nn.Linear):
 # xl = bf16(x - xh): 16 mantissa bits together), a product is (ah + al)(bh + bl) ~ ah bh + al bh + ah bl (the tail x tail term, 2^-18, is dropped) and the activations stay
 # fp32 between the layers.  The three partial products of one product are ONE MFMA GEMM with a three times longer reduction -- chunks (ah, al, ah) against (bh, bh, bl) --
 # with an fp32 result (`torch.mm(..., out_dtype=torch.float32)`, aten::mm.dtype).  `phc_split3_bf16` writes an operand's three chunks in one pass (reads the fp32 tensor
-# once, applies the ReLU mask of a backward pass on the way, pads the reduction length to a multiple of 32); the SAME [rows, 3, cols] buffer is the [rows, 3 cols] operand
+# once, applies the ReLU mask of a backward pass on the way, pads the reduction length to a multiple of 32, carries the ones / bias column that makes the bias part of the
+# product and the bias gradient a column of the weight gradient); the SAME [rows, 3, cols] buffer is the [rows, 3 cols] operand
 # of the forward / input-gradient product and the [3 rows, cols] operand of the weight gradient (reduction over rows AND chunks), so every tensor is split once.
 def _pad32(n):
     return (n + 31) // 32 * 32
 
 
-def _split3(x, order, gate=None, rows_pad=None, cols_pad=None, chunk_major=False):
-    """x fp32 [R, C] (unit column stride) -> bf16 [Rp, 3, Cp] (chunks (h, h, l) for order 0, (h, l, h) for order 1), or [3, Rp, Cp] with `chunk_major`."""
+def _split3(x, order, gate=None, rows_pad=None, cols_pad=None, chunk_major=False, extra=None, ones=False):
+    """x fp32 [R, C] (unit column stride) -> bf16 [Rp, 3, Cp] (chunks (h, h, l) for order 0, (h, l, h) for order 1), or [3, Rp, Cp] with `chunk_major`;
+    `ones`: column C of the valid rows is 1, `extra` (fp32 [R]): column C holds it."""
     R, C = x.shape
     Rp, Cp = rows_pad or R, cols_pad or _pad32(C)
     assert x.dtype == torch.float32 and x.stride(1) == 1 and (gate is None or (gate.dtype == torch.float32 and gate.stride(1) == 1 and gate.shape == x.shape))
+    assert extra is None or (extra.dtype == torch.float32 and extra.is_contiguous() and extra.numel() == R)
     out = torch.empty((3, Rp, Cp) if chunk_major else (Rp, 3, Cp), dtype=torch.bfloat16, device=x.device)
     row_stride, chunk_stride = (Cp, Rp * Cp) if chunk_major else (3 * Cp, Cp)
     L.check(L.load().phc_split3_bf16(x.data_ptr(), x.stride(0), gate.data_ptr() if gate is not None else None, gate.stride(0) if gate is not None else 0, R, C, Rp, Cp,
+                                     extra.data_ptr() if extra is not None else None, 2 if extra is not None else int(bool(ones)),
                                      out.data_ptr(), row_stride, chunk_stride, order, _stream(x.device)), "phc_split3_bf16")
     return out
 
 
 def _split_forward(x, weight, bias, relu):
-    """y = x W^T + b with split operands: xc [B, 3, Kp] order 1 against wc [Np, 3, Kp] order 0 -> fp32 [B, N] (a view of the N-padded result)."""
+    """y = x W^T + b with split operands: xc [B, 3, Kp] order 1 (with the ones column) against wc [Np, 3, Kp] order 0 (with the bias column) -> fp32 [B, N]."""
     N, K = weight.shape
-    Np, Kp = _pad32(N), _pad32(K)
-    xc = _split3(x, 1, cols_pad=Kp)
-    wc = _split3(weight, 0, rows_pad=Np, cols_pad=Kp)
-    if Np != N:
-        bias = torch.cat([bias, bias.new_zeros(Np - N)])
-    y = torch.addmm(bias, xc.view(-1, 3 * Kp), wc.view(Np, 3 * Kp).t(), out_dtype=torch.float32)
+    Np, Kp = _pad32(N), _pad32(K + 1)
+    xc = _split3(x, 1, cols_pad=Kp, ones=True)
+    wc = _split3(weight, 0, rows_pad=Np, cols_pad=Kp, extra=bias)
+    y = torch.mm(xc.view(-1, 3 * Kp), wc.view(Np, 3 * Kp).t(), out_dtype=torch.float32)
     if relu:
         torch.relu_(y)
     return (y if Np == N else y[:, :N].contiguous()), xc
@@ -673,7 +675,7 @@ class _SplitLinearFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias, relu):
         with torch.autocast("cuda", enabled=False):
             w = weight.detach()
-            y, xc = _split_forward(x, w, bias.detach().float(), relu)
+            y, xc = _split_forward(x, w, bias.detach().float().contiguous(), relu)
         ctx.save_for_backward(xc, w, *((y,) if relu else ()))
         ctx.relu = relu
         return y
@@ -692,21 +694,19 @@ class _SplitLinearFn(torch.autograd.Function):
             gc = _split3(gy, 0, gate=ctx.saved_tensors[2] if ctx.relu else None, cols_pad=Np)           # [B, 3, Np] chunks (gh, gh, gl): the ReLU mask applied on the way
             gx = gw = gb = None
             if ctx.needs_input_grad[0]:
-                wr = _split3(w, 1, rows_pad=Np, cols_pad=K if K % 4 == 0 else Kp, chunk_major=True)     # [3, Np, K] chunks (wh, wl, wh)
+                wr = _split3(w, 1, rows_pad=Np, cols_pad=K if K % 4 == 0 else _pad32(K), chunk_major=True)   # [3, Np, K] chunks (wh, wl, wh)
                 gx = torch.mm(gc.view(B, 3 * Np), wr.view(3 * Np, -1), out_dtype=torch.float32)
                 if gx.shape[1] != K:
                     gx = gx[:, :K]
-            if ctx.needs_input_grad[1]:
-                # dW = gh^T xh + gh^T xl + gl^T xh: one reduction over rows AND chunks = [3 B, Np]^T [3 B, Kp], cut into SPLIT_K slabs like the bf16 layers' (wgrad_split_k)
+            if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+                # dW = gh^T xh + gh^T xl + gl^T xh: one reduction over rows AND chunks = [3 B, Np]^T [3 B, Kp], cut into SPLIT_K slabs like the bf16 layers' (wgrad_split_k);
+                # column K of it -- the gradient against the ones column -- is the bias gradient
                 rows = 3 * B
                 if rows % SPLIT_K == 0 and rows >= 2048:
-                    gw = torch.bmm(gc.view(SPLIT_K, rows // SPLIT_K, Np).transpose(1, 2), xc.view(SPLIT_K, rows // SPLIT_K, Kp), out_dtype=torch.float32).sum(0)
+                    g = torch.bmm(gc.view(SPLIT_K, rows // SPLIT_K, Np).transpose(1, 2), xc.view(SPLIT_K, rows // SPLIT_K, Kp), out_dtype=torch.float32).sum(0)
                 else:
-                    gw = torch.mm(gc.view(rows, Np).t(), xc.view(rows, Kp), out_dtype=torch.float32)
-                if gw.shape != (N, K):
-                    gw = gw[:N, :K]
-            if ctx.needs_input_grad[2]:
-                gb = torch.sum(gc[:, 1:, :N], dim=(0, 1), dtype=torch.float32)                          # chunks 1, 2 = head + tail of the masked gradient
+                    g = torch.mm(gc.view(rows, Np).t(), xc.view(rows, Kp), out_dtype=torch.float32)
+                gw, gb = g[:N, :K], g[:N, K]
         return gx, gw, gb, None
 
 
@@ -722,7 +722,7 @@ class FastLinear(nn.Linear):
             if torch.is_grad_enabled() and self.weight.requires_grad:
                 return _SplitLinearFn.apply(x[:, :self.in_features] if x.shape[1] > self.in_features else x, self.weight, self.bias, self.fuse_relu)
             with torch.autocast("cuda", enabled=False):
-                return _split_forward(x[:, :self.in_features] if x.shape[1] > self.in_features else x, self.weight.detach(), self.bias.detach().float(), self.fuse_relu)[0]
+                return _split_forward(x[:, :self.in_features] if x.shape[1] > self.in_features else x, self.weight.detach(), self.bias.detach().float().contiguous(), self.fuse_relu)[0]
         if self.out_features == 1 and x.is_cuda and x.dim() == 2 and x.dtype == torch.bfloat16 and x.is_contiguous() and self.bias is not None:
             if _device_training_pass(self, x):
                 return _Linear1Fn.apply(x, self.weight, self.bias)

@@ -591,6 +591,18 @@ def test_split3_kernel_writes_head_tail_chunks_of_the_operand(rows, cols, gated)
             for c in range(3):
                 assert torch.equal(out[c, :rows, :cols], chunks[c])
             assert not bool(out[:, rows:, :].any()) and not bool(out[:, :, cols:].any())
+    # the ones / bias column (column `cols` of the valid rows; the forward product's bias and the weight-gradient product's bias-gradient row)
+    Cq = F._pad32(cols + 1)
+    e = torch.randn(rows, device="cuda", generator=g)
+    eh = e.to(torch.bfloat16)
+    el = (e - eh.float()).to(torch.bfloat16)
+    o1 = F._split3(x, 1, gate=gate, rows_pad=Rp, cols_pad=Cq, ones=True).permute(1, 0, 2)
+    o2 = F._split3(x, 0, gate=gate, rows_pad=Rp, cols_pad=Cq, extra=e).permute(1, 0, 2)
+    one = torch.ones(rows, device="cuda", dtype=torch.bfloat16)
+    for c, (a, b) in enumerate(zip((one, 0 * one, one), (eh, eh, el))):
+        assert torch.equal(o1[c, :rows, cols], a) and torch.equal(o2[c, :rows, cols], b)
+        assert torch.equal(o1[c, :rows, :cols], (h, l, h)[c]) and torch.equal(o2[c, :rows, :cols], (h, h, l)[c])
+    assert not bool(o1[:, rows:, :].any()) and not bool(o1[:, :, cols + 1:].any()) and not bool(o2[:, rows:, :].any()) and not bool(o2[:, :, cols + 1:].any())
 
 
 @pytest.mark.parametrize("B,K,N,relu", [(16384, 934, 1024, True), (4096, 512, 69, False), (300, 100, 40, True)])
