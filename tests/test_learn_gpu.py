@@ -626,6 +626,6 @@ def test_split_precision_layer_matches_the_fp64_layer(B, K, N, relu):
     rel = lambda a, b: float((a.double() - b).abs().max() / b.abs().max())
     errs = {"y": rel(y.detach(), yd.detach()), "gx": rel(x.grad, xd.grad), "gw": rel(lin.weight.grad, wd.grad), "gb": rel(lin.bias.grad, bd.grad)}
     print(f"split-precision layer {B}x{K}->{N}: max error / max value {errs}")
-    assert max(errs.values()) < 2e-4, errs          # (bf16 operands: ~4e-3)
+    assert max(errs.values()) < 5e-5, errs          # (measured 6e-6; bf16 operands: ~4e-3)
     with torch.no_grad():
         assert torch.equal(lin(x.detach()), y.detach())      # the no-grad path (rollout inference) is the same product
