@@ -4,7 +4,7 @@ Trains the 64-clip library WITHOUT the power term for `train_s` seconds (every s
 deterministic (mu), sampled as a rollout samples (mu + sigma * noise, sigma = exp(-2.9)), and with zero actions -- and prints sum |dof_force * dof_vel| per env step
 (watts; x 0.0005 = the reward term), by clip class, for steps with progress > 3 (the reference zeroes the first three).
 
-    python scripts/probes/power_probe.py [train_s=40] [seed=1] [envs=3072]
+    python scripts/probes/power_probe.py [train_s=40] [seed=1] [envs=3072] [more overrides, e.g. +solver.force_average=1 sim.substeps=8]
 """
 import json
 import sys
@@ -23,7 +23,7 @@ seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 envs = int(sys.argv[3]) if len(sys.argv) > 3 else 3072
 torch.manual_seed(seed)
 cfg = compose(["learning=im_pnn", "env=env_im_pnn", f"env.num_envs={envs}", "env.motion_file=locomotion:64:0", "env.num_prim=2", "env.training_prim=0",
-               "env.auto_pmcp=False", "env.auto_pmcp_soft=True", "env.power_reward=False"])
+               "env.auto_pmcp=False", "env.auto_pmcp_soft=True", "env.power_reward=False"] + sys.argv[4:])
 task, env = parse_task(cfg)
 agent = IMAmpAgent(env, cfg)
 agent.init_train()
