@@ -17,13 +17,21 @@ OUT = os.path.join(HERE, "_build", "libphc_hostemu.so")
 CSRC = os.path.join(os.path.dirname(HERE), "phc_amd", "csrc")
 
 
+# PHC_HOSTEMU_SANITIZE=1 (scripts/sanitize_hostemu.sh): the same sources under AddressSanitizer + UndefinedBehaviorSanitizer -- the per-lane code of the kernels, their
+# LDS-array stand-ins and the table indexing checked for out-of-bounds accesses and undefined arithmetic on the CPU (GPU sanitizers are not available on the pool).
+SANITIZE = os.environ.get("PHC_HOSTEMU_SANITIZE", "") not in ("", "0")
+if SANITIZE:
+    OUT = os.path.join(HERE, "_build", "libphc_hostemu_asan.so")
+_FLAGS = ["-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"] if SANITIZE else ["-O2"]
+
+
 def build():
     deps = [SRC] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + \
            [os.path.join(os.path.dirname(HERE), "include", "phc_amd.h")]
     if os.path.exists(OUT) and all(os.path.getmtime(d) <= os.path.getmtime(OUT) for d in deps):
         return OUT
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fopenmp", "-ffp-contract=off", SRC, "-o", OUT], check=True)
+    subprocess.run(["g++"] + _FLAGS + ["-std=c++17", "-fPIC", "-shared", "-fopenmp", "-ffp-contract=off", SRC, "-o", OUT], check=True)
     return OUT
 
 
@@ -74,7 +82,7 @@ def np_motion_lib(lib):
 
 # ---- the stepper at DOUBLE precision (oracle/hostemu/hostemu64.cpp): the exact-arithmetic statement of the kernel's recursion, incl. the lagged scheme -------------------
 SRC64 = os.path.join(HERE, "hostemu", "hostemu64.cpp")
-OUT64 = os.path.join(HERE, "_build", "libphc_hostemu64.so")
+OUT64 = os.path.join(HERE, "_build", "libphc_hostemu64_asan.so" if SANITIZE else "libphc_hostemu64.so")
 
 
 def build64():
@@ -82,7 +90,7 @@ def build64():
     if os.path.exists(OUT64) and all(os.path.getmtime(d) <= os.path.getmtime(OUT64) for d in deps):
         return OUT64
     os.makedirs(os.path.dirname(OUT64), exist_ok=True)
-    subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fopenmp", "-ffp-contract=off", SRC64, "-o", OUT64], check=True)
+    subprocess.run(["g++"] + _FLAGS + ["-std=c++17", "-fPIC", "-shared", "-fopenmp", "-ffp-contract=off", SRC64, "-o", OUT64], check=True)
     return OUT64
 
 
