@@ -58,28 +58,31 @@ __global__ __launch_bounds__(RN_COLS) void k_running_norm(const float* __restric
 }
 
 // Batch moments from the partial sums and the parallel-variance update of the running statistics
-// (running_mean_std.py:56-67,100-104).  Block = 64 columns x 16 slices of the chunk list.  Every block reads the old count; the
+// (running_mean_std.py:56-67,100-104).  Block = RNF_COLS columns x RNF_SLICES slices of the chunk list.  Every block reads the old count; the
 // block that finishes LAST (a ticket counter behind the partial sums, left at zero again) writes the new one.
+// (round 6: 16 columns x 64 slices instead of 64 x 16 -- the 934-column observation batch of an optimizer step has 512 chunks: 15 blocks walked them in eight
+// dependent rounds of loads, 29 us at the head of the policy pass; 59 blocks need one round.)
+#define RNF_COLS 16
+#define RNF_SLICES 64
 __global__ __launch_bounds__(1024) void k_running_norm_finish(const double* __restrict__ partial, int nchunks, int64_t rows, int cols,
                                                               double* __restrict__ run_mean, double* __restrict__ run_var,
                                                               double* __restrict__ run_count, unsigned int* __restrict__ ticket) {
-    __shared__ double ls[16][64], lq[16][64];
-    const int cx = threadIdx.x & 63, sy = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cx;
+    __shared__ double ls[RNF_SLICES][RNF_COLS], lq[RNF_SLICES][RNF_COLS];
+    const int cx = threadIdx.x & (RNF_COLS - 1), sy = threadIdx.x / RNF_COLS;
+    const int c = blockIdx.x * RNF_COLS + cx;
     double s = 0.0, q = 0.0;
     if (c < cols) {
-        // eight independent loads in flight per thread (round 5: one load pair at a time made the 512-chunk finish of the 16 384-row observation batch a
-        // 35 us chain of 32 dependent L2 round trips -- at the head of the policy pass, in front of its first GEMM)
+        // eight independent loads in flight per thread
         int k = sy;
         double s1 = 0.0, q1 = 0.0, s2 = 0.0, q2 = 0.0, s3 = 0.0, q3 = 0.0;
-        for (; k + 48 < nchunks; k += 64) {
+        for (; k + 3 * RNF_SLICES < nchunks; k += 4 * RNF_SLICES) {
             const double a0 = partial[((int64_t)k * 2 + 0) * cols + c], b0 = partial[((int64_t)k * 2 + 1) * cols + c];
-            const double a1 = partial[((int64_t)(k + 16) * 2 + 0) * cols + c], b1 = partial[((int64_t)(k + 16) * 2 + 1) * cols + c];
-            const double a2 = partial[((int64_t)(k + 32) * 2 + 0) * cols + c], b2 = partial[((int64_t)(k + 32) * 2 + 1) * cols + c];
-            const double a3 = partial[((int64_t)(k + 48) * 2 + 0) * cols + c], b3 = partial[((int64_t)(k + 48) * 2 + 1) * cols + c];
+            const double a1 = partial[((int64_t)(k + RNF_SLICES) * 2 + 0) * cols + c], b1 = partial[((int64_t)(k + RNF_SLICES) * 2 + 1) * cols + c];
+            const double a2 = partial[((int64_t)(k + 2 * RNF_SLICES) * 2 + 0) * cols + c], b2 = partial[((int64_t)(k + 2 * RNF_SLICES) * 2 + 1) * cols + c];
+            const double a3 = partial[((int64_t)(k + 3 * RNF_SLICES) * 2 + 0) * cols + c], b3 = partial[((int64_t)(k + 3 * RNF_SLICES) * 2 + 1) * cols + c];
             s += a0; q += b0; s1 += a1; q1 += b1; s2 += a2; q2 += b2; s3 += a3; q3 += b3;
         }
-        for (; k < nchunks; k += 16) {
+        for (; k < nchunks; k += RNF_SLICES) {
             s += partial[((int64_t)k * 2 + 0) * cols + c];
             q += partial[((int64_t)k * 2 + 1) * cols + c];
         }
@@ -94,9 +97,14 @@ __global__ __launch_bounds__(1024) void k_running_norm_finish(const double* __re
         __threadfence();
         if (atomicAdd(ticket, 1u) == gridDim.x - 1) { *run_count = tot; *ticket = 0u; }   // all blocks have read the old count by now
     }
+    // tree over the slices: 64 -> 4 per column, then the column's first lane adds the four
+    for (int h = RNF_SLICES / 2; h >= 4; h >>= 1) {
+        if (sy < h) { ls[sy][cx] += ls[sy + h][cx]; lq[sy][cx] += lq[sy + h][cx]; }
+        __syncthreads();
+    }
     if (sy != 0 || c >= cols) return;
-    s = 0.0; q = 0.0;
-    for (int k = 0; k < 16; ++k) { s += ls[k][cx]; q += lq[k][cx]; }
+    s = (ls[0][cx] + ls[1][cx]) + (ls[2][cx] + ls[3][cx]);
+    q = (lq[0][cx] + lq[1][cx]) + (lq[2][cx] + lq[3][cx]);
     // input.mean(0), input.var(0) are fp32 tensors in the reference: round the batch moments to fp32 before the fp64 update
     const double bm = (double)(float)(s / n);
     const double bv = (double)(float)((q - s * s / n) / (n - 1.0));
@@ -684,7 +692,7 @@ int32_t phc_running_norm(const float* x, const int64_t* row_index, int64_t rows,
     else
         hipLaunchKernelGGL(k_running_norm<false>, grid, dim3(RN_COLS), 0, st, x, row_index, rows, cols, norm_mean, norm_var, epsilon, clamp, out, out_stride, update ? workspace : nullptr);
     if (update)
-        hipLaunchKernelGGL(k_running_norm_finish, dim3((cols + 63) / 64), dim3(1024), 0, st, workspace, (int)nchunks, rows, cols, run_mean, run_var, run_count,
+        hipLaunchKernelGGL(k_running_norm_finish, dim3((cols + RNF_COLS - 1) / RNF_COLS), dim3(RNF_COLS * RNF_SLICES), 0, st, workspace, (int)nchunks, rows, cols, run_mean, run_var, run_count,
                            reinterpret_cast<unsigned int*>(workspace + nchunks * 2 * (int64_t)cols));
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int32_t)e;
