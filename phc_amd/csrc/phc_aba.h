@@ -570,10 +570,19 @@ PHC_HD void aba_body_init(AbaLane& L, const phc_model_t& m, const phc_sim_params
             if (prm.limit_stiffness > 0.f) {
                 const float lo = f[32], hi = f[33];
                 const float e = L.th < lo ? lo - L.th : (L.th > hi ? hi - L.th : 0.f);
+                // A lagged sub-step (`inertia_lag`) eliminates with the D^-1 of the last fresh sub-step: a limit that was not engaged THEN has no implicit share in it, and
+                // its damper, applied to the current rate without that share, is an explicit integrator -- dt c / I = 5e4 on G1's 14-gram finger links, which reached
+                // 100 rad/s under target noise (round 6; `tests/test_stepper_options.py::test_inertia_lag_is_stable_under_target_noise`).  Such a joint gets the spring
+                // only until the next fresh sub-step (<= one sub-step later); target.z (unused by revolute joints) remembers what the kept D^-1 contains.
                 if (e != 0.f) {
-                    tau += prm.limit_stiffness * e - (prm.limit_damping + dt * prm.limit_stiffness) * L.thd;
-                    d += dt * prm.limit_damping + dt * dt * prm.limit_stiffness;
+                    if (!lag || L.target.z != 0.f) {
+                        tau += prm.limit_stiffness * e - (prm.limit_damping + dt * prm.limit_stiffness) * L.thd;
+                        d += dt * prm.limit_damping + dt * dt * prm.limit_stiffness;
+                    } else {
+                        tau += prm.limit_stiffness * e;
+                    }
                 }
+                if (!lag) L.target.z = e != 0.f ? 1.f : 0.f;
             }
             L.tau_local = L.axis * tau;
             L.dimp = v3(d, 0.f, 0.f);
