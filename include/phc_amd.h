@@ -441,7 +441,9 @@ int32_t phc_split3_bf16(const float* x, int64_t ld_in, const float* gate, int64_
  * phc_weighted_sumsq: out[0] = sum_i coefs[i] * |tensors[i]|^2 over count <= 4 device tensors of sizes[i] elements (all fp32 or all
  *   bf16): the logit regulariser + weight decay in one pass, or -- one bf16 tensor, coef = c / rows -- the gradient penalty
  *   c * mean_rows(sum_cols g^2).  out[1 + i] = |tensors[i]|^2 (ABI 20: `out` holds 1 + count floats; the last one of the weight call
- *   is the reference's `disc_logit_loss`, amp_agent.py:757-758).  workspace: phc_sumsq_workspace() bytes. */
+ *   is the reference's `disc_logit_loss`, amp_agent.py:757-758).  workspace: phc_sumsq_workspace() bytes. 
+ * (Round 6: one block per 1024 logits, the last block to finish adds the per-block sums; they live in a static device buffer, so launches of phc_disc_bce on DIFFERENT streams
+ * of one process must not overlap.) */
 int32_t phc_disc_bce(const void* logits, int32_t is_bf16, int32_t n_agent, int32_t n_demo, float scale, void* grad, float* stats,
                      void* stream);
 int64_t phc_sumsq_workspace(void);

@@ -522,13 +522,20 @@ __global__ __launch_bounds__(256) void k_policy_sample(const T* __restrict__ mu,
 //   k_sumsq_multi (+ finish): sum_i coef_i |w_i|^2 over up to 4 tensors (logit regulariser + weight decay), or with one bf16 tensor
 //                 the gradient penalty coef * mean_rows(sum_cols g^2)
 // ------------------------------------------------------------------------------------------
+// One 1024-lane block per 1024 logits (round 6: ONE block for all 12 288 was 34 k wavefront-instructions of exp / log1p on a single CU, 17.8 us); the block that finishes
+// last (ticket counter) adds the per-block sums in block order and writes the scalars.  The partial sums live in a static device buffer: launches of this kernel on
+// DIFFERENT streams of one process must not overlap (the learner issues one per optimizer step, on the discriminator's stream).
+#define BCE_MAX_BLOCKS 64
+__device__ float g_bce_partial[BCE_MAX_BLOCKS * 6];
+__device__ unsigned int g_bce_ticket = 0;
 template <typename T>
 __global__ __launch_bounds__(1024) void k_disc_bce(const T* __restrict__ logits, int n_agent, int n_demo, float scale, T* __restrict__ grad,
                                                    float* __restrict__ stats) {
     __shared__ float l[6][16];
+    __shared__ int last;
     float la = 0.f, ld = 0.f, ca = 0.f, cd = 0.f, xa = 0.f, xd = 0.f;
     const int n = n_agent + n_demo;
-    for (int i = threadIdx.x; i < n; i += 1024) {
+    for (int i = blockIdx.x * 1024 + threadIdx.x; i < n; i += gridDim.x * 1024) {
         const float x = ld_f(logits, i);
         const float sp = fmaxf(x, 0.f) + log1pf(expf(-fabsf(x)));   // softplus(x) = BCEWithLogits(x, 0); BCEWithLogits(x, 1) = softplus(x) - x
         const float sg = 1.0f / (1.0f + expf(-x));
@@ -542,10 +549,22 @@ __global__ __launch_bounds__(1024) void k_disc_bce(const T* __restrict__ logits,
     if (threadIdx.x < 6) {
         float t = 0.f;
         for (int k = 0; k < 16; ++k) t += l[threadIdx.x][k];
+        g_bce_partial[blockIdx.x * 6 + threadIdx.x] = t;
+        __threadfence();
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) last = atomicAdd(&g_bce_ticket, 1u) == gridDim.x - 1;
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    if (threadIdx.x < 6) {
+        float t = 0.f;
+        for (int b = 0; b < (int)gridDim.x; ++b) t += __builtin_nontemporal_load(&g_bce_partial[b * 6 + threadIdx.x]);
         l[threadIdx.x][0] = t;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
+        g_bce_ticket = 0u;
         stats[0] = scale * 0.5f * (l[0][0] / (float)n_agent + l[1][0] / (float)n_demo);
         stats[1] = l[2][0] / (float)n_agent;
         stats[2] = l[3][0] / (float)n_demo;
@@ -892,11 +911,13 @@ int32_t phc_policy_sample(const void* mu, const void* value, int32_t is_bf16, co
 
 int32_t phc_disc_bce(const void* logits, int32_t is_bf16, int32_t n_agent, int32_t n_demo, float scale, void* grad, float* stats, void* stream) {
     if (!logits || !grad || !stats || n_agent < 1 || n_demo < 1) return PHC_EINVAL;
+    const int64_t nb = ((int64_t)n_agent + n_demo + 1023) / 1024;
+    const dim3 grid((unsigned)(nb < BCE_MAX_BLOCKS ? nb : BCE_MAX_BLOCKS));
     if (is_bf16)
-        hipLaunchKernelGGL(k_disc_bce<__hip_bfloat16>, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const __hip_bfloat16*)logits, n_agent, n_demo, scale,
+        hipLaunchKernelGGL(k_disc_bce<__hip_bfloat16>, grid, dim3(1024), 0, (hipStream_t)stream, (const __hip_bfloat16*)logits, n_agent, n_demo, scale,
                            (__hip_bfloat16*)grad, stats);
     else
-        hipLaunchKernelGGL(k_disc_bce<float>, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const float*)logits, n_agent, n_demo, scale, (float*)grad, stats);
+        hipLaunchKernelGGL(k_disc_bce<float>, grid, dim3(1024), 0, (hipStream_t)stream, (const float*)logits, n_agent, n_demo, scale, (float*)grad, stats);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int32_t)e;
 }
